@@ -1,0 +1,165 @@
+/*
+ * savfi_hip.h -- C ABI of libsavfi_hip.so, the MI355X (gfx950) kernels behind the
+ * MAML inner-loop adaptation path of scene-adaptive video frame interpolation.
+ *
+ * This header is the drop-in boundary.  Each entry point replaces one piece of the
+ * reference's hot path (file:line are relative to the reference checkout):
+ *
+ *   savfi_sepconv_fwd_f32      kernel_Sepconv_updateOutput            sepconv/sepconv_op/sepconv.py:5-30, launch :280-291
+ *   savfi_sepconv_bwd_f32      kernel_Sepconv_updateGradVertical      sepconv/sepconv_op/sepconv.py:138-163, launch :343-356
+ *                              kernel_Sepconv_updateGradHorizontal    sepconv/sepconv_op/sepconv.py:165-190, launch :358-371
+ *                              kernel_Sepconv_updateGradInput         sepconv/sepconv_op/sepconv.py:32-63,  launch :328-341
+ *   savfi_voxelwarp_fwd_f32    flow/mask split + meshgrid + 2x grid_sample + blend
+ *   savfi_voxelwarp_bwd_f32                                          voxelflow/core/models/voxel_flow.py:471-509, :9-17
+ *   savfi_pixel_unshuffle_f32  pixel_shuffle(scale<1)                 model_utils.py:202-217 (else branch)
+ *   savfi_pixel_shuffle_f32    pixel_shuffle(scale>=1)                model_utils.py:202-217 (if branch)
+ *   savfi_mt_update_f32        LSLR / Meta-SGD update_sgd/adam/adamax inner_loop_optimizers.py:136-244, :324-425
+ *   savfi_mt_update_bwd_f32    (autograd of the above w.r.t. the learning rates)
+ *   savfi_mt_mean_f32          per-tensor mean of grads (L2F embedding) meta_learning_system.py:249-253
+ *   savfi_mt_scale_f32         gamma_i * w_i (L2F attenuation)        meta_learning_system.py:267-268
+ *   savfi_l1_mse_f32           nn.L1Loss / nn.MSELoss                 loss.py:287-290
+ *
+ * Conventions (all functions):
+ *   - extern "C", return int: 0 = ok; >0 = hipError_t reported by the launch;
+ *     <0 = argument error (SAVFI_E_*).  No exceptions cross the boundary.
+ *   - every pointer is a DEVICE pointer to a contiguous fp32 NCHW buffer owned by the
+ *     caller, unless the parameter is documented as a host array.  The library never
+ *     allocates device memory, never synchronises, and is re-entrant.
+ *   - `stream` is a hipStream_t passed as void* (the caller passes
+ *     torch.cuda.current_stream().cuda_stream); launches are asynchronous on it.
+ */
+#ifndef SAVFI_HIP_H_
+#define SAVFI_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SAVFI_ABI_VERSION 1
+
+#define SAVFI_OK            0
+#define SAVFI_E_NULL       (-1)  /* a required pointer is NULL                          */
+#define SAVFI_E_SHAPE      (-2)  /* a dimension is <= 0 or inconsistent                  */
+#define SAVFI_E_UNSUPPORTED (-3) /* e.g. scale factor / rule id not implemented          */
+#define SAVFI_E_TOOBIG     (-4)  /* index arithmetic would overflow 32-bit element index */
+
+/* ABI version of the loaded library (== SAVFI_ABI_VERSION it was built against). */
+int savfi_version(void);
+
+/* ------------------------------------------------------------------------------------
+ * Separable local convolution (SepConv), K taps per axis (K = 51 in the model).
+ *   in  [B, C, Ho+K-1, Wo+K-1]   v, h [B, K, Ho, Wo]   out [B, C, Ho, Wo]
+ *   out[b,c,y,x] = sum_{fy<K} sum_{fx<K} in[b,c,y+fy,x+fx] * v[b,fy,y,x] * h[b,fx,y,x]
+ * ---------------------------------------------------------------------------------- */
+int savfi_sepconv_fwd_f32(const float* in, const float* v, const float* h, float* out,
+                          int B, int C, int Ho, int Wo, int K, void* stream);
+
+/* Gradients of the above.  Any of gI / gV / gH may be NULL (= not needed, like
+ * needs_input_grad in sepconv.py:319-321).  gI is the mathematically exact adjoint
+ * (the reference's kernel has an off-by-one bounds test, sepconv.py:51,54).
+ *   gO [B,C,Ho,Wo]  gI [B,C,Ho+K-1,Wo+K-1]  gV, gH [B,K,Ho,Wo]
+ * Outputs are fully overwritten (no pre-zeroing needed). */
+int savfi_sepconv_bwd_f32(const float* in, const float* v, const float* h, const float* gO,
+                          float* gI, float* gV, float* gH,
+                          int B, int C, int Ho, int Wo, int K, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * VoxelFlow warp + blend (syn_type 'inter').
+ *   frames [B,6,H,W] (I0 = ch 0..2, I1 = ch 3..5), x3 [B,3,H,W] = tanh output
+ *   flow = 0.5*x3[:,0:2] (normalised units), mask = 0.5*(1+x3[:,2])
+ *   out[b,c] = mask * bilinear(I0, grid - flow) + (1-mask) * bilinear(I1, grid + flow)
+ *   with grid = linspace(-1,1), align_corners=True, padding_mode='border'.
+ * bwd: g_x3 [B,3,H,W] always written; g_frames [B,6,H,W] may be NULL (frames are data).
+ *      When g_frames != NULL it must be zero-filled by the caller (scatter-add).
+ * ---------------------------------------------------------------------------------- */
+int savfi_voxelwarp_fwd_f32(const float* frames, const float* x3, float* out,
+                            int B, int H, int W, void* stream);
+int savfi_voxelwarp_bwd_f32(const float* frames, const float* x3, const float* gO,
+                            float* g_x3, float* g_frames,
+                            int B, int H, int W, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Pixel (un)shuffle with the reference's channel order.
+ *   unshuffle: in [B,C,H,W] -> out [B,C*r*r,H/r,W/r], out ch = c*r*r + i*r + j
+ *              out[b, c*r*r+i*r+j, y, x] = in[b, c, y*r+i, x*r+j]
+ *   shuffle:   in [B,C*r*r,H,W] -> out [B,C,H*r,W*r]   (exact inverse)
+ * Dimensions passed are those of `in`.  Each is the other's autograd adjoint.
+ * ---------------------------------------------------------------------------------- */
+int savfi_pixel_unshuffle_f32(const float* in, float* out, int B, int C, int H, int W, int r, void* stream);
+int savfi_pixel_shuffle_f32(const float* in, float* out, int B, int C, int H, int W, int r, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Fused multi-tensor inner-loop update (one launch per <= SAVFI_MT_MAX_TENSORS tensors;
+ * the library chunks internally).  Host arrays of device pointers, length n.
+ *
+ *   rule: SAVFI_RULE_SGD      out = w - lr * g
+ *         SAVFI_RULE_ADAM     m = b1*m + (1-b1)*g ; s = b2*s + (1-b2)*g*g   (m, s updated IN PLACE)
+ *                             out = w - (lr/bc1) * m / (sqrt(s)/sqrt(bc2) + eps)
+ *         SAVFI_RULE_ADAMAX_LSLR   m = b1*m + (1-b1)*g (in place) ; out = w - (lr/bc1) * m / (|g| + eps)
+ *         SAVFI_RULE_ADAMAX_MSGD   out = w - (lr/bc1) * ((1-b1)*g) / (|g| + eps)   (state untouched)
+ *       (the two Adamax forms are the reference's as-implemented arithmetic,
+ *        inner_loop_optimizers.py:201-244 and :385-425)
+ *   lr_mode: SAVFI_LR_SCALAR   lr[i] points at ONE float (LSLR: &table_i[num_step])
+ *            SAVFI_LR_ELEMENT  lr[i] points at numel[i] floats (Meta-SGD)
+ *   bc1[i], sqrt_bc2[i]: host float arrays with the per-tensor bias corrections
+ *                   1-b1^step_i and sqrt(1-b2^step_i) (computed in double by the caller like
+ *                   the reference does in Python floats, then rounded); ignored by SGD.
+ *   beta1, beta2, eps are doubles so that (1-beta) is rounded to fp32 from the double
+ *   difference, as the reference's Python-float arithmetic does.
+ *   m, s: host arrays of device pointers (may be NULL for rules that do not use them).
+ *   coef[i] (optional device float*, may be NULL array): when non-NULL the kernel also
+ *   writes the per-element d out / d lr = -(update direction) so that the autograd
+ *   backward w.r.t. lr is a plain product (see savfi_mt_update_bwd_f32).
+ * ---------------------------------------------------------------------------------- */
+#define SAVFI_RULE_SGD          0
+#define SAVFI_RULE_ADAM         1
+#define SAVFI_RULE_ADAMAX_LSLR  2
+#define SAVFI_RULE_ADAMAX_MSGD  3
+#define SAVFI_LR_SCALAR   0
+#define SAVFI_LR_ELEMENT  1
+#define SAVFI_MT_MAX_TENSORS 48
+
+int savfi_mt_update_f32(int rule, int lr_mode, int n,
+                        const float* const* w, const float* const* g, const float* const* lr,
+                        float* const* m, float* const* s, float* const* out, float* const* coef,
+                        const int64_t* numel, const float* bc1, const float* sqrt_bc2,
+                        double beta1, double beta2, double eps, void* stream);
+
+/* Backward of the update w.r.t. the learning rates (first-order MAML: g is a constant).
+ *   dir[i] = the `coef` buffer written by the forward (= d out / d lr, per element), scale = 1;
+ *            for SGD pass dir = g and scale = -1 (no coef buffer needed).
+ *   lr_mode ELEMENT: g_lr[i][e]  = scale * g_out[i][e] * dir[i][e]
+ *   lr_mode SCALAR : g_lr[i][0] += scale * sum_e g_out[i][e] * dir[i][e]   (one float per tensor,
+ *                    accumulated with one atomic per workgroup: the caller zero-fills it)
+ * g_w is the identity (g_w = g_out) and needs no kernel. */
+int savfi_mt_update_bwd_f32(int lr_mode, int n,
+                            const float* const* g_out, const float* const* dir, float* const* g_lr,
+                            const int64_t* numel, float scale, void* stream);
+
+/* L2F: per-tensor mean -> out_vec[i] (device float[n], zero-filled by the caller, accumulated
+ * with one atomic per workgroup);  per-tensor scale out[i] = gamma[i]*w[i] (gamma: device
+ * float[n]).  scale_bwd: g_w[i] = gamma[i]*g_out[i] (g_w may be NULL or hold NULL entries);
+ * g_gamma[i] += sum_e g_out[i][e]*w[i][e] (zero-filled by the caller; may be NULL). */
+int savfi_mt_mean_f32(int n, const float* const* x, const int64_t* numel, float* out_vec, void* stream);
+int savfi_mt_scale_f32(int n, const float* const* w, const float* gamma, float* const* out,
+                       const int64_t* numel, void* stream);
+int savfi_mt_scale_bwd_f32(int n, const float* const* g_out, const float* const* w, const float* gamma,
+                           float* const* g_w, float* g_gamma, const int64_t* numel, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Fused mean-reduced L1 / MSE loss and its gradient.
+ *   kind 0: mean |a-b| ; kind 1: mean (a-b)^2 ;  result[0] must be zeroed by the caller
+ *   (accumulated with one atomic per workgroup).  bwd: g_a = g_loss[0]*sign(a-b)/n or
+ *   g_loss[0]*2*(a-b)/n.
+ * ---------------------------------------------------------------------------------- */
+int savfi_l1_mse_f32(int kind, const float* a, const float* b, float* result, int64_t n, void* stream);
+int savfi_l1_mse_bwd_f32(int kind, const float* a, const float* b, const float* g_loss, float* g_a,
+                         int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAVFI_HIP_H_ */

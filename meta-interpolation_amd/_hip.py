@@ -1,0 +1,171 @@
+"""ctypes binding of libsavfi_hip.so -- the only door between the Python host code and the kernels.
+
+The prototypes below are the ones declared in include/savfi_hip.h.  There is NO fallback: if the
+shared object is missing or a call returns non-zero, a SavfiHipError is raised.  On a machine
+without a GPU the library still loads (hipcc cross-compiled it) so that the symbol table can be
+checked, but nothing may be launched.
+"""
+import ctypes
+import os
+import re
+from ctypes import c_double, c_float, c_int, c_int64, c_void_p, POINTER
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "lib", "libsavfi_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_PKG_DIR), "include", "savfi_hip.h")
+
+RULE_SGD, RULE_ADAM, RULE_ADAMAX_LSLR, RULE_ADAMAX_MSGD = 0, 1, 2, 3
+LR_SCALAR, LR_ELEMENT = 0, 1
+ABI_VERSION = 1
+
+_ERRORS = {-1: "SAVFI_E_NULL (a required pointer is NULL)",
+           -2: "SAVFI_E_SHAPE (bad or inconsistent dimension)",
+           -3: "SAVFI_E_UNSUPPORTED",
+           -4: "SAVFI_E_TOOBIG (index arithmetic would overflow)"}
+
+
+class SavfiHipError(RuntimeError):
+    pass
+
+
+_P = c_void_p          # device pointer
+_PP = POINTER(c_void_p)  # host array of device pointers
+_I64P = POINTER(c_int64)
+_FP = POINTER(c_float)
+
+_PROTOTYPES = {
+    "savfi_version": [],
+    "savfi_sepconv_fwd_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P],
+    "savfi_sepconv_bwd_f32": [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P],
+    "savfi_voxelwarp_fwd_f32": [_P, _P, _P, c_int, c_int, c_int, _P],
+    "savfi_voxelwarp_bwd_f32": [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P],
+    "savfi_pixel_unshuffle_f32": [_P, _P, c_int, c_int, c_int, c_int, c_int, _P],
+    "savfi_pixel_shuffle_f32": [_P, _P, c_int, c_int, c_int, c_int, c_int, _P],
+    "savfi_mt_update_f32": [c_int, c_int, c_int, _PP, _PP, _PP, _PP, _PP, _PP, _PP, _I64P, _FP, _FP,
+                            c_double, c_double, c_double, _P],
+    "savfi_mt_update_bwd_f32": [c_int, c_int, _PP, _PP, _PP, _I64P, c_float, _P],
+    "savfi_mt_mean_f32": [c_int, _PP, _I64P, _P, _P],
+    "savfi_mt_scale_f32": [c_int, _PP, _P, _PP, _I64P, _P],
+    "savfi_mt_scale_bwd_f32": [c_int, _PP, _PP, _P, _PP, _P, _I64P, _P],
+    "savfi_l1_mse_f32": [c_int, _P, _P, _P, c_int64, _P],
+    "savfi_l1_mse_bwd_f32": [c_int, _P, _P, _P, _P, c_int64, _P],
+}
+
+_lib = None
+
+
+def declared_symbols():
+    """Function names declared in include/savfi_hip.h (used by the symbol-export test)."""
+    with open(HEADER_PATH) as fh:
+        text = fh.read()
+    return sorted(set(re.findall(r"^\s*int\s+(savfi_\w+)\s*\(", text, flags=re.M)))
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises SavfiHipError when the .so is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SavfiHipError(
+            "%s is missing: build it with `python __graft_entry__.py build` "
+            "(there is no CPU or PyTorch fallback for the savfi kernels)" % LIB_PATH)
+    try:
+        handle = ctypes.CDLL(LIB_PATH)
+    except OSError as exc:  # pragma: no cover - depends on the host's ROCm install
+        raise SavfiHipError("cannot load %s: %s" % (LIB_PATH, exc))
+    for name, argtypes in _PROTOTYPES.items():
+        try:
+            fn = getattr(handle, name)
+        except AttributeError:
+            raise SavfiHipError("%s does not export %s" % (LIB_PATH, name))
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    got = handle.savfi_version()
+    if got != ABI_VERSION:
+        raise SavfiHipError("libsavfi_hip ABI %d != expected %d; rebuild" % (got, ABI_VERSION))
+    _lib = handle
+    return _lib
+
+
+def check(code, what):
+    if code == 0:
+        return
+    if code < 0:
+        raise SavfiHipError("%s: %s" % (what, _ERRORS.get(code, "error %d" % code)))
+    raise SavfiHipError("%s: HIP launch failed with hipError_t %d" % (what, code))
+
+
+def ptr_array(tensors):
+    """Host array of device pointers (None -> NULL)."""
+    arr = (c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = None if t is None else t.data_ptr()
+    return arr
+
+
+def i64_array(values):
+    return (c_int64 * len(values))(*values)
+
+
+def f32_array(values):
+    return (c_float * len(values))(*values)
+
+
+def current_stream():
+    import torch
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda(*tensors):
+    """The kernels only take fp32 contiguous device tensors; anything else is a caller bug."""
+    import torch
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise NotImplementedError(
+                "savfi HIP ops need device tensors (the reference raises NotImplementedError for "
+                "CPU tensors too, sepconv/sepconv_op/sepconv.py:293-294)")
+        if t.dtype != torch.float32:
+            raise TypeError("savfi HIP ops are fp32-only, got %s" % t.dtype)
+        assert t.is_contiguous(), "savfi HIP ops need contiguous tensors"
+
+
+class KernelTimer:
+    """Optional HIP-event timing of individual launches (used by bench.py for the roofline line).
+
+    Events are recorded on torch's current stream, which is the stream every savfi launch uses.
+    Nothing is synchronised until `summary()` is called.
+    """
+
+    def __init__(self):
+        self.records = {}
+
+    def launch(self, name, fn):
+        import torch
+        a = torch.cuda.Event(enable_timing=True)
+        b = torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        self.records.setdefault(name, []).append((a, b))
+
+    def summary(self):
+        import torch
+        torch.cuda.synchronize()
+        out = {}
+        for name, evs in self.records.items():
+            ms = [a.elapsed_time(b) for a, b in evs]
+            out[name] = {"launches": len(ms), "total_ms": sum(ms), "avg_us": 1e3 * sum(ms) / len(ms)}
+        return out
+
+
+TIMER = None  # set to a KernelTimer instance to time launches
+
+
+def launch(name, fn):
+    if TIMER is None:
+        fn()
+    else:
+        TIMER.launch(name, fn)

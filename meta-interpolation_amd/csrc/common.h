@@ -1,0 +1,34 @@
+// Shared helpers for the savfi HIP kernels (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "savfi_hip.h"
+
+#define SAVFI_WAVE 64
+
+static inline int savfi_launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? SAVFI_OK : (int)e;
+}
+
+static inline int savfi_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// 64-lane butterfly sum; every lane ends with the total.
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, SAVFI_WAVE);
+  return x;
+}
+
+// Block-wide sum for blocks of NW waves; result valid in thread 0 (and wave 0 lanes).
+template <int NW>
+__device__ __forceinline__ float block_sum(float x, float* lds /* >= NW floats */) {
+  x = wave_sum(x);
+  const int lane = threadIdx.x & (SAVFI_WAVE - 1), wid = threadIdx.x / SAVFI_WAVE;
+  if (lane == 0) lds[wid] = x;
+  __syncthreads();
+  float t = (threadIdx.x < NW) ? lds[threadIdx.x] : 0.f;
+  if (wid == 0) t = wave_sum(t);
+  __syncthreads();
+  return t;
+}

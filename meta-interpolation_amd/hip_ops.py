@@ -1,0 +1,258 @@
+"""torch.autograd wrappers over the non-sepconv entry points of libsavfi_hip.so.
+
+Every function here launches a hand-written gfx950 kernel through the C ABI (include/savfi_hip.h)
+on torch's current stream.  Device tensors only -- there is no CPU or eager-PyTorch fallback.
+"""
+import torch
+
+from . import _hip
+
+
+# --------------------------------------------------------------------------------------------
+# VoxelFlow warp + blend            (reference: voxelflow/core/models/voxel_flow.py:471-509)
+# --------------------------------------------------------------------------------------------
+class _VoxelWarp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, frames, x3):
+        _hip.require_cuda(frames, x3)
+        B, six, H, W = frames.shape
+        assert six == 6 and x3.shape == (B, 3, H, W)
+        out = torch.empty((B, 3, H, W), dtype=frames.dtype, device=frames.device)
+        lib = _hip.lib()
+        _hip.launch("voxelwarp_fwd", lambda: _hip.check(lib.savfi_voxelwarp_fwd_f32(
+            frames.data_ptr(), x3.data_ptr(), out.data_ptr(), B, H, W, _hip.current_stream()),
+            "savfi_voxelwarp_fwd_f32"))
+        ctx.save_for_backward(frames, x3)
+        return out
+
+    @staticmethod
+    def backward(ctx, gO):
+        frames, x3 = ctx.saved_tensors
+        B, _, H, W = frames.shape
+        gO = gO.contiguous()
+        need_f, need_x = ctx.needs_input_grad
+        g_x3 = torch.empty_like(x3)
+        g_fr = torch.zeros_like(frames) if need_f else None
+        lib = _hip.lib()
+        _hip.launch("voxelwarp_bwd", lambda: _hip.check(lib.savfi_voxelwarp_bwd_f32(
+            frames.data_ptr(), x3.data_ptr(), gO.data_ptr(), g_x3.data_ptr(),
+            None if g_fr is None else g_fr.data_ptr(), B, H, W, _hip.current_stream()),
+            "savfi_voxelwarp_bwd_f32"))
+        return g_fr, (g_x3 if need_x else None)
+
+
+def voxel_warp_blend(frames, x3):
+    """frames [B,6,H,W] (I0|I1), x3 [B,3,H,W] = tanh(conv4) -> interpolated frame [B,3,H,W]."""
+    return _VoxelWarp.apply(frames.contiguous(), x3.contiguous())
+
+
+# --------------------------------------------------------------------------------------------
+# Pixel (un)shuffle                                   (reference: model_utils.py:202-217)
+# --------------------------------------------------------------------------------------------
+def _launch_shuffle(x, r, down):
+    _hip.require_cuda(x)
+    B, C, H, W = x.shape
+    lib = _hip.lib()
+    if down:
+        assert H % r == 0 and W % r == 0
+        out = torch.empty((B, C * r * r, H // r, W // r), dtype=x.dtype, device=x.device)
+        _hip.launch("pixel_unshuffle", lambda: _hip.check(lib.savfi_pixel_unshuffle_f32(
+            x.data_ptr(), out.data_ptr(), B, C, H, W, r, _hip.current_stream()), "savfi_pixel_unshuffle_f32"))
+    else:
+        assert C % (r * r) == 0
+        out = torch.empty((B, C // (r * r), H * r, W * r), dtype=x.dtype, device=x.device)
+        _hip.launch("pixel_shuffle", lambda: _hip.check(lib.savfi_pixel_shuffle_f32(
+            x.data_ptr(), out.data_ptr(), B, C, H, W, r, _hip.current_stream()), "savfi_pixel_shuffle_f32"))
+    return out
+
+
+class _PixelShuffle(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, r, down):
+        ctx.r, ctx.down = r, down
+        return _launch_shuffle(x.contiguous(), r, down)
+
+    @staticmethod
+    def backward(ctx, g):
+        # the permutation's adjoint is its inverse
+        return _launch_shuffle(g.contiguous(), ctx.r, not ctx.down), None, None
+
+
+def pixel_shuffle(input, scale_factor):
+    """Same call surface as the reference's pixel_shuffle: scale<1 packs space into channels
+    (block 1/scale), scale>=1 unpacks."""
+    if scale_factor >= 1:
+        return _PixelShuffle.apply(input, int(scale_factor), False)
+    return _PixelShuffle.apply(input, int(round(1 / scale_factor)), True)
+
+
+# --------------------------------------------------------------------------------------------
+# Fused multi-tensor inner-loop update            (reference: inner_loop_optimizers.py)
+# --------------------------------------------------------------------------------------------
+class _MtUpdate(torch.autograd.Function):
+    """(w_1..w_n, lr_1..lr_n) -> (w'_1..w'_n); g, moments and hyper-parameters ride in `spec`.
+
+    First-order MAML semantics: the gradients g are constants.  d w'/d w = I, and d w'/d lr is the
+    per-element update direction, saved by the forward kernel when some lr requires grad.
+    """
+
+    @staticmethod
+    def forward(ctx, spec, *tensors):
+        n = spec["n"]
+        ws, lrs = tensors[:n], tensors[n:]
+        gs = spec["grads"]
+        rule, lr_mode = spec["rule"], spec["lr_mode"]
+        outs = [torch.empty_like(w) for w in ws]
+        need_lr = any(ctx.needs_input_grad[1 + n + i] for i in range(n))
+        save_dir = need_lr and rule != _hip.RULE_SGD
+        coefs = [torch.empty_like(w) for w in ws] if save_dir else None
+        lib = _hip.lib()
+        numel = [w.numel() for w in ws]
+        ms, ss = spec.get("m"), spec.get("s")
+        args = (rule, lr_mode, n, _hip.ptr_array(ws), _hip.ptr_array(gs), _hip.ptr_array(lrs),
+                _hip.ptr_array(ms) if ms is not None else None,
+                _hip.ptr_array(ss) if ss is not None else None,
+                _hip.ptr_array(outs), _hip.ptr_array(coefs) if coefs is not None else None,
+                _hip.i64_array(numel),
+                _hip.f32_array(spec["bc1"]) if spec.get("bc1") is not None else None,
+                _hip.f32_array(spec["sqrt_bc2"]) if spec.get("sqrt_bc2") is not None else None,
+                spec["beta1"], spec["beta2"], spec["eps"], _hip.current_stream())
+        _hip.launch("mt_update", lambda: _hip.check(lib.savfi_mt_update_f32(*args), "savfi_mt_update_f32"))
+        ctx.n, ctx.lr_mode, ctx.numel = n, lr_mode, numel
+        ctx.lr_shapes = [lr.shape for lr in lrs]
+        if need_lr:
+            ctx.dirs = coefs if save_dir else list(gs)
+            ctx.dir_scale = 1.0 if save_dir else -1.0
+        else:
+            ctx.dirs = None
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *g_outs):
+        n = ctx.n
+        g_ws = [g if ctx.needs_input_grad[1 + i] else None for i, g in enumerate(g_outs)]
+        g_lrs = [None] * n
+        if ctx.dirs is not None:
+            idx = [i for i in range(n) if ctx.needs_input_grad[1 + n + i] and g_outs[i] is not None]
+            if idx:
+                gos = [g_outs[i].contiguous() for i in idx]
+                dirs = [ctx.dirs[i] for i in idx]
+                dev = gos[0].device
+                if ctx.lr_mode == _hip.LR_SCALAR:
+                    dst = [torch.zeros((), dtype=torch.float32, device=dev) for _ in idx]
+                else:
+                    dst = [torch.empty_like(go) for go in gos]
+                lib = _hip.lib()
+                numel = [ctx.numel[i] for i in idx]
+                args = (ctx.lr_mode, len(idx), _hip.ptr_array(gos), _hip.ptr_array(dirs), _hip.ptr_array(dst),
+                        _hip.i64_array(numel), ctx.dir_scale, _hip.current_stream())
+                _hip.launch("mt_update_bwd", lambda: _hip.check(lib.savfi_mt_update_bwd_f32(*args),
+                                                                 "savfi_mt_update_bwd_f32"))
+                for j, i in enumerate(idx):
+                    g_lrs[i] = dst[j].reshape(ctx.lr_shapes[i])
+        return (None, *g_ws, *g_lrs)
+
+
+def mt_update(rule, lr_mode, weights, grads, lrs, m=None, s=None, bc1=None, sqrt_bc2=None,
+              beta1=0.9, beta2=0.99, eps=1e-8):
+    """Fused update of a list of tensors.  `lrs[i]` is a 0-dim tensor (LR_SCALAR) or a tensor shaped
+    like weights[i] (LR_ELEMENT).  m / s are updated in place by the kernel.  Returns new tensors."""
+    n = len(weights)
+    if n == 0:
+        return []
+    _hip.require_cuda(*weights, *grads, *lrs)
+    if m is not None:
+        _hip.require_cuda(*m)
+    if s is not None:
+        _hip.require_cuda(*s)
+    spec = dict(n=n, rule=rule, lr_mode=lr_mode, grads=[g.detach() for g in grads], m=m, s=s, bc1=bc1,
+                sqrt_bc2=sqrt_bc2, beta1=beta1, beta2=beta2, eps=eps)
+    ws = [w if w.is_contiguous() else w.contiguous() for w in weights]
+    return list(_MtUpdate.apply(spec, *ws, *lrs))
+
+
+# --------------------------------------------------------------------------------------------
+# L2F: per-tensor mean of gradients, per-tensor attenuation   (meta_learning_system.py:249-268)
+# --------------------------------------------------------------------------------------------
+def mt_mean(tensors):
+    """[t_1..t_n] -> float32[n] of per-tensor means (no autograd: inputs are first-order grads)."""
+    ts = [t.detach().contiguous() for t in tensors]
+    _hip.require_cuda(*ts)
+    out = torch.zeros(len(ts), dtype=torch.float32, device=ts[0].device)
+    lib = _hip.lib()
+    args = (len(ts), _hip.ptr_array(ts), _hip.i64_array([t.numel() for t in ts]), out.data_ptr(),
+            _hip.current_stream())
+    _hip.launch("mt_mean", lambda: _hip.check(lib.savfi_mt_mean_f32(*args), "savfi_mt_mean_f32"))
+    return out
+
+
+class _MtScale(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gamma, *ws):
+        _hip.require_cuda(gamma, *ws)
+        outs = [torch.empty_like(w) for w in ws]
+        lib = _hip.lib()
+        numel = [w.numel() for w in ws]
+        args = (len(ws), _hip.ptr_array(ws), gamma.data_ptr(), _hip.ptr_array(outs), _hip.i64_array(numel),
+                _hip.current_stream())
+        _hip.launch("mt_scale", lambda: _hip.check(lib.savfi_mt_scale_f32(*args), "savfi_mt_scale_f32"))
+        ctx.save_for_backward(gamma, *ws)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *g_outs):
+        gamma, *ws = ctx.saved_tensors
+        n = len(ws)
+        gos = [g.contiguous() if g is not None else torch.zeros_like(w) for g, w in zip(g_outs, ws)]
+        g_ws = [torch.empty_like(w) if ctx.needs_input_grad[1 + i] else None for i, w in enumerate(ws)]
+        g_gamma = torch.zeros_like(gamma) if ctx.needs_input_grad[0] else None
+        lib = _hip.lib()
+        args = (n, _hip.ptr_array(gos), _hip.ptr_array(ws), gamma.data_ptr(), _hip.ptr_array(g_ws),
+                None if g_gamma is None else g_gamma.data_ptr(), _hip.i64_array([w.numel() for w in ws]),
+                _hip.current_stream())
+        _hip.launch("mt_scale_bwd", lambda: _hip.check(lib.savfi_mt_scale_bwd_f32(*args), "savfi_mt_scale_bwd_f32"))
+        return (g_gamma, *g_ws)
+
+
+def mt_scale(gamma, weights):
+    """gamma float32[n] (device), weights list of n tensors -> [gamma[i] * weights[i]]."""
+    ws = [w if w.is_contiguous() else w.contiguous() for w in weights]
+    return list(_MtScale.apply(gamma.contiguous(), *ws))
+
+
+# --------------------------------------------------------------------------------------------
+# Fused L1 / MSE                                                     (loss.py:287-290)
+# --------------------------------------------------------------------------------------------
+class _L1Mse(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, kind, a, b):
+        _hip.require_cuda(a, b)
+        assert a.shape == b.shape
+        res = torch.zeros((), dtype=torch.float32, device=a.device)
+        lib = _hip.lib()
+        _hip.launch("l1_mse", lambda: _hip.check(lib.savfi_l1_mse_f32(
+            kind, a.data_ptr(), b.data_ptr(), res.data_ptr(), a.numel(), _hip.current_stream()),
+            "savfi_l1_mse_f32"))
+        ctx.kind = kind
+        ctx.save_for_backward(a, b)
+        return res
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = g.contiguous()
+        ga = torch.empty_like(a)
+        lib = _hip.lib()
+        _hip.launch("l1_mse_bwd", lambda: _hip.check(lib.savfi_l1_mse_bwd_f32(
+            ctx.kind, a.data_ptr(), b.data_ptr(), g.data_ptr(), ga.data_ptr(), a.numel(),
+            _hip.current_stream()), "savfi_l1_mse_bwd_f32"))
+        gb = -ga if ctx.needs_input_grad[2] else None
+        return None, ga, gb
+
+
+def l1_loss(a, b):
+    return _L1Mse.apply(0, a.contiguous(), b.contiguous())
+
+
+def mse_loss(a, b):
+    return _L1Mse.apply(1, a.contiguous(), b.contiguous())

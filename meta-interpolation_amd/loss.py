@@ -1,0 +1,34 @@
+"""Loss wrapper for the inner/outer objectives: ``'w*TYPE+w*TYPE'`` with TYPE in {L1, MSE}.
+
+Surface follows the reference's ``Loss`` (loss.py:278-350): ``criterion(sr, hr) -> {TYPE: w*loss, ...,
+'total': sum}``.  L1 / MSE run on the fused savfi reduction kernel (one launch, no temporaries);
+the reference's VGG / GAN / SSIM / SuperSloMo terms are outside this path and are rejected loudly.
+"""
+import torch.nn as nn
+
+from . import hip_ops
+
+_KERNELS = {'L1': hip_ops.l1_loss, 'MSE': hip_ops.mse_loss}
+
+
+class Loss(nn.modules.loss._Loss):
+    def __init__(self, args):
+        super().__init__()
+        self.loss = []
+        for term in args.loss.split('+'):
+            weight, loss_type = term.split('*')
+            if loss_type not in _KERNELS:
+                raise NotImplementedError(
+                    "loss '%s' is outside the SepConv/VoxelFlow/CAIN inner-loop path (only L1, MSE)" % loss_type)
+            self.loss.append({'type': loss_type, 'weight': float(weight), 'function': _KERNELS[loss_type]})
+        self.cuda_only = True
+
+    def forward(self, sr, hr, **kwargs):
+        total = 0
+        losses = {}
+        for l in self.loss:
+            eff = l['weight'] * l['function'](sr, hr)
+            losses[l['type']] = eff
+            total = total + eff
+        losses['total'] = total
+        return losses

@@ -1,0 +1,452 @@
+"""SceneAdaptiveInterpolation: the MAML / MAML++ / Meta-SGD / L2F system around a VFI plugin.
+
+Drop-in for the reference class of the same name (meta_learning_system.py:29-697): same constructor
+(``SceneAdaptiveInterpolation(args)``), same methods called by ExperimentBuilder
+(``run_train_iter / run_validation_iter / run_test_iter``), same attributes (``optimizer``,
+``scheduler``, ``net``, ``inner_loop_optimizer``, ``attenuator``, ``gamma_mult``, ``mean``/``std``) and
+the same ``state_dict`` key layout.  Per task and inner step: two support passes ((0,4)->2 and
+(2,6)->4), one ``autograd.grad`` over both, one per-parameter update; then the target pass (2,4)->3.
+
+What is different (MI355X-first, results identical):
+  * model ops and the update are HIP kernels behind the C ABI (sepconv, voxel warp, pixel shuffle,
+    fused multi-tensor update, L2F mean/scale, fused L1/MSE);
+  * the two support triplets of a step -- same weights, independent samples -- run as one N=2 forward
+    (``--fuse_support_pairs 0`` restores two N=1 calls);
+  * no host synchronisation inside the task loop: the reference pulls every loss to the host
+    (:332) and every ``zero_grad(params)`` syncs per parameter; here loss scalars stay on the device
+    and are fetched once per iteration;
+  * tasks shard across processes (task_parallel.TaskParallel) with one all-reduce of outer grads;
+    with a single process this is the reference's sequential loop.  The reference's ``.module`` call
+    for >1 visible device (:285-287) is not reproduced: one process owns one device.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.optim as optim
+
+from . import hip_ops, utils
+from .inner_loop_optimizers import LSLRGradientDescentLearningRule, MetaSGDLearningRule
+from .loss import Loss
+from .task_parallel import TaskParallel
+
+
+def set_torch_seed(seed):
+    """Seed torch from a numpy stream, returning that stream (reference :16-26)."""
+    rng = np.random.RandomState(seed=seed)
+    torch.manual_seed(seed=int(rng.randint(0, 999999)))
+    return rng
+
+
+# ---------------------------------------------------------------------------------------------
+# --model plugin surface
+# ---------------------------------------------------------------------------------------------
+def _build_sepconv(args, resume):
+    from .sepconv.model import MetaNetwork
+    return MetaNetwork(resume=resume, strModel='l1')
+
+
+def _build_cain(args, resume):
+    from .cain.model import MetaCAIN
+    return MetaCAIN(depth=3, resume=resume)
+
+
+def _build_voxelflow(args, resume):
+    from .voxelflow.core.models.voxel_flow import MetaVoxelFlow
+    return MetaVoxelFlow(args, resume=resume)
+
+
+MODEL_REGISTRY = {'sepconv': _build_sepconv, 'cain': _build_cain, 'voxelflow': _build_voxelflow}
+
+
+def register_model(name, factory):
+    """Add a ``--model`` plugin: ``factory(args, resume) -> nn.Module`` with
+    ``forward(frame0, frame1, params=None, **kw)``, ``zero_grad(params)``, ``restore_backup_stats()``."""
+    MODEL_REGISTRY[name] = factory
+
+
+class _DeferredMeters:
+    """Collects device scalars during the task loop; turns them into AverageMeters with ONE sync."""
+
+    def __init__(self):
+        self.items = {}
+
+    def add(self, key, value):
+        self.items.setdefault(key, []).append(value.detach())
+
+    def flush(self):
+        meters = {}
+        if not self.items:
+            return meters
+        keys = list(self.items)
+        flat = torch.stack([v.reshape(()) for k in keys for v in self.items[k]]).cpu().numpy()
+        i = 0
+        for k in keys:
+            m = utils.AverageMeter()
+            for _ in self.items[k]:
+                m.update(flat[i])
+                i += 1
+            meters[k] = m
+        return meters
+
+
+class SceneAdaptiveInterpolation(nn.Module):
+    def __init__(self, args, net=None, inner_loop_optimizer=None, criterion=None, task_parallel=None):
+        super().__init__()
+        self.args = args
+        self.device = torch.device('cuda') if args.cuda else torch.device('cpu')
+        self.batch_size = args.batch_size
+        self.use_cuda = args.cuda
+        self.current_epoch = 0
+        self.fuse_support_pairs = bool(getattr(args, 'fuse_support_pairs', 1))
+
+        # 7-frame septuplets: supports (0,4)->2 and (2,6)->4, target (2,4)->3; 4-frame clips at test time
+        self.support_idxs = [[0, 1, 2], [1, 2, 3]] if args.mode == 'test' else [[0, 2, 4], [2, 4, 6]]
+        self.target_idxs = [2, 3, 4]
+
+        self.rng = set_torch_seed(seed=args.random_seed)
+        if net is not None:
+            self.net = net.to(self.device)
+        else:
+            if args.model not in MODEL_REGISTRY:
+                raise NotImplementedError('Model not implemented yet!')
+            print('Building %s model...' % args.model)
+            self.net = MODEL_REGISTRY[args.model](args, not args.resume).to(self.device)
+        if args.model == 'voxelflow':
+            half = torch.full((3, 1, 1), 0.5 * 255, device=self.device)
+            self.mean, self.std = half.clone(), half.clone()
+
+        self.inner_learning_rate = args.inner_lr
+        if inner_loop_optimizer is not None:
+            self.inner_loop_optimizer = inner_loop_optimizer
+        elif args.metasgd:
+            print('Adaptation with Meta-SGD')
+            self.inner_loop_optimizer = MetaSGDLearningRule(device=self.device, optimizer=args.optimizer,
+                                                            init_learning_rate=self.inner_learning_rate)
+        else:
+            self.inner_loop_optimizer = LSLRGradientDescentLearningRule(
+                device=self.device, optimizer=args.optimizer, init_learning_rate=self.inner_learning_rate,
+                total_num_inner_loop_steps=args.number_of_training_steps_per_iter,
+                use_learnable_learning_rates=args.learnable_per_layer_per_step_inner_loop_learning_rate)
+
+        names_weights = self.get_inner_loop_parameter_dict(self.net.named_parameters())
+        self.inner_loop_optimizer.initialize(names_weights_dict=names_weights)
+
+        if args.attenuate:  # L2F: gamma = 1 - gamma_mult * MLP(layer-wise mean grads)
+            L = len(names_weights)
+            print('# of layers: %d' % L)
+            self.attenuator = nn.Sequential(nn.Linear(L, L), nn.ReLU(inplace=True), nn.Linear(L, L),
+                                            nn.Sigmoid()).to(self.device)
+            self.gamma_mult = nn.Parameter(torch.zeros(1))
+
+        self.to(self.device)
+
+        if args.optimizer == 'Adam':
+            if args.model == 'voxelflow' and hasattr(self.net, 'get_optim_policies'):
+                self.optimizer = optim.Adam(self.net.get_optim_policies(), lr=args.outer_lr,
+                                            weight_decay=args.weight_decay)
+            else:
+                self.optimizer = optim.Adam(self.trainable_parameters(), lr=args.outer_lr, betas=(0.9, 0.99))
+        elif args.optimizer == 'Adamax':
+            self.optimizer = optim.Adamax(self.trainable_parameters(), lr=args.outer_lr, betas=(0.9, 0.999))
+        else:
+            self.optimizer = optim.SGD(self.trainable_parameters(), lr=args.outer_lr)
+        self.scheduler = optim.lr_scheduler.ReduceLROnPlateau(optimizer=self.optimizer, mode='min', factor=0.2,
+                                                              patience=5)
+        print('# of parameters: %d' % sum(p.numel() for p in self.trainable_parameters()))
+
+        self.criterion = criterion if criterion is not None else Loss(args)
+        self.task_parallel = task_parallel if task_parallel is not None else TaskParallel()
+
+        if args.resume:
+            print('Resume training')
+            utils.load_checkpoint(args, self, None)
+        if args.pretrained_model is not None:
+            print('Loading pretrained model: %s' % args.pretrained_model)
+            ckpt = torch.load(args.pretrained_model, map_location='cpu', weights_only=False)
+            with torch.no_grad():
+                utils.lossy_load_state_dict(self.net, ckpt['state_dict'])
+
+    # -----------------------------------------------------------------------------------------
+    # small pieces kept with the reference's names
+    # -----------------------------------------------------------------------------------------
+    def get_per_step_loss_importance_vector(self):
+        """MAML++ multi-step-loss weights (reference :186-210): uniform 1/S, non-final entries decay
+        with the epoch down to 0.03/S, the final one grows up to 1-(S-1)*0.03/S."""
+        S = self.args.number_of_training_steps_per_iter
+        if S == 0:
+            return torch.ones(1, device=self.device)
+        w = np.ones(shape=(S,)) * (1.0 / S)
+        decay = 1.0 / S / self.args.multi_step_loss_num_epochs
+        floor = 0.03 / S
+        for i in range(S - 1):
+            w[i] = np.maximum(w[i] - self.current_epoch * decay, floor)
+        w[-1] = np.minimum(w[-1] + self.current_epoch * (S - 1) * decay, 1.0 - (S - 1) * floor)
+        return torch.Tensor(w).to(device=self.device)
+
+    def get_inner_loop_parameter_dict(self, params):
+        """{name: param} of what the inner loop adapts (reference :213-228)."""
+        keep_bn = self.args.enable_inner_loop_optimizable_bn_params
+        return {name: p for name, p in params if p.requires_grad and (keep_bn or "norm_layer" not in name)}
+
+    def trainable_parameters(self):
+        for p in self.parameters():
+            if p.requires_grad:
+                yield p
+
+    # -----------------------------------------------------------------------------------------
+    # forward passes
+    # -----------------------------------------------------------------------------------------
+    def net_forward(self, frame0, frame1, target, weights, backup_running_statistics, training, num_step):
+        """One backbone pass with fast weights + criterion -> (losses dict, output)  (reference :475-509)."""
+        output = self.net.forward(frame0, frame1, params=weights,
+                                  backup_running_statistics=backup_running_statistics, num_step=num_step)
+        return self.criterion(output, target), output
+
+    def _support_loss(self, frames, task_id, weights, num_step):
+        """Sum of the two support-triplet losses of one inner step (reference :387-396)."""
+        a, b = self.support_idxs
+        if self.fuse_support_pairs:
+            sl = slice(task_id, task_id + 1)
+            f0 = torch.cat([frames[a[0]][sl], frames[b[0]][sl]], 0)
+            f1 = torch.cat([frames[a[2]][sl], frames[b[2]][sl]], 0)
+            out = self.net.forward(f0, f1, params=weights, backup_running_statistics=(num_step == 0),
+                                   num_step=num_step)
+            la = self.criterion(out[0:1], frames[a[1]][sl])
+            lb = self.criterion(out[1:2], frames[b[1]][sl])
+            return la['total'] + lb['total']
+        total = 0
+        for ind in (a, b):
+            losses, _ = self.net_forward(frame0=frames[ind[0]][task_id].unsqueeze(0),
+                                         frame1=frames[ind[2]][task_id].unsqueeze(0),
+                                         target=frames[ind[1]][task_id].unsqueeze(0), weights=weights,
+                                         backup_running_statistics=(num_step == 0), training=True,
+                                         num_step=num_step)
+            total = total + losses['total']
+        return total
+
+    def _target_pass(self, frames, task_id, weights, num_step):
+        t = self.target_idxs
+        return self.net_forward(frame0=frames[t[0]][task_id].unsqueeze(0), frame1=frames[t[2]][task_id].unsqueeze(0),
+                                target=frames[t[1]][task_id].unsqueeze(0), weights=weights,
+                                backup_running_statistics=False, training=True, num_step=num_step)
+
+    # -----------------------------------------------------------------------------------------
+    # L2F
+    # -----------------------------------------------------------------------------------------
+    def get_task_embeddings(self, frames, task_id, names_weights_copy):
+        """Layer-wise mean of the support gradient at theta (reference :231-255), one fused reduction."""
+        loss = self._support_loss(frames, task_id, names_weights_copy, num_step=0)
+        self.net.zero_grad(names_weights_copy)
+        grads = torch.autograd.grad(loss, names_weights_copy.values(), create_graph=False, allow_unused=True)
+        if any(g is None for g in grads):
+            raise AttributeError("L2F needs a gradient for every inner-loop tensor (the reference calls "
+                                 ".mean() on None here, meta_learning_system.py:251)")
+        return hip_ops.mt_mean(grads)
+
+    def attenuate_init(self, task_embeddings, names_weights_copy):
+        """w_i <- gamma_i * w_i with gamma = clamp(1 - gamma_mult * attenuator(e), 0, 1)  (reference :258-272)."""
+        gamma = 1 - self.gamma_mult * self.attenuator(task_embeddings)
+        gamma.clamp_(0, 1)
+        scaled = hip_ops.mt_scale(gamma, list(names_weights_copy.values()))
+        return dict(zip(names_weights_copy.keys(), scaled))
+
+    # -----------------------------------------------------------------------------------------
+    # inner loop
+    # -----------------------------------------------------------------------------------------
+    def apply_inner_loop_update(self, loss, names_weights_copy, use_second_order, current_step_idx):
+        """grad of the support loss w.r.t. the fast weights, then the learned update (reference :275-321).
+        Tensors without a gradient drop out of the dict."""
+        self.net.zero_grad(params=names_weights_copy)
+        grads = torch.autograd.grad(loss, names_weights_copy.values(), create_graph=use_second_order,
+                                    allow_unused=True)
+        return self.inner_loop_optimizer.update_params(
+            names_weights_dict=names_weights_copy,
+            names_grads_wrt_params_dict=dict(zip(names_weights_copy.keys(), grads)),
+            num_step=current_step_idx)
+
+    def _adapt(self, frames, task_id, num_steps, use_second_order, per_step_hook=None):
+        """Run the inner loop of one task; returns the adapted fast weights."""
+        weights = self.get_inner_loop_parameter_dict(self.net.named_parameters())
+        weights = {name.replace('module.', ''): v for name, v in weights.items()}
+        self.inner_loop_optimizer.initialize_state()
+        if self.args.attenuate:
+            emb = self.get_task_embeddings(frames, task_id, weights)
+            weights = self.attenuate_init(task_embeddings=emb, names_weights_copy=weights)
+        for num_step in range(num_steps):
+            support_loss = self._support_loss(frames, task_id, weights, num_step)
+            weights = self.apply_inner_loop_update(loss=support_loss, names_weights_copy=weights,
+                                                   use_second_order=use_second_order, current_step_idx=num_step)
+            if per_step_hook is not None:
+                per_step_hook(num_step, weights)
+        return weights
+
+    def _to_unit_range(self, img):
+        if self.args.model == 'voxelflow':
+            return (img * self.std + self.mean) / 255.0
+        return img
+
+    def forward(self, data_batch, epoch, use_second_order, use_multi_step_loss_optimization, num_steps,
+                training_phase, do_evaluation=False):
+        """Outer-loop forward over the (local shard of the) meta-batch  (reference :346-472).
+        Returns (losses, per_task_target_preds, metrics)."""
+        frames = data_batch
+        num_tasks = len(frames[0])
+        tp = self.task_parallel
+        local = tp.local_tasks(num_tasks)
+        msl = bool(use_multi_step_loss_optimization and training_phase
+                   and epoch < self.args.multi_step_loss_num_epochs)
+
+        total_losses = []
+        deferred = _DeferredMeters()
+        eval_mse, eval_ssim = [], []
+        preds = [[] for _ in range(num_tasks)]
+        self.net.zero_grad()
+        importance = self.get_per_step_loss_importance_vector()
+
+        for task_id in local:
+            task_losses = []
+            state = {}
+
+            def after_step(num_step, weights):
+                if msl:  # MAML++: weighted target loss after every inner step
+                    tl, tp_ = self._target_pass(frames, task_id, weights, num_step)
+                    task_losses.append(importance[num_step] * tl['total'])
+                    for k, v in tl.items():
+                        deferred.add(k, v)
+                    state['preds'] = tp_
+
+            weights = self._adapt(frames, task_id, num_steps, use_second_order, after_step)
+
+            if not training_phase:
+                with torch.no_grad():
+                    tl, state['preds'] = self._target_pass(frames, task_id, weights, num_steps)
+                task_losses.append(tl['total'])
+                for k, v in tl.items():
+                    deferred.add(k, v)
+            elif not msl:
+                tl, state['preds'] = self._target_pass(frames, task_id, weights, num_steps)
+                task_losses.append(tl['total'])
+                for k, v in tl.items():
+                    deferred.add(k, v)
+
+            target_preds = state['preds']
+            preds[task_id] = self._to_unit_range(target_preds.detach().squeeze(0)).unsqueeze(0)
+            if do_evaluation:
+                out01 = self._to_unit_range(target_preds.detach().squeeze(0))
+                tgt01 = self._to_unit_range(frames[self.target_idxs[1]][task_id].detach())
+                q_o, q_t = utils.quantize(out01, 1.), utils.quantize(tgt01, 1.)
+                eval_mse.append((q_o - q_t).div(255).pow(2).mean())
+                eval_ssim.append(utils.ssim(q_o.unsqueeze(0), q_t.unsqueeze(0), val_range=255))
+
+            total_losses.append(torch.sum(torch.stack(task_losses)))
+            if not training_phase:
+                self.net.restore_backup_stats()
+
+        # mean over the GLOBAL meta-batch: local sum / B (the all-reduce of grads completes the mean)
+        if total_losses:
+            local_sum = torch.sum(torch.stack(total_losses))
+        else:
+            local_sum = torch.zeros((), device=self.device)
+        losses = {'loss': local_sum / num_tasks}
+
+        # one host sync for everything that is logged
+        meters = deferred.flush()
+        metrics = {'psnr': utils.AverageMeter(), 'ssim': utils.AverageMeter()}
+        if eval_mse:
+            mse = torch.stack(eval_mse).cpu().tolist()
+            ssims = torch.stack(eval_ssim).cpu()
+            for m, s in zip(mse, ssims):
+                metrics['psnr'].update(-10 * np.log10(m + 1e-8).item())
+                metrics['ssim'].update(s)
+        if tp.active:
+            self._reduce_logging(losses, meters, metrics)
+        for key, meter in meters.items():
+            losses[key] = meter.avg
+        for idx, item in enumerate(importance):
+            losses['loss_importance_vector_{}'.format(idx)] = item.detach().cpu().numpy()
+        return losses, preds, metrics
+
+    def _reduce_logging(self, losses, meters, metrics):
+        """Average logging scalars over ranks (second, tiny all-reduce; the loss used for backward stays local)."""
+        keys = sorted(meters)
+        vec = [float(losses['loss'].detach())]
+        for k in keys:
+            vec += [float(meters[k].sum), float(meters[k].count)]
+        for k in ('psnr', 'ssim'):
+            vec += [float(metrics[k].sum), float(metrics[k].count)]
+        red = self.task_parallel.allreduce_scalars(torch.tensor(vec, dtype=torch.float64)).cpu().tolist()
+        losses['loss_global'] = red[0]
+        i = 1
+        for k in keys:
+            meters[k].sum, meters[k].count = red[i], red[i + 1]
+            meters[k].avg = red[i] / max(red[i + 1], 1)
+            i += 2
+        for k in ('psnr', 'ssim'):
+            metrics[k].sum, metrics[k].count = red[i], red[i + 1]
+            metrics[k].avg = red[i] / max(red[i + 1], 1)
+            i += 2
+
+    # -----------------------------------------------------------------------------------------
+    # outer loop entry points (called by ExperimentBuilder)
+    # -----------------------------------------------------------------------------------------
+    def train_forward_prop(self, data_batch, epoch, do_evaluation=False):
+        return self.forward(data_batch=data_batch, epoch=epoch,
+                            use_second_order=self.args.second_order and epoch > self.args.first_order_to_second_order_epoch,
+                            use_multi_step_loss_optimization=self.args.use_multi_step_loss_optimization,
+                            num_steps=self.args.number_of_training_steps_per_iter, training_phase=True,
+                            do_evaluation=do_evaluation)
+
+    def evaluation_forward_prop(self, data_batch, epoch):
+        return self.forward(data_batch=data_batch, epoch=epoch, use_second_order=False,
+                            use_multi_step_loss_optimization=True,
+                            num_steps=self.args.number_of_evaluation_steps_per_iter, training_phase=False,
+                            do_evaluation=True)
+
+    def meta_update(self, loss):
+        """zero_grad -> backward -> (all-reduce of outer grads) -> optimizer step  (reference :551-574)."""
+        self.optimizer.zero_grad()
+        if loss.requires_grad:
+            loss.backward()
+        self.task_parallel.allreduce_gradients(list(self.trainable_parameters()))
+        self.optimizer.step()
+
+    def run_train_iter(self, data_batch, epoch, do_evaluation=False):
+        epoch = int(epoch)
+        self.current_epoch = epoch
+        if not self.training:
+            self.train()
+        data_batch = [frame.to(device=self.device, non_blocking=True) for frame in data_batch]
+        losses, preds, metrics = self.train_forward_prop(data_batch=data_batch, epoch=epoch,
+                                                         do_evaluation=do_evaluation)
+        self.meta_update(loss=losses['loss'])
+        self.optimizer.zero_grad()
+        self.zero_grad()
+        return losses, preds, metrics
+
+    def run_validation_iter(self, data_batch):
+        data_batch = [frame.to(device=self.device, non_blocking=True) for frame in data_batch]
+        return self.evaluation_forward_prop(data_batch=data_batch, epoch=self.current_epoch)
+
+    def run_test_iter(self, data_batch):
+        """Adapt on a 4-frame clip ((0,2)->1, (1,3)->2), then interpolate between frames 1 and 2
+        (reference :630-697).  Returns a list of [3,H,W] predictions."""
+        if self.training:
+            self.eval()
+        frames = [frame.to(device=self.device, non_blocking=True) for frame in data_batch]
+        saved = self.support_idxs
+        self.support_idxs = [[0, 1, 2], [1, 2, 3]]
+        preds = [[] for _ in range(len(frames[0]))]
+        self.net.zero_grad()
+        try:
+            for task_id in range(len(frames[0])):
+                steps = self.args.number_of_evaluation_steps_per_iter
+                weights = self._adapt(frames, task_id, steps, self.args.second_order)
+                with torch.no_grad():
+                    out = self.net.forward(frames[1][task_id].unsqueeze(0), frames[2][task_id].unsqueeze(0),
+                                           params=weights, backup_running_statistics=False,
+                                           num_step=max(steps - 1, 0))
+                preds[task_id] = out.squeeze(0).detach()
+                self.net.restore_backup_stats()
+        finally:
+            self.support_idxs = saved
+        return preds

@@ -1,0 +1,276 @@
+"""Fast-weight ("Meta") layers shared by the SepConv / VoxelFlow / CAIN plugins.
+
+Surface kept from the reference (model_utils.py:11-28, :202-228, :272-366, :821-1053): every Meta*
+layer is an nn.Module whose ``forward(x, params=None)`` uses its own parameters when ``params`` is
+None and externally supplied fast weights otherwise; parameter NAMES are part of the contract (they
+key the inner-loop lr tables and checkpoints).
+
+Routing is different by design.  The reference rebuilds nested dicts with ``extract_top_level_dict``
+at every nesting level of every forward (O(#params x depth) Python work per pass, 494 keys x ~6
+levels for CAIN).  Here the fast weights stay in ONE flat ``{name: tensor}`` dict for the whole inner
+loop and layers receive a ``ParamView`` = (flat dict, name prefix); descending a level is a string
+concatenation and a leaf lookup is a single dict access.  Plain (possibly nested) dicts are still
+accepted anywhere a ParamView is, so the reference's call pattern ``module(x, params=subdict)`` works.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import hip_ops
+
+
+# --------------------------------------------------------------------------------------------
+# fast-weight routing
+# --------------------------------------------------------------------------------------------
+class ParamView:
+    """A window ``prefix*`` onto a flat fast-weight dict."""
+    __slots__ = ("flat", "prefix")
+
+    def __init__(self, flat, prefix=""):
+        self.flat = flat
+        self.prefix = prefix
+
+    def sub(self, name):
+        return ParamView(self.flat, self.prefix + str(name) + ".")
+
+    def __getitem__(self, name):
+        key = self.prefix + str(name)
+        if key in self.flat:
+            return self.flat[key]
+        # an interior name: hand out the sub-window (mirrors params['conv'] returning a sub-dict)
+        pre = key + "."
+        if any(k.startswith(pre) for k in self.flat):
+            return ParamView(self.flat, pre)
+        raise KeyError(key)
+
+    def __contains__(self, name):
+        key = self.prefix + str(name)
+        return key in self.flat or any(k.startswith(key + ".") for k in self.flat)
+
+    def leaf(self, name):
+        return self.flat[self.prefix + name]
+
+
+def _flatten(d, prefix, out):
+    for k, v in d.items():
+        if isinstance(v, dict):
+            _flatten(v, prefix + str(k) + ".", out)
+        else:
+            out[prefix + str(k)] = v
+    return out
+
+
+def as_view(params):
+    """None | ParamView | flat dict | nested dict  ->  None | ParamView."""
+    if params is None or isinstance(params, ParamView):
+        return params
+    if any(isinstance(v, dict) for v in params.values()):
+        params = _flatten(params, "", {})
+    return ParamView(params)
+
+
+def extract_top_level_dict(current_dict):
+    """Compatibility helper with the reference's name (model_utils.py:272-305): split a flat
+    ``a.b.c`` dict on its first level.  The plugins in this package do not need it (see ParamView)."""
+    out = {}
+    for key, value in current_dict.items():
+        name = key.replace("layer_dict.", "").replace("block_dict.", "").replace("module-", "")
+        top, _, rest = name.partition(".")
+        if rest == "":
+            out[top] = value
+        else:
+            out.setdefault(top, {})[rest] = value
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# small tensor helpers
+# --------------------------------------------------------------------------------------------
+def sub_mean(x):
+    """Remove the per-channel spatial mean; returns (x - mean, mean)  (reference :11-15)."""
+    mean = x.mean(2, keepdim=True).mean(3, keepdim=True)
+    return x - mean, mean
+
+
+def _pad_to_multiple(size, shift):
+    return 0 if size == ((size >> shift) << shift) else (((size >> shift) + 1) << shift) - size
+
+
+def InOutPaddings(x):
+    """Reflection pad to a multiple of 128 and the matching crop (reference :17-28)."""
+    pw, ph = _pad_to_multiple(x.size(3), 7), _pad_to_multiple(x.size(2), 7)
+    left, top = pw // 2, ph // 2
+    pad_in = nn.ReflectionPad2d([left, pw - left, top, ph - top])
+    pad_out = nn.ReflectionPad2d([-left, left - pw, -top, top - ph])
+    return pad_in, pad_out
+
+
+def pixel_shuffle(input, scale_factor):
+    """Space-to-depth (scale<1) / depth-to-space (scale>=1) with the reference's channel order
+    (reference :202-217), on the savfi HIP permutation kernels."""
+    return hip_ops.pixel_shuffle(input, scale_factor)
+
+
+class PixelShuffle(nn.Module):
+    def __init__(self, scale_factor):
+        super().__init__()
+        self.scale_factor = scale_factor
+
+    def forward(self, x):
+        return pixel_shuffle(x, self.scale_factor)
+
+    def extra_repr(self):
+        return 'scale_factor={}'.format(self.scale_factor)
+
+
+# --------------------------------------------------------------------------------------------
+# Meta layers
+# --------------------------------------------------------------------------------------------
+class MetaConv2dLayer(nn.Module):
+    """conv2d with internal (Xavier-uniform weight, zero bias) or external weights (reference :308-366)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride, padding, use_bias=True, groups=1,
+                 dilation_rate=1):
+        super().__init__()
+        self.stride, self.padding = int(stride), int(padding)
+        self.dilation_rate, self.groups, self.use_bias = int(dilation_rate), int(groups), use_bias
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, kernel_size, kernel_size))
+        nn.init.xavier_uniform_(self.weight)
+        self.bias = nn.Parameter(torch.zeros(out_channels)) if use_bias else None
+
+    def forward(self, x, params=None):
+        if params is not None:
+            pv = as_view(params)
+            weight = pv.leaf("weight")
+            bias = pv.leaf("bias") if self.use_bias else None
+        else:
+            weight, bias = self.weight, self.bias
+        return F.conv2d(x, weight, bias, self.stride, self.padding, self.dilation_rate, self.groups)
+
+    def restore_backup_stats(self):
+        pass
+
+
+class MetaConvNorm(nn.Module):
+    """reflection pad + conv (norm is never enabled by the three plugins; reference :821-848)."""
+
+    def __init__(self, in_feat, out_feat, kernel_size, stride=1, norm=False):
+        super().__init__()
+        assert not norm, "normalisation inside MetaConvNorm is unused on this path"
+        self.reflection_pad = nn.ReflectionPad2d(kernel_size // 2)
+        self.conv = MetaConv2dLayer(in_feat, out_feat, kernel_size=kernel_size, stride=stride, padding=0,
+                                    use_bias=True)
+        self.norm = norm
+
+    def forward(self, x, params=None):
+        pv = as_view(params)
+        return self.conv(self.reflection_pad(x), params=None if pv is None else pv.sub("conv"))
+
+
+_META_TYPES = ()
+
+
+class MetaSequential(nn.Sequential):
+    """nn.Sequential whose meta children receive ``params[str(index)]`` (reference :851-891)."""
+
+    def is_meta_layer(self, module):
+        return isinstance(module, _META_TYPES)
+
+    def forward(self, input, params=None):
+        pv = as_view(params)
+        for ind, module in enumerate(self):
+            if pv is not None and isinstance(module, _META_TYPES):
+                input = module(input, params=pv.sub(ind))
+            else:
+                input = module(input)
+        return input
+
+    def restore_backup_stats(self):
+        pass
+
+
+class MetaCALayer(nn.Module):
+    """Channel attention: GAP -> 1x1 (C -> C/r) -> ReLU -> 1x1 -> sigmoid -> scale (reference :931-953)."""
+
+    def __init__(self, channel, reduction=16):
+        super().__init__()
+        self.avg_pool = nn.AdaptiveAvgPool2d(1)
+        self.conv_du = MetaSequential(
+            MetaConv2dLayer(channel, channel // reduction, kernel_size=1, stride=1, padding=0),
+            nn.ReLU(inplace=False),
+            MetaConv2dLayer(channel // reduction, channel, kernel_size=1, stride=1, padding=0),
+            nn.Sigmoid())
+
+    def forward(self, x, params=None):
+        pv = as_view(params)
+        y = self.conv_du(self.avg_pool(x), None if pv is None else pv.sub("conv_du"))
+        return x * y, y
+
+
+class MetaRCAB(nn.Module):
+    """Residual channel-attention block (reference :957-990); no downscale variant on this path."""
+
+    def __init__(self, in_feat, out_feat, kernel_size, reduction, bias=True, norm=False, act=nn.ReLU(True),
+                 downscale=False, return_ca=False):
+        super().__init__()
+        assert not downscale, "downscaling RCABs are not used by MetaCAIN"
+        self.body = MetaSequential(
+            MetaConvNorm(in_feat, out_feat, kernel_size, stride=1, norm=norm),
+            act,
+            MetaConvNorm(out_feat, out_feat, kernel_size, stride=1, norm=norm),
+            MetaCALayer(out_feat, reduction))
+        self.downscale = downscale
+        self.return_ca = return_ca
+
+    def forward(self, x, params=None):
+        pv = as_view(params)
+        out, ca = self.body(x, None if pv is None else pv.sub("body"))
+        out = out + x
+        return (out, ca) if self.return_ca else out
+
+
+class MetaResidualGroup(nn.Module):
+    """n_resblocks blocks + one conv, with a group-level skip (reference :994-1011)."""
+
+    def __init__(self, Block, n_resblocks, n_feat, kernel_size, reduction, act, norm=False):
+        super().__init__()
+        blocks = [Block(n_feat, n_feat, kernel_size, reduction, bias=True, norm=norm, act=act)
+                  for _ in range(n_resblocks)]
+        blocks.append(MetaConvNorm(n_feat, n_feat, kernel_size, stride=1, norm=norm))
+        self.body = MetaSequential(*blocks)
+
+    def forward(self, x, params=None):
+        pv = as_view(params)
+        return self.body(x, None if pv is None else pv.sub("body")) + x
+
+
+class MetaInterpolation(nn.Module):
+    """CAIN trunk: head conv (2F -> F), residual groups, long skip, tail conv (reference :1014-1053)."""
+
+    def __init__(self, n_resgroups, n_resblocks, n_feats, reduction=16, act=nn.LeakyReLU(0.2, False),
+                 norm=False):
+        super().__init__()
+        self.headConv = MetaConv2dLayer(n_feats * 2, n_feats, kernel_size=3, stride=1, padding=1)
+        self.body = MetaSequential(*[
+            MetaResidualGroup(MetaRCAB, n_resblocks=n_resblocks, n_feat=n_feats, kernel_size=3,
+                              reduction=reduction, act=act, norm=norm) for _ in range(n_resgroups)])
+        self.tailConv = MetaConv2dLayer(n_feats, n_feats, kernel_size=3, stride=1, padding=1)
+
+    def forward(self, x0, x1, params=None):
+        pv = as_view(params)
+        sub = (lambda n: None) if pv is None else pv.sub
+        x = self.headConv(torch.cat([x0, x1], dim=1), sub("headConv"))
+        res = self.body(x, sub("body")) + x
+        return self.tailConv(res, sub("tailConv"))
+
+
+_META_TYPES = (MetaConv2dLayer, MetaConvNorm, MetaSequential, MetaCALayer, MetaRCAB, MetaResidualGroup)
+
+
+def zero_grad_params(module, params=None):
+    """``net.zero_grad(params)`` of the plugins (e.g. sepconv/model.py:352-367) without the
+    reference's per-parameter host sync (``torch.sum(param.grad) > 0`` + print)."""
+    it = module.parameters() if params is None else params.values()
+    for p in it:
+        if p.requires_grad and p.grad is not None:
+            p.grad = None

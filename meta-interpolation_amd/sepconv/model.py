@@ -1,0 +1,112 @@
+"""SepConv plugin (``--model sepconv``): the adaptive separable-convolution U-Net with fast weights.
+
+Surface and parameter names follow the reference's ``MetaNetwork`` (sepconv/model.py:168-375):
+``forward(frame0, frame1, params=None, **kwargs) -> [N,3,H,W]``, ``zero_grad(params)``,
+``restore_backup_stats()``; parameters ``moduleConv{1..5}.{0,2,4}``, ``moduleDeconv{5..2}.{0,2,4}``,
+``moduleUpsample{5..2}.1``, ``module{Vertical,Horizontal}{1,2}.{0,2,4,7}`` (.weight/.bias).
+
+As in the reference (:276-306 vs :292-307, :346-347) only the encoder/decoder ``Basic`` blocks read
+the fast-weight dict; the four ``moduleUpsampleN`` and the four 51-tap ``Subnet``s always use the
+module's own parameters.  The two local separable convolutions run on the savfi HIP kernel
+(FunctionSepconv); frames are replication-padded by 25 px and up to a multiple of 128.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..model_utils import MetaConv2dLayer, MetaSequential, as_view, zero_grad_params
+from .sepconv_op.sepconv import FunctionSepconv
+
+FILTER_TAPS = 51
+HALF = FILTER_TAPS // 2  # 25
+
+
+def _conv(cin, cout):
+    return MetaConv2dLayer(in_channels=cin, out_channels=cout, kernel_size=3, stride=1, padding=1)
+
+
+def _basic(cin, cout):
+    return MetaSequential(_conv(cin, cout), nn.ReLU(inplace=False),
+                          _conv(cout, cout), nn.ReLU(inplace=False),
+                          _conv(cout, cout), nn.ReLU(inplace=False))
+
+
+def _upsample(ch):
+    return MetaSequential(nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True),
+                          _conv(ch, ch), nn.ReLU(inplace=False))
+
+
+def _subnet():
+    return MetaSequential(_conv(64, 64), nn.ReLU(inplace=False),
+                          _conv(64, 64), nn.ReLU(inplace=False),
+                          _conv(64, FILTER_TAPS), nn.ReLU(inplace=False),
+                          nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True),
+                          _conv(FILTER_TAPS, FILTER_TAPS))
+
+
+_ENCODER = [("moduleConv1", 6, 32), ("moduleConv2", 32, 64), ("moduleConv3", 64, 128),
+            ("moduleConv4", 128, 256), ("moduleConv5", 256, 512)]
+_DECODER = [("moduleDeconv5", 512, 512), ("moduleDeconv4", 512, 256), ("moduleDeconv3", 256, 128),
+            ("moduleDeconv2", 128, 64)]
+
+
+class MetaNetwork(nn.Module):
+    def __init__(self, resume=False, strModel='lf'):
+        super().__init__()
+        for i, (name, cin, cout) in enumerate(_ENCODER, start=1):
+            setattr(self, name, _basic(cin, cout))
+            setattr(self, "modulePool%d" % i, nn.AvgPool2d(kernel_size=2, stride=2))
+        for name, cin, cout in _DECODER:
+            setattr(self, name, _basic(cin, cout))
+            setattr(self, name.replace("Deconv", "Upsample"), _upsample(cout))
+        self.moduleVertical1 = _subnet()
+        self.moduleVertical2 = _subnet()
+        self.moduleHorizontal1 = _subnet()
+        self.moduleHorizontal2 = _subnet()
+        self.padding = [HALF] * 4
+        self.modulePad = nn.ReplicationPad2d(self.padding)
+        if resume:
+            path = 'pretrained_models/sepconv_base_' + strModel + '.pth'
+            print('Loading model: ' + path)
+            self.load_state_dict(torch.load(path))
+
+    @staticmethod
+    def padded_size(height, width):
+        """(H+50, W+50) rounded up to multiples of 128 (reference :254-260)."""
+        up = lambda n: n if n == ((n >> 7) << 7) else (((n >> 7) + 1) << 7)
+        return up(height + 2 * HALF), up(width + 2 * HALF)
+
+    def forward(self, tensorFirst, tensorSecond, params=None, **kwargs):
+        height, width = tensorFirst.size(2), tensorFirst.size(3)
+        ph, pw = self.padded_size(height, width)
+        pad_in = (HALF, pw - HALF - width, HALF, ph - HALF - height)
+        first = F.pad(tensorFirst, pad_in, mode='replicate')
+        second = F.pad(tensorSecond, pad_in, mode='replicate')
+
+        pv = as_view(params)
+        fast = (lambda n: None) if pv is None else pv.sub
+
+        x = torch.cat([first, second], 1)
+        skips = []
+        for i, (name, _, _) in enumerate(_ENCODER, start=1):
+            x = getattr(self, name)(x, fast(name))
+            skips.append(x)
+            x = getattr(self, "modulePool%d" % i)(x)
+        for name, _, _ in _DECODER:
+            x = getattr(self, name)(x, fast(name))
+            x = getattr(self, name.replace("Deconv", "Upsample"))(x)   # own parameters, as the reference
+            x = x + skips.pop()
+        combine = x  # [N,64,ph/2,pw/2]
+
+        dot1 = FunctionSepconv.apply(self.modulePad(first).contiguous(),
+                                     self.moduleVertical1(combine), self.moduleHorizontal1(combine))
+        dot2 = FunctionSepconv.apply(self.modulePad(second).contiguous(),
+                                     self.moduleVertical2(combine), self.moduleHorizontal2(combine))
+        out = dot1 + dot2
+        return out[:, :, HALF:HALF + height, HALF:HALF + width]
+
+    def zero_grad(self, params=None):
+        zero_grad_params(self, params)
+
+    def restore_backup_stats(self):
+        pass  # no batch statistics in this model

@@ -1,0 +1,96 @@
+"""Deterministic synthetic inputs: seeded weights for the three plugins and seeded septuplets.
+
+There is no network for datasets or checkpoints, and the reference ships no weights
+(pretrained_models/_dummy_model.pth is empty), so benchmarks, parity tests and the golden fixtures
+all use THIS recipe (SURVEY.md section 8c "Weights", 8d "Synthetic inputs").  Everything is numpy
+RandomState based, so the same bytes come out on the GPU box, in this container, and inside the
+reference import that generated tests/golden.
+"""
+import zlib
+
+import numpy as np
+import torch
+
+# Xavier-uniform bound multiplier per plugin: keeps un-normalised random nets at O(1) outputs
+# (raw Xavier makes CAIN's 127-conv stack blow up to L1 ~ 20).
+_GAIN = {'sepconv': 1.0, 'cain': 0.5, 'voxelflow': 1.0}
+
+
+def _stream(seed, name):
+    return np.random.RandomState((zlib.crc32(name.encode()) ^ (seed * 2654435761)) & 0x7fffffff)
+
+
+def seeded_state_dict(net, model, seed=12345):
+    """{name: tensor} for every parameter and buffer of `net`, one independent numpy stream per name."""
+    gain = _GAIN.get(model, 1.0)
+    out = {}
+    for name, ref in net.state_dict().items():
+        rs = _stream(seed, name)
+        shape = tuple(ref.shape)
+        if name.endswith('num_batches_tracked'):
+            val = np.zeros(shape, dtype=np.int64)
+        elif name.endswith('running_mean'):
+            val = rs.uniform(-0.1, 0.1, size=shape)
+        elif name.endswith('running_var'):
+            val = rs.uniform(0.5, 1.5, size=shape)
+        elif len(shape) == 4:  # conv weight [out, in, kh, kw]
+            fan_in = shape[1] * shape[2] * shape[3]
+            fan_out = shape[0] * shape[2] * shape[3]
+            if model == 'voxelflow':
+                val = rs.normal(0.0, 0.01, size=shape) * 3.0
+            else:
+                bound = gain * np.sqrt(6.0 / (fan_in + fan_out))
+                val = rs.uniform(-bound, bound, size=shape)
+        elif name.endswith('_bn.weight'):
+            val = rs.uniform(0.8, 1.2, size=shape)
+        else:  # biases (conv bias, BN bias)
+            val = rs.uniform(-0.02, 0.02, size=shape)
+        out[name] = torch.from_numpy(np.asarray(val)).to(ref.dtype)
+    return out
+
+
+def load_seeded_weights(net, model, seed=12345):
+    sd = seeded_state_dict(net, model, seed)
+    net.load_state_dict(sd)
+    return sd
+
+
+def _box_blur(a, k):
+    """k x k box filter (valid) with cumulative sums."""
+    c = np.cumsum(np.cumsum(np.pad(a, ((1, 0), (1, 0), (0, 0))), axis=0), axis=1)
+    return (c[k:, k:] - c[:-k, k:] - c[k:, :-k] + c[:-k, :-k]) / float(k * k)
+
+
+def septuplet(task_seed, height, width, frames=7, model='sepconv'):
+    """7 frames [3,H,W] float32 of a smooth texture translating by (1, 2) px per frame, quantised to
+    k/255 like decoded PNGs.  VoxelFlow gets the (255 x - 127.5)/127.5 normalisation of the
+    reference's loader (data/vimeo_septuplet.py:38-40)."""
+    rs = np.random.RandomState(1234 + task_seed)
+    k = 9
+    hh, ww = height + (frames - 1) * 1 + k - 1, width + (frames - 1) * 2 + k - 1
+    tex = _box_blur(rs.uniform(0.0, 1.0, size=(hh, ww, 3)), k)
+    tex = np.clip((tex - 0.5) * 6.0 + 0.5, 0.0, 1.0)
+    out = []
+    for f in range(frames):
+        crop = tex[f * 1:f * 1 + height, f * 2:f * 2 + width]
+        q = np.round(crop * 255.0) / 255.0
+        if model == 'voxelflow':
+            q = (255.0 * q - 127.5) / 127.5
+        out.append(torch.from_numpy(np.ascontiguousarray(q.transpose(2, 0, 1)).astype(np.float32)))
+    return out
+
+
+def septuplet_batch(num_tasks, height, width, model='sepconv', first_task=0, frames=7):
+    """list of `frames` tensors [B,3,H,W] -- the data_batch layout run_train_iter consumes."""
+    tasks = [septuplet(first_task + t, height, width, frames, model) for t in range(num_tasks)]
+    return [torch.stack([tasks[t][f] for t in range(num_tasks)], 0) for f in range(frames)]
+
+
+def seeded_attenuator_state(num_layers, seed=777, gamma_mult=0.5):
+    """L2F attenuator (Linear(L,L)-ReLU-Linear(L,L)-Sigmoid) + gamma_mult with a non-trivial seeded
+    state (the reference initialises gamma_mult to 0, which turns L2F into a no-op)."""
+    rs = np.random.RandomState(seed)
+    shapes = [('0.weight', (num_layers, num_layers)), ('0.bias', (num_layers,)),
+              ('2.weight', (num_layers, num_layers)), ('2.bias', (num_layers,))]
+    sd = {k: torch.from_numpy(rs.uniform(-0.05, 0.05, size=s).astype(np.float32)) for k, s in shapes}
+    return sd, torch.full((1,), float(gamma_mult))

@@ -1,0 +1,178 @@
+"""-m gpu: every HIP kernel, called through the C ABI (ctypes -> libsavfi_hip.so), against the CPU
+oracle on identical seeded inputs.  Tolerances are stated per test; fp32 everywhere."""
+import math
+
+import pytest
+import torch
+
+from meta_interpolation_amd import _hip, hip_ops
+from meta_interpolation_amd.sepconv.sepconv_op.sepconv import FunctionSepconv
+from oracle import torch_ops as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _rel(a, b):
+    return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-12)
+
+
+def _sepconv_inputs(B, C, Ho, Wo, K, seed):
+    g = torch.Generator().manual_seed(seed)
+    inp = torch.rand(B, C, Ho + K - 1, Wo + K - 1, generator=g)
+    v = torch.randn(B, K, Ho, Wo, generator=g) / math.sqrt(K)
+    h = torch.randn(B, K, Ho, Wo, generator=g) / math.sqrt(K)
+    gO = torch.randn(B, C, Ho, Wo, generator=g)
+    return inp, v, h, gO
+
+
+# shapes: the K=51 fast path with ragged tiles, batch>1, the generic path (K!=51, C!=3), tiny
+SEPCONV_CASES = [
+    (1, 3, 16, 32, 51), (2, 3, 37, 45, 51), (1, 3, 128, 128, 51), (1, 1, 9, 70, 51),
+    (1, 3, 7, 5, 5), (2, 4, 10, 33, 3), (1, 2, 1, 1, 1), (1, 3, 20, 20, 13),
+]
+
+
+@pytest.mark.parametrize("B,C,Ho,Wo,K", SEPCONV_CASES)
+def test_sepconv_forward_backward_vs_oracle(B, C, Ho, Wo, K):
+    inp, v, h, gO = _sepconv_inputs(B, C, Ho, Wo, K, seed=B * 1000 + Ho * 10 + K)
+    ref = O.sepconv_forward_c(inp, v, h)
+    rI, rV, rH = O.sepconv_backward_c(inp, v, h, gO, need_input=True)
+
+    di, dv, dh = (t.to(DEV).requires_grad_() for t in (inp, v, h))
+    out = FunctionSepconv.apply(di, dv, dh)
+    out.backward(gO.to(DEV))
+    torch.cuda.synchronize()
+    # fp32 sums of K*K (2601) products in a different association: 1e-5 relative to max|ref|
+    assert _rel(out.detach().cpu(), ref) < 1e-5
+    assert _rel(dv.grad.cpu(), rV) < 1e-5
+    assert _rel(dh.grad.cpu(), rH) < 1e-5
+    assert _rel(di.grad.cpu(), rI) < 1e-5
+
+
+def test_sepconv_needs_input_grad_subsets():
+    inp, v, h, gO = _sepconv_inputs(1, 3, 24, 40, 51, seed=7)
+    _, rV, rH = O.sepconv_backward_c(inp, v, h, gO)
+    for need_v, need_h in [(True, False), (False, True)]:
+        di = inp.to(DEV)
+        dv = v.to(DEV).requires_grad_(need_v)
+        dh = h.to(DEV).requires_grad_(need_h)
+        FunctionSepconv.apply(di, dv, dh).backward(gO.to(DEV))
+        if need_v:
+            assert _rel(dv.grad.cpu(), rV) < 1e-5 and dh.grad is None
+        else:
+            assert _rel(dh.grad.cpu(), rH) < 1e-5 and dv.grad is None
+
+
+def test_sepconv_full_size_properties():
+    """BASELINE config-2 shape (256x448 -> padded 384x512, K=51): oracle parity on the full tensor
+    plus size-independent properties (linearity in the input; a delta kernel reproduces a shift)."""
+    B, C, Ho, Wo, K = 1, 3, 384, 512, 51
+    inp, v, h, gO = _sepconv_inputs(B, C, Ho, Wo, K, seed=99)
+    di, dv, dh = inp.to(DEV), v.to(DEV), h.to(DEV)
+    out = FunctionSepconv.apply(di, dv, dh)
+    ref = O.sepconv_forward_c(inp, v, h)
+    assert _rel(out.cpu(), ref) < 1e-5
+    # linearity: f(a*x + y) = a*f(x) + f(y)
+    inp2 = torch.rand_like(inp).to(DEV)
+    lhs = FunctionSepconv.apply(2.5 * di + inp2, dv, dh)
+    rhs = 2.5 * out + FunctionSepconv.apply(inp2, dv, dh)
+    assert _rel(lhs, rhs) < 1e-5
+    # delta taps at (fy0, fx0) -> pure crop/shift of the input, bit exact
+    fy0, fx0 = 13, 42
+    vd = torch.zeros_like(dv); vd[:, fy0] = 1
+    hd = torch.zeros_like(dh); hd[:, fx0] = 1
+    shifted = FunctionSepconv.apply(di, vd, hd)
+    assert torch.equal(shifted, di[:, :, fy0:fy0 + Ho, fx0:fx0 + Wo])
+    # filter gradients at full size
+    dv.requires_grad_(); dh.requires_grad_()
+    FunctionSepconv.apply(di, dv, dh).backward(gO.to(DEV))
+    _, rV, rH = O.sepconv_backward_c(inp, v, h, gO)
+    assert _rel(dv.grad.cpu(), rV) < 1e-5
+    assert _rel(dh.grad.cpu(), rH) < 1e-5
+
+
+def test_sepconv_does_not_write_out_of_bounds():
+    """Canary-padded outputs around ragged tiles (odd sizes, K=51 halo edges)."""
+    B, C, Ho, Wo, K = 1, 3, 19, 41, 51
+    inp, v, h, gO = _sepconv_inputs(B, C, Ho, Wo, K, seed=5)
+    lib = _hip.lib()
+    n_out, n_f = B * C * Ho * Wo, B * K * Ho * Wo
+    pad = 4096
+    bufs = {k: torch.full((n + 2 * pad,), 7777.0, device=DEV) for k, n in
+            dict(out=n_out, gV=n_f, gH=n_f).items()}
+    di, dv, dh, dg = inp.to(DEV), v.to(DEV), h.to(DEV), gO.to(DEV)
+    st = _hip.current_stream()
+    _hip.check(lib.savfi_sepconv_fwd_f32(di.data_ptr(), dv.data_ptr(), dh.data_ptr(),
+                                         bufs["out"][pad:].data_ptr(), B, C, Ho, Wo, K, st), "fwd")
+    _hip.check(lib.savfi_sepconv_bwd_f32(di.data_ptr(), dv.data_ptr(), dh.data_ptr(), dg.data_ptr(), None,
+                                         bufs["gV"][pad:].data_ptr(), bufs["gH"][pad:].data_ptr(),
+                                         B, C, Ho, Wo, K, st), "bwd")
+    torch.cuda.synchronize()
+    for k, n in dict(out=n_out, gV=n_f, gH=n_f).items():
+        assert torch.all(bufs[k][:pad] == 7777.0) and torch.all(bufs[k][pad + n:] == 7777.0), k
+    assert _rel(bufs["out"][pad:pad + n_out].cpu().view(B, C, Ho, Wo), O.sepconv_forward_c(inp, v, h)) < 1e-5
+
+
+def test_sepconv_argument_errors():
+    lib = _hip.lib()
+    x = torch.zeros(16, device=DEV)
+    st = _hip.current_stream()
+    assert lib.savfi_sepconv_fwd_f32(None, x.data_ptr(), x.data_ptr(), x.data_ptr(), 1, 1, 1, 1, 1, st) == -1
+    assert lib.savfi_sepconv_fwd_f32(x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), 1, 1, 0, 1, 1, st) == -2
+    with pytest.raises(NotImplementedError):
+        FunctionSepconv.apply(torch.zeros(1, 1, 3, 3), torch.zeros(1, 3, 1, 1), torch.zeros(1, 3, 1, 1))
+    with pytest.raises(AssertionError):
+        FunctionSepconv.apply(torch.zeros(1, 1, 4, 3, device=DEV), torch.zeros(1, 3, 1, 1, device=DEV),
+                              torch.zeros(1, 3, 1, 1, device=DEV))
+
+
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,H,W,amp", [(1, 64, 64, 0.3), (2, 33, 47, 1.0), (1, 256, 256, 1.0), (1, 5, 3, 2.0)])
+def test_voxelwarp_vs_oracle(B, H, W, amp):
+    g = torch.Generator().manual_seed(H * W)
+    frames = torch.rand(B, 6, H, W, generator=g) * 2 - 1
+    x3 = torch.tanh(torch.randn(B, 3, H, W, generator=g) * amp)  # amp>=1 pushes samples past the border
+    gO = torch.randn(B, 3, H, W, generator=g)
+    fr, xr = frames.clone().requires_grad_(), x3.clone().requires_grad_()
+    ref = O.voxel_warp_blend(fr, xr)
+    ref.backward(gO)
+
+    fd, xd = frames.to(DEV).requires_grad_(), x3.to(DEV).requires_grad_()
+    out = hip_ops.voxel_warp_blend(fd, xd)
+    out.backward(gO.to(DEV))
+    # bilinear weights are built from coordinates ~1e2 px: 1e-5 absolute on [-1,1] images
+    assert (out.detach().cpu() - ref.detach()).abs().max() < 2e-5
+    # d/dflow multiplies texel differences by (size-1)/2: compare relative to the largest gradient
+    assert _rel(xd.grad.cpu(), xr.grad) < 1e-4
+    assert _rel(fd.grad.cpu(), fr.grad) < 1e-4
+
+
+@pytest.mark.parametrize("B,C,H,W,r", [(1, 3, 128, 128, 8), (2, 3, 16, 24, 2), (1, 3, 768, 1280, 8), (1, 1, 8, 8, 8),
+                                       (1, 2, 9, 15, 3)])
+def test_pixel_shuffle_roundtrip_and_oracle(B, C, H, W, r):
+    x = torch.randn(B, C, H, W)
+    xd = x.to(DEV).requires_grad_()
+    down = hip_ops.pixel_shuffle(xd, 1.0 / r)
+    assert torch.equal(down.detach().cpu(), O.pixel_shuffle(x, 1.0 / r))   # pure permutation: bit exact
+    up = hip_ops.pixel_shuffle(down, r)
+    assert torch.equal(up.detach().cpu(), x)
+    assert torch.equal(hip_ops.pixel_shuffle(down.detach(), r).cpu(), O.pixel_shuffle(down.detach().cpu(), r))
+    g = torch.randn_like(down)
+    down.backward(g)
+    assert torch.equal(xd.grad.cpu(), O.pixel_shuffle(g.cpu(), r))            # adjoint = inverse permutation
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+@pytest.mark.parametrize("shape", [(1, 3, 256, 448), (1, 3, 7, 5), (2, 3, 64, 64)])
+def test_l1_mse_vs_torch(kind, shape):
+    a, b = torch.rand(shape), torch.rand(shape)
+    ar = a.clone().requires_grad_()
+    ref = (torch.nn.functional.l1_loss if kind == 0 else torch.nn.functional.mse_loss)(ar, b)
+    ref.backward()
+    ad = a.to(DEV).requires_grad_()
+    out = (hip_ops.l1_loss if kind == 0 else hip_ops.mse_loss)(ad, b.to(DEV))
+    (out * 1.0).backward()
+    assert abs(out.item() - ref.item()) < 1e-6 * max(1.0, abs(ref.item())) + 1e-7
+    assert _rel(ad.grad.cpu(), ar.grad) < 1e-6

@@ -1,0 +1,176 @@
+"""CPU: the oracle (oracle/*.py, the CPU restatement of the reference path) against the golden
+fixtures produced by importing the reference itself (oracle/gen_golden.py).  This is what pins the
+oracle; the -m gpu tests then compare the HIP product path with the oracle and the same fixtures.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import meta, models, rules
+from oracle import torch_ops as O
+from tests.helpers import assert_fp_close, fp, golden, oracle_base, parse_case_args
+from meta_interpolation_amd import synthetic
+
+torch.set_num_threads(8)
+
+
+# ---------------------------------------------------------------------------------------------
+# ops
+# ---------------------------------------------------------------------------------------------
+def test_pixel_shuffle_matches_reference():
+    g = golden("ops")
+    x = torch.from_numpy(g['ps_in'])
+    assert np.array_equal(O.pixel_shuffle(x, 1 / 8).numpy(), g['ps_down8'])
+    assert np.array_equal(O.pixel_shuffle(x, 1 / 2).numpy(), g['ps_down2'])
+    assert np.array_equal(O.pixel_shuffle(torch.from_numpy(g['ps_up_in']), 8).numpy(), g['ps_up8'])
+
+
+def test_voxel_warp_matches_reference_model_tail():
+    g = golden("ops")
+    f0, f1 = torch.from_numpy(g['vf_f0']), torch.from_numpy(g['vf_f1'])
+    frames = torch.cat([f0, f1], 1)
+    ph, pw = 64 - 48, 128 - 80
+    inp = torch.nn.functional.pad(frames, [pw // 2, pw - pw // 2, ph // 2, ph - ph // 2], mode='reflect')
+    out = O.voxel_warp_blend(inp, torch.from_numpy(g['vf_x3']))
+    out = out[:, :, ph // 2:ph // 2 + 48, pw // 2:pw // 2 + 80]
+    assert np.abs(out.numpy() - g['vf_out']).max() < 1e-6
+    big = O.voxel_warp_blend(inp, torch.from_numpy(g['vf_big_x3']))[:, :, ph // 2:ph // 2 + 48, pw // 2:pw // 2 + 80]
+    assert np.abs(big.numpy() - g['vf_big_out']).max() < 2e-5   # atanh/tanh round trip in the fixture
+
+
+def test_sepconv_c_and_torch_restatements_agree():
+    gen = torch.Generator().manual_seed(3)
+    inp = torch.rand(2, 3, 20 + 50, 31 + 50, generator=gen)
+    v = torch.randn(2, 51, 20, 31, generator=gen) / 7
+    h = torch.randn(2, 51, 20, 31, generator=gen) / 7
+    gO = torch.randn(2, 3, 20, 31, generator=gen)
+    out_c = O.sepconv_forward_c(inp, v, h)
+    i2, v2, h2 = (t.clone().double().requires_grad_() for t in (inp, v, h))
+    out_t = O.sepconv_torch(i2, v2, h2)
+    out_t.backward(gO.double())
+    gI, gV, gH = O.sepconv_backward_c(inp, v, h, gO, need_input=True)
+    rel = lambda a, b: (a.double() - b).abs().max().item() / b.abs().max().item()
+    assert rel(out_c, out_t.detach()) < 1e-5
+    assert rel(gV, v2.grad) < 1e-5 and rel(gH, h2.grad) < 1e-5 and rel(gI, i2.grad) < 1e-5
+
+
+def test_sepconv_torch_gradcheck_fp64():
+    gen = torch.Generator().manual_seed(0)
+    inp = torch.randn(1, 2, 6, 7, dtype=torch.float64, generator=gen).requires_grad_()
+    v = torch.randn(1, 3, 4, 5, dtype=torch.float64, generator=gen).requires_grad_()
+    h = torch.randn(1, 3, 4, 5, dtype=torch.float64, generator=gen).requires_grad_()
+    assert torch.autograd.gradcheck(O.sepconv_torch, (inp, v, h))
+
+
+def test_metrics_match_reference():
+    from meta_interpolation_amd import utils as U
+    g = golden("ops")
+    a, b = torch.from_numpy(g['metric_a']), torch.from_numpy(g['metric_b'])
+    psnr, ssim = U.calc_metrics(a, b)
+    assert abs(psnr - float(g['metric_psnr'])) < 1e-6
+    assert abs(float(ssim) - float(g['metric_ssim'])) < 1e-6
+    assert abs(meta.psnr(a, b) - float(g['metric_psnr'])) < 1e-6
+
+
+@pytest.mark.parametrize("S,epoch,E", [(5, 0, 10), (5, 3, 10), (5, 50, 10), (1, 0, 1), (3, 2, 4)])
+def test_msl_importance_vector(S, epoch, E):
+    g = golden("ops")
+    assert np.array_equal(meta.importance_vector(S, epoch, E).numpy(), g['msl_%d_%d_%d' % (S, epoch, E)])
+
+
+# ---------------------------------------------------------------------------------------------
+# update rules, tau = 1..3, against the reference classes' outputs
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind", ["lslr", "metasgd"])
+@pytest.mark.parametrize("opt", ["SGD", "Adam", "Adamax"])
+def test_rules_match_reference(kind, opt):
+    g = golden("rules")
+    names = ['a.weight', 'a.bias', 'b.weight', 'c.weight']
+    w = {k: torch.from_numpy(g['w0/' + k]) for k in names}
+    lrs = {rules.lr_key(k): torch.from_numpy(g['lr/%s/%s' % (kind, rules.lr_key(k))]) for k in names}
+    st = rules.RuleState()
+    for t in range(3):
+        grads = {k: torch.from_numpy(g['g%d/%s' % (t, k)]) for k in w}
+        if t >= 1 and 'c.weight' in grads:
+            grads['c.weight'] = None
+        w = rules.update_params(kind, opt, w, grads, lrs, t, st)
+        for k, v in w.items():
+            want = g['out/%s/%s/%d/%s' % (kind, opt, t, k)]
+            assert np.abs(v.numpy() - want).max() <= 2e-7 * max(1.0, np.abs(want).max()), (kind, opt, t, k)
+        assert ('c.weight' in w) == (t == 0)
+
+
+# ---------------------------------------------------------------------------------------------
+# whole path: one meta-iteration per fixture
+# ---------------------------------------------------------------------------------------------
+SYSTEM = ['c1_cain_lslr_sgd', 'cain_l2f', 'cain_lslr_adam_1step', 'sepconv_lslr_sgd_2step',
+          'sepconv_metasgd_adamax_2step', 'sepconv_msl_learnable_2step', 'voxelflow_metasgd_adamax_2step']
+
+
+def _run_oracle_case(name, phase):
+    g = golden("system_" + name)
+    model = str(g['model'])
+    a = parse_case_args(g)
+    H, W, B = int(g['H']), int(g['W']), int(g['B'])
+    base = oracle_base(model)
+    frames = synthetic.septuplet_batch(B, H, W, model=model)
+    kind = 'metasgd' if a.get('metasgd') else 'lslr'
+    S_train = a.get('number_of_training_steps_per_iter', 1)
+    S = S_train if phase == 'train' else a.get('number_of_evaluation_steps_per_iter', 1)
+    names_w = {n: base[n] for n in meta.inner_param_names(
+        [(n, p) for n, p in base.items() if p.is_floating_point()])}
+    lrs = rules.init_lrs(kind, names_w, a['inner_lr'], num_steps=S_train,
+                         learnable=a.get('learnable_per_layer_per_step_inner_loop_learning_rate', False))
+    att, gm = None, None
+    if a.get('attenuate'):
+        L = len(names_w)
+        sd, gm = synthetic.seeded_attenuator_state(L)
+        att = torch.nn.Sequential(torch.nn.Linear(L, L), torch.nn.ReLU(), torch.nn.Linear(L, L), torch.nn.Sigmoid())
+        att.load_state_dict(sd)
+        gm = gm.requires_grad_()
+    rec = {}
+    res = meta.run_iteration(model, base, frames, rule=kind, optimizer=a['optimizer'], lrs=lrs, num_steps=S,
+                             loss=a['loss'].split('*')[1], training=(phase == 'train'),
+                             msl=(a.get('use_multi_step_loss_optimization', False) if phase == 'train' else True),
+                             epoch=0, msl_epochs=a.get('multi_step_loss_num_epochs', 1),
+                             attenuator=att, gamma_mult=gm, record=rec)
+    return g, res, rec, base, lrs, att, gm
+
+
+@pytest.mark.parametrize("name", SYSTEM)
+@pytest.mark.parametrize("phase", ["train", "val"])
+def test_oracle_iteration_matches_reference(name, phase):
+    g, res, rec, base, lrs, att, gm = _run_oracle_case(name, phase)
+    want_loss = float(g[phase + '_loss'])
+    assert abs(res['loss'].item() - want_loss) <= 1e-5 * abs(want_loss)
+    preds = torch.stack([p.squeeze(0) for p in res['preds']]).numpy()
+    want = g[phase + '_preds']
+    if str(g['model']) == 'voxelflow':      # fixture preds are mapped back to [0,1] (x*127.5+127.5)/255
+        preds = (preds * 127.5 + 127.5) / 255.0
+    assert np.abs(preds - want).mean() < 1e-5            # pixel L1 gate is 1e-4
+    assert list(g[phase + '_n_live']) == rec['n_live']
+    for i, d in enumerate(rec['weight_fp']):
+        keys = list(g['%s_weight_fp_%d_keys' % (phase, i)])
+        assert sorted(d) == keys
+        for k, row in zip(keys, g['%s_weight_fp_%d' % (phase, i)]):
+            assert_fp_close(np.array(d[k]), row, 1e-5, (name, i, k))
+    for i, d in enumerate(rec['grad_fp']):
+        keys = list(g['%s_grad_fp_%d_keys' % (phase, i)])
+        assert sorted(d) == keys
+        for k, row in zip(keys, g['%s_grad_fp_%d' % (phase, i)]):
+            assert_fp_close(np.array(d[k]), row, 2e-4, (name, i, k))
+    if phase == 'train':
+        # outer gradients after loss.backward()
+        res['loss'].backward()
+        keys = list(g['outer_grad_fp_0_keys'])
+        rows = dict(zip(keys, g['outer_grad_fp_0']))
+        checked = 0
+        for n, p in base.items():
+            if p.requires_grad and p.grad is not None and ('net.' + n) in rows:
+                assert_fp_close(fp(p.grad), rows['net.' + n], 2e-4, (name, 'outer', n))
+                checked += 1
+        assert checked > 0
+        for k, lr in lrs.items():
+            full = 'inner_loop_optimizer.names_learning_rates_dict.' + k
+            if lr.requires_grad and lr.grad is not None and full in rows:
+                assert_fp_close(fp(lr.grad), rows[full], 2e-4, (name, 'outer-lr', k))
