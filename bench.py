@@ -1,0 +1,159 @@
+"""bench.py -- inner-loop steps/sec of the MAML adaptation path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): SepConv, meta-batch 4 tasks per GPU, 5 inner steps, synthetic
+256x448x3 septuplets, LSLR + SGD inner rule, L1 loss, outer Adam -- seeded random-init weights.
+One "step" of this script = one run_train_iter over the rank's meta-batch (4 tasks x 5 inner steps =
+20 inner-loop steps, + target passes, outer backward, all-reduce of outer grads, outer Adam).
+`value` = inner-loop steps/sec summed over all ranks (weak scaling: 4 tasks per GPU).
+
+The line also carries
+  roofline     : the dominant custom kernel (sepconv backward, gV+gH) -- algorithmic bytes per launch
+                 (165.72 MB at B=1,C=3,K=51,384x512: SURVEY.md 8d) / mean launch time from HIP events
+                 recorded on the launch stream INSIDE the timed region, against the 8 TB/s HBM peak;
+  cpu_baseline : the CPU oracle (oracle/meta.py, the restatement pinned to the reference) timed on the
+                 host cores for a bounded sample of the same workload (1 task x 1 inner step at 256x448,
+                 incl. target pass and outer backward).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import torch  # noqa: E402
+
+WORKLOADS = {
+    # name: (model, H, W, tasks/GPU, inner steps, overrides)
+    'c2_sepconv_256x448_b4_s5': ('sepconv', 256, 448, 4, 5, dict(optimizer='SGD', loss='1*L1', inner_lr=1e-5)),
+    'c3_voxelflow_metasgd_256x256_b8_s5': ('voxelflow', 256, 256, 8, 5,
+                                           dict(optimizer='Adamax', metasgd=True, loss='1*MSE', inner_lr=1e-5)),
+    'c1_cain_64x64_b1_s1': ('cain', 64, 64, 1, 1, dict(optimizer='SGD', loss='1*L1', inner_lr=1e-5)),
+}
+
+# algorithmic HBM bytes per launch (fp32, each operand once): SURVEY.md 8(d)
+def sepconv_bytes(B, C, Ho, Wo, K, backward):
+    fwd = 4 * (B * C * (Ho + K - 1) * (Wo + K - 1) + 2 * B * K * Ho * Wo + B * C * Ho * Wo)
+    return fwd + 4 * 2 * B * K * Ho * Wo if backward else fwd
+
+
+def cpu_baseline(model, H, W, overrides):
+    """Oracle (CPU restatement) on a bounded sample: 1 task x 1 inner step, full resolution."""
+    from meta_interpolation_amd import synthetic
+    from oracle import meta, rules
+    from tests.helpers import oracle_base
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    base = oracle_base(model)
+    frames = synthetic.septuplet_batch(1, H, W, model=model)
+    kind = 'metasgd' if overrides.get('metasgd') else 'lslr'
+    names_w = {n: base[n] for n in meta.inner_param_names([(n, p) for n, p in base.items() if p.is_floating_point()])}
+    lrs = rules.init_lrs(kind, names_w, overrides['inner_lr'], num_steps=1)
+    t0 = time.perf_counter()
+    res = meta.run_iteration(model, base, frames, rule=kind, optimizer=overrides['optimizer'], lrs=lrs, num_steps=1,
+                             loss=overrides['loss'].split('*')[1], training=True)
+    res['loss'].backward()
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "inner-loop steps/sec", "cores": cores, "kind": "port",
+            "sample": "1 task x 1 inner step (2 support fwd+bwd, update, target pass, outer backward) at "
+                      "%dx%d, %s, wall %.1f s" % (H, W, model, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--workload', default='c2_sepconv_256x448_b4_s5', choices=sorted(WORKLOADS))
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timer', action='store_true')
+    opt = ap.parse_args()
+
+    from meta_interpolation_amd import _hip, synthetic, task_parallel
+    from meta_interpolation_amd.config import default_args
+    from meta_interpolation_amd.meta_learning_system import MODEL_REGISTRY, SceneAdaptiveInterpolation
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    rank, world, local_rank = task_parallel.init_from_env()
+    if world != opt.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (opt.gpus, world))
+    dev = torch.device('cuda', torch.cuda.current_device())
+
+    model, H, W, tasks, S, over = WORKLOADS[opt.workload]
+    args = default_args(model=model, num_gpu=1, batch_size=tasks * world,
+                        number_of_training_steps_per_iter=S, number_of_evaluation_steps_per_iter=S, **over)
+    net = MODEL_REGISTRY[model](args, False)
+    synthetic.load_seeded_weights(net, model)          # identical theta on every rank, no broadcast
+    system = SceneAdaptiveInterpolation(args, net=net.to(dev))
+    tp = system.task_parallel
+
+    # the global meta-batch has tasks*world tasks; rank r adapts tasks {t : t mod world == r}.
+    # Build only the local ones (others are placeholders that are never touched).
+    frames = synthetic.septuplet_batch(tasks * world, H, W, model=model)
+    frames = [f.to(dev) for f in frames]                # inputs resident in HBM before the timed region
+
+    def one_iter(it):
+        system.run_train_iter(data_batch=frames, epoch=0, do_evaluation=False)
+
+    for i in range(opt.warmup):
+        one_iter(i)
+    timer = None
+    if not opt.no_kernel_timer and model == 'sepconv':
+        timer = _hip.KernelTimer()
+        _hip.TIMER = timer
+    tp.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(opt.steps):
+        one_iter(i)
+    torch.cuda.synchronize()
+    tp.barrier()
+    elapsed = time.perf_counter() - t0
+    _hip.TIMER = None
+    if tp.active:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    inner_steps = tasks * world * S * opt.steps
+    line = {
+        "metric": "inner-loop steps/sec", "value": inner_steps / elapsed, "unit": "inner-loop steps/sec",
+        "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": 1e3 * elapsed / opt.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": opt.workload, "model": model, "tasks_per_gpu": tasks, "global_meta_batch": tasks * world,
+                   "inner_steps": S, "frame": "%dx%dx3" % (H, W), "inner_rule": ("metasgd" if over.get('metasgd') else "lslr")
+                   + "+" + over['optimizer'], "parallelism": "task-parallel x%d, 1 all-reduce of outer grads" % world,
+                   "outer_tasks_per_sec": tasks * world * opt.steps / elapsed},
+    }
+    if rank == 0:
+        if timer is not None:
+            summ = timer.summary()
+            line["kernels"] = summ
+            k = summ.get("sepconv_bwd")
+            if k:
+                ph, pw = net.padded_size(H, W)
+                line["roofline"] = {
+                    "bound": "hbm", "kernel": "sepconv_bwd_filters (gV+gH, K=51)",
+                    "achieved": k["achieved_GBps"], "peak": 8000.0, "unit": "GB/s",
+                    "frac": k["achieved_GBps"] / 8000.0, "traffic": None,
+                    "avg_us_per_launch": k["avg_us"], "launches": k["launches"],
+                    "algorithmic_bytes_per_launch": k["algorithmic_bytes"] / k["launches"],
+                    "note": "algorithmic bytes = 165.72 MB per [1,3,%d,%d] call (x2 for the fused N=2 support "
+                            "pair); fp32 VALU ceiling of this kernel is ~53%% of HBM peak (SURVEY.md 7)" % (ph, pw)}
+        if world == 1 and not opt.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(model, H, W, over)
+        print(json.dumps(line), flush=True)
+    tp.barrier()
+
+
+if __name__ == '__main__':
+    main()

@@ -142,30 +142,34 @@ class KernelTimer:
     def __init__(self):
         self.records = {}
 
-    def launch(self, name, fn):
+    def launch(self, name, fn, nbytes=0):
         import torch
         a = torch.cuda.Event(enable_timing=True)
         b = torch.cuda.Event(enable_timing=True)
         a.record()
         fn()
         b.record()
-        self.records.setdefault(name, []).append((a, b))
+        self.records.setdefault(name, []).append((a, b, nbytes))
 
     def summary(self):
         import torch
         torch.cuda.synchronize()
         out = {}
         for name, evs in self.records.items():
-            ms = [a.elapsed_time(b) for a, b in evs]
-            out[name] = {"launches": len(ms), "total_ms": sum(ms), "avg_us": 1e3 * sum(ms) / len(ms)}
+            ms = [a.elapsed_time(b) for a, b, _ in evs]
+            nbytes = sum(n for _, _, n in evs)
+            out[name] = {"launches": len(ms), "total_ms": sum(ms), "avg_us": 1e3 * sum(ms) / len(ms),
+                         "min_us": 1e3 * min(ms), "algorithmic_bytes": nbytes,
+                         "achieved_GBps": (nbytes / (sum(ms) * 1e-3) / 1e9) if sum(ms) > 0 else None}
         return out
 
 
 TIMER = None  # set to a KernelTimer instance to time launches
 
 
-def launch(name, fn):
+def launch(name, fn, nbytes=0):
+    """Run one C-ABI launch; `nbytes` = its algorithmic HBM bytes (each operand once), for the timer."""
     if TIMER is None:
         fn()
     else:
-        TIMER.launch(name, fn)
+        TIMER.launch(name, fn, nbytes)

@@ -14,6 +14,13 @@ import torch
 from ... import _hip
 
 
+def algorithmic_bytes(B, C, Ho, Wo, K, grads=0):
+    """HBM bytes if every operand is read / written exactly once (fp32): input halo + v + h + out
+    (+ gO is the `out`-sized term of the backward) + one [B,K,Ho,Wo] plane set per filter gradient."""
+    return 4 * (B * C * (Ho + K - 1) * (Wo + K - 1) + 2 * B * K * Ho * Wo + B * C * Ho * Wo
+                + grads * B * K * Ho * Wo)
+
+
 def _dims(input, vertical, horizontal):
     B, C, Hi, Wi = input.shape
     K = min(vertical.size(1), horizontal.size(1))
@@ -38,7 +45,8 @@ class FunctionSepconv(torch.autograd.Function):
         lib = _hip.lib()
         _hip.launch("sepconv_fwd", lambda: _hip.check(lib.savfi_sepconv_fwd_f32(
             input.data_ptr(), vertical.data_ptr(), horizontal.data_ptr(), output.data_ptr(),
-            B, C, Ho, Wo, K, _hip.current_stream()), "savfi_sepconv_fwd_f32"))
+            B, C, Ho, Wo, K, _hip.current_stream()), "savfi_sepconv_fwd_f32"),
+            nbytes=algorithmic_bytes(B, C, Ho, Wo, K))
         return output
 
     @staticmethod
@@ -60,7 +68,8 @@ class FunctionSepconv(torch.autograd.Function):
             name = "sepconv_bwd" if not need_i else "sepconv_bwd+gI"
             _hip.launch(name, lambda: _hip.check(lib.savfi_sepconv_bwd_f32(
                 input.data_ptr(), vertical.data_ptr(), horizontal.data_ptr(), gradOutput.data_ptr(),
-                p(gI), p(gV), p(gH), B, C, Ho, Wo, K, _hip.current_stream()), "savfi_sepconv_bwd_f32"))
+                p(gI), p(gV), p(gH), B, C, Ho, Wo, K, _hip.current_stream()), "savfi_sepconv_bwd_f32"),
+                nbytes=algorithmic_bytes(B, C, Ho, Wo, K, grads=int(need_v) + int(need_h)))
         return gI, gV, gH
 
 

@@ -51,3 +51,39 @@ def assert_fp_close(got, want, rtol=1e-5, what=""):
     scale = max(abs(want[1]), 1e-12)
     assert abs(got[0] - want[0]) <= rtol * scale, (what, got[0], want[0])
     assert abs(got[1] - want[1]) <= rtol * scale, (what, got[1], want[1])
+
+
+def build_system(model, overrides, fuse=1, device="cuda"):
+    from meta_interpolation_amd.meta_learning_system import SceneAdaptiveInterpolation
+    args = default_args(model=model, num_gpu=1, fuse_support_pairs=fuse, **overrides)
+    net = build_plugin(model, device)
+    system = SceneAdaptiveInterpolation(args, net=net)
+    if args.attenuate:
+        sd, gm = synthetic.seeded_attenuator_state(len(system.inner_loop_optimizer.names_learning_rates_dict))
+        system.attenuator.load_state_dict(sd)
+        with torch.no_grad():
+            system.gamma_mult.copy_(gm)
+    return system
+
+
+def observe(system):
+    rec = dict(n_live=[], grad_fp=[], weight_fp=[], outer_grad_fp={})
+    rule = system.inner_loop_optimizer
+    orig = rule.update_params
+
+    def update_params(names_weights_dict, names_grads_wrt_params_dict, num_step, **kw):
+        out = orig(names_weights_dict=names_weights_dict, names_grads_wrt_params_dict=names_grads_wrt_params_dict,
+                   num_step=num_step, **kw)
+        rec['n_live'].append(len(out))
+        rec['grad_fp'].append({k: fp(v) for k, v in names_grads_wrt_params_dict.items() if v is not None})
+        rec['weight_fp'].append({k: fp(v) for k, v in out.items()})
+        return out
+    rule.update_params = update_params
+
+    def step(*a, **k):
+        rec['outer_grad_fp'] = {n: fp(p.grad) for n, p in system.named_parameters()
+                                if p.requires_grad and p.grad is not None}
+    system.optimizer.step = step
+    return rec
+
+

@@ -1,0 +1,174 @@
+"""-m gpu: the HIP product path (SceneAdaptiveInterpolation + plugins + fused rules, every custom op
+through libsavfi_hip.so) against (a) the golden fixtures generated from the imported reference and
+(b) the CPU oracle, on identical seeded weights and septuplets.
+
+Gates (SURVEY.md 8d "Parity gate"): output frames <= 1e-4 mean abs (pixel L1, [0,1] scale) and
+<= 1e-3 dB PSNR; losses rel 1e-5 (5e-5 allowed: MIOpen's fp32 conv algorithms sum in another order
+than the CPU's); fast-weight fingerprints rel 1e-5; gradient fingerprints rel 1e-3 of their abs-sum.
+"""
+import numpy as np
+import pytest
+import torch
+
+from meta_interpolation_amd import _hip, hip_ops, synthetic
+from meta_interpolation_amd.config import default_args
+from meta_interpolation_amd.inner_loop_optimizers import LSLRGradientDescentLearningRule, MetaSGDLearningRule
+from meta_interpolation_amd.meta_learning_system import SceneAdaptiveInterpolation
+from oracle import rules as orules
+from tests.helpers import assert_fp_close, build_plugin, build_system, fp, golden, observe, parse_case_args
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+SYSTEM = ['c1_cain_lslr_sgd', 'cain_l2f', 'cain_lslr_adam_1step', 'sepconv_lslr_sgd_2step',
+          'sepconv_metasgd_adamax_2step', 'sepconv_msl_learnable_2step', 'voxelflow_metasgd_adamax_2step']
+
+
+def run_case(name, phase, fuse=1):
+    g = golden("system_" + name)
+    model = str(g['model'])
+    system = build_system(model, parse_case_args(g), fuse=fuse)
+    rec = observe(system)
+    frames = synthetic.septuplet_batch(int(g['B']), int(g['H']), int(g['W']), model=model)
+    if phase == 'train':
+        losses, preds, metrics = system.run_train_iter(data_batch=frames, epoch=0, do_evaluation=True)
+    else:
+        losses, preds, metrics = system.run_validation_iter(data_batch=frames)
+    torch.cuda.synchronize()
+    return g, losses, preds, metrics, rec
+
+
+@pytest.mark.parametrize("name", SYSTEM)
+@pytest.mark.parametrize("phase", ["train", "val"])
+def test_iteration_matches_reference_fixture(name, phase):
+    g, losses, preds, metrics, rec = run_case(name, phase)
+    want_loss = float(g[phase + '_loss'])
+    assert abs(losses['loss'].item() - want_loss) <= 5e-5 * abs(want_loss)
+    got = torch.stack([p.squeeze(0) for p in preds]).cpu().numpy()
+    assert np.abs(got - g[phase + '_preds']).mean() < 1e-4                      # pixel L1 gate
+    assert abs(metrics['psnr'].avg - float(g[phase + '_psnr'])) < 1e-3           # dB gate
+    assert abs(float(metrics['ssim'].avg) - float(g[phase + '_ssim'])) < 1e-4
+    assert list(g[phase + '_n_live']) == rec['n_live']                           # fact 6: 94 -> 54, 23 -> 9
+    for i, d in enumerate(rec['weight_fp']):
+        keys = list(g['%s_weight_fp_%d_keys' % (phase, i)])
+        assert sorted(d) == keys
+        for k, row in zip(keys, g['%s_weight_fp_%d' % (phase, i)]):
+            assert_fp_close(d[k], row, 1e-5, (name, 'w', i, k))
+    for i, d in enumerate(rec['grad_fp']):
+        for k, row in zip(list(g['%s_grad_fp_%d_keys' % (phase, i)]), g['%s_grad_fp_%d' % (phase, i)]):
+            assert_fp_close(d[k], row, 1e-3, (name, 'g', i, k))
+    if phase == 'train':
+        rows = dict(zip(list(g['outer_grad_fp_0_keys']), g['outer_grad_fp_0']))
+        assert set(rec['outer_grad_fp']) == set(rows)
+        for k, row in rows.items():
+            assert_fp_close(rec['outer_grad_fp'][k], row, 1e-3, (name, 'outer', k))
+
+
+@pytest.mark.parametrize("name", ['sepconv_lslr_sgd_2step', 'voxelflow_metasgd_adamax_2step', 'c1_cain_lslr_sgd'])
+def test_fused_support_pair_equals_two_single_passes(name):
+    _, l1, p1, _, r1 = run_case(name, 'train', fuse=1)
+    _, l0, p0, _, r0 = run_case(name, 'train', fuse=0)
+    assert abs(l1['loss'].item() - l0['loss'].item()) <= 2e-5 * abs(l0['loss'].item())
+    for a, b in zip(p1, p0):
+        assert (a - b).abs().mean().item() < 1e-5
+    for k in r0['outer_grad_fp']:
+        assert_fp_close(r1['outer_grad_fp'][k], r0['outer_grad_fp'][k], 1e-3, k)
+
+
+# ---------------------------------------------------------------------------------------------
+# fused multi-tensor rules against the reference classes' outputs (tests/golden/rules.npz)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind", ["lslr", "metasgd"])
+@pytest.mark.parametrize("opt", ["SGD", "Adam", "Adamax"])
+def test_fused_rules_match_reference(kind, opt):
+    g = golden("rules")
+    names = ['a.weight', 'a.bias', 'b.weight', 'c.weight']
+    w = {k: torch.from_numpy(g['w0/' + k]).to(DEV) for k in names}
+    if kind == 'lslr':
+        rule = LSLRGradientDescentLearningRule(device=DEV, optimizer=opt, total_num_inner_loop_steps=3,
+                                               use_learnable_learning_rates=False, init_learning_rate=0.01)
+    else:
+        rule = MetaSGDLearningRule(device=DEV, optimizer=opt, init_learning_rate=0.01)
+    rule.initialize(w)
+    with torch.no_grad():
+        for k, p in rule.names_learning_rates_dict.items():
+            p.copy_(torch.from_numpy(g['lr/%s/%s' % (kind, k)]))
+    rule.initialize_state()
+    for t in range(3):
+        grads = {k: torch.from_numpy(g['g%d/%s' % (t, k)]).to(DEV) for k in w}
+        if t >= 1 and 'c.weight' in grads:
+            grads['c.weight'] = None
+        with torch.no_grad():
+            w = rule.update_params(w, grads, t)
+        assert ('c.weight' in w) == (t == 0)
+        for k, v in w.items():
+            want = g['out/%s/%s/%d/%s' % (kind, opt, t, k)]
+            assert np.abs(v.cpu().numpy() - want).max() <= 1e-6 * max(1.0, np.abs(want).max()), (kind, opt, t, k)
+
+
+@pytest.mark.parametrize("kind", ["lslr", "metasgd"])
+@pytest.mark.parametrize("opt", ["SGD", "Adam", "Adamax"])
+def test_fused_rule_lr_gradients_match_oracle_autograd(kind, opt):
+    """d(sum c*w_T)/d lr and /d w0 through 3 fused steps == autograd through the oracle's formulas.
+    (Adam/Adamax + learnable lr + >= 2 steps is a configuration the reference itself cannot train.)"""
+    gen = torch.Generator().manual_seed(11)
+    shapes = {'p.weight': (6, 5, 3, 3), 'p.bias': (6,), 'q.weight': (4100,)}
+    w0 = {k: torch.randn(s, generator=gen) for k, s in shapes.items()}
+    grads = [{k: torch.randn(s, generator=gen) for k, s in shapes.items()} for _ in range(3)]
+    coef = {k: torch.randn(s, generator=gen) for k, s in shapes.items()}
+    # oracle, CPU autograd
+    wo = {k: v.clone().requires_grad_() for k, v in w0.items()}
+    lrs = orules.init_lrs(kind, wo, 0.01, num_steps=3, learnable=True)
+    with torch.no_grad():
+        for i, p in enumerate(lrs.values()):
+            p.mul_(1.0 + 0.1 * i)
+    st, cur = orules.RuleState(), dict(wo)
+    for t in range(3):
+        cur = orules.update_params(kind, opt, cur, grads[t], lrs, t, st)
+    sum((coef[k] * cur[k]).sum() for k in cur).backward()
+    # product, fused kernels
+    wd = {k: v.clone().to(DEV).requires_grad_() for k, v in w0.items()}
+    if kind == 'lslr':
+        rule = LSLRGradientDescentLearningRule(device=DEV, optimizer=opt, total_num_inner_loop_steps=3,
+                                               use_learnable_learning_rates=True, init_learning_rate=0.01)
+    else:
+        rule = MetaSGDLearningRule(device=DEV, optimizer=opt, init_learning_rate=0.01)
+    rule.initialize(wd)
+    with torch.no_grad():
+        for i, p in enumerate(rule.names_learning_rates_dict.values()):
+            p.mul_(1.0 + 0.1 * i)
+    rule.initialize_state()
+    cur = dict(wd)
+    for t in range(3):
+        cur = rule.update_params(cur, {k: v.to(DEV) for k, v in grads[t].items()}, t)
+    sum((coef[k].to(DEV) * cur[k]).sum() for k in cur).backward()
+    for k in w0:
+        assert torch.allclose(wd[k].grad.cpu(), wo[k].grad, rtol=1e-5, atol=1e-6)
+        a, b = rule.names_learning_rates_dict[orules.lr_key(k)].grad.cpu(), lrs[orules.lr_key(k)].grad
+        assert (a - b).abs().max() <= 2e-5 * b.abs().max() + 1e-6, (kind, opt, k)
+
+
+def test_l2f_mean_and_scale_kernels():
+    gen = torch.Generator().manual_seed(5)
+    ts = [torch.randn(s, generator=gen) for s in [(192, 192, 3, 3), (192,), (12, 192, 1, 1), (5,), (4097,)] * 30]
+    emb = hip_ops.mt_mean([t.to(DEV) for t in ts])
+    want = torch.stack([t.double().mean() for t in ts]).float()
+    assert (emb.cpu() - want).abs().max() < 1e-6
+    gamma = torch.rand(len(ts), generator=gen).to(DEV).requires_grad_()
+    wd = [t.to(DEV).requires_grad_() for t in ts]
+    outs = hip_ops.mt_scale(gamma, wd)
+    co = [torch.randn(t.shape, generator=gen) for t in ts]
+    sum((c.to(DEV) * o).sum() for c, o in zip(co, outs)).backward()
+    for i, (o, t) in enumerate(zip(outs, ts)):
+        assert torch.allclose(o.detach().cpu(), gamma[i].item() * t, rtol=1e-6, atol=1e-7)
+        assert torch.allclose(wd[i].grad.cpu(), gamma[i].item() * co[i], rtol=1e-6, atol=1e-7)
+    want_g = torch.stack([(c.double() * t.double()).sum() for c, t in zip(co, ts)]).float()
+    assert (gamma.grad.cpu() - want_g).abs().max() <= 1e-4 * want_g.abs().max()
+
+
+def test_product_path_uses_the_hip_library_and_fails_loudly_without_it(monkeypatch):
+    assert _hip.lib().savfi_version() == _hip.ABI_VERSION
+    monkeypatch.setattr(_hip, "_lib", None)
+    monkeypatch.setattr(_hip, "LIB_PATH", "/nonexistent/libsavfi_hip.so")
+    with pytest.raises(_hip.SavfiHipError):
+        hip_ops.l1_loss(torch.zeros(4, device=DEV), torch.zeros(4, device=DEV))
