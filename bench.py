@@ -38,19 +38,15 @@ WORKLOADS = {
     'c1_cain_64x64_b1_s1': ('cain', 64, 64, 1, 1, dict(optimizer='SGD', loss='1*L1', inner_lr=1e-5)),
 }
 
-# algorithmic HBM bytes per launch (fp32, each operand once): SURVEY.md 8(d)
-def sepconv_bytes(B, C, Ho, Wo, K, backward):
-    fwd = 4 * (B * C * (Ho + K - 1) * (Wo + K - 1) + 2 * B * K * Ho * Wo + B * C * Ho * Wo)
-    return fwd + 4 * 2 * B * K * Ho * Wo if backward else fwd
-
-
 def cpu_baseline(model, H, W, overrides):
     """Oracle (CPU restatement) on a bounded sample: 1 task x 1 inner step, full resolution."""
     from meta_interpolation_amd import synthetic
     from oracle import meta, rules
     from tests.helpers import oracle_base
-    cores = os.cpu_count() or 1
+    # N=1 convolutions do not scale past a few dozen threads (256 threads: 10x slower than 32)
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
+    os.environ["OMP_NUM_THREADS"] = str(cores)
     base = oracle_base(model)
     frames = synthetic.septuplet_batch(1, H, W, model=model)
     kind = 'metasgd' if overrides.get('metasgd') else 'lslr'

@@ -98,6 +98,7 @@ class _MtUpdate(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, spec, *tensors):
+        ctx.set_materialize_grads(False)   # unused outputs (e.g. SepConv's subnet copies) stay None
         n = spec["n"]
         ws, lrs = tensors[:n], tensors[n:]
         gs = spec["grads"]
@@ -189,6 +190,7 @@ def mt_mean(tensors):
 class _MtScale(torch.autograd.Function):
     @staticmethod
     def forward(ctx, gamma, *ws):
+        ctx.set_materialize_grads(False)
         _hip.require_cuda(gamma, *ws)
         outs = [torch.empty_like(w) for w in ws]
         lib = _hip.lib()
@@ -203,14 +205,28 @@ class _MtScale(torch.autograd.Function):
     def backward(ctx, *g_outs):
         gamma, *ws = ctx.saved_tensors
         n = len(ws)
-        gos = [g.contiguous() if g is not None else torch.zeros_like(w) for g, w in zip(g_outs, ws)]
-        g_ws = [torch.empty_like(w) if ctx.needs_input_grad[1 + i] else None for i, w in enumerate(ws)]
+        live = [i for i in range(n) if g_outs[i] is not None]
+        g_ws = [None] * n
         g_gamma = torch.zeros_like(gamma) if ctx.needs_input_grad[0] else None
-        lib = _hip.lib()
-        args = (n, _hip.ptr_array(gos), _hip.ptr_array(ws), gamma.data_ptr(), _hip.ptr_array(g_ws),
-                None if g_gamma is None else g_gamma.data_ptr(), _hip.i64_array([w.numel() for w in ws]),
-                _hip.current_stream())
-        _hip.launch("mt_scale_bwd", lambda: _hip.check(lib.savfi_mt_scale_bwd_f32(*args), "savfi_mt_scale_bwd_f32"))
+        if live:
+            # gamma / g_gamma are indexed by tensor position: run the live tensors through a compacted
+            # gamma vector and scatter the per-tensor reductions back
+            gos = [g_outs[i].contiguous() for i in live]
+            wl = [ws[i] for i in live]
+            gw_l = [torch.empty_like(ws[i]) if ctx.needs_input_grad[1 + i] else None for i in live]
+            full = len(live) == n
+            gam_l = gamma if full else gamma[live].contiguous()
+            gg_l = None if g_gamma is None else (g_gamma if full else torch.zeros_like(gam_l))
+            lib = _hip.lib()
+            args = (len(live), _hip.ptr_array(gos), _hip.ptr_array(wl), gam_l.data_ptr(), _hip.ptr_array(gw_l),
+                    None if gg_l is None else gg_l.data_ptr(), _hip.i64_array([w.numel() for w in wl]),
+                    _hip.current_stream())
+            _hip.launch("mt_scale_bwd", lambda: _hip.check(lib.savfi_mt_scale_bwd_f32(*args),
+                                                            "savfi_mt_scale_bwd_f32"))
+            for j, i in enumerate(live):
+                g_ws[i] = gw_l[j]
+            if g_gamma is not None and not full:
+                g_gamma[live] = gg_l
         return (g_gamma, *g_ws)
 
 

@@ -272,5 +272,5 @@ def zero_grad_params(module, params=None):
     reference's per-parameter host sync (``torch.sum(param.grad) > 0`` + print)."""
     it = module.parameters() if params is None else params.values()
     for p in it:
-        if p.requires_grad and p.grad is not None:
+        if p.is_leaf and p.requires_grad and p.grad is not None:
             p.grad = None

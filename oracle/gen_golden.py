@@ -162,6 +162,13 @@ SYSTEM_CASES = {
                                                                     number_of_training_steps_per_iter=2,
                                                                     number_of_evaluation_steps_per_iter=2)),
     'cain_lslr_adam_1step': ('cain', 64, 64, 1, dict(optimizer='Adam', inner_lr=1e-4, loss='1*L1')),
+    # smooth-rule VoxelFlow case (tight parity gate; the Adamax case above is chaotic by construction)
+    'voxelflow_lslr_sgd_2step': ('voxelflow', 64, 64, 2, dict(optimizer='SGD', inner_lr=1e-3, loss='1*MSE',
+                                                              number_of_training_steps_per_iter=2,
+                                                              number_of_evaluation_steps_per_iter=2)),
+    # the reference's own launch-script settings: run_voxelflow.sh / run_cain.sh (Adam + Meta-SGD, 1 step, lr 1e-5)
+    'voxelflow_script_metasgd_adam_1step': ('voxelflow', 64, 64, 1, dict(optimizer='Adam', inner_lr=1e-5, metasgd=True,
+                                                                         loss='1*MSE')),
 }
 
 

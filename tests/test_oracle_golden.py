@@ -104,7 +104,8 @@ def test_rules_match_reference(kind, opt):
 # whole path: one meta-iteration per fixture
 # ---------------------------------------------------------------------------------------------
 SYSTEM = ['c1_cain_lslr_sgd', 'cain_l2f', 'cain_lslr_adam_1step', 'sepconv_lslr_sgd_2step',
-          'sepconv_metasgd_adamax_2step', 'sepconv_msl_learnable_2step', 'voxelflow_metasgd_adamax_2step']
+          'sepconv_metasgd_adamax_2step', 'sepconv_msl_learnable_2step', 'voxelflow_metasgd_adamax_2step',
+          'voxelflow_lslr_sgd_2step', 'voxelflow_script_metasgd_adam_1step']
 
 
 def _run_oracle_case(name, phase):

@@ -1,0 +1,76 @@
+"""CPU, world_size 2, gloo: the task-parallel meta-batch gives the sequential loop's outer gradients.
+
+The real plugins need the GPU (HIP ops), so the N>1 HOST path -- round-robin task sharding, local
+loss scaled by the GLOBAL batch, one flat-bucket all-reduce, identical optimizer step on every rank,
+logging reduction -- is exercised with a small conv plugin and an oracle-backed inner rule on CPU.
+"""
+import os
+import tempfile
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from meta_interpolation_amd.task_parallel import TaskParallel
+from meta_interpolation_amd import synthetic
+from tests.helpers import build_toy_system
+
+B, H, W = 5, 16, 24   # 5 tasks over 2 ranks: uneven shards (3 + 2)
+
+
+def _grads_after_iteration(system, frames, msl):
+    captured = {}
+
+    def step(*a, **k):
+        captured.update({n: p.grad.detach().clone() for n, p in system.named_parameters() if p.grad is not None})
+    system.optimizer.step = step
+    losses, preds, _ = system.run_train_iter(data_batch=frames, epoch=0, do_evaluation=False)
+    return captured, losses, preds
+
+
+def _worker(rank, world, port, outdir, msl):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    try:
+        tp = TaskParallel()
+        assert tp.active and tp.world == world and tp.local_tasks(B) == list(range(rank, B, world))
+        system = build_toy_system(task_parallel=tp, batch=B, msl=msl)
+        frames = synthetic.septuplet_batch(B, H, W)
+        grads, losses, preds = _grads_after_iteration(system, frames, msl)
+        torch.save({'grads': grads, 'loss_global': losses['loss_global'],
+                    'local_preds': [i for i, p in enumerate(preds) if torch.is_tensor(p)]},
+                   os.path.join(outdir, "rank%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("msl", [False, True])
+def test_sharded_outer_gradients_equal_sequential(msl):
+    torch.set_num_threads(2)
+    seq = build_toy_system(batch=B, msl=msl)
+    want, losses, _ = _grads_after_iteration(seq, synthetic.septuplet_batch(B, H, W), msl)
+    assert len(want) > 0 and any(k.startswith('inner_loop_optimizer') for k in want)
+    with tempfile.TemporaryDirectory() as d:
+        port = 29500 + (os.getpid() % 2000) + (7 if msl else 0)
+        mp.spawn(_worker, args=(2, port, d, msl), nprocs=2, join=True)
+        ranks = [torch.load(os.path.join(d, "rank%d.pt" % r), weights_only=False) for r in range(2)]
+    for r in ranks:
+        assert set(r['grads']) == set(want)
+        for k, v in want.items():
+            assert torch.allclose(r['grads'][k], v, rtol=1e-5, atol=1e-7), k
+        assert abs(r['loss_global'] - losses['loss'].item()) < 1e-6
+    # replicas end with bit-identical gradients (-> identical optimizer steps, no broadcast needed)
+    for k in want:
+        assert torch.equal(ranks[0]['grads'][k], ranks[1]['grads'][k])
+    assert ranks[0]['local_preds'] == [0, 2, 4] and ranks[1]['local_preds'] == [1, 3]
+
+
+def test_single_process_task_parallel_is_a_noop():
+    tp = TaskParallel()
+    assert not tp.active and tp.local_tasks(3) == [0, 1, 2]
+    p = torch.nn.Parameter(torch.ones(3))
+    p.grad = torch.full((3,), 2.0)
+    tp.allreduce_gradients([p])
+    assert torch.equal(p.grad, torch.full((3,), 2.0))
