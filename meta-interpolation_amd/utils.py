@@ -108,7 +108,8 @@ def load_checkpoint(args, model, optimizer=None, fix_loaded=False):
     """Resume from checkpoint/<resume_exp or exp_name>/checkpoint.pth (reference :34-86): keys are
     filtered by name and shape, args.start_epoch is set from the file."""
     exp = args.resume_exp if getattr(args, 'resume_exp', None) else args.exp_name
-    path = os.path.join('checkpoint', exp, 'checkpoint.pth')
+    name = 'model_best.pth' if getattr(args, 'mode', 'train') in ('val', 'test') else 'checkpoint.pth'
+    path = os.path.join('checkpoint', exp, name)
     ckpt = torch.load(path, map_location='cpu', weights_only=False)
     args.start_epoch = ckpt.get('epoch', 0)
     with torch.no_grad():
