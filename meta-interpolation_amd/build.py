@@ -20,7 +20,7 @@ STAMP = os.path.join(LIB_DIR, "libsavfi_hip.stamp")
 
 HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-    "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
+    "-fno-gpu-rdc", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function",
 ]
 
 

@@ -18,6 +18,7 @@
 //   gV[fy] = sum_fx P[fy][fx]*h[fx]     gH[fx] = sum_fy P[fy][fx]*v[fy]   (5*K*K FMA for C=3)
 // Any other K (or C != 3 in the backward) takes the generic direct kernels below.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -129,6 +130,359 @@ __global__ __launch_bounds__(NT) void sepconv_bwd_filters_tiled(const float* __r
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// K = 51 fast path, second generation: TWO horizontally adjacent pixels per thread.
+//
+// v1 (one pixel per thread, one ds_read_b32 per FMA) is LDS-bound: a CU moves 128 B/clk with
+// ds_read_b32 against 128 FMA lanes/clk, i.e. 1 float per FMA where the FMA pipe wants 4.
+// Here thread (ty, l) owns pixels x = x0+2l and x0+2l+1 of row y0+ty.  One 8-byte-aligned
+// ds_read_b64 returns (a, b) = in[2l+2k], in[2l+2k+1]; both feed BOTH pixels
+//     pixel0: a*h0[2k] + b*h0[2k+1]        pixel1: a*h1[2k-1] + b*h1[2k]
+// so the forward does 4 FMA and the backward 20 FMA per 8 bytes of LDS traffic (ds_read_b64 runs
+// at 256 B/clk/CU): the loop is FMA-issue bound.  A 32-lane ds_read_b64 group is two tile rows of
+// 16 lanes x 8 B; with the row pitch LW = 96 floats (= 32 banks mod 64) the two rows land on
+// disjoint bank halves, so the reads are conflict-free.  Tile = 16 rows x 32 columns per 256
+// threads; v / h / out / gV / gH move as float2 per lane (128-byte runs per 16-lane row segment).
+// ------------------------------------------------------------------------------------------
+constexpr int T2Y = 16, T2X = 32, T2LW = 96;
+
+// Stage an LH x SPAN window of a [Hi, Wi] plane (top-left at (y0, x0)) into LDS rows of pitch LW.
+// All global loads of a thread are issued back to back (no branch, no wait between them) and the
+// ds_writes follow; coordinates past the plane are clamped -- such entries only ever feed output
+// pixels that lie outside the image and are never stored.
+template <int LH, int SPAN, int LW, int NTHREADS>
+__device__ __forceinline__ void stage_window(float* __restrict__ tile, const float* __restrict__ src, int y0,
+                                             int x0, int Hi, int Wi, int tid) {
+  constexpr int TOTAL = LH * SPAN, NIT = (TOTAL + NTHREADS - 1) / NTHREADS;
+  float buf[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int i = min(tid + it * NTHREADS, TOTAL - 1);
+    const int r = i / SPAN, q = i - r * SPAN;
+    buf[it] = src[(size_t)min(y0 + r, Hi - 1) * Wi + min(x0 + q, Wi - 1)];
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int i = tid + it * NTHREADS;
+    const int r = i / SPAN, q = i - r * SPAN;
+    if (i < TOTAL) tile[r * LW + q] = buf[it];
+  }
+}
+
+
+template <int K>
+__global__ __launch_bounds__(NT) void sepconv_fwd_x2(const float* __restrict__ in, const float* __restrict__ v,
+                                                     const float* __restrict__ h, float* __restrict__ out,
+                                                     int C, int Ho, int Wo) {
+  static_assert(K % 2 == 1 && T2X + K - 1 <= T2LW, "tile geometry");
+  constexpr int LH = T2Y + K - 1, LW = T2LW, NK = (K + 1) / 2, SPAN = T2X + K - 1, U = 3;
+  static_assert(K % U == 0, "tap loop is grouped by U");
+  __shared__ __attribute__((aligned(16))) float tile[LH * LW];
+  const int tid = threadIdx.x, l = tid & 15, ty = tid >> 4;
+  const int x0 = blockIdx.x * T2X, y0 = blockIdx.y * T2Y, b = blockIdx.z;
+  const int x = x0 + 2 * l, y = y0 + ty;
+  const bool valid = (x < Wo) && (y < Ho);   // Wo is even: x and x+1 are valid together
+  const int Hi = Ho + K - 1, Wi = Wo + K - 1;
+  const size_t plane = (size_t)Ho * Wo;
+  const size_t pix = (size_t)b * K * plane + (size_t)(valid ? y : 0) * Wo + (valid ? x : 0);
+
+  float h0[K], h1[K];
+#pragma unroll
+  for (int f = 0; f < K; ++f) {
+    const float2 t = *reinterpret_cast<const float2*>(h + pix + f * plane);
+    h0[f] = t.x; h1[f] = t.y;
+  }
+
+  for (int c = 0; c < C; ++c) {
+    const float* src = in + ((size_t)b * C + c) * Hi * Wi;
+    __syncthreads();
+    stage_window<LH, SPAN, LW, NT>(tile, src, y0, x0, Hi, Wi, tid);
+    __syncthreads();
+    float acc0 = 0.f, acc1 = 0.f;
+    // The vertical taps are the only global loads inside the tap loop; a dependent HBM load per fy makes
+    // the loop latency-bound (~1 us per iteration).  They are fetched one group of U rows ahead.
+    float2 vc[U], vn[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) vc[u] = *reinterpret_cast<const float2*>(v + pix + u * plane);
+    for (int g = 0; g < K / U; ++g) {
+      const int gn = min(g + 1, K / U - 1);   // the last group re-reads itself (keeps the load unconditional)
+#pragma unroll
+      for (int u = 0; u < U; ++u) vn[u] = *reinterpret_cast<const float2*>(v + pix + (gn * U + u) * plane);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const float2* row = reinterpret_cast<const float2*>(&tile[(ty + g * U + u) * LW + 2 * l]);
+        float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+          const float2 ab = row[k];
+          t0 = fmaf(ab.x, h0[2 * k], t0);
+          if (2 * k + 1 < K) t0 = fmaf(ab.y, h0[2 * k + 1], t0);
+          if (k >= 1) t1 = fmaf(ab.x, h1[2 * k - 1], t1);
+          t1 = fmaf(ab.y, h1[2 * k], t1);
+        }
+        acc0 = fmaf(vc[u].x, t0, acc0);
+        acc1 = fmaf(vc[u].y, t1, acc1);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) vc[u] = vn[u];
+    }
+    if (valid)
+      *reinterpret_cast<float2*>(out + ((size_t)b * C + c) * plane + (size_t)y * Wo + x) = make_float2(acc0, acc1);
+  }
+}
+
+template <int K, bool WANT_V, bool WANT_H>
+__global__ __launch_bounds__(NT) void sepconv_bwd_filters_x2(const float* __restrict__ in,
+                                                             const float* __restrict__ v,
+                                                             const float* __restrict__ h,
+                                                             const float* __restrict__ gO,
+                                                             float* __restrict__ gV, float* __restrict__ gH,
+                                                             int Ho, int Wo) {
+  constexpr int C = 3;
+  constexpr int LH = T2Y + K - 1, LW = T2LW, LP = LH * LW, NK = (K + 1) / 2, SPAN = T2X + K - 1;
+  extern __shared__ __attribute__((aligned(16))) float tile[];  // C * LP floats
+  const int tid = threadIdx.x, l = tid & 15, ty = tid >> 4;
+  const int x0 = blockIdx.x * T2X, y0 = blockIdx.y * T2Y, b = blockIdx.z;
+  const int x = x0 + 2 * l, y = y0 + ty;
+  const bool valid = (x < Wo) && (y < Ho);
+  const int Hi = Ho + K - 1, Wi = Wo + K - 1;
+  const size_t plane = (size_t)Ho * Wo;
+  const size_t opix = (size_t)(valid ? y : 0) * Wo + (valid ? x : 0);
+  const size_t pix = (size_t)b * K * plane + opix;
+
+  for (int c = 0; c < C; ++c) {
+    const float* src = in + ((size_t)b * C + c) * Hi * Wi;
+    stage_window<LH, SPAN, LW, NT>(tile + c * LP, src, y0, x0, Hi, Wi, tid);
+  }
+  float h0[K], h1[K], gh0[K], gh1[K];
+#pragma unroll
+  for (int f = 0; f < K; ++f) {
+    const float2 t = WANT_V ? *reinterpret_cast<const float2*>(h + pix + f * plane) : make_float2(0.f, 0.f);
+    h0[f] = t.x; h1[f] = t.y;
+    gh0[f] = 0.f; gh1[f] = 0.f;
+  }
+  float g0[C], g1[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const float2 t = *reinterpret_cast<const float2*>(gO + ((size_t)b * C + c) * plane + opix);
+    g0[c] = t.x; g1[c] = t.y;
+  }
+  __syncthreads();
+
+  // v is fetched one group of U rows ahead of use (see the forward kernel).  U = 1 here: one row of this
+  // kernel is ~510 FMA per lane (>1000 cycles), enough to cover an HBM load, and unrolling more rows lets
+  // the scheduler interleave their 78 ds_read_b64 each and spill.
+  constexpr int U = 1;
+  static_assert(K % U == 0, "tap loop is grouped by U");
+  float2 vc[U], vn[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+    vc[u] = WANT_H ? *reinterpret_cast<const float2*>(v + pix + u * plane) : make_float2(0.f, 0.f);
+  for (int g = 0; g < K / U; ++g) {
+    const int gn = min(g + 1, K / U - 1);
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      vn[u] = WANT_H ? *reinterpret_cast<const float2*>(v + pix + (gn * U + u) * plane) : make_float2(0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int fy = g * U + u;
+      const float2 vv = vc[u];
+      const float2* r0 = reinterpret_cast<const float2*>(&tile[(ty + fy) * LW + 2 * l]);
+      float gv0a = 0.f, gv0b = 0.f, gv1a = 0.f, gv1b = 0.f;
+#pragma unroll
+      for (int k = 0; k < NK; ++k) {
+        const float2 c0 = r0[k], c1 = r0[k + LP / 2], c2 = r0[k + LP];
+        // P for pixel 0 / pixel 1 at columns (2l+2k) [a] and (2l+2k+1) [b]
+        const float pa0 = fmaf(g0[2], c2.x, fmaf(g0[1], c1.x, g0[0] * c0.x));
+        const float pb1 = fmaf(g1[2], c2.y, fmaf(g1[1], c1.y, g1[0] * c0.y));
+        if (WANT_V) { gv0a = fmaf(pa0, h0[2 * k], gv0a); gv1b = fmaf(pb1, h1[2 * k], gv1b); }
+        if (WANT_H) { gh0[2 * k] = fmaf(pa0, vv.x, gh0[2 * k]); gh1[2 * k] = fmaf(pb1, vv.y, gh1[2 * k]); }
+        if (2 * k + 1 < K) {
+          const float pb0 = fmaf(g0[2], c2.y, fmaf(g0[1], c1.y, g0[0] * c0.y));
+          if (WANT_V) gv0b = fmaf(pb0, h0[2 * k + 1], gv0b);
+          if (WANT_H) gh0[2 * k + 1] = fmaf(pb0, vv.x, gh0[2 * k + 1]);
+        }
+        if (k >= 1) {
+          const float pa1 = fmaf(g1[2], c2.x, fmaf(g1[1], c1.x, g1[0] * c0.x));
+          if (WANT_V) gv1a = fmaf(pa1, h1[2 * k - 1], gv1a);
+          if (WANT_H) gh1[2 * k - 1] = fmaf(pa1, vv.y, gh1[2 * k - 1]);
+        }
+      }
+      if (WANT_V && valid) *reinterpret_cast<float2*>(gV + pix + fy * plane) = make_float2(gv0a + gv0b, gv1a + gv1b);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) vc[u] = vn[u];
+  }
+  if (WANT_H && valid) {
+#pragma unroll
+    for (int f = 0; f < K; ++f) *reinterpret_cast<float2*>(gH + pix + f * plane) = make_float2(gh0[f], gh1[f]);
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// K = 51 fast path, third generation: the horizontal pass on the matrix cores (exact fp32 MFMA).
+//
+// For 16 pixels of one output row (y, x0..x0+15) the horizontal pass is a small GEMM
+//     T[(c,fy), p] = sum_q  In[c][y+fy][x0+q] * Hb[q][p],      Hb[q][p] = h[q-p][y][x0+p]  (0 <= q-p < 51)
+// with M = 3*51 = 153 rows (c,fy), K = 16+50 = 66 input columns, N = 16 pixels: a banded ("Toeplitz
+// with per-pixel taps") B operand.  v_mfma_f32_16x16x4_f32 is bit-for-bit an fp32 fmaf chain at the
+// fp32 VALU rate, but it needs ONE ds_read_b32 per 1024 FMA instead of one LDS float per 1-4 FMA, which
+// is what bounds the VALU kernels above (LDS bandwidth, not FMA issue).  The band wastes 68/51 of the
+// MFMA work (170 MFMA = 32 cycles each per 16 pixels -> 340 cycles/pixel/SIMD vs 249 for ideal VALU).
+// The vertical pass  out[c,p] = sum_fy v[fy,p] * T[(c,fy),p]  runs on the accumulator registers.
+//
+// Workgroup = 4 waves = a 4-row x 64-column output tile; wave w owns columns 16w..16w+15 and walks the
+// 4 rows.  LDS: the 3 x 54 x 116 input window (pitch 130 == 2 mod 32: the A-fragment reads, 16 rows x
+// 2 k-columns per 32-lane group, hit 32 distinct banks) + double-buffered [51][64] h and v rows, which
+// are fetched from HBM one row ahead with fully coalesced 256-byte segments.
+// ------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// geometry of the MFMA kernels: 8 waves = 2 row lanes x 4 column groups of 16 pixels; MROWS output rows
+// per workgroup are processed in phases of 2 rows.
+constexpr int MC = 64, MLW = 130, MSPAN = 116, MHP = 64, MNT = 512, MROWS = 6;
+constexpr int MKP = 52;   // rows per channel in the M dimension (51 taps + 1 zero row): lanes never straddle channels
+
+// taps of two output rows: [2][K][64] floats, as float4 (x0 is a multiple of 64, Wo a multiple of 4)
+template <int K, int NREG>
+__device__ __forceinline__ void mfma_load_taps(f32x4 (&regs)[NREG], const float* __restrict__ src, size_t plane, int Ho,
+                                               int Wo, int y, int x0, int tid) {
+  constexpr int N4 = 2 * K * (MC / 4);
+#pragma unroll
+  for (int it = 0; it < NREG; ++it) {
+    const int i = min(tid + it * MNT, N4 - 1);
+    const int row = i / (K * 16), rem = i - row * (K * 16), tap = rem >> 4, c4 = rem & 15;
+    const int yy = min(y + row, Ho - 1);
+    const int xx = min(x0 + 4 * c4, Wo - 4);
+    regs[it] = *reinterpret_cast<const f32x4*>(src + (size_t)tap * plane + (size_t)yy * Wo + xx);
+  }
+}
+template <int K, int KROWS, int NREG>
+__device__ __forceinline__ void mfma_store_taps(float* __restrict__ dst, const f32x4 (&regs)[NREG], int tid) {
+  constexpr int N4 = 2 * K * (MC / 4);
+#pragma unroll
+  for (int it = 0; it < NREG; ++it) {
+    const int i = tid + it * MNT;
+    const int row = i / (K * 16), rem = i - row * (K * 16), tap = rem >> 4, c4 = rem & 15;
+    if (i < N4) *reinterpret_cast<f32x4*>(dst + (row * KROWS + tap) * MHP + 4 * c4) = regs[it];
+  }
+}
+
+template <int K>
+__global__ __launch_bounds__(MNT) void sepconv_fwd_mfma(const float* __restrict__ in, const float* __restrict__ v,
+                                                          const float* __restrict__ h, float* __restrict__ out,
+                                                          int Ho, int Wo) {
+  constexpr int C = 3, LH = MROWS + K - 1, LP = LH * MLW;
+  constexpr int M = C * MKP, MT = (M + 15) / 16, KT = (16 + K - 1 + 3) / 4;   // 156 rows -> 10 tiles; 17 k-steps
+  constexpr int NREG = (2 * K * 16 + MNT - 1) / MNT;                           // 4 float4 per thread per array
+  static_assert(K < MKP && MKP % 4 == 0 && MT % 2 == 0, "M layout");
+  static_assert(16 * 3 + 4 * KT <= MSPAN && MSPAN <= MLW && MROWS % 2 == 0, "window must cover every A column");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* inT = lds;                       // [C][LH][MLW]
+  float* hB = lds + C * LP;               // [2][K][MHP]
+  float* vB = hB + 2 * K * MHP;           // [2][MKP][MHP]  (row K of each is zero)
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wc = w & 3, wr = w >> 2;      // column group, row lane
+  const int j = lane & 15, ks = lane >> 4;
+  const int x0 = blockIdx.x * MC, y0 = blockIdx.y * MROWS, b = blockIdx.z;
+  const int Hi = Ho + K - 1, Wi = Wo + K - 1;
+  const size_t plane = (size_t)Ho * Wo;
+  const float* hsrc = h + (size_t)b * K * plane;
+  const float* vsrc = v + (size_t)b * K * plane;
+
+  f32x4 hreg[NREG], vreg[NREG];
+  mfma_load_taps<K, NREG>(hreg, hsrc, plane, Ho, Wo, y0, x0, tid);
+  mfma_load_taps<K, NREG>(vreg, vsrc, plane, Ho, Wo, y0, x0, tid);
+#pragma unroll
+  for (int c = 0; c < C; ++c)
+    stage_window<LH, MSPAN, MLW, MNT>(inT + c * LP, in + ((size_t)b * C + c) * Hi * Wi, y0, x0, Hi, Wi, tid);
+  if (tid < 2 * MHP) vB[((tid >> 6) * MKP + K) * MHP + (tid & 63)] = 0.f;     // the zero tap row
+  mfma_store_taps<K, K, NREG>(hB, hreg, tid);
+  mfma_store_taps<K, MKP, NREG>(vB, vreg, tid);
+
+  // per-lane A-row bases: M index mi = 16*m + j -> (c, fy) = (mi / 52, mi % 52); rows fy = 51 and mi >= 156
+  // are padding (their T rows meet the zero tap row / are never read) and clamp to valid LDS rows
+  int abase[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int mi = min(16 * m + j, M - 1);
+    const int c = mi / MKP, fy = min(mi - c * MKP, K - 1);
+    abase[m] = (c * LH + fy + wr) * MLW + 16 * wc + ks;
+  }
+  __syncthreads();
+
+#pragma unroll
+  for (int ph = 0; ph < MROWS / 2; ++ph) {
+    const int y = y0 + 2 * ph + wr;
+    if (ph + 1 < MROWS / 2) {   // next phase's taps: HBM -> registers while this phase computes
+      mfma_load_taps<K, NREG>(hreg, hsrc, plane, Ho, Wo, y0 + 2 * ph + 2, x0, tid);
+      mfma_load_taps<K, NREG>(vreg, vsrc, plane, Ho, Wo, y0 + 2 * ph + 2, x0, tid);
+    }
+    const float* hb = hB + wr * K * MHP + 16 * wc + j;
+    const float* vb = vB + wr * MKP * MHP + 16 * wc + j;
+
+    // banded B fragments: lane (k = ks, n = j) of k-step t holds Hb[4t+ks][j] = h[4t+ks-j] of pixel j
+    float bf[KT];
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+      const int tap = 4 * t + ks - j;
+      const float val = hb[min(max(tap, 0), K - 1) * MHP];
+      bf[t] = (tap >= 0 && tap < K) ? val : 0.f;
+    }
+
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+    const int rowoff = 2 * ph * MLW;
+#pragma unroll
+    for (int mp = 0; mp < MT / 2; ++mp) {
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      const float* a0p = inT + abase[2 * mp] + rowoff;
+      const float* a1p = inT + abase[2 * mp + 1] + rowoff;
+#pragma unroll
+      for (int t = 0; t < KT; ++t) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0p[4 * t], bf[t], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1p[4 * t], bf[t], acc1, 0, 0, 0);
+      }
+      // vertical pass on the accumulators: lane holds T rows 16*m + 4*ks + e (e = 0..3) of pixel j, all of
+      // one channel (52 = 4*13), at taps fy0..fy0+3 (tap 51 is the zero row)
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const f32x4 acc = half ? acc1 : acc0;
+        const int mi0 = 16 * (2 * mp + half) + 4 * ks;
+        const int c = (mi0 >= MKP) + (mi0 >= 2 * MKP);
+        const int fy0 = min(mi0 - c * MKP, MKP - 4);
+        const float* vp = vb + fy0 * MHP;
+        float sdot = vp[0] * acc[0];
+        sdot = fmaf(vp[MHP], acc[1], sdot);
+        sdot = fmaf(vp[2 * MHP], acc[2], sdot);
+        sdot = fmaf(vp[3 * MHP], acc[3], sdot);
+        sdot = (mi0 < M) ? sdot : 0.f;
+        o0 += (c == 0) ? sdot : 0.f;
+        o1 += (c == 1) ? sdot : 0.f;
+        o2 += (c == 2) ? sdot : 0.f;
+      }
+    }
+    // the 4 k-lanes of a pixel hold disjoint row subsets: fold them
+    o0 += __shfl_xor(o0, 16, 64); o0 += __shfl_xor(o0, 32, 64);
+    o1 += __shfl_xor(o1, 16, 64); o1 += __shfl_xor(o1, 32, 64);
+    o2 += __shfl_xor(o2, 16, 64); o2 += __shfl_xor(o2, 32, 64);
+    const int x = x0 + 16 * wc + j;
+    if (ks == 0 && x < Wo && y < Ho) {
+      float* o = out + (size_t)b * C * plane + (size_t)y * Wo + x;
+      o[0] = o0; o[plane] = o1; o[2 * plane] = o2;
+    }
+
+    if (ph + 1 < MROWS / 2) {
+      __syncthreads();                       // every wave is done with this phase's tap rows
+      mfma_store_taps<K, K, NREG>(hB, hreg, tid);
+      mfma_store_taps<K, MKP, NREG>(vB, vreg, tid);
+      __syncthreads();
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // generic direct kernels (any K, any C): one thread per output element, x fastest.
 // ------------------------------------------------------------------------------------------
@@ -209,6 +563,28 @@ __global__ void sepconv_bwd_input_direct(const float* __restrict__ v, const floa
   gI[(size_t)bc * Hi * Wi + (size_t)Y * Wi + X] = acc;
 }
 
+// The x2 kernels move float2 per lane: even width and 8-byte aligned planes.
+bool x2_ok(int Wo, const void* a, const void* b, const void* c, const void* d) {
+  return (Wo % 2 == 0) && ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d) & 7u) == 0);
+}
+
+// The MFMA kernels fetch tap rows as float4: width a multiple of 4 (>= 4) and 16-byte aligned planes.
+bool mfma_ok(int Wo, const void* a, const void* b) {
+  return (Wo % 4 == 0) && Wo >= 4 && ((((uintptr_t)a | (uintptr_t)b) & 15u) == 0);
+}
+
+hipError_t set_bwd_x2_lds(size_t lds) {
+  hipError_t e = hipFuncSetAttribute((const void*)sepconv_bwd_filters_x2<KFAST, true, true>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute((const void*)sepconv_bwd_filters_x2<KFAST, true, false>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute((const void*)sepconv_bwd_filters_x2<KFAST, false, true>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  return e;
+}
+
 int check_dims(int B, int C, int Ho, int Wo, int K) {
   if (B <= 0 || C <= 0 || Ho <= 0 || Wo <= 0 || K <= 0) return SAVFI_E_SHAPE;
   const int64_t Hi = (int64_t)Ho + K - 1, Wi = (int64_t)Wo + K - 1;
@@ -225,7 +601,17 @@ extern "C" int savfi_sepconv_fwd_f32(const float* in, const float* v, const floa
   if (!in || !v || !h || !out) return SAVFI_E_NULL;
   if (int e = check_dims(B, C, Ho, Wo, K)) return e;
   hipStream_t st = (hipStream_t)stream;
-  if (K == KFAST) {
+  if (K == KFAST && C == 3 && mfma_ok(Wo, v, h) && !getenv("SAVFI_SEPCONV_NO_MFMA")) {
+    constexpr size_t lds = ((size_t)3 * (MROWS + KFAST - 1) * MLW + (size_t)2 * (KFAST + MKP) * MHP) * sizeof(float);  // 140,080 B
+    static const hipError_t attr = hipFuncSetAttribute((const void*)sepconv_fwd_mfma<KFAST>,
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (attr != hipSuccess) return (int)attr;
+    dim3 grid(savfi_cdiv(Wo, MC), savfi_cdiv(Ho, MROWS), B);
+    hipLaunchKernelGGL(sepconv_fwd_mfma<KFAST>, grid, dim3(MNT), lds, st, in, v, h, out, Ho, Wo);
+  } else if (K == KFAST && x2_ok(Wo, in, v, h, out)) {
+    dim3 grid(savfi_cdiv(Wo, T2X), savfi_cdiv(Ho, T2Y), B);
+    hipLaunchKernelGGL(sepconv_fwd_x2<KFAST>, grid, dim3(NT), 0, st, in, v, h, out, C, Ho, Wo);
+  } else if (K == KFAST) {
     dim3 grid(savfi_cdiv(Wo, TX), savfi_cdiv(Ho, TY), B);
     hipLaunchKernelGGL(sepconv_fwd_tiled<KFAST>, grid, dim3(NT), 0, st, in, v, h, out, C, Ho, Wo);
   } else {
@@ -242,7 +628,19 @@ extern "C" int savfi_sepconv_bwd_f32(const float* in, const float* v, const floa
   if (int e = check_dims(B, C, Ho, Wo, K)) return e;
   hipStream_t st = (hipStream_t)stream;
   if (gV || gH) {
-    if (K == KFAST && C == 3) {
+    if (K == KFAST && C == 3 && x2_ok(Wo, gO, v, h, gV ? gV : gH) && x2_ok(Wo, gO, v, h, gH ? gH : gV)) {
+      constexpr size_t lds = (size_t)3 * (T2Y + KFAST - 1) * T2LW * sizeof(float);  // 76032 B: 2 workgroups / CU
+      static const hipError_t attr = set_bwd_x2_lds(lds);
+      if (attr != hipSuccess) return (int)attr;
+      dim3 grid(savfi_cdiv(Wo, T2X), savfi_cdiv(Ho, T2Y), B);
+      if (gV && gH)
+        hipLaunchKernelGGL((sepconv_bwd_filters_x2<KFAST, true, true>), grid, dim3(NT), lds, st, in, v, h, gO, gV, gH, Ho, Wo);
+      else if (gV)
+        hipLaunchKernelGGL((sepconv_bwd_filters_x2<KFAST, true, false>), grid, dim3(NT), lds, st, in, v, h, gO, gV, gH, Ho, Wo);
+      else
+        hipLaunchKernelGGL((sepconv_bwd_filters_x2<KFAST, false, true>), grid, dim3(NT), lds, st, in, v, h, gO, gV, gH, Ho, Wo);
+      if (int e = savfi_launch_status()) return e;
+    } else if (K == KFAST && C == 3) {
       constexpr int LP = (TY + KFAST - 1) * (TX + KFAST - 1);
       const size_t lds = (size_t)3 * LP * sizeof(float);
       dim3 grid(savfi_cdiv(Wo, TX), savfi_cdiv(Ho, TY), B);
