@@ -483,6 +483,156 @@ __global__ __launch_bounds__(MNT) void sepconv_fwd_mfma(const float* __restrict_
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Filter gradients on the matrix cores.  Same workgroup geometry, LDS window and tap-row pipeline as
+// sepconv_fwd_mfma; per 16-pixel tile two banded GEMMs share the staged input window:
+//
+//   gV[fy,p] = sum_{c,q} In[c][y+fy][x0+q] * (gO[c,p] * Hb[q][p])            M = fy (51 -> 64), K = 3*68
+//   D'[q,p]  = sum_{c,fy} In[c][y+fy][x0+q] * (gO[c,p] * v[fy,p])            M = q (66 -> 80),  K = 3*52
+//   gH[fx,p] = D'[p+fx, p]                                                   (the band of D')
+//
+// i.e. the upstream gradient is folded into the B operand, so the accumulators ARE the results (no
+// cross-lane reduction): 204 + 195 MFMA per tile.  gV rows leave as 64-byte runs per tap plane; the gH
+// band is stored element-wise (each lane owns a different tap plane: 16 stores of 4 B per instruction --
+// ~10 % of the MFMA time, and L2 merges the sectors before they reach HBM).
+// ------------------------------------------------------------------------------------------
+template <int K, bool WANT_V, bool WANT_H>
+__global__ __launch_bounds__(MNT) void sepconv_bwd_mfma(const float* __restrict__ in, const float* __restrict__ v,
+                                                       const float* __restrict__ h, const float* __restrict__ gO,
+                                                       float* __restrict__ gV, float* __restrict__ gH,
+                                                       int Ho, int Wo) {
+  constexpr int C = 3, LH = MROWS + K - 1, LP = LH * MLW;
+  constexpr int KT = (16 + K - 1 + 3) / 4;                 // 17 column steps of the banded H operand
+  constexpr int MTV = (K + 15) / 16;                       // 4 M-tiles of taps fy
+  constexpr int KTV = (K + 3) / 4;                         // 13 row steps (taps fy = 4t+ks; tap 51 is the zero row)
+  constexpr int MTH = (16 + K - 1 + 15) / 16;              // 5 M-tiles of window columns q
+  constexpr int NREG = (2 * K * 16 + MNT - 1) / MNT;
+  static_assert(4 * KTV == MKP && 16 * 3 + 16 * MTH <= MLW, "gH operand geometry");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* inT = lds;
+  float* hB = lds + C * LP;
+  float* vB = hB + 2 * K * MHP;
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wc = w & 3, wr = w >> 2;
+  const int j = lane & 15, ks = lane >> 4;
+  const int x0 = blockIdx.x * MC, y0 = blockIdx.y * MROWS, b = blockIdx.z;
+  const int Hi = Ho + K - 1, Wi = Wo + K - 1;
+  const size_t plane = (size_t)Ho * Wo;
+  const float* hsrc = h + (size_t)b * K * plane;
+  const float* vsrc = v + (size_t)b * K * plane;
+
+  f32x4 hreg[NREG], vreg[NREG];
+  mfma_load_taps<K, NREG>(hreg, hsrc, plane, Ho, Wo, y0, x0, tid);
+  mfma_load_taps<K, NREG>(vreg, vsrc, plane, Ho, Wo, y0, x0, tid);
+#pragma unroll
+  for (int c = 0; c < C; ++c)
+    stage_window<LH, MSPAN, MLW, MNT>(inT + c * LP, in + ((size_t)b * C + c) * Hi * Wi, y0, x0, Hi, Wi, tid);
+  // columns MSPAN..MLW-1 of the window are only read by gH rows q >= 66, which are discarded, but keep them finite
+  for (int i = tid; i < C * LH * (MLW - MSPAN); i += MNT) {
+    const int rr = i / (MLW - MSPAN), q = i - rr * (MLW - MSPAN);
+    inT[rr * MLW + MSPAN + q] = 0.f;
+  }
+  if (tid < 2 * MHP) vB[((tid >> 6) * MKP + K) * MHP + (tid & 63)] = 0.f;
+  mfma_store_taps<K, K, NREG>(hB, hreg, tid);
+  mfma_store_taps<K, MKP, NREG>(vB, vreg, tid);
+
+  // A-row bases.  gV: M index = tap fy = 16m + j (clamped), column = k.   gH: M index = window column q = 16m + j,
+  // k index = tap row 4t + ks (clamped to the last window row; that tap's B operand is the zero row).
+  int abV[MTV], abH[MTH];
+#pragma unroll
+  for (int m = 0; m < MTV; ++m) abV[m] = (min(16 * m + j, K - 1) + wr) * MLW + 16 * wc + ks;
+#pragma unroll
+  for (int m = 0; m < MTH; ++m) abH[m] = (wr + ks) * MLW + 16 * wc + 16 * m + j;
+  __syncthreads();
+
+#pragma unroll 1
+  for (int ph = 0; ph < MROWS / 2; ++ph) {
+    const int y = y0 + 2 * ph + wr;
+    const int x = x0 + 16 * wc + j;
+    const bool pvalid = (x < Wo) && (y < Ho);
+    const size_t opix = (size_t)min(y, Ho - 1) * Wo + min(x, Wo - 1);
+    if (ph + 1 < MROWS / 2) {
+      mfma_load_taps<K, NREG>(hreg, hsrc, plane, Ho, Wo, y0 + 2 * ph + 2, x0, tid);
+      mfma_load_taps<K, NREG>(vreg, vsrc, plane, Ho, Wo, y0 + 2 * ph + 2, x0, tid);
+    }
+    float g[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) g[c] = gO[((size_t)b * C + c) * plane + opix];
+    const float* hb = hB + wr * K * MHP + 16 * wc + j;
+    const float* vb = vB + wr * MKP * MHP + 16 * wc + j;
+    const int rowoff = 2 * ph * MLW;
+
+    if (WANT_V) {
+      float bf[KT];
+#pragma unroll
+      for (int t = 0; t < KT; ++t) {
+        const int tap = 4 * t + ks - j;
+        const float val = hb[min(max(tap, 0), K - 1) * MHP];
+        bf[t] = (tap >= 0 && tap < K) ? val : 0.f;
+      }
+      f32x4 acc[MTV];
+#pragma unroll
+      for (int m = 0; m < MTV; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+          const float bb = g[c] * bf[t];
+#pragma unroll
+          for (int m = 0; m < MTV; ++m)
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(inT[abV[m] + rowoff + c * LP + 4 * t], bb, acc[m], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < MTV; ++m) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int fy = 16 * m + 4 * ks + e;
+          if (pvalid && fy < K) gV[(size_t)b * K * plane + (size_t)fy * plane + opix] = acc[m][e];
+        }
+      }
+    }
+
+    if (WANT_H) {
+      float bv[KTV];
+#pragma unroll
+      for (int t = 0; t < KTV; ++t) bv[t] = vb[(4 * t + ks) * MHP];          // tap 51 reads the zero row
+      f32x4 acc[MTH];
+#pragma unroll
+      for (int m = 0; m < MTH; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+#pragma unroll
+        for (int t = 0; t < KTV; ++t) {
+          const float bb = g[c] * bv[t];
+          // window row of tap 4t+ks; the zero tap (51) would be one row past the window: step back one row
+          const int arow = (t == KTV - 1) ? ((ks == 3) ? (4 * t - 1) * MLW : 4 * t * MLW) : 4 * t * MLW;
+#pragma unroll
+          for (int m = 0; m < MTH; ++m)
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(inT[abH[m] + rowoff + c * LP + arow], bb, acc[m], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < MTH; ++m) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int fx = 16 * m + 4 * ks + e - j;
+          if (pvalid && fx >= 0 && fx < K) gH[(size_t)b * K * plane + (size_t)fx * plane + opix] = acc[m][e];
+        }
+      }
+    }
+
+    if (ph + 1 < MROWS / 2) {
+      __syncthreads();
+      mfma_store_taps<K, K, NREG>(hB, hreg, tid);
+      mfma_store_taps<K, MKP, NREG>(vB, vreg, tid);
+      __syncthreads();
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // generic direct kernels (any K, any C): one thread per output element, x fastest.
 // ------------------------------------------------------------------------------------------
@@ -573,6 +723,18 @@ bool mfma_ok(int Wo, const void* a, const void* b) {
   return (Wo % 4 == 0) && Wo >= 4 && ((((uintptr_t)a | (uintptr_t)b) & 15u) == 0);
 }
 
+hipError_t set_bwd_mfma_lds(size_t lds) {
+  hipError_t e = hipFuncSetAttribute((const void*)sepconv_bwd_mfma<KFAST, true, true>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute((const void*)sepconv_bwd_mfma<KFAST, true, false>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e == hipSuccess)
+    e = hipFuncSetAttribute((const void*)sepconv_bwd_mfma<KFAST, false, true>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  return e;
+}
+
 hipError_t set_bwd_x2_lds(size_t lds) {
   hipError_t e = hipFuncSetAttribute((const void*)sepconv_bwd_filters_x2<KFAST, true, true>,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -628,7 +790,19 @@ extern "C" int savfi_sepconv_bwd_f32(const float* in, const float* v, const floa
   if (int e = check_dims(B, C, Ho, Wo, K)) return e;
   hipStream_t st = (hipStream_t)stream;
   if (gV || gH) {
-    if (K == KFAST && C == 3 && x2_ok(Wo, gO, v, h, gV ? gV : gH) && x2_ok(Wo, gO, v, h, gH ? gH : gV)) {
+    if (K == KFAST && C == 3 && mfma_ok(Wo, v, h) && !getenv("SAVFI_SEPCONV_NO_MFMA")) {
+      constexpr size_t lds = ((size_t)3 * (MROWS + KFAST - 1) * MLW + (size_t)2 * (KFAST + MKP) * MHP) * sizeof(float);
+      static const hipError_t attr = set_bwd_mfma_lds(lds);
+      if (attr != hipSuccess) return (int)attr;
+      dim3 grid(savfi_cdiv(Wo, MC), savfi_cdiv(Ho, MROWS), B);
+      if (gV && gH)
+        hipLaunchKernelGGL((sepconv_bwd_mfma<KFAST, true, true>), grid, dim3(MNT), lds, st, in, v, h, gO, gV, gH, Ho, Wo);
+      else if (gV)
+        hipLaunchKernelGGL((sepconv_bwd_mfma<KFAST, true, false>), grid, dim3(MNT), lds, st, in, v, h, gO, gV, gH, Ho, Wo);
+      else
+        hipLaunchKernelGGL((sepconv_bwd_mfma<KFAST, false, true>), grid, dim3(MNT), lds, st, in, v, h, gO, gV, gH, Ho, Wo);
+      if (int e = savfi_launch_status()) return e;
+    } else if (K == KFAST && C == 3 && x2_ok(Wo, gO, v, h, gV ? gV : gH) && x2_ok(Wo, gO, v, h, gH ? gH : gV)) {
       constexpr size_t lds = (size_t)3 * (T2Y + KFAST - 1) * T2LW * sizeof(float);  // 76032 B: 2 workgroups / CU
       static const hipError_t attr = set_bwd_x2_lds(lds);
       if (attr != hipSuccess) return (int)attr;
