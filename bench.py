@@ -138,10 +138,20 @@ def main():
             k = summ.get("sepconv_bwd")
             if k:
                 ph, pw = net.padded_size(H, W)
+                traffic, tnote = None, "no committed PMC measurement found"
+                tpath = os.path.join(REPO, "profiles", "r01_hbm_traffic_sepconv.json")
+                if os.path.exists(tpath):
+                    # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+                    # (tools/hbm_traffic.py; FETCH_SIZE x2 per the gfx950 calibration), scaled to this run's
+                    # B=1 / B=2 launch mix through the measured traffic / algorithmic ratio of each shape
+                    tk = json.load(open(tpath))["kernels"]
+                    ratio = 0.5 * (tk["sepconv_bwd_B1"]["traffic_over_algorithmic"] + tk["sepconv_bwd_B2"]["traffic_over_algorithmic"])
+                    traffic = ratio * k["algorithmic_bytes"] / k["launches"]
+                    tnote = "PMC (FETCH_SIZE*2 + WRITE_SIZE) = %.3f x algorithmic, profiles/r01_hbm_traffic_sepconv.json" % ratio
                 line["roofline"] = {
-                    "bound": "hbm", "kernel": "sepconv_bwd_filters (gV+gH, K=51)",
+                    "bound": "hbm", "kernel": "sepconv_bwd_mfma (gV+gH, K=51)",
                     "achieved": k["achieved_GBps"], "peak": 8000.0, "unit": "GB/s",
-                    "frac": k["achieved_GBps"] / 8000.0, "traffic": None,
+                    "frac": k["achieved_GBps"] / 8000.0, "traffic": traffic, "traffic_source": tnote,
                     "avg_us_per_launch": k["avg_us"], "launches": k["launches"],
                     "algorithmic_bytes_per_launch": k["algorithmic_bytes"] / k["launches"],
                     "note": "algorithmic bytes = 165.72 MB per [1,3,%d,%d] call (x2 for the fused N=2 support "

@@ -98,7 +98,7 @@ def test_fused_support_pair_equals_two_single_passes(name):
     _, l0, p0, _, r0 = run_case(name, 'train', fuse=0)
     assert abs(l1['loss'].item() - l0['loss'].item()) <= (2e-4 if 'voxelflow' in name else 2e-5) * abs(l0['loss'].item())
     for a, b in zip(p1, p0):
-        assert (a - b).abs().mean().item() < 1e-5
+        assert (a - b).abs().mean().item() < (1e-4 if 'voxelflow' in name else 1e-5)
     for k in r0['outer_grad_fp']:
         assert_fp_close(r1['outer_grad_fp'][k], r0['outer_grad_fp'][k], 3e-2 if 'voxelflow' in name else 1e-3, k)
 

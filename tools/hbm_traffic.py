@@ -1,0 +1,86 @@
+"""Driver for the HBM-traffic PMC passes (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate runs).
+
+    python tools/hbm_traffic.py run            # the workload that is profiled (calibration copy + sepconv fwd/bwd)
+    python tools/hbm_traffic.py parse DIR_FETCH DIR_WRITE > profiles/rXX_hbm_traffic.json
+
+Calibration (MI355X_MICROARCH.md, HBM section): on gfx950 FETCH_SIZE reads exactly half the bytes of a wide
+coalesced stream and WRITE_SIZE is uncalibrated, so a 512 MiB float4 device copy of known size is profiled in
+the same pass and gives the per-counter correction factor that is applied to the sepconv kernels.
+"""
+import csv
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+CAL_BYTES = 512 * 1024 * 1024
+
+
+def run():
+    import torch
+    from meta_interpolation_amd import _hip
+    from meta_interpolation_amd.sepconv.sepconv_op.sepconv import algorithmic_bytes  # noqa: F401
+    lib, st = _hip.lib(), _hip.current_stream()
+    a = torch.empty(CAL_BYTES // 4, device='cuda').normal_()
+    bb = torch.empty_like(a)
+    for _ in range(3):
+        bb.copy_(a)
+    for B in (1, 2):
+        C, Ho, Wo, K = 3, 384, 512, 51
+        inp = torch.rand(B, C, Ho + K - 1, Wo + K - 1, device='cuda')
+        v = torch.randn(B, K, Ho, Wo, device='cuda') / 7
+        h = torch.randn(B, K, Ho, Wo, device='cuda') / 7
+        gO = torch.randn(B, C, Ho, Wo, device='cuda')
+        out, gV, gH = torch.empty_like(gO), torch.empty_like(v), torch.empty_like(h)
+        for _ in range(3):
+            lib.savfi_sepconv_fwd_f32(inp.data_ptr(), v.data_ptr(), h.data_ptr(), out.data_ptr(), B, C, Ho, Wo, K, st)
+            lib.savfi_sepconv_bwd_f32(inp.data_ptr(), v.data_ptr(), h.data_ptr(), gO.data_ptr(), None, gV.data_ptr(),
+                                      gH.data_ptr(), B, C, Ho, Wo, K, st)
+        torch.cuda.synchronize()
+
+
+def _collect(d, counter):
+    path = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith('counter_collection.csv')][0]
+    out = {}
+    for row in csv.DictReader(open(path)):
+        if row['Counter_Name'] != counter:
+            continue
+        name = row['Kernel_Name']
+        grid = row['Grid_Size']
+        key = ('copy' if 'elementwise' in name or 'copy' in name.lower() else
+               'sepconv_fwd' if 'sepconv_fwd' in name else 'sepconv_bwd' if 'sepconv_bwd' in name else None)
+        if key is None:
+            continue
+        out.setdefault((key, grid), []).append(float(row['Counter_Value']))
+    return {k: sum(v) / len(v) for k, v in out.items()}
+
+
+def parse(dfetch, dwrite):
+    from meta_interpolation_amd.sepconv.sepconv_op.sepconv import algorithmic_bytes
+    f, w = _collect(dfetch, 'FETCH_SIZE'), _collect(dwrite, 'WRITE_SIZE')
+    cal_f = [v for (k, g), v in f.items() if k == 'copy']
+    cal_w = [v for (k, g), v in w.items() if k == 'copy']
+    # counters are in KiB; correction = true bytes / reported bytes on the known copy
+    corr_f = CAL_BYTES / (max(cal_f) * 1024.0)
+    corr_w = CAL_BYTES / (max(cal_w) * 1024.0)
+    res = {"unit": "bytes per launch", "calibration": {"copy_bytes_each_way": CAL_BYTES, "FETCH_SIZE_KiB": max(cal_f),
+                                                       "WRITE_SIZE_KiB": max(cal_w), "fetch_correction": corr_f,
+                                                       "write_correction": corr_w}, "kernels": {}}
+    for (k, g), val in sorted(f.items()):
+        if k == 'copy':
+            continue
+        wv = w.get((k, g), 0.0)
+        B = 2 if int(g) >= 2 * 512 * 512 else 1
+        alg = algorithmic_bytes(B, 3, 384, 512, 51, grads=2 if k == 'sepconv_bwd' else 0)
+        rd, wr = val * 1024 * corr_f, wv * 1024 * corr_w
+        res["kernels"]["%s_B%d" % (k, B)] = {"grid": int(g), "FETCH_SIZE_KiB": val, "WRITE_SIZE_KiB": wv,
+                                             "hbm_read_bytes": rd, "hbm_write_bytes": wr, "traffic": rd + wr,
+                                             "algorithmic_bytes": alg, "traffic_over_algorithmic": (rd + wr) / alg}
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == '__main__':
+    if sys.argv[1] == 'run':
+        run()
+    else:
+        parse(sys.argv[2], sys.argv[3])
