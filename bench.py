@@ -36,6 +36,7 @@ WORKLOADS = {
     'c3_voxelflow_metasgd_256x256_b8_s5': ('voxelflow', 256, 256, 8, 5,
                                            dict(optimizer='Adamax', metasgd=True, loss='1*MSE', inner_lr=1e-5)),
     'c1_cain_64x64_b1_s1': ('cain', 64, 64, 1, 1, dict(optimizer='SGD', loss='1*L1', inner_lr=1e-5)),
+    'c5_cain_l2f_720p_b1_s1': ('cain', 720, 1280, 1, 1, dict(optimizer='SGD', loss='1*L1', inner_lr=1e-5, attenuate=True)),
 }
 
 def cpu_baseline(model, H, W, overrides):
@@ -90,6 +91,11 @@ def main():
     net = MODEL_REGISTRY[model](args, False)
     synthetic.load_seeded_weights(net, model)          # identical theta on every rank, no broadcast
     system = SceneAdaptiveInterpolation(args, net=net.to(dev))
+    if args.attenuate:   # L2F: non-trivial seeded attenuator (gamma_mult = 0 would make it a no-op)
+        sd, gm = synthetic.seeded_attenuator_state(len(system.inner_loop_optimizer.names_learning_rates_dict))
+        system.attenuator.load_state_dict(sd)
+        with torch.no_grad():
+            system.gamma_mult.copy_(gm)
     tp = system.task_parallel
 
     # the global meta-batch has tasks*world tasks; rank r adapts tasks {t : t mod world == r}.

@@ -18,6 +18,8 @@
  *   savfi_mt_mean_f32          per-tensor mean of grads (L2F embedding) meta_learning_system.py:249-253
  *   savfi_mt_scale_f32         gamma_i * w_i (L2F attenuation)        meta_learning_system.py:267-268
  *   savfi_l1_mse_f32           nn.L1Loss / nn.MSELoss                 loss.py:287-290
+ *   savfi_bias_act_fwd/bwd_f32 conv bias add + (Leaky)ReLU and their backward + bias gradient
+ *                                                                     sepconv/model.py:172-194, model_utils.py:957-990
  *
  * Conventions (all functions):
  *   - extern "C", return int: 0 = ok; >0 = hipError_t reported by the launch;
@@ -158,6 +160,17 @@ int savfi_mt_scale_bwd_f32(int n, const float* const* g_out, const float* const*
 int savfi_l1_mse_f32(int kind, const float* a, const float* b, float* result, int64_t n, void* stream);
 int savfi_l1_mse_bwd_f32(int kind, const float* a, const float* b, const float* g_loss, float* g_a,
                          int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Convolution epilogue: bias + activation, in place on the conv output z [N,C,H*W]:
+ *   z <- act(z + bias[c]),  act(x) = x > 0 ? x : slope*x   (slope 0 ReLU, 0.2 LeakyReLU, 1 bias only)
+ * bwd: gz = gy * act'(y) with y the forward OUTPUT (sign(y) == sign(z+b) for slope >= 0);
+ *      gbias[c] += sum over n, hw of gz (may be NULL; zero-filled by the caller; one atomic per workgroup).
+ *      gz may alias gy.
+ * ---------------------------------------------------------------------------------- */
+int savfi_bias_act_fwd_f32(float* z, const float* bias, int N, int C, int HW, float slope, void* stream);
+int savfi_bias_act_bwd_f32(const float* gy, const float* y, float* gz, float* gbias,
+                           int N, int C, int HW, float slope, void* stream);
 
 #ifdef __cplusplus
 }

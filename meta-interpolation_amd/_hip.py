@@ -49,6 +49,8 @@ _PROTOTYPES = {
     "savfi_mt_scale_bwd_f32": [c_int, _PP, _PP, _P, _PP, _P, _I64P, _P],
     "savfi_l1_mse_f32": [c_int, _P, _P, _P, c_int64, _P],
     "savfi_l1_mse_bwd_f32": [c_int, _P, _P, _P, _P, c_int64, _P],
+    "savfi_bias_act_fwd_f32": [_P, _P, c_int, c_int, c_int, c_float, _P],
+    "savfi_bias_act_bwd_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_float, _P],
 }
 
 _lib = None

@@ -272,3 +272,52 @@ def l1_loss(a, b):
 
 def mse_loss(a, b):
     return _L1Mse.apply(1, a.contiguous(), b.contiguous())
+
+
+# --------------------------------------------------------------------------------------------
+# conv + bias + (leaky) ReLU with fused epilogues   (sepconv/model.py:172-194, model_utils.py:957-990)
+# --------------------------------------------------------------------------------------------
+class _ConvBiasAct(torch.autograd.Function):
+    """y = act(conv2d(x, w) + b).  The convolution itself stays on MIOpen; the bias add and activation
+    run as ONE in-place kernel on its output, and the backward computes act' * gy and the bias gradient
+    in one pass before handing the result to MIOpen's data / weight gradient kernels.  First-order only
+    (the backward is not differentiable): callers use the unfused ops under --second_order."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, padding, dilation, groups, slope):
+        z = torch.nn.functional.conv2d(x, w, None, stride, padding, dilation, groups)
+        if not z.is_contiguous():
+            z = z.contiguous()
+        _hip.require_cuda(z, b)
+        N, C, H, W = z.shape
+        lib = _hip.lib()
+        _hip.launch("bias_act_fwd", lambda: _hip.check(lib.savfi_bias_act_fwd_f32(
+            z.data_ptr(), b.data_ptr(), N, C, H * W, slope, _hip.current_stream()), "savfi_bias_act_fwd_f32"))
+        ctx.conf = (stride, padding, dilation, groups, slope)
+        ctx.save_for_backward(x, w, z)
+        return z
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        stride, padding, dilation, groups, slope = ctx.conf
+        gy = gy.contiguous()
+        N, C, H, W = y.shape
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        gz = torch.empty_like(gy)
+        gb = torch.zeros(C, dtype=gy.dtype, device=gy.device) if need_b else None
+        lib = _hip.lib()
+        _hip.launch("bias_act_bwd", lambda: _hip.check(lib.savfi_bias_act_bwd_f32(
+            gy.data_ptr(), y.data_ptr(), gz.data_ptr(), None if gb is None else gb.data_ptr(), N, C, H * W, slope,
+            _hip.current_stream()), "savfi_bias_act_bwd_f32"))
+        gx = gw = None
+        if need_x or need_w:
+            pair = lambda v: [v, v] if isinstance(v, int) else list(v)
+            gx, gw, _ = torch.ops.aten.convolution_backward(gz, x, w, None, pair(stride), pair(padding), pair(dilation),
+                                                            False, [0, 0], groups, [need_x, need_w, False])
+        return gx, gw, gb, None, None, None, None, None
+
+
+def conv_bias_act(x, weight, bias, stride=1, padding=0, dilation=1, groups=1, slope=0.0):
+    """act(conv2d(x, weight) + bias) with act = LeakyReLU(slope) (0 -> ReLU, 1 -> identity)."""
+    return _ConvBiasAct.apply(x, weight, bias, stride, padding, dilation, groups, float(slope))

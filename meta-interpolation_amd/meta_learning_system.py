@@ -24,7 +24,7 @@ import torch
 import torch.nn as nn
 import torch.optim as optim
 
-from . import hip_ops, utils
+from . import hip_ops, model_utils, utils
 from .inner_loop_optimizers import LSLRGradientDescentLearningRule, MetaSGDLearningRule
 from .loss import Loss
 from .task_parallel import TaskParallel
@@ -291,6 +291,8 @@ class SceneAdaptiveInterpolation(nn.Module):
         Returns (losses, per_task_target_preds, metrics)."""
         frames = data_batch
         num_tasks = len(frames[0])
+        # fused conv epilogues: opt-in, and first-order only
+        model_utils.FUSE_CONV_ACT = bool(getattr(self.args, 'fuse_conv_act', 0)) and not use_second_order
         tp = self.task_parallel
         local = tp.local_tasks(num_tasks)
         msl = bool(use_multi_step_loss_optimization and training_phase

@@ -126,6 +126,23 @@ class PixelShuffle(nn.Module):
 # --------------------------------------------------------------------------------------------
 # Meta layers
 # --------------------------------------------------------------------------------------------
+# conv -> bias -> (Leaky)ReLU can run with fused epilogue kernels (hip_ops.conv_bias_act): it removes ~13 % of
+# the SepConv step's kernel time (bias add, clamp, threshold_backward, per-channel sum) but each fused call
+# goes through a Python autograd.Function + ctypes, and at 256x448 the inner loop is then host-bound
+# (measured 58.7 vs 62.3 inner steps/s, round 1) -- so it is opt-in (--fuse_conv_act 1) until the host side
+# is captured in a hipGraph.  The fused backward is first-order only (off under --second_order).
+FUSE_CONV_ACT = False
+
+
+def _act_slope(module):
+    """Negative slope if `module` is an activation the fused epilogue implements, else None."""
+    if isinstance(module, nn.ReLU):
+        return 0.0
+    if isinstance(module, nn.LeakyReLU):
+        return float(module.negative_slope)
+    return None
+
+
 class MetaConv2dLayer(nn.Module):
     """conv2d with internal (Xavier-uniform weight, zero bias) or external weights (reference :308-366)."""
 
@@ -138,14 +155,21 @@ class MetaConv2dLayer(nn.Module):
         nn.init.xavier_uniform_(self.weight)
         self.bias = nn.Parameter(torch.zeros(out_channels)) if use_bias else None
 
-    def forward(self, x, params=None):
+    def forward(self, x, params=None, act_slope=None):
+        """`act_slope` (set by MetaSequential when an activation follows) applies LeakyReLU(act_slope)."""
         if params is not None:
             pv = as_view(params)
             weight = pv.leaf("weight")
             bias = pv.leaf("bias") if self.use_bias else None
         else:
             weight, bias = self.weight, self.bias
-        return F.conv2d(x, weight, bias, self.stride, self.padding, self.dilation_rate, self.groups)
+        if act_slope is not None and bias is not None and x.is_cuda and FUSE_CONV_ACT:
+            return hip_ops.conv_bias_act(x, weight, bias, self.stride, self.padding, self.dilation_rate, self.groups,
+                                         act_slope)
+        out = F.conv2d(x, weight, bias, self.stride, self.padding, self.dilation_rate, self.groups)
+        if act_slope is not None:
+            out = F.relu(out) if act_slope == 0.0 else F.leaky_relu(out, act_slope)
+        return out
 
     def restore_backup_stats(self):
         pass
@@ -162,9 +186,9 @@ class MetaConvNorm(nn.Module):
                                     use_bias=True)
         self.norm = norm
 
-    def forward(self, x, params=None):
+    def forward(self, x, params=None, act_slope=None):
         pv = as_view(params)
-        return self.conv(self.reflection_pad(x), params=None if pv is None else pv.sub("conv"))
+        return self.conv(self.reflection_pad(x), params=None if pv is None else pv.sub("conv"), act_slope=act_slope)
 
 
 _META_TYPES = ()
@@ -178,11 +202,20 @@ class MetaSequential(nn.Sequential):
 
     def forward(self, input, params=None):
         pv = as_view(params)
-        for ind, module in enumerate(self):
+        mods = list(self)
+        ind = 0
+        while ind < len(mods):
+            module = mods[ind]
+            kw = {}
+            if isinstance(module, (MetaConv2dLayer, MetaConvNorm)) and ind + 1 < len(mods):
+                slope = _act_slope(mods[ind + 1])
+                if slope is not None:          # conv + activation pair: one fused call, skip the activation module
+                    kw["act_slope"] = slope
             if pv is not None and isinstance(module, _META_TYPES):
-                input = module(input, params=pv.sub(ind))
+                input = module(input, params=pv.sub(ind), **kw)
             else:
-                input = module(input)
+                input = module(input, **kw)
+            ind += 2 if kw else 1
         return input
 
     def restore_backup_stats(self):

@@ -176,3 +176,47 @@ def test_l1_mse_vs_torch(kind, shape):
     (out * 1.0).backward()
     assert abs(out.item() - ref.item()) < 1e-6 * max(1.0, abs(ref.item())) + 1e-7
     assert _rel(ad.grad.cpu(), ar.grad) < 1e-6
+
+
+@pytest.mark.parametrize("slope", [0.0, 0.2, 1.0])
+@pytest.mark.parametrize("shape,k,pad", [((2, 6, 37, 45), 3, 1), ((1, 64, 96, 128), 3, 1), ((1, 8, 16, 16), 5, 2), ((1, 3, 7, 9), 1, 0)])
+def test_conv_bias_act_matches_unfused_torch(slope, shape, k, pad):
+    """Fused conv epilogue (bias + LeakyReLU(slope) in place; act' * gy + bias gradient in one pass) against
+    F.conv2d + F.leaky_relu and autograd on the same device: identical conv kernels, so 1e-6."""
+    g = torch.Generator().manual_seed(int(slope * 10) + shape[1])
+    x = torch.randn(shape, generator=g).to(DEV).requires_grad_()
+    w = (torch.randn(shape[1] + 1, shape[1], k, k, generator=g) / (k * shape[1] ** 0.5)).to(DEV).requires_grad_()
+    b = torch.randn(shape[1] + 1, generator=g).to(DEV).requires_grad_()
+    go = torch.randn(shape[0], shape[1] + 1, shape[2], shape[3], generator=g).to(DEV)
+    ref = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(x, w, b, 1, pad), slope)
+    gx, gw, gb = torch.autograd.grad(ref, (x, w, b), go)
+    out = hip_ops.conv_bias_act(x, w, b, 1, pad, 1, 1, slope)
+    fx, fw, fb = torch.autograd.grad(out, (x, w, b), go)
+    assert _rel(out.detach(), ref.detach()) < 1e-6
+    assert _rel(fx, gx) < 1e-6 and _rel(fw, gw) < 1e-6 and _rel(fb, gb) < 1e-5
+
+
+def test_meta_sequential_fuses_conv_relu_pairs_and_matches_reference_modules():
+    from meta_interpolation_amd import model_utils as mu
+    torch.manual_seed(0)
+    seq = mu.MetaSequential(mu.MetaConv2dLayer(6, 8, 3, 1, 1), torch.nn.ReLU(), mu.MetaConv2dLayer(8, 5, 3, 1, 1),
+                            torch.nn.ReLU(), torch.nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True),
+                            mu.MetaConv2dLayer(5, 5, 3, 1, 1)).to(DEV)
+    x = torch.randn(2, 6, 20, 24, device=DEV)
+    fast = {n: torch.randn_like(p).mul(0.1).requires_grad_() for n, p in seq.named_parameters()}
+    calls = []
+    orig = hip_ops.conv_bias_act
+    hip_ops.conv_bias_act = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    mu.FUSE_CONV_ACT = True
+    try:
+        y = seq(x, params=fast)
+        gf = torch.autograd.grad(y.square().mean(), list(fast.values()))
+    finally:
+        hip_ops.conv_bias_act = orig
+        mu.FUSE_CONV_ACT = False
+    assert len(calls) == 2                                    # two conv+ReLU pairs fused, the last conv is plain
+    y0 = seq(x, params=fast)
+    g0 = torch.autograd.grad(y0.square().mean(), list(fast.values()))
+    assert _rel(y, y0) < 1e-6
+    for a, b in zip(gf, g0):
+        assert _rel(a, b) < 1e-5
