@@ -36,6 +36,8 @@ WORKLOADS = {
     'c3_voxelflow_metasgd_256x256_b8_s5': ('voxelflow', 256, 256, 8, 5,
                                            dict(optimizer='Adamax', metasgd=True, loss='1*MSE', inner_lr=1e-5)),
     'c1_cain_64x64_b1_s1': ('cain', 64, 64, 1, 1, dict(optimizer='SGD', loss='1*L1', inner_lr=1e-5)),
+    # same launch sequence as C2 on tiny frames: wall time ~= the host-side floor of one C2 meta-iteration
+    'c2_host_floor_64x64_b4_s5': ('sepconv', 64, 64, 4, 5, dict(optimizer='SGD', loss='1*L1', inner_lr=1e-5)),
     'c5_cain_l2f_720p_b1_s1': ('cain', 720, 1280, 1, 1, dict(optimizer='SGD', loss='1*L1', inner_lr=1e-5, attenuate=True)),
 }
 
@@ -72,6 +74,7 @@ def main():
     ap.add_argument('--workload', default='c2_sepconv_256x448_b4_s5', choices=sorted(WORKLOADS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timer', action='store_true')
+    ap.add_argument('--fuse-conv-act', type=int, default=0)
     opt = ap.parse_args()
 
     from meta_interpolation_amd import _hip, synthetic, task_parallel
@@ -87,7 +90,8 @@ def main():
 
     model, H, W, tasks, S, over = WORKLOADS[opt.workload]
     args = default_args(model=model, num_gpu=1, batch_size=tasks * world,
-                        number_of_training_steps_per_iter=S, number_of_evaluation_steps_per_iter=S, **over)
+                        number_of_training_steps_per_iter=S, number_of_evaluation_steps_per_iter=S,
+                        fuse_conv_act=opt.fuse_conv_act, **over)
     net = MODEL_REGISTRY[model](args, False)
     synthetic.load_seeded_weights(net, model)          # identical theta on every rank, no broadcast
     system = SceneAdaptiveInterpolation(args, net=net.to(dev))

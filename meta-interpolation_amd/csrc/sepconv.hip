@@ -342,7 +342,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // geometry of the MFMA kernels: 8 waves = 2 row lanes x 4 column groups of 16 pixels; MROWS output rows
 // per workgroup are processed in phases of 2 rows.
-constexpr int MC = 64, MLW = 130, MSPAN = 116, MHP = 64, MNT = 512, MROWS = 6;
+constexpr int MC = 64, MLW = 130, MSPAN = 116, MHP = 64, MNT = 512, MROWS = 12;
 constexpr int MKP = 52;   // rows per channel in the M dimension (51 taps + 1 zero row): lanes never straddle channels
 
 // taps of two output rows: [2][K][64] floats, as float4 (x0 is a multiple of 64, Wo a multiple of 4)
