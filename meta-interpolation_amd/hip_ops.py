@@ -4,8 +4,15 @@ Every function here launches a hand-written gfx950 kernel through the C ABI (inc
 on torch's current stream.  Device tensors only -- there is no CPU or eager-PyTorch fallback.
 """
 import torch
+from torch.autograd.function import once_differentiable
 
 from . import _hip
+
+# Set by the meta system for the duration of a forward with --second_order: ops whose hand-written backward
+# is not itself differentiable switch to composed device ops (losses) or refuse (voxel warp) instead of
+# silently dropping second-order terms.  (The sepconv op does drop them, exactly like the reference:
+# SURVEY.md section 0, fact 9.)
+DOUBLE_BACKWARD = False
 
 
 # --------------------------------------------------------------------------------------------
@@ -26,6 +33,7 @@ class _VoxelWarp(torch.autograd.Function):
         return out
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, gO):
         frames, x3 = ctx.saved_tensors
         B, _, H, W = frames.shape
@@ -74,8 +82,9 @@ class _PixelShuffle(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        # the permutation's adjoint is its inverse
-        return _launch_shuffle(g.contiguous(), ctx.r, not ctx.down), None, None
+        # the permutation's adjoint is its inverse; applied through the Function so that it stays
+        # differentiable (second-order MAML through CAIN)
+        return _PixelShuffle.apply(g, ctx.r, not ctx.down), None, None
 
 
 def pixel_shuffle(input, scale_factor):
@@ -254,6 +263,7 @@ class _L1Mse(torch.autograd.Function):
         return res
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g):
         a, b = ctx.saved_tensors
         g = g.contiguous()
@@ -267,10 +277,14 @@ class _L1Mse(torch.autograd.Function):
 
 
 def l1_loss(a, b):
+    if DOUBLE_BACKWARD:
+        return torch.nn.functional.l1_loss(a, b)
     return _L1Mse.apply(0, a.contiguous(), b.contiguous())
 
 
 def mse_loss(a, b):
+    if DOUBLE_BACKWARD:
+        return torch.nn.functional.mse_loss(a, b)
     return _L1Mse.apply(1, a.contiguous(), b.contiguous())
 
 

@@ -291,6 +291,7 @@ class SceneAdaptiveInterpolation(nn.Module):
         Returns (losses, per_task_target_preds, metrics)."""
         frames = data_batch
         num_tasks = len(frames[0])
+        hip_ops.DOUBLE_BACKWARD = bool(use_second_order)
         # fused conv epilogues: opt-in, and first-order only
         model_utils.FUSE_CONV_ACT = bool(getattr(self.args, 'fuse_conv_act', 0)) and not use_second_order
         tp = self.task_parallel

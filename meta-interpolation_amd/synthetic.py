@@ -12,8 +12,8 @@ import numpy as np
 import torch
 
 # Xavier-uniform bound multiplier per plugin: keeps un-normalised random nets at O(1) outputs
-# (raw Xavier makes CAIN's 127-conv stack blow up to L1 ~ 20).
-_GAIN = {'sepconv': 1.0, 'cain': 0.5, 'voxelflow': 1.0}
+# (raw Xavier makes CAIN's 127-conv stack blow up to L1 ~ 20; SepConv's separable taps need 1.2x to leave ~0).
+_GAIN = {'sepconv': 1.2, 'cain': 0.5, 'voxelflow': 1.0}
 
 
 def _stream(seed, name):

@@ -101,7 +101,8 @@ def build_reference_system(args, model, seed=12345):
     try:
         # two-pass: build once with an empty checkpoint to learn the net's state_dict, then reload seeded
         os.makedirs(os.path.join("checkpoint", args.exp_name), exist_ok=True)
-        torch.save({'epoch': 0, 'state_dict': {}}, os.path.join("checkpoint", args.exp_name, "checkpoint.pth"))
+        for fname in ("checkpoint.pth", "model_best.pth"):      # val/test modes resume from model_best.pth (utils.py:37-40)
+            torch.save({'epoch': 0, 'state_dict': {}}, os.path.join("checkpoint", args.exp_name, fname))
         system = ref_mls.SceneAdaptiveInterpolation(args)
         sd = synthetic.seeded_state_dict(system.net, model, seed)
         system.net.load_state_dict(sd)
@@ -213,6 +214,21 @@ def run_system_case(name):
     np.savez_compressed(os.path.join(GOLD, 'system_%s.npz' % name), **out)
 
 
+def run_test_mode_case():
+    """run_test_iter (meta_learning_system.py:630-697): adapt on a 4-frame clip, interpolate between frames 1 and 2."""
+    out = {}
+    for model, over in (('sepconv', dict(optimizer='SGD', inner_lr=1e-3, loss='1*L1', number_of_evaluation_steps_per_iter=2)),
+                        ('cain', dict(optimizer='SGD', inner_lr=1e-3, loss='1*L1', number_of_evaluation_steps_per_iter=1))):
+        args = reference_args(model=model, batch_size=1, mode='test', **over)
+        system = build_reference_system(args, model)
+        frames = synthetic.septuplet_batch(2, 64, 64, model=model, frames=4)
+        preds = system.run_test_iter(data_batch=[f.clone() for f in frames])
+        out[model + '_preds'] = torch.stack(preds).numpy()
+        out[model + '_args'] = np.array(repr(sorted(over.items())))
+        print('  test-mode %s: %s mean %.6f' % (model, tuple(out[model + '_preds'].shape), out[model + '_preds'].mean()))
+    np.savez_compressed(os.path.join(GOLD, 'test_mode.npz'), **out)
+
+
 def run_rule_cases():
     """Each reference rule x optimizer for tau = 1..3 on seeded tensors (one tensor gets a None grad from
     step 2 on, like SepConv's subnets)."""
@@ -316,13 +332,15 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
     install_shims()
-    todo = opts.only or (['rules', 'ops'] + list(SYSTEM_CASES))
+    todo = opts.only or (['rules', 'ops', 'test_mode'] + list(SYSTEM_CASES))
     for item in todo:
         print('[golden]', item, flush=True)
         if item == 'rules':
             run_rule_cases()
         elif item == 'ops':
             run_op_cases()
+        elif item == 'test_mode':
+            run_test_mode_case()
         else:
             run_system_case(item)
 

@@ -113,3 +113,28 @@ def psnr(pred01, gt01):
     q = lambda x: x.mul(255).clamp(0, 255).round()
     diff = (q(pred01) - q(gt01)).div(255)
     return -10 * math.log10(diff.pow(2).mean() + 1e-8)
+
+
+def run_test_iteration(model, base, frames, *, rule='lslr', optimizer='SGD', lrs, num_steps, loss='L1',
+                       forward_kwargs=None):
+    """run_test_iter, meta_learning_system.py:630-697: per clip of 4 frames, adapt on (0,2)->1 and (1,3)->2
+    (:653), then interpolate between frames 1 and 2 with the adapted weights (:680-684)."""
+    fwd = models.FORWARD[model]
+    kw = forward_kwargs or {}
+    crit = criterion(loss)
+    names = inner_param_names([(n, p) for n, p in base.items() if p.is_floating_point()], False)
+    support = [[0, 1, 2], [1, 2, 3]]
+    preds = []
+    for t in range(frames[0].shape[0]):
+        fast = {n: base[n] for n in names}
+        st = rules.RuleState()
+        for step in range(num_steps):
+            sl = 0
+            for ind in support:
+                sl = sl + crit(fwd(frames[ind[0]][t][None], frames[ind[2]][t][None], base, fast, **kw),
+                               frames[ind[1]][t][None])
+            g = torch.autograd.grad(sl, list(fast.values()), create_graph=False, allow_unused=True)
+            fast = rules.update_params(rule, optimizer, fast, dict(zip(fast.keys(), g)), lrs, step, st)
+        with torch.no_grad():
+            preds.append(fwd(frames[1][t][None], frames[2][t][None], base, fast, **kw).squeeze(0))
+    return preds

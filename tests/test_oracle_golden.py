@@ -175,3 +175,20 @@ def test_oracle_iteration_matches_reference(name, phase):
             full = 'inner_loop_optimizer.names_learning_rates_dict.' + k
             if lr.requires_grad and lr.grad is not None and full in rows:
                 assert_fp_close(fp(lr.grad), rows[full], 2e-4, (name, 'outer-lr', k))
+
+
+@pytest.mark.parametrize("model", ["sepconv", "cain"])
+def test_oracle_test_mode_matches_reference(model):
+    """run_test_iter on 4-frame clips (adapt on (0,2)->1, (1,3)->2; interpolate 1,2)."""
+    g = golden("test_mode")
+    a = dict(eval(str(g[model + '_args'])))
+    base = oracle_base(model)
+    frames = synthetic.septuplet_batch(2, 64, 64, model=model, frames=4)
+    names_w = {n: base[n] for n in meta.inner_param_names([(n, p) for n, p in base.items() if p.is_floating_point()])}
+    S = a['number_of_evaluation_steps_per_iter']
+    lrs = rules.init_lrs('lslr', names_w, a['inner_lr'], num_steps=1)     # table sized by the TRAINING steps (default 1)
+    if S > 1:   # the reference indexes lr[key][num_step] with num_step < eval steps: needs a table of >= S entries
+        lrs = rules.init_lrs('lslr', names_w, a['inner_lr'], num_steps=S)
+    preds = meta.run_test_iteration(model, base, frames, rule='lslr', optimizer=a['optimizer'], lrs=lrs, num_steps=S,
+                                    loss=a['loss'].split('*')[1])
+    assert np.abs(torch.stack(preds).numpy() - g[model + '_preds']).mean() < 1e-5

@@ -33,16 +33,16 @@ SYSTEM = ['c1_cain_lslr_sgd', 'cain_l2f', 'cain_lslr_adam_1step', 'sepconv_lslr_
 # step-0 quantities and the in-loop "fused rule == oracle rule on identical inputs" check; the end-of-
 # iteration quantities get the looser, measured bounds below.
 SMOOTH = dict(loss=5e-5, l1=1e-4, psnr=1e-3, ssim=1e-4, w=1e-5, g=1e-3, outer=1e-3)
-SIGNLIKE = dict(loss=5e-5, l1=1e-4, psnr=1e-3, ssim=1e-4, w=1e-4, g=1e-3, outer=2e-2)
+SIGNLIKE = dict(loss=5e-5, l1=1e-4, psnr=1e-3, ssim=1e-4, w=5e-4, g=2e-3, outer=5e-2)
 # VoxelFlow turns the tanh map into a displacement of up to +-W/4 pixels: a 1e-6 conv rounding difference
 # moves the sample point by ~3e-5 px on a noise-like texture, i.e. the forward pass at theta already differs
 # by 1.3e-5 (max) between MIOpen and the CPU.  The north-star gates (1e-4 pixel L1, 1e-3 dB) still hold for
 # the smooth rule; the relative loss / outer-gradient bounds are wider than for SepConv / CAIN.
 VOXEL = dict(loss=2e-4, l1=1e-4, psnr=1e-3, ssim=1e-4, w=1e-5, g=2e-3, outer=3e-2)
-CHAOTIC = dict(loss=5e-3, l1=1e-2, psnr=5e-2, ssim=5e-3, w=1e-4, g=5e-2, outer=2e-1)
+CHAOTIC = dict(loss=5e-3, l1=1e-2, psnr=5e-2, ssim=5e-3, w=2e-3, g=5e-2, outer=2e-1)
 TOL = {name: SMOOTH for name in SYSTEM}
 TOL.update(cain_lslr_adam_1step=SIGNLIKE, sepconv_metasgd_adamax_2step=SIGNLIKE,
-           voxelflow_lslr_sgd_2step=VOXEL, voxelflow_script_metasgd_adam_1step=dict(VOXEL, w=1e-4),
+           voxelflow_lslr_sgd_2step=VOXEL, voxelflow_script_metasgd_adam_1step=dict(VOXEL, w=5e-4),
            voxelflow_metasgd_adamax_2step=CHAOTIC)
 
 
@@ -200,3 +200,44 @@ def test_product_path_uses_the_hip_library_and_fails_loudly_without_it(monkeypat
     monkeypatch.setattr(_hip, "LIB_PATH", "/nonexistent/libsavfi_hip.so")
     with pytest.raises(_hip.SavfiHipError):
         hip_ops.l1_loss(torch.zeros(4, device=DEV), torch.zeros(4, device=DEV))
+
+
+@pytest.mark.parametrize("model", ["sepconv", "cain"])
+def test_run_test_iter_matches_reference_fixture(model):
+    """--mode test: adapt on a 4-frame clip and interpolate between frames 1 and 2 (reference run_test_iter)."""
+    g = golden("test_mode")
+    over = dict(eval(str(g[model + '_args'])))
+    over.setdefault('number_of_training_steps_per_iter', over['number_of_evaluation_steps_per_iter'])
+    system = build_system(model, dict(over, mode='test'))
+    frames = synthetic.septuplet_batch(2, 64, 64, model=model, frames=4)
+    preds = system.run_test_iter(data_batch=frames)
+    assert len(preds) == 2 and preds[0].shape == (3, 64, 64)
+    assert np.abs(torch.stack(preds).cpu().numpy() - g[model + '_preds']).mean() < 1e-4
+
+
+def test_second_order_cain_matches_oracle():
+    """--second_order (create_graph=True): the update goes through composed device ops, pixel shuffle stays
+    differentiable, the loss uses composed ops -- outer gradients must equal the oracle's second-order run."""
+    from oracle import meta as ometa
+    from tests.helpers import oracle_base
+    over = dict(optimizer='SGD', inner_lr=1e-2, loss='1*MSE', number_of_training_steps_per_iter=2,
+                number_of_evaluation_steps_per_iter=2, second_order=True, first_order_to_second_order_epoch=-1)
+    system = build_system('cain', over)
+    rec = observe(system)
+    frames = synthetic.septuplet_batch(1, 64, 64, model='cain')
+    losses, _, _ = system.run_train_iter(data_batch=frames, epoch=0, do_evaluation=False)
+    base = oracle_base('cain')
+    names_w = {n: base[n] for n in ometa.inner_param_names([(n, p) for n, p in base.items() if p.is_floating_point()])}
+    lrs = orules.init_lrs('lslr', names_w, 1e-2, num_steps=2)
+    torch.set_num_threads(16)
+    res = ometa.run_iteration('cain', base, frames, rule='lslr', optimizer='SGD', lrs=lrs, num_steps=2, loss='MSE',
+                              training=True, second_order=True)
+    res['loss'].backward()
+    assert abs(losses['loss'].item() - res['loss'].item()) <= 5e-5 * abs(res['loss'].item())
+    checked = 0
+    for n, p in base.items():
+        key = 'net.' + n
+        if p.requires_grad and p.grad is not None and key in rec['outer_grad_fp']:
+            assert_fp_close(rec['outer_grad_fp'][key], fp(p.grad), 2e-3, ('second-order', n))
+            checked += 1
+    assert checked == 494
