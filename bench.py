@@ -114,7 +114,7 @@ def main():
         one_iter(i)
     timer = None
     if not opt.no_kernel_timer and model == 'sepconv':
-        timer = _hip.KernelTimer()
+        timer = _hip.KernelTimer(only='sepconv')   # HIP events around the custom sepconv launches only
         _hip.TIMER = timer
     tp.barrier()
     torch.cuda.synchronize()

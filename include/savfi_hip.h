@@ -18,6 +18,7 @@
  *   savfi_mt_mean_f32          per-tensor mean of grads (L2F embedding) meta_learning_system.py:249-253
  *   savfi_mt_scale_f32         gamma_i * w_i (L2F attenuation)        meta_learning_system.py:267-268
  *   savfi_l1_mse_f32           nn.L1Loss / nn.MSELoss                 loss.py:287-290
+ *   savfi_upsample2x_fwd/bwd_f32  bilinear x2 up-sampling                 sepconv/model.py:191,213-234; voxel_flow.py:400-414
  *   savfi_bias_act_fwd/bwd_f32 conv bias add + (Leaky)ReLU and their backward + bias gradient
  *                                                                     sepconv/model.py:172-194, model_utils.py:957-990
  *
@@ -171,6 +172,15 @@ int savfi_l1_mse_bwd_f32(int kind, const float* a, const float* b, const float* 
 int savfi_bias_act_fwd_f32(float* z, const float* bias, int N, int C, int HW, float slope, void* stream);
 int savfi_bias_act_bwd_f32(const float* gy, const float* y, float* gz, float* gbias,
                            int N, int C, int HW, float slope, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Bilinear x2 up-sampling of `planes` = N*C maps [H,W] -> [2H,2W] with ATen's source-index rules
+ * (align_corners 1: torch.nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True),
+ *  sepconv/model.py:191,213-234;  0: F.interpolate(scale_factor=2, align_corners=False), voxel_flow.py:400-414).
+ * bwd is the exact adjoint, computed as a gather (gin fully overwritten, deterministic).
+ * ---------------------------------------------------------------------------------- */
+int savfi_upsample2x_fwd_f32(const float* in, float* out, int planes, int H, int W, int align_corners, void* stream);
+int savfi_upsample2x_bwd_f32(const float* gout, float* gin, int planes, int H, int W, int align_corners, void* stream);
 
 #ifdef __cplusplus
 }

@@ -49,6 +49,8 @@ _PROTOTYPES = {
     "savfi_mt_scale_bwd_f32": [c_int, _PP, _PP, _P, _PP, _P, _I64P, _P],
     "savfi_l1_mse_f32": [c_int, _P, _P, _P, c_int64, _P],
     "savfi_l1_mse_bwd_f32": [c_int, _P, _P, _P, _P, c_int64, _P],
+    "savfi_upsample2x_fwd_f32": [_P, _P, c_int, c_int, c_int, c_int, _P],
+    "savfi_upsample2x_bwd_f32": [_P, _P, c_int, c_int, c_int, c_int, _P],
     "savfi_bias_act_fwd_f32": [_P, _P, c_int, c_int, c_int, c_float, _P],
     "savfi_bias_act_bwd_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_float, _P],
 }
@@ -141,8 +143,9 @@ class KernelTimer:
     Nothing is synchronised until `summary()` is called.
     """
 
-    def __init__(self):
+    def __init__(self, only=None):
         self.records = {}
+        self.only = only          # time only launches whose name starts with this prefix (None = all)
 
     def launch(self, name, fn, nbytes=0):
         import torch
@@ -171,7 +174,7 @@ TIMER = None  # set to a KernelTimer instance to time launches
 
 def launch(name, fn, nbytes=0):
     """Run one C-ABI launch; `nbytes` = its algorithmic HBM bytes (each operand once), for the timer."""
-    if TIMER is None:
+    if TIMER is None or (TIMER.only is not None and not name.startswith(TIMER.only)):
         fn()
     else:
         TIMER.launch(name, fn, nbytes)

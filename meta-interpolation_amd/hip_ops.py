@@ -335,3 +335,65 @@ class _ConvBiasAct(torch.autograd.Function):
 def conv_bias_act(x, weight, bias, stride=1, padding=0, dilation=1, groups=1, slope=0.0):
     """act(conv2d(x, weight) + bias) with act = LeakyReLU(slope) (0 -> ReLU, 1 -> identity)."""
     return _ConvBiasAct.apply(x, weight, bias, stride, padding, dilation, groups, float(slope))
+
+
+# --------------------------------------------------------------------------------------------
+# Bilinear x2 up-sampling      (sepconv/model.py:191, :213-234; voxel_flow.py:400-414)
+# --------------------------------------------------------------------------------------------
+class _Upsample2x(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, align_corners):
+        _hip.require_cuda(x)
+        N, C, H, W = x.shape
+        out = torch.empty((N, C, 2 * H, 2 * W), dtype=x.dtype, device=x.device)
+        lib = _hip.lib()
+        _hip.launch("upsample2x_fwd", lambda: _hip.check(lib.savfi_upsample2x_fwd_f32(
+            x.data_ptr(), out.data_ptr(), N * C, H, W, int(align_corners), _hip.current_stream()),
+            "savfi_upsample2x_fwd_f32"), nbytes=4 * 5 * N * C * H * W)
+        ctx.align, ctx.shape = bool(align_corners), (N, C, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        # linear op: its adjoint goes through the Function too, so double-backward keeps working
+        return _Upsample2xAdjoint.apply(g, ctx.align), None
+
+
+class _Upsample2xAdjoint(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, g, align_corners):
+        g = g.contiguous()
+        _hip.require_cuda(g)
+        N, C, Ho, Wo = g.shape
+        gin = torch.empty((N, C, Ho // 2, Wo // 2), dtype=g.dtype, device=g.device)
+        lib = _hip.lib()
+        _hip.launch("upsample2x_bwd", lambda: _hip.check(lib.savfi_upsample2x_bwd_f32(
+            g.data_ptr(), gin.data_ptr(), N * C, Ho // 2, Wo // 2, int(align_corners), _hip.current_stream()),
+            "savfi_upsample2x_bwd_f32"), nbytes=4 * 5 * N * C * (Ho // 2) * (Wo // 2))
+        ctx.align = bool(align_corners)
+        return gin
+
+    @staticmethod
+    def backward(ctx, gg):
+        return _Upsample2x.apply(gg.contiguous(), ctx.align), None
+
+
+def upsample_bilinear2x(x, align_corners):
+    """[N,C,H,W] -> [N,C,2H,2W], bilinear, ATen-identical source indices."""
+    return _Upsample2x.apply(x.contiguous(), bool(align_corners))
+
+
+class Upsample2x(torch.nn.Module):
+    """Parameter-free stand-in for torch.nn.Upsample(scale_factor=2, mode='bilinear', align_corners=...)."""
+
+    def __init__(self, align_corners=True):
+        super().__init__()
+        self.align_corners = align_corners
+
+    def forward(self, x):
+        if not x.is_cuda:    # CPU tensors (host-logic tests): the plain ATen op
+            return torch.nn.functional.interpolate(x, scale_factor=2, mode='bilinear', align_corners=self.align_corners)
+        return upsample_bilinear2x(x, self.align_corners)
+
+    def extra_repr(self):
+        return 'scale_factor=2, mode=bilinear, align_corners=%s' % self.align_corners

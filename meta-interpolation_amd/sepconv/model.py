@@ -14,6 +14,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ..hip_ops import Upsample2x
 from ..model_utils import MetaConv2dLayer, MetaSequential, as_view, zero_grad_params
 from .sepconv_op.sepconv import FunctionSepconv
 
@@ -32,15 +33,14 @@ def _basic(cin, cout):
 
 
 def _upsample(ch):
-    return MetaSequential(nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True),
-                          _conv(ch, ch), nn.ReLU(inplace=False))
+    return MetaSequential(Upsample2x(align_corners=True), _conv(ch, ch), nn.ReLU(inplace=False))
 
 
 def _subnet():
     return MetaSequential(_conv(64, 64), nn.ReLU(inplace=False),
                           _conv(64, 64), nn.ReLU(inplace=False),
                           _conv(64, FILTER_TAPS), nn.ReLU(inplace=False),
-                          nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True),
+                          Upsample2x(align_corners=True),
                           _conv(FILTER_TAPS, FILTER_TAPS))
 
 

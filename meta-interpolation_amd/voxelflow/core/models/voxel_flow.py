@@ -97,7 +97,7 @@ class MetaVoxelFlow(nn.Module):
         c2 = self._block("conv2", self.pool(c1), pv)
         c3 = self._block("conv3", self.pool(c2), pv)
         y = self._block("bottleneck", self.pool(c3), pv)
-        up = lambda t: F.interpolate(t, scale_factor=2, mode='bilinear', align_corners=False)
+        up = lambda t: hip_ops.upsample_bilinear2x(t, align_corners=False)
         y = self._block("deconv1", torch.cat([up(y), c3], dim=1), pv)
         y = self._block("deconv2", torch.cat([up(y), c2], dim=1), pv)
         y = self._block("deconv3", torch.cat([up(y), c1], dim=1), pv)

@@ -220,3 +220,21 @@ def test_meta_sequential_fuses_conv_relu_pairs_and_matches_reference_modules():
     assert _rel(y, y0) < 1e-6
     for a, b in zip(gf, g0):
         assert _rel(a, b) < 1e-5
+
+
+@pytest.mark.parametrize("align", [True, False])
+@pytest.mark.parametrize("shape", [(1, 51, 192, 256), (2, 7, 5, 9), (1, 3, 1, 1), (1, 64, 12, 16), (2, 4, 33, 17)])
+def test_upsample2x_matches_aten(align, shape):
+    """Bilinear x2 forward and adjoint against F.interpolate + autograd on the device (same index rules)."""
+    g = torch.Generator().manual_seed(shape[2] * 7 + shape[3])
+    x = torch.randn(shape, generator=g).to(DEV).requires_grad_()
+    ref = torch.nn.functional.interpolate(x, scale_factor=2, mode='bilinear', align_corners=align)
+    go = torch.randn(ref.shape, generator=g).to(DEV)
+    gref, = torch.autograd.grad(ref, x, go)
+    out = hip_ops.upsample_bilinear2x(x, align)
+    gx, = torch.autograd.grad(out, x, go)
+    assert (out - ref).abs().max().item() <= 2e-6 * max(1.0, ref.abs().max().item())
+    assert _rel(gx, gref) < 1e-5
+    # and against the CPU result (pins the index arithmetic independently of the device ATen kernel)
+    cpu = torch.nn.functional.interpolate(x.detach().cpu(), scale_factor=2, mode='bilinear', align_corners=align)
+    assert (out.detach().cpu() - cpu).abs().max().item() <= 2e-6 * max(1.0, cpu.abs().max().item())
