@@ -334,39 +334,35 @@ __global__ __launch_bounds__(NT) void sepconv_bwd_filters_x2(const float* __rest
 // The vertical pass  out[c,p] = sum_fy v[fy,p] * T[(c,fy),p]  runs on the accumulator registers.
 //
 // Workgroup = 4 waves = a 4-row x 64-column output tile; wave w owns columns 16w..16w+15 and walks the
-// 4 rows.  LDS: the 3 x 54 x 116 input window (pitch 130 == 2 mod 32: the A-fragment reads, 16 rows x
-// 2 k-columns per 32-lane group, hit 32 distinct banks) + double-buffered [51][64] h and v rows, which
+// 4 rows.  LDS: the 3 x 54 x 116 input window (pitch 132: 16-byte aligned A fragments) + double-buffered [51][64] h and v rows, which
 // are fetched from HBM one row ahead with fully coalesced 256-byte segments.
 // ------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // geometry of the MFMA kernels: 8 waves = 2 row lanes x 4 column groups of 16 pixels; MROWS output rows
 // per workgroup are processed in phases of 2 rows.
-constexpr int MC = 64, MLW = 130, MSPAN = 116, MHP = 64, MNT = 512, MROWS = 12;
+constexpr int MC = 64, MLW = 132, MSPAN = 116, MHP = 64, MNT = 512, MROWS = 12;
 constexpr int MKP = 52;   // rows per channel in the M dimension (51 taps + 1 zero row): lanes never straddle channels
 
-// taps of two output rows: [2][K][64] floats, as float4 (x0 is a multiple of 64, Wo a multiple of 4)
+// Tap rows are PRIVATE to a wave: wave (wr, wc) needs h / v of its own 16 pixels only ([K][16] floats = 64-byte
+// runs per tap plane).  Keeping them private removes every workgroup barrier from the row loop, so the two waves
+// that share a SIMD drift out of phase and one's VALU / LDS / store phases hide under the other's MFMAs.
+// lane = (tap group tg = lane >> 4, column j = lane & 15); NREG = ceil(K / 4) dwords per lane.
 template <int K, int NREG>
-__device__ __forceinline__ void mfma_load_taps(f32x4 (&regs)[NREG], const float* __restrict__ src, size_t plane, int Ho,
-                                               int Wo, int y, int x0, int tid) {
-  constexpr int N4 = 2 * K * (MC / 4);
+__device__ __forceinline__ void mfma_load_taps(float (&regs)[NREG], const float* __restrict__ src, size_t plane,
+                                               int Ho, int Wo, int y, int xw, int lane) {
+  const int yy = min(y, Ho - 1), xx = min(xw + (lane & 15), Wo - 1);
+  const float* p = src + (size_t)yy * Wo + xx;
 #pragma unroll
-  for (int it = 0; it < NREG; ++it) {
-    const int i = min(tid + it * MNT, N4 - 1);
-    const int row = i / (K * 16), rem = i - row * (K * 16), tap = rem >> 4, c4 = rem & 15;
-    const int yy = min(y + row, Ho - 1);
-    const int xx = min(x0 + 4 * c4, Wo - 4);
-    regs[it] = *reinterpret_cast<const f32x4*>(src + (size_t)tap * plane + (size_t)yy * Wo + xx);
-  }
+  for (int it = 0; it < NREG; ++it) regs[it] = p[(size_t)min(4 * it + (lane >> 4), K - 1) * plane];
 }
-template <int K, int KROWS, int NREG>
-__device__ __forceinline__ void mfma_store_taps(float* __restrict__ dst, const f32x4 (&regs)[NREG], int tid) {
-  constexpr int N4 = 2 * K * (MC / 4);
+template <int K, int NREG>
+__device__ __forceinline__ void mfma_store_taps(float* __restrict__ dst /* [>=K][16] */, const float (&regs)[NREG],
+                                                int lane) {
 #pragma unroll
   for (int it = 0; it < NREG; ++it) {
-    const int i = tid + it * MNT;
-    const int row = i / (K * 16), rem = i - row * (K * 16), tap = rem >> 4, c4 = rem & 15;
-    if (i < N4) *reinterpret_cast<f32x4*>(dst + (row * KROWS + tap) * MHP + 4 * c4) = regs[it];
+    const int tap = 4 * it + (lane >> 4);
+    if (tap < K) dst[tap * 16 + (lane & 15)] = regs[it];
   }
 }
 
@@ -376,13 +372,13 @@ __global__ __launch_bounds__(MNT) void sepconv_fwd_mfma(const float* __restrict_
                                                           int Ho, int Wo) {
   constexpr int C = 3, LH = MROWS + K - 1, LP = LH * MLW;
   constexpr int M = C * MKP, MT = (M + 15) / 16, KT = (16 + K - 1 + 3) / 4;   // 156 rows -> 10 tiles; 17 k-steps
-  constexpr int NREG = (2 * K * 16 + MNT - 1) / MNT;                           // 4 float4 per thread per array
+  constexpr int NREG = (K + 3) / 4;                                            // 13 dwords per lane per tap array
   static_assert(K < MKP && MKP % 4 == 0 && MT % 2 == 0, "M layout");
-  static_assert(16 * 3 + 4 * KT <= MSPAN && MSPAN <= MLW && MROWS % 2 == 0, "window must cover every A column");
+  static_assert(KT == 17 && 16 * 3 + 4 * KT <= MSPAN && MSPAN <= MLW && MLW % 4 == 0 && MROWS % 2 == 0, "A fragment layout");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* inT = lds;                       // [C][LH][MLW]
-  float* hB = lds + C * LP;               // [2][K][MHP]
-  float* vB = hB + 2 * K * MHP;           // [2][MKP][MHP]  (row K of each is zero)
+  float* hB = lds + C * LP + (threadIdx.x >> 6) * (K + MKP) * 16;   // this wave's [K][16] h taps ...
+  float* vB = hB + K * 16;                                  // ... and [MKP][16] v taps (row K is zero)
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wc = w & 3, wr = w >> 2;      // column group, row lane
@@ -393,15 +389,15 @@ __global__ __launch_bounds__(MNT) void sepconv_fwd_mfma(const float* __restrict_
   const float* hsrc = h + (size_t)b * K * plane;
   const float* vsrc = v + (size_t)b * K * plane;
 
-  f32x4 hreg[NREG], vreg[NREG];
-  mfma_load_taps<K, NREG>(hreg, hsrc, plane, Ho, Wo, y0, x0, tid);
-  mfma_load_taps<K, NREG>(vreg, vsrc, plane, Ho, Wo, y0, x0, tid);
+  float hreg[NREG], vreg[NREG];
+  mfma_load_taps<K, NREG>(hreg, hsrc, plane, Ho, Wo, y0 + wr, x0 + 16 * wc, lane);
+  mfma_load_taps<K, NREG>(vreg, vsrc, plane, Ho, Wo, y0 + wr, x0 + 16 * wc, lane);
 #pragma unroll
   for (int c = 0; c < C; ++c)
     stage_window<LH, MSPAN, MLW, MNT>(inT + c * LP, in + ((size_t)b * C + c) * Hi * Wi, y0, x0, Hi, Wi, tid);
-  if (tid < 2 * MHP) vB[((tid >> 6) * MKP + K) * MHP + (tid & 63)] = 0.f;     // the zero tap row
-  mfma_store_taps<K, K, NREG>(hB, hreg, tid);
-  mfma_store_taps<K, MKP, NREG>(vB, vreg, tid);
+  if (lane < 16) vB[K * 16 + lane] = 0.f;                                       // the zero tap row
+  mfma_store_taps<K, NREG>(hB, hreg, lane);
+  mfma_store_taps<K, NREG>(vB, vreg, lane);
 
   // per-lane A-row bases: M index mi = 16*m + j -> (c, fy) = (mi / 52, mi % 52); rows fy = 51 and mi >= 156
   // are padding (their T rows meet the zero tap row / are never read) and clamp to valid LDS rows
@@ -410,26 +406,30 @@ __global__ __launch_bounds__(MNT) void sepconv_fwd_mfma(const float* __restrict_
   for (int m = 0; m < MT; ++m) {
     const int mi = min(16 * m + j, M - 1);
     const int c = mi / MKP, fy = min(mi - c * MKP, K - 1);
-    abase[m] = (c * LH + fy + wr) * MLW + 16 * wc + ks;
+    abase[m] = (c * LH + fy + wr) * MLW + 16 * wc + 4 * ks;
   }
   __syncthreads();
 
 #pragma unroll
   for (int ph = 0; ph < MROWS / 2; ++ph) {
     const int y = y0 + 2 * ph + wr;
-    if (ph + 1 < MROWS / 2) {   // next phase's taps: HBM -> registers while this phase computes
-      mfma_load_taps<K, NREG>(hreg, hsrc, plane, Ho, Wo, y0 + 2 * ph + 2, x0, tid);
-      mfma_load_taps<K, NREG>(vreg, vsrc, plane, Ho, Wo, y0 + 2 * ph + 2, x0, tid);
+    if (ph + 1 < MROWS / 2) {   // next row's taps: HBM -> registers while this row computes
+      mfma_load_taps<K, NREG>(hreg, hsrc, plane, Ho, Wo, y + 2, x0 + 16 * wc, lane);
+      mfma_load_taps<K, NREG>(vreg, vsrc, plane, Ho, Wo, y + 2, x0 + 16 * wc, lane);
     }
-    const float* hb = hB + wr * K * MHP + 16 * wc + j;
-    const float* vb = vB + wr * MKP * MHP + 16 * wc + j;
+    const float* hb = hB + j;
+    const float* vb = vB + j;
 
-    // banded B fragments: lane (k = ks, n = j) of k-step t holds Hb[4t+ks][j] = h[4t+ks-j] of pixel j
+    // The order in which window columns q are assigned to the MFMA k-slots is free as long as A and B agree.
+    // Slot (step s, lane group ks) takes column q = 16*(s/4) + 4*ks + s%4 for s < 16 and q = 64 + ks for s = 16, so
+    // that a lane's 16 A values of an M-tile are four aligned 16-byte LDS reads (+ one dword) instead of 17 dwords:
+    // the LDS read instructions, not their latency, were what held the MFMA pipe at 50 %.
     float bf[KT];
 #pragma unroll
     for (int t = 0; t < KT; ++t) {
-      const int tap = 4 * t + ks - j;
-      const float val = hb[min(max(tap, 0), K - 1) * MHP];
+      const int q = (t < 16) ? (16 * (t >> 2) + 4 * ks + (t & 3)) : (64 + ks);
+      const int tap = q - j;
+      const float val = hb[min(max(tap, 0), K - 1) * 16];
       bf[t] = (tap >= 0 && tap < K) ? val : 0.f;
     }
 
@@ -440,11 +440,20 @@ __global__ __launch_bounds__(MNT) void sepconv_fwd_mfma(const float* __restrict_
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
       const float* a0p = inT + abase[2 * mp] + rowoff;
       const float* a1p = inT + abase[2 * mp + 1] + rowoff;
+      f32x4 a0[4], a1[4];
 #pragma unroll
-      for (int t = 0; t < KT; ++t) {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0p[4 * t], bf[t], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1p[4 * t], bf[t], acc1, 0, 0, 0);
+      for (int u = 0; u < 4; ++u) {
+        a0[u] = *reinterpret_cast<const f32x4*>(a0p + 16 * u);
+        a1[u] = *reinterpret_cast<const f32x4*>(a1p + 16 * u);
       }
+      const float a0t = a0p[64 - 3 * ks], a1t = a1p[64 - 3 * ks];      // column 64 + ks (the base holds + 4*ks)
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[t >> 2][t & 3], bf[t], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[t >> 2][t & 3], bf[t], acc1, 0, 0, 0);
+      }
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0t, bf[16], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1t, bf[16], acc1, 0, 0, 0);
       // vertical pass on the accumulators: lane holds T rows 16*m + 4*ks + e (e = 0..3) of pixel j, all of
       // one channel (52 = 4*13), at taps fy0..fy0+3 (tap 51 is the zero row)
 #pragma unroll
@@ -453,11 +462,11 @@ __global__ __launch_bounds__(MNT) void sepconv_fwd_mfma(const float* __restrict_
         const int mi0 = 16 * (2 * mp + half) + 4 * ks;
         const int c = (mi0 >= MKP) + (mi0 >= 2 * MKP);
         const int fy0 = min(mi0 - c * MKP, MKP - 4);
-        const float* vp = vb + fy0 * MHP;
+        const float* vp = vb + fy0 * 16;
         float sdot = vp[0] * acc[0];
-        sdot = fmaf(vp[MHP], acc[1], sdot);
-        sdot = fmaf(vp[2 * MHP], acc[2], sdot);
-        sdot = fmaf(vp[3 * MHP], acc[3], sdot);
+        sdot = fmaf(vp[16], acc[1], sdot);
+        sdot = fmaf(vp[32], acc[2], sdot);
+        sdot = fmaf(vp[48], acc[3], sdot);
         sdot = (mi0 < M) ? sdot : 0.f;
         o0 += (c == 0) ? sdot : 0.f;
         o1 += (c == 1) ? sdot : 0.f;
@@ -475,10 +484,11 @@ __global__ __launch_bounds__(MNT) void sepconv_fwd_mfma(const float* __restrict_
     }
 
     if (ph + 1 < MROWS / 2) {
-      __syncthreads();                       // every wave is done with this phase's tap rows
-      mfma_store_taps<K, K, NREG>(hB, hreg, tid);
-      mfma_store_taps<K, MKP, NREG>(vB, vreg, tid);
-      __syncthreads();
+      // wave-private buffers: the LDS queue of a wave is in order, so no workgroup barrier is needed
+      __builtin_amdgcn_wave_barrier();
+      mfma_store_taps<K, NREG>(hB, hreg, lane);
+      mfma_store_taps<K, NREG>(vB, vreg, lane);
+      __builtin_amdgcn_wave_barrier();
     }
   }
 }
@@ -507,12 +517,12 @@ __global__ __launch_bounds__(MNT) void sepconv_bwd_mfma(const float* __restrict_
   constexpr int MTV = (K + 15) / 16;                       // 4 M-tiles of taps fy
   constexpr int KTV = (K + 3) / 4;                         // 13 row steps (taps fy = 4t+ks; tap 51 is the zero row)
   constexpr int MTH = (16 + K - 1 + 15) / 16;              // 5 M-tiles of window columns q
-  constexpr int NREG = (2 * K * 16 + MNT - 1) / MNT;
-  static_assert(4 * KTV == MKP && 16 * 3 + 16 * MTH <= MLW, "gH operand geometry");
+  constexpr int NREG = (K + 3) / 4;
+  static_assert(KT == 17 && MLW % 4 == 0 && 4 * KTV == MKP && 16 * 3 + 16 * MTH <= MLW, "operand geometry");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* inT = lds;
-  float* hB = lds + C * LP;
-  float* vB = hB + 2 * K * MHP;
+  float* hB = lds + C * LP + (threadIdx.x >> 6) * (K + MKP) * 16;   // wave-private tap rows (see the forward kernel)
+  float* vB = hB + K * 16;
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wc = w & 3, wr = w >> 2;
@@ -523,9 +533,9 @@ __global__ __launch_bounds__(MNT) void sepconv_bwd_mfma(const float* __restrict_
   const float* hsrc = h + (size_t)b * K * plane;
   const float* vsrc = v + (size_t)b * K * plane;
 
-  f32x4 hreg[NREG], vreg[NREG];
-  mfma_load_taps<K, NREG>(hreg, hsrc, plane, Ho, Wo, y0, x0, tid);
-  mfma_load_taps<K, NREG>(vreg, vsrc, plane, Ho, Wo, y0, x0, tid);
+  float hreg[NREG], vreg[NREG];
+  mfma_load_taps<K, NREG>(hreg, hsrc, plane, Ho, Wo, y0 + wr, x0 + 16 * wc, lane);
+  mfma_load_taps<K, NREG>(vreg, vsrc, plane, Ho, Wo, y0 + wr, x0 + 16 * wc, lane);
 #pragma unroll
   for (int c = 0; c < C; ++c)
     stage_window<LH, MSPAN, MLW, MNT>(inT + c * LP, in + ((size_t)b * C + c) * Hi * Wi, y0, x0, Hi, Wi, tid);
@@ -534,15 +544,15 @@ __global__ __launch_bounds__(MNT) void sepconv_bwd_mfma(const float* __restrict_
     const int rr = i / (MLW - MSPAN), q = i - rr * (MLW - MSPAN);
     inT[rr * MLW + MSPAN + q] = 0.f;
   }
-  if (tid < 2 * MHP) vB[((tid >> 6) * MKP + K) * MHP + (tid & 63)] = 0.f;
-  mfma_store_taps<K, K, NREG>(hB, hreg, tid);
-  mfma_store_taps<K, MKP, NREG>(vB, vreg, tid);
+  if (lane < 16) vB[K * 16 + lane] = 0.f;
+  mfma_store_taps<K, NREG>(hB, hreg, lane);
+  mfma_store_taps<K, NREG>(vB, vreg, lane);
 
   // A-row bases.  gV: M index = tap fy = 16m + j (clamped), column = k.   gH: M index = window column q = 16m + j,
   // k index = tap row 4t + ks (clamped to the last window row; that tap's B operand is the zero row).
   int abV[MTV], abH[MTH];
 #pragma unroll
-  for (int m = 0; m < MTV; ++m) abV[m] = (min(16 * m + j, K - 1) + wr) * MLW + 16 * wc + ks;
+  for (int m = 0; m < MTV; ++m) abV[m] = (min(16 * m + j, K - 1) + wr) * MLW + 16 * wc + 4 * ks;   // b128 k-slot order
 #pragma unroll
   for (int m = 0; m < MTH; ++m) abH[m] = (wr + ks) * MLW + 16 * wc + 16 * m + j;
   __syncthreads();
@@ -554,22 +564,23 @@ __global__ __launch_bounds__(MNT) void sepconv_bwd_mfma(const float* __restrict_
     const bool pvalid = (x < Wo) && (y < Ho);
     const size_t opix = (size_t)min(y, Ho - 1) * Wo + min(x, Wo - 1);
     if (ph + 1 < MROWS / 2) {
-      mfma_load_taps<K, NREG>(hreg, hsrc, plane, Ho, Wo, y0 + 2 * ph + 2, x0, tid);
-      mfma_load_taps<K, NREG>(vreg, vsrc, plane, Ho, Wo, y0 + 2 * ph + 2, x0, tid);
+      mfma_load_taps<K, NREG>(hreg, hsrc, plane, Ho, Wo, y + 2, x0 + 16 * wc, lane);
+      mfma_load_taps<K, NREG>(vreg, vsrc, plane, Ho, Wo, y + 2, x0 + 16 * wc, lane);
     }
     float g[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) g[c] = gO[((size_t)b * C + c) * plane + opix];
-    const float* hb = hB + wr * K * MHP + 16 * wc + j;
-    const float* vb = vB + wr * MKP * MHP + 16 * wc + j;
+    const float* hb = hB + j;
+    const float* vb = vB + j;
     const int rowoff = 2 * ph * MLW;
 
     if (WANT_V) {
-      float bf[KT];
+      float bf[KT];      // same k-slot order as the forward kernel: q = 16*(t/4) + 4*ks + t%4, last step q = 64 + ks
 #pragma unroll
       for (int t = 0; t < KT; ++t) {
-        const int tap = 4 * t + ks - j;
-        const float val = hb[min(max(tap, 0), K - 1) * MHP];
+        const int q = (t < 16) ? (16 * (t >> 2) + 4 * ks + (t & 3)) : (64 + ks);
+        const int tap = q - j;
+        const float val = hb[min(max(tap, 0), K - 1) * 16];
         bf[t] = (tap >= 0 && tap < K) ? val : 0.f;
       }
       f32x4 acc[MTV];
@@ -577,12 +588,21 @@ __global__ __launch_bounds__(MNT) void sepconv_bwd_mfma(const float* __restrict_
       for (int m = 0; m < MTV; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int c = 0; c < C; ++c) {
+        f32x4 av[MTV][4];
+        float at[MTV];
+#pragma unroll
+        for (int m = 0; m < MTV; ++m) {
+          const float* ap = inT + abV[m] + rowoff + c * LP;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) av[m][u] = *reinterpret_cast<const f32x4*>(ap + 16 * u);
+          at[m] = ap[64 - 3 * ks];
+        }
 #pragma unroll
         for (int t = 0; t < KT; ++t) {
           const float bb = g[c] * bf[t];
 #pragma unroll
           for (int m = 0; m < MTV; ++m)
-            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(inT[abV[m] + rowoff + c * LP + 4 * t], bb, acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(t < 16 ? av[m][t >> 2][t & 3] : at[m], bb, acc[m], 0, 0, 0);
         }
       }
 #pragma unroll
@@ -598,7 +618,7 @@ __global__ __launch_bounds__(MNT) void sepconv_bwd_mfma(const float* __restrict_
     if (WANT_H) {
       float bv[KTV];
 #pragma unroll
-      for (int t = 0; t < KTV; ++t) bv[t] = vb[(4 * t + ks) * MHP];          // tap 51 reads the zero row
+      for (int t = 0; t < KTV; ++t) bv[t] = vb[(4 * t + ks) * 16];           // tap 51 reads the zero row
       f32x4 acc[MTH];
 #pragma unroll
       for (int m = 0; m < MTH; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -625,10 +645,10 @@ __global__ __launch_bounds__(MNT) void sepconv_bwd_mfma(const float* __restrict_
     }
 
     if (ph + 1 < MROWS / 2) {
-      __syncthreads();
-      mfma_store_taps<K, K, NREG>(hB, hreg, tid);
-      mfma_store_taps<K, MKP, NREG>(vB, vreg, tid);
-      __syncthreads();
+      __builtin_amdgcn_wave_barrier();
+      mfma_store_taps<K, NREG>(hB, hreg, lane);
+      mfma_store_taps<K, NREG>(vB, vreg, lane);
+      __builtin_amdgcn_wave_barrier();
     }
   }
 }
@@ -718,9 +738,10 @@ bool x2_ok(int Wo, const void* a, const void* b, const void* c, const void* d) {
   return (Wo % 2 == 0) && ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d) & 7u) == 0);
 }
 
-// The MFMA kernels fetch tap rows as float4: width a multiple of 4 (>= 4) and 16-byte aligned planes.
+// The MFMA kernels take any width / alignment (dword tap loads, clamped coordinates).
 bool mfma_ok(int Wo, const void* a, const void* b) {
-  return (Wo % 4 == 0) && Wo >= 4 && ((((uintptr_t)a | (uintptr_t)b) & 15u) == 0);
+  (void)a; (void)b;
+  return Wo >= 1;
 }
 
 hipError_t set_bwd_mfma_lds(size_t lds) {
@@ -764,7 +785,7 @@ extern "C" int savfi_sepconv_fwd_f32(const float* in, const float* v, const floa
   if (int e = check_dims(B, C, Ho, Wo, K)) return e;
   hipStream_t st = (hipStream_t)stream;
   if (K == KFAST && C == 3 && mfma_ok(Wo, v, h) && !getenv("SAVFI_SEPCONV_NO_MFMA")) {
-    constexpr size_t lds = ((size_t)3 * (MROWS + KFAST - 1) * MLW + (size_t)2 * (KFAST + MKP) * MHP) * sizeof(float);  // 140,080 B
+    constexpr size_t lds = ((size_t)3 * (MROWS + KFAST - 1) * MLW + (size_t)(MNT / 64) * (KFAST + MKP) * 16) * sizeof(float);  // 150,944 B
     static const hipError_t attr = hipFuncSetAttribute((const void*)sepconv_fwd_mfma<KFAST>,
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (attr != hipSuccess) return (int)attr;
@@ -791,7 +812,7 @@ extern "C" int savfi_sepconv_bwd_f32(const float* in, const float* v, const floa
   hipStream_t st = (hipStream_t)stream;
   if (gV || gH) {
     if (K == KFAST && C == 3 && mfma_ok(Wo, v, h) && !getenv("SAVFI_SEPCONV_NO_MFMA")) {
-      constexpr size_t lds = ((size_t)3 * (MROWS + KFAST - 1) * MLW + (size_t)2 * (KFAST + MKP) * MHP) * sizeof(float);
+      constexpr size_t lds = ((size_t)3 * (MROWS + KFAST - 1) * MLW + (size_t)(MNT / 64) * (KFAST + MKP) * 16) * sizeof(float);
       static const hipError_t attr = set_bwd_mfma_lds(lds);
       if (attr != hipSuccess) return (int)attr;
       dim3 grid(savfi_cdiv(Wo, MC), savfi_cdiv(Ho, MROWS), B);
