@@ -5,6 +5,7 @@ config.py:14-77 so that its launch scripts (scripts/run_*.sh) keep working.  ``g
 Additions for the MI355X build (all optional, all default to the reference behaviour):
   --fuse_support_pairs {0,1}   run the two support triplets of an inner step as one N=2 forward
   --fuse_conv_act {0,1}        conv+bias+(Leaky)ReLU with fused epilogue kernels (opt-in, first-order only)
+  --graph_inner_loop {0,1}     replay the first-order inner loop from captured hipGraphs (graph_inner_loop.py)
   --synthetic                  feed seeded synthetic septuplets instead of reading a dataset
 """
 import argparse
@@ -38,7 +39,8 @@ _FLAGS = {
         ('use_tensorboard', 'flag', False), ('viz', 'flag', False), ('lpips', 'flag', False),
     ],
     'MI355X': [
-        ('fuse_support_pairs', int, 1), ('fuse_conv_act', int, 0), ('synthetic', 'flag', False),
+        ('fuse_support_pairs', int, 1), ('fuse_conv_act', int, 0), ('graph_inner_loop', int, 0),
+        ('synthetic', 'flag', False),
     ],
 }
 

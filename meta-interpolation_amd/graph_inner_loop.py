@@ -1,0 +1,256 @@
+"""hipGraph-captured first-order inner loop.
+
+In eager mode one inner step of SepConv at 256x448 issues ~600 kernel launches from Python (forward,
+autograd, fused update); the host needs ~8 ms for them, and for the low-resolution / many-layer
+configurations (CAIN: ~8k launches per iteration) the GPU simply waits for the host.  First-order MAML
+makes the whole step capturable:
+
+    support step t :  W_t  --[ N=2 support forward, loss, autograd.grad, fused update ]-->  W_{t+1}   (one hipGraph)
+    target pass    :  W_S  --[ forward, loss, grads w.r.t. W_S and the non-routed theta ]-->  G_S      (one hipGraph)
+
+and, because d W_{t+1} / d W_t = I when the gradients are constants, the outer gradient needs NO autograd
+graph across steps:   dL/d theta_k = sum_s w_s G_s,k   (routed tensors; identity chain W_S -> ... -> W_0 = theta),
+dL/d lr_t = < sum_{s>t} w_s G_s , dir_t >   with dir_t = d W_{t+1} / d lr_t (= -g_t for SGD, the kernel's `coef` else).
+Every graph replays on static buffers: step graph t reads the tensors graph t-1 wrote.  All graphs share one
+memory pool (they never run concurrently).  The numerics are those of the eager path (same kernels, same order).
+
+Not captured (the caller falls back to the eager loop): --second_order, --attenuate (L2F), CPU tensors.
+"""
+import torch
+
+from . import _hip, hip_ops, utils
+
+
+def supported(system, use_second_order):
+    a = system.args
+    return (bool(getattr(a, 'graph_inner_loop', 0)) and system.device.type == 'cuda' and not use_second_order
+            and not a.attenuate and hasattr(system.inner_loop_optimizer, 'lr_mode'))
+
+
+class GraphedInnerLoop:
+    def __init__(self, system, frame_shape, num_steps, training, msl):
+        self.sys = system
+        self.net, self.rule, self.crit = system.net, system.inner_loop_optimizer, system.criterion
+        self.S, self.training, self.msl = num_steps, training, msl
+        self.shape = tuple(frame_shape)            # (3, H, W)
+        dev = system.device
+        named = system.get_inner_loop_parameter_dict(self.net.named_parameters())
+        self.all_keys = list(named.keys())
+        self.theta = named
+        self._probe_routing()
+        C, H, W = self.shape
+        self.sup = [torch.zeros(2, C, H, W, device=dev) for _ in range(3)]      # frame0 | target | frame1, pair batch
+        self.tgt = [torch.zeros(1, C, H, W, device=dev) for _ in range(3)]
+        self.W0 = {k: torch.zeros_like(self.theta[k]).requires_grad_() for k in self.routed}
+        self.learn_lr = any(p.requires_grad for p in self.rule.names_learning_rates_dict.values())
+        opt = self.rule.optimizer
+        self.rule_id = {('SGD', True): _hip.RULE_SGD, ('SGD', False): _hip.RULE_SGD,
+                        ('Adam', True): _hip.RULE_ADAM, ('Adam', False): _hip.RULE_ADAM,
+                        ('Adamax', True): _hip.RULE_ADAMAX_LSLR, ('Adamax', False): _hip.RULE_ADAMAX_MSGD}[
+            (opt, self.rule.keeps_adamax_moment)]
+        self.m = [torch.zeros_like(self.theta[k]) for k in self.routed] if self.rule_id in (1, 2) else None
+        self.s = [torch.zeros_like(self.theta[k]) for k in self.routed] if self.rule_id == 1 else None
+        self.step_graphs, self.step_out = [], []     # per step: graph, dict(W_out, g, dir)
+        self.target_graphs = {}                      # step index s (params = W_s) -> (graph, outputs)
+        self.pool = None
+        self._capture()
+
+    # ------------------------------------------------------------------------------------------
+    def _probe_routing(self):
+        """Which inner-loop tensors does the plugin actually read from the fast dict?  (SepConv 54 of 94,
+        VoxelFlow 9 of 23, CAIN 494 of 494: SURVEY.md fact 6.)  One eager forward on cloned tensors."""
+        C, H, W = self.shape
+        dev = self.sys.device
+        fast = {k: v.detach().clone().requires_grad_() for k, v in self.theta.items()}
+        x = torch.zeros(1, C, H, W, device=dev)
+        out = self.net.forward(x, x, params=fast, backup_running_statistics=False, num_step=0)
+        g = torch.autograd.grad(out.sum(), list(fast.values()), allow_unused=True)
+        self.routed = [k for k, gi in zip(self.all_keys, g) if gi is not None]
+        self.unrouted = [k for k, gi in zip(self.all_keys, g) if gi is None]
+
+    def _lrs(self, t):
+        return [self.rule._lr(k, t) for k in self.routed]
+
+    def _support_step(self, W, t):
+        out = self.net.forward(self.sup[0], self.sup[2], params=W, backup_running_statistics=(t == 0), num_step=t)
+        loss = self.crit(out[0:1], self.sup[1][0:1])['total'] + self.crit(out[1:2], self.sup[1][1:2])['total']
+        g = torch.autograd.grad(loss, [W[k] for k in self.routed])
+        ws = [W[k].detach() for k in self.routed]
+        lrs = [l.detach() for l in self._lrs(t)]
+        bc1 = [1 - self.rule.beta1 ** (t + 1)] * len(ws)
+        sbc2 = [(1 - self.rule.beta2 ** (t + 1)) ** 0.5] * len(ws)
+        want_coef = self.learn_lr and self.rule_id != _hip.RULE_SGD
+        new, coef = hip_ops.mt_update_nograd(self.rule_id, self.rule.lr_mode, ws, list(g), lrs, self.m, self.s, bc1, sbc2,
+                                             self.rule.beta1, self.rule.beta2, self.rule.eps, want_coef)
+        Wn = {k: v.requires_grad_() for k, v in zip(self.routed, new)}
+        return dict(W=Wn, g=list(g), dir=(coef if want_coef else list(g)), loss=loss.detach())
+
+    def _target(self, W, s, with_grad):
+        if not with_grad:
+            with torch.no_grad():
+                pred = self.net.forward(self.tgt[0], self.tgt[2], params=W, backup_running_statistics=False, num_step=s)
+                parts = self.crit(pred, self.tgt[1])
+            return dict(pred=pred, parts={k: v.detach() for k, v in parts.items()})
+        pred = self.net.forward(self.tgt[0], self.tgt[2], params=W, backup_running_statistics=False, num_step=s)
+        parts = self.crit(pred, self.tgt[1])
+        own = [self.theta[k] for k in self.unrouted]
+        g = torch.autograd.grad(parts['total'], [W[k] for k in self.routed] + own, allow_unused=True)
+        n = len(self.routed)
+        return dict(pred=pred.detach(), parts={k: v.detach() for k, v in parts.items()}, g_routed=list(g[:n]),
+                    g_own=list(g[n:]))
+
+    def _capture(self):
+        need_target = sorted(set(range(1, self.S + 1)) if (self.msl and self.training) else {self.S})
+        with_grad = self.training
+
+        def run_all():
+            W = self.W0
+            outs, tg = [], {}
+            for t in range(self.S):
+                o = self._support_step(W, t)
+                outs.append(o)
+                W = o['W']
+                if (t + 1) in need_target:
+                    tg[t + 1] = self._target(W, t + 1, with_grad)
+            if 0 in need_target or self.S == 0:
+                tg[self.S] = self._target(W, self.S, with_grad)
+            return outs, tg
+
+        # warm-up on a side stream (MIOpen find, lazy inits), never on the default stream
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                run_all()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+
+        self.pool = torch.cuda.graph_pool_handle()
+        W = self.W0
+        for t in range(self.S):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=self.pool):
+                o = self._support_step(W, t)
+            self.step_graphs.append(g)
+            self.step_out.append(o)
+            W = o['W']
+            if (t + 1) in need_target:
+                tgph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(tgph, pool=self.pool):
+                    to = self._target(W, t + 1, with_grad)
+                self.target_graphs[t + 1] = (tgph, to)
+        if self.S == 0:
+            tgph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(tgph, pool=self.pool):
+                to = self._target(W, 0, with_grad)
+            self.target_graphs[0] = (tgph, to)
+
+    # ------------------------------------------------------------------------------------------
+    def run_task(self, frames, task_id, importance, accum):
+        """Adapt on one task and (when training) add its outer-gradient contribution to `accum`.
+        Returns (task_loss scalar tensor, pred [1,3,H,W], list of loss-part dicts)."""
+        sysm = self.sys
+        a, b = sysm.support_idxs
+        tix = sysm.target_idxs
+        sl = slice(task_id, task_id + 1)
+        for dst, (ia, ib) in zip(self.sup, ((a[0], b[0]), (a[1], b[1]), (a[2], b[2]))):
+            dst[0:1].copy_(frames[ia][sl])
+            dst[1:2].copy_(frames[ib][sl])
+        for dst, i in zip(self.tgt, tix):
+            dst.copy_(frames[i][sl])
+        with torch.no_grad():
+            torch._foreach_copy_([self.W0[k] for k in self.routed], [self.theta[k] for k in self.routed])
+            for buf in (self.m, self.s):
+                if buf is not None:
+                    torch._foreach_zero_(buf)
+        logs, task_loss, pred = [], None, None
+        n = len(self.routed)
+        # replay: S support steps, target passes where needed
+        for t in range(self.S):
+            self.step_graphs[t].replay()
+            if (t + 1) in self.target_graphs:
+                self.target_graphs[t + 1][0].replay()
+        if self.S == 0:
+            self.target_graphs[0][0].replay()
+
+        # losses / outer gradients from the static outputs
+        msl = self.msl and self.training
+        weights = {s: (importance[s - 1] if msl else 1.0) for s in self.target_graphs}
+        for s, (_, to) in sorted(self.target_graphs.items()):
+            w = weights[s]
+            term = w * to['parts']['total']
+            task_loss = term if task_loss is None else task_loss + term
+            logs.append(to['parts'])
+            pred = to['pred']
+        if self.training:
+            suffix = None      # sum_{s > t} w_s G_s  over routed tensors
+            for t in range(self.S, -1, -1):
+                if t in self.target_graphs:
+                    to = self.target_graphs[t][1]
+                    w = weights[t]
+                    gs = to['g_routed']
+                    if suffix is None:
+                        suffix = [w * g for g in gs] if not isinstance(w, float) or w != 1.0 else [g.clone() for g in gs]
+                    else:
+                        torch._foreach_add_(suffix, [w * g for g in gs] if not isinstance(w, float) or w != 1.0 else gs)
+                    own = [(k, g) for k, g in zip(self.unrouted, to['g_own']) if g is not None]
+                    accum.add_params([k for k, _ in own], [w * g for _, g in own])
+                if t > 0 and self.learn_lr and suffix is not None:
+                    accum.add_lr_grads(self, t - 1, suffix)
+            if suffix is not None:
+                accum.add_params(self.routed, suffix)
+        return task_loss, pred.clone(), logs
+
+
+class OuterGradAccumulator:
+    """Sum over tasks of the manually assembled first-order outer gradients (scaled by 1/B at the end)."""
+
+    def __init__(self, system, theta):
+        self.sys = system
+        self.theta = theta      # inner-loop key -> nn.Parameter
+        self.param = {}         # inner-loop key -> tensor
+        self.lr = {}            # lr key -> tensor shaped like the lr parameter
+
+    def add_params(self, keys, grads):
+        for k, g in zip(keys, grads):
+            if k in self.param:
+                self.param[k].add_(g)
+            else:
+                self.param[k] = g.clone()
+
+    def add_lr_grads(self, gl, t, suffix):
+        """dL/d lr_t = <suffix, dir_t> (scalar per tensor for LSLR, element-wise for Meta-SGD)."""
+        rule = gl.rule
+        dirs = gl.step_out[t]['dir']
+        scale = -1.0 if gl.rule_id == _hip.RULE_SGD else 1.0
+        lib = _hip.lib()
+        n = len(gl.routed)
+        numel = [x.numel() for x in suffix]
+        gos = [x.contiguous() for x in suffix]
+        if rule.lr_mode == _hip.LR_SCALAR:
+            dst = torch.zeros(n, dtype=torch.float32, device=gos[0].device)
+            outs = [dst[i] for i in range(n)]
+        else:
+            outs = [torch.empty_like(x) for x in gos]
+        args = (rule.lr_mode, n, _hip.ptr_array(gos), _hip.ptr_array(dirs), _hip.ptr_array(outs), _hip.i64_array(numel),
+                scale, _hip.current_stream())
+        _hip.launch("mt_update_bwd", lambda: _hip.check(lib.savfi_mt_update_bwd_f32(*args), "savfi_mt_update_bwd_f32"))
+        for i, k in enumerate(gl.routed):
+            lk = k.replace(".", "-")
+            p = rule.names_learning_rates_dict[lk]
+            if not p.requires_grad:
+                continue
+            if lk not in self.lr:
+                self.lr[lk] = torch.zeros_like(p)
+            if rule.lr_mode == _hip.LR_SCALAR:
+                self.lr[lk][t] += dst[i]
+            else:
+                self.lr[lk].add_(outs[i])
+
+    def install(self, num_tasks):
+        """Write the accumulated gradients (mean over the GLOBAL meta-batch) into .grad."""
+        inv = 1.0 / float(num_tasks)
+        for k, g in self.param.items():
+            self.theta[k].grad = g.mul_(inv)
+        for lk, g in self.lr.items():
+            self.sys.inner_loop_optimizer.names_learning_rates_dict[lk].grad = g.mul_(inv)

@@ -181,6 +181,22 @@ def mt_update(rule, lr_mode, weights, grads, lrs, m=None, s=None, bc1=None, sqrt
     return list(_MtUpdate.apply(spec, *ws, *lrs))
 
 
+def mt_update_nograd(rule, lr_mode, weights, grads, lrs, m, s, bc1, sqrt_bc2, beta1, beta2, eps, want_coef):
+    """The fused update without the autograd wrapper (used inside captured hipGraphs, where the outer gradient
+    is assembled by hand): returns (new weights, coef or None) with coef = d w' / d lr per element."""
+    n = len(weights)
+    outs = [torch.empty_like(w) for w in weights]
+    coefs = [torch.empty_like(w) for w in weights] if want_coef else None
+    lib = _hip.lib()
+    args = (rule, lr_mode, n, _hip.ptr_array(weights), _hip.ptr_array(grads), _hip.ptr_array(lrs),
+            _hip.ptr_array(m) if m is not None else None, _hip.ptr_array(s) if s is not None else None,
+            _hip.ptr_array(outs), _hip.ptr_array(coefs) if coefs is not None else None,
+            _hip.i64_array([w.numel() for w in weights]), _hip.f32_array(bc1), _hip.f32_array(sqrt_bc2),
+            beta1, beta2, eps, _hip.current_stream())
+    _hip.launch("mt_update", lambda: _hip.check(lib.savfi_mt_update_f32(*args), "savfi_mt_update_f32"))
+    return outs, coefs
+
+
 # --------------------------------------------------------------------------------------------
 # L2F: per-tensor mean of gradients, per-tensor attenuation   (meta_learning_system.py:249-268)
 # --------------------------------------------------------------------------------------------

@@ -24,7 +24,7 @@ import torch
 import torch.nn as nn
 import torch.optim as optim
 
-from . import hip_ops, model_utils, utils
+from . import graph_inner_loop, hip_ops, model_utils, utils
 from .inner_loop_optimizers import LSLRGradientDescentLearningRule, MetaSGDLearningRule
 from .loss import Loss
 from .task_parallel import TaskParallel
@@ -156,6 +156,8 @@ class SceneAdaptiveInterpolation(nn.Module):
 
         self.criterion = criterion if criterion is not None else Loss(args)
         self.task_parallel = task_parallel if task_parallel is not None else TaskParallel()
+        self._graphs = {}            # (frame shape, steps, training, msl) -> GraphedInnerLoop
+        self._manual_grads = None    # OuterGradAccumulator of the last graphed training forward
 
         if args.resume:
             print('Resume training')
@@ -291,6 +293,10 @@ class SceneAdaptiveInterpolation(nn.Module):
         Returns (losses, per_task_target_preds, metrics)."""
         frames = data_batch
         num_tasks = len(frames[0])
+        self._manual_grads = None
+        if graph_inner_loop.supported(self, use_second_order):
+            return self._forward_graphed(frames, epoch, use_multi_step_loss_optimization, num_steps, training_phase,
+                                         do_evaluation)
         hip_ops.DOUBLE_BACKWARD = bool(use_second_order)
         # fused conv epilogues: opt-in, and first-order only
         model_utils.FUSE_CONV_ACT = bool(getattr(self.args, 'fuse_conv_act', 0)) and not use_second_order
@@ -369,6 +375,62 @@ class SceneAdaptiveInterpolation(nn.Module):
             losses['loss_importance_vector_{}'.format(idx)] = item.detach().cpu().numpy()
         return losses, preds, metrics
 
+    def _forward_graphed(self, frames, epoch, use_multi_step_loss_optimization, num_steps, training_phase,
+                         do_evaluation):
+        """Same contract as forward(), executed by hipGraph replays (graph_inner_loop.py): first-order only, the
+        outer gradients are assembled by hand and installed by meta_update()."""
+        num_tasks = len(frames[0])
+        tp = self.task_parallel
+        msl = bool(use_multi_step_loss_optimization and training_phase
+                   and epoch < self.args.multi_step_loss_num_epochs)
+        hip_ops.DOUBLE_BACKWARD = False
+        model_utils.FUSE_CONV_ACT = bool(getattr(self.args, 'fuse_conv_act', 0))
+        key = (tuple(frames[0].shape[1:]), num_steps, bool(training_phase), msl)
+        if key not in self._graphs:
+            import gc
+            gc.collect()
+            self._graphs[key] = graph_inner_loop.GraphedInnerLoop(self, frames[0].shape[1:], num_steps,
+                                                                  bool(training_phase), msl)
+        gl = self._graphs[key]
+        importance = self.get_per_step_loss_importance_vector()
+        accum = graph_inner_loop.OuterGradAccumulator(self, gl.theta) if training_phase else None
+        deferred = _DeferredMeters()
+        eval_mse, eval_ssim, total_losses = [], [], []
+        preds = [[] for _ in range(num_tasks)]
+        for task_id in tp.local_tasks(num_tasks):
+            task_loss, pred, logs = gl.run_task(frames, task_id, importance, accum)
+            for parts in logs:
+                for k, v in parts.items():
+                    deferred.add(k, v)
+            total_losses.append(task_loss)
+            preds[task_id] = self._to_unit_range(pred.squeeze(0)).unsqueeze(0)
+            if do_evaluation:
+                out01 = self._to_unit_range(pred.squeeze(0))
+                tgt01 = self._to_unit_range(frames[self.target_idxs[1]][task_id].detach())
+                q_o, q_t = utils.quantize(out01, 1.), utils.quantize(tgt01, 1.)
+                eval_mse.append((q_o - q_t).div(255).pow(2).mean())
+                eval_ssim.append(utils.ssim(q_o.unsqueeze(0), q_t.unsqueeze(0), val_range=255))
+        local_sum = torch.sum(torch.stack(total_losses)) if total_losses else torch.zeros((), device=self.device)
+        losses = {'loss': (local_sum / num_tasks).detach()}
+        if training_phase:
+            accum.num_tasks = num_tasks
+            self._manual_grads = accum
+        meters = deferred.flush()
+        metrics = {'psnr': utils.AverageMeter(), 'ssim': utils.AverageMeter()}
+        if eval_mse:
+            mse = torch.stack(eval_mse).cpu().tolist()
+            ssims = torch.stack(eval_ssim).cpu()
+            for m, s_ in zip(mse, ssims):
+                metrics['psnr'].update(-10 * np.log10(m + 1e-8).item())
+                metrics['ssim'].update(s_)
+        if tp.active:
+            self._reduce_logging(losses, meters, metrics)
+        for k, meter in meters.items():
+            losses[k] = meter.avg
+        for idx, item in enumerate(importance):
+            losses['loss_importance_vector_{}'.format(idx)] = item.detach().cpu().numpy()
+        return losses, preds, metrics
+
     def _reduce_logging(self, losses, meters, metrics):
         """Average logging scalars over ranks (second, tiny all-reduce; the loss used for backward stays local)."""
         keys = sorted(meters)
@@ -408,7 +470,10 @@ class SceneAdaptiveInterpolation(nn.Module):
     def meta_update(self, loss):
         """zero_grad -> backward -> (all-reduce of outer grads) -> optimizer step  (reference :551-574)."""
         self.optimizer.zero_grad()
-        if loss.requires_grad:
+        if self._manual_grads is not None:        # graphed forward: first-order outer gradients assembled by hand
+            self._manual_grads.install(self._manual_grads.num_tasks)
+            self._manual_grads = None
+        elif loss.requires_grad:
             loss.backward()
         self.task_parallel.allreduce_gradients(list(self.trainable_parameters()))
         self.optimizer.step()
