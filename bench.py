@@ -75,6 +75,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timer', action='store_true')
     ap.add_argument('--fuse-conv-act', type=int, default=0)
+    ap.add_argument('--graph-inner-loop', type=int, default=0)
+    ap.add_argument('--sepconv-window', type=int, default=1)
     opt = ap.parse_args()
 
     from meta_interpolation_amd import _hip, synthetic, task_parallel
@@ -91,7 +93,8 @@ def main():
     model, H, W, tasks, S, over = WORKLOADS[opt.workload]
     args = default_args(model=model, num_gpu=1, batch_size=tasks * world,
                         number_of_training_steps_per_iter=S, number_of_evaluation_steps_per_iter=S,
-                        fuse_conv_act=opt.fuse_conv_act, **over)
+                        fuse_conv_act=opt.fuse_conv_act, graph_inner_loop=opt.graph_inner_loop,
+                        sepconv_window=opt.sepconv_window, **over)
     net = MODEL_REGISTRY[model](args, False)
     synthetic.load_seeded_weights(net, model)          # identical theta on every rank, no broadcast
     system = SceneAdaptiveInterpolation(args, net=net.to(dev))

@@ -182,6 +182,17 @@ int savfi_bias_act_bwd_f32(const float* gy, const float* y, float* gz, float* gb
 int savfi_upsample2x_fwd_f32(const float* in, float* out, int planes, int H, int W, int align_corners, void* stream);
 int savfi_upsample2x_bwd_f32(const float* gout, float* gin, int planes, int H, int W, int align_corners, void* stream);
 
+/* Windowed form of the same map: `in` holds the crop rows [sy0,sy0+Hs) x cols [sx0,sx0+Ws) of the virtual
+ * [planes,H,W] source, `out` the window rows [oy0,oy0+Hw) x cols [ox0,ox0+Ww) of the virtual [planes,2H,2W]
+ * result (identical values to the full op on that window).  SAVFI_E_SHAPE if the window reads a source pixel
+ * outside the crop.  bwd: gout is the window, gin the crop (fully overwritten; crop pixels no window output
+ * reads get 0).  Used for SepConv's sub-networks (sepconv/model.py:196-245), whose 51-tap maps are consumed
+ * only on the un-padded frame area (sepconv/model.py:346-349 crops the result). */
+int savfi_upsample2x_window_fwd_f32(const float* in, float* out, int planes, int H, int W, int sy0, int sx0,
+                                    int Hs, int Ws, int oy0, int ox0, int Hw, int Ww, int align_corners, void* stream);
+int savfi_upsample2x_window_bwd_f32(const float* gout, float* gin, int planes, int H, int W, int sy0, int sx0,
+                                    int Hs, int Ws, int oy0, int ox0, int Hw, int Ww, int align_corners, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

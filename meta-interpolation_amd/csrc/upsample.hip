@@ -32,87 +32,130 @@ __device__ __forceinline__ float scale_of(int in, int out, int align) {
   return align ? (out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f) : 0.5f;
 }
 
-__global__ __launch_bounds__(256) void upsample2x_fwd(const float* __restrict__ in, float* __restrict__ out,
-                                                      int H, int W, int align) {
-  const int Ho = 2 * H, Wo = 2 * W;
-  const int ox = (blockIdx.x * 256 + threadIdx.x) * 4;     // 4 consecutive outputs per thread
-  const int oy = blockIdx.y;
-  if (ox >= Wo) return;
-  const float* p = in + (size_t)blockIdx.z * H * W;
-  const Src sy = source(oy, H, scale_of(H, Ho, align), align);
-  const float sw = scale_of(W, Wo, align);
-  const float* r0 = p + (size_t)sy.i0 * W;
-  const float* r1 = p + (size_t)sy.i1 * W;
+// Window geometry.  The op is defined on a virtual [H, W] -> [2H, 2W] map; the source buffer holds the crop
+// rows [sy0, sy0+Hs) x cols [sx0, sx0+Ws) of it and the output buffer the window rows [oy0, oy0+Hw) x cols
+// [ox0, ox0+Ww) of the result.  The full op is the window (0, 0, H, W) -> (0, 0, 2H, 2W).  Used by SepConv's
+// sub-networks, whose 51-tap maps are only consumed on the un-padded frame area (sepconv/model.py).
+struct Win { int H, W, sy0, sx0, Hs, Ws, oy0, ox0, Hw, Ww, align; };
+
+__global__ __launch_bounds__(256) void upsample2x_fwd(const float* __restrict__ in, float* __restrict__ out, Win g) {
+  const int Ho = 2 * g.H, Wo = 2 * g.W;
+  const int wx = (blockIdx.x * 256 + threadIdx.x) * 4;     // 4 consecutive outputs per thread
+  const int wy = blockIdx.y;
+  if (wx >= g.Ww) return;
+  const float* p = in + (size_t)blockIdx.z * g.Hs * g.Ws;
+  const Src sy = source(g.oy0 + wy, g.H, scale_of(g.H, Ho, g.align), g.align);
+  const float sw = scale_of(g.W, Wo, g.align);
+  const float* r0 = p + (size_t)(sy.i0 - g.sy0) * g.Ws - g.sx0;
+  const float* r1 = p + (size_t)(sy.i1 - g.sy0) * g.Ws - g.sx0;
   float v[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const Src sx = source(min(ox + k, Wo - 1), W, sw, align);
+    const Src sx = source(min(g.ox0 + wx + k, g.ox0 + g.Ww - 1), g.W, sw, g.align);
     v[k] = sy.l0 * (sx.l0 * r0[sx.i0] + sx.l1 * r0[sx.i1]) + sy.l1 * (sx.l0 * r1[sx.i0] + sx.l1 * r1[sx.i1]);
   }
-  float* o = out + ((size_t)blockIdx.z * Ho + oy) * Wo + ox;
-  if (ox + 3 < Wo && ((((uintptr_t)o) & 15u) == 0)) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+  float* o = out + ((size_t)blockIdx.z * g.Hw + wy) * g.Ww + wx;
+  if (wx + 3 < g.Ww && ((((uintptr_t)o) & 15u) == 0)) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
   else
-    for (int k = 0; k < 4 && ox + k < Wo; ++k) o[k] = v[k];
+    for (int k = 0; k < 4 && wx + k < g.Ww; ++k) o[k] = v[k];
 }
 
-__global__ __launch_bounds__(256) void upsample2x_bwd(const float* __restrict__ gout, float* __restrict__ gin,
-                                                      int H, int W, int align) {
-  const int Ho = 2 * H, Wo = 2 * W;
-  const int ix = blockIdx.x * 256 + threadIdx.x;
-  const int iy = blockIdx.y;
-  if (ix >= W) return;
-  const float* g = gout + (size_t)blockIdx.z * Ho * Wo;
-  const float sh = scale_of(H, Ho, align), sw = scale_of(W, Wo, align);
+__global__ __launch_bounds__(256) void upsample2x_bwd(const float* __restrict__ gout, float* __restrict__ gin, Win g) {
+  const int Ho = 2 * g.H, Wo = 2 * g.W;
+  const int cx = blockIdx.x * 256 + threadIdx.x;
+  const int cy = blockIdx.y;
+  if (cx >= g.Ws) return;
+  const int ix = g.sx0 + cx, iy = g.sy0 + cy;               // coordinates in the virtual source
+  const float* gp = gout + (size_t)blockIdx.z * g.Hw * g.Ww;
+  const float sh = scale_of(g.H, Ho, g.align), sw = scale_of(g.W, Wo, g.align);
   // candidate outputs: src(o) in (i-1, i+1).  For both index rules that is o in {2i-1 .. 2i+2}; one more on each
   // side is visited so that a rounding of src at an integer cannot drop a contribution (weights are re-evaluated
-  // with the forward's arithmetic, so extra candidates simply weigh zero)
+  // with the forward's arithmetic, so extra candidates simply weigh zero); clipped to the output window
   constexpr int NC = 6;
-  const int oy_lo = max(0, 2 * iy - 2), oy_hi = min(Ho - 1, 2 * iy + 3);
-  const int ox_lo = max(0, 2 * ix - 2), ox_hi = min(Wo - 1, 2 * ix + 3);
-  float wx[NC];
+  const int oy_lo = max(g.oy0, 2 * iy - 2), oy_hi = min(g.oy0 + g.Hw - 1, 2 * iy + 3);
+  const int ox_lo = max(g.ox0, 2 * ix - 2), ox_hi = min(g.ox0 + g.Ww - 1, 2 * ix + 3);
+  float wxs[NC];
 #pragma unroll
   for (int k = 0; k < NC; ++k) {
     const int ox = ox_lo + k;
     float w = 0.f;
     if (ox <= ox_hi) {
-      const Src s = source(ox, W, sw, align);
+      const Src s = source(ox, g.W, sw, g.align);
       w = (s.i0 == ix ? s.l0 : 0.f) + (s.i1 == ix ? s.l1 : 0.f);
     }
-    wx[k] = w;
+    wxs[k] = w;
   }
   float acc = 0.f;
   for (int oy = oy_lo; oy <= oy_hi; ++oy) {
-    const Src s = source(oy, H, sh, align);
+    const Src s = source(oy, g.H, sh, g.align);
     const float wy = (s.i0 == iy ? s.l0 : 0.f) + (s.i1 == iy ? s.l1 : 0.f);
     if (wy == 0.f) continue;
-    const float* row = g + (size_t)oy * Wo;
+    const float* row = gp + (size_t)(oy - g.oy0) * g.Ww - g.ox0;
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < NC; ++k)
-      if (ox_lo + k <= ox_hi) t = fmaf(wx[k], row[ox_lo + k], t);
+      if (ox_lo + k <= ox_hi) t = fmaf(wxs[k], row[ox_lo + k], t);
     acc = fmaf(wy, t, acc);
   }
-  gin[((size_t)blockIdx.z * H + iy) * W + ix] = acc;
+  gin[((size_t)blockIdx.z * g.Hs + cy) * g.Ws + cx] = acc;
+}
+
+// host mirror of source(): first / last source index an output range touches
+void touched(int o_first, int o_last, int in, int out, int align, int* lo, int* hi) {
+  const float scale = align ? (out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f) : 0.5f;
+  auto idx0 = [&](int dst) {
+    float s = align ? scale * (float)dst : fmaxf(((float)dst + 0.5f) * scale - 0.5f, 0.f);
+    int i0 = (int)s;
+    return i0 < in - 1 ? i0 : in - 1;
+  };
+  *lo = idx0(o_first);
+  const int i0 = idx0(o_last);
+  *hi = i0 + (i0 < in - 1 ? 1 : 0);
+}
+
+int check_window(const Win& g, int planes) {
+  if (planes <= 0 || g.H <= 0 || g.W <= 0 || g.Hs <= 0 || g.Ws <= 0 || g.Hw <= 0 || g.Ww <= 0) return SAVFI_E_SHAPE;
+  if (g.sy0 < 0 || g.sx0 < 0 || g.sy0 + g.Hs > g.H || g.sx0 + g.Ws > g.W) return SAVFI_E_SHAPE;
+  if (g.oy0 < 0 || g.ox0 < 0 || g.oy0 + g.Hw > 2 * g.H || g.ox0 + g.Ww > 2 * g.W) return SAVFI_E_SHAPE;
+  int lo, hi;   // every source pixel the window reads must be inside the crop
+  touched(g.oy0, g.oy0 + g.Hw - 1, g.H, 2 * g.H, g.align, &lo, &hi);
+  if (lo < g.sy0 || hi >= g.sy0 + g.Hs) return SAVFI_E_SHAPE;
+  touched(g.ox0, g.ox0 + g.Ww - 1, g.W, 2 * g.W, g.align, &lo, &hi);
+  if (lo < g.sx0 || hi >= g.sx0 + g.Ws) return SAVFI_E_SHAPE;
+  if (planes > 65535 || g.Hw > 65535 || g.Hs > 65535) return SAVFI_E_TOOBIG;
+  return 0;
 }
 
 }  // namespace
 
+extern "C" int savfi_upsample2x_window_fwd_f32(const float* in, float* out, int planes, int H, int W, int sy0, int sx0,
+                                               int Hs, int Ws, int oy0, int ox0, int Hw, int Ww, int align_corners,
+                                               void* stream) {
+  if (!in || !out) return SAVFI_E_NULL;
+  const Win g{H, W, sy0, sx0, Hs, Ws, oy0, ox0, Hw, Ww, align_corners ? 1 : 0};
+  if (int rc = check_window(g, planes)) return rc;
+  dim3 grid(savfi_cdiv(Ww, 1024), Hw, planes);
+  hipLaunchKernelGGL(upsample2x_fwd, grid, dim3(256), 0, (hipStream_t)stream, in, out, g);
+  return savfi_launch_status();
+}
+
+extern "C" int savfi_upsample2x_window_bwd_f32(const float* gout, float* gin, int planes, int H, int W, int sy0, int sx0,
+                                               int Hs, int Ws, int oy0, int ox0, int Hw, int Ww, int align_corners,
+                                               void* stream) {
+  if (!gout || !gin) return SAVFI_E_NULL;
+  const Win g{H, W, sy0, sx0, Hs, Ws, oy0, ox0, Hw, Ww, align_corners ? 1 : 0};
+  if (int rc = check_window(g, planes)) return rc;
+  dim3 grid(savfi_cdiv(Ws, 256), Hs, planes);
+  hipLaunchKernelGGL(upsample2x_bwd, grid, dim3(256), 0, (hipStream_t)stream, gout, gin, g);
+  return savfi_launch_status();
+}
+
 extern "C" int savfi_upsample2x_fwd_f32(const float* in, float* out, int planes, int H, int W, int align_corners,
                                         void* stream) {
-  if (!in || !out) return SAVFI_E_NULL;
-  if (planes <= 0 || H <= 0 || W <= 0) return SAVFI_E_SHAPE;
-  if (planes > 65535 || 2 * H > 65535) return SAVFI_E_TOOBIG;
-  dim3 grid(savfi_cdiv(2 * W, 1024), 2 * H, planes);
-  hipLaunchKernelGGL(upsample2x_fwd, grid, dim3(256), 0, (hipStream_t)stream, in, out, H, W, align_corners ? 1 : 0);
-  return savfi_launch_status();
+  return savfi_upsample2x_window_fwd_f32(in, out, planes, H, W, 0, 0, H, W, 0, 0, 2 * H, 2 * W, align_corners, stream);
 }
 
 extern "C" int savfi_upsample2x_bwd_f32(const float* gout, float* gin, int planes, int H, int W, int align_corners,
                                         void* stream) {
-  if (!gout || !gin) return SAVFI_E_NULL;
-  if (planes <= 0 || H <= 0 || W <= 0) return SAVFI_E_SHAPE;
-  if (planes > 65535 || H > 65535) return SAVFI_E_TOOBIG;
-  dim3 grid(savfi_cdiv(W, 256), H, planes);
-  hipLaunchKernelGGL(upsample2x_bwd, grid, dim3(256), 0, (hipStream_t)stream, gout, gin, H, W, align_corners ? 1 : 0);
-  return savfi_launch_status();
+  return savfi_upsample2x_window_bwd_f32(gout, gin, planes, H, W, 0, 0, H, W, 0, 0, 2 * H, 2 * W, align_corners, stream);
 }

@@ -357,46 +357,78 @@ def conv_bias_act(x, weight, bias, stride=1, padding=0, dilation=1, groups=1, sl
 # Bilinear x2 up-sampling      (sepconv/model.py:191, :213-234; voxel_flow.py:400-414)
 # --------------------------------------------------------------------------------------------
 class _Upsample2x(torch.autograd.Function):
+    """geom = (H, W, sy0, sx0, Hs, Ws, oy0, ox0, Hw, Ww): x is the crop [sy0:sy0+Hs, sx0:sx0+Ws] of a virtual
+    [H, W] map, the result the window [oy0:oy0+Hw, ox0:ox0+Ww] of its x2 up-sampling (full op: crop = window = all)."""
+
     @staticmethod
-    def forward(ctx, x, align_corners):
+    def forward(ctx, x, align_corners, geom):
         _hip.require_cuda(x)
-        N, C, H, W = x.shape
-        out = torch.empty((N, C, 2 * H, 2 * W), dtype=x.dtype, device=x.device)
+        N, C = x.shape[:2]
+        H, W, sy0, sx0, Hs, Ws, oy0, ox0, Hw, Ww = geom
+        assert tuple(x.shape[2:]) == (Hs, Ws), (x.shape, geom)
+        out = torch.empty((N, C, Hw, Ww), dtype=x.dtype, device=x.device)
         lib = _hip.lib()
-        _hip.launch("upsample2x_fwd", lambda: _hip.check(lib.savfi_upsample2x_fwd_f32(
-            x.data_ptr(), out.data_ptr(), N * C, H, W, int(align_corners), _hip.current_stream()),
-            "savfi_upsample2x_fwd_f32"), nbytes=4 * 5 * N * C * H * W)
-        ctx.align, ctx.shape = bool(align_corners), (N, C, H, W)
+        _hip.launch("upsample2x_fwd", lambda: _hip.check(lib.savfi_upsample2x_window_fwd_f32(
+            x.data_ptr(), out.data_ptr(), N * C, *geom, int(align_corners), _hip.current_stream()),
+            "savfi_upsample2x_window_fwd_f32"), nbytes=4 * N * C * (Hs * Ws + Hw * Ww))
+        ctx.align, ctx.geom = bool(align_corners), geom
         return out
 
     @staticmethod
     def backward(ctx, g):
         # linear op: its adjoint goes through the Function too, so double-backward keeps working
-        return _Upsample2xAdjoint.apply(g, ctx.align), None
+        return _Upsample2xAdjoint.apply(g, ctx.align, ctx.geom), None, None
 
 
 class _Upsample2xAdjoint(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, g, align_corners):
+    def forward(ctx, g, align_corners, geom):
         g = g.contiguous()
         _hip.require_cuda(g)
-        N, C, Ho, Wo = g.shape
-        gin = torch.empty((N, C, Ho // 2, Wo // 2), dtype=g.dtype, device=g.device)
+        N, C = g.shape[:2]
+        H, W, sy0, sx0, Hs, Ws, oy0, ox0, Hw, Ww = geom
+        assert tuple(g.shape[2:]) == (Hw, Ww), (g.shape, geom)
+        gin = torch.empty((N, C, Hs, Ws), dtype=g.dtype, device=g.device)
         lib = _hip.lib()
-        _hip.launch("upsample2x_bwd", lambda: _hip.check(lib.savfi_upsample2x_bwd_f32(
-            g.data_ptr(), gin.data_ptr(), N * C, Ho // 2, Wo // 2, int(align_corners), _hip.current_stream()),
-            "savfi_upsample2x_bwd_f32"), nbytes=4 * 5 * N * C * (Ho // 2) * (Wo // 2))
-        ctx.align = bool(align_corners)
+        _hip.launch("upsample2x_bwd", lambda: _hip.check(lib.savfi_upsample2x_window_bwd_f32(
+            g.data_ptr(), gin.data_ptr(), N * C, *geom, int(align_corners), _hip.current_stream()),
+            "savfi_upsample2x_window_bwd_f32"), nbytes=4 * N * C * (Hs * Ws + Hw * Ww))
+        ctx.align, ctx.geom = bool(align_corners), geom
         return gin
 
     @staticmethod
     def backward(ctx, gg):
-        return _Upsample2x.apply(gg.contiguous(), ctx.align), None
+        return _Upsample2x.apply(gg.contiguous(), ctx.align, ctx.geom), None, None
+
+
+def upsample_window_sources(o0, o1, size_in, align_corners):
+    """First / last source index the outputs [o0, o1) of a x2 up-sampling of `size_in` samples read
+    (float32 arithmetic of the kernel, which is ATen's area_pixel_compute_source_index)."""
+    import numpy as np
+    f = np.float32
+    if align_corners:
+        scale = f(size_in - 1) / f(2 * size_in - 1) if size_in > 0 else f(0)
+        src = lambda d: scale * f(d)
+    else:
+        src = lambda d: max((f(d) + f(0.5)) * f(0.5) - f(0.5), f(0))
+    lo = min(int(src(o0)), size_in - 1)
+    hi = min(int(src(o1 - 1)), size_in - 1)
+    return lo, min(hi + 1, size_in - 1)
+
+
+def upsample_bilinear2x_window(x, full_hw, crop_origin, out_window, align_corners):
+    """x = crop of a virtual [N,C,*full_hw] map starting at crop_origin (y, x); returns rows/cols
+    out_window = (oy0, ox0, Hw, Ww) of its bilinear x2 up-sampling."""
+    H, W = full_hw
+    geom = (int(H), int(W), int(crop_origin[0]), int(crop_origin[1]), int(x.shape[2]), int(x.shape[3]),
+            int(out_window[0]), int(out_window[1]), int(out_window[2]), int(out_window[3]))
+    return _Upsample2x.apply(x.contiguous(), bool(align_corners), geom)
 
 
 def upsample_bilinear2x(x, align_corners):
     """[N,C,H,W] -> [N,C,2H,2W], bilinear, ATen-identical source indices."""
-    return _Upsample2x.apply(x.contiguous(), bool(align_corners))
+    H, W = int(x.shape[2]), int(x.shape[3])
+    return _Upsample2x.apply(x.contiguous(), bool(align_corners), (H, W, 0, 0, H, W, 0, 0, 2 * H, 2 * W))
 
 
 class Upsample2x(torch.nn.Module):

@@ -42,7 +42,7 @@ def set_torch_seed(seed):
 # ---------------------------------------------------------------------------------------------
 def _build_sepconv(args, resume):
     from .sepconv.model import MetaNetwork
-    return MetaNetwork(resume=resume, strModel='l1')
+    return MetaNetwork(resume=resume, strModel='l1', windowed=bool(getattr(args, 'sepconv_window', 1)))
 
 
 def _build_cain(args, resume):

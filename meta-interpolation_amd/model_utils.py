@@ -155,8 +155,10 @@ class MetaConv2dLayer(nn.Module):
         nn.init.xavier_uniform_(self.weight)
         self.bias = nn.Parameter(torch.zeros(out_channels)) if use_bias else None
 
-    def forward(self, x, params=None, act_slope=None):
-        """`act_slope` (set by MetaSequential when an activation follows) applies LeakyReLU(act_slope)."""
+    def forward(self, x, params=None, act_slope=None, padding=None):
+        """`act_slope` (set by MetaSequential when an activation follows) applies LeakyReLU(act_slope);
+        `padding` overrides the layer's own zero padding (windowed evaluation, sepconv/model.py)."""
+        padding = self.padding if padding is None else padding
         if params is not None:
             pv = as_view(params)
             weight = pv.leaf("weight")
@@ -164,9 +166,9 @@ class MetaConv2dLayer(nn.Module):
         else:
             weight, bias = self.weight, self.bias
         if act_slope is not None and bias is not None and x.is_cuda and FUSE_CONV_ACT:
-            return hip_ops.conv_bias_act(x, weight, bias, self.stride, self.padding, self.dilation_rate, self.groups,
+            return hip_ops.conv_bias_act(x, weight, bias, self.stride, padding, self.dilation_rate, self.groups,
                                          act_slope)
-        out = F.conv2d(x, weight, bias, self.stride, self.padding, self.dilation_rate, self.groups)
+        out = F.conv2d(x, weight, bias, self.stride, padding, self.dilation_rate, self.groups)
         if act_slope is not None:
             out = F.relu(out) if act_slope == 0.0 else F.leaky_relu(out, act_slope)
         return out

@@ -9,12 +9,22 @@ As in the reference (:276-306 vs :292-307, :346-347) only the encoder/decoder ``
 the fast-weight dict; the four ``moduleUpsampleN`` and the four 51-tap ``Subnet``s always use the
 module's own parameters.  The two local separable convolutions run on the savfi HIP kernel
 (FunctionSepconv); frames are replication-padded by 25 px and up to a multiple of 128.
+
+Windowed sub-networks (``windowed=True``, GPU tensors).  The reference evaluates the four Subnets and the
+two separable convolutions on the whole padded canvas (384x512 for a 256x448 frame) and then keeps only the
+frame area (:346-349) - 42 % of those pixels are discarded, and the Subnets are 52 % of the network's MACs.
+Every operator after ``tensorCombine`` is local (3x3 convs, ReLU, bilinear x2, the per-pixel 51-tap op), so
+the kept pixels depend only on a window of ``tensorCombine``: here the Subnets run on that window (+3 px
+halo for their three half-resolution convs, +1 px for the full-resolution one), the up-sampling produces
+just the window it feeds (savfi_upsample2x_window_*), and FunctionSepconv produces the H x W frame
+directly from the frame padded by 25 px.  Same values as the full-canvas evaluation (which stays available:
+``windowed=False`` / ``--sepconv_window 0``; tests compare the two), forward and backward.
 """
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..hip_ops import Upsample2x
+from ..hip_ops import Upsample2x, upsample_bilinear2x_window, upsample_window_sources
 from ..model_utils import MetaConv2dLayer, MetaSequential, as_view, zero_grad_params
 from .sepconv_op.sepconv import FunctionSepconv
 
@@ -51,8 +61,10 @@ _DECODER = [("moduleDeconv5", 512, 512), ("moduleDeconv4", 512, 256), ("moduleDe
 
 
 class MetaNetwork(nn.Module):
-    def __init__(self, resume=False, strModel='lf'):
+    def __init__(self, resume=False, strModel='lf', windowed=True):
         super().__init__()
+        self.windowed = bool(windowed)
+        self._windows = {}
         for i, (name, cin, cout) in enumerate(_ENCODER, start=1):
             setattr(self, name, _basic(cin, cout))
             setattr(self, "modulePool%d" % i, nn.AvgPool2d(kernel_size=2, stride=2))
@@ -98,12 +110,51 @@ class MetaNetwork(nn.Module):
             x = x + skips.pop()
         combine = x  # [N,64,ph/2,pw/2]
 
+        if self.windowed and combine.is_cuda:
+            return self._windowed_tail(tensorFirst, tensorSecond, combine, height, width, ph, pw)
         dot1 = FunctionSepconv.apply(self.modulePad(first).contiguous(),
                                      self.moduleVertical1(combine), self.moduleHorizontal1(combine))
         dot2 = FunctionSepconv.apply(self.modulePad(second).contiguous(),
                                      self.moduleVertical2(combine), self.moduleHorizontal2(combine))
         out = dot1 + dot2
         return out[:, :, HALF:HALF + height, HALF:HALF + width]
+
+    # ---- windowed evaluation of everything after tensorCombine (see the module docstring) -------------
+    def _window(self, height, width, ph, pw):
+        key = (height, width)
+        if key not in self._windows:
+            hh, hw = ph // 2, pw // 2
+            # full-resolution window the last 3x3 conv reads: frame area +-1 (never touches the canvas border,
+            # ph >= height + 2*HALF)
+            up = (HALF - 1, HALF - 1, height + 2, width + 2)
+            sy = upsample_window_sources(up[0], up[0] + up[2], hh, True)      # half-res rows / cols it reads
+            sx = upsample_window_sources(up[1], up[1] + up[3], hw, True)
+            # +3 halo for the three half-resolution convs; where the crop is clipped at the canvas border the
+            # convs' own zero padding is the true one, elsewhere the (wrong) outer rings are never read
+            cy0, cy1 = max(0, sy[0] - 3), min(hh, sy[1] + 1 + 3)
+            cx0, cx1 = max(0, sx[0] - 3), min(hw, sx[1] + 1 + 3)
+            self._windows[key] = dict(half=(hh, hw), crop=(cy0, cy1, cx0, cx1), up=up)
+        return self._windows[key]
+
+    def _subnet_window(self, seq, crop, win):
+        x = seq[0](crop, act_slope=0.0)
+        x = seq[2](x, act_slope=0.0)
+        x = seq[4](x, act_slope=0.0)
+        x = upsample_bilinear2x_window(x, win['half'], (win['crop'][0], win['crop'][2]), win['up'], True)
+        return seq[7](x, padding=0)       # [N,51,height,width]: exactly the frame area
+
+    def _windowed_tail(self, frame0, frame1, combine, height, width, ph, pw):
+        win = self._window(height, width, ph, pw)
+        cy0, cy1, cx0, cx1 = win['crop']
+        crop = combine[:, :, cy0:cy1, cx0:cx1].contiguous()
+        rim = (HALF,) * 4
+        dot1 = FunctionSepconv.apply(F.pad(frame0, rim, mode='replicate'),
+                                     self._subnet_window(self.moduleVertical1, crop, win),
+                                     self._subnet_window(self.moduleHorizontal1, crop, win))
+        dot2 = FunctionSepconv.apply(F.pad(frame1, rim, mode='replicate'),
+                                     self._subnet_window(self.moduleVertical2, crop, win),
+                                     self._subnet_window(self.moduleHorizontal2, crop, win))
+        return dot1 + dot2
 
     def zero_grad(self, params=None):
         zero_grad_params(self, params)

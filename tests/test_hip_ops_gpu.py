@@ -4,6 +4,7 @@ import math
 
 import pytest
 import torch
+import torch.nn.functional as F
 
 from meta_interpolation_amd import _hip, hip_ops
 from meta_interpolation_amd.sepconv.sepconv_op.sepconv import FunctionSepconv
@@ -238,3 +239,73 @@ def test_upsample2x_matches_aten(align, shape):
     # and against the CPU result (pins the index arithmetic independently of the device ATen kernel)
     cpu = torch.nn.functional.interpolate(x.detach().cpu(), scale_factor=2, mode='bilinear', align_corners=align)
     assert (out.detach().cpu() - cpu).abs().max().item() <= 2e-6 * max(1.0, cpu.abs().max().item())
+
+
+# ---------------------------------------------------------------------------------------------
+# windowed x2 up-sampling and the windowed SepConv tail
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("align", [True, False])
+@pytest.mark.parametrize("geom", [
+    # (H, W, crop y0, y1, x0, x1, window oy0, ox0, Hw, Ww)
+    (24, 32, 0, 24, 0, 32, 0, 0, 48, 64),          # the full op
+    (24, 32, 3, 20, 5, 30, 9, 13, 28, 40),
+    (96, 128, 8, 80, 0, 128, 24, 0, 130, 256),     # clipped at the left / right border
+    (17, 19, 0, 9, 10, 19, 0, 23, 15, 15),
+])
+def test_upsample_window_matches_full_op(align, geom):
+    H, W, cy0, cy1, cx0, cx1, oy0, ox0, Hw, Ww = geom
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 5, H, W, generator=g).cuda()
+    full = F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=align)
+    crop = x[:, :, cy0:cy1, cx0:cx1].contiguous().requires_grad_()
+    out = hip_ops.upsample_bilinear2x_window(crop, (H, W), (cy0, cx0), (oy0, ox0, Hw, Ww), align)
+    assert torch.equal(out, hip_ops.upsample_bilinear2x(x, align)[:, :, oy0:oy0 + Hw, ox0:ox0 + Ww])
+    assert (out - full[:, :, oy0:oy0 + Hw, ox0:ox0 + Ww]).abs().max() < 1e-6
+    # adjoint: gradient of the full op fed with a cotangent that is zero outside the window, cropped
+    go = torch.randn(out.shape, generator=g).cuda()
+    (gc,) = torch.autograd.grad(out, crop, go)
+    xr = x.clone().requires_grad_()
+    fr = F.interpolate(xr, scale_factor=2, mode='bilinear', align_corners=align)
+    gfull = torch.zeros_like(fr)
+    gfull[:, :, oy0:oy0 + Hw, ox0:ox0 + Ww] = go
+    (gx,) = torch.autograd.grad(fr, xr, gfull)
+    assert (gc - gx[:, :, cy0:cy1, cx0:cx1]).abs().max() < 2e-6
+    # nothing of the cotangent may land outside the crop (the window reads only the crop)
+    mask = torch.ones_like(gx, dtype=torch.bool)
+    mask[:, :, cy0:cy1, cx0:cx1] = False
+    assert gx[mask].abs().sum() == 0
+
+
+def test_upsample_window_rejects_window_outside_crop():
+    x = torch.zeros(1, 1, 8, 8).cuda()
+    with pytest.raises(_hip.SavfiHipError):
+        hip_ops.upsample_bilinear2x_window(x[:, :, 2:6, 2:6].contiguous(), (8, 8), (2, 2), (0, 0, 16, 16), True)
+
+
+@pytest.mark.parametrize("hw", [(64, 96), (78, 60), (256, 448)])
+def test_sepconv_windowed_tail_equals_full_canvas(hw):
+    """sepconv/model.py: the sub-networks / 51-tap op evaluated on the frame window give the values (and the
+    parameter / fast-weight gradients) of the reference's full-canvas evaluation (sepconv/model.py:309-349)."""
+    from meta_interpolation_amd import synthetic
+    from meta_interpolation_amd.sepconv.model import MetaNetwork
+    H, W = hw
+    nets = []
+    for windowed in (False, True):
+        net = MetaNetwork(windowed=windowed)
+        synthetic.load_seeded_weights(net, 'sepconv')
+        nets.append(net.cuda())
+    frames = synthetic.septuplet_batch(2, H, W, model='sepconv')
+    f0, f1, tgt = frames[2].cuda(), frames[4].cuda(), frames[3].cuda()
+    res = []
+    for net in nets:
+        out = net(f0, f1)
+        loss = (out - tgt).abs().mean()
+        names = [n for n, _ in net.named_parameters()]
+        grads = torch.autograd.grad(loss, list(net.parameters()))
+        res.append((out.detach(), dict(zip(names, grads))))
+    (o_full, g_full), (o_win, g_win) = res
+    assert o_win.shape == o_full.shape == (2, 3, H, W)
+    assert (o_win - o_full).abs().max() < 2e-6
+    for n in g_full:
+        ref = g_full[n]
+        assert (g_win[n] - ref).abs().max() <= 2e-5 * ref.abs().max() + 1e-9, n
