@@ -341,7 +341,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // geometry of the MFMA kernels: 8 waves = 2 row lanes x 4 column groups of 16 pixels; MROWS output rows
 // per workgroup are processed in phases of 2 rows.
-constexpr int MC = 64, MLW = 132, MSPAN = 116, MNT = 512, MROWS = 12;
+// MROWS is a template parameter (8 / 12 / 16) picked per launch so that the grid fills the 256 CUs in as few
+// rounds as possible (1 workgroup per CU: the window + tap rows take ~150 KB of LDS).
+constexpr int MC = 64, MLW = 132, MSPAN = 116, MNT = 512;
 constexpr int MKP = 52;   // rows per channel in the M dimension (51 taps + 1 zero row): lanes never straddle channels
 
 // Tap rows are PRIVATE to a wave: wave (wr, wc) needs h / v of its own 16 pixels only ([K][16] floats = 64-byte
@@ -366,7 +368,7 @@ __device__ __forceinline__ void mfma_store_taps(float* __restrict__ dst /* [>=K]
   }
 }
 
-template <int K>
+template <int K, int MROWS>
 __global__ __launch_bounds__(MNT) void sepconv_fwd_mfma(const float* __restrict__ in, const float* __restrict__ v,
                                                           const float* __restrict__ h, float* __restrict__ out,
                                                           int Ho, int Wo) {
@@ -512,7 +514,7 @@ __global__ __launch_bounds__(MNT) void sepconv_fwd_mfma(const float* __restrict_
 // band is stored element-wise (each lane owns a different tap plane: 16 stores of 4 B per instruction --
 // ~10 % of the MFMA time, and L2 merges the sectors before they reach HBM).
 // ------------------------------------------------------------------------------------------
-template <int K, bool WANT_V, bool WANT_H>
+template <int K, int MROWS, bool WANT_V, bool WANT_H>
 __global__ __launch_bounds__(MNT) void sepconv_bwd_mfma(const float* __restrict__ in, const float* __restrict__ v,
                                                        const float* __restrict__ h, const float* __restrict__ gO,
                                                        float* __restrict__ gV, float* __restrict__ gH,
@@ -754,16 +756,59 @@ bool mfma_ok(int Wo, const void* a, const void* b) {
   return Wo >= 1;
 }
 
-hipError_t set_bwd_mfma_lds(size_t lds) {
-  hipError_t e = hipFuncSetAttribute((const void*)sepconv_bwd_mfma<KFAST, true, true>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e == hipSuccess)
-    e = hipFuncSetAttribute((const void*)sepconv_bwd_mfma<KFAST, true, false>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e == hipSuccess)
-    e = hipFuncSetAttribute((const void*)sepconv_bwd_mfma<KFAST, false, true>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  return e;
+constexpr size_t mfma_lds_bytes(int rows) {
+  return ((size_t)3 * (rows + KFAST - 1) * MLW + (size_t)(MNT / 64) * (KFAST + MKP) * 16) * sizeof(float);
+}
+
+// Rows per workgroup: one workgroup per CU, so the launch takes ceil(workgroups / 256) rounds of ~(rows + 2) row
+// times each (the 2 stands for staging the 50-row halo and the prologue).  E.g. 256x448, B=2: 16 rows -> 224
+// workgroups in one round instead of 308 in two with 12; 384x512: 12 rows -> exactly 256 per image.
+int mfma_rows(int B, int Ho, int Wo) {
+  const int cand[3] = {12, 8, 16};
+  int best = 12;
+  long best_cost = -1;
+  for (int r : cand) {
+    const long wgs = (long)B * savfi_cdiv(Wo, MC) * savfi_cdiv(Ho, r);
+    const long cost = ((wgs + 255) / 256) * (r + 2);
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = r; }
+  }
+  if (const char* e = getenv("SAVFI_SEPCONV_MFMA_ROWS")) {
+    const int r = atoi(e);
+    if (r == 8 || r == 12 || r == 16) best = r;
+  }
+  return best;
+}
+
+template <int R>
+int launch_fwd_mfma(const float* in, const float* v, const float* h, float* out, int B, int Ho, int Wo, hipStream_t st) {
+  constexpr size_t lds = mfma_lds_bytes(R);
+  static_assert(lds <= 160 * 1024, "LDS per CU");
+  static const hipError_t attr = hipFuncSetAttribute((const void*)sepconv_fwd_mfma<KFAST, R>,
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (attr != hipSuccess) return (int)attr;
+  dim3 grid(savfi_cdiv(Wo, MC), savfi_cdiv(Ho, R), B);
+  hipLaunchKernelGGL((sepconv_fwd_mfma<KFAST, R>), grid, dim3(MNT), lds, st, in, v, h, out, Ho, Wo);
+  return savfi_launch_status();
+}
+
+template <int R, bool WV, bool WH>
+int launch_bwd_mfma_one(const float* in, const float* v, const float* h, const float* gO, float* gV, float* gH, int B,
+                        int Ho, int Wo, hipStream_t st) {
+  constexpr size_t lds = mfma_lds_bytes(R);
+  static const hipError_t attr = hipFuncSetAttribute((const void*)sepconv_bwd_mfma<KFAST, R, WV, WH>,
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (attr != hipSuccess) return (int)attr;
+  dim3 grid(savfi_cdiv(Wo, MC), savfi_cdiv(Ho, R), B);
+  hipLaunchKernelGGL((sepconv_bwd_mfma<KFAST, R, WV, WH>), grid, dim3(MNT), lds, st, in, v, h, gO, gV, gH, Ho, Wo);
+  return savfi_launch_status();
+}
+
+template <int R>
+int launch_bwd_mfma(const float* in, const float* v, const float* h, const float* gO, float* gV, float* gH, int B,
+                    int Ho, int Wo, hipStream_t st) {
+  if (gV && gH) return launch_bwd_mfma_one<R, true, true>(in, v, h, gO, gV, gH, B, Ho, Wo, st);
+  if (gV) return launch_bwd_mfma_one<R, true, false>(in, v, h, gO, gV, gH, B, Ho, Wo, st);
+  return launch_bwd_mfma_one<R, false, true>(in, v, h, gO, gV, gH, B, Ho, Wo, st);
 }
 
 hipError_t set_bwd_x2_lds(size_t lds) {
@@ -795,12 +840,11 @@ extern "C" int savfi_sepconv_fwd_f32(const float* in, const float* v, const floa
   if (int e = check_dims(B, C, Ho, Wo, K)) return e;
   hipStream_t st = (hipStream_t)stream;
   if (K == KFAST && C == 3 && mfma_ok(Wo, v, h) && !getenv("SAVFI_SEPCONV_NO_MFMA")) {
-    constexpr size_t lds = ((size_t)3 * (MROWS + KFAST - 1) * MLW + (size_t)(MNT / 64) * (KFAST + MKP) * 16) * sizeof(float);  // 150,944 B
-    static const hipError_t attr = hipFuncSetAttribute((const void*)sepconv_fwd_mfma<KFAST>,
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (attr != hipSuccess) return (int)attr;
-    dim3 grid(savfi_cdiv(Wo, MC), savfi_cdiv(Ho, MROWS), B);
-    hipLaunchKernelGGL(sepconv_fwd_mfma<KFAST>, grid, dim3(MNT), lds, st, in, v, h, out, Ho, Wo);
+    switch (mfma_rows(B, Ho, Wo)) {
+      case 8: return launch_fwd_mfma<8>(in, v, h, out, B, Ho, Wo, st);
+      case 16: return launch_fwd_mfma<16>(in, v, h, out, B, Ho, Wo, st);
+      default: return launch_fwd_mfma<12>(in, v, h, out, B, Ho, Wo, st);
+    }
   } else if (K == KFAST && x2_ok(Wo, in, v, h, out)) {
     dim3 grid(savfi_cdiv(Wo, T2X), savfi_cdiv(Ho, T2Y), B);
     hipLaunchKernelGGL(sepconv_fwd_x2<KFAST>, grid, dim3(NT), 0, st, in, v, h, out, C, Ho, Wo);
@@ -822,17 +866,13 @@ extern "C" int savfi_sepconv_bwd_f32(const float* in, const float* v, const floa
   hipStream_t st = (hipStream_t)stream;
   if (gV || gH) {
     if (K == KFAST && C == 3 && mfma_ok(Wo, v, h) && !getenv("SAVFI_SEPCONV_NO_MFMA")) {
-      constexpr size_t lds = ((size_t)3 * (MROWS + KFAST - 1) * MLW + (size_t)(MNT / 64) * (KFAST + MKP) * 16) * sizeof(float);
-      static const hipError_t attr = set_bwd_mfma_lds(lds);
-      if (attr != hipSuccess) return (int)attr;
-      dim3 grid(savfi_cdiv(Wo, MC), savfi_cdiv(Ho, MROWS), B);
-      if (gV && gH)
-        hipLaunchKernelGGL((sepconv_bwd_mfma<KFAST, true, true>), grid, dim3(MNT), lds, st, in, v, h, gO, gV, gH, Ho, Wo);
-      else if (gV)
-        hipLaunchKernelGGL((sepconv_bwd_mfma<KFAST, true, false>), grid, dim3(MNT), lds, st, in, v, h, gO, gV, gH, Ho, Wo);
-      else
-        hipLaunchKernelGGL((sepconv_bwd_mfma<KFAST, false, true>), grid, dim3(MNT), lds, st, in, v, h, gO, gV, gH, Ho, Wo);
-      if (int e = savfi_launch_status()) return e;
+      int e;
+      switch (mfma_rows(B, Ho, Wo)) {
+        case 8: e = launch_bwd_mfma<8>(in, v, h, gO, gV, gH, B, Ho, Wo, st); break;
+        case 16: e = launch_bwd_mfma<16>(in, v, h, gO, gV, gH, B, Ho, Wo, st); break;
+        default: e = launch_bwd_mfma<12>(in, v, h, gO, gV, gH, B, Ho, Wo, st); break;
+      }
+      if (e) return e;
     } else if (K == KFAST && C == 3 && x2_ok(Wo, gO, v, h, gV ? gV : gH) && x2_ok(Wo, gO, v, h, gH ? gH : gV)) {
       constexpr size_t lds = (size_t)3 * (T2Y + KFAST - 1) * T2LW * sizeof(float);  // 76032 B: 2 workgroups / CU
       static const hipError_t attr = set_bwd_x2_lds(lds);
