@@ -74,7 +74,7 @@ def main():
     ap.add_argument('--workload', default='c2_sepconv_256x448_b4_s5', choices=sorted(WORKLOADS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timer', action='store_true')
-    ap.add_argument('--fuse-conv-act', type=int, default=0)
+    ap.add_argument('--fuse-conv-act', type=int, default=1)
     ap.add_argument('--graph-inner-loop', type=int, default=0)
     ap.add_argument('--sepconv-window', type=int, default=1)
     opt = ap.parse_args()

@@ -4,7 +4,7 @@ config.py:14-77 so that its launch scripts (scripts/run_*.sh) keep working.  ``g
 
 Additions for the MI355X build (all optional, all default to the reference behaviour):
   --fuse_support_pairs {0,1}   run the two support triplets of an inner step as one N=2 forward
-  --fuse_conv_act {0,1}        conv+bias+(Leaky)ReLU with fused epilogue kernels (opt-in, first-order only)
+  --fuse_conv_act {0,1}        conv+bias+(Leaky)ReLU with fused epilogue kernels (default 1; first-order only)
   --graph_inner_loop {0,1}     replay the first-order inner loop from captured hipGraphs (graph_inner_loop.py)
   --sepconv_window {0,1}       SepConv: evaluate the sub-networks / 51-tap op on the frame window only (same values)
   --synthetic                  feed seeded synthetic septuplets instead of reading a dataset
@@ -40,7 +40,7 @@ _FLAGS = {
         ('use_tensorboard', 'flag', False), ('viz', 'flag', False), ('lpips', 'flag', False),
     ],
     'MI355X': [
-        ('fuse_support_pairs', int, 1), ('fuse_conv_act', int, 0), ('graph_inner_loop', int, 0), ('sepconv_window', int, 1),
+        ('fuse_support_pairs', int, 1), ('fuse_conv_act', int, 1), ('graph_inner_loop', int, 0), ('sepconv_window', int, 1),
         ('synthetic', 'flag', False),
     ],
 }

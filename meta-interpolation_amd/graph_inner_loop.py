@@ -18,7 +18,7 @@ Not captured (the caller falls back to the eager loop): --second_order, --attenu
 """
 import torch
 
-from . import _hip, hip_ops, utils
+from . import _hip, hip_ops, model_utils, utils
 
 
 def supported(system, use_second_order):
@@ -72,7 +72,11 @@ class GraphedInnerLoop:
         return [self.rule._lr(k, t) for k in self.routed]
 
     def _support_step(self, W, t):
-        out = self.net.forward(self.sup[0], self.sup[2], params=W, backup_running_statistics=(t == 0), num_step=t)
+        model_utils.OWN_PARAMS_CONST = True      # first-order support pass: non-routed parameters are constants
+        try:
+            out = self.net.forward(self.sup[0], self.sup[2], params=W, backup_running_statistics=(t == 0), num_step=t)
+        finally:
+            model_utils.OWN_PARAMS_CONST = False
         loss = self.crit(out[0:1], self.sup[1][0:1])['total'] + self.crit(out[1:2], self.sup[1][1:2])['total']
         g = torch.autograd.grad(loss, [W[k] for k in self.routed])
         ws = [W[k].detach() for k in self.routed]

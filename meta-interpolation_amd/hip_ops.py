@@ -335,7 +335,7 @@ class _ConvBiasAct(torch.autograd.Function):
         N, C, H, W = y.shape
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         gz = torch.empty_like(gy)
-        gb = torch.zeros(C, dtype=gy.dtype, device=gy.device) if need_b else None
+        gb = torch.zeros(C, dtype=gy.dtype, device=gy.device) if need_b else None     # atomically accumulated
         lib = _hip.lib()
         _hip.launch("bias_act_bwd", lambda: _hip.check(lib.savfi_bias_act_bwd_f32(
             gy.data_ptr(), y.data_ptr(), gz.data_ptr(), None if gb is None else gb.data_ptr(), N, C, H * W, slope,

@@ -156,6 +156,7 @@ class SceneAdaptiveInterpolation(nn.Module):
 
         self.criterion = criterion if criterion is not None else Loss(args)
         self.task_parallel = task_parallel if task_parallel is not None else TaskParallel()
+        self._first_order = False
         self._graphs = {}            # (frame shape, steps, training, msl) -> GraphedInnerLoop
         self._manual_grads = None    # OuterGradAccumulator of the last graphed training forward
 
@@ -207,6 +208,15 @@ class SceneAdaptiveInterpolation(nn.Module):
     def _support_loss(self, frames, task_id, weights, num_step):
         """Sum of the two support-triplet losses of one inner step (reference :387-396)."""
         a, b = self.support_idxs
+        # step 0 differentiates w.r.t. theta itself, whose non-routed tensors ARE the modules' own parameters
+        # (reference fact: 94 live tensors at step 0, 54 afterwards); from step 1 on those are constants
+        model_utils.OWN_PARAMS_CONST = self._first_order and num_step > 0
+        try:
+            return self._support_loss_impl(frames, task_id, weights, num_step, a, b)
+        finally:
+            model_utils.OWN_PARAMS_CONST = False
+
+    def _support_loss_impl(self, frames, task_id, weights, num_step, a, b):
         if self.fuse_support_pairs:
             sl = slice(task_id, task_id + 1)
             f0 = torch.cat([frames[a[0]][sl], frames[b[0]][sl]], 0)
@@ -298,6 +308,7 @@ class SceneAdaptiveInterpolation(nn.Module):
             return self._forward_graphed(frames, epoch, use_multi_step_loss_optimization, num_steps, training_phase,
                                          do_evaluation)
         hip_ops.DOUBLE_BACKWARD = bool(use_second_order)
+        self._first_order = not use_second_order
         # fused conv epilogues: opt-in, and first-order only
         model_utils.FUSE_CONV_ACT = bool(getattr(self.args, 'fuse_conv_act', 0)) and not use_second_order
         tp = self.task_parallel

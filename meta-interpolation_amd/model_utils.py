@@ -126,12 +126,17 @@ class PixelShuffle(nn.Module):
 # --------------------------------------------------------------------------------------------
 # Meta layers
 # --------------------------------------------------------------------------------------------
-# conv -> bias -> (Leaky)ReLU can run with fused epilogue kernels (hip_ops.conv_bias_act): it removes ~13 % of
-# the SepConv step's kernel time (bias add, clamp, threshold_backward, per-channel sum) but each fused call
-# goes through a Python autograd.Function + ctypes, and at 256x448 the inner loop is then host-bound
-# (measured 58.7 vs 62.3 inner steps/s, round 1) -- so it is opt-in (--fuse_conv_act 1) until the host side
-# is captured in a hipGraph.  The fused backward is first-order only (off under --second_order).
+# conv -> bias -> (Leaky)ReLU runs with fused epilogue kernels (hip_ops.conv_bias_act, --fuse_conv_act 1, the default):
+# bias add + clamp become one in-place pass over the conv output, threshold_backward + the per-channel bias-gradient
+# sum one pass over the cotangent (76.9 -> 82.4 inner steps/s on SepConv 256x448, eager).  The fused backward is
+# first-order only (off under --second_order).  Round-1 note: this was slower at first (58.7 vs 62.3) because a
+# custom Function cannot tell that autograd.grad() does not need its weight gradient - see OWN_PARAMS_CONST.
 FUSE_CONV_ACT = False
+# True while a first-order support pass runs: layers that use their OWN parameters (not the fast-weight dict) treat
+# them as constants.  The inner gradient is taken w.r.t. the fast weights only and its graph is dropped, so nothing
+# changes - but custom autograd Functions cannot see which of their inputs a particular autograd.grad() call
+# needs (ctx.needs_input_grad only says requires_grad) and would compute unused weight gradients.
+OWN_PARAMS_CONST = False
 
 
 def _act_slope(module):
@@ -163,6 +168,8 @@ class MetaConv2dLayer(nn.Module):
             pv = as_view(params)
             weight = pv.leaf("weight")
             bias = pv.leaf("bias") if self.use_bias else None
+        elif OWN_PARAMS_CONST:
+            weight, bias = self.weight.detach(), (self.bias.detach() if self.bias is not None else None)
         else:
             weight, bias = self.weight, self.bias
         if act_slope is not None and bias is not None and x.is_cuda and FUSE_CONV_ACT:
