@@ -83,6 +83,8 @@ def main():
     from meta_interpolation_amd.config import default_args
     from meta_interpolation_amd.meta_learning_system import MODEL_REGISTRY, SceneAdaptiveInterpolation
 
+    if os.environ.get('SAVFI_MIOPEN_FIND'):     # experiment: let MIOpen benchmark its solvers per conv shape
+        torch.backends.cudnn.benchmark = True
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     rank, world, local_rank = task_parallel.init_from_env()
@@ -150,7 +152,8 @@ def main():
             line["kernels"] = summ
             k = summ.get("sepconv_bwd")
             if k:
-                ph, pw = net.padded_size(H, W)
+                # the op runs on the frame window (H x W) or, with --sepconv-window 0, on the reference's padded canvas
+                oh, ow = (H, W) if opt.sepconv_window else net.padded_size(H, W)
                 traffic, tnote = None, "no committed PMC measurement found"
                 tpath = os.path.join(REPO, "profiles", "r01_hbm_traffic_sepconv.json")
                 if os.path.exists(tpath):
@@ -158,17 +161,22 @@ def main():
                     # (tools/hbm_traffic.py; FETCH_SIZE x2 per the gfx950 calibration), scaled to this run's
                     # B=1 / B=2 launch mix through the measured traffic / algorithmic ratio of each shape
                     tk = json.load(open(tpath))["kernels"]
-                    ratio = 0.5 * (tk["sepconv_bwd_B1"]["traffic_over_algorithmic"] + tk["sepconv_bwd_B2"]["traffic_over_algorithmic"])
-                    traffic = ratio * k["algorithmic_bytes"] / k["launches"]
-                    tnote = "PMC (FETCH_SIZE*2 + WRITE_SIZE) = %.3f x algorithmic, profiles/r01_hbm_traffic_sepconv.json" % ratio
+                    keys = ["sepconv_bwd_B%d_%dx%d" % (b, oh, ow) for b in (1, 2)]
+                    if all(kk in tk for kk in keys):
+                        ratio = 0.5 * sum(tk[kk]["traffic_over_algorithmic"] for kk in keys)
+                        traffic = ratio * k["algorithmic_bytes"] / k["launches"]
+                        tnote = ("PMC (FETCH_SIZE*2 + WRITE_SIZE) = %.3f x algorithmic at %dx%d, "
+                                 "profiles/r01_hbm_traffic_sepconv.json" % (ratio, oh, ow))
+                per_call = 4.0 * (3 * (oh + 50) * (ow + 50) + 4 * 51 * oh * ow + 3 * oh * ow)
                 line["roofline"] = {
                     "bound": "hbm", "kernel": "sepconv_bwd_mfma (gV+gH, K=51)",
                     "achieved": k["achieved_GBps"], "peak": 8000.0, "unit": "GB/s",
                     "frac": k["achieved_GBps"] / 8000.0, "traffic": traffic, "traffic_source": tnote,
                     "avg_us_per_launch": k["avg_us"], "launches": k["launches"],
                     "algorithmic_bytes_per_launch": k["algorithmic_bytes"] / k["launches"],
-                    "note": "algorithmic bytes = 165.72 MB per [1,3,%d,%d] call (x2 for the fused N=2 support "
-                            "pair); fp32 VALU ceiling of this kernel is ~53%% of HBM peak (SURVEY.md 7)" % (ph, pw)}
+                    "note": "algorithmic bytes = %.2f MB per [1,3,%d,%d] call (x2 for the fused N=2 support "
+                            "pair); fp32 issue ceiling of this kernel is ~53%% of HBM peak (SURVEY.md 7)"
+                            % (per_call / 1e6, oh, ow)}
         if world == 1 and not opt.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(model, H, W, over)
         print(json.dumps(line), flush=True)

@@ -193,6 +193,22 @@ int savfi_upsample2x_window_fwd_f32(const float* in, float* out, int planes, int
 int savfi_upsample2x_window_bwd_f32(const float* gout, float* gin, int planes, int H, int W, int sy0, int sx0,
                                     int Hs, int Ws, int oy0, int ox0, int Hw, int Ww, int align_corners, void* stream);
 
+/* ----------------------------------------------------------------------------------
+ * 3x3 / stride 1 / zero-pad 1 convolution of the backbones (sepconv/model.py:172-245 Basic / Subnet /
+ * Upsample blocks through model_utils.py:308-366 MetaConv2dLayer -> F.conv2d; cain, voxelflow likewise):
+ * Winograd F(2x2,3x3) with its 16 batched GEMMs on the fp32 matrix cores, one fused kernel.
+ *   mode 0  forward:        out[N,Co,H+2p-2,W+2p-2] = act(conv2d(x[N,Ci,H,W], w[Co,Ci,3,3], zero pad p) + bias)
+ *                           (p = pad in {0,1}; bias may be NULL)
+ *   mode 1  data gradient of that convolution:  x = gy[N,Co,H,W] -> out = gx[N,Ci,H+2-2p,W+2-2p]
+ *                           (bias ignored, pass slope 1)
+ * act(v) = v > 0 ? v : slope * v  (slope 1 = none, 0 = ReLU).  `workspace` is caller-owned device memory of
+ * savfi_conv3x3_workspace_floats(K, I) floats (K = reduction channels, I = produced channels: (Ci, Co) for mode 0,
+ * (Co, Ci) for mode 1); it receives the transformed filter and may be reused by the next call on the same stream.
+ * ---------------------------------------------------------------------------------- */
+int64_t savfi_conv3x3_workspace_floats(int K, int I);
+int savfi_conv3x3_f32(const float* x, const float* w, const float* bias, float* out, float* workspace,
+                      int N, int Ci, int Co, int H, int W, int pad, int mode, float slope, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,6 +51,8 @@ _PROTOTYPES = {
     "savfi_l1_mse_bwd_f32": [c_int, _P, _P, _P, _P, c_int64, _P],
     "savfi_upsample2x_fwd_f32": [_P, _P, c_int, c_int, c_int, c_int, _P],
     "savfi_upsample2x_bwd_f32": [_P, _P, c_int, c_int, c_int, c_int, _P],
+    "savfi_conv3x3_workspace_floats": [c_int, c_int],
+    "savfi_conv3x3_f32": [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P],
     "savfi_upsample2x_window_fwd_f32": [_P, _P] + [c_int] * 12 + [_P],
     "savfi_upsample2x_window_bwd_f32": [_P, _P] + [c_int] * 12 + [_P],
     "savfi_bias_act_fwd_f32": [_P, _P, c_int, c_int, c_int, c_float, _P],
@@ -86,7 +88,7 @@ def lib():
         except AttributeError:
             raise SavfiHipError("%s does not export %s" % (LIB_PATH, name))
         fn.argtypes = argtypes
-        fn.restype = c_int
+        fn.restype = c_int64 if name == 'savfi_conv3x3_workspace_floats' else c_int
     got = handle.savfi_version()
     if got != ABI_VERSION:
         raise SavfiHipError("libsavfi_hip ABI %d != expected %d; rebuild" % (got, ABI_VERSION))

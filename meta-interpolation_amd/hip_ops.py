@@ -348,6 +348,26 @@ class _ConvBiasAct(torch.autograd.Function):
         return gx, gw, gb, None, None, None, None, None
 
 
+def conv3x3(x, weight, bias=None, mode=0, slope=1.0, pad=1):
+    """savfi_conv3x3_f32 without autograd.  mode 0: act(conv2d(x, weight, padding=pad) + bias); mode 1: the data
+    gradient of that convolution (x = gy [N,Co,H,W] -> gx [N,Ci,H+2-2pad,W+2-2pad])."""
+    x = x.contiguous()
+    weight = weight.contiguous()
+    _hip.require_cuda(x, weight)
+    N, _, H, W = x.shape
+    Co, Ci = weight.shape[:2]
+    assert tuple(weight.shape[2:]) == (3, 3) and x.shape[1] == (Ci if mode == 0 else Co), (x.shape, weight.shape, mode)
+    K, I = (Ci, Co) if mode == 0 else (Co, Ci)
+    grow = 2 * (pad if mode == 0 else 2 - pad) - 2
+    lib = _hip.lib()
+    ws = torch.empty(int(lib.savfi_conv3x3_workspace_floats(K, I)), dtype=x.dtype, device=x.device)
+    out = torch.empty((N, I, H + grow, W + grow), dtype=x.dtype, device=x.device)
+    _hip.launch("conv3x3_fwd" if mode == 0 else "conv3x3_bwd_data", lambda: _hip.check(lib.savfi_conv3x3_f32(
+        x.data_ptr(), weight.data_ptr(), None if bias is None else bias.data_ptr(), out.data_ptr(), ws.data_ptr(),
+        N, Ci, Co, H, W, int(pad), mode, float(slope), _hip.current_stream()), "savfi_conv3x3_f32"))
+    return out
+
+
 def conv_bias_act(x, weight, bias, stride=1, padding=0, dilation=1, groups=1, slope=0.0):
     """act(conv2d(x, weight) + bias) with act = LeakyReLU(slope) (0 -> ReLU, 1 -> identity)."""
     return _ConvBiasAct.apply(x, weight, bias, stride, padding, dilation, groups, float(slope))

@@ -309,3 +309,51 @@ def test_sepconv_windowed_tail_equals_full_canvas(hw):
     for n in g_full:
         ref = g_full[n]
         assert (g_win[n] - ref).abs().max() <= 2e-5 * ref.abs().max() + 1e-9, n
+
+
+# ---------------------------------------------------------------------------------------------
+# Winograd F(2x2,3x3) convolution on the fp32 matrix cores
+# ---------------------------------------------------------------------------------------------
+CONV_SHAPES = [
+    # N, Ci, Co, H, W
+    (1, 8, 64, 16, 64),       # exactly one tile block
+    (2, 6, 32, 24, 40),       # padded Ci / Co, ragged tile block
+    (1, 64, 51, 37, 45),      # odd sizes, Co = 51
+    (2, 51, 51, 18, 30),
+    (1, 128, 128, 48, 64),
+    (1, 3, 5, 5, 7),
+]
+
+
+@pytest.mark.parametrize("pad", [1, 0])
+@pytest.mark.parametrize("shape", CONV_SHAPES)
+def test_conv3x3_forward_matches_conv2d(shape, pad):
+    N, Ci, Co, H, W = shape
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(N, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (3 * Ci ** 0.5)
+    b = torch.randn(Co, generator=g)
+    want = F.conv2d(x.double(), w.double(), b.double(), padding=pad)
+    got = hip_ops.conv3x3(x.cuda(), w.cuda(), b.cuda(), mode=0, slope=1.0, pad=pad).cpu().double()
+    scale = want.abs().max()
+    assert got.shape == want.shape
+    assert (got - want).abs().max() <= 2e-6 * scale
+    got = hip_ops.conv3x3(x.cuda(), w.cuda(), b.cuda(), mode=0, slope=0.0, pad=pad).cpu().double()
+    assert (got - F.relu(want)).abs().max() <= 2e-6 * scale
+    got = hip_ops.conv3x3(x.cuda(), w.cuda(), None, mode=0, slope=0.2, pad=pad).cpu().double()
+    assert (got - F.leaky_relu(F.conv2d(x.double(), w.double(), None, padding=pad), 0.2)).abs().max() <= 2e-6 * scale
+
+
+@pytest.mark.parametrize("pad", [1, 0])
+@pytest.mark.parametrize("shape", CONV_SHAPES)
+def test_conv3x3_data_gradient_matches_autograd(shape, pad):
+    N, Ci, Co, H, W = shape
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(N, Ci, H, W, generator=g).double().requires_grad_()
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (3 * Co ** 0.5)
+    y = F.conv2d(x, w.double(), None, padding=pad)
+    gy = torch.randn(y.shape, generator=g)
+    (want,) = torch.autograd.grad(y, x, gy.double())
+    got = hip_ops.conv3x3(gy.cuda(), w.cuda(), None, mode=1, slope=1.0, pad=pad).cpu().double()
+    assert got.shape == want.shape
+    assert (got - want).abs().max() <= 2e-6 * want.abs().max()

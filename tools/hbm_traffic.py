@@ -14,6 +14,19 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CAL_BYTES = 512 * 1024 * 1024
+# (B, Ho, Wo): the full padded canvas of the reference and the frame window this build evaluates (sepconv/model.py)
+CASES = [(1, 384, 512), (2, 384, 512), (1, 256, 448), (2, 256, 448)]
+
+
+def mfma_rows(B, Ho, Wo):
+    """csrc/sepconv.hip mfma_rows(): rows per workgroup of the MFMA kernels."""
+    best, best_cost = 12, None
+    for r in (12, 8, 16):
+        wgs = B * -(-Wo // 64) * -(-Ho // r)
+        cost = -(-wgs // 256) * (r + 2)
+        if best_cost is None or cost < best_cost:
+            best, best_cost = r, cost
+    return best
 
 
 def run():
@@ -25,8 +38,8 @@ def run():
     bb = torch.empty_like(a)
     for _ in range(3):
         bb.copy_(a)
-    for B in (1, 2):
-        C, Ho, Wo, K = 3, 384, 512, 51
+    for (B, Ho, Wo) in CASES:
+        C, K = 3, 51
         inp = torch.rand(B, C, Ho + K - 1, Wo + K - 1, device='cuda')
         v = torch.randn(B, K, Ho, Wo, device='cuda') / 7
         h = torch.randn(B, K, Ho, Wo, device='cuda') / 7
@@ -51,6 +64,8 @@ def _collect(d, counter):
                'sepconv_fwd' if 'sepconv_fwd' in name else 'sepconv_bwd' if 'sepconv_bwd' in name else None)
         if key is None:
             continue
+        if key != 'copy':      # template arguments <51, ROWS, ...>: two cases can share a grid size
+            key += '/' + name.split('<')[1].split('>')[0].split(',')[1].strip()
         out.setdefault((key, grid), []).append(float(row['Counter_Value']))
     return {k: sum(v) / len(v) for k, v in out.items()}
 
@@ -70,12 +85,18 @@ def parse(dfetch, dwrite):
         if k == 'copy':
             continue
         wv = w.get((k, g), 0.0)
-        B = 2 if int(g) >= 2 * 512 * 512 else 1
-        alg = algorithmic_bytes(B, 3, 384, 512, 51, grads=2 if k == 'sepconv_bwd' else 0)
+        kind, rows = k.split('/')
+        case = [c for c in CASES if mfma_rows(*c) == int(rows)
+                and c[0] * -(-c[2] // 64) * -(-c[1] // int(rows)) * 512 == int(g)]
+        if len(case) != 1:
+            continue
+        B, Ho, Wo = case[0]
+        alg = algorithmic_bytes(B, 3, Ho, Wo, 51, grads=2 if kind == 'sepconv_bwd' else 0)
         rd, wr = val * 1024 * corr_f, wv * 1024 * corr_w
-        res["kernels"]["%s_B%d" % (k, B)] = {"grid": int(g), "FETCH_SIZE_KiB": val, "WRITE_SIZE_KiB": wv,
-                                             "hbm_read_bytes": rd, "hbm_write_bytes": wr, "traffic": rd + wr,
-                                             "algorithmic_bytes": alg, "traffic_over_algorithmic": (rd + wr) / alg}
+        res["kernels"]["%s_B%d_%dx%d" % (kind, B, Ho, Wo)] = {
+            "grid": int(g), "rows_per_workgroup": int(rows), "FETCH_SIZE_KiB": val, "WRITE_SIZE_KiB": wv,
+            "hbm_read_bytes": rd, "hbm_write_bytes": wr, "traffic": rd + wr, "algorithmic_bytes": alg,
+            "traffic_over_algorithmic": (rd + wr) / alg}
     print(json.dumps(res, indent=1))
 
 

@@ -1,0 +1,15 @@
+import ctypes, sys, torch
+lib = ctypes.CDLL(sys.argv[1])
+P, I = ctypes.c_void_p, ctypes.c_int
+lib.savfi_conv3x3_f32.argtypes = [P, P, P, P, P, I, I, I, I, I, I, I, ctypes.c_float, P]
+lib.savfi_conv3x3_workspace_floats.restype = ctypes.c_int64
+dev = torch.device('cuda')
+for (ci, co, h, w) in [(32, 32, 384, 512), (64, 64, 192, 256), (128, 128, 96, 128), (256, 256, 48, 64)]:
+    x = torch.randn(2, ci, h, w, device=dev); wt = torch.randn(co, ci, 3, 3, device=dev) / 30; b = torch.randn(co, device=dev)
+    out = torch.empty(2, co, h, w, device=dev)
+    ws = torch.empty(int(lib.savfi_conv3x3_workspace_floats(ci, co)), device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(5):
+        rc = lib.savfi_conv3x3_f32(x.data_ptr(), wt.data_ptr(), b.data_ptr(), out.data_ptr(), ws.data_ptr(), 2, ci, co, h, w, 1, 0, 0.0, st)
+        assert rc == 0, rc
+torch.cuda.synchronize()
