@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define SAVFI_ABI_VERSION 1
+#define SAVFI_ABI_VERSION 2
 
 #define SAVFI_OK            0
 #define SAVFI_E_NULL       (-1)  /* a required pointer is NULL                          */
@@ -166,11 +166,13 @@ int savfi_l1_mse_bwd_f32(int kind, const float* a, const float* b, const float* 
  * Convolution epilogue: bias + activation, in place on the conv output z [N,C,H*W]:
  *   z <- act(z + bias[c]),  act(x) = x > 0 ? x : slope*x   (slope 0 ReLU, 0.2 LeakyReLU, 1 bias only)
  * bwd: gz = gy * act'(y) with y the forward OUTPUT (sign(y) == sign(z+b) for slope >= 0);
- *      gbias[c] += sum over n, hw of gz (may be NULL; zero-filled by the caller; one atomic per workgroup).
- *      gz may alias gy.
+ *      gbias[c] = sum over n, hw of gz (may be NULL; fully overwritten; deterministic: per-workgroup partial sums
+ *      go to `scratch` (caller-owned, savfi_bias_act_scratch_floats(N, C, HW) floats) and are added in a fixed order).
+ *      gz may alias gy; gz may be NULL when only the bias gradient is wanted (slope 1: gz == gy).
  * ---------------------------------------------------------------------------------- */
 int savfi_bias_act_fwd_f32(float* z, const float* bias, int N, int C, int HW, float slope, void* stream);
-int savfi_bias_act_bwd_f32(const float* gy, const float* y, float* gz, float* gbias,
+int64_t savfi_bias_act_scratch_floats(int N, int C, int HW);
+int savfi_bias_act_bwd_f32(const float* gy, const float* y, float* gz, float* gbias, float* scratch,
                            int N, int C, int HW, float slope, void* stream);
 
 /* ------------------------------------------------------------------------------------

@@ -16,7 +16,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_PKG_DIR), "include", "savfi_hip.h")
 
 RULE_SGD, RULE_ADAM, RULE_ADAMAX_LSLR, RULE_ADAMAX_MSGD = 0, 1, 2, 3
 LR_SCALAR, LR_ELEMENT = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _ERRORS = {-1: "SAVFI_E_NULL (a required pointer is NULL)",
            -2: "SAVFI_E_SHAPE (bad or inconsistent dimension)",
@@ -56,7 +56,8 @@ _PROTOTYPES = {
     "savfi_upsample2x_window_fwd_f32": [_P, _P] + [c_int] * 12 + [_P],
     "savfi_upsample2x_window_bwd_f32": [_P, _P] + [c_int] * 12 + [_P],
     "savfi_bias_act_fwd_f32": [_P, _P, c_int, c_int, c_int, c_float, _P],
-    "savfi_bias_act_bwd_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_float, _P],
+    "savfi_bias_act_scratch_floats": [c_int, c_int, c_int],
+    "savfi_bias_act_bwd_f32": [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P],
 }
 
 _lib = None
@@ -66,7 +67,7 @@ def declared_symbols():
     """Function names declared in include/savfi_hip.h (used by the symbol-export test)."""
     with open(HEADER_PATH) as fh:
         text = fh.read()
-    return sorted(set(re.findall(r"^\s*int\s+(savfi_\w+)\s*\(", text, flags=re.M)))
+    return sorted(set(re.findall(r"^\s*(?:int|int64_t)\s+(savfi_\w+)\s*\(", text, flags=re.M)))
 
 
 def lib():
@@ -88,7 +89,7 @@ def lib():
         except AttributeError:
             raise SavfiHipError("%s does not export %s" % (LIB_PATH, name))
         fn.argtypes = argtypes
-        fn.restype = c_int64 if name == 'savfi_conv3x3_workspace_floats' else c_int
+        fn.restype = c_int64 if name in ('savfi_conv3x3_workspace_floats', 'savfi_bias_act_scratch_floats') else c_int
     got = handle.savfi_version()
     if got != ABI_VERSION:
         raise SavfiHipError("libsavfi_hip ABI %d != expected %d; rebuild" % (got, ABI_VERSION))

@@ -6,7 +6,8 @@
 // (sepconv/model.py:172-194 Basic/Subnet blocks; model_utils.py:957-990 RCAB with LeakyReLU(0.2)).
 // At 384x512 those elementwise passes are ~13 % of the inner step's GPU time.  Here:
 //   fwd:  y = act(z + b[c])            in place on the conv output, one read + one write
-//   bwd:  gz = gy * act'(y),  gb[c] += sum gz      one pass: two reads, one write, one atomic / workgroup
+//   bwd:  gz = gy * act'(y),  gb[c] = sum gz       one pass: two reads, one write, one partial sum / workgroup,
+//         then a fixed-order sum of the partials (deterministic: no atomics)
 // act(x) = x > 0 ? x : slope * x   (slope 0 = ReLU, 0.2 = CAIN's LeakyReLU, 1 = bias only).
 // Pure HBM streaming: one workgroup per 4096-element chunk of an (n, c) plane, float4 per lane.
 #include "common.h"
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(NT) void bias_act_fwd(float* __restrict__ z, const 
 }
 
 __global__ __launch_bounds__(NT) void bias_act_bwd(const float* __restrict__ gy, const float* __restrict__ y,
-                                                   float* __restrict__ gz, float* __restrict__ gbias, int C, int HW,
+                                                   float* __restrict__ gz, float* __restrict__ partial, int C, int HW,
                                                    int chunks, float slope, int vec_ok) {
   __shared__ float red[NT / SAVFI_WAVE];
   const int plane = blockIdx.x / chunks, ch = blockIdx.x - plane * chunks;
@@ -51,17 +52,30 @@ __global__ __launch_bounds__(NT) void bias_act_bwd(const float* __restrict__ gy,
       const float4 g = *reinterpret_cast<const float4*>(gy + off + e);
       const float4 o = *reinterpret_cast<const float4*>(y + off + e);
       const float4 r = make_float4(d(g.x, o.x), d(g.y, o.y), d(g.z, o.z), d(g.w, o.w));
-      *reinterpret_cast<float4*>(gz + off + e) = r;
+      if (gz) *reinterpret_cast<float4*>(gz + off + e) = r;
       acc += (r.x + r.y) + (r.z + r.w);
     }
-    for (int e = vend + threadIdx.x; e < end; e += NT) { const float r = d(gy[off + e], y[off + e]); gz[off + e] = r; acc += r; }
+    for (int e = vend + threadIdx.x; e < end; e += NT) { const float r = d(gy[off + e], y[off + e]); if (gz) gz[off + e] = r; acc += r; }
   } else {
-    for (int e = base + threadIdx.x; e < end; e += NT) { const float r = d(gy[off + e], y[off + e]); gz[off + e] = r; acc += r; }
+    for (int e = base + threadIdx.x; e < end; e += NT) { const float r = d(gy[off + e], y[off + e]); if (gz) gz[off + e] = r; acc += r; }
   }
-  if (gbias) {
+  if (partial) {     // one partial sum per (plane, chunk); reduced in a fixed order by bias_grad_finish (deterministic)
     const float tot = block_sum<NT / SAVFI_WAVE>(acc, red);
-    if (threadIdx.x == 0) atomicAdd(&gbias[plane % C], tot);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
   }
+}
+
+// gbias[c] = sum over n and chunks of partial[(n * C + c) * chunks + ch], always in the same order
+__global__ __launch_bounds__(64) void bias_grad_finish(const float* __restrict__ partial, float* __restrict__ gbias, int N, int C,
+                                                       int chunks) {
+  const int c = blockIdx.x;
+  float acc = 0.f;
+  for (int n = 0; n < N; ++n) {
+    const float* p = partial + ((size_t)n * C + c) * chunks;
+    for (int i = threadIdx.x; i < chunks; i += 64) acc += p[i];
+  }
+  acc = wave_sum(acc);
+  if (threadIdx.x == 0) gbias[c] = acc;
 }
 
 }  // namespace
@@ -77,15 +91,25 @@ extern "C" int savfi_bias_act_fwd_f32(float* z, const float* bias, int N, int C,
   return savfi_launch_status();
 }
 
-extern "C" int savfi_bias_act_bwd_f32(const float* gy, const float* y, float* gz, float* gbias, int N, int C, int HW,
-                                      float slope, void* stream) {
-  if (!gy || !y || !gz) return SAVFI_E_NULL;
+extern "C" int64_t savfi_bias_act_scratch_floats(int N, int C, int HW) {
+  if (N <= 0 || C <= 0 || HW <= 0) return SAVFI_E_SHAPE;
+  return (int64_t)N * C * savfi_cdiv(HW, CHUNK);
+}
+
+extern "C" int savfi_bias_act_bwd_f32(const float* gy, const float* y, float* gz, float* gbias, float* scratch, int N, int C,
+                                      int HW, float slope, void* stream) {
+  if (!gy || !y || (!gz && !gbias) || (gbias && !scratch)) return SAVFI_E_NULL;   // gz may be NULL: bias gradient only
   if (N <= 0 || C <= 0 || HW <= 0) return SAVFI_E_SHAPE;
   const int chunks = savfi_cdiv(HW, CHUNK);
   const int64_t blocks = (int64_t)N * C * chunks;
   if (blocks > 0x7fffffffLL) return SAVFI_E_TOOBIG;
-  const int vec_ok = ((((uintptr_t)gy | (uintptr_t)y | (uintptr_t)gz) & 15u) == 0) && (HW % 4 == 0);
-  hipLaunchKernelGGL(bias_act_bwd, dim3((unsigned)blocks), dim3(NT), 0, (hipStream_t)stream, gy, y, gz, gbias, C, HW, chunks,
-                     slope, vec_ok);
-  return savfi_launch_status();
+  const int vec_ok = ((((uintptr_t)gy | (uintptr_t)y | (uintptr_t)gz) & 15u) == 0) && (HW % 4 == 0);   // NULL gz is "aligned"
+  hipLaunchKernelGGL(bias_act_bwd, dim3((unsigned)blocks), dim3(NT), 0, (hipStream_t)stream, gy, y, gz, gbias ? scratch : nullptr,
+                     C, HW, chunks, slope, vec_ok);
+  if (int e = savfi_launch_status()) return e;
+  if (gbias) {
+    hipLaunchKernelGGL(bias_grad_finish, dim3(C), dim3(64), 0, (hipStream_t)stream, scratch, gbias, N, C, chunks);
+    return savfi_launch_status();
+  }
+  return SAVFI_OK;
 }

@@ -3,6 +3,8 @@
 Every function here launches a hand-written gfx950 kernel through the C ABI (include/savfi_hip.h)
 on torch's current stream.  Device tensors only -- there is no CPU or eager-PyTorch fallback.
 """
+import os
+
 import torch
 from torch.autograd.function import once_differentiable
 
@@ -307,22 +309,50 @@ def mse_loss(a, b):
 # --------------------------------------------------------------------------------------------
 # conv + bias + (leaky) ReLU with fused epilogues   (sepconv/model.py:172-194, model_utils.py:957-990)
 # --------------------------------------------------------------------------------------------
+# 3x3 / stride 1 convolutions with many output tiles run on savfi_conv3x3_f32 (Winograd on the fp32 matrix cores,
+# bias + activation in its epilogue); below these tile counts MIOpen's kernels are faster (tools/conv_bench.py,
+# profiles/r01_conv_bench.jsonl).  tiles = N * ceil(Ho/2) * ceil(Wo/2).
+WINOGRAD_CONV = not os.environ.get('SAVFI_NO_WINOGRAD')
+WINO_MIN_TILES_FWD = 12000
+WINO_MIN_TILES_BWD = 20000
+
+
+def conv3x3_eligible(x, weight, stride, padding, dilation, groups, backward=False):
+    if not (WINOGRAD_CONV and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
+        return False
+    one = lambda v, k: (v == k) if isinstance(v, int) else all(t == k for t in v)
+    pad = padding if isinstance(padding, int) else (padding[0] if padding[0] == padding[1] else -1)
+    if tuple(weight.shape[2:]) != (3, 3) or not one(stride, 1) or not one(dilation, 1) or groups != 1 or pad not in (0, 1):
+        return False
+    N, _, H, W = x.shape
+    Ho, Wo = H + 2 * pad - 2, W + 2 * pad - 2
+    if Ho < 1 or Wo < 1 or H * W < 4:
+        return False
+    tiles = N * ((Ho + 1) // 2) * ((Wo + 1) // 2)
+    return tiles >= (WINO_MIN_TILES_BWD if backward else WINO_MIN_TILES_FWD)
+
+
 class _ConvBiasAct(torch.autograd.Function):
-    """y = act(conv2d(x, w) + b).  The convolution itself stays on MIOpen; the bias add and activation
-    run as ONE in-place kernel on its output, and the backward computes act' * gy and the bias gradient
-    in one pass before handing the result to MIOpen's data / weight gradient kernels.  First-order only
-    (the backward is not differentiable): callers use the unfused ops under --second_order."""
+    """y = act(conv2d(x, w) + b).  Large 3x3 convolutions run on the savfi Winograd/MFMA kernel with bias and
+    activation in its epilogue; the others stay on MIOpen with the bias add and activation as ONE in-place kernel
+    on the output.  The backward computes act' * gy and the bias gradient in one pass, then the data gradient
+    (savfi kernel or MIOpen) and the weight gradient (MIOpen).  First-order only (the backward is not
+    differentiable): callers use the unfused ops under --second_order."""
 
     @staticmethod
     def forward(ctx, x, w, b, stride, padding, dilation, groups, slope):
-        z = torch.nn.functional.conv2d(x, w, None, stride, padding, dilation, groups)
-        if not z.is_contiguous():
-            z = z.contiguous()
-        _hip.require_cuda(z, b)
-        N, C, H, W = z.shape
-        lib = _hip.lib()
-        _hip.launch("bias_act_fwd", lambda: _hip.check(lib.savfi_bias_act_fwd_f32(
-            z.data_ptr(), b.data_ptr(), N, C, H * W, slope, _hip.current_stream()), "savfi_bias_act_fwd_f32"))
+        pad = padding if isinstance(padding, int) else padding[0]
+        if conv3x3_eligible(x, w, stride, padding, dilation, groups):
+            z = conv3x3(x, w, b, 0, slope, pad)
+        else:
+            z = torch.nn.functional.conv2d(x, w, None, stride, padding, dilation, groups)
+            if not z.is_contiguous():
+                z = z.contiguous()
+            _hip.require_cuda(z, b)
+            N, C, H, W = z.shape
+            lib = _hip.lib()
+            _hip.launch("bias_act_fwd", lambda: _hip.check(lib.savfi_bias_act_fwd_f32(
+                z.data_ptr(), b.data_ptr(), N, C, H * W, slope, _hip.current_stream()), "savfi_bias_act_fwd_f32"))
         ctx.conf = (stride, padding, dilation, groups, slope)
         ctx.save_for_backward(x, w, z)
         return z
@@ -334,17 +364,26 @@ class _ConvBiasAct(torch.autograd.Function):
         gy = gy.contiguous()
         N, C, H, W = y.shape
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
-        gz = torch.empty_like(gy)
-        gb = torch.zeros(C, dtype=gy.dtype, device=gy.device) if need_b else None     # atomically accumulated
-        lib = _hip.lib()
-        _hip.launch("bias_act_bwd", lambda: _hip.check(lib.savfi_bias_act_bwd_f32(
-            gy.data_ptr(), y.data_ptr(), gz.data_ptr(), None if gb is None else gb.data_ptr(), N, C, H * W, slope,
-            _hip.current_stream()), "savfi_bias_act_bwd_f32"))
+        identity = slope == 1.0                  # no activation: gz is gy itself, only the bias gradient is computed
+        gz = gy if identity else torch.empty_like(gy)
+        gb = torch.empty(C, dtype=gy.dtype, device=gy.device) if need_b else None
+        if need_b or not identity:
+            lib = _hip.lib()
+            scratch = (torch.empty(int(lib.savfi_bias_act_scratch_floats(N, C, H * W)), dtype=gy.dtype, device=gy.device)
+                       if need_b else None)
+            _hip.launch("bias_act_bwd", lambda: _hip.check(lib.savfi_bias_act_bwd_f32(
+                gy.data_ptr(), (gy if identity else y).data_ptr(), None if identity else gz.data_ptr(),
+                None if gb is None else gb.data_ptr(), None if scratch is None else scratch.data_ptr(),
+                N, C, H * W, slope, _hip.current_stream()), "savfi_bias_act_bwd_f32"))
         gx = gw = None
+        if need_x and conv3x3_eligible(x, w, stride, padding, dilation, groups, backward=True):
+            gx = conv3x3(gz, w, None, 1, 1.0, padding if isinstance(padding, int) else padding[0])
+            need_x = False
         if need_x or need_w:
             pair = lambda v: [v, v] if isinstance(v, int) else list(v)
-            gx, gw, _ = torch.ops.aten.convolution_backward(gz, x, w, None, pair(stride), pair(padding), pair(dilation),
-                                                            False, [0, 0], groups, [need_x, need_w, False])
+            gx2, gw, _ = torch.ops.aten.convolution_backward(gz, x, w, None, pair(stride), pair(padding), pair(dilation),
+                                                             False, [0, 0], groups, [need_x, need_w, False])
+            gx = gx2 if need_x else gx
         return gx, gw, gb, None, None, None, None, None
 
 

@@ -172,9 +172,13 @@ class MetaConv2dLayer(nn.Module):
             weight, bias = self.weight.detach(), (self.bias.detach() if self.bias is not None else None)
         else:
             weight, bias = self.weight, self.bias
-        if act_slope is not None and bias is not None and x.is_cuda and FUSE_CONV_ACT:
-            return hip_ops.conv_bias_act(x, weight, bias, self.stride, padding, self.dilation_rate, self.groups,
-                                         act_slope)
+        if bias is not None and x.is_cuda and FUSE_CONV_ACT:
+            if act_slope is not None:
+                return hip_ops.conv_bias_act(x, weight, bias, self.stride, padding, self.dilation_rate, self.groups,
+                                             act_slope)
+            if hip_ops.conv3x3_eligible(x, weight, self.stride, padding, self.dilation_rate, self.groups):
+                # no activation follows: still worth the savfi kernel (bias in its epilogue) for large maps
+                return hip_ops.conv_bias_act(x, weight, bias, self.stride, padding, self.dilation_rate, self.groups, 1.0)
         out = F.conv2d(x, weight, bias, self.stride, padding, self.dilation_rate, self.groups)
         if act_slope is not None:
             out = F.relu(out) if act_slope == 0.0 else F.leaky_relu(out, act_slope)

@@ -12,6 +12,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True, scope="session")
+def _deterministic_library_kernels():
+    """MIOpen's default fp32 solvers are not run-to-run reproducible on gfx950: the weight-gradient kernels of every
+    layer and the forward / data-gradient kernels of the deep 4x4..16x16 layers accumulate with atomics (bit-level
+    survey: profiles/r01_determinism_survey.txt; every savfi kernel is bit-reproducible).  Through the L1 loss (sign
+    flips of out - target) and VoxelFlow's warp that 3e-7 noise occasionally becomes a 1e-4-level deviation of a
+    gradient fingerprint, i.e. flaky parity gates.  The parity tests therefore pin MIOpen to its deterministic
+    solvers; bench.py and the product default do not."""
+    import torch
+    if torch.cuda.is_available():
+        torch.backends.cudnn.deterministic = True
+    yield
+
+
 def pytest_collection_modifyitems(config, items):
     """GPU tests must not silently pass on a box without a GPU: they fail loudly when selected."""
     import torch

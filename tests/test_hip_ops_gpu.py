@@ -357,3 +357,36 @@ def test_conv3x3_data_gradient_matches_autograd(shape, pad):
     got = hip_ops.conv3x3(gy.cuda(), w.cuda(), None, mode=1, slope=1.0, pad=pad).cpu().double()
     assert got.shape == want.shape
     assert (got - want).abs().max() <= 2e-6 * want.abs().max()
+
+
+def test_sepconv_with_winograd_convs_equals_miopen_convs():
+    """BASELINE config-2 frame size: the backbone's large 3x3 convolutions on savfi_conv3x3_f32 (forward with fused
+    bias + ReLU, data gradient) give the network output and every parameter gradient of the MIOpen path.
+    A smooth loss is used: with L1 a 1e-7 output difference flips sign(out - target) for a few pixels."""
+    from meta_interpolation_amd import model_utils as mu, synthetic
+    from meta_interpolation_amd.sepconv.model import MetaNetwork
+    net = MetaNetwork()
+    synthetic.load_seeded_weights(net, 'sepconv')
+    net = net.cuda()
+    frames = synthetic.septuplet_batch(2, 256, 448, model='sepconv')
+    f0, f1, tgt = frames[2].cuda(), frames[4].cuda(), frames[3].cuda()
+    res = []
+    mu.FUSE_CONV_ACT = True
+    calls = []
+    orig = hip_ops.conv3x3
+    try:
+        for wino in (False, True):
+            hip_ops.WINOGRAD_CONV = wino
+            hip_ops.conv3x3 = (lambda *a, **k: (calls.append(a[3] if len(a) > 3 else k.get('mode', 0)), orig(*a, **k))[1])
+            out = net(f0, f1)
+            loss = ((out - tgt) ** 2).mean()
+            res.append((out.detach(), torch.autograd.grad(loss, list(net.parameters()))))
+    finally:
+        mu.FUSE_CONV_ACT = False
+        hip_ops.WINOGRAD_CONV = True
+        hip_ops.conv3x3 = orig
+    assert calls.count(0) >= 20 and calls.count(1) >= 8, calls          # forward and data-gradient launches happened
+    (o_mi, g_mi), (o_wi, g_wi) = res
+    assert (o_wi - o_mi).abs().max() < 5e-6
+    for (n, _), a, b in zip(net.named_parameters(), g_wi, g_mi):
+        assert (a - b).abs().max() <= 2e-4 * b.abs().max() + 1e-12, n

@@ -21,17 +21,29 @@ LAYERS = [(6, 32, 384, 512), (32, 32, 384, 512), (32, 64, 192, 256), (64, 64, 19
           (64, 64, 136, 233), (64, 51, 136, 233), (51, 51, 258, 450)]
 
 
-def timeit(fn, iters):
-    for _ in range(3):
-        fn()
+def timeit(fn, iters, reps=10):
+    """Device time per call: `reps` calls captured in one hipGraph (no host gaps between the kernels, filter
+    transform / layout kernels included), median over `iters` replays."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(reps):
+            fn()
+    g.replay()
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
     for a, b in ev:
         a.record()
-        fn()
+        g.replay()
         b.record()
     torch.cuda.synchronize()
-    ts = sorted(a.elapsed_time(b) * 1e3 for a, b in ev)
+    ts = sorted(a.elapsed_time(b) * 1e3 / reps for a, b in ev)
     return ts[len(ts) // 2]
 
 
@@ -55,9 +67,9 @@ def main():
         t_mi_b = timeit(lambda: torch.ops.aten.convolution_backward(gy, x, wt, None, [1, 1], [1, 1], [1, 1], False, [0, 0],
                                                                     1, [True, False, False]), o.iters)
         t_my_b = timeit(lambda: hip_ops.conv3x3(gy, wt, None, 1, 1.0), o.iters)
-        print(json.dumps({"layer": "%dx%d->%d @%dx%d N=%d" % (ci, 3, co, h, w, o.n), "gflop": round(gflop, 2),
+        print(json.dumps({"layer": "%d->%d @%dx%d N=%d" % (ci, co, h, w, o.n), "gflop": round(gflop, 2),
                           "fwd_miopen_us": round(t_mi_f, 1), "fwd_savfi_us": round(t_my_f, 1),
-                          "fwd_savfi_TFLOPs_direct_equiv": round(gflop / t_my_f * 1e3, 1),
+                          "fwd_savfi_TFLOPs_direct_equiv": round(gflop / t_my_f * 1e3, 1), "fwd_ratio": round(t_mi_f / t_my_f, 2), "bwd_ratio": round(t_mi_b / t_my_b, 2),
                           "bwd_miopen_us": round(t_mi_b, 1), "bwd_savfi_us": round(t_my_b, 1),
                           "rel_err_vs_miopen": err}), flush=True)
 
