@@ -97,9 +97,12 @@ def main():
                         number_of_training_steps_per_iter=S, number_of_evaluation_steps_per_iter=S,
                         fuse_conv_act=opt.fuse_conv_act, graph_inner_loop=opt.graph_inner_loop,
                         sepconv_window=opt.sepconv_window, **over)
-    net = MODEL_REGISTRY[model](args, False)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):      # the ONE line on stdout is the JSON result
+        net = MODEL_REGISTRY[model](args, False)
     synthetic.load_seeded_weights(net, model)          # identical theta on every rank, no broadcast
-    system = SceneAdaptiveInterpolation(args, net=net.to(dev))
+    with contextlib.redirect_stdout(sys.stderr):
+        system = SceneAdaptiveInterpolation(args, net=net.to(dev))
     if args.attenuate:   # L2F: non-trivial seeded attenuator (gamma_mult = 0 would make it a no-op)
         sd, gm = synthetic.seeded_attenuator_state(len(system.inner_loop_optimizer.names_learning_rates_dict))
         system.attenuator.load_state_dict(sd)
