@@ -28,6 +28,13 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
+# MIOpen records solver choices per problem shape in a user find-db (~/.config/miopen) and re-uses them in later
+# processes - including choices made under torch.backends.cudnn.deterministic=True by the parity tests, which are
+# several times slower (measured: 86 -> 15 steps/s when bench.py ran after the test suite on the same box).  The
+# benchmark therefore always starts from an empty, private find-db: the numbers are those of a fresh box.
+import tempfile  # noqa: E402
+os.environ['MIOPEN_USER_DB_PATH'] = tempfile.mkdtemp(prefix='savfi_bench_miopen_')
+
 import torch  # noqa: E402
 
 WORKLOADS = {

@@ -3,6 +3,13 @@ import sys
 
 import pytest
 
+import tempfile
+
+# The GPU tests pin MIOpen to deterministic solvers (fixture below).  MIOpen would record those choices in the user
+# find-db (~/.config/miopen) and later processes - bench.py, training runs - would silently re-use them at several
+# times lower speed.  Keep the test suite's find-db private and throw-away.
+os.environ['MIOPEN_USER_DB_PATH'] = tempfile.mkdtemp(prefix='savfi_tests_miopen_')
+
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
