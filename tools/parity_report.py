@@ -1,9 +1,16 @@
 """Run every reference-generated system fixture through the HIP product path and print the deviations
 (one JSON line per case and phase).  The -m gpu tests assert on these quantities; this tool shows the
-margins.  Usage (GPU box): python tools/parity_report.py > gpurun_out/parity.jsonl"""
+margins.  Usage (GPU box): python tools/parity_report.py [--deterministic 0|1] [--repeat N] > gpurun_out/parity.jsonl
+
+--deterministic 1 (default) pins MIOpen to its deterministic solvers like tests/conftest.py does; with 0 the report
+shows one draw of MIOpen's run-to-run noise on top."""
+import argparse
 import json
 import os
 import sys
+import tempfile
+
+os.environ['MIOPEN_USER_DB_PATH'] = tempfile.mkdtemp(prefix='savfi_parity_miopen_')   # see bench.py
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402
@@ -23,7 +30,13 @@ def fp_dev(got, want):
 
 
 def main():
-    for name in CASES:
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--deterministic', type=int, default=1)
+    ap.add_argument('--repeat', type=int, default=1)
+    ap.add_argument('--cases', default=','.join(CASES))
+    o = ap.parse_args()
+    torch.backends.cudnn.deterministic = bool(o.deterministic)
+    for name in [c for c in o.cases.split(',') for _ in range(o.repeat)]:
         g = golden("system_" + name)
         model = str(g['model'])
         for phase in ('train', 'val'):
@@ -36,7 +49,7 @@ def main():
                 losses, preds, metrics = system.run_validation_iter(data_batch=frames)
             torch.cuda.synchronize()
             got = torch.stack([p.squeeze(0) for p in preds]).cpu().numpy()
-            row = dict(case=name, phase=phase,
+            row = dict(case=name, phase=phase, miopen_deterministic=bool(o.deterministic),
                        loss_rel=abs(losses['loss'].item() - float(g[phase + '_loss'])) / abs(float(g[phase + '_loss'])),
                        pixel_l1=float(np.abs(got - g[phase + '_preds']).mean()),
                        dpsnr=abs(metrics['psnr'].avg - float(g[phase + '_psnr'])),
