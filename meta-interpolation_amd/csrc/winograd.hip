@@ -428,10 +428,7 @@ extern "C" int savfi_conv3x3_f32(const float* x, const float* w, const float* bi
   hipLaunchKernelGGL(wino_filter_transform, dim3(savfi_cdiv(KP * IP, 256)), dim3(256), 0, st, w, workspace, Co, Ci, K, I,
                      KP, IP, mode);
   if (int e = savfi_launch_status()) return e;
-  constexpr size_t lds = (size_t)LDS_FLOATS * sizeof(float);
-  static const hipError_t attr = hipFuncSetAttribute((const void*)wino_conv3x3, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                     (int)lds);
-  if (attr != hipSuccess) return (int)attr;
+  constexpr size_t lds = (size_t)LDS_FLOATS * sizeof(float);      // 40 KB: two workgroups per CU
   WinoArgs a{x, workspace, mode == 0 ? bias : nullptr, out, K, I, KP, IP, H, W, Ho, Wo, off, th, tw, slope};
   hipLaunchKernelGGL(wino_conv3x3, dim3(th * tw, IP / COB, N), dim3(WNT), lds, st, a);
   return savfi_launch_status();
