@@ -204,10 +204,11 @@ int savfi_upsample2x_window_bwd_f32(const float* gout, float* gin, int planes, i
  *   mode 1  data gradient of that convolution:  x = gy[N,Co,H,W] -> out = gx[N,Ci,H+2-2p,W+2-2p]
  *                           (bias ignored, pass slope 1)
  * act(v) = v > 0 ? v : slope * v  (slope 1 = none, 0 = ReLU).  `workspace` is caller-owned device memory of
- * savfi_conv3x3_workspace_floats(K, I) floats (K = reduction channels, I = produced channels: (Ci, Co) for mode 0,
- * (Co, Ci) for mode 1); it receives the transformed filter and may be reused by the next call on the same stream.
+ * savfi_conv3x3_workspace_floats(same N, Ci, Co, H, W, pad, mode) floats; it receives the transformed filter and, for
+ * deep layers whose reduction channels are split over workgroups, the partial outputs; it may be reused by the next
+ * call on the same stream.
  * ---------------------------------------------------------------------------------- */
-int64_t savfi_conv3x3_workspace_floats(int K, int I);
+int64_t savfi_conv3x3_workspace_floats(int N, int Ci, int Co, int H, int W, int pad, int mode);
 int savfi_conv3x3_f32(const float* x, const float* w, const float* bias, float* out, float* workspace,
                       int N, int Ci, int Co, int H, int W, int pad, int mode, float slope, void* stream);
 

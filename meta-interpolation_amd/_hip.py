@@ -51,7 +51,7 @@ _PROTOTYPES = {
     "savfi_l1_mse_bwd_f32": [c_int, _P, _P, _P, _P, c_int64, _P],
     "savfi_upsample2x_fwd_f32": [_P, _P, c_int, c_int, c_int, c_int, _P],
     "savfi_upsample2x_bwd_f32": [_P, _P, c_int, c_int, c_int, c_int, _P],
-    "savfi_conv3x3_workspace_floats": [c_int, c_int],
+    "savfi_conv3x3_workspace_floats": [c_int] * 7,
     "savfi_conv3x3_f32": [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P],
     "savfi_upsample2x_window_fwd_f32": [_P, _P] + [c_int] * 12 + [_P],
     "savfi_upsample2x_window_bwd_f32": [_P, _P] + [c_int] * 12 + [_P],

@@ -98,6 +98,8 @@ struct WinoArgs {
   float* out;
   int K, I, KP, IP, H, W, Ho, Wo, off, tiles_y, tiles_x;   // input H x W, output Ho x Wo, patch origin 2t - off;
   float slope;                                             // tiles_* = number of TBH x TBW tile blocks
+  int nsplit, chunks_per_split;                            // reduction channels split over workgroups (deep layers)
+  float* partial;                                          // nsplit > 1: raw partial outputs [split][N][I][Ho][Wo]
 };
 
 // The 4x4 patch of a thread sits at the same (y, x) for every channel: its row offsets and the zero-padding mask are
@@ -260,7 +262,9 @@ __global__ __launch_bounds__(WNT, 2) void wino_conv3x3(WinoArgs a) {
 
   const int tb = blockIdx.x;                       // tile block within the image
   const int tby = tb / a.tiles_x, tbx = tb - tby * a.tiles_x;
-  const int i0 = blockIdx.y * COB;                 // first produced channel
+  const int nblk = a.IP / COB;
+  const int cob = blockIdx.y % nblk, sp = blockIdx.y / nblk;       // channel block, reduction split
+  const int i0 = cob * COB;                        // first produced channel
   const int n = blockIdx.z;
   const float* xp = a.x + (size_t)n * a.K * a.H * a.W;
   const size_t cplane = (size_t)a.H * a.W;
@@ -277,9 +281,10 @@ __global__ __launch_bounds__(WNT, 2) void wino_conv3x3(WinoArgs a) {
       for (int t = 0; t < 4; ++t) acc[c][cb][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // A fragments of this wave for chunk c: 2 x f32x4 at ((c * nblk + blockIdx.y) * 4 + w) * 64 lanes * 32 bytes
-  const int nblk = a.IP / COB, nchunk = a.KP / CIB;
+  // this workgroup reduces over chunks [cbeg, nchunk) of the KP / CIB chunks (an even count)
+  const int cbeg = sp * a.chunks_per_split, nchunk = min(cbeg + a.chunks_per_split, a.KP / CIB);
   const size_t ustride = (size_t)nblk * 4 * 64 * 32;                                     // bytes per chunk
-  const char* ubase = reinterpret_cast<const char*>(a.U) + ((size_t)blockIdx.y * 4 + w) * 64 * 32;
+  const char* ubase = reinterpret_cast<const char*>(a.U) + ((size_t)cob * 4 + w) * 64 * 32;
   const unsigned ulane = (unsigned)lane * 32u;
   auto plane_of = [&](int chunk) { return xp + (size_t)min(min(chunk, nchunk - 1) * CIB + w, a.K - 1) * cplane; };
   auto u_of = [&](int chunk) { return ubase + (size_t)min(chunk, nchunk - 1) * ustride; };
@@ -291,22 +296,22 @@ __global__ __launch_bounds__(WNT, 2) void wino_conv3x3(WinoArgs a) {
   // prologue: P(0) -> V(0); P(1), P(2), A(0), A(1) in flight / resident
   float dA[16], dB[16];        // dA: patches of even chunks, dB: odd chunks
   f32x4 afrA[2], afrB[2];
-  load_patch(dA, plane_of(0), patch);
-  load_patch(dB, plane_of(1), patch);
-  afrA[0] = *reinterpret_cast<const f32x4*>(u_of(0) + ulane);
-  afrA[1] = *reinterpret_cast<const f32x4*>(u_of(0) + ulane + 16);
-  afrB[0] = *reinterpret_cast<const f32x4*>(u_of(1) + ulane);
-  afrB[1] = *reinterpret_cast<const f32x4*>(u_of(1) + ulane + 16);
+  load_patch(dA, plane_of(cbeg), patch);
+  load_patch(dB, plane_of(cbeg + 1), patch);
+  afrA[0] = *reinterpret_cast<const f32x4*>(u_of(cbeg) + ulane);
+  afrA[1] = *reinterpret_cast<const f32x4*>(u_of(cbeg) + ulane + 16);
+  afrB[0] = *reinterpret_cast<const f32x4*>(u_of(cbeg + 1) + ulane);
+  afrB[1] = *reinterpret_cast<const f32x4*>(u_of(cbeg + 1) + ulane + 16);
   {
     float v[16];
     if (fixup & 2) shift_patch(dA, patch);
-    if (fixup & 1) mask_patch(dA, patch, w < a.K);
+    if (fixup & 1) mask_patch(dA, patch, cbeg * CIB + w < a.K);
     input_transform(v, dA);
     float* vb = lds + w * VS + lane;
 #pragma unroll
     for (int xi = 0; xi < 16; ++xi) vb[xi * CIB * VS] = v[xi];
   }
-  load_patch(dA, plane_of(2), patch);
+  load_patch(dA, plane_of(cbeg + 2), patch);
   // Everything the prologue loaded must have landed before the loop: otherwise the compiler's wait-count bookkeeping
   // carries "may still be in flight" into the loop header and, vmcnt being in-order, makes every iteration wait for
   // its own freshly issued prefetches before the first MFMA.
@@ -315,7 +320,7 @@ __global__ __launch_bounds__(WNT, 2) void wino_conv3x3(WinoArgs a) {
 
   const int vwoff = w * VS + lane;                    // V write: [xi][k = w][tile = lane]
   const int vroff = (4 * w) * CIB * VS + kg * VS + j; // V read:  [xi = 4w + c][k = kg][tile = 16 t + j]
-  for (int ch = 0; ch < ((WINO_ABL & 32) ? 0 : nchunk); ch += 2) {
+  for (int ch = cbeg; ch < ((WINO_ABL & 32) ? 0 : nchunk); ch += 2) {
     // even chunk: MFMAs on V(0) with A(ch); transforms P(ch+1) = dB -> V(1); reloads dB <- P(ch+3), afrA <- A(ch+2)
     chunk_body(acc, afrA, lds + vroff, dB, patch, fixup, min(ch + 1, nchunk - 1) * CIB + w < a.K, lds + VBUF + vwoff,
                plane_of(ch + 3), u_of(ch + 2), ulane);
@@ -376,16 +381,18 @@ __global__ __launch_bounds__(WNT, 2) void wino_conv3x3(WinoArgs a) {
         y[1][c] = s[1][c] - s[2][c] - s[3][c];
       }
       if (i < a.I) {
-        const float b = a.bias ? a.bias[i] : 0.f;
+        const float b = (a.bias && a.nsplit == 1) ? a.bias[i] : 0.f;
         const int oty = tby * TBH + (t >> 4), otx = tbx * TBW + (t & 15);
         const int oy = 2 * oty, ox = 2 * otx;
-        float* op = a.out + (((size_t)n * a.I + i) * a.Ho + oy) * a.Wo + ox;
+        float* obase = a.nsplit == 1 ? a.out : a.partial + (size_t)sp * gridDim.z * a.I * a.Ho * a.Wo;
+        const float slope = a.nsplit == 1 ? a.slope : 1.f;       // bias / activation happen in wino_split_reduce
+        float* op = obase + (((size_t)n * a.I + i) * a.Ho + oy) * a.Wo + ox;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
           if (oy + r >= a.Ho) break;
           float v0 = y[r][0] + b, v1 = y[r][1] + b;
-          v0 = v0 > 0.f ? v0 : a.slope * v0;
-          v1 = v1 > 0.f ? v1 : a.slope * v1;
+          v0 = v0 > 0.f ? v0 : slope * v0;
+          v1 = v1 > 0.f ? v1 : slope * v1;
           float* o = op + (size_t)r * a.Wo;
           if (vec_ok && ox + 1 < a.Wo) *reinterpret_cast<float2*>(o) = make_float2(v0, v1);
           else {
@@ -399,13 +406,67 @@ __global__ __launch_bounds__(WNT, 2) void wino_conv3x3(WinoArgs a) {
   }
 }
 
+// out = act(sum over splits of partial (fixed order: deterministic) + bias[c])
+__global__ __launch_bounds__(256) void wino_split_reduce(const float* __restrict__ partial, const float* __restrict__ bias,
+                                                         float* __restrict__ out, int nsplit, size_t total, int I, int HW,
+                                                         float slope) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  float acc = 0.f;
+  for (int s = 0; s < nsplit; ++s) acc += partial[(size_t)s * total + e];
+  if (bias) acc += bias[(e / HW) % I];
+  out[e] = acc > 0.f ? acc : slope * acc;
+}
+
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// Launch plan shared by the workspace query and the launch.  Deep layers have few tiles and many reduction channels
+// (256->256 at 48x64: 192 workgroups x 64 chunks on 512 slots): the chunks are split over up to 8 workgroups whose
+// raw partial outputs are added by wino_split_reduce.
+struct WinoPlan {
+  int K, I, KP, IP, off, Ho, Wo, th, tw, nsplit, chunks_per_split;
+  int64_t u_floats, partial_floats;
+};
+
+bool make_plan(WinoPlan& p, int N, int Ci, int Co, int H, int W, int pad, int mode) {
+  p.K = mode == 0 ? Ci : Co;
+  p.I = mode == 0 ? Co : Ci;       // reduction / produced channels
+  p.KP = round_up(p.K, 2 * CIB);   // an even number of chunks (see the channel loop)
+  p.IP = round_up(p.I, COB);
+  // forward: patch origin 2t - pad; gradient of a pad-p convolution = pad-(2-p) correlation with the flipped filter
+  p.off = mode == 0 ? pad : 2 - pad;
+  p.Ho = H + 2 * p.off - 2;
+  p.Wo = W + 2 * p.off - 2;
+  if (p.Ho <= 0 || p.Wo <= 0) return false;
+  p.th = savfi_cdiv(savfi_cdiv(p.Ho, 2), TBH);
+  p.tw = savfi_cdiv(savfi_cdiv(p.Wo, 2), TBW);
+  const int nchunk = p.KP / CIB;
+  const int64_t wgs = (int64_t)p.th * p.tw * (p.IP / COB) * N;
+  // split only launches that would leave workgroup slots empty (2 per CU x 256 CUs): the partial outputs cost an
+  // extra pass, which loses on launches that already fill the chip (64->64 at 192x256: 64 -> 87 us when split)
+  static const int slots = getenv("SAVFI_WINO_SPLIT_SLOTS") ? atoi(getenv("SAVFI_WINO_SPLIT_SLOTS")) : 512;
+  int want = (int)(slots / wgs);
+  want = want < 1 ? 1 : (want > 8 ? 8 : want);
+  int cps = round_up(savfi_cdiv(nchunk, want), 2);
+  if (cps < 8) cps = nchunk < 8 ? nchunk : 8;          // at least 8 chunks per workgroup (prologue / output stage cost)
+  p.chunks_per_split = cps;
+  p.nsplit = savfi_cdiv(nchunk, cps);
+  if (const char* e = getenv("SAVFI_WINO_NO_SPLIT")) { (void)e; p.nsplit = 1; p.chunks_per_split = nchunk; }
+  p.u_floats = (int64_t)16 * p.KP * p.IP;
+  p.partial_floats = p.nsplit > 1 ? (int64_t)p.nsplit * N * p.I * p.Ho * p.Wo : 0;
+  return true;
+}
+
+
 
 }  // namespace
 
-extern "C" int64_t savfi_conv3x3_workspace_floats(int K, int I) {
-  if (K <= 0 || I <= 0) return SAVFI_E_SHAPE;
-  return (int64_t)16 * round_up(K, 2 * CIB) * round_up(I, COB);
+extern "C" int64_t savfi_conv3x3_workspace_floats(int N, int Ci, int Co, int H, int W, int pad, int mode) {
+  if (N <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return SAVFI_E_SHAPE;
+  if ((mode != 0 && mode != 1) || (pad != 0 && pad != 1)) return SAVFI_E_UNSUPPORTED;
+  WinoPlan p;
+  if (!make_plan(p, N, Ci, Co, H, W, pad, mode)) return SAVFI_E_SHAPE;
+  return p.u_floats + p.partial_floats;
 }
 
 // mode 0: out[n][co] = act(conv2d(x[n], w, zero padding `pad`)[co] + bias[co])   x [N][Ci][H][W] -> [N][Co][H+2pad-2][W+2pad-2]
@@ -415,21 +476,26 @@ extern "C" int savfi_conv3x3_f32(const float* x, const float* w, const float* bi
   if (!x || !w || !out || !workspace) return SAVFI_E_NULL;
   if (N <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return SAVFI_E_SHAPE;
   if ((mode != 0 && mode != 1) || (pad != 0 && pad != 1) || (int64_t)H * W < 4) return SAVFI_E_UNSUPPORTED;   // rows are 16-byte loads
-  const int K = mode == 0 ? Ci : Co, I = mode == 0 ? Co : Ci;       // reduction / produced channels
-  const int KP = round_up(K, 2 * CIB), IP = round_up(I, COB);      // an even number of chunks (see the channel loop)
-  // forward: patch origin 2t - pad; gradient of a pad-p convolution = pad-(2-p) correlation with the flipped filter
-  const int off = mode == 0 ? pad : 2 - pad;
-  const int Ho = H + 2 * off - 2, Wo = W + 2 * off - 2;
-  if (Ho <= 0 || Wo <= 0) return SAVFI_E_SHAPE;
+  WinoPlan p;
+  if (!make_plan(p, N, Ci, Co, H, W, pad, mode)) return SAVFI_E_SHAPE;
   if ((int64_t)H * W >= ((int64_t)1 << 29)) return SAVFI_E_TOOBIG;     // 32-bit byte offsets inside a channel plane
-  const int th = savfi_cdiv(savfi_cdiv(Ho, 2), TBH), tw = savfi_cdiv(savfi_cdiv(Wo, 2), TBW);
-  if ((int64_t)th * tw > 0x7fffffffLL || IP / COB > 65535 || N > 65535) return SAVFI_E_TOOBIG;
+  if ((int64_t)p.th * p.tw > 0x7fffffffLL || (int64_t)(p.IP / COB) * p.nsplit > 65535 || N > 65535) return SAVFI_E_TOOBIG;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(wino_filter_transform, dim3(savfi_cdiv(KP * IP, 256)), dim3(256), 0, st, w, workspace, Co, Ci, K, I,
-                     KP, IP, mode);
+  hipLaunchKernelGGL(wino_filter_transform, dim3(savfi_cdiv(p.KP * p.IP, 256)), dim3(256), 0, st, w, workspace, Co, Ci, p.K,
+                     p.I, p.KP, p.IP, mode);
   if (int e = savfi_launch_status()) return e;
   constexpr size_t lds = (size_t)LDS_FLOATS * sizeof(float);      // 40 KB: two workgroups per CU
-  WinoArgs a{x, workspace, mode == 0 ? bias : nullptr, out, K, I, KP, IP, H, W, Ho, Wo, off, th, tw, slope};
-  hipLaunchKernelGGL(wino_conv3x3, dim3(th * tw, IP / COB, N), dim3(WNT), lds, st, a);
-  return savfi_launch_status();
+  const float* b = mode == 0 ? bias : nullptr;
+  float* partial = workspace + p.u_floats;
+  WinoArgs a{x, workspace, b, out, p.K, p.I, p.KP, p.IP, H, W, p.Ho, p.Wo, p.off, p.th, p.tw, slope, p.nsplit,
+             p.chunks_per_split, partial};
+  hipLaunchKernelGGL(wino_conv3x3, dim3(p.th * p.tw, (p.IP / COB) * p.nsplit, N), dim3(WNT), lds, st, a);
+  if (int e = savfi_launch_status()) return e;
+  if (p.nsplit > 1) {
+    const size_t total = (size_t)N * p.I * p.Ho * p.Wo;
+    hipLaunchKernelGGL(wino_split_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, partial, b, out, p.nsplit, total,
+                       p.I, p.Ho * p.Wo, slope);
+    return savfi_launch_status();
+  }
+  return SAVFI_OK;
 }

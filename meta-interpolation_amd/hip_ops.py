@@ -310,8 +310,10 @@ def mse_loss(a, b):
 # conv + bias + (leaky) ReLU with fused epilogues   (sepconv/model.py:172-194, model_utils.py:957-990)
 # --------------------------------------------------------------------------------------------
 # 3x3 / stride 1 convolutions with many output tiles run on savfi_conv3x3_f32 (Winograd on the fp32 matrix cores,
-# bias + activation in its epilogue); below these tile counts MIOpen's kernels are faster (tools/conv_bench.py,
-# profiles/r01_conv_bench.jsonl).  tiles = N * ceil(Ho/2) * ceil(Wo/2).
+# bias + activation in its epilogue); tiles = N * ceil(Ho/2) * ceil(Wo/2).  Thresholds from tools/conv_bench.py
+# (profiles/r01_conv_bench.jsonl): above them the kernel is 1.2-1.6x faster than MIOpen.  With the reduction-channel
+# split it is also on par or slightly ahead for the N=2 deep layers (down to 24x32), but routing those through it did
+# not move the meta-iteration (87.2 vs 86.8 steps/s: two more small launches per call), so they stay on MIOpen.
 WINOGRAD_CONV = not os.environ.get('SAVFI_NO_WINOGRAD')
 WINO_MIN_TILES_FWD = 12000
 WINO_MIN_TILES_BWD = 20000
@@ -399,7 +401,7 @@ def conv3x3(x, weight, bias=None, mode=0, slope=1.0, pad=1):
     K, I = (Ci, Co) if mode == 0 else (Co, Ci)
     grow = 2 * (pad if mode == 0 else 2 - pad) - 2
     lib = _hip.lib()
-    ws = torch.empty(int(lib.savfi_conv3x3_workspace_floats(K, I)), dtype=x.dtype, device=x.device)
+    ws = torch.empty(int(lib.savfi_conv3x3_workspace_floats(N, Ci, Co, H, W, int(pad), mode)), dtype=x.dtype, device=x.device)
     out = torch.empty((N, I, H + grow, W + grow), dtype=x.dtype, device=x.device)
     _hip.launch("conv3x3_fwd" if mode == 0 else "conv3x3_bwd_data", lambda: _hip.check(lib.savfi_conv3x3_f32(
         x.data_ptr(), weight.data_ptr(), None if bias is None else bias.data_ptr(), out.data_ptr(), ws.data_ptr(),

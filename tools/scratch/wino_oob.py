@@ -22,7 +22,7 @@ for it in range(120):
     x = torch.randn(n, K, h, w, device=dev)
     wt = torch.randn(co, ci, 3, 3, device=dev) / 10
     b = torch.randn(co, device=dev)
-    nws = int(lib.savfi_conv3x3_workspace_floats(K, I))
+    nws = int(lib.savfi_conv3x3_workspace_floats(n, ci, co, h, w, pad, mode))
     nout = n * I * ho * wo
     wsb = torch.full((nws + 2 * G,), 7.25, device=dev)
     outb = torch.full((nout + 2 * G,), 7.25, device=dev)

@@ -7,7 +7,7 @@ dev = torch.device('cuda')
 for (ci, co, h, w) in [(64, 32, 64, 512)]:
     x = torch.randn(2, ci, h, w, device=dev); wt = torch.randn(co, ci, 3, 3, device=dev) / 30; b = torch.randn(co, device=dev)
     out = torch.empty(2, co, h, w, device=dev)
-    ws = torch.empty(int(lib.savfi_conv3x3_workspace_floats(ci, co)), device=dev)
+    ws = torch.empty(int(lib.savfi_conv3x3_workspace_floats(2, ci, co, h, w, 1, 0)), device=dev)
     st = torch.cuda.current_stream().cuda_stream
     for _ in range(5):
         rc = lib.savfi_conv3x3_f32(x.data_ptr(), wt.data_ptr(), b.data_ptr(), out.data_ptr(), ws.data_ptr(), 2, ci, co, h, w, 1, 0, 0.0, st)
