@@ -27,10 +27,6 @@
 // The data gradient is the same kernel on the flipped / transposed filter (wino_filter_transform mode 1).
 #include "common.h"
 
-#ifndef WINO_ABL
-#define WINO_ABL 0      // experiment switches (tools/scratch/wino_var): never set in the product build
-#endif
-
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -208,11 +204,7 @@ __device__ __forceinline__ void chunk_body(f32x4 (&acc)[4][2][4], f32x4 (&afr)[2
     if (cb == 0 && c < 3) {   // B fragments of the next xi
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt)
-#if (WINO_ABL & 16)
-        bfr[cur ^ 1][tt] = bfr[cur][tt] + 1.f;
-#else
         bfr[cur ^ 1][tt] = vcur[(c + 1) * CIB * VS + 16 * tt];
-#endif
     }
     const float a = afr[c >> 1][2 * (c & 1) + cb];
 #pragma unroll
@@ -223,35 +215,19 @@ __device__ __forceinline__ void chunk_body(f32x4 (&acc)[4][2][4], f32x4 (&afr)[2
       t[1 * 4 + g] = d[1 * 4 + g] + d[2 * 4 + g];
       t[2 * 4 + g] = d[2 * 4 + g] - d[1 * 4 + g];
       t[3 * 4 + g] = d[1 * 4 + g] - d[3 * 4 + g];
-#if !(WINO_ABL & 8)
       if (g == 3) load_patch(d, plane3, patch);
-#endif
-#if (WINO_ABL & 4)
-    } else if (g == 4) {
-      float sacc = 0.f;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) sacc += t[e];
-      if (sacc == 12345.f) vnext[0] = sacc;
-    } else if (false) {
-      const int r = 0;
-#else
     } else {                   // (B^T d) B : row g - 4, written straight to the next V buffer
       const int r = g - 4;
-#endif
       vnext[(r * 4 + 0) * CIB * VS] = t[r * 4 + 0] - t[r * 4 + 2];
       vnext[(r * 4 + 1) * CIB * VS] = t[r * 4 + 1] + t[r * 4 + 2];
       vnext[(r * 4 + 2) * CIB * VS] = t[r * 4 + 2] - t[r * 4 + 1];
       vnext[(r * 4 + 3) * CIB * VS] = t[r * 4 + 1] - t[r * 4 + 3];
     }
-#if !(WINO_ABL & 8)
     if (g == 7) {
       afr[0] = *reinterpret_cast<const f32x4*>(unext + ulane);
       afr[1] = *reinterpret_cast<const f32x4*>(unext + ulane + 16);
     }
-#endif
-#if !(WINO_ABL & 1)
     __builtin_amdgcn_sched_barrier(0);
-#endif
   }
 }
 
@@ -320,35 +296,18 @@ __global__ __launch_bounds__(WNT, 2) void wino_conv3x3(WinoArgs a) {
 
   const int vwoff = w * VS + lane;                    // V write: [xi][k = w][tile = lane]
   const int vroff = (4 * w) * CIB * VS + kg * VS + j; // V read:  [xi = 4w + c][k = kg][tile = 16 t + j]
-  for (int ch = cbeg; ch < ((WINO_ABL & 32) ? 0 : nchunk); ch += 2) {
+  for (int ch = cbeg; ch < nchunk; ch += 2) {
     // even chunk: MFMAs on V(0) with A(ch); transforms P(ch+1) = dB -> V(1); reloads dB <- P(ch+3), afrA <- A(ch+2)
     chunk_body(acc, afrA, lds + vroff, dB, patch, fixup, min(ch + 1, nchunk - 1) * CIB + w < a.K, lds + VBUF + vwoff,
                plane_of(ch + 3), u_of(ch + 2), ulane);
-#if !(WINO_ABL & 2)
     __syncthreads();
-#endif
     // nchunk is even (KP is a multiple of 2 * CIB): an `if (ch + 1 < nchunk)` here would make the compiler assume the
     // A fragments loaded at the end of the even chunk may be the youngest load in flight -> vmcnt(0) every iteration
     chunk_body(acc, afrB, lds + VBUF + vroff, dA, patch, fixup, min(ch + 2, nchunk - 1) * CIB + w < a.K, lds + vwoff,
                plane_of(ch + 4), u_of(ch + 3), ulane);
-#if !(WINO_ABL & 2)
     __syncthreads();
-#endif
   }
 
-#if (WINO_ABL & 64)
-  {
-    float sum = 0.f;
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) sum += acc[c][cb][t][0] + acc[c][cb][t][1] + acc[c][cb][t][2] + acc[c][cb][t][3];
-    if (sum == 123.456f) a.out[0] = sum;
-    return;
-  }
-#endif
   // ---- output stage ------------------------------------------------------------------------------------------
   // column half of A^T M A in registers (this wave holds the whole row r = w):  s0 = m0 + m1 + m2,  s1 = m1 - m2 - m3
   // accumulator tile layout: row (channel) = 4 * kg + reg, column (tile) = j
