@@ -212,6 +212,14 @@ int64_t savfi_conv3x3_workspace_floats(int N, int Ci, int Co, int H, int W, int 
 int savfi_conv3x3_f32(const float* x, const float* w, const float* bias, float* out, float* workspace,
                       int N, int Ci, int Co, int H, int W, int pad, int mode, float slope, void* stream);
 
+/* ----------------------------------------------------------------------------------
+ * Frame staging (data/vimeo_septuplet.py:68-80, data/video.py:44-51: channel swap, HWC->CHW, .float()/255,
+ * Normalize): src = N decoded frames, uint8 [N,H,W,3] on the DEVICE (copied there as bytes);
+ * dst[n][c][y][x] = (src[n][y][x][swap_rb ? 2-c : c] / div - mean) / std, fp32 [N,3,H,W].
+ * ---------------------------------------------------------------------------------- */
+int savfi_frames_u8_to_f32(const unsigned char* src, float* dst, int64_t N, int H, int W, int swap_rb, float div,
+                           float mean, float std, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -53,6 +53,7 @@ _PROTOTYPES = {
     "savfi_upsample2x_bwd_f32": [_P, _P, c_int, c_int, c_int, c_int, _P],
     "savfi_conv3x3_workspace_floats": [c_int] * 7,
     "savfi_conv3x3_f32": [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P],
+    "savfi_frames_u8_to_f32": [_P, _P, c_int64, c_int, c_int, c_int, c_float, c_float, c_float, _P],
     "savfi_upsample2x_window_fwd_f32": [_P, _P] + [c_int] * 12 + [_P],
     "savfi_upsample2x_window_bwd_f32": [_P, _P] + [c_int] * 12 + [_P],
     "savfi_bias_act_fwd_f32": [_P, _P, c_int, c_int, c_int, c_float, _P],

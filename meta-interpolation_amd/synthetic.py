@@ -94,3 +94,43 @@ def seeded_attenuator_state(num_layers, seed=777, gamma_mult=0.5):
               ('2.weight', (num_layers, num_layers)), ('2.bias', (num_layers,))]
     sd = {k: torch.from_numpy(rs.uniform(-0.05, 0.05, size=s).astype(np.float32)) for k, s in shapes}
     return sd, torch.full((1,), float(gamma_mult))
+
+
+# --------------------------------------------------------------------------------------------
+# tiny on-disk datasets in the reference's layouts (tests, fixtures, smoke runs of the data pipeline)
+# --------------------------------------------------------------------------------------------
+def _fake_frame(rng, height, width, k):
+    base = rng.randint(0, 256, size=(height // 4 + 2, width // 4 + 2, 3)).astype(np.float32)
+    img = np.kron(base, np.ones((4, 4, 1), dtype=np.float32))[:height, :width]
+    img = np.roll(img, shift=(k, 2 * k), axis=(0, 1)) + rng.randint(0, 8, size=(height, width, 3))
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def write_fake_vimeo(root, n_train=3, n_test=2, height=260, width=272, seed=99):
+    """`root/sequences/000XX/000Y/im{1..7}.png` + `sep_trainlist.txt` / `sep_testlist.txt` (data/vimeo_septuplet.py:14-21)."""
+    import os
+    from PIL import Image
+    rng = np.random.RandomState(seed)
+    lists = {'sep_trainlist.txt': [], 'sep_testlist.txt': []}
+    for split, n, name in (('train', n_train, 'sep_trainlist.txt'), ('test', n_test, 'sep_testlist.txt')):
+        for s in range(n):
+            rel = '%05d/%04d' % (1 if split == 'train' else 2, s + 1)
+            os.makedirs(os.path.join(root, 'sequences', rel), exist_ok=True)
+            for k in range(7):
+                Image.fromarray(_fake_frame(rng, height, width, k)).save(os.path.join(root, 'sequences', rel, 'im%d.png' % (k + 1)))
+            lists[name].append(rel)
+    for name, rows in lists.items():
+        with open(os.path.join(root, name), 'w') as f:
+            f.write('\n'.join(rows))
+    return root
+
+
+def write_fake_video(root, n_frames=6, height=96, width=128, seed=7):
+    """`root/frame_000K_0.000000.png`: the layout data/video.py:13-27 leaves after its in-place renaming."""
+    import os
+    from PIL import Image
+    rng = np.random.RandomState(seed)
+    os.makedirs(root, exist_ok=True)
+    for k in range(n_frames):
+        Image.fromarray(_fake_frame(rng, height, width, k)).save(os.path.join(root, 'frame_%04d_%.06f.png' % (k, 0.0)))
+    return root

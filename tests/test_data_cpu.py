@@ -1,0 +1,103 @@
+"""CPU: the dataset readers against vectors produced by the reference's own VimeoSeptuplet / Video
+classes (oracle/gen_golden_data.py -> tests/golden/data_readers.npz), and the provider surface ExperimentBuilder uses."""
+import os
+import random
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from meta_interpolation_amd import data, synthetic
+from tests.helpers import golden
+
+
+def summary(t):
+    d = t.double().reshape(-1)
+    return np.array([d.sum().item(), d.abs().sum().item()]), t.reshape(-1)[::997].numpy()
+
+
+@pytest.fixture(scope="module")
+def vimeo_root(tmp_path_factory):
+    return synthetic.write_fake_vimeo(str(tmp_path_factory.mktemp("vimeo")))
+
+
+def vimeo_args(root, model, mode, **kw):
+    base = dict(data_root=root, batch_size=2, val_batch_size=1, test_batch_size=1, mode=mode, model=model, num_gpu=0,
+                num_workers=2, random_seed=5, dataset='vimeo90k', synthetic=False)
+    base.update(kw)
+    return types.SimpleNamespace(**base)
+
+
+@pytest.mark.parametrize("model", ["sepconv", "voxelflow"])
+@pytest.mark.parametrize("mode", ["train", "val"])
+def test_vimeo_reader_matches_the_reference_class(vimeo_root, model, mode):
+    g = golden("data_readers")
+    ds = data.VimeoSeptuplet(vimeo_args(vimeo_root, model, mode))
+    assert list(g['vimeo_%s_%s_len' % (model, mode)]) == [len(ds), ds.data_length['train'], ds.data_length['val']]
+    random.seed(4321)                      # same `random` state as the generator: same crops / temporal flips
+    for idx in range(3):
+        images, meta = ds[idx]
+        key = 'vimeo_%s_%s_%d' % (model, mode, idx)
+        assert list(images[0].shape) == list(g[key + '_shape'])
+        assert [os.path.relpath(p, vimeo_root) for p in meta['imgpaths']] == list(g[key + '_paths'])
+        for f, im in enumerate(images):
+            fp, sample = summary(im)
+            assert np.array_equal(sample, g[key + '_s%d' % f])            # bit-exact
+            assert np.allclose(fp, g[key + '_fp%d' % f], rtol=1e-12)
+
+
+def test_video_reader_matches_the_reference_class(tmp_path):
+    g = golden("data_readers")
+    root = synthetic.write_fake_video(str(tmp_path / "clip"))
+    ds = data.Video(types.SimpleNamespace(data_root=root, img_fmt='png', test_batch_size=1, model='sepconv'))
+    assert len(ds) == int(g['video_len'][0])
+    for idx in range(len(ds)):
+        images, meta = ds[idx]
+        assert [os.path.basename(p) for p in meta['imgpaths']] == list(g['video_%d_paths' % idx])
+        for f, im in enumerate(images):
+            fp, sample = summary(im)
+            assert np.array_equal(sample, g['video_%d_s%d' % (idx, f)])
+            assert np.allclose(fp, g['video_%d_fp%d' % (idx, f)], rtol=1e-12)
+
+
+def test_video_reader_renames_and_pads_short_clips(tmp_path):
+    from PIL import Image
+    root = tmp_path / "short"
+    root.mkdir()
+    for k in range(2):
+        Image.fromarray(np.full((8, 8, 3), 40 * k, np.uint8)).save(str(root / ("f%d.png" % k)))
+    ds = data.Video(types.SimpleNamespace(data_root=str(root), img_fmt='png', test_batch_size=1, model='sepconv'))
+    assert sorted(os.listdir(str(root))) == ['f0_0.000000.png', 'f1_0.000000.png']       # data/video.py:13-18
+    assert len(ds) == 1 and len(ds.imglist[0]) == 4 and ds.imglist[0][2] == ds.imglist[0][3]
+
+
+def test_provider_surface_and_batch_layout(vimeo_root):
+    args = vimeo_args(vimeo_root, 'sepconv', 'train')
+    prov = data.MetaLearningSystemDataLoader(args, current_iter=3)
+    assert prov.dataset.data_length == {'train': 3, 'val': 2, 'test': 0}
+    assert prov.total_train_iters_produced == 3 * args.batch_size
+    random.seed(1)
+    batches = list(prov.get_train_batches(total_batches=-1))
+    assert [b[0][0].shape[0] for b in batches] == [2, 1]                    # drop_last=False
+    images, meta = batches[0]
+    assert len(images) == 7 and images[0].shape == (2, 3, 256, 256) and images[0].dtype == torch.float32
+    assert len(meta['imgpaths']) == 7 and len(meta['imgpaths'][0]) == 2     # [frame][item], the DataLoader collation
+    assert 0.0 <= float(images[3].min()) and float(images[3].max()) <= 1.0
+    val = list(prov.get_val_batches(total_batches=1))
+    assert len(val) == 1 and val[0][0][0].shape == (1, 3, 260, 272)         # validation frames are not cropped
+    assert prov.dataset.current_set_name == 'val'
+    with pytest.raises(NotImplementedError):
+        data.MetaLearningSystemDataLoader(vimeo_args(vimeo_root, 'sepconv', 'train', dataset='middlebury'))
+    with pytest.raises(NotImplementedError):
+        data.VimeoSeptuplet(vimeo_args(vimeo_root, 'superslomo', 'train'))
+
+
+def test_training_batches_are_reproducible_with_parallel_decode(vimeo_root):
+    outs = []
+    for workers in (1, 4):
+        prov = data.MetaLearningSystemDataLoader(vimeo_args(vimeo_root, 'sepconv', 'train', num_workers=workers))
+        random.seed(77)
+        outs.append([b for b in prov.get_train_batches()])
+    for (ia, ma), (ib, mb) in zip(*outs):
+        assert ma == mb and all(torch.equal(a, b) for a, b in zip(ia, ib))

@@ -55,8 +55,23 @@ def test_val_and_test_modes_and_hd_split(tmp_path, monkeypatch):
     assert len(outs) == 2 and outs[0][0].shape == (3, 16, 24)
 
 
-def test_dataset_readers_are_out_of_scope_but_fail_loudly():
+def test_train_loop_runs_from_a_vimeo_directory_with_the_toy_plugin(tmp_path, monkeypatch):
+    """main.py's wiring: MetaLearningSystemDataLoader(args) -> VimeoSeptuplet reader -> ExperimentBuilder (CPU tensors)."""
+    from meta_interpolation_amd import synthetic
+    monkeypatch.chdir(tmp_path)
+    system = build_toy_system(batch=2, steps=1)
+    args = system.args
+    args.synthetic, args.dataset, args.data_root = False, 'vimeo90k', synthetic.write_fake_vimeo(str(tmp_path / 'vimeo'))
+    args.total_iter_per_epoch, args.max_epoch, args.exp_name, args.log_iter, args.num_workers = 2, 1, 'toyv', 2, 2
+    eb = ExperimentBuilder(args, MetaLearningSystemDataLoader, system)
+    eb.run_experiment()
+    assert eb.state['current_iter'] == 2 and eb.epoch == 1
+    assert os.path.exists(os.path.join('checkpoint', 'toyv', 'checkpoint.pth'))
+
+
+def test_unsupported_datasets_fail_loudly():
     import pytest
     system = build_toy_system(batch=1, steps=1)
+    system.args.synthetic, system.args.dataset = False, 'middlebury'
     with pytest.raises(NotImplementedError):
         MetaLearningSystemDataLoader(system.args)

@@ -390,3 +390,28 @@ def test_sepconv_with_winograd_convs_equals_miopen_convs():
     assert (o_wi - o_mi).abs().max() < 5e-6
     for (n, _), a, b in zip(net.named_parameters(), g_wi, g_mi):
         assert (a - b).abs().max() <= 2e-4 * b.abs().max() + 1e-12, n
+
+
+# ---------------------------------------------------------------------------------------------
+# frame staging: uint8 HWC over PCIe -> fp32 NCHW on the GPU
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("model", ["sepconv", "voxelflow"])
+def test_frame_stager_is_bit_identical_to_the_cpu_reader(model, tmp_path):
+    import random
+    import types
+    from meta_interpolation_amd import data, synthetic
+    root = synthetic.write_fake_vimeo(str(tmp_path / "vimeo"))
+    mk = lambda gpus: types.SimpleNamespace(data_root=root, batch_size=2, val_batch_size=1, test_batch_size=1, mode='train',
+                                            model=model, num_gpu=gpus, num_workers=3, random_seed=5, dataset='vimeo90k',
+                                            synthetic=False)
+    got = []
+    for gpus in (0, 1):
+        prov = data.MetaLearningSystemDataLoader(mk(gpus))
+        assert (prov.stager is not None) == bool(gpus)
+        random.seed(11)
+        got.append([b for b in prov.get_train_batches()] + [b for b in prov.get_val_batches()])
+    assert len(got[0]) == len(got[1]) == 4
+    for (ic, mc), (ig, mg) in zip(*got):
+        assert mc == mg
+        for a, b in zip(ic, ig):
+            assert b.is_cuda and torch.equal(a, b.cpu())
