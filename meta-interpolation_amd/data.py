@@ -3,7 +3,8 @@
 ``.get_train_batches / .get_val_batches / .get_test_batches(total_batches=...)`` yielding
 ``(images: list of Tensor[B,3,H,W], metadata: {'imgpaths': ...})``.
 
-* ``VimeoSeptuplet`` / ``Video``: the reference's readers (data/vimeo_septuplet.py:10-88, data/video.py:9-60) —
+* ``VimeoSeptuplet`` / ``HD`` / ``Video``: the reference's readers (data/vimeo_septuplet.py:10-88,
+  data/hd_dataset.py:11-79, data/video.py:9-60) —
   same attributes, same ``__getitem__`` results (CPU fp32 CHW tensors) for the same ``random`` state.  Decoding uses
   PIL (the reference's cv2.imread + BGR->RGB swap gives the same RGB bytes for 8-bit PNGs).
 * ``FrameStager``: the MI355X feeding path.  Worker threads decode into pinned uint8 HWC buffers (cropped on the
@@ -12,7 +13,7 @@
   meta-iteration still computes.  Bit-identical to the CPU path (same fp32 operation order).
 * ``SyntheticSeptupletLoader``: seeded synthetic septuplets (``--synthetic``; bench.py and the parity fixtures).
 
-superslomo normalisation, Middlebury / HD / DAVIS / SNU-FILM readers: out of scope.
+superslomo normalisation, Middlebury / DAVIS / SNU-FILM readers: out of scope.
 """
 import glob
 import os
@@ -156,6 +157,51 @@ class Video(object):
         return self.data_length[self.current_set_name]
 
 
+class HD(object):
+    """data/hd_dataset.py:11-79: every video directory under `data_root`, 7-frame windows with stride 2 (the last
+    windows are clamped to the final 7 frames; shorter videos give one short window), validation split only."""
+
+    def __init__(self, args):
+        self.args = args
+        self.data_root = args.data_root
+        self.image_root = self.data_root
+        vidlist = sorted(glob.glob(os.path.join(self.image_root, '*')))
+        imglist = [sorted(glob.glob(os.path.join(v, '*.png'))) for v in vidlist]
+        n_frames = 7
+        self.imgBatch = []
+        for frames in imglist:
+            t = 0
+            while t < len(frames):
+                if len(frames) >= n_frames:
+                    self.imgBatch.append(frames[t:t + n_frames] if t + n_frames <= len(frames) else frames[-n_frames:])
+                else:
+                    self.imgBatch.append(frames)
+                t += 2
+        self.batch_size = {'train': 1, 'val': 1, 'test': 1}
+        self.current_set_name = 'val'
+        self.data_length = {'train': 0, 'val': len(self.imgBatch), 'test': 0}
+        _normalisation(args.model)
+
+    def plan(self, index):
+        return list(self.imgBatch[index]), None
+
+    def load(self, plan):
+        return np.stack([_read_rgb(p) for p in plan[0]]), plan[0]
+
+    def decode(self, index):
+        return self.load(self.plan(index))
+
+    def __getitem__(self, index):
+        frames, imgpaths = self.decode(index)
+        return [_to_float_chw(f, self.args.model) for f in frames], {'imgpaths': imgpaths}
+
+    def switch_set(self, set_name, current_iter=None):
+        self.current_set_name = set_name
+
+    def __len__(self):
+        return self.data_length[self.current_set_name]
+
+
 class FrameStager(object):
     """Decoded uint8 frames -> fp32 [B,3,H,W] tensors on the GPU (see the module docstring).
 
@@ -227,7 +273,8 @@ class DatasetProvider(object):
         self.full_data_length = dict(dataset.data_length)
         self.total_train_iters_produced = current_iter * self.batch_size['train']
         use_gpu = torch.cuda.is_available() and getattr(args, 'num_gpu', 0) > 0
-        self.stager = FrameStager(torch.device('cuda', torch.cuda.current_device()), args.model) if use_gpu else None
+        norm_model = args.model if isinstance(dataset, (VimeoSeptuplet, HD)) else 'other'          # Video: ToTensor, always /255
+        self.stager = FrameStager(torch.device('cuda', torch.cuda.current_device()), norm_model) if use_gpu else None
         self._shuffle = torch.Generator().manual_seed(int(getattr(args, 'random_seed', 0)))
 
     def _index_batches(self, mode):
@@ -249,7 +296,7 @@ class DatasetProvider(object):
             if self.stager is None:
                 for idxs in batches:
                     frames, meta = self._decode_batch(pool, idxs)
-                    model = self.args.model if isinstance(self.dataset, VimeoSeptuplet) else 'other'
+                    model = self.args.model if isinstance(self.dataset, (VimeoSeptuplet, HD)) else 'other'
                     yield [torch.stack([_to_float_chw(fr[f], model) for fr in frames]) for f in range(frames[0].shape[0])], meta
                 return
             pending = None
@@ -324,6 +371,8 @@ def MetaLearningSystemDataLoader(args, current_iter=0):
         return SyntheticSeptupletLoader(args, current_iter)
     if args.dataset == 'vimeo90k':
         return DatasetProvider(args, VimeoSeptuplet(args), current_iter)
+    if args.dataset == 'hd':
+        return DatasetProvider(args, HD(args), current_iter)
     if args.dataset == 'test':
         return DatasetProvider(args, Video(args), current_iter)
-    raise NotImplementedError("dataset %r is outside this build's scope (vimeo90k, test, or --synthetic)" % args.dataset)
+    raise NotImplementedError("dataset %r is outside this build's scope (vimeo90k, hd, test, or --synthetic)" % args.dataset)

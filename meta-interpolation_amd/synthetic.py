@@ -134,3 +134,15 @@ def write_fake_video(root, n_frames=6, height=96, width=128, seed=7):
     for k in range(n_frames):
         Image.fromarray(_fake_frame(rng, height, width, k)).save(os.path.join(root, 'frame_%04d_%.06f.png' % (k, 0.0)))
     return root
+
+
+def write_fake_hd(root, lengths=(9, 7, 4), height=48, width=64, seed=21):
+    """`root/<video>/<frame>.png` for data/hd_dataset.py:18-40 (one long, one exactly-7 and one short video)."""
+    import os
+    from PIL import Image
+    rng = np.random.RandomState(seed)
+    for v, n in enumerate(lengths):
+        os.makedirs(os.path.join(root, 'video%02d' % v), exist_ok=True)
+        for k in range(n):
+            Image.fromarray(_fake_frame(rng, height, width, k)).save(os.path.join(root, 'video%02d' % v, '%04d.png' % k))
+    return root

@@ -61,6 +61,21 @@ def test_video_reader_matches_the_reference_class(tmp_path):
             assert np.allclose(fp, g['video_%d_fp%d' % (idx, f)], rtol=1e-12)
 
 
+@pytest.mark.parametrize("model", ["sepconv", "voxelflow"])
+def test_hd_reader_matches_the_reference_class(tmp_path, model):
+    g = golden("data_readers")
+    root = synthetic.write_fake_hd(str(tmp_path / "hd"))
+    ds = data.HD(types.SimpleNamespace(data_root=root, model=model))
+    assert len(ds) == int(g['hd_%s_len' % model][0]) and ds.data_length['train'] == 0
+    for idx in range(len(ds)):
+        images, meta = ds[idx]
+        assert [os.path.relpath(p, root) for p in meta['imgpaths']] == list(g['hd_%s_%d_paths' % (model, idx)])
+        for f, im in enumerate(images):
+            fp, sample = summary(im)
+            assert np.array_equal(sample, g['hd_%s_%d_s%d' % (model, idx, f)])
+            assert np.allclose(fp, g['hd_%s_%d_fp%d' % (model, idx, f)], rtol=1e-12)
+
+
 def test_video_reader_renames_and_pads_short_clips(tmp_path):
     from PIL import Image
     root = tmp_path / "short"
