@@ -6,7 +6,8 @@ Entry-point surface kept from the reference (experiment_builder.py:9-319): const
 ``model.run_test_iter(data_batch)``, reads ``model.optimizer.param_groups[0]['lr']``, steps
 ``model.scheduler`` on the validation loss and saves ``{'epoch','arch','state_dict','best_PSNR'}``
 checkpoints.  Frames with H*W > 5e5 are evaluated in two halves and stitched (reference :105-115,
-:160-169).  Tensorboard and image writers are out of scope (predictions are returned / counted).
+:160-169).  Test mode writes each interpolated frame next to its clip and val mode under
+``checkpoint/<exp>/<dataset>/...`` like the reference (:194-206, :228-234); tensorboard is out of scope.
 """
 import time
 
@@ -86,14 +87,43 @@ class ExperimentBuilder(object):
             return [torch.cat([x, y], dim=dim) for x, y in zip(oa, ob)]
         return self.model.run_test_iter(data_batch=images)
 
+    # ---- image writers (reference :194-206, :228-234) ---------------------------------------------
+    def _write_test_frames(self, imgpaths, outputs):
+        """`<data_root>/<prefix>_<mean of the two neighbours' time stamps>.<fmt>` per clip; a right neighbour stamped
+        0 counts as 1.0, exactly as the reference does.  Paths that do not carry a time stamp are not written."""
+        import os
+        for k in range(len(outputs)):
+            try:
+                f1, f2 = imgpaths[1][k].split('/')[-1], imgpaths[2][k].split('/')[-1]
+                t1, t2 = float(f1.split('_')[-1][:-4]), float(f2.split('_')[-1][:-4])
+            except (ValueError, IndexError):
+                continue
+            t2 = 1.0 if t2 == 0 else t2
+            utils.save_image(outputs[k], os.path.join(self.args.data_root, '%s_%.06f.%s'
+                                                      % (f1.split('_')[0], (t1 + t2) / 2, self.args.img_fmt)))
+
+    def _write_val_frames(self, imgpaths, outputs):
+        """`checkpoint/<exp_name>/<dataset>/<a>/<b>/im4.png` for every item of a validation batch."""
+        import os
+        for k in range(outputs[0].shape[0] if outputs[0].dim() == 4 else len(outputs)):
+            paths = imgpaths[3][k].split('/')
+            if len(paths) < 3:
+                continue
+            save_dir = os.path.join('checkpoint', self.args.exp_name, self.args.dataset, paths[-3], paths[-2])
+            os.makedirs(save_dir, exist_ok=True)
+            out = outputs[0][k] if outputs[0].dim() == 4 else outputs[k].squeeze(0)
+            utils.save_image(out, os.path.join(save_dir, paths[-1]))
+
     # ---- sweeps ------------------------------------------------------------------------------
-    def _validation_sweep(self):
+    def _validation_sweep(self, write_images=False):
         acc = {'psnr': utils.AverageMeter(), 'ssim': utils.AverageMeter()}
         val_losses = {}
         n = self.data.dataset.data_length['val']
         total = int(n / self.args.val_batch_size + 0.99)
         for val_sample in self.data.get_val_batches(total_batches=total):
-            losses, _, metrics = self.evaluation_iteration(val_sample)
+            losses, outputs, metrics = self.evaluation_iteration(val_sample)
+            if write_images:                      # `--mode val` only (reference :228-234)
+                self._write_val_frames(val_sample[1]['imgpaths'], outputs)
             for k, v in metrics.items():
                 acc[k].update(v.avg, n=v.count)
             for k, v in losses.items():
@@ -108,11 +138,13 @@ class ExperimentBuilder(object):
             n = self.data.dataset.data_length['test']
             outs = []
             for sample in self.data.get_test_batches(total_batches=int(n / args.test_batch_size)):
-                outs.append(self.test_iteration(sample))
+                outputs = self.test_iteration(sample)
+                outs.append(outputs)
+                self._write_test_frames(sample[1]['imgpaths'], outputs)
             print('Test finished: %d clips.' % len(outs))
             return outs
         if args.mode == 'val':
-            losses, acc = self._validation_sweep()
+            losses, acc = self._validation_sweep(write_images=True)
             print("%d examples processed" % acc['psnr'].count)
             print("PSNR: %.2f,  SSIM: %.4f\n" % (acc['psnr'].avg, acc['ssim'].avg))
             return losses, acc

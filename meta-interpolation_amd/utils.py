@@ -104,21 +104,50 @@ def lossy_load_state_dict(model, state_dict, verbose=False):
     return loaded, skipped
 
 
+def update_lr(optimizer, lr):
+    for group in optimizer.param_groups:
+        group['lr'] = lr
+
+
 def load_checkpoint(args, model, optimizer=None, fix_loaded=False):
-    """Resume from checkpoint/<resume_exp or exp_name>/checkpoint.pth (reference :34-86): keys are
-    filtered by name and shape, args.start_epoch is set from the file."""
-    exp = args.resume_exp if getattr(args, 'resume_exp', None) else args.exp_name
+    """Resume from checkpoint/<resume_exp or exp_name>/{checkpoint,model_best}.pth (reference :34-86): keys are
+    filtered by name and shape; args.start_epoch comes from the file (0 when resuming ANOTHER experiment's weights);
+    the optimizer state is restored only if every model tensor was found, outside test mode."""
+    if getattr(args, 'resume_exp', None) is None:
+        args.resume_exp = args.exp_name
     name = 'model_best.pth' if getattr(args, 'mode', 'train') in ('val', 'test') else 'checkpoint.pth'
-    path = os.path.join('checkpoint', exp, name)
+    path = os.path.join('checkpoint', args.resume_exp, name)
+    print("loading checkpoint %s" % path)
     ckpt = torch.load(path, map_location='cpu', weights_only=False)
     args.start_epoch = ckpt.get('epoch', 0)
+    if args.resume_exp != args.exp_name:
+        args.start_epoch = 0
     with torch.no_grad():
-        loaded, _ = lossy_load_state_dict(model, ckpt['state_dict'])
+        loaded, skipped = lossy_load_state_dict(model, ckpt['state_dict'], verbose=True)
+    mismatch = bool(skipped) or len(model.state_dict()) > len(loaded)
+    if not mismatch and optimizer is not None and getattr(args, 'mode', 'train') != 'test' and 'optimizer' in ckpt:
+        optimizer.load_state_dict(ckpt['optimizer'])
+        if hasattr(args, 'lr'):
+            update_lr(optimizer, args.lr)
     if fix_loaded:
         params = dict(model.named_parameters())
         for name in loaded:
             if name in params:
                 params[name].requires_grad = False
-    if optimizer is not None and 'optimizer' in ckpt:
-        optimizer.load_state_dict(ckpt['optimizer'])
+    print("loaded checkpoint %s" % path)
     return ckpt
+
+
+# ---------------------------------------------------------------------------------------------
+# image writer (reference :276-285): [C,H,W] or [H,W] tensor in [0,1] -> 8-bit PNG
+# ---------------------------------------------------------------------------------------------
+def save_image(img, path):
+    from PIL import Image
+    q = quantize(img.detach().mul(255)).cpu().numpy().astype('uint8')
+    if img.dim() == 2:
+        im = Image.fromarray(q, 'L')
+    elif img.dim() == 3:
+        im = Image.fromarray(q.transpose(1, 2, 0), 'RGB')
+    else:
+        return
+    im.save(path)

@@ -75,3 +75,44 @@ def test_unsupported_datasets_fail_loudly():
     system.args.synthetic, system.args.dataset = False, 'middlebury'
     with pytest.raises(NotImplementedError):
         MetaLearningSystemDataLoader(system.args)
+
+
+def test_val_and_test_modes_write_frames_like_the_reference(tmp_path, monkeypatch):
+    """experiment_builder.py:194-206 (test: `<prefix>_<mid time stamp>.png` next to the clip) and :228-234 (val:
+    checkpoint/<exp>/<dataset>/<a>/<b>/im4.png), through the real readers."""
+    from PIL import Image
+    import numpy as np
+    from meta_interpolation_amd import synthetic
+    monkeypatch.chdir(tmp_path)
+    system = build_toy_system(batch=1, steps=1)
+    args = system.args
+    args.synthetic, args.exp_name, args.num_workers, args.img_fmt = False, 'writer', 2, 'png'
+    # val mode over a vimeo directory
+    args.mode, args.dataset, args.data_root = 'val', 'vimeo90k', synthetic.write_fake_vimeo(str(tmp_path / 'vimeo'), height=32, width=48)
+    ExperimentBuilder(args, MetaLearningSystemDataLoader, system).run_experiment()
+    written = sorted(os.path.relpath(os.path.join(r, f), 'checkpoint/writer/vimeo90k')
+                     for r, _, fs in os.walk('checkpoint/writer/vimeo90k') for f in fs)
+    assert written == ['00002/0001/im4.png', '00002/0002/im4.png']
+    assert np.asarray(Image.open('checkpoint/writer/vimeo90k/00002/0001/im4.png')).shape == (32, 48, 3)
+    # test mode over a folder of frames
+    args.mode, args.dataset, args.data_root = 'test', 'test', synthetic.write_fake_video(str(tmp_path / 'clip'), n_frames=5, height=16, width=24)
+    outs = ExperimentBuilder(args, MetaLearningSystemDataLoader, system).run_experiment()
+    assert len(outs) == 2
+    new = sorted(f for f in os.listdir(args.data_root) if not f.endswith('_0.000000.png'))
+    assert new == ['frame_0.500000.png']        # both clips map to the same name: stamps 0 / 0 -> (0 + 1.0) / 2, prefix 'frame'
+
+
+def test_load_checkpoint_follows_the_reference_rules(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    a = build_toy_system(batch=1, steps=1)
+    utils.save_checkpoint({'epoch': 7, 'state_dict': a.state_dict(), 'optimizer': a.optimizer.state_dict()}, True, 'src')
+    b = build_toy_system(batch=1, steps=1, seed=5)
+    b.args.exp_name, b.args.resume_exp, b.args.mode = 'dst', 'src', 'train'
+    utils.load_checkpoint(b.args, b, b.optimizer)
+    assert b.args.start_epoch == 0                                   # another experiment's weights: restart the epochs
+    assert all(torch.equal(v, a.state_dict()[k]) for k, v in b.state_dict().items())
+    b.args.exp_name = 'src'
+    utils.load_checkpoint(b.args, b, b.optimizer)
+    assert b.args.start_epoch == 7
+    b.args.mode = 'val'                                               # val / test read model_best.pth
+    utils.load_checkpoint(b.args, b, None)
