@@ -212,6 +212,14 @@ int64_t savfi_conv3x3_workspace_floats(int N, int Ci, int Co, int H, int W, int 
 int savfi_conv3x3_f32(const float* x, const float* w, const float* bias, float* out, float* workspace,
                       int N, int Ci, int Co, int H, int W, int pad, int mode, float slope, void* stream);
 
+/* Weight gradient of the same convolution (zero padding `pad` in {0,1}), NCHW in and out, deterministic:
+ *   gw[Co,Ci,3,3] = sum over n,y,x of gz[n,co,y,x] * x[n,ci,y+a-pad,x+b-pad]      x [N,Ci,H,W], gz [N,Co,H+2pad-2,W+2pad-2]
+ * `workspace`: savfi_conv3x3_wgrad_workspace_floats(same N, Ci, Co, H, W, pad) floats of caller-owned device memory
+ * (per-workgroup partial blocks, added in a fixed order). */
+int64_t savfi_conv3x3_wgrad_workspace_floats(int N, int Ci, int Co, int H, int W, int pad);
+int savfi_conv3x3_wgrad_f32(const float* x, const float* gz, float* gw, float* workspace, int N, int Ci, int Co,
+                            int H, int W, int pad, void* stream);
+
 /* ----------------------------------------------------------------------------------
  * Frame staging (data/vimeo_septuplet.py:68-80, data/video.py:44-51: channel swap, HWC->CHW, .float()/255,
  * Normalize): src = N decoded frames, uint8 [N,H,W,3] on the DEVICE (copied there as bytes);

@@ -53,6 +53,8 @@ _PROTOTYPES = {
     "savfi_upsample2x_bwd_f32": [_P, _P, c_int, c_int, c_int, c_int, _P],
     "savfi_conv3x3_workspace_floats": [c_int] * 7,
     "savfi_conv3x3_f32": [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P],
+    "savfi_conv3x3_wgrad_workspace_floats": [c_int] * 6,
+    "savfi_conv3x3_wgrad_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P],
     "savfi_frames_u8_to_f32": [_P, _P, c_int64, c_int, c_int, c_int, c_float, c_float, c_float, _P],
     "savfi_upsample2x_window_fwd_f32": [_P, _P] + [c_int] * 12 + [_P],
     "savfi_upsample2x_window_bwd_f32": [_P, _P] + [c_int] * 12 + [_P],
@@ -90,7 +92,7 @@ def lib():
         except AttributeError:
             raise SavfiHipError("%s does not export %s" % (LIB_PATH, name))
         fn.argtypes = argtypes
-        fn.restype = c_int64 if name in ('savfi_conv3x3_workspace_floats', 'savfi_bias_act_scratch_floats') else c_int
+        fn.restype = c_int64 if name in ('savfi_conv3x3_workspace_floats', 'savfi_bias_act_scratch_floats', 'savfi_conv3x3_wgrad_workspace_floats') else c_int
     got = handle.savfi_version()
     if got != ABI_VERSION:
         raise SavfiHipError("libsavfi_hip ABI %d != expected %d; rebuild" % (got, ABI_VERSION))

@@ -317,6 +317,11 @@ def mse_loss(a, b):
 WINOGRAD_CONV = not os.environ.get('SAVFI_NO_WINOGRAD')
 WINO_MIN_TILES_FWD = 12000
 WINO_MIN_TILES_BWD = 20000
+# The weight gradient of the same layers runs on savfi_conv3x3_wgrad_f32 (NCHW-native MFMA kernel, deterministic) when a
+# map has >= 3000 output pixels and >= 16 input channels: 1.2-1.8x faster than MIOpen's igemm kernel + its two layout
+# transposes there (tools/wgrad_bench.py, profiles/r01_wgrad_bench.jsonl); the deep 24x32 / 12x16 layers stay on MIOpen.
+WGRAD_MIN_PIXELS = 3000
+WGRAD_MIN_CI = 16
 
 
 def conv3x3_eligible(x, weight, stride, padding, dilation, groups, backward=False):
@@ -332,6 +337,17 @@ def conv3x3_eligible(x, weight, stride, padding, dilation, groups, backward=Fals
         return False
     tiles = N * ((Ho + 1) // 2) * ((Wo + 1) // 2)
     return tiles >= (WINO_MIN_TILES_BWD if backward else WINO_MIN_TILES_FWD)
+
+
+def conv3x3_wgrad_eligible(x, weight, stride, padding, dilation, groups):
+    if not (WINOGRAD_CONV and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
+        return False
+    one = lambda v, k: (v == k) if isinstance(v, int) else all(t == k for t in v)
+    pad = padding if isinstance(padding, int) else (padding[0] if padding[0] == padding[1] else -1)
+    if tuple(weight.shape[2:]) != (3, 3) or not one(stride, 1) or not one(dilation, 1) or groups != 1 or pad not in (0, 1):
+        return False
+    _, Ci, H, W = x.shape
+    return Ci >= WGRAD_MIN_CI and (H + 2 * pad - 2) * (W + 2 * pad - 2) >= WGRAD_MIN_PIXELS
 
 
 class _ConvBiasAct(torch.autograd.Function):
@@ -378,14 +394,19 @@ class _ConvBiasAct(torch.autograd.Function):
                 None if gb is None else gb.data_ptr(), None if scratch is None else scratch.data_ptr(),
                 N, C, H * W, slope, _hip.current_stream()), "savfi_bias_act_bwd_f32"))
         gx = gw = None
+        pad = padding if isinstance(padding, int) else padding[0]
         if need_x and conv3x3_eligible(x, w, stride, padding, dilation, groups, backward=True):
-            gx = conv3x3(gz, w, None, 1, 1.0, padding if isinstance(padding, int) else padding[0])
+            gx = conv3x3(gz, w, None, 1, 1.0, pad)
             need_x = False
+        if need_w and conv3x3_wgrad_eligible(x, w, stride, padding, dilation, groups):
+            gw = conv3x3_wgrad(x, gz, pad)
+            need_w = False
         if need_x or need_w:
             pair = lambda v: [v, v] if isinstance(v, int) else list(v)
-            gx2, gw, _ = torch.ops.aten.convolution_backward(gz, x, w, None, pair(stride), pair(padding), pair(dilation),
-                                                             False, [0, 0], groups, [need_x, need_w, False])
+            gx2, gw2, _ = torch.ops.aten.convolution_backward(gz, x, w, None, pair(stride), pair(padding), pair(dilation),
+                                                              False, [0, 0], groups, [need_x, need_w, False])
             gx = gx2 if need_x else gx
+            gw = gw2 if need_w else gw
         return gx, gw, gb, None, None, None, None, None
 
 
@@ -407,6 +428,22 @@ def conv3x3(x, weight, bias=None, mode=0, slope=1.0, pad=1):
         x.data_ptr(), weight.data_ptr(), None if bias is None else bias.data_ptr(), out.data_ptr(), ws.data_ptr(),
         N, Ci, Co, H, W, int(pad), mode, float(slope), _hip.current_stream()), "savfi_conv3x3_f32"))
     return out
+
+
+def conv3x3_wgrad(x, gz, pad=1):
+    """savfi_conv3x3_wgrad_f32: weight gradient [Co,Ci,3,3] of conv2d(x, w, padding=pad) for the cotangent gz."""
+    x, gz = x.contiguous(), gz.contiguous()
+    _hip.require_cuda(x, gz)
+    N, Ci, H, W = x.shape
+    Co = gz.shape[1]
+    assert tuple(gz.shape) == (N, Co, H + 2 * pad - 2, W + 2 * pad - 2), (x.shape, gz.shape, pad)
+    lib = _hip.lib()
+    ws = torch.empty(int(lib.savfi_conv3x3_wgrad_workspace_floats(N, Ci, Co, H, W, int(pad))), dtype=x.dtype, device=x.device)
+    gw = torch.empty((Co, Ci, 3, 3), dtype=x.dtype, device=x.device)
+    _hip.launch("conv3x3_wgrad", lambda: _hip.check(lib.savfi_conv3x3_wgrad_f32(
+        x.data_ptr(), gz.data_ptr(), gw.data_ptr(), ws.data_ptr(), N, Ci, Co, H, W, int(pad), _hip.current_stream()),
+        "savfi_conv3x3_wgrad_f32"))
+    return gw
 
 
 def conv_bias_act(x, weight, bias, stride=1, padding=0, dilation=1, groups=1, slope=0.0):
