@@ -253,14 +253,22 @@ bool wgrad_plan(WgradPlan& p, int N, int Ci, int Co, int H, int W, int pad) {
   p.cobs = savfi_cdiv(Co, GCO);
   p.cibs = savfi_cdiv(Ci, GCI);
   p.nseg = savfi_cdiv(p.Wo, GSEG);
-  // ~512 workgroups (one round of the 2 x 256 slots; every workgroup costs a 37 KB partial block that is written and
-  // read again) unless that makes the strips shorter than 4 rows
+  // Rows per workgroup: 512 workgroup slots (2 per CU), so a launch takes ceil(workgroups / 512) rounds of about
+  // (rows + 3) row times (3 ~ prologue, cross-wave reduction and the 37 KB partial block that is written and read again);
+  // pick the strip height that minimises it (e.g. 192->192 at 96x160, N=2: 2 chunks = 432 workgroups in one round instead
+  // of 3 chunks = 648 in two).
   const int64_t per_row = (int64_t)N * p.nseg * p.cobs * p.cibs;
-  int64_t chunks = per_row >= 512 ? 1 : (512 + per_row - 1) / per_row;
-  int rows = (int)((p.Ho + chunks - 1) / chunks);
-  if (rows < 4) rows = p.Ho < 4 ? p.Ho : 4;
-  p.rows = rows;
-  p.nrowchunk = savfi_cdiv(p.Ho, rows);
+  int best_rows = p.Ho;
+  double best_cost = -1.0;
+  for (int chunks = 1; chunks <= 128; ++chunks) {
+    const int rows = savfi_cdiv(p.Ho, chunks);
+    if (rows < 4 && chunks > 1) break;
+    const int64_t wgs = per_row * savfi_cdiv(p.Ho, rows);
+    const double cost = (double)((wgs + 511) / 512) * (rows + 3) + 0.004 * (double)wgs;
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_rows = rows; }
+  }
+  p.rows = best_rows;
+  p.nrowchunk = savfi_cdiv(p.Ho, best_rows);
   p.splits = (int64_t)N * p.nrowchunk * p.nseg;
   p.partial_floats = p.splits * p.cobs * p.cibs * TILE_FLOATS;
   p.ngroups = (int)((p.splits + RG - 1) / RG);

@@ -347,7 +347,10 @@ def conv3x3_wgrad_eligible(x, weight, stride, padding, dilation, groups):
     if tuple(weight.shape[2:]) != (3, 3) or not one(stride, 1) or not one(dilation, 1) or groups != 1 or pad not in (0, 1):
         return False
     _, Ci, H, W = x.shape
-    return Ci >= WGRAD_MIN_CI and (H + 2 * pad - 2) * (W + 2 * pad - 2) >= WGRAD_MIN_PIXELS
+    Ho, Wo = H + 2 * pad - 2, W + 2 * pad - 2
+    # the kernel works on 64-pixel row segments: a mostly empty last segment (CAIN's 160-wide maps: 83 % used) loses
+    fill = Wo / (64.0 * ((Wo + 63) // 64)) if Wo > 0 else 0.0
+    return Ci >= WGRAD_MIN_CI and Ho * Wo >= WGRAD_MIN_PIXELS and fill >= 0.85
 
 
 class _ConvBiasAct(torch.autograd.Function):
