@@ -19,8 +19,13 @@
  *   savfi_mt_scale_f32         gamma_i * w_i (L2F attenuation)        meta_learning_system.py:267-268
  *   savfi_l1_mse_f32           nn.L1Loss / nn.MSELoss                 loss.py:287-290
  *   savfi_upsample2x_fwd/bwd_f32  bilinear x2 up-sampling                 sepconv/model.py:191,213-234; voxel_flow.py:400-414
+ *   savfi_upsample2x_window_fwd/bwd_f32  the same map on a window (SepConv Subnets on the frame area)  sepconv/model.py:309-349
  *   savfi_bias_act_fwd/bwd_f32 conv bias add + (Leaky)ReLU and their backward + bias gradient
  *                                                                     sepconv/model.py:172-194, model_utils.py:957-990
+ *   savfi_conv3x3_f32          F.conv2d 3x3 / stride 1 (+ bias, activation) and its data gradient
+ *   savfi_conv3x3_wgrad_f32    its weight gradient                    model_utils.py:308-366 (MetaConv2dLayer.forward -> F.conv2d)
+ *   savfi_frames_u8_to_f32     HWC uint8 frames -> normalised fp32 NCHW  data/vimeo_septuplet.py:68-80, data/video.py:44-51
+ *   savfi_*_workspace_floats / savfi_bias_act_scratch_floats: sizes of the caller-owned scratch buffers (return int64_t)
  *
  * Conventions (all functions):
  *   - extern "C", return int: 0 = ok; >0 = hipError_t reported by the launch;
