@@ -265,9 +265,14 @@ class DatasetProvider(object):
     decode threads; on a GPU they go through FrameStager one batch ahead of the consumer, otherwise (CPU tensors) through
     the reader's own `__getitem__`."""
 
-    def __init__(self, args, dataset, current_iter=0):
+    def __init__(self, args, dataset, current_iter=0, task_parallel=None):
+        from .task_parallel import TaskParallel
         self.args = args
         self.dataset = dataset
+        # one process per GPU: rank r adapts tasks {t : t mod G == r} of every meta-batch and only decodes those; the
+        # other items of the batch stay zero (never read), their `random` draws are still consumed so that crops and
+        # flips do not depend on the number of ranks
+        self.task_parallel = task_parallel if task_parallel is not None else TaskParallel()
         self.batch_size = {'train': args.batch_size, 'val': args.val_batch_size, 'test': args.test_batch_size}
         self.num_workers = max(1, int(getattr(args, 'num_workers', 1)))
         self.full_data_length = dict(dataset.data_length)
@@ -283,25 +288,29 @@ class DatasetProvider(object):
         bs = max(1, self.batch_size[mode])
         return [order[i:i + bs] for i in range(0, n, bs)]            # drop_last=False, like the reference's DataLoader
 
-    def _decode_batch(self, pool, idxs):
+    def _decode_batch(self, pool, idxs, shard):
         plans = [self.dataset.plan(i) for i in idxs]          # `random` draws in item order (reproducible)
-        items = list(pool.map(self.dataset.load, plans))      # PNG decode in parallel (PIL releases the GIL)
-        frames = [it[0] for it in items]
-        paths = [[it[1][f] for it in items] for f in range(len(items[0][1]))]
+        mine = set(self.task_parallel.local_tasks(len(idxs))) if shard else set(range(len(idxs)))
+        order = sorted(mine)
+        loaded = dict(zip(order, pool.map(self.dataset.load, [plans[t] for t in order])))   # PNG decode in parallel
+        ref = loaded[order[0]][0] if order else self.dataset.load(plans[0])[0]
+        frames = [loaded[t][0] if t in loaded else np.zeros_like(ref) for t in range(len(idxs))]
+        paths = [[plans[t][0][f] for t in range(len(idxs))] for f in range(len(plans[0][0]))]
         return frames, {'imgpaths': paths}
 
     def _batches(self, mode):
         batches = self._index_batches(mode)
+        shard = mode == 'train' and self.task_parallel.active      # validation / test sweeps run on every rank
         with ThreadPoolExecutor(self.num_workers) as pool:
             if self.stager is None:
                 for idxs in batches:
-                    frames, meta = self._decode_batch(pool, idxs)
+                    frames, meta = self._decode_batch(pool, idxs, shard)
                     model = self.args.model if isinstance(self.dataset, (VimeoSeptuplet, HD)) else 'other'
                     yield [torch.stack([_to_float_chw(fr[f], model) for fr in frames]) for f in range(frames[0].shape[0])], meta
                 return
             pending = None
             for idxs in batches:                                   # one batch staged ahead of the one being consumed
-                frames, meta = self._decode_batch(pool, idxs)
+                frames, meta = self._decode_batch(pool, idxs, shard)
                 staged = (self.stager.stage(frames), meta)
                 if pending is not None:
                     yield pending[0].tensors(), pending[1]

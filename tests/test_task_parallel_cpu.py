@@ -74,3 +74,56 @@ def test_single_process_task_parallel_is_a_noop():
     p.grad = torch.full((3,), 2.0)
     tp.allreduce_gradients([p])
     assert torch.equal(p.grad, torch.full((3,), 2.0))
+
+
+# ---------------------------------------------------------------------------------------------
+# the dataset provider decodes only the local tasks of a training meta-batch
+# ---------------------------------------------------------------------------------------------
+def _data_worker(rank, world, port, outdir, root):
+    import random
+    import types
+    from meta_interpolation_amd import data
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        args = types.SimpleNamespace(data_root=root, batch_size=3, val_batch_size=1, test_batch_size=1, mode='train', model='sepconv',
+                                     num_gpu=0, num_workers=2, random_seed=5, dataset='vimeo90k', synthetic=False)
+        prov = data.MetaLearningSystemDataLoader(args)
+        loads = []
+        orig = prov.dataset.load
+        prov.dataset.load = lambda plan: (loads.append(plan[0][0]), orig(plan))[1]
+        random.seed(9)
+        train = [(im, me) for im, me in prov.get_train_batches()]
+        n_train_loads = len(loads)
+        val = [(im, me) for im, me in prov.get_val_batches()]
+        torch.save({'train': train, 'val': val, 'n_train_loads': n_train_loads}, os.path.join(outdir, "data%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_provider_decodes_only_local_tasks_and_matches_the_single_process_batches(tmp_path):
+    import random
+    import types
+    from meta_interpolation_amd import data
+    root = synthetic.write_fake_vimeo(str(tmp_path / "vimeo"), n_train=6, n_test=2, height=260, width=264)
+    args = types.SimpleNamespace(data_root=root, batch_size=3, val_batch_size=1, test_batch_size=1, mode='train', model='sepconv',
+                                 num_gpu=0, num_workers=2, random_seed=5, dataset='vimeo90k', synthetic=False)
+    random.seed(9)
+    full = [(im, me) for im, me in data.MetaLearningSystemDataLoader(args).get_train_batches()]
+    with tempfile.TemporaryDirectory() as d:
+        port = 29500 + (os.getpid() % 2000) + 21
+        mp.spawn(_data_worker, args=(2, port, d, root), nprocs=2, join=True)
+        ranks = [torch.load(os.path.join(d, "data%d.pt" % r), weights_only=False) for r in range(2)]
+    assert ranks[0]['n_train_loads'] + ranks[1]['n_train_loads'] == 6        # every training item decoded exactly once
+    for b, (images, meta) in enumerate(full):
+        for r in range(2):
+            got_images, got_meta = ranks[r]['train'][b]
+            assert got_meta == meta                                              # same crops / flips / paths on every rank
+            for t in range(images[0].shape[0]):
+                for f in range(7):
+                    if t % 2 == r:
+                        assert torch.equal(got_images[f][t], images[f][t])       # local task: the real frames
+                    else:
+                        assert float(got_images[f][t].abs().max()) == 0.0        # someone else's task: never decoded
+    assert len(ranks[0]['val']) == len(ranks[1]['val']) == 2                     # validation runs on every rank
+    assert all(torch.equal(a[0][3], b[0][3]) for a, b in zip(ranks[0]['val'], ranks[1]['val']))
