@@ -318,6 +318,10 @@ WINOGRAD_CONV = not os.environ.get('SAVFI_NO_WINOGRAD')
 WINO_MIN_TILES_FWD = 12000
 WINO_MIN_TILES_BWD = 20000
 WINO_MIN_TILES_FWD_BATCHED = 6000     # N >= 2 (support pairs): the 96x128 layers, 1.17-1.19x, same launch count as MIOpen + epilogue
+WINO_MIN_TILES_BWD_BATCHED = 20000
+if os.environ.get('SAVFI_WINO_TILES'):      # experiment knob: "fwd,bwd,fwd_batched,bwd_batched"
+    WINO_MIN_TILES_FWD, WINO_MIN_TILES_BWD, WINO_MIN_TILES_FWD_BATCHED, WINO_MIN_TILES_BWD_BATCHED = (
+        int(t) for t in os.environ['SAVFI_WINO_TILES'].split(','))
 # The weight gradient of the same layers runs on savfi_conv3x3_wgrad_f32 (NCHW-native MFMA kernel, deterministic) when a
 # map has >= 3000 output pixels and >= 16 input channels: 1.2-1.8x faster than MIOpen's igemm kernel + its two layout
 # transposes there (tools/wgrad_bench.py, profiles/r01_wgrad_bench.jsonl); the deep 24x32 / 12x16 layers stay on MIOpen.
@@ -337,7 +341,7 @@ def conv3x3_eligible(x, weight, stride, padding, dilation, groups, backward=Fals
     if Ho < 1 or Wo < 1 or H * W < 4:
         return False
     tiles = N * ((Ho + 1) // 2) * ((Wo + 1) // 2)
-    if not backward and N >= 2 and tiles >= WINO_MIN_TILES_FWD_BATCHED:
+    if N >= 2 and tiles >= (WINO_MIN_TILES_BWD_BATCHED if backward else WINO_MIN_TILES_FWD_BATCHED):
         return True
     return tiles >= (WINO_MIN_TILES_BWD if backward else WINO_MIN_TILES_FWD)
 
