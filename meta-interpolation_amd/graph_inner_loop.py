@@ -187,6 +187,8 @@ class GraphedInnerLoop:
             logs.append(to['parts'])
             pred = to['pred']
         if self.training:
+            # multi-tensor (foreach) arithmetic throughout: ~100 tensors per list, one or two launches per list
+            scaled = lambda gs, w: list(gs) if isinstance(w, float) and w == 1.0 else list(torch._foreach_mul(list(gs), w))
             suffix = None      # sum_{s > t} w_s G_s  over routed tensors
             for t in range(self.S, -1, -1):
                 if t in self.target_graphs:
@@ -194,11 +196,12 @@ class GraphedInnerLoop:
                     w = weights[t]
                     gs = to['g_routed']
                     if suffix is None:
-                        suffix = [w * g for g in gs] if not isinstance(w, float) or w != 1.0 else [g.clone() for g in gs]
+                        suffix = scaled(gs, w) if not (isinstance(w, float) and w == 1.0) else [g.clone() for g in gs]
                     else:
-                        torch._foreach_add_(suffix, [w * g for g in gs] if not isinstance(w, float) or w != 1.0 else gs)
+                        torch._foreach_add_(suffix, scaled(gs, w))
                     own = [(k, g) for k, g in zip(self.unrouted, to['g_own']) if g is not None]
-                    accum.add_params([k for k, _ in own], [w * g for _, g in own])
+                    if own:
+                        accum.add_params([k for k, _ in own], scaled([g for _, g in own], w))
                 if t > 0 and self.learn_lr and suffix is not None:
                     accum.add_lr_grads(self, t - 1, suffix)
             if suffix is not None:
@@ -213,13 +216,17 @@ class OuterGradAccumulator:
         self.sys = system
         self.theta = theta      # inner-loop key -> nn.Parameter
         self.param = {}         # inner-loop key -> tensor
-        self.lr = {}            # lr key -> tensor shaped like the lr parameter
+        self.lr = {}            # lr key -> tensor shaped like the lr parameter (Meta-SGD: element-wise rates)
+        self.lr_rows = None     # LSLR: [inner step, routed tensor] scalars
+        self.lr_keys = None
 
     def add_params(self, keys, grads):
+        """param[k] += g  (the first contribution of a key is copied: `grads` may be static graph outputs)."""
+        have = [(self.param[k], g) for k, g in zip(keys, grads) if k in self.param]
+        if have:
+            torch._foreach_add_([a for a, _ in have], [g for _, g in have])
         for k, g in zip(keys, grads):
-            if k in self.param:
-                self.param[k].add_(g)
-            else:
+            if k not in self.param:
                 self.param[k] = g.clone()
 
     def add_lr_grads(self, gl, t, suffix):
@@ -239,22 +246,41 @@ class OuterGradAccumulator:
         args = (rule.lr_mode, n, _hip.ptr_array(gos), _hip.ptr_array(dirs), _hip.ptr_array(outs), _hip.i64_array(numel),
                 scale, _hip.current_stream())
         _hip.launch("mt_update_bwd", lambda: _hip.check(lib.savfi_mt_update_bwd_f32(*args), "savfi_mt_update_bwd_f32"))
-        for i, k in enumerate(gl.routed):
-            lk = k.replace(".", "-")
-            p = rule.names_learning_rates_dict[lk]
-            if not p.requires_grad:
-                continue
-            if lk not in self.lr:
-                self.lr[lk] = torch.zeros_like(p)
-            if rule.lr_mode == _hip.LR_SCALAR:
-                self.lr[lk][t] += dst[i]
-            else:
-                self.lr[lk].add_(outs[i])
+        lr_keys = [k.replace(".", "-") for k in gl.routed]
+        if rule.lr_mode == _hip.LR_SCALAR:
+            # one row of per-tensor scalars per inner step; scattered into the lr parameters' .grad by install()
+            if self.lr_rows is None:
+                steps = max(rule.names_learning_rates_dict[lk].numel() for lk in lr_keys)
+                self.lr_rows = torch.zeros(steps, n, dtype=torch.float32, device=dst.device)
+                self.lr_keys = lr_keys
+            self.lr_rows[t].add_(dst)
+        else:
+            live = [(lk, o) for lk, o in zip(lr_keys, outs) if rule.names_learning_rates_dict[lk].requires_grad]
+            self.add_lr_tensors([lk for lk, _ in live], [o for _, o in live])
+
+    def add_lr_tensors(self, keys, grads):
+        have = [(self.lr[k], g) for k, g in zip(keys, grads) if k in self.lr]
+        if have:
+            torch._foreach_add_([a for a, _ in have], [g for _, g in have])
+        for k, g in zip(keys, grads):
+            if k not in self.lr:
+                self.lr[k] = g.clone()
 
     def install(self, num_tasks):
         """Write the accumulated gradients (mean over the GLOBAL meta-batch) into .grad."""
         inv = 1.0 / float(num_tasks)
+        rates = self.sys.inner_loop_optimizer.names_learning_rates_dict
+        if self.lr_rows is not None:
+            cols = self.lr_rows.t().mul(inv).contiguous()            # [tensor, step]
+            for i, lk in enumerate(self.lr_keys):
+                p = rates[lk]
+                if p.requires_grad:
+                    rates[lk].grad = cols[i, :p.numel()].reshape(p.shape)
+        if self.param:
+            torch._foreach_mul_(list(self.param.values()), inv)
         for k, g in self.param.items():
-            self.theta[k].grad = g.mul_(inv)
+            self.theta[k].grad = g
+        if self.lr:
+            torch._foreach_mul_(list(self.lr.values()), inv)
         for lk, g in self.lr.items():
-            self.sys.inner_loop_optimizer.names_learning_rates_dict[lk].grad = g.mul_(inv)
+            rates[lk].grad = g

@@ -3,6 +3,7 @@
 Every function here launches a hand-written gfx950 kernel through the C ABI (include/savfi_hip.h)
 on torch's current stream.  Device tensors only -- there is no CPU or eager-PyTorch fallback.
 """
+import functools
 import os
 
 import torch
@@ -397,7 +398,7 @@ class _ConvBiasAct(torch.autograd.Function):
         gb = torch.empty(C, dtype=gy.dtype, device=gy.device) if need_b else None
         if need_b or not identity:
             lib = _hip.lib()
-            scratch = (torch.empty(int(lib.savfi_bias_act_scratch_floats(N, C, H * W)), dtype=gy.dtype, device=gy.device)
+            scratch = (torch.empty(_workspace_floats("savfi_bias_act_scratch_floats", N, C, H * W), dtype=gy.dtype, device=gy.device)
                        if need_b else None)
             _hip.launch("bias_act_bwd", lambda: _hip.check(lib.savfi_bias_act_bwd_f32(
                 gy.data_ptr(), (gy if identity else y).data_ptr(), None if identity else gz.data_ptr(),
@@ -420,6 +421,15 @@ class _ConvBiasAct(torch.autograd.Function):
         return gx, gw, gb, None, None, None, None, None
 
 
+@functools.lru_cache(maxsize=None)
+def _workspace_floats(query, *shape):
+    """Size queries of the C ABI are pure functions of the shape: ask once per shape."""
+    n = int(getattr(_hip.lib(), query)(*shape))
+    if n < 0:
+        _hip.check(n, query)
+    return n
+
+
 def conv3x3(x, weight, bias=None, mode=0, slope=1.0, pad=1):
     """savfi_conv3x3_f32 without autograd.  mode 0: act(conv2d(x, weight, padding=pad) + bias); mode 1: the data
     gradient of that convolution (x = gy [N,Co,H,W] -> gx [N,Ci,H+2-2pad,W+2-2pad])."""
@@ -432,7 +442,7 @@ def conv3x3(x, weight, bias=None, mode=0, slope=1.0, pad=1):
     K, I = (Ci, Co) if mode == 0 else (Co, Ci)
     grow = 2 * (pad if mode == 0 else 2 - pad) - 2
     lib = _hip.lib()
-    ws = torch.empty(int(lib.savfi_conv3x3_workspace_floats(N, Ci, Co, H, W, int(pad), mode)), dtype=x.dtype, device=x.device)
+    ws = torch.empty(_workspace_floats("savfi_conv3x3_workspace_floats", N, Ci, Co, H, W, int(pad), mode), dtype=x.dtype, device=x.device)
     out = torch.empty((N, I, H + grow, W + grow), dtype=x.dtype, device=x.device)
     _hip.launch("conv3x3_fwd" if mode == 0 else "conv3x3_bwd_data", lambda: _hip.check(lib.savfi_conv3x3_f32(
         x.data_ptr(), weight.data_ptr(), None if bias is None else bias.data_ptr(), out.data_ptr(), ws.data_ptr(),
@@ -448,7 +458,7 @@ def conv3x3_wgrad(x, gz, pad=1):
     Co = gz.shape[1]
     assert tuple(gz.shape) == (N, Co, H + 2 * pad - 2, W + 2 * pad - 2), (x.shape, gz.shape, pad)
     lib = _hip.lib()
-    ws = torch.empty(int(lib.savfi_conv3x3_wgrad_workspace_floats(N, Ci, Co, H, W, int(pad))), dtype=x.dtype, device=x.device)
+    ws = torch.empty(_workspace_floats("savfi_conv3x3_wgrad_workspace_floats", N, Ci, Co, H, W, int(pad)), dtype=x.dtype, device=x.device)
     gw = torch.empty((Co, Ci, 3, 3), dtype=x.dtype, device=x.device)
     _hip.launch("conv3x3_wgrad", lambda: _hip.check(lib.savfi_conv3x3_wgrad_f32(
         x.data_ptr(), gz.data_ptr(), gw.data_ptr(), ws.data_ptr(), N, Ci, Co, H, W, int(pad), _hip.current_stream()),

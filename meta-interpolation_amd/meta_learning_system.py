@@ -19,6 +19,8 @@ What is different (MI355X-first, results identical):
     with a single process this is the reference's sequential loop.  The reference's ``.module`` call
     for >1 visible device (:285-287) is not reproduced: one process owns one device.
 """
+import functools
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -157,6 +159,8 @@ class SceneAdaptiveInterpolation(nn.Module):
         self.criterion = criterion if criterion is not None else Loss(args)
         self.task_parallel = task_parallel if task_parallel is not None else TaskParallel()
         self._first_order = False
+        self._defer_logging = False
+        self._pending_logging = None
         self._graphs = {}            # (frame shape, steps, training, msl) -> GraphedInnerLoop
         self._manual_grads = None    # OuterGradAccumulator of the last graphed training forward
 
@@ -369,22 +373,36 @@ class SceneAdaptiveInterpolation(nn.Module):
             local_sum = torch.zeros((), device=self.device)
         losses = {'loss': local_sum / num_tasks}
 
-        # one host sync for everything that is logged
-        meters = deferred.flush()
         metrics = {'psnr': utils.AverageMeter(), 'ssim': utils.AverageMeter()}
+        self._logging(losses, metrics, deferred, eval_mse, eval_ssim, importance)
+        return losses, preds, metrics
+
+    def _logging(self, losses, metrics, deferred, eval_mse, eval_ssim, importance):
+        """Everything that is logged needs the device to have finished the forward passes.  During training that host sync
+        is postponed until the outer backward and the optimizer step are queued (run_train_iter): waiting here would
+        drain the queue and the backward would start with the host a whole launch queue behind the GPU."""
+        finish = functools.partial(self._finish_logging, losses, metrics, deferred, eval_mse, eval_ssim, importance)
+        if self._defer_logging:
+            self._pending_logging = finish
+        else:
+            finish()
+
+    def _finish_logging(self, losses, metrics, deferred, eval_mse, eval_ssim, importance):
+        """ONE host sync; fills `losses` and `metrics` in place."""
+        meters = deferred.flush()
         if eval_mse:
             mse = torch.stack(eval_mse).cpu().tolist()
             ssims = torch.stack(eval_ssim).cpu()
             for m, s in zip(mse, ssims):
                 metrics['psnr'].update(-10 * np.log10(m + 1e-8).item())
                 metrics['ssim'].update(s)
-        if tp.active:
+        if self.task_parallel.active:
             self._reduce_logging(losses, meters, metrics)
         for key, meter in meters.items():
             losses[key] = meter.avg
-        for idx, item in enumerate(importance):
-            losses['loss_importance_vector_{}'.format(idx)] = item.detach().cpu().numpy()
-        return losses, preds, metrics
+        weights = importance.detach().cpu().numpy()
+        for idx in range(len(weights)):
+            losses['loss_importance_vector_{}'.format(idx)] = np.asarray(weights[idx])
 
     def _forward_graphed(self, frames, epoch, use_multi_step_loss_optimization, num_steps, training_phase,
                          do_evaluation):
@@ -426,20 +444,8 @@ class SceneAdaptiveInterpolation(nn.Module):
         if training_phase:
             accum.num_tasks = num_tasks
             self._manual_grads = accum
-        meters = deferred.flush()
         metrics = {'psnr': utils.AverageMeter(), 'ssim': utils.AverageMeter()}
-        if eval_mse:
-            mse = torch.stack(eval_mse).cpu().tolist()
-            ssims = torch.stack(eval_ssim).cpu()
-            for m, s_ in zip(mse, ssims):
-                metrics['psnr'].update(-10 * np.log10(m + 1e-8).item())
-                metrics['ssim'].update(s_)
-        if tp.active:
-            self._reduce_logging(losses, meters, metrics)
-        for k, meter in meters.items():
-            losses[k] = meter.avg
-        for idx, item in enumerate(importance):
-            losses['loss_importance_vector_{}'.format(idx)] = item.detach().cpu().numpy()
+        self._logging(losses, metrics, deferred, eval_mse, eval_ssim, importance)
         return losses, preds, metrics
 
     def _reduce_logging(self, losses, meters, metrics):
@@ -495,11 +501,18 @@ class SceneAdaptiveInterpolation(nn.Module):
         if not self.training:
             self.train()
         data_batch = [frame.to(device=self.device, non_blocking=True) for frame in data_batch]
-        losses, preds, metrics = self.train_forward_prop(data_batch=data_batch, epoch=epoch,
-                                                         do_evaluation=do_evaluation)
-        self.meta_update(loss=losses['loss'])
-        self.optimizer.zero_grad()
-        self.zero_grad()
+        self._defer_logging = True
+        try:
+            losses, preds, metrics = self.train_forward_prop(data_batch=data_batch, epoch=epoch,
+                                                             do_evaluation=do_evaluation)
+            self.meta_update(loss=losses['loss'])
+            self.optimizer.zero_grad()
+            self.zero_grad()
+        finally:
+            self._defer_logging = False
+            finish, self._pending_logging = self._pending_logging, None
+        if finish is not None:
+            finish()
         return losses, preds, metrics
 
     def run_validation_iter(self, data_batch):
