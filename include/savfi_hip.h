@@ -11,6 +11,7 @@
  *                              kernel_Sepconv_updateGradInput         sepconv/sepconv_op/sepconv.py:32-63,  launch :328-341
  *   savfi_voxelwarp_fwd_f32    flow/mask split + meshgrid + 2x grid_sample + blend
  *   savfi_voxelwarp_bwd_f32                                          voxelflow/core/models/voxel_flow.py:471-509, :9-17
+ *   savfi_flowwarp_fwd/bwd_f32 pixel-flow backward warp              superslomo/model.py:231-307, rrin/model.py:8-20
  *   savfi_pixel_unshuffle_f32  pixel_shuffle(scale<1)                 model_utils.py:202-217 (else branch)
  *   savfi_pixel_shuffle_f32    pixel_shuffle(scale>=1)                model_utils.py:202-217 (if branch)
  *   savfi_mt_update_f32        LSLR / Meta-SGD update_sgd/adam/adamax inner_loop_optimizers.py:136-244, :324-425
@@ -46,7 +47,7 @@
 extern "C" {
 #endif
 
-#define SAVFI_ABI_VERSION 2
+#define SAVFI_ABI_VERSION 3
 
 #define SAVFI_OK            0
 #define SAVFI_E_NULL       (-1)  /* a required pointer is NULL                          */
@@ -88,6 +89,19 @@ int savfi_voxelwarp_fwd_f32(const float* frames, const float* x3, float* out,
 int savfi_voxelwarp_bwd_f32(const float* frames, const float* x3, const float* gO,
                             float* g_x3, float* g_frames,
                             int B, int H, int W, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Backward warping by a pixel-unit flow (SuperSloMo backWarp superslomo/model.py:231-307, RRIN warp
+ * rrin/model.py:8-20: meshgrid + 2*(x/W-0.5) normalisation + F.grid_sample(bilinear, zeros, align_corners=False)).
+ *   img [N,C,H,W], flow [N,2,H,W] (u, v in pixels) -> out [N,C,H,W]
+ *   out[n,c,y,x] = bilinear(img[n,c]; x + u - 0.5, y + v - 0.5), corners outside the image count as zero
+ *   (the half-pixel offset is what the reference's normalisation amounts to under align_corners=False).
+ * bwd: gflow [N,2,H,W] = dL/d(u,v), fully written (a gather: deterministic).  No image gradient: the warped
+ *      images are network inputs on this path.
+ * ---------------------------------------------------------------------------------- */
+int savfi_flowwarp_fwd_f32(const float* img, const float* flow, float* out, int N, int C, int H, int W, void* stream);
+int savfi_flowwarp_bwd_f32(const float* img, const float* flow, const float* gout, float* gflow,
+                           int N, int C, int H, int W, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Pixel (un)shuffle with the reference's channel order.
@@ -228,10 +242,11 @@ int savfi_conv3x3_wgrad_f32(const float* x, const float* gz, float* gw, float* w
 /* ----------------------------------------------------------------------------------
  * Frame staging (data/vimeo_septuplet.py:68-80, data/video.py:44-51: channel swap, HWC->CHW, .float()/255,
  * Normalize): src = N decoded frames, uint8 [N,H,W,3] on the DEVICE (copied there as bytes);
- * dst[n][c][y][x] = (src[n][y][x][swap_rb ? 2-c : c] / div - mean) / std, fp32 [N,3,H,W].
+ * dst[n][c][y][x] = (src[n][y][x][swap_rb ? 2-c : c] / div - mean_c) / std, fp32 [N,3,H,W]; one mean per OUTPUT
+ * channel (Super SloMo subtracts 0.429 / 0.431 / 0.397, data/vimeo_septuplet.py:31-35).
  * ---------------------------------------------------------------------------------- */
 int savfi_frames_u8_to_f32(const unsigned char* src, float* dst, int64_t N, int H, int W, int swap_rb, float div,
-                           float mean, float std, void* stream);
+                           float mean_c0, float mean_c1, float mean_c2, float std, void* stream);
 
 #ifdef __cplusplus
 }

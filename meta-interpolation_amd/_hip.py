@@ -16,7 +16,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_PKG_DIR), "include", "savfi_hip.h")
 
 RULE_SGD, RULE_ADAM, RULE_ADAMAX_LSLR, RULE_ADAMAX_MSGD = 0, 1, 2, 3
 LR_SCALAR, LR_ELEMENT = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _ERRORS = {-1: "SAVFI_E_NULL (a required pointer is NULL)",
            -2: "SAVFI_E_SHAPE (bad or inconsistent dimension)",
@@ -39,6 +39,8 @@ _PROTOTYPES = {
     "savfi_sepconv_bwd_f32": [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P],
     "savfi_voxelwarp_fwd_f32": [_P, _P, _P, c_int, c_int, c_int, _P],
     "savfi_voxelwarp_bwd_f32": [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P],
+    "savfi_flowwarp_fwd_f32": [_P, _P, _P, c_int, c_int, c_int, c_int, _P],
+    "savfi_flowwarp_bwd_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P],
     "savfi_pixel_unshuffle_f32": [_P, _P, c_int, c_int, c_int, c_int, c_int, _P],
     "savfi_pixel_shuffle_f32": [_P, _P, c_int, c_int, c_int, c_int, c_int, _P],
     "savfi_mt_update_f32": [c_int, c_int, c_int, _PP, _PP, _PP, _PP, _PP, _PP, _PP, _I64P, _FP, _FP,
@@ -55,7 +57,7 @@ _PROTOTYPES = {
     "savfi_conv3x3_f32": [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P],
     "savfi_conv3x3_wgrad_workspace_floats": [c_int] * 6,
     "savfi_conv3x3_wgrad_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P],
-    "savfi_frames_u8_to_f32": [_P, _P, c_int64, c_int, c_int, c_int, c_float, c_float, c_float, _P],
+    "savfi_frames_u8_to_f32": [_P, _P, c_int64, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float, _P],
     "savfi_upsample2x_window_fwd_f32": [_P, _P] + [c_int] * 12 + [_P],
     "savfi_upsample2x_window_bwd_f32": [_P, _P] + [c_int] * 12 + [_P],
     "savfi_bias_act_fwd_f32": [_P, _P, c_int, c_int, c_int, c_float, _P],

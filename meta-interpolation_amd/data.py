@@ -13,7 +13,7 @@
   meta-iteration still computes.  Bit-identical to the CPU path (same fp32 operation order).
 * ``SyntheticSeptupletLoader``: seeded synthetic septuplets (``--synthetic``; bench.py and the parity fixtures).
 
-superslomo normalisation, Middlebury / DAVIS / SNU-FILM readers: out of scope.
+Middlebury / DAVIS / SNU-FILM readers: out of scope.
 """
 import glob
 import os
@@ -34,12 +34,12 @@ def _read_rgb(path):
 
 
 def _normalisation(model):
-    """(div, mean, std) of dst = (u8 / div - mean) / std."""
+    """(div, mean per channel, std) of dst[c] = (u8[c] / div - mean[c]) / std."""
     if model == 'voxelflow':                          # .float() then Normalize(127.5, 127.5)   (:39-41, :74, :80)
-        return 1.0, 0.5 * 255, 0.5 * 255
-    if model == 'superslomo':
-        raise NotImplementedError("superslomo normalisation is outside this build's scope")
-    return 255.0, 0.0, 1.0                            # .float() / 255                         (:76)
+        return 1.0, (0.5 * 255,) * 3, 0.5 * 255
+    if model == 'superslomo':                         # .float() / 255 then Normalize((.429, .431, .397), 1)   (:31-35)
+        return 255.0, (0.429, 0.431, 0.397), 1.0
+    return 255.0, (0.0,) * 3, 1.0                     # .float() / 255                         (:76)
 
 
 def _to_float_chw(u8_hwc, model):
@@ -47,8 +47,8 @@ def _to_float_chw(u8_hwc, model):
     t = torch.from_numpy(np.ascontiguousarray(np.transpose(u8_hwc, (2, 0, 1)))).float()
     if div != 1.0:
         t = t / div
-    if mean != 0.0 or std != 1.0:
-        t = (t - mean) / std
+    if any(m != 0.0 for m in mean) or std != 1.0:
+        t = (t - torch.tensor(mean, dtype=t.dtype).view(3, 1, 1)) / std
     return t
 
 
@@ -68,7 +68,6 @@ class VimeoSeptuplet(object):
         self.frames = [1, 2, 3, 4, 5, 6, 7]
         self.current_set_name = "train" if args.mode == 'train' else 'val'
         self.data_length = {'train': len(self.trainlist), 'val': len(self.testlist), 'test': 0}
-        _normalisation(args.model)                    # raises for models this build does not cover
 
     def plan(self, index):
         """Paths + crop + flip of item `index`.  Consumes `random` exactly like the reference (randint(h), randint(w),
@@ -134,8 +133,6 @@ class Video(object):
         self.batch_size = {'train': 0, 'val': 0, 'test': args.test_batch_size}
         self.data_length = {'train': 0, 'val': 0, 'test': len(self.imglist)}
         self.current_set_name = 'test'
-        if args.model == 'superslomo':
-            raise NotImplementedError("superslomo normalisation is outside this build's scope")
 
     def plan(self, index):
         return list(self.imglist[index]), None
@@ -241,7 +238,7 @@ class FrameStager(object):
             out = torch.empty((F, B, 3, H, W), dtype=torch.float32, device=self.device)
             dev_u8.copy_(pinned, non_blocking=True)
             lib = self._hip.lib()
-            self._hip.check(lib.savfi_frames_u8_to_f32(dev_u8.data_ptr(), out.data_ptr(), F * B, H, W, 0, self.div, self.mean,
+            self._hip.check(lib.savfi_frames_u8_to_f32(dev_u8.data_ptr(), out.data_ptr(), F * B, H, W, 0, self.div, *self.mean,
                                                        self.std, self.stream.cuda_stream), "savfi_frames_u8_to_f32")
             done.record(self.stream)
         ready = torch.cuda.Event()

@@ -54,7 +54,7 @@ class ExperimentBuilder(object):
 
     def _eval_frames(self, frames):
         H, W = frames[0].shape[-2:]
-        if H * W > 5e5:
+        if H * W > 5e5 or (self.args.model == 'rrin' and H * W > 3e5):     # reference :105
             a, b, dim = self._split(frames)
             la, oa = self._eval_frames(a)
             lb, ob = self._eval_frames(b)
@@ -72,6 +72,8 @@ class ExperimentBuilder(object):
         target = images[3][0].detach().to(output.device)
         if self.args.model == 'voxelflow':
             target = (target * self.model.std + self.model.mean) / 255.0
+        elif self.args.model == 'superslomo':
+            target = self.model.revNormalize(target)
         metrics = {'psnr': utils.AverageMeter(), 'ssim': utils.AverageMeter()}
         psnr, ssim = utils.calc_metrics(output, target)
         metrics['psnr'].update(psnr)
@@ -81,7 +83,7 @@ class ExperimentBuilder(object):
     def test_iteration(self, test_sample):
         images, _ = test_sample
         H, W = images[0].shape[-2:]
-        if H * W > 5e5:
+        if H * W > 5e5 or (self.args.model == 'rrin' and H * W > 3e5):
             a, b, dim = self._split(images)
             oa, ob = self.model.run_test_iter(data_batch=a), self.model.run_test_iter(data_batch=b)
             return [torch.cat([x, y], dim=dim) for x, y in zip(oa, ob)]

@@ -24,7 +24,7 @@ from . import _hip, hip_ops, model_utils, utils
 def supported(system, use_second_order):
     a = system.args
     return (bool(getattr(a, 'graph_inner_loop', 0)) and system.device.type == 'cuda' and not use_second_order
-            and not a.attenuate and hasattr(system.inner_loop_optimizer, 'lr_mode'))
+            and a.model != 'superslomo' and not a.attenuate and hasattr(system.inner_loop_optimizer, 'lr_mode'))
 
 
 class GraphedInnerLoop:

@@ -58,6 +58,46 @@ def voxel_warp_blend(frames, x3):
 
 
 # --------------------------------------------------------------------------------------------
+# Backward warp by a pixel-unit flow    (reference: superslomo/model.py:231-307, rrin/model.py:8-20)
+# --------------------------------------------------------------------------------------------
+class _FlowWarp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, flow):
+        _hip.require_cuda(img, flow)
+        N, C, H, W = img.shape
+        assert flow.shape == (N, 2, H, W), (img.shape, flow.shape)
+        if ctx.needs_input_grad[0]:
+            raise NotImplementedError("flow_warp differentiates w.r.t. the flow only: on the reference's path the warped "
+                                      "images are network inputs (superslomo/model.py:600-624, rrin/model.py:99-100)")
+        out = torch.empty_like(img)
+        lib = _hip.lib()
+        _hip.launch("flowwarp_fwd", lambda: _hip.check(lib.savfi_flowwarp_fwd_f32(
+            img.data_ptr(), flow.data_ptr(), out.data_ptr(), N, C, H, W, _hip.current_stream()),
+            "savfi_flowwarp_fwd_f32"), nbytes=4 * N * H * W * (2 * C + 2))
+        ctx.save_for_backward(img, flow)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        img, flow = ctx.saved_tensors
+        N, C, H, W = img.shape
+        gout = gout.contiguous()
+        gflow = torch.empty_like(flow)
+        lib = _hip.lib()
+        _hip.launch("flowwarp_bwd", lambda: _hip.check(lib.savfi_flowwarp_bwd_f32(
+            img.data_ptr(), flow.data_ptr(), gout.data_ptr(), gflow.data_ptr(), N, C, H, W, _hip.current_stream()),
+            "savfi_flowwarp_bwd_f32"), nbytes=4 * N * H * W * (2 * C + 4))
+        return None, gflow
+
+
+def flow_warp(img, flow):
+    """img [N,C,H,W] sampled at (x + u - 0.5, y + v - 0.5), flow = (u, v) [N,2,H,W] in pixels: exactly what
+    backWarp / warp of the reference compute (their normalisation under grid_sample's align_corners=False)."""
+    return _FlowWarp.apply(img.contiguous(), flow.contiguous())
+
+
+# --------------------------------------------------------------------------------------------
 # Pixel (un)shuffle                                   (reference: model_utils.py:202-217)
 # --------------------------------------------------------------------------------------------
 def _launch_shuffle(x, r, down):

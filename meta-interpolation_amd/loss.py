@@ -19,7 +19,7 @@ class Loss(nn.modules.loss._Loss):
             weight, loss_type = term.split('*')
             if loss_type not in _KERNELS:
                 raise NotImplementedError(
-                    "loss '%s' is outside the SepConv/VoxelFlow/CAIN inner-loop path (only L1, MSE)" % loss_type)
+                    "loss '%s' is outside the inner-loop path built here (only L1, MSE; 'Super' / VGG terms need pretrained VGG16 weights)" % loss_type)
             self.loss.append({'type': loss_type, 'weight': float(weight), 'function': _KERNELS[loss_type]})
         self.cuda_only = True
 

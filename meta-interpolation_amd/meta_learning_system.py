@@ -57,7 +57,18 @@ def _build_voxelflow(args, resume):
     return MetaVoxelFlow(args, resume=resume)
 
 
-MODEL_REGISTRY = {'sepconv': _build_sepconv, 'cain': _build_cain, 'voxelflow': _build_voxelflow}
+def _build_rrin(args, resume):
+    from .rrin.model import MetaRRIN
+    return MetaRRIN(level=3, resume=resume)
+
+
+def _build_superslomo(args, resume):
+    from .superslomo.model import MetaSuperSloMo
+    return MetaSuperSloMo(torch.device('cuda') if args.cuda else torch.device('cpu'), resume=resume)
+
+
+MODEL_REGISTRY = {'sepconv': _build_sepconv, 'cain': _build_cain, 'voxelflow': _build_voxelflow, 'rrin': _build_rrin,
+                  'superslomo': _build_superslomo}
 
 
 def register_model(name, factory):
@@ -116,6 +127,11 @@ class SceneAdaptiveInterpolation(nn.Module):
         if args.model == 'voxelflow':
             half = torch.full((3, 1, 1), 0.5 * 255, device=self.device)
             self.mean, self.std = half.clone(), half.clone()
+        if args.model == 'superslomo':
+            # Super SloMo frames are mean-subtracted by the loaders; revNormalize brings outputs back to 0..1
+            # (the reference builds transforms.Normalize(mean=-m, std=1) for this, :69-73)
+            shift = torch.tensor([.429, .431, .397], device=self.device).view(3, 1, 1)
+            self.revNormalize = lambda img: img + shift
 
         self.inner_learning_rate = args.inner_lr
         if inner_loop_optimizer is not None:
@@ -207,6 +223,9 @@ class SceneAdaptiveInterpolation(nn.Module):
         """One backbone pass with fast weights + criterion -> (losses dict, output)  (reference :475-509)."""
         output = self.net.forward(frame0, frame1, params=weights,
                                   backup_running_statistics=backup_running_statistics, num_step=num_step)
+        if isinstance(output, tuple):     # superslomo: (frame, flows and warped frames for the 'Super' loss)  (:499-502)
+            output, extras = output
+            return self.criterion(output, target, I0=frame0, I1=frame1, **extras), output
         return self.criterion(output, target), output
 
     def _support_loss(self, frames, task_id, weights, num_step):
@@ -227,6 +246,8 @@ class SceneAdaptiveInterpolation(nn.Module):
             f1 = torch.cat([frames[a[2]][sl], frames[b[2]][sl]], 0)
             out = self.net.forward(f0, f1, params=weights, backup_running_statistics=(num_step == 0),
                                    num_step=num_step)
+            if isinstance(out, tuple):    # superslomo; its extras only feed the 'Super' loss, which Loss rejects
+                out = out[0]
             la = self.criterion(out[0:1], frames[a[1]][sl])
             lb = self.criterion(out[1:2], frames[b[1]][sl])
             return la['total'] + lb['total']
@@ -299,6 +320,8 @@ class SceneAdaptiveInterpolation(nn.Module):
     def _to_unit_range(self, img):
         if self.args.model == 'voxelflow':
             return (img * self.std + self.mean) / 255.0
+        if self.args.model == 'superslomo':
+            return self.revNormalize(img)
         return img
 
     def forward(self, data_batch, epoch, use_second_order, use_multi_step_loss_optimization, num_steps,
@@ -537,6 +560,8 @@ class SceneAdaptiveInterpolation(nn.Module):
                     out = self.net.forward(frames[1][task_id].unsqueeze(0), frames[2][task_id].unsqueeze(0),
                                            params=weights, backup_running_statistics=False,
                                            num_step=max(steps - 1, 0))
+                if isinstance(out, tuple):     # superslomo (:686-688)
+                    out = self.revNormalize(out[0].squeeze(0)).unsqueeze(0)
                 preds[task_id] = out.squeeze(0).detach()
                 self.net.restore_backup_stats()
         finally:

@@ -13,7 +13,12 @@ import torch
 
 # Xavier-uniform bound multiplier per plugin: keeps un-normalised random nets at O(1) outputs
 # (raw Xavier makes CAIN's 127-conv stack blow up to L1 ~ 20; SepConv's separable taps need 1.2x to leave ~0).
-_GAIN = {'sepconv': 1.2, 'cain': 0.5, 'voxelflow': 1.0}
+_GAIN = {'sepconv': 1.2, 'cain': 0.5, 'voxelflow': 1.0, 'rrin': 1.0, 'superslomo': 1.68}
+# per sub-network overrides (name prefix): RRIN's flow nets need > 1 to produce flows of a sizeable fraction of a pixel,
+# its `final` residual net < 1 so that the clamp(0, 1) at the end does not saturate
+_GAIN_PREFIX = {'rrin': {'Flow_L.': 1.3, 'refine_flow.': 1.3, 'final.': 0.85}}
+# Super SloMo works on mean-subtracted frames (data/vimeo_septuplet.py:31-33; meta_learning_system.py:71-73 undoes it)
+SUPERSLOMO_MEAN = (0.429, 0.431, 0.397)
 
 
 def _stream(seed, name):
@@ -22,9 +27,12 @@ def _stream(seed, name):
 
 def seeded_state_dict(net, model, seed=12345):
     """{name: tensor} for every parameter and buffer of `net`, one independent numpy stream per name."""
-    gain = _GAIN.get(model, 1.0)
     out = {}
     for name, ref in net.state_dict().items():
+        gain = _GAIN.get(model, 1.0)
+        for prefix, g in _GAIN_PREFIX.get(model, {}).items():
+            if name.startswith(prefix):
+                gain = g
         rs = _stream(seed, name)
         shape = tuple(ref.shape)
         if name.endswith('num_batches_tracked'):
@@ -76,6 +84,8 @@ def septuplet(task_seed, height, width, frames=7, model='sepconv'):
         q = np.round(crop * 255.0) / 255.0
         if model == 'voxelflow':
             q = (255.0 * q - 127.5) / 127.5
+        elif model == 'superslomo':
+            q = q - np.asarray(SUPERSLOMO_MEAN)
         out.append(torch.from_numpy(np.ascontiguousarray(q.transpose(2, 0, 1)).astype(np.float32)))
     return out
 

@@ -49,9 +49,13 @@ def install_shims():
     tv = types.ModuleType("torchvision")
     tv.transforms = types.ModuleType("torchvision.transforms")
 
-    class Normalize:  # only constructed for superslomo; never called on this path
+    class Normalize:  # torchvision.transforms.Normalize: (x - mean[:, None, None]) / std[:, None, None]
         def __init__(self, mean, std):
-            self.mean, self.std = mean, std
+            self.mean = torch.tensor(mean, dtype=torch.float32)[:, None, None]
+            self.std = torch.tensor(std, dtype=torch.float32)[:, None, None]
+
+        def __call__(self, x):
+            return (x - self.mean) / self.std
     tv.transforms.Normalize = Normalize
     tv.models = types.ModuleType("torchvision.models")
     sys.modules["torchvision"] = tv
@@ -93,7 +97,7 @@ def build_reference_system(args, model, seed=12345):
     if model == 'sepconv':
         import sepconv.sepconv_op.sepconv as ref_op
         ref_op.FunctionSepconv = O.SepconvCPU
-    if model == 'voxelflow':
+    if model in ('voxelflow', 'rrin'):       # hard-coded .cuda() calls (voxel_flow.py:476-477, rrin/model.py:11-12)
         torch.Tensor.cuda = lambda self, *a, **k: self
     cwd = os.getcwd()
     tmp = tempfile.mkdtemp(prefix="savfi_golden_")
@@ -167,6 +171,13 @@ SYSTEM_CASES = {
     'voxelflow_lslr_sgd_2step': ('voxelflow', 64, 64, 2, dict(optimizer='SGD', inner_lr=1e-3, loss='1*MSE',
                                                               number_of_training_steps_per_iter=2,
                                                               number_of_evaluation_steps_per_iter=2)),
+    # the two plugins built on the pixel-flow warp
+    'rrin_lslr_sgd_2step': ('rrin', 64, 64, 1, dict(optimizer='SGD', inner_lr=1e-3, loss='1*L1',
+                                                    number_of_training_steps_per_iter=2,
+                                                    number_of_evaluation_steps_per_iter=2)),
+    'superslomo_lslr_sgd_2step': ('superslomo', 64, 64, 2, dict(optimizer='SGD', inner_lr=1e-3, loss='1*L1',
+                                                                number_of_training_steps_per_iter=2,
+                                                                number_of_evaluation_steps_per_iter=2)),
     # the reference's own launch-script settings: run_voxelflow.sh / run_cain.sh (Adam + Meta-SGD, 1 step, lr 1e-5)
     'voxelflow_script_metasgd_adam_1step': ('voxelflow', 64, 64, 1, dict(optimizer='Adam', inner_lr=1e-5, metasgd=True,
                                                                          loss='1*MSE')),
@@ -321,6 +332,19 @@ def run_op_cases():
         o2 = net(fr[0], fr[2])
     out['vf_big_x3'] = torch.tanh(torch.atanh(big.clamp(-0.9999, 0.9999))).numpy()
     out['vf_big_out'] = o2.numpy()
+    # pixel-flow backward warp: the reference's own backWarp (superslomo/model.py:231-307) and warp (rrin/model.py:8-20)
+    # on a seeded image and a flow whose targets partly leave the frame; flow gradient by autograd
+    from superslomo.model import backWarp
+    from rrin.model import warp as rrin_warp
+    rw = np.random.RandomState(11)
+    img = torch.from_numpy(rw.uniform(size=(2, 3, 20, 36)).astype(np.float32))
+    flow = torch.from_numpy(rw.normal(scale=4.0, size=(2, 2, 20, 36)).astype(np.float32)).requires_grad_()
+    gout = torch.from_numpy(rw.normal(size=(2, 3, 20, 36)).astype(np.float32))
+    warped = backWarp(36, 20, torch.device('cpu'))(img, flow)
+    gflow, = torch.autograd.grad((warped * gout).sum(), flow)
+    out['fw_img'], out['fw_flow'], out['fw_gout'] = img.numpy(), flow.detach().numpy(), gout.numpy()
+    out['fw_out'], out['fw_gflow'] = warped.detach().numpy(), gflow.numpy()
+    out['fw_out_rrin'] = rrin_warp(img, flow.detach()).numpy()
     np.savez_compressed(os.path.join(GOLD, 'ops.npz'), **out)
     print('  ops.npz: %d arrays' % len(out))
 

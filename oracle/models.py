@@ -158,4 +158,104 @@ def voxelflow_forward(x0, x1, base, fast=None, warp=None):
     return out[:, :, pad[2]:pad[2] + h, pad[0]:pad[0] + w]
 
 
-FORWARD = {'sepconv': sepconv_forward, 'cain': cain_forward, 'voxelflow': voxelflow_forward}
+# ---------------------------------------------------------------------------------------------
+# RRIN                                                    rrin/model.py:69-131, rrin/unet.py:101-208
+# ---------------------------------------------------------------------------------------------
+def _lrelu(x):
+    return F.leaky_relu(x, negative_slope=0.1)
+
+
+def _reflect_to(x, shift):
+    """Reflection pad to a multiple of 2**shift; returns (padded, crop function)."""
+    w, h = x.size(3), x.size(2)
+    pw = 0 if w == ((w >> shift) << shift) else (((w >> shift) + 1) << shift) - w
+    ph = 0 if h == ((h >> shift) << shift) else (((h >> shift) + 1) << shift) - h
+    pad = [pw // 2, pw - pw // 2, ph // 2, ph - ph // 2]
+    crop = lambda t: t[:, :, pad[2]:pad[2] + h, pad[0]:pad[0] + w]
+    return (lambda t: F.pad(t, pad, mode='reflect') if (pw or ph) else t), crop
+
+
+def _rrin_unet(x, get, name, depth):
+    """MetaUNet.forward (unet.py:130-158): conv blocks + avg-pool down, midconv, (x2 bilinear, conv, cat, conv block) up."""
+    conv = lambda t, n: F.conv2d(t, get(n + '.weight'), get(n + '.bias'), 1, 1)
+    block = lambda t, n: _lrelu(conv(_lrelu(conv(t, n + '.block.0')), n + '.block.2'))
+    bridges = []
+    for i in range(depth):
+        x = block(x, '%s.down_path.%d' % (name, i))
+        if i != depth - 1:
+            bridges.append(x)
+            x = F.avg_pool2d(x, 2)
+    x = _lrelu(conv(x, name + '.midconv'))
+    for i in range(depth - 1):
+        up = conv(F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False), '%s.up_path.%d.up.1' % (name, i))
+        bridge = bridges[-i - 1]
+        dy, dx = (bridge.size(2) - up.size(2)) // 2, (bridge.size(3) - up.size(3)) // 2
+        x = block(torch.cat((up, bridge[:, :, dy:dy + up.size(2), dx:dx + up.size(3)]), 1), '%s.up_path.%d.conv_block' % (name, i))
+    return conv(x, name + '.last')
+
+
+def rrin_forward(x0, x1, base, fast=None, warp=None, t=0.5):
+    warp = warp or O.flow_warp
+    get = _W(base, fast)
+    pad, crop = _reflect_to(x0, 7)
+    x0, x1 = pad(x0), pad(x1)
+    x = torch.cat((x0, x1), 1)
+    flow = _rrin_unet(x, get, 'Flow_L', 5)
+    f01, f10 = flow[:, :2], flow[:, 2:4]
+    ft0 = -(1 - t) * t * f01 + t * t * f10
+    ft1 = (1 - t) * (1 - t) * f01 - t * (1 - t) * f10
+    res = _rrin_unet(torch.cat((ft0, ft1, x), 1), get, 'refine_flow', 4)
+    ft0, ft1 = ft0 + res[:, :2], ft1 + res[:, 2:4]
+    xt0, xt1 = warp(x0, ft0), warp(x1, ft1)
+    mask = torch.sigmoid(_rrin_unet(torch.cat((ft0, ft1, x, xt0, xt1), 1), _W(base, None), 'Mask', 4))   # own weights: :104
+    w0, w1 = (1 - t) * mask[:, 0:1], t * mask[:, 1:2]
+    blend = (w0 * xt0 + w1 * xt1) / (w0 + w1 + 1e-8)
+    final = _rrin_unet(torch.cat((x0, x1, blend), 1), get, 'final', 4) + blend
+    return crop(final.clamp(0, 1))
+
+
+# ---------------------------------------------------------------------------------------------
+# Super SloMo                                                     superslomo/model.py:457-646
+# ---------------------------------------------------------------------------------------------
+def _slomo_unet(x, get, name):
+    """MetaUNet.forward (:499-545): 7x7, 7x7, five (avg-pool, k x k, k x k) downs, five (x2, 3x3, cat skip, 3x3) ups, 3x3."""
+    conv = lambda t, n, k: _lrelu(F.conv2d(t, get('%s.%s.weight' % (name, n)), get('%s.%s.bias' % (name, n)), 1, (k - 1) // 2))
+    x = conv(x, 'conv1', 7)
+    skips = [conv(x, 'conv2', 7)]
+    for i, k in enumerate((5, 3, 3, 3, 3)):
+        y = F.avg_pool2d(skips[-1] if i < 5 else x, 2)
+        y = conv(conv(y, 'down%d.conv1' % (i + 1), k), 'down%d.conv2' % (i + 1), k)
+        skips.append(y)
+    x = skips.pop()
+    for i in range(5):
+        x = conv(F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False), 'up%d.conv1' % (i + 1), 3)
+        x = conv(torch.cat((x, skips.pop()), 1), 'up%d.conv2' % (i + 1), 3)
+    return conv(x, 'conv3', 3)
+
+
+def superslomo_forward(I0, I1, base, fast=None, warp=None, ind=3):
+    """Returns the interpolated (mean-subtracted) frame; the extra outputs of the reference only feed its 'Super' loss."""
+    import numpy as np
+    warp = warp or O.flow_warp
+    get = _W(base, fast)
+    t = float(np.linspace(0.125, 0.875, 7)[ind])                         # :308, getFlowCoeff / getWarpCoeff :310-382
+    c00 = c11 = float(np.float32(-(1 - t) * t))
+    c01, c10 = float(np.float32(t * t)), float(np.float32((1 - t) * (1 - t)))
+    pad, crop = _reflect_to(I0, 6)
+    I0, I1 = pad(I0), pad(I1)
+    flows = _slomo_unet(torch.cat((I0, I1), 1), get, 'flowComp')
+    F01, F10 = flows[:, :2], flows[:, 2:]
+    Ft0 = c00 * F01 + c01 * F10
+    Ft1 = c10 * F01 + c11 * F10
+    g0, g1 = warp(I0, Ft0), warp(I1, Ft1)
+    intrp = _slomo_unet(torch.cat((I0, I1, F01, F10, Ft1, Ft0, g1, g0), 1), get, 'arbTimeFlowIntrp')
+    Ft0f, Ft1f = intrp[:, :2] + Ft0, intrp[:, 2:4] + Ft1
+    V0 = torch.sigmoid(intrp[:, 4:5])
+    V1 = 1 - V0
+    g0f, g1f = warp(I0, Ft0f), warp(I1, Ft1f)
+    C0, C1 = float(np.float32(1 - t)), float(np.float32(t))
+    return crop((C0 * V0 * g0f + C1 * V1 * g1f) / (C0 * V0 + C1 * V1))
+
+
+FORWARD = {'sepconv': sepconv_forward, 'cain': cain_forward, 'voxelflow': voxelflow_forward, 'rrin': rrin_forward,
+           'superslomo': superslomo_forward}

@@ -29,7 +29,7 @@ def vimeo_args(root, model, mode, **kw):
     return types.SimpleNamespace(**base)
 
 
-@pytest.mark.parametrize("model", ["sepconv", "voxelflow"])
+@pytest.mark.parametrize("model", ["sepconv", "voxelflow", "superslomo"])
 @pytest.mark.parametrize("mode", ["train", "val"])
 def test_vimeo_reader_matches_the_reference_class(vimeo_root, model, mode):
     g = golden("data_readers")
@@ -61,7 +61,7 @@ def test_video_reader_matches_the_reference_class(tmp_path):
             assert np.allclose(fp, g['video_%d_fp%d' % (idx, f)], rtol=1e-12)
 
 
-@pytest.mark.parametrize("model", ["sepconv", "voxelflow"])
+@pytest.mark.parametrize("model", ["sepconv", "voxelflow", "superslomo"])
 def test_hd_reader_matches_the_reference_class(tmp_path, model):
     g = golden("data_readers")
     root = synthetic.write_fake_hd(str(tmp_path / "hd"))
@@ -104,8 +104,6 @@ def test_provider_surface_and_batch_layout(vimeo_root):
     assert prov.dataset.current_set_name == 'val'
     with pytest.raises(NotImplementedError):
         data.MetaLearningSystemDataLoader(vimeo_args(vimeo_root, 'sepconv', 'train', dataset='middlebury'))
-    with pytest.raises(NotImplementedError):
-        data.VimeoSeptuplet(vimeo_args(vimeo_root, 'superslomo', 'train'))
 
 
 def test_training_batches_are_reproducible_with_parallel_decode(vimeo_root):

@@ -2,6 +2,8 @@
 oracle on identical seeded inputs.  Tolerances are stated per test; fp32 everywhere."""
 import math
 
+import numpy as np
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -9,6 +11,7 @@ import torch.nn.functional as F
 from meta_interpolation_amd import _hip, hip_ops
 from meta_interpolation_amd.sepconv.sepconv_op.sepconv import FunctionSepconv
 from oracle import torch_ops as O
+from tests.helpers import golden
 
 pytestmark = pytest.mark.gpu
 
@@ -148,6 +151,51 @@ def test_voxelwarp_vs_oracle(B, H, W, amp):
     # d/dflow multiplies texel differences by (size-1)/2: compare relative to the largest gradient
     assert _rel(xd.grad.cpu(), xr.grad) < 1e-4
     assert _rel(fd.grad.cpu(), fr.grad) < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------
+# pixel-flow backward warp (Super SloMo backWarp / RRIN warp)
+# ---------------------------------------------------------------------------------------------
+def test_flowwarp_matches_the_reference_fixture():
+    """Values and flow gradient of the reference's own backWarp run on CPU (tests/golden/ops.npz: fw_*)."""
+    g = golden("ops")
+    img, gout = torch.from_numpy(g['fw_img']).to(DEV), torch.from_numpy(g['fw_gout']).to(DEV)
+    flow = torch.from_numpy(g['fw_flow']).to(DEV).requires_grad_()
+    out = hip_ops.flow_warp(img, flow)
+    out.backward(gout)
+    assert np.abs(out.detach().cpu().numpy() - g['fw_out']).max() < 2e-6
+    assert np.abs(flow.grad.cpu().numpy() - g['fw_gflow']).max() < 1e-5 * np.abs(g['fw_gflow']).max()
+
+
+@pytest.mark.parametrize("N,C,H,W,amp", [(1, 3, 128, 128, 1.0), (2, 3, 64, 192, 6.0), (1, 3, 37, 53, 30.0), (1, 1, 1, 1, 0.7),
+                                         (2, 5, 3, 300, 2.0), (1, 3, 768, 1280, 8.0)])
+def test_flowwarp_vs_oracle(N, C, H, W, amp):
+    gen = torch.Generator().manual_seed(H * W + C)
+    img = torch.rand(N, C, H, W, generator=gen)
+    flow = torch.randn(N, 2, H, W, generator=gen) * amp              # large amp: most targets leave the frame
+    gout = torch.randn(N, C, H, W, generator=gen)
+    fr = flow.clone().requires_grad_()
+    ref = O.flow_warp(img, fr)
+    ref.backward(gout)
+    fd = flow.to(DEV).requires_grad_()
+    out = hip_ops.flow_warp(img.to(DEV), fd)
+    out.backward(gout.to(DEV))
+    # coordinates are rounded at ~6e-8 * W px; the image is white noise (texel differences ~1)
+    assert (out.detach().cpu() - ref.detach()).abs().max() < 5e-6 * max(1.0, W / 64.0)
+    assert _rel(fd.grad.cpu(), fr.grad) < 1e-5 * max(1.0, W / 64.0)
+    # idempotence under a zero flow shifted by the reference's half pixel: sampling at (x - 0.5, y - 0.5)
+    zero = hip_ops.flow_warp(img.to(DEV), torch.full((N, 2, H, W), 0.5, device=DEV))
+    assert torch.allclose(zero.cpu(), img, atol=2e-4)      # the coordinate round trip is exact to ~1e-4 px at W = 1280
+
+
+def test_flowwarp_refuses_an_image_gradient_and_survives_nan_flows():
+    img = torch.rand(1, 3, 8, 8, device=DEV, requires_grad=True)
+    with pytest.raises(NotImplementedError):
+        hip_ops.flow_warp(img, torch.zeros(1, 2, 8, 8, device=DEV))
+    bad = torch.zeros(1, 2, 8, 8, device=DEV)
+    bad[0, 0, 0, 0], bad[0, 1, 1, 1], bad[0, 0, 2, 2] = float('nan'), float('inf'), -1e30
+    out = hip_ops.flow_warp(img.detach(), bad)
+    assert out[0, :, 0, 0].abs().sum() == 0 and out[0, :, 1, 1].abs().sum() == 0 and out[0, :, 2, 2].abs().sum() == 0
 
 
 @pytest.mark.parametrize("B,C,H,W,r", [(1, 3, 128, 128, 8), (2, 3, 16, 24, 2), (1, 3, 768, 1280, 8), (1, 1, 8, 8, 8),
@@ -398,7 +446,7 @@ def test_sepconv_with_winograd_convs_equals_miopen_convs():
 # ---------------------------------------------------------------------------------------------
 # frame staging: uint8 HWC over PCIe -> fp32 NCHW on the GPU
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("model", ["sepconv", "voxelflow"])
+@pytest.mark.parametrize("model", ["sepconv", "voxelflow", "superslomo"])
 def test_frame_stager_is_bit_identical_to_the_cpu_reader(model, tmp_path):
     import random
     import types

@@ -55,7 +55,8 @@ def test_flags_keep_reference_names_and_defaults():
 
 
 @pytest.mark.parametrize("model,count,numel", [("sepconv", 94, 21675452), ("voxelflow", 23, 3821891),
-                                               ("cain", 494, 42780432)])
+                                               ("cain", 494, 42780432), ("rrin", 162, 19194445),
+                                               ("superslomo", 92, 39610473)])
 def test_inner_loop_dict_sizes(model, count, numel):
     """94 / 23 / 494 tensors."""
     net = build_plugin(model)
@@ -67,7 +68,9 @@ def test_inner_loop_dict_sizes(model, count, numel):
 
 @pytest.mark.parametrize("case,model", [("system_sepconv_lslr_sgd_2step", "sepconv"),
                                         ("system_voxelflow_metasgd_adamax_2step", "voxelflow"),
-                                        ("system_c1_cain_lslr_sgd", "cain")])
+                                        ("system_c1_cain_lslr_sgd", "cain"),
+                                        ("system_rrin_lslr_sgd_2step", "rrin"),
+                                        ("system_superslomo_lslr_sgd_2step", "superslomo")])
 def test_parameter_names_match_the_reference(case, model):
     """Names key the lr tables, checkpoints and the fast-weight routing: they must be the reference's."""
     g = golden(case)
@@ -155,5 +158,5 @@ def test_synthetic_recipe_is_deterministic_and_well_formed():
     assert all(torch.equal(p, q) for p, q in zip(n1.state_dict().values(), n2.state_dict().values()))
 
 
-def test_registry_has_the_three_plugins():
-    assert {'sepconv', 'voxelflow', 'cain'} <= set(MODEL_REGISTRY)
+def test_registry_has_the_plugins():
+    assert {'sepconv', 'voxelflow', 'cain', 'rrin', 'superslomo'} <= set(MODEL_REGISTRY)

@@ -38,6 +38,21 @@ def test_voxel_warp_matches_reference_model_tail():
     assert np.abs(big.numpy() - g['vf_big_out']).max() < 2e-5   # atanh/tanh round trip in the fixture
 
 
+def test_flow_warp_matches_reference_backwarp():
+    """The written-out bilinear gather == the reference's backWarp / warp (superslomo/model.py:231-307, rrin/model.py:8-20)
+    run here on CPU: values and the flow gradient, with a flow that partly leaves the frame."""
+    g = golden("ops")
+    img, gout = torch.from_numpy(g['fw_img']), torch.from_numpy(g['fw_gout'])
+    for fn in (O.flow_warp, O.flow_warp_reference_ops):
+        flow = torch.from_numpy(g['fw_flow']).requires_grad_()
+        out = fn(img, flow)
+        gflow, = torch.autograd.grad((out * gout).sum(), flow)
+        assert np.abs(out.detach().numpy() - g['fw_out']).max() < 2e-6
+        assert np.abs(out.detach().numpy() - g['fw_out_rrin']).max() < 2e-6
+        assert np.abs(gflow.numpy() - g['fw_gflow']).max() < 1e-5 * np.abs(g['fw_gflow']).max()
+    assert (g['fw_out'] == 0).mean() > 0.02            # the case does sample outside the image
+
+
 def test_sepconv_c_and_torch_restatements_agree():
     gen = torch.Generator().manual_seed(3)
     inp = torch.rand(2, 3, 20 + 50, 31 + 50, generator=gen)
@@ -105,7 +120,8 @@ def test_rules_match_reference(kind, opt):
 # ---------------------------------------------------------------------------------------------
 SYSTEM = ['c1_cain_lslr_sgd', 'cain_l2f', 'cain_lslr_adam_1step', 'sepconv_lslr_sgd_2step',
           'sepconv_metasgd_adamax_2step', 'sepconv_msl_learnable_2step', 'voxelflow_metasgd_adamax_2step',
-          'voxelflow_lslr_sgd_2step', 'voxelflow_script_metasgd_adam_1step']
+          'voxelflow_lslr_sgd_2step', 'voxelflow_script_metasgd_adam_1step',
+          'rrin_lslr_sgd_2step', 'superslomo_lslr_sgd_2step']
 
 
 def _run_oracle_case(name, phase):
@@ -148,6 +164,8 @@ def test_oracle_iteration_matches_reference(name, phase):
     want = g[phase + '_preds']
     if str(g['model']) == 'voxelflow':      # fixture preds are mapped back to [0,1] (x*127.5+127.5)/255
         preds = (preds * 127.5 + 127.5) / 255.0
+    if str(g['model']) == 'superslomo':     # revNormalize (meta_learning_system.py:69-73, :435): + channel means
+        preds = preds + np.asarray(synthetic.SUPERSLOMO_MEAN, dtype=np.float32).reshape(1, 3, 1, 1)
     assert np.abs(preds - want).mean() < 1e-5            # pixel L1 gate is 1e-4
     assert list(g[phase + '_n_live']) == rec['n_live']
     for i, d in enumerate(rec['weight_fp']):

@@ -22,7 +22,8 @@ DEV = "cuda"
 
 SYSTEM = ['c1_cain_lslr_sgd', 'cain_l2f', 'cain_lslr_adam_1step', 'sepconv_lslr_sgd_2step',
           'sepconv_metasgd_adamax_2step', 'sepconv_msl_learnable_2step', 'voxelflow_metasgd_adamax_2step',
-          'voxelflow_lslr_sgd_2step', 'voxelflow_script_metasgd_adam_1step']
+          'voxelflow_lslr_sgd_2step', 'voxelflow_script_metasgd_adam_1step', 'rrin_lslr_sgd_2step',
+          'superslomo_lslr_sgd_2step']
 
 # Gates.  `smooth` = SGD-type inner rules, where the whole path is a smooth function of the conv outputs.
 # Adam / Adamax steps are +-lr*c per element whatever |g| (g/(|g|+1e-8), m/(sqrt(v)+1e-8)): an element
