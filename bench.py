@@ -45,6 +45,9 @@ WORKLOADS = {
     'c1_cain_64x64_b1_s1': ('cain', 64, 64, 1, 1, dict(optimizer='SGD', loss='1*L1', inner_lr=1e-5)),
     # same launch sequence as C2 on tiny frames: wall time ~= the host-side floor of one C2 meta-iteration
     'c2_host_floor_64x64_b4_s5': ('sepconv', 64, 64, 4, 5, dict(optimizer='SGD', loss='1*L1', inner_lr=1e-5)),
+    # SURVEY 8(f) rank 4 plugins (no BASELINE.json config names them: extra lines, same metric)
+    'rrin_256x448_b4_s5': ('rrin', 256, 448, 4, 5, dict(optimizer='SGD', loss='1*L1', inner_lr=1e-5)),
+    'superslomo_256x448_b4_s5': ('superslomo', 256, 448, 4, 5, dict(optimizer='SGD', loss='1*L1', inner_lr=1e-5)),
     'c5_cain_l2f_720p_b1_s1': ('cain', 720, 1280, 1, 1, dict(optimizer='SGD', loss='1*L1', inner_lr=1e-5, attenuate=True)),
 }
 

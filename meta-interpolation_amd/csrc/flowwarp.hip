@@ -11,10 +11,13 @@
 // produced: a pure gather, no atomics, bit-reproducible.
 //
 // HBM-bound: per pixel 2 floats of flow in, C out, 4 corners x C channels from L2 (neighbouring lanes sample
-// neighbouring texels).  One thread per pixel, x fastest: flow / out / gout accesses are coalesced 256-byte segments.
+// neighbouring texels).  One thread per pixel in 64 x 4 pixel workgroups: flow / out / gout accesses are coalesced
+// 256-byte segments, and the two texel rows a pixel row samples are shared with the rows above / below through the CU's L1.
 #include "common.h"
 
 namespace {
+
+constexpr int TX = 64, TY = 4;      // pixels per workgroup
 
 struct Corner {
   int x0, y0;          // north-west corner (may lie outside)
@@ -53,9 +56,9 @@ __device__ __forceinline__ float texel(const float* __restrict__ plane, int y, i
 
 __global__ __launch_bounds__(256) void flowwarp_fwd(const float* __restrict__ img, const float* __restrict__ flow,
                                                     float* __restrict__ out, int C, int H, int W) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  const int y = blockIdx.y, n = blockIdx.z;
-  if (x >= W) return;
+  const int x = blockIdx.x * TX + threadIdx.x;
+  const int y = blockIdx.y * TY + threadIdx.y, n = blockIdx.z;
+  if (x >= W || y >= H) return;
   const size_t plane = (size_t)H * W, p = (size_t)y * W + x;
   const float* f = flow + (size_t)n * 2 * plane + p;
   const Corner c = source_cell(x, y, f[0], f[plane], H, W);
@@ -71,9 +74,9 @@ __global__ __launch_bounds__(256) void flowwarp_fwd(const float* __restrict__ im
 __global__ __launch_bounds__(256) void flowwarp_bwd(const float* __restrict__ img, const float* __restrict__ flow,
                                                     const float* __restrict__ gout, float* __restrict__ gflow, int C, int H,
                                                     int W) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x;
-  const int y = blockIdx.y, n = blockIdx.z;
-  if (x >= W) return;
+  const int x = blockIdx.x * TX + threadIdx.x;
+  const int y = blockIdx.y * TY + threadIdx.y, n = blockIdx.z;
+  if (x >= W || y >= H) return;
   const size_t plane = (size_t)H * W, p = (size_t)y * W + x;
   const float* f = flow + (size_t)n * 2 * plane + p;
   const Corner c = source_cell(x, y, f[0], f[plane], H, W);
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(256) void flowwarp_bwd(const float* __restrict__ im
 int check(const void* a, const void* b, const void* c, int N, int C, int H, int W) {
   if (!a || !b || !c) return SAVFI_E_NULL;
   if (N <= 0 || C <= 0 || H <= 0 || W <= 0) return SAVFI_E_SHAPE;
-  if (H > 65535 || N > 65535 || (int64_t)N * C * H * W >= ((int64_t)1 << 40)) return SAVFI_E_TOOBIG;
+  if (savfi_cdiv(H, TY) > 65535 || N > 65535 || (int64_t)N * C * H * W >= ((int64_t)1 << 40)) return SAVFI_E_TOOBIG;
   return SAVFI_OK;
 }
 
@@ -105,7 +108,7 @@ int check(const void* a, const void* b, const void* c, int N, int C, int H, int 
 
 extern "C" int savfi_flowwarp_fwd_f32(const float* img, const float* flow, float* out, int N, int C, int H, int W, void* stream) {
   if (int e = check(img, flow, out, N, C, H, W)) return e;
-  hipLaunchKernelGGL(flowwarp_fwd, dim3(savfi_cdiv(W, 256), H, N), dim3(256), 0, (hipStream_t)stream, img, flow, out, C, H, W);
+  hipLaunchKernelGGL(flowwarp_fwd, dim3(savfi_cdiv(W, TX), savfi_cdiv(H, TY), N), dim3(TX, TY), 0, (hipStream_t)stream, img, flow, out, C, H, W);
   return savfi_launch_status();
 }
 
@@ -113,7 +116,7 @@ extern "C" int savfi_flowwarp_bwd_f32(const float* img, const float* flow, const
                                       int H, int W, void* stream) {
   if (!gout) return SAVFI_E_NULL;
   if (int e = check(img, flow, gflow, N, C, H, W)) return e;
-  hipLaunchKernelGGL(flowwarp_bwd, dim3(savfi_cdiv(W, 256), H, N), dim3(256), 0, (hipStream_t)stream, img, flow, gout, gflow, C,
+  hipLaunchKernelGGL(flowwarp_bwd, dim3(savfi_cdiv(W, TX), savfi_cdiv(H, TY), N), dim3(TX, TY), 0, (hipStream_t)stream, img, flow, gout, gflow, C,
                      H, W);
   return savfi_launch_status();
 }

@@ -94,6 +94,27 @@ def bench_misc(iters):
     with torch.no_grad():
         m, mn = timeit(lambda: hip_ops.voxel_warp_blend(fr, x3), iters)
     report("voxelwarp_fwd 256x256", m, mn, 4 * 12 * 256 * 256)
+    # straight through the C ABI, 20 launches per timed region: the autograd wrapper costs more host time than these kernels run
+    from meta_interpolation_amd import _hip
+    lib, REP = _hip.lib(), 20
+    for (n, h, w) in ((2, 256, 448), (1, 768, 1280)):          # Super SloMo / RRIN: a padded 256x448 pair, padded 720p
+        img = torch.rand(n, 3, h, w, device=DEV)
+        # a smooth flow field of a few pixels (optical flow is piecewise smooth): low-pass filtered noise
+        flow = torch.nn.functional.avg_pool2d(torch.randn(n, 2, h + 32, w + 32, device=DEV) * 40, 33, stride=1).contiguous()
+        gout, out, gflow = torch.randn(n, 3, h, w, device=DEV), torch.empty(n, 3, h, w, device=DEV), torch.empty_like(flow)
+
+        def fwd():
+            for _ in range(REP):
+                lib.savfi_flowwarp_fwd_f32(img.data_ptr(), flow.data_ptr(), out.data_ptr(), n, 3, h, w, _hip.current_stream())
+
+        def bwd():
+            for _ in range(REP):
+                lib.savfi_flowwarp_bwd_f32(img.data_ptr(), flow.data_ptr(), gout.data_ptr(), gflow.data_ptr(), n, 3, h, w,
+                                           _hip.current_stream())
+        m, mn = timeit(fwd, iters)
+        report("flowwarp_fwd N=%d %dx%d" % (n, h, w), m / REP, mn / REP, 4 * n * h * w * (3 + 2 + 3))
+        m, mn = timeit(bwd, iters)
+        report("flowwarp_bwd N=%d %dx%d" % (n, h, w), m / REP, mn / REP, 4 * n * h * w * (3 + 2 + 3 + 2))
     x = torch.randn(1, 3, 768, 1280, device=DEV)
     with torch.no_grad():
         m, mn = timeit(lambda: hip_ops.pixel_shuffle(x, 1 / 8), iters)
