@@ -229,7 +229,9 @@ def run_test_mode_case():
     """run_test_iter (meta_learning_system.py:630-697): adapt on a 4-frame clip, interpolate between frames 1 and 2."""
     out = {}
     for model, over in (('sepconv', dict(optimizer='SGD', inner_lr=1e-3, loss='1*L1', number_of_evaluation_steps_per_iter=2)),
-                        ('cain', dict(optimizer='SGD', inner_lr=1e-3, loss='1*L1', number_of_evaluation_steps_per_iter=1))):
+                        ('cain', dict(optimizer='SGD', inner_lr=1e-3, loss='1*L1', number_of_evaluation_steps_per_iter=1)),
+                        ('rrin', dict(optimizer='SGD', inner_lr=1e-3, loss='1*L1', number_of_evaluation_steps_per_iter=1)),
+                        ('superslomo', dict(optimizer='SGD', inner_lr=1e-3, loss='1*L1', number_of_evaluation_steps_per_iter=1))):
         args = reference_args(model=model, batch_size=1, mode='test', **over)
         system = build_reference_system(args, model)
         frames = synthetic.septuplet_batch(2, 64, 64, model=model, frames=4)

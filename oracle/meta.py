@@ -136,5 +136,8 @@ def run_test_iteration(model, base, frames, *, rule='lslr', optimizer='SGD', lrs
             g = torch.autograd.grad(sl, list(fast.values()), create_graph=False, allow_unused=True)
             fast = rules.update_params(rule, optimizer, fast, dict(zip(fast.keys(), g)), lrs, step, st)
         with torch.no_grad():
-            preds.append(fwd(frames[1][t][None], frames[2][t][None], base, fast, **kw).squeeze(0))
+            out = fwd(frames[1][t][None], frames[2][t][None], base, fast, **kw).squeeze(0)
+            if model == 'superslomo':        # revNormalize, :686-688 (Normalize(mean=-m, std=1): x + m)
+                out = out + torch.tensor([0.429, 0.431, 0.397]).view(3, 1, 1)
+            preds.append(out)
     return preds

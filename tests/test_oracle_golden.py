@@ -195,7 +195,7 @@ def test_oracle_iteration_matches_reference(name, phase):
                 assert_fp_close(fp(lr.grad), rows[full], 2e-4, (name, 'outer-lr', k))
 
 
-@pytest.mark.parametrize("model", ["sepconv", "cain"])
+@pytest.mark.parametrize("model", ["sepconv", "cain", "rrin", "superslomo"])
 def test_oracle_test_mode_matches_reference(model):
     """run_test_iter on 4-frame clips (adapt on (0,2)->1, (1,3)->2; interpolate 1,2)."""
     g = golden("test_mode")

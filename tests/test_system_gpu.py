@@ -41,7 +41,12 @@ SIGNLIKE = dict(loss=5e-5, l1=1e-4, psnr=1e-3, ssim=1e-4, w=5e-4, g=2e-3, outer=
 # the smooth rule; the relative loss / outer-gradient bounds are wider than for SepConv / CAIN.
 VOXEL = dict(loss=2e-4, l1=1e-4, psnr=1e-3, ssim=1e-4, w=1e-5, g=2e-3, outer=3e-2)
 CHAOTIC = dict(loss=5e-3, l1=1e-2, psnr=5e-2, ssim=5e-3, w=2e-3, g=5e-2, outer=2e-1)
+# Super SloMo: two 39-layer U-Nets whose first stages are 7x7 / 5x5 convolutions (MIOpen igemm kernels, solver choice
+# varies between processes) feeding a warp; individual gradient fingerprints of its smallest tensors were measured at
+# 1.8e-3 (tools/parity_report.py, profiles/r01_parity_report.jsonl) while loss / pixels / PSNR / weights stay at the 1e-6 level.
+SLOMO = dict(SMOOTH, g=5e-3, outer=1e-2)
 TOL = {name: SMOOTH for name in SYSTEM}
+TOL.update(superslomo_lslr_sgd_2step=SLOMO)
 TOL.update(cain_lslr_adam_1step=SIGNLIKE, sepconv_metasgd_adamax_2step=SIGNLIKE,
            voxelflow_lslr_sgd_2step=VOXEL, voxelflow_script_metasgd_adam_1step=dict(VOXEL, w=5e-4),
            voxelflow_metasgd_adamax_2step=CHAOTIC)
@@ -203,7 +208,7 @@ def test_product_path_uses_the_hip_library_and_fails_loudly_without_it(monkeypat
         hip_ops.l1_loss(torch.zeros(4, device=DEV), torch.zeros(4, device=DEV))
 
 
-@pytest.mark.parametrize("model", ["sepconv", "cain"])
+@pytest.mark.parametrize("model", ["sepconv", "cain", "rrin", "superslomo"])
 def test_run_test_iter_matches_reference_fixture(model):
     """--mode test: adapt on a 4-frame clip and interpolate between frames 1 and 2 (reference run_test_iter)."""
     g = golden("test_mode")

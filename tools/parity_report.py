@@ -21,7 +21,7 @@ from tests.helpers import build_system, golden, observe, parse_case_args  # noqa
 
 CASES = ['c1_cain_lslr_sgd', 'cain_l2f', 'cain_lslr_adam_1step', 'sepconv_lslr_sgd_2step',
          'sepconv_metasgd_adamax_2step', 'sepconv_msl_learnable_2step', 'voxelflow_metasgd_adamax_2step',
-         'voxelflow_lslr_sgd_2step', 'voxelflow_script_metasgd_adam_1step']
+         'voxelflow_lslr_sgd_2step', 'voxelflow_script_metasgd_adam_1step', 'rrin_lslr_sgd_2step', 'superslomo_lslr_sgd_2step']
 
 
 def fp_dev(got, want):
