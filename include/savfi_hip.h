@@ -11,6 +11,7 @@
  *                              kernel_Sepconv_updateGradInput         sepconv/sepconv_op/sepconv.py:32-63,  launch :328-341
  *   savfi_voxelwarp_fwd_f32    flow/mask split + meshgrid + 2x grid_sample + blend
  *   savfi_voxelwarp_bwd_f32                                          voxelflow/core/models/voxel_flow.py:471-509, :9-17
+ *   savfi_avgpool2x2_fwd/bwd_f32  2x2 average pooling                 sepconv/model.py:176-187, rrin/unet.py:146, superslomo/model.py:66
  *   savfi_flowwarp_fwd/bwd_f32 pixel-flow backward warp              superslomo/model.py:231-307, rrin/model.py:8-20
  *   savfi_pixel_unshuffle_f32  pixel_shuffle(scale<1)                 model_utils.py:202-217 (else branch)
  *   savfi_pixel_shuffle_f32    pixel_shuffle(scale>=1)                model_utils.py:202-217 (if branch)
@@ -89,6 +90,15 @@ int savfi_voxelwarp_fwd_f32(const float* frames, const float* x3, float* out,
 int savfi_voxelwarp_bwd_f32(const float* frames, const float* x3, const float* gO,
                             float* g_x3, float* g_frames,
                             int B, int H, int W, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * 2x2 / stride 2 average pooling of `planes` = N*C maps [H,W] -> [H/2,W/2] (floor): torch.nn.AvgPool2d(2, 2)
+ * sepconv/model.py:176-187, F.avg_pool2d(x, 2) rrin/unet.py:146, superslomo/model.py:66.
+ *   fwd: out[y][x] = (in[2y][2x] + in[2y][2x+1] + in[2y+1][2x] + in[2y+1][2x+1]) / 4
+ *   bwd: gin [planes,H,W] fully written: gout[y/2][x/2] / 4, zero in an odd last row / column
+ * ---------------------------------------------------------------------------------- */
+int savfi_avgpool2x2_fwd_f32(const float* in, float* out, int64_t planes, int H, int W, void* stream);
+int savfi_avgpool2x2_bwd_f32(const float* gout, float* gin, int64_t planes, int H, int W, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Backward warping by a pixel-unit flow (SuperSloMo backWarp superslomo/model.py:231-307, RRIN warp

@@ -39,6 +39,8 @@ _PROTOTYPES = {
     "savfi_sepconv_bwd_f32": [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P],
     "savfi_voxelwarp_fwd_f32": [_P, _P, _P, c_int, c_int, c_int, _P],
     "savfi_voxelwarp_bwd_f32": [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P],
+    "savfi_avgpool2x2_fwd_f32": [_P, _P, c_int64, c_int, c_int, _P],
+    "savfi_avgpool2x2_bwd_f32": [_P, _P, c_int64, c_int, c_int, _P],
     "savfi_flowwarp_fwd_f32": [_P, _P, _P, c_int, c_int, c_int, c_int, _P],
     "savfi_flowwarp_bwd_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P],
     "savfi_pixel_unshuffle_f32": [_P, _P, c_int, c_int, c_int, c_int, c_int, _P],

@@ -58,6 +58,64 @@ def voxel_warp_blend(frames, x3):
 
 
 # --------------------------------------------------------------------------------------------
+# 2x2 average pooling          (reference: sepconv/model.py:176-187, rrin/unet.py:146, superslomo/model.py:66)
+# --------------------------------------------------------------------------------------------
+class _AvgPool2x2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _hip.require_cuda(x)
+        N, C, H, W = x.shape
+        out = torch.empty((N, C, H // 2, W // 2), dtype=x.dtype, device=x.device)
+        lib = _hip.lib()
+        _hip.launch("avgpool2x2_fwd", lambda: _hip.check(lib.savfi_avgpool2x2_fwd_f32(
+            x.data_ptr(), out.data_ptr(), N * C, H, W, _hip.current_stream()), "savfi_avgpool2x2_fwd_f32"),
+            nbytes=4 * N * C * (H * W + (H // 2) * (W // 2)))
+        ctx.hw = (H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        # linear op: its adjoint goes through a Function too, so double-backward keeps working
+        return _AvgPool2x2Adjoint.apply(g, ctx.hw)
+
+
+class _AvgPool2x2Adjoint(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, g, hw):
+        g = g.contiguous()
+        _hip.require_cuda(g)
+        N, C = g.shape[:2]
+        H, W = hw
+        gin = torch.empty((N, C, H, W), dtype=g.dtype, device=g.device)
+        lib = _hip.lib()
+        _hip.launch("avgpool2x2_bwd", lambda: _hip.check(lib.savfi_avgpool2x2_bwd_f32(
+            g.data_ptr(), gin.data_ptr(), N * C, H, W, _hip.current_stream()), "savfi_avgpool2x2_bwd_f32"),
+            nbytes=4 * N * C * (H * W + (H // 2) * (W // 2)))
+        return gin
+
+    @staticmethod
+    def backward(ctx, gg):
+        return _AvgPool2x2.apply(gg.contiguous()), None
+
+
+def avg_pool2x2(x):
+    """F.avg_pool2d(x, 2) == nn.AvgPool2d(2, 2): [N,C,H,W] -> [N,C,H//2,W//2]; plain ATen on CPU tensors (host-logic tests)."""
+    if not x.is_cuda or x.dim() != 4 or x.shape[2] < 2 or x.shape[3] < 2 or x.dtype != torch.float32:
+        return torch.nn.functional.avg_pool2d(x, 2)
+    return _AvgPool2x2.apply(x.contiguous())
+
+
+class AvgPool2x2(torch.nn.Module):
+    """Parameter-free stand-in for torch.nn.AvgPool2d(kernel_size=2, stride=2)."""
+
+    def forward(self, x):
+        return avg_pool2x2(x)
+
+    def extra_repr(self):
+        return 'kernel_size=2, stride=2'
+
+
+# --------------------------------------------------------------------------------------------
 # Backward warp by a pixel-unit flow    (reference: superslomo/model.py:231-307, rrin/model.py:8-20)
 # --------------------------------------------------------------------------------------------
 class _FlowWarp(torch.autograd.Function):

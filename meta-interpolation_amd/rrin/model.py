@@ -73,7 +73,7 @@ class MetaUNet(nn.Module):
             x = block(x, params=_sub(down, str(i)))
             if i != self.depth - 1:
                 bridges.append(x)
-                x = F.avg_pool2d(x, 2)
+                x = hip_ops.avg_pool2x2(x)
         x = self.midconv(x, params=_sub(pv, "midconv"), act_slope=SLOPE)
         for i, block in enumerate(self.up_path):
             x = block(x, bridges[-i - 1], params=_sub(up, str(i)))

@@ -24,6 +24,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import hip_ops
 from ..hip_ops import Upsample2x, upsample_bilinear2x_window, upsample_window_sources
 from ..model_utils import MetaConv2dLayer, MetaSequential, as_view, zero_grad_params
 from .sepconv_op.sepconv import FunctionSepconv
@@ -67,7 +68,7 @@ class MetaNetwork(nn.Module):
         self._windows = {}
         for i, (name, cin, cout) in enumerate(_ENCODER, start=1):
             setattr(self, name, _basic(cin, cout))
-            setattr(self, "modulePool%d" % i, nn.AvgPool2d(kernel_size=2, stride=2))
+            setattr(self, "modulePool%d" % i, hip_ops.AvgPool2x2())
         for name, cin, cout in _DECODER:
             setattr(self, name, _basic(cin, cout))
             setattr(self, name.replace("Deconv", "Upsample"), _upsample(cout))

@@ -40,7 +40,7 @@ class down(nn.Module):
 
     def forward(self, x, params=None):
         pv = as_view(params)
-        x = self.conv1(F.avg_pool2d(x, 2), params=_sub(pv, "conv1"), act_slope=SLOPE)
+        x = self.conv1(hip_ops.avg_pool2x2(x), params=_sub(pv, "conv1"), act_slope=SLOPE)
         return self.conv2(x, params=_sub(pv, "conv2"), act_slope=SLOPE)
 
 

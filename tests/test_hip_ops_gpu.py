@@ -154,6 +154,28 @@ def test_voxelwarp_vs_oracle(B, H, W, amp):
 
 
 # ---------------------------------------------------------------------------------------------
+# 2x2 average pooling
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,C,H,W", [(2, 32, 384, 512), (1, 5, 7, 9), (1, 3, 2, 2), (2, 4, 65, 130), (1, 2, 64, 67)])
+def test_avgpool2x2_matches_aten(N, C, H, W):
+    gen = torch.Generator().manual_seed(H * W)
+    x = torch.randn(N, C, H, W, generator=gen)
+    g = torch.randn(N, C, H // 2, W // 2, generator=gen)
+    xr = x.clone().requires_grad_()
+    ref = F.avg_pool2d(xr, 2)
+    ref.backward(g)
+    xd = x.to(DEV).requires_grad_()
+    out = hip_ops.avg_pool2x2(xd)
+    out.backward(g.to(DEV))
+    assert torch.allclose(out.detach().cpu(), ref.detach(), atol=1e-6, rtol=1e-6)
+    assert torch.equal(xd.grad.cpu(), xr.grad)                   # g / 4 and zeros: exact
+    # the adjoint is a Function too: double backward (second-order MAML) goes through the forward kernel
+    xd2 = x.to(DEV).requires_grad_()
+    (gx,) = torch.autograd.grad(hip_ops.avg_pool2x2(xd2), xd2, g.to(DEV).requires_grad_(), create_graph=True)
+    assert gx.requires_grad
+
+
+# ---------------------------------------------------------------------------------------------
 # pixel-flow backward warp (Super SloMo backWarp / RRIN warp)
 # ---------------------------------------------------------------------------------------------
 def test_flowwarp_matches_the_reference_fixture():
