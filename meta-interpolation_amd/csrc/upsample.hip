@@ -40,10 +40,13 @@ struct Win { int H, W, sy0, sx0, Hs, Ws, oy0, ox0, Hw, Ww, align; };
 
 __global__ __launch_bounds__(256) void upsample2x_fwd(const float* __restrict__ in, float* __restrict__ out, Win g) {
   const int Ho = 2 * g.H, Wo = 2 * g.W;
-  const int wx = (blockIdx.x * 256 + threadIdx.x) * 4;     // 4 consecutive outputs per thread
-  const int wy = blockIdx.y;
-  if (wx >= g.Ww) return;
-  const float* p = in + (size_t)blockIdx.z * g.Hs * g.Ws;
+  // work items of one plane = (row, group of 4 consecutive outputs), numbered row-major: narrow maps (the 64-wide deep
+  // decoder layers) fill their workgroups as well as wide ones
+  const int per_row = (g.Ww + 3) >> 2;
+  const int item = blockIdx.x * 256 + threadIdx.x;
+  if (item >= per_row * g.Hw) return;
+  const int wy = item / per_row, wx = (item - wy * per_row) * 4;
+  const float* p = in + (size_t)blockIdx.y * g.Hs * g.Ws;
   const Src sy = source(g.oy0 + wy, g.H, scale_of(g.H, Ho, g.align), g.align);
   const float sw = scale_of(g.W, Wo, g.align);
   const float* r0 = p + (size_t)(sy.i0 - g.sy0) * g.Ws - g.sx0;
@@ -54,7 +57,7 @@ __global__ __launch_bounds__(256) void upsample2x_fwd(const float* __restrict__ 
     const Src sx = source(min(g.ox0 + wx + k, g.ox0 + g.Ww - 1), g.W, sw, g.align);
     v[k] = sy.l0 * (sx.l0 * r0[sx.i0] + sx.l1 * r0[sx.i1]) + sy.l1 * (sx.l0 * r1[sx.i0] + sx.l1 * r1[sx.i1]);
   }
-  float* o = out + ((size_t)blockIdx.z * g.Hw + wy) * g.Ww + wx;
+  float* o = out + ((size_t)blockIdx.y * g.Hw + wy) * g.Ww + wx;
   if (wx + 3 < g.Ww && ((((uintptr_t)o) & 15u) == 0)) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
   else
     for (int k = 0; k < 4 && wx + k < g.Ww; ++k) o[k] = v[k];
@@ -62,11 +65,11 @@ __global__ __launch_bounds__(256) void upsample2x_fwd(const float* __restrict__ 
 
 __global__ __launch_bounds__(256) void upsample2x_bwd(const float* __restrict__ gout, float* __restrict__ gin, Win g) {
   const int Ho = 2 * g.H, Wo = 2 * g.W;
-  const int cx = blockIdx.x * 256 + threadIdx.x;
-  const int cy = blockIdx.y;
-  if (cx >= g.Ws) return;
+  const int item = blockIdx.x * 256 + threadIdx.x;           // pixels of one source plane, row-major
+  if (item >= g.Hs * g.Ws) return;
+  const int cy = item / g.Ws, cx = item - cy * g.Ws;
   const int ix = g.sx0 + cx, iy = g.sy0 + cy;               // coordinates in the virtual source
-  const float* gp = gout + (size_t)blockIdx.z * g.Hw * g.Ww;
+  const float* gp = gout + (size_t)blockIdx.y * g.Hw * g.Ww;
   const float sh = scale_of(g.H, Ho, g.align), sw = scale_of(g.W, Wo, g.align);
   // candidate outputs: src(o) in (i-1, i+1).  For both index rules that is o in {2i-1 .. 2i+2}; one more on each
   // side is visited so that a rounding of src at an integer cannot drop a contribution (weights are re-evaluated
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(256) void upsample2x_bwd(const float* __restrict__ 
       if (ox_lo + k <= ox_hi) t = fmaf(wxs[k], row[ox_lo + k], t);
     acc = fmaf(wy, t, acc);
   }
-  gin[((size_t)blockIdx.z * g.Hs + cy) * g.Ws + cx] = acc;
+  gin[((size_t)blockIdx.y * g.Hs + cy) * g.Ws + cx] = acc;
 }
 
 // host mirror of source(): first / last source index an output range touches
@@ -122,7 +125,7 @@ int check_window(const Win& g, int planes) {
   if (lo < g.sy0 || hi >= g.sy0 + g.Hs) return SAVFI_E_SHAPE;
   touched(g.ox0, g.ox0 + g.Ww - 1, g.W, 2 * g.W, g.align, &lo, &hi);
   if (lo < g.sx0 || hi >= g.sx0 + g.Ws) return SAVFI_E_SHAPE;
-  if (planes > 65535 || g.Hw > 65535 || g.Hs > 65535) return SAVFI_E_TOOBIG;
+  if (planes > 65535 || (int64_t)g.Hw * g.Ww >= ((int64_t)1 << 31) || (int64_t)g.Hs * g.Ws >= ((int64_t)1 << 31)) return SAVFI_E_TOOBIG;
   return 0;
 }
 
@@ -134,7 +137,7 @@ extern "C" int savfi_upsample2x_window_fwd_f32(const float* in, float* out, int 
   if (!in || !out) return SAVFI_E_NULL;
   const Win g{H, W, sy0, sx0, Hs, Ws, oy0, ox0, Hw, Ww, align_corners ? 1 : 0};
   if (int rc = check_window(g, planes)) return rc;
-  dim3 grid(savfi_cdiv(Ww, 1024), Hw, planes);
+  dim3 grid(savfi_cdiv((int64_t)Hw * savfi_cdiv(Ww, 4), 256), planes, 1);
   hipLaunchKernelGGL(upsample2x_fwd, grid, dim3(256), 0, (hipStream_t)stream, in, out, g);
   return savfi_launch_status();
 }
@@ -145,7 +148,7 @@ extern "C" int savfi_upsample2x_window_bwd_f32(const float* gout, float* gin, in
   if (!gout || !gin) return SAVFI_E_NULL;
   const Win g{H, W, sy0, sx0, Hs, Ws, oy0, ox0, Hw, Ww, align_corners ? 1 : 0};
   if (int rc = check_window(g, planes)) return rc;
-  dim3 grid(savfi_cdiv(Ws, 256), Hs, planes);
+  dim3 grid(savfi_cdiv((int64_t)Hs * Ws, 256), planes, 1);
   hipLaunchKernelGGL(upsample2x_bwd, grid, dim3(256), 0, (hipStream_t)stream, gout, gin, g);
   return savfi_launch_status();
 }
