@@ -130,6 +130,27 @@ def main():
 
     for i in range(opt.warmup):
         one_iter(i)
+
+    # SURVEY 8(d) second figure: the step bodies alone (2 support passes -> grad -> update), by HIP events around each
+    # body on the compute stream.  Eager loop only: hipGraph replays have no per-step host hooks.
+    bodies = []
+    if not opt.graph_inner_loop and not opt.no_kernel_timer:
+        orig_loss, orig_update = system._support_loss, system.apply_inner_loop_update
+
+        def support_loss(*a, **k):
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            bodies.append([ev, None])
+            return orig_loss(*a, **k)
+
+        def inner_update(*a, **k):
+            out = orig_update(*a, **k)
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            if bodies and bodies[-1][1] is None:
+                bodies[-1][1] = ev
+            return out
+        system._support_loss, system.apply_inner_loop_update = support_loss, inner_update
     timer = None
     if not opt.no_kernel_timer and model == 'sepconv':
         timer = _hip.KernelTimer(only='sepconv')   # HIP events around the custom sepconv launches only
@@ -159,6 +180,11 @@ def main():
                    + "+" + over['optimizer'], "parallelism": "task-parallel x%d, 1 all-reduce of outer grads" % world,
                    "outer_tasks_per_sec": tasks * world * opt.steps / elapsed},
     }
+    done = [(a, b) for a, b in bodies if b is not None]
+    if done:
+        body_ms = sum(a.elapsed_time(b) for a, b in done)
+        line["config"]["step_bodies_only_steps_per_sec"] = len(done) / (body_ms * 1e-3) * world
+        line["config"]["step_bodies_share_of_iteration"] = body_ms * 1e-3 / elapsed
     if rank == 0:
         if timer is not None:
             summ = timer.summary()

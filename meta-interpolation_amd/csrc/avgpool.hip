@@ -14,9 +14,10 @@ namespace {
 
 __global__ __launch_bounds__(256) void avgpool2x2_fwd(const float* __restrict__ in, float* __restrict__ out, int H, int W,
                                                       int Ho, int Wo, int vec_ok) {
-  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-  if (x >= Wo) return;
-  const size_t pl = blockIdx.z;
+  const int item = blockIdx.x * 256 + threadIdx.x;         // pooled pixels of one plane, row-major (narrow maps fill workgroups too)
+  if (item >= Ho * Wo) return;
+  const int y = item / Wo, x = item - y * Wo;
+  const size_t pl = blockIdx.y;
   const float* r0 = in + (pl * H + 2 * y) * W + 2 * x;
   const float* r1 = r0 + W;
   float a, b, c, d;
@@ -32,9 +33,10 @@ __global__ __launch_bounds__(256) void avgpool2x2_fwd(const float* __restrict__ 
 // one thread per pooled pixel writes its 2x2 block; the threads of the last pooled row / column also clear the odd rest
 __global__ __launch_bounds__(256) void avgpool2x2_bwd(const float* __restrict__ gout, float* __restrict__ gin, int H, int W,
                                                       int Ho, int Wo, int vec_ok) {
-  const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-  if (x >= Wo) return;
-  const size_t pl = blockIdx.z;
+  const int item = blockIdx.x * 256 + threadIdx.x;
+  if (item >= Ho * Wo) return;
+  const int y = item / Wo, x = item - y * Wo;
+  const size_t pl = blockIdx.y;
   const float g = gout[(pl * Ho + y) * Wo + x] / 4.f;
   float* r0 = gin + (pl * H + 2 * y) * W + 2 * x;
   float* r1 = r0 + W;
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(256) void avgpool2x2_bwd(const float* __restrict__ 
 int check(const void* a, const void* b, int64_t planes, int H, int W) {
   if (!a || !b) return SAVFI_E_NULL;
   if (planes <= 0 || H < 2 || W < 2) return SAVFI_E_SHAPE;
-  if (planes > 65535 || H / 2 > 65535 || planes * H * W >= ((int64_t)1 << 40)) return SAVFI_E_TOOBIG;
+  if (planes > 65535 || (int64_t)H * W >= ((int64_t)1 << 31) || planes * H * W >= ((int64_t)1 << 40)) return SAVFI_E_TOOBIG;
   return SAVFI_OK;
 }
 
@@ -65,7 +67,7 @@ extern "C" int savfi_avgpool2x2_fwd_f32(const float* in, float* out, int64_t pla
   if (int e = check(in, out, planes, H, W)) return e;
   const int Ho = H / 2, Wo = W / 2;
   const int vec_ok = (W % 2 == 0) && (((uintptr_t)in & 7u) == 0);
-  hipLaunchKernelGGL(avgpool2x2_fwd, dim3(savfi_cdiv(Wo, 256), Ho, (unsigned)planes), dim3(256), 0, (hipStream_t)stream, in, out, H,
+  hipLaunchKernelGGL(avgpool2x2_fwd, dim3(savfi_cdiv((int64_t)Ho * Wo, 256), (unsigned)planes, 1), dim3(256), 0, (hipStream_t)stream, in, out, H,
                      W, Ho, Wo, vec_ok);
   return savfi_launch_status();
 }
@@ -74,7 +76,7 @@ extern "C" int savfi_avgpool2x2_bwd_f32(const float* gout, float* gin, int64_t p
   if (int e = check(gout, gin, planes, H, W)) return e;
   const int Ho = H / 2, Wo = W / 2;
   const int vec_ok = (W % 2 == 0) && (((uintptr_t)gin & 7u) == 0);
-  hipLaunchKernelGGL(avgpool2x2_bwd, dim3(savfi_cdiv(Wo, 256), Ho, (unsigned)planes), dim3(256), 0, (hipStream_t)stream, gout, gin,
+  hipLaunchKernelGGL(avgpool2x2_bwd, dim3(savfi_cdiv((int64_t)Ho * Wo, 256), (unsigned)planes, 1), dim3(256), 0, (hipStream_t)stream, gout, gin,
                      H, W, Ho, Wo, vec_ok);
   return savfi_launch_status();
 }
