@@ -47,13 +47,19 @@ def timeit(fn, iters, reps=10):
     return ts[len(ts) // 2]
 
 
+# CAIN at 720p (C5): 127 convolutions 192->192 on the 1/8-resolution 96x160 map; RRIN / Super SloMo U-Net levels at 256x448
+EXTRA = {"cain": [(192, 192, 96, 160), (384, 192, 96, 160), (192, 192, 32, 56)],
+         "unet": [(32, 32, 256, 448), (64, 64, 128, 224), (128, 128, 64, 112), (256, 256, 32, 56), (512, 512, 16, 28)]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--n", type=int, default=2)
+    ap.add_argument("--set", default="sepconv", choices=["sepconv"] + sorted(EXTRA))
     o = ap.parse_args()
     dev = torch.device("cuda")
-    for (ci, co, h, w) in LAYERS:
+    for (ci, co, h, w) in (LAYERS if o.set == "sepconv" else EXTRA[o.set]):
         x = torch.randn(o.n, ci, h, w, device=dev)
         wt = torch.randn(co, ci, 3, 3, device=dev) / (3 * ci ** 0.5)
         b = torch.randn(co, device=dev)
