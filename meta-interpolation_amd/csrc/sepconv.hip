@@ -628,12 +628,17 @@ __global__ __launch_bounds__(MNT) void sepconv_bwd_mfma(const float* __restrict_
     }
 
     if (WANT_H) {
+      // Window columns q = 0..63 go through the matrix cores (4 M-tiles).  Of the fifth tile (q = 64..79) only three
+      // entries lie inside the band 0 <= q - j <= 50: (q, j) = (64, 14), (64, 15), (65, 15); they are three 153-term dot
+      // products on the VALU below instead of 39 more MFMAs per row (10 % of this kernel's matrix work).
+      constexpr int MTHM = MTH - 1;
+      static_assert(K == 51 && 16 * MTHM == 64, "band geometry of the VALU tail");
       float bv[KTV];
 #pragma unroll
       for (int t = 0; t < KTV; ++t) bv[t] = vb[(4 * t + ks) * 16];           // tap 51 reads the zero row
-      f32x4 acc[MTH];
+      f32x4 acc[MTHM];
 #pragma unroll
-      for (int m = 0; m < MTH; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int m = 0; m < MTHM; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int c = 0; c < C; ++c) {
 #pragma unroll
@@ -642,17 +647,42 @@ __global__ __launch_bounds__(MNT) void sepconv_bwd_mfma(const float* __restrict_
           // window row of tap 4t+ks; the zero tap (51) would be one row past the window: step back one row
           const int arow = (t == KTV - 1) ? ((ks == 3) ? (4 * t - 1) * MLW : 4 * t * MLW) : 4 * t * MLW;
 #pragma unroll
-          for (int m = 0; m < MTH; ++m)
+          for (int m = 0; m < MTHM; ++m)
             acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(inT[abH[m] + rowoff + c * LP + arow], bb, acc[m], 0, 0, 0);
         }
       }
+      // VALU tail: lane = tap row fy (lanes 51..63 idle), then a 64-lane sum of the three partial products
+      float s6414 = 0.f, s6415 = 0.f, s6515 = 0.f;
+      {
+        const int fy = min(lane, K - 1);
+        const float live = lane < K ? 1.f : 0.f;
+        const float v14 = vB[fy * 16 + 14] * live, v15 = vB[fy * 16 + 15] * live;
+        const float* col = inT + rowoff + (wr + fy) * MLW + 16 * wc + 64;
 #pragma unroll
-      for (int m = 0; m < MTH; ++m) {
+        for (int c = 0; c < C; ++c) {
+          const float a64 = col[c * LP], a65 = col[c * LP + 1];
+          const float g14 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, g[c]), 14));
+          const float g15 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, g[c]), 15));
+          s6414 = fmaf(g14 * v14, a64, s6414);
+          s6415 = fmaf(g15 * v15, a64, s6415);
+          s6515 = fmaf(g15 * v15, a65, s6515);
+        }
+        s6414 = wave_sum(s6414);
+        s6415 = wave_sum(s6415);
+        s6515 = wave_sum(s6515);
+      }
+#pragma unroll
+      for (int m = 0; m < MTHM; ++m) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int fx = 16 * m + 4 * ks + e - j;
           if (pvalid && fx >= 0 && fx < K) gH[(size_t)b * K * plane + (size_t)fx * plane + opix] = acc[m][e];
         }
+      }
+      if (pvalid && lane == 14) gH[(size_t)b * K * plane + (size_t)50 * plane + opix] = s6414;
+      if (pvalid && lane == 15) {
+        gH[(size_t)b * K * plane + (size_t)49 * plane + opix] = s6415;
+        gH[(size_t)b * K * plane + (size_t)50 * plane + opix] = s6515;
       }
     }
 
