@@ -87,12 +87,11 @@ class TaskParallel:
         dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group)
         # the presence flags only matter for parameters without a local gradient (no host sync otherwise)
         keep_all = [True] * len(params) if all(have) else (flags.cpu() > 0).tolist()
+        back = [(p.grad, v.view_as(p.grad)) for p, v, h, keep in zip(params, views, have, keep_all) if keep and h]
+        if back:
+            torch._foreach_copy_([g for g, _ in back], [v for _, v in back])
         for p, v, h, keep in zip(params, views, have, keep_all):
-            if not keep:
-                continue
-            if h:
-                p.grad.copy_(v.view_as(p.grad))
-            else:
+            if keep and not h:
                 p.grad = v.view_as(p).clone()
 
     def allreduce_scalars(self, values):
