@@ -24,7 +24,12 @@ from . import _hip, hip_ops, model_utils, utils
 def supported(system, use_second_order):
     a = system.args
     return (bool(getattr(a, 'graph_inner_loop', 0)) and system.device.type == 'cuda' and not use_second_order
-            and a.model != 'superslomo' and not a.attenuate and hasattr(system.inner_loop_optimizer, 'lr_mode'))
+            and not a.attenuate and hasattr(system.inner_loop_optimizer, 'lr_mode'))
+
+
+def _frame(out):
+    """Super SloMo's forward returns (frame, extras for its 'Super' loss): the frame is what this path uses."""
+    return out[0] if isinstance(out, tuple) else out
 
 
 class GraphedInnerLoop:
@@ -63,7 +68,7 @@ class GraphedInnerLoop:
         dev = self.sys.device
         fast = {k: v.detach().clone().requires_grad_() for k, v in self.theta.items()}
         x = torch.zeros(1, C, H, W, device=dev)
-        out = self.net.forward(x, x, params=fast, backup_running_statistics=False, num_step=0)
+        out = _frame(self.net.forward(x, x, params=fast, backup_running_statistics=False, num_step=0))
         g = torch.autograd.grad(out.sum(), list(fast.values()), allow_unused=True)
         self.routed = [k for k, gi in zip(self.all_keys, g) if gi is not None]
         self.unrouted = [k for k, gi in zip(self.all_keys, g) if gi is None]
@@ -74,7 +79,7 @@ class GraphedInnerLoop:
     def _support_step(self, W, t):
         model_utils.OWN_PARAMS_CONST = True      # first-order support pass: non-routed parameters are constants
         try:
-            out = self.net.forward(self.sup[0], self.sup[2], params=W, backup_running_statistics=(t == 0), num_step=t)
+            out = _frame(self.net.forward(self.sup[0], self.sup[2], params=W, backup_running_statistics=(t == 0), num_step=t))
         finally:
             model_utils.OWN_PARAMS_CONST = False
         loss = self.crit(out[0:1], self.sup[1][0:1])['total'] + self.crit(out[1:2], self.sup[1][1:2])['total']
@@ -92,10 +97,10 @@ class GraphedInnerLoop:
     def _target(self, W, s, with_grad):
         if not with_grad:
             with torch.no_grad():
-                pred = self.net.forward(self.tgt[0], self.tgt[2], params=W, backup_running_statistics=False, num_step=s)
+                pred = _frame(self.net.forward(self.tgt[0], self.tgt[2], params=W, backup_running_statistics=False, num_step=s))
                 parts = self.crit(pred, self.tgt[1])
             return dict(pred=pred, parts={k: v.detach() for k, v in parts.items()})
-        pred = self.net.forward(self.tgt[0], self.tgt[2], params=W, backup_running_statistics=False, num_step=s)
+        pred = _frame(self.net.forward(self.tgt[0], self.tgt[2], params=W, backup_running_statistics=False, num_step=s))
         parts = self.crit(pred, self.tgt[1])
         own = [self.theta[k] for k in self.unrouted]
         g = torch.autograd.grad(parts['total'], [W[k] for k in self.routed] + own, allow_unused=True)

@@ -112,6 +112,14 @@ def getWarpCoeff(indices, device):
     return tuple(torch.tensor(c, dtype=torch.float32, device=device).view(-1, 1, 1, 1) for c in (1 - t, t))
 
 
+def _time_coefficients(ind):
+    """(C00, C01, C10, C11), (C0, C1) as Python floats rounded to fp32, for one time stamp shared by the whole batch (the
+    plugin is always called with a scalar `ind`): no host-to-device copy per forward, so the pass can be captured in a hipGraph."""
+    t = T_GRID[int(ind)]
+    f32 = lambda v: float(np.float32(v))
+    return (f32(-(1 - t) * t), f32(t * t), f32((1 - t) * (1 - t)), f32(-(1 - t) * t)), (f32(1 - t), f32(t))
+
+
 class MetaSuperSloMo(nn.Module):
     def __init__(self, device=None, resume=False):
         super().__init__()
@@ -125,8 +133,7 @@ class MetaSuperSloMo(nn.Module):
             self.arbTimeFlowIntrp.load_state_dict(ckpt['state_dictAT'])
 
     def forward(self, I0, I1, ind=3, params=None, **kwargs):
-        dev = I0.device
-        ind = [int(ind)] * I0.size(0)
+        (c00, c01, c10, c11), (c0, c1) = _time_coefficients(ind)
         pw, ph = _pad_to_multiple(I0.size(3), 6), _pad_to_multiple(I0.size(2), 6)
         left, top = pw // 2, ph // 2
         pad_in = nn.ReflectionPad2d([left, pw - left, top, ph - top])
@@ -136,7 +143,6 @@ class MetaSuperSloMo(nn.Module):
 
         flows = self.flowComp(torch.cat((I0, I1), dim=1), params=_sub(pv, "flowComp"))
         F_0_1, F_1_0 = flows[:, :2], flows[:, 2:]
-        c00, c01, c10, c11 = getFlowCoeff(ind, dev)
         F_t_0 = c00 * F_0_1 + c01 * F_1_0
         F_t_1 = c10 * F_0_1 + c11 * F_1_0
         g_I0_F_t_0, g_I1_F_t_1 = warp(I0, F_t_0), warp(I1, F_t_1)
@@ -147,7 +153,6 @@ class MetaSuperSloMo(nn.Module):
         V_t_0 = torch.sigmoid(intrp[:, 4:5])
         V_t_1 = 1 - V_t_0
         g0, g1 = warp(I0, F_t_0_f), warp(I1, F_t_1_f)
-        c0, c1 = getWarpCoeff(ind, dev)
         Ft_p = (c0 * V_t_0 * g0 + c1 * V_t_1 * g1) / (c0 * V_t_0 + c1 * V_t_1)
         warped_I0, warped_I1 = warp(I0, F_1_0), warp(I1, F_0_1)
         return crop(Ft_p), {'bidirectional_flow': (crop(F_0_1), crop(F_1_0)),

@@ -253,7 +253,7 @@ def test_second_order_cain_matches_oracle():
 # hipGraph-captured inner loop (--graph_inner_loop 1): same results as the eager loop and the fixtures
 # ---------------------------------------------------------------------------------------------
 GRAPH_CASES = ['sepconv_lslr_sgd_2step', 'sepconv_msl_learnable_2step', 'sepconv_metasgd_adamax_2step',
-               'voxelflow_lslr_sgd_2step', 'c1_cain_lslr_sgd', 'cain_lslr_adam_1step']
+               'voxelflow_lslr_sgd_2step', 'c1_cain_lslr_sgd', 'cain_lslr_adam_1step', 'rrin_lslr_sgd_2step', 'superslomo_lslr_sgd_2step']
 
 
 @pytest.mark.parametrize("name", GRAPH_CASES)
