@@ -175,7 +175,7 @@ def main():
         "metric": "inner-loop steps/sec", "value": inner_steps / elapsed, "unit": "inner-loop steps/sec",
         "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": 1e3 * elapsed / opt.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": opt.workload, "model": model, "tasks_per_gpu": tasks, "global_meta_batch": tasks * world,
+        "config": {"workload": opt.workload, "plugin": model, "tasks_per_gpu": tasks, "global_meta_batch": tasks * world,
                    "inner_steps": S, "frame": "%dx%dx3" % (H, W), "inner_rule": ("metasgd" if over.get('metasgd') else "lslr")
                    + "+" + over['optimizer'], "parallelism": "task-parallel x%d, 1 all-reduce of outer grads" % world,
                    "outer_tasks_per_sec": tasks * world * opt.steps / elapsed},
