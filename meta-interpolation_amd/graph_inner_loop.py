@@ -77,11 +77,11 @@ class GraphedInnerLoop:
         return [self.rule._lr(k, t) for k in self.routed]
 
     def _support_step(self, W, t):
-        model_utils.OWN_PARAMS_CONST = True      # first-order support pass: non-routed parameters are constants
+        model_utils.set_own_params_const(True)      # first-order support pass: non-routed parameters are constants
         try:
             out = _frame(self.net.forward(self.sup[0], self.sup[2], params=W, backup_running_statistics=(t == 0), num_step=t))
         finally:
-            model_utils.OWN_PARAMS_CONST = False
+            model_utils.set_own_params_const(False)
         loss = self.crit(out[0:1], self.sup[1][0:1])['total'] + self.crit(out[1:2], self.sup[1][1:2])['total']
         g = torch.autograd.grad(loss, [W[k] for k in self.routed])
         ws = [W[k].detach() for k in self.routed]

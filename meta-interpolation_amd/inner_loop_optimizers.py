@@ -21,6 +21,8 @@ Behaviour on the reference's crashing configurations (documented divergence, DES
 """
 import math
 
+import threading
+
 import torch
 import torch.nn as nn
 
@@ -37,8 +39,19 @@ class _FusedInnerRule(nn.Module):
     def __init__(self, optimizer):
         super().__init__()
         self.optimizer = optimizer
-        self.state = {}
+        object.__setattr__(self, '_tls', threading.local())      # per-task moments live per THREAD (concurrent tasks)
         self.names_learning_rates_dict = nn.ParameterDict()
+
+    @property
+    def state(self):
+        st = getattr(self._tls, 'state', None)
+        if st is None:
+            st = self._tls.state = {}
+        return st
+
+    @state.setter
+    def state(self, value):
+        self._tls.state = value
 
     # -- surface ---------------------------------------------------------------------------
     def initialize_state(self):

@@ -20,6 +20,7 @@ What is different (MI355X-first, results identical):
     for >1 visible device (:285-287) is not reproduced: one process owns one device.
 """
 import functools
+import threading
 
 import numpy as np
 import torch
@@ -177,6 +178,7 @@ class SceneAdaptiveInterpolation(nn.Module):
         self._first_order = False
         self._defer_logging = False
         self._pending_logging = None
+        self._task_stream_pool = None
         self._graphs = {}            # (frame shape, steps, training, msl) -> GraphedInnerLoop
         self._manual_grads = None    # OuterGradAccumulator of the last graphed training forward
 
@@ -233,11 +235,11 @@ class SceneAdaptiveInterpolation(nn.Module):
         a, b = self.support_idxs
         # step 0 differentiates w.r.t. theta itself, whose non-routed tensors ARE the modules' own parameters
         # (reference fact: 94 live tensors at step 0, 54 afterwards); from step 1 on those are constants
-        model_utils.OWN_PARAMS_CONST = self._first_order and num_step > 0
+        model_utils.set_own_params_const(self._first_order and num_step > 0)
         try:
             return self._support_loss_impl(frames, task_id, weights, num_step, a, b)
         finally:
-            model_utils.OWN_PARAMS_CONST = False
+            model_utils.set_own_params_const(False)
 
     def _support_loss_impl(self, frames, task_id, weights, num_step, a, b):
         if self.fuse_support_pairs:
@@ -324,6 +326,85 @@ class SceneAdaptiveInterpolation(nn.Module):
             return self.revNormalize(img)
         return img
 
+    def _task_body(self, frames, task_id, *, num_steps, use_second_order, msl, training_phase, do_evaluation, importance):
+        """Everything one task contributes to a meta-iteration (reference :366-461): adaptation, target pass(es), its
+        loss term, prediction, logging scalars.  Touches no shared mutable state, so tasks can run concurrently."""
+        task_losses, logs, state = [], [], {}
+
+        def after_step(num_step, weights):
+            if msl:  # MAML++: weighted target loss after every inner step
+                tl, tp_ = self._target_pass(frames, task_id, weights, num_step)
+                task_losses.append(importance[num_step] * tl['total'])
+                logs.extend(tl.items())
+                state['preds'] = tp_
+
+        weights = self._adapt(frames, task_id, num_steps, use_second_order, after_step)
+
+        if not training_phase:
+            with torch.no_grad():
+                tl, state['preds'] = self._target_pass(frames, task_id, weights, num_steps)
+            task_losses.append(tl['total'])
+            logs.extend(tl.items())
+        elif not msl:
+            tl, state['preds'] = self._target_pass(frames, task_id, weights, num_steps)
+            task_losses.append(tl['total'])
+            logs.extend(tl.items())
+
+        target_preds = state['preds']
+        res = {'pred': self._to_unit_range(target_preds.detach().squeeze(0)).unsqueeze(0), 'logs': logs}
+        if do_evaluation:
+            out01 = self._to_unit_range(target_preds.detach().squeeze(0))
+            tgt01 = self._to_unit_range(frames[self.target_idxs[1]][task_id].detach())
+            q_o, q_t = utils.quantize(out01, 1.), utils.quantize(tgt01, 1.)
+            res['mse'] = (q_o - q_t).div(255).pow(2).mean()
+            res['ssim'] = utils.ssim(q_o.unsqueeze(0), q_t.unsqueeze(0), val_range=255)
+        res['loss'] = torch.sum(torch.stack(task_losses))
+        if not training_phase:
+            self.net.restore_backup_stats()
+        return res
+
+    def _run_tasks(self, local, body):
+        """Results of body(task) for the local tasks, in order.  With --task_streams N > 1 on a GPU the tasks are spread
+        over N Python threads, each on its own HIP stream: tasks are independent, and the many small kernels of the deep
+        layers (a 12x16 map occupies a fraction of the 256 CUs) then overlap with another task's instead of queueing
+        behind each other.  Autograd, the caching allocator and MIOpen handles are per-thread / per-stream safe; the
+        per-task rule state and the OWN_PARAMS_CONST flag are thread-local."""
+        n = min(int(getattr(self.args, 'task_streams', 1) or 1), len(local))
+        if n <= 1 or self.device.type != 'cuda':
+            return [body(t) for t in local]
+        dev_index = torch.cuda.current_device()
+        if self._task_stream_pool is None or len(self._task_stream_pool) < n:
+            self._task_stream_pool = [torch.cuda.Stream(device=dev_index) for _ in range(n)]
+        streams = self._task_stream_pool[:n]
+        cur = torch.cuda.current_stream(dev_index)
+        results, errors = {}, []
+
+        def worker(i):
+            try:
+                torch.cuda.set_device(dev_index)                # new threads start on device 0
+                with torch.cuda.stream(streams[i]):
+                    for t in local[i::n]:
+                        results[t] = body(t)
+            except BaseException as e:                          # re-raised on the calling thread
+                errors.append(e)
+
+        for s in streams:
+            s.wait_stream(cur)
+        threads = [threading.Thread(target=worker, args=(i,), name="savfi-task-%d" % i) for i in range(n)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        for s in streams:
+            cur.wait_stream(s)
+        if errors:
+            raise errors[0]
+        for res in results.values():                            # produced on a side stream, consumed on the caller's
+            for v in [res['loss'], res['pred'], res.get('mse'), res.get('ssim')] + [v for _, v in res['logs']]:
+                if torch.is_tensor(v) and v.is_cuda:
+                    v.record_stream(cur)
+        return [results[t] for t in local]
+
     def forward(self, data_batch, epoch, use_second_order, use_multi_step_loss_optimization, num_steps,
                 training_phase, do_evaluation=False):
         """Outer-loop forward over the (local shard of the) meta-batch  (reference :346-472).
@@ -350,44 +431,16 @@ class SceneAdaptiveInterpolation(nn.Module):
         self.net.zero_grad()
         importance = self.get_per_step_loss_importance_vector()
 
-        for task_id in local:
-            task_losses = []
-            state = {}
-
-            def after_step(num_step, weights):
-                if msl:  # MAML++: weighted target loss after every inner step
-                    tl, tp_ = self._target_pass(frames, task_id, weights, num_step)
-                    task_losses.append(importance[num_step] * tl['total'])
-                    for k, v in tl.items():
-                        deferred.add(k, v)
-                    state['preds'] = tp_
-
-            weights = self._adapt(frames, task_id, num_steps, use_second_order, after_step)
-
-            if not training_phase:
-                with torch.no_grad():
-                    tl, state['preds'] = self._target_pass(frames, task_id, weights, num_steps)
-                task_losses.append(tl['total'])
-                for k, v in tl.items():
-                    deferred.add(k, v)
-            elif not msl:
-                tl, state['preds'] = self._target_pass(frames, task_id, weights, num_steps)
-                task_losses.append(tl['total'])
-                for k, v in tl.items():
-                    deferred.add(k, v)
-
-            target_preds = state['preds']
-            preds[task_id] = self._to_unit_range(target_preds.detach().squeeze(0)).unsqueeze(0)
+        body = functools.partial(self._task_body, frames, num_steps=num_steps, use_second_order=use_second_order, msl=msl,
+                                 training_phase=training_phase, do_evaluation=do_evaluation, importance=importance)
+        for task_id, res in zip(local, self._run_tasks(local, body)):
+            total_losses.append(res['loss'])
+            preds[task_id] = res['pred']
+            for k, v in res['logs']:
+                deferred.add(k, v)
             if do_evaluation:
-                out01 = self._to_unit_range(target_preds.detach().squeeze(0))
-                tgt01 = self._to_unit_range(frames[self.target_idxs[1]][task_id].detach())
-                q_o, q_t = utils.quantize(out01, 1.), utils.quantize(tgt01, 1.)
-                eval_mse.append((q_o - q_t).div(255).pow(2).mean())
-                eval_ssim.append(utils.ssim(q_o.unsqueeze(0), q_t.unsqueeze(0), val_range=255))
-
-            total_losses.append(torch.sum(torch.stack(task_losses)))
-            if not training_phase:
-                self.net.restore_backup_stats()
+                eval_mse.append(res['mse'])
+                eval_ssim.append(res['ssim'])
 
         # mean over the GLOBAL meta-batch: local sum / B (the all-reduce of grads completes the mean)
         if total_losses:

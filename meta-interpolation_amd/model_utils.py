@@ -12,6 +12,8 @@ loop and layers receive a ``ParamView`` = (flat dict, name prefix); descending a
 concatenation and a leaf lookup is a single dict access.  Plain (possibly nested) dicts are still
 accepted anywhere a ParamView is, so the reference's call pattern ``module(x, params=subdict)`` works.
 """
+import threading
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -136,7 +138,16 @@ FUSE_CONV_ACT = False
 # them as constants.  The inner gradient is taken w.r.t. the fast weights only and its graph is dropped, so nothing
 # changes - but custom autograd Functions cannot see which of their inputs a particular autograd.grad() call
 # needs (ctx.needs_input_grad only says requires_grad) and would compute unused weight gradients.
-OWN_PARAMS_CONST = False
+# Per THREAD: tasks may be adapted concurrently, one Python thread and HIP stream each (meta_learning_system.py).
+_TLS = threading.local()
+
+
+def own_params_const():
+    return getattr(_TLS, 'own_params_const', False)
+
+
+def set_own_params_const(value):
+    _TLS.own_params_const = bool(value)
 
 
 def _act_slope(module):
@@ -168,7 +179,7 @@ class MetaConv2dLayer(nn.Module):
             pv = as_view(params)
             weight = pv.leaf("weight")
             bias = pv.leaf("bias") if self.use_bias else None
-        elif OWN_PARAMS_CONST:
+        elif own_params_const():
             weight, bias = self.weight.detach(), (self.bias.detach() if self.bias is not None else None)
         else:
             weight, bias = self.weight, self.bias

@@ -15,6 +15,7 @@ from meta_interpolation_amd.config import default_args
 from meta_interpolation_amd.inner_loop_optimizers import LSLRGradientDescentLearningRule, MetaSGDLearningRule
 from meta_interpolation_amd.meta_learning_system import SceneAdaptiveInterpolation
 from oracle import rules as orules
+from tests.helpers import fp as helpers_fp
 from tests.helpers import assert_fp_close, build_plugin, build_system, fp, golden, observe, parse_case_args
 
 pytestmark = pytest.mark.gpu
@@ -247,6 +248,42 @@ def test_second_order_cain_matches_oracle():
             assert_fp_close(rec['outer_grad_fp'][key], fp(p.grad), 2e-3, ('second-order', n))
             checked += 1
     assert checked == 494
+
+
+# ---------------------------------------------------------------------------------------------
+# concurrent tasks (--task_streams 2): one Python thread + HIP stream per task, same results as the sequential loop
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ['sepconv_msl_learnable_2step', 'voxelflow_lslr_sgd_2step', 'voxelflow_script_metasgd_adam_1step',
+                                  'superslomo_lslr_sgd_2step'])
+@pytest.mark.parametrize("phase", ["train", "val"])
+def test_concurrent_tasks_match_reference_fixture(name, phase):
+    g = golden("system_" + name)
+    model = str(g['model'])
+    assert int(g['B']) >= 1
+    over = dict(parse_case_args(g), task_streams=2)
+    system = build_system(model, over)
+    frames = synthetic.septuplet_batch(max(int(g['B']), 2), int(g['H']), int(g['W']), model=model)
+    if int(g['B']) == 1:          # single-task fixture: run it next to a second task and compare task 0 only
+        pytest.skip("fixture has one task")
+    rec_outer = {}
+    system.optimizer.step = lambda *a, **k: rec_outer.update(
+        {n: helpers_fp(p.grad) for n, p in system.named_parameters() if p.requires_grad and p.grad is not None})
+    if phase == 'train':
+        losses, preds, metrics = system.run_train_iter(data_batch=frames, epoch=0, do_evaluation=True)
+    else:
+        losses, preds, metrics = system.run_validation_iter(data_batch=frames)
+    torch.cuda.synchronize()
+    tol = TOL[name]
+    want_loss = float(g[phase + '_loss'])
+    assert abs(losses['loss'].item() - want_loss) <= tol['loss'] * abs(want_loss)
+    got = torch.stack([p.squeeze(0) for p in preds]).cpu().numpy()
+    assert np.abs(got - g[phase + '_preds']).mean() < tol['l1']
+    assert abs(metrics['psnr'].avg - float(g[phase + '_psnr'])) < tol['psnr']
+    if phase == 'train':
+        rows = dict(zip(list(g['outer_grad_fp_0_keys']), g['outer_grad_fp_0']))
+        assert set(rec_outer) == set(rows)
+        for k, row in rows.items():
+            assert_fp_close(rec_outer[k], row, tol['outer'], (name, 'outer', k))
 
 
 # ---------------------------------------------------------------------------------------------
