@@ -286,6 +286,25 @@ def test_concurrent_tasks_match_reference_fixture(name, phase):
             assert_fp_close(rec_outer[k], row, tol['outer'], (name, 'outer', k))
 
 
+@pytest.mark.parametrize("optimizer,metasgd", [("Adam", False), ("Adamax", True)])
+def test_concurrent_tasks_keep_rule_state_per_task(optimizer, metasgd):
+    """Stateful inner rules (Adam / Adamax moments, step counts) under --task_streams 2: same losses and outer gradients as
+    the sequential loop on the same 4 tasks (the state is per thread; a shared state would mix the tasks' moments)."""
+    over = dict(optimizer=optimizer, metasgd=metasgd, inner_lr=1e-4, loss='1*L1', batch_size=4,
+                number_of_training_steps_per_iter=2, number_of_evaluation_steps_per_iter=2)
+    frames = synthetic.septuplet_batch(4, 64, 64, model='cain')
+    out = []
+    for streams in (1, 1, 2):      # the first iteration of a process is a warm-up: MIOpen's first call per convolution
+        system = build_system('cain', dict(over, task_streams=streams))   # config may run another solver than later calls
+        losses, preds, _ = system.run_train_iter(data_batch=frames, epoch=0, do_evaluation=False)
+        torch.cuda.synchronize()
+        out.append((losses['loss'].item(), torch.stack([p.squeeze(0) for p in preds])))
+    (_, _), (l1, p1), (l2, p2) = out
+    assert abs(l1 - l2) <= 1e-5 * abs(l1)
+    # a shared state would move the predictions by >= 1e-3 (Adam-type steps are +-lr*c per element)
+    assert (p1 - p2).abs().max() < 5e-5
+
+
 # ---------------------------------------------------------------------------------------------
 # hipGraph-captured inner loop (--graph_inner_loop 1): same results as the eager loop and the fixtures
 # ---------------------------------------------------------------------------------------------
