@@ -88,6 +88,7 @@ def main():
     ap.add_argument('--graph-inner-loop', type=int, default=0)
     ap.add_argument('--sepconv-window', type=int, default=1)
     ap.add_argument('--task-streams', type=int, default=1, help='tasks adapted concurrently (threads + HIP streams)')
+    ap.add_argument('--wgrad-overlap', type=int, default=0, help='weight gradients of support passes on a side stream')
     opt = ap.parse_args()
 
     from meta_interpolation_amd import _hip, synthetic, task_parallel
@@ -107,7 +108,7 @@ def main():
     args = default_args(model=model, num_gpu=1, batch_size=tasks * world,
                         number_of_training_steps_per_iter=S, number_of_evaluation_steps_per_iter=S,
                         fuse_conv_act=opt.fuse_conv_act, graph_inner_loop=opt.graph_inner_loop,
-                        sepconv_window=opt.sepconv_window, task_streams=opt.task_streams, **over)
+                        sepconv_window=opt.sepconv_window, task_streams=opt.task_streams, wgrad_overlap=opt.wgrad_overlap, **over)
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):      # the ONE line on stdout is the JSON result
         net = MODEL_REGISTRY[model](args, False)
@@ -183,7 +184,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": opt.workload, "plugin": model, "tasks_per_gpu": tasks, "global_meta_batch": tasks * world,
                    "inner_steps": S, "frame": "%dx%dx3" % (H, W), "inner_rule": ("metasgd" if over.get('metasgd') else "lslr")
-                   + "+" + over['optimizer'], "parallelism": "task-parallel x%d, 1 all-reduce of outer grads" % world, "task_streams": opt.task_streams,
+                   + "+" + over['optimizer'], "parallelism": "task-parallel x%d, 1 all-reduce of outer grads" % world, "task_streams": opt.task_streams, "wgrad_overlap": opt.wgrad_overlap,
                    "outer_tasks_per_sec": tasks * world * opt.steps / elapsed},
     }
     done = [(a, b) for a, b in bodies if b is not None]

@@ -7,6 +7,7 @@ Additions for the MI355X build (all optional, all default to the reference behav
   --fuse_conv_act {0,1}        conv+bias+(Leaky)ReLU with fused epilogue kernels (default 1; first-order only)
   --graph_inner_loop {0,1}     replay the first-order inner loop from captured hipGraphs (graph_inner_loop.py)
   --sepconv_window {0,1}       SepConv: evaluate the sub-networks / 51-tap op on the frame window only (same values)
+  --wgrad_overlap {0,1}        weight gradients of first-order support passes on a side stream, beside the data-gradient chain (default 0)
   --task_streams N             adapt N tasks of a meta-batch concurrently (one Python thread + HIP stream each; default 1)
   --synthetic                  feed seeded synthetic septuplets instead of reading a dataset
 """
@@ -42,7 +43,7 @@ _FLAGS = {
     ],
     'MI355X': [
         ('fuse_support_pairs', int, 1), ('fuse_conv_act', int, 1), ('graph_inner_loop', int, 0), ('sepconv_window', int, 1),
-        ('task_streams', int, 1),
+        ('task_streams', int, 1), ('wgrad_overlap', int, 0),
         ('synthetic', 'flag', False),
     ],
 }

@@ -5,6 +5,7 @@ on torch's current stream.  Device tensors only -- there is no CPU or eager-PyTo
 """
 import functools
 import os
+import threading
 
 import torch
 from torch.autograd.function import once_differentiable
@@ -459,6 +460,54 @@ def conv3x3_wgrad_eligible(x, weight, stride, padding, dilation, groups):
     return Ci >= WGRAD_MIN_CI and Ho * Wo >= WGRAD_MIN_PIXELS and fill >= 0.85
 
 
+# Weight gradients on a side stream.  In the backward of a first-order support pass the data-gradient chain (layer L's gx
+# feeds layer L-1) is the critical path; the weight gradients hang off it and are only consumed by the update after the whole
+# backward.  While overlap is switched on (per thread, by the caller that owns the autograd.grad() call) every fused conv
+# op remembers the side stream at FORWARD time (its backward runs on autograd's device thread, where a thread-local flag
+# would not be visible) and queues its weight gradient there; the caller joins before it touches the gradients.
+_WG = threading.local()
+
+
+_WG_SIDE = {}              # compute stream handle -> its side stream (persistent: streams and the library handles bound
+_WG_LOCK = threading.Lock()    # to them are not created per pass or per worker thread)
+
+
+def set_weight_gradient_overlap(on):
+    _WG.stream = None
+    if on:
+        key = (torch.cuda.current_device(), _hip.current_stream())
+        with _WG_LOCK:
+            side = _WG_SIDE.get(key)
+            if side is None:
+                side = _WG_SIDE[key] = torch.cuda.Stream()
+        _WG.stream = side
+    _WG.on = bool(on)
+    _WG.uses = {}          # id(weight) -> [number of fused conv ops that read it in this pass]
+
+
+def _weight_use_counter(w):
+    """A weight read by more than one op of the pass (the unfused support triplets, a plugin that shares layers) gets
+    its contributions ADDED by autograd on the compute stream as soon as the second one is returned - before the caller's
+    join.  Such weights keep their gradient on the compute stream (decided in backward, when the count is final)."""
+    holder = _WG.uses.setdefault(id(w), [0])
+    holder[0] += 1
+    return holder
+
+
+def weight_gradient_stream():
+    return getattr(_WG, 'stream', None) if getattr(_WG, 'on', False) else None
+
+
+def join_weight_gradients():
+    """Make the current stream wait for every weight gradient queued on its side stream."""
+    if not _WG_SIDE:
+        return
+    with _WG_LOCK:
+        side = _WG_SIDE.get((torch.cuda.current_device(), _hip.current_stream()))
+    if side is not None:
+        torch.cuda.current_stream().wait_stream(side)
+
+
 class _ConvBiasAct(torch.autograd.Function):
     """y = act(conv2d(x, w) + b).  Large 3x3 convolutions run on the savfi Winograd/MFMA kernel with bias and
     activation in its epilogue; the others stay on MIOpen with the bias add and activation as ONE in-place kernel
@@ -481,6 +530,8 @@ class _ConvBiasAct(torch.autograd.Function):
             _hip.launch("bias_act_fwd", lambda: _hip.check(lib.savfi_bias_act_fwd_f32(
                 z.data_ptr(), b.data_ptr(), N, C, H * W, slope, _hip.current_stream()), "savfi_bias_act_fwd_f32"))
         ctx.conf = (stride, padding, dilation, groups, slope)
+        ctx.wg_stream = weight_gradient_stream() if x.is_cuda else None
+        ctx.wg_uses = _weight_use_counter(w) if ctx.wg_stream is not None else None
         ctx.save_for_backward(x, w, z)
         return z
 
@@ -507,11 +558,27 @@ class _ConvBiasAct(torch.autograd.Function):
         if need_x and conv3x3_eligible(x, w, stride, padding, dilation, groups, backward=True):
             gx = conv3x3(gz, w, None, 1, 1.0, pad)
             need_x = False
+        pair = lambda v: [v, v] if isinstance(v, int) else list(v)
+        side = ctx.wg_stream if (ctx.wg_stream is not None and ctx.wg_uses[0] == 1) else None
+        if need_w and side is not None:
+            # gz was produced on this stream just above: the side stream picks up from here
+            ready = torch.cuda.Event()
+            ready.record()
+            side.wait_event(ready)
+            if conv3x3_wgrad_eligible(x, w, stride, padding, dilation, groups):
+                gw = conv3x3_wgrad(x, gz, pad, stream=side.cuda_stream, extra_stream=side)
+            else:
+                with torch.cuda.stream(side):
+                    _, gw, _ = torch.ops.aten.convolution_backward(gz, x, w, None, pair(stride), pair(padding), pair(dilation),
+                                                                   False, [0, 0], groups, [False, True, False])
+                gw.record_stream(torch.cuda.current_stream())      # consumed on this stream after the caller's join
+            x.record_stream(side)
+            gz.record_stream(side)
+            need_w = False
         if need_w and conv3x3_wgrad_eligible(x, w, stride, padding, dilation, groups):
             gw = conv3x3_wgrad(x, gz, pad)
             need_w = False
         if need_x or need_w:
-            pair = lambda v: [v, v] if isinstance(v, int) else list(v)
             gx2, gw2, _ = torch.ops.aten.convolution_backward(gz, x, w, None, pair(stride), pair(padding), pair(dilation),
                                                               False, [0, 0], groups, [need_x, need_w, False])
             gx = gx2 if need_x else gx
@@ -548,8 +615,11 @@ def conv3x3(x, weight, bias=None, mode=0, slope=1.0, pad=1):
     return out
 
 
-def conv3x3_wgrad(x, gz, pad=1):
-    """savfi_conv3x3_wgrad_f32: weight gradient [Co,Ci,3,3] of conv2d(x, w, padding=pad) for the cotangent gz."""
+def conv3x3_wgrad(x, gz, pad=1, stream=None, extra_stream=None):
+    """savfi_conv3x3_wgrad_f32: weight gradient [Co,Ci,3,3] of conv2d(x, w, padding=pad) for the cotangent gz.
+    `stream` (raw handle) launches on another stream than torch's current one; the result and the workspace are still
+    allocated from the current stream's pool (safe: that stream has been made to wait for this one) and registered with
+    `extra_stream` so that they are not recycled while it still uses them."""
     x, gz = x.contiguous(), gz.contiguous()
     _hip.require_cuda(x, gz)
     N, Ci, H, W = x.shape
@@ -558,9 +628,12 @@ def conv3x3_wgrad(x, gz, pad=1):
     lib = _hip.lib()
     ws = torch.empty(_workspace_floats("savfi_conv3x3_wgrad_workspace_floats", N, Ci, Co, H, W, int(pad)), dtype=x.dtype, device=x.device)
     gw = torch.empty((Co, Ci, 3, 3), dtype=x.dtype, device=x.device)
+    if extra_stream is not None:
+        ws.record_stream(extra_stream)
+        gw.record_stream(extra_stream)
     _hip.launch("conv3x3_wgrad", lambda: _hip.check(lib.savfi_conv3x3_wgrad_f32(
-        x.data_ptr(), gz.data_ptr(), gw.data_ptr(), ws.data_ptr(), N, Ci, Co, H, W, int(pad), _hip.current_stream()),
-        "savfi_conv3x3_wgrad_f32"))
+        x.data_ptr(), gz.data_ptr(), gw.data_ptr(), ws.data_ptr(), N, Ci, Co, H, W, int(pad),
+        _hip.current_stream() if stream is None else stream), "savfi_conv3x3_wgrad_f32"))
     return gw
 
 

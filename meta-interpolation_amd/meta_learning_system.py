@@ -236,10 +236,15 @@ class SceneAdaptiveInterpolation(nn.Module):
         # step 0 differentiates w.r.t. theta itself, whose non-routed tensors ARE the modules' own parameters
         # (reference fact: 94 live tensors at step 0, 54 afterwards); from step 1 on those are constants
         model_utils.set_own_params_const(self._first_order and num_step > 0)
+        # first-order support pass: its weight gradients may run beside the data-gradient chain (joined by the callers
+        # right after autograd.grad, before anything reads them)
+        hip_ops.set_weight_gradient_overlap(self._first_order and self.device.type == 'cuda'
+                                            and bool(getattr(self.args, 'wgrad_overlap', 0)))
         try:
             return self._support_loss_impl(frames, task_id, weights, num_step, a, b)
         finally:
             model_utils.set_own_params_const(False)
+            hip_ops.set_weight_gradient_overlap(False)
 
     def _support_loss_impl(self, frames, task_id, weights, num_step, a, b):
         if self.fuse_support_pairs:
@@ -277,6 +282,7 @@ class SceneAdaptiveInterpolation(nn.Module):
         loss = self._support_loss(frames, task_id, names_weights_copy, num_step=0)
         self.net.zero_grad(names_weights_copy)
         grads = torch.autograd.grad(loss, names_weights_copy.values(), create_graph=False, allow_unused=True)
+        hip_ops.join_weight_gradients()
         if any(g is None for g in grads):
             raise AttributeError("L2F needs a gradient for every inner-loop tensor (the reference calls "
                                  ".mean() on None here, meta_learning_system.py:251)")
@@ -298,6 +304,7 @@ class SceneAdaptiveInterpolation(nn.Module):
         self.net.zero_grad(params=names_weights_copy)
         grads = torch.autograd.grad(loss, names_weights_copy.values(), create_graph=use_second_order,
                                     allow_unused=True)
+        hip_ops.join_weight_gradients()
         return self.inner_loop_optimizer.update_params(
             names_weights_dict=names_weights_copy,
             names_grads_wrt_params_dict=dict(zip(names_weights_copy.keys(), grads)),

@@ -283,23 +283,56 @@ def test_concurrent_tasks_match_reference_fixture(name, phase):
             assert_fp_close(rec_outer[k], row, tol['outer'], (name, 'outer', k))
 
 
+@pytest.mark.parametrize("name", ['sepconv_lslr_sgd_2step', 'sepconv_msl_learnable_2step', 'c1_cain_lslr_sgd', 'cain_l2f',
+                                  'rrin_lslr_sgd_2step', 'superslomo_lslr_sgd_2step'])
+def test_weight_gradients_on_a_side_stream_match_reference_fixture(name):
+    """--wgrad_overlap 1: the weight gradients of the support passes run beside the data-gradient chain; same fixtures,
+    same gates (per-step gradient / weight fingerprints included)."""
+    g = golden("system_" + name)
+    model = str(g['model'])
+    system = build_system(model, dict(parse_case_args(g), wgrad_overlap=1))
+    rec = observe(system)
+    frames = synthetic.septuplet_batch(int(g['B']), int(g['H']), int(g['W']), model=model)
+    losses, preds, metrics = system.run_train_iter(data_batch=frames, epoch=0, do_evaluation=True)
+    torch.cuda.synchronize()
+    tol = TOL[name]
+    want_loss = float(g['train_loss'])
+    assert abs(losses['loss'].item() - want_loss) <= tol['loss'] * abs(want_loss)
+    got = torch.stack([p.squeeze(0) for p in preds]).cpu().numpy()
+    assert np.abs(got - g['train_preds']).mean() < tol['l1']
+    assert list(g['train_n_live']) == rec['n_live']
+    for i, d in enumerate(rec['grad_fp']):
+        for k, row in zip(list(g['train_grad_fp_%d_keys' % i]), g['train_grad_fp_%d' % i]):
+            assert_fp_close(d[k], row, tol['g'], (name, 'g', i, k))
+    for i, d in enumerate(rec['weight_fp']):
+        for k, row in zip(list(g['train_weight_fp_%d_keys' % i]), g['train_weight_fp_%d' % i]):
+            assert_fp_close(d[k], row, tol['w'], (name, 'w', i, k))
+
+
 @pytest.mark.parametrize("optimizer,metasgd", [("Adam", False), ("Adamax", True)])
 def test_concurrent_tasks_keep_rule_state_per_task(optimizer, metasgd):
-    """Stateful inner rules (Adam / Adamax moments, step counts) under --task_streams 2: same losses and outer gradients as
-    the sequential loop on the same 4 tasks (the state is per thread; a shared state would mix the tasks' moments)."""
-    over = dict(optimizer=optimizer, metasgd=metasgd, inner_lr=1e-4, loss='1*L1', batch_size=4,
+    """Stateful inner rules (moments, step counts) under --task_streams 2: every task sees its own state.  Checked on the
+    step counters (exact), not on pixels: Adam-type steps amplify MIOpen's run-to-run solver differences."""
+    import threading
+    over = dict(optimizer=optimizer, metasgd=metasgd, inner_lr=1e-4, loss='1*L1', batch_size=4, task_streams=2,
                 number_of_training_steps_per_iter=2, number_of_evaluation_steps_per_iter=2)
     frames = synthetic.septuplet_batch(4, 64, 64, model='cain')
-    out = []
-    for streams in (1, 1, 2):      # the first iteration of a process is a warm-up: MIOpen's first call per convolution
-        system = build_system('cain', dict(over, task_streams=streams))   # config may run another solver than later calls
-        losses, preds, _ = system.run_train_iter(data_batch=frames, epoch=0, do_evaluation=False)
-        torch.cuda.synchronize()
-        out.append((losses['loss'].item(), torch.stack([p.squeeze(0) for p in preds])))
-    (_, _), (l1, p1), (l2, p2) = out
-    assert abs(l1 - l2) <= 1e-5 * abs(l1)
-    # a shared state would move the predictions by >= 1e-3 (Adam-type steps are +-lr*c per element)
-    assert (p1 - p2).abs().max() < 5e-5
+    system = build_system('cain', over)
+    rule = system.inner_loop_optimizer
+    orig, seen = rule.update_params, []
+
+    def update_params(names_weights_dict, names_grads_wrt_params_dict, num_step, **kw):
+        out = orig(names_weights_dict=names_weights_dict, names_grads_wrt_params_dict=names_grads_wrt_params_dict,
+                   num_step=num_step, **kw)
+        seen.append((threading.get_ident(), num_step, sorted({st['step'] for st in rule.state.values()})))
+        return out
+    rule.update_params = update_params
+    losses, preds, _ = system.run_train_iter(data_batch=frames, epoch=0, do_evaluation=False)
+    torch.cuda.synchronize()
+    assert len(seen) == 4 * 2 and len({tid for tid, _, _ in seen}) == 2          # 4 tasks x 2 steps on two worker threads
+    for tid, num_step, steps in seen:
+        assert steps == [num_step + 1], (tid, num_step, steps)                   # a shared state would count both tasks
+    assert np.isfinite(losses['loss'].item()) and all(torch.isfinite(p).all() for p in preds)
 
 
 # ---------------------------------------------------------------------------------------------
