@@ -160,3 +160,42 @@ def test_synthetic_recipe_is_deterministic_and_well_formed():
 
 def test_registry_has_the_plugins():
     assert {'sepconv', 'voxelflow', 'cain', 'rrin', 'superslomo'} <= set(MODEL_REGISTRY)
+
+
+def test_per_task_state_and_flags_are_thread_local():
+    """Concurrent task adaptation (--task_streams): the inner rule's per-task moments / step counts and the
+    OWN_PARAMS_CONST flag live per thread."""
+    import threading
+    from meta_interpolation_amd import model_utils
+    from meta_interpolation_amd.inner_loop_optimizers import LSLRGradientDescentLearningRule
+    rule = LSLRGradientDescentLearningRule(device=torch.device('cpu'), optimizer='Adam', init_learning_rate=1e-3,
+                                           total_num_inner_loop_steps=2, use_learnable_learning_rates=False)
+    rule.initialize_state()
+    rule.state['k'] = {'step': 7}
+    model_utils.set_own_params_const(True)
+    seen = {}
+
+    def other():
+        seen['state'] = dict(rule.state)                 # a fresh thread starts with an empty state ...
+        seen['flag'] = model_utils.own_params_const()    # ... and the flag off
+        rule.state['k'] = {'step': 1}
+        model_utils.set_own_params_const(True)
+    th = threading.Thread(target=other)
+    th.start()
+    th.join()
+    try:
+        assert seen == {'state': {}, 'flag': False}
+        assert rule.state == {'k': {'step': 7}} and model_utils.own_params_const()
+    finally:
+        model_utils.set_own_params_const(False)
+
+
+def test_weight_gradient_overlap_is_off_without_a_gpu_and_counts_weight_uses():
+    from meta_interpolation_amd import hip_ops
+    hip_ops.set_weight_gradient_overlap(False)
+    assert hip_ops.weight_gradient_stream() is None
+    hip_ops.join_weight_gradients()                      # no side stream was ever created: a no-op, also on CPU
+    w = torch.zeros(1)
+    assert hip_ops._weight_use_counter(w)[0] == 1 and hip_ops._weight_use_counter(w)[0] == 2
+    hip_ops.set_weight_gradient_overlap(False)           # a new pass starts counting again
+    assert hip_ops._weight_use_counter(w)[0] == 1
