@@ -89,6 +89,8 @@ def main():
     ap.add_argument('--sepconv-window', type=int, default=1)
     ap.add_argument('--task-streams', type=int, default=1, help='tasks adapted concurrently (threads + HIP streams)')
     ap.add_argument('--wgrad-overlap', type=int, default=0, help='weight gradients of support passes on a side stream')
+    ap.add_argument('--fast-path', type=int, default=1,
+                    help='after the main measurement also time --graph-inner-loop 1 --task-streams 2 (reported as fast_path)')
     opt = ap.parse_args()
 
     from meta_interpolation_amd import _hip, synthetic, task_parallel
@@ -187,6 +189,40 @@ def main():
                    + "+" + over['optimizer'], "parallelism": "task-parallel x%d, 1 all-reduce of outer grads" % world, "task_streams": opt.task_streams, "wgrad_overlap": opt.wgrad_overlap,
                    "outer_tasks_per_sec": tasks * world * opt.steps / elapsed},
     }
+    # Second measurement, same workload, same K: the hipGraph-captured inner loop replayed on two task streams.  Reported
+    # beside `value`, not as `value`: graph replays carry no per-launch events, and kernels that share the GPU with
+    # another stream cannot be priced against a roofline in place.  Parity of this mode: tests/test_system_gpu.py
+    # (test_graph_replays_on_two_task_streams_match_reference_fixture).
+    fast = None
+    from meta_interpolation_amd import graph_inner_loop as _gil
+    if opt.fast_path and not opt.graph_inner_loop and opt.task_streams <= 1:
+        saved = (system.args.graph_inner_loop, system.args.task_streams)
+        system.args.graph_inner_loop, system.args.task_streams = 1, 2
+        try:
+            if _gil.supported(system, bool(getattr(system.args, 'second_order', False))):
+                for i in range(max(opt.warmup, 2)):
+                    one_iter(i)                      # captures one graph set per stream
+                tp.barrier()
+                torch.cuda.synchronize()
+                f0 = time.perf_counter()
+                for i in range(opt.steps):
+                    one_iter(i)
+                torch.cuda.synchronize()
+                tp.barrier()
+                fel = time.perf_counter() - f0
+                if tp.active:
+                    import torch.distributed as dist
+                    ft = torch.tensor([fel], dtype=torch.float64, device=dev)
+                    dist.all_reduce(ft, op=dist.ReduceOp.MAX)
+                    fel = float(ft.item())
+                fast = {"value": inner_steps / fel, "unit": "inner-loop steps/sec", "ms_per_step": 1e3 * fel / opt.steps,
+                        "mode": "--graph-inner-loop 1 --task-streams 2",
+                        "note": "same workload and step count, measured after the main region; first-order inner loop replayed from "
+                                "hipGraphs on two task streams, outer gradients assembled by hand"}
+        finally:
+            system.args.graph_inner_loop, system.args.task_streams = saved
+    if fast is not None:
+        line["fast_path"] = fast
     done = [(a, b) for a, b in bodies if b is not None]
     if done:
         body_ms = sum(a.elapsed_time(b) for a, b in done)

@@ -271,6 +271,21 @@ class OuterGradAccumulator:
             if k not in self.lr:
                 self.lr[k] = g.clone()
 
+    def tensors(self):
+        return list(self.param.values()) + list(self.lr.values()) + ([self.lr_rows] if self.lr_rows is not None else [])
+
+    def merge(self, other):
+        """Add another accumulator's sums (tasks adapted on another stream; the caller has joined the streams)."""
+        if other.param:
+            self.add_params(list(other.param.keys()), list(other.param.values()))
+        if other.lr_rows is not None:
+            if self.lr_rows is None:
+                self.lr_rows, self.lr_keys = other.lr_rows.clone(), other.lr_keys
+            else:
+                self.lr_rows.add_(other.lr_rows)
+        if other.lr:
+            self.add_lr_tensors(list(other.lr.keys()), list(other.lr.values()))
+
     def install(self, num_tasks):
         """Write the accumulated gradients (mean over the GLOBAL meta-batch) into .grad."""
         inv = 1.0 / float(num_tasks)

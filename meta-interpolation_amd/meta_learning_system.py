@@ -498,30 +498,56 @@ class SceneAdaptiveInterpolation(nn.Module):
         hip_ops.DOUBLE_BACKWARD = False
         model_utils.FUSE_CONV_ACT = bool(getattr(self.args, 'fuse_conv_act', 0))
         key = (tuple(frames[0].shape[1:]), num_steps, bool(training_phase), msl)
-        if key not in self._graphs:
-            import gc
-            gc.collect()
-            self._graphs[key] = graph_inner_loop.GraphedInnerLoop(self, frames[0].shape[1:], num_steps,
-                                                                  bool(training_phase), msl)
-        gl = self._graphs[key]
+        local = tp.local_tasks(num_tasks)
+        # --task_streams N: N graph sets (own static buffers and memory pool each), replayed from N threads on N streams
+        n = max(1, min(int(getattr(self.args, 'task_streams', 1) or 1), len(local)))
+        loops = []
+        for i in range(n):
+            if key + (i,) not in self._graphs:
+                import gc
+                gc.collect()
+                self._graphs[key + (i,)] = graph_inner_loop.GraphedInnerLoop(self, frames[0].shape[1:], num_steps,
+                                                                             bool(training_phase), msl)
+            loops.append(self._graphs[key + (i,)])
         importance = self.get_per_step_loss_importance_vector()
-        accum = graph_inner_loop.OuterGradAccumulator(self, gl.theta) if training_phase else None
-        deferred = _DeferredMeters()
-        eval_mse, eval_ssim, total_losses = [], [], []
-        preds = [[] for _ in range(num_tasks)]
-        for task_id in tp.local_tasks(num_tasks):
-            task_loss, pred, logs = gl.run_task(frames, task_id, importance, accum)
-            for parts in logs:
-                for k, v in parts.items():
-                    deferred.add(k, v)
-            total_losses.append(task_loss)
-            preds[task_id] = self._to_unit_range(pred.squeeze(0)).unsqueeze(0)
+        accums = [graph_inner_loop.OuterGradAccumulator(self, gl.theta) if training_phase else None for gl in loops]
+
+        def body(i, task_id):
+            task_loss, pred, logs = loops[i].run_task(frames, task_id, importance, accums[i])
+            res = {'loss': task_loss, 'pred': self._to_unit_range(pred.squeeze(0)).unsqueeze(0),
+                   'logs': [(k, v) for parts in logs for k, v in parts.items()]}
             if do_evaluation:
                 out01 = self._to_unit_range(pred.squeeze(0))
                 tgt01 = self._to_unit_range(frames[self.target_idxs[1]][task_id].detach())
                 q_o, q_t = utils.quantize(out01, 1.), utils.quantize(tgt01, 1.)
-                eval_mse.append((q_o - q_t).div(255).pow(2).mean())
-                eval_ssim.append(utils.ssim(q_o.unsqueeze(0), q_t.unsqueeze(0), val_range=255))
+                res['mse'] = (q_o - q_t).div(255).pow(2).mean()
+                res['ssim'] = utils.ssim(q_o.unsqueeze(0), q_t.unsqueeze(0), val_range=255)
+            return res
+
+        if n == 1:
+            results = [body(0, t) for t in local]
+        else:
+            owner = {t: j % n for j, t in enumerate(local)}
+            results = self._run_tasks(local, lambda t: body(owner[t], t))
+            cur = torch.cuda.current_stream()
+            for a in accums:                     # summed on the worker streams, merged / installed on this one
+                for t in (a.tensors() if a is not None else []):
+                    t.record_stream(cur)
+        accum = accums[0]
+        for other in accums[1:]:
+            if other is not None:
+                accum.merge(other)
+        deferred = _DeferredMeters()
+        eval_mse, eval_ssim, total_losses = [], [], []
+        preds = [[] for _ in range(num_tasks)]
+        for task_id, res in zip(local, results):
+            total_losses.append(res['loss'])
+            preds[task_id] = res['pred']
+            for k, v in res['logs']:
+                deferred.add(k, v)
+            if do_evaluation:
+                eval_mse.append(res['mse'])
+                eval_ssim.append(res['ssim'])
         local_sum = torch.sum(torch.stack(total_losses)) if total_losses else torch.zeros((), device=self.device)
         losses = {'loss': (local_sum / num_tasks).detach()}
         if training_phase:

@@ -335,6 +335,31 @@ def test_concurrent_tasks_keep_rule_state_per_task(optimizer, metasgd):
     assert np.isfinite(losses['loss'].item()) and all(torch.isfinite(p).all() for p in preds)
 
 
+@pytest.mark.parametrize("name", ['sepconv_msl_learnable_2step', 'voxelflow_lslr_sgd_2step', 'superslomo_lslr_sgd_2step'])
+def test_graph_replays_on_two_task_streams_match_reference_fixture(name):
+    """--graph_inner_loop 1 --task_streams 2: one graph set per stream, replayed from two threads; outer gradients merged."""
+    g = golden("system_" + name)
+    model = str(g['model'])
+    system = build_system(model, dict(parse_case_args(g), graph_inner_loop=1, task_streams=2))
+    rec_outer = {}
+    system.optimizer.step = lambda *a, **k: rec_outer.update(
+        {n: helpers_fp(p.grad) for n, p in system.named_parameters() if p.requires_grad and p.grad is not None})
+    frames = synthetic.septuplet_batch(int(g['B']), int(g['H']), int(g['W']), model=model)
+    losses, preds, metrics = system.run_train_iter(data_batch=frames, epoch=0, do_evaluation=True)
+    torch.cuda.synchronize()
+    tol = TOL[name]
+    want_loss = float(g['train_loss'])
+    assert abs(losses['loss'].item() - want_loss) <= tol['loss'] * abs(want_loss)
+    got = torch.stack([p.squeeze(0) for p in preds]).cpu().numpy()
+    assert np.abs(got - g['train_preds']).mean() < tol['l1']
+    assert abs(metrics['psnr'].avg - float(g['train_psnr'])) < tol['psnr']
+    rows = dict(zip(list(g['outer_grad_fp_0_keys']), g['outer_grad_fp_0']))
+    for k, row in rows.items():
+        if abs(row[1]) > 0:
+            assert k in rec_outer, k
+            assert_fp_close(rec_outer[k], row, tol['outer'], (name, 'outer', k))
+
+
 # ---------------------------------------------------------------------------------------------
 # hipGraph-captured inner loop (--graph_inner_loop 1): same results as the eager loop and the fixtures
 # ---------------------------------------------------------------------------------------------
