@@ -195,7 +195,8 @@ def main():
     # (test_graph_replays_on_two_task_streams_match_reference_fixture).
     fast = None
     from meta_interpolation_amd import graph_inner_loop as _gil
-    if opt.fast_path and not opt.graph_inner_loop and opt.task_streams <= 1:
+    # single-process runs only: a rank that failed inside this optional block would leave the others waiting in a collective
+    if opt.fast_path and world == 1 and not opt.graph_inner_loop and opt.task_streams <= 1:
         saved = (system.args.graph_inner_loop, system.args.task_streams)
         system.args.graph_inner_loop, system.args.task_streams = 1, 2
         try:
@@ -219,6 +220,8 @@ def main():
                         "mode": "--graph-inner-loop 1 --task-streams 2",
                         "note": "same workload and step count, measured after the main region; first-order inner loop replayed from "
                                 "hipGraphs on two task streams, outer gradients assembled by hand"}
+        except Exception as e:       # optional figure: never lose the main line over it
+            fast = {"error": "%s: %s" % (type(e).__name__, str(e)[:200]), "mode": "--graph-inner-loop 1 --task-streams 2"}
         finally:
             system.args.graph_inner_loop, system.args.task_streams = saved
     if fast is not None:
