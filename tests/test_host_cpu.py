@@ -199,3 +199,27 @@ def test_weight_gradient_overlap_is_off_without_a_gpu_and_counts_weight_uses():
     assert hip_ops._weight_use_counter(w)[0] == 1 and hip_ops._weight_use_counter(w)[0] == 2
     hip_ops.set_weight_gradient_overlap(False)           # a new pass starts counting again
     assert hip_ops._weight_use_counter(w)[0] == 1
+
+
+def test_outer_gradient_accumulators_merge_and_install():
+    """graph_inner_loop.OuterGradAccumulator: per-stream accumulators of the graphed two-stream mode sum into one and are
+    installed as the mean over the global meta-batch."""
+    import types
+    from meta_interpolation_amd.graph_inner_loop import OuterGradAccumulator
+    theta = {'a': torch.nn.Parameter(torch.zeros(3)), 'b': torch.nn.Parameter(torch.zeros(2))}
+    rates = torch.nn.ParameterDict({'a': torch.nn.Parameter(torch.zeros(3)), 'b': torch.nn.Parameter(torch.zeros(3))})
+    sysm = types.SimpleNamespace(inner_loop_optimizer=types.SimpleNamespace(names_learning_rates_dict=rates))
+    one, two = OuterGradAccumulator(sysm, theta), OuterGradAccumulator(sysm, theta)
+    one.add_params(['a', 'b'], [torch.ones(3), torch.full((2,), 2.0)])
+    one.add_params(['a'], [torch.ones(3)])                                   # second task on the same stream
+    two.add_params(['a'], [torch.full((3,), 4.0)])                            # a task on the other stream ('b' unused there)
+    one.lr_rows, one.lr_keys = torch.tensor([[1.0, 2.0], [3.0, 4.0], [0.0, 0.0]]), ['a', 'b']
+    two.lr_rows, two.lr_keys = torch.tensor([[1.0, 1.0], [1.0, 1.0], [0.0, 0.0]]), ['a', 'b']
+    one.merge(two)
+    one.install(num_tasks=4)
+    assert torch.equal(theta['a'].grad, torch.full((3,), 6.0 / 4)) and torch.equal(theta['b'].grad, torch.full((2,), 2.0 / 4))
+    assert torch.equal(rates['a'].grad, torch.tensor([2.0, 4.0, 0.0]) / 4)    # column of tensor 'a': one value per inner step
+    assert torch.equal(rates['b'].grad, torch.tensor([3.0, 5.0, 0.0]) / 4)
+    empty = OuterGradAccumulator(sysm, theta)
+    empty.merge(two)                                                         # merging into an accumulator that saw no task
+    assert torch.equal(empty.param['a'], two.param['a']) and empty.param['a'] is not two.param['a']
