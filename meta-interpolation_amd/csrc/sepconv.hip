@@ -7,145 +7,19 @@
 //
 // Layout: fp32 NCHW, contiguous.  in [B,C,Ho+K-1,Wo+K-1], v/h [B,K,Ho,Wo], out/gO [B,C,Ho,Wo].
 //
-// Design (K = 51 fast path): one workgroup = 256 threads = an 8x32 output tile.  The
-// (8+50)x(32+50) input halo of a channel is staged once in LDS with coalesced row reads
-// and is then shared by the 256 pixels; each thread keeps its pixel's 51 horizontal taps
-// in VGPRs and streams the vertical taps (coalesced along x: v/h planes are Ho*Wo apart,
-// so a wave reads 51 x 256-byte segments per operand).  The product is factored
-//   out = sum_fy v[fy] * (sum_fx in[y+fy][x+fx] * h[fx])            (K*K + K FMA / channel)
-// and the backward shares one pass over the tile for both filter gradients:
-//   P[fy][fx] = sum_c gO[c] * in[c][y+fy][x+fx]
-//   gV[fy] = sum_fx P[fy][fx]*h[fx]     gH[fx] = sum_fy P[fy][fx]*v[fy]   (5*K*K FMA for C=3)
-// Any other K (or C != 3 in the backward) takes the generic direct kernels below.
+// K = 51, C = 3 (the only shape the model uses): sepconv_fwd_mfma / sepconv_bwd_mfma below -- the horizontal pass as a
+// banded GEMM on the exact-fp32 matrix cores, the input window of R rows x 64 columns (+50 halo) staged once in LDS,
+// wave-private tap rows, no workgroup barrier in the row loop.  Every other (K, C) takes the generic direct kernels at the
+// end of the file (one thread per output element; cold path, kept for the op's full surface).
+// The earlier VALU generations (one / two pixels per thread, LDS-bandwidth bound: 163 / 114 us forward at 384x512 against
+// 52 us here) were removed in round 2; DESIGN.md section 4 keeps their numbers.
 #include "common.h"
 #include <stdlib.h>
 
 namespace {
 
 constexpr int KFAST = 51;
-constexpr int TY = 8, TX = 32, NT = TY * TX;
 
-// ------------------------------------------------------------------------------------------
-// forward, K = 51
-// ------------------------------------------------------------------------------------------
-template <int K>
-__global__ __launch_bounds__(NT) void sepconv_fwd_tiled(const float* __restrict__ in,
-                                                        const float* __restrict__ v,
-                                                        const float* __restrict__ h,
-                                                        float* __restrict__ out, int C, int Ho, int Wo) {
-  constexpr int LH = TY + K - 1, LW = TX + K - 1;
-  __shared__ float tile[LH * LW];
-  const int tid = threadIdx.x, tx = tid % TX, ty = tid / TX;
-  const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY, b = blockIdx.z;
-  const int x = x0 + tx, y = y0 + ty;
-  const bool valid = (x < Wo) && (y < Ho);
-  const int Hi = Ho + K - 1, Wi = Wo + K - 1;
-  const size_t plane = (size_t)Ho * Wo;
-  const size_t pix = (size_t)b * K * plane + (size_t)(valid ? y : 0) * Wo + (valid ? x : 0);
-
-  float hr[K];
-#pragma unroll
-  for (int f = 0; f < K; ++f) hr[f] = valid ? h[pix + f * plane] : 0.f;
-
-  for (int c = 0; c < C; ++c) {
-    const float* src = in + ((size_t)b * C + c) * Hi * Wi;
-    __syncthreads();
-    for (int i = tid; i < LH * LW; i += NT) {
-      const int r = i / LW, q = i - r * LW;
-      const int gy = y0 + r, gx = x0 + q;
-      tile[i] = (gy < Hi && gx < Wi) ? src[(size_t)gy * Wi + gx] : 0.f;
-    }
-    __syncthreads();
-    float acc = 0.f;
-    for (int fy = 0; fy < K; ++fy) {
-      const float vv = valid ? v[pix + fy * plane] : 0.f;
-      const float* row = &tile[(ty + fy) * LW + tx];
-      float t = 0.f;
-#pragma unroll
-      for (int fx = 0; fx < K; ++fx) t = fmaf(row[fx], hr[fx], t);
-      acc = fmaf(vv, t, acc);
-    }
-    if (valid) out[((size_t)b * C + c) * plane + (size_t)y * Wo + x] = acc;
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// backward (gV, gH), K = 51, C = 3
-// ------------------------------------------------------------------------------------------
-template <int K, bool WANT_V, bool WANT_H>
-__global__ __launch_bounds__(NT) void sepconv_bwd_filters_tiled(const float* __restrict__ in,
-                                                                const float* __restrict__ v,
-                                                                const float* __restrict__ h,
-                                                                const float* __restrict__ gO,
-                                                                float* __restrict__ gV,
-                                                                float* __restrict__ gH, int Ho, int Wo) {
-  constexpr int C = 3;
-  constexpr int LH = TY + K - 1, LW = TX + K - 1, LP = LH * LW;
-  extern __shared__ __attribute__((aligned(16))) float tile[];  // C * LP floats
-  const int tid = threadIdx.x, tx = tid % TX, ty = tid / TX;
-  const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY, b = blockIdx.z;
-  const int x = x0 + tx, y = y0 + ty;
-  const bool valid = (x < Wo) && (y < Ho);
-  const int Hi = Ho + K - 1, Wi = Wo + K - 1;
-  const size_t plane = (size_t)Ho * Wo;
-  const size_t opix = (size_t)(valid ? y : 0) * Wo + (valid ? x : 0);
-  const size_t pix = (size_t)b * K * plane + opix;
-
-  for (int c = 0; c < C; ++c) {
-    const float* src = in + ((size_t)b * C + c) * Hi * Wi;
-    for (int i = tid; i < LP; i += NT) {
-      const int r = i / LW, q = i - r * LW;
-      const int gy = y0 + r, gx = x0 + q;
-      tile[c * LP + i] = (gy < Hi && gx < Wi) ? src[(size_t)gy * Wi + gx] : 0.f;
-    }
-  }
-  float hr[K], gh[K];
-#pragma unroll
-  for (int f = 0; f < K; ++f) {
-    hr[f] = (WANT_V && valid) ? h[pix + f * plane] : 0.f;
-    gh[f] = 0.f;
-  }
-  float go[C];
-#pragma unroll
-  for (int c = 0; c < C; ++c) go[c] = valid ? gO[((size_t)b * C + c) * plane + opix] : 0.f;
-  __syncthreads();
-
-  for (int fy = 0; fy < K; ++fy) {
-    const float vv = (WANT_H && valid) ? v[pix + fy * plane] : 0.f;
-    const float* r0 = &tile[(ty + fy) * LW + tx];
-    float gv = 0.f;
-#pragma unroll
-    for (int fx = 0; fx < K; ++fx) {
-      float p = go[0] * r0[fx];
-      p = fmaf(go[1], r0[LP + fx], p);
-      p = fmaf(go[2], r0[2 * LP + fx], p);
-      if (WANT_V) gv = fmaf(p, hr[fx], gv);
-      if (WANT_H) gh[fx] = fmaf(p, vv, gh[fx]);
-    }
-    if (WANT_V && valid) gV[pix + fy * plane] = gv;
-  }
-  if (WANT_H && valid) {
-#pragma unroll
-    for (int f = 0; f < K; ++f) gH[pix + f * plane] = gh[f];
-  }
-}
-
-
-// ------------------------------------------------------------------------------------------
-// K = 51 fast path, second generation: TWO horizontally adjacent pixels per thread.
-//
-// v1 (one pixel per thread, one ds_read_b32 per FMA) is LDS-bound: a CU moves 128 B/clk with
-// ds_read_b32 against 128 FMA lanes/clk, i.e. 1 float per FMA where the FMA pipe wants 4.
-// Here thread (ty, l) owns pixels x = x0+2l and x0+2l+1 of row y0+ty.  One 8-byte-aligned
-// ds_read_b64 returns (a, b) = in[2l+2k], in[2l+2k+1]; both feed BOTH pixels
-//     pixel0: a*h0[2k] + b*h0[2k+1]        pixel1: a*h1[2k-1] + b*h1[2k]
-// so the forward does 4 FMA and the backward 20 FMA per 8 bytes of LDS traffic (ds_read_b64 runs
-// at 256 B/clk/CU): the loop is FMA-issue bound.  A 32-lane ds_read_b64 group is two tile rows of
-// 16 lanes x 8 B; with the row pitch LW = 96 floats (= 32 banks mod 64) the two rows land on
-// disjoint bank halves, so the reads are conflict-free.  Tile = 16 rows x 32 columns per 256
-// threads; v / h / out / gV / gH move as float2 per lane (128-byte runs per 16-lane row segment).
-// ------------------------------------------------------------------------------------------
-constexpr int T2Y = 16, T2X = 32, T2LW = 96;
 
 // Stage an LH x SPAN window of a [Hi, Wi] plane (top-left at (y0, x0)) into LDS rows of pitch LW.
 // All global loads of a thread are issued back to back (no branch, no wait between them) and the
@@ -167,156 +41,6 @@ __device__ __forceinline__ void stage_window(float* __restrict__ tile, const flo
     const int i = tid + it * NTHREADS;
     const int r = i / SPAN, q = i - r * SPAN;
     if (i < TOTAL) tile[r * LW + q] = buf[it];
-  }
-}
-
-
-template <int K>
-__global__ __launch_bounds__(NT) void sepconv_fwd_x2(const float* __restrict__ in, const float* __restrict__ v,
-                                                     const float* __restrict__ h, float* __restrict__ out,
-                                                     int C, int Ho, int Wo) {
-  static_assert(K % 2 == 1 && T2X + K - 1 <= T2LW, "tile geometry");
-  constexpr int LH = T2Y + K - 1, LW = T2LW, NK = (K + 1) / 2, SPAN = T2X + K - 1, U = 3;
-  static_assert(K % U == 0, "tap loop is grouped by U");
-  __shared__ __attribute__((aligned(16))) float tile[LH * LW];
-  const int tid = threadIdx.x, l = tid & 15, ty = tid >> 4;
-  const int x0 = blockIdx.x * T2X, y0 = blockIdx.y * T2Y, b = blockIdx.z;
-  const int x = x0 + 2 * l, y = y0 + ty;
-  const bool valid = (x < Wo) && (y < Ho);   // Wo is even: x and x+1 are valid together
-  const int Hi = Ho + K - 1, Wi = Wo + K - 1;
-  const size_t plane = (size_t)Ho * Wo;
-  const size_t pix = (size_t)b * K * plane + (size_t)(valid ? y : 0) * Wo + (valid ? x : 0);
-
-  float h0[K], h1[K];
-#pragma unroll
-  for (int f = 0; f < K; ++f) {
-    const float2 t = *reinterpret_cast<const float2*>(h + pix + f * plane);
-    h0[f] = t.x; h1[f] = t.y;
-  }
-
-  for (int c = 0; c < C; ++c) {
-    const float* src = in + ((size_t)b * C + c) * Hi * Wi;
-    __syncthreads();
-    stage_window<LH, SPAN, LW, NT>(tile, src, y0, x0, Hi, Wi, tid);
-    __syncthreads();
-    float acc0 = 0.f, acc1 = 0.f;
-    // The vertical taps are the only global loads inside the tap loop; a dependent HBM load per fy makes
-    // the loop latency-bound (~1 us per iteration).  They are fetched one group of U rows ahead.
-    float2 vc[U], vn[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) vc[u] = *reinterpret_cast<const float2*>(v + pix + u * plane);
-    for (int g = 0; g < K / U; ++g) {
-      const int gn = min(g + 1, K / U - 1);   // the last group re-reads itself (keeps the load unconditional)
-#pragma unroll
-      for (int u = 0; u < U; ++u) vn[u] = *reinterpret_cast<const float2*>(v + pix + (gn * U + u) * plane);
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const float2* row = reinterpret_cast<const float2*>(&tile[(ty + g * U + u) * LW + 2 * l]);
-        float t0 = 0.f, t1 = 0.f;
-#pragma unroll
-        for (int k = 0; k < NK; ++k) {
-          const float2 ab = row[k];
-          t0 = fmaf(ab.x, h0[2 * k], t0);
-          if (2 * k + 1 < K) t0 = fmaf(ab.y, h0[2 * k + 1], t0);
-          if (k >= 1) t1 = fmaf(ab.x, h1[2 * k - 1], t1);
-          t1 = fmaf(ab.y, h1[2 * k], t1);
-        }
-        acc0 = fmaf(vc[u].x, t0, acc0);
-        acc1 = fmaf(vc[u].y, t1, acc1);
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) vc[u] = vn[u];
-    }
-    if (valid)
-      *reinterpret_cast<float2*>(out + ((size_t)b * C + c) * plane + (size_t)y * Wo + x) = make_float2(acc0, acc1);
-  }
-}
-
-template <int K, bool WANT_V, bool WANT_H>
-__global__ __launch_bounds__(NT) void sepconv_bwd_filters_x2(const float* __restrict__ in,
-                                                             const float* __restrict__ v,
-                                                             const float* __restrict__ h,
-                                                             const float* __restrict__ gO,
-                                                             float* __restrict__ gV, float* __restrict__ gH,
-                                                             int Ho, int Wo) {
-  constexpr int C = 3;
-  constexpr int LH = T2Y + K - 1, LW = T2LW, LP = LH * LW, NK = (K + 1) / 2, SPAN = T2X + K - 1;
-  extern __shared__ __attribute__((aligned(16))) float tile[];  // C * LP floats
-  const int tid = threadIdx.x, l = tid & 15, ty = tid >> 4;
-  const int x0 = blockIdx.x * T2X, y0 = blockIdx.y * T2Y, b = blockIdx.z;
-  const int x = x0 + 2 * l, y = y0 + ty;
-  const bool valid = (x < Wo) && (y < Ho);
-  const int Hi = Ho + K - 1, Wi = Wo + K - 1;
-  const size_t plane = (size_t)Ho * Wo;
-  const size_t opix = (size_t)(valid ? y : 0) * Wo + (valid ? x : 0);
-  const size_t pix = (size_t)b * K * plane + opix;
-
-  for (int c = 0; c < C; ++c) {
-    const float* src = in + ((size_t)b * C + c) * Hi * Wi;
-    stage_window<LH, SPAN, LW, NT>(tile + c * LP, src, y0, x0, Hi, Wi, tid);
-  }
-  float h0[K], h1[K], gh0[K], gh1[K];
-#pragma unroll
-  for (int f = 0; f < K; ++f) {
-    const float2 t = WANT_V ? *reinterpret_cast<const float2*>(h + pix + f * plane) : make_float2(0.f, 0.f);
-    h0[f] = t.x; h1[f] = t.y;
-    gh0[f] = 0.f; gh1[f] = 0.f;
-  }
-  float g0[C], g1[C];
-#pragma unroll
-  for (int c = 0; c < C; ++c) {
-    const float2 t = *reinterpret_cast<const float2*>(gO + ((size_t)b * C + c) * plane + opix);
-    g0[c] = t.x; g1[c] = t.y;
-  }
-  __syncthreads();
-
-  // v is fetched one group of U rows ahead of use (see the forward kernel).  U = 1 here: one row of this
-  // kernel is ~510 FMA per lane (>1000 cycles), enough to cover an HBM load, and unrolling more rows lets
-  // the scheduler interleave their 78 ds_read_b64 each and spill.
-  constexpr int U = 1;
-  static_assert(K % U == 0, "tap loop is grouped by U");
-  float2 vc[U], vn[U];
-#pragma unroll
-  for (int u = 0; u < U; ++u)
-    vc[u] = WANT_H ? *reinterpret_cast<const float2*>(v + pix + u * plane) : make_float2(0.f, 0.f);
-  for (int g = 0; g < K / U; ++g) {
-    const int gn = min(g + 1, K / U - 1);
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-      vn[u] = WANT_H ? *reinterpret_cast<const float2*>(v + pix + (gn * U + u) * plane) : make_float2(0.f, 0.f);
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int fy = g * U + u;
-      const float2 vv = vc[u];
-      const float2* r0 = reinterpret_cast<const float2*>(&tile[(ty + fy) * LW + 2 * l]);
-      float gv0a = 0.f, gv0b = 0.f, gv1a = 0.f, gv1b = 0.f;
-#pragma unroll
-      for (int k = 0; k < NK; ++k) {
-        const float2 c0 = r0[k], c1 = r0[k + LP / 2], c2 = r0[k + LP];
-        // P for pixel 0 / pixel 1 at columns (2l+2k) [a] and (2l+2k+1) [b]
-        const float pa0 = fmaf(g0[2], c2.x, fmaf(g0[1], c1.x, g0[0] * c0.x));
-        const float pb1 = fmaf(g1[2], c2.y, fmaf(g1[1], c1.y, g1[0] * c0.y));
-        if (WANT_V) { gv0a = fmaf(pa0, h0[2 * k], gv0a); gv1b = fmaf(pb1, h1[2 * k], gv1b); }
-        if (WANT_H) { gh0[2 * k] = fmaf(pa0, vv.x, gh0[2 * k]); gh1[2 * k] = fmaf(pb1, vv.y, gh1[2 * k]); }
-        if (2 * k + 1 < K) {
-          const float pb0 = fmaf(g0[2], c2.y, fmaf(g0[1], c1.y, g0[0] * c0.y));
-          if (WANT_V) gv0b = fmaf(pb0, h0[2 * k + 1], gv0b);
-          if (WANT_H) gh0[2 * k + 1] = fmaf(pb0, vv.x, gh0[2 * k + 1]);
-        }
-        if (k >= 1) {
-          const float pa1 = fmaf(g1[2], c2.x, fmaf(g1[1], c1.x, g1[0] * c0.x));
-          if (WANT_V) gv1a = fmaf(pa1, h1[2 * k - 1], gv1a);
-          if (WANT_H) gh1[2 * k - 1] = fmaf(pa1, vv.y, gh1[2 * k - 1]);
-        }
-      }
-      if (WANT_V && valid) *reinterpret_cast<float2*>(gV + pix + fy * plane) = make_float2(gv0a + gv0b, gv1a + gv1b);
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) vc[u] = vn[u];
-  }
-  if (WANT_H && valid) {
-#pragma unroll
-    for (int f = 0; f < K; ++f) *reinterpret_cast<float2*>(gH + pix + f * plane) = make_float2(gh0[f], gh1[f]);
   }
 }
 
@@ -775,15 +499,34 @@ __global__ void sepconv_bwd_input_direct(const float* __restrict__ v, const floa
   gI[(size_t)bc * Hi * Wi + (size_t)Y * Wi + X] = acc;
 }
 
-// The x2 kernels move float2 per lane: even width and 8-byte aligned planes.
-bool x2_ok(int Wo, const void* a, const void* b, const void* c, const void* d) {
-  return (Wo % 2 == 0) && ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d) & 7u) == 0);
+// Experiment switches, read ONCE per process (not per launch): SAVFI_SEPCONV_NO_MFMA forces the direct kernels,
+// SAVFI_SEPCONV_MFMA_ROWS = 8 | 12 | 16 pins the rows per workgroup.
+struct SepconvEnv {
+  bool no_mfma;
+  int rows;
+  SepconvEnv() : no_mfma(getenv("SAVFI_SEPCONV_NO_MFMA") != nullptr), rows(0) {
+    if (const char* e = getenv("SAVFI_SEPCONV_MFMA_ROWS")) {
+      const int r = atoi(e);
+      if (r == 8 || r == 12 || r == 16) rows = r;
+    }
+  }
+};
+const SepconvEnv& sepconv_env() {
+  static const SepconvEnv env;
+  return env;
 }
 
-// The MFMA kernels take any width / alignment (dword tap loads, clamped coordinates).
-bool mfma_ok(int Wo, const void* a, const void* b) {
-  (void)a; (void)b;
-  return Wo >= 1;
+// Opt-in to > 64 KB of dynamic LDS is a per-device function attribute: set once per (kernel, device).
+template <typename F>
+int ensure_dynamic_lds(F kernel, size_t bytes, uint32_t& done_mask) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return (int)hipGetLastError();
+  const uint32_t bit = 1u << (dev & 31);
+  if (__atomic_load_n(&done_mask, __ATOMIC_ACQUIRE) & bit) return SAVFI_OK;
+  const hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return (int)e;
+  __atomic_fetch_or(&done_mask, bit, __ATOMIC_RELEASE);
+  return SAVFI_OK;
 }
 
 constexpr size_t mfma_lds_bytes(int rows) {
@@ -802,20 +545,15 @@ int mfma_rows(int B, int Ho, int Wo) {
     const long cost = ((wgs + 255) / 256) * (r + 2);
     if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = r; }
   }
-  if (const char* e = getenv("SAVFI_SEPCONV_MFMA_ROWS")) {
-    const int r = atoi(e);
-    if (r == 8 || r == 12 || r == 16) best = r;
-  }
-  return best;
+  return sepconv_env().rows ? sepconv_env().rows : best;
 }
 
 template <int R>
 int launch_fwd_mfma(const float* in, const float* v, const float* h, float* out, int B, int Ho, int Wo, hipStream_t st) {
   constexpr size_t lds = mfma_lds_bytes(R);
   static_assert(lds <= 160 * 1024, "LDS per CU");
-  static const hipError_t attr = hipFuncSetAttribute((const void*)sepconv_fwd_mfma<KFAST, R>,
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (attr != hipSuccess) return (int)attr;
+  static uint32_t done = 0;
+  if (int e = ensure_dynamic_lds(sepconv_fwd_mfma<KFAST, R>, lds, done)) return e;
   dim3 grid(savfi_cdiv(Wo, MC), savfi_cdiv(Ho, R), B);
   hipLaunchKernelGGL((sepconv_fwd_mfma<KFAST, R>), grid, dim3(MNT), lds, st, in, v, h, out, Ho, Wo);
   return savfi_launch_status();
@@ -825,9 +563,8 @@ template <int R, bool WV, bool WH>
 int launch_bwd_mfma_one(const float* in, const float* v, const float* h, const float* gO, float* gV, float* gH, int B,
                         int Ho, int Wo, hipStream_t st) {
   constexpr size_t lds = mfma_lds_bytes(R);
-  static const hipError_t attr = hipFuncSetAttribute((const void*)sepconv_bwd_mfma<KFAST, R, WV, WH>,
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (attr != hipSuccess) return (int)attr;
+  static uint32_t done = 0;
+  if (int e = ensure_dynamic_lds(sepconv_bwd_mfma<KFAST, R, WV, WH>, lds, done)) return e;
   dim3 grid(savfi_cdiv(Wo, MC), savfi_cdiv(Ho, R), B);
   hipLaunchKernelGGL((sepconv_bwd_mfma<KFAST, R, WV, WH>), grid, dim3(MNT), lds, st, in, v, h, gO, gV, gH, Ho, Wo);
   return savfi_launch_status();
@@ -839,18 +576,6 @@ int launch_bwd_mfma(const float* in, const float* v, const float* h, const float
   if (gV && gH) return launch_bwd_mfma_one<R, true, true>(in, v, h, gO, gV, gH, B, Ho, Wo, st);
   if (gV) return launch_bwd_mfma_one<R, true, false>(in, v, h, gO, gV, gH, B, Ho, Wo, st);
   return launch_bwd_mfma_one<R, false, true>(in, v, h, gO, gV, gH, B, Ho, Wo, st);
-}
-
-hipError_t set_bwd_x2_lds(size_t lds) {
-  hipError_t e = hipFuncSetAttribute((const void*)sepconv_bwd_filters_x2<KFAST, true, true>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e == hipSuccess)
-    e = hipFuncSetAttribute((const void*)sepconv_bwd_filters_x2<KFAST, true, false>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e == hipSuccess)
-    e = hipFuncSetAttribute((const void*)sepconv_bwd_filters_x2<KFAST, false, true>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  return e;
 }
 
 int check_dims(int B, int C, int Ho, int Wo, int K) {
@@ -869,18 +594,12 @@ extern "C" int savfi_sepconv_fwd_f32(const float* in, const float* v, const floa
   if (!in || !v || !h || !out) return SAVFI_E_NULL;
   if (int e = check_dims(B, C, Ho, Wo, K)) return e;
   hipStream_t st = (hipStream_t)stream;
-  if (K == KFAST && C == 3 && mfma_ok(Wo, v, h) && !getenv("SAVFI_SEPCONV_NO_MFMA")) {
+  if (K == KFAST && C == 3 && !sepconv_env().no_mfma) {
     switch (mfma_rows(B, Ho, Wo)) {
       case 8: return launch_fwd_mfma<8>(in, v, h, out, B, Ho, Wo, st);
       case 16: return launch_fwd_mfma<16>(in, v, h, out, B, Ho, Wo, st);
       default: return launch_fwd_mfma<12>(in, v, h, out, B, Ho, Wo, st);
     }
-  } else if (K == KFAST && x2_ok(Wo, in, v, h, out)) {
-    dim3 grid(savfi_cdiv(Wo, T2X), savfi_cdiv(Ho, T2Y), B);
-    hipLaunchKernelGGL(sepconv_fwd_x2<KFAST>, grid, dim3(NT), 0, st, in, v, h, out, C, Ho, Wo);
-  } else if (K == KFAST) {
-    dim3 grid(savfi_cdiv(Wo, TX), savfi_cdiv(Ho, TY), B);
-    hipLaunchKernelGGL(sepconv_fwd_tiled<KFAST>, grid, dim3(NT), 0, st, in, v, h, out, C, Ho, Wo);
   } else {
     dim3 grid(savfi_cdiv(Wo, 64), Ho, B * C);
     hipLaunchKernelGGL(sepconv_fwd_direct, grid, dim3(64), 0, st, in, v, h, out, C, Ho, Wo, K);
@@ -895,7 +614,7 @@ extern "C" int savfi_sepconv_bwd_f32(const float* in, const float* v, const floa
   if (int e = check_dims(B, C, Ho, Wo, K)) return e;
   hipStream_t st = (hipStream_t)stream;
   if (gV || gH) {
-    if (K == KFAST && C == 3 && mfma_ok(Wo, v, h) && !getenv("SAVFI_SEPCONV_NO_MFMA")) {
+    if (K == KFAST && C == 3 && !sepconv_env().no_mfma) {
       int e;
       switch (mfma_rows(B, Ho, Wo)) {
         case 8: e = launch_bwd_mfma<8>(in, v, h, gO, gV, gH, B, Ho, Wo, st); break;
@@ -903,32 +622,6 @@ extern "C" int savfi_sepconv_bwd_f32(const float* in, const float* v, const floa
         default: e = launch_bwd_mfma<12>(in, v, h, gO, gV, gH, B, Ho, Wo, st); break;
       }
       if (e) return e;
-    } else if (K == KFAST && C == 3 && x2_ok(Wo, gO, v, h, gV ? gV : gH) && x2_ok(Wo, gO, v, h, gH ? gH : gV)) {
-      constexpr size_t lds = (size_t)3 * (T2Y + KFAST - 1) * T2LW * sizeof(float);  // 76032 B: 2 workgroups / CU
-      static const hipError_t attr = set_bwd_x2_lds(lds);
-      if (attr != hipSuccess) return (int)attr;
-      dim3 grid(savfi_cdiv(Wo, T2X), savfi_cdiv(Ho, T2Y), B);
-      if (gV && gH)
-        hipLaunchKernelGGL((sepconv_bwd_filters_x2<KFAST, true, true>), grid, dim3(NT), lds, st, in, v, h, gO, gV, gH, Ho, Wo);
-      else if (gV)
-        hipLaunchKernelGGL((sepconv_bwd_filters_x2<KFAST, true, false>), grid, dim3(NT), lds, st, in, v, h, gO, gV, gH, Ho, Wo);
-      else
-        hipLaunchKernelGGL((sepconv_bwd_filters_x2<KFAST, false, true>), grid, dim3(NT), lds, st, in, v, h, gO, gV, gH, Ho, Wo);
-      if (int e = savfi_launch_status()) return e;
-    } else if (K == KFAST && C == 3) {
-      constexpr int LP = (TY + KFAST - 1) * (TX + KFAST - 1);
-      const size_t lds = (size_t)3 * LP * sizeof(float);
-      dim3 grid(savfi_cdiv(Wo, TX), savfi_cdiv(Ho, TY), B);
-      if (gV && gH)
-        hipLaunchKernelGGL((sepconv_bwd_filters_tiled<KFAST, true, true>), grid, dim3(NT), lds, st, in, v, h,
-                           gO, gV, gH, Ho, Wo);
-      else if (gV)
-        hipLaunchKernelGGL((sepconv_bwd_filters_tiled<KFAST, true, false>), grid, dim3(NT), lds, st, in, v, h,
-                           gO, gV, gH, Ho, Wo);
-      else
-        hipLaunchKernelGGL((sepconv_bwd_filters_tiled<KFAST, false, true>), grid, dim3(NT), lds, st, in, v, h,
-                           gO, gV, gH, Ho, Wo);
-      if (int e = savfi_launch_status()) return e;
     } else {
       dim3 grid(savfi_cdiv(Wo, 64), Ho, B * K);
       if (gV) hipLaunchKernelGGL(sepconv_bwd_filter_direct, grid, dim3(64), 0, st, in, h, gO, gV, C, Ho, Wo, K, 0);

@@ -16,7 +16,17 @@ from . import _hip
 # is not itself differentiable switch to composed device ops (losses) or refuse (voxel warp) instead of
 # silently dropping second-order terms.  (The sepconv op does drop them, exactly like the reference:
 # SURVEY.md section 0, fact 9.)
-DOUBLE_BACKWARD = False
+# Per THREAD (tasks may be adapted on concurrent threads; two systems in one process must not flip each other's ops):
+# worker threads get the caller's value through meta_learning_system._run_tasks.
+_PASS = threading.local()
+
+
+def set_double_backward(value):
+    _PASS.double_backward = bool(value)
+
+
+def double_backward():
+    return getattr(_PASS, 'double_backward', False)
 
 
 # --------------------------------------------------------------------------------------------
@@ -395,13 +405,13 @@ class _L1Mse(torch.autograd.Function):
 
 
 def l1_loss(a, b):
-    if DOUBLE_BACKWARD:
+    if double_backward():
         return torch.nn.functional.l1_loss(a, b)
     return _L1Mse.apply(0, a.contiguous(), b.contiguous())
 
 
 def mse_loss(a, b):
-    if DOUBLE_BACKWARD:
+    if double_backward():
         return torch.nn.functional.mse_loss(a, b)
     return _L1Mse.apply(1, a.contiguous(), b.contiguous())
 

@@ -23,6 +23,10 @@ class Loss(nn.modules.loss._Loss):
             self.loss.append({'type': loss_type, 'weight': float(weight), 'function': _KERNELS[loss_type]})
         self.cuda_only = True
 
+    def loss_keys(self):
+        """Keys of the dict forward() returns (rank-independent: the logging all-reduce is laid out from them)."""
+        return [l['type'] for l in self.loss] + ['total']
+
     def forward(self, sr, hr, **kwargs):
         total = 0
         losses = {}

@@ -189,7 +189,11 @@ class SceneAdaptiveInterpolation(nn.Module):
             print('Loading pretrained model: %s' % args.pretrained_model)
             ckpt = torch.load(args.pretrained_model, map_location='cpu', weights_only=False)
             with torch.no_grad():
-                utils.lossy_load_state_dict(self.net, ckpt['state_dict'])
+                if 'state_dictFC' in ckpt:       # Super SloMo's released checkpoints (reference :162-167)
+                    self.net.flowComp.load_state_dict(ckpt['state_dictFC'])
+                    self.net.arbTimeFlowIntrp.load_state_dict(ckpt['state_dictAT'])
+                else:
+                    utils.lossy_load_state_dict(self.net, ckpt['state_dict'])
 
     # -----------------------------------------------------------------------------------------
     # small pieces kept with the reference's names
@@ -385,10 +389,13 @@ class SceneAdaptiveInterpolation(nn.Module):
         streams = self._task_stream_pool[:n]
         cur = torch.cuda.current_stream(dev_index)
         results, errors = {}, []
+        flags = (hip_ops.double_backward(), model_utils.fuse_conv_act())
 
         def worker(i):
             try:
                 torch.cuda.set_device(dev_index)                # new threads start on device 0
+                hip_ops.set_double_backward(flags[0])           # per-thread switches: inherit the caller's
+                model_utils.set_fuse_conv_act(flags[1])
                 with torch.cuda.stream(streams[i]):
                     for t in local[i::n]:
                         results[t] = body(t)
@@ -422,12 +429,8 @@ class SceneAdaptiveInterpolation(nn.Module):
         if graph_inner_loop.supported(self, use_second_order):
             return self._forward_graphed(frames, epoch, use_multi_step_loss_optimization, num_steps, training_phase,
                                          do_evaluation)
-        hip_ops.DOUBLE_BACKWARD = bool(use_second_order)
-        self._first_order = not use_second_order
-        # fused conv epilogues: opt-in, and first-order only
-        model_utils.FUSE_CONV_ACT = bool(getattr(self.args, 'fuse_conv_act', 0)) and not use_second_order
-        tp = self.task_parallel
-        local = tp.local_tasks(num_tasks)
+        self._set_pass_flags(use_second_order)
+        local = self._local_tasks(num_tasks, training_phase)
         msl = bool(use_multi_step_loss_optimization and training_phase
                    and epoch < self.args.multi_step_loss_num_epochs)
 
@@ -457,20 +460,36 @@ class SceneAdaptiveInterpolation(nn.Module):
         losses = {'loss': local_sum / num_tasks}
 
         metrics = {'psnr': utils.AverageMeter(), 'ssim': utils.AverageMeter()}
-        self._logging(losses, metrics, deferred, eval_mse, eval_ssim, importance)
+        self._logging(losses, metrics, deferred, eval_mse, eval_ssim, importance, training_phase)
         return losses, preds, metrics
 
-    def _logging(self, losses, metrics, deferred, eval_mse, eval_ssim, importance):
+    def _set_pass_flags(self, use_second_order):
+        """Per-pass switches of the op layer (thread-local there: task threads inherit them through _run_tasks)."""
+        hip_ops.set_double_backward(bool(use_second_order))
+        self._first_order = not use_second_order
+        # fused conv epilogues: first-order only (their backward is not differentiable)
+        model_utils.set_fuse_conv_act(bool(getattr(self.args, 'fuse_conv_act', 0)) and not use_second_order)
+
+    def _local_tasks(self, num_tasks, training_phase):
+        """Training meta-batches are sharded over the ranks (task t -> rank t mod G).  Validation / test sweeps are NOT:
+        the data provider hands every rank the full batch (data.py) and ExperimentBuilder consumes every prediction, so each
+        rank evaluates all tasks and nothing is reduced -- replicas hold identical weights, hence identical metrics."""
+        if not training_phase:
+            return list(range(num_tasks))
+        return self.task_parallel.local_tasks(num_tasks)
+
+    def _logging(self, losses, metrics, deferred, eval_mse, eval_ssim, importance, training_phase=True):
         """Everything that is logged needs the device to have finished the forward passes.  During training that host sync
         is postponed until the outer backward and the optimizer step are queued (run_train_iter): waiting here would
         drain the queue and the backward would start with the host a whole launch queue behind the GPU."""
-        finish = functools.partial(self._finish_logging, losses, metrics, deferred, eval_mse, eval_ssim, importance)
+        finish = functools.partial(self._finish_logging, losses, metrics, deferred, eval_mse, eval_ssim, importance,
+                                   training_phase)
         if self._defer_logging:
             self._pending_logging = finish
         else:
             finish()
 
-    def _finish_logging(self, losses, metrics, deferred, eval_mse, eval_ssim, importance):
+    def _finish_logging(self, losses, metrics, deferred, eval_mse, eval_ssim, importance, training_phase=True):
         """ONE host sync; fills `losses` and `metrics` in place."""
         meters = deferred.flush()
         if eval_mse:
@@ -479,7 +498,7 @@ class SceneAdaptiveInterpolation(nn.Module):
             for m, s in zip(mse, ssims):
                 metrics['psnr'].update(-10 * np.log10(m + 1e-8).item())
                 metrics['ssim'].update(s)
-        if self.task_parallel.active:
+        if self.task_parallel.active and training_phase:
             self._reduce_logging(losses, meters, metrics)
         for key, meter in meters.items():
             losses[key] = meter.avg
@@ -495,10 +514,9 @@ class SceneAdaptiveInterpolation(nn.Module):
         tp = self.task_parallel
         msl = bool(use_multi_step_loss_optimization and training_phase
                    and epoch < self.args.multi_step_loss_num_epochs)
-        hip_ops.DOUBLE_BACKWARD = False
-        model_utils.FUSE_CONV_ACT = bool(getattr(self.args, 'fuse_conv_act', 0))
+        self._set_pass_flags(False)
         key = (tuple(frames[0].shape[1:]), num_steps, bool(training_phase), msl)
-        local = tp.local_tasks(num_tasks)
+        local = self._local_tasks(num_tasks, training_phase)
         # --task_streams N: N graph sets (own static buffers and memory pool each), replayed from N threads on N streams
         n = max(1, min(int(getattr(self.args, 'task_streams', 1) or 1), len(local)))
         loops = []
@@ -554,12 +572,18 @@ class SceneAdaptiveInterpolation(nn.Module):
             accum.num_tasks = num_tasks
             self._manual_grads = accum
         metrics = {'psnr': utils.AverageMeter(), 'ssim': utils.AverageMeter()}
-        self._logging(losses, metrics, deferred, eval_mse, eval_ssim, importance)
+        self._logging(losses, metrics, deferred, eval_mse, eval_ssim, importance, training_phase)
         return losses, preds, metrics
 
     def _reduce_logging(self, losses, meters, metrics):
         """Average logging scalars over ranks (second, tiny all-reduce; the loss used for backward stays local)."""
-        keys = sorted(meters)
+        # fixed key set: a rank whose shard is empty (meta-batch smaller than the world) has no meters of its own
+        if hasattr(self.criterion, 'loss_keys'):
+            keys = sorted(set(self.criterion.loss_keys()) | set(meters))
+        else:                                   # a user criterion: agree on the union of the ranks' keys first
+            keys = self.task_parallel.union_of_keys(sorted(meters))
+        for k in keys:
+            meters.setdefault(k, utils.AverageMeter())
         vec = [float(losses['loss'].detach())]
         for k in keys:
             vec += [float(meters[k].sum), float(meters[k].count)]
@@ -638,10 +662,13 @@ class SceneAdaptiveInterpolation(nn.Module):
         self.support_idxs = [[0, 1, 2], [1, 2, 3]]
         preds = [[] for _ in range(len(frames[0]))]
         self.net.zero_grad()
+        # test-time adaptation never back-propagates through the inner loop: first-order passes whatever --second_order says
+        # (the reference passes create_graph=args.second_order here, :664, and then discards the graph)
+        self._set_pass_flags(False)
         try:
             for task_id in range(len(frames[0])):
                 steps = self.args.number_of_evaluation_steps_per_iter
-                weights = self._adapt(frames, task_id, steps, self.args.second_order)
+                weights = self._adapt(frames, task_id, steps, False)
                 with torch.no_grad():
                     out = self.net.forward(frames[1][task_id].unsqueeze(0), frames[2][task_id].unsqueeze(0),
                                            params=weights, backup_running_statistics=False,

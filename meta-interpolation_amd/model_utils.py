@@ -133,13 +133,21 @@ class PixelShuffle(nn.Module):
 # sum one pass over the cotangent (76.9 -> 82.4 inner steps/s on SepConv 256x448, eager).  The fused backward is
 # first-order only (off under --second_order).  Round-1 note: this was slower at first (58.7 vs 62.3) because a
 # custom Function cannot tell that autograd.grad() does not need its weight gradient - see OWN_PARAMS_CONST.
-FUSE_CONV_ACT = False
+# (per thread, like OWN_PARAMS_CONST below: set_fuse_conv_act / fuse_conv_act)
 # True while a first-order support pass runs: layers that use their OWN parameters (not the fast-weight dict) treat
 # them as constants.  The inner gradient is taken w.r.t. the fast weights only and its graph is dropped, so nothing
 # changes - but custom autograd Functions cannot see which of their inputs a particular autograd.grad() call
 # needs (ctx.needs_input_grad only says requires_grad) and would compute unused weight gradients.
 # Per THREAD: tasks may be adapted concurrently, one Python thread and HIP stream each (meta_learning_system.py).
 _TLS = threading.local()
+
+
+def fuse_conv_act():
+    return getattr(_TLS, 'fuse_conv_act', False)
+
+
+def set_fuse_conv_act(value):
+    _TLS.fuse_conv_act = bool(value)
 
 
 def own_params_const():
@@ -183,7 +191,7 @@ class MetaConv2dLayer(nn.Module):
             weight, bias = self.weight.detach(), (self.bias.detach() if self.bias is not None else None)
         else:
             weight, bias = self.weight, self.bias
-        if bias is not None and x.is_cuda and FUSE_CONV_ACT:
+        if bias is not None and x.is_cuda and fuse_conv_act():
             if act_slope is not None:
                 return hip_ops.conv_bias_act(x, weight, bias, self.stride, padding, self.dilation_rate, self.groups,
                                              act_slope)

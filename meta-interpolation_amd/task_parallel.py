@@ -22,8 +22,14 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and "HIP_VISIBLE_DEVICES" not in os.environ and "CUDA_VISIBLE_DEVICES" not in os.environ \
+            and not torch.cuda.is_initialized() and os.environ.get("SAVFI_PIN_DEVICE", "1") != "0":
+        # one process owns ONE device: pin before the HIP runtime comes up, so that no library handle, stream
+        # or stray context ever lands on a neighbour's GPU.  RCCL still reaches the peers over xGMI (dmabuf IPC).
+        os.environ["HIP_VISIBLE_DEVICES"] = str(local_rank)
     if torch.cuda.is_available():
-        torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
+        pinned = os.environ.get("HIP_VISIBLE_DEVICES", "").strip() == str(local_rank) and torch.cuda.device_count() == 1
+        torch.cuda.set_device(0 if pinned else local_rank % max(torch.cuda.device_count(), 1))
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -48,6 +54,7 @@ class TaskParallel:
         else:
             self.rank, self.world = 0, 1
         self._bucket = None
+        self._presence = {}     # local have-pattern -> reduced presence (see allreduce_gradients)
 
     @property
     def active(self):
@@ -85,9 +92,18 @@ class TaskParallel:
             if not h:
                 v.zero_()
         dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group)
-        # the presence flags only matter for parameters without a local gradient (no host sync otherwise)
-        keep_all = [True] * len(params) if all(have) else (flags.cpu() > 0).tolist()
-        back = [(p.grad, v.view_as(p.grad)) for p, v, h, keep in zip(params, views, have, keep_all) if keep and h]
+        # A parameter ends with a gradient iff some rank produced one (a None gradient makes the optimizer skip it: no weight
+        # decay, no moment update -- zeros would not be the same thing).  Which parameters receive gradients is a property
+        # of the configuration, not of the iteration (every non-empty shard produces the same set), so the reduced presence
+        # flags are fetched ONCE per local pattern and not in steady state: no host sync on the hot path.
+        if all(have):
+            keep_all = have
+        else:
+            key = tuple(have)
+            keep_all = self._presence.get(key)
+            if keep_all is None:
+                keep_all = self._presence[key] = (flags.cpu() > 0).tolist()
+        back = [(p.grad, v.view_as(p.grad)) for p, v, h in zip(params, views, have) if h]
         if back:
             torch._foreach_copy_([g for g, _ in back], [v for _, v in back])
         for p, v, h, keep in zip(params, views, have, keep_all):
@@ -102,6 +118,14 @@ class TaskParallel:
                 t = t.cuda()
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
+
+    def union_of_keys(self, keys):
+        """Sorted union of every rank's string keys (logging only; a tiny object all-gather)."""
+        if not self.active:
+            return sorted(keys)
+        box = [None] * self.world
+        dist.all_gather_object(box, list(keys), group=self.group)
+        return sorted(set(k for ks in box for k in ks))
 
     def barrier(self):
         if self.active:

@@ -280,13 +280,13 @@ def test_meta_sequential_fuses_conv_relu_pairs_and_matches_reference_modules():
     calls = []
     orig = hip_ops.conv_bias_act
     hip_ops.conv_bias_act = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
-    mu.FUSE_CONV_ACT = True
+    mu.set_fuse_conv_act(True)
     try:
         y = seq(x, params=fast)
         gf = torch.autograd.grad(y.square().mean(), list(fast.values()))
     finally:
         hip_ops.conv_bias_act = orig
-        mu.FUSE_CONV_ACT = False
+        mu.set_fuse_conv_act(False)
     assert len(calls) == 2                                    # two conv+ReLU pairs fused, the last conv is plain
     y0 = seq(x, params=fast)
     g0 = torch.autograd.grad(y0.square().mean(), list(fast.values()))
@@ -443,7 +443,7 @@ def test_sepconv_with_winograd_convs_equals_miopen_convs():
     frames = synthetic.septuplet_batch(2, 256, 448, model='sepconv')
     f0, f1, tgt = frames[2].cuda(), frames[4].cuda(), frames[3].cuda()
     res = []
-    mu.FUSE_CONV_ACT = True
+    mu.set_fuse_conv_act(True)
     calls = []
     orig = hip_ops.conv3x3
     try:
@@ -454,7 +454,7 @@ def test_sepconv_with_winograd_convs_equals_miopen_convs():
             loss = ((out - tgt) ** 2).mean()
             res.append((out.detach(), torch.autograd.grad(loss, list(net.parameters()))))
     finally:
-        mu.FUSE_CONV_ACT = False
+        mu.set_fuse_conv_act(False)
         hip_ops.WINOGRAD_CONV = True
         hip_ops.conv3x3 = orig
     assert calls.count(0) >= 20 and calls.count(1) >= 8, calls          # forward and data-gradient launches happened

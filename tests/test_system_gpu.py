@@ -3,8 +3,8 @@ through libsavfi_hip.so) against (a) the golden fixtures generated from the impo
 (b) the CPU oracle, on identical seeded weights and septuplets.
 
 Gates (SURVEY.md 8d "Parity gate"): output frames <= 1e-4 mean abs (pixel L1, [0,1] scale) and
-<= 1e-3 dB PSNR; losses rel 1e-5 (5e-5 allowed: MIOpen's fp32 conv algorithms sum in another order
-than the CPU's); fast-weight fingerprints rel 1e-5; gradient fingerprints rel 1e-3 of their abs-sum.
+<= 1e-3 dB PSNR; losses rel 1e-5; fast-weight fingerprints rel 1e-5; gradient fingerprints rel 1e-3 of
+their abs-sum -- or K x the reference's own measured spread where that is larger (see `tolerances`).
 """
 import numpy as np
 import pytest
@@ -26,31 +26,44 @@ SYSTEM = ['c1_cain_lslr_sgd', 'cain_l2f', 'cain_lslr_adam_1step', 'sepconv_lslr_
           'voxelflow_lslr_sgd_2step', 'voxelflow_script_metasgd_adam_1step', 'rrin_lslr_sgd_2step',
           'superslomo_lslr_sgd_2step']
 
-# Gates.  `smooth` = SGD-type inner rules, where the whole path is a smooth function of the conv outputs.
-# Adam / Adamax steps are +-lr*c per element whatever |g| (g/(|g|+1e-8), m/(sqrt(v)+1e-8)): an element
-# whose gradient is below the rounding noise of the convolution (|g| ~ 1e-8) takes a different step under
-# MIOpen's summation order than under the CPU's (measured: 78 of 3.8M VoxelFlow elements after ONE Adamax
-# step, tools/scratch/vf_diag.py), and VoxelFlow's flow-to-pixel map amplifies it over further steps.  The
-# same spread separates the reference's CUDA and CPU runs.  For those cases the tight checks are the
-# step-0 quantities and the in-loop "fused rule == oracle rule on identical inputs" check; the end-of-
-# iteration quantities get the looser, measured bounds below.
-SMOOTH = dict(loss=5e-5, l1=1e-4, psnr=1e-3, ssim=1e-4, w=1e-5, g=1e-3, outer=1e-3)
-SIGNLIKE = dict(loss=5e-5, l1=1e-4, psnr=1e-3, ssim=1e-4, w=5e-4, g=2e-3, outer=5e-2)
-# VoxelFlow turns the tanh map into a displacement of up to +-W/4 pixels: a 1e-6 conv rounding difference
-# moves the sample point by ~3e-5 px on a noise-like texture, i.e. the forward pass at theta already differs
-# by 1.3e-5 (max) between MIOpen and the CPU.  The north-star gates (1e-4 pixel L1, 1e-3 dB) still hold for
-# the smooth rule; the relative loss / outer-gradient bounds are wider than for SepConv / CAIN.
-VOXEL = dict(loss=2e-4, l1=1e-4, psnr=1e-3, ssim=1e-4, w=1e-5, g=2e-3, outer=3e-2)
-CHAOTIC = dict(loss=5e-3, l1=1e-2, psnr=5e-2, ssim=5e-3, w=2e-3, g=5e-2, outer=2e-1)
-# Super SloMo: two 39-layer U-Nets whose first stages are 7x7 / 5x5 convolutions (MIOpen igemm kernels, solver choice
-# varies between processes) feeding a warp; individual gradient fingerprints of its smallest tensors were measured at
-# 1.8e-3 (tools/parity_report.py, profiles/r01_parity_report.jsonl) while loss / pixels / PSNR / weights stay at the 1e-6 level.
-SLOMO = dict(SMOOTH, g=5e-3, outer=1e-2)
-TOL = {name: SMOOTH for name in SYSTEM}
-TOL.update(superslomo_lslr_sgd_2step=SLOMO)
-TOL.update(cain_lslr_adam_1step=SIGNLIKE, sepconv_metasgd_adamax_2step=SIGNLIKE,
-           voxelflow_lslr_sgd_2step=VOXEL, voxelflow_script_metasgd_adam_1step=dict(VOXEL, w=5e-4),
-           voxelflow_metasgd_adamax_2step=CHAOTIC)
+# Gates = max(contract bound, K x the REFERENCE's own spread).
+#
+# Contract (north star / SURVEY.md 8d): pixel L1 <= 1e-4, PSNR <= 1e-3 dB, loss rel 1e-5, fast-weight fingerprints rel
+# 1e-5 (+ SSIM 1e-4 and gradient fingerprints 1e-3 of their abs-sum, which are this suite's own additions).
+#
+# tests/golden/sensitivity.npz (oracle/gen_sensitivity.py) holds, per case and phase, how far the imported reference moves
+# away from ITSELF when its float32 convolutions are summed in another order (two operand permutations) and when it runs in
+# float64.  SGD-type rules: that spread is far below the contract and the contract bound is the gate.  Adam / Adamax-type
+# rules step +-lr*c per element whatever |g| (g/(|g|+1e-8)): elements whose gradient is below conv rounding noise flip, and
+# VoxelFlow's flow-to-pixel map amplifies that over further steps -- the reference's 2-step VoxelFlow+Meta-SGD+Adamax run
+# differs from its own float64 run by 1.8e-3 pixel L1 / 3.3e-3 dB.  No implementation, the reference's CUDA path included,
+# can be closer to the CPU reference than the CPU reference is to itself, so for those quantities the gate is K x the
+# measured spread (K = 3 for the contract quantities, K = 5 for gradient fingerprints: MIOpen / Winograd kernels differ from
+# the CPU's direct convolution by algorithm, not only by summation order).  The step-level checks that do not compound --
+# gradients at theta, "fused rule == oracle rule on identical inputs", and the teacher-forced test further down -- stay
+# at the contract bounds for every case.
+CONTRACT = dict(loss=1e-5, l1=1e-4, psnr=1e-3, ssim=1e-4, w=1e-5, g=1e-3, outer=1e-3)
+K_SPREAD = dict(loss=3, l1=3, psnr=3, ssim=3, w=3, g=5, outer=5)
+_SENS = golden("sensitivity")
+_SENS_COL = {q: i for i, q in enumerate(_SENS['quantities'].tolist())}
+
+
+def tolerances(name, phase='train'):
+    tol = dict(CONTRACT)
+    key = '%s/%s' % (name, phase)
+    if key in _SENS.files:
+        table = _SENS[key]                              # [variant, quantity]
+        for q in tol:
+            tol[q] = max(tol[q], K_SPREAD[q] * float(table[:, _SENS_COL[q]].max()))
+    if name == 'superslomo_lslr_sgd_2step':
+        # not a north-star model.  Its first stages are 7x7 / 5x5 convolutions on MIOpen's implicit-GEMM
+        # kernels in front of a warp: outer-gradient fingerprints of its smallest tensors measured at 3.1e-3
+        # (profiles/r01_parity_report.jsonl) against a reference self-spread of 6.3e-4; pixels / loss / weights are at 1e-6.
+        tol['outer'] = max(tol['outer'], 1e-2)
+    return tol
+
+
+TOL = {name: tolerances(name) for name in SYSTEM}
 
 
 def run_case(name, phase, fuse=1, check_rule=False):
@@ -70,7 +83,7 @@ def run_case(name, phase, fuse=1, check_rule=False):
 @pytest.mark.parametrize("name", SYSTEM)
 @pytest.mark.parametrize("phase", ["train", "val"])
 def test_iteration_matches_reference_fixture(name, phase):
-    tol = TOL[name]
+    tol = tolerances(name, phase)
     g, losses, preds, metrics, rec = run_case(name, phase, check_rule=True)
     # every fused update in the loop == the oracle's rule applied to the same weights / grads / lrs
     assert max(rec['rule_err']) <= 1e-6, rec['rule_err']
@@ -97,6 +110,95 @@ def test_iteration_matches_reference_fixture(name, phase):
         assert set(rec['outer_grad_fp']) == set(rows)
         for k, row in rows.items():
             assert_fp_close(rec['outer_grad_fp'][k], row, tol['outer'], (name, 'outer', k))
+
+
+@pytest.mark.parametrize("name", [n for n in SYSTEM if n not in ('rrin_lslr_sgd_2step', 'superslomo_lslr_sgd_2step')])
+def test_iteration_matches_reference_fixture_under_default_miopen_solvers(name):
+    """The same fixtures with MIOpen's DEFAULT (non-deterministic, atomics-based) fp32 solvers -- the solver set bench.py and
+    the product run with (conftest.py pins the deterministic ones for every other test).  Contract quantities only:
+    gradient fingerprints wander at the 1e-4 level run to run under atomic accumulation (profiles/r01_determinism_survey.txt)."""
+    tol = tolerances(name, 'train')
+    prev = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = False
+    try:
+        g, losses, preds, metrics, rec = run_case(name, 'train', check_rule=False)
+    finally:
+        torch.backends.cudnn.deterministic = prev
+    assert list(g['train_n_live']) == rec['n_live']
+    want_loss = float(g['train_loss'])
+    assert abs(losses['loss'].item() - want_loss) <= tol['loss'] * abs(want_loss)
+    got = torch.stack([p.squeeze(0) for p in preds]).cpu().numpy()
+    assert np.abs(got - g['train_preds']).mean() < tol['l1']
+    assert abs(metrics['psnr'].avg - float(g['train_psnr'])) < tol['psnr']
+    assert abs(float(metrics['ssim'].avg) - float(g['train_ssim'])) < tol['ssim']
+    for i, d in enumerate(rec['weight_fp']):
+        for k, row in zip(list(g['train_weight_fp_%d_keys' % i]), g['train_weight_fp_%d' % i]):
+            assert_fp_close(d[k], row, tol['w'], (name, 'w', i, k))
+
+
+# ---------------------------------------------------------------------------------------------
+# Teacher-forced steps: the cases whose end-of-iteration gates are wider than the contract (sign-like inner rules).
+# Every inner step of the HIP path starts from the ORACLE's weights W_t (computed live on the CPU; the oracle is pinned to
+# the reference fixtures at 1e-5 by tests/test_oracle_golden.py) and must land on the oracle's W_{t+1}; the target pass
+# with the oracle's adapted weights must give the oracle's frame.  Nothing compounds here, so the contract bounds apply:
+# fast-weight fingerprints 1e-5, pixel L1 1e-4, PSNR 1e-3 dB -- plus a count of the elements that stepped the other way.
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ['voxelflow_metasgd_adamax_2step', 'sepconv_metasgd_adamax_2step', 'cain_lslr_adam_1step',
+                                  'voxelflow_script_metasgd_adam_1step', 'voxelflow_lslr_sgd_2step'])
+def test_teacher_forced_steps_meet_the_contract(name):
+    from oracle import meta as ometa, models as omodels
+    from tests.helpers import oracle_base
+    g = golden("system_" + name)
+    model, over = str(g['model']), parse_case_args(g)
+    B, H, W = int(g['B']), int(g['H']), int(g['W'])
+    S = int(over.get('number_of_training_steps_per_iter', 1))
+    kind = 'metasgd' if over.get('metasgd') else 'lslr'
+    opt, loss_kind = over['optimizer'], over['loss'].split('*')[1]
+    system = build_system(model, over)
+    system._set_pass_flags(False)
+    frames = synthetic.septuplet_batch(B, H, W, model=model)
+    frames_gpu = [f.to(DEV) for f in frames]
+    base = oracle_base(model)
+    names = ometa.inner_param_names([(n, p) for n, p in base.items() if p.is_floating_point()])
+    lrs = orules.init_lrs(kind, {n: base[n] for n in names}, over['inner_lr'], num_steps=S)
+    crit, fwd = ometa.criterion(loss_kind), omodels.FORWARD[model]
+    torch.set_num_threads(16)
+    flipped = total = 0
+    for t in range(B):
+        fast_o = {n: base[n] for n in names}
+        st = orules.RuleState()
+        system.inner_loop_optimizer.initialize_state()
+        for step in range(S):
+            sl = sum(crit(fwd(frames[i0][t][None], frames[i2][t][None], base, fast_o), frames[i1][t][None])
+                     for i0, i1, i2 in ometa.SUPPORT)
+            go = torch.autograd.grad(sl, list(fast_o.values()), allow_unused=True)
+            next_o = orules.update_params(kind, opt, fast_o, dict(zip(fast_o.keys(), go)), lrs, step, st)
+            Wg = {k: v.detach().to(DEV).requires_grad_() for k, v in fast_o.items()}
+            loss_g = system._support_loss(frames_gpu, t, Wg, step)
+            next_g = system.apply_inner_loop_update(loss_g, Wg, False, step)
+            assert set(next_g) <= set(next_o) and len(next_g) > 0
+            for k, v in next_g.items():
+                want = next_o[k].detach()
+                assert_fp_close(fp(v), fp(want), CONTRACT['w'], (name, 'teacher-forced w', t, step, k))
+                # an element that moved the other way: more than half a step from where the oracle put it
+                move = (want - fast_o[k].detach()).abs()
+                flipped += int(((v.detach().cpu() - want).abs() > 0.5 * move + 1e-12).sum())
+                total += want.numel()
+            fast_o = {k: v.detach().requires_grad_() for k, v in next_o.items()}
+        with torch.no_grad():
+            i0, i1, i2 = ometa.TARGET
+            pred_o = fwd(frames[i0][t][None], frames[i2][t][None], base, fast_o)
+            Wg = {k: v.detach().to(DEV) for k, v in fast_o.items()}
+            _, pred_g = system._target_pass(frames_gpu, t, Wg, S)
+            a = system._to_unit_range(pred_g.squeeze(0)).cpu()
+            b = system._to_unit_range(pred_o.squeeze(0).to(DEV)).cpu()
+            tgt = system._to_unit_range(frames_gpu[i1][t]).cpu()
+        assert (a - b).abs().mean().item() < CONTRACT['l1'], (name, t)
+        assert abs(ometa.psnr(a, tgt) - ometa.psnr(b, tgt)) < CONTRACT['psnr'], (name, t)
+    # SGD-type rules cannot flip; sign-like rules flip where |g| is below conv rounding noise (78 of 3.8M after one
+    # VoxelFlow step in round 1): a fraction, not a population
+    if opt != 'SGD':
+        assert flipped <= 2e-3 * total, (name, flipped, total)
 
 
 @pytest.mark.parametrize("name", ['sepconv_lslr_sgd_2step', 'voxelflow_lslr_sgd_2step', 'c1_cain_lslr_sgd'])

@@ -127,3 +127,45 @@ def test_provider_decodes_only_local_tasks_and_matches_the_single_process_batche
                         assert float(got_images[f][t].abs().max()) == 0.0        # someone else's task: never decoded
     assert len(ranks[0]['val']) == len(ranks[1]['val']) == 2                     # validation runs on every rank
     assert all(torch.equal(a[0][3], b[0][3]) for a, b in zip(ranks[0]['val'], ranks[1]['val']))
+
+
+# ---------------------------------------------------------------------------------------------
+# ExperimentBuilder with two ranks: training shards the meta-batch, the end-of-epoch validation sweep does not
+# (val_batch_size = 1 < world: a sharded sweep would leave rank 1 without a task, an all-reduce of mismatched length and an
+# empty prediction list -- round-1 advisor finding)
+# ---------------------------------------------------------------------------------------------
+def _eb_worker(rank, world, port, outdir):
+    from meta_interpolation_amd.data import SyntheticSeptupletLoader
+    from meta_interpolation_amd.experiment_builder import ExperimentBuilder
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    os.chdir(outdir)
+    try:
+        system = build_toy_system(task_parallel=TaskParallel(), batch=1, steps=1)      # batch 1 < world: rank 1 trains on nothing
+        args = system.args
+        args.synthetic, args.total_iter_per_epoch, args.max_epoch, args.exp_name, args.log_iter = True, 2, 1, 'toy2', 1
+        provider = lambda args, current_iter=0: SyntheticSeptupletLoader(args, current_iter, height=16, width=24,
+                                                                         length={'train': 4, 'val': 2, 'test': 1})
+        eb = ExperimentBuilder(args, provider, system)
+        seen = []
+        orig = system.run_validation_iter
+        system.run_validation_iter = lambda data_batch: (lambda r: (seen.append((float(r[0]['loss']), r[1][0].clone())), r)[1])(orig(data_batch))
+        eb.run_experiment()
+        torch.save({'state': {k: v.clone() for k, v in system.state_dict().items()}, 'val': seen, 'epoch': eb.epoch,
+                    'best': eb.best_PSNR}, os.path.join(outdir, "eb%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_experiment_builder_trains_and_validates_with_two_ranks(tmp_path):
+    port = 29500 + (os.getpid() % 2000) + 33
+    mp.spawn(_eb_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(str(tmp_path / ("eb%d.pt" % r)), weights_only=False) for r in range(2))
+    assert r0['epoch'] == r1['epoch'] == 1 and len(r0['val']) == len(r1['val']) == 2
+    for (la, pa), (lb, pb) in zip(r0['val'], r1['val']):          # every rank evaluated every validation item, same numbers
+        assert la == lb and torch.equal(pa, pb)
+    assert r0['best'] == r1['best']
+    for k, v in r0['state'].items():                                # replicas identical after training + scheduler step
+        assert torch.equal(v, r1['state'][k]), k
+    assert os.path.exists(str(tmp_path / 'checkpoint' / 'toy2' / 'checkpoint.pth'))
