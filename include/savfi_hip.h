@@ -26,6 +26,8 @@
  *                                                                     sepconv/model.py:172-194, model_utils.py:957-990
  *   savfi_conv3x3_f32          F.conv2d 3x3 / stride 1 (+ bias, activation) and its data gradient
  *   savfi_conv3x3_wgrad_f32    its weight gradient                    model_utils.py:308-366 (MetaConv2dLayer.forward -> F.conv2d)
+ *   savfi_conv3x3_tasks_f32, savfi_conv3x3_wgrad_tasks_f32   the same for T tasks with their own fast weights in ONE launch
+ *                              (the sequential task loop meta_learning_system.py:366 run in lockstep)
  *   savfi_frames_u8_to_f32     HWC uint8 frames -> normalised fp32 NCHW  data/vimeo_septuplet.py:68-80, data/video.py:44-51
  *   savfi_*_workspace_floats / savfi_bias_act_scratch_floats: sizes of the caller-owned scratch buffers (return int64_t)
  *
@@ -48,7 +50,7 @@
 extern "C" {
 #endif
 
-#define SAVFI_ABI_VERSION 3
+#define SAVFI_ABI_VERSION 4
 
 #define SAVFI_OK            0
 #define SAVFI_E_NULL       (-1)  /* a required pointer is NULL                          */
@@ -182,14 +184,17 @@ int savfi_mt_scale_bwd_f32(int n, const float* const* g_out, const float* const*
                            float* const* g_w, float* g_gamma, const int64_t* numel, void* stream);
 
 /* ------------------------------------------------------------------------------------
- * Fused mean-reduced L1 / MSE loss and its gradient.
- *   kind 0: mean |a-b| ; kind 1: mean (a-b)^2 ;  result[0] must be zeroed by the caller
- *   (accumulated with one atomic per workgroup).  bwd: g_a = g_loss[0]*sign(a-b)/n or
- *   g_loss[0]*2*(a-b)/n.
+ * Fused mean-reduced L1 / MSE loss and its gradient, `rows` independent reductions per launch:
+ *   a, b [rows, n];  kind 0: result[r] = mean |a[r]-b[r]| ; kind 1: mean (a[r]-b[r])^2   (fully overwritten)
+ *   `scratch`: savfi_l1_mse_scratch_floats(rows, n) floats of caller-owned device memory (per-workgroup partial sums,
+ *   added in a fixed order: the value is bit-reproducible).
+ *   bwd: g_a[r] = g_loss[r]*sign(a-b)/n or g_loss[r]*2*(a-b)/n.
+ * rows = 1 is nn.L1Loss / nn.MSELoss (loss.py:287-290); rows > 1 serves the per-sample losses of tasks adapted in lockstep.
  * ---------------------------------------------------------------------------------- */
-int savfi_l1_mse_f32(int kind, const float* a, const float* b, float* result, int64_t n, void* stream);
+int64_t savfi_l1_mse_scratch_floats(int rows, int64_t n);
+int savfi_l1_mse_f32(int kind, const float* a, const float* b, float* result, float* scratch, int rows, int64_t n, void* stream);
 int savfi_l1_mse_bwd_f32(int kind, const float* a, const float* b, const float* g_loss, float* g_a,
-                         int64_t n, void* stream);
+                         int rows, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Convolution epilogue: bias + activation, in place on the conv output z [N,C,H*W]:
@@ -241,6 +246,13 @@ int64_t savfi_conv3x3_workspace_floats(int N, int Ci, int Co, int H, int W, int 
 int savfi_conv3x3_f32(const float* x, const float* w, const float* bias, float* out, float* workspace,
                       int N, int Ci, int Co, int H, int W, int pad, int mode, float slope, void* stream);
 
+/* The same convolution for T tasks adapted in lockstep (the task loop of meta_learning_system.py:366 as ONE launch per
+ * layer): T filter sets w [T,Co,Ci,3,3], bias [T,Co]; the N samples are ordered sample-major, sample n belongs to task
+ * n % T and is convolved with that task's filters (N % T == 0).  T = 1 is savfi_conv3x3_f32. */
+int64_t savfi_conv3x3_tasks_workspace_floats(int N, int T, int Ci, int Co, int H, int W, int pad, int mode);
+int savfi_conv3x3_tasks_f32(const float* x, const float* w, const float* bias, float* out, float* workspace,
+                            int N, int T, int Ci, int Co, int H, int W, int pad, int mode, float slope, void* stream);
+
 /* Weight gradient of the same convolution (zero padding `pad` in {0,1}), NCHW in and out, deterministic:
  *   gw[Co,Ci,3,3] = sum over n,y,x of gz[n,co,y,x] * x[n,ci,y+a-pad,x+b-pad]      x [N,Ci,H,W], gz [N,Co,H+2pad-2,W+2pad-2]
  * `workspace`: savfi_conv3x3_wgrad_workspace_floats(same N, Ci, Co, H, W, pad) floats of caller-owned device memory
@@ -248,6 +260,11 @@ int savfi_conv3x3_f32(const float* x, const float* w, const float* bias, float* 
 int64_t savfi_conv3x3_wgrad_workspace_floats(int N, int Ci, int Co, int H, int W, int pad);
 int savfi_conv3x3_wgrad_f32(const float* x, const float* gz, float* gw, float* workspace, int N, int Ci, int Co,
                             int H, int W, int pad, void* stream);
+
+/* Per-task weight gradients of T tasks in lockstep: gw [T,Co,Ci,3,3], gw[t] sums over the samples n with n % T == t. */
+int64_t savfi_conv3x3_wgrad_tasks_workspace_floats(int N, int T, int Ci, int Co, int H, int W, int pad);
+int savfi_conv3x3_wgrad_tasks_f32(const float* x, const float* gz, float* gw, float* workspace, int N, int T, int Ci,
+                                  int Co, int H, int W, int pad, void* stream);
 
 /* ----------------------------------------------------------------------------------
  * Frame staging (data/vimeo_septuplet.py:68-80, data/video.py:44-51: channel swap, HWC->CHW, .float()/255,

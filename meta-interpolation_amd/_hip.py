@@ -16,7 +16,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_PKG_DIR), "include", "savfi_hip.h")
 
 RULE_SGD, RULE_ADAM, RULE_ADAMAX_LSLR, RULE_ADAMAX_MSGD = 0, 1, 2, 3
 LR_SCALAR, LR_ELEMENT = 0, 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _ERRORS = {-1: "SAVFI_E_NULL (a required pointer is NULL)",
            -2: "SAVFI_E_SHAPE (bad or inconsistent dimension)",
@@ -51,12 +51,17 @@ _PROTOTYPES = {
     "savfi_mt_mean_f32": [c_int, _PP, _I64P, _P, _P],
     "savfi_mt_scale_f32": [c_int, _PP, _P, _PP, _I64P, _P],
     "savfi_mt_scale_bwd_f32": [c_int, _PP, _PP, _P, _PP, _P, _I64P, _P],
-    "savfi_l1_mse_f32": [c_int, _P, _P, _P, c_int64, _P],
-    "savfi_l1_mse_bwd_f32": [c_int, _P, _P, _P, _P, c_int64, _P],
+    "savfi_l1_mse_scratch_floats": [c_int, c_int64],
+    "savfi_l1_mse_f32": [c_int, _P, _P, _P, _P, c_int, c_int64, _P],
+    "savfi_l1_mse_bwd_f32": [c_int, _P, _P, _P, _P, c_int, c_int64, _P],
     "savfi_upsample2x_fwd_f32": [_P, _P, c_int, c_int, c_int, c_int, _P],
     "savfi_upsample2x_bwd_f32": [_P, _P, c_int, c_int, c_int, c_int, _P],
     "savfi_conv3x3_workspace_floats": [c_int] * 7,
     "savfi_conv3x3_f32": [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P],
+    "savfi_conv3x3_tasks_workspace_floats": [c_int] * 8,
+    "savfi_conv3x3_tasks_f32": [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P],
+    "savfi_conv3x3_wgrad_tasks_workspace_floats": [c_int] * 7,
+    "savfi_conv3x3_wgrad_tasks_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P],
     "savfi_conv3x3_wgrad_workspace_floats": [c_int] * 6,
     "savfi_conv3x3_wgrad_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P],
     "savfi_frames_u8_to_f32": [_P, _P, c_int64, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float, _P],
@@ -96,7 +101,7 @@ def lib():
         except AttributeError:
             raise SavfiHipError("%s does not export %s" % (LIB_PATH, name))
         fn.argtypes = argtypes
-        fn.restype = c_int64 if name in ('savfi_conv3x3_workspace_floats', 'savfi_bias_act_scratch_floats', 'savfi_conv3x3_wgrad_workspace_floats') else c_int
+        fn.restype = c_int64 if name.endswith('_floats') else c_int
     got = handle.savfi_version()
     if got != ABI_VERSION:
         raise SavfiHipError("libsavfi_hip ABI %d != expected %d; rebuild" % (got, ABI_VERSION))

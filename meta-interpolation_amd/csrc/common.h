@@ -13,6 +13,19 @@ static inline int savfi_launch_status() {
 
 static inline int savfi_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// Opt-in to > 64 KB of dynamic LDS is a per-device function attribute: set once per (kernel, device); `done_mask` is the
+// caller's static bit set of devices already configured.
+static inline int savfi_ensure_dynamic_lds(const void* kernel, size_t bytes, uint32_t& done_mask) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return (int)hipGetLastError();
+  const uint32_t bit = 1u << (dev & 31);
+  if (__atomic_load_n(&done_mask, __ATOMIC_ACQUIRE) & bit) return SAVFI_OK;
+  const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return (int)e;
+  __atomic_fetch_or(&done_mask, bit, __ATOMIC_RELEASE);
+  return SAVFI_OK;
+}
+
 // 64-lane butterfly sum; every lane ends with the total.
 __device__ __forceinline__ float wave_sum(float x) {
 #pragma unroll

@@ -516,19 +516,6 @@ const SepconvEnv& sepconv_env() {
   return env;
 }
 
-// Opt-in to > 64 KB of dynamic LDS is a per-device function attribute: set once per (kernel, device).
-template <typename F>
-int ensure_dynamic_lds(F kernel, size_t bytes, uint32_t& done_mask) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return (int)hipGetLastError();
-  const uint32_t bit = 1u << (dev & 31);
-  if (__atomic_load_n(&done_mask, __ATOMIC_ACQUIRE) & bit) return SAVFI_OK;
-  const hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-  if (e != hipSuccess) return (int)e;
-  __atomic_fetch_or(&done_mask, bit, __ATOMIC_RELEASE);
-  return SAVFI_OK;
-}
-
 constexpr size_t mfma_lds_bytes(int rows) {
   return ((size_t)3 * (rows + KFAST - 1) * MLW + (size_t)(MNT / 64) * (KFAST + MKP) * 16) * sizeof(float);
 }
@@ -553,7 +540,7 @@ int launch_fwd_mfma(const float* in, const float* v, const float* h, float* out,
   constexpr size_t lds = mfma_lds_bytes(R);
   static_assert(lds <= 160 * 1024, "LDS per CU");
   static uint32_t done = 0;
-  if (int e = ensure_dynamic_lds(sepconv_fwd_mfma<KFAST, R>, lds, done)) return e;
+  if (int e = savfi_ensure_dynamic_lds((const void*)sepconv_fwd_mfma<KFAST, R>, lds, done)) return e;
   dim3 grid(savfi_cdiv(Wo, MC), savfi_cdiv(Ho, R), B);
   hipLaunchKernelGGL((sepconv_fwd_mfma<KFAST, R>), grid, dim3(MNT), lds, st, in, v, h, out, Ho, Wo);
   return savfi_launch_status();
@@ -564,7 +551,7 @@ int launch_bwd_mfma_one(const float* in, const float* v, const float* h, const f
                         int Ho, int Wo, hipStream_t st) {
   constexpr size_t lds = mfma_lds_bytes(R);
   static uint32_t done = 0;
-  if (int e = ensure_dynamic_lds(sepconv_bwd_mfma<KFAST, R, WV, WH>, lds, done)) return e;
+  if (int e = savfi_ensure_dynamic_lds((const void*)sepconv_bwd_mfma<KFAST, R, WV, WH>, lds, done)) return e;
   dim3 grid(savfi_cdiv(Wo, MC), savfi_cdiv(Ho, R), B);
   hipLaunchKernelGGL((sepconv_bwd_mfma<KFAST, R, WV, WH>), grid, dim3(MNT), lds, st, in, v, h, gO, gV, gH, Ho, Wo);
   return savfi_launch_status();

@@ -36,6 +36,7 @@ struct WgradArgs {
   const float* gz;    // [N][Co][Ho][Wo]
   float* partial;     // [splits][cobs * cibs][TILE_FLOATS]
   int Ci, Co, H, W, Ho, Wo, pad, rows, nseg, nrowchunk, cibs;
+  int T;              // tasks (blockIdx.z): task t reduces over samples n' * T + t and writes its own partial blocks
 };
 
 // Staging of one row step: cotangent row y ([32][64]) and input rows y - pad .. y - pad + 2 ([3][32][66]).  Wave w
@@ -134,7 +135,8 @@ __global__ __launch_bounds__(GNT, 2) void wgrad3x3(WgradArgs a) {
   const int i = lane & 15, k = lane >> 4;     // A fragment: (channel i, pixel k);  B fragment: (pixel k, channel i)
 
   // spatial strip: blockIdx.x = (n * nrowchunk + rowchunk) * nseg + seg;  channel tile: blockIdx.y = cob * cibs + cib
-  const int seg = blockIdx.x % a.nseg, rc = (blockIdx.x / a.nseg) % a.nrowchunk, n = blockIdx.x / (a.nseg * a.nrowchunk);
+  const int seg = blockIdx.x % a.nseg, rc = (blockIdx.x / a.nseg) % a.nrowchunk;
+  const int n = (blockIdx.x / (a.nseg * a.nrowchunk)) * a.T + blockIdx.z;
   const int cob = blockIdx.y / a.cibs, cib = blockIdx.y - cob * a.cibs;
   const int co0 = cob * GCO, ci0 = cib * GCI, x0 = seg * GSEG;
   const int y0 = rc * a.rows, y1 = min(y0 + a.rows, a.Ho);
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(GNT, 2) void wgrad3x3(WgradArgs a) {
     __syncthreads();
   }
   if (w == 3) {
-    float* out = a.partial + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * TILE_FLOATS + lane * 4;
+    float* out = a.partial + (((size_t)blockIdx.z * gridDim.x + blockIdx.x) * gridDim.y + blockIdx.y) * TILE_FLOATS + lane * 4;
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
@@ -220,6 +222,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce1(const float* __restrict__ p
                                                      size_t block_floats, int nsplit) {
   const size_t e4 = (size_t)blockIdx.x * 256 + threadIdx.x;         // float4 index inside one split's block
   if (e4 * 4 >= block_floats) return;
+  partial += (size_t)blockIdx.z * nsplit * block_floats;              // blockIdx.z = task
+  stage2 += (size_t)blockIdx.z * gridDim.y * block_floats;
   const int s0 = blockIdx.y * RG, s1 = min(s0 + RG, nsplit);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   for (int sp = s0; sp < s1; ++sp) acc += *reinterpret_cast<const f32x4*>(partial + (size_t)sp * block_floats + e4 * 4);
@@ -232,6 +236,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce2(const float* __restrict__ s
                                                      int cibs, int ntiles, int ngroups) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= Co * Ci * 9) return;
+  stage2 += (size_t)blockIdx.y * ngroups * ntiles * TILE_FLOATS;      // blockIdx.y = task
+  gw += (size_t)blockIdx.y * Co * Ci * 9;
   const int tap = e % 9, ci = (e / 9) % Ci, co = e / (9 * Ci);
   const int cob = co >> 5, cib = ci >> 5, rb = (co >> 4) & 1, cb = (ci >> 4) & 1;
   const int row = co & 15, col = ci & 15, lane = (row >> 2) * 16 + col, reg = row & 3;
@@ -246,7 +252,7 @@ struct WgradPlan {
   int64_t splits, partial_floats, stage2_floats;
 };
 
-bool wgrad_plan(WgradPlan& p, int N, int Ci, int Co, int H, int W, int pad) {
+bool wgrad_plan(WgradPlan& p, int N, int T, int Ci, int Co, int H, int W, int pad) {
   p.Ho = H + 2 * pad - 2;
   p.Wo = W + 2 * pad - 2;
   if (p.Ho <= 0 || p.Wo <= 0) return false;
@@ -269,46 +275,57 @@ bool wgrad_plan(WgradPlan& p, int N, int Ci, int Co, int H, int W, int pad) {
   }
   p.rows = best_rows;
   p.nrowchunk = savfi_cdiv(p.Ho, best_rows);
-  p.splits = (int64_t)N * p.nrowchunk * p.nseg;
-  p.partial_floats = p.splits * p.cobs * p.cibs * TILE_FLOATS;
+  // per task: N / T samples (the cost model above counts the workgroups of all tasks: they share the launch)
+  p.splits = (int64_t)(N / T) * p.nrowchunk * p.nseg;
+  p.partial_floats = (int64_t)T * p.splits * p.cobs * p.cibs * TILE_FLOATS;
   p.ngroups = (int)((p.splits + RG - 1) / RG);
-  p.stage2_floats = (int64_t)p.ngroups * p.cobs * p.cibs * TILE_FLOATS;
+  p.stage2_floats = (int64_t)T * p.ngroups * p.cobs * p.cibs * TILE_FLOATS;
   return true;
 }
 
 }  // namespace
 
-extern "C" int64_t savfi_conv3x3_wgrad_workspace_floats(int N, int Ci, int Co, int H, int W, int pad) {
-  if (N <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return SAVFI_E_SHAPE;
+extern "C" int64_t savfi_conv3x3_wgrad_tasks_workspace_floats(int N, int T, int Ci, int Co, int H, int W, int pad) {
+  if (N <= 0 || T <= 0 || N % T != 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return SAVFI_E_SHAPE;
   if (pad != 0 && pad != 1) return SAVFI_E_UNSUPPORTED;
   WgradPlan p;
-  if (!wgrad_plan(p, N, Ci, Co, H, W, pad)) return SAVFI_E_SHAPE;
+  if (!wgrad_plan(p, N, T, Ci, Co, H, W, pad)) return SAVFI_E_SHAPE;
   return p.partial_floats + p.stage2_floats;
 }
 
-extern "C" int savfi_conv3x3_wgrad_f32(const float* x, const float* gz, float* gw, float* workspace, int N, int Ci, int Co,
-                                       int H, int W, int pad, void* stream) {
+extern "C" int64_t savfi_conv3x3_wgrad_workspace_floats(int N, int Ci, int Co, int H, int W, int pad) {
+  return savfi_conv3x3_wgrad_tasks_workspace_floats(N, 1, Ci, Co, H, W, pad);
+}
+
+// gw[t] = weight gradient over the samples n with n % T == t      gw [T][Co][Ci][3][3]
+extern "C" int savfi_conv3x3_wgrad_tasks_f32(const float* x, const float* gz, float* gw, float* workspace, int N, int T, int Ci,
+                                             int Co, int H, int W, int pad, void* stream) {
   if (!x || !gz || !gw || !workspace) return SAVFI_E_NULL;
-  if (N <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return SAVFI_E_SHAPE;
+  if (N <= 0 || T <= 0 || N % T != 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return SAVFI_E_SHAPE;
   if (pad != 0 && pad != 1) return SAVFI_E_UNSUPPORTED;
   WgradPlan p;
-  if (!wgrad_plan(p, N, Ci, Co, H, W, pad)) return SAVFI_E_SHAPE;
+  if (!wgrad_plan(p, N, T, Ci, Co, H, W, pad)) return SAVFI_E_SHAPE;
   if ((int64_t)Ci * H * W >= ((int64_t)1 << 29) || (int64_t)Co * p.Ho * p.Wo >= ((int64_t)1 << 29)) return SAVFI_E_TOOBIG;   // 32-bit byte offsets
-  if (p.ngroups > 65535 || p.splits > 0x7fffffffLL || (int64_t)p.cobs * p.cibs > 65535 || (int64_t)Co * Ci * 9 > 0x7fffffffLL) return SAVFI_E_TOOBIG;
+  if (p.ngroups > 65535 || p.splits > 0x7fffffffLL || (int64_t)p.cobs * p.cibs > 65535 || (int64_t)Co * Ci * 9 > 0x7fffffffLL || T > 65535) return SAVFI_E_TOOBIG;
   hipStream_t st = (hipStream_t)stream;
   constexpr size_t lds = (size_t)LDS_FLOATS_G * sizeof(float);
-  static const hipError_t attr = hipFuncSetAttribute((const void*)wgrad3x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (attr != hipSuccess) return (int)attr;
-  WgradArgs a{x, gz, workspace, Ci, Co, H, W, p.Ho, p.Wo, pad, p.rows, p.nseg, p.nrowchunk, p.cibs};
-  hipLaunchKernelGGL(wgrad3x3, dim3((unsigned)p.splits, p.cobs * p.cibs, 1), dim3(GNT), lds, st, a);
+  static uint32_t attr_done = 0;
+  if (int e = savfi_ensure_dynamic_lds((const void*)wgrad3x3, lds, attr_done)) return e;
+  WgradArgs a{x, gz, workspace, Ci, Co, H, W, p.Ho, p.Wo, pad, p.rows, p.nseg, p.nrowchunk, p.cibs, T};
+  hipLaunchKernelGGL(wgrad3x3, dim3((unsigned)p.splits, p.cobs * p.cibs, T), dim3(GNT), lds, st, a);
   if (int e = savfi_launch_status()) return e;
   const int ntiles = p.cobs * p.cibs;
   const size_t block_floats = (size_t)ntiles * TILE_FLOATS;
   float* stage2 = workspace + p.partial_floats;
-  hipLaunchKernelGGL(wgrad_reduce1, dim3((unsigned)((block_floats / 4 + 255) / 256), p.ngroups), dim3(256), 0, st, workspace,
+  hipLaunchKernelGGL(wgrad_reduce1, dim3((unsigned)((block_floats / 4 + 255) / 256), p.ngroups, T), dim3(256), 0, st, workspace,
                      stage2, block_floats, (int)p.splits);
   if (int e = savfi_launch_status()) return e;
-  hipLaunchKernelGGL(wgrad_reduce2, dim3(savfi_cdiv(Co * Ci * 9, 256)), dim3(256), 0, st, stage2, gw, Co, Ci, p.cibs, ntiles,
+  hipLaunchKernelGGL(wgrad_reduce2, dim3(savfi_cdiv(Co * Ci * 9, 256), T), dim3(256), 0, st, stage2, gw, Co, Ci, p.cibs, ntiles,
                      p.ngroups);
   return savfi_launch_status();
+}
+
+extern "C" int savfi_conv3x3_wgrad_f32(const float* x, const float* gz, float* gw, float* workspace, int N, int Ci, int Co,
+                                       int H, int W, int pad, void* stream) {
+  return savfi_conv3x3_wgrad_tasks_f32(x, gz, gw, workspace, N, 1, Ci, Co, H, W, pad, stream);
 }

@@ -49,10 +49,13 @@ constexpr int LDS_FLOATS = (2 * VBUF > XBUF) ? 2 * VBUF : XBUF;
 //   Uf[k / 4][i / 32][r][lane = (k % 4) * 16 + i % 16][c][(i % 32) / 16]        (xi = 4 r + c)
 // mode 0 (forward):        g[a][b] = w[i][k][a][b]           (w is [Co][Ci][3][3]; i = co, k = ci)
 // mode 1 (data gradient):  g[a][b] = w[k][i][2-a][2-b]       (i = ci, k = co)
+// blockIdx.y = task: filter set w + task * Co*Ci*9 -> U + task * 16*KP*IP (tasks adapted in lockstep own their weights).
 __global__ __launch_bounds__(256) void wino_filter_transform(const float* __restrict__ w, float* __restrict__ U,
                                                              int Co, int Ci, int K, int I, int KP, int IP, int mode) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= KP * IP) return;
+  w += (size_t)blockIdx.y * Co * Ci * 9;
+  U += (size_t)blockIdx.y * 16 * KP * IP;
   const int k = idx / IP, i = idx - k * IP;
   float g[3][3];
 #pragma unroll
@@ -96,6 +99,7 @@ struct WinoArgs {
   float slope;                                             // tiles_* = number of TBH x TBW tile blocks
   int nsplit, chunks_per_split;                            // reduction channels split over workgroups (deep layers)
   float* partial;                                          // nsplit > 1: raw partial outputs [split][N][I][Ho][Wo]
+  int T;                                                   // filter sets: sample n uses set n % T (U [T][...], bias [T][I])
 };
 
 // The 4x4 patch of a thread sits at the same (y, x) for every channel: its row offsets and the zero-padding mask are
@@ -242,6 +246,7 @@ __global__ __launch_bounds__(WNT, 2) void wino_conv3x3(WinoArgs a) {
   const int cob = blockIdx.y % nblk, sp = blockIdx.y / nblk;       // channel block, reduction split
   const int i0 = cob * COB;                        // first produced channel
   const int n = blockIdx.z;
+  const int task = a.T > 1 ? n % a.T : 0;
   const float* xp = a.x + (size_t)n * a.K * a.H * a.W;
   const size_t cplane = (size_t)a.H * a.W;
 
@@ -260,7 +265,7 @@ __global__ __launch_bounds__(WNT, 2) void wino_conv3x3(WinoArgs a) {
   // this workgroup reduces over chunks [cbeg, nchunk) of the KP / CIB chunks (an even count)
   const int cbeg = sp * a.chunks_per_split, nchunk = min(cbeg + a.chunks_per_split, a.KP / CIB);
   const size_t ustride = (size_t)nblk * 4 * 64 * 32;                                     // bytes per chunk
-  const char* ubase = reinterpret_cast<const char*>(a.U) + ((size_t)cob * 4 + w) * 64 * 32;
+  const char* ubase = reinterpret_cast<const char*>(a.U + (size_t)task * 16 * a.KP * a.IP) + ((size_t)cob * 4 + w) * 64 * 32;
   const unsigned ulane = (unsigned)lane * 32u;
   auto plane_of = [&](int chunk) { return xp + (size_t)min(min(chunk, nchunk - 1) * CIB + w, a.K - 1) * cplane; };
   auto u_of = [&](int chunk) { return ubase + (size_t)min(chunk, nchunk - 1) * ustride; };
@@ -340,7 +345,7 @@ __global__ __launch_bounds__(WNT, 2) void wino_conv3x3(WinoArgs a) {
         y[1][c] = s[1][c] - s[2][c] - s[3][c];
       }
       if (i < a.I) {
-        const float b = (a.bias && a.nsplit == 1) ? a.bias[i] : 0.f;
+        const float b = (a.bias && a.nsplit == 1) ? a.bias[task * a.I + i] : 0.f;
         const int oty = tby * TBH + (t >> 4), otx = tbx * TBW + (t & 15);
         const int oy = 2 * oty, ox = 2 * otx;
         float* obase = a.nsplit == 1 ? a.out : a.partial + (size_t)sp * gridDim.z * a.I * a.Ho * a.Wo;
@@ -368,12 +373,15 @@ __global__ __launch_bounds__(WNT, 2) void wino_conv3x3(WinoArgs a) {
 // out = act(sum over splits of partial (fixed order: deterministic) + bias[c])
 __global__ __launch_bounds__(256) void wino_split_reduce(const float* __restrict__ partial, const float* __restrict__ bias,
                                                          float* __restrict__ out, int nsplit, size_t total, int I, int HW,
-                                                         float slope) {
+                                                         float slope, int T) {
   const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= total) return;
   float acc = 0.f;
   for (int s = 0; s < nsplit; ++s) acc += partial[(size_t)s * total + e];
-  if (bias) acc += bias[(e / HW) % I];
+  if (bias) {
+    const size_t plane = e / HW;                    // n * I + c
+    acc += bias[((plane / I) % T) * I + plane % I];
+  }
   out[e] = acc > 0.f ? acc : slope * acc;
 }
 
@@ -420,41 +428,50 @@ bool make_plan(WinoPlan& p, int N, int Ci, int Co, int H, int W, int pad, int mo
 
 }  // namespace
 
-extern "C" int64_t savfi_conv3x3_workspace_floats(int N, int Ci, int Co, int H, int W, int pad, int mode) {
-  if (N <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return SAVFI_E_SHAPE;
+extern "C" int64_t savfi_conv3x3_tasks_workspace_floats(int N, int T, int Ci, int Co, int H, int W, int pad, int mode) {
+  if (N <= 0 || T <= 0 || N % T != 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return SAVFI_E_SHAPE;
   if ((mode != 0 && mode != 1) || (pad != 0 && pad != 1)) return SAVFI_E_UNSUPPORTED;
   WinoPlan p;
   if (!make_plan(p, N, Ci, Co, H, W, pad, mode)) return SAVFI_E_SHAPE;
-  return p.u_floats + p.partial_floats;
+  return (int64_t)T * p.u_floats + p.partial_floats;
 }
 
-// mode 0: out[n][co] = act(conv2d(x[n], w, zero padding `pad`)[co] + bias[co])   x [N][Ci][H][W] -> [N][Co][H+2pad-2][W+2pad-2]
+extern "C" int64_t savfi_conv3x3_workspace_floats(int N, int Ci, int Co, int H, int W, int pad, int mode) {
+  return savfi_conv3x3_tasks_workspace_floats(N, 1, Ci, Co, H, W, pad, mode);
+}
+
+// mode 0: out[n][co] = act(conv2d(x[n], w[n % T], zero padding `pad`)[co] + bias[n % T][co])   x [N][Ci][H][W] -> [N][Co][H+2pad-2][W+2pad-2]
 // mode 1: its data gradient: x = gy [N][Co][H][W] -> out = gx [N][Ci][H+2-2pad][W+2-2pad]
-extern "C" int savfi_conv3x3_f32(const float* x, const float* w, const float* bias, float* out, float* workspace,
-                                 int N, int Ci, int Co, int H, int W, int pad, int mode, float slope, void* stream) {
+extern "C" int savfi_conv3x3_tasks_f32(const float* x, const float* w, const float* bias, float* out, float* workspace,
+                                       int N, int T, int Ci, int Co, int H, int W, int pad, int mode, float slope, void* stream) {
   if (!x || !w || !out || !workspace) return SAVFI_E_NULL;
-  if (N <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return SAVFI_E_SHAPE;
+  if (N <= 0 || T <= 0 || N % T != 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return SAVFI_E_SHAPE;
   if ((mode != 0 && mode != 1) || (pad != 0 && pad != 1) || (int64_t)H * W < 4) return SAVFI_E_UNSUPPORTED;   // rows are 16-byte loads
   WinoPlan p;
   if (!make_plan(p, N, Ci, Co, H, W, pad, mode)) return SAVFI_E_SHAPE;
   if ((int64_t)H * W >= ((int64_t)1 << 29)) return SAVFI_E_TOOBIG;     // 32-bit byte offsets inside a channel plane
-  if ((int64_t)p.th * p.tw > 0x7fffffffLL || (int64_t)(p.IP / COB) * p.nsplit > 65535 || N > 65535) return SAVFI_E_TOOBIG;
+  if ((int64_t)p.th * p.tw > 0x7fffffffLL || (int64_t)(p.IP / COB) * p.nsplit > 65535 || N > 65535 || T > 65535) return SAVFI_E_TOOBIG;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(wino_filter_transform, dim3(savfi_cdiv(p.KP * p.IP, 256)), dim3(256), 0, st, w, workspace, Co, Ci, p.K,
+  hipLaunchKernelGGL(wino_filter_transform, dim3(savfi_cdiv(p.KP * p.IP, 256), T), dim3(256), 0, st, w, workspace, Co, Ci, p.K,
                      p.I, p.KP, p.IP, mode);
   if (int e = savfi_launch_status()) return e;
   constexpr size_t lds = (size_t)LDS_FLOATS * sizeof(float);      // 40 KB: two workgroups per CU
   const float* b = mode == 0 ? bias : nullptr;
-  float* partial = workspace + p.u_floats;
+  float* partial = workspace + (int64_t)T * p.u_floats;
   WinoArgs a{x, workspace, b, out, p.K, p.I, p.KP, p.IP, H, W, p.Ho, p.Wo, p.off, p.th, p.tw, slope, p.nsplit,
-             p.chunks_per_split, partial};
+             p.chunks_per_split, partial, T};
   hipLaunchKernelGGL(wino_conv3x3, dim3(p.th * p.tw, (p.IP / COB) * p.nsplit, N), dim3(WNT), lds, st, a);
   if (int e = savfi_launch_status()) return e;
   if (p.nsplit > 1) {
     const size_t total = (size_t)N * p.I * p.Ho * p.Wo;
     hipLaunchKernelGGL(wino_split_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, partial, b, out, p.nsplit, total,
-                       p.I, p.Ho * p.Wo, slope);
+                       p.I, p.Ho * p.Wo, slope, T);
     return savfi_launch_status();
   }
   return SAVFI_OK;
+}
+
+extern "C" int savfi_conv3x3_f32(const float* x, const float* w, const float* bias, float* out, float* workspace,
+                                 int N, int Ci, int Co, int H, int W, int pad, int mode, float slope, void* stream) {
+  return savfi_conv3x3_tasks_f32(x, w, bias, out, workspace, N, 1, Ci, Co, H, W, pad, mode, slope, stream);
 }

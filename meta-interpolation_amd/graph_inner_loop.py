@@ -14,6 +14,10 @@ dL/d lr_t = < sum_{s>t} w_s G_s , dir_t >   with dir_t = d W_{t+1} / d lr_t (= -
 Every graph replays on static buffers: step graph t reads the tensors graph t-1 wrote.  All graphs share one
 memory pool (they never run concurrently).  The numerics are those of the eager path (same kernels, same order).
 
+Tasks in lockstep (``tasks`` = T > 1, --task_batch): the same graphs over T tasks at once -- support batch [2T,3,H,W] in
+sample-major order, fast weights / moments / gradients stacked [T, *shape], per-sample losses; the identity chain then sums
+the stacked target gradients over the task axis.  T = 1 is the per-task form above, unchanged.
+
 Not captured (the caller falls back to the eager loop): --second_order, --attenuate (L2F), CPU tensors.
 """
 import torch
@@ -33,8 +37,9 @@ def _frame(out):
 
 
 class GraphedInnerLoop:
-    def __init__(self, system, frame_shape, num_steps, training, msl):
+    def __init__(self, system, frame_shape, num_steps, training, msl, tasks=1):
         self.sys = system
+        self.T = int(tasks)
         self.net, self.rule, self.crit = system.net, system.inner_loop_optimizer, system.criterion
         self.S, self.training, self.msl = num_steps, training, msl
         self.shape = tuple(frame_shape)            # (3, H, W)
@@ -44,17 +49,20 @@ class GraphedInnerLoop:
         self.theta = named
         self._probe_routing()
         C, H, W = self.shape
-        self.sup = [torch.zeros(2, C, H, W, device=dev) for _ in range(3)]      # frame0 | target | frame1, pair batch
-        self.tgt = [torch.zeros(1, C, H, W, device=dev) for _ in range(3)]
-        self.W0 = {k: torch.zeros_like(self.theta[k]).requires_grad_() for k in self.routed}
+        T = self.T
+        self.sup = [torch.zeros(2 * T, C, H, W, device=dev) for _ in range(3)]      # frame0 | target | frame1, pair batch
+        self.tgt = [torch.zeros(T, C, H, W, device=dev) for _ in range(3)]
+        stacked = (lambda p: torch.zeros_like(p)) if T == 1 else (lambda p: torch.zeros((T,) + tuple(p.shape), device=dev))
+        self._like = stacked
+        self.W0 = {k: stacked(self.theta[k]).requires_grad_() for k in self.routed}
         self.learn_lr = any(p.requires_grad for p in self.rule.names_learning_rates_dict.values())
         opt = self.rule.optimizer
         self.rule_id = {('SGD', True): _hip.RULE_SGD, ('SGD', False): _hip.RULE_SGD,
                         ('Adam', True): _hip.RULE_ADAM, ('Adam', False): _hip.RULE_ADAM,
                         ('Adamax', True): _hip.RULE_ADAMAX_LSLR, ('Adamax', False): _hip.RULE_ADAMAX_MSGD}[
             (opt, self.rule.keeps_adamax_moment)]
-        self.m = [torch.zeros_like(self.theta[k]) for k in self.routed] if self.rule_id in (1, 2) else None
-        self.s = [torch.zeros_like(self.theta[k]) for k in self.routed] if self.rule_id == 1 else None
+        self.m = [stacked(self.theta[k]) for k in self.routed] if self.rule_id in (1, 2) else None
+        self.s = [stacked(self.theta[k]) for k in self.routed] if self.rule_id == 1 else None
         self.step_graphs, self.step_out = [], []     # per step: graph, dict(W_out, g, dir)
         self.target_graphs = {}                      # step index s (params = W_s) -> (graph, outputs)
         self.pool = None
@@ -82,7 +90,10 @@ class GraphedInnerLoop:
             out = _frame(self.net.forward(self.sup[0], self.sup[2], params=W, backup_running_statistics=(t == 0), num_step=t))
         finally:
             model_utils.set_own_params_const(False)
-        loss = self.crit(out[0:1], self.sup[1][0:1])['total'] + self.crit(out[1:2], self.sup[1][1:2])['total']
+        if self.T == 1:
+            loss = self.crit(out[0:1], self.sup[1][0:1])['total'] + self.crit(out[1:2], self.sup[1][1:2])['total']
+        else:
+            loss = self.crit.per_sample(out, self.sup[1])['total'].sum()
         g = torch.autograd.grad(loss, [W[k] for k in self.routed])
         ws = [W[k].detach() for k in self.routed]
         lrs = [l.detach() for l in self._lrs(t)]
@@ -95,15 +106,16 @@ class GraphedInnerLoop:
         return dict(W=Wn, g=list(g), dir=(coef if want_coef else list(g)), loss=loss.detach())
 
     def _target(self, W, s, with_grad):
+        crit = self.crit if self.T == 1 else self.crit.per_sample          # T > 1: every loss part is a [T] vector
         if not with_grad:
             with torch.no_grad():
                 pred = _frame(self.net.forward(self.tgt[0], self.tgt[2], params=W, backup_running_statistics=False, num_step=s))
-                parts = self.crit(pred, self.tgt[1])
+                parts = crit(pred, self.tgt[1])
             return dict(pred=pred, parts={k: v.detach() for k, v in parts.items()})
         pred = _frame(self.net.forward(self.tgt[0], self.tgt[2], params=W, backup_running_statistics=False, num_step=s))
-        parts = self.crit(pred, self.tgt[1])
+        parts = crit(pred, self.tgt[1])
         own = [self.theta[k] for k in self.unrouted]
-        g = torch.autograd.grad(parts['total'], [W[k] for k in self.routed] + own, allow_unused=True)
+        g = torch.autograd.grad(parts['total'].sum(), [W[k] for k in self.routed] + own, allow_unused=True)
         n = len(self.routed)
         return dict(pred=pred.detach(), parts={k: v.detach() for k, v in parts.items()}, g_routed=list(g[:n]),
                     g_own=list(g[n:]))
@@ -156,24 +168,38 @@ class GraphedInnerLoop:
 
     # ------------------------------------------------------------------------------------------
     def run_task(self, frames, task_id, importance, accum):
-        """Adapt on one task and (when training) add its outer-gradient contribution to `accum`.
+        """Adapt on one task (T = 1) and (when training) add its outer-gradient contribution to `accum`.
         Returns (task_loss scalar tensor, pred [1,3,H,W], list of loss-part dicts)."""
+        losses, preds, logs = self.run_tasks(frames, [task_id], importance, accum)
+        return losses[0], preds[0:1], logs[0]
+
+    def run_tasks(self, frames, ids, importance, accum):
+        """Adapt the T tasks `ids` together; returns (task losses [T], preds [T,3,H,W], per task a list of loss-part dicts)."""
         sysm = self.sys
+        T = self.T
+        assert len(ids) == T, (ids, T)
         a, b = sysm.support_idxs
         tix = sysm.target_idxs
-        sl = slice(task_id, task_id + 1)
+        if list(ids) == list(range(ids[0], ids[0] + T)):
+            pick = lambda i: frames[i][ids[0]:ids[0] + T]
+        else:
+            sel = torch.as_tensor(list(ids), device=frames[0].device)
+            pick = lambda i: frames[i].index_select(0, sel)
         for dst, (ia, ib) in zip(self.sup, ((a[0], b[0]), (a[1], b[1]), (a[2], b[2]))):
-            dst[0:1].copy_(frames[ia][sl])
-            dst[1:2].copy_(frames[ib][sl])
+            dst[0:T].copy_(pick(ia))           # sample-major: sample j * T + t belongs to task t
+            dst[T:2 * T].copy_(pick(ib))
         for dst, i in zip(self.tgt, tix):
-            dst.copy_(frames[i][sl])
+            dst.copy_(pick(i))
         with torch.no_grad():
-            torch._foreach_copy_([self.W0[k] for k in self.routed], [self.theta[k] for k in self.routed])
+            if T == 1:
+                torch._foreach_copy_([self.W0[k] for k in self.routed], [self.theta[k] for k in self.routed])
+            else:
+                for k in self.routed:
+                    self.W0[k].copy_(self.theta[k].unsqueeze(0).expand_as(self.W0[k]))
             for buf in (self.m, self.s):
                 if buf is not None:
                     torch._foreach_zero_(buf)
         logs, task_loss, pred = [], None, None
-        n = len(self.routed)
         # replay: S support steps, target passes where needed
         for t in range(self.S):
             self.step_graphs[t].replay()
@@ -210,8 +236,12 @@ class GraphedInnerLoop:
                 if t > 0 and self.learn_lr and suffix is not None:
                     accum.add_lr_grads(self, t - 1, suffix)
             if suffix is not None:
-                accum.add_params(self.routed, suffix)
-        return task_loss, pred.clone(), logs
+                # identity chain W_S -> ... -> W_0 = theta broadcast over the tasks: the task axis is summed
+                accum.add_params(self.routed, suffix if T == 1 else [x.sum(0) for x in suffix])
+        if T == 1:
+            return task_loss.reshape(1), pred.clone(), [logs]
+        per_task_logs = [[{k: v[t] for k, v in parts.items()} for parts in logs] for t in range(T)]
+        return task_loss, pred.clone(), per_task_logs
 
 
 class OuterGradAccumulator:
@@ -260,6 +290,8 @@ class OuterGradAccumulator:
                 self.lr_keys = lr_keys
             self.lr_rows[t].add_(dst)
         else:
+            if gl.T > 1:             # stacked over tasks, ONE rate table: add the tasks
+                outs = [o.sum(0) for o in outs]
             live = [(lk, o) for lk, o in zip(lr_keys, outs) if rule.names_learning_rates_dict[lk].requires_grad]
             self.add_lr_tensors([lk for lk, _ in live], [o for _, o in live])
 

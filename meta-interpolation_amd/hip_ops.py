@@ -228,20 +228,13 @@ class _MtUpdate(torch.autograd.Function):
         need_lr = any(ctx.needs_input_grad[1 + n + i] for i in range(n))
         save_dir = need_lr and rule != _hip.RULE_SGD
         coefs = [torch.empty_like(w) for w in ws] if save_dir else None
-        lib = _hip.lib()
-        numel = [w.numel() for w in ws]
         ms, ss = spec.get("m"), spec.get("s")
-        args = (rule, lr_mode, n, _hip.ptr_array(ws), _hip.ptr_array(gs), _hip.ptr_array(lrs),
-                _hip.ptr_array(ms) if ms is not None else None,
-                _hip.ptr_array(ss) if ss is not None else None,
-                _hip.ptr_array(outs), _hip.ptr_array(coefs) if coefs is not None else None,
-                _hip.i64_array(numel),
-                _hip.f32_array(spec["bc1"]) if spec.get("bc1") is not None else None,
-                _hip.f32_array(spec["sqrt_bc2"]) if spec.get("sqrt_bc2") is not None else None,
-                spec["beta1"], spec["beta2"], spec["eps"], _hip.current_stream())
-        _hip.launch("mt_update", lambda: _hip.check(lib.savfi_mt_update_f32(*args), "savfi_mt_update_f32"))
+        _launch_mt_update(rule, lr_mode, ws, gs, lrs, ms, ss, outs, coefs, spec.get("bc1"), spec.get("sqrt_bc2"),
+                          spec["beta1"], spec["beta2"], spec["eps"])
+        numel = [w.numel() for w in ws]
         ctx.n, ctx.lr_mode, ctx.numel = n, lr_mode, numel
         ctx.lr_shapes = [lr.shape for lr in lrs]
+        ctx.w_shapes = [w.shape for w in ws]
         if need_lr:
             ctx.dirs = coefs if save_dir else list(gs)
             ctx.dir_scale = 1.0 if save_dir else -1.0
@@ -271,8 +264,39 @@ class _MtUpdate(torch.autograd.Function):
                 _hip.launch("mt_update_bwd", lambda: _hip.check(lib.savfi_mt_update_bwd_f32(*args),
                                                                  "savfi_mt_update_bwd_f32"))
                 for j, i in enumerate(idx):
-                    g_lrs[i] = dst[j].reshape(ctx.lr_shapes[i])
+                    if ctx.lr_mode == _hip.LR_ELEMENT and tuple(ctx.w_shapes[i]) != tuple(ctx.lr_shapes[i]):
+                        g_lrs[i] = dst[j].sum(0)         # weights stacked over tasks, ONE element-wise lr table: add the tasks
+                    else:
+                        g_lrs[i] = dst[j].reshape(ctx.lr_shapes[i])
         return (None, *g_ws, *g_lrs)
+
+
+def _launch_mt_update(rule, lr_mode, ws, gs, lrs, ms, ss, outs, coefs, bc1, sqrt_bc2, beta1, beta2, eps):
+    """One savfi_mt_update_f32 call.  Weights stacked over tasks ([T, *shape], tasks adapted in lockstep) with an element-wise
+    learning-rate table of shape `shape` (Meta-SGD) go in as T entries, one per task slice, that share the lr pointer; with a
+    scalar lr (LSLR) a stacked tensor is just a tensor of T x numel elements."""
+    if lr_mode == _hip.LR_ELEMENT and any(w.shape != lr.shape for w, lr in zip(ws, lrs)):
+        def cut(ts):
+            if ts is None:
+                return None
+            out = []
+            for t, w, lr in zip(ts, ws, lrs):
+                out.extend([t] if w.shape == lr.shape else list(t.unbind(0)))
+            return out
+        rep = lambda vals: None if vals is None else [v for v, w, lr in zip(vals, ws, lrs)
+                                                      for _ in range(1 if w.shape == lr.shape else w.shape[0])]
+        lrs = rep(list(lrs))
+        bc1, sqrt_bc2 = rep(bc1), rep(sqrt_bc2)
+        ws_, gs, ms, ss, outs, coefs = cut(ws), cut(gs), cut(ms), cut(ss), cut(outs), cut(coefs)
+        ws = ws_
+    lib = _hip.lib()
+    args = (rule, lr_mode, len(ws), _hip.ptr_array(ws), _hip.ptr_array(gs), _hip.ptr_array(lrs),
+            _hip.ptr_array(ms) if ms is not None else None, _hip.ptr_array(ss) if ss is not None else None,
+            _hip.ptr_array(outs), _hip.ptr_array(coefs) if coefs is not None else None,
+            _hip.i64_array([w.numel() for w in ws]),
+            _hip.f32_array(bc1) if bc1 is not None else None, _hip.f32_array(sqrt_bc2) if sqrt_bc2 is not None else None,
+            beta1, beta2, eps, _hip.current_stream())
+    _hip.launch("mt_update", lambda: _hip.check(lib.savfi_mt_update_f32(*args), "savfi_mt_update_f32"))
 
 
 def mt_update(rule, lr_mode, weights, grads, lrs, m=None, s=None, bc1=None, sqrt_bc2=None,
@@ -296,16 +320,9 @@ def mt_update(rule, lr_mode, weights, grads, lrs, m=None, s=None, bc1=None, sqrt
 def mt_update_nograd(rule, lr_mode, weights, grads, lrs, m, s, bc1, sqrt_bc2, beta1, beta2, eps, want_coef):
     """The fused update without the autograd wrapper (used inside captured hipGraphs, where the outer gradient
     is assembled by hand): returns (new weights, coef or None) with coef = d w' / d lr per element."""
-    n = len(weights)
     outs = [torch.empty_like(w) for w in weights]
     coefs = [torch.empty_like(w) for w in weights] if want_coef else None
-    lib = _hip.lib()
-    args = (rule, lr_mode, n, _hip.ptr_array(weights), _hip.ptr_array(grads), _hip.ptr_array(lrs),
-            _hip.ptr_array(m) if m is not None else None, _hip.ptr_array(s) if s is not None else None,
-            _hip.ptr_array(outs), _hip.ptr_array(coefs) if coefs is not None else None,
-            _hip.i64_array([w.numel() for w in weights]), _hip.f32_array(bc1), _hip.f32_array(sqrt_bc2),
-            beta1, beta2, eps, _hip.current_stream())
-    _hip.launch("mt_update", lambda: _hip.check(lib.savfi_mt_update_f32(*args), "savfi_mt_update_f32"))
+    _launch_mt_update(rule, lr_mode, list(weights), list(grads), list(lrs), m, s, outs, coefs, bc1, sqrt_bc2, beta1, beta2, eps)
     return outs, coefs
 
 
@@ -377,14 +394,19 @@ def mt_scale(gamma, weights):
 # Fused L1 / MSE                                                     (loss.py:287-290)
 # --------------------------------------------------------------------------------------------
 class _L1Mse(torch.autograd.Function):
+    """a, b [rows, ...] -> float32[rows] of per-row mean |a-b| (kind 0) / mean (a-b)^2 (kind 1); deterministic."""
+
     @staticmethod
     def forward(ctx, kind, a, b):
         _hip.require_cuda(a, b)
         assert a.shape == b.shape
-        res = torch.zeros((), dtype=torch.float32, device=a.device)
+        rows = a.shape[0]
+        n = a.numel() // rows
+        res = torch.empty(rows, dtype=torch.float32, device=a.device)
+        scratch = torch.empty(_workspace_floats("savfi_l1_mse_scratch_floats", rows, n), dtype=torch.float32, device=a.device)
         lib = _hip.lib()
         _hip.launch("l1_mse", lambda: _hip.check(lib.savfi_l1_mse_f32(
-            kind, a.data_ptr(), b.data_ptr(), res.data_ptr(), a.numel(), _hip.current_stream()),
+            kind, a.data_ptr(), b.data_ptr(), res.data_ptr(), scratch.data_ptr(), rows, n, _hip.current_stream()),
             "savfi_l1_mse_f32"))
         ctx.kind = kind
         ctx.save_for_backward(a, b)
@@ -396,24 +418,44 @@ class _L1Mse(torch.autograd.Function):
         a, b = ctx.saved_tensors
         g = g.contiguous()
         ga = torch.empty_like(a)
+        rows = a.shape[0]
         lib = _hip.lib()
         _hip.launch("l1_mse_bwd", lambda: _hip.check(lib.savfi_l1_mse_bwd_f32(
-            ctx.kind, a.data_ptr(), b.data_ptr(), g.data_ptr(), ga.data_ptr(), a.numel(),
+            ctx.kind, a.data_ptr(), b.data_ptr(), g.data_ptr(), ga.data_ptr(), rows, a.numel() // rows,
             _hip.current_stream()), "savfi_l1_mse_bwd_f32"))
         gb = -ga if ctx.needs_input_grad[2] else None
         return None, ga, gb
 
 
+def _loss_rows(kind, a, b):
+    a, b = a.contiguous(), b.contiguous()
+    return _L1Mse.apply(kind, a.reshape(1, -1) if a.dim() < 2 else a, b.reshape(1, -1) if b.dim() < 2 else b)
+
+
 def l1_loss(a, b):
+    """nn.L1Loss(): mean over everything (loss.py:287)."""
     if double_backward():
         return torch.nn.functional.l1_loss(a, b)
-    return _L1Mse.apply(0, a.contiguous(), b.contiguous())
+    return _L1Mse.apply(0, a.contiguous().reshape(1, -1), b.contiguous().reshape(1, -1)).reshape(())
 
 
 def mse_loss(a, b):
     if double_backward():
         return torch.nn.functional.mse_loss(a, b)
-    return _L1Mse.apply(1, a.contiguous(), b.contiguous())
+    return _L1Mse.apply(1, a.contiguous().reshape(1, -1), b.contiguous().reshape(1, -1)).reshape(())
+
+
+def l1_loss_per_sample(a, b):
+    """[N,...] x [N,...] -> [N]: nn.L1Loss() of every sample on its own (tasks adapted in lockstep), one launch."""
+    if double_backward():
+        return (a - b).abs().flatten(1).mean(1)
+    return _loss_rows(0, a, b)
+
+
+def mse_loss_per_sample(a, b):
+    if double_backward():
+        return (a - b).pow(2).flatten(1).mean(1)
+    return _loss_rows(1, a, b)
 
 
 # --------------------------------------------------------------------------------------------
@@ -594,6 +636,169 @@ class _ConvBiasAct(torch.autograd.Function):
             gx = gx2 if need_x else gx
             gw = gw2 if need_w else gw
         return gx, gw, gb, None, None, None, None, None
+
+
+# --------------------------------------------------------------------------------------------
+# The same fused conv for T tasks adapted in LOCKSTEP (reference: the sequential task loop meta_learning_system.py:366).
+# Activations [n*T, C, H, W] are ordered sample-major (sample s = j*T + t belongs to task t), fast weights are stacked
+# [T, Co, Ci, kh, kw] / [T, Co]: one launch per layer for the whole meta-batch.  Large-enough 3x3 layers run on the savfi
+# kernels with a task index on the grid (per-task filter sets); everything else is ONE grouped MIOpen convolution --
+# [n*T, C, H, W] viewed as [n, T*C, H, W] with groups = T, which the sample-major order makes a free view in and out.
+# --------------------------------------------------------------------------------------------
+# Thresholds from tools/tasks_bench.py (profiles/r02_tasks_bench_*.jsonl; T = 4 tasks x 2 samples).  Forward / data gradient:
+# the savfi kernel wins or ties everywhere down to 24x32 maps (against 4 MIOpen calls: 1.1-2x); ONE grouped MIOpen call is
+# ~15 % ahead on the 24x32 / 12x16 layers only (2 % of a step), not worth a second code path.  Weight gradient: the savfi
+# kernel works on 64-pixel row segments and loses on maps under ~3000 px (512->512 @12x16: 311 us vs 111 us grouped);
+# MIOpen's grouped weight gradient collapses on LARGE maps (10.5 ms at 384x512), so those always stay here, whatever Ci.
+TASKS_MIN_TILES_FWD = 1          # N * ceil(Ho/2) * ceil(Wo/2) tiles over all tasks
+TASKS_MIN_TILES_BWD = 1
+TASKS_WGRAD_MIN_PIXELS = 3000
+if os.environ.get('SAVFI_TASKS_TILES'):      # experiment knob: "fwd,bwd,wgrad_pixels"
+    TASKS_MIN_TILES_FWD, TASKS_MIN_TILES_BWD, TASKS_WGRAD_MIN_PIXELS = (int(t) for t in os.environ['SAVFI_TASKS_TILES'].split(','))
+
+
+def _is3x3s1(weight, stride, padding, dilation):
+    one = lambda v, k: (v == k) if isinstance(v, int) else all(t == k for t in v)
+    pad = padding if isinstance(padding, int) else (padding[0] if padding[0] == padding[1] else -1)
+    return tuple(weight.shape[-2:]) == (3, 3) and one(stride, 1) and one(dilation, 1) and pad in (0, 1)
+
+
+def conv3x3_tasks_eligible(x, weight, stride, padding, dilation, backward=False):
+    if not (WINOGRAD_CONV and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and _is3x3s1(weight, stride, padding, dilation)):
+        return False
+    pad = padding if isinstance(padding, int) else padding[0]
+    N, _, H, W = x.shape
+    Ho, Wo = H + 2 * pad - 2, W + 2 * pad - 2
+    if Ho < 1 or Wo < 1 or H * W < 4:
+        return False
+    return N * ((Ho + 1) // 2) * ((Wo + 1) // 2) >= (TASKS_MIN_TILES_BWD if backward else TASKS_MIN_TILES_FWD)
+
+
+def conv3x3_wgrad_tasks_eligible(x, weight, stride, padding, dilation):
+    if not (WINOGRAD_CONV and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and _is3x3s1(weight, stride, padding, dilation)):
+        return False
+    pad = padding if isinstance(padding, int) else padding[0]
+    _, Ci, H, W = x.shape
+    Ho, Wo = H + 2 * pad - 2, W + 2 * pad - 2
+    return Ho * Wo >= TASKS_WGRAD_MIN_PIXELS
+
+
+def conv3x3_tasks(x, weight, bias=None, mode=0, slope=1.0, pad=1):
+    """savfi_conv3x3_tasks_f32 without autograd: weight [T,Co,Ci,3,3], bias [T,Co] or None; sample n uses task n % T."""
+    x, weight = x.contiguous(), weight.contiguous()
+    _hip.require_cuda(x, weight)
+    N, _, H, W = x.shape
+    T, Co, Ci = weight.shape[:3]
+    assert N % T == 0 and tuple(weight.shape[3:]) == (3, 3) and x.shape[1] == (Ci if mode == 0 else Co), (x.shape, weight.shape, mode)
+    I = Co if mode == 0 else Ci
+    grow = 2 * (pad if mode == 0 else 2 - pad) - 2
+    lib = _hip.lib()
+    ws = torch.empty(_workspace_floats("savfi_conv3x3_tasks_workspace_floats", N, T, Ci, Co, H, W, int(pad), mode), dtype=x.dtype, device=x.device)
+    out = torch.empty((N, I, H + grow, W + grow), dtype=x.dtype, device=x.device)
+    _hip.launch("conv3x3_fwd" if mode == 0 else "conv3x3_bwd_data", lambda: _hip.check(lib.savfi_conv3x3_tasks_f32(
+        x.data_ptr(), weight.data_ptr(), None if bias is None else bias.data_ptr(), out.data_ptr(), ws.data_ptr(),
+        N, T, Ci, Co, H, W, int(pad), mode, float(slope), _hip.current_stream()), "savfi_conv3x3_tasks_f32"))
+    return out
+
+
+def conv3x3_wgrad_tasks(x, gz, T, pad=1):
+    """savfi_conv3x3_wgrad_tasks_f32: gw [T,Co,Ci,3,3], gw[t] over the samples n % T == t."""
+    x, gz = x.contiguous(), gz.contiguous()
+    _hip.require_cuda(x, gz)
+    N, Ci, H, W = x.shape
+    Co = gz.shape[1]
+    assert N % T == 0 and tuple(gz.shape) == (N, Co, H + 2 * pad - 2, W + 2 * pad - 2), (x.shape, gz.shape, pad, T)
+    lib = _hip.lib()
+    ws = torch.empty(_workspace_floats("savfi_conv3x3_wgrad_tasks_workspace_floats", N, T, Ci, Co, H, W, int(pad)), dtype=x.dtype, device=x.device)
+    gw = torch.empty((T, Co, Ci, 3, 3), dtype=x.dtype, device=x.device)
+    _hip.launch("conv3x3_wgrad", lambda: _hip.check(lib.savfi_conv3x3_wgrad_tasks_f32(
+        x.data_ptr(), gz.data_ptr(), gw.data_ptr(), ws.data_ptr(), N, T, Ci, Co, H, W, int(pad), _hip.current_stream()),
+        "savfi_conv3x3_wgrad_tasks_f32"))
+    return gw
+
+
+def conv2d_tasks(x, weight, bias, stride=1, padding=0, dilation=1):
+    """conv2d of [n*T, Ci, H, W] (sample-major) with per-task weights [T, Co, Ci, kh, kw] / bias [T, Co] as one grouped
+    convolution; composed of differentiable torch ops (second order, CPU host-logic tests)."""
+    T, Co, Ci = weight.shape[:3]
+    N, _, H, W = x.shape
+    n = N // T
+    z = torch.nn.functional.conv2d(x.reshape(n, T * Ci, H, W), weight.reshape(T * Co, Ci, *weight.shape[3:]),
+                                   None if bias is None else bias.reshape(T * Co), stride, padding, dilation, T)
+    return z.reshape(N, Co, z.shape[2], z.shape[3])
+
+
+class _ConvBiasActTasks(torch.autograd.Function):
+    """y = act(conv2d(x[s], w[s % T]) + b[s % T]) for every sample s.  First-order only (like _ConvBiasAct)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, padding, dilation, slope):
+        x = x.contiguous()
+        T, Co, Ci = w.shape[:3]
+        N, _, H, W = x.shape
+        n = N // T
+        pad = padding if isinstance(padding, int) else padding[0]
+        if conv3x3_tasks_eligible(x, w, stride, padding, dilation):
+            z = conv3x3_tasks(x, w, b, 0, slope, pad)
+        else:
+            z = torch.nn.functional.conv2d(x.view(n, T * Ci, H, W), w.reshape(T * Co, Ci, *w.shape[3:]), None, stride, padding,
+                                           dilation, T)
+            if not z.is_contiguous():
+                z = z.contiguous()
+            _hip.require_cuda(z, b)
+            lib = _hip.lib()
+            hw = z.shape[2] * z.shape[3]
+            _hip.launch("bias_act_fwd", lambda: _hip.check(lib.savfi_bias_act_fwd_f32(
+                z.data_ptr(), b.data_ptr(), n, T * Co, hw, slope, _hip.current_stream()), "savfi_bias_act_fwd_f32"))
+            z = z.view(N, Co, z.shape[2], z.shape[3])
+        ctx.conf = (stride, padding, dilation, slope)
+        ctx.save_for_backward(x, w, z)
+        return z
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        stride, padding, dilation, slope = ctx.conf
+        gy = gy.contiguous()
+        T, Co, Ci = w.shape[:3]
+        N, _, Ho, Wo = y.shape
+        n = N // T
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        identity = slope == 1.0
+        gz = gy if identity else torch.empty_like(gy)
+        gb = torch.empty((T, Co), dtype=gy.dtype, device=gy.device) if need_b else None
+        if need_b or not identity:
+            lib = _hip.lib()
+            scratch = (torch.empty(_workspace_floats("savfi_bias_act_scratch_floats", n, T * Co, Ho * Wo), dtype=gy.dtype, device=gy.device)
+                       if need_b else None)
+            _hip.launch("bias_act_bwd", lambda: _hip.check(lib.savfi_bias_act_bwd_f32(
+                gy.data_ptr(), (gy if identity else y).data_ptr(), None if identity else gz.data_ptr(),
+                None if gb is None else gb.data_ptr(), None if scratch is None else scratch.data_ptr(),
+                n, T * Co, Ho * Wo, slope, _hip.current_stream()), "savfi_bias_act_bwd_f32"))
+        gx = gw = None
+        pad = padding if isinstance(padding, int) else padding[0]
+        if need_x and conv3x3_tasks_eligible(x, w, stride, padding, dilation, backward=True):
+            gx = conv3x3_tasks(gz, w, None, 1, 1.0, pad)
+            need_x = False
+        if need_w and conv3x3_wgrad_tasks_eligible(x, w, stride, padding, dilation):
+            gw = conv3x3_wgrad_tasks(x, gz, T, pad)
+            need_w = False
+        if need_x or need_w:
+            pair = lambda v: [v, v] if isinstance(v, int) else list(v)
+            H, W = x.shape[2:]
+            gx2, gw2, _ = torch.ops.aten.convolution_backward(
+                gz.view(n, T * Co, Ho, Wo), x.view(n, T * Ci, H, W), w.reshape(T * Co, Ci, *w.shape[3:]), None, pair(stride),
+                pair(padding), pair(dilation), False, [0, 0], T, [need_x, need_w, False])
+            if need_x:
+                gx = gx2.contiguous().view(N, Ci, H, W)
+            if need_w:
+                gw = gw2.view(w.shape)
+        return gx, gw, gb, None, None, None, None
+
+
+def conv_bias_act_tasks(x, weight, bias, stride=1, padding=0, dilation=1, slope=0.0):
+    """act(conv2d(x[s], weight[s % T]) + bias[s % T]): the lockstep form of conv_bias_act."""
+    return _ConvBiasActTasks.apply(x, weight, bias, stride, padding, dilation, float(slope))
 
 
 @functools.lru_cache(maxsize=None)

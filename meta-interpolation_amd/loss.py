@@ -9,6 +9,7 @@ import torch.nn as nn
 from . import hip_ops
 
 _KERNELS = {'L1': hip_ops.l1_loss, 'MSE': hip_ops.mse_loss}
+_KERNELS_PER_SAMPLE = {'L1': hip_ops.l1_loss_per_sample, 'MSE': hip_ops.mse_loss_per_sample}
 
 
 class Loss(nn.modules.loss._Loss):
@@ -26,6 +27,18 @@ class Loss(nn.modules.loss._Loss):
     def loss_keys(self):
         """Keys of the dict forward() returns (rank-independent: the logging all-reduce is laid out from them)."""
         return [l['type'] for l in self.loss] + ['total']
+
+    def per_sample(self, sr, hr):
+        """The same terms for every sample of a batch on its own: {TYPE: [N], 'total': [N]} (tasks adapted in lockstep:
+        the reference evaluates the criterion once per task on N=1 tensors, meta_learning_system.py:389-395)."""
+        total = 0
+        losses = {}
+        for l in self.loss:
+            eff = l['weight'] * _KERNELS_PER_SAMPLE[l['type']](sr, hr)
+            losses[l['type']] = eff
+            total = total + eff
+        losses['total'] = total
+        return losses
 
     def forward(self, sr, hr, **kwargs):
         total = 0

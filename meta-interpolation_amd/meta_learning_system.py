@@ -179,6 +179,7 @@ class SceneAdaptiveInterpolation(nn.Module):
         self._defer_logging = False
         self._pending_logging = None
         self._task_stream_pool = None
+        self._routes = None          # (routed, unrouted) inner-loop tensor names, probed once (_routing)
         self._graphs = {}            # (frame shape, steps, training, msl) -> GraphedInnerLoop
         self._manual_grads = None    # OuterGradAccumulator of the last graphed training forward
 
@@ -374,7 +375,117 @@ class SceneAdaptiveInterpolation(nn.Module):
             self.net.restore_backup_stats()
         return res
 
-    def _run_tasks(self, local, body):
+    # -----------------------------------------------------------------------------------------
+    # tasks in lockstep (--task_batch T): the reference's sequential task loop (:366) as ONE pass per inner step
+    # -----------------------------------------------------------------------------------------
+    def _routing(self, frame_shape):
+        """(routed, unrouted) inner-loop tensor names: which of them the plugin actually reads from the fast-weight dict
+        (SepConv 54 of 94, VoxelFlow 9 of 23, CAIN 494 of 494: SURVEY.md fact 6).  One eager pass on cloned tensors, once."""
+        if self._routes is None:
+            theta = self.get_inner_loop_parameter_dict(self.net.named_parameters())
+            fast = {k: v.detach().clone().requires_grad_() for k, v in theta.items()}
+            x = torch.zeros((1,) + tuple(frame_shape), device=self.device)
+            out = self.net.forward(x, x, params=fast, backup_running_statistics=False, num_step=0)
+            out = out[0] if isinstance(out, tuple) else out
+            g = torch.autograd.grad(out.sum(), list(fast.values()), allow_unused=True)
+            self._routes = ([k for k, gi in zip(fast, g) if gi is not None], [k for k, gi in zip(fast, g) if gi is None])
+        return self._routes
+
+    def _lockstep_width(self, use_second_order, frame_shape):
+        """Tasks per lockstep group, or 0 when this pass must take the sequential loop (second order; L2F on a plugin that
+        does not route every tensor: its per-task embedding needs per-task gradients of the plugin's own parameters)."""
+        width = int(getattr(self.args, 'task_batch', 0) or 0)
+        if width <= 1 or use_second_order:
+            return 0
+        if self.args.attenuate and self._routing(frame_shape)[1]:
+            return 0
+        return width
+
+    def _lockstep_body(self, frames, ids, *, num_steps, msl, training_phase, do_evaluation, importance):
+        """What _task_body computes for every task in `ids`, with the T tasks advancing together: activations are
+        [n*T, C, H, W] in sample-major order (sample j*T + t belongs to task t), fast weights are stacked [T, *shape], every
+        layer is one launch for the whole group (hip_ops.conv_bias_act_tasks), the rule updates the stacked tensors, and the
+        criterion is evaluated per sample.  First order only.  Tasks never mix: each task's numbers are those of the
+        sequential loop (same kernels per task where the savfi kernels run; MIOpen's grouped solvers elsewhere).
+
+        One difference, invisible in any output: tensors the plugin never reads from the fast dict (SepConv's Subnet /
+        Upsample copies) are not carried through step 0.  The reference updates those copies once and never uses them
+        (SURVEY.md fact 6); a shared-weight pass cannot give their per-task gradients."""
+        T = len(ids)
+        routed, _ = self._routing(frames[0].shape[1:])
+        theta = self.get_inner_loop_parameter_dict(self.net.named_parameters())
+        sel = torch.as_tensor(ids, device=self.device)
+        consecutive = list(ids) == list(range(ids[0], ids[0] + T))
+        pick = (lambda i: frames[i][ids[0]:ids[0] + T]) if consecutive else (lambda i: frames[i].index_select(0, sel))
+        W = {k: theta[k].unsqueeze(0).expand(T, *theta[k].shape).contiguous() for k in routed}
+        self.inner_loop_optimizer.initialize_state()
+        a, b = self.support_idxs
+        sup = [torch.cat([pick(a[i]), pick(b[i])], 0) for i in range(3)]           # frame0 | target | frame1, [2T,3,H,W]
+        tgt = [pick(i) for i in self.target_idxs]
+
+        def support_loss(weights, num_step):
+            model_utils.set_own_params_const(True)      # first-order support pass: the plugin's own parameters are constants
+            try:
+                out = self.net.forward(sup[0], sup[2], params=weights, backup_running_statistics=(num_step == 0), num_step=num_step)
+            finally:
+                model_utils.set_own_params_const(False)
+            out = out[0] if isinstance(out, tuple) else out
+            return self.criterion.per_sample(out, sup[1])['total'].sum()
+
+        def target_pass(weights, num_step):
+            out = self.net.forward(tgt[0], tgt[2], params=weights, backup_running_statistics=False, num_step=num_step)
+            out = out[0] if isinstance(out, tuple) else out
+            return self.criterion.per_sample(out, tgt[1]), out
+
+        if self.args.attenuate:        # L2F per task: embedding [T, L] -> gamma [T, L] -> w_i <- gamma_i * w_i
+            keys = list(W)
+            loss = support_loss(W, 0)
+            grads = torch.autograd.grad(loss, [W[k] for k in keys])
+            emb = hip_ops.mt_mean([g[t] for g in grads for t in range(T)]).view(len(keys), T).t()
+            gamma = 1 - self.gamma_mult * self.attenuator(emb)
+            gamma.clamp_(0, 1)
+            W = {k: gamma[:, i].reshape((T,) + (1,) * (W[k].dim() - 1)) * W[k] for i, k in enumerate(keys)}
+
+        task_terms, logs, preds = [], [[] for _ in range(T)], None
+        for num_step in range(num_steps):
+            loss = support_loss(W, num_step)
+            keys = list(W)
+            grads = torch.autograd.grad(loss, [W[k] for k in keys], allow_unused=True)
+            W = self.inner_loop_optimizer.update_params(names_weights_dict=W, names_grads_wrt_params_dict=dict(zip(keys, grads)),
+                                                        num_step=num_step)
+            if msl:
+                parts, preds = target_pass(W, num_step)
+                task_terms.append(importance[num_step] * parts['total'])
+                for k, v in parts.items():
+                    for t in range(T):
+                        logs[t].append((k, v[t]))
+        if not training_phase:
+            with torch.no_grad():
+                parts, preds = target_pass(W, num_steps)
+        elif not msl:
+            parts, preds = target_pass(W, num_steps)
+        if not training_phase or not msl:
+            task_terms.append(parts['total'])
+            for k, v in parts.items():
+                for t in range(T):
+                    logs[t].append((k, v[t]))
+        per_task = torch.stack(task_terms, 0).sum(0)                            # [T]
+        preds = preds.detach()
+        results = []
+        for t, task_id in enumerate(ids):
+            res = {'pred': self._to_unit_range(preds[t]).unsqueeze(0), 'logs': logs[t], 'loss': per_task[t]}
+            if do_evaluation:
+                out01 = self._to_unit_range(preds[t])
+                tgt01 = self._to_unit_range(frames[self.target_idxs[1]][task_id].detach())
+                q_o, q_t = utils.quantize(out01, 1.), utils.quantize(tgt01, 1.)
+                res['mse'] = (q_o - q_t).div(255).pow(2).mean()
+                res['ssim'] = utils.ssim(q_o.unsqueeze(0), q_t.unsqueeze(0), val_range=255)
+            results.append(res)
+        if not training_phase:
+            self.net.restore_backup_stats()
+        return results
+
+    def _run_tasks(self, local, body, flatten=None):
         """Results of body(task) for the local tasks, in order.  With --task_streams N > 1 on a GPU the tasks are spread
         over N Python threads, each on its own HIP stream: tasks are independent, and the many small kernels of the deep
         layers (a 12x16 map occupies a fraction of the 256 CUs) then overlap with another task's instead of queueing
@@ -413,10 +524,11 @@ class SceneAdaptiveInterpolation(nn.Module):
             cur.wait_stream(s)
         if errors:
             raise errors[0]
-        for res in results.values():                            # produced on a side stream, consumed on the caller's
-            for v in [res['loss'], res['pred'], res.get('mse'), res.get('ssim')] + [v for _, v in res['logs']]:
-                if torch.is_tensor(v) and v.is_cuda:
-                    v.record_stream(cur)
+        for packed in results.values():                         # produced on a side stream, consumed on the caller's
+            for res in ([packed] if flatten is None else flatten(packed)):
+                for v in [res['loss'], res['pred'], res.get('mse'), res.get('ssim')] + [v for _, v in res['logs']]:
+                    if torch.is_tensor(v) and v.is_cuda:
+                        v.record_stream(cur)
         return [results[t] for t in local]
 
     def forward(self, data_batch, epoch, use_second_order, use_multi_step_loss_optimization, num_steps,
@@ -443,7 +555,19 @@ class SceneAdaptiveInterpolation(nn.Module):
 
         body = functools.partial(self._task_body, frames, num_steps=num_steps, use_second_order=use_second_order, msl=msl,
                                  training_phase=training_phase, do_evaluation=do_evaluation, importance=importance)
-        for task_id, res in zip(local, self._run_tasks(local, body)):
+        width = self._lockstep_width(use_second_order, frames[0].shape[1:]) if len(local) > 1 else 0
+        if width:
+            results = []
+            for lo in range(0, len(local), width):
+                group = local[lo:lo + width]
+                if len(group) == 1:
+                    results.append(body(group[0]))
+                else:
+                    results.extend(self._lockstep_body(frames, group, num_steps=num_steps, msl=msl, training_phase=training_phase,
+                                                       do_evaluation=do_evaluation, importance=importance))
+        else:
+            results = self._run_tasks(local, body)
+        for task_id, res in zip(local, results):
             total_losses.append(res['loss'])
             preds[task_id] = res['pred']
             for k, v in res['logs']:
@@ -517,40 +641,54 @@ class SceneAdaptiveInterpolation(nn.Module):
         self._set_pass_flags(False)
         key = (tuple(frames[0].shape[1:]), num_steps, bool(training_phase), msl)
         local = self._local_tasks(num_tasks, training_phase)
-        # --task_streams N: N graph sets (own static buffers and memory pool each), replayed from N threads on N streams
-        n = max(1, min(int(getattr(self.args, 'task_streams', 1) or 1), len(local)))
-        loops = []
-        for i in range(n):
-            if key + (i,) not in self._graphs:
+        # --task_batch T: groups of T tasks advance in lockstep through ONE graph set (a shorter last group gets its own);
+        # --task_streams N: N graph sets per width (own static buffers and memory pool each), replayed from N threads
+        width = max(1, int(getattr(self.args, 'task_batch', 0) or 0))
+        groups = [local[i:i + width] for i in range(0, len(local), width)]
+        n = max(1, min(int(getattr(self.args, 'task_streams', 1) or 1), len(groups)))
+
+        def loop_for(i, T):
+            if key + (i, T) not in self._graphs:
                 import gc
                 gc.collect()
-                self._graphs[key + (i,)] = graph_inner_loop.GraphedInnerLoop(self, frames[0].shape[1:], num_steps,
-                                                                             bool(training_phase), msl)
-            loops.append(self._graphs[key + (i,)])
+                self._graphs[key + (i, T)] = graph_inner_loop.GraphedInnerLoop(self, frames[0].shape[1:], num_steps,
+                                                                               bool(training_phase), msl, tasks=T)
+            return self._graphs[key + (i, T)]
+        owner = {tuple(g): j % n for j, g in enumerate(groups)}
+        for g in groups:                                   # capture on this thread, before any worker starts
+            loop_for(owner[tuple(g)], len(g))
         importance = self.get_per_step_loss_importance_vector()
-        accums = [graph_inner_loop.OuterGradAccumulator(self, gl.theta) if training_phase else None for gl in loops]
+        accums = [graph_inner_loop.OuterGradAccumulator(self, self.get_inner_loop_parameter_dict(self.net.named_parameters()))
+                  if training_phase else None for _ in range(n)]
 
-        def body(i, task_id):
-            task_loss, pred, logs = loops[i].run_task(frames, task_id, importance, accums[i])
-            res = {'loss': task_loss, 'pred': self._to_unit_range(pred.squeeze(0)).unsqueeze(0),
-                   'logs': [(k, v) for parts in logs for k, v in parts.items()]}
-            if do_evaluation:
-                out01 = self._to_unit_range(pred.squeeze(0))
-                tgt01 = self._to_unit_range(frames[self.target_idxs[1]][task_id].detach())
-                q_o, q_t = utils.quantize(out01, 1.), utils.quantize(tgt01, 1.)
-                res['mse'] = (q_o - q_t).div(255).pow(2).mean()
-                res['ssim'] = utils.ssim(q_o.unsqueeze(0), q_t.unsqueeze(0), val_range=255)
-            return res
+        def body(group):
+            i = owner[tuple(group)]
+            task_losses, preds_g, logs_g = loop_for(i, len(group)).run_tasks(frames, list(group), importance, accums[i])
+            out = []
+            for t, task_id in enumerate(group):
+                pred = preds_g[t]
+                res = {'loss': task_losses[t], 'pred': self._to_unit_range(pred).unsqueeze(0),
+                       'logs': [(k, v) for parts in logs_g[t] for k, v in parts.items()]}
+                if do_evaluation:
+                    out01 = self._to_unit_range(pred)
+                    tgt01 = self._to_unit_range(frames[self.target_idxs[1]][task_id].detach())
+                    q_o, q_t = utils.quantize(out01, 1.), utils.quantize(tgt01, 1.)
+                    res['mse'] = (q_o - q_t).div(255).pow(2).mean()
+                    res['ssim'] = utils.ssim(q_o.unsqueeze(0), q_t.unsqueeze(0), val_range=255)
+                out.append(res)
+            return out
 
         if n == 1:
-            results = [body(0, t) for t in local]
+            grouped = [body(g) for g in groups]
         else:
-            owner = {t: j % n for j, t in enumerate(local)}
-            results = self._run_tasks(local, lambda t: body(owner[t], t))
+            index = {j: g for j, g in enumerate(groups)}
+            by_index = self._run_tasks(list(index), lambda j: {'group': body(index[j])}, flatten=lambda r: r['group'])
+            grouped = [r['group'] for r in by_index]
             cur = torch.cuda.current_stream()
             for a in accums:                     # summed on the worker streams, merged / installed on this one
                 for t in (a.tensors() if a is not None else []):
                     t.record_stream(cur)
+        results = [res for group in grouped for res in group]
         accum = accums[0]
         for other in accums[1:]:
             if other is not None:

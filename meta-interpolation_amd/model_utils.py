@@ -191,6 +191,17 @@ class MetaConv2dLayer(nn.Module):
             weight, bias = self.weight.detach(), (self.bias.detach() if self.bias is not None else None)
         else:
             weight, bias = self.weight, self.bias
+        if weight.dim() == 5:
+            # fast weights stacked over the tasks of a meta-batch adapted in lockstep: [T, Co, Ci, kh, kw], x [n*T, ...]
+            if bias is not None and x.is_cuda and fuse_conv_act() and self.groups == 1 and (
+                    act_slope is not None or hip_ops.conv3x3_tasks_eligible(x, weight, self.stride, padding, self.dilation_rate)):
+                return hip_ops.conv_bias_act_tasks(x, weight, bias, self.stride, padding, self.dilation_rate,
+                                                   1.0 if act_slope is None else act_slope)
+            assert self.groups == 1, "lockstep tasks on a grouped convolution"
+            out = hip_ops.conv2d_tasks(x, weight, bias, self.stride, padding, self.dilation_rate)
+            if act_slope is not None:
+                out = F.relu(out) if act_slope == 0.0 else F.leaky_relu(out, act_slope)
+            return out
         if bias is not None and x.is_cuda and fuse_conv_act():
             if act_slope is not None:
                 return hip_ops.conv_bias_act(x, weight, bias, self.stride, padding, self.dilation_rate, self.groups,

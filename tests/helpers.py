@@ -169,12 +169,20 @@ class CpuL1(torch.nn.Module):
         l = torch.nn.functional.l1_loss(out, tgt)
         return {'L1': l, 'total': l}
 
+    def per_sample(self, out, tgt):
+        l = (out - tgt).abs().flatten(1).mean(1)
+        return {'L1': l, 'total': l}
 
-def build_toy_system(task_parallel=None, steps=2, batch=4, seed=0, msl=False):
+    def loss_keys(self):
+        return ['L1', 'total']
+
+
+def build_toy_system(task_parallel=None, steps=2, batch=4, seed=0, msl=False, task_batch=0):
     from meta_interpolation_amd.meta_learning_system import SceneAdaptiveInterpolation
     args = default_args(model='toy', num_gpu=0, optimizer='SGD', inner_lr=0.05, outer_lr=0.01, batch_size=batch,
                         number_of_training_steps_per_iter=steps, number_of_evaluation_steps_per_iter=steps,
-                        use_multi_step_loss_optimization=msl, multi_step_loss_num_epochs=5, fuse_support_pairs=0)
+                        use_multi_step_loss_optimization=msl, multi_step_loss_num_epochs=5, fuse_support_pairs=0,
+                        task_batch=task_batch)
     torch.manual_seed(seed)
     net = ToyNet()
     return SceneAdaptiveInterpolation(args, net=net, inner_loop_optimizer=OracleRule('lslr', 'SGD', 0.05, steps),

@@ -522,3 +522,88 @@ def test_conv3x3_weight_gradient_matches_autograd_and_is_deterministic(shape, pa
     assert (got.cpu().double() - want).abs().max() <= 3e-6 * want.abs().max()
     again = hip_ops.conv3x3_wgrad(x.cuda(), gz.cuda(), pad)
     assert torch.equal(got, again)                       # fixed-order reductions: bit-reproducible
+
+
+# ---------------------------------------------------------------------------------------------
+# tasks in lockstep: per-task filter sets in one launch (savfi_conv3x3_tasks_f32, savfi_conv3x3_wgrad_tasks_f32,
+# hip_ops.conv_bias_act_tasks) against the same op run once per task
+# ---------------------------------------------------------------------------------------------
+TASK_CONV_CASES = [  # T, n (samples per task), Ci, Co, H, W
+    (4, 2, 6, 32, 40, 72), (4, 2, 64, 64, 24, 32), (3, 1, 51, 51, 33, 29), (2, 2, 512, 512, 4, 6), (4, 1, 128, 256, 12, 16),
+    (4, 2, 32, 32, 96, 128)]
+
+
+@pytest.mark.parametrize("pad", [1, 0])
+@pytest.mark.parametrize("T,n,Ci,Co,H,W", TASK_CONV_CASES)
+def test_conv3x3_tasks_equals_one_launch_per_task(T, n, Ci, Co, H, W, pad):
+    if pad == 0 and min(H, W) < 3:
+        pytest.skip("no output")
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(n * T, Ci, H, W, generator=g).to(DEV)
+    w = (torch.randn(T, Co, Ci, 3, 3, generator=g) / (3 * Ci ** 0.5)).to(DEV)
+    b = torch.randn(T, Co, generator=g).to(DEV)
+    y = hip_ops.conv3x3_tasks(x, w, b, 0, 0.2, pad)
+    gy = torch.randn(y.shape, generator=g).to(DEV)
+    gx = hip_ops.conv3x3_tasks(gy, w, None, 1, 1.0, pad)
+    for t in range(T):
+        sel = torch.arange(t, n * T, T, device=DEV)            # sample-major: task t owns samples t, t+T, ...
+        yt = hip_ops.conv3x3(x[sel], w[t], b[t], 0, 0.2, pad)
+        assert _rel(y[sel], yt) < 2e-6, (t, 'forward')           # same kernel and filters (deep layers may split the reduction differently)
+        gxt = hip_ops.conv3x3(gy[sel], w[t], None, 1, 1.0, pad)
+        assert _rel(gx[sel], gxt) < 2e-6, (t, 'data gradient')
+    ref = torch.nn.functional.leaky_relu(hip_ops.conv2d_tasks(x, w, b, 1, pad, 1), 0.2)
+    assert _rel(y, ref) < 2e-5
+
+
+@pytest.mark.parametrize("pad", [1, 0])
+@pytest.mark.parametrize("T,n,Ci,Co,H,W", [c for c in TASK_CONV_CASES if c[2] >= 16])
+def test_conv3x3_wgrad_tasks_equals_per_task_gradients(T, n, Ci, Co, H, W, pad):
+    if pad == 0 and min(H, W) < 3:
+        pytest.skip("no output")
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(n * T, Ci, H, W, generator=g).to(DEV)
+    gz = torch.randn(n * T, Co, H + 2 * pad - 2, W + 2 * pad - 2, generator=g).to(DEV)
+    gw = hip_ops.conv3x3_wgrad_tasks(x, gz, T, pad)
+    again = hip_ops.conv3x3_wgrad_tasks(x, gz, T, pad)
+    assert torch.equal(gw, again)                                  # deterministic
+    for t in range(T):
+        sel = torch.arange(t, n * T, T, device=DEV)
+        want = torch.ops.aten.convolution_backward(gz[sel].double(), x[sel].double(), torch.zeros(Co, Ci, 3, 3, device=DEV).double(), None,
+                                                   [1, 1], [pad, pad], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+        assert _rel(gw[t], want.float()) < 2e-5, t
+
+
+@pytest.mark.parametrize("slope", [0.0, 0.2, 1.0])
+@pytest.mark.parametrize("T,n,Ci,Co,H,W,k,pad", [(4, 2, 32, 32, 48, 64, 3, 1), (4, 2, 64, 64, 12, 16, 3, 1), (3, 1, 6, 16, 20, 24, 5, 2),
+                                                   (2, 2, 192, 12, 1, 1, 1, 0), (4, 2, 51, 51, 34, 30, 3, 0)])
+def test_conv_bias_act_tasks_matches_per_task_torch(T, n, Ci, Co, H, W, k, pad, slope):
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(n * T, Ci, H, W, generator=g).to(DEV).requires_grad_()
+    w = (torch.randn(T, Co, Ci, k, k, generator=g) / (k * Ci ** 0.5)).to(DEV).requires_grad_()
+    b = torch.randn(T, Co, generator=g).to(DEV).requires_grad_()
+    y = hip_ops.conv_bias_act_tasks(x, w, b, 1, pad, 1, slope)
+    co = torch.randn(y.shape, generator=g).to(DEV)
+    gx, gw, gb = torch.autograd.grad((y * co).sum(), [x, w, b])
+    xr, wr, br = (t.detach().double().requires_grad_() for t in (x, w, b))
+    yr = hip_ops.conv2d_tasks(xr, wr, br, 1, pad, 1)
+    yr = yr if slope == 1.0 else torch.nn.functional.leaky_relu(yr, slope)
+    gxr, gwr, gbr = torch.autograd.grad((yr * co.double()).sum(), [xr, wr, br])
+    assert _rel(y, yr.float()) < 2e-5
+    assert _rel(gx, gxr.float()) < 2e-5 and _rel(gw, gwr.float()) < 5e-5 and _rel(gb, gbr.float()) < 2e-5
+    assert gw.shape == w.shape and gb.shape == b.shape
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_per_sample_losses(kind):
+    g = torch.Generator().manual_seed(3)
+    a = torch.rand(8, 3, 64, 72, generator=g).to(DEV).requires_grad_()
+    b = torch.rand(8, 3, 64, 72, generator=g).to(DEV)
+    fn = hip_ops.l1_loss_per_sample if kind == 0 else hip_ops.mse_loss_per_sample
+    got = fn(a, b)
+    want = ((a - b).abs() if kind == 0 else (a - b).pow(2)).flatten(1).mean(1)
+    assert got.shape == (8,) and _rel(got, want.detach()) < 1e-6
+    co = torch.randn(8, generator=g).to(DEV)
+    ga, = torch.autograd.grad((got * co).sum(), a)
+    gr, = torch.autograd.grad((want * co).sum(), a)
+    assert _rel(ga, gr) < 1e-6
+    assert torch.equal(fn(a, b), got)                              # fixed-order reduction: bit-reproducible

@@ -223,3 +223,33 @@ def test_outer_gradient_accumulators_merge_and_install():
     empty = OuterGradAccumulator(sysm, theta)
     empty.merge(two)                                                         # merging into an accumulator that saw no task
     assert torch.equal(empty.param['a'], two.param['a']) and empty.param['a'] is not two.param['a']
+
+
+# ---------------------------------------------------------------------------------------------
+# tasks in lockstep (--task_batch): host logic on CPU with the toy plugin -- stacked fast weights, sample-major batches,
+# per-sample criterion, outer gradients through the expand of theta; must equal the sequential task loop
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("msl", [False, True])
+@pytest.mark.parametrize("width", [2, 3, 5])
+def test_lockstep_tasks_equal_the_sequential_loop(msl, width):
+    from tests.helpers import build_toy_system
+    B = 5
+    frames = synthetic.septuplet_batch(B, 16, 24)
+    got = {}
+    for tb in (0, width):
+        system = build_toy_system(batch=B, msl=msl, task_batch=tb)
+        grads = {}
+        system.optimizer.step = lambda *a, **k: grads.update(
+            {n: p.grad.detach().clone() for n, p in system.named_parameters() if p.grad is not None})
+        losses, preds, metrics = system.run_train_iter(data_batch=frames, epoch=0, do_evaluation=True)
+        vl, vp, vm = system.run_validation_iter(data_batch=frames)
+        got[tb] = (losses, preds, metrics, grads, vl, vp, vm)
+    (l0, p0, m0, g0, vl0, vp0, vm0), (l1, p1, m1, g1, vl1, vp1, vm1) = got[0], got[width]
+    assert abs(float(l0['loss']) - float(l1['loss'])) < 1e-6 and abs(float(vl0['loss']) - float(vl1['loss'])) < 1e-6
+    assert abs(m0['psnr'].avg - m1['psnr'].avg) < 1e-4 and abs(vm0['psnr'].avg - vm1['psnr'].avg) < 1e-4
+    assert abs(float(l0['L1']) - float(l1['L1'])) < 1e-6
+    for a, b in zip(p0 + vp0, p1 + vp1):
+        assert a.shape == b.shape and torch.allclose(a, b, atol=1e-6)
+    assert set(g0) == set(g1) and any(k.startswith('inner_loop_optimizer') for k in g0)
+    for k in g0:
+        assert torch.allclose(g0[k], g1[k], rtol=1e-4, atol=1e-7), k

@@ -169,3 +169,31 @@ def test_experiment_builder_trains_and_validates_with_two_ranks(tmp_path):
     for k, v in r0['state'].items():                                # replicas identical after training + scheduler step
         assert torch.equal(v, r1['state'][k]), k
     assert os.path.exists(str(tmp_path / 'checkpoint' / 'toy2' / 'checkpoint.pth'))
+
+
+# ---------------------------------------------------------------------------------------------
+# bench.py's multi-process host path exactly as the driver launches it (torch.distributed.run, one rank per device),
+# on gloo with the toy CPU plugin: rendezvous from the environment, device pinning, task sharding, barrier + max-over-ranks
+# timing, ONE JSON line from rank 0
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("task_batch", [0, 2])
+def test_bench_runs_under_torch_distributed_run_with_two_ranks(task_batch):
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29500 + (os.getpid() % 2000) + 55 + task_batch
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "HIP_VISIBLE_DEVICES"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--workload", "toy_cpu", "--task-batch", str(task_batch)]
+    out = subprocess.run(cmd, cwd=repo, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout                       # rank 0 prints, rank 1 stays silent
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "weak"
+    assert line["config"]["global_meta_batch"] == 6 and line["config"]["mode"]["task_batch"] == task_batch
+    assert line["value"] > 0 and abs(line["value"] - 6 * 2 * 2 / (line["ms_per_step"] * 2e-3)) < 1e-6 * line["value"]

@@ -40,7 +40,7 @@ def main():
         g = golden("system_" + name)
         model = str(g['model'])
         for phase in ('train', 'val'):
-            system = build_system(model, parse_case_args(g))
+            system = build_system(model, dict(parse_case_args(g), task_batch=0))
             rec = observe(system, check_rule=True)
             frames = synthetic.septuplet_batch(int(g['B']), int(g['H']), int(g['W']), model=model)
             if phase == 'train':
