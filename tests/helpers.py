@@ -46,11 +46,16 @@ def fp(t):
     return np.array(v + [0.0] * (6 - len(v)))
 
 
+FP_ATOL = 1e-8     # absolute floor of a fingerprint sum: fp32 rounding of O(1) activations summed over a layer
+
+
 def assert_fp_close(got, want, rtol=1e-5, what=""):
-    """Fingerprints: [sum, abs-sum, first 4].  Compared relative to the abs-sum scale."""
+    """Fingerprints: [sum, abs-sum, first 4].  Compared relative to the abs-sum scale, with an absolute floor: the gradient
+    of a 12-element channel-attention bias has an abs-sum of 5e-6, and 1e-3 of that is below the rounding noise of the
+    convolutions it is summed from (seen as a run-order dependent 1.06e-3 on exactly that tensor)."""
     scale = max(abs(want[1]), 1e-12)
-    assert abs(got[0] - want[0]) <= rtol * scale, (what, got[0], want[0])
-    assert abs(got[1] - want[1]) <= rtol * scale, (what, got[1], want[1])
+    assert abs(got[0] - want[0]) <= rtol * scale + FP_ATOL, (what, got[0], want[0])
+    assert abs(got[1] - want[1]) <= rtol * scale + FP_ATOL, (what, got[1], want[1])
 
 
 def build_system(model, overrides, fuse=1, device="cuda"):
