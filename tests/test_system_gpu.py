@@ -182,9 +182,11 @@ def test_teacher_forced_steps_meet_the_contract(name):
             for k, v in next_g.items():
                 want = next_o[k].detach()
                 assert_fp_close(fp(v), fp(want), CONTRACT['w'], (name, 'teacher-forced w', t, step, k))
-                # an element that moved the other way: more than half a step from where the oracle put it
-                move = (want - fast_o[k].detach()).abs()
-                flipped += int(((v.detach().cpu() - want).abs() > 0.5 * move + 1e-12).sum())
+                # an element that moved the other way: more than half a full step (the largest move in its tensor) from
+                # where the oracle put it.  (Measured against the tensor's step size, not the element's own move: elements with
+                # an exactly-zero oracle gradient -- dead ReLU channels -- do not move at all.)
+                step_size = (want - fast_o[k].detach()).abs().max().item()
+                flipped += int(((v.detach().cpu() - want).abs() > 0.5 * step_size + 1e-12).sum())
                 total += want.numel()
             fast_o = {k: v.detach().requires_grad_() for k, v in next_o.items()}
         with torch.no_grad():
