@@ -11,7 +11,7 @@ import re
 from ctypes import c_double, c_float, c_int, c_int64, c_void_p, POINTER
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG_DIR, "lib", "libsavfi_hip.so")
+LIB_PATH = os.environ.get("SAVFI_HIP_LIB") or os.path.join(_PKG_DIR, "lib", "libsavfi_hip.so")     # override: kernel experiments
 HEADER_PATH = os.path.join(os.path.dirname(_PKG_DIR), "include", "savfi_hip.h")
 
 RULE_SGD, RULE_ADAM, RULE_ADAMAX_LSLR, RULE_ADAMAX_MSGD = 0, 1, 2, 3

@@ -16,31 +16,45 @@
 #include "common.h"
 #include <stdlib.h>
 
+// Compile-time experiment switches (both on in the shipped library; profiles/r02_sepconv_variants.txt has the A/B numbers):
+//   SC_PIN     pin the LDS-read / MFMA interleave with sched_group_barrier (software-pipelined A fragments)
+//   SC_GH_LDS  gH leaves through an LDS transpose as 64-byte runs instead of 64 scattered dwords per store instruction
+#ifndef SC_PIN
+#define SC_PIN 1
+#endif
+#ifndef SC_GH_LDS
+#define SC_GH_LDS 1
+#endif
+
 namespace {
 
 constexpr int KFAST = 51;
 
 
 // Stage an LH x SPAN window of a [Hi, Wi] plane (top-left at (y0, x0)) into LDS rows of pitch LW.
-// All global loads of a thread are issued back to back (no branch, no wait between them) and the
-// ds_writes follow; coordinates past the plane are clamped -- such entries only ever feed output
-// pixels that lie outside the image and are never stored.
+// Thread -> (column q = tid % 128, row group tid / 128): a thread keeps its column and walks rows in steps of NTHREADS / 128,
+// so a load is one raw buffer load (per-lane byte offset = clamped row * Wi + clamped column: one v_min + one v_mad) and an
+// LDS write is a constant offset from a per-thread base -- ~3 VALU per element where the flattened index (i / SPAN, i % SPAN,
+// 64-bit address) cost ~30: the PMC profile of round 2 showed the staging prologue issuing more VALU than the whole row loop,
+// on a datapath the fp32 MFMAs share.  All loads of a thread are issued back to back, the ds_writes follow.  Coordinates
+// past the plane are clamped -- such entries only ever feed output pixels that lie outside the image and are never stored.
 template <int LH, int SPAN, int LW, int NTHREADS>
 __device__ __forceinline__ void stage_window(float* __restrict__ tile, const float* __restrict__ src, int y0,
                                              int x0, int Hi, int Wi, int tid) {
-  constexpr int TOTAL = LH * SPAN, NIT = (TOTAL + NTHREADS - 1) / NTHREADS;
+  static_assert(SPAN <= 128 && NTHREADS % 128 == 0, "one column per thread");
+  constexpr int RG = NTHREADS / 128, NIT = (LH + RG - 1) / RG;
+  const int q = tid & 127, rg = tid >> 7;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, Hi * Wi * 4, 0x00020000);
+  const int colb = min(x0 + q, Wi - 1) * 4, rowb = Wi * 4;
   float buf[NIT];
 #pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int i = min(tid + it * NTHREADS, TOTAL - 1);
-    const int r = i / SPAN, q = i - r * SPAN;
-    buf[it] = src[(size_t)min(y0 + r, Hi - 1) * Wi + min(x0 + q, Wi - 1)];
-  }
+  for (int it = 0; it < NIT; ++it)
+    buf[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, min(y0 + rg + it * RG, Hi - 1) * rowb + colb, 0, 0));
+  float* dst = tile + rg * LW + q;
+  if (q < SPAN) {
 #pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int i = tid + it * NTHREADS;
-    const int r = i / SPAN, q = i - r * SPAN;
-    if (i < TOTAL) tile[r * LW + q] = buf[it];
+    for (int it = 0; it < NIT; ++it)
+      if (it * RG + RG <= LH || rg + it * RG < LH) dst[it * RG * LW] = buf[it];
   }
 }
 
@@ -74,13 +88,22 @@ constexpr int MKP = 52;   // rows per channel in the M dimension (51 taps + 1 ze
 // runs per tap plane).  Keeping them private removes every workgroup barrier from the row loop, so the two waves
 // that share a SIMD drift out of phase and one's VALU / LDS / store phases hide under the other's MFMAs.
 // lane = (tap group tg = lane >> 4, column j = lane & 15); NREG = ceil(K / 4) dwords per lane.
+// Raw buffer loads: one resource per sample's [K][Ho][Wo] tap tensor, a per-lane byte offset (tap group + pixel) computed once
+// per row and a wave-uniform byte offset per tap quadruple -- no 64-bit per-load addresses on the VALU (26 of them per row
+// before), and tap 51 of the last quadruple lies past num_records = K planes, so the hardware returns 0 for it.
+__device__ __forceinline__ float sc_bload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t sc_rsrc(const float* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)bytes, 0x00020000);
+}
 template <int K, int NREG>
-__device__ __forceinline__ void mfma_load_taps(float (&regs)[NREG], const float* __restrict__ src, size_t plane,
+__device__ __forceinline__ void mfma_load_taps(float (&regs)[NREG], __amdgpu_buffer_rsrc_t src, unsigned plane_bytes,
                                                int Ho, int Wo, int y, int xw, int lane) {
   const int yy = min(y, Ho - 1), xx = min(xw + (lane & 15), Wo - 1);
-  const float* p = src + (size_t)yy * Wo + xx;
+  const unsigned voff = (unsigned)(lane >> 4) * plane_bytes + (unsigned)(yy * Wo + xx) * 4u;
 #pragma unroll
-  for (int it = 0; it < NREG; ++it) regs[it] = p[(size_t)min(4 * it + (lane >> 4), K - 1) * plane];
+  for (int it = 0; it < NREG; ++it) regs[it] = sc_bload(src, voff, (unsigned)(4 * it) * plane_bytes);
 }
 template <int K, int NREG>
 __device__ __forceinline__ void mfma_store_taps(float* __restrict__ dst /* [>=K][16] */, const float (&regs)[NREG],
@@ -112,12 +135,13 @@ __global__ __launch_bounds__(MNT) void sepconv_fwd_mfma(const float* __restrict_
   const int x0 = blockIdx.x * MC, y0 = blockIdx.y * MROWS, b = blockIdx.z;
   const int Hi = Ho + K - 1, Wi = Wo + K - 1;
   const size_t plane = (size_t)Ho * Wo;
-  const float* hsrc = h + (size_t)b * K * plane;
-  const float* vsrc = v + (size_t)b * K * plane;
+  const unsigned plane_b = (unsigned)plane * 4u;
+  const __amdgpu_buffer_rsrc_t hsrc = sc_rsrc(h + (size_t)b * K * plane, (unsigned)K * plane_b);
+  const __amdgpu_buffer_rsrc_t vsrc = sc_rsrc(v + (size_t)b * K * plane, (unsigned)K * plane_b);
 
   float hreg[NREG], vreg[NREG];
-  mfma_load_taps<K, NREG>(hreg, hsrc, plane, Ho, Wo, y0 + wr, x0 + 16 * wc, lane);
-  mfma_load_taps<K, NREG>(vreg, vsrc, plane, Ho, Wo, y0 + wr, x0 + 16 * wc, lane);
+  mfma_load_taps<K, NREG>(hreg, hsrc, plane_b, Ho, Wo, y0 + wr, x0 + 16 * wc, lane);
+  mfma_load_taps<K, NREG>(vreg, vsrc, plane_b, Ho, Wo, y0 + wr, x0 + 16 * wc, lane);
 #pragma unroll
   for (int c = 0; c < C; ++c)
     stage_window<LH, MSPAN, MLW, MNT>(inT + c * LP, in + ((size_t)b * C + c) * Hi * Wi, y0, x0, Hi, Wi, tid);
@@ -145,8 +169,8 @@ __global__ __launch_bounds__(MNT) void sepconv_fwd_mfma(const float* __restrict_
   for (int ph = 0; ph < MROWS / 2; ++ph) {
     const int y = y0 + 2 * ph + wr;
     if (ph + 1 < MROWS / 2) {   // next row's taps: HBM -> registers while this row computes
-      mfma_load_taps<K, NREG>(hreg, hsrc, plane, Ho, Wo, y + 2, x0 + 16 * wc, lane);
-      mfma_load_taps<K, NREG>(vreg, vsrc, plane, Ho, Wo, y + 2, x0 + 16 * wc, lane);
+      mfma_load_taps<K, NREG>(hreg, hsrc, plane_b, Ho, Wo, y + 2, x0 + 16 * wc, lane);
+      mfma_load_taps<K, NREG>(vreg, vsrc, plane_b, Ho, Wo, y + 2, x0 + 16 * wc, lane);
     }
     const float* hb = hB + j;
     const float* vb = vB + j;
@@ -166,18 +190,32 @@ __global__ __launch_bounds__(MNT) void sepconv_fwd_mfma(const float* __restrict_
 
     float o0 = 0.f, o1 = 0.f, o2 = 0.f;
     const int rowoff = 2 * ph * MLW;
+    // A fragments of the NEXT pair of M-tiles are in flight while this pair's 34 MFMAs issue (the compiler, left alone, sinks
+    // every LDS read to just before its first use: each pair then starts with an exposed LDS round trip)
+    auto load_pair = [&](f32x4 (&d0)[4], f32x4 (&d1)[4], float& t0, float& t1, int mp) {
+      const float* a0p = inT + abase[2 * mp] + rowoff;
+      const float* a1p = inT + abase[2 * mp + 1] + rowoff;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        d0[u] = *reinterpret_cast<const f32x4*>(a0p + 16 * u);
+        d1[u] = *reinterpret_cast<const f32x4*>(a1p + 16 * u);
+      }
+      t0 = a0p[64 - 3 * ks];                                             // column 64 + ks (the base holds + 4*ks)
+      t1 = a1p[64 - 3 * ks];
+    };
+    f32x4 a0[4], a1[4], n0[4], n1[4];
+    float a0t, a1t, n0t, n1t;
+#if SC_PIN
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    load_pair(a0, a1, a0t, a1t, 0);
+#if SC_PIN
+    __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
+#endif
 #pragma unroll
     for (int mp = 0; mp < MT / 2; ++mp) {
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-      const float* a0p = inT + abase[2 * mp] + rowoff;
-      const float* a1p = inT + abase[2 * mp + 1] + rowoff;
-      f32x4 a0[4], a1[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        a0[u] = *reinterpret_cast<const f32x4*>(a0p + 16 * u);
-        a1[u] = *reinterpret_cast<const f32x4*>(a1p + 16 * u);
-      }
-      const float a0t = a0p[64 - 3 * ks], a1t = a1p[64 - 3 * ks];      // column 64 + ks (the base holds + 4*ks)
+      if (mp + 1 < MT / 2) load_pair(n0, n1, n0t, n1t, mp + 1);
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[t >> 2][t & 3], bf[t], acc0, 0, 0, 0);
@@ -185,6 +223,10 @@ __global__ __launch_bounds__(MNT) void sepconv_fwd_mfma(const float* __restrict_
       }
       acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0t, bf[16], acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1t, bf[16], acc1, 0, 0, 0);
+#if SC_PIN
+      if (mp + 1 < MT / 2) __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 34, 0);
+#endif
       // vertical pass on the accumulators: lane holds T rows 16*m + 4*ks + e (e = 0..3) of pixel j, all of
       // one channel (52 = 4*13), at taps fy0..fy0+3 (tap 51 is the zero row)
 #pragma unroll
@@ -203,6 +245,10 @@ __global__ __launch_bounds__(MNT) void sepconv_fwd_mfma(const float* __restrict_
         o1 += (c == 1) ? sdot : 0.f;
         o2 += (c == 2) ? sdot : 0.f;
       }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { a0[u] = n0[u]; a1[u] = n1[u]; }
+      a0t = n0t;
+      a1t = n1t;
     }
     // the 4 k-lanes of a pixel hold disjoint row subsets: fold them
     o0 += __shfl_xor(o0, 16, 64); o0 += __shfl_xor(o0, 32, 64);
@@ -249,7 +295,7 @@ __global__ __launch_bounds__(MNT) void sepconv_bwd_mfma(const float* __restrict_
   constexpr int KTV = (K + 3) / 4;                         // 13 row steps (taps fy = 4t+ks; tap 51 is the zero row)
   constexpr int MTH = (16 + K - 1 + 15) / 16;              // 5 M-tiles of window columns q
   constexpr int NREG = (K + 3) / 4;
-  static_assert(KT == 17 && MLW % 4 == 0 && 4 * KTV == MKP && 16 * 3 + 16 * MTH <= MLW, "operand geometry");
+  static_assert(KT == 17 && MTV == 4 && MLW % 4 == 0 && 4 * KTV == MKP && 16 * 3 + 16 * MTH <= MLW, "operand geometry");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* inT = lds;
   float* hB = lds + C * LP + (threadIdx.x >> 6) * (K + MKP) * 16;   // wave-private tap rows (see the forward kernel)
@@ -261,36 +307,39 @@ __global__ __launch_bounds__(MNT) void sepconv_bwd_mfma(const float* __restrict_
   const int x0 = blockIdx.x * MC, y0 = blockIdx.y * MROWS, b = blockIdx.z;
   const int Hi = Ho + K - 1, Wi = Wo + K - 1;
   const size_t plane = (size_t)Ho * Wo;
-  const float* hsrc = h + (size_t)b * K * plane;
-  const float* vsrc = v + (size_t)b * K * plane;
+  const unsigned plane_b = (unsigned)plane * 4u;
+  const __amdgpu_buffer_rsrc_t hsrc = sc_rsrc(h + (size_t)b * K * plane, (unsigned)K * plane_b);
+  const __amdgpu_buffer_rsrc_t vsrc = sc_rsrc(v + (size_t)b * K * plane, (unsigned)K * plane_b);
+  const __amdgpu_buffer_rsrc_t gsrc = sc_rsrc(gO + (size_t)b * C * plane, (unsigned)C * plane_b);
+  // byte offset of this lane's pixel in row y of a plane (clamped: out-of-image pixels are computed and never stored)
+  auto pix_off = [&](int y) { return (unsigned)(min(y, Ho - 1) * Wo + min(x0 + 16 * wc + j, Wo - 1)) * 4u; };
 
-  float hreg[NREG], vreg[NREG];
-  mfma_load_taps<K, NREG>(hreg, hsrc, plane, Ho, Wo, y0 + wr, x0 + 16 * wc, lane);
-  mfma_load_taps<K, NREG>(vreg, vsrc, plane, Ho, Wo, y0 + wr, x0 + 16 * wc, lane);
+  float hreg[NREG], vreg[NREG], gnext[C];
+  mfma_load_taps<K, NREG>(hreg, hsrc, plane_b, Ho, Wo, y0 + wr, x0 + 16 * wc, lane);
+  mfma_load_taps<K, NREG>(vreg, vsrc, plane_b, Ho, Wo, y0 + wr, x0 + 16 * wc, lane);
+#pragma unroll
+  for (int c = 0; c < C; ++c) gnext[c] = sc_bload(gsrc, pix_off(y0 + wr), (unsigned)c * plane_b);
 #pragma unroll
   for (int c = 0; c < C; ++c)
     stage_window<LH, MSPAN, MLW, MNT>(inT + c * LP, in + ((size_t)b * C + c) * Hi * Wi, y0, x0, Hi, Wi, tid);
   // columns MSPAN..MLW-1 of the window are only read by gH rows q >= 66, which are discarded, but keep them finite
-  for (int i = tid; i < C * LH * (MLW - MSPAN); i += MNT) {
-    const int rr = i / (MLW - MSPAN), q = i - rr * (MLW - MSPAN);
-    inT[rr * MLW + MSPAN + q] = 0.f;
-  }
+  static_assert(MLW - MSPAN == 16, "zero-fill indexing");
+  for (int i = tid; i < C * LH * 16; i += MNT) inT[(i >> 4) * MLW + MSPAN + (i & 15)] = 0.f;
   if (lane < 16) vB[K * 16 + lane] = 0.f;
   mfma_store_taps<K, NREG>(hB, hreg, lane);
   mfma_store_taps<K, NREG>(vB, vreg, lane);
 
-  // A-row bases.  gV: M index = tap fy = 16m + j (clamped), column = k.   gH: M index = window column q = 16m + j,
-  // k index = tap row 4t + ks (clamped to the last window row; that tap's B operand is the zero row).
-  int abV[MTV], abH[MTH];
+  // A-row bases.  gV: M index = tap fy = 16m + j (clamped), column = k (b128 k-slot order, see the forward kernel).
+  // gH: M index = window column q, k index = tap row 4t + ks.  The assignment of window columns to (M-tile m, row i) is free
+  // as long as the store below agrees: q = 4 i + m puts the four M-tiles' A values of a lane (i = j) into ONE aligned
+  // 16-byte LDS read -- 39 ds_read_b128 per row instead of 156 dword reads, each fetched two steps ahead of its MFMAs.
+  int abV[MTV];
 #pragma unroll
-  for (int m = 0; m < MTV; ++m) abV[m] = (min(16 * m + j, K - 1) + wr) * MLW + 16 * wc + 4 * ks;   // b128 k-slot order
-#pragma unroll
-  for (int m = 0; m < MTH; ++m) abH[m] = (wr + ks) * MLW + 16 * wc + 16 * m + j;
+  for (int m = 0; m < MTV; ++m) abV[m] = (min(16 * m + j, K - 1) + wr) * MLW + 16 * wc + 4 * ks;
+  const int abH = (wr + ks) * MLW + 16 * wc + 4 * j;
   __syncthreads();
-  // The two waves of a SIMD (row lanes wr = 0 / 1) run identical instruction streams and would stay in
-  // lockstep: both in their VALU / LDS / store phases, then both competing for the matrix pipe.  A one-off
-  // ~2.5k-cycle head start for one of them lets each wave's non-MFMA work hide under the other's MFMAs
-  // (measured: fwd 47.9 -> 46.1 us, bwd 105.5 -> 96.4 us at 384x512).
+  // The two waves of a SIMD (row lanes wr = 0 / 1) run identical instruction streams and would stay in lockstep: a one-off
+  // head start for one of them lets each wave's non-MFMA phases hide under the other's MFMAs.
   if (wr == 1) __builtin_amdgcn_s_sleep(40);
 
 #pragma unroll 1
@@ -299,13 +348,15 @@ __global__ __launch_bounds__(MNT) void sepconv_bwd_mfma(const float* __restrict_
     const int x = x0 + 16 * wc + j;
     const bool pvalid = (x < Wo) && (y < Ho);
     const size_t opix = (size_t)min(y, Ho - 1) * Wo + min(x, Wo - 1);
-    if (ph + 1 < MROWS / 2) {
-      mfma_load_taps<K, NREG>(hreg, hsrc, plane, Ho, Wo, y + 2, x0 + 16 * wc, lane);
-      mfma_load_taps<K, NREG>(vreg, vsrc, plane, Ho, Wo, y + 2, x0 + 16 * wc, lane);
-    }
     float g[C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) g[c] = gO[((size_t)b * C + c) * plane + opix];
+    for (int c = 0; c < C; ++c) g[c] = gnext[c];              // fetched during the previous row
+    if (ph + 1 < MROWS / 2) {                                   // next row's taps and upstream gradient: HBM -> registers
+      mfma_load_taps<K, NREG>(hreg, hsrc, plane_b, Ho, Wo, y + 2, x0 + 16 * wc, lane);
+      mfma_load_taps<K, NREG>(vreg, vsrc, plane_b, Ho, Wo, y + 2, x0 + 16 * wc, lane);
+#pragma unroll
+      for (int c = 0; c < C; ++c) gnext[c] = sc_bload(gsrc, pix_off(y + 2), (unsigned)c * plane_b);
+    }
     const float* hb = hB + j;
     const float* vb = vB + j;
     const int rowoff = 2 * ph * MLW;
@@ -322,25 +373,56 @@ __global__ __launch_bounds__(MNT) void sepconv_bwd_mfma(const float* __restrict_
       f32x4 acc[MTV];
 #pragma unroll
       for (int m = 0; m < MTV; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int c = 0; c < C; ++c) {
-        f32x4 av[MTV][4];
-        float at[MTV];
+      // groups of 4 k-steps (one 16-byte A read per M-tile) + the tail step per channel; the next group's A fragments are
+      // in flight while this group's 16 MFMAs issue
+      constexpr int NG = C * 5;            // per channel: u = 0..3 (4 steps each), u = 4: the single step t = 16
+      auto load_group = [&](f32x4 (&dst)[MTV], int gi) {
+        const int c = gi / 5, u = gi - 5 * c;
 #pragma unroll
         for (int m = 0; m < MTV; ++m) {
           const float* ap = inT + abV[m] + rowoff + c * LP;
-#pragma unroll
-          for (int u = 0; u < 4; ++u) av[m][u] = *reinterpret_cast<const f32x4*>(ap + 16 * u);
-          at[m] = ap[64 - 3 * ks];
+          if (u < 4) dst[m] = *reinterpret_cast<const f32x4*>(ap + 16 * u);
+          else dst[m][0] = ap[64 - 3 * ks];
         }
+      };
+      f32x4 acur[MTV], anxt[MTV];
+      // The schedule is pinned (sched_group_barrier): left alone, the compiler sinks every LDS read to just before its first
+      // use and each group of MFMAs then starts with an exposed LDS round trip.
+#if SC_PIN
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      load_group(acur, 0);
+#if SC_PIN
+      __builtin_amdgcn_sched_group_barrier(0x100, MTV, 0);
+#endif
 #pragma unroll
-        for (int t = 0; t < KT; ++t) {
-          const float bb = g[c] * bf[t];
+      for (int gi = 0; gi < NG; ++gi) {
+        if (gi + 1 < NG) load_group(anxt, gi + 1);
+        const int c = gi / 5, u = gi - 5 * c;
+#pragma unroll
+        for (int e = 0; e < (u < 4 ? 4 : 1); ++e) {
+          const float bb = g[c] * bf[u < 4 ? 4 * u + e : 16];
 #pragma unroll
           for (int m = 0; m < MTV; ++m)
-            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(t < 16 ? av[m][t >> 2][t & 3] : at[m], bb, acc[m], 0, 0, 0);
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[m][e], bb, acc[m], 0, 0, 0);
         }
+#pragma unroll
+        for (int m = 0; m < MTV; ++m) acur[m] = anxt[m];
+#if SC_PIN
+        // next group's A fragments first, then this group's B products and MFMAs
+        if (gi + 1 < NG) __builtin_amdgcn_sched_group_barrier(0x100, MTV, 0);
+        if (u < 4) {
+          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 4 * MTV, 0);
+        } else {
+          __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, MTV, 0);
+        }
+#endif
       }
+#if SC_PIN
+      __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
       for (int m = 0; m < MTV; ++m) {
 #pragma unroll
@@ -363,18 +445,41 @@ __global__ __launch_bounds__(MNT) void sepconv_bwd_mfma(const float* __restrict_
       f32x4 acc[MTHM];
 #pragma unroll
       for (int m = 0; m < MTHM; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      // step (c, t): window row of tap 4t + ks; the zero tap (51, lane group ks = 3 of the last step) would be one row past
+      // the window: step back one row (its B operand is zero)
+      const float* abase = inT + abH + rowoff;
+      const int last_row = ((ks == 3) ? (4 * (KTV - 1) - 1) : 4 * (KTV - 1)) * MLW;
+      auto a_of = [&](int idx) {
+        const int c = idx / KTV, t = idx - KTV * c;
+        return *reinterpret_cast<const f32x4*>(abase + c * LP + (t == KTV - 1 ? last_row : 4 * t * MLW));
+      };
+      constexpr int NS = C * KTV;
+#if SC_PIN
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      f32x4 a0 = a_of(0), a1 = a_of(1);
+#if SC_PIN
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#endif
 #pragma unroll
-      for (int c = 0; c < C; ++c) {
+      for (int idx = 0; idx < NS; ++idx) {
+        f32x4 a2 = a0;
+        if (idx + 2 < NS) a2 = a_of(idx + 2);
+        const int c = idx / KTV, t = idx - KTV * c;
+        const float bb = g[c] * bv[t];
 #pragma unroll
-        for (int t = 0; t < KTV; ++t) {
-          const float bb = g[c] * bv[t];
-          // window row of tap 4t+ks; the zero tap (51) would be one row past the window: step back one row
-          const int arow = (t == KTV - 1) ? ((ks == 3) ? (4 * t - 1) * MLW : 4 * t * MLW) : 4 * t * MLW;
-#pragma unroll
-          for (int m = 0; m < MTHM; ++m)
-            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(inT[abH[m] + rowoff + c * LP + arow], bb, acc[m], 0, 0, 0);
-        }
+        for (int m = 0; m < MTHM; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[m], bb, acc[m], 0, 0, 0);
+        a0 = a1;
+        a1 = a2;
+#if SC_PIN
+        if (idx + 2 < NS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // the A read of step idx + 2 ...
+        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);                        // ... this step's B product ...
+        __builtin_amdgcn_sched_group_barrier(0x008, MTHM, 0);                     // ... and its 4 MFMAs
+#endif
       }
+#if SC_PIN
+      __builtin_amdgcn_sched_barrier(0);
+#endif
       // VALU tail: lane = tap row fy (lanes 51..63 idle), then a 64-lane sum of the three partial products
       float s6414 = 0.f, s6415 = 0.f, s6515 = 0.f;
       {
@@ -395,14 +500,37 @@ __global__ __launch_bounds__(MNT) void sepconv_bwd_mfma(const float* __restrict_
         s6415 = wave_sum(s6415);
         s6515 = wave_sum(s6515);
       }
+      // accumulator (m, e) of lane (j, ks) is D'[q][j] with q = 4 * (4 ks + e) + m  (the M permutation chosen above)
+#if SC_GH_LDS
+      // gH[fx][p] = D'[p + fx][p]: straight from the accumulators every lane of a store instruction would hit a different tap
+      // plane (64 separate 4-byte writes per instruction, 64 instructions per row).  The wave's tap rows are dead from here
+      // to the end of the row, so the 64 x 16 tile goes through them and leaves as 13 instructions of four 64-byte runs.
+      {
+        __builtin_amdgcn_wave_barrier();
+        float* tile = hB;                                   // [64 q][16 p] floats = 4 KB of the wave's 6.4 KB tap buffer
+#pragma unroll
+        for (int m = 0; m < MTHM; ++m)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) tile[(16 * ks + 4 * e + m) * 16 + j] = acc[m][e];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int t = 0; t < KTV; ++t) {
+          const int fx = 4 * t + ks;
+          const float val = tile[min(j + fx, 63) * 16 + j];
+          if (pvalid && fx < K && j + fx < 64) gH[(size_t)b * K * plane + (size_t)fx * plane + opix] = val;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+#else
 #pragma unroll
       for (int m = 0; m < MTHM; ++m) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int fx = 16 * m + 4 * ks + e - j;
+          const int fx = 16 * ks + 4 * e + m - j;
           if (pvalid && fx >= 0 && fx < K) gH[(size_t)b * K * plane + (size_t)fx * plane + opix] = acc[m][e];
         }
       }
+#endif
       if (pvalid && lane == 14) gH[(size_t)b * K * plane + (size_t)50 * plane + opix] = s6414;
       if (pvalid && lane == 15) {
         gH[(size_t)b * K * plane + (size_t)49 * plane + opix] = s6415;

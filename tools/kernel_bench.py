@@ -132,12 +132,13 @@ if __name__ == "__main__":
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--only", default=None)
     ap.add_argument("--hw", default="384x512,256x448", help="sepconv output sizes: padded canvas, frame window")
+    ap.add_argument("--batches", default="1,2", help="sepconv batch sizes (8 = 4 tasks in lockstep x the support pair)")
     o = ap.parse_args()
     if o.only in (None, "sepconv"):
         for hw in o.hw.split(","):
             Ho, Wo = (int(t) for t in hw.split("x"))
-            bench_sepconv(o.iters, B=1, Ho=Ho, Wo=Wo)
-            bench_sepconv(o.iters, B=2, Ho=Ho, Wo=Wo)
+            for B in (int(t) for t in o.batches.split(",")):
+                bench_sepconv(o.iters, B=B, Ho=Ho, Wo=Wo)
     if o.only in (None, "update"):
         bench_update(o.iters, "sepconv")
         bench_update(o.iters, "cain")
