@@ -717,15 +717,29 @@ def conv3x3_wgrad_tasks(x, gz, T, pad=1):
     return gw
 
 
+TASKS_GROUPED_MAX_PIXELS = 3000      # MIOpen's grouped solvers: fine on small maps, 5-30x slower than T plain calls on large ones
+
+
+def _grouped_ok(x):
+    return x.shape[2] * x.shape[3] < TASKS_GROUPED_MAX_PIXELS
+
+
 def conv2d_tasks(x, weight, bias, stride=1, padding=0, dilation=1):
-    """conv2d of [n*T, Ci, H, W] (sample-major) with per-task weights [T, Co, Ci, kh, kw] / bias [T, Co] as one grouped
-    convolution; composed of differentiable torch ops (second order, CPU host-logic tests)."""
+    """conv2d of [n*T, Ci, H, W] (sample-major) with per-task weights [T, Co, Ci, kh, kw] / bias [T, Co], composed of
+    differentiable torch ops (second order, bias-free layers, CPU host-logic tests): ONE grouped convolution on small maps,
+    one plain convolution per task on large ones (tools/tasks_bench.py: MIOpen's grouped kernels take 1.5-10 ms there)."""
     T, Co, Ci = weight.shape[:3]
     N, _, H, W = x.shape
     n = N // T
-    z = torch.nn.functional.conv2d(x.reshape(n, T * Ci, H, W), weight.reshape(T * Co, Ci, *weight.shape[3:]),
-                                   None if bias is None else bias.reshape(T * Co), stride, padding, dilation, T)
-    return z.reshape(N, Co, z.shape[2], z.shape[3])
+    if _grouped_ok(x) or not x.is_cuda:
+        z = torch.nn.functional.conv2d(x.reshape(n, T * Ci, H, W), weight.reshape(T * Co, Ci, *weight.shape[3:]),
+                                       None if bias is None else bias.reshape(T * Co), stride, padding, dilation, T)
+        return z.reshape(N, Co, z.shape[2], z.shape[3])
+    xs = x.reshape(n, T, Ci, H, W)
+    zs = [torch.nn.functional.conv2d(xs[:, t], weight[t], None if bias is None else bias[t], stride, padding, dilation)
+          for t in range(T)]
+    z = torch.stack(zs, 1)                                     # [n, T, Co, Ho, Wo]: sample-major again
+    return z.reshape(N, Co, z.shape[3], z.shape[4])
 
 
 class _ConvBiasActTasks(torch.autograd.Function):
@@ -741,17 +755,25 @@ class _ConvBiasActTasks(torch.autograd.Function):
         if conv3x3_tasks_eligible(x, w, stride, padding, dilation):
             z = conv3x3_tasks(x, w, b, 0, slope, pad)
         else:
-            z = torch.nn.functional.conv2d(x.view(n, T * Ci, H, W), w.reshape(T * Co, Ci, *w.shape[3:]), None, stride, padding,
-                                           dilation, T)
-            if not z.is_contiguous():
-                z = z.contiguous()
-            _hip.require_cuda(z, b)
-            lib = _hip.lib()
-            hw = z.shape[2] * z.shape[3]
-            _hip.launch("bias_act_fwd", lambda: _hip.check(lib.savfi_bias_act_fwd_f32(
-                z.data_ptr(), b.data_ptr(), n, T * Co, hw, slope, _hip.current_stream()), "savfi_bias_act_fwd_f32"))
-            z = z.view(N, Co, z.shape[2], z.shape[3])
+            if _grouped_ok(x):
+                z = torch.nn.functional.conv2d(x.view(n, T * Ci, H, W), w.reshape(T * Co, Ci, *w.shape[3:]), None, stride, padding,
+                                               dilation, T)
+                if not z.is_contiguous():
+                    z = z.contiguous()
+            else:           # large map, no savfi kernel (5x5 / 7x7 / strided): one MIOpen call per task, results interleaved
+                xs = x.view(n, T, Ci, H, W)
+                z = torch.stack([torch.nn.functional.conv2d(xs[:, t], w[t], None, stride, padding, dilation) for t in range(T)], 1)
+                z = z.view(N, Co, z.shape[3], z.shape[4])
+            if b is not None or slope != 1.0:
+                zb = b if b is not None else torch.zeros((T, Co), dtype=z.dtype, device=z.device)
+                _hip.require_cuda(z, zb)
+                lib = _hip.lib()
+                hw = z.shape[-2] * z.shape[-1]
+                _hip.launch("bias_act_fwd", lambda: _hip.check(lib.savfi_bias_act_fwd_f32(
+                    z.data_ptr(), zb.data_ptr(), n, T * Co, hw, slope, _hip.current_stream()), "savfi_bias_act_fwd_f32"))
+            z = z.view(N, Co, z.shape[-2], z.shape[-1])
         ctx.conf = (stride, padding, dilation, slope)
+        ctx.has_bias = b is not None
         ctx.save_for_backward(x, w, z)
         return z
 
@@ -766,6 +788,7 @@ class _ConvBiasActTasks(torch.autograd.Function):
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         identity = slope == 1.0
         gz = gy if identity else torch.empty_like(gy)
+        need_b = need_b and ctx.has_bias
         gb = torch.empty((T, Co), dtype=gy.dtype, device=gy.device) if need_b else None
         if need_b or not identity:
             lib = _hip.lib()
@@ -786,13 +809,23 @@ class _ConvBiasActTasks(torch.autograd.Function):
         if need_x or need_w:
             pair = lambda v: [v, v] if isinstance(v, int) else list(v)
             H, W = x.shape[2:]
-            gx2, gw2, _ = torch.ops.aten.convolution_backward(
-                gz.view(n, T * Co, Ho, Wo), x.view(n, T * Ci, H, W), w.reshape(T * Co, Ci, *w.shape[3:]), None, pair(stride),
-                pair(padding), pair(dilation), False, [0, 0], T, [need_x, need_w, False])
-            if need_x:
-                gx = gx2.contiguous().view(N, Ci, H, W)
-            if need_w:
-                gw = gw2.view(w.shape)
+            if _grouped_ok(x):
+                gx2, gw2, _ = torch.ops.aten.convolution_backward(
+                    gz.view(n, T * Co, Ho, Wo), x.view(n, T * Ci, H, W), w.reshape(T * Co, Ci, *w.shape[3:]), None, pair(stride),
+                    pair(padding), pair(dilation), False, [0, 0], T, [need_x, need_w, False])
+                if need_x:
+                    gx = gx2.contiguous().view(N, Ci, H, W)
+                if need_w:
+                    gw = gw2.view(w.shape)
+            else:
+                gzs, xs = gz.view(n, T, Co, Ho, Wo), x.view(n, T, Ci, H, W)
+                per = [torch.ops.aten.convolution_backward(gzs[:, t].contiguous(), xs[:, t].contiguous(), w[t], None, pair(stride),
+                                                           pair(padding), pair(dilation), False, [0, 0], 1, [need_x, need_w, False])
+                       for t in range(T)]
+                if need_x:
+                    gx = torch.stack([p[0] for p in per], 1).view(N, Ci, H, W)
+                if need_w:
+                    gw = torch.stack([p[1] for p in per], 0)
         return gx, gw, gb, None, None, None, None
 
 

@@ -20,6 +20,7 @@ What is different (MI355X-first, results identical):
     for >1 visible device (:285-287) is not reproduced: one process owns one device.
 """
 import functools
+import os
 import threading
 
 import numpy as np
@@ -397,6 +398,10 @@ class SceneAdaptiveInterpolation(nn.Module):
         width = int(getattr(self.args, 'task_batch', 0) or 0)
         if width <= 1 or use_second_order:
             return 0
+        if not getattr(self.net, 'lockstep_tasks', True) and not os.environ.get('SAVFI_LOCKSTEP_ALL'):
+            # the plugin opts out: its per-task convolutions would fall to MIOpen's GROUPED solvers (VoxelFlow's bias-free 5x5
+            # layers: 1.5-3.5 ms per call at 256x256, config C3 drops from 135 to 78 steps/s)
+            return 0
         if self.args.attenuate and self._routing(frame_shape)[1]:
             return 0
         return width
@@ -643,7 +648,7 @@ class SceneAdaptiveInterpolation(nn.Module):
         local = self._local_tasks(num_tasks, training_phase)
         # --task_batch T: groups of T tasks advance in lockstep through ONE graph set (a shorter last group gets its own);
         # --task_streams N: N graph sets per width (own static buffers and memory pool each), replayed from N threads
-        width = max(1, int(getattr(self.args, 'task_batch', 0) or 0))
+        width = max(1, self._lockstep_width(False, frames[0].shape[1:]))
         groups = [local[i:i + width] for i in range(0, len(local), width)]
         n = max(1, min(int(getattr(self.args, 'task_streams', 1) or 1), len(groups)))
 

@@ -193,8 +193,8 @@ class MetaConv2dLayer(nn.Module):
             weight, bias = self.weight, self.bias
         if weight.dim() == 5:
             # fast weights stacked over the tasks of a meta-batch adapted in lockstep: [T, Co, Ci, kh, kw], x [n*T, ...]
-            if bias is not None and x.is_cuda and fuse_conv_act() and self.groups == 1 and (
-                    act_slope is not None or hip_ops.conv3x3_tasks_eligible(x, weight, self.stride, padding, self.dilation_rate)):
+            if x.is_cuda and fuse_conv_act() and self.groups == 1 and (
+                    act_slope is not None or bias is None or hip_ops.conv3x3_tasks_eligible(x, weight, self.stride, padding, self.dilation_rate)):
                 return hip_ops.conv_bias_act_tasks(x, weight, bias, self.stride, padding, self.dilation_rate,
                                                    1.0 if act_slope is None else act_slope)
             assert self.groups == 1, "lockstep tasks on a grouped convolution"

@@ -24,6 +24,12 @@ _TRUNK = [("conv1", 6, 64, 5), ("conv2", 64, 128, 5), ("conv3", 128, 256, 3), ("
 
 
 class MetaVoxelFlow(nn.Module):
+    # tasks of a meta-batch are adapted one after another, not in lockstep (meta_learning_system._lockstep_width): five of
+    # the eight layers are 5x5 convolutions, which have no savfi kernel (one MIOpen call per task either way: config C3
+    # measures 134.7 steps/s sequential, 136.1 in lockstep), and the three 3x3 layers would move from MIOpen to the savfi
+    # Winograd kernel, whose coarser rounding this network amplifies (tests/test_system_gpu.py::lockstep_for)
+    lockstep_tasks = False
+
     def __init__(self, config, resume=False):
         super().__init__()
         self.config = config

@@ -536,14 +536,31 @@ def test_sepconv_trains_from_a_vimeo_directory_through_the_frame_stager(tmp_path
 # ---------------------------------------------------------------------------------------------
 # tasks in lockstep (--task_batch T): one launch per layer for all tasks of a meta-batch, per-task fast weights
 # ---------------------------------------------------------------------------------------------
+@pytest.fixture
+def lockstep_for(monkeypatch):
+    """Force lockstep on a plugin that opts out (VoxelFlow, where it is speed-neutral) so that its per-task layers exercise
+    the generic fallbacks -- ONE grouped MIOpen convolution on small maps, one plain call per task on large ones.  Its 3x3
+    layers are kept off the savfi Winograd kernel like in the product path: F(2x2,3x3) rounds ~3x coarser than a direct
+    convolution (2e-7 of the output scale), and VoxelFlow's flow-to-pixel map turns that into 1e-3 of a step-0 gradient
+    fingerprint and 1.7e-3 pixel L1 after two steps (against 1.4e-4 / 6.6e-5 through MIOpen; measured, 64x64 fixture)."""
+    def apply(system, model):
+        system.net.lockstep_tasks = True
+        if model == 'voxelflow':
+            monkeypatch.setattr(hip_ops, 'TASKS_MIN_TILES_FWD', 10 ** 9)
+            monkeypatch.setattr(hip_ops, 'TASKS_MIN_TILES_BWD', 10 ** 9)
+            monkeypatch.setattr(hip_ops, 'TASKS_WGRAD_MIN_PIXELS', 10 ** 9)
+    return apply
+
+
 @pytest.mark.parametrize("name", ['sepconv_msl_learnable_2step', 'voxelflow_lslr_sgd_2step', 'voxelflow_metasgd_adamax_2step',
                                   'superslomo_lslr_sgd_2step'])          # the 2-task fixtures
 @pytest.mark.parametrize("phase", ["train", "val"])
-def test_lockstep_tasks_match_reference_fixture(name, phase):
+def test_lockstep_tasks_match_reference_fixture(name, phase, lockstep_for):
     g = golden("system_" + name)
     model = str(g['model'])
     assert int(g['B']) == 2
     system = build_system(model, dict(parse_case_args(g), task_batch=2))
+    lockstep_for(system, model)
     calls = []
     orig = system._lockstep_body
     system._lockstep_body = lambda *a, **k: (calls.append(len(a[1])), orig(*a, **k))[1]
@@ -581,7 +598,7 @@ def test_lockstep_tasks_match_reference_fixture(name, phase):
     ('cain', dict(optimizer='SGD', inner_lr=1e-3, loss='1*L1', attenuate=True)),
     ('voxelflow', dict(optimizer='SGD', inner_lr=1e-3, loss='1*MSE')),
     ('rrin', dict(optimizer='SGD', inner_lr=1e-3, loss='1*L1'))])
-def test_lockstep_equals_the_sequential_loop(model, over):
+def test_lockstep_equals_the_sequential_loop(model, over, lockstep_for):
     """5 tasks in groups of up to 4 (so one lockstep group of 4 and a sequential straggler) against the plain task loop:
     losses, predictions, PSNR and every outer gradient."""
     over = dict(over, number_of_training_steps_per_iter=2, number_of_evaluation_steps_per_iter=2, batch_size=5)
@@ -589,6 +606,7 @@ def test_lockstep_equals_the_sequential_loop(model, over):
     got = {}
     for tb in (0, 4):
         system = build_system(model, dict(over, task_batch=tb))
+        lockstep_for(system, model)
         grads = {}
         system.optimizer.step = lambda *a, **k: grads.update(
             {n: p.grad.detach().clone() for n, p in system.named_parameters() if p.requires_grad and p.grad is not None})
@@ -612,11 +630,12 @@ def test_lockstep_equals_the_sequential_loop(model, over):
 @pytest.mark.parametrize("name", ['sepconv_msl_learnable_2step', 'voxelflow_lslr_sgd_2step', 'voxelflow_metasgd_adamax_2step',
                                   'superslomo_lslr_sgd_2step'])
 @pytest.mark.parametrize("phase", ["train", "val"])
-def test_graphed_lockstep_tasks_match_reference_fixture(name, phase):
+def test_graphed_lockstep_tasks_match_reference_fixture(name, phase, lockstep_for):
     """--graph_inner_loop 1 --task_batch 2: the lockstep pass replayed from hipGraphs (stacked static buffers)."""
     g = golden("system_" + name)
     model = str(g['model'])
     system = build_system(model, dict(parse_case_args(g), graph_inner_loop=1, task_batch=2))
+    lockstep_for(system, model)
     rec_outer = {}
     system.optimizer.step = lambda *a, **k: rec_outer.update(
         {n: helpers_fp(p.grad) for n, p in system.named_parameters() if p.requires_grad and p.grad is not None})
