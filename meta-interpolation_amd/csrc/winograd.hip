@@ -33,8 +33,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 
 constexpr int WNT = 256;            // threads
-constexpr int TBH = 4, TBW = 16;    // tiles per workgroup (rows x cols) -> 8 x 32 output pixels
-static_assert(TBH * TBW == 64, "one tile per lane");
+// 64 tiles per workgroup, one per lane, as a 2^(6-s) x 2^s block of tiles (s = WinoArgs::tile_shift, picked per launch):
+// 4 x 16 tiles (8 x 32 output pixels: wide rows, the default), 8 x 8 for small maps (a 12 x 16 map is 6 x 8 tiles: one 8 x 8
+// block holds it at 75 % where 4 x 16 blocks reach 37.5 %), 2 x 32 / 16 x 4 for very flat / narrow ones.
+constexpr int TILES_WG = 64;
 constexpr int COB = 32;             // produced channels per workgroup
 constexpr int CIB = 4;              // reduction channels per chunk (one MFMA k-step), one per wave
 constexpr int VS = 80;              // pitch of a V row [k] in floats: 64 tiles + 16 -> the 4 k-groups hit disjoint banks
@@ -96,7 +98,8 @@ struct WinoArgs {
   const float* bias;
   float* out;
   int K, I, KP, IP, H, W, Ho, Wo, off, tiles_y, tiles_x;   // input H x W, output Ho x Wo, patch origin 2t - off;
-  float slope;                                             // tiles_* = number of TBH x TBW tile blocks
+  float slope;                                             // tiles_* = number of tile blocks per image
+  int tile_shift;                                          // log2 of the tile block's width in tiles (see TILES_WG)
   int nsplit, chunks_per_split;                            // reduction channels split over workgroups (deep layers)
   float* partial;                                          // nsplit > 1: raw partial outputs [split][N][I][Ho][Wo]
   int T;                                                   // filter sets: sample n uses set n % T (U [T][...], bias [T][I])
@@ -251,7 +254,8 @@ __global__ __launch_bounds__(WNT, 2) void wino_conv3x3(WinoArgs a) {
   const size_t cplane = (size_t)a.H * a.W;
 
   // this thread's tile for the input transform: lane -> tile (4 x 16), wave -> channel within the chunk
-  const Patch patch = make_patch(2 * (tby * TBH + (lane >> 4)) - a.off, 2 * (tbx * TBW + (lane & 15)) - a.off, a.H, a.W);
+  const int tsh = a.tile_shift, tbw = 1 << tsh, tbh = TILES_WG >> tsh;
+  const Patch patch = make_patch(2 * (tby * tbh + (lane >> tsh)) - a.off, 2 * (tbx * tbw + (lane & (tbw - 1))) - a.off, a.H, a.W);
 
   f32x4 acc[4][2][4];
 #pragma unroll
@@ -346,7 +350,7 @@ __global__ __launch_bounds__(WNT, 2) void wino_conv3x3(WinoArgs a) {
       }
       if (i < a.I) {
         const float b = (a.bias && a.nsplit == 1) ? a.bias[task * a.I + i] : 0.f;
-        const int oty = tby * TBH + (t >> 4), otx = tbx * TBW + (t & 15);
+        const int oty = tby * tbh + (t >> tsh), otx = tbx * tbw + (t & (tbw - 1));
         const int oy = 2 * oty, ox = 2 * otx;
         float* obase = a.nsplit == 1 ? a.out : a.partial + (size_t)sp * gridDim.z * a.I * a.Ho * a.Wo;
         const float slope = a.nsplit == 1 ? a.slope : 1.f;       // bias / activation happen in wino_split_reduce
@@ -391,7 +395,7 @@ int round_up(int v, int m) { return (v + m - 1) / m * m; }
 // (256->256 at 48x64: 192 workgroups x 64 chunks on 512 slots): the chunks are split over up to 8 workgroups whose
 // raw partial outputs are added by wino_split_reduce.
 struct WinoPlan {
-  int K, I, KP, IP, off, Ho, Wo, th, tw, nsplit, chunks_per_split;
+  int K, I, KP, IP, off, Ho, Wo, th, tw, tile_shift, nsplit, chunks_per_split;
   int64_t u_floats, partial_floats;
 };
 
@@ -405,8 +409,15 @@ bool make_plan(WinoPlan& p, int N, int Ci, int Co, int H, int W, int pad, int mo
   p.Ho = H + 2 * p.off - 2;
   p.Wo = W + 2 * p.off - 2;
   if (p.Ho <= 0 || p.Wo <= 0) return false;
-  p.th = savfi_cdiv(savfi_cdiv(p.Ho, 2), TBH);
-  p.tw = savfi_cdiv(savfi_cdiv(p.Wo, 2), TBW);
+  // tile block shape: the one that covers the tile map with the fewest blocks (ties: the widest rows, 4 x 16 first)
+  const int ty = savfi_cdiv(p.Ho, 2), tx = savfi_cdiv(p.Wo, 2);
+  int64_t best = -1;
+  for (int s : {4, 3, 5, 2}) {
+    const int64_t blocks = (int64_t)savfi_cdiv(ty, TILES_WG >> s) * savfi_cdiv(tx, 1 << s);
+    if (best < 0 || blocks < best) { best = blocks; p.tile_shift = s; }
+  }
+  p.th = savfi_cdiv(ty, TILES_WG >> p.tile_shift);
+  p.tw = savfi_cdiv(tx, 1 << p.tile_shift);
   const int nchunk = p.KP / CIB;
   const int64_t wgs = (int64_t)p.th * p.tw * (p.IP / COB) * N;
   // split only launches that would leave workgroup slots empty (2 per CU x 256 CUs): the partial outputs cost an
@@ -458,7 +469,7 @@ extern "C" int savfi_conv3x3_tasks_f32(const float* x, const float* w, const flo
   constexpr size_t lds = (size_t)LDS_FLOATS * sizeof(float);      // 40 KB: two workgroups per CU
   const float* b = mode == 0 ? bias : nullptr;
   float* partial = workspace + (int64_t)T * p.u_floats;
-  WinoArgs a{x, workspace, b, out, p.K, p.I, p.KP, p.IP, H, W, p.Ho, p.Wo, p.off, p.th, p.tw, slope, p.nsplit,
+  WinoArgs a{x, workspace, b, out, p.K, p.I, p.KP, p.IP, H, W, p.Ho, p.Wo, p.off, p.th, p.tw, slope, p.tile_shift, p.nsplit,
              p.chunks_per_split, partial, T};
   hipLaunchKernelGGL(wino_conv3x3, dim3(p.th * p.tw, (p.IP / COB) * p.nsplit, N), dim3(WNT), lds, st, a);
   if (int e = savfi_launch_status()) return e;

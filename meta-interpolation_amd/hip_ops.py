@@ -701,8 +701,9 @@ def conv3x3_tasks(x, weight, bias=None, mode=0, slope=1.0, pad=1):
     return out
 
 
-def conv3x3_wgrad_tasks(x, gz, T, pad=1):
-    """savfi_conv3x3_wgrad_tasks_f32: gw [T,Co,Ci,3,3], gw[t] over the samples n % T == t."""
+def conv3x3_wgrad_tasks(x, gz, T, pad=1, stream=None, extra_stream=None):
+    """savfi_conv3x3_wgrad_tasks_f32: gw [T,Co,Ci,3,3], gw[t] over the samples n % T == t.  `stream` / `extra_stream`: as in
+    conv3x3_wgrad (launch on a side stream, buffers from the current stream's pool)."""
     x, gz = x.contiguous(), gz.contiguous()
     _hip.require_cuda(x, gz)
     N, Ci, H, W = x.shape
@@ -711,9 +712,12 @@ def conv3x3_wgrad_tasks(x, gz, T, pad=1):
     lib = _hip.lib()
     ws = torch.empty(_workspace_floats("savfi_conv3x3_wgrad_tasks_workspace_floats", N, T, Ci, Co, H, W, int(pad)), dtype=x.dtype, device=x.device)
     gw = torch.empty((T, Co, Ci, 3, 3), dtype=x.dtype, device=x.device)
+    if extra_stream is not None:
+        ws.record_stream(extra_stream)
+        gw.record_stream(extra_stream)
     _hip.launch("conv3x3_wgrad", lambda: _hip.check(lib.savfi_conv3x3_wgrad_tasks_f32(
-        x.data_ptr(), gz.data_ptr(), gw.data_ptr(), ws.data_ptr(), N, T, Ci, Co, H, W, int(pad), _hip.current_stream()),
-        "savfi_conv3x3_wgrad_tasks_f32"))
+        x.data_ptr(), gz.data_ptr(), gw.data_ptr(), ws.data_ptr(), N, T, Ci, Co, H, W, int(pad),
+        _hip.current_stream() if stream is None else stream), "savfi_conv3x3_wgrad_tasks_f32"))
     return gw
 
 
@@ -774,6 +778,8 @@ class _ConvBiasActTasks(torch.autograd.Function):
             z = z.view(N, Co, z.shape[-2], z.shape[-1])
         ctx.conf = (stride, padding, dilation, slope)
         ctx.has_bias = b is not None
+        ctx.wg_stream = weight_gradient_stream() if x.is_cuda else None
+        ctx.wg_uses = _weight_use_counter(w) if ctx.wg_stream is not None else None
         ctx.save_for_backward(x, w, z)
         return z
 
@@ -804,7 +810,16 @@ class _ConvBiasActTasks(torch.autograd.Function):
             gx = conv3x3_tasks(gz, w, None, 1, 1.0, pad)
             need_x = False
         if need_w and conv3x3_wgrad_tasks_eligible(x, w, stride, padding, dilation):
-            gw = conv3x3_wgrad_tasks(x, gz, T, pad)
+            side = ctx.wg_stream if (ctx.wg_stream is not None and ctx.wg_uses[0] == 1) else None
+            if side is not None:     # beside the data-gradient chain (see _ConvBiasAct.backward); joined by the caller
+                ready = torch.cuda.Event()
+                ready.record()
+                side.wait_event(ready)
+                gw = conv3x3_wgrad_tasks(x, gz, T, pad, stream=side.cuda_stream, extra_stream=side)
+                x.record_stream(side)
+                gz.record_stream(side)
+            else:
+                gw = conv3x3_wgrad_tasks(x, gz, T, pad)
             need_w = False
         if need_x or need_w:
             pair = lambda v: [v, v] if isinstance(v, int) else list(v)

@@ -428,12 +428,16 @@ class SceneAdaptiveInterpolation(nn.Module):
         sup = [torch.cat([pick(a[i]), pick(b[i])], 0) for i in range(3)]           # frame0 | target | frame1, [2T,3,H,W]
         tgt = [pick(i) for i in self.target_idxs]
 
+        overlap = self.device.type == 'cuda' and bool(getattr(self.args, 'wgrad_overlap', 0))
+
         def support_loss(weights, num_step):
             model_utils.set_own_params_const(True)      # first-order support pass: the plugin's own parameters are constants
+            hip_ops.set_weight_gradient_overlap(overlap)    # weight gradients beside the data-gradient chain; joined below
             try:
                 out = self.net.forward(sup[0], sup[2], params=weights, backup_running_statistics=(num_step == 0), num_step=num_step)
             finally:
                 model_utils.set_own_params_const(False)
+                hip_ops.set_weight_gradient_overlap(False)
             out = out[0] if isinstance(out, tuple) else out
             return self.criterion.per_sample(out, sup[1])['total'].sum()
 
@@ -446,6 +450,7 @@ class SceneAdaptiveInterpolation(nn.Module):
             keys = list(W)
             loss = support_loss(W, 0)
             grads = torch.autograd.grad(loss, [W[k] for k in keys])
+            hip_ops.join_weight_gradients()
             emb = hip_ops.mt_mean([g[t] for g in grads for t in range(T)]).view(len(keys), T).t()
             gamma = 1 - self.gamma_mult * self.attenuator(emb)
             gamma.clamp_(0, 1)
@@ -456,6 +461,7 @@ class SceneAdaptiveInterpolation(nn.Module):
             loss = support_loss(W, num_step)
             keys = list(W)
             grads = torch.autograd.grad(loss, [W[k] for k in keys], allow_unused=True)
+            hip_ops.join_weight_gradients()
             W = self.inner_loop_optimizer.update_params(names_weights_dict=W, names_grads_wrt_params_dict=dict(zip(keys, grads)),
                                                         num_step=num_step)
             if msl:

@@ -15,7 +15,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CAL_BYTES = 512 * 1024 * 1024
 # (B, Ho, Wo): the full padded canvas of the reference and the frame window this build evaluates (sepconv/model.py)
-CASES = [(1, 384, 512), (2, 384, 512), (1, 256, 448), (2, 256, 448)]
+CASES = [(1, 384, 512), (1, 256, 448), (2, 256, 448), (4, 256, 448), (8, 256, 448)]     # B = 8 / 4: lockstep support / target pass
 
 
 def mfma_rows(B, Ho, Wo):
