@@ -41,7 +41,7 @@ class MetaCAIN(nn.Module):
         self.decoder = Decoder(depth=depth)
         if resume:
             print('Loading model: pretrained_models/cain_base.pth')
-            ckpt = torch.load('pretrained_models/cain_base.pth')
+            ckpt = torch.load('pretrained_models/cain_base.pth', map_location='cpu', weights_only=False)      # authors' files pickle an args namespace
             self.load_state_dict({k.replace("module.", ""): v for k, v in ckpt['state_dict'].items()})
 
     def forward(self, x1, x2, params=None, **kwargs):

@@ -100,7 +100,7 @@ class MetaRRIN(nn.Module):
         self.final = MetaUNet(9, 3, 4)
         if resume:
             print('Loading model: pretrained_models/rrin_base.pth')
-            self.load_state_dict(torch.load('pretrained_models/rrin_base.pth'))
+            self.load_state_dict(torch.load('pretrained_models/rrin_base.pth', map_location='cpu', weights_only=False))
 
     def process(self, x0, x1, t, params=None):
         pv = as_view(params)

@@ -81,7 +81,7 @@ class MetaNetwork(nn.Module):
         if resume:
             path = 'pretrained_models/sepconv_base_' + strModel + '.pth'
             print('Loading model: ' + path)
-            self.load_state_dict(torch.load(path))
+            self.load_state_dict(torch.load(path, map_location='cpu', weights_only=False))
 
     @staticmethod
     def padded_size(height, width):

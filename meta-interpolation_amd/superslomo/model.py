@@ -128,7 +128,7 @@ class MetaSuperSloMo(nn.Module):
         self.arbTimeFlowIntrp = MetaUNet(20, 5)
         if resume:
             print('Loading model: pretrained_models/superslomo_base.pth')
-            ckpt = torch.load('pretrained_models/superslomo_base.pth')
+            ckpt = torch.load('pretrained_models/superslomo_base.pth', map_location='cpu', weights_only=False)
             self.flowComp.load_state_dict(ckpt['state_dictFC'])
             self.arbTimeFlowIntrp.load_state_dict(ckpt['state_dictAT'])
 

@@ -53,7 +53,7 @@ class MetaVoxelFlow(nn.Module):
                 m.bias.data.zero_()
         if resume:
             print('Loading model: pretrained_models/voxelflow_ft.pth')
-            self.load_state_dict(torch.load('pretrained_models/voxelflow_ft.pth')['state_dict'])
+            self.load_state_dict(torch.load('pretrained_models/voxelflow_ft.pth', map_location='cpu', weights_only=False)['state_dict'])
         self.fix_batchnorm_parameters()
         for attr, val in (('mult_conv_w', [1, 1]), ('mult_conv_b', [2, 0]), ('mult_bn', [1, 1])):
             setattr(self.config, attr, val)
