@@ -568,14 +568,17 @@ class SceneAdaptiveInterpolation(nn.Module):
                                  training_phase=training_phase, do_evaluation=do_evaluation, importance=importance)
         width = self._lockstep_width(use_second_order, frames[0].shape[1:]) if len(local) > 1 else 0
         if width:
-            results = []
-            for lo in range(0, len(local), width):
-                group = local[lo:lo + width]
+            groups = [local[lo:lo + width] for lo in range(0, len(local), width)]
+
+            def group_body(j):
+                group = groups[j]
                 if len(group) == 1:
-                    results.append(body(group[0]))
-                else:
-                    results.extend(self._lockstep_body(frames, group, num_steps=num_steps, msl=msl, training_phase=training_phase,
-                                                       do_evaluation=do_evaluation, importance=importance))
+                    return {'group': [body(group[0])]}
+                return {'group': self._lockstep_body(frames, group, num_steps=num_steps, msl=msl, training_phase=training_phase,
+                                                     do_evaluation=do_evaluation, importance=importance)}
+            # --task_streams N > 1: the lockstep groups themselves run concurrently, one thread + HIP stream each
+            packed = self._run_tasks(list(range(len(groups))), group_body, flatten=lambda r: r['group'])
+            results = [res for p_ in packed for res in p_['group']]
         else:
             results = self._run_tasks(local, body)
         for task_id, res in zip(local, results):
