@@ -17,7 +17,7 @@
  * The reference has no CPU implementation of this op (both branches raise NotImplementedError,
  * sepconv.py:293-294,373-374) and its kernels cannot be run here (CUDA + cupy), so this file is
  * pinned only by (a) being a transcription of the kernel text, (b) agreeing with an independent
- * PyTorch restatement checked by fp64 gradcheck (oracle/torch_ops.py, tests/test_oracle_ops.py).
+ * PyTorch restatement checked by fp64 gradcheck (oracle/torch_ops.py, tests/test_oracle_golden.py).
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
  *
  * Layout: contiguous fp32 NCHW.  `n` threads of the CUDA grid become the `idx` loop (OpenMP).
