@@ -22,10 +22,12 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and "HIP_VISIBLE_DEVICES" not in os.environ and "CUDA_VISIBLE_DEVICES" not in os.environ \
-            and not torch.cuda.is_initialized() and os.environ.get("SAVFI_PIN_DEVICE", "1") != "0":
-        # one process owns ONE device: pin before the HIP runtime comes up, so that no library handle, stream
-        # or stray context ever lands on a neighbour's GPU.  RCCL still reaches the peers over xGMI (dmabuf IPC).
+    if world > 1 and os.environ.get("SAVFI_PIN_DEVICE") == "1" and "HIP_VISIBLE_DEVICES" not in os.environ \
+            and "CUDA_VISIBLE_DEVICES" not in os.environ and not torch.cuda.is_initialized():
+        # Opt-in (SAVFI_PIN_DEVICE=1): hide every device but this rank's before the HIP runtime comes up.  Not the
+        # default: under ROCm, isolating ranks with *_VISIBLE_DEVICES can take peer-to-peer IPC away from RCCL (ranks that cannot
+        # see each other's GPU fall back to host staging), and the one all-reduce of a meta-iteration wants xGMI.  One process
+        # still owns ONE device either way: everything below runs on `local_rank` only.
         os.environ["HIP_VISIBLE_DEVICES"] = str(local_rank)
     if torch.cuda.is_available():
         pinned = os.environ.get("HIP_VISIBLE_DEVICES", "").strip() == str(local_rank) and torch.cuda.device_count() == 1
