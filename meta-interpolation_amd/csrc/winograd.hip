@@ -51,14 +51,19 @@ constexpr int LDS_FLOATS = (2 * VBUF > XBUF) ? 2 * VBUF : XBUF;
 //   Uf[k / 4][i / 32][r][lane = (k % 4) * 16 + i % 16][c][(i % 32) / 16]        (xi = 4 r + c)
 // mode 0 (forward):        g[a][b] = w[i][k][a][b]           (w is [Co][Ci][3][3]; i = co, k = ci)
 // mode 1 (data gradient):  g[a][b] = w[k][i][2-a][2-b]       (i = ci, k = co)
-// blockIdx.y = task: filter set w + task * Co*Ci*9 -> U + task * 16*KP*IP (tasks adapted in lockstep own their weights).
+// Filter set `task` (tasks adapted in lockstep own their weights): w + task * Co*Ci*9 -> U + task * 16*KP*IP.
 __global__ __launch_bounds__(256) void wino_filter_transform(const float* __restrict__ w, float* __restrict__ U,
                                                              int Co, int Ci, int K, int I, int KP, int IP, int mode) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= KP * IP) return;
-  w += (size_t)blockIdx.y * Co * Ci * 9;
-  U += (size_t)blockIdx.y * 16 * KP * IP;
-  const int k = idx / IP, i = idx - k * IP;
+  // One workgroup = 4 reduction channels (one MFMA k-step) x 64 produced channels: it fills two whole
+  // [4 rows][64 lanes][8 floats] fragment blocks (16 KB) of U by itself -- full cache lines leave the CU, where a
+  // k-major thread numbering made every 2 KB block the target of four workgroups' partial writes -- and its reads of a
+  // forward filter (mode 0: w[i][k][3][3]) are runs of 4 channels = 144 contiguous bytes per lane quad.
+  const int kk = threadIdx.x & 3, ii = threadIdx.x >> 2;
+  const int k = 4 * blockIdx.x + kk, i = 64 * (blockIdx.y % ((IP + 63) / 64)) + ii;
+  const int task = blockIdx.y / ((IP + 63) / 64);
+  if (i >= IP) return;
+  w += (size_t)task * Co * Ci * 9;
+  U += (size_t)task * 16 * KP * IP;
   float g[3][3];
 #pragma unroll
   for (int a = 0; a < 3; ++a)
@@ -463,7 +468,7 @@ extern "C" int savfi_conv3x3_tasks_f32(const float* x, const float* w, const flo
   if ((int64_t)H * W >= ((int64_t)1 << 29)) return SAVFI_E_TOOBIG;     // 32-bit byte offsets inside a channel plane
   if ((int64_t)p.th * p.tw > 0x7fffffffLL || (int64_t)(p.IP / COB) * p.nsplit > 65535 || N > 65535 || T > 65535) return SAVFI_E_TOOBIG;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(wino_filter_transform, dim3(savfi_cdiv(p.KP * p.IP, 256), T), dim3(256), 0, st, w, workspace, Co, Ci, p.K,
+  hipLaunchKernelGGL(wino_filter_transform, dim3(p.KP / 4, savfi_cdiv(p.IP, 64) * T), dim3(256), 0, st, w, workspace, Co, Ci, p.K,
                      p.I, p.KP, p.IP, mode);
   if (int e = savfi_launch_status()) return e;
   constexpr size_t lds = (size_t)LDS_FLOATS * sizeof(float);      // 40 KB: two workgroups per CU
