@@ -5,7 +5,8 @@ config.py:14-77 so that its launch scripts (scripts/run_*.sh) keep working.  ``g
 Additions for the MI355X build (all optional, all default to the reference behaviour):
   --fuse_support_pairs {0,1}   run the two support triplets of an inner step as one N=2 forward
   --fuse_conv_act {0,1}        conv+bias+(Leaky)ReLU with fused epilogue kernels (default 1; first-order only)
-  --graph_inner_loop {0,1}     replay the first-order inner loop from captured hipGraphs (graph_inner_loop.py)
+  --graph_inner_loop {-1,0,1}  replay the first-order inner loop from captured hipGraphs (graph_inner_loop.py): 1 always, 0 never,
+                               -1 (default) when the rank would otherwise adapt its tasks one at a time (launch-bound passes)
   --sepconv_window {0,1}       SepConv: evaluate the sub-networks / 51-tap op on the frame window only (same values)
   --wgrad_overlap {0,1}        weight gradients of first-order support passes on a side stream, beside the data-gradient chain (default 0)
   --task_streams N             adapt N tasks of a meta-batch concurrently (one Python thread + HIP stream each; default 1)
@@ -45,7 +46,7 @@ _FLAGS = {
         ('use_tensorboard', 'flag', False), ('viz', 'flag', False), ('lpips', 'flag', False),
     ],
     'MI355X': [
-        ('fuse_support_pairs', int, 1), ('fuse_conv_act', int, 1), ('graph_inner_loop', int, 0), ('sepconv_window', int, 1),
+        ('fuse_support_pairs', int, 1), ('fuse_conv_act', int, 1), ('graph_inner_loop', int, -1), ('sepconv_window', int, 1),
         ('task_streams', int, 1), ('wgrad_overlap', int, 0), ('task_batch', int, 4),
         ('synthetic', 'flag', False),
     ],

@@ -105,6 +105,8 @@ class _DeferredMeters:
 
 
 class SceneAdaptiveInterpolation(nn.Module):
+    MAX_GRAPH_SETS = 8
+
     def __init__(self, args, net=None, inner_loop_optimizer=None, criterion=None, task_parallel=None):
         super().__init__()
         self.args = args
@@ -549,7 +551,7 @@ class SceneAdaptiveInterpolation(nn.Module):
         frames = data_batch
         num_tasks = len(frames[0])
         self._manual_grads = None
-        if graph_inner_loop.supported(self, use_second_order):
+        if graph_inner_loop.supported(self, use_second_order) and self._wants_graphs(frames, training_phase):
             return self._forward_graphed(frames, epoch, use_multi_step_loss_optimization, num_steps, training_phase,
                                          do_evaluation)
         self._set_pass_flags(use_second_order)
@@ -600,6 +602,17 @@ class SceneAdaptiveInterpolation(nn.Module):
         metrics = {'psnr': utils.AverageMeter(), 'ssim': utils.AverageMeter()}
         self._logging(losses, metrics, deferred, eval_mse, eval_ssim, importance, training_phase)
         return losses, preds, metrics
+
+    def _wants_graphs(self, frames, training_phase):
+        """--graph_inner_loop 1: always (where supported); -1 (default): when this rank would otherwise adapt its tasks ONE AT A
+        TIME -- a single local task, or a plugin / configuration outside the lockstep path.  A per-task pass is launch-bound
+        (CAIN 64x64: 11 steps/s eager, 31 from graphs); a lockstep pass over several tasks is GPU-bound in eager mode already
+        and stays there, where every kernel can be timed in place."""
+        mode = int(getattr(self.args, 'graph_inner_loop', 0) or 0)
+        if mode > 0:
+            return True
+        local = self._local_tasks(len(frames[0]), training_phase)
+        return len(local) <= 1 or self._lockstep_width(False, frames[0].shape[1:]) <= 1
 
     def _set_pass_flags(self, use_second_order):
         """Per-pass switches of the op layer (thread-local there: task threads inherit them through _run_tasks)."""
@@ -662,12 +675,19 @@ class SceneAdaptiveInterpolation(nn.Module):
         n = max(1, min(int(getattr(self.args, 'task_streams', 1) or 1), len(groups)))
 
         def loop_for(i, T):
-            if key + (i, T) not in self._graphs:
+            k = key + (i, T)
+            if k not in self._graphs:
                 import gc
+                # a graph set pins its static buffers and memory pool: keep the most recently used ones only (evaluation over
+                # clips of many different sizes would otherwise capture, and keep, one set per size)
+                while len(self._graphs) >= self.MAX_GRAPH_SETS:
+                    self._graphs.pop(next(iter(self._graphs)))
                 gc.collect()
-                self._graphs[key + (i, T)] = graph_inner_loop.GraphedInnerLoop(self, frames[0].shape[1:], num_steps,
-                                                                               bool(training_phase), msl, tasks=T)
-            return self._graphs[key + (i, T)]
+                self._graphs[k] = graph_inner_loop.GraphedInnerLoop(self, frames[0].shape[1:], num_steps,
+                                                                    bool(training_phase), msl, tasks=T)
+            else:
+                self._graphs[k] = self._graphs.pop(k)          # most recently used last
+            return self._graphs[k]
         owner = {tuple(g): j % n for j, g in enumerate(groups)}
         for g in groups:                                   # capture on this thread, before any worker starts
             loop_for(owner[tuple(g)], len(g))

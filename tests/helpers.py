@@ -59,7 +59,11 @@ def assert_fp_close(got, want, rtol=1e-5, what=""):
 
 
 def build_system(model, overrides, fuse=1, device="cuda"):
+    """Product system with seeded weights.  Execution-mode switches are pinned to the plain eager loop unless a test asks for a
+    mode (`graph_inner_loop`, `task_batch`, `task_streams` in `overrides`): the fixture tests hook update_params per step."""
     from meta_interpolation_amd.meta_learning_system import SceneAdaptiveInterpolation
+    overrides = dict(overrides)
+    overrides.setdefault('graph_inner_loop', 0)
     args = default_args(model=model, num_gpu=1, fuse_support_pairs=fuse, **overrides)
     net = build_plugin(model, device)
     system = SceneAdaptiveInterpolation(args, net=net)

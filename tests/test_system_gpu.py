@@ -659,3 +659,24 @@ def test_graphed_lockstep_tasks_match_reference_fixture(name, phase, lockstep_fo
                 if abs(row[1]) > 0:
                     assert k in rec_outer, k
                     assert_fp_close(rec_outer[k], row, tol['outer'], (name, 'outer', k))
+
+
+def test_default_execution_mode_policy():
+    """config.py defaults (--graph_inner_loop -1, --task_batch 4): a rank with ONE task replays hipGraphs (launch-bound pass), a rank
+    with several adapts them in lockstep in the eager loop, L2F (not capturable) stays eager -- all with the fixture's numbers."""
+    for name, want_graphs, want_lockstep in (('c1_cain_lslr_sgd', 1, 0), ('sepconv_msl_learnable_2step', 0, 1), ('cain_l2f', 0, 0)):
+        g = golden("system_" + name)
+        model = str(g['model'])
+        system = build_system(model, dict(parse_case_args(g), graph_inner_loop=-1))
+        calls = []
+        orig = system._lockstep_body
+        system._lockstep_body = lambda *a, **k: (calls.append(len(a[1])), orig(*a, **k))[1]
+        frames = synthetic.septuplet_batch(int(g['B']), int(g['H']), int(g['W']), model=model)
+        losses, preds, metrics = system.run_train_iter(data_batch=frames, epoch=0, do_evaluation=True)
+        torch.cuda.synchronize()
+        assert len(system._graphs) == want_graphs and len(calls) == want_lockstep, (name, len(system._graphs), calls)
+        tol = tolerances(name, 'train')
+        assert abs(losses['loss'].item() - float(g['train_loss'])) <= tol['loss'] * abs(float(g['train_loss']))
+        got = torch.stack([p.squeeze(0) for p in preds]).cpu().numpy()
+        assert np.abs(got - g['train_preds']).mean() < tol['l1']
+        assert abs(metrics['psnr'].avg - float(g['train_psnr'])) < tol['psnr']
