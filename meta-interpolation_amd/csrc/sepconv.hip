@@ -548,6 +548,319 @@ __global__ __launch_bounds__(MNT) void sepconv_bwd_mfma(const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------
+// Persistent form of the filter-gradient kernel (round 2).
+//
+// The tiled kernel above stages (R + 50) input rows for R output rows and its launch is a whole number of workgroup rounds:
+// PMC showed 12 % of the kernel in the partly filled last round and ~8 % in staging prologues (one workgroup per CU).
+// Here the launch has ONE workgroup per CU and the output is cut into "phases" (two output rows of one 64-column strip of
+// one sample, the unit the 2 x 4 waves process), numbered strip-major; workgroup w takes the phases [w Q, (w + 1) Q): equal
+// shares, no tail.  Consecutive phases of a strip slide down by two rows, so the input window lives in a CIRCULAR buffer of 64
+// rows per channel (slot = input row & 63): a phase reads rows 2 ph .. 2 ph + 51, twelve further rows are staged every sixth
+// phase (two barriers), the full 64 only when a workgroup enters a strip.  Compute per phase is that of sepconv_bwd_mfma.
+// ------------------------------------------------------------------------------------------
+constexpr int PWIN = 64;                       // window rows per channel (power of two >= K + 1)
+constexpr int PAHEAD = PWIN - (KFAST + 1);     // rows staged per refill (12)
+
+// rows [r_lo, r_lo + nrows) of the strip (b, x0) -> their circular slots, all three channels; thread -> (column, row group)
+template <int NROWS>
+__device__ __forceinline__ void stage_rows_circular(float* __restrict__ inT, __amdgpu_buffer_rsrc_t in_rs, int b, int x0, int r_lo,
+                                                    int Hi, int Wi, int tid) {
+  constexpr int C = 3, RG = MNT / 128, NIT = (NROWS + RG - 1) / RG, LP = PWIN * MLW;
+  const int q = tid & 127, rg = tid >> 7;
+  const int colb = min(x0 + q, Wi - 1) * 4;
+  float buf[C][NIT];
+#pragma unroll
+  for (int c = 0; c < C; ++c)
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int r = min(r_lo + rg + it * RG, Hi - 1);
+      buf[c][it] = sc_bload(in_rs, (unsigned)(((b * C + c) * Hi + r) * Wi * 4 + colb), 0u);
+    }
+  if (q < MSPAN) {
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int rr = rg + it * RG;
+        if (rr < NROWS) inT[c * LP + ((r_lo + rr) & (PWIN - 1)) * MLW + q] = buf[c][it];
+      }
+  }
+}
+
+template <int K, bool WANT_V, bool WANT_H>
+__global__ __launch_bounds__(MNT) void sepconv_bwd_mfma_p(const float* __restrict__ in, const float* __restrict__ v,
+                                                         const float* __restrict__ h, const float* __restrict__ gO,
+                                                         float* __restrict__ gV, float* __restrict__ gH,
+                                                         int B, int Ho, int Wo, int nph, int ncol, int per_wg) {
+  constexpr int C = 3, LP = PWIN * MLW;
+  constexpr int KT = (16 + K - 1 + 3) / 4, MTV = (K + 15) / 16, KTV = (K + 3) / 4, MTH = (16 + K - 1 + 15) / 16, NREG = (K + 3) / 4;
+  static_assert(KT == 17 && MTV == 4 && MLW % 4 == 0 && 4 * KTV == MKP && 16 * 3 + 16 * MTH <= MLW && K + 1 <= PWIN, "operand geometry");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* inT = lds;
+  float* hB = lds + C * LP + (threadIdx.x >> 6) * (K + MKP) * 16;
+  float* vB = hB + K * 16;
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wc = w & 3, wr = w >> 2;
+  const int j = lane & 15, ks = lane >> 4;
+  const int total = B * ncol * nph;
+  const int g0 = blockIdx.x * per_wg, g1 = min(g0 + per_wg, total);
+  if (g0 >= g1) return;
+  const int Hi = Ho + K - 1, Wi = Wo + K - 1;
+  const size_t plane = (size_t)Ho * Wo;
+  const unsigned plane_b = (unsigned)plane * 4u;
+  // whole-tensor resources (the launcher checks that they fit 2^31 bytes); the sample goes into the per-lane offset
+  const __amdgpu_buffer_rsrc_t hsrc = sc_rsrc(h, (unsigned)(B * K) * plane_b);
+  const __amdgpu_buffer_rsrc_t vsrc = sc_rsrc(v, (unsigned)(B * K) * plane_b);
+  const __amdgpu_buffer_rsrc_t gsrc = sc_rsrc(gO, (unsigned)(B * C) * plane_b);
+  const __amdgpu_buffer_rsrc_t isrc = sc_rsrc(in, (unsigned)(B * C) * (unsigned)(Hi * Wi) * 4u);
+
+  auto pos_of = [&](int g, int& b, int& x0, int& ph) {
+    const int s = g / nph;
+    ph = g - s * nph;
+    b = s / ncol;
+    x0 = (s - b * ncol) * MC;
+  };
+  // byte offset of this lane's pixel (row y of sample b, clamped) inside a [B][*][Ho][Wo] tensor with `ch` planes per sample
+  auto pix_off = [&](int b, int x0, int y, int ch) {
+    return (unsigned)b * (unsigned)ch * plane_b + (unsigned)(min(y, Ho - 1) * Wo + min(x0 + 16 * wc + j, Wo - 1)) * 4u;
+  };
+  auto load_taps = [&](float (&regs)[NREG], __amdgpu_buffer_rsrc_t src, int b, int x0, int y) {
+    const unsigned voff = pix_off(b, x0, y, K) + (unsigned)(lane >> 4) * plane_b;
+#pragma unroll
+    for (int it = 0; it < NREG; ++it) regs[it] = sc_bload(src, voff, (unsigned)(4 * it) * plane_b);
+  };
+
+  int b, x0, ph;
+  pos_of(g0, b, x0, ph);
+  float hreg[NREG], vreg[NREG], gnext[C];
+  load_taps(hreg, hsrc, b, x0, 2 * ph + wr);
+  load_taps(vreg, vsrc, b, x0, 2 * ph + wr);
+  {
+    const unsigned go = pix_off(b, x0, 2 * ph + wr, C);
+#pragma unroll
+    for (int c = 0; c < C; ++c) gnext[c] = sc_bload(gsrc, go, (unsigned)c * plane_b);
+  }
+  stage_rows_circular<PWIN>(inT, isrc, b, x0, 2 * ph, Hi, Wi, tid);
+  int loaded_hi = 2 * ph + PWIN;
+  // columns MSPAN..MLW-1 are only read by gH rows q >= 66, which are discarded, but keep them finite (never restaged)
+  static_assert(MLW - MSPAN == 16, "zero-fill indexing");
+  for (int i = tid; i < C * PWIN * 16; i += MNT) inT[(i >> 4) * MLW + MSPAN + (i & 15)] = 0.f;
+  if (lane < 16) vB[K * 16 + lane] = 0.f;
+  mfma_store_taps<K, NREG>(hB, hreg, lane);
+  mfma_store_taps<K, NREG>(vB, vreg, lane);
+  __syncthreads();
+  if (wr == 1) __builtin_amdgcn_s_sleep(40);      // de-phase the two waves of a SIMD (see the tiled kernel)
+
+#pragma unroll 1
+  for (int g = g0; g < g1; ++g) {
+    // ---- window upkeep (workgroup-uniform decisions) ------------------------------------------------------------
+    if (g != g0 && ph == 0) {                      // entered the next strip: the whole window is new
+      __syncthreads();
+#pragma unroll 1
+      for (int r = 0; r < PWIN; r += 16)           // in four pieces: 12 staging registers instead of 48 (rare path)
+        stage_rows_circular<16>(inT, isrc, b, x0, r, Hi, Wi, tid);
+      loaded_hi = PWIN;
+      __syncthreads();
+    } else if (2 * ph + K + 1 > loaded_hi) {       // slide: the twelve oldest rows are behind every wave's current phase
+      __syncthreads();
+      stage_rows_circular<PAHEAD>(inT, isrc, b, x0, loaded_hi, Hi, Wi, tid);
+      loaded_hi += PAHEAD;
+      __syncthreads();
+    }
+    const int y = 2 * ph + wr;
+    const int x = x0 + 16 * wc + j;
+    const bool pvalid = (x < Wo) && (y < Ho);
+    const size_t opix = (size_t)min(y, Ho - 1) * Wo + min(x, Wo - 1);
+    const size_t sample_k = (size_t)b * K * plane;
+    float g_[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) g_[c] = gnext[c];
+    int nb = b, nx0 = x0, nph_ = ph;
+    if (g + 1 < g1) {                              // next phase's taps and upstream gradient: HBM -> registers
+      pos_of(g + 1, nb, nx0, nph_);
+      load_taps(hreg, hsrc, nb, nx0, 2 * nph_ + wr);
+      load_taps(vreg, vsrc, nb, nx0, 2 * nph_ + wr);
+      const unsigned go = pix_off(nb, nx0, 2 * nph_ + wr, C);
+#pragma unroll
+      for (int c = 0; c < C; ++c) gnext[c] = sc_bload(gsrc, go, (unsigned)c * plane_b);
+    }
+    const float* hb = hB + j;
+    const float* vb = vB + j;
+
+    if (WANT_V) {
+      float bf[KT];
+#pragma unroll
+      for (int t = 0; t < KT; ++t) {
+        const int q = (t < 16) ? (16 * (t >> 2) + 4 * ks + (t & 3)) : (64 + ks);
+        const int tap = q - j;
+        const float val = hb[min(max(tap, 0), K - 1) * 16];
+        bf[t] = (tap >= 0 && tap < K) ? val : 0.f;
+      }
+      // A rows: tap fy = 16 m + j (clamped) of this wave's output row -> input row y + fy -> its circular slot
+      int abV[MTV];
+#pragma unroll
+      for (int m = 0; m < MTV; ++m) abV[m] = ((y + min(16 * m + j, K - 1)) & (PWIN - 1)) * MLW + 16 * wc + 4 * ks;
+      f32x4 acc[MTV];
+#pragma unroll
+      for (int m = 0; m < MTV; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      constexpr int NG = C * 5;
+      auto load_group = [&](f32x4 (&dst)[MTV], int gi) {
+        const int c = gi / 5, u = gi - 5 * c;
+#pragma unroll
+        for (int m = 0; m < MTV; ++m) {
+          const float* ap = inT + abV[m] + c * LP;
+          if (u < 4) dst[m] = *reinterpret_cast<const f32x4*>(ap + 16 * u);
+          else dst[m][0] = ap[64 - 3 * ks];
+        }
+      };
+      f32x4 acur[MTV], anxt[MTV];
+#if SC_PIN
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      load_group(acur, 0);
+#if SC_PIN
+      __builtin_amdgcn_sched_group_barrier(0x100, MTV, 0);
+#endif
+#pragma unroll
+      for (int gi = 0; gi < NG; ++gi) {
+        if (gi + 1 < NG) load_group(anxt, gi + 1);
+        const int c = gi / 5, u = gi - 5 * c;
+#pragma unroll
+        for (int e = 0; e < (u < 4 ? 4 : 1); ++e) {
+          const float bb = g_[c] * bf[u < 4 ? 4 * u + e : 16];
+#pragma unroll
+          for (int m = 0; m < MTV; ++m)
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[m][e], bb, acc[m], 0, 0, 0);
+        }
+#pragma unroll
+        for (int m = 0; m < MTV; ++m) acur[m] = anxt[m];
+#if SC_PIN
+        if (gi + 1 < NG) __builtin_amdgcn_sched_group_barrier(0x100, MTV, 0);
+        if (u < 4) {
+          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 4 * MTV, 0);
+        } else {
+          __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, MTV, 0);
+        }
+#endif
+      }
+#if SC_PIN
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+      for (int m = 0; m < MTV; ++m) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int fy = 16 * m + 4 * ks + e;
+          if (pvalid && fy < K) gV[sample_k + (size_t)fy * plane + opix] = acc[m][e];
+        }
+      }
+    }
+
+    if (WANT_H) {
+      constexpr int MTHM = MTH - 1;
+      static_assert(K == 51 && 16 * MTHM == 64, "band geometry of the VALU tail");
+      float bv[KTV];
+#pragma unroll
+      for (int t = 0; t < KTV; ++t) bv[t] = vb[(4 * t + ks) * 16];
+      f32x4 acc[MTHM];
+#pragma unroll
+      for (int m = 0; m < MTHM; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      // step (c, t) reads input row y + 4 t + ks (tap 4t + ks; the zero tap 51 steps back one row): slot (s0 + 4 t) & 63.
+      // The 13 rows span 48 < 64 slots, so they wrap at most once: two bases, picked per step by a compare.
+      const int s0 = (y + ks) & (PWIN - 1);
+      const float* pA = inT + s0 * MLW + 16 * wc + 4 * j;
+      const float* pB = pA - PWIN * MLW;
+      const int s0l = (y + 4 * (KTV - 1) + ks - (ks == 3 ? 1 : 0)) & (PWIN - 1);      // last step's row
+      const float* pL = inT + s0l * MLW + 16 * wc + 4 * j;
+      auto a_of = [&](int idx) {
+        const int c = idx / KTV, t = idx - KTV * c;
+        const float* p = (t == KTV - 1) ? pL : ((s0 + 4 * t >= PWIN) ? pB : pA) + 4 * t * MLW;
+        return *reinterpret_cast<const f32x4*>(p + c * LP);
+      };
+      constexpr int NS = C * KTV;
+#if SC_PIN
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      f32x4 a0 = a_of(0), a1 = a_of(1);
+#if SC_PIN
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#endif
+#pragma unroll
+      for (int idx = 0; idx < NS; ++idx) {
+        f32x4 a2 = a0;
+        if (idx + 2 < NS) a2 = a_of(idx + 2);
+        const int c = idx / KTV, t = idx - KTV * c;
+        const float bb = g_[c] * bv[t];
+#pragma unroll
+        for (int m = 0; m < MTHM; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[m], bb, acc[m], 0, 0, 0);
+        a0 = a1;
+        a1 = a2;
+#if SC_PIN
+        if (idx + 2 < NS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, MTHM, 0);
+#endif
+      }
+#if SC_PIN
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      // VALU tail (q = 64, 65): lane = tap row fy, then a 64-lane sum of the three partial products
+      float s6414 = 0.f, s6415 = 0.f, s6515 = 0.f;
+      {
+        const int fy = min(lane, K - 1);
+        const float live = lane < K ? 1.f : 0.f;
+        const float v14 = vB[fy * 16 + 14] * live, v15 = vB[fy * 16 + 15] * live;
+        const float* col = inT + ((y + fy) & (PWIN - 1)) * MLW + 16 * wc + 64;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const float a64 = col[c * LP], a65 = col[c * LP + 1];
+          const float g14 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, g_[c]), 14));
+          const float g15 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, g_[c]), 15));
+          s6414 = fmaf(g14 * v14, a64, s6414);
+          s6415 = fmaf(g15 * v15, a64, s6415);
+          s6515 = fmaf(g15 * v15, a65, s6515);
+        }
+        s6414 = wave_sum(s6414);
+        s6415 = wave_sum(s6415);
+        s6515 = wave_sum(s6515);
+      }
+      {   // gH through an LDS transpose of the wave's (dead) tap rows: 13 x four 64-byte runs
+        __builtin_amdgcn_wave_barrier();
+        float* tile = hB;
+#pragma unroll
+        for (int m = 0; m < MTHM; ++m)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) tile[(16 * ks + 4 * e + m) * 16 + j] = acc[m][e];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int t = 0; t < KTV; ++t) {
+          const int fx = 4 * t + ks;
+          const float val = tile[min(j + fx, 63) * 16 + j];
+          if (pvalid && fx < K && j + fx < 64) gH[sample_k + (size_t)fx * plane + opix] = val;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      if (pvalid && lane == 14) gH[sample_k + (size_t)50 * plane + opix] = s6414;
+      if (pvalid && lane == 15) {
+        gH[sample_k + (size_t)49 * plane + opix] = s6415;
+        gH[sample_k + (size_t)50 * plane + opix] = s6515;
+      }
+    }
+
+    if (g + 1 < g1) {
+      __builtin_amdgcn_wave_barrier();
+      mfma_store_taps<K, NREG>(hB, hreg, lane);
+      mfma_store_taps<K, NREG>(vB, vreg, lane);
+      __builtin_amdgcn_wave_barrier();
+    }
+    b = nb; x0 = nx0; ph = nph_;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // generic direct kernels (any K, any C): one thread per output element, x fastest.
 // ------------------------------------------------------------------------------------------
 __global__ void sepconv_fwd_direct(const float* __restrict__ in, const float* __restrict__ v,
@@ -628,11 +941,11 @@ __global__ void sepconv_bwd_input_direct(const float* __restrict__ v, const floa
 }
 
 // Experiment switches, read ONCE per process (not per launch): SAVFI_SEPCONV_NO_MFMA forces the direct kernels,
-// SAVFI_SEPCONV_MFMA_ROWS = 8 | 12 | 16 pins the rows per workgroup.
+// SAVFI_SEPCONV_TILED the tiled (non-persistent) MFMA kernels, SAVFI_SEPCONV_MFMA_ROWS = 8 | 12 | 16 pins their rows per workgroup.
 struct SepconvEnv {
-  bool no_mfma;
+  bool no_mfma, tiled;
   int rows;
-  SepconvEnv() : no_mfma(getenv("SAVFI_SEPCONV_NO_MFMA") != nullptr), rows(0) {
+  SepconvEnv() : no_mfma(getenv("SAVFI_SEPCONV_NO_MFMA") != nullptr), tiled(getenv("SAVFI_SEPCONV_TILED") != nullptr), rows(0) {
     if (const char* e = getenv("SAVFI_SEPCONV_MFMA_ROWS")) {
       const int r = atoi(e);
       if (r == 8 || r == 12 || r == 16) rows = r;
@@ -693,6 +1006,51 @@ int launch_bwd_mfma(const float* in, const float* v, const float* h, const float
   return launch_bwd_mfma_one<R, false, true>(in, v, h, gO, gV, gH, B, Ho, Wo, st);
 }
 
+constexpr size_t persistent_lds_bytes() {
+  return ((size_t)3 * PWIN * MLW + (size_t)(MNT / 64) * (KFAST + MKP) * 16) * sizeof(float);
+}
+
+int device_cu_count() {
+  static int cus[32] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  int& n = cus[dev & 31];
+  if (n == 0) {
+    int v = 0;
+    n = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+  }
+  return n;
+}
+
+// whole-tensor buffer resources: every tensor must stay below 2^31 bytes
+bool persistent_ok(int B, int Ho, int Wo) {
+  const int64_t taps = (int64_t)B * KFAST * Ho * Wo * 4, win = (int64_t)B * 3 * (Ho + KFAST - 1) * (Wo + KFAST - 1) * 4;
+  return taps < ((int64_t)1 << 31) && win < ((int64_t)1 << 31);
+}
+
+template <bool WV, bool WH>
+int launch_bwd_persistent_one(const float* in, const float* v, const float* h, const float* gO, float* gV, float* gH, int B,
+                              int Ho, int Wo, hipStream_t st) {
+  constexpr size_t lds = persistent_lds_bytes();
+  static_assert(lds <= 160 * 1024, "LDS per CU");
+  static uint32_t done = 0;
+  if (int e = savfi_ensure_dynamic_lds((const void*)sepconv_bwd_mfma_p<KFAST, WV, WH>, lds, done)) return e;
+  const int nph = savfi_cdiv(Ho, 2), ncol = savfi_cdiv(Wo, MC);
+  const int64_t total = (int64_t)B * ncol * nph;
+  const int per_wg = savfi_cdiv(total, device_cu_count());
+  const int grid = savfi_cdiv(total, per_wg);
+  hipLaunchKernelGGL((sepconv_bwd_mfma_p<KFAST, WV, WH>), dim3(grid), dim3(MNT), lds, st, in, v, h, gO, gV, gH, B, Ho, Wo, nph, ncol,
+                     per_wg);
+  return savfi_launch_status();
+}
+
+int launch_bwd_persistent(const float* in, const float* v, const float* h, const float* gO, float* gV, float* gH, int B, int Ho,
+                          int Wo, hipStream_t st) {
+  if (gV && gH) return launch_bwd_persistent_one<true, true>(in, v, h, gO, gV, gH, B, Ho, Wo, st);
+  if (gV) return launch_bwd_persistent_one<true, false>(in, v, h, gO, gV, gH, B, Ho, Wo, st);
+  return launch_bwd_persistent_one<false, true>(in, v, h, gO, gV, gH, B, Ho, Wo, st);
+}
+
 int check_dims(int B, int C, int Ho, int Wo, int K) {
   if (B <= 0 || C <= 0 || Ho <= 0 || Wo <= 0 || K <= 0) return SAVFI_E_SHAPE;
   const int64_t Hi = (int64_t)Ho + K - 1, Wi = (int64_t)Wo + K - 1;
@@ -729,7 +1087,9 @@ extern "C" int savfi_sepconv_bwd_f32(const float* in, const float* v, const floa
   if (int e = check_dims(B, C, Ho, Wo, K)) return e;
   hipStream_t st = (hipStream_t)stream;
   if (gV || gH) {
-    if (K == KFAST && C == 3 && !sepconv_env().no_mfma) {
+    if (K == KFAST && C == 3 && !sepconv_env().no_mfma && !sepconv_env().tiled && persistent_ok(B, Ho, Wo)) {
+      if (int e = launch_bwd_persistent(in, v, h, gO, gV, gH, B, Ho, Wo, st)) return e;
+    } else if (K == KFAST && C == 3 && !sepconv_env().no_mfma) {
       int e;
       switch (mfma_rows(B, Ho, Wo)) {
         case 8: e = launch_bwd_mfma<8>(in, v, h, gO, gV, gH, B, Ho, Wo, st); break;
