@@ -1,5 +1,5 @@
 set -x
-mkdir -p gpurun_out/art
+rm -rf gpurun_out/art; mkdir -p gpurun_out/art
 R=$GRAFT_REPO_ROOT
 python bench.py --steps 5 --warmup 2 > gpurun_out/art/r02_bench_line.json 2> gpurun_out/art/r02_bench_line.err
 cd /tmp && export TMPDIR=/tmp
@@ -14,7 +14,8 @@ python tools/kernel_bench.py --batches 1,2,4,8 > gpurun_out/art/r02_kernel_bench
 python tools/tasks_bench.py > gpurun_out/art/r02_tasks_bench.jsonl 2>/dev/null
 python tools/parity_report.py > gpurun_out/art/r02_parity_report.jsonl 2>/dev/null
 for w in c3_voxelflow_metasgd_256x256_b8_s5 c5_cain_l2f_720p_b1_s1 c1_cain_64x64_b1_s1 rrin_256x448_b4_s5 superslomo_256x448_b4_s5; do python bench.py --workload $w --steps 3 --warmup 2 --no-cpu-baseline 2>/dev/null >> gpurun_out/art/r02_other_configs.jsonl; done
-python bench.py --workload c1_cain_64x64_b1_s1 --steps 5 --warmup 2 --no-cpu-baseline --graph-inner-loop 1 2>/dev/null >> gpurun_out/art/r02_other_configs.jsonl
+python bench.py --workload c1_cain_64x64_b1_s1 --steps 5 --warmup 2 --no-cpu-baseline --graph-inner-loop 0 2>/dev/null >> gpurun_out/art/r02_other_configs.jsonl
 python bench.py --workload c3_voxelflow_metasgd_256x256_b8_s5 --steps 3 --warmup 2 --no-cpu-baseline --graph-inner-loop 1 --task-streams 4 2>/dev/null >> gpurun_out/art/r02_other_configs.jsonl
-for cfg in "0 1 0" "0 1 4" "1 1 4" "1 2 2" "1 4 0" "1 2 0"; do set -- $cfg; python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timer --graph-inner-loop $1 --task-streams $2 --task-batch $3 2>/dev/null >> gpurun_out/art/r02_modes.jsonl; done
+cd /tmp; rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_c3 -- python $R/bench.py --workload c3_voxelflow_metasgd_256x256_b8_s5 --steps 3 --warmup 2 --no-cpu-baseline --graph-inner-loop 0 > /dev/null 2>&1; python $R/tools/gap_report.py /tmp/prof_c3 0 > $R/gpurun_out/art/r02_c3_voxelflow_one_iteration.txt 2>&1; cd $R
+for cfg in "0 1 0" "0 1 4" "1 1 4" "0 2 2" "1 2 2" "1 4 0" "1 2 0"; do set -- $cfg; python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timer --graph-inner-loop $1 --task-streams $2 --task-batch $3 2>/dev/null >> gpurun_out/art/r02_modes.jsonl; done
 ls -la gpurun_out/art

@@ -53,50 +53,47 @@ def run():
 
 
 def _collect(d, counter):
+    """Counter values per sepconv launch, keyed (kernel kind, case index): run() launches, case after case, three fwd/bwd pairs,
+    so the n-th sepconv_fwd (sepconv_bwd) dispatch belongs to case n // 3 -- the persistent backward kernel always launches one
+    workgroup per CU, its grid no longer identifies the shape."""
     path = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith('counter_collection.csv')][0]
-    out = {}
-    for row in csv.DictReader(open(path)):
-        if row['Counter_Name'] != counter:
-            continue
+    rows = [r for r in csv.DictReader(open(path)) if r['Counter_Name'] == counter]
+    rows.sort(key=lambda r: int(r['Dispatch_Id']))
+    out, seen = {}, {'sepconv_fwd': 0, 'sepconv_bwd': 0}
+    for row in rows:
         name = row['Kernel_Name']
-        grid = row['Grid_Size']
-        key = ('copy' if 'elementwise' in name or 'copy' in name.lower() else
-               'sepconv_fwd' if 'sepconv_fwd' in name else 'sepconv_bwd' if 'sepconv_bwd' in name else None)
-        if key is None:
+        if 'elementwise' in name or 'copy' in name.lower():
+            out.setdefault(('copy', -1), []).append(float(row['Counter_Value']))
             continue
-        if key != 'copy':      # template arguments <51, ROWS, ...>: two cases can share a grid size
-            key += '/' + name.split('<')[1].split('>')[0].split(',')[1].strip()
-        out.setdefault((key, grid), []).append(float(row['Counter_Value']))
-    return {k: sum(v) / len(v) for k, v in out.items()}
+        kind = 'sepconv_fwd' if 'sepconv_fwd' in name else 'sepconv_bwd' if 'sepconv_bwd' in name else None
+        if kind is None:
+            continue
+        out.setdefault((kind, seen[kind] // 3), []).append(float(row['Counter_Value']))
+        seen[kind] += 1
+    # the calibration copy is the largest of the elementwise / copy kernels (tensor initialisation launches some small ones)
+    return {k: (max(v) if k[0] == 'copy' else sum(v) / len(v)) for k, v in out.items()}
 
 
 def parse(dfetch, dwrite):
     from meta_interpolation_amd.sepconv.sepconv_op.sepconv import algorithmic_bytes
     f, w = _collect(dfetch, 'FETCH_SIZE'), _collect(dwrite, 'WRITE_SIZE')
-    cal_f = [v for (k, g), v in f.items() if k == 'copy']
-    cal_w = [v for (k, g), v in w.items() if k == 'copy']
+    cal_f, cal_w = f[('copy', -1)], w[('copy', -1)]
     # counters are in KiB; correction = true bytes / reported bytes on the known copy
-    corr_f = CAL_BYTES / (max(cal_f) * 1024.0)
-    corr_w = CAL_BYTES / (max(cal_w) * 1024.0)
-    res = {"unit": "bytes per launch", "calibration": {"copy_bytes_each_way": CAL_BYTES, "FETCH_SIZE_KiB": max(cal_f),
-                                                       "WRITE_SIZE_KiB": max(cal_w), "fetch_correction": corr_f,
+    corr_f = CAL_BYTES / (cal_f * 1024.0)
+    corr_w = CAL_BYTES / (cal_w * 1024.0)
+    res = {"unit": "bytes per launch", "calibration": {"copy_bytes_each_way": CAL_BYTES, "FETCH_SIZE_KiB": cal_f,
+                                                       "WRITE_SIZE_KiB": cal_w, "fetch_correction": corr_f,
                                                        "write_correction": corr_w}, "kernels": {}}
-    for (k, g), val in sorted(f.items()):
-        if k == 'copy':
+    for (kind, ci), val in sorted(f.items()):
+        if kind == 'copy' or ci >= len(CASES):
             continue
-        wv = w.get((k, g), 0.0)
-        kind, rows = k.split('/')
-        case = [c for c in CASES if mfma_rows(*c) == int(rows)
-                and c[0] * -(-c[2] // 64) * -(-c[1] // int(rows)) * 512 == int(g)]
-        if len(case) != 1:
-            continue
-        B, Ho, Wo = case[0]
+        wv = w.get((kind, ci), 0.0)
+        B, Ho, Wo = CASES[ci]
         alg = algorithmic_bytes(B, 3, Ho, Wo, 51, grads=2 if kind == 'sepconv_bwd' else 0)
         rd, wr = val * 1024 * corr_f, wv * 1024 * corr_w
         res["kernels"]["%s_B%d_%dx%d" % (kind, B, Ho, Wo)] = {
-            "grid": int(g), "rows_per_workgroup": int(rows), "FETCH_SIZE_KiB": val, "WRITE_SIZE_KiB": wv,
-            "hbm_read_bytes": rd, "hbm_write_bytes": wr, "traffic": rd + wr, "algorithmic_bytes": alg,
-            "traffic_over_algorithmic": (rd + wr) / alg}
+            "FETCH_SIZE_KiB": val, "WRITE_SIZE_KiB": wv, "hbm_read_bytes": rd, "hbm_write_bytes": wr, "traffic": rd + wr,
+            "algorithmic_bytes": alg, "traffic_over_algorithmic": (rd + wr) / alg}
     print(json.dumps(res, indent=1))
 
 
