@@ -27,10 +27,13 @@
 // The data gradient is the same kernel on the flipped / transposed filter (wino_filter_transform mode 1).
 #include "common.h"
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+// 16-byte raw buffer load (the clang builtin of this release narrows the b128 form to one dword)
+__device__ f32x4 savfi_raw_buffer_load_x4(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+
 namespace {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 
 constexpr int WNT = 256;            // threads
 // 64 tiles per workgroup, one per lane, as a 2^(6-s) x 2^s block of tiles (s = WinoArgs::tile_shift, picked per launch):
@@ -44,6 +47,10 @@ constexpr int XS = 68;              // pitch of an exchange row [channel] (outpu
 constexpr int VBUF = 16 * CIB * VS; // floats per V buffer (20 KB)
 constexpr int XBUF = 4 * 2 * 16 * XS;  // exchange: [row xi_r][column c][16 channels][XS]
 constexpr int LDS_FLOATS = (2 * VBUF > XBUF) ? 2 * VBUF : XBUF;
+#ifndef WINO_EXP
+#define WINO_EXP 0
+#endif
+constexpr int EXP = WINO_EXP;   // timing experiments only (wrong results): 1 no barrier, 2 no patch loads, 4 no A loads, 8 no transform, 16 no MFMA
 
 // ---- filter transform ------------------------------------------------------------------------------------
 // U = G g G^T for reduction channel k < KP and produced channel i < IP (zero padded), stored in MFMA A-fragment
@@ -110,71 +117,104 @@ struct WinoArgs {
   int T;                                                   // filter sets: sample n uses set n % T (U [T][...], bias [T][I])
 };
 
-// The 4x4 patch of a thread sits at the same (y, x) for every channel: its row offsets and the zero-padding mask are
-// computed once.  A row is ONE unaligned 16-byte load at the patch's own column even when that crosses the left /
-// right image border: the out-of-image elements then come from the neighbouring row of the same plane and are zeroed
-// by the mask.  Only at the very first / last elements of a plane would the load leave the plane: there the window is
-// clamped into [0, H*W-4] and the loaded values are permuted in registers (shift != 0: the corner tiles only).
-// Loads are unconditional and masked with integer ANDs afterwards: with `cond ? load : 0` the compiler sinks every
-// load under its own branch + s_waitcnt, i.e. dependent HBM round trips.
+// The 4x4 patch of a thread sits at the same (y, x) for every channel: its four row offsets are computed once.  A row is
+// ONE dword-aligned 16-byte RAW BUFFER load at the patch's own column, through a descriptor that spans exactly the
+// channel plane (base and size in SGPRs, rebuilt per chunk with two scalar adds), and the hardware's per-dword range
+// check does most of the zero padding:
+//   * a row above / below the image gets an offset beyond the plane: the load returns zeros;
+//   * a row that runs past the END of the plane (bottom-right tiles) returns zeros for the dwords beyond it;
+//   * a row that crosses the left / right image border picks up the neighbouring row's pixels: those COLUMNS are zeroed
+//     with one v_cndmask per element, the lane masks of the four columns sitting in SGPR pairs (one ballot each per
+//     workgroup) and only for the columns that are partial somewhere in the wave: 4 VALU per chunk in a wave on the left
+//     edge, none in an interior wave;
+//   * a row that would start BEFORE the plane (image row 0 of the tile at x = 0: offset -4 or -8) is the one case the range
+//     check gets wrong -- a negative offset zeroes the whole load (measured on gfx950) -- so that row is loaded from
+//     offset 0 and moved up by `off` elements in lane 0 of the workgroup that owns tile (0, 0): 2-3 v_cndmask.
+// The first version used global loads with clamped addresses, rebuilt each lane's predicate from a bit mask in a VGPR
+// (~60 VALU per chunk in every border wave) and fixed the corner rows with per-lane divergent code: the two workgroups per
+// image that hold a corner ran several times longer than the rest, and because the bottom-right one is the LAST block
+// of a launch it was the tail of every launch -- 25 % of the kernel's time on 96 x 128 maps (190 -> 148 us, 128 -> 128).
+// Reduction channels beyond K need no masking: their filter transform is zero and the patch is a finite duplicate of
+// channel K - 1 at the same tile.
+
 struct Patch {
-  unsigned off[4];    // row r: byte offset of the loaded window from the (wave-uniform) plane base
-  int shift[4];       // loaded element index - wanted element index (0 except at the plane's first / last elements)
-  int mask;           // bit 4r+c set = inside the image
+  unsigned voff[4];   // row r: byte offset of the 16-byte window from the plane base (>= 2^31: a row outside the image)
+};
+
+struct LaneMasks {
+  unsigned long long col[4];  // bit l of col[c]: column c of lane l's patch is inside the image
+  int partial_cols;           // bit c: some lane of the wave has column c outside
 };
 
 __device__ __forceinline__ Patch make_patch(int y0, int x0, int H, int W) {
   Patch p;
-  p.mask = 0;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int y = y0 + r;
-    const int want = min(max(y, 0), H - 1) * W + x0;
-    const int got = min(max(want, 0), H * W - 4);
-    p.off[r] = (unsigned)got * 4u;
-    p.shift[r] = got - want;
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-      if (y >= 0 && y < H && x0 + c >= 0 && x0 + c < W) p.mask |= 1 << (4 * r + c);
+    const int lin = y * W + x0;                    // < 0 only for y == 0, x0 < 0: loaded from 0, see fix_corner
+    p.voff[r] = (y >= 0 && y < H) ? (unsigned)max(lin, 0) * 4u : 0x80000000u;
   }
   return p;
 }
 
-__device__ __forceinline__ void load_patch(float (&d)[16], const float* __restrict__ plane, const Patch& p) {
-  const char* base = reinterpret_cast<const char*>(plane);
+__device__ __forceinline__ LaneMasks make_lane_masks(int x0, int W) {
+  LaneMasks lm;
+  lm.partial_cols = 0;
+  const unsigned long long all = __builtin_amdgcn_ballot_w64(true);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    lm.col[c] = __builtin_amdgcn_ballot_w64(x0 + c >= 0 && x0 + c < W);
+    if (lm.col[c] != all) lm.partial_cols |= 1 << c;
+  }
+  return lm;
+}
+
+__device__ __forceinline__ i32x4 plane_rsrc(const float* plane, unsigned bytes) {
+  const unsigned long long p = reinterpret_cast<unsigned long long>(plane);
+  i32x4 r;
+  r.x = (int)(unsigned)p;
+  r.y = (int)(unsigned)(p >> 32);       // stride 0: raw buffer
+  r.z = (int)bytes;
+  r.w = 0x00020000;
+  return r;
+}
+
+__device__ __forceinline__ void load_patch(float (&d)[16], const float* __restrict__ plane, unsigned plane_bytes, const Patch& p) {
+  const i32x4 rs = plane_rsrc(plane, plane_bytes);
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const f4u v = *reinterpret_cast<const f4u*>(base + p.off[r]);
+    const f32x4 v = savfi_raw_buffer_load_x4(rs, (int)p.voff[r], 0, 0);
     d[4 * r + 0] = v.x; d[4 * r + 1] = v.y; d[4 * r + 2] = v.z; d[4 * r + 3] = v.w;
   }
 }
 
-// corner tiles only: d[c] = loaded[c - shift]; every in-image element of the row lies inside the loaded window
-__device__ __forceinline__ void shift_patch(float (&d)[16], const Patch& p) {
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int shift = p.shift[r];
-    if (shift != 0) {
-      const float l0 = d[4 * r], l1 = d[4 * r + 1], l2 = d[4 * r + 2], l3 = d[4 * r + 3];
-      switch (shift) {
-        case 1: d[4 * r + 1] = l0; d[4 * r + 2] = l1; d[4 * r + 3] = l2; break;
-        case 2: d[4 * r + 2] = l0; d[4 * r + 3] = l1; break;
-        case 3: d[4 * r + 3] = l0; break;
-        case -1: d[4 * r + 0] = l1; d[4 * r + 1] = l2; d[4 * r + 2] = l3; break;
-        case -2: d[4 * r + 0] = l2; d[4 * r + 1] = l3; break;
-        case -3: d[4 * r + 0] = l3; break;
-        default: break;
-      }
-    }
+// Workgroup of tile (0, 0): the patch row that is image row 0 was loaded from column 0 instead of column -off in the
+// tiles of tile column 0 that contain it -- tile (0, 0) = lane 0, patch row `off`, and for off = 2 also tile (1, 0) = lane
+// `tbw` (the block's width in tiles), patch row 0: d[c] = loaded[c - off] for c >= off (the columns below `off` are
+// cleared by the column masks).
+__device__ __forceinline__ void fix_corner(float (&d)[16], int off, int tbw) {
+  const unsigned long long lane0 = 1ull;
+  if (off == 1) {
+    asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(d[7]) : "v"(d[6]), "s"(lane0));
+    asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(d[6]) : "v"(d[5]), "s"(lane0));
+    asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(d[5]) : "v"(d[4]), "s"(lane0));
+  } else {
+    const unsigned long long lane1 = 1ull << tbw;
+    asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(d[11]) : "v"(d[9]), "s"(lane0));
+    asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(d[10]) : "v"(d[8]), "s"(lane0));
+    asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(d[3]) : "v"(d[1]), "s"(lane1));
+    asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(d[2]) : "v"(d[0]), "s"(lane1));
   }
 }
 
-// border waves only: everything outside the image (or beyond K) is zeroed
-__device__ __forceinline__ void mask_patch(float (&d)[16], const Patch& p, bool channel_ok) {
-  const int mask = channel_ok ? p.mask : 0;
+__device__ __forceinline__ void mask_patch(float (&d)[16], const LaneMasks& lm) {
 #pragma unroll
-  for (int e = 0; e < 16; ++e)
-    d[e] = __uint_as_float(__float_as_uint(d[e]) & (unsigned)__builtin_amdgcn_sbfe(mask, e, 1));
+  for (int c = 0; c < 4; ++c)
+    if (lm.partial_cols & (1 << c)) {       // wave-uniform
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        asm volatile("v_cndmask_b32 %0, 0, %0, %1" : "+v"(d[4 * r + c]) : "s"(lm.col[c]));
+    }
 }
 
 __device__ __forceinline__ void input_transform(float (&v)[16], const float (&d)[16]) {
@@ -202,18 +242,18 @@ __device__ __forceinline__ void input_transform(float (&v)[16], const float (&d)
 //   groups 4-7   (B^T d) B, one row each, written straight into the other V buffer
 //   group  7     last use of this chunk's A fragments: those of chunk c+2 are loaded in place
 __device__ __forceinline__ void chunk_body(f32x4 (&acc)[4][2][4], f32x4 (&afr)[2], const float* __restrict__ vcur,
-                                           float (&d)[16], const Patch& patch, int fixup, bool channel_ok,
+                                           float (&d)[16], const Patch& patch, int fixup, int tbw, const LaneMasks& lm,
                                            float* __restrict__ vnext,
-                                           const float* __restrict__ plane3, const char* __restrict__ unext, unsigned ulane) {
+                                           const float* __restrict__ plane3, unsigned plane_bytes, const char* __restrict__ unext, unsigned ulane) {
   float bfr[2][4], t[16];
 #pragma unroll
   for (int tt = 0; tt < 4; ++tt) bfr[0][tt] = vcur[16 * tt];
-  if (fixup & 2) shift_patch(d, patch);              // wave-uniform branches
-  if (fixup & 1) mask_patch(d, patch, channel_ok);
+  if (fixup & 6) fix_corner(d, fixup >> 1, tbw);     // wave-uniform branches
+  if (fixup & 1) mask_patch(d, lm);
 #pragma unroll
   for (int g = 0; g < 8; ++g) {
     const int c = g >> 1, cb = g & 1, cur = c & 1;       // xi column, channel block
-    if (cb == 0 && c < 3) {   // B fragments of the next xi
+    if (cb == 0 && c < 3 && !(EXP & 256)) {   // B fragments of the next xi
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt)
         bfr[cur ^ 1][tt] = vcur[(c + 1) * CIB * VS + 16 * tt];
@@ -221,13 +261,30 @@ __device__ __forceinline__ void chunk_body(f32x4 (&acc)[4][2][4], f32x4 (&afr)[2
     const float a = afr[c >> 1][2 * (c & 1) + cb];
 #pragma unroll
     for (int tt = 0; tt < 4; ++tt)
-      acc[c][cb][tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bfr[cur][tt], acc[c][cb][tt], 0, 0, 0);
-    if (g < 4) {               // B^T d : column g
-      t[0 * 4 + g] = d[0 * 4 + g] - d[2 * 4 + g];
-      t[1 * 4 + g] = d[1 * 4 + g] + d[2 * 4 + g];
-      t[2 * 4 + g] = d[2 * 4 + g] - d[1 * 4 + g];
-      t[3 * 4 + g] = d[1 * 4 + g] - d[3 * 4 + g];
-      if (g == 3) load_patch(d, plane3, patch);
+      if (!(EXP & 16)) acc[c][cb][tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bfr[cur][tt], acc[c][cb][tt], 0, 0, 0);
+      else acc[c][cb][tt][0] += a * bfr[cur][tt];
+    if (EXP & 8) {
+    } else if (g < 4) {               // B^T d : column g
+      if (!(EXP & 128)) {
+        t[0 * 4 + g] = d[0 * 4 + g] - d[2 * 4 + g];
+        t[1 * 4 + g] = d[1 * 4 + g] + d[2 * 4 + g];
+        t[2 * 4 + g] = d[2 * 4 + g] - d[1 * 4 + g];
+        t[3 * 4 + g] = d[1 * 4 + g] - d[3 * 4 + g];
+      } else {
+        t[0 * 4 + g] = d[0 * 4 + g]; t[1 * 4 + g] = d[1 * 4 + g]; t[2 * 4 + g] = d[2 * 4 + g]; t[3 * 4 + g] = d[3 * 4 + g];
+      }
+      if (g == 3 && !(EXP & 2)) load_patch(d, plane3, plane_bytes, patch);
+    } else if (EXP & 64) {     // transform computed, ONE LDS write per chunk instead of 16
+      const int r = g - 4;
+      const float s0 = (t[r * 4 + 0] - t[r * 4 + 2]) + (t[r * 4 + 1] + t[r * 4 + 2]) * 3.f + (t[r * 4 + 2] - t[r * 4 + 1]) * 5.f + (t[r * 4 + 1] - t[r * 4 + 3]) * 7.f;
+      t[r] = s0;
+      if (r == 3) vnext[0] = t[0] + t[1] * 2.f + t[2] * 3.f + t[3] * 4.f;
+    } else if (EXP & 128) {
+      const int r = g - 4;
+      vnext[(r * 4 + 0) * CIB * VS] = t[r * 4 + 0];
+      vnext[(r * 4 + 1) * CIB * VS] = t[r * 4 + 1];
+      vnext[(r * 4 + 2) * CIB * VS] = t[r * 4 + 2];
+      vnext[(r * 4 + 3) * CIB * VS] = t[r * 4 + 3];
     } else {                   // (B^T d) B : row g - 4, written straight to the next V buffer
       const int r = g - 4;
       vnext[(r * 4 + 0) * CIB * VS] = t[r * 4 + 0] - t[r * 4 + 2];
@@ -235,7 +292,7 @@ __device__ __forceinline__ void chunk_body(f32x4 (&acc)[4][2][4], f32x4 (&afr)[2
       vnext[(r * 4 + 2) * CIB * VS] = t[r * 4 + 2] - t[r * 4 + 1];
       vnext[(r * 4 + 3) * CIB * VS] = t[r * 4 + 1] - t[r * 4 + 3];
     }
-    if (g == 7) {
+    if (g == 7 && !(EXP & 4)) {
       afr[0] = *reinterpret_cast<const f32x4*>(unext + ulane);
       afr[1] = *reinterpret_cast<const f32x4*>(unext + ulane + 16);
     }
@@ -260,7 +317,9 @@ __global__ __launch_bounds__(WNT, 2) void wino_conv3x3(WinoArgs a) {
 
   // this thread's tile for the input transform: lane -> tile (4 x 16), wave -> channel within the chunk
   const int tsh = a.tile_shift, tbw = 1 << tsh, tbh = TILES_WG >> tsh;
-  const Patch patch = make_patch(2 * (tby * tbh + (lane >> tsh)) - a.off, 2 * (tbx * tbw + (lane & (tbw - 1))) - a.off, a.H, a.W);
+  const int px0 = 2 * (tbx * tbw + (lane & (tbw - 1))) - a.off;
+  const Patch patch = make_patch(2 * (tby * tbh + (lane >> tsh)) - a.off, px0, a.H, a.W);
+  const unsigned plane_bytes = (unsigned)cplane * 4u;
 
   f32x4 acc[4][2][4];
 #pragma unroll
@@ -279,29 +338,30 @@ __global__ __launch_bounds__(WNT, 2) void wino_conv3x3(WinoArgs a) {
   auto plane_of = [&](int chunk) { return xp + (size_t)min(min(chunk, nchunk - 1) * CIB + w, a.K - 1) * cplane; };
   auto u_of = [&](int chunk) { return ubase + (size_t)min(chunk, nchunk - 1) * ustride; };
 
-  // waves whose 64 patches are all interior (and whose channels are all real) skip the padding fix-ups
-  const int fixup = ((__builtin_amdgcn_ballot_w64(patch.mask != 0xffff) != 0 || a.K % (2 * CIB) != 0) ? 1 : 0) |
-                    (__builtin_amdgcn_ballot_w64((patch.shift[0] | patch.shift[1] | patch.shift[2] | patch.shift[3]) != 0) != 0 ? 2 : 0);
+  // fix-ups (wave-uniform): bit 0 = some column of some lane is outside the image; bits 1-2 = `off` in the workgroup that
+  // owns tile (0, 0) of a padded map (its lane 0 holds the row that would start before the plane)
+  const LaneMasks lm = make_lane_masks(px0, a.W);
+  const int fixup = (EXP & 512) ? 0 : (lm.partial_cols != 0 ? 1 : 0) | ((tb == 0 && a.off > 0) ? 2 * a.off : 0);
 
   // prologue: P(0) -> V(0); P(1), P(2), A(0), A(1) in flight / resident
   float dA[16], dB[16];        // dA: patches of even chunks, dB: odd chunks
   f32x4 afrA[2], afrB[2];
-  load_patch(dA, plane_of(cbeg), patch);
-  load_patch(dB, plane_of(cbeg + 1), patch);
+  load_patch(dA, plane_of(cbeg), plane_bytes, patch);
+  load_patch(dB, plane_of(cbeg + 1), plane_bytes, patch);
   afrA[0] = *reinterpret_cast<const f32x4*>(u_of(cbeg) + ulane);
   afrA[1] = *reinterpret_cast<const f32x4*>(u_of(cbeg) + ulane + 16);
   afrB[0] = *reinterpret_cast<const f32x4*>(u_of(cbeg + 1) + ulane);
   afrB[1] = *reinterpret_cast<const f32x4*>(u_of(cbeg + 1) + ulane + 16);
   {
     float v[16];
-    if (fixup & 2) shift_patch(dA, patch);
-    if (fixup & 1) mask_patch(dA, patch, cbeg * CIB + w < a.K);
+    if (fixup & 6) fix_corner(dA, fixup >> 1, tbw);
+    if (fixup & 1) mask_patch(dA, lm);
     input_transform(v, dA);
     float* vb = lds + w * VS + lane;
 #pragma unroll
     for (int xi = 0; xi < 16; ++xi) vb[xi * CIB * VS] = v[xi];
   }
-  load_patch(dA, plane_of(cbeg + 2), patch);
+  load_patch(dA, plane_of(cbeg + 2), plane_bytes, patch);
   // Everything the prologue loaded must have landed before the loop: otherwise the compiler's wait-count bookkeeping
   // carries "may still be in flight" into the loop header and, vmcnt being in-order, makes every iteration wait for
   // its own freshly issued prefetches before the first MFMA.
@@ -312,14 +372,14 @@ __global__ __launch_bounds__(WNT, 2) void wino_conv3x3(WinoArgs a) {
   const int vroff = (4 * w) * CIB * VS + kg * VS + j; // V read:  [xi = 4w + c][k = kg][tile = 16 t + j]
   for (int ch = cbeg; ch < nchunk; ch += 2) {
     // even chunk: MFMAs on V(0) with A(ch); transforms P(ch+1) = dB -> V(1); reloads dB <- P(ch+3), afrA <- A(ch+2)
-    chunk_body(acc, afrA, lds + vroff, dB, patch, fixup, min(ch + 1, nchunk - 1) * CIB + w < a.K, lds + VBUF + vwoff,
-               plane_of(ch + 3), u_of(ch + 2), ulane);
-    __syncthreads();
+    chunk_body(acc, afrA, lds + vroff, dB, patch, fixup, tbw, lm, lds + VBUF + vwoff,
+               plane_of(ch + 3), plane_bytes, u_of(ch + 2), ulane);
+    if (!(EXP & 1)) __syncthreads();
     // nchunk is even (KP is a multiple of 2 * CIB): an `if (ch + 1 < nchunk)` here would make the compiler assume the
     // A fragments loaded at the end of the even chunk may be the youngest load in flight -> vmcnt(0) every iteration
-    chunk_body(acc, afrB, lds + VBUF + vroff, dA, patch, fixup, min(ch + 2, nchunk - 1) * CIB + w < a.K, lds + vwoff,
-               plane_of(ch + 4), u_of(ch + 3), ulane);
-    __syncthreads();
+    chunk_body(acc, afrB, lds + VBUF + vroff, dA, patch, fixup, tbw, lm, lds + vwoff,
+               plane_of(ch + 4), plane_bytes, u_of(ch + 3), ulane);
+    if (!(EXP & 1)) __syncthreads();
   }
 
   // ---- output stage ------------------------------------------------------------------------------------------
@@ -471,7 +531,7 @@ extern "C" int savfi_conv3x3_tasks_f32(const float* x, const float* w, const flo
   hipLaunchKernelGGL(wino_filter_transform, dim3(p.KP / 4, savfi_cdiv(p.IP, 64) * T), dim3(256), 0, st, w, workspace, Co, Ci, p.K,
                      p.I, p.KP, p.IP, mode);
   if (int e = savfi_launch_status()) return e;
-  constexpr size_t lds = (size_t)LDS_FLOATS * sizeof(float);      // 40 KB: two workgroups per CU
+  constexpr size_t lds = (EXP & 32) ? 65536 : (size_t)LDS_FLOATS * sizeof(float);      // 40 KB: two workgroups per CU
   const float* b = mode == 0 ? bias : nullptr;
   float* partial = workspace + (int64_t)T * p.u_floats;
   WinoArgs a{x, workspace, b, out, p.K, p.I, p.KP, p.IP, H, W, p.Ho, p.Wo, p.off, p.th, p.tw, slope, p.tile_shift, p.nsplit,
