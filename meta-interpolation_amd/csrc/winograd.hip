@@ -115,6 +115,7 @@ struct WinoArgs {
   int nsplit, chunks_per_split;                            // reduction channels split over workgroups (deep layers)
   float* partial;                                          // nsplit > 1: raw partial outputs [split][N][I][Ho][Wo]
   int T;                                                   // filter sets: sample n uses set n % T (U [T][...], bias [T][I])
+  int N;                                                   // samples
 };
 
 // The 4x4 patch of a thread sits at the same (y, x) for every channel: its four row offsets are computed once.  A row is
@@ -305,12 +306,30 @@ __global__ __launch_bounds__(WNT, 2) void wino_conv3x3(WinoArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, kg = lane >> 4;
 
-  const int tb = blockIdx.x;                       // tile block within the image
-  const int tby = tb / a.tiles_x, tbx = tb - tby * a.tiles_x;
+  // Work item of this workgroup: logical order [sample][channel block x split][tile block], tile block fastest.
+  // Blocks are dispatched round-robin over the 8 XCDs (block b runs on XCD b % 8, each with its own 4 MB L2).  For the
+  // layers with at most two channel blocks -- the large maps, where the input is most of the traffic -- the block index is
+  // remapped (bijectively, any grid size) so that one XCD walks a CONTIGUOUS eighth of that order: neighbouring tile blocks
+  // (shared halo rows, shared 128-byte lines) then meet in the same L2.  PMC fetch traffic: 3.0 x the input -> 1.0 x for
+  // 32 -> 32 @ 384 x 512, 7.3 x -> 1.08 x for 51 -> 51 @ 258 x 450.  The time moves by 0-5 % only (the re-reads were served by
+  // the Infinity Cache); with more channel blocks the remap measured SLOWER (256 -> 256 @ 48 x 64: 153 -> 175 us), so those keep
+  // the dispatch order.
   const int nblk = a.IP / COB;
-  const int cob = blockIdx.y % nblk, sp = blockIdx.y / nblk;       // channel block, reduction split
+  int tb, cob, sp, n;
+  {
+    const unsigned flat = blockIdx.x, nwg = gridDim.x;
+    const unsigned ncs = (unsigned)(nblk * a.nsplit), ntb = (unsigned)(a.tiles_y * a.tiles_x);
+    const unsigned xcd = flat & 7u, q = nwg >> 3, rem = nwg & 7u;
+    unsigned item = ncs <= 2u ? xcd * q + min(xcd, rem) + (flat >> 3) : flat;
+    tb = (int)(item % ntb);
+    item /= ntb;
+    const unsigned cs = item % ncs;
+    n = (int)(item / ncs);
+    cob = (int)(cs % (unsigned)nblk);
+    sp = (int)(cs / (unsigned)nblk);
+  }
+  const int tby = tb / a.tiles_x, tbx = tb - tby * a.tiles_x;
   const int i0 = cob * COB;                        // first produced channel
-  const int n = blockIdx.z;
   const int task = a.T > 1 ? n % a.T : 0;
   const float* xp = a.x + (size_t)n * a.K * a.H * a.W;
   const size_t cplane = (size_t)a.H * a.W;
@@ -329,9 +348,9 @@ __global__ __launch_bounds__(WNT, 2) void wino_conv3x3(WinoArgs a) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) acc[c][cb][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // A fragments of this wave for chunk c: 2 x f32x4 at ((c * nblk + blockIdx.y) * 4 + w) * 64 lanes * 32 bytes
+  // A fragments of this wave for chunk c: 2 x f32x4 at ((c * nblk + cob) * 4 + w) * 64 lanes * 32 bytes
   // this workgroup reduces over chunks [cbeg, nchunk) of the KP / CIB chunks (an even count)
-  const int cbeg = sp * a.chunks_per_split, nchunk = min(cbeg + a.chunks_per_split, a.KP / CIB);
+  const int cbeg = sp * a.chunks_per_split, nchunk = (EXP & 8192) ? cbeg + 2 : min(cbeg + a.chunks_per_split, a.KP / CIB);
   const size_t ustride = (size_t)nblk * 4 * 64 * 32;                                     // bytes per chunk
   const char* ubase = reinterpret_cast<const char*>(a.U + (size_t)task * 16 * a.KP * a.IP) + ((size_t)cob * 4 + w) * 64 * 32;
   const unsigned ulane = (unsigned)lane * 32u;
@@ -385,6 +404,17 @@ __global__ __launch_bounds__(WNT, 2) void wino_conv3x3(WinoArgs a) {
   // ---- output stage ------------------------------------------------------------------------------------------
   // column half of A^T M A in registers (this wave holds the whole row r = w):  s0 = m0 + m1 + m2,  s1 = m1 - m2 - m3
   // accumulator tile layout: row (channel) = 4 * kg + reg, column (tile) = j
+  if (EXP & 4096) {      // timing: no output stage (one store per lane keeps the accumulators alive)
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) sum += acc[c][cb][t][0] + acc[c][cb][t][1] + acc[c][cb][t][2] + acc[c][cb][t][3];
+    a.out[(((size_t)n * a.I + i0 + w) * a.Ho + 2 * (tby * tbh)) * a.Wo + 2 * tbx * tbw + lane] = sum;
+    return;
+  }
   const bool vec_ok = (a.Wo % 2 == 0);
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb) {
@@ -399,7 +429,7 @@ __global__ __launch_bounds__(WNT, 2) void wino_conv3x3(WinoArgs a) {
       }
     __syncthreads();
 #pragma unroll
-    for (int rep = 0; rep < 4; ++rep) {
+    for (int rep = 0; rep < ((EXP & 131072) ? 1 : 4); ++rep) {
       const int il = w + 4 * rep, t = lane;         // channel within the block of 16 (wave-uniform), tile
       const int i = i0 + 16 * cb + il;
       float s[4][2];
@@ -413,11 +443,11 @@ __global__ __launch_bounds__(WNT, 2) void wino_conv3x3(WinoArgs a) {
         y[0][c] = s[0][c] + s[1][c] + s[2][c];
         y[1][c] = s[1][c] - s[2][c] - s[3][c];
       }
-      if (i < a.I) {
+      if ((EXP & 65536) ? (i < a.I && a.off > 100) : (i < a.I)) {
         const float b = (a.bias && a.nsplit == 1) ? a.bias[task * a.I + i] : 0.f;
         const int oty = tby * tbh + (t >> tsh), otx = tbx * tbw + (t & (tbw - 1));
         const int oy = 2 * oty, ox = 2 * otx;
-        float* obase = a.nsplit == 1 ? a.out : a.partial + (size_t)sp * gridDim.z * a.I * a.Ho * a.Wo;
+        float* obase = a.nsplit == 1 ? a.out : a.partial + (size_t)sp * a.N * a.I * a.Ho * a.Wo;
         const float slope = a.nsplit == 1 ? a.slope : 1.f;       // bias / activation happen in wino_split_reduce
         float* op = obase + (((size_t)n * a.I + i) * a.Ho + oy) * a.Wo + ox;
 #pragma unroll
@@ -427,7 +457,10 @@ __global__ __launch_bounds__(WNT, 2) void wino_conv3x3(WinoArgs a) {
           v0 = v0 > 0.f ? v0 : slope * v0;
           v1 = v1 > 0.f ? v1 : slope * v1;
           float* o = op + (size_t)r * a.Wo;
-          if (vec_ok && ox + 1 < a.Wo) *reinterpret_cast<float2*>(o) = make_float2(v0, v1);
+          if (vec_ok && ox + 1 < a.Wo) {
+            if (EXP & 262144) { typedef float f32x2 __attribute__((ext_vector_type(2))); __builtin_nontemporal_store((f32x2){v0, v1}, reinterpret_cast<f32x2*>(o)); }
+            else *reinterpret_cast<float2*>(o) = make_float2(v0, v1);
+          }
           else {
             if (ox < a.Wo) o[0] = v0;
             if (ox + 1 < a.Wo) o[1] = v1;
@@ -477,7 +510,9 @@ bool make_plan(WinoPlan& p, int N, int Ci, int Co, int H, int W, int pad, int mo
   // tile block shape: the one that covers the tile map with the fewest blocks (ties: the widest rows, 4 x 16 first)
   const int ty = savfi_cdiv(p.Ho, 2), tx = savfi_cdiv(p.Wo, 2);
   int64_t best = -1;
+  static const int force_shift = getenv("SAVFI_WINO_SHIFT") ? atoi(getenv("SAVFI_WINO_SHIFT")) : 0;
   for (int s : {4, 3, 5, 2}) {
+    if (force_shift && s != force_shift) continue;
     const int64_t blocks = (int64_t)savfi_cdiv(ty, TILES_WG >> s) * savfi_cdiv(tx, 1 << s);
     if (best < 0 || blocks < best) { best = blocks; p.tile_shift = s; }
   }
@@ -526,7 +561,8 @@ extern "C" int savfi_conv3x3_tasks_f32(const float* x, const float* w, const flo
   WinoPlan p;
   if (!make_plan(p, N, Ci, Co, H, W, pad, mode)) return SAVFI_E_SHAPE;
   if ((int64_t)H * W >= ((int64_t)1 << 29)) return SAVFI_E_TOOBIG;     // 32-bit byte offsets inside a channel plane
-  if ((int64_t)p.th * p.tw > 0x7fffffffLL || (int64_t)(p.IP / COB) * p.nsplit > 65535 || N > 65535 || T > 65535) return SAVFI_E_TOOBIG;
+  const int64_t wgs = (int64_t)p.th * p.tw * (p.IP / COB) * p.nsplit * N;
+  if (wgs > 0x7fffffffLL || T > 65535) return SAVFI_E_TOOBIG;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(wino_filter_transform, dim3(p.KP / 4, savfi_cdiv(p.IP, 64) * T), dim3(256), 0, st, w, workspace, Co, Ci, p.K,
                      p.I, p.KP, p.IP, mode);
@@ -535,8 +571,8 @@ extern "C" int savfi_conv3x3_tasks_f32(const float* x, const float* w, const flo
   const float* b = mode == 0 ? bias : nullptr;
   float* partial = workspace + (int64_t)T * p.u_floats;
   WinoArgs a{x, workspace, b, out, p.K, p.I, p.KP, p.IP, H, W, p.Ho, p.Wo, p.off, p.th, p.tw, slope, p.tile_shift, p.nsplit,
-             p.chunks_per_split, partial, T};
-  hipLaunchKernelGGL(wino_conv3x3, dim3(p.th * p.tw, (p.IP / COB) * p.nsplit, N), dim3(WNT), lds, st, a);
+             p.chunks_per_split, partial, T, N};
+  hipLaunchKernelGGL(wino_conv3x3, dim3((unsigned)wgs), dim3(WNT), lds, st, a);
   if (int e = savfi_launch_status()) return e;
   if (p.nsplit > 1) {
     const size_t total = (size_t)N * p.I * p.Ho * p.Wo;
