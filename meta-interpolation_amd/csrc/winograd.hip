@@ -31,6 +31,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 // 16-byte raw buffer load (the clang builtin of this release narrows the b128 form to one dword)
 __device__ f32x4 savfi_raw_buffer_load_x4(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ void savfi_raw_buffer_store_x2(f32x2 data, i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v2f32");
+__device__ void savfi_raw_buffer_store_x1(float data, i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.f32");
 
 namespace {
 
@@ -116,6 +119,9 @@ struct WinoArgs {
   float* partial;                                          // nsplit > 1: raw partial outputs [split][N][I][Ho][Wo]
   int T;                                                   // filter sets: sample n uses set n % T (U [T][...], bias [T][I])
   int N;                                                   // samples
+#ifdef WINO_TRACE
+  unsigned long long* trace;                               // [workgroup][8]: timestamps (100 MHz) + hardware ids
+#endif
 };
 
 // The 4x4 patch of a thread sits at the same (y, x) for every channel: its four row offsets are computed once.  A row is
@@ -301,7 +307,12 @@ __device__ __forceinline__ void chunk_body(f32x4 (&acc)[4][2][4], f32x4 (&afr)[2
   }
 }
 
+// VEC: the output width is even (pairs never straddle a row end and are 8-byte aligned)
+template <bool VEC>
 __global__ __launch_bounds__(WNT, 2) void wino_conv3x3(WinoArgs a) {
+#ifdef WINO_TRACE
+  const unsigned long long tr0 = __builtin_amdgcn_s_memrealtime();
+#endif
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 15, kg = lane >> 4;
@@ -362,6 +373,19 @@ __global__ __launch_bounds__(WNT, 2) void wino_conv3x3(WinoArgs a) {
   const LaneMasks lm = make_lane_masks(px0, a.W);
   const int fixup = (EXP & 512) ? 0 : (lm.partial_cols != 0 ? 1 : 0) | ((tb == 0 && a.off > 0) ? 2 * a.off : 0);
 
+  // The 8 bias values of this wave are fetched HERE, with the first patches: vmcnt counts loads and stores in one in-order
+  // counter, so a bias load issued between the output stage's stores (as the first version did, once per channel) can only be
+  // waited for together with every older store's write acknowledge -- 8 round trips of ~0.8 us per workgroup, which made the
+  // output stage as long as the channel loop of a 32-channel layer (7.3 of 18.7 us per workgroup, per-workgroup timestamps).
+  float bvals[2][4];
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+    for (int rep = 0; rep < 4; ++rep) {
+      const int i = i0 + 16 * cb + w + 4 * rep;
+      bvals[cb][rep] = (a.bias && a.nsplit == 1 && i < a.I) ? a.bias[task * a.I + i] : 0.f;
+    }
+
   // prologue: P(0) -> V(0); P(1), P(2), A(0), A(1) in flight / resident
   float dA[16], dB[16];        // dA: patches of even chunks, dB: odd chunks
   f32x4 afrA[2], afrB[2];
@@ -386,6 +410,9 @@ __global__ __launch_bounds__(WNT, 2) void wino_conv3x3(WinoArgs a) {
   // its own freshly issued prefetches before the first MFMA.
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
+#ifdef WINO_TRACE
+  const unsigned long long tr1 = __builtin_amdgcn_s_memrealtime();
+#endif
 
   const int vwoff = w * VS + lane;                    // V write: [xi][k = w][tile = lane]
   const int vroff = (4 * w) * CIB * VS + kg * VS + j; // V read:  [xi = 4w + c][k = kg][tile = 16 t + j]
@@ -401,6 +428,9 @@ __global__ __launch_bounds__(WNT, 2) void wino_conv3x3(WinoArgs a) {
     if (!(EXP & 1)) __syncthreads();
   }
 
+#ifdef WINO_TRACE
+  const unsigned long long tr2 = __builtin_amdgcn_s_memrealtime();
+#endif
   // ---- output stage ------------------------------------------------------------------------------------------
   // column half of A^T M A in registers (this wave holds the whole row r = w):  s0 = m0 + m1 + m2,  s1 = m1 - m2 - m3
   // accumulator tile layout: row (channel) = 4 * kg + reg, column (tile) = j
@@ -415,7 +445,23 @@ __global__ __launch_bounds__(WNT, 2) void wino_conv3x3(WinoArgs a) {
     a.out[(((size_t)n * a.I + i0 + w) * a.Ho + 2 * (tby * tbh)) * a.Wo + 2 * tbx * tbw + lane] = sum;
     return;
   }
-  const bool vec_ok = (a.Wo % 2 == 0);
+  // Stores are RAW BUFFER stores through a descriptor that spans one output plane (zero bytes for a padded channel):
+  // a lane whose pixel lies outside the map gets an offset beyond the plane and the hardware drops its store.  The
+  // output stage is therefore straight-line code -- no per-lane branches around the stores, a fixed number of memory
+  // instructions per wave -- which is also what lets the compiler count vmcnt exactly instead of waiting for zero.
+  unsigned ooff[2][2];                          // [row][element]: byte offset inside the plane, or out of range
+  {
+    const int oty = tby * tbh + (lane >> tsh), otx = tbx * tbw + (lane & (tbw - 1));
+    const int oy = 2 * oty, ox = 2 * otx;
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+        ooff[r][c] = (oy + r < a.Ho && ox + c < a.Wo) ? (unsigned)((oy + r) * a.Wo + ox + c) * 4u : 0x80000000u;
+  }
+  float* const obase = a.nsplit == 1 ? a.out : a.partial + (size_t)sp * a.N * a.I * a.Ho * a.Wo;
+  const float slope = a.nsplit == 1 ? a.slope : 1.f;       // bias / activation happen in wino_split_reduce
+  const unsigned oplane_bytes = (unsigned)(a.Ho * a.Wo) * 4u;
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb) {
 #pragma unroll
@@ -429,7 +475,7 @@ __global__ __launch_bounds__(WNT, 2) void wino_conv3x3(WinoArgs a) {
       }
     __syncthreads();
 #pragma unroll
-    for (int rep = 0; rep < ((EXP & 131072) ? 1 : 4); ++rep) {
+    for (int rep = 0; rep < 4; ++rep) {
       const int il = w + 4 * rep, t = lane;         // channel within the block of 16 (wave-uniform), tile
       const int i = i0 + 16 * cb + il;
       float s[4][2];
@@ -443,33 +489,35 @@ __global__ __launch_bounds__(WNT, 2) void wino_conv3x3(WinoArgs a) {
         y[0][c] = s[0][c] + s[1][c] + s[2][c];
         y[1][c] = s[1][c] - s[2][c] - s[3][c];
       }
-      if ((EXP & 65536) ? (i < a.I && a.off > 100) : (i < a.I)) {
-        const float b = (a.bias && a.nsplit == 1) ? a.bias[task * a.I + i] : 0.f;
-        const int oty = tby * tbh + (t >> tsh), otx = tbx * tbw + (t & (tbw - 1));
-        const int oy = 2 * oty, ox = 2 * otx;
-        float* obase = a.nsplit == 1 ? a.out : a.partial + (size_t)sp * a.N * a.I * a.Ho * a.Wo;
-        const float slope = a.nsplit == 1 ? a.slope : 1.f;       // bias / activation happen in wino_split_reduce
-        float* op = obase + (((size_t)n * a.I + i) * a.Ho + oy) * a.Wo + ox;
+      const float b = bvals[cb][rep];
+      const i32x4 ors = plane_rsrc(obase + ((size_t)n * a.I + min(i, a.I - 1)) * a.Ho * a.Wo, i < a.I ? oplane_bytes : 0u);
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-          if (oy + r >= a.Ho) break;
-          float v0 = y[r][0] + b, v1 = y[r][1] + b;
-          v0 = v0 > 0.f ? v0 : slope * v0;
-          v1 = v1 > 0.f ? v1 : slope * v1;
-          float* o = op + (size_t)r * a.Wo;
-          if (vec_ok && ox + 1 < a.Wo) {
-            if (EXP & 262144) { typedef float f32x2 __attribute__((ext_vector_type(2))); __builtin_nontemporal_store((f32x2){v0, v1}, reinterpret_cast<f32x2*>(o)); }
-            else *reinterpret_cast<float2*>(o) = make_float2(v0, v1);
-          }
-          else {
-            if (ox < a.Wo) o[0] = v0;
-            if (ox + 1 < a.Wo) o[1] = v1;
-          }
+      for (int r = 0; r < 2; ++r) {
+        float v0 = y[r][0] + b, v1 = y[r][1] + b;
+        v0 = fmaxf(v0, 0.f) + slope * fminf(v0, 0.f);      // v > 0 ? v : slope * v
+        v1 = fmaxf(v1, 0.f) + slope * fminf(v1, 0.f);
+        if (VEC) {
+          savfi_raw_buffer_store_x2((f32x2){v0, v1}, ors, (int)ooff[r][0], 0, 0);
+        } else {
+          savfi_raw_buffer_store_x1(v0, ors, (int)ooff[r][0], 0, 0);
+          savfi_raw_buffer_store_x1(v1, ors, (int)ooff[r][1], 0, 0);
         }
       }
     }
     __syncthreads();
   }
+#ifdef WINO_TRACE
+  if (threadIdx.x == 0) {
+    const unsigned long long tr3 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0);
+    const unsigned long long tr4 = __builtin_amdgcn_s_memrealtime();
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned long long* t = a.trace + (size_t)blockIdx.x * 8;
+    t[0] = tr0; t[1] = tr1; t[2] = tr2; t[3] = tr3; t[4] = tr4; t[5] = hw; t[6] = xcc; t[7] = blockIdx.x;
+  }
+#endif
 }
 
 // out = act(sum over splits of partial (fixed order: deterministic) + bias[c])
@@ -539,6 +587,22 @@ bool make_plan(WinoPlan& p, int N, int Ci, int Co, int H, int W, int pad, int mo
 
 }  // namespace
 
+#ifdef WINO_TRACE
+static unsigned long long* g_trace = nullptr;
+static size_t g_trace_wgs = 0;
+static unsigned long long* savfi_wino_trace_buffer(size_t wgs) {
+  if (!g_trace) (void)hipMalloc(&g_trace, (size_t)(1 << 20) * 64);
+  g_trace_wgs = wgs;
+  return g_trace;
+}
+extern "C" int savfi_debug_wino_trace(unsigned long long* host, long long cap) {   // copies the last launch's records
+  (void)hipDeviceSynchronize();
+  const size_t n = g_trace_wgs < (size_t)cap ? g_trace_wgs : (size_t)cap;
+  (void)hipMemcpy(host, g_trace, n * 64, hipMemcpyDeviceToHost);
+  return (int)n;
+}
+#endif
+
 extern "C" int64_t savfi_conv3x3_tasks_workspace_floats(int N, int T, int Ci, int Co, int H, int W, int pad, int mode) {
   if (N <= 0 || T <= 0 || N % T != 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return SAVFI_E_SHAPE;
   if ((mode != 0 && mode != 1) || (pad != 0 && pad != 1)) return SAVFI_E_UNSUPPORTED;
@@ -571,8 +635,13 @@ extern "C" int savfi_conv3x3_tasks_f32(const float* x, const float* w, const flo
   const float* b = mode == 0 ? bias : nullptr;
   float* partial = workspace + (int64_t)T * p.u_floats;
   WinoArgs a{x, workspace, b, out, p.K, p.I, p.KP, p.IP, H, W, p.Ho, p.Wo, p.off, p.th, p.tw, slope, p.tile_shift, p.nsplit,
-             p.chunks_per_split, partial, T, N};
-  hipLaunchKernelGGL(wino_conv3x3, dim3((unsigned)wgs), dim3(WNT), lds, st, a);
+             p.chunks_per_split, partial, T, N
+#ifdef WINO_TRACE
+             , savfi_wino_trace_buffer((size_t)wgs)
+#endif
+  };
+  if (p.Wo % 2 == 0) hipLaunchKernelGGL(wino_conv3x3<true>, dim3((unsigned)wgs), dim3(WNT), lds, st, a);
+  else hipLaunchKernelGGL(wino_conv3x3<false>, dim3((unsigned)wgs), dim3(WNT), lds, st, a);
   if (int e = savfi_launch_status()) return e;
   if (p.nsplit > 1) {
     const size_t total = (size_t)N * p.I * p.Ho * p.Wo;
