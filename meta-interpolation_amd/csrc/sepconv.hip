@@ -94,6 +94,12 @@ constexpr int MKP = 52;   // rows per channel in the M dimension (51 taps + 1 ze
 __device__ __forceinline__ float sc_bload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
 }
+// store with the same addressing; a lane whose offset is >= num_records (SC_OOR) writes nothing: predication without a branch,
+// so a row's stores are a FIXED number of memory instructions and the compiler can count vmcnt for the loads around them
+constexpr unsigned SC_OOR = 0x80000000u;
+__device__ __forceinline__ void sc_bstore(float val, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), r, (int)voff, (int)soff, 0);
+}
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t sc_rsrc(const float* base, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)bytes, 0x00020000);
 }
@@ -108,10 +114,14 @@ __device__ __forceinline__ void mfma_load_taps(float (&regs)[NREG], __amdgpu_buf
 template <int K, int NREG>
 __device__ __forceinline__ void mfma_store_taps(float* __restrict__ dst /* [>=K][16] */, const float (&regs)[NREG],
                                                 int lane) {
+  // Branch-free: row K (one past the last tap) is written with zeros.  For the h rows that is row 0 of the v rows right behind
+  // them, which the v copy that always follows overwrites; for the v rows it is the zero tap row itself.  (A lane-predicated
+  // write made the compiler wait for vmcnt(0) -- every outstanding gradient store -- in front of the last quadruple.)
 #pragma unroll
   for (int it = 0; it < NREG; ++it) {
     const int tap = 4 * it + (lane >> 4);
-    if (tap < K) dst[tap * 16 + (lane & 15)] = regs[it];
+    if (4 * it + 3 < K) dst[tap * 16 + (lane & 15)] = regs[it];
+    else dst[min(tap, K) * 16 + (lane & 15)] = tap < K ? regs[it] : 0.f;
   }
 }
 
@@ -585,6 +595,10 @@ __device__ __forceinline__ void stage_rows_circular(float* __restrict__ inT, __a
         if (rr < NROWS) inT[c * LP + ((r_lo + rr) & (PWIN - 1)) * MLW + q] = buf[c][it];
       }
   }
+  // every load of this call has landed, on the lanes that skipped the writes too: without this the compiler has to assume
+  // that the skipped lanes' loads may still be in flight when their registers are reused, and it put a vmcnt(0) right
+  // after the NEXT phase's tap prefetch had been issued -- the full memory latency, every phase
+  __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0), lgkmcnt / expcnt untouched
 }
 
 template <int K, bool WANT_V, bool WANT_H>
@@ -614,6 +628,8 @@ __global__ __launch_bounds__(MNT) void sepconv_bwd_mfma_p(const float* __restric
   const __amdgpu_buffer_rsrc_t vsrc = sc_rsrc(v, (unsigned)(B * K) * plane_b);
   const __amdgpu_buffer_rsrc_t gsrc = sc_rsrc(gO, (unsigned)(B * C) * plane_b);
   const __amdgpu_buffer_rsrc_t isrc = sc_rsrc(in, (unsigned)(B * C) * (unsigned)(Hi * Wi) * 4u);
+  const __amdgpu_buffer_rsrc_t gvdst = sc_rsrc(gV, WANT_V ? (unsigned)(B * K) * plane_b : 0u);
+  const __amdgpu_buffer_rsrc_t ghdst = sc_rsrc(gH, WANT_H ? (unsigned)(B * K) * plane_b : 0u);
 
   auto pos_of = [&](int g, int& b, int& x0, int& ph) {
     const int s = g / nph;
@@ -671,16 +687,19 @@ __global__ __launch_bounds__(MNT) void sepconv_bwd_mfma_p(const float* __restric
     const int y = 2 * ph + wr;
     const int x = x0 + 16 * wc + j;
     const bool pvalid = (x < Wo) && (y < Ho);
-    const size_t opix = (size_t)min(y, Ho - 1) * Wo + min(x, Wo - 1);
-    const size_t sample_k = (size_t)b * K * plane;
+    // byte offset of this lane's pixel in tap plane 0 of sample b (gV / gH are [B][K][Ho][Wo]); out of range = no store
+    const unsigned opix_b = (unsigned)b * (unsigned)K * plane_b + (unsigned)(min(y, Ho - 1) * Wo + min(x, Wo - 1)) * 4u;
     float g_[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) g_[c] = gnext[c];
-    int nb = b, nx0 = x0, nph_ = ph;
-    if (g + 1 < g1) {                              // next phase's taps and upstream gradient: HBM -> registers
-      pos_of(g + 1, nb, nx0, nph_);
-      load_taps(hreg, hsrc, nb, nx0, 2 * nph_ + wr);
-      load_taps(vreg, vsrc, nb, nx0, 2 * nph_ + wr);
+    // next phase's taps and upstream gradient: HBM -> registers.  Unconditional (the last phase re-reads itself), and the
+    // stores below are a fixed number of instructions, so the wait in front of the LDS copy at the end of the phase is an
+    // exact vmcnt(#stores) -- not a wait for every store's write acknowledge.
+    int nb, nx0, nph_;
+    pos_of(min(g + 1, g1 - 1), nb, nx0, nph_);
+    load_taps(hreg, hsrc, nb, nx0, 2 * nph_ + wr);
+    load_taps(vreg, vsrc, nb, nx0, 2 * nph_ + wr);
+    {
       const unsigned go = pix_off(nb, nx0, 2 * nph_ + wr, C);
 #pragma unroll
       for (int c = 0; c < C; ++c) gnext[c] = sc_bload(gsrc, go, (unsigned)c * plane_b);
@@ -749,13 +768,14 @@ __global__ __launch_bounds__(MNT) void sepconv_bwd_mfma_p(const float* __restric
 #if SC_PIN
       __builtin_amdgcn_sched_barrier(0);
 #endif
+      {   // fy = 16 m + 4 ks + e: all real for m < 3; for m = 3 only ks = 0, e < 3 (fy = 48, 49, 50)
+        static_assert(K == 51 && MTV == 4, "gV store predication");
+        const unsigned vo = opix_b + (unsigned)(4 * ks) * plane_b;
+        const unsigned voA = pvalid ? vo : SC_OOR, voB = (pvalid && ks == 0) ? vo : SC_OOR;
 #pragma unroll
-      for (int m = 0; m < MTV; ++m) {
+        for (int m = 0; m < MTV; ++m)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int fy = 16 * m + 4 * ks + e;
-          if (pvalid && fy < K) gV[sample_k + (size_t)fy * plane + opix] = acc[m][e];
-        }
+          for (int e = 0; e < (m < 3 ? 4 : 3); ++e) sc_bstore(acc[m][e], gvdst, m < 3 ? voA : voB, (unsigned)(16 * m + e) * plane_b);
       }
     }
 
@@ -835,27 +855,24 @@ __global__ __launch_bounds__(MNT) void sepconv_bwd_mfma_p(const float* __restric
 #pragma unroll
           for (int e = 0; e < 4; ++e) tile[(16 * ks + 4 * e + m) * 16 + j] = acc[m][e];
         __builtin_amdgcn_wave_barrier();
+        const unsigned ho = opix_b + (unsigned)ks * plane_b;
 #pragma unroll
         for (int t = 0; t < KTV; ++t) {
           const int fx = 4 * t + ks;
           const float val = tile[min(j + fx, 63) * 16 + j];
-          if (pvalid && fx < K && j + fx < 64) gH[sample_k + (size_t)fx * plane + opix] = val;
+          sc_bstore(val, ghdst, (pvalid && fx < K && j + fx < 64) ? ho : SC_OOR, (unsigned)(4 * t) * plane_b);
         }
         __builtin_amdgcn_wave_barrier();
       }
-      if (pvalid && lane == 14) gH[sample_k + (size_t)50 * plane + opix] = s6414;
-      if (pvalid && lane == 15) {
-        gH[sample_k + (size_t)49 * plane + opix] = s6415;
-        gH[sample_k + (size_t)50 * plane + opix] = s6515;
-      }
+      sc_bstore(s6414, ghdst, (pvalid && lane == 14) ? opix_b : SC_OOR, 50u * plane_b);
+      sc_bstore(s6415, ghdst, (pvalid && lane == 15) ? opix_b : SC_OOR, 49u * plane_b);
+      sc_bstore(s6515, ghdst, (pvalid && lane == 15) ? opix_b : SC_OOR, 50u * plane_b);
     }
 
-    if (g + 1 < g1) {
-      __builtin_amdgcn_wave_barrier();
-      mfma_store_taps<K, NREG>(hB, hreg, lane);
-      mfma_store_taps<K, NREG>(vB, vreg, lane);
-      __builtin_amdgcn_wave_barrier();
-    }
+    __builtin_amdgcn_wave_barrier();
+    mfma_store_taps<K, NREG>(hB, hreg, lane);
+    mfma_store_taps<K, NREG>(vB, vreg, lane);
+    __builtin_amdgcn_wave_barrier();
     b = nb; x0 = nx0; ph = nph_;
   }
 }
