@@ -148,6 +148,7 @@ __global__ __launch_bounds__(MNT) void sepconv_fwd_mfma(const float* __restrict_
   const unsigned plane_b = (unsigned)plane * 4u;
   const __amdgpu_buffer_rsrc_t hsrc = sc_rsrc(h + (size_t)b * K * plane, (unsigned)K * plane_b);
   const __amdgpu_buffer_rsrc_t vsrc = sc_rsrc(v + (size_t)b * K * plane, (unsigned)K * plane_b);
+  const __amdgpu_buffer_rsrc_t osrc = sc_rsrc(out + (size_t)b * C * plane, (unsigned)C * plane_b);
 
   float hreg[NREG], vreg[NREG];
   mfma_load_taps<K, NREG>(hreg, hsrc, plane_b, Ho, Wo, y0 + wr, x0 + 16 * wc, lane);
@@ -264,10 +265,12 @@ __global__ __launch_bounds__(MNT) void sepconv_fwd_mfma(const float* __restrict_
     o0 += __shfl_xor(o0, 16, 64); o0 += __shfl_xor(o0, 32, 64);
     o1 += __shfl_xor(o1, 16, 64); o1 += __shfl_xor(o1, 32, 64);
     o2 += __shfl_xor(o2, 16, 64); o2 += __shfl_xor(o2, 32, 64);
-    const int x = x0 + 16 * wc + j;
-    if (ks == 0 && x < Wo && y < Ho) {
-      float* o = out + (size_t)b * C * plane + (size_t)y * Wo + x;
-      o[0] = o0; o[plane] = o1; o[2 * plane] = o2;
+    {   // branch-free stores (see sc_bstore): a fixed three per row, so the tap prefetch above is waited for with an exact count
+      const int x = x0 + 16 * wc + j;
+      const unsigned oo = (ks == 0 && x < Wo && y < Ho) ? (unsigned)(y * Wo + x) * 4u : SC_OOR;
+      sc_bstore(o0, osrc, oo, 0u);
+      sc_bstore(o1, osrc, oo, plane_b);
+      sc_bstore(o2, osrc, oo, 2u * plane_b);
     }
 
     if (ph + 1 < MROWS / 2) {
@@ -321,6 +324,8 @@ __global__ __launch_bounds__(MNT) void sepconv_bwd_mfma(const float* __restrict_
   const __amdgpu_buffer_rsrc_t hsrc = sc_rsrc(h + (size_t)b * K * plane, (unsigned)K * plane_b);
   const __amdgpu_buffer_rsrc_t vsrc = sc_rsrc(v + (size_t)b * K * plane, (unsigned)K * plane_b);
   const __amdgpu_buffer_rsrc_t gsrc = sc_rsrc(gO + (size_t)b * C * plane, (unsigned)C * plane_b);
+  const __amdgpu_buffer_rsrc_t gvdst = sc_rsrc(gV + (size_t)b * K * plane, WANT_V ? (unsigned)K * plane_b : 0u);
+  const __amdgpu_buffer_rsrc_t ghdst = sc_rsrc(gH + (size_t)b * K * plane, WANT_H ? (unsigned)K * plane_b : 0u);
   // byte offset of this lane's pixel in row y of a plane (clamped: out-of-image pixels are computed and never stored)
   auto pix_off = [&](int y) { return (unsigned)(min(y, Ho - 1) * Wo + min(x0 + 16 * wc + j, Wo - 1)) * 4u; };
 
@@ -357,7 +362,7 @@ __global__ __launch_bounds__(MNT) void sepconv_bwd_mfma(const float* __restrict_
     const int y = y0 + 2 * ph + wr;
     const int x = x0 + 16 * wc + j;
     const bool pvalid = (x < Wo) && (y < Ho);
-    const size_t opix = (size_t)min(y, Ho - 1) * Wo + min(x, Wo - 1);
+    const unsigned opix_b = (unsigned)(min(y, Ho - 1) * Wo + min(x, Wo - 1)) * 4u;   // this lane's pixel inside a tap plane
     float g[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) g[c] = gnext[c];              // fetched during the previous row
@@ -433,13 +438,14 @@ __global__ __launch_bounds__(MNT) void sepconv_bwd_mfma(const float* __restrict_
 #if SC_PIN
       __builtin_amdgcn_sched_barrier(0);
 #endif
+      {   // branch-free stores (see sc_bstore); fy = 16 m + 4 ks + e: all real for m < 3, for m = 3 only ks = 0, e < 3
+        static_assert(K == 51 && MTV == 4, "gV store predication");
+        const unsigned vo = opix_b + (unsigned)(4 * ks) * plane_b;
+        const unsigned voA = pvalid ? vo : SC_OOR, voB = (pvalid && ks == 0) ? vo : SC_OOR;
 #pragma unroll
-      for (int m = 0; m < MTV; ++m) {
+        for (int m = 0; m < MTV; ++m)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int fy = 16 * m + 4 * ks + e;
-          if (pvalid && fy < K) gV[(size_t)b * K * plane + (size_t)fy * plane + opix] = acc[m][e];
-        }
+          for (int e = 0; e < (m < 3 ? 4 : 3); ++e) sc_bstore(acc[m][e], gvdst, m < 3 ? voA : voB, (unsigned)(16 * m + e) * plane_b);
       }
     }
 
@@ -527,7 +533,7 @@ __global__ __launch_bounds__(MNT) void sepconv_bwd_mfma(const float* __restrict_
         for (int t = 0; t < KTV; ++t) {
           const int fx = 4 * t + ks;
           const float val = tile[min(j + fx, 63) * 16 + j];
-          if (pvalid && fx < K && j + fx < 64) gH[(size_t)b * K * plane + (size_t)fx * plane + opix] = val;
+          sc_bstore(val, ghdst, (pvalid && fx < K && j + fx < 64) ? opix_b + (unsigned)ks * plane_b : SC_OOR, (unsigned)(4 * t) * plane_b);
         }
         __builtin_amdgcn_wave_barrier();
       }
@@ -537,15 +543,13 @@ __global__ __launch_bounds__(MNT) void sepconv_bwd_mfma(const float* __restrict_
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int fx = 16 * ks + 4 * e + m - j;
-          if (pvalid && fx >= 0 && fx < K) gH[(size_t)b * K * plane + (size_t)fx * plane + opix] = acc[m][e];
+          sc_bstore(acc[m][e], ghdst, (pvalid && fx >= 0 && fx < K) ? opix_b + (unsigned)max(fx, 0) * plane_b : SC_OOR, 0u);
         }
       }
 #endif
-      if (pvalid && lane == 14) gH[(size_t)b * K * plane + (size_t)50 * plane + opix] = s6414;
-      if (pvalid && lane == 15) {
-        gH[(size_t)b * K * plane + (size_t)49 * plane + opix] = s6415;
-        gH[(size_t)b * K * plane + (size_t)50 * plane + opix] = s6515;
-      }
+      sc_bstore(s6414, ghdst, (pvalid && lane == 14) ? opix_b : SC_OOR, 50u * plane_b);
+      sc_bstore(s6415, ghdst, (pvalid && lane == 15) ? opix_b : SC_OOR, 49u * plane_b);
+      sc_bstore(s6515, ghdst, (pvalid && lane == 15) ? opix_b : SC_OOR, 50u * plane_b);
     }
 
     if (ph + 1 < MROWS / 2) {
