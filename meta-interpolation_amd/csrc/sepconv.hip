@@ -575,34 +575,51 @@ __global__ __launch_bounds__(MNT) void sepconv_bwd_mfma(const float* __restrict_
 constexpr int PWIN = 64;                       // window rows per channel (power of two >= K + 1)
 constexpr int PAHEAD = PWIN - (KFAST + 1);     // rows staged per refill (12)
 
-// rows [r_lo, r_lo + nrows) of the strip (b, x0) -> their circular slots, all three channels; thread -> (column, row group)
+// rows [r_lo, r_lo + nrows) of the strip (b, x0) -> their circular slots, all three channels; thread -> (column, row group).
+// Two halves so that the slide (twelve rows every sixth phase) can be in flight for a whole phase: loads -> registers, then,
+// behind a barrier, registers -> LDS.
 template <int NROWS>
-__device__ __forceinline__ void stage_rows_circular(float* __restrict__ inT, __amdgpu_buffer_rsrc_t in_rs, int b, int x0, int r_lo,
-                                                    int Hi, int Wi, int tid) {
-  constexpr int C = 3, RG = MNT / 128, NIT = (NROWS + RG - 1) / RG, LP = PWIN * MLW;
+struct StagedRows {
+  static constexpr int C = 3, RG = MNT / 128, NIT = (NROWS + RG - 1) / RG;
+  float buf[C][NIT];
+};
+template <int NROWS>
+__device__ __forceinline__ void stage_rows_load(StagedRows<NROWS>& sr, __amdgpu_buffer_rsrc_t in_rs, int b, int x0, int r_lo,
+                                                int Hi, int Wi, int tid) {
+  constexpr int C = 3, RG = MNT / 128, NIT = StagedRows<NROWS>::NIT;
   const int q = tid & 127, rg = tid >> 7;
   const int colb = min(x0 + q, Wi - 1) * 4;
-  float buf[C][NIT];
 #pragma unroll
   for (int c = 0; c < C; ++c)
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int r = min(r_lo + rg + it * RG, Hi - 1);
-      buf[c][it] = sc_bload(in_rs, (unsigned)(((b * C + c) * Hi + r) * Wi * 4 + colb), 0u);
+      sr.buf[c][it] = sc_bload(in_rs, (unsigned)(((b * C + c) * Hi + r) * Wi * 4 + colb), 0u);
     }
-  if (q < MSPAN) {
+}
+template <int NROWS>
+__device__ __forceinline__ void stage_rows_write(const StagedRows<NROWS>& sr, float* __restrict__ inT, int r_lo, int tid) {
+  constexpr int C = 3, RG = MNT / 128, NIT = StagedRows<NROWS>::NIT, LP = PWIN * MLW;
+  const int q = tid & 127, rg = tid >> 7;
+  // branch-free: all 128 columns are written.  Columns MSPAN .. 127 of a window row are only read by gH rows that are
+  // discarded (they must merely stay finite, and image data is), and no lane skips the reads of its staging registers -- a
+  // skipped lane leaves its loads "possibly in flight" for the compiler, which then waits for vmcnt(0) wherever those
+  // registers are reused.
+  static_assert(128 <= MLW, "staged columns fit a window row");
 #pragma unroll
-    for (int c = 0; c < C; ++c)
+  for (int c = 0; c < C; ++c)
 #pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const int rr = rg + it * RG;
-        if (rr < NROWS) inT[c * LP + ((r_lo + rr) & (PWIN - 1)) * MLW + q] = buf[c][it];
-      }
-  }
-  // every load of this call has landed, on the lanes that skipped the writes too: without this the compiler has to assume
-  // that the skipped lanes' loads may still be in flight when their registers are reused, and it put a vmcnt(0) right
-  // after the NEXT phase's tap prefetch had been issued -- the full memory latency, every phase
-  __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0), lgkmcnt / expcnt untouched
+    for (int it = 0; it < NIT; ++it) {
+      const int rr = rg + it * RG;
+      if (rr < NROWS) inT[c * LP + ((r_lo + rr) & (PWIN - 1)) * MLW + q] = sr.buf[c][it];
+    }
+}
+template <int NROWS>
+__device__ __forceinline__ void stage_rows_circular(float* __restrict__ inT, __amdgpu_buffer_rsrc_t in_rs, int b, int x0, int r_lo,
+                                                    int Hi, int Wi, int tid) {
+  StagedRows<NROWS> sr;
+  stage_rows_load<NROWS>(sr, in_rs, b, x0, r_lo, Hi, Wi, tid);
+  stage_rows_write<NROWS>(sr, inT, r_lo, tid);
 }
 
 template <int K, bool WANT_V, bool WANT_H>
@@ -682,12 +699,16 @@ __global__ __launch_bounds__(MNT) void sepconv_bwd_mfma_p(const float* __restric
         stage_rows_circular<16>(inT, isrc, b, x0, r, Hi, Wi, tid);
       loaded_hi = PWIN;
       __syncthreads();
-    } else if (2 * ph + K + 1 > loaded_hi) {       // slide: the twelve oldest rows are behind every wave's current phase
-      __syncthreads();
-      stage_rows_circular<PAHEAD>(inT, isrc, b, x0, loaded_hi, Hi, Wi, tid);
-      loaded_hi += PAHEAD;
-      __syncthreads();
     }
+    // next phase (position and whether it needs the window slid by twelve rows first)
+    int nb, nx0, nph_;
+    pos_of(min(g + 1, g1 - 1), nb, nx0, nph_);
+    const bool slide = (g + 1 < g1) && nph_ != 0 && (2 * nph_ + K + 1 > loaded_hi);
+    // The slide's rows travel HBM -> registers during this phase and registers -> LDS behind the barrier at its end: issued
+    // first, they are older than the tap prefetch, so the exact vmcnt wait of the tap copy covers them and nobody waits for
+    // memory with the matrix pipe idle (before: two barriers around a load + wait, every sixth phase, with all eight waves idle).
+    StagedRows<PAHEAD> slid;
+    if (slide) stage_rows_load<PAHEAD>(slid, isrc, b, x0, loaded_hi, Hi, Wi, tid);
     const int y = 2 * ph + wr;
     const int x = x0 + 16 * wc + j;
     const bool pvalid = (x < Wo) && (y < Ho);
@@ -699,8 +720,6 @@ __global__ __launch_bounds__(MNT) void sepconv_bwd_mfma_p(const float* __restric
     // next phase's taps and upstream gradient: HBM -> registers.  Unconditional (the last phase re-reads itself), and the
     // stores below are a fixed number of instructions, so the wait in front of the LDS copy at the end of the phase is an
     // exact vmcnt(#stores) -- not a wait for every store's write acknowledge.
-    int nb, nx0, nph_;
-    pos_of(min(g + 1, g1 - 1), nb, nx0, nph_);
     load_taps(hreg, hsrc, nb, nx0, 2 * nph_ + wr);
     load_taps(vreg, vsrc, nb, nx0, 2 * nph_ + wr);
     {
@@ -877,6 +896,12 @@ __global__ __launch_bounds__(MNT) void sepconv_bwd_mfma_p(const float* __restric
     mfma_store_taps<K, NREG>(hB, hreg, lane);
     mfma_store_taps<K, NREG>(vB, vreg, lane);
     __builtin_amdgcn_wave_barrier();
+    if (slide) {                                   // the twelve oldest rows are behind every wave's next phase
+      __syncthreads();
+      stage_rows_write<PAHEAD>(slid, inT, loaded_hi, tid);
+      loaded_hi += PAHEAD;
+      __syncthreads();
+    }
     b = nb; x0 = nx0; ph = nph_;
   }
 }

@@ -12,17 +12,24 @@
 //   V[xi][k][t] = (B^T d B)[xi]                     input transform, in registers, one (tile, channel) per thread
 //   M[xi][i][t] = sum_k U[xi][k][i] V[xi][k][t]     16 GEMMs -> MFMA 16x16x4 f32        (k: reduction channel, i: produced)
 //
-// Workgroup = 256 threads = 4 waves, TWO workgroups per CU (each ~200 VGPRs, 40 KB LDS) so that one's prologue /
+// Workgroup = 256 threads = 4 waves, TWO workgroups per CU (each ~210 VGPRs, 40 KB LDS) so that one's prologue /
 // output stage overlaps the other's channel loop.  A workgroup owns 64 tiles (4 x 16 tiles = 8 x 32 output pixels)
 // x 32 produced channels and walks the reduction channels 4 at a time (one MFMA k-step).  Wave w owns the Winograd
 // row xi = 4w .. 4w+3 for all 32 channels x 64 tiles: 4 x 2 x 4 accumulator tiles = 128 registers.
 // Per chunk every thread transforms ONE 4x4 patch (tile = lane, channel = wave) in registers and writes its 16 values
 // to the V buffer in LDS (double buffered, one barrier per chunk); a wave reads 16 B fragments from LDS and holds its
 // A fragments (straight from global / L2, pre-swizzled so that a lane gets them with two 16-byte loads) for 32 MFMAs.
-// fp32 MFMA and VALU share the SIMD's fp32 datapath (measured: VALU instructions add their full issue time to the MFMA
-// time), so the loop is kept at ~45 VALU per 32 MFMAs; patches and A fragments are prefetched TWO chunks ahead into
-// the registers their predecessors just vacated.  Output stage: the wave reduces its row in registers
-// (column half of A^T M A), the four rows meet in LDS 16 channels at a time, + bias, (leaky) ReLU, 2x2 stores.
+// The matrix pipe of a SIMD executes nothing else while a VALU / LDS / memory instruction of ANY of its waves issues
+// (micro-benchmark, round 2: 32 MFMAs + 32 VALU take 1028 + ~5 x 32 cycles, also when they come from two waves), so the
+// loop is kept at ~40 VALU per 32 MFMAs; patches and A fragments are prefetched TWO chunks ahead into the registers
+// their predecessors just vacated.  Output stage: the wave reduces its row in registers (column half of A^T M A), the
+// four rows meet in LDS 16 channels at a time, + bias, (leaky) ReLU, raw buffer stores.
+//
+// Memory instructions: vmcnt counts loads AND stores in one in-order counter.  Every load whose value is needed after a
+// store has been issued is therefore placed BEFORE the stores of that stretch (bias: prologue), and the stores are
+// branch-free (out-of-range offsets instead of per-lane branches) so that the compiler can count them: a conservative
+// vmcnt(0) in front of a load's first use waits for every outstanding store's write acknowledge (~0.8 us each time).
+// tools/wino_trace.py (per-workgroup timestamps, -DWINO_TRACE build) is how these stalls were found.
 //
 // The data gradient is the same kernel on the flipped / transposed filter (wino_filter_transform mode 1).
 #include "common.h"
@@ -50,10 +57,6 @@ constexpr int XS = 68;              // pitch of an exchange row [channel] (outpu
 constexpr int VBUF = 16 * CIB * VS; // floats per V buffer (20 KB)
 constexpr int XBUF = 4 * 2 * 16 * XS;  // exchange: [row xi_r][column c][16 channels][XS]
 constexpr int LDS_FLOATS = (2 * VBUF > XBUF) ? 2 * VBUF : XBUF;
-#ifndef WINO_EXP
-#define WINO_EXP 0
-#endif
-constexpr int EXP = WINO_EXP;   // timing experiments only (wrong results): 1 no barrier, 2 no patch loads, 4 no A loads, 8 no transform, 16 no MFMA
 
 // ---- filter transform ------------------------------------------------------------------------------------
 // U = G g G^T for reduction channel k < KP and produced channel i < IP (zero padded), stored in MFMA A-fragment
@@ -260,7 +263,7 @@ __device__ __forceinline__ void chunk_body(f32x4 (&acc)[4][2][4], f32x4 (&afr)[2
 #pragma unroll
   for (int g = 0; g < 8; ++g) {
     const int c = g >> 1, cb = g & 1, cur = c & 1;       // xi column, channel block
-    if (cb == 0 && c < 3 && !(EXP & 256)) {   // B fragments of the next xi
+    if (cb == 0 && c < 3) {   // B fragments of the next xi
 #pragma unroll
       for (int tt = 0; tt < 4; ++tt)
         bfr[cur ^ 1][tt] = vcur[(c + 1) * CIB * VS + 16 * tt];
@@ -268,30 +271,13 @@ __device__ __forceinline__ void chunk_body(f32x4 (&acc)[4][2][4], f32x4 (&afr)[2
     const float a = afr[c >> 1][2 * (c & 1) + cb];
 #pragma unroll
     for (int tt = 0; tt < 4; ++tt)
-      if (!(EXP & 16)) acc[c][cb][tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bfr[cur][tt], acc[c][cb][tt], 0, 0, 0);
-      else acc[c][cb][tt][0] += a * bfr[cur][tt];
-    if (EXP & 8) {
-    } else if (g < 4) {               // B^T d : column g
-      if (!(EXP & 128)) {
-        t[0 * 4 + g] = d[0 * 4 + g] - d[2 * 4 + g];
-        t[1 * 4 + g] = d[1 * 4 + g] + d[2 * 4 + g];
-        t[2 * 4 + g] = d[2 * 4 + g] - d[1 * 4 + g];
-        t[3 * 4 + g] = d[1 * 4 + g] - d[3 * 4 + g];
-      } else {
-        t[0 * 4 + g] = d[0 * 4 + g]; t[1 * 4 + g] = d[1 * 4 + g]; t[2 * 4 + g] = d[2 * 4 + g]; t[3 * 4 + g] = d[3 * 4 + g];
-      }
-      if (g == 3 && !(EXP & 2)) load_patch(d, plane3, plane_bytes, patch);
-    } else if (EXP & 64) {     // transform computed, ONE LDS write per chunk instead of 16
-      const int r = g - 4;
-      const float s0 = (t[r * 4 + 0] - t[r * 4 + 2]) + (t[r * 4 + 1] + t[r * 4 + 2]) * 3.f + (t[r * 4 + 2] - t[r * 4 + 1]) * 5.f + (t[r * 4 + 1] - t[r * 4 + 3]) * 7.f;
-      t[r] = s0;
-      if (r == 3) vnext[0] = t[0] + t[1] * 2.f + t[2] * 3.f + t[3] * 4.f;
-    } else if (EXP & 128) {
-      const int r = g - 4;
-      vnext[(r * 4 + 0) * CIB * VS] = t[r * 4 + 0];
-      vnext[(r * 4 + 1) * CIB * VS] = t[r * 4 + 1];
-      vnext[(r * 4 + 2) * CIB * VS] = t[r * 4 + 2];
-      vnext[(r * 4 + 3) * CIB * VS] = t[r * 4 + 3];
+      acc[c][cb][tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bfr[cur][tt], acc[c][cb][tt], 0, 0, 0);
+    if (g < 4) {               // B^T d : column g
+      t[0 * 4 + g] = d[0 * 4 + g] - d[2 * 4 + g];
+      t[1 * 4 + g] = d[1 * 4 + g] + d[2 * 4 + g];
+      t[2 * 4 + g] = d[2 * 4 + g] - d[1 * 4 + g];
+      t[3 * 4 + g] = d[1 * 4 + g] - d[3 * 4 + g];
+      if (g == 3) load_patch(d, plane3, plane_bytes, patch);
     } else {                   // (B^T d) B : row g - 4, written straight to the next V buffer
       const int r = g - 4;
       vnext[(r * 4 + 0) * CIB * VS] = t[r * 4 + 0] - t[r * 4 + 2];
@@ -299,7 +285,7 @@ __device__ __forceinline__ void chunk_body(f32x4 (&acc)[4][2][4], f32x4 (&afr)[2
       vnext[(r * 4 + 2) * CIB * VS] = t[r * 4 + 2] - t[r * 4 + 1];
       vnext[(r * 4 + 3) * CIB * VS] = t[r * 4 + 1] - t[r * 4 + 3];
     }
-    if (g == 7 && !(EXP & 4)) {
+    if (g == 7) {
       afr[0] = *reinterpret_cast<const f32x4*>(unext + ulane);
       afr[1] = *reinterpret_cast<const f32x4*>(unext + ulane + 16);
     }
@@ -361,7 +347,7 @@ __global__ __launch_bounds__(WNT, 2) void wino_conv3x3(WinoArgs a) {
 
   // A fragments of this wave for chunk c: 2 x f32x4 at ((c * nblk + cob) * 4 + w) * 64 lanes * 32 bytes
   // this workgroup reduces over chunks [cbeg, nchunk) of the KP / CIB chunks (an even count)
-  const int cbeg = sp * a.chunks_per_split, nchunk = (EXP & 8192) ? cbeg + 2 : min(cbeg + a.chunks_per_split, a.KP / CIB);
+  const int cbeg = sp * a.chunks_per_split, nchunk = min(cbeg + a.chunks_per_split, a.KP / CIB);
   const size_t ustride = (size_t)nblk * 4 * 64 * 32;                                     // bytes per chunk
   const char* ubase = reinterpret_cast<const char*>(a.U + (size_t)task * 16 * a.KP * a.IP) + ((size_t)cob * 4 + w) * 64 * 32;
   const unsigned ulane = (unsigned)lane * 32u;
@@ -371,7 +357,7 @@ __global__ __launch_bounds__(WNT, 2) void wino_conv3x3(WinoArgs a) {
   // fix-ups (wave-uniform): bit 0 = some column of some lane is outside the image; bits 1-2 = `off` in the workgroup that
   // owns tile (0, 0) of a padded map (its lane 0 holds the row that would start before the plane)
   const LaneMasks lm = make_lane_masks(px0, a.W);
-  const int fixup = (EXP & 512) ? 0 : (lm.partial_cols != 0 ? 1 : 0) | ((tb == 0 && a.off > 0) ? 2 * a.off : 0);
+  const int fixup = (lm.partial_cols != 0 ? 1 : 0) | ((tb == 0 && a.off > 0) ? 2 * a.off : 0);
 
   // The 8 bias values of this wave are fetched HERE, with the first patches: vmcnt counts loads and stores in one in-order
   // counter, so a bias load issued between the output stage's stores (as the first version did, once per channel) can only be
@@ -420,12 +406,12 @@ __global__ __launch_bounds__(WNT, 2) void wino_conv3x3(WinoArgs a) {
     // even chunk: MFMAs on V(0) with A(ch); transforms P(ch+1) = dB -> V(1); reloads dB <- P(ch+3), afrA <- A(ch+2)
     chunk_body(acc, afrA, lds + vroff, dB, patch, fixup, tbw, lm, lds + VBUF + vwoff,
                plane_of(ch + 3), plane_bytes, u_of(ch + 2), ulane);
-    if (!(EXP & 1)) __syncthreads();
+    __syncthreads();
     // nchunk is even (KP is a multiple of 2 * CIB): an `if (ch + 1 < nchunk)` here would make the compiler assume the
     // A fragments loaded at the end of the even chunk may be the youngest load in flight -> vmcnt(0) every iteration
     chunk_body(acc, afrB, lds + VBUF + vroff, dA, patch, fixup, tbw, lm, lds + vwoff,
                plane_of(ch + 4), plane_bytes, u_of(ch + 3), ulane);
-    if (!(EXP & 1)) __syncthreads();
+    __syncthreads();
   }
 
 #ifdef WINO_TRACE
@@ -434,17 +420,6 @@ __global__ __launch_bounds__(WNT, 2) void wino_conv3x3(WinoArgs a) {
   // ---- output stage ------------------------------------------------------------------------------------------
   // column half of A^T M A in registers (this wave holds the whole row r = w):  s0 = m0 + m1 + m2,  s1 = m1 - m2 - m3
   // accumulator tile layout: row (channel) = 4 * kg + reg, column (tile) = j
-  if (EXP & 4096) {      // timing: no output stage (one store per lane keeps the accumulators alive)
-    float sum = 0.f;
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) sum += acc[c][cb][t][0] + acc[c][cb][t][1] + acc[c][cb][t][2] + acc[c][cb][t][3];
-    a.out[(((size_t)n * a.I + i0 + w) * a.Ho + 2 * (tby * tbh)) * a.Wo + 2 * tbx * tbw + lane] = sum;
-    return;
-  }
   // Stores are RAW BUFFER stores through a descriptor that spans one output plane (zero bytes for a padded channel):
   // a lane whose pixel lies outside the map gets an offset beyond the plane and the hardware drops its store.  The
   // output stage is therefore straight-line code -- no per-lane branches around the stores, a fixed number of memory
@@ -558,9 +533,7 @@ bool make_plan(WinoPlan& p, int N, int Ci, int Co, int H, int W, int pad, int mo
   // tile block shape: the one that covers the tile map with the fewest blocks (ties: the widest rows, 4 x 16 first)
   const int ty = savfi_cdiv(p.Ho, 2), tx = savfi_cdiv(p.Wo, 2);
   int64_t best = -1;
-  static const int force_shift = getenv("SAVFI_WINO_SHIFT") ? atoi(getenv("SAVFI_WINO_SHIFT")) : 0;
   for (int s : {4, 3, 5, 2}) {
-    if (force_shift && s != force_shift) continue;
     const int64_t blocks = (int64_t)savfi_cdiv(ty, TILES_WG >> s) * savfi_cdiv(tx, 1 << s);
     if (best < 0 || blocks < best) { best = blocks; p.tile_shift = s; }
   }
@@ -631,7 +604,7 @@ extern "C" int savfi_conv3x3_tasks_f32(const float* x, const float* w, const flo
   hipLaunchKernelGGL(wino_filter_transform, dim3(p.KP / 4, savfi_cdiv(p.IP, 64) * T), dim3(256), 0, st, w, workspace, Co, Ci, p.K,
                      p.I, p.KP, p.IP, mode);
   if (int e = savfi_launch_status()) return e;
-  constexpr size_t lds = (EXP & 32) ? 65536 : (size_t)LDS_FLOATS * sizeof(float);      // 40 KB: two workgroups per CU
+  constexpr size_t lds = (size_t)LDS_FLOATS * sizeof(float);      // 40 KB: two workgroups per CU
   const float* b = mode == 0 ? bias : nullptr;
   float* partial = workspace + (int64_t)T * p.u_floats;
   WinoArgs a{x, workspace, b, out, p.K, p.I, p.KP, p.IP, H, W, p.Ho, p.Wo, p.off, p.th, p.tw, slope, p.tile_shift, p.nsplit,
