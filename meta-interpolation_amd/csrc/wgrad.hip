@@ -14,7 +14,7 @@
 // (2 x 2 x 9 accumulator tiles = 144 registers per lane) over a strip of R rows x 64 columns of one image.  Per row the
 // cotangent row [32][64] and the three input rows [3][32][66] are staged in LDS (double buffered, one barrier per row,
 // pitch 68 so that both fragment reads are bank-conflict free); wave w multiplies pixels [16w, 16w+16): 4 k-steps x 36
-// MFMAs against 20 LDS dwords per k-step.  The four waves' accumulators are added through LDS in a fixed order, every
+// MFMAs against 14 LDS reads (b128 / b64) per row.  The four waves' accumulators are added through LDS in a fixed order, every
 // workgroup writes one partial block, and wgrad_reduce adds the partial blocks in a fixed order (no atomics).
 #include "common.h"
 
@@ -163,21 +163,33 @@ __global__ __launch_bounds__(GNT, 2) void wgrad3x3(WgradArgs a) {
     const float* cur = lds + ((y - y0) & 1) * BUF_FLOATS;
     float* nxt = lds + ((y - y0 + 1) & 1) * BUF_FLOATS;
     load_rows(st, a, cols, gr, xr, co0, ci0, y + 1, w);       // next row: in flight during this row's MFMAs
-    const float* G = cur + i * GP + 16 * w + k;                      // A: G[rb * 16 + i][16 w + 4 ks + k]
-    const float* X = cur + G_FLOATS + i * GP + 16 * w + k;           // B: X[r][cb * 16 + i][16 w + 4 ks + k + b]
+    __builtin_amdgcn_sched_barrier(0);                       // ... which the scheduler otherwise sinks behind ~120 of the 144
+    // k-slot (step ks, lane group k) takes pixel 16 w + 4 k + ks -- any assignment works as long as A and B agree -- so that a
+    // lane's four steps are CONSECUTIVE pixels: the A values of a row block are one ds_read_b128, the B values of an input row
+    // block (pixels 4k .. 4k + 5: three column taps) one b128 + one b64, 14 LDS reads per row where the ks-major assignment
+    // needed 80 dwords (44 read2).  Pitch 68: lane (i, k) starts at bank 4 i + const, a quarter wave covers all 64 banks.
+    const float* G = cur + i * GP + 16 * w + 4 * k;                  // A: G[rb * 16 + i][16 w + 4 k + ks]
+    const float* X = cur + G_FLOATS + i * GP + 16 * w + 4 * k;       // B: X[r][cb * 16 + i][16 w + 4 k + ks + b]
+    const f32x4 ga0 = *reinterpret_cast<const f32x4*>(G), ga1 = *reinterpret_cast<const f32x4*>(G + 16 * GP);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const float a0 = G[4 * ks], a1 = G[16 * GP + 4 * ks];
+    for (int r = 0; r < 3; ++r) {
+      float xs[2][6];
 #pragma unroll
-      for (int r = 0; r < 3; ++r)
+      for (int cb = 0; cb < 2; ++cb) {
+        const float* xp = X + (r * GCI + 16 * cb) * GP;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(xp);
+        const float2 hi = *reinterpret_cast<const float2*>(xp + 4);
+        xs[cb][0] = lo[0]; xs[cb][1] = lo[1]; xs[cb][2] = lo[2]; xs[cb][3] = lo[3]; xs[cb][4] = hi.x; xs[cb][5] = hi.y;
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int b = 0; b < 3; ++b) {
-          const float b0 = X[(r * GCI) * GP + 4 * ks + b], b1 = X[(r * GCI + 16) * GP + 4 * ks + b];
           const int t = r * 3 + b;
-          acc[0][0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0][t], 0, 0, 0);
-          acc[0][1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1][t], 0, 0, 0);
-          acc[1][0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0][t], 0, 0, 0);
-          acc[1][1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1][t], 0, 0, 0);
+          acc[0][0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga0[ks], xs[0][ks + b], acc[0][0][t], 0, 0, 0);
+          acc[0][1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga0[ks], xs[1][ks + b], acc[0][1][t], 0, 0, 0);
+          acc[1][0][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga1[ks], xs[0][ks + b], acc[1][0][t], 0, 0, 0);
+          acc[1][1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga1[ks], xs[1][ks + b], acc[1][1][t], 0, 0, 0);
         }
     }
     store_rows(nxt, st, a, cols, co0, ci0, y + 1, tid, w);
