@@ -308,7 +308,7 @@ __global__ __launch_bounds__(WNT, 2) void wino_conv3x3(WinoArgs a) {
   // layers with at most two channel blocks -- the large maps, where the input is most of the traffic -- the block index is
   // remapped (bijectively, any grid size) so that one XCD walks a CONTIGUOUS eighth of that order: neighbouring tile blocks
   // (shared halo rows, shared 128-byte lines) then meet in the same L2.  PMC fetch traffic: 3.0 x the input -> 1.0 x for
-  // 32 -> 32 @ 384 x 512, 7.3 x -> 1.08 x for 51 -> 51 @ 258 x 450.  The time moves by 0-5 % only (the re-reads were served by
+  // 32 -> 32 @ 384 x 512, 7.3 x -> 2.1 x for 51 -> 51 @ 258 x 450 (two channel blocks).  The time moves by 0-5 % only (the re-reads were served by
   // the Infinity Cache); with more channel blocks the remap measured SLOWER (256 -> 256 @ 48 x 64: 153 -> 175 us), so those keep
   // the dispatch order.
   const int nblk = a.IP / COB;
