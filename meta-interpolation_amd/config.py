@@ -9,7 +9,8 @@ Additions for the MI355X build (all optional, all default to the reference behav
                                -1 (default) when the rank would otherwise adapt its tasks one at a time (launch-bound passes)
   --sepconv_window {0,1}       SepConv: evaluate the sub-networks / 51-tap op on the frame window only (same values)
   --wgrad_overlap {0,1}        weight gradients of first-order support passes on a side stream, beside the data-gradient chain (default 0)
-  --task_streams N             adapt N tasks of a meta-batch concurrently (one Python thread + HIP stream each; default 1)
+  --task_streams N             adapt N tasks of a meta-batch concurrently (one Python thread + HIP stream each); default -1:
+                               1 in the eager loops, up to 4 where single tasks are replayed from hipGraphs
   --task_batch T               adapt up to T tasks of a meta-batch in LOCKSTEP: one launch per layer for all of them, per-task fast
                                weights (default 4; first order -- second order, L2F on partly routed plugins and T <= 1 take the
                                reference's sequential task loop)
@@ -47,7 +48,7 @@ _FLAGS = {
     ],
     'MI355X': [
         ('fuse_support_pairs', int, 1), ('fuse_conv_act', int, 1), ('graph_inner_loop', int, -1), ('sepconv_window', int, 1),
-        ('task_streams', int, 1), ('wgrad_overlap', int, 0), ('task_batch', int, 4),
+        ('task_streams', int, -1), ('wgrad_overlap', int, 0), ('task_batch', int, 4),
         ('synthetic', 'flag', False),
     ],
 }

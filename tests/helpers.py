@@ -64,6 +64,7 @@ def build_system(model, overrides, fuse=1, device="cuda"):
     from meta_interpolation_amd.meta_learning_system import SceneAdaptiveInterpolation
     overrides = dict(overrides)
     overrides.setdefault('graph_inner_loop', 0)
+    overrides.setdefault('task_streams', 1)
     args = default_args(model=model, num_gpu=1, fuse_support_pairs=fuse, **overrides)
     net = build_plugin(model, device)
     system = SceneAdaptiveInterpolation(args, net=net)

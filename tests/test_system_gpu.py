@@ -479,7 +479,7 @@ def test_graphed_inner_loop_matches_reference_fixture(name, phase):
     tol = TOL[name]
     g = golden("system_" + name)
     model = str(g['model'])
-    system = build_system(model, dict(parse_case_args(g), graph_inner_loop=1, task_batch=0))
+    system = build_system(model, dict(parse_case_args(g), graph_inner_loop=1, task_batch=0, task_streams=1))
     rec = {}
     system.optimizer.step = lambda *a, **k: rec.update(
         {n: fp(p.grad) for n, p in system.named_parameters() if p.requires_grad and p.grad is not None})
@@ -664,10 +664,13 @@ def test_graphed_lockstep_tasks_match_reference_fixture(name, phase, lockstep_fo
 def test_default_execution_mode_policy():
     """config.py defaults (--graph_inner_loop -1, --task_batch 4): a rank with ONE task replays hipGraphs (launch-bound pass), a rank
     with several adapts them in lockstep in the eager loop, L2F (not capturable) stays eager -- all with the fixture's numbers."""
-    for name, want_graphs, want_lockstep in (('c1_cain_lslr_sgd', 1, 0), ('sepconv_msl_learnable_2step', 0, 1), ('cain_l2f', 0, 0)):
+    # VoxelFlow opts out of the lockstep path: its two tasks are replayed from hipGraphs, one graph set per task stream
+    # (--task_streams -1: up to four streams under graphs, one in the eager loops)
+    for name, want_graphs, want_lockstep in (('c1_cain_lslr_sgd', 1, 0), ('sepconv_msl_learnable_2step', 0, 1), ('cain_l2f', 0, 0),
+                                             ('voxelflow_lslr_sgd_2step', 2, 0)):
         g = golden("system_" + name)
         model = str(g['model'])
-        system = build_system(model, dict(parse_case_args(g), graph_inner_loop=-1))
+        system = build_system(model, dict(parse_case_args(g), graph_inner_loop=-1, task_streams=-1))
         calls = []
         orig = system._lockstep_body
         system._lockstep_body = lambda *a, **k: (calls.append(len(a[1])), orig(*a, **k))[1]
