@@ -27,6 +27,7 @@
  *   savfi_conv3x3_f32          F.conv2d 3x3 / stride 1 (+ bias, activation) and its data gradient
  *   savfi_conv3x3_wgrad_f32    its weight gradient                    model_utils.py:308-366 (MetaConv2dLayer.forward -> F.conv2d)
  *   savfi_conv3x3_tasks_f32, savfi_conv3x3_wgrad_tasks_f32   the same for T tasks with their own fast weights in ONE launch
+ *   savfi_conv3x3_filters_f32, savfi_conv3x3_tasks_pre_f32   filter transforms of forward + data gradient in one launch / convolution on a transformed filter
  *                              (the sequential task loop meta_learning_system.py:366 run in lockstep)
  *   savfi_frames_u8_to_f32     HWC uint8 frames -> normalised fp32 NCHW  data/vimeo_septuplet.py:68-80, data/video.py:44-51
  *   savfi_*_workspace_floats / savfi_bias_act_scratch_floats: sizes of the caller-owned scratch buffers (return int64_t)
@@ -50,7 +51,7 @@
 extern "C" {
 #endif
 
-#define SAVFI_ABI_VERSION 4
+#define SAVFI_ABI_VERSION 5
 
 #define SAVFI_OK            0
 #define SAVFI_E_NULL       (-1)  /* a required pointer is NULL                          */
@@ -252,6 +253,20 @@ int savfi_conv3x3_f32(const float* x, const float* w, const float* bias, float* 
 int64_t savfi_conv3x3_tasks_workspace_floats(int N, int T, int Ci, int Co, int H, int W, int pad, int mode);
 int savfi_conv3x3_tasks_f32(const float* x, const float* w, const float* bias, float* out, float* workspace,
                             int N, int T, int Ci, int Co, int H, int W, int pad, int mode, float slope, void* stream);
+
+/* The two halves of savfi_conv3x3_tasks_f32, for a training step that runs the forward pass AND the data gradient on the
+ * same filters (F.conv2d and its autograd backward, model_utils.py:308-366): the Winograd transform of both uses in ONE
+ * launch, and the convolution on an already transformed filter.
+ *   savfi_conv3x3_filters_f32      u_fwd / u_bwd (either may be NULL): the mode-0 / mode-1 transform of w [T,Co,Ci,3,3],
+ *                                  savfi_conv3x3_filter_floats(T, Ci, Co, mode) floats each
+ *   savfi_conv3x3_tasks_pre_f32    savfi_conv3x3_tasks_f32 with `u` (of the same mode) in place of w; `workspace`:
+ *                                  savfi_conv3x3_tasks_pre_workspace_floats(...) floats (partial outputs of split
+ *                                  launches; 0 for most shapes, then it may be NULL) */
+int64_t savfi_conv3x3_filter_floats(int T, int Ci, int Co, int mode);
+int savfi_conv3x3_filters_f32(const float* w, float* u_fwd, float* u_bwd, int T, int Ci, int Co, void* stream);
+int64_t savfi_conv3x3_tasks_pre_workspace_floats(int N, int T, int Ci, int Co, int H, int W, int pad, int mode);
+int savfi_conv3x3_tasks_pre_f32(const float* x, const float* u, const float* bias, float* out, float* workspace,
+                                int N, int T, int Ci, int Co, int H, int W, int pad, int mode, float slope, void* stream);
 
 /* Weight gradient of the same convolution (zero padding `pad` in {0,1}), NCHW in and out, deterministic:
  *   gw[Co,Ci,3,3] = sum over n,y,x of gz[n,co,y,x] * x[n,ci,y+a-pad,x+b-pad]      x [N,Ci,H,W], gz [N,Co,H+2pad-2,W+2pad-2]

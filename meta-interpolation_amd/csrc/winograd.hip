@@ -65,15 +65,15 @@ constexpr int LDS_FLOATS = (2 * VBUF > XBUF) ? 2 * VBUF : XBUF;
 // mode 0 (forward):        g[a][b] = w[i][k][a][b]           (w is [Co][Ci][3][3]; i = co, k = ci)
 // mode 1 (data gradient):  g[a][b] = w[k][i][2-a][2-b]       (i = ci, k = co)
 // Filter set `task` (tasks adapted in lockstep own their weights): w + task * Co*Ci*9 -> U + task * 16*KP*IP.
-__global__ __launch_bounds__(256) void wino_filter_transform(const float* __restrict__ w, float* __restrict__ U,
-                                                             int Co, int Ci, int K, int I, int KP, int IP, int mode) {
+__device__ __forceinline__ void filter_transform_block(const float* __restrict__ w, float* __restrict__ U, int Co, int Ci, int K,
+                                                       int I, int KP, int IP, int mode, int bx, int by) {
   // One workgroup = 4 reduction channels (one MFMA k-step) x 64 produced channels: it fills two whole
   // [4 rows][64 lanes][8 floats] fragment blocks (16 KB) of U by itself -- full cache lines leave the CU, where a
   // k-major thread numbering made every 2 KB block the target of four workgroups' partial writes -- and its reads of a
   // forward filter (mode 0: w[i][k][3][3]) are runs of 4 channels = 144 contiguous bytes per lane quad.
   const int kk = threadIdx.x & 3, ii = threadIdx.x >> 2;
-  const int k = 4 * blockIdx.x + kk, i = 64 * (blockIdx.y % ((IP + 63) / 64)) + ii;
-  const int task = blockIdx.y / ((IP + 63) / 64);
+  const int k = 4 * bx + kk, i = 64 * (by % ((IP + 63) / 64)) + ii;
+  const int task = by / ((IP + 63) / 64);
   if (i >= IP) return;
   w += (size_t)task * Co * Ci * 9;
   U += (size_t)task * 16 * KP * IP;
@@ -106,6 +106,23 @@ __global__ __launch_bounds__(256) void wino_filter_transform(const float* __rest
     o[4] = 0.5f * (t[r][0] - t[r][1] + t[r][2]);
     o[6] = t[r][2];
   }
+}
+
+__global__ __launch_bounds__(256) void wino_filter_transform(const float* __restrict__ w, float* __restrict__ U,
+                                                             int Co, int Ci, int K, int I, int KP, int IP, int mode) {
+  filter_transform_block(w, U, Co, Ci, K, I, KP, IP, mode, blockIdx.x, blockIdx.y);
+}
+
+// Both transforms of a layer in ONE launch (blockIdx.z = mode): the forward pass of a training step knows that the data
+// gradient will need the flipped / transposed filter, and a transform launch costs more than it computes (538 of them were
+// 5 % of a SepConv meta-iteration).  The grid covers the larger of the two block ranges; surplus blocks leave at once.
+__global__ __launch_bounds__(256) void wino_filter_transform_dual(const float* __restrict__ w, float* __restrict__ Uf,
+                                                                  float* __restrict__ Ub, int Co, int Ci, int KPf, int IPf,
+                                                                  int KPb, int IPb, int T) {
+  const int mode = blockIdx.z;
+  const int KP = mode == 0 ? KPf : KPb, IP = mode == 0 ? IPf : IPb;
+  if ((int)blockIdx.x >= KP / 4 || (int)blockIdx.y >= ((IP + 63) / 64) * T) return;
+  filter_transform_block(w, mode == 0 ? Uf : Ub, Co, Ci, mode == 0 ? Ci : Co, mode == 0 ? Co : Ci, KP, IP, mode, blockIdx.x, blockIdx.y);
 }
 
 // ---- fused convolution -------------------------------------------------------------------------------------
@@ -588,26 +605,16 @@ extern "C" int64_t savfi_conv3x3_workspace_floats(int N, int Ci, int Co, int H, 
   return savfi_conv3x3_tasks_workspace_floats(N, 1, Ci, Co, H, W, pad, mode);
 }
 
-// mode 0: out[n][co] = act(conv2d(x[n], w[n % T], zero padding `pad`)[co] + bias[n % T][co])   x [N][Ci][H][W] -> [N][Co][H+2pad-2][W+2pad-2]
-// mode 1: its data gradient: x = gy [N][Co][H][W] -> out = gx [N][Ci][H+2-2pad][W+2-2pad]
-extern "C" int savfi_conv3x3_tasks_f32(const float* x, const float* w, const float* bias, float* out, float* workspace,
-                                       int N, int T, int Ci, int Co, int H, int W, int pad, int mode, float slope, void* stream) {
-  if (!x || !w || !out || !workspace) return SAVFI_E_NULL;
-  if (N <= 0 || T <= 0 || N % T != 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return SAVFI_E_SHAPE;
-  if ((mode != 0 && mode != 1) || (pad != 0 && pad != 1) || (int64_t)H * W < 4) return SAVFI_E_UNSUPPORTED;   // rows are 16-byte loads
-  WinoPlan p;
-  if (!make_plan(p, N, Ci, Co, H, W, pad, mode)) return SAVFI_E_SHAPE;
-  if ((int64_t)H * W >= ((int64_t)1 << 29)) return SAVFI_E_TOOBIG;     // 32-bit byte offsets inside a channel plane
+namespace {
+
+// launches wino_conv3x3 (+ the split reduction) on an already transformed filter U [T][16 * KP * IP]
+int launch_conv(const WinoPlan& p, const float* x, const float* U, const float* bias, float* out, float* partial, int N, int T,
+                int H, int W, int mode, float slope, hipStream_t st) {
   const int64_t wgs = (int64_t)p.th * p.tw * (p.IP / COB) * p.nsplit * N;
   if (wgs > 0x7fffffffLL || T > 65535) return SAVFI_E_TOOBIG;
-  hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(wino_filter_transform, dim3(p.KP / 4, savfi_cdiv(p.IP, 64) * T), dim3(256), 0, st, w, workspace, Co, Ci, p.K,
-                     p.I, p.KP, p.IP, mode);
-  if (int e = savfi_launch_status()) return e;
   constexpr size_t lds = (size_t)LDS_FLOATS * sizeof(float);      // 40 KB: two workgroups per CU
   const float* b = mode == 0 ? bias : nullptr;
-  float* partial = workspace + (int64_t)T * p.u_floats;
-  WinoArgs a{x, workspace, b, out, p.K, p.I, p.KP, p.IP, H, W, p.Ho, p.Wo, p.off, p.th, p.tw, slope, p.tile_shift, p.nsplit,
+  WinoArgs a{x, U, b, out, p.K, p.I, p.KP, p.IP, H, W, p.Ho, p.Wo, p.off, p.th, p.tw, slope, p.tile_shift, p.nsplit,
              p.chunks_per_split, partial, T, N
 #ifdef WINO_TRACE
              , savfi_wino_trace_buffer((size_t)wgs)
@@ -623,6 +630,72 @@ extern "C" int savfi_conv3x3_tasks_f32(const float* x, const float* w, const flo
     return savfi_launch_status();
   }
   return SAVFI_OK;
+}
+
+int check_conv_args(WinoPlan& p, int N, int T, int Ci, int Co, int H, int W, int pad, int mode) {
+  if (N <= 0 || T <= 0 || N % T != 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return SAVFI_E_SHAPE;
+  if ((mode != 0 && mode != 1) || (pad != 0 && pad != 1) || (int64_t)H * W < 4) return SAVFI_E_UNSUPPORTED;   // rows are 16-byte loads
+  if (!make_plan(p, N, Ci, Co, H, W, pad, mode)) return SAVFI_E_SHAPE;
+  if ((int64_t)H * W >= ((int64_t)1 << 29)) return SAVFI_E_TOOBIG;     // 32-bit byte offsets inside a channel plane
+  return SAVFI_OK;
+}
+
+}  // namespace
+
+// mode 0: out[n][co] = act(conv2d(x[n], w[n % T], zero padding `pad`)[co] + bias[n % T][co])   x [N][Ci][H][W] -> [N][Co][H+2pad-2][W+2pad-2]
+// mode 1: its data gradient: x = gy [N][Co][H][W] -> out = gx [N][Ci][H+2-2pad][W+2-2pad]
+extern "C" int savfi_conv3x3_tasks_f32(const float* x, const float* w, const float* bias, float* out, float* workspace,
+                                       int N, int T, int Ci, int Co, int H, int W, int pad, int mode, float slope, void* stream) {
+  if (!x || !w || !out || !workspace) return SAVFI_E_NULL;
+  WinoPlan p;
+  if (int e = check_conv_args(p, N, T, Ci, Co, H, W, pad, mode)) return e;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(wino_filter_transform, dim3(p.KP / 4, savfi_cdiv(p.IP, 64) * T), dim3(256), 0, st, w, workspace, Co, Ci, p.K,
+                     p.I, p.KP, p.IP, mode);
+  if (int e = savfi_launch_status()) return e;
+  return launch_conv(p, x, workspace, bias, out, workspace + (int64_t)T * p.u_floats, N, T, H, W, mode, slope, st);
+}
+
+// The two halves of savfi_conv3x3_tasks_f32 for a caller that runs forward AND data gradient on the same filters (a training
+// step): savfi_conv3x3_filters_f32 writes the forward filter transform to u_fwd and / or the data-gradient one to u_bwd (either
+// may be NULL; savfi_conv3x3_filter_floats(T, Ci, Co, mode) floats each) in ONE launch, savfi_conv3x3_tasks_pre_f32 convolves
+// with an already transformed filter (workspace: savfi_conv3x3_tasks_workspace_floats minus the filter, i.e.
+// savfi_conv3x3_tasks_pre_workspace_floats, possibly 0 -> may be NULL).
+extern "C" int64_t savfi_conv3x3_filter_floats(int T, int Ci, int Co, int mode) {
+  if (T <= 0 || Ci <= 0 || Co <= 0 || (mode != 0 && mode != 1)) return SAVFI_E_SHAPE;
+  const int K = mode == 0 ? Ci : Co, I = mode == 0 ? Co : Ci;
+  return (int64_t)T * 16 * round_up(K, 2 * CIB) * round_up(I, COB);
+}
+
+extern "C" int savfi_conv3x3_filters_f32(const float* w, float* u_fwd, float* u_bwd, int T, int Ci, int Co, void* stream) {
+  if (!w || (!u_fwd && !u_bwd)) return SAVFI_E_NULL;
+  if (T <= 0 || T > 65535 || Ci <= 0 || Co <= 0) return SAVFI_E_SHAPE;
+  const int KPf = round_up(Ci, 2 * CIB), IPf = round_up(Co, COB), KPb = round_up(Co, 2 * CIB), IPb = round_up(Ci, COB);
+  hipStream_t st = (hipStream_t)stream;
+  if (u_fwd && u_bwd) {
+    const int gx = (KPf > KPb ? KPf : KPb) / 4, gy = savfi_cdiv(IPf > IPb ? IPf : IPb, 64) * T;
+    hipLaunchKernelGGL(wino_filter_transform_dual, dim3(gx, gy, 2), dim3(256), 0, st, w, u_fwd, u_bwd, Co, Ci, KPf, IPf, KPb, IPb, T);
+  } else if (u_fwd) {
+    hipLaunchKernelGGL(wino_filter_transform, dim3(KPf / 4, savfi_cdiv(IPf, 64) * T), dim3(256), 0, st, w, u_fwd, Co, Ci, Ci, Co, KPf, IPf, 0);
+  } else {
+    hipLaunchKernelGGL(wino_filter_transform, dim3(KPb / 4, savfi_cdiv(IPb, 64) * T), dim3(256), 0, st, w, u_bwd, Co, Ci, Co, Ci, KPb, IPb, 1);
+  }
+  return savfi_launch_status();
+}
+
+extern "C" int64_t savfi_conv3x3_tasks_pre_workspace_floats(int N, int T, int Ci, int Co, int H, int W, int pad, int mode) {
+  WinoPlan p;
+  if (int e = check_conv_args(p, N, T, Ci, Co, H, W, pad, mode)) return e;
+  return p.partial_floats;
+}
+
+extern "C" int savfi_conv3x3_tasks_pre_f32(const float* x, const float* u, const float* bias, float* out, float* workspace,
+                                           int N, int T, int Ci, int Co, int H, int W, int pad, int mode, float slope, void* stream) {
+  if (!x || !u || !out) return SAVFI_E_NULL;
+  WinoPlan p;
+  if (int e = check_conv_args(p, N, T, Ci, Co, H, W, pad, mode)) return e;
+  if (p.partial_floats > 0 && !workspace) return SAVFI_E_NULL;
+  return launch_conv(p, x, u, bias, out, workspace, N, T, H, W, mode, slope, (hipStream_t)stream);
 }
 
 extern "C" int savfi_conv3x3_f32(const float* x, const float* w, const float* bias, float* out, float* workspace,

@@ -570,8 +570,11 @@ class _ConvBiasAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, stride, padding, dilation, groups, slope):
         pad = padding if isinstance(padding, int) else padding[0]
+        ctx.u_bwd = None
         if conv3x3_eligible(x, w, stride, padding, dilation, groups):
-            z = conv3x3(x, w, b, 0, slope, pad)
+            want_bwd = ctx.needs_input_grad[0] and conv3x3_eligible(x, w, stride, padding, dilation, groups, backward=True)
+            u_fwd, ctx.u_bwd = conv3x3_filters(w, True, want_bwd)
+            z = conv3x3_tasks_pre(x, u_fwd, 1, w.shape[1], w.shape[0], b, 0, slope, pad)
         else:
             z = torch.nn.functional.conv2d(x, w, None, stride, padding, dilation, groups)
             if not z.is_contiguous():
@@ -608,7 +611,11 @@ class _ConvBiasAct(torch.autograd.Function):
         gx = gw = None
         pad = padding if isinstance(padding, int) else padding[0]
         if need_x and conv3x3_eligible(x, w, stride, padding, dilation, groups, backward=True):
-            gx = conv3x3(gz, w, None, 1, 1.0, pad)
+            if ctx.u_bwd is not None:
+                gx = conv3x3_tasks_pre(gz, ctx.u_bwd, 1, w.shape[1], w.shape[0], None, 1, 1.0, pad)
+                ctx.u_bwd = None
+            else:
+                gx = conv3x3(gz, w, None, 1, 1.0, pad)
             need_x = False
         pair = lambda v: [v, v] if isinstance(v, int) else list(v)
         side = ctx.wg_stream if (ctx.wg_stream is not None and ctx.wg_uses[0] == 1) else None
@@ -701,6 +708,40 @@ def conv3x3_tasks(x, weight, bias=None, mode=0, slope=1.0, pad=1):
     return out
 
 
+def conv3x3_filters(weight, fwd=True, bwd=True):
+    """savfi_conv3x3_filters_f32: the Winograd transforms of weight [T,Co,Ci,3,3] (or [Co,Ci,3,3]) for the forward pass and / or
+    the data gradient, in ONE launch.  Returns (u_fwd, u_bwd); an entry is None when not asked for."""
+    weight = weight.contiguous()
+    _hip.require_cuda(weight)
+    T, Co, Ci = (1,) + tuple(weight.shape[:2]) if weight.dim() == 4 else tuple(weight.shape[:3])
+    assert tuple(weight.shape[-2:]) == (3, 3) and (fwd or bwd), weight.shape
+    lib = _hip.lib()
+    us = [torch.empty(_workspace_floats("savfi_conv3x3_filter_floats", T, Ci, Co, mode), dtype=weight.dtype, device=weight.device) if want else None
+          for mode, want in ((0, fwd), (1, bwd))]
+    _hip.launch("conv3x3_filters", lambda: _hip.check(lib.savfi_conv3x3_filters_f32(
+        weight.data_ptr(), None if us[0] is None else us[0].data_ptr(), None if us[1] is None else us[1].data_ptr(), T, Ci, Co,
+        _hip.current_stream()), "savfi_conv3x3_filters_f32"))
+    return us[0], us[1]
+
+
+def conv3x3_tasks_pre(x, u, T, Ci, Co, bias=None, mode=0, slope=1.0, pad=1):
+    """savfi_conv3x3_tasks_pre_f32: conv3x3_tasks on a filter already transformed by conv3x3_filters (same mode)."""
+    x = x.contiguous()
+    _hip.require_cuda(x, u)
+    N, _, H, W = x.shape
+    assert N % T == 0 and x.shape[1] == (Ci if mode == 0 else Co), (x.shape, T, Ci, Co, mode)
+    I = Co if mode == 0 else Ci
+    grow = 2 * (pad if mode == 0 else 2 - pad) - 2
+    lib = _hip.lib()
+    nws = _workspace_floats("savfi_conv3x3_tasks_pre_workspace_floats", N, T, Ci, Co, H, W, int(pad), mode)
+    ws = torch.empty(nws, dtype=x.dtype, device=x.device) if nws else None
+    out = torch.empty((N, I, H + grow, W + grow), dtype=x.dtype, device=x.device)
+    _hip.launch("conv3x3_fwd" if mode == 0 else "conv3x3_bwd_data", lambda: _hip.check(lib.savfi_conv3x3_tasks_pre_f32(
+        x.data_ptr(), u.data_ptr(), None if bias is None else bias.data_ptr(), out.data_ptr(), None if ws is None else ws.data_ptr(),
+        N, T, Ci, Co, H, W, int(pad), mode, float(slope), _hip.current_stream()), "savfi_conv3x3_tasks_pre_f32"))
+    return out
+
+
 def conv3x3_wgrad_tasks(x, gz, T, pad=1, stream=None, extra_stream=None):
     """savfi_conv3x3_wgrad_tasks_f32: gw [T,Co,Ci,3,3], gw[t] over the samples n % T == t.  `stream` / `extra_stream`: as in
     conv3x3_wgrad (launch on a side stream, buffers from the current stream's pool)."""
@@ -756,8 +797,12 @@ class _ConvBiasActTasks(torch.autograd.Function):
         N, _, H, W = x.shape
         n = N // T
         pad = padding if isinstance(padding, int) else padding[0]
+        ctx.u_bwd = None
         if conv3x3_tasks_eligible(x, w, stride, padding, dilation):
-            z = conv3x3_tasks(x, w, b, 0, slope, pad)
+            # both filter transforms of this layer in one launch: the data gradient of the same step will want the other one
+            want_bwd = ctx.needs_input_grad[0] and conv3x3_tasks_eligible(x, w, stride, padding, dilation, backward=True)
+            u_fwd, ctx.u_bwd = conv3x3_filters(w, True, want_bwd)
+            z = conv3x3_tasks_pre(x, u_fwd, T, Ci, Co, b, 0, slope, pad)
         else:
             if _grouped_ok(x):
                 z = torch.nn.functional.conv2d(x.view(n, T * Ci, H, W), w.reshape(T * Co, Ci, *w.shape[3:]), None, stride, padding,
@@ -807,7 +852,11 @@ class _ConvBiasActTasks(torch.autograd.Function):
         gx = gw = None
         pad = padding if isinstance(padding, int) else padding[0]
         if need_x and conv3x3_tasks_eligible(x, w, stride, padding, dilation, backward=True):
-            gx = conv3x3_tasks(gz, w, None, 1, 1.0, pad)
+            if ctx.u_bwd is not None:
+                gx = conv3x3_tasks_pre(gz, ctx.u_bwd, T, Ci, Co, None, 1, 1.0, pad)
+                ctx.u_bwd = None
+            else:
+                gx = conv3x3_tasks(gz, w, None, 1, 1.0, pad)
             need_x = False
         if need_w and conv3x3_wgrad_tasks_eligible(x, w, stride, padding, dilation):
             side = ctx.wg_stream if (ctx.wg_stream is not None and ctx.wg_uses[0] == 1) else None

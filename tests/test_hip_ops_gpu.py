@@ -431,6 +431,26 @@ def test_conv3x3_data_gradient_matches_autograd(shape, pad):
     assert (got - want).abs().max() <= 2e-6 * want.abs().max()
 
 
+@pytest.mark.parametrize("T,N,Ci,Co,H,W,pad", [(1, 2, 6, 32, 24, 40, 1), (4, 8, 51, 51, 18, 30, 1), (2, 4, 64, 32, 16, 64, 0), (4, 8, 256, 256, 12, 16, 1)])
+def test_conv3x3_split_entry_points_equal_the_fused_one(T, N, Ci, Co, H, W, pad):
+    """savfi_conv3x3_filters_f32 (both transforms in one launch) + savfi_conv3x3_tasks_pre_f32 == savfi_conv3x3_tasks_f32,
+    bit for bit, forward and data gradient (the last shape splits its reduction channels: partial-output workspace)."""
+    g = torch.Generator().manual_seed(5)
+    w = (torch.randn(T, Co, Ci, 3, 3, generator=g) / (3 * Ci ** 0.5)).cuda()
+    b = torch.randn(T, Co, generator=g).cuda()
+    x = torch.randn(N, Ci, H, W, generator=g).cuda()
+    want = hip_ops.conv3x3_tasks(x, w, b, 0, 0.2, pad)
+    gy = torch.randn(want.shape, generator=g).cuda()
+    want_gx = hip_ops.conv3x3_tasks(gy, w, None, 1, 1.0, pad)
+    for fwd, bwd in ((True, True), (True, False), (False, True)):
+        u_f, u_b = hip_ops.conv3x3_filters(w, fwd, bwd)
+        assert (u_f is None) == (not fwd) and (u_b is None) == (not bwd)
+        if fwd:
+            assert torch.equal(hip_ops.conv3x3_tasks_pre(x, u_f, T, Ci, Co, b, 0, 0.2, pad), want)
+        if bwd:
+            assert torch.equal(hip_ops.conv3x3_tasks_pre(gy, u_b, T, Ci, Co, None, 1, 1.0, pad), want_gx)
+
+
 def test_sepconv_with_winograd_convs_equals_miopen_convs():
     """BASELINE config-2 frame size: the backbone's large 3x3 convolutions on savfi_conv3x3_f32 (forward with fused
     bias + ReLU, data gradient) and savfi_conv3x3_wgrad_f32 give the network output and every parameter gradient of the MIOpen path.
@@ -445,18 +465,18 @@ def test_sepconv_with_winograd_convs_equals_miopen_convs():
     res = []
     mu.set_fuse_conv_act(True)
     calls = []
-    orig = hip_ops.conv3x3
+    orig = hip_ops.conv3x3_tasks_pre
     try:
         for wino in (False, True):
             hip_ops.WINOGRAD_CONV = wino
-            hip_ops.conv3x3 = (lambda *a, **k: (calls.append(a[3] if len(a) > 3 else k.get('mode', 0)), orig(*a, **k))[1])
+            hip_ops.conv3x3_tasks_pre = (lambda *a, **k: (calls.append(a[6] if len(a) > 6 else k.get('mode', 0)), orig(*a, **k))[1])
             out = net(f0, f1)
             loss = ((out - tgt) ** 2).mean()
             res.append((out.detach(), torch.autograd.grad(loss, list(net.parameters()))))
     finally:
         mu.set_fuse_conv_act(False)
         hip_ops.WINOGRAD_CONV = True
-        hip_ops.conv3x3 = orig
+        hip_ops.conv3x3_tasks_pre = orig
     assert calls.count(0) >= 20 and calls.count(1) >= 8, calls          # forward and data-gradient launches happened
     (o_mi, g_mi), (o_wi, g_wi) = res
     assert (o_wi - o_mi).abs().max() < 5e-6
