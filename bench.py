@@ -46,6 +46,9 @@ WORKLOADS = {
     'c3_voxelflow_metasgd_256x256_b8_s5': ('voxelflow', 256, 256, 8, 5,
                                            dict(optimizer='Adamax', metasgd=True, loss='1*MSE', inner_lr=1e-5)),
     'c1_cain_64x64_b1_s1': ('cain', 64, 64, 1, 1, dict(optimizer='SGD', loss='1*L1', inner_lr=1e-5)),
+    # one GPU's share of BASELINE config 4 (meta-batch 32 over 8 GPUs): MAML++ multi-step loss = a target pass after every step
+    'c4_sepconv_msl_256x448_b4_s5': ('sepconv', 256, 448, 4, 5, dict(optimizer='SGD', loss='1*L1', inner_lr=1e-5,
+                                                                       use_multi_step_loss_optimization=True)),
     # same launch sequence as C2 on tiny frames: wall time ~= the host-side floor of one C2 meta-iteration
     'c2_host_floor_64x64_b4_s5': ('sepconv', 64, 64, 4, 5, dict(optimizer='SGD', loss='1*L1', inner_lr=1e-5)),
     # SURVEY 8(f) rank 4 plugins (no BASELINE.json config names them: extra lines, same metric)

@@ -13,7 +13,7 @@ python tools/hbm_traffic.py parse /tmp/pmc_f /tmp/pmc_w > gpurun_out/art/r02_hbm
 python tools/kernel_bench.py --batches 1,2,4,8 > gpurun_out/art/r02_kernel_bench.jsonl 2>/dev/null
 python tools/tasks_bench.py > gpurun_out/art/r02_tasks_bench.jsonl 2>/dev/null
 python tools/parity_report.py > gpurun_out/art/r02_parity_report.jsonl 2>/dev/null
-for w in c3_voxelflow_metasgd_256x256_b8_s5 c5_cain_l2f_720p_b1_s1 c1_cain_64x64_b1_s1 rrin_256x448_b4_s5 superslomo_256x448_b4_s5; do python bench.py --workload $w --steps 3 --warmup 2 --no-cpu-baseline 2>/dev/null >> gpurun_out/art/r02_other_configs.jsonl; done
+for w in c3_voxelflow_metasgd_256x256_b8_s5 c4_sepconv_msl_256x448_b4_s5 c5_cain_l2f_720p_b1_s1 c1_cain_64x64_b1_s1 rrin_256x448_b4_s5 superslomo_256x448_b4_s5; do python bench.py --workload $w --steps 3 --warmup 2 --no-cpu-baseline 2>/dev/null >> gpurun_out/art/r02_other_configs.jsonl; done
 python bench.py --workload c1_cain_64x64_b1_s1 --steps 5 --warmup 2 --no-cpu-baseline --graph-inner-loop 0 2>/dev/null >> gpurun_out/art/r02_other_configs.jsonl
 python bench.py --workload c3_voxelflow_metasgd_256x256_b8_s5 --steps 3 --warmup 2 --no-cpu-baseline --graph-inner-loop 1 --task-streams 4 2>/dev/null >> gpurun_out/art/r02_other_configs.jsonl
 cd /tmp; rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_c3 -- python $R/bench.py --workload c3_voxelflow_metasgd_256x256_b8_s5 --steps 3 --warmup 2 --no-cpu-baseline --graph-inner-loop 0 > /dev/null 2>&1; python $R/tools/gap_report.py /tmp/prof_c3 0 > $R/gpurun_out/art/r02_c3_voxelflow_one_iteration.txt 2>&1; cd $R
