@@ -461,16 +461,17 @@ def mse_loss_per_sample(a, b):
 # --------------------------------------------------------------------------------------------
 # conv + bias + (leaky) ReLU with fused epilogues   (sepconv/model.py:172-194, model_utils.py:957-990)
 # --------------------------------------------------------------------------------------------
-# 3x3 / stride 1 convolutions with many output tiles run on savfi_conv3x3_f32 (Winograd on the fp32 matrix cores,
-# bias + activation in its epilogue); tiles = N * ceil(Ho/2) * ceil(Wo/2).  Thresholds from tools/conv_bench.py
-# (profiles/r01_conv_bench.jsonl): above them the kernel is 1.2-1.6x faster than MIOpen.  With the reduction-channel
-# split it is also on par or slightly ahead for the N=2 deep layers (down to 24x32), but routing those through it did
-# not move the meta-iteration (87.2 vs 86.8 steps/s: two more small launches per call), so they stay on MIOpen.
+# 3x3 / stride 1 convolutions run on savfi_conv3x3_f32 (Winograd on the fp32 matrix cores, bias + activation in its
+# epilogue) wherever it beats MIOpen; tiles = N * ceil(Ho/2) * ceil(Wo/2).  Thresholds from tools/conv_bench.py with the
+# late round-2 kernel (profiles/r02_conv_bench.jsonl: filter transform included): at N >= 2 it is 1.15-2.1x faster forward and
+# 1.1-1.9x for the data gradient on every layer shape of the four plugins down to 24x32 maps (12x16 / 16x16 stay on MIOpen:
+# forward 1.27x, data gradient 0.87x, on ~40 us kernels); at N = 1 it wins from 48x64 maps up (1.05-1.9x) and loses on 24x32 (0.86-1.04x).  (Round 1 needed 6000-
+# 20000 tiles: the corner-tile tail and the output stage's store stalls, DESIGN.md 4b, weighed most on small maps.)
 WINOGRAD_CONV = not os.environ.get('SAVFI_NO_WINOGRAD')
-WINO_MIN_TILES_FWD = 12000
-WINO_MIN_TILES_BWD = 20000
-WINO_MIN_TILES_FWD_BATCHED = 6000     # N >= 2 (support pairs): the 96x128 layers, 1.17-1.19x, same launch count as MIOpen + epilogue
-WINO_MIN_TILES_BWD_BATCHED = 20000
+WINO_MIN_TILES_FWD = 700
+WINO_MIN_TILES_BWD = 700
+WINO_MIN_TILES_FWD_BATCHED = 150      # N >= 2 (support pairs, lockstep batches of shared weights): 24x32 maps and up
+WINO_MIN_TILES_BWD_BATCHED = 200
 if os.environ.get('SAVFI_WINO_TILES'):      # experiment knob: "fwd,bwd,fwd_batched,bwd_batched"
     WINO_MIN_TILES_FWD, WINO_MIN_TILES_BWD, WINO_MIN_TILES_FWD_BATCHED, WINO_MIN_TILES_BWD_BATCHED = (
         int(t) for t in os.environ['SAVFI_WINO_TILES'].split(','))

@@ -287,12 +287,13 @@ def test_meta_sequential_fuses_conv_relu_pairs_and_matches_reference_modules():
     finally:
         hip_ops.conv_bias_act = orig
         mu.set_fuse_conv_act(False)
-    assert len(calls) == 2                                    # two conv+ReLU pairs fused, the last conv is plain
-    y0 = seq(x, params=fast)
+    # two conv+ReLU pairs fused; the last conv (bias, no activation) also takes the fused op: 2 x 20 x 24 tiles >= WINO_MIN_TILES_FWD_BATCHED
+    assert len(calls) == 3
+    y0 = seq(x, params=fast)                                  # unfused: MIOpen convolutions, separate activations
     g0 = torch.autograd.grad(y0.square().mean(), list(fast.values()))
-    assert _rel(y, y0) < 1e-6
+    assert _rel(y, y0) < 5e-6                                 # Winograd rounding: <= 2e-7 of the output scale per layer
     for a, b in zip(gf, g0):
-        assert _rel(a, b) < 1e-5
+        assert _rel(a, b) < 2e-5
 
 
 @pytest.mark.parametrize("align", [True, False])
