@@ -1069,6 +1069,13 @@ int device_cu_count() {
 }
 
 // whole-tensor buffer resources: every tensor must stay below 2^31 bytes
+// the MFMA kernels address one sample's tap planes / output planes through raw buffer descriptors: offsets, and the
+// out-of-range marker SC_OOR, need the sample to stay below 2^31 bytes (K = 51: frames up to 10.5 Mpixel); larger ones take
+// the generic kernels
+bool mfma_fits(int Ho, int Wo) {
+  return (int64_t)KFAST * Ho * Wo * 4 < ((int64_t)1 << 31);
+}
+
 bool persistent_ok(int B, int Ho, int Wo) {
   const int64_t taps = (int64_t)B * KFAST * Ho * Wo * 4, win = (int64_t)B * 3 * (Ho + KFAST - 1) * (Wo + KFAST - 1) * 4;
   return taps < ((int64_t)1 << 31) && win < ((int64_t)1 << 31);
@@ -1113,7 +1120,7 @@ extern "C" int savfi_sepconv_fwd_f32(const float* in, const float* v, const floa
   if (!in || !v || !h || !out) return SAVFI_E_NULL;
   if (int e = check_dims(B, C, Ho, Wo, K)) return e;
   hipStream_t st = (hipStream_t)stream;
-  if (K == KFAST && C == 3 && !sepconv_env().no_mfma) {
+  if (K == KFAST && C == 3 && !sepconv_env().no_mfma && mfma_fits(Ho, Wo)) {
     switch (mfma_rows(B, Ho, Wo)) {
       case 8: return launch_fwd_mfma<8>(in, v, h, out, B, Ho, Wo, st);
       case 16: return launch_fwd_mfma<16>(in, v, h, out, B, Ho, Wo, st);
@@ -1135,7 +1142,7 @@ extern "C" int savfi_sepconv_bwd_f32(const float* in, const float* v, const floa
   if (gV || gH) {
     if (K == KFAST && C == 3 && !sepconv_env().no_mfma && !sepconv_env().tiled && persistent_ok(B, Ho, Wo)) {
       if (int e = launch_bwd_persistent(in, v, h, gO, gV, gH, B, Ho, Wo, st)) return e;
-    } else if (K == KFAST && C == 3 && !sepconv_env().no_mfma) {
+    } else if (K == KFAST && C == 3 && !sepconv_env().no_mfma && mfma_fits(Ho, Wo)) {
       int e;
       switch (mfma_rows(B, Ho, Wo)) {
         case 8: e = launch_bwd_mfma<8>(in, v, h, gO, gV, gH, B, Ho, Wo, st); break;

@@ -636,7 +636,8 @@ int check_conv_args(WinoPlan& p, int N, int T, int Ci, int Co, int H, int W, int
   if (N <= 0 || T <= 0 || N % T != 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return SAVFI_E_SHAPE;
   if ((mode != 0 && mode != 1) || (pad != 0 && pad != 1) || (int64_t)H * W < 4) return SAVFI_E_UNSUPPORTED;   // rows are 16-byte loads
   if (!make_plan(p, N, Ci, Co, H, W, pad, mode)) return SAVFI_E_SHAPE;
-  if ((int64_t)H * W >= ((int64_t)1 << 29)) return SAVFI_E_TOOBIG;     // 32-bit byte offsets inside a channel plane
+  // 32-bit byte offsets inside a channel plane, and 0x80000000 must lie beyond the input and the output plane
+  if ((int64_t)H * W >= ((int64_t)1 << 29) || (int64_t)p.Ho * p.Wo >= ((int64_t)1 << 29)) return SAVFI_E_TOOBIG;
   return SAVFI_OK;
 }
 

@@ -9,16 +9,17 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from meta_interpolation_amd import hip_ops  # noqa: E402
-from tools.conv_bench import LAYERS, timeit  # noqa: E402
+from tools.conv_bench import EXTRA, LAYERS, timeit  # noqa: E402
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--n", type=int, default=2)
+    ap.add_argument("--set", default="sepconv", choices=["sepconv"] + sorted(EXTRA))
     o = ap.parse_args()
     dev = torch.device("cuda")
-    for (ci, co, h, w) in LAYERS:
+    for (ci, co, h, w) in (LAYERS if o.set == "sepconv" else EXTRA[o.set]):
         x = torch.randn(o.n, ci, h, w, device=dev)
         wt = torch.randn(co, ci, 3, 3, device=dev)
         gy = torch.randn(o.n, co, h, w, device=dev)
