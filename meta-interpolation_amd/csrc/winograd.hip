@@ -272,18 +272,16 @@ __device__ __forceinline__ void chunk_body(f32x4 (&acc)[4][2][4], f32x4 (&afr)[2
                                            float (&d)[16], const Patch& patch, int fixup, int tbw, const LaneMasks& lm,
                                            float* __restrict__ vnext,
                                            const float* __restrict__ plane3, unsigned plane_bytes, const char* __restrict__ unext, unsigned ulane) {
-  float bfr[2][4], t[16];
-#pragma unroll
-  for (int tt = 0; tt < 4; ++tt) bfr[0][tt] = vcur[16 * tt];
+  f32x4 bfr[2];
+  float t[16];
+  bfr[0] = *reinterpret_cast<const f32x4*>(vcur);
   if (fixup & 6) fix_corner(d, fixup >> 1, tbw);     // wave-uniform branches
   if (fixup & 1) mask_patch(d, lm);
 #pragma unroll
   for (int g = 0; g < 8; ++g) {
     const int c = g >> 1, cb = g & 1, cur = c & 1;       // xi column, channel block
     if (cb == 0 && c < 3) {   // B fragments of the next xi
-#pragma unroll
-      for (int tt = 0; tt < 4; ++tt)
-        bfr[cur ^ 1][tt] = vcur[(c + 1) * CIB * VS + 16 * tt];
+      bfr[cur ^ 1] = *reinterpret_cast<const f32x4*>(vcur + (c + 1) * CIB * VS);
     }
     const float a = afr[c >> 1][2 * (c & 1) + cb];
 #pragma unroll
@@ -403,7 +401,7 @@ __global__ __launch_bounds__(WNT, 2) void wino_conv3x3(WinoArgs a) {
     if (fixup & 6) fix_corner(dA, fixup >> 1, tbw);
     if (fixup & 1) mask_patch(dA, lm);
     input_transform(v, dA);
-    float* vb = lds + w * VS + lane;
+    float* vb = lds + w * VS + 4 * (lane & 15) + (lane >> 4);       // = vwoff below: [k = w][j][t]
 #pragma unroll
     for (int xi = 0; xi < 16; ++xi) vb[xi * CIB * VS] = v[xi];
   }
@@ -417,8 +415,10 @@ __global__ __launch_bounds__(WNT, 2) void wino_conv3x3(WinoArgs a) {
   const unsigned long long tr1 = __builtin_amdgcn_s_memrealtime();
 #endif
 
-  const int vwoff = w * VS + lane;                    // V write: [xi][k = w][tile = lane]
-  const int vroff = (4 * w) * CIB * VS + kg * VS + j; // V read:  [xi = 4w + c][k = kg][tile = 16 t + j]
+  // V[xi][k][j][t] for tile 16 t + j: a lane's four B fragments (t = 0..3) of one (xi, k) are ONE ds_read_b128; the 64 lanes of
+  // a writing wave still cover the 64 dwords of a row exactly once (4 j + t is a permutation): no bank conflicts either way
+  const int vwoff = w * VS + 4 * (lane & 15) + (lane >> 4);   // V write: [xi][k = w][j = lane % 16][t = lane / 16]
+  const int vroff = (4 * w) * CIB * VS + kg * VS + 4 * j;      // V read:  [xi = 4w + c][k = kg][j][t = 0..3]
   for (int ch = cbeg; ch < nchunk; ch += 2) {
     // even chunk: MFMAs on V(0) with A(ch); transforms P(ch+1) = dB -> V(1); reloads dB <- P(ch+3), afrA <- A(ch+2)
     chunk_body(acc, afrA, lds + vroff, dB, patch, fixup, tbw, lm, lds + VBUF + vwoff,
