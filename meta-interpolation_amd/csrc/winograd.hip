@@ -271,7 +271,7 @@ __device__ __forceinline__ void input_transform(float (&v)[16], const float (&d)
 __device__ __forceinline__ void chunk_body(f32x4 (&acc)[4][2][4], f32x4 (&afr)[2], const float* __restrict__ vcur,
                                            float (&d)[16], const Patch& patch, int fixup, int tbw, const LaneMasks& lm,
                                            float* __restrict__ vnext,
-                                           const float* __restrict__ plane3, unsigned plane_bytes, const char* __restrict__ unext, unsigned ulane) {
+                                           const float* __restrict__ plane3, unsigned plane_bytes, i32x4 urs, unsigned unext, unsigned ulane) {
   f32x4 bfr[2];
   float t[16];
   bfr[0] = *reinterpret_cast<const f32x4*>(vcur);
@@ -301,8 +301,8 @@ __device__ __forceinline__ void chunk_body(f32x4 (&acc)[4][2][4], f32x4 (&afr)[2
       vnext[(r * 4 + 3) * CIB * VS] = t[r * 4 + 1] - t[r * 4 + 3];
     }
     if (g == 7) {
-      afr[0] = *reinterpret_cast<const f32x4*>(unext + ulane);
-      afr[1] = *reinterpret_cast<const f32x4*>(unext + ulane + 16);
+      afr[0] = savfi_raw_buffer_load_x4(urs, (int)ulane, (int)unext, 0);
+      afr[1] = savfi_raw_buffer_load_x4(urs, (int)ulane + 16, (int)unext, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -364,10 +364,14 @@ __global__ __launch_bounds__(WNT, 2) void wino_conv3x3(WinoArgs a) {
   // this workgroup reduces over chunks [cbeg, nchunk) of the KP / CIB chunks (an even count)
   const int cbeg = sp * a.chunks_per_split, nchunk = min(cbeg + a.chunks_per_split, a.KP / CIB);
   const size_t ustride = (size_t)nblk * 4 * 64 * 32;                                     // bytes per chunk
-  const char* ubase = reinterpret_cast<const char*>(a.U + (size_t)task * 16 * a.KP * a.IP) + ((size_t)cob * 4 + w) * 64 * 32;
+  // through a raw buffer descriptor over this task's U: a per-lane offset computed once and a wave-uniform byte offset per chunk
+  // (SALU) instead of a 64-bit per-lane address per load
+  const unsigned ubytes = 16u * (unsigned)a.KP * (unsigned)a.IP * 4u;
+  const i32x4 urs = plane_rsrc(a.U + (size_t)task * 16 * a.KP * a.IP, ubytes);
+  const unsigned ubase = ((unsigned)cob * 4u + (unsigned)w) * 64u * 32u;
   const unsigned ulane = (unsigned)lane * 32u;
   auto plane_of = [&](int chunk) { return xp + (size_t)min(min(chunk, nchunk - 1) * CIB + w, a.K - 1) * cplane; };
-  auto u_of = [&](int chunk) { return ubase + (size_t)min(chunk, nchunk - 1) * ustride; };
+  auto u_of = [&](int chunk) { return ubase + (unsigned)min(chunk, nchunk - 1) * (unsigned)ustride; };
 
   // fix-ups (wave-uniform): bit 0 = some column of some lane is outside the image; bits 1-2 = `off` in the workgroup that
   // owns tile (0, 0) of a padded map (its lane 0 holds the row that would start before the plane)
@@ -392,10 +396,10 @@ __global__ __launch_bounds__(WNT, 2) void wino_conv3x3(WinoArgs a) {
   f32x4 afrA[2], afrB[2];
   load_patch(dA, plane_of(cbeg), plane_bytes, patch);
   load_patch(dB, plane_of(cbeg + 1), plane_bytes, patch);
-  afrA[0] = *reinterpret_cast<const f32x4*>(u_of(cbeg) + ulane);
-  afrA[1] = *reinterpret_cast<const f32x4*>(u_of(cbeg) + ulane + 16);
-  afrB[0] = *reinterpret_cast<const f32x4*>(u_of(cbeg + 1) + ulane);
-  afrB[1] = *reinterpret_cast<const f32x4*>(u_of(cbeg + 1) + ulane + 16);
+  afrA[0] = savfi_raw_buffer_load_x4(urs, (int)ulane, (int)u_of(cbeg), 0);
+  afrA[1] = savfi_raw_buffer_load_x4(urs, (int)ulane + 16, (int)u_of(cbeg), 0);
+  afrB[0] = savfi_raw_buffer_load_x4(urs, (int)ulane, (int)u_of(cbeg + 1), 0);
+  afrB[1] = savfi_raw_buffer_load_x4(urs, (int)ulane + 16, (int)u_of(cbeg + 1), 0);
   {
     float v[16];
     if (fixup & 6) fix_corner(dA, fixup >> 1, tbw);
@@ -422,12 +426,12 @@ __global__ __launch_bounds__(WNT, 2) void wino_conv3x3(WinoArgs a) {
   for (int ch = cbeg; ch < nchunk; ch += 2) {
     // even chunk: MFMAs on V(0) with A(ch); transforms P(ch+1) = dB -> V(1); reloads dB <- P(ch+3), afrA <- A(ch+2)
     chunk_body(acc, afrA, lds + vroff, dB, patch, fixup, tbw, lm, lds + VBUF + vwoff,
-               plane_of(ch + 3), plane_bytes, u_of(ch + 2), ulane);
+               plane_of(ch + 3), plane_bytes, urs, u_of(ch + 2), ulane);
     __syncthreads();
     // nchunk is even (KP is a multiple of 2 * CIB): an `if (ch + 1 < nchunk)` here would make the compiler assume the
     // A fragments loaded at the end of the even chunk may be the youngest load in flight -> vmcnt(0) every iteration
     chunk_body(acc, afrB, lds + VBUF + vroff, dA, patch, fixup, tbw, lm, lds + vwoff,
-               plane_of(ch + 4), plane_bytes, u_of(ch + 3), ulane);
+               plane_of(ch + 4), plane_bytes, urs, u_of(ch + 3), ulane);
     __syncthreads();
   }
 
@@ -638,6 +642,7 @@ int check_conv_args(WinoPlan& p, int N, int T, int Ci, int Co, int H, int W, int
   if (!make_plan(p, N, Ci, Co, H, W, pad, mode)) return SAVFI_E_SHAPE;
   // 32-bit byte offsets inside a channel plane, and 0x80000000 must lie beyond the input and the output plane
   if ((int64_t)H * W >= ((int64_t)1 << 29) || (int64_t)p.Ho * p.Wo >= ((int64_t)1 << 29)) return SAVFI_E_TOOBIG;
+  if (p.u_floats >= ((int64_t)1 << 29)) return SAVFI_E_TOOBIG;           // one task's transformed filter: 32-bit byte offsets
   return SAVFI_OK;
 }
 
