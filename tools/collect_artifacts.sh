@@ -20,6 +20,7 @@ cd /tmp; rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_c3 -- python 
 for cfg in "0 1 0" "0 1 4" "1 1 4" "0 2 2" "1 2 2" "1 4 0" "1 2 0"; do set -- $cfg; python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timer --graph-inner-loop $1 --task-streams $2 --task-batch $3 2>/dev/null >> gpurun_out/art/r02_modes.jsonl; done
 cd /tmp; for c in FETCH_SIZE WRITE_SIZE; do rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/wp_$c -- python $R/tools/wino_traffic.py > /dev/null 2>&1; done; cd $R
 python tools/wino_traffic.py parse /tmp/wp_FETCH_SIZE /tmp/wp_WRITE_SIZE > gpurun_out/art/r02_wino_traffic.json 2>/dev/null
+[ -f $R/tools/scratch/libsavfi_hip_trace.so ] || python tools/wino_trace.py --build > /dev/null 2>&1
 SAVFI_HIP_LIB=$R/tools/scratch/libsavfi_hip_trace.so python tools/wino_trace.py 2>/dev/null | grep -v "^/opt" > gpurun_out/art/r02_wino_workgroup_phases.txt
 hipcc --offload-arch=gfx950 -O3 -Wno-unused-value -o /tmp/mfma_valu tools/mfma_valu_overlap.hip 2>/dev/null && /tmp/mfma_valu > gpurun_out/art/r02_mfma_valu_overlap.txt 2>&1
 ls -la gpurun_out/art
