@@ -42,23 +42,22 @@ struct WgradArgs {
 // Staging of one row step: cotangent row y ([32][64]) and input rows y - pad .. y - pad + 2 ([3][32][66]).  Wave w
 // stages channels w, w+4, ..., w+28 with lane = pixel, so every address is a wave-uniform base (channel plane + row, SALU)
 // plus one per-lane column offset, and every LDS write is a conflict-free row.  The loads go to registers first (issued
-// before the row's MFMAs; unconditional with clamped addresses and zeroed with integer masks - a `cond ? load : 0`
-// makes the compiler put every load under its own branch + wait) and are written to the other LDS buffer afterwards.
+// before the row's MFMAs; unconditional - a `cond ? load : 0` makes the compiler put every load under its own branch +
+// wait) and are written to the other LDS buffer afterwards.
 struct Staged {
   float g[8], x[3][8], halo;
 };
 
-// v if ok else 0.  The mask goes through an empty asm so that the compiler cannot prove "not ok => the load is dead" and
-// wrap the load in a branch + s_waitcnt (it does that even for wave-uniform conditions): the load stays unconditional.
-__device__ __forceinline__ float masked(float v, bool ok) {
-  unsigned m = ok ? 0xffffffffu : 0u;
-  asm volatile("" : "+v"(m));
-  return __uint_as_float(__float_as_uint(v) & m);
-}
+// Everything outside the tensors is zeroed BY THE LOADS: a row or channel that does not exist gets the wave-uniform offset
+// ROW_OOR, a column that does not exist the per-lane offset COL_OOR; either puts the address beyond num_records (< 2^31, checked
+// by the host) and the hardware returns 0; together they still fit 32 bits.  (The first version loaded clamped addresses and
+// zeroed with an integer mask per element while writing to LDS: ~100 VALU per row and wave, paid in matrix-pipe time.)
+constexpr unsigned ROW_OOR = 0x80000000u, COL_OOR = 0x7ffffffcu;
+
 
 struct Cols {
-  unsigned gcol, xcol, hcol;     // byte offsets of this lane's cotangent / input / halo column inside a row
-  bool gok, xok, hok;
+  unsigned gcol, xcol, hcol;     // byte offsets of this lane's cotangent / input / halo column inside a row (COL_OOR: none)
+  bool hok;
   int hr, hc;                    // halo element of this thread: input row hr (0..2), channel hc, column 64 + (tid & 1)
 };
 
@@ -66,10 +65,8 @@ __device__ __forceinline__ Cols make_cols(const WgradArgs& a, int x0, int tid) {
   Cols c;
   const int lane = tid & 63;
   const int gx = x0 + lane, xx = x0 - a.pad + lane;
-  c.gcol = (unsigned)min(gx, a.Wo - 1) * 4u;
-  c.gok = gx < a.Wo;
-  c.xcol = (unsigned)min(max(xx, 0), a.W - 1) * 4u;
-  c.xok = xx >= 0 && xx < a.W;
+  c.gcol = gx < a.Wo ? (unsigned)gx * 4u : COL_OOR;
+  c.xcol = (xx >= 0 && xx < a.W) ? (unsigned)xx * 4u : COL_OOR;
   // the 2 halo columns (64, 65) x 32 channels x 3 rows = 192 elements: one per thread of the first 192
   c.hr = tid >> 6;
   c.hc = (tid & 63) >> 1;
@@ -87,46 +84,36 @@ __device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, unsigned voff, 
 
 __device__ __forceinline__ void load_rows(Staged& s, const WgradArgs& a, const Cols& c, __amdgpu_buffer_rsrc_t gr,
                                           __amdgpu_buffer_rsrc_t xr, int co0, int ci0, int y, int w) {
-  const int yc = min(y, a.Ho - 1);
-#pragma unroll
-  for (int jc = 0; jc < 8; ++jc) {
-    const int co = min(co0 + w + 4 * jc, a.Co - 1);
-    s.g[jc] = bload(gr, c.gcol, (unsigned)((co * a.Ho + yc) * a.Wo) * 4u);
-  }
-#pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    const int yyc = min(max(yc - a.pad + r, 0), a.H - 1);
-#pragma unroll
-    for (int jc = 0; jc < 8; ++jc) {
-      const int ci = min(ci0 + w + 4 * jc, a.Ci - 1);
-      s.x[r][jc] = bload(xr, c.xcol, (unsigned)((ci * a.H + yyc) * a.W) * 4u);
-    }
-  }
-  const int yyh = min(max(yc - a.pad + min(c.hr, 2), 0), a.H - 1);
-  s.halo = bload(xr, c.hcol + (unsigned)((min(ci0 + c.hc, a.Ci - 1) * a.H + yyh) * a.W) * 4u, 0u);
-}
-
-// zero what lies outside the tensors (row y of the cotangent, rows y - pad + r of the input) while writing to LDS
-__device__ __forceinline__ void store_rows(float* __restrict__ buf, const Staged& s, const WgradArgs& a, const Cols& c, int co0,
-                                           int ci0, int y, int tid, int w) {
-  const int lane = tid & 63;
   const bool yok = y < a.Ho;
 #pragma unroll
-  for (int jc = 0; jc < 8; ++jc)
-    buf[(w + 4 * jc) * GP + lane] = masked(s.g[jc], yok && co0 + w + 4 * jc < a.Co && c.gok);
+  for (int jc = 0; jc < 8; ++jc) {
+    const int co = co0 + w + 4 * jc;
+    s.g[jc] = bload(gr, c.gcol, (yok && co < a.Co) ? (unsigned)((co * a.Ho + y) * a.Wo) * 4u : ROW_OOR);
+  }
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
     const int yy = y - a.pad + r;
     const bool rok = yok && yy >= 0 && yy < a.H;
 #pragma unroll
-    for (int jc = 0; jc < 8; ++jc)
-      buf[G_FLOATS + (r * GCI + w + 4 * jc) * GP + lane] = masked(s.x[r][jc], rok && ci0 + w + 4 * jc < a.Ci && c.xok);
+    for (int jc = 0; jc < 8; ++jc) {
+      const int ci = ci0 + w + 4 * jc;
+      s.x[r][jc] = bload(xr, c.xcol, (rok && ci < a.Ci) ? (unsigned)((ci * a.H + yy) * a.W) * 4u : ROW_OOR);
+    }
   }
-  if (tid < 192) {
-    const int yy = y - a.pad + c.hr;
-    buf[G_FLOATS + (c.hr * GCI + c.hc) * GP + 64 + (tid & 1)] =
-        masked(s.halo, yok && yy >= 0 && yy < a.H && ci0 + c.hc < a.Ci && c.hok);
-  }
+  const int yyh = y - a.pad + min(c.hr, 2), cih = ci0 + c.hc;
+  const bool hok = c.hok && yok && yyh >= 0 && yyh < a.H && cih < a.Ci;
+  s.halo = bload(xr, hok ? c.hcol + (unsigned)((cih * a.H + yyh) * a.W) * 4u : COL_OOR, 0u);
+}
+
+__device__ __forceinline__ void store_rows(float* __restrict__ buf, const Staged& s, const Cols& c, int tid, int w) {
+  const int lane = tid & 63;
+#pragma unroll
+  for (int jc = 0; jc < 8; ++jc) buf[(w + 4 * jc) * GP + lane] = s.g[jc];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int jc = 0; jc < 8; ++jc) buf[G_FLOATS + (r * GCI + w + 4 * jc) * GP + lane] = s.x[r][jc];
+  if (tid < 192) buf[G_FLOATS + (c.hr * GCI + c.hc) * GP + 64 + (tid & 1)] = s.halo;
 }
 
 __global__ __launch_bounds__(GNT, 2) void wgrad3x3(WgradArgs a) {
@@ -157,7 +144,7 @@ __global__ __launch_bounds__(GNT, 2) void wgrad3x3(WgradArgs a) {
   const Cols cols = make_cols(a, x0, tid);
   Staged st;
   load_rows(st, a, cols, gr, xr, co0, ci0, y0, w);
-  store_rows(lds, st, a, cols, co0, ci0, y0, tid, w);
+  store_rows(lds, st, cols, tid, w);
   __syncthreads();
   for (int y = y0; y < y1; ++y) {
     const float* cur = lds + ((y - y0) & 1) * BUF_FLOATS;
@@ -192,7 +179,7 @@ __global__ __launch_bounds__(GNT, 2) void wgrad3x3(WgradArgs a) {
           acc[1][1][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga1[ks], xs[1][ks + b], acc[1][1][t], 0, 0, 0);
         }
     }
-    store_rows(nxt, st, a, cols, co0, ci0, y + 1, tid, w);
+    store_rows(nxt, st, cols, tid, w);
     __syncthreads();
   }
 
