@@ -126,7 +126,9 @@ def main():
     ap.add_argument('--graph-inner-loop', type=int, default=None)
     ap.add_argument('--sepconv-window', type=int, default=None)
     ap.add_argument('--task-streams', type=int, default=None, help='tasks adapted concurrently (threads + HIP streams)')
-    ap.add_argument('--no-fast-path', action='store_true', help='skip the extra fast_path measurement (hipGraph replays on 4 task streams)')
+    ap.add_argument('--fast-path', action='store_true',
+                    help='also measure the same workload from hipGraph replays on 4 task streams and report it as `fast_path` '
+                         '(off by default: the default command runs ONE mode, so that a rocprofv3 trace of it shows the kernels of `value` only)')
     ap.add_argument('--wgrad-overlap', type=int, default=None, help='weight gradients of support passes on a side stream')
     ap.add_argument('--task-batch', type=int, default=None, help='tasks adapted in lockstep (one launch per layer for all of them)')
     opt = ap.parse_args()
@@ -250,7 +252,7 @@ def main():
                     "note": "algorithmic bytes = %.2f MB per [1,3,%d,%d] sample (x samples per launch: tasks in lockstep x the "
                             "support pair); fp32 issue ceiling of this op is ~53%% of HBM peak (SURVEY.md 7)"
                             % (per_call / 1e6, oh, ow)}
-        if world == 1 and not toy and not opt.no_fast_path and not switches and not getattr(system, '_graphs', None):
+        if world == 1 and not toy and opt.fast_path and not switches and not getattr(system, '_graphs', None):
             # The default mode adapted the tasks in lockstep in the eager loop (where the roofline kernel can be timed in place).
             # The same workload and step count again from hipGraph replays of single tasks on four task streams -- the fastest
             # parity-gated mode on a GPU that one stream of kernels does not fill (tests/test_system_gpu.py: graph replays on task
