@@ -281,6 +281,12 @@ int64_t savfi_conv3x3_wgrad_tasks_workspace_floats(int N, int T, int Ci, int Co,
 int savfi_conv3x3_wgrad_tasks_f32(const float* x, const float* gz, float* gw, float* workspace, int N, int T, int Ci,
                                   int Co, int H, int W, int pad, void* stream);
 
+/* The same weight gradient in Winograd form F(3x3, 2x2) (2.25x fewer multiplies; same contract, its own workspace size;
+ * deterministic; sums in a different order than the direct form: results agree to fp32 rounding of the reduction). */
+int64_t savfi_conv3x3_wgrad_wino_tasks_workspace_floats(int N, int T, int Ci, int Co, int H, int W, int pad);
+int savfi_conv3x3_wgrad_wino_tasks_f32(const float* x, const float* gz, float* gw, float* workspace, int N, int T, int Ci,
+                                       int Co, int H, int W, int pad, void* stream);
+
 /* ----------------------------------------------------------------------------------
  * Frame staging (data/vimeo_septuplet.py:68-80, data/video.py:44-51: channel swap, HWC->CHW, .float()/255,
  * Normalize): src = N decoded frames, uint8 [N,H,W,3] on the DEVICE (copied there as bytes);

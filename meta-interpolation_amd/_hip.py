@@ -66,6 +66,8 @@ _PROTOTYPES = {
     "savfi_conv3x3_tasks_pre_f32": [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P],
     "savfi_conv3x3_wgrad_tasks_workspace_floats": [c_int] * 7,
     "savfi_conv3x3_wgrad_tasks_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P],
+    "savfi_conv3x3_wgrad_wino_tasks_workspace_floats": [c_int] * 7,
+    "savfi_conv3x3_wgrad_wino_tasks_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P],
     "savfi_conv3x3_wgrad_workspace_floats": [c_int] * 6,
     "savfi_conv3x3_wgrad_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P],
     "savfi_frames_u8_to_f32": [_P, _P, c_int64, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float, _P],

@@ -328,3 +328,342 @@ extern "C" int savfi_conv3x3_wgrad_f32(const float* x, const float* gz, float* g
                                        int H, int W, int pad, void* stream) {
   return savfi_conv3x3_wgrad_tasks_f32(x, gz, gw, workspace, N, 1, Ci, Co, H, W, pad, stream);
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Winograd form of the same weight gradient: F(3x3, 2x2).  Per 2x2 tile of the cotangent and its 4x4 input patch
+//   dW[co][ci] += A'^T [ (G' g G'^T) (.) (B^T d B) ] A'        B^T as in winograd.hip (same interpolation points),
+//   G' = [1 0; .5 .5; .5 -.5; 0 1],   A'^T = [1 1 1 0; 0 1 -1 0; 0 1 1 -1]
+// so the sum over tiles is 16 GEMMs  M[xi][co][ci] = sum_tile Y[xi][co][tile] V[xi][ci][tile]  with 2.25x fewer multiplies than
+// the direct form above; the output transform runs once per workgroup.  The factors .5 of G' are applied to M in the output
+// stage (M is linear in Y), so the cotangent transform is 12 additions.
+//
+// Workgroup = 4 waves = 32 co x 32 ci of one task over a range of tile chunks (8 consecutive tiles of a tile row); wave w owns
+// the Winograd row r = w (xi = 4 w .. 4 w + 3): 4 x 2 x 2 accumulator tiles = 64 registers.  Per chunk every thread transforms
+// one input patch (ci = tid / 8, tile = tid % 8) and one cotangent tile (co = tid / 8) and writes each as four ds_write_b128
+// ([r][channel][tile][c], pitch 36 floats per channel: a quarter wave reads 16 channels x 16 bytes over all 64 banks); the MFMA
+// k-step is 4 tiles.  LDS is double buffered (one barrier per chunk), the next chunk's loads are in flight during the MFMAs.
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+
+typedef int i32x4w __attribute__((ext_vector_type(4)));
+typedef float f32x2w __attribute__((ext_vector_type(2)));
+
+constexpr int WW_TK = 8;                  // tiles per chunk (two MFMA k-steps)
+constexpr int WW_PY = WW_TK * 4 + 4;      // floats per channel row of a buffer: [tile][c] + pad
+constexpr int WW_CB = 32;                 // channels per block (co and ci)
+constexpr int WW_HALF = 4 * WW_CB * WW_PY;        // floats of Y (or V) in one buffer: [r][channel][tile][c]
+constexpr int WW_BUF = 2 * WW_HALF;               // Y + V
+constexpr int WW_BLOCK_FLOATS = WW_CB * WW_CB * 9;  // one workgroup's partial result [co][ci][3][3]
+#ifndef WW_DOUBLE
+#define WW_DOUBLE 0
+#endif
+// single buffered (two barriers per chunk): 36.9 KB and ~120 VGPRs -> FOUR workgroups per CU, which hides the barriers and the
+// LDS / memory latencies of a chunk better than a second buffer does with two
+constexpr int WW_LDS_FLOATS = (WW_DOUBLE ? 2 : 1) * WW_BUF;
+
+struct WWArgs {
+  const float* x;      // [N][Ci][H][W]
+  const float* gz;     // [N][Co][Ho][Wo]
+  float* partial;      // [T][nsplit][cobs * cibs][32][32][9]
+  int Ci, Co, H, W, Ho, Wo, pad, T, cibs;
+  int ty_cnt, tx_cnt, cpr;        // tile rows, tile columns, chunks per tile row
+  int chunks_total;               // per task: (N / T) * ty_cnt * cpr
+  int chunks_per_split;
+};
+
+}  // namespace
+
+__device__ f32x4 savfi_wg_buffer_load_x4(i32x4w rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+__device__ f32x2w savfi_wg_buffer_load_x2(i32x4w rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2f32");
+
+namespace {
+
+__device__ __forceinline__ i32x4w ww_rsrc(const float* base, unsigned bytes) {
+  const unsigned long long p = reinterpret_cast<unsigned long long>(base);
+  i32x4w r;
+  r.x = (int)(unsigned)p; r.y = (int)(unsigned)(p >> 32); r.z = (int)bytes; r.w = 0x00020000;
+  return r;
+}
+
+struct WWChunk {          // what a thread holds of one chunk between its loads and its transforms
+  float d[16];            // input patch (row-major 4x4)
+  float g[4];             // cotangent tile (row-major 2x2)
+  int edge;               // wave-uniform: bit 0 = first chunk of a padded row (lane tile 0 was loaded from column 0 instead of
+                          // -1: shift right), bit 1 = last chunk of a row (columns beyond the image are cleared)
+  int wcols;              // columns of the patch inside the image, counted from its first (4 = all)
+  int gcols;              // columns of the cotangent tile inside the map (2, 1 or 0)
+};
+
+// Position of a thread in the chunk sequence: sample, tile row and chunk column are wave-uniform; the byte offsets of its four
+// patch rows and two cotangent rows (column 0) are recomputed only when the tile row changes.
+struct WWPos {
+  int nq, ty, cx;
+  unsigned xrow[4], grow[2];      // offsets inside the sample, or ROW_OOR + small (row / channel outside)
+};
+
+__device__ __forceinline__ void ww_set_row(WWPos& p, const WWArgs& a, int ci, int co) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int y = 2 * p.ty - a.pad + r;
+    p.xrow[r] = (y >= 0 && y < a.H && ci < a.Ci) ? (unsigned)((ci * a.H + y) * a.W) * 4u : ROW_OOR;
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int y = 2 * p.ty + u;
+    p.grow[u] = (y < a.Ho && co < a.Co) ? (unsigned)((co * a.Ho + y) * a.Wo) * 4u : ROW_OOR;
+  }
+}
+
+__device__ __forceinline__ void ww_load(WWChunk& c, const WWArgs& a, const WWPos& p, int task, int tl) {
+  const int n = p.nq * a.T + task;
+  const int tx = p.cx * WW_TK + tl;
+  // input patch: rows 2 ty - pad + (0..3), columns x0 .. x0 + 3; rows outside the image and channels beyond Ci come back as zeros
+  const i32x4w xr = ww_rsrc(a.x + (size_t)n * a.Ci * a.H * a.W, (unsigned)(a.Ci * a.H * a.W) * 4u);
+  const int x0 = 2 * tx - a.pad;
+  c.edge = ((p.cx == 0 && a.pad > 0) ? 1 : 0) | (p.cx == a.cpr - 1 ? 2 : 0);
+  c.wcols = min(max(a.W - x0, 0), 4);
+  const unsigned xcol = (unsigned)max(x0, 0) * 4u;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const f32x4 v = savfi_wg_buffer_load_x4(xr, (int)(p.xrow[r] + xcol), 0, 0);
+    c.d[4 * r] = v.x; c.d[4 * r + 1] = v.y; c.d[4 * r + 2] = v.z; c.d[4 * r + 3] = v.w;
+  }
+  // cotangent tile: rows 2 ty, 2 ty + 1, columns 2 tx, 2 tx + 1 (a tile beyond the last column: out of range -> zeros)
+  const i32x4w gr = ww_rsrc(a.gz + (size_t)n * a.Co * a.Ho * a.Wo, (unsigned)(a.Co * a.Ho * a.Wo) * 4u);
+  c.gcols = min(max(a.Wo - 2 * tx, 0), 2);
+  const unsigned gcol = c.gcols > 0 ? (unsigned)(2 * tx) * 4u : ROW_OOR;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const f32x2w v = savfi_wg_buffer_load_x2(gr, (int)((p.grow[u] | (gcol & ROW_OOR)) + (gcol & ~ROW_OOR)), 0, 0);
+    c.g[2 * u] = v.x; c.g[2 * u + 1] = v.y;
+  }
+}
+
+// registers -> transforms -> this thread's rows of the V and Y buffers
+__device__ __forceinline__ void ww_transform_store(WWChunk& c, float* __restrict__ ybuf, float* __restrict__ vbuf, int ch, int tl) {
+  float (&d)[16] = c.d;
+  if (c.edge & 1) {                 // wave-uniform: only the first chunk of a tile row
+    if (tl == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { d[4 * r + 3] = d[4 * r + 2]; d[4 * r + 2] = d[4 * r + 1]; d[4 * r + 1] = d[4 * r]; d[4 * r] = 0.f; }
+    }
+  }
+  if (c.edge & 2) {                 // wave-uniform: only the last chunk of a tile row
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      d[4 * r] = c.wcols > 0 ? d[4 * r] : 0.f;
+      d[4 * r + 1] = c.wcols > 1 ? d[4 * r + 1] : 0.f;
+      d[4 * r + 2] = c.wcols > 2 ? d[4 * r + 2] : 0.f;
+      d[4 * r + 3] = c.wcols > 3 ? d[4 * r + 3] : 0.f;
+    }
+    c.g[1] = c.gcols > 1 ? c.g[1] : 0.f;
+    c.g[3] = c.gcols > 1 ? c.g[3] : 0.f;
+  }
+  // V = B^T d B,  B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
+  float t[16];
+#pragma unroll
+  for (int cc = 0; cc < 4; ++cc) {
+    t[cc] = d[cc] - d[8 + cc];
+    t[4 + cc] = d[4 + cc] + d[8 + cc];
+    t[8 + cc] = d[8 + cc] - d[4 + cc];
+    t[12 + cc] = d[4 + cc] - d[12 + cc];
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    *reinterpret_cast<f32x4*>(vbuf + (r * WW_CB + ch) * WW_PY + 4 * tl) =
+        (f32x4){t[4 * r] - t[4 * r + 2], t[4 * r + 1] + t[4 * r + 2], t[4 * r + 2] - t[4 * r + 1], t[4 * r + 1] - t[4 * r + 3]};
+  // Y' = G'' g G''^T with G'' = [1 0; 1 1; 1 -1; 0 1] (the factors .5 of rows / columns 1, 2 are applied in the output stage)
+  const float g00 = c.g[0], g01 = c.g[1], g10 = c.g[2], g11 = c.g[3];
+  const float s0[2] = {g00, g01}, s1[2] = {g00 + g10, g01 + g11}, s2[2] = {g00 - g10, g01 - g11}, s3[2] = {g10, g11};
+  *reinterpret_cast<f32x4*>(ybuf + (0 * WW_CB + ch) * WW_PY + 4 * tl) = (f32x4){s0[0], s0[0] + s0[1], s0[0] - s0[1], s0[1]};
+  *reinterpret_cast<f32x4*>(ybuf + (1 * WW_CB + ch) * WW_PY + 4 * tl) = (f32x4){s1[0], s1[0] + s1[1], s1[0] - s1[1], s1[1]};
+  *reinterpret_cast<f32x4*>(ybuf + (2 * WW_CB + ch) * WW_PY + 4 * tl) = (f32x4){s2[0], s2[0] + s2[1], s2[0] - s2[1], s2[1]};
+  *reinterpret_cast<f32x4*>(ybuf + (3 * WW_CB + ch) * WW_PY + 4 * tl) = (f32x4){s3[0], s3[0] + s3[1], s3[0] - s3[1], s3[1]};
+}
+
+__global__ __launch_bounds__(256, WW_DOUBLE ? 2 : 4) void wino_wgrad3x3(WWArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tl = tid & 7, ch = tid >> 3;
+  const int task = blockIdx.z;
+  const int cob = blockIdx.y / a.cibs, cib = blockIdx.y - cob * a.cibs;
+  const int q0 = blockIdx.x * a.chunks_per_split, q1 = min(q0 + a.chunks_per_split, a.chunks_total);
+  const int ci = cib * WW_CB + ch, co = cob * WW_CB + ch;
+
+  f32x4 acc[4][2][2];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[c][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // fragment reads: row = channel lane % 16 of the co / ci tile, k = tile 4 ks + lane / 16, the four xi columns in one b128
+  const int frag = (w * WW_CB + (lane & 15)) * WW_PY + 4 * (lane >> 4);
+  WWChunk cur;
+  WWPos pos;
+  {
+    const int per_img = a.ty_cnt * a.cpr;
+    pos.nq = q0 / per_img;
+    const int rem = q0 - pos.nq * per_img;
+    pos.ty = rem / a.cpr;
+    pos.cx = rem - pos.ty * a.cpr;
+  }
+  ww_set_row(pos, a, ci, co);
+  if (q0 < q1) ww_load(cur, a, pos, task, tl);
+  for (int q = q0; q < q1; ++q) {
+    float* buf = lds + (WW_DOUBLE ? ((q - q0) & 1) * WW_BUF : 0);
+    if (!WW_DOUBLE && q != q0) __syncthreads();          // every wave is done with the previous chunk's fragments
+    ww_transform_store(cur, buf, buf + WW_HALF, ch, tl);
+    if (q + 1 < q1) {                                  // next chunk: in flight during this chunk's MFMAs
+      if (++pos.cx == a.cpr) {                         // wave-uniform
+        pos.cx = 0;
+        if (++pos.ty == a.ty_cnt) { pos.ty = 0; ++pos.nq; }
+        ww_set_row(pos, a, ci, co);
+      }
+      ww_load(cur, a, pos, task, tl);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    const float* yb = buf + frag;
+    const float* vb = buf + WW_HALF + frag;
+#pragma unroll
+    for (int ks = 0; ks < WW_TK / 4; ++ks) {
+      f32x4 ya[2], va[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ya[i] = *reinterpret_cast<const f32x4*>(yb + 16 * i * WW_PY + 16 * ks);
+        va[i] = *reinterpret_cast<const f32x4*>(vb + 16 * i * WW_PY + 16 * ks);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[c][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ya[i][c], va[j][c], acc[c][i][j], 0, 0, 0);
+    }
+  }
+  __syncthreads();
+
+  // output stage.  Column pass in registers (this wave holds row r = w, scale s_r s_c with s = 1, .5, .5, 1):
+  //   u[b] = sum_c A'^T[b][c] s_c M[r][c]:  u0 = m0 + (m1 + m2)/2,  u1 = (m1 - m2)/2,  u2 = (m1 + m2)/2 - m3;   times s_r
+  // rows meet in LDS:  dW[0][b] = u_0 + u_1 + u_2,  dW[1][b] = u_1 - u_2,  dW[2][b] = u_1 + u_2 - u_3
+  const float sr = (w == 1 || w == 2) ? 0.5f : 1.f;
+  float* ex = lds;      // one co tile at a time: [r][b][ci tile j][lane][reg] = 4 x 3 x 2 x 256 floats = 24 KB
+  // accumulator tile layout: row (co within 16) = 4 * (lane >> 4) + reg, column (ci within 16) = lane & 15
+  float* out = a.partial + (((size_t)task * gridDim.x + blockIdx.x) * gridDim.y + blockIdx.y) * WW_BLOCK_FLOATS;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      f32x4 u0, u1, u2;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float m0 = acc[0][i][j][e], m1 = acc[1][i][j][e], m2 = acc[2][i][j][e], m3 = acc[3][i][j][e];
+        const float h = 0.5f * (m1 + m2);
+        u0[e] = sr * (m0 + h);
+        u1[e] = sr * (0.5f * (m1 - m2));
+        u2[e] = sr * (h - m3);
+      }
+      float* p = ex + ((w * 3) * 2 + j) * 256 + lane * 4;
+      *reinterpret_cast<f32x4*>(p) = u0;
+      *reinterpret_cast<f32x4*>(p + 2 * 256) = u1;
+      *reinterpret_cast<f32x4*>(p + 4 * 256) = u2;
+    }
+    __syncthreads();
+    for (int item = tid; item < 3 * 2 * 256; item += 256) {         // (b, ci tile, lane, reg)
+      const int reg = item & 3, ln = (item >> 2) & 63, j = (item >> 8) & 1, b = item >> 9;
+      const float* p = ex + (b * 2 + j) * 256 + ln * 4 + reg;
+      const float u_0 = p[0], u_1 = p[3 * 2 * 256], u_2 = p[2 * 3 * 2 * 256], u_3 = p[3 * 3 * 2 * 256];
+      const int cor = 16 * i + 4 * (ln >> 4) + reg, cic = 16 * j + (ln & 15);
+      float* o = out + (cor * WW_CB + cic) * 9 + b;
+      o[0] = u_0 + u_1 + u_2;
+      o[3] = u_1 - u_2;
+      o[6] = u_1 + u_2 - u_3;
+    }
+    __syncthreads();
+  }
+}
+
+// gw[t][co][ci][k] = sum over the groups (fixed order) of stage2[t][g][cob * cibs + cib][co % 32][ci % 32][k]
+__global__ __launch_bounds__(256) void wino_wgrad_reduce2(const float* __restrict__ stage2, float* __restrict__ gw, int Co, int Ci,
+                                                          int cibs, int ntiles, int ngroups) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= Co * Ci * 9) return;
+  stage2 += (size_t)blockIdx.y * ngroups * ntiles * WW_BLOCK_FLOATS;      // blockIdx.y = task
+  gw += (size_t)blockIdx.y * Co * Ci * 9;
+  const int k = e % 9, ci = (e / 9) % Ci, co = e / (9 * Ci);
+  const size_t off = (size_t)((co / WW_CB) * cibs + ci / WW_CB) * WW_BLOCK_FLOATS + ((co % WW_CB) * WW_CB + ci % WW_CB) * 9 + k;
+  float s = 0.f;
+  for (int g = 0; g < ngroups; ++g) s += stage2[(size_t)g * ntiles * WW_BLOCK_FLOATS + off];
+  gw[e] = s;
+}
+
+struct WWPlan {
+  int Ho, Wo, cobs, cibs, ty_cnt, tx_cnt, cpr, chunks_total, chunks_per_split, nsplit, ngroups;
+  int64_t partial_floats, stage2_floats;
+};
+
+bool ww_plan(WWPlan& p, int N, int T, int Ci, int Co, int H, int W, int pad) {
+  p.Ho = H + 2 * pad - 2;
+  p.Wo = W + 2 * pad - 2;
+  if (p.Ho <= 0 || p.Wo <= 0) return false;
+  p.cobs = savfi_cdiv(Co, WW_CB);
+  p.cibs = savfi_cdiv(Ci, WW_CB);
+  p.ty_cnt = savfi_cdiv(p.Ho, 2);
+  p.tx_cnt = savfi_cdiv(p.Wo, 2);
+  p.cpr = savfi_cdiv(p.tx_cnt, WW_TK);
+  const int64_t chunks = (int64_t)(N / T) * p.ty_cnt * p.cpr;
+  if (chunks > 0x7fffffffLL) return false;
+  p.chunks_total = (int)chunks;
+  // splits: enough workgroups for a few rounds of the 512 slots, at least 32 chunks each (output stage + 36 KB partial block)
+  const int64_t blocks = (int64_t)T * p.cobs * p.cibs;
+  int64_t want = (512 * 2 + blocks - 1) / blocks;
+  const int64_t most = chunks / 32 > 0 ? chunks / 32 : 1;
+  if (want > most) want = most;
+  if (want < 1) want = 1;
+  p.chunks_per_split = savfi_cdiv(chunks, want);
+  p.nsplit = savfi_cdiv(chunks, p.chunks_per_split);
+  p.ngroups = savfi_cdiv(p.nsplit, RG);
+  p.partial_floats = (int64_t)T * p.nsplit * p.cobs * p.cibs * WW_BLOCK_FLOATS;
+  p.stage2_floats = (int64_t)T * p.ngroups * p.cobs * p.cibs * WW_BLOCK_FLOATS;
+  return true;
+}
+
+}  // namespace
+
+extern "C" int64_t savfi_conv3x3_wgrad_wino_tasks_workspace_floats(int N, int T, int Ci, int Co, int H, int W, int pad) {
+  if (N <= 0 || T <= 0 || N % T != 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return SAVFI_E_SHAPE;
+  if (pad != 0 && pad != 1) return SAVFI_E_UNSUPPORTED;
+  WWPlan p;
+  if (!ww_plan(p, N, T, Ci, Co, H, W, pad)) return SAVFI_E_SHAPE;
+  return p.partial_floats + p.stage2_floats;
+}
+
+// Same contract as savfi_conv3x3_wgrad_tasks_f32 (gw [T][Co][Ci][3][3], gw[t] over the samples n % T == t), Winograd form.
+extern "C" int savfi_conv3x3_wgrad_wino_tasks_f32(const float* x, const float* gz, float* gw, float* workspace, int N, int T,
+                                                  int Ci, int Co, int H, int W, int pad, void* stream) {
+  if (!x || !gz || !gw || !workspace) return SAVFI_E_NULL;
+  if (N <= 0 || T <= 0 || N % T != 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return SAVFI_E_SHAPE;
+  if (pad != 0 && pad != 1) return SAVFI_E_UNSUPPORTED;
+  WWPlan p;
+  if (!ww_plan(p, N, T, Ci, Co, H, W, pad)) return SAVFI_E_SHAPE;
+  if ((int64_t)Ci * H * W >= ((int64_t)1 << 29) || (int64_t)Co * p.Ho * p.Wo >= ((int64_t)1 << 29)) return SAVFI_E_TOOBIG;   // 32-bit byte offsets
+  if (p.ngroups > 65535 || (int64_t)p.cobs * p.cibs > 65535 || (int64_t)Co * Ci * 9 > 0x7fffffffLL || T > 65535) return SAVFI_E_TOOBIG;
+  hipStream_t st = (hipStream_t)stream;
+  constexpr size_t lds = (size_t)WW_LDS_FLOATS * sizeof(float);
+  static uint32_t attr_done = 0;
+  if (int e = savfi_ensure_dynamic_lds((const void*)wino_wgrad3x3, lds, attr_done)) return e;
+  WWArgs a{x, gz, workspace, Ci, Co, H, W, p.Ho, p.Wo, pad, T, p.cibs, p.ty_cnt, p.tx_cnt, p.cpr, p.chunks_total, p.chunks_per_split};
+  hipLaunchKernelGGL(wino_wgrad3x3, dim3(p.nsplit, p.cobs * p.cibs, T), dim3(256), lds, st, a);
+  if (int e = savfi_launch_status()) return e;
+  const int ntiles = p.cobs * p.cibs;
+  const size_t block_floats = (size_t)ntiles * WW_BLOCK_FLOATS;
+  float* stage2 = workspace + p.partial_floats;
+  hipLaunchKernelGGL(wgrad_reduce1, dim3((unsigned)((block_floats / 4 + 255) / 256), p.ngroups, T), dim3(256), 0, st, workspace,
+                     stage2, block_floats, p.nsplit);
+  if (int e = savfi_launch_status()) return e;
+  hipLaunchKernelGGL(wino_wgrad_reduce2, dim3(savfi_cdiv(Co * Ci * 9, 256), T), dim3(256), 0, st, stage2, gw, Co, Ci, p.cibs, ntiles,
+                     p.ngroups);
+  return savfi_launch_status();
+}

@@ -480,6 +480,16 @@ if os.environ.get('SAVFI_WINO_TILES'):      # experiment knob: "fwd,bwd,fwd_batc
 # transposes there (tools/wgrad_bench.py, profiles/r01_wgrad_bench.jsonl); the deep 24x32 / 12x16 layers stay on MIOpen.
 WGRAD_MIN_PIXELS = 3000
 WGRAD_MIN_CI = 16
+# Winograd form of the weight gradient (savfi_conv3x3_wgrad_wino_tasks_f32, F(3x3, 2x2)): 1.4-1.6x faster than the direct kernel
+# on the large layers and 1.2-1.5x faster than MIOpen (grouped or not) on the deep 24x32 / 12x16 ones once a call carries enough
+# work; below ~6 GFLOP the three launches (kernel + two reduction levels) are the cost and the old routing stays.
+WGRAD_WINO = not os.environ.get('SAVFI_NO_WINO_WGRAD')
+WGRAD_WINO_MIN_GFLOP = 6.0
+WGRAD_WINO_MIN_PIXELS = 192
+
+
+def _wgrad_wino(N, Ci, Co, Ho, Wo):
+    return WGRAD_WINO and Ho * Wo >= WGRAD_WINO_MIN_PIXELS and 18e-9 * Ci * Co * Ho * Wo * N >= WGRAD_WINO_MIN_GFLOP
 
 
 def conv3x3_eligible(x, weight, stride, padding, dilation, groups, backward=False):
@@ -510,6 +520,8 @@ def conv3x3_wgrad_eligible(x, weight, stride, padding, dilation, groups):
     Ho, Wo = H + 2 * pad - 2, W + 2 * pad - 2
     # the kernel works on 64-pixel row segments: a mostly empty last segment (CAIN's 160-wide maps: 83 % used) loses
     fill = Wo / (64.0 * ((Wo + 63) // 64)) if Wo > 0 else 0.0
+    if Ho > 0 and Wo > 0 and _wgrad_wino(x.shape[0], Ci, weight.shape[0], Ho, Wo):
+        return True
     return Ci >= WGRAD_MIN_CI and Ho * Wo >= WGRAD_MIN_PIXELS and fill >= 0.85
 
 
@@ -686,9 +698,9 @@ def conv3x3_wgrad_tasks_eligible(x, weight, stride, padding, dilation):
     if not (WINOGRAD_CONV and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and _is3x3s1(weight, stride, padding, dilation)):
         return False
     pad = padding if isinstance(padding, int) else padding[0]
-    _, Ci, H, W = x.shape
+    N, Ci, H, W = x.shape
     Ho, Wo = H + 2 * pad - 2, W + 2 * pad - 2
-    return Ho * Wo >= TASKS_WGRAD_MIN_PIXELS
+    return Ho * Wo >= TASKS_WGRAD_MIN_PIXELS or (Ho > 0 and Wo > 0 and _wgrad_wino(N, Ci, weight.shape[1], Ho, Wo))
 
 
 def conv3x3_tasks(x, weight, bias=None, mode=0, slope=1.0, pad=1):
@@ -752,14 +764,16 @@ def conv3x3_wgrad_tasks(x, gz, T, pad=1, stream=None, extra_stream=None):
     Co = gz.shape[1]
     assert N % T == 0 and tuple(gz.shape) == (N, Co, H + 2 * pad - 2, W + 2 * pad - 2), (x.shape, gz.shape, pad, T)
     lib = _hip.lib()
-    ws = torch.empty(_workspace_floats("savfi_conv3x3_wgrad_tasks_workspace_floats", N, T, Ci, Co, H, W, int(pad)), dtype=x.dtype, device=x.device)
+    form = "wino_" if _wgrad_wino(N, Ci, Co, H + 2 * pad - 2, W + 2 * pad - 2) else ""
+    ws = torch.empty(_workspace_floats("savfi_conv3x3_wgrad_%stasks_workspace_floats" % form, N, T, Ci, Co, H, W, int(pad)), dtype=x.dtype, device=x.device)
     gw = torch.empty((T, Co, Ci, 3, 3), dtype=x.dtype, device=x.device)
     if extra_stream is not None:
         ws.record_stream(extra_stream)
         gw.record_stream(extra_stream)
-    _hip.launch("conv3x3_wgrad", lambda: _hip.check(lib.savfi_conv3x3_wgrad_tasks_f32(
+    entry = "savfi_conv3x3_wgrad_%stasks_f32" % form
+    _hip.launch("conv3x3_wgrad", lambda: _hip.check(getattr(lib, entry)(
         x.data_ptr(), gz.data_ptr(), gw.data_ptr(), ws.data_ptr(), N, T, Ci, Co, H, W, int(pad),
-        _hip.current_stream() if stream is None else stream), "savfi_conv3x3_wgrad_tasks_f32"))
+        _hip.current_stream() if stream is None else stream), entry))
     return gw
 
 
@@ -938,6 +952,8 @@ def conv3x3_wgrad(x, gz, pad=1, stream=None, extra_stream=None):
     N, Ci, H, W = x.shape
     Co = gz.shape[1]
     assert tuple(gz.shape) == (N, Co, H + 2 * pad - 2, W + 2 * pad - 2), (x.shape, gz.shape, pad)
+    if _wgrad_wino(N, Ci, Co, H + 2 * pad - 2, W + 2 * pad - 2):
+        return conv3x3_wgrad_tasks(x, gz, 1, pad, stream, extra_stream)[0]
     lib = _hip.lib()
     ws = torch.empty(_workspace_floats("savfi_conv3x3_wgrad_workspace_floats", N, Ci, Co, H, W, int(pad)), dtype=x.dtype, device=x.device)
     gw = torch.empty((Co, Ci, 3, 3), dtype=x.dtype, device=x.device)

@@ -452,6 +452,36 @@ def test_conv3x3_split_entry_points_equal_the_fused_one(T, N, Ci, Co, H, W, pad)
             assert torch.equal(hip_ops.conv3x3_tasks_pre(gy, u_b, T, Ci, Co, None, 1, 1.0, pad), want_gx)
 
 
+@pytest.mark.parametrize("T,N,Ci,Co,H,W,pad", [(1, 1, 3, 5, 6, 8, 1), (1, 2, 32, 32, 16, 16, 1), (2, 4, 6, 32, 24, 40, 1), (1, 1, 64, 51, 37, 45, 1),
+                                               (1, 2, 51, 51, 18, 30, 0), (4, 8, 32, 32, 20, 30, 1), (1, 1, 8, 8, 5, 7, 0), (2, 2, 40, 70, 9, 130, 1)])
+def test_conv3x3_wgrad_winograd_form_matches_autograd(T, N, Ci, Co, H, W, pad):
+    """savfi_conv3x3_wgrad_wino_tasks_f32 (F(3x3, 2x2): cotangent and input transformed per 2x2 tile, 16 GEMMs over the tiles, one
+    output transform per workgroup) against autograd in float64, per task: odd sizes, both paddings, channel counts that do not
+    fill a 32-block, a row of more than eight tile chunks, and bit-reproducibility (fixed-order reduction)."""
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(N, Ci, H, W, generator=g)
+    gz = torch.randn(N, Co, H + 2 * pad - 2, W + 2 * pad - 2, generator=g)
+    want = []
+    for t in range(T):
+        w = torch.zeros(Co, Ci, 3, 3, dtype=torch.float64, requires_grad=True)
+        (gw,) = torch.autograd.grad(F.conv2d(x[t::T].double(), w, None, padding=pad), w, gz[t::T].double())
+        want.append(gw)
+    want = torch.stack(want)
+    lib = _hip.lib()
+    xd, gd = x.to(DEV), gz.to(DEV)
+
+    def run():
+        ws = torch.empty(int(lib.savfi_conv3x3_wgrad_wino_tasks_workspace_floats(N, T, Ci, Co, H, W, pad)), device=DEV)
+        gw = torch.full((T, Co, Ci, 3, 3), float('nan'), device=DEV)
+        _hip.check(lib.savfi_conv3x3_wgrad_wino_tasks_f32(xd.data_ptr(), gd.data_ptr(), gw.data_ptr(), ws.data_ptr(), N, T, Ci, Co, H, W, pad,
+                                                          _hip.current_stream()), "wino wgrad")
+        return gw
+    got = run()
+    # transformed-domain sums over all tiles in fp32: a few ulp more than the direct form (2e-7)
+    assert (got.cpu().double() - want).abs().max() <= 3e-6 * want.abs().max()
+    assert torch.equal(got, run())
+
+
 def test_sepconv_with_winograd_convs_equals_miopen_convs():
     """BASELINE config-2 frame size: the backbone's large 3x3 convolutions on savfi_conv3x3_f32 (forward with fused
     bias + ReLU, data gradient) and savfi_conv3x3_wgrad_f32 give the network output and every parameter gradient of the MIOpen path.
