@@ -388,76 +388,78 @@ __device__ __forceinline__ i32x4w ww_rsrc(const float* base, unsigned bytes) {
 struct WWChunk {          // what a thread holds of one chunk between its loads and its transforms
   float d[16];            // input patch (row-major 4x4)
   float g[4];             // cotangent tile (row-major 2x2)
-  int edge;               // wave-uniform: bit 0 = first chunk of a padded row (lane tile 0 was loaded from column 0 instead of
-                          // -1: shift right), bit 1 = last chunk of a row (columns beyond the image are cleared)
-  int wcols;              // columns of the patch inside the image, counted from its first (4 = all)
-  int gcols;              // columns of the cotangent tile inside the map (2, 1 or 0)
+  int cx;                 // wave-uniform: chunk column (first chunk of a padded row: lane tile 0 was loaded from column 0 instead
+                          // of -1 -> shift right; last chunk of a row: columns beyond the image are cleared)
 };
 
-// Position of a thread in the chunk sequence: sample, tile row and chunk column are wave-uniform; the byte offsets of its four
-// patch rows and two cotangent rows (column 0) are recomputed only when the tile row changes.
+// Position in the chunk sequence: sample, tile row and chunk column are wave-uniform, and so are the byte offsets of the four
+// patch rows and the two cotangent rows inside a channel plane (SGPRs: they go into the loads' scalar offset); the channel plane
+// of a lane is a constant per-lane offset.  A row outside the map / a channel beyond Ci or Co is marked WW_OOR in its part of
+// the offset: either part alone puts the address beyond num_records (the host keeps a sample below 2^30 bytes for this
+// kernel), both together still fit 32 bits.
+constexpr unsigned WW_OOR = 0x40000000u;
 struct WWPos {
   int nq, ty, cx;
-  unsigned xrow[4], grow[2];      // offsets inside the sample, or ROW_OOR + small (row / channel outside)
+  unsigned xrow[4], grow[2];
 };
 
-__device__ __forceinline__ void ww_set_row(WWPos& p, const WWArgs& a, int ci, int co) {
+__device__ __forceinline__ void ww_set_row(WWPos& p, const WWArgs& a) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int y = 2 * p.ty - a.pad + r;
-    p.xrow[r] = (y >= 0 && y < a.H && ci < a.Ci) ? (unsigned)((ci * a.H + y) * a.W) * 4u : ROW_OOR;
+    p.xrow[r] = (y >= 0 && y < a.H) ? (unsigned)(y * a.W) * 4u : WW_OOR;
   }
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int y = 2 * p.ty + u;
-    p.grow[u] = (y < a.Ho && co < a.Co) ? (unsigned)((co * a.Ho + y) * a.Wo) * 4u : ROW_OOR;
+    p.grow[u] = y < a.Ho ? (unsigned)(y * a.Wo) * 4u : WW_OOR;
   }
 }
 
-__device__ __forceinline__ void ww_load(WWChunk& c, const WWArgs& a, const WWPos& p, int task, int tl) {
+__device__ __forceinline__ void ww_load(WWChunk& c, const WWArgs& a, const WWPos& p, int task, int tl, unsigned xplane, unsigned gplane) {
   const int n = p.nq * a.T + task;
   const int tx = p.cx * WW_TK + tl;
   // input patch: rows 2 ty - pad + (0..3), columns x0 .. x0 + 3; rows outside the image and channels beyond Ci come back as zeros
   const i32x4w xr = ww_rsrc(a.x + (size_t)n * a.Ci * a.H * a.W, (unsigned)(a.Ci * a.H * a.W) * 4u);
   const int x0 = 2 * tx - a.pad;
-  c.edge = ((p.cx == 0 && a.pad > 0) ? 1 : 0) | (p.cx == a.cpr - 1 ? 2 : 0);
-  c.wcols = min(max(a.W - x0, 0), 4);
-  const unsigned xcol = (unsigned)max(x0, 0) * 4u;
+  c.cx = p.cx;
+  const unsigned xoff = xplane + (unsigned)max(x0, 0) * 4u;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const f32x4 v = savfi_wg_buffer_load_x4(xr, (int)(p.xrow[r] + xcol), 0, 0);
+    const f32x4 v = savfi_wg_buffer_load_x4(xr, (int)xoff, (int)p.xrow[r], 0);
     c.d[4 * r] = v.x; c.d[4 * r + 1] = v.y; c.d[4 * r + 2] = v.z; c.d[4 * r + 3] = v.w;
   }
   // cotangent tile: rows 2 ty, 2 ty + 1, columns 2 tx, 2 tx + 1 (a tile beyond the last column: out of range -> zeros)
   const i32x4w gr = ww_rsrc(a.gz + (size_t)n * a.Co * a.Ho * a.Wo, (unsigned)(a.Co * a.Ho * a.Wo) * 4u);
-  c.gcols = min(max(a.Wo - 2 * tx, 0), 2);
-  const unsigned gcol = c.gcols > 0 ? (unsigned)(2 * tx) * 4u : ROW_OOR;
+  const unsigned goff = 2 * tx < a.Wo ? gplane + (unsigned)(2 * tx) * 4u : WW_OOR;
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
-    const f32x2w v = savfi_wg_buffer_load_x2(gr, (int)((p.grow[u] | (gcol & ROW_OOR)) + (gcol & ~ROW_OOR)), 0, 0);
+    const f32x2w v = savfi_wg_buffer_load_x2(gr, (int)goff, (int)p.grow[u], 0);
     c.g[2 * u] = v.x; c.g[2 * u + 1] = v.y;
   }
 }
 
 // registers -> transforms -> this thread's rows of the V and Y buffers
-__device__ __forceinline__ void ww_transform_store(WWChunk& c, float* __restrict__ ybuf, float* __restrict__ vbuf, int ch, int tl) {
+__device__ __forceinline__ void ww_transform_store(WWChunk& c, const WWArgs& a, float* __restrict__ ybuf, float* __restrict__ vbuf, int ch, int tl) {
   float (&d)[16] = c.d;
-  if (c.edge & 1) {                 // wave-uniform: only the first chunk of a tile row
+  if (c.cx == 0 && a.pad > 0) {     // wave-uniform: only the first chunk of a tile row
     if (tl == 0) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) { d[4 * r + 3] = d[4 * r + 2]; d[4 * r + 2] = d[4 * r + 1]; d[4 * r + 1] = d[4 * r]; d[4 * r] = 0.f; }
     }
   }
-  if (c.edge & 2) {                 // wave-uniform: only the last chunk of a tile row
+  if (c.cx == a.cpr - 1) {          // wave-uniform: only the last chunk of a tile row
+    const int tx = c.cx * WW_TK + tl;
+    const int wcols = a.W - (2 * tx - a.pad), gcols = a.Wo - 2 * tx;      // columns of the patch / cotangent tile inside the map
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      d[4 * r] = c.wcols > 0 ? d[4 * r] : 0.f;
-      d[4 * r + 1] = c.wcols > 1 ? d[4 * r + 1] : 0.f;
-      d[4 * r + 2] = c.wcols > 2 ? d[4 * r + 2] : 0.f;
-      d[4 * r + 3] = c.wcols > 3 ? d[4 * r + 3] : 0.f;
+      d[4 * r] = wcols > 0 ? d[4 * r] : 0.f;
+      d[4 * r + 1] = wcols > 1 ? d[4 * r + 1] : 0.f;
+      d[4 * r + 2] = wcols > 2 ? d[4 * r + 2] : 0.f;
+      d[4 * r + 3] = wcols > 3 ? d[4 * r + 3] : 0.f;
     }
-    c.g[1] = c.gcols > 1 ? c.g[1] : 0.f;
-    c.g[3] = c.gcols > 1 ? c.g[3] : 0.f;
+    c.g[1] = gcols > 1 ? c.g[1] : 0.f;
+    c.g[3] = gcols > 1 ? c.g[3] : 0.f;
   }
   // V = B^T d B,  B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
   float t[16];
@@ -509,19 +511,22 @@ __global__ __launch_bounds__(256, WW_DOUBLE ? 2 : 4) void wino_wgrad3x3(WWArgs a
     pos.ty = rem / a.cpr;
     pos.cx = rem - pos.ty * a.cpr;
   }
-  ww_set_row(pos, a, ci, co);
-  if (q0 < q1) ww_load(cur, a, pos, task, tl);
+  // this lane's channel planes inside a sample (constant for the whole kernel)
+  const unsigned xplane = ci < a.Ci ? (unsigned)(ci * a.H * a.W) * 4u : WW_OOR;
+  const unsigned gplane = co < a.Co ? (unsigned)(co * a.Ho * a.Wo) * 4u : WW_OOR;
+  ww_set_row(pos, a);
+  if (q0 < q1) ww_load(cur, a, pos, task, tl, xplane, gplane);
   for (int q = q0; q < q1; ++q) {
     float* buf = lds + (WW_DOUBLE ? ((q - q0) & 1) * WW_BUF : 0);
     if (!WW_DOUBLE && q != q0) __syncthreads();          // every wave is done with the previous chunk's fragments
-    ww_transform_store(cur, buf, buf + WW_HALF, ch, tl);
+    ww_transform_store(cur, a, buf, buf + WW_HALF, ch, tl);
     if (q + 1 < q1) {                                  // next chunk: in flight during this chunk's MFMAs
       if (++pos.cx == a.cpr) {                         // wave-uniform
         pos.cx = 0;
         if (++pos.ty == a.ty_cnt) { pos.ty = 0; ++pos.nq; }
-        ww_set_row(pos, a, ci, co);
+        ww_set_row(pos, a);
       }
-      ww_load(cur, a, pos, task, tl);
+      ww_load(cur, a, pos, task, tl, xplane, gplane);
     }
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
@@ -541,6 +546,7 @@ __global__ __launch_bounds__(256, WW_DOUBLE ? 2 : 4) void wino_wgrad3x3(WWArgs a
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j) acc[c][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ya[i][c], va[j][c], acc[c][i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);       // one k-step's fragments at a time: 16 registers, not 32 (no spills at 128 VGPRs)
     }
   }
   __syncthreads();
@@ -648,7 +654,8 @@ extern "C" int savfi_conv3x3_wgrad_wino_tasks_f32(const float* x, const float* g
   if (pad != 0 && pad != 1) return SAVFI_E_UNSUPPORTED;
   WWPlan p;
   if (!ww_plan(p, N, T, Ci, Co, H, W, pad)) return SAVFI_E_SHAPE;
-  if ((int64_t)Ci * H * W >= ((int64_t)1 << 29) || (int64_t)Co * p.Ho * p.Wo >= ((int64_t)1 << 29)) return SAVFI_E_TOOBIG;   // 32-bit byte offsets
+  // a sample below 2^30 bytes: byte offsets plus the out-of-range markers (WW_OOR) stay inside 32 bits
+  if ((int64_t)Ci * H * W >= ((int64_t)1 << 28) || (int64_t)Co * p.Ho * p.Wo >= ((int64_t)1 << 28)) return SAVFI_E_TOOBIG;
   if (p.ngroups > 65535 || (int64_t)p.cobs * p.cibs > 65535 || (int64_t)Co * Ci * 9 > 0x7fffffffLL || T > 65535) return SAVFI_E_TOOBIG;
   hipStream_t st = (hipStream_t)stream;
   constexpr size_t lds = (size_t)WW_LDS_FLOATS * sizeof(float);
