@@ -482,9 +482,9 @@ WGRAD_MIN_PIXELS = 3000
 WGRAD_MIN_CI = 16
 # Winograd form of the weight gradient (savfi_conv3x3_wgrad_wino_tasks_f32, F(3x3, 2x2)): 1.4-1.6x faster than the direct kernel
 # on the large layers and 1.2-1.5x faster than MIOpen (grouped or not) on the deep 24x32 / 12x16 ones once a call carries enough
-# work; below ~6 GFLOP the three launches (kernel + two reduction levels) are the cost and the old routing stays.
+# work; below ~5 GFLOP the three launches (kernel + two reduction levels) are the cost and the old routing stays.
 WGRAD_WINO = not os.environ.get('SAVFI_NO_WINO_WGRAD')
-WGRAD_WINO_MIN_GFLOP = 6.0
+WGRAD_WINO_MIN_GFLOP = 5.0
 WGRAD_WINO_MIN_PIXELS = 192
 
 
