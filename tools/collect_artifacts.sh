@@ -24,4 +24,5 @@ python tools/wino_traffic.py parse /tmp/wp_FETCH_SIZE /tmp/wp_WRITE_SIZE > gpuru
 SAVFI_HIP_LIB=$R/tools/scratch/libsavfi_hip_trace.so python tools/wino_trace.py 2>/dev/null | grep -v "^/opt" > gpurun_out/art/r02_wino_workgroup_phases.txt
 hipcc --offload-arch=gfx950 -O3 -Wno-unused-value -o /tmp/mfma_valu tools/mfma_valu_overlap.hip 2>/dev/null && /tmp/mfma_valu > gpurun_out/art/r02_mfma_valu_overlap.txt 2>&1
 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --fast-path 2>/dev/null >> gpurun_out/art/r02_modes.jsonl
+python tools/wgrad_forms_bench.py > gpurun_out/art/r02_wgrad_forms.txt 2>/dev/null
 ls -la gpurun_out/art
