@@ -29,6 +29,10 @@
  *   savfi_conv3x3_tasks_f32, savfi_conv3x3_wgrad_tasks_f32   the same for T tasks with their own fast weights in ONE launch
  *   savfi_conv3x3_filters_f32, savfi_conv3x3_tasks_pre_f32   filter transforms of forward + data gradient in one launch / convolution on a transformed filter
  *                              (the sequential task loop meta_learning_system.py:366 run in lockstep)
+ *   savfi_convk_filters_f32, savfi_convk_tasks_pre_f32   F.conv2d K x K (K = 3, 5, 7) / stride 1 and its data gradient as a direct
+ *                              implicit GEMM on the bf16 matrix cores from error-free 3-way operand splits (fp32-equivalent)
+ *                                                                     voxelflow/core/models/voxel_flow.py:357-470 (5x5 layers),
+ *                                                                     superslomo/model.py:547-646 (7x7 / 5x5), model_utils.py:308-366
  *   savfi_frames_u8_to_f32     HWC uint8 frames -> normalised fp32 NCHW  data/vimeo_septuplet.py:68-80, data/video.py:44-51
  *   savfi_*_workspace_floats / savfi_bias_act_scratch_floats: sizes of the caller-owned scratch buffers (return int64_t)
  *
@@ -51,7 +55,7 @@
 extern "C" {
 #endif
 
-#define SAVFI_ABI_VERSION 5
+#define SAVFI_ABI_VERSION 6
 
 #define SAVFI_OK            0
 #define SAVFI_E_NULL       (-1)  /* a required pointer is NULL                          */
@@ -286,6 +290,24 @@ int savfi_conv3x3_wgrad_tasks_f32(const float* x, const float* gz, float* gw, fl
 int64_t savfi_conv3x3_wgrad_wino_tasks_workspace_floats(int N, int T, int Ci, int Co, int H, int W, int pad);
 int savfi_conv3x3_wgrad_wino_tasks_f32(const float* x, const float* gz, float* gw, float* workspace, int N, int T, int Ci,
                                        int Co, int H, int W, int pad, void* stream);
+
+/* ----------------------------------------------------------------------------------
+ * Direct K x K convolution, K in {3, 5, 7}, stride 1, zero padding `pad` (0 .. K-1), T filter sets (sample n uses set n % T):
+ * F.conv2d of the backbones' layers that are not 3x3 (VoxelFlow's 5x5, Super SloMo's 7x7 / 5x5 heads) and of 3x3 layers where
+ * Winograd rounding is not acceptable.  Arithmetic: every fp32 operand is split exactly into three bf16 pieces
+ * (a = a1 + a2 + a3), the product sum runs as SIX bf16 MFMAs per K-slab (a1b1, a1b2, a2b1, a1b3, a3b1, a2b2) with fp32
+ * accumulation: the dropped terms are < 2^-26 of a product, the result is as close to fp64 as an fp32 fmaf chain.
+ *   savfi_convk_filters_f32     p_fwd / p_bwd (either may be NULL): w [T,Co,Ci,K,K] packed as bf16 triples in MFMA fragment
+ *                               order for the forward pass (mode 0) / the data gradient (mode 1);
+ *                               savfi_convk_filter_floats(T, Ci, Co, K, mode) 4-byte units each, caller-owned
+ *   savfi_convk_tasks_pre_f32   mode 0: out[N,Co,H+2p-K+1,W+2p-K+1] = act(conv2d(x[N,Ci,H,W], w, pad p) + bias[T,Co])
+ *                               mode 1: x = gy[N,Co,H,W] -> out = gx[N,Ci,H+K-1-2p,W+K-1-2p]   (bias ignored, pass slope 1)
+ *                               `packed` = the buffer of the same mode from savfi_convk_filters_f32
+ * ---------------------------------------------------------------------------------- */
+int64_t savfi_convk_filter_floats(int T, int Ci, int Co, int K, int mode);
+int savfi_convk_filters_f32(const float* w, float* p_fwd, float* p_bwd, int T, int Ci, int Co, int K, void* stream);
+int savfi_convk_tasks_pre_f32(const float* x, const float* packed, const float* bias, float* out, int N, int T, int Ci,
+                              int Co, int H, int W, int K, int pad, int mode, float slope, void* stream);
 
 /* ----------------------------------------------------------------------------------
  * Frame staging (data/vimeo_septuplet.py:68-80, data/video.py:44-51: channel swap, HWC->CHW, .float()/255,

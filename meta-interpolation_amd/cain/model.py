@@ -35,6 +35,7 @@ class Decoder(nn.Module):
 
 
 class MetaCAIN(nn.Module):
+    lockstep_tasks = True     # verified against the sequential loop and the reference fixtures (tests/test_system_gpu.py)
     def __init__(self, depth=3, resume=False):
         super().__init__()
         self.encoder = Encoder(in_channels=3, depth=depth)

@@ -1,0 +1,385 @@
+// K x K / stride 1 convolution (K = 3, 5, 7; forward and data gradient, any zero padding) for gfx950 as a DIRECT implicit
+// GEMM on the bf16 matrix cores, with fp32 operands split error-free into three bf16 pieces each:
+//
+//     a = a1 + a2 + a3   (exactly: 3 x 8 significant bits, round-to-nearest pieces),  same for b
+//     a*b = a1b1 + (a1b2 + a2b1) + (a1b3 + a3b1 + a2b2)  + O(2^-26 |ab|)          6 products, fp32 accumulate
+//
+// Why.  fp32 MFMA runs at the fp32 VECTOR rate (157 TFLOP/s); v_mfma_f32_16x16x32_bf16 is 16x faster, so six of them do the
+// work of one fp32 MFMA K-slab in 6/16 of the time: 350-390 "fp32-equivalent" TFLOP/s from registers or LDS
+// (tools/bf16_split_probe.hip, profiles/r03_bf16_split_probe.txt).  The result is NOT narrower than fp32 arithmetic: against
+// an fp64 reference the 6-product sum is as close as the fmaf chain of the fp32 MFMA or closer (K = 288..4608: 1.0-1.7e-6
+// vs 0.5-1.9e-6 of max|C|; the dropped terms are below half an fp32 ulp of every product), a one-hot operand reproduces
+// the other one bit for bit, and unlike Winograd F(2x2,3x3) nothing is amplified (2e-7 there).  This is what lets the
+// 5x5 / 7x7 layers of VoxelFlow and Super SloMo (reference voxelflow/core/models/voxel_flow.py:357-470, superslomo/
+// model.py:547-646) and VoxelFlow's rounding-sensitive 3x3 layers leave MIOpen.
+//
+//   out[n][co][y][x] = act( bias[t][co] + sum_{ci,ky,kx} w[t][co][ci][ky][kx] * in[n][ci][y+ky-pad][x+kx-pad] ),  t = n % T
+//
+// GEMM view: M = 16 consecutive output pixels of a row (A operand: input patches), N = 16 output channels (B: weights),
+// K = (tap, 8 input channels): one MFMA k-step = 4 (tap, channel-octet) pairs.  Workgroup = 4 waves = a TH x TW pixel tile
+// (8 x 32 or 16 x 16) x 16*NT output channels; a wave owns 4 M-tiles x NT N-tiles (64 px x 64 channels at NT = 4).
+//   * The input tile (+ halo) of a chunk of 8*QC channels is staged ONCE per workgroup: fp32 NCHW loads (coalesced along x),
+//     split in registers (v_cvt_pk_bf16_f32), written as three bf16 planes in [octet][row][col][8 channels] order, so that an
+//     A fragment (16 pixels x 8 channels of one tap) is ONE conflict-free ds_read_b128 per plane with an immediate offset
+//     per tap.  The split costs ~5.5 VALU per element and is amortised over K*K*16*NT MACs.
+//   * Weights are packed once per weight version (convk_pack) as bf16 triples in B-fragment order: a lane fetches its 8 values
+//     of a plane with one coalesced 16-byte load straight from L2 -- no LDS, no transform in the loop.
+//   * Main loop per k-step and wave: 12 ds_read_b128 + 3*NT global 16-byte loads feed 96 (NT = 4) MFMAs; the six products
+//     of a tile are issued across the 16 accumulators, small terms first.
+//   * Epilogue: bias + (leaky) ReLU, 16-byte stores (4 consecutive pixels per lane).
+// The data gradient is the same kernel on a filter packed flipped / transposed (mode 1) with padding K-1-pad.
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int CK_THREADS = 256;
+
+__host__ __device__ constexpr int ck_round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+// chunk width in channel octets for a reduction of `cin` channels: a k-step holds 4 (tap, octet) pairs, so 4 octets make
+// every step one tap; 5x5 / 7x7 keep 2 (LDS: the tile + halo of 4 octets would not leave room for two workgroups per CU)
+__host__ __device__ inline int ck_qc(int cin, int ks) {
+  const int q = (cin + 7) / 8;
+  if (q >= 4 && ks == 3) return 4;
+  return q >= 2 ? 2 : 1;
+}
+__host__ __device__ inline int ck_steps(int ks, int qc) { return (ks * ks * qc + 3) / 4; }
+__host__ __device__ inline int ck_chunks(int cin, int qc) { return ((cin + 7) / 8 + qc - 1) / qc; }
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+
+// 8 floats -> three planes of 8 bf16 (element e in the low / high half of dword e/2)
+__device__ __forceinline__ void split8(const float (&v)[8], u32x4& p1, u32x4& p2, u32x4& p3) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float a = v[2 * i], b = v[2 * i + 1];
+    const unsigned h1 = cvt_pk_bf16(a, b);
+    const float ra = a - __uint_as_float(h1 << 16), rb = b - __uint_as_float(h1 & 0xffff0000u);
+    const unsigned h2 = cvt_pk_bf16(ra, rb);
+    const float qa = ra - __uint_as_float(h2 << 16), qb = rb - __uint_as_float(h2 & 0xffff0000u);
+    p1[i] = h1; p2[i] = h2; p3[i] = cvt_pk_bf16(qa, qb);
+  }
+}
+
+// ---- filter packing ----------------------------------------------------------------------------------------------
+// packed[t][co16][chunk c][step s][plane][lane][8 bf16]: the B fragment of MFMA k-step (c, s) for output channels
+// 16*co16 .. +15; lane = 16 g + (co % 16) holds pair j = 4 s + g -> tap = j / QC, octet o = j % QC, channels 8 (c QC + o) + e.
+// mode 0 (forward):        value = w[t][co][ci][tap]                 (w is [T][Co][Ci][K][K]; the conv reduces over Ci)
+// mode 1 (data gradient):  value = w[t][ci'][co'][K*K-1-tap]         (the conv reduces over Co and produces Ci: co' = produced, ci' = reduced)
+__global__ __launch_bounds__(256) void convk_pack(const float* __restrict__ w, u32x4* __restrict__ out, int T, int cin, int cout,
+                                                  int ks, int qc, int C, int S, int co16s, int mode, long long total) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int lane = (int)(idx & 63);
+  long long frag = idx >> 6;
+  const int s = (int)(frag % S); frag /= S;
+  const int c = (int)(frag % C); frag /= C;
+  const int co16 = (int)(frag % co16s);
+  const int t = (int)(frag / co16s);
+  const int taps = ks * ks;
+  const int co = co16 * 16 + (lane & 15), j = 4 * s + (lane >> 4);
+  const int tap = j / qc, o = j % qc;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int ci = (c * qc + o) * 8 + e;
+    float val = 0.f;
+    if (tap < taps && co < cout && ci < cin)
+      val = mode == 0 ? w[(((size_t)t * cout + co) * cin + ci) * taps + tap]
+                      : w[(((size_t)t * cin + ci) * cout + co) * taps + (taps - 1 - tap)];
+    v[e] = val;
+  }
+  u32x4 p1, p2, p3;
+  split8(v, p1, p2, p3);
+  u32x4* dst = out + ((idx >> 6) * 3) * 64 + lane;
+  dst[0] = p1; dst[64] = p2; dst[128] = p3;
+}
+
+// ---- convolution ---------------------------------------------------------------------------------------------------
+struct ConvkArgs {
+  const float* x;      // [N][cin][H][W]
+  const u32x4* wp;     // packed filter
+  const float* bias;   // [T][cout] or null
+  float* out;          // [N][cout][Ho][Wo]
+  int N, T, cin, cout, H, W, Ho, Wo, pad;
+  int tiles_x, tiles_y, CB, C, co16s;
+  int total, per_xcd, order;
+  float slope;
+};
+
+template <int KS, int QC, int NT, int TW>
+struct ConvkGeom {
+  static constexpr int TH = 256 / TW;
+  static constexpr int ROWS = TH + KS - 1, COLS = TW + KS - 1, POS = ROWS * COLS;
+  static constexpr int OCT = ck_round_up(POS * 16, 256);      // bytes per channel octet (multiple of 256: the four k-groups of a read hit disjoint banks)
+  static constexpr int PLANE = QC * OCT;
+  static constexpr int LDS = 3 * PLANE;
+  static constexpr int TAPS = KS * KS;
+  static constexpr int S = (TAPS * QC + 3) / 4;
+  static constexpr int ITEMS = POS * QC;                       // (position, octet) items of a chunk
+  static constexpr int IPT = (ITEMS + CK_THREADS - 1) / CK_THREADS;
+  static constexpr int MPR = TW / 16;                          // M-tiles per tile row
+};
+
+template <int KS, int QC, int NT, int TW>
+__global__ __launch_bounds__(CK_THREADS, 2) void convk_kernel(const ConvkArgs a) {
+  using G = ConvkGeom<KS, QC, NT, TW>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, px = lane & 15, g = lane >> 4;
+
+  // XCD-contiguous block order: hardware block b runs on XCD b % 8; give each XCD a contiguous range of logical blocks so
+  // that the blocks sharing an input tile (or a filter block) meet in ONE L2
+  const int logical = (int)(blockIdx.x & 7) * a.per_xcd + (int)(blockIdx.x >> 3);
+  if (logical >= a.total) return;
+  int cb, tile;
+  if (a.order == 0) { cb = logical % a.CB; tile = logical / a.CB; }
+  else { const int ntiles = a.total / a.CB; tile = logical % ntiles; cb = logical / ntiles; }
+  const int tx = tile % a.tiles_x;
+  const int ty = (tile / a.tiles_x) % a.tiles_y;
+  const int n = tile / (a.tiles_x * a.tiles_y);
+  const int t = n % a.T;
+  const int y0 = ty * G::TH, x0 = tx * TW;
+
+  const size_t plane_in = (size_t)a.H * a.W;
+  const float* __restrict__ xin = a.x + (size_t)n * a.cin * plane_in;
+
+  // staging geometry of this thread's items (fixed over the chunks): LDS byte offset, global element offset, validity
+  int s_lds[G::IPT], s_goff[G::IPT], s_oct[G::IPT];
+  bool s_ok[G::IPT];
+#pragma unroll
+  for (int k = 0; k < G::IPT; ++k) {
+    const int item = tid + CK_THREADS * k;
+    const int o = item / G::POS, pos = item - o * G::POS;
+    const int r = pos / G::COLS, c = pos - r * G::COLS;
+    const int iy = y0 - a.pad + r, ix = x0 - a.pad + c;
+    s_ok[k] = item < G::ITEMS && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+    s_goff[k] = iy * a.W + ix;
+    s_oct[k] = o;
+    s_lds[k] = item < G::ITEMS ? o * G::OCT + pos * 16 : -1;
+  }
+
+  float stage[G::IPT][8];
+  auto stage_load = [&](int chunk) {
+#pragma unroll
+    for (int k = 0; k < G::IPT; ++k) {
+      const int ci0 = (chunk * QC + s_oct[k]) * 8;
+      const float* p = xin + (size_t)ci0 * plane_in + s_goff[k];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) stage[k][e] = (s_ok[k] && ci0 + e < a.cin) ? p[(size_t)e * plane_in] : 0.f;
+    }
+  };
+  auto stage_write = [&]() {
+#pragma unroll
+    for (int k = 0; k < G::IPT; ++k) {
+      if (s_lds[k] < 0) continue;
+      u32x4 p1, p2, p3;
+      split8(stage[k], p1, p2, p3);
+      *reinterpret_cast<u32x4*>(smem + s_lds[k]) = p1;
+      *reinterpret_cast<u32x4*>(smem + G::PLANE + s_lds[k]) = p2;
+      *reinterpret_cast<u32x4*>(smem + 2 * G::PLANE + s_lds[k]) = p3;
+    }
+  };
+
+  // A-fragment base addresses of the wave's four M-tiles (pixel px of tile i), without tap / octet
+  int abase[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = wv * (4 / G::MPR) + i / G::MPR, col = 16 * (i % G::MPR) + px;
+    abase[i] = (row * G::COLS + col) * 16;
+  }
+  // B fragments: wp + ((((t co16s + cb NT + nn) C + c) S + s) 3 + plane) 64 + lane
+  const u32x4* __restrict__ wbase = a.wp + ((size_t)((size_t)t * a.co16s + (size_t)cb * NT) * a.C * G::S * 3) * 64 + lane;
+  const size_t wtile = (size_t)a.C * G::S * 3 * 64;            // stride between 16-channel blocks
+
+  f32x4 acc[4][NT];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int nn = 0; nn < NT; ++nn) acc[i][nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  stage_load(0);
+  for (int c = 0; c < a.C; ++c) {
+    stage_write();
+    __syncthreads();
+    if (c + 1 < a.C) stage_load(c + 1);          // in flight while this chunk's MFMAs issue
+    const u32x4* __restrict__ wc = wbase + (size_t)c * G::S * 3 * 64;
+#pragma unroll
+    for (int s = 0; s < G::S; ++s) {
+      const int j = 4 * s + g;
+      int tap = j / QC;
+      const int o = j % QC;
+      tap = tap < G::TAPS ? tap : G::TAPS - 1;   // padding slots of the last step: any valid address (their weights are zero)
+      const int ky = tap / KS, kx = tap - ky * KS;
+      const int aoff = o * G::OCT + (ky * G::COLS + kx) * 16;
+      bf16x8 bq[NT][3], aq[4][3];
+#pragma unroll
+      for (int nn = 0; nn < NT; ++nn)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          const u32x4 raw = wc[(size_t)nn * wtile + (s * 3 + p) * 64];
+          bq[nn][p] = __builtin_bit_cast(bf16x8, raw);
+        }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) aq[i][p] = *reinterpret_cast<const bf16x8*>(smem + p * G::PLANE + abase[i] + aoff);
+      // six products per tile, spread over the 4 x NT accumulators (no back-to-back dependence), small terms first
+      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+      for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int nn = 0; nn < NT; ++nn)
+            acc[i][nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[i][PA[q]], bq[nn][PB[q]], acc[i][nn], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: lane holds pixels 4 g .. 4 g + 3 of M-tile i (rows of D) for channel 16 nn + px (column of D)
+  const size_t plane_out = (size_t)a.Ho * a.Wo;
+  float* __restrict__ outn = a.out + (size_t)n * a.cout * plane_out;
+  const bool vec_ok = (a.Wo & 3) == 0;
+#pragma unroll
+  for (int nn = 0; nn < NT; ++nn) {
+    const int co = (cb * NT + nn) * 16 + px;
+    if (co >= a.cout) continue;
+    const float b = a.bias ? a.bias[(size_t)t * a.cout + co] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int oy = y0 + wv * (4 / G::MPR) + i / G::MPR;
+      const int ox = x0 + 16 * (i % G::MPR) + 4 * g;
+      if (oy >= a.Ho || ox >= a.Wo) continue;
+      f32x4 v = acc[i][nn];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float u = v[r] + b;
+        v[r] = u > 0.f ? u : u * a.slope;
+      }
+      float* dst = outn + (size_t)co * plane_out + (size_t)oy * a.Wo + ox;
+      if (vec_ok && ox + 3 < a.Wo) {
+        *reinterpret_cast<f32x4*>(dst) = v;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (ox + r < a.Wo) dst[r] = v[r];
+      }
+    }
+  }
+}
+
+template <int KS, int QC, int NT, int TW>
+int launch_convk(const ConvkArgs& a, hipStream_t stream) {
+  using G = ConvkGeom<KS, QC, NT, TW>;
+  static uint32_t configured = 0;
+  auto kern = convk_kernel<KS, QC, NT, TW>;
+  if (G::LDS > 64 * 1024) {
+    const int rc = savfi_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), G::LDS, configured);
+    if (rc != SAVFI_OK) return rc;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.per_xcd * 8), dim3(CK_THREADS), G::LDS, stream, a);
+  return savfi_launch_status();
+}
+
+template <int KS, int QC>
+int dispatch_nt_tw(const ConvkArgs& a, int nt, int tw, hipStream_t stream) {
+  if (tw == 32) {
+    if (nt == 4) return launch_convk<KS, QC, 4, 32>(a, stream);
+    if (nt == 2) return launch_convk<KS, QC, 2, 32>(a, stream);
+    return launch_convk<KS, QC, 1, 32>(a, stream);
+  }
+  if (nt == 4) return launch_convk<KS, QC, 4, 16>(a, stream);
+  if (nt == 2) return launch_convk<KS, QC, 2, 16>(a, stream);
+  return launch_convk<KS, QC, 1, 16>(a, stream);
+}
+
+int dispatch_convk(const ConvkArgs& a, int ks, int qc, int nt, int tw, hipStream_t stream) {
+  if (ks == 3) {
+    if (qc == 4) return dispatch_nt_tw<3, 4>(a, nt, tw, stream);
+    if (qc == 2) return dispatch_nt_tw<3, 2>(a, nt, tw, stream);
+    return dispatch_nt_tw<3, 1>(a, nt, tw, stream);
+  }
+  if (ks == 5) {
+    if (qc == 2) return dispatch_nt_tw<5, 2>(a, nt, tw, stream);
+    return dispatch_nt_tw<5, 1>(a, nt, tw, stream);
+  }
+  if (qc == 2) return dispatch_nt_tw<7, 2>(a, nt, tw, stream);
+  return dispatch_nt_tw<7, 1>(a, nt, tw, stream);
+}
+
+inline bool ck_supported_k(int k) { return k == 3 || k == 5 || k == 7; }
+
+}  // namespace
+
+extern "C" int64_t savfi_convk_filter_floats(int T, int Ci, int Co, int K, int mode) {
+  if (T <= 0 || Ci <= 0 || Co <= 0) return SAVFI_E_SHAPE;
+  if (!ck_supported_k(K) || (mode != 0 && mode != 1)) return SAVFI_E_UNSUPPORTED;
+  const int cin = mode == 0 ? Ci : Co, cout = mode == 0 ? Co : Ci;
+  const int qc = ck_qc(cin, K);
+  return (int64_t)T * ck_round_up((cout + 15) / 16, 4) * ck_chunks(cin, qc) * ck_steps(K, qc) * 3 * 64 * 4;   // 4-byte units
+}
+
+extern "C" int savfi_convk_filters_f32(const float* w, float* p_fwd, float* p_bwd, int T, int Ci, int Co, int K, void* stream) {
+  if (!w || (!p_fwd && !p_bwd)) return SAVFI_E_NULL;
+  if (T <= 0 || Ci <= 0 || Co <= 0) return SAVFI_E_SHAPE;
+  if (!ck_supported_k(K)) return SAVFI_E_UNSUPPORTED;
+  for (int mode = 0; mode < 2; ++mode) {
+    float* dst = mode == 0 ? p_fwd : p_bwd;
+    if (!dst) continue;
+    const int cin = mode == 0 ? Ci : Co, cout = mode == 0 ? Co : Ci;
+    const int qc = ck_qc(cin, K), C = ck_chunks(cin, qc), S = ck_steps(K, qc), co16s = ck_round_up((cout + 15) / 16, 4);
+    const long long total = (long long)T * co16s * C * S * 64;
+    hipLaunchKernelGGL(convk_pack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
+                       reinterpret_cast<u32x4*>(dst), T, cin, cout, K, qc, C, S, co16s, mode, total);
+    const int rc = savfi_launch_status();
+    if (rc != SAVFI_OK) return rc;
+  }
+  return SAVFI_OK;
+}
+
+extern "C" int savfi_convk_tasks_pre_f32(const float* x, const float* packed, const float* bias, float* out, int N, int T, int Ci,
+                                         int Co, int H, int W, int K, int pad, int mode, float slope, void* stream) {
+  if (!x || !packed || !out) return SAVFI_E_NULL;
+  if (N <= 0 || T <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0 || N % T != 0 || pad < 0 || pad > K - 1) return SAVFI_E_SHAPE;
+  if (!ck_supported_k(K) || (mode != 0 && mode != 1)) return SAVFI_E_UNSUPPORTED;
+  ConvkArgs a;
+  a.x = x; a.wp = reinterpret_cast<const u32x4*>(packed); a.bias = bias; a.out = out;
+  a.N = N; a.T = T; a.H = H; a.W = W;
+  a.cin = mode == 0 ? Ci : Co; a.cout = mode == 0 ? Co : Ci;
+  a.pad = mode == 0 ? pad : K - 1 - pad;
+  a.Ho = H + 2 * a.pad - K + 1; a.Wo = W + 2 * a.pad - K + 1;
+  if (a.Ho <= 0 || a.Wo <= 0) return SAVFI_E_SHAPE;
+  if ((int64_t)a.cin * H * W >= (1ll << 31) || (int64_t)a.cout * a.Ho * a.Wo >= (1ll << 31)) return SAVFI_E_TOOBIG;
+  a.slope = slope;
+  const int qc = ck_qc(a.cin, K);
+  a.C = ck_chunks(a.cin, qc);
+  a.co16s = ck_round_up((a.cout + 15) / 16, 4);       // packed filter blocks (zero padded to a multiple of 4)
+  // tile shape: the better-filled of 8 x 32 and 16 x 16
+  auto fill = [&](int th, int tw) { return (double)a.Ho * a.Wo / ((double)((a.Ho + th - 1) / th * th) * ((a.Wo + tw - 1) / tw * tw)); };
+  const int tw = fill(16, 16) > fill(8, 32) + 1e-9 ? 16 : 32;
+  const int th = 256 / tw;
+  a.tiles_x = (a.Wo + tw - 1) / tw; a.tiles_y = (a.Ho + th - 1) / th;
+  const int64_t tiles = (int64_t)N * a.tiles_x * a.tiles_y;
+  // output channels per workgroup: 64 unless that wastes a half-empty block or leaves the GPU under-filled
+  int nt = 4;
+  const int rem = a.cout % 64;
+  if (a.cout <= 16) nt = 1;
+  else if (a.cout <= 32 || (rem != 0 && rem <= 32 && a.cout < 128)) nt = 2;
+  else if (tiles * ((a.cout + 63) / 64) < 512 && a.cout >= 64) nt = 2;
+  a.CB = ((a.cout + 15) / 16 + nt - 1) / nt;
+  if (tiles * a.CB >= (1ll << 30)) return SAVFI_E_TOOBIG;
+  a.total = (int)(tiles * a.CB);
+  a.per_xcd = (a.total + 7) / 8;
+  // blocks that share an input tile next to each other, unless the filter is the larger object
+  const int64_t w_bytes = (int64_t)a.co16s * 16 * a.cin * K * K * 6, in_bytes = (int64_t)a.cin * H * W * 4 * (N / T);
+  a.order = w_bytes > in_bytes ? 1 : 0;
+  return dispatch_convk(a, K, qc, nt, tw, (hipStream_t)stream);
+}

@@ -318,21 +318,28 @@ class OuterGradAccumulator:
         if other.lr:
             self.add_lr_tensors(list(other.lr.keys()), list(other.lr.values()))
 
-    def install(self, num_tasks):
-        """Write the accumulated gradients (mean over the GLOBAL meta-batch) into .grad."""
+    def install(self, num_tasks, into=None):
+        """Write the accumulated gradients (mean over the GLOBAL meta-batch) into .grad.  `into` = {param: preassigned .grad
+        view} (task parallelism: the views of the all-reduce bucket, TaskParallel.prepare_gradients): the sums are copied there
+        instead of re-binding .grad; returns the parameters that received a gradient."""
         inv = 1.0 / float(num_tasks)
         rates = self.sys.inner_loop_optimizer.names_learning_rates_dict
+        pairs = []
         if self.lr_rows is not None:
             cols = self.lr_rows.t().mul(inv).contiguous()            # [tensor, step]
             for i, lk in enumerate(self.lr_keys):
                 p = rates[lk]
                 if p.requires_grad:
-                    rates[lk].grad = cols[i, :p.numel()].reshape(p.shape)
+                    pairs.append((p, cols[i, :p.numel()].reshape(p.shape)))
         if self.param:
             torch._foreach_mul_(list(self.param.values()), inv)
-        for k, g in self.param.items():
-            self.theta[k].grad = g
+        pairs += [(self.theta[k], g) for k, g in self.param.items()]
         if self.lr:
             torch._foreach_mul_(list(self.lr.values()), inv)
-        for lk, g in self.lr.items():
-            rates[lk].grad = g
+        pairs += [(rates[lk], g) for lk, g in self.lr.items()]
+        if into is None:
+            for p, g in pairs:
+                p.grad = g
+        elif pairs:
+            torch._foreach_copy_([into[p] for p, _ in pairs], [g.view_as(into[p]) for p, g in pairs])
+        return [p for p, _ in pairs]

@@ -755,6 +755,40 @@ def conv3x3_tasks_pre(x, u, T, Ci, Co, bias=None, mode=0, slope=1.0, pad=1):
     return out
 
 
+def convk_filters(weight, fwd=True, bwd=True):
+    """savfi_convk_filters_f32: weight [T,Co,Ci,K,K] (or [Co,Ci,K,K]) packed as bf16 triples in MFMA fragment order for the
+    forward pass and / or the data gradient of the direct K x K convolution, in one call.  Returns (p_fwd, p_bwd)."""
+    weight = weight.contiguous()
+    _hip.require_cuda(weight)
+    T, Co, Ci = (1,) + tuple(weight.shape[:2]) if weight.dim() == 4 else tuple(weight.shape[:3])
+    K = int(weight.shape[-1])
+    assert weight.shape[-2] == K and (fwd or bwd), weight.shape
+    lib = _hip.lib()
+    ps = [torch.empty(_workspace_floats("savfi_convk_filter_floats", T, Ci, Co, K, mode), dtype=torch.float32, device=weight.device)
+          if want else None for mode, want in ((0, fwd), (1, bwd))]
+    _hip.launch("convk_filters", lambda: _hip.check(lib.savfi_convk_filters_f32(
+        weight.data_ptr(), None if ps[0] is None else ps[0].data_ptr(), None if ps[1] is None else ps[1].data_ptr(), T, Ci, Co, K,
+        _hip.current_stream()), "savfi_convk_filters_f32"))
+    return ps[0], ps[1]
+
+
+def convk_tasks_pre(x, packed, T, Ci, Co, K, bias=None, mode=0, slope=1.0, pad=1):
+    """savfi_convk_tasks_pre_f32: direct K x K convolution (mode 0, + bias + activation) or its data gradient (mode 1) on a
+    filter packed by convk_filters (same mode); sample n uses filter set n % T."""
+    x = x.contiguous()
+    _hip.require_cuda(x, packed)
+    N, _, H, W = x.shape
+    assert N % T == 0 and x.shape[1] == (Ci if mode == 0 else Co), (x.shape, T, Ci, Co, mode)
+    I = Co if mode == 0 else Ci
+    p_eff = pad if mode == 0 else K - 1 - pad
+    out = torch.empty((N, I, H + 2 * p_eff - K + 1, W + 2 * p_eff - K + 1), dtype=x.dtype, device=x.device)
+    lib = _hip.lib()
+    _hip.launch("convk_fwd" if mode == 0 else "convk_bwd_data", lambda: _hip.check(lib.savfi_convk_tasks_pre_f32(
+        x.data_ptr(), packed.data_ptr(), None if bias is None else bias.data_ptr(), out.data_ptr(), N, T, Ci, Co, H, W, K, int(pad),
+        mode, float(slope), _hip.current_stream()), "savfi_convk_tasks_pre_f32"))
+    return out
+
+
 def conv3x3_wgrad_tasks(x, gz, T, pad=1, stream=None, extra_stream=None):
     """savfi_conv3x3_wgrad_tasks_f32: gw [T,Co,Ci,3,3], gw[t] over the samples n % T == t.  `stream` / `extra_stream`: as in
     conv3x3_wgrad (launch on a side stream, buffers from the current stream's pool)."""

@@ -400,10 +400,13 @@ class SceneAdaptiveInterpolation(nn.Module):
         width = int(getattr(self.args, 'task_batch', 0) or 0)
         if width <= 1 or use_second_order:
             return 0
-        if not getattr(self.net, 'lockstep_tasks', True) and not os.environ.get('SAVFI_LOCKSTEP_ALL'):
-            # the plugin opts out: its per-task convolutions would fall to MIOpen's GROUPED solvers (VoxelFlow's bias-free 5x5
-            # layers: 1.5-3.5 ms per call at 256x256, config C3 drops from 135 to 78 steps/s)
+        if not getattr(self.net, 'lockstep_tasks', False) and not os.environ.get('SAVFI_LOCKSTEP_ALL'):
+            # lockstep is OPT-IN per plugin (class attribute `lockstep_tasks = True`): the pass stacks the tasks' samples into
+            # one [n*T, ...] batch and hands 5-D stacked weights to MetaConv2dLayer, which is only right for a plugin whose
+            # samples never interact (no train-mode BatchNorm) and that reads fast weights through the meta layers only
             return 0
+        if not hasattr(self.criterion, 'per_sample'):
+            return 0        # a user criterion without per-sample rows: the sequential loop calls it once per task
         if self.args.attenuate and self._routing(frame_shape)[1]:
             return 0
         return width
@@ -801,12 +804,17 @@ class SceneAdaptiveInterpolation(nn.Module):
     def meta_update(self, loss):
         """zero_grad -> backward -> (all-reduce of outer grads) -> optimizer step  (reference :551-574)."""
         self.optimizer.zero_grad()
+        params = list(self.trainable_parameters())
+        # task parallelism: .grad = zeroed views of the flat all-reduce bucket, filled in place by the backward pass
+        views = self.task_parallel.prepare_gradients(params)
         if self._manual_grads is not None:        # graphed forward: first-order outer gradients assembled by hand
-            self._manual_grads.install(self._manual_grads.num_tasks)
+            reached = self._manual_grads.install(self._manual_grads.num_tasks, into=views)
+            if views is not None:
+                self.task_parallel.mark_touched(reached)
             self._manual_grads = None
         elif loss.requires_grad:
             loss.backward()
-        self.task_parallel.allreduce_gradients(list(self.trainable_parameters()))
+        self.task_parallel.allreduce_gradients(params)
         self.optimizer.step()
 
     def run_train_iter(self, data_batch, epoch, do_evaluation=False):

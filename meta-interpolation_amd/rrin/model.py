@@ -92,6 +92,7 @@ def warp(img, flow):
 
 
 class MetaRRIN(nn.Module):
+    lockstep_tasks = True     # verified against the sequential loop and the reference fixtures (tests/test_system_gpu.py)
     def __init__(self, level=3, resume=False):
         super().__init__()
         self.Mask = MetaUNet(16, 2, 4)

@@ -62,6 +62,7 @@ _DECODER = [("moduleDeconv5", 512, 512), ("moduleDeconv4", 512, 256), ("moduleDe
 
 
 class MetaNetwork(nn.Module):
+    lockstep_tasks = True     # verified against the sequential loop and the reference fixtures (tests/test_system_gpu.py)
     def __init__(self, resume=False, strModel='lf', windowed=True):
         super().__init__()
         self.windowed = bool(windowed)

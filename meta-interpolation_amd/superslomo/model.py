@@ -121,6 +121,7 @@ def _time_coefficients(ind):
 
 
 class MetaSuperSloMo(nn.Module):
+    lockstep_tasks = True     # verified against the sequential loop and the reference fixtures (tests/test_system_gpu.py)
     def __init__(self, device=None, resume=False):
         super().__init__()
         self.device = device

@@ -55,8 +55,12 @@ class TaskParallel:
             self.world = dist.get_world_size(group)
         else:
             self.rank, self.world = 0, 1
-        self._bucket = None
-        self._presence = {}     # local have-pattern -> reduced presence (see allreduce_gradients)
+        self._bucket = None     # flat fp32 buffer: every trainable gradient + one presence flag per parameter
+        self._bucket_key = None
+        self._views = None      # per-parameter views of the bucket (these ARE the .grad tensors during an outer step)
+        self._flag_cache = {}   # local presence pattern -> device tensor of flags
+        self._touched = set()   # id(param) of the parameters the current backward pass reached
+        self._hooked = set()
 
     @property
     def active(self):
@@ -67,6 +71,41 @@ class TaskParallel:
         return [t for t in range(num_tasks) if t % self.world == self.rank]
 
     # -- the one collective of a meta-iteration ---------------------------------------------
+    def _ensure_bucket(self, params):
+        sizes = [p.numel() for p in params]
+        total = sum(sizes)
+        dev = params[0].device
+        key = (tuple(id(p) for p in params), tuple(sizes), str(dev))
+        if self._bucket is None or self._bucket_key != key:
+            self._bucket = torch.empty(total + len(params), dtype=torch.float32, device=dev)
+            self._bucket_key = key
+            self._views = [v.view_as(p) for v, p in zip(self._bucket[:total].split(sizes), params)]
+            self._flag_cache = {}
+            for p in params:        # which parameters a backward pass reached is recorded on the HOST (no device sync)
+                if id(p) not in self._hooked:
+                    self._hooked.add(id(p))
+                    p.register_post_accumulate_grad_hook(lambda q, _t=self._touched: _t.add(id(q)))
+        return self._bucket, self._views
+
+    def prepare_gradients(self, params):
+        """Before the outer backward: every .grad becomes a zeroed VIEW of the flat bucket, so autograd accumulates straight
+        into the buffer that is all-reduced (no copy into the bucket, none back out).  Returns {param: view} (the graphed
+        path writes its hand-assembled gradients there, then calls mark_touched) or None for a single process."""
+        if not self.active:
+            return None
+        params = [p for p in params]
+        if not params:
+            return None
+        bucket, views = self._ensure_bucket(params)
+        bucket.zero_()
+        self._touched.clear()
+        for p, v in zip(params, views):
+            p.grad = v
+        return dict(zip(params, views))
+
+    def mark_touched(self, params):
+        self._touched.update(id(p) for p in params)
+
     def allreduce_gradients(self, params):
         """SUM-reduce .grad of `params` (fixed order on every rank) through one flat bucket.
         A parameter that received no gradient locally contributes zeros; it ends with a gradient iff
@@ -76,41 +115,38 @@ class TaskParallel:
         params = [p for p in params]
         if not params:
             return
-        sizes = [p.numel() for p in params]
-        total = sum(sizes)
-        dev, dt = params[0].device, torch.float32
-        if self._bucket is None or self._bucket.numel() != total + len(params) or self._bucket.device != dev:
-            self._bucket = torch.empty(total + len(params), dtype=dt, device=dev)
-        bucket = self._bucket
-        views = list(bucket[:total].split(sizes))
-        flags = bucket[total:]
-        have = [p.grad is not None for p in params]
-        flags.copy_(torch.tensor([1.0 if h else 0.0 for h in have], dtype=dt), non_blocking=True)
-        src = [p.grad.reshape(-1) for p, h in zip(params, have) if h]
-        dst = [v for v, h in zip(views, have) if h]
-        if src:
-            torch._foreach_copy_(dst, src)
-        for v, h in zip(views, have):
-            if not h:
-                v.zero_()
+        bucket, views = self._ensure_bucket(params)
+        total = bucket.numel() - len(params)
+        prepared = all(p.grad is v for p, v in zip(params, views))
+        if prepared:            # gradients already live in the bucket (prepare_gradients): nothing to copy
+            have = [id(p) in self._touched for p in params]
+        else:                   # stand-alone use: gather whatever .grad tensors exist
+            have = [p.grad is not None for p in params]
+            src = [p.grad.reshape(-1) for p, h in zip(params, have) if h]
+            dst = [v.reshape(-1) for v, h in zip(views, have) if h]
+            if src:
+                torch._foreach_copy_(dst, src)
+            for v, h in zip(views, have):
+                if not h:
+                    v.zero_()
+        key = tuple(have)
+        dev_flags = self._flag_cache.get(key)
+        if dev_flags is None:   # one H2D per presence pattern, device-to-device afterwards
+            dev_flags = self._flag_cache[key] = torch.tensor([1.0 if h else 0.0 for h in have], dtype=torch.float32).to(bucket.device)
+        bucket[total:].copy_(dev_flags, non_blocking=True)
         dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group)
         # A parameter ends with a gradient iff some rank produced one (a None gradient makes the optimizer skip it: no weight
-        # decay, no moment update -- zeros would not be the same thing).  Which parameters receive gradients is a property
-        # of the configuration, not of the iteration (every non-empty shard produces the same set), so the reduced presence
-        # flags are fetched ONCE per local pattern and not in steady state: no host sync on the hot path.
-        if all(have):
-            keep_all = have
-        else:
-            key = tuple(have)
-            keep_all = self._presence.get(key)
-            if keep_all is None:
-                keep_all = self._presence[key] = (flags.cpu() > 0).tolist()
-        back = [(p.grad, v.view_as(p.grad)) for p, v, h in zip(params, views, have) if h]
-        if back:
-            torch._foreach_copy_([g for g, _ in back], [v for _, v in back])
+        # decay, no moment update -- zeros would not be the same thing).  When this rank produced every gradient itself the
+        # answer is known without looking; otherwise (an empty or partial shard: the rare case) the reduced flags are fetched,
+        # every time -- which parameters the OTHER ranks reached can change with the pass (MSL epochs ending, eager vs graphed).
+        keep_all = have if all(have) else (bucket[total:].cpu() > 0).tolist()
         for p, v, h, keep in zip(params, views, have, keep_all):
-            if keep and not h:
-                p.grad = v.view_as(p).clone()
+            if not keep:
+                p.grad = None
+            elif prepared or not h:
+                p.grad = v          # the reduced sum, in place in the bucket
+            else:
+                p.grad.copy_(v)
 
     def allreduce_scalars(self, values):
         """SUM a small list/1-D tensor of logging scalars; returns a tensor on the input's device."""

@@ -10,6 +10,10 @@ shims as gen_golden.py, no reference file modified -- at the sizes BASELINE.json
     c3_voxelflow_256x256_s5      VoxelFlow, Meta-SGD + Adamax, 5 inner steps, 256x256    (config C3; + the reference's own
                                  spread under another conv summation order / float64, like gen_sensitivity.py)
     c3sgd_voxelflow_256x256_s5   the same with the smooth LSLR + SGD rule
+    c2b4_sepconv_256x448_s5      config C2 as benchmarked: the reference's run_train_iter over a meta-batch of FOUR tasks (seeds
+                                 1234+t) -- what the product adapts in lockstep (T=4) / from graphs on task streams
+    c4_sepconv_msl_256x448_s5    one GPU's share of config C4: 4 tasks, MAML++ multi-step loss (a weighted target pass after
+                                 every inner step) + learnable per-layer per-step learning rates
     c5_cain_l2f_720p             CAIN + L2F attenuation, 1 inner step, 1280x720, run_train_iter   (config C5)
     c5eval_cain_l2f_720p         the reference's ExperimentBuilder.evaluation_iteration (experiment_builder.py:93-148) on the
                                  same clip: 720x1280 > 5e5 pixels, so two 720x640 halves are adapted separately and stitched
@@ -39,6 +43,15 @@ CASES = {
     'c2_sepconv_256x448_s5': ('sepconv', 256, 448, dict(optimizer='SGD', inner_lr=1e-3, loss='1*L1',
                                                          number_of_training_steps_per_iter=5,
                                                          number_of_evaluation_steps_per_iter=5)),
+    'c2b4_sepconv_256x448_s5': ('sepconv', 256, 448, dict(optimizer='SGD', inner_lr=1e-3, loss='1*L1',
+                                                           number_of_training_steps_per_iter=5,
+                                                           number_of_evaluation_steps_per_iter=5)),
+    'c4_sepconv_msl_256x448_s5': ('sepconv', 256, 448, dict(optimizer='SGD', inner_lr=1e-3, loss='1*L1',
+                                                             number_of_training_steps_per_iter=5,
+                                                             number_of_evaluation_steps_per_iter=5,
+                                                             use_multi_step_loss_optimization=True,
+                                                             multi_step_loss_num_epochs=10,
+                                                             learnable_per_layer_per_step_inner_loop_learning_rate=True)),
     'c3_voxelflow_256x256_s5': ('voxelflow', 256, 256, dict(optimizer='Adamax', inner_lr=1e-5, metasgd=True, loss='1*MSE',
                                                              number_of_training_steps_per_iter=5,
                                                              number_of_evaluation_steps_per_iter=5)),
@@ -48,14 +61,15 @@ CASES = {
     'c5_cain_l2f_720p': ('cain', 720, 1280, dict(optimizer='SGD', inner_lr=1e-3, attenuate=True, loss='1*L1')),
     'c5eval_cain_l2f_720p': ('cain', 720, 1280, dict(optimizer='SGD', inner_lr=1e-3, attenuate=True, loss='1*L1')),
 }
+TASKS = {'c2b4_sepconv_256x448_s5': 4, 'c4_sepconv_msl_256x448_s5': 4}      # meta-batch size (default 1)
 SPREAD_FOR = {'c3_voxelflow_256x256_s5', 'c3sgd_voxelflow_256x256_s5', 'c2_sepconv_256x448_s5'}
 Q_LO, Q_HI = -0.25, 1.25
 
 
-def pack_pred(pred):
+def pack_pred(pred, compact=False):
     """[3,H,W] float tensor -> dict of arrays (see the module docstring)."""
     p = pred.detach().float()
-    if p.shape[-2] * p.shape[-1] <= 256 * 448:
+    if p.shape[-2] * p.shape[-1] <= 256 * 448 and not compact:
         return {'pred': p.numpy()}
     q = ((p[:, ::2, ::2].clamp(Q_LO, Q_HI) - Q_LO) / (Q_HI - Q_LO) * 65535.0).round().numpy().astype(np.uint16)
     return {'pred_u16_stride2': q, 'pred_q_range': np.array([Q_LO, Q_HI])}
@@ -71,8 +85,9 @@ def seed_attenuator(system):
 
 def run_train(name, variant='base'):
     model, H, W, over = CASES[name]
-    args = G.reference_args(model=model, batch_size=1, **over)
-    frames = synthetic.septuplet_batch(1, H, W, model=model)
+    B = TASKS.get(name, 1)
+    args = G.reference_args(model=model, batch_size=B, **over)
+    frames = synthetic.septuplet_batch(B, H, W, model=model)
     torch.manual_seed(0)
     torch.nn.functional.conv2d = {'perm': S._conv2d_perm, 'perm2': S._conv2d_perm2}.get(variant, S._ORIG_CONV2D)
     try:
@@ -113,12 +128,14 @@ def gen_train_case(name):
     model, H, W, over = CASES[name]
     t0 = time.time()
     base = run_train(name)
-    out = {'model': np.array(model), 'H': H, 'W': W, 'B': 1, 'args': np.array(repr(sorted(over.items()))),
+    out = {'model': np.array(model), 'H': H, 'W': W, 'B': TASKS.get(name, 1), 'args': np.array(repr(sorted(over.items()))),
            'train_loss': np.float64(base['loss']), 'train_psnr': np.float64(base['psnr']), 'train_ssim': np.float64(base['ssim']),
            'train_n_live': np.array(base['rec']['n_live'])}
     for k, v in base['parts'].items():
         out['train_part_' + k] = np.float64(v)
     out.update({'train_' + k: v for k, v in pack_pred(torch.from_numpy(base['preds'][0])).items()})
+    for t in range(1, TASKS.get(name, 1)):       # further tasks of the meta-batch: the compact form (keeps the fixture small)
+        out.update({'train_task%d_%s' % (t, k): v for k, v in pack_pred(torch.from_numpy(base['preds'][t]), compact=True).items()})
     G.pack_fp('train_grad_fp', base['rec']['grad_fp'], out)
     G.pack_fp('train_weight_fp', base['rec']['weight_fp'], out)
     G.pack_fp('outer_grad_fp', [base['rec']['outer_grad_fp']], out)

@@ -155,6 +155,7 @@ class OracleRule(torch.nn.Module):
 
 class ToyNet(torch.nn.Module):
     """Two-conv interpolation plugin built from the product's Meta layers (CPU-capable: conv2d only)."""
+    lockstep_tasks = True      # samples never interact, fast weights only through the meta layers
 
     def __init__(self):
         super().__init__()
