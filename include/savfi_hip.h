@@ -29,7 +29,7 @@
  *   savfi_conv3x3_tasks_f32, savfi_conv3x3_wgrad_tasks_f32   the same for T tasks with their own fast weights in ONE launch
  *   savfi_conv3x3_filters_f32, savfi_conv3x3_tasks_pre_f32   filter transforms of forward + data gradient in one launch / convolution on a transformed filter
  *                              (the sequential task loop meta_learning_system.py:366 run in lockstep)
- *   savfi_convk_filters_f32, savfi_convk_tasks_pre_f32   F.conv2d K x K (K = 3, 5, 7) / stride 1 and its data gradient as a direct
+ *   savfi_convk_filters_f32, savfi_convk_tasks_pre_f32, savfi_convk_wgrad_tasks_f32   F.conv2d K x K (K = 3, 5, 7) / stride 1 and its data gradient as a direct
  *                              implicit GEMM on the bf16 matrix cores from error-free 3-way operand splits (fp32-equivalent)
  *                                                                     voxelflow/core/models/voxel_flow.py:357-470 (5x5 layers),
  *                                                                     superslomo/model.py:547-646 (7x7 / 5x5), model_utils.py:308-366
@@ -303,11 +303,20 @@ int savfi_conv3x3_wgrad_wino_tasks_f32(const float* x, const float* gz, float* g
  *   savfi_convk_tasks_pre_f32   mode 0: out[N,Co,H+2p-K+1,W+2p-K+1] = act(conv2d(x[N,Ci,H,W], w, pad p) + bias[T,Co])
  *                               mode 1: x = gy[N,Co,H,W] -> out = gx[N,Ci,H+K-1-2p,W+K-1-2p]   (bias ignored, pass slope 1)
  *                               `packed` = the buffer of the same mode from savfi_convk_filters_f32
+ *                               `precise` != 0: the five cross terms accumulate apart from the a1b1 sum (3x closer to float64
+ *                               than an fp32 fmaf chain; for networks that amplify convolution rounding, ~10-15 % slower)
  * ---------------------------------------------------------------------------------- */
 int64_t savfi_convk_filter_floats(int T, int Ci, int Co, int K, int mode);
 int savfi_convk_filters_f32(const float* w, float* p_fwd, float* p_bwd, int T, int Ci, int Co, int K, void* stream);
 int savfi_convk_tasks_pre_f32(const float* x, const float* packed, const float* bias, float* out, int N, int T, int Ci,
-                              int Co, int H, int W, int K, int pad, int mode, float slope, void* stream);
+                              int Co, int H, int W, int K, int pad, int mode, float slope, int precise, void* stream);
+
+/* Weight gradient of the same convolution (same arithmetic; deterministic: per-workgroup partial blocks added in a fixed order):
+ *   gw[T,Co,Ci,K,K], gw[t] = sum over samples n with n % T == t, y, x of gz[n,co,y,x] * x[n,ci,y+ky-pad,x+kx-pad]
+ *   x [N,Ci,H,W], gz [N,Co,H+2pad-K+1,W+2pad-K+1]; `workspace`: savfi_convk_wgrad_workspace_floats(...) floats, caller-owned. */
+int64_t savfi_convk_wgrad_workspace_floats(int N, int T, int Ci, int Co, int H, int W, int K, int pad);
+int savfi_convk_wgrad_tasks_f32(const float* x, const float* gz, float* gw, float* workspace, int N, int T, int Ci, int Co,
+                                int H, int W, int K, int pad, int precise, void* stream);
 
 /* ----------------------------------------------------------------------------------
  * Frame staging (data/vimeo_septuplet.py:68-80, data/video.py:44-51: channel swap, HWC->CHW, .float()/255,

@@ -72,7 +72,9 @@ _PROTOTYPES = {
     "savfi_conv3x3_wgrad_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P],
     "savfi_convk_filter_floats": [c_int] * 5,
     "savfi_convk_filters_f32": [_P, _P, _P, c_int, c_int, c_int, c_int, _P],
-    "savfi_convk_tasks_pre_f32": [_P, _P, _P, _P] + [c_int] * 9 + [c_float, _P],
+    "savfi_convk_tasks_pre_f32": [_P, _P, _P, _P] + [c_int] * 9 + [c_float, c_int, _P],
+    "savfi_convk_wgrad_workspace_floats": [c_int] * 8,
+    "savfi_convk_wgrad_tasks_f32": [_P, _P, _P, _P] + [c_int] * 9 + [_P],
     "savfi_frames_u8_to_f32": [_P, _P, c_int64, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float, _P],
     "savfi_upsample2x_window_fwd_f32": [_P, _P] + [c_int] * 12 + [_P],
     "savfi_upsample2x_window_bwd_f32": [_P, _P] + [c_int] * 12 + [_P],

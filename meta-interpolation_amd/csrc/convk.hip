@@ -34,9 +34,22 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ float ck_raw_buffer_load_f32(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
+
 namespace {
 
 constexpr int CK_THREADS = 256;
+
+__device__ __forceinline__ i32x4 ck_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long p = reinterpret_cast<unsigned long long>(base);
+  i32x4 r;
+  r.x = (int)(unsigned)p;
+  r.y = (int)(unsigned)(p >> 32);       // stride 0: raw buffer
+  r.z = (int)bytes;
+  r.w = 0x00020000;
+  return r;
+}
 
 __host__ __device__ constexpr int ck_round_up(int a, int b) { return (a + b - 1) / b * b; }
 
@@ -129,7 +142,12 @@ struct ConvkGeom {
   static constexpr int MPR = TW / 16;                          // M-tiles per tile row
 };
 
-template <int KS, int QC, int NT, int TW>
+// P2 ("precise"): the five cross terms a1b2 .. a2b2 of a tile accumulate in their OWN registers and meet the a1b1 sum in the
+// epilogue.  One accumulator takes six roundings per k-step at the magnitude of the running sum (error of an fp32 fmaf chain);
+// split, the large sum takes one (of exact 16-bit-mantissa products) and the small one rounds 2^-8 lower: 3x closer to
+// float64 (tools/bf16_split_probe.hip "2 accumulators"), better than a blocked fp32 CPU convolution.  For networks that
+// amplify conv rounding (VoxelFlow's flow-to-pixel map: ~1000x into its gradients); costs the registers of half the tile.
+template <int KS, int QC, int NT, int TW, bool P2>
 __global__ __launch_bounds__(CK_THREADS, 2) void convk_kernel(const ConvkArgs a) {
   using G = ConvkGeom<KS, QC, NT, TW>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -150,30 +168,40 @@ __global__ __launch_bounds__(CK_THREADS, 2) void convk_kernel(const ConvkArgs a)
 
   const size_t plane_in = (size_t)a.H * a.W;
   const float* __restrict__ xin = a.x + (size_t)n * a.cin * plane_in;
+  // raw buffer over this sample: an item outside the image gets an offset beyond num_records and reads as 0 (no branches)
+  const i32x4 xrs = ck_rsrc(xin, (unsigned)((size_t)a.cin * plane_in * 4));
+  const int plane_bytes = (int)(plane_in * 4);
 
-  // staging geometry of this thread's items (fixed over the chunks): LDS byte offset, global element offset, validity
-  int s_lds[G::IPT], s_goff[G::IPT], s_oct[G::IPT];
-  bool s_ok[G::IPT];
+  // staging geometry of this thread's items (fixed over the chunks): LDS byte offset, buffer offset (octet included)
+  int s_lds[G::IPT], s_voff[G::IPT], s_oct[G::IPT];
 #pragma unroll
   for (int k = 0; k < G::IPT; ++k) {
     const int item = tid + CK_THREADS * k;
     const int o = item / G::POS, pos = item - o * G::POS;
     const int r = pos / G::COLS, c = pos - r * G::COLS;
     const int iy = y0 - a.pad + r, ix = x0 - a.pad + c;
-    s_ok[k] = item < G::ITEMS && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-    s_goff[k] = iy * a.W + ix;
+    const bool ok = item < G::ITEMS && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+    s_voff[k] = ok ? (o * 8 * (int)plane_in + iy * a.W + ix) * 4 : 0x7fffffff;
     s_oct[k] = o;
     s_lds[k] = item < G::ITEMS ? o * G::OCT + pos * 16 : -1;
   }
 
   float stage[G::IPT][8];
   auto stage_load = [&](int chunk) {
+    const int soff = chunk * QC * 8 * plane_bytes;
+    if ((chunk + 1) * QC * 8 <= a.cin) {       // every channel of the chunk exists (wave-uniform)
 #pragma unroll
-    for (int k = 0; k < G::IPT; ++k) {
-      const int ci0 = (chunk * QC + s_oct[k]) * 8;
-      const float* p = xin + (size_t)ci0 * plane_in + s_goff[k];
+      for (int k = 0; k < G::IPT; ++k)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) stage[k][e] = (s_ok[k] && ci0 + e < a.cin) ? p[(size_t)e * plane_in] : 0.f;
+        for (int e = 0; e < 8; ++e) stage[k][e] = ck_raw_buffer_load_f32(xrs, s_voff[k], soff + e * plane_bytes, 0);
+    } else {                                   // the channel tail: the scalar offset is not range checked, test per element
+#pragma unroll
+      for (int k = 0; k < G::IPT; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const bool have = (chunk * QC + s_oct[k]) * 8 + e < a.cin;
+          stage[k][e] = ck_raw_buffer_load_f32(xrs, have ? s_voff[k] : 0x7fffffff, have ? soff + e * plane_bytes : 0, 0);
+        }
     }
   };
   auto stage_write = [&]() {
@@ -199,47 +227,71 @@ __global__ __launch_bounds__(CK_THREADS, 2) void convk_kernel(const ConvkArgs a)
   const u32x4* __restrict__ wbase = a.wp + ((size_t)((size_t)t * a.co16s + (size_t)cb * NT) * a.C * G::S * 3) * 64 + lane;
   const size_t wtile = (size_t)a.C * G::S * 3 * 64;            // stride between 16-channel blocks
 
-  f32x4 acc[4][NT];
+  f32x4 acc[4][NT], lo[P2 ? 4 : 1][P2 ? NT : 1];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int nn = 0; nn < NT; ++nn) acc[i][nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int nn = 0; nn < NT; ++nn) {
+      acc[i][nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (P2) lo[P2 ? i : 0][P2 ? nn : 0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+
+  // Software pipeline of a chunk.  A "group" = one k-step x one N-tile = 24 MFMAs; weights ride a ring of three fragment
+  // sets fetched two groups ahead (global / L2 latency), the A fragments of the next k-step are re-read from LDS into the
+  // registers of an M-tile pair right behind that pair's last MFMAs of the step.
+  constexpr int GT = G::S * NT;
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // six products, small terms first
+  bf16x8 bq[3][3], aq[4][3];
+  auto load_b = [&](bf16x8 (&dst)[3], const u32x4* __restrict__ wc, int grp) {
+    const int s = grp / NT, nn = grp % NT;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) dst[p] = __builtin_bit_cast(bf16x8, wc[(size_t)nn * wtile + (s * 3 + p) * 64]);
+  };
+  auto load_a = [&](int i, int s) {
+    const int j = 4 * s + g;
+    int tap = j / QC;
+    const int o = j % QC;
+    tap = tap < G::TAPS ? tap : G::TAPS - 1;     // padding slots of the last step: any valid address (their weights are zero)
+    const int ky = tap / KS, kx = tap - ky * KS;
+    const int aoff = o * G::OCT + (ky * G::COLS + kx) * 16;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) aq[i][p] = *reinterpret_cast<const bf16x8*>(smem + p * G::PLANE + abase[i] + aoff);
+  };
 
   stage_load(0);
   for (int c = 0; c < a.C; ++c) {
+    const u32x4* __restrict__ wc = wbase + (size_t)c * G::S * 3 * 64;
+    load_b(bq[0], wc, 0);                       // in flight across the staging bubble
+    if (GT > 1) load_b(bq[1], wc, 1);
     stage_write();
     __syncthreads();
     if (c + 1 < a.C) stage_load(c + 1);          // in flight while this chunk's MFMAs issue
-    const u32x4* __restrict__ wc = wbase + (size_t)c * G::S * 3 * 64;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) load_a(i, 0);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < G::S; ++s) {
-      const int j = 4 * s + g;
-      int tap = j / QC;
-      const int o = j % QC;
-      tap = tap < G::TAPS ? tap : G::TAPS - 1;   // padding slots of the last step: any valid address (their weights are zero)
-      const int ky = tap / KS, kx = tap - ky * KS;
-      const int aoff = o * G::OCT + (ky * G::COLS + kx) * 16;
-      bf16x8 bq[NT][3], aq[4][3];
 #pragma unroll
-      for (int nn = 0; nn < NT; ++nn)
+      for (int nn = 0; nn < NT; ++nn) {
+        constexpr int dummy = 0; (void)dummy;
+        const int grp = s * NT + nn;
+        if (grp + 2 < GT) load_b(bq[(grp + 2) % 3], wc, grp + 2);
+        const bool next_a = nn == NT - 1 && s + 1 < G::S;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          const u32x4 raw = wc[(size_t)nn * wtile + (s * 3 + p) * 64];
-          bq[nn][p] = __builtin_bit_cast(bf16x8, raw);
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+          for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int i = 2 * h; i < 2 * h + 2; ++i) {
+              if (P2 && q < 5)
+                lo[P2 ? i : 0][P2 ? nn : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[i][PA[q]], bq[grp % 3][PB[q]], lo[P2 ? i : 0][P2 ? nn : 0], 0, 0, 0);
+              else
+                acc[i][nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[i][PA[q]], bq[grp % 3][PB[q]], acc[i][nn], 0, 0, 0);
+            }
+          if (next_a) { load_a(2 * h, s + 1); load_a(2 * h + 1, s + 1); }
         }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int p = 0; p < 3; ++p) aq[i][p] = *reinterpret_cast<const bf16x8*>(smem + p * G::PLANE + abase[i] + aoff);
-      // six products per tile, spread over the 4 x NT accumulators (no back-to-back dependence), small terms first
-      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-      for (int q = 0; q < 6; ++q)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int nn = 0; nn < NT; ++nn)
-            acc[i][nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[i][PA[q]], bq[nn][PB[q]], acc[i][nn], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     __syncthreads();
   }
@@ -259,6 +311,7 @@ __global__ __launch_bounds__(CK_THREADS, 2) void convk_kernel(const ConvkArgs a)
       const int ox = x0 + 16 * (i % G::MPR) + 4 * g;
       if (oy >= a.Ho || ox >= a.Wo) continue;
       f32x4 v = acc[i][nn];
+      if (P2) v += lo[P2 ? i : 0][P2 ? nn : 0];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float u = v[r] + b;
@@ -276,11 +329,11 @@ __global__ __launch_bounds__(CK_THREADS, 2) void convk_kernel(const ConvkArgs a)
   }
 }
 
-template <int KS, int QC, int NT, int TW>
+template <int KS, int QC, int NT, int TW, bool P2 = false>
 int launch_convk(const ConvkArgs& a, hipStream_t stream) {
   using G = ConvkGeom<KS, QC, NT, TW>;
   static uint32_t configured = 0;
-  auto kern = convk_kernel<KS, QC, NT, TW>;
+  auto kern = convk_kernel<KS, QC, NT, TW, P2>;
   if (G::LDS > 64 * 1024) {
     const int rc = savfi_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), G::LDS, configured);
     if (rc != SAVFI_OK) return rc;
@@ -290,7 +343,11 @@ int launch_convk(const ConvkArgs& a, hipStream_t stream) {
 }
 
 template <int KS, int QC>
-int dispatch_nt_tw(const ConvkArgs& a, int nt, int tw, hipStream_t stream) {
+int dispatch_nt_tw(const ConvkArgs& a, int nt, int tw, bool precise, hipStream_t stream) {
+  if (precise) {          // two accumulator sets: at most 32 output channels per wave
+    if (tw == 32) return nt >= 2 ? launch_convk<KS, QC, 2, 32, true>(a, stream) : launch_convk<KS, QC, 1, 32, true>(a, stream);
+    return nt >= 2 ? launch_convk<KS, QC, 2, 16, true>(a, stream) : launch_convk<KS, QC, 1, 16, true>(a, stream);
+  }
   if (tw == 32) {
     if (nt == 4) return launch_convk<KS, QC, 4, 32>(a, stream);
     if (nt == 2) return launch_convk<KS, QC, 2, 32>(a, stream);
@@ -301,18 +358,18 @@ int dispatch_nt_tw(const ConvkArgs& a, int nt, int tw, hipStream_t stream) {
   return launch_convk<KS, QC, 1, 16>(a, stream);
 }
 
-int dispatch_convk(const ConvkArgs& a, int ks, int qc, int nt, int tw, hipStream_t stream) {
+int dispatch_convk(const ConvkArgs& a, int ks, int qc, int nt, int tw, bool precise, hipStream_t stream) {
   if (ks == 3) {
-    if (qc == 4) return dispatch_nt_tw<3, 4>(a, nt, tw, stream);
-    if (qc == 2) return dispatch_nt_tw<3, 2>(a, nt, tw, stream);
-    return dispatch_nt_tw<3, 1>(a, nt, tw, stream);
+    if (qc == 4) return dispatch_nt_tw<3, 4>(a, nt, tw, precise, stream);
+    if (qc == 2) return dispatch_nt_tw<3, 2>(a, nt, tw, precise, stream);
+    return dispatch_nt_tw<3, 1>(a, nt, tw, precise, stream);
   }
   if (ks == 5) {
-    if (qc == 2) return dispatch_nt_tw<5, 2>(a, nt, tw, stream);
-    return dispatch_nt_tw<5, 1>(a, nt, tw, stream);
+    if (qc == 2) return dispatch_nt_tw<5, 2>(a, nt, tw, precise, stream);
+    return dispatch_nt_tw<5, 1>(a, nt, tw, precise, stream);
   }
-  if (qc == 2) return dispatch_nt_tw<7, 2>(a, nt, tw, stream);
-  return dispatch_nt_tw<7, 1>(a, nt, tw, stream);
+  if (qc == 2) return dispatch_nt_tw<7, 2>(a, nt, tw, precise, stream);
+  return dispatch_nt_tw<7, 1>(a, nt, tw, precise, stream);
 }
 
 inline bool ck_supported_k(int k) { return k == 3 || k == 5 || k == 7; }
@@ -346,7 +403,7 @@ extern "C" int savfi_convk_filters_f32(const float* w, float* p_fwd, float* p_bw
 }
 
 extern "C" int savfi_convk_tasks_pre_f32(const float* x, const float* packed, const float* bias, float* out, int N, int T, int Ci,
-                                         int Co, int H, int W, int K, int pad, int mode, float slope, void* stream) {
+                                         int Co, int H, int W, int K, int pad, int mode, float slope, int precise, void* stream) {
   if (!x || !packed || !out) return SAVFI_E_NULL;
   if (N <= 0 || T <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0 || N % T != 0 || pad < 0 || pad > K - 1) return SAVFI_E_SHAPE;
   if (!ck_supported_k(K) || (mode != 0 && mode != 1)) return SAVFI_E_UNSUPPORTED;
@@ -357,7 +414,7 @@ extern "C" int savfi_convk_tasks_pre_f32(const float* x, const float* packed, co
   a.pad = mode == 0 ? pad : K - 1 - pad;
   a.Ho = H + 2 * a.pad - K + 1; a.Wo = W + 2 * a.pad - K + 1;
   if (a.Ho <= 0 || a.Wo <= 0) return SAVFI_E_SHAPE;
-  if ((int64_t)a.cin * H * W >= (1ll << 31) || (int64_t)a.cout * a.Ho * a.Wo >= (1ll << 31)) return SAVFI_E_TOOBIG;
+  if ((int64_t)a.cin * H * W >= (1ll << 29) || (int64_t)a.cout * a.Ho * a.Wo >= (1ll << 31)) return SAVFI_E_TOOBIG;   // byte offsets of a sample fit 31 bits
   a.slope = slope;
   const int qc = ck_qc(a.cin, K);
   a.C = ck_chunks(a.cin, qc);
@@ -374,6 +431,7 @@ extern "C" int savfi_convk_tasks_pre_f32(const float* x, const float* packed, co
   if (a.cout <= 16) nt = 1;
   else if (a.cout <= 32 || (rem != 0 && rem <= 32 && a.cout < 128)) nt = 2;
   else if (tiles * ((a.cout + 63) / 64) < 512 && a.cout >= 64) nt = 2;
+  if (precise && nt > 2) nt = 2;
   a.CB = ((a.cout + 15) / 16 + nt - 1) / nt;
   if (tiles * a.CB >= (1ll << 30)) return SAVFI_E_TOOBIG;
   a.total = (int)(tiles * a.CB);
@@ -381,5 +439,5 @@ extern "C" int savfi_convk_tasks_pre_f32(const float* x, const float* packed, co
   // blocks that share an input tile next to each other, unless the filter is the larger object
   const int64_t w_bytes = (int64_t)a.co16s * 16 * a.cin * K * K * 6, in_bytes = (int64_t)a.cin * H * W * 4 * (N / T);
   a.order = w_bytes > in_bytes ? 1 : 0;
-  return dispatch_convk(a, K, qc, nt, tw, (hipStream_t)stream);
+  return dispatch_convk(a, K, qc, nt, tw, precise != 0, (hipStream_t)stream);
 }

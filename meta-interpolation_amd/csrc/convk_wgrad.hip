@@ -1,0 +1,344 @@
+// Weight gradient of the K x K / stride 1 convolutions (K = 3, 5, 7; any zero padding) for gfx950, NCHW in and out,
+// deterministic, on the bf16 matrix cores with error-free 3-way operand splits (six products, fp32 accumulate: the
+// arithmetic of csrc/convk.hip -- fp32-equivalent, see the header there):
+//
+//   gw[t][co][ci][ky][kx] = sum over n = t (mod T), y, x of  gz[n][co][y][x] * x[n][ci][y + ky - pad][x + kx - pad]
+//
+// Replaces MIOpen's implicit-GEMM weight-gradient kernels (+ their two NCHW<->NHWC transposes, + atomics) under
+// aten::convolution_backward for the 5x5 / 7x7 layers of VoxelFlow and Super SloMo (reference voxelflow/core/models/
+// voxel_flow.py:357-470, superslomo/model.py:547-646; model_utils.py:308-366 MetaConv2dLayer -> F.conv2d): 25 % of a config-C3
+// iteration + 5 % in the transposes (profiles/r02_c3_voxelflow_one_iteration.txt).
+//
+// GEMM view: M = co (A operand from gz), N = ci (B operand from x, shifted by the tap), K = pixels.  The k index of
+// v_mfma_f32_16x16x32_bf16 is 8 consecutive values per lane, so a pixel-major operand would need 8 consecutive PIXELS of
+// one channel per lane -- and a tap shift of one pixel would misalign every 16-byte read.  Instead both tiles are staged
+// CHANNELS-LAST (three bf16 planes of [octet][row][col][8 channels], the image csrc/convk.hip stages) and the fragments
+// come out of LDS through the gfx950 transpose read ds_read_b64_tr_b16: a 16-lane group supplies sixteen 8-byte addresses
+// (4 pixels x 4 channel quads) and lane i receives channel i of those 4 pixels.  A tap shift is then an ADDRESS offset.
+//
+// Workgroup = 4 waves, all on the same 16*MT output channels x 16*NT input channels and the same pixels; wave w owns the
+// taps w, w+4, w+8, ... (own accumulators, no reduction between waves).  Unit of staging = 4 output rows x 32 columns of one
+// sample (gz tile + x tile with its K-1 halo); a workgroup walks a contiguous range of units, keeps its accumulators, and
+// writes ONE partial block; convk_wgrad_reduce adds the partial blocks in a fixed order (no atomics).
+#include "common.h"
+#include <stdlib.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ float ckw_raw_buffer_load_f32(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
+
+namespace {
+
+constexpr int WG_THREADS = 256;
+constexpr int UR = 4, UW = 32;          // unit: rows x columns of the cotangent
+
+__device__ __forceinline__ i32x4 ckw_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long p = reinterpret_cast<unsigned long long>(base);
+  i32x4 r;
+  r.x = (int)(unsigned)p;
+  r.y = (int)(unsigned)(p >> 32);
+  r.z = (int)bytes;
+  r.w = 0x00020000;
+  return r;
+}
+
+__device__ __forceinline__ unsigned ckw_cvt_pk_bf16(float lo, float hi) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+
+__device__ __forceinline__ void ckw_split8(const float (&v)[8], u32x4& p1, u32x4& p2, u32x4& p3) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float a = v[2 * i], b = v[2 * i + 1];
+    const unsigned h1 = ckw_cvt_pk_bf16(a, b);
+    const float ra = a - __uint_as_float(h1 << 16), rb = b - __uint_as_float(h1 & 0xffff0000u);
+    const unsigned h2 = ckw_cvt_pk_bf16(ra, rb);
+    const float qa = ra - __uint_as_float(h2 << 16), qb = rb - __uint_as_float(h2 & 0xffff0000u);
+    p1[i] = h1; p2[i] = h2; p3[i] = ckw_cvt_pk_bf16(qa, qb);
+  }
+}
+
+// bytes per channel octet of an LDS image of `cells` 16-byte cells: = 64 (mod 256), so that the 32 lanes of a transpose read
+// (4 pixels x 2 pixel-octets x 2 channel halves x 2 channel octets) touch 32 distinct 8-byte slots
+__host__ __device__ constexpr int ckw_oct(int cells) { return (cells * 16 - 64 + 255) / 256 * 256 + 64; }
+
+struct WgArgs {
+  const float* x;       // [N][Ci][H][W]
+  const float* gz;      // [N][Co][Ho][Wo]
+  float* partial;       // [splits][T][Co][Ci][K*K]
+  int N, T, Ci, Co, H, W, Ho, Wo, pad;
+  int cobs, cibs, splits, units, units_per_split, upr, ups;   // upr = row pairs per sample, ups = column segments per row
+};
+
+template <int KS, int MT, int NT>
+struct WgGeom {
+  static constexpr int TAPS = KS * KS, TPW = (TAPS + 3) / 4;
+  static constexpr int GOCTS = 2 * MT, XOCTS = 2 * NT;
+  static constexpr int GCELLS = UR * UW, XROWS = UR + KS - 1, XCOLS = UW + KS - 1, XCELLS = XROWS * XCOLS;
+  static constexpr int GOCT = ckw_oct(GCELLS), XOCT = ckw_oct(XCELLS);
+  static constexpr int GPLANE = GOCTS * GOCT, XPLANE = XOCTS * XOCT;
+  static constexpr int XBASE = 3 * GPLANE;                    // x image behind the three cotangent planes
+  static constexpr int LDS = 3 * GPLANE + 3 * XPLANE;
+  static constexpr int GITEMS = GOCTS * GCELLS, XITEMS = XOCTS * XCELLS, ITEMS = GITEMS + XITEMS;
+};
+
+// P2: the cross terms of the six-product sum in their own accumulators (see csrc/convk.hip)
+template <int KS, int MT, int NT, bool P2>
+__global__ __launch_bounds__(WG_THREADS, 2) void convk_wgrad_kernel(const WgArgs a) {
+  using G = WgGeom<KS, MT, NT>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, sl = lane & 15, kq = sl >> 2, c4 = sl & 3;     // transpose-read source lane: pixel kq, channel quad c4
+
+  int b = blockIdx.x;
+  const int split = b % a.splits; b /= a.splits;
+  const int cib = b % a.cibs; b /= a.cibs;
+  const int cob = b % a.cobs;
+  const int t = b / a.cobs;
+  const int co0 = cob * 16 * MT, ci0 = cib * 16 * NT;
+  const int u_begin = split * a.units_per_split, u_end = min(u_begin + a.units_per_split, a.units);
+
+  const size_t gplane = (size_t)a.Ho * a.Wo, xplane = (size_t)a.H * a.W;
+  const int gplane_b = (int)(gplane * 4), xplane_b = (int)(xplane * 4);
+
+  // ---- staging: items = (octet, cell); thread tid takes cotangent items tid + 256 k and input items tid + 256 k ----
+  constexpr int GIPT = (G::GITEMS + WG_THREADS - 1) / WG_THREADS, XIPT = (G::XITEMS + WG_THREADS - 1) / WG_THREADS;
+  float stage_g[GIPT][8], stage_x[XIPT][8];
+  auto stage_load = [&](int u) {
+    const int seg = u % a.ups, rp = (u / a.ups) % a.upr, n = (u / (a.ups * a.upr)) * a.T + t;
+    const int y0 = rp * UR, x0 = seg * UW;
+    const i32x4 grs = ckw_rsrc(a.gz + (size_t)n * a.Co * gplane, (unsigned)((size_t)a.Co * gplane * 4));
+    const i32x4 xrs = ckw_rsrc(a.x + (size_t)n * a.Ci * xplane, (unsigned)((size_t)a.Ci * xplane * 4));
+#pragma unroll
+    for (int k = 0; k < GIPT; ++k) {
+      const int item = tid + WG_THREADS * k;
+      const int o = item / G::GCELLS, cell = item - o * G::GCELLS;
+      const int y = y0 + cell / UW, xx = x0 + cell % UW;
+      const bool ok = item < G::GITEMS && y < a.Ho && xx < a.Wo;
+      const int base = (y * a.Wo + xx) * 4, ch0 = co0 + 8 * o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        stage_g[k][e] = ckw_raw_buffer_load_f32(grs, (ok && ch0 + e < a.Co) ? base + (ch0 + e) * gplane_b : 0x7fffffff, 0, 0);
+    }
+#pragma unroll
+    for (int k = 0; k < XIPT; ++k) {
+      const int item = tid + WG_THREADS * k;
+      const int o = item / G::XCELLS, cell = item - o * G::XCELLS;
+      const int y = y0 - a.pad + cell / G::XCOLS, xx = x0 - a.pad + cell % G::XCOLS;
+      const bool ok = item < G::XITEMS && (unsigned)y < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+      const int base = (y * a.W + xx) * 4, ch0 = ci0 + 8 * o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        stage_x[k][e] = ckw_raw_buffer_load_f32(xrs, (ok && ch0 + e < a.Ci) ? base + (ch0 + e) * xplane_b : 0x7fffffff, 0, 0);
+    }
+  };
+  auto stage_write = [&]() {
+#pragma unroll
+    for (int k = 0; k < GIPT; ++k) {
+      const int item = tid + WG_THREADS * k;
+      if (item >= G::GITEMS) continue;
+      const int o = item / G::GCELLS, cell = item - o * G::GCELLS;
+      char* dst = smem + o * G::GOCT + cell * 16;
+      u32x4 p1, p2, p3;
+      ckw_split8(stage_g[k], p1, p2, p3);
+      *reinterpret_cast<u32x4*>(dst) = p1;
+      *reinterpret_cast<u32x4*>(dst + G::GPLANE) = p2;
+      *reinterpret_cast<u32x4*>(dst + 2 * G::GPLANE) = p3;
+    }
+#pragma unroll
+    for (int k = 0; k < XIPT; ++k) {
+      const int item = tid + WG_THREADS * k;
+      if (item >= G::XITEMS) continue;
+      const int o = item / G::XCELLS, cell = item - o * G::XCELLS;
+      char* dst = smem + G::XBASE + o * G::XOCT + cell * 16;
+      u32x4 p1, p2, p3;
+      ckw_split8(stage_x[k], p1, p2, p3);
+      *reinterpret_cast<u32x4*>(dst) = p1;
+      *reinterpret_cast<u32x4*>(dst + G::XPLANE) = p2;
+      *reinterpret_cast<u32x4*>(dst + 2 * G::XPLANE) = p3;
+    }
+  };
+
+  // ---- fragment addresses (transpose reads): source lane (kq, c4) of 16-lane group g points at pixel 8 g + kq (+ 4) ----
+  const int frag_lane = (c4 >> 1) * 0 + (c4 & 1) * 8;       // channel half inside a cell; the octet is added per tile
+  int a_addr[MT], b_addr[NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) a_addr[m] = (2 * m + (c4 >> 1)) * G::GOCT + (8 * g + kq) * 16 + frag_lane;
+#pragma unroll
+  for (int nn = 0; nn < NT; ++nn) b_addr[nn] = G::XBASE + (2 * nn + (c4 >> 1)) * G::XOCT + (8 * g + kq) * 16 + frag_lane;
+
+  f32x4 acc[G::TPW][MT][NT], lo[P2 ? G::TPW : 1][P2 ? MT : 1][P2 ? NT : 1];
+#pragma unroll
+  for (int tp = 0; tp < G::TPW; ++tp)
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int nn = 0; nn < NT; ++nn) {
+        acc[tp][m][nn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (P2) lo[P2 ? tp : 0][P2 ? m : 0][P2 ? nn : 0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+
+  auto tr_read = [&](int addr) -> bf16x8 {
+    typedef __attribute__((address_space(3))) bf16x4 lds_b4;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(smem + addr));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(smem + addr + 4 * 16));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+  if (u_begin < u_end) stage_load(u_begin);
+  for (int u = u_begin; u < u_end; ++u) {
+    stage_write();
+    __syncthreads();
+    if (u + 1 < u_end) stage_load(u + 1);
+#pragma unroll
+    for (int r = 0; r < UR; ++r) {
+      bf16x8 aq[MT][3];
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) aq[m][p] = tr_read(p * G::GPLANE + a_addr[m] + r * UW * 16);
+#pragma unroll
+      for (int tp = 0; tp < G::TPW; ++tp) {
+        int tap = wv + 4 * tp;
+        const bool live = tap < G::TAPS;        // wave-uniform
+        tap = live ? tap : 0;
+        const int ky = tap / KS, kx = tap - ky * KS;
+        const int boff = ((r + ky) * G::XCOLS + kx) * 16;
+        if (live) {
+#pragma unroll
+          for (int nn = 0; nn < NT; ++nn) {
+            bf16x8 bq[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bq[p] = tr_read(p * G::XPLANE + b_addr[nn] + boff);
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+              for (int m = 0; m < MT; ++m) {
+                if (P2 && q < 5)
+                  lo[P2 ? tp : 0][P2 ? m : 0][P2 ? nn : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                      aq[m][PA[q]], bq[PB[q]], lo[P2 ? tp : 0][P2 ? m : 0][P2 ? nn : 0], 0, 0, 0);
+                else
+                  acc[tp][m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[m][PA[q]], bq[PB[q]], acc[tp][m][nn], 0, 0, 0);
+              }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- this wave's taps of the partial block: D row 4 g + j = co, D column sl = ci ----
+  float* __restrict__ pout = a.partial + ((size_t)split * a.T + t) * a.Co * a.Ci * G::TAPS;
+#pragma unroll
+  for (int tp = 0; tp < G::TPW; ++tp) {
+    const int tap = wv + 4 * tp;
+    if (tap >= G::TAPS) continue;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int nn = 0; nn < NT; ++nn) {
+        const int ci = ci0 + 16 * nn + sl;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int co = co0 + 16 * m + 4 * g + j;
+          if (co < a.Co && ci < a.Ci)
+            pout[((size_t)co * a.Ci + ci) * G::TAPS + tap] = acc[tp][m][nn][j] + (P2 ? lo[P2 ? tp : 0][P2 ? m : 0][P2 ? nn : 0][j] : 0.f);
+        }
+      }
+  }
+}
+
+// Sum of the partial blocks in a FIXED order (deterministic): a workgroup = 32 outputs x 8 split groups; thread (output, group)
+// adds the splits k = group (mod 8) in increasing order, the eight group sums meet in LDS and are added in group order.
+__global__ __launch_bounds__(256) void convk_wgrad_reduce(const float* __restrict__ partial, float* __restrict__ gw, long long n, int splits) {
+  __shared__ float part[8][32];
+  const int o = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const long long i = (long long)blockIdx.x * 32 + o;
+  float s = 0.f;
+  if (i < n)
+    for (int k = grp; k < splits; k += 8) s += partial[(size_t)k * n + i];
+  part[grp][o] = s;
+  __syncthreads();
+  if (grp == 0 && i < n) {
+    float tot = part[0][o];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) tot += part[q][o];
+    gw[i] = tot;
+  }
+}
+
+struct WgPlan { int mt, nt, cobs, cibs, units, upr, ups, splits, ups_per_split; };
+
+inline int wg_plan(WgPlan& p, int N, int T, int Ci, int Co, int H, int W, int K, int pad) {
+  if (N <= 0 || T <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0 || N % T != 0 || pad < 0 || pad > K - 1) return SAVFI_E_SHAPE;
+  if (K != 3 && K != 5 && K != 7) return SAVFI_E_UNSUPPORTED;
+  const int Ho = H + 2 * pad - K + 1, Wo = W + 2 * pad - K + 1;
+  if (Ho <= 0 || Wo <= 0) return SAVFI_E_SHAPE;
+  if ((int64_t)Ci * H * W >= (1ll << 29) || (int64_t)Co * Ho * Wo >= (1ll << 29)) return SAVFI_E_TOOBIG;
+  p.mt = (K == 3 && Co >= 192) ? 4 : 2;     // 5x5 / 7x7: 7 / 13 taps per wave x 4 tiles would not fit the register file
+  p.nt = 1;
+  p.cobs = (Co + 16 * p.mt - 1) / (16 * p.mt);
+  p.cibs = (Ci + 16 * p.nt - 1) / (16 * p.nt);
+  p.upr = (Ho + UR - 1) / UR;
+  p.ups = (Wo + UW - 1) / UW;
+  p.units = (N / T) * p.upr * p.ups;
+  const int blocks = T * p.cobs * p.cibs;
+  int splits = (768 + blocks - 1) / blocks;            // ~3 workgroups per CU over the launch
+  if (splits > p.units) splits = p.units;
+  if (splits < 1) splits = 1;
+  p.ups_per_split = (p.units + splits - 1) / splits;
+  p.splits = (p.units + p.ups_per_split - 1) / p.ups_per_split;
+  return SAVFI_OK;
+}
+
+template <int KS, int MT, int NT, bool P2 = false>
+int launch_wgrad(const WgArgs& a, int blocks, hipStream_t stream) {
+  using G = WgGeom<KS, MT, NT>;
+  static uint32_t configured = 0;
+  auto kern = convk_wgrad_kernel<KS, MT, NT, P2>;
+  if (G::LDS > 64 * 1024) {
+    const int rc = savfi_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), G::LDS, configured);
+    if (rc != SAVFI_OK) return rc;
+  }
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(WG_THREADS), G::LDS, stream, a);
+  return savfi_launch_status();
+}
+
+}  // namespace
+
+extern "C" int64_t savfi_convk_wgrad_workspace_floats(int N, int T, int Ci, int Co, int H, int W, int K, int pad) {
+  WgPlan p;
+  const int rc = wg_plan(p, N, T, Ci, Co, H, W, K, pad);
+  if (rc != SAVFI_OK) return rc;
+  return (int64_t)p.splits * T * Co * Ci * K * K;
+}
+
+extern "C" int savfi_convk_wgrad_tasks_f32(const float* x, const float* gz, float* gw, float* workspace, int N, int T, int Ci, int Co,
+                                           int H, int W, int K, int pad, int precise, void* stream) {
+  if (!x || !gz || !gw || !workspace) return SAVFI_E_NULL;
+  WgPlan p;
+  int rc = wg_plan(p, N, T, Ci, Co, H, W, K, pad);
+  if (rc != SAVFI_OK) return rc;
+  WgArgs a;
+  a.x = x; a.gz = gz; a.partial = workspace;
+  a.N = N; a.T = T; a.Ci = Ci; a.Co = Co; a.H = H; a.W = W; a.pad = pad;
+  a.Ho = H + 2 * pad - K + 1; a.Wo = W + 2 * pad - K + 1;
+  a.cobs = p.cobs; a.cibs = p.cibs; a.splits = p.splits; a.units = p.units; a.units_per_split = p.ups_per_split;
+  a.upr = p.upr; a.ups = p.ups;
+  const int blocks = T * p.cobs * p.cibs * p.splits;
+  hipStream_t st = (hipStream_t)stream;
+  if (K == 3 && precise) rc = p.mt == 4 ? launch_wgrad<3, 4, 1, true>(a, blocks, st) : launch_wgrad<3, 2, 1, true>(a, blocks, st);
+  else if (K == 3) rc = p.mt == 4 ? launch_wgrad<3, 4, 1>(a, blocks, st) : launch_wgrad<3, 2, 1>(a, blocks, st);
+  else if (K == 5) rc = precise ? launch_wgrad<5, 2, 1, true>(a, blocks, st) : launch_wgrad<5, 2, 1>(a, blocks, st);
+  else rc = launch_wgrad<7, 2, 1>(a, blocks, st);       // 13 taps per wave: no room for a second accumulator set
+  if (rc != SAVFI_OK) return rc;
+  const long long n = (long long)T * Co * Ci * K * K;
+  hipLaunchKernelGGL(convk_wgrad_reduce, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, st, workspace, gw, n, p.splits);
+  return savfi_launch_status();
+}

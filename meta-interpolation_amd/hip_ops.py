@@ -489,7 +489,77 @@ WGRAD_WINO_MIN_PIXELS = 192
 
 
 def _wgrad_wino(N, Ci, Co, Ho, Wo):
+    # the Winograd form indexes a sample's channels with 28-bit element offsets (SAVFI_E_TOOBIG beyond): oversize layers fall back
+    if Ci * (Ho + 2) * (Wo + 2) >= (1 << 28) or Co * Ho * Wo >= (1 << 28):
+        return False
     return WGRAD_WINO and Ho * Wo >= WGRAD_WINO_MIN_PIXELS and 18e-9 * Ci * Co * Ho * Wo * N >= WGRAD_WINO_MIN_GFLOP
+
+
+# Direct K x K convolution on split-bf16 MFMAs (savfi_convk_*: csrc/convk.hip, csrc/convk_wgrad.hip).  fp32-equivalent arithmetic
+# (six bf16 products per fp32 product, fp32 accumulate; as close to fp64 as an fp32 fmaf chain, tools/bf16_split_probe.hip) at
+# up to 2.4x the fp32 matrix rate.  Routing (tools/convk_bench.py, profiles/r03_convk_bench.txt):
+#   5x5 / 7x7 (VoxelFlow, Super SloMo): always -- forward / data gradient 1.8-3x MIOpen's igemm kernels, weight gradient 1.4-1.7x;
+#   3x3: where it beats the Winograd kernel -- layers of >= 64 -> 64 channels in whole 64-channel blocks on maps of >= 700 pixels
+#        (220-240 vs 200-208 direct-equivalent TFLOP/s) and the <= 8-channel input layers -- or where a plugin asks for the
+#        direct form because it amplifies Winograd rounding (VoxelFlow: `direct=True`).
+CONVK = not os.environ.get('SAVFI_NO_CONVK')
+CONVK_3X3_MIN_PIXELS = 700
+
+
+def _convk_geometry(weight, stride, padding, dilation, groups):
+    """(K, pad) if the layer is a square K x K / stride 1 / undilated / ungrouped convolution with symmetric padding the direct
+    kernels take, else None."""
+    one = lambda v, k: (v == k) if isinstance(v, int) else all(t == k for t in v)
+    K = int(weight.shape[-1])
+    if K not in (3, 5, 7) or int(weight.shape[-2]) != K or not one(stride, 1) or not one(dilation, 1) or groups != 1:
+        return None
+    pad = padding if isinstance(padding, int) else (padding[0] if padding[0] == padding[1] else -1)
+    if pad < 0 or pad > K - 1:
+        return None
+    return K, int(pad)
+
+
+def convk_eligible(x, weight, stride, padding, dilation, groups=1, direct=False):
+    """Does this convolution (and its data gradient) run on the direct split-bf16 kernel?  weight [Co,Ci,K,K] or [T,Co,Ci,K,K]."""
+    if not (CONVK and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
+        return False
+    geo = _convk_geometry(weight, stride, padding, dilation, groups)
+    if geo is None:
+        return False
+    K, pad = geo
+    H, W = x.shape[2:]
+    Ho, Wo = H + 2 * pad - K + 1, W + 2 * pad - K + 1
+    Co, Ci = weight.shape[-4], weight.shape[-3]
+    if Ho < 1 or Wo < 1 or Ci * H * W >= (1 << 29) or Co * Ho * Wo >= (1 << 29):
+        return False
+    if K != 3 or direct:
+        return True
+    return Ho * Wo >= CONVK_3X3_MIN_PIXELS and (Ci <= 8 or (Ci >= 64 and Co >= 64 and Co % 64 == 0))
+
+
+# Packed / transformed filters of a module's OWN parameters are cached per weight version: a first-order meta-iteration
+# reads them in every support and target pass (SepConv's Subnets: 11 passes) and only the outer optimizer step changes them.
+# The cache is a dict OWNED BY THE MODULE (MetaConv2dLayer passes its own): it dies with the module, so a parameter of a later
+# module that happens to reuse the address can never alias an entry.  Fast weights are new tensors every inner step and are
+# never cached.  Nothing is looked up or stored while a hipGraph is being captured (a replay must recompute the filters from
+# the live weights).
+_FILTER_CACHE_PER_MODULE = 6
+
+
+def _filters(kind, weight, fwd, bwd, cache):
+    make = convk_filters if kind == 'convk' else conv3x3_filters
+    if cache is None or torch.cuda.is_current_stream_capturing():
+        return make(weight, fwd, bwd)
+    key = (kind, weight.data_ptr(), weight._version, tuple(weight.shape), weight.device.index, _hip.current_stream())
+    hit = cache.get(key)
+    if hit is not None and (hit[0] is not None or not fwd) and (hit[1] is not None or not bwd):
+        return (hit[0] if fwd else None), (hit[1] if bwd else None)
+    pf, pb = make(weight, fwd or (hit is not None and hit[0] is not None), bwd or (hit is not None and hit[1] is not None))
+    cache.pop(key, None)
+    while len(cache) >= _FILTER_CACHE_PER_MODULE:
+        cache.pop(next(iter(cache)))
+    cache[key] = (pf, pb)
+    return (pf if fwd else None), (pb if bwd else None)
 
 
 def conv3x3_eligible(x, weight, stride, padding, dilation, groups, backward=False):
@@ -581,23 +651,32 @@ class _ConvBiasAct(torch.autograd.Function):
     differentiable): callers use the unfused ops under --second_order."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, padding, dilation, groups, slope):
+    def forward(ctx, x, w, b, stride, padding, dilation, groups, slope, direct=False, cache=None):
         pad = padding if isinstance(padding, int) else padding[0]
-        ctx.u_bwd = None
-        if conv3x3_eligible(x, w, stride, padding, dilation, groups):
+        ctx.u_bwd, ctx.route = None, None
+        if convk_eligible(x, w, stride, padding, dilation, groups, direct):
+            K = int(w.shape[-1])
+            u_fwd, ctx.u_bwd = _filters('convk', w, True, bool(ctx.needs_input_grad[0]), cache)
+            z = convk_tasks_pre(x, u_fwd, 1, w.shape[1], w.shape[0], K, b, 0, slope, pad, direct)
+            ctx.route = 'convk'
+        elif conv3x3_eligible(x, w, stride, padding, dilation, groups):
             want_bwd = ctx.needs_input_grad[0] and conv3x3_eligible(x, w, stride, padding, dilation, groups, backward=True)
-            u_fwd, ctx.u_bwd = conv3x3_filters(w, True, want_bwd)
+            u_fwd, ctx.u_bwd = _filters('wino', w, True, want_bwd, cache)
             z = conv3x3_tasks_pre(x, u_fwd, 1, w.shape[1], w.shape[0], b, 0, slope, pad)
+            ctx.route = 'wino'
         else:
             z = torch.nn.functional.conv2d(x, w, None, stride, padding, dilation, groups)
             if not z.is_contiguous():
                 z = z.contiguous()
-            _hip.require_cuda(z, b)
-            N, C, H, W = z.shape
-            lib = _hip.lib()
-            _hip.launch("bias_act_fwd", lambda: _hip.check(lib.savfi_bias_act_fwd_f32(
-                z.data_ptr(), b.data_ptr(), N, C, H * W, slope, _hip.current_stream()), "savfi_bias_act_fwd_f32"))
+            if b is not None or slope != 1.0:
+                zb = b if b is not None else torch.zeros(z.shape[1], dtype=z.dtype, device=z.device)
+                _hip.require_cuda(z, zb)
+                N, C, H, W = z.shape
+                lib = _hip.lib()
+                _hip.launch("bias_act_fwd", lambda: _hip.check(lib.savfi_bias_act_fwd_f32(
+                    z.data_ptr(), zb.data_ptr(), N, C, H * W, slope, _hip.current_stream()), "savfi_bias_act_fwd_f32"))
         ctx.conf = (stride, padding, dilation, groups, slope)
+        ctx.direct, ctx.cache, ctx.w_version, ctx.has_bias = direct, cache, w._version, b is not None
         ctx.wg_stream = weight_gradient_stream() if x.is_cuda else None
         ctx.wg_uses = _weight_use_counter(w) if ctx.wg_stream is not None else None
         ctx.save_for_backward(x, w, z)
@@ -609,7 +688,7 @@ class _ConvBiasAct(torch.autograd.Function):
         stride, padding, dilation, groups, slope = ctx.conf
         gy = gy.contiguous()
         N, C, H, W = y.shape
-        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2] and ctx.has_bias
         identity = slope == 1.0                  # no activation: gz is gy itself, only the bias gradient is computed
         gz = gy if identity else torch.empty_like(gy)
         gb = torch.empty(C, dtype=gy.dtype, device=gy.device) if need_b else None
@@ -623,14 +702,26 @@ class _ConvBiasAct(torch.autograd.Function):
                 N, C, H * W, slope, _hip.current_stream()), "savfi_bias_act_bwd_f32"))
         gx = gw = None
         pad = padding if isinstance(padding, int) else padding[0]
-        if need_x and conv3x3_eligible(x, w, stride, padding, dilation, groups, backward=True):
-            if ctx.u_bwd is not None:
-                gx = conv3x3_tasks_pre(gz, ctx.u_bwd, 1, w.shape[1], w.shape[0], None, 1, 1.0, pad)
-                ctx.u_bwd = None
+        K = int(w.shape[-1])
+        # the filter packed / transformed at forward time is only valid for the weight version the forward saw
+        u_bwd = ctx.u_bwd if w._version == ctx.w_version else None
+        ctx.u_bwd = None
+        if need_x and ctx.route == 'convk':
+            if u_bwd is None:
+                u_bwd = _filters('convk', w, False, True, ctx.cache)[1]
+            gx = convk_tasks_pre(gz, u_bwd, 1, w.shape[1], w.shape[0], K, None, 1, 1.0, pad, ctx.direct)
+            need_x = False
+        elif need_x and conv3x3_eligible(x, w, stride, padding, dilation, groups, backward=True):
+            if u_bwd is not None and ctx.route == 'wino':
+                gx = conv3x3_tasks_pre(gz, u_bwd, 1, w.shape[1], w.shape[0], None, 1, 1.0, pad)
             else:
                 gx = conv3x3(gz, w, None, 1, 1.0, pad)
             need_x = False
         pair = lambda v: [v, v] if isinstance(v, int) else list(v)
+        # 5x5 / 7x7 layers and plugins that asked for the direct form: weight gradient on the split-bf16 kernel as well
+        if need_w and ctx.route == 'convk' and (K != 3 or ctx.direct):
+            gw = convk_wgrad_tasks(x, gz, 1, K, pad, ctx.direct)[0]
+            need_w = False
         side = ctx.wg_stream if (ctx.wg_stream is not None and ctx.wg_uses[0] == 1) else None
         if need_w and side is not None:
             # gz was produced on this stream just above: the side stream picks up from here
@@ -655,7 +746,7 @@ class _ConvBiasAct(torch.autograd.Function):
                                                               False, [0, 0], groups, [need_x, need_w, False])
             gx = gx2 if need_x else gx
             gw = gw2 if need_w else gw
-        return gx, gw, gb, None, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None, None, None
 
 
 # --------------------------------------------------------------------------------------------
@@ -772,7 +863,7 @@ def convk_filters(weight, fwd=True, bwd=True):
     return ps[0], ps[1]
 
 
-def convk_tasks_pre(x, packed, T, Ci, Co, K, bias=None, mode=0, slope=1.0, pad=1):
+def convk_tasks_pre(x, packed, T, Ci, Co, K, bias=None, mode=0, slope=1.0, pad=1, precise=False):
     """savfi_convk_tasks_pre_f32: direct K x K convolution (mode 0, + bias + activation) or its data gradient (mode 1) on a
     filter packed by convk_filters (same mode); sample n uses filter set n % T."""
     x = x.contiguous()
@@ -785,8 +876,24 @@ def convk_tasks_pre(x, packed, T, Ci, Co, K, bias=None, mode=0, slope=1.0, pad=1
     lib = _hip.lib()
     _hip.launch("convk_fwd" if mode == 0 else "convk_bwd_data", lambda: _hip.check(lib.savfi_convk_tasks_pre_f32(
         x.data_ptr(), packed.data_ptr(), None if bias is None else bias.data_ptr(), out.data_ptr(), N, T, Ci, Co, H, W, K, int(pad),
-        mode, float(slope), _hip.current_stream()), "savfi_convk_tasks_pre_f32"))
+        mode, float(slope), int(bool(precise)), _hip.current_stream()), "savfi_convk_tasks_pre_f32"))
     return out
+
+
+def convk_wgrad_tasks(x, gz, T, K, pad, precise=False):
+    """savfi_convk_wgrad_tasks_f32: gw [T,Co,Ci,K,K], gw[t] over the samples n % T == t (direct K x K form, split-bf16 MFMAs)."""
+    x, gz = x.contiguous(), gz.contiguous()
+    _hip.require_cuda(x, gz)
+    N, Ci, H, W = x.shape
+    Co = gz.shape[1]
+    assert N % T == 0 and tuple(gz.shape) == (N, Co, H + 2 * pad - K + 1, W + 2 * pad - K + 1), (x.shape, gz.shape, K, pad, T)
+    lib = _hip.lib()
+    ws = torch.empty(_workspace_floats("savfi_convk_wgrad_workspace_floats", N, T, Ci, Co, H, W, K, int(pad)), dtype=x.dtype, device=x.device)
+    gw = torch.empty((T, Co, Ci, K, K), dtype=x.dtype, device=x.device)
+    _hip.launch("convk_wgrad", lambda: _hip.check(lib.savfi_convk_wgrad_tasks_f32(
+        x.data_ptr(), gz.data_ptr(), gw.data_ptr(), ws.data_ptr(), N, T, Ci, Co, H, W, K, int(pad), int(bool(precise)),
+        _hip.current_stream()), "savfi_convk_wgrad_tasks_f32"))
+    return gw
 
 
 def conv3x3_wgrad_tasks(x, gz, T, pad=1, stream=None, extra_stream=None):
@@ -840,18 +947,23 @@ class _ConvBiasActTasks(torch.autograd.Function):
     """y = act(conv2d(x[s], w[s % T]) + b[s % T]) for every sample s.  First-order only (like _ConvBiasAct)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, padding, dilation, slope):
+    def forward(ctx, x, w, b, stride, padding, dilation, slope, direct=False):
         x = x.contiguous()
         T, Co, Ci = w.shape[:3]
         N, _, H, W = x.shape
         n = N // T
         pad = padding if isinstance(padding, int) else padding[0]
-        ctx.u_bwd = None
-        if conv3x3_tasks_eligible(x, w, stride, padding, dilation):
+        ctx.u_bwd, ctx.route = None, None
+        if convk_eligible(x, w, stride, padding, dilation, 1, direct):
+            u_fwd, ctx.u_bwd = convk_filters(w, True, bool(ctx.needs_input_grad[0]))
+            z = convk_tasks_pre(x, u_fwd, T, Ci, Co, int(w.shape[-1]), b, 0, slope, pad, direct)
+            ctx.route = 'convk'
+        elif conv3x3_tasks_eligible(x, w, stride, padding, dilation):
             # both filter transforms of this layer in one launch: the data gradient of the same step will want the other one
             want_bwd = ctx.needs_input_grad[0] and conv3x3_tasks_eligible(x, w, stride, padding, dilation, backward=True)
             u_fwd, ctx.u_bwd = conv3x3_filters(w, True, want_bwd)
             z = conv3x3_tasks_pre(x, u_fwd, T, Ci, Co, b, 0, slope, pad)
+            ctx.route = 'wino'
         else:
             if _grouped_ok(x):
                 z = torch.nn.functional.conv2d(x.view(n, T * Ci, H, W), w.reshape(T * Co, Ci, *w.shape[3:]), None, stride, padding,
@@ -871,7 +983,7 @@ class _ConvBiasActTasks(torch.autograd.Function):
                     z.data_ptr(), zb.data_ptr(), n, T * Co, hw, slope, _hip.current_stream()), "savfi_bias_act_fwd_f32"))
             z = z.view(N, Co, z.shape[-2], z.shape[-1])
         ctx.conf = (stride, padding, dilation, slope)
-        ctx.has_bias = b is not None
+        ctx.has_bias, ctx.direct, ctx.w_version = b is not None, direct, w._version
         ctx.wg_stream = weight_gradient_stream() if x.is_cuda else None
         ctx.wg_uses = _weight_use_counter(w) if ctx.wg_stream is not None else None
         ctx.save_for_backward(x, w, z)
@@ -900,13 +1012,23 @@ class _ConvBiasActTasks(torch.autograd.Function):
                 n, T * Co, Ho * Wo, slope, _hip.current_stream()), "savfi_bias_act_bwd_f32"))
         gx = gw = None
         pad = padding if isinstance(padding, int) else padding[0]
-        if need_x and conv3x3_tasks_eligible(x, w, stride, padding, dilation, backward=True):
-            if ctx.u_bwd is not None:
-                gx = conv3x3_tasks_pre(gz, ctx.u_bwd, T, Ci, Co, None, 1, 1.0, pad)
-                ctx.u_bwd = None
+        K = int(w.shape[-1])
+        u_bwd = ctx.u_bwd if w._version == ctx.w_version else None      # valid for the weight version the forward saw only
+        ctx.u_bwd = None
+        if need_x and ctx.route == 'convk':
+            if u_bwd is None:
+                u_bwd = convk_filters(w, False, True)[1]
+            gx = convk_tasks_pre(gz, u_bwd, T, Ci, Co, K, None, 1, 1.0, pad, ctx.direct)
+            need_x = False
+        elif need_x and conv3x3_tasks_eligible(x, w, stride, padding, dilation, backward=True):
+            if u_bwd is not None and ctx.route == 'wino':
+                gx = conv3x3_tasks_pre(gz, u_bwd, T, Ci, Co, None, 1, 1.0, pad)
             else:
                 gx = conv3x3_tasks(gz, w, None, 1, 1.0, pad)
             need_x = False
+        if need_w and ctx.route == 'convk' and (K != 3 or ctx.direct):
+            gw = convk_wgrad_tasks(x, gz, T, K, pad, ctx.direct)
+            need_w = False
         if need_w and conv3x3_wgrad_tasks_eligible(x, w, stride, padding, dilation):
             side = ctx.wg_stream if (ctx.wg_stream is not None and ctx.wg_uses[0] == 1) else None
             if side is not None:     # beside the data-gradient chain (see _ConvBiasAct.backward); joined by the caller
@@ -939,12 +1061,12 @@ class _ConvBiasActTasks(torch.autograd.Function):
                     gx = torch.stack([p[0] for p in per], 1).view(N, Ci, H, W)
                 if need_w:
                     gw = torch.stack([p[1] for p in per], 0)
-        return gx, gw, gb, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None
 
 
-def conv_bias_act_tasks(x, weight, bias, stride=1, padding=0, dilation=1, slope=0.0):
+def conv_bias_act_tasks(x, weight, bias, stride=1, padding=0, dilation=1, slope=0.0, direct=False):
     """act(conv2d(x[s], weight[s % T]) + bias[s % T]): the lockstep form of conv_bias_act."""
-    return _ConvBiasActTasks.apply(x, weight, bias, stride, padding, dilation, float(slope))
+    return _ConvBiasActTasks.apply(x, weight, bias, stride, padding, dilation, float(slope), bool(direct))
 
 
 @functools.lru_cache(maxsize=None)
@@ -1000,9 +1122,11 @@ def conv3x3_wgrad(x, gz, pad=1, stream=None, extra_stream=None):
     return gw
 
 
-def conv_bias_act(x, weight, bias, stride=1, padding=0, dilation=1, groups=1, slope=0.0):
-    """act(conv2d(x, weight) + bias) with act = LeakyReLU(slope) (0 -> ReLU, 1 -> identity)."""
-    return _ConvBiasAct.apply(x, weight, bias, stride, padding, dilation, groups, float(slope))
+def conv_bias_act(x, weight, bias, stride=1, padding=0, dilation=1, groups=1, slope=0.0, direct=False, cache=None):
+    """act(conv2d(x, weight) + bias) with act = LeakyReLU(slope) (0 -> ReLU, 1 -> identity); bias may be None.  `direct`: a 3x3
+    layer wants the direct split-bf16 kernel whatever its size (no Winograd rounding); `cache`: a dict owned by the module whose
+    own parameter `weight` is (its packed filters are kept there per weight version), None for fast weights."""
+    return _ConvBiasAct.apply(x, weight, bias, stride, padding, dilation, groups, float(slope), bool(direct), cache)
 
 
 # --------------------------------------------------------------------------------------------

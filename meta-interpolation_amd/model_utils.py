@@ -171,8 +171,12 @@ class MetaConv2dLayer(nn.Module):
     """conv2d with internal (Xavier-uniform weight, zero bias) or external weights (reference :308-366)."""
 
     def __init__(self, in_channels, out_channels, kernel_size, stride, padding, use_bias=True, groups=1,
-                 dilation_rate=1):
+                 dilation_rate=1, direct=False):
         super().__init__()
+        # direct = True: a 3x3 layer of a network that amplifies Winograd rounding (VoxelFlow) asks for the direct split-bf16
+        # convolution whatever its size; 5x5 / 7x7 layers take it anyway (hip_ops.convk_eligible)
+        self.direct = bool(direct)
+        self._filters = {}          # packed / transformed filters of self.weight (hip_ops._filters)
         self.stride, self.padding = int(stride), int(padding)
         self.dilation_rate, self.groups, self.use_bias = int(dilation_rate), int(groups), use_bias
         self.weight = nn.Parameter(torch.empty(out_channels, in_channels, kernel_size, kernel_size))
@@ -191,24 +195,30 @@ class MetaConv2dLayer(nn.Module):
             weight, bias = self.weight.detach(), (self.bias.detach() if self.bias is not None else None)
         else:
             weight, bias = self.weight, self.bias
+        direct = getattr(self, 'direct', False)
         if weight.dim() == 5:
             # fast weights stacked over the tasks of a meta-batch adapted in lockstep: [T, Co, Ci, kh, kw], x [n*T, ...]
             if x.is_cuda and fuse_conv_act() and self.groups == 1 and (
-                    act_slope is not None or bias is None or hip_ops.conv3x3_tasks_eligible(x, weight, self.stride, padding, self.dilation_rate)):
+                    act_slope is not None or bias is None or hip_ops.conv3x3_tasks_eligible(x, weight, self.stride, padding, self.dilation_rate)
+                    or hip_ops.convk_eligible(x, weight, self.stride, padding, self.dilation_rate, 1, direct)):
                 return hip_ops.conv_bias_act_tasks(x, weight, bias, self.stride, padding, self.dilation_rate,
-                                                   1.0 if act_slope is None else act_slope)
+                                                   1.0 if act_slope is None else act_slope, direct)
             assert self.groups == 1, "lockstep tasks on a grouped convolution"
             out = hip_ops.conv2d_tasks(x, weight, bias, self.stride, padding, self.dilation_rate)
             if act_slope is not None:
                 out = F.relu(out) if act_slope == 0.0 else F.leaky_relu(out, act_slope)
             return out
-        if bias is not None and x.is_cuda and fuse_conv_act():
-            if act_slope is not None:
+        if x.is_cuda and fuse_conv_act():
+            own = self._filters if params is None else None     # own parameter: packed filters cached per weight version, here
+            if hip_ops.convk_eligible(x, weight, self.stride, padding, self.dilation_rate, self.groups, direct):
                 return hip_ops.conv_bias_act(x, weight, bias, self.stride, padding, self.dilation_rate, self.groups,
-                                             act_slope)
-            if hip_ops.conv3x3_eligible(x, weight, self.stride, padding, self.dilation_rate, self.groups):
+                                             1.0 if act_slope is None else act_slope, direct, own)
+            if bias is not None and act_slope is not None:
+                return hip_ops.conv_bias_act(x, weight, bias, self.stride, padding, self.dilation_rate, self.groups,
+                                             act_slope, direct, own)
+            if bias is not None and hip_ops.conv3x3_eligible(x, weight, self.stride, padding, self.dilation_rate, self.groups):
                 # no activation follows: still worth the savfi kernel (bias in its epilogue) for large maps
-                return hip_ops.conv_bias_act(x, weight, bias, self.stride, padding, self.dilation_rate, self.groups, 1.0)
+                return hip_ops.conv_bias_act(x, weight, bias, self.stride, padding, self.dilation_rate, self.groups, 1.0, direct, own)
         out = F.conv2d(x, weight, bias, self.stride, padding, self.dilation_rate, self.groups)
         if act_slope is not None:
             out = F.relu(out) if act_slope == 0.0 else F.leaky_relu(out, act_slope)

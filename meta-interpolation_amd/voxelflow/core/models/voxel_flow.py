@@ -39,9 +39,9 @@ class MetaVoxelFlow(nn.Module):
         self.relu = nn.ReLU(inplace=True)
         self.pool = nn.MaxPool2d(kernel_size=2, stride=2)
         for name, cin, cout, k in _TRUNK:
-            setattr(self, name, MetaConv2dLayer(cin, cout, kernel_size=k, stride=1, padding=k // 2, use_bias=False))
+            setattr(self, name, MetaConv2dLayer(cin, cout, kernel_size=k, stride=1, padding=k // 2, use_bias=False, direct=True))
             setattr(self, name + "_bn", BatchNorm2d(cout, momentum=0.9997))
-        self.conv4 = MetaConv2dLayer(64, 3, kernel_size=5, stride=1, padding=2)
+        self.conv4 = MetaConv2dLayer(64, 3, kernel_size=5, stride=1, padding=2, direct=True)
 
         for m in self.modules():
             if isinstance(m, MetaConv2dLayer):

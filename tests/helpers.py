@@ -49,13 +49,14 @@ def fp(t):
 FP_ATOL = 1e-8     # absolute floor of a fingerprint sum: fp32 rounding of O(1) activations summed over a layer
 
 
-def assert_fp_close(got, want, rtol=1e-5, what=""):
+def assert_fp_close(got, want, rtol=1e-5, what="", extra_abs=0.0):
     """Fingerprints: [sum, abs-sum, first 4].  Compared relative to the abs-sum scale, with an absolute floor: the gradient
     of a 12-element channel-attention bias has an abs-sum of 5e-6, and 1e-3 of that is below the rounding noise of the
-    convolutions it is summed from (seen as a run-order dependent 1.06e-3 on exactly that tensor)."""
+    convolutions it is summed from (seen as a run-order dependent 1.06e-3 on exactly that tensor).  `extra_abs`: an absolute
+    allowance the caller derives from another contract bound (an updated weight w - lr g carries the gradient's bound on lr g)."""
     scale = max(abs(want[1]), 1e-12)
-    assert abs(got[0] - want[0]) <= rtol * scale + FP_ATOL, (what, got[0], want[0])
-    assert abs(got[1] - want[1]) <= rtol * scale + FP_ATOL, (what, got[1], want[1])
+    assert abs(got[0] - want[0]) <= rtol * scale + FP_ATOL + extra_abs, (what, got[0], want[0])
+    assert abs(got[1] - want[1]) <= rtol * scale + FP_ATOL + extra_abs, (what, got[1], want[1])
 
 
 def build_system(model, overrides, fuse=1, device="cuda"):
@@ -80,8 +81,9 @@ def observe(system, check_rule=False):
     """Wrap update_params / optimizer.step of a product system to record fingerprints.  With
     check_rule=True every fused update is also replayed on the CPU by the oracle's rule from the SAME
     weights / grads / learning rates and the element-wise deviation is recorded (rec['rule_err'])."""
-    rec = dict(n_live=[], grad_fp=[], weight_fp=[], outer_grad_fp={}, rule_err=[])
+    rec = dict(n_live=[], grad_fp=[], weight_fp=[], moved=[], outer_grad_fp={}, rule_err=[])
     rule = system.inner_loop_optimizer
+    theta = {k.replace('module.', ''): v.detach() for k, v in system.net.named_parameters()}
     orig = rule.update_params
     kind = 'metasgd' if type(rule).__name__.startswith('MetaSGD') else 'lslr'
     ostate = {}
@@ -113,6 +115,9 @@ def observe(system, check_rule=False):
         rec['n_live'].append(len(out))
         rec['grad_fp'].append({k: fp(v) for k, v in names_grads_wrt_params_dict.items() if v is not None})
         rec['weight_fp'].append({k: fp(v) for k, v in out.items()})
+        # how far each fast weight has moved away from theta (abs-sum): the part of its value that is accumulated lr * g
+        rec['moved'].append({k: ((v.detach() - theta[k]).abs().sum().item() if k in theta and v.shape == theta[k].shape else 0.0)
+                             for k, v in out.items()})
         return out
     rule.update_params = update_params
 

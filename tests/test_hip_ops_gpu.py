@@ -482,10 +482,13 @@ def test_conv3x3_wgrad_winograd_form_matches_autograd(T, N, Ci, Co, H, W, pad):
     assert torch.equal(got, run())
 
 
-def test_sepconv_with_winograd_convs_equals_miopen_convs():
+@pytest.mark.parametrize("route", ["winograd", "winograd+direct"])
+def test_sepconv_with_winograd_convs_equals_miopen_convs(route):
     """BASELINE config-2 frame size: the backbone's large 3x3 convolutions on savfi_conv3x3_f32 (forward with fused
     bias + ReLU, data gradient) and savfi_conv3x3_wgrad_f32 give the network output and every parameter gradient of the MIOpen path.
-    A smooth loss is used: with L1 a 1e-7 output difference flips sign(out - target) for a few pixels."""
+    A smooth loss is used: with L1 a 1e-7 output difference flips sign(out - target) for a few pixels.
+    route "winograd+direct" = the product routing: the >= 64-channel layers and the 6-channel input layer on the direct
+    split-bf16 kernel (hip_ops.convk_eligible), the rest on the Winograd kernel."""
     from meta_interpolation_amd import model_utils as mu, synthetic
     from meta_interpolation_amd.sepconv.model import MetaNetwork
     net = MetaNetwork()
@@ -495,20 +498,27 @@ def test_sepconv_with_winograd_convs_equals_miopen_convs():
     f0, f1, tgt = frames[2].cuda(), frames[4].cuda(), frames[3].cuda()
     res = []
     mu.set_fuse_conv_act(True)
-    calls = []
-    orig = hip_ops.conv3x3_tasks_pre
+    calls, kcalls = [], []
+    orig, korig = hip_ops.conv3x3_tasks_pre, hip_ops.convk_tasks_pre
     try:
         for wino in (False, True):
             hip_ops.WINOGRAD_CONV = wino
+            hip_ops.CONVK = wino and route == "winograd+direct"
             hip_ops.conv3x3_tasks_pre = (lambda *a, **k: (calls.append(a[6] if len(a) > 6 else k.get('mode', 0)), orig(*a, **k))[1])
+            hip_ops.convk_tasks_pre = (lambda *a, **k: (kcalls.append(a[7] if len(a) > 7 else k.get('mode', 0)), korig(*a, **k))[1])
             out = net(f0, f1)
             loss = ((out - tgt) ** 2).mean()
             res.append((out.detach(), torch.autograd.grad(loss, list(net.parameters()))))
     finally:
         mu.set_fuse_conv_act(False)
         hip_ops.WINOGRAD_CONV = True
-        hip_ops.conv3x3_tasks_pre = orig
-    assert calls.count(0) >= 20 and calls.count(1) >= 8, calls          # forward and data-gradient launches happened
+        hip_ops.CONVK = True
+        hip_ops.conv3x3_tasks_pre, hip_ops.convk_tasks_pre = orig, korig
+    # forward and data-gradient launches happened
+    if route == "winograd":
+        assert calls.count(0) >= 20 and calls.count(1) >= 8 and not kcalls, (calls, kcalls)
+    else:
+        assert calls.count(0) + kcalls.count(0) >= 20 and kcalls.count(0) >= 8 and kcalls.count(1) >= 4, (calls, kcalls)
     (o_mi, g_mi), (o_wi, g_wi) = res
     assert (o_wi - o_mi).abs().max() < 5e-6
     for (n, _), a, b in zip(net.named_parameters(), g_wi, g_mi):
@@ -658,3 +668,126 @@ def test_per_sample_losses(kind):
     gr, = torch.autograd.grad((want * co).sum(), a)
     assert _rel(ga, gr) < 1e-6
     assert torch.equal(fn(a, b), got)                              # fixed-order reduction: bit-reproducible
+
+
+# ---------------------------------------------------------------------------------------------
+# direct K x K convolution on split-bf16 MFMAs (csrc/convk.hip, csrc/convk_wgrad.hip): fp32-equivalent arithmetic, so it is
+# held to a float64 CPU convolution at fp32-rounding bounds (a CPU fp32 convolution differs from float64 by 2e-7 .. 1e-6 on
+# these shapes); ragged tiles, channel tails, every padding, several tasks
+# ---------------------------------------------------------------------------------------------
+CONVK_CASES = [  # K, Ci, Co, H, W, pad, T, N
+    (3, 6, 32, 20, 40, 1, 1, 1), (3, 64, 51, 17, 33, 1, 1, 2), (3, 51, 51, 18, 50, 0, 1, 1), (3, 128, 64, 12, 16, 1, 4, 8),
+    (3, 24, 40, 9, 70, 2, 1, 1), (5, 6, 64, 32, 32, 2, 1, 2), (5, 64, 128, 16, 48, 2, 2, 2), (5, 64, 3, 24, 40, 2, 1, 2),
+    (5, 20, 24, 11, 13, 0, 1, 1), (7, 6, 32, 24, 40, 3, 1, 1), (7, 32, 32, 16, 36, 3, 2, 2), (7, 20, 2, 10, 12, 6, 1, 1),
+    (3, 1, 1, 1, 1, 1, 1, 1), (5, 3, 17, 33, 65, 4, 1, 1),
+]
+
+
+@pytest.mark.parametrize("precise", [False, True])
+@pytest.mark.parametrize("K,Ci,Co,H,W,pad,T,N", CONVK_CASES)
+def test_convk_forward_data_and_weight_gradient_match_float64(K, Ci, Co, H, W, pad, T, N, precise):
+    g = torch.Generator().manual_seed(K * 1000 + Ci + Co)
+    x = torch.randn(N, Ci, H, W, generator=g)
+    w = torch.randn(T, Co, Ci, K, K, generator=g) / (K * math.sqrt(Ci))
+    b = torch.randn(T, Co, generator=g)
+    Ho, Wo = H + 2 * pad - K + 1, W + 2 * pad - K + 1
+    gy = torch.randn(N, Co, Ho, Wo, generator=g)
+    pf, pb = hip_ops.convk_filters(w.to(DEV), True, True)
+    y = hip_ops.convk_tasks_pre(x.to(DEV), pf, T, Ci, Co, K, b.to(DEV), 0, 0.2, pad, precise).cpu().double()
+    gx = hip_ops.convk_tasks_pre(gy.to(DEV), pb, T, Ci, Co, K, None, 1, 1.0, pad, precise).cpu().double()
+    gw = hip_ops.convk_wgrad_tasks(x.to(DEV), gy.to(DEV), T, K, pad, precise).cpu().double()
+    gw2 = hip_ops.convk_wgrad_tasks(x.to(DEV), gy.to(DEV), T, K, pad, precise).cpu().double()
+    xd, wd, bd, gd = x.double(), w.double(), b.double(), gy.double()
+    z = torch.cat([F.conv2d(xd[n:n + 1], wd[n % T], bd[n % T], padding=pad) for n in range(N)], 0)
+    ref = torch.where(z > 0, z, 0.2 * z)
+    gref = torch.cat([F.conv_transpose2d(gd[n:n + 1], wd[n % T], padding=pad) for n in range(N)], 0)
+    wref = torch.stack([torch.nn.grad.conv2d_weight(xd[t::T], (Co, Ci, K, K), gd[t::T], padding=pad) for t in range(T)], 0)
+    assert y.shape == ref.shape and gx.shape == (N, Ci, H, W) and gw.shape == wref.shape
+    assert _rel(y, ref) < 3e-6 and _rel(gx, gref) < 3e-6 and _rel(gw, wref) < 3e-6
+    assert torch.equal(gw, gw2)          # fixed-order reduction of the partial blocks: bit-reproducible
+
+
+def test_convk_precise_mode_is_closer_to_float64_than_a_cpu_float32_convolution():
+    """`precise` (cross terms in their own accumulators): on a long reduction (K = 25 * 192) the result is closer to float64
+    than the single-accumulator form and not further than the CPU's blocked fp32 convolution."""
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(1, 192, 24, 40, generator=g).relu()
+    w = torch.randn(1, 64, 192, 5, 5, generator=g) * 0.05
+    ref = F.conv2d(x.double(), w[0].double(), padding=2)
+    cpu32 = F.conv2d(x, w[0], padding=2).double()
+    pf, _ = hip_ops.convk_filters(w.to(DEV), True, False)
+    err = {p: (hip_ops.convk_tasks_pre(x.to(DEV), pf, 1, 192, 64, 5, None, 0, 1.0, 2, p).cpu().double() - ref).abs().mean().item() for p in (False, True)}
+    err_cpu = (cpu32 - ref).abs().mean().item()
+    assert err[True] < 0.6 * err[False] and err[True] < 1.5 * err_cpu, (err, err_cpu)
+
+
+def test_convk_one_hot_filter_reproduces_the_input_bit_for_bit():
+    """The split is error-free: a filter that is 1 at one tap of one channel copies that (shifted) channel exactly."""
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(1, 16, 20, 33, generator=g) * torch.logspace(-6, 6, 16).view(1, 16, 1, 1)).to(DEV)
+    w = torch.zeros(1, 16, 16, 5, 5)
+    for c in range(16):
+        w[0, c, (5 * c) % 16, c % 5, (c // 5) % 5] = 1.0
+    pf, _ = hip_ops.convk_filters(w.to(DEV), True, False)
+    y = hip_ops.convk_tasks_pre(x, pf, 1, 16, 16, 5, None, 0, 1.0, 2)
+    ref = F.conv2d(x.cpu().double(), w[0].double(), padding=2).float()
+    assert torch.equal(y.cpu(), ref)
+
+
+@pytest.mark.parametrize("slope", [0.0, 1.0])
+@pytest.mark.parametrize("shape,k,pad,co,bias", [((2, 6, 40, 48), 5, 2, 64, False), ((1, 64, 32, 32), 5, 2, 3, True), ((2, 6, 24, 40), 7, 3, 32, True),
+                                                 ((1, 64, 32, 64), 3, 1, 64, True), ((1, 128, 16, 16), 3, 1, 256, False)])
+def test_conv_bias_act_on_the_direct_kernel_matches_torch_autograd(slope, shape, k, pad, co, bias):
+    """hip_ops.conv_bias_act routed to the split-bf16 kernels (5x5 / 7x7 always, 3x3 with direct=True): value, data gradient,
+    weight gradient, bias gradient against plain torch ops in float64."""
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(*shape, generator=g)
+    w = torch.randn(co, shape[1], k, k, generator=g) / (k * math.sqrt(shape[1]))
+    b = torch.randn(co, generator=g) if bias else None
+    leaves = [t.to(DEV).requires_grad_() for t in (x, w)] + ([b.to(DEV).requires_grad_()] if bias else [])
+    assert hip_ops.convk_eligible(leaves[0], leaves[1], 1, pad, 1, 1, True)
+    y = hip_ops.conv_bias_act(leaves[0], leaves[1], leaves[2] if bias else None, 1, pad, 1, 1, slope, True, None)
+    gy = torch.randn(y.shape, generator=g)
+    grads = torch.autograd.grad(y, leaves, gy.to(DEV))
+    ref_leaves = [t.double().requires_grad_() for t in (x, w)] + ([b.double().requires_grad_()] if bias else [])
+    z = F.conv2d(ref_leaves[0], ref_leaves[1], ref_leaves[2] if bias else None, padding=pad)
+    yr = torch.where(z > 0, z, slope * z)
+    rgrads = torch.autograd.grad(yr, ref_leaves, gy.double())
+    assert _rel(y.detach().cpu().double(), yr.detach()) < 3e-6
+    for a, r in zip(grads, rgrads):
+        assert _rel(a.cpu().double(), r) < 5e-6
+
+
+@pytest.mark.parametrize("T,n,Ci,Co,H,W,k,pad", [(4, 2, 64, 64, 32, 32, 3, 1), (3, 1, 6, 16, 20, 24, 5, 2), (2, 2, 32, 32, 24, 40, 7, 3)])
+def test_conv_bias_act_tasks_on_the_direct_kernel_matches_per_task_torch(T, n, Ci, Co, H, W, k, pad):
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(n * T, Ci, H, W, generator=g)
+    w = torch.randn(T, Co, Ci, k, k, generator=g) / (k * math.sqrt(Ci))
+    b = torch.randn(T, Co, generator=g)
+    xg, wg, bg = (t.to(DEV).requires_grad_() for t in (x, w, b))
+    assert hip_ops.convk_eligible(xg, wg, 1, pad, 1, 1, True)
+    y = hip_ops.conv_bias_act_tasks(xg, wg, bg, 1, pad, 1, 0.1, True)
+    gy = torch.randn(y.shape, generator=g)
+    grads = torch.autograd.grad(y, (xg, wg, bg), gy.to(DEV))
+    xr, wr, br = (t.double().requires_grad_() for t in (x, w, b))
+    z = torch.cat([F.conv2d(xr[s:s + 1], wr[s % T], br[s % T], padding=pad) for s in range(n * T)], 0)
+    yr = torch.where(z > 0, z, 0.1 * z)
+    rgrads = torch.autograd.grad(yr, (xr, wr, br), gy.double())
+    assert _rel(y.detach().cpu().double(), yr.detach()) < 3e-6
+    for a, r in zip(grads, rgrads):
+        assert _rel(a.cpu().double(), r) < 5e-6
+
+
+def test_own_weight_filters_are_cached_per_weight_version():
+    """A module's own parameter is packed once per version: the second pass reuses the buffers, an in-place update repacks."""
+    cache = {}
+    w = torch.nn.Parameter(torch.randn(64, 64, 5, 5, device=DEV) / 40)
+    x = torch.randn(1, 64, 32, 32, device=DEV)
+    y1 = hip_ops.conv_bias_act(x, w, None, 1, 2, 1, 1, 1.0, False, cache)
+    n1 = len(cache)
+    y2 = hip_ops.conv_bias_act(x, w, None, 1, 2, 1, 1, 1.0, False, cache)
+    assert n1 == 1 and len(cache) == 1 and torch.equal(y1, y2)
+    with torch.no_grad():
+        w.mul_(2.0)
+    y3 = hip_ops.conv_bias_act(x, w, None, 1, 2, 1, 1, 1.0, False, cache)
+    assert len(cache) == 2 and _rel(y3.detach(), 2 * y1.detach()) < 1e-6

@@ -618,7 +618,11 @@ def test_lockstep_equals_the_sequential_loop(model, over, lockstep_for):
     # VoxelFlow: its 5x5 layers run on another MIOpen solver when grouped and the flow-to-pixel map amplifies conv rounding (the
     # reference moves by 7e-5..9e-4 in loss against itself: tests/golden/sensitivity.npz); measured here: 4.1e-4
     assert abs(l0 - l1) <= (1e-3 if model == 'voxelflow' else 2e-5) * abs(l0)
-    assert (p0 - p1).abs().mean().item() < 1e-4 and abs(s0 - s1) < 1e-3
+    # VoxelFlow: a self-comparison of two summation orders (the weight-gradient partial blocks are cut differently for 8 and 2
+    # samples) under its rounding amplification: the reference moves by 6.9e-5 pixel L1 / 3.3e-4 dB against ITSELF on the 2-task
+    # fixture (tests/golden/sensitivity.npz); 3x that here
+    l1_lim, psnr_lim = ((3 * 6.9e-5, 3 * 3.4e-4) if model == 'voxelflow' else (1e-4, 1e-3))
+    assert (p0 - p1).abs().mean().item() < max(l1_lim, 1e-4) and abs(s0 - s1) < max(psnr_lim, 1e-3)
     for k, v in g0.items():
         if v.abs().sum().item() == 0:
             continue

@@ -64,9 +64,14 @@ def check():
         gx = hip_ops.convk_tasks_pre(gy, pb, T, ci, co, K, None, 1, 1.0, pad)
         gref = torch.cat([F.conv_transpose2d(gy[n:n + 1].cpu().double(), w[n % T].cpu().double(), padding=pad) for n in range(N)], 0)
         gerr = ((gx.cpu().double() - gref).abs().max() / gref.abs().max()).item()
-        worst = max(worst, err, gerr)
+        # weight gradient
+        gw = hip_ops.convk_wgrad_tasks(x, gy, T, K, pad)
+        wref = torch.stack([torch.nn.grad.conv2d_weight(x[t::T].cpu().double(), (co, ci, K, K), gy[t::T].cpu().double(), padding=pad)
+                            for t in range(T)], 0)
+        werr = ((gw.cpu().double() - wref).abs().max() / wref.abs().max()).item()
+        worst = max(worst, err, gerr, werr)
         print(json.dumps({"check": "K%d %d->%d @%dx%d pad %d T%d N%d" % (K, ci, co, H, W, pad, T, N), "fwd_err": err, "cpu_f32_conv_err": err32,
-                          "dgrad_err": gerr, "ok": bool(err < 2e-6 and gerr < 2e-6)}), flush=True)
+                          "dgrad_err": gerr, "wgrad_err": werr, "ok": bool(err < 3e-6 and gerr < 3e-6 and werr < 3e-6)}), flush=True)
     print(json.dumps({"worst_rel_err": worst}), flush=True)
     return worst
 
@@ -85,7 +90,11 @@ def time_layers(iters, miopen=True):
         row["pack_both"] = timeit(lambda: hip_ops.convk_filters(w, True, True), iters)
         row["convk_fwd"] = timeit(lambda: hip_ops.convk_tasks_pre(x, pf, T, ci, co, K, b, 0, 0.0, pad), iters)
         row["convk_dgrad"] = timeit(lambda: hip_ops.convk_tasks_pre(gy, pb, T, ci, co, K, None, 1, 1.0, pad), iters)
+        row["convk_fwd_precise"] = timeit(lambda: hip_ops.convk_tasks_pre(x, pf, T, ci, co, K, b, 0, 0.0, pad, True), iters)
+        row["convk_wgrad_precise"] = timeit(lambda: hip_ops.convk_wgrad_tasks(x, gy, T, K, pad, True), iters)
+        row["convk_wgrad"] = timeit(lambda: hip_ops.convk_wgrad_tasks(x, gy, T, K, pad), iters)
         if K == 3:
+            row["wino_wgrad"] = timeit(lambda: hip_ops.conv3x3_wgrad_tasks(x, gy, T, pad), iters)
             uf, ub = hip_ops.conv3x3_filters(w, True, True)
             row["wino_filters"] = timeit(lambda: hip_ops.conv3x3_filters(w, True, True), iters)
             row["wino_fwd"] = timeit(lambda: hip_ops.conv3x3_tasks_pre(x, uf, T, ci, co, b, 0, 0.0, pad), iters)
@@ -102,6 +111,7 @@ def time_layers(iters, miopen=True):
                 row[k] = round(v, 1)
         row["convk_fwd_TF"] = round(gflop / row["convk_fwd"] * 1e3, 1)
         row["convk_dgrad_TF"] = round(gflop / row["convk_dgrad"] * 1e3, 1)
+        row["convk_wgrad_TF"] = round(gflop / row["convk_wgrad"] * 1e3, 1)
         if K == 3:
             row["wino_fwd_TF"] = round(gflop / row["wino_fwd"] * 1e3, 1)
         if miopen:
