@@ -16,10 +16,15 @@ The line also carries
                  (4*[B*3*(Ho+50)(Wo+50) + 4*B*51*Ho*Wo + B*3*Ho*Wo]) / mean launch time from HIP events
                  recorded on the launch stream INSIDE the timed region (single stream: nothing shares the GPU with a
                  launch), against the 8 TB/s HBM peak; `traffic` from the committed rocprofv3 --pmc measurement;
+  roofline_mfma: the convolution kernels (Winograd on fp32 MFMA, direct on split-bf16 MFMA), timed in place with HIP events in
+                 ONE extra iteration of the timed system after the timed region: direct-equivalent TFLOP/s per kernel family
+                 against that family's matrix-pipe ceiling;
   cpu_baseline : the CPU oracle (oracle/meta.py, the restatement pinned to the reference) timed on the host cores for a
-                 bounded sample of the same workload (1 task x 3 inner steps at full resolution, incl. target pass and outer
+                 bounded sample of the same workload (task 0, all inner steps at full resolution, incl. target pass and outer
                  backward);
-  parity_check : that same oracle sample against the HIP path on the same task, steps and weights (loss, pixel L1, PSNR).
+  parity_check : that same oracle sample against the TIMED system in the TIMED mode: theta restored to the seeded weights, the
+                 outer step disabled, one more meta-iteration over the same meta-batch (tasks in lockstep), task 0's
+                 prediction / loss / PSNR against the oracle's.
 """
 import argparse
 import json
@@ -58,11 +63,22 @@ WORKLOADS = {
     # host-path check without a GPU (tests/test_task_parallel_cpu.py: world 2 over gloo): toy conv plugin from tests/helpers.py
     'toy_cpu': ('toy', 16, 24, 3, 2, dict()),
 }
-CPU_SAMPLE_STEPS = 3
 
 
-def cpu_baseline(model, H, W, overrides):
-    """Oracle (CPU restatement) on a bounded sample: 1 task x CPU_SAMPLE_STEPS inner steps, full resolution.
+def _cpu_model():
+    try:
+        with open('/proc/cpuinfo') as fh:
+            for line in fh:
+                if line.lower().startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
+def cpu_baseline(model, H, W, S, overrides):
+    """Oracle (CPU restatement) on a bounded sample: task 0 x S inner steps, full resolution.
     Returns (json dict, oracle result) -- the result feeds parity_check."""
     from meta_interpolation_amd import synthetic
     from oracle import meta, rules
@@ -75,42 +91,61 @@ def cpu_baseline(model, H, W, overrides):
     frames = synthetic.septuplet_batch(1, H, W, model=model)
     kind = 'metasgd' if overrides.get('metasgd') else 'lslr'
     names_w = {n: base[n] for n in meta.inner_param_names([(n, p) for n, p in base.items() if p.is_floating_point()])}
-    n_steps = CPU_SAMPLE_STEPS
-    lrs = rules.init_lrs(kind, names_w, overrides['inner_lr'], num_steps=n_steps)
+    lrs = rules.init_lrs(kind, names_w, overrides['inner_lr'], num_steps=S)
     t0 = time.perf_counter()
     res = meta.run_iteration(model, base, frames, rule=kind, optimizer=overrides['optimizer'], lrs=lrs,
-                             num_steps=n_steps, loss=overrides['loss'].split('*')[1], training=True)
+                             num_steps=S, loss=overrides['loss'].split('*')[1], training=True)
     res['loss'].backward()
     dt = time.perf_counter() - t0
-    line = {"value": n_steps / dt, "unit": "inner-loop steps/sec", "cores": cores, "kind": "port",
-            "sample": "1 task x %d inner steps (each: 2 support fwd+bwd + update) + target pass + outer backward "
-                      "at %dx%d, %s, wall %.1f s on %d threads" % (n_steps, H, W, model, dt, cores)}
+    line = {"value": S / dt, "unit": "inner-loop steps/sec", "cores": cores, "os_cpu_count": os.cpu_count(), "cpu_model": _cpu_model(),
+            "kind": "port",
+            "sample": "task 0 x %d inner steps (each: 2 support fwd+bwd + update) + target pass + outer backward "
+                      "at %dx%d, %s, wall %.1f s on %d threads" % (S, H, W, model, dt, cores)}
     return line, res
 
 
-def parity_check(model, H, W, overrides, oracle_res, dev):
-    """The HIP path on the oracle's sample: task 0, CPU_SAMPLE_STEPS inner steps, same seeded weights and frames."""
-    from meta_interpolation_amd import synthetic
+def parity_check(system, theta0, frames, model, H, W, S, oracle_res, dev, mode):
+    """The TIMED system in the TIMED mode against the oracle's sample: theta back to the seeded weights, outer step disabled,
+    one more meta-iteration over the same resident meta-batch; task 0 is the oracle's task."""
     from oracle import meta
-    from tests.helpers import build_system
-    import contextlib
-    with contextlib.redirect_stdout(sys.stderr):
-        system = build_system(model, dict(overrides, number_of_training_steps_per_iter=CPU_SAMPLE_STEPS,
-                                          number_of_evaluation_steps_per_iter=CPU_SAMPLE_STEPS, batch_size=1))
+    system.load_state_dict(theta0)
+    real_step = system.optimizer.step
     system.optimizer.step = lambda *a, **k: None
-    frames = synthetic.septuplet_batch(1, H, W, model=model)
-    losses, preds, _ = system.run_train_iter(data_batch=frames, epoch=0, do_evaluation=False)
-    torch.cuda.synchronize()
-    got, want = float(losses['loss'].detach()), float(oracle_res['loss'])
+    calls = []
+    orig = system._lockstep_body
+    system._lockstep_body = lambda *a, **k: (calls.append(len(a[1])), orig(*a, **k))[1]
+    try:
+        losses, preds, _ = system.run_train_iter(data_batch=frames, epoch=0, do_evaluation=False)
+        torch.cuda.synchronize()
+    finally:
+        system.optimizer.step = real_step
+        system._lockstep_body = orig
     a = preds[0].squeeze(0).detach().cpu()
     b = system._to_unit_range(oracle_res['preds'][0].squeeze(0).to(dev)).cpu()
     tgt = system._to_unit_range(frames[3][0].to(dev)).cpu()
     l1 = float((a - b).abs().mean())
     dpsnr = abs(meta.psnr(a, tgt) - meta.psnr(b, tgt))
+    # task 0's loss term of the meta-batch = criterion(prediction, target) in the plugin's own value range
+    crit = (lambda p, t: (p - t).abs().mean()) if 'L1' in system.args.loss else (lambda p, t: (p - t).pow(2).mean())
+    with torch.no_grad():
+        got = float(crit(preds[0].squeeze(0).to(dev) if model not in ('voxelflow', 'superslomo') else
+                         _from_unit_range(system, preds[0].squeeze(0).to(dev)), frames[3][0].to(dev)))
+    want = float(oracle_res['loss'])
     rel = abs(got - want) / max(abs(want), 1e-30)
+    how = ("lockstep T=%s" % calls) if calls else ("hipGraph replays" if getattr(system, '_graphs', None) else "sequential task loop")
     return {"loss_rel": rel, "pixel_l1": l1, "dpsnr_db": dpsnr, "ok": bool(rel <= 1e-5 and l1 <= 1e-4 and dpsnr <= 1e-3),
             "bounds": {"loss_rel": 1e-5, "pixel_l1": 1e-4, "dpsnr_db": 1e-3},
-            "sample": "HIP path vs the CPU oracle of cpu_baseline: task 0, %d inner steps, %dx%d" % (CPU_SAMPLE_STEPS, H, W)}
+            "sample": "the timed system in the timed mode (%s, execution switches %s): one more meta-iteration of %d tasks from the "
+                      "seeded theta, task 0 vs the CPU oracle of cpu_baseline, %d inner steps, %dx%d" % (how, mode, len(frames[0]), S, H, W)}
+
+
+def _from_unit_range(system, img01):
+    """Inverse of SceneAdaptiveInterpolation._to_unit_range (predictions are returned in 0..1; the loss lives in the plugin's range)."""
+    if system.args.model == 'voxelflow':
+        return (img01 * 255.0 - system.mean) / system.std
+    if system.args.model == 'superslomo':
+        return img01 - (system.revNormalize(torch.zeros_like(img01)))
+    return img01
 
 
 def main():
@@ -131,6 +166,9 @@ def main():
                          '(off by default: the default command runs ONE mode, so that a rocprofv3 trace of it shows the kernels of `value` only)')
     ap.add_argument('--wgrad-overlap', type=int, default=None, help='weight gradients of support passes on a side stream')
     ap.add_argument('--task-batch', type=int, default=None, help='tasks adapted in lockstep (one launch per layer for all of them)')
+    ap.add_argument('--global-batch', type=int, default=None,
+                    help='FIXED global meta-batch (strong scaling: tasks/GPU = global / gpus, e.g. 32 for BASELINE config 4); default: '
+                         'the workload\'s tasks per GPU on every rank (weak scaling)')
     opt = ap.parse_args()
 
     from meta_interpolation_amd import _hip, synthetic, task_parallel
@@ -152,6 +190,11 @@ def main():
             torch.cuda.synchronize()
 
     model, H, W, tasks, S, over = WORKLOADS[opt.workload]
+    scaling = "weak"
+    if opt.global_batch:
+        if opt.global_batch % world:
+            raise SystemExit("--global-batch %d is not a multiple of %d ranks" % (opt.global_batch, world))
+        tasks, scaling = opt.global_batch // world, "strong"
     switches = {k: v for k, v in dict(fuse_conv_act=opt.fuse_conv_act, graph_inner_loop=opt.graph_inner_loop,
                                       sepconv_window=opt.sepconv_window, task_streams=opt.task_streams,
                                       wgrad_overlap=opt.wgrad_overlap, task_batch=opt.task_batch).items() if v is not None}
@@ -181,15 +224,20 @@ def main():
     frames = synthetic.septuplet_batch(tasks * world, H, W, model='sepconv' if toy else model)
     frames = [f.to(dev) for f in frames]                # inputs resident in HBM before the timed region
 
+    theta0 = {k: v.detach().clone() for k, v in system.state_dict().items()} if (rank == 0 and not toy) else None
+
     def one_iter(it):
         system.run_train_iter(data_batch=frames, epoch=0, do_evaluation=False)
 
     for i in range(opt.warmup):
         one_iter(i)
 
+    # HIP events around the HBM-bound custom launches of the workload only (a handful per iteration: the host stays ahead)
+    HBM_KERNELS = {'sepconv': ('sepconv',), 'voxelflow': ('voxelwarp', 'mt_update'), 'cain': ('pixel_', 'mt_update'),
+                   'rrin': ('flowwarp', 'mt_update'), 'superslomo': ('flowwarp', 'mt_update')}
     timer = None
-    if not opt.no_kernel_timer and model == 'sepconv':
-        timer = _hip.KernelTimer(only='sepconv')   # HIP events around the custom sepconv launches only
+    if not opt.no_kernel_timer and model in HBM_KERNELS:
+        timer = _hip.KernelTimer(only=HBM_KERNELS[model])
         _hip.TIMER = timer
     tp.barrier()
     sync()
@@ -212,7 +260,7 @@ def main():
     line = {
         "metric": "inner-loop steps/sec", "value": inner_steps / elapsed, "unit": "inner-loop steps/sec",
         "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": 1e3 * elapsed / opt.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": opt.workload, "plugin": model, "tasks_per_gpu": tasks, "global_meta_batch": tasks * world,
                    "inner_steps": S, "frame": "%dx%dx3" % (H, W),
                    "inner_rule": ("metasgd" if over.get('metasgd') else "lslr") + "+" + over.get('optimizer', 'SGD'),
@@ -228,7 +276,7 @@ def main():
                 # the op runs on the frame window (H x W) or, with --sepconv-window 0, on the reference's padded canvas
                 oh, ow = (H, W) if args.sepconv_window else net.padded_size(H, W)
                 traffic, tnote = None, "no committed PMC measurement found"
-                for tname in ("r02_hbm_traffic_sepconv.json", "r01_hbm_traffic_sepconv.json"):
+                for tname in ("r03_hbm_traffic_sepconv.json", "r02_hbm_traffic_sepconv.json", "r01_hbm_traffic_sepconv.json"):
                     tpath = os.path.join(REPO, "profiles", tname)
                     if not os.path.exists(tpath):
                         continue
@@ -252,6 +300,48 @@ def main():
                     "note": "algorithmic bytes = %.2f MB per [1,3,%d,%d] sample (x samples per launch: tasks in lockstep x the "
                             "support pair); fp32 issue ceiling of this op is ~53%% of HBM peak (SURVEY.md 7)"
                             % (per_call / 1e6, oh, ow)}
+            elif summ:
+                # workloads without the 51-tap op: the HBM-bound savfi kernel that takes the most time in the timed region
+                # (VoxelFlow: warp + fused update; CAIN: pixel (un)shuffle + fused update), algorithmic bytes from its launches
+                name = max((n for n in summ if summ[n]["algorithmic_bytes"]), key=lambda n: summ[n]["total_ms"], default=None)
+                if name:
+                    k = summ[name]
+                    line["roofline"] = {
+                        "bound": "hbm", "kernel": name, "achieved": k["achieved_GBps"], "peak": 8000.0, "unit": "GB/s",
+                        "frac": k["achieved_GBps"] / 8000.0, "traffic": None, "traffic_source": "no PMC measurement for this kernel",
+                        "avg_us_per_launch": k["avg_us"], "launches": k["launches"],
+                        "algorithmic_bytes_per_launch": k["algorithmic_bytes"] / k["launches"],
+                        "note": "largest HBM-bound savfi kernel of this workload by time; launches of a few microseconds are "
+                                "latency-bound, not bandwidth-bound (see `kernels` for the others)"}
+        if world == 1 and not toy and dev.type == 'cuda' and not opt.no_kernel_timer and not getattr(system, '_graphs', None):
+            # ONE extra meta-iteration of the timed system with HIP events around every convolution launch (outside the timed
+            # region: ~600 event records per iteration would sit between the kernels of `value`)
+            ct = _hip.KernelTimer(only=('conv3x3', 'convk'))
+            _hip.TIMER = ct
+            try:
+                one_iter(0)
+                sync()
+            finally:
+                _hip.TIMER = None
+            cs = ct.summary()
+            fam = {"winograd_f32_mfma": ("conv3x3_fwd", "conv3x3_bwd_data"), "winograd_wgrad_f32_mfma": ("conv3x3_wgrad",),
+                   "direct_bf16x6_mfma": ("convk_fwd", "convk_bwd_data"), "direct_wgrad_bf16x6_mfma": ("convk_wgrad",)}
+            # ceilings in direct-equivalent TFLOP/s: fp32 MFMA 157.3 x 2.25 (Winograd F(2x2,3x3) / F(3x3,2x2)); bf16 MFMA 2500 / 6 products
+            peak = {"winograd_f32_mfma": 353.9, "winograd_wgrad_f32_mfma": 353.9, "direct_bf16x6_mfma": 416.7, "direct_wgrad_bf16x6_mfma": 416.7}
+            rows, tot_ms, tot_fl = {}, 0.0, 0.0
+            for f, names in fam.items():
+                ms = sum(cs[n]["total_ms"] for n in names if n in cs)
+                fl = sum(cs[n].get("direct_flops", 0.0) for n in names if n in cs)
+                if ms > 0:
+                    rows[f] = {"ms_per_iteration": ms, "direct_TFLOP": fl / 1e12, "achieved": fl / ms / 1e9, "peak": peak[f],
+                               "frac": fl / ms / 1e9 / peak[f], "launches": sum(cs[n]["launches"] for n in names if n in cs)}
+                    tot_ms += ms
+                    tot_fl += fl
+            if rows:
+                line["roofline_mfma"] = {"bound": "mfma", "unit": "direct-equivalent TFLOP/s", "families": rows,
+                                         "all_conv_kernels": {"ms_per_iteration": tot_ms, "achieved": tot_fl / tot_ms / 1e9},
+                                         "note": "HIP events around every savfi convolution launch in one extra iteration of the timed "
+                                                 "system (same mode); Winograd ceilings = fp32 MFMA peak x 2.25, direct = bf16 MFMA peak / 6"}
         if world == 1 and not toy and opt.fast_path and not switches and not getattr(system, '_graphs', None):
             # The default mode adapted the tasks in lockstep in the eager loop (where the roofline kernel can be timed in place).
             # The same workload and step count again from hipGraph replays of single tasks on four task streams -- the fastest
@@ -282,9 +372,9 @@ def main():
             except Exception as e:
                 line["fast_path"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
         if world == 1 and not opt.no_cpu_baseline and not toy:
-            line["cpu_baseline"], oracle_res = cpu_baseline(model, H, W, over)
+            line["cpu_baseline"], oracle_res = cpu_baseline(model, H, W, S, over)
             try:
-                line["parity_check"] = parity_check(model, H, W, over, oracle_res, dev)
+                line["parity_check"] = parity_check(system, theta0, frames, model, H, W, S, oracle_res, dev, mode)
             except Exception as e:       # never lose the measurement over the checker
                 line["parity_check"] = {"ok": False, "error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         print(json.dumps(line), flush=True)

@@ -175,36 +175,45 @@ class KernelTimer:
 
     def __init__(self, only=None):
         self.records = {}
-        self.only = only          # time only launches whose name starts with this prefix (None = all)
+        # time only launches whose name starts with this prefix / one of these prefixes (None = all)
+        self.only = (only,) if isinstance(only, str) else (None if only is None else tuple(only))
 
-    def launch(self, name, fn, nbytes=0):
+    def wants(self, name):
+        return self.only is None or name.startswith(self.only)
+
+    def launch(self, name, fn, nbytes=0, flops=0):
         import torch
         a = torch.cuda.Event(enable_timing=True)
         b = torch.cuda.Event(enable_timing=True)
         a.record()
         fn()
         b.record()
-        self.records.setdefault(name, []).append((a, b, nbytes))
+        self.records.setdefault(name, []).append((a, b, nbytes, flops))
 
     def summary(self):
         import torch
         torch.cuda.synchronize()
         out = {}
         for name, evs in self.records.items():
-            ms = [a.elapsed_time(b) for a, b, _ in evs]
-            nbytes = sum(n for _, _, n in evs)
+            ms = [a.elapsed_time(b) for a, b, _, _ in evs]
+            nbytes = sum(n for _, _, n, _ in evs)
+            flops = sum(f for _, _, _, f in evs)
             out[name] = {"launches": len(ms), "total_ms": sum(ms), "avg_us": 1e3 * sum(ms) / len(ms),
                          "min_us": 1e3 * min(ms), "algorithmic_bytes": nbytes,
                          "achieved_GBps": (nbytes / (sum(ms) * 1e-3) / 1e9) if sum(ms) > 0 else None}
+            if flops:
+                out[name]["direct_flops"] = flops
+                out[name]["direct_TFLOPs"] = flops / (sum(ms) * 1e-3) / 1e12 if sum(ms) > 0 else None
         return out
 
 
 TIMER = None  # set to a KernelTimer instance to time launches
 
 
-def launch(name, fn, nbytes=0):
-    """Run one C-ABI launch; `nbytes` = its algorithmic HBM bytes (each operand once), for the timer."""
-    if TIMER is None or (TIMER.only is not None and not name.startswith(TIMER.only)):
+def launch(name, fn, nbytes=0, flops=0):
+    """Run one C-ABI launch; `nbytes` = its algorithmic HBM bytes (each operand once), `flops` = its direct-convolution
+    floating-point operations, for the timer."""
+    if TIMER is None or not TIMER.wants(name):
         fn()
     else:
-        TIMER.launch(name, fn, nbytes)
+        TIMER.launch(name, fn, nbytes, flops)

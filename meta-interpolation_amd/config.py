@@ -12,7 +12,7 @@ Additions for the MI355X build (all optional, all default to the reference behav
   --task_streams N             adapt N tasks of a meta-batch concurrently (one Python thread + HIP stream each); default -1:
                                1 in the eager loops, up to 4 where single tasks are replayed from hipGraphs
   --task_batch T               adapt up to T tasks of a meta-batch in LOCKSTEP: one launch per layer for all of them, per-task fast
-                               weights (default 4; first order -- second order, L2F on partly routed plugins and T <= 1 take the
+                               weights (default 8; first order -- second order, L2F on partly routed plugins and T <= 1 take the
                                reference's sequential task loop)
   --synthetic                  feed seeded synthetic septuplets instead of reading a dataset
 """
@@ -48,7 +48,7 @@ _FLAGS = {
     ],
     'MI355X': [
         ('fuse_support_pairs', int, 1), ('fuse_conv_act', int, 1), ('graph_inner_loop', int, -1), ('sepconv_window', int, 1),
-        ('task_streams', int, -1), ('wgrad_overlap', int, 0), ('task_batch', int, 4),
+        ('task_streams', int, -1), ('wgrad_overlap', int, 0), ('task_batch', int, 8),
         ('synthetic', 'flag', False),
     ],
 }

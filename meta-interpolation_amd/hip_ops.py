@@ -42,7 +42,7 @@ class _VoxelWarp(torch.autograd.Function):
         lib = _hip.lib()
         _hip.launch("voxelwarp_fwd", lambda: _hip.check(lib.savfi_voxelwarp_fwd_f32(
             frames.data_ptr(), x3.data_ptr(), out.data_ptr(), B, H, W, _hip.current_stream()),
-            "savfi_voxelwarp_fwd_f32"))
+            "savfi_voxelwarp_fwd_f32"), nbytes=4 * 12 * B * H * W)
         ctx.save_for_backward(frames, x3)
         return out
 
@@ -59,7 +59,7 @@ class _VoxelWarp(torch.autograd.Function):
         _hip.launch("voxelwarp_bwd", lambda: _hip.check(lib.savfi_voxelwarp_bwd_f32(
             frames.data_ptr(), x3.data_ptr(), gO.data_ptr(), g_x3.data_ptr(),
             None if g_fr is None else g_fr.data_ptr(), B, H, W, _hip.current_stream()),
-            "savfi_voxelwarp_bwd_f32"))
+            "savfi_voxelwarp_bwd_f32"), nbytes=4 * 15 * B * H * W)
         return g_fr, (g_x3 if need_x else None)
 
 
@@ -177,12 +177,12 @@ def _launch_shuffle(x, r, down):
         assert H % r == 0 and W % r == 0
         out = torch.empty((B, C * r * r, H // r, W // r), dtype=x.dtype, device=x.device)
         _hip.launch("pixel_unshuffle", lambda: _hip.check(lib.savfi_pixel_unshuffle_f32(
-            x.data_ptr(), out.data_ptr(), B, C, H, W, r, _hip.current_stream()), "savfi_pixel_unshuffle_f32"))
+            x.data_ptr(), out.data_ptr(), B, C, H, W, r, _hip.current_stream()), "savfi_pixel_unshuffle_f32"), nbytes=8 * x.numel())
     else:
         assert C % (r * r) == 0
         out = torch.empty((B, C // (r * r), H * r, W * r), dtype=x.dtype, device=x.device)
         _hip.launch("pixel_shuffle", lambda: _hip.check(lib.savfi_pixel_shuffle_f32(
-            x.data_ptr(), out.data_ptr(), B, C, H, W, r, _hip.current_stream()), "savfi_pixel_shuffle_f32"))
+            x.data_ptr(), out.data_ptr(), B, C, H, W, r, _hip.current_stream()), "savfi_pixel_shuffle_f32"), nbytes=8 * x.numel())
     return out
 
 
@@ -296,7 +296,9 @@ def _launch_mt_update(rule, lr_mode, ws, gs, lrs, ms, ss, outs, coefs, bc1, sqrt
             _hip.i64_array([w.numel() for w in ws]),
             _hip.f32_array(bc1) if bc1 is not None else None, _hip.f32_array(sqrt_bc2) if sqrt_bc2 is not None else None,
             beta1, beta2, eps, _hip.current_stream())
-    _hip.launch("mt_update", lambda: _hip.check(lib.savfi_mt_update_f32(*args), "savfi_mt_update_f32"))
+    per_el = 12 + (4 if lr_mode == _hip.LR_ELEMENT else 0) + (8 if ms is not None else 0) + (8 if ss is not None else 0) + (4 if coefs is not None else 0)
+    _hip.launch("mt_update", lambda: _hip.check(lib.savfi_mt_update_f32(*args), "savfi_mt_update_f32"),
+                nbytes=per_el * sum(w.numel() for w in ws))
 
 
 def mt_update(rule, lr_mode, weights, grads, lrs, m=None, s=None, bc1=None, sqrt_bc2=None,
@@ -808,7 +810,8 @@ def conv3x3_tasks(x, weight, bias=None, mode=0, slope=1.0, pad=1):
     out = torch.empty((N, I, H + grow, W + grow), dtype=x.dtype, device=x.device)
     _hip.launch("conv3x3_fwd" if mode == 0 else "conv3x3_bwd_data", lambda: _hip.check(lib.savfi_conv3x3_tasks_f32(
         x.data_ptr(), weight.data_ptr(), None if bias is None else bias.data_ptr(), out.data_ptr(), ws.data_ptr(),
-        N, T, Ci, Co, H, W, int(pad), mode, float(slope), _hip.current_stream()), "savfi_conv3x3_tasks_f32"))
+        N, T, Ci, Co, H, W, int(pad), mode, float(slope), _hip.current_stream()), "savfi_conv3x3_tasks_f32"),
+        flops=18.0 * Ci * Co * out.shape[2] * out.shape[3] * N if mode == 0 else 18.0 * Ci * Co * H * W * N)
     return out
 
 
@@ -842,7 +845,8 @@ def conv3x3_tasks_pre(x, u, T, Ci, Co, bias=None, mode=0, slope=1.0, pad=1):
     out = torch.empty((N, I, H + grow, W + grow), dtype=x.dtype, device=x.device)
     _hip.launch("conv3x3_fwd" if mode == 0 else "conv3x3_bwd_data", lambda: _hip.check(lib.savfi_conv3x3_tasks_pre_f32(
         x.data_ptr(), u.data_ptr(), None if bias is None else bias.data_ptr(), out.data_ptr(), None if ws is None else ws.data_ptr(),
-        N, T, Ci, Co, H, W, int(pad), mode, float(slope), _hip.current_stream()), "savfi_conv3x3_tasks_pre_f32"))
+        N, T, Ci, Co, H, W, int(pad), mode, float(slope), _hip.current_stream()), "savfi_conv3x3_tasks_pre_f32"),
+        flops=18.0 * Ci * Co * out.shape[2] * out.shape[3] * N if mode == 0 else 18.0 * Ci * Co * H * W * N)
     return out
 
 
@@ -876,7 +880,8 @@ def convk_tasks_pre(x, packed, T, Ci, Co, K, bias=None, mode=0, slope=1.0, pad=1
     lib = _hip.lib()
     _hip.launch("convk_fwd" if mode == 0 else "convk_bwd_data", lambda: _hip.check(lib.savfi_convk_tasks_pre_f32(
         x.data_ptr(), packed.data_ptr(), None if bias is None else bias.data_ptr(), out.data_ptr(), N, T, Ci, Co, H, W, K, int(pad),
-        mode, float(slope), int(bool(precise)), _hip.current_stream()), "savfi_convk_tasks_pre_f32"))
+        mode, float(slope), int(bool(precise)), _hip.current_stream()), "savfi_convk_tasks_pre_f32"),
+        flops=2.0 * K * K * Ci * Co * N * (out.shape[2] * out.shape[3] if mode == 0 else H * W))
     return out
 
 
@@ -892,7 +897,7 @@ def convk_wgrad_tasks(x, gz, T, K, pad, precise=False):
     gw = torch.empty((T, Co, Ci, K, K), dtype=x.dtype, device=x.device)
     _hip.launch("convk_wgrad", lambda: _hip.check(lib.savfi_convk_wgrad_tasks_f32(
         x.data_ptr(), gz.data_ptr(), gw.data_ptr(), ws.data_ptr(), N, T, Ci, Co, H, W, K, int(pad), int(bool(precise)),
-        _hip.current_stream()), "savfi_convk_wgrad_tasks_f32"))
+        _hip.current_stream()), "savfi_convk_wgrad_tasks_f32"), flops=2.0 * K * K * Ci * Co * N * gz.shape[2] * gz.shape[3])
     return gw
 
 
@@ -914,7 +919,7 @@ def conv3x3_wgrad_tasks(x, gz, T, pad=1, stream=None, extra_stream=None):
     entry = "savfi_conv3x3_wgrad_%stasks_f32" % form
     _hip.launch("conv3x3_wgrad", lambda: _hip.check(getattr(lib, entry)(
         x.data_ptr(), gz.data_ptr(), gw.data_ptr(), ws.data_ptr(), N, T, Ci, Co, H, W, int(pad),
-        _hip.current_stream() if stream is None else stream), entry))
+        _hip.current_stream() if stream is None else stream), entry), flops=18.0 * Ci * Co * gz.shape[2] * gz.shape[3] * N)
     return gw
 
 
@@ -1094,7 +1099,8 @@ def conv3x3(x, weight, bias=None, mode=0, slope=1.0, pad=1):
     out = torch.empty((N, I, H + grow, W + grow), dtype=x.dtype, device=x.device)
     _hip.launch("conv3x3_fwd" if mode == 0 else "conv3x3_bwd_data", lambda: _hip.check(lib.savfi_conv3x3_f32(
         x.data_ptr(), weight.data_ptr(), None if bias is None else bias.data_ptr(), out.data_ptr(), ws.data_ptr(),
-        N, Ci, Co, H, W, int(pad), mode, float(slope), _hip.current_stream()), "savfi_conv3x3_f32"))
+        N, Ci, Co, H, W, int(pad), mode, float(slope), _hip.current_stream()), "savfi_conv3x3_f32"),
+        flops=18.0 * Ci * Co * out.shape[2] * out.shape[3] * N if mode == 0 else 18.0 * Ci * Co * H * W * N)
     return out
 
 
@@ -1118,7 +1124,7 @@ def conv3x3_wgrad(x, gz, pad=1, stream=None, extra_stream=None):
         gw.record_stream(extra_stream)
     _hip.launch("conv3x3_wgrad", lambda: _hip.check(lib.savfi_conv3x3_wgrad_f32(
         x.data_ptr(), gz.data_ptr(), gw.data_ptr(), ws.data_ptr(), N, Ci, Co, H, W, int(pad),
-        _hip.current_stream() if stream is None else stream), "savfi_conv3x3_wgrad_f32"))
+        _hip.current_stream() if stream is None else stream), "savfi_conv3x3_wgrad_f32"), flops=18.0 * Ci * Co * gz.shape[2] * gz.shape[3] * N)
     return gw
 
 

@@ -24,11 +24,11 @@ _TRUNK = [("conv1", 6, 64, 5), ("conv2", 64, 128, 5), ("conv3", 128, 256, 3), ("
 
 
 class MetaVoxelFlow(nn.Module):
-    # tasks of a meta-batch are adapted one after another, not in lockstep (meta_learning_system._lockstep_width): five of
-    # the eight layers are 5x5 convolutions, which have no savfi kernel (one MIOpen call per task either way: config C3
-    # measures 134.7 steps/s sequential, 136.1 in lockstep), and the three 3x3 layers would move from MIOpen to the savfi
-    # Winograd kernel, whose coarser rounding this network amplifies (tests/test_system_gpu.py::lockstep_for)
-    lockstep_tasks = False
+    # Round 3: every layer (five 5x5, three 3x3) runs on the direct split-bf16 convolution kernels in `precise` mode with per-task
+    # filter sets (hip_ops.convk_*), so the tasks of a meta-batch advance in lockstep like the other plugins (config C3:
+    # 208 steps/s from graphs on four task streams, 254 with its 8 tasks in one lockstep group).  BatchNorm is frozen in eval
+    # mode (no coupling between samples), fast weights are read through MetaConv2dLayer only.
+    lockstep_tasks = True
 
     def __init__(self, config, resume=False):
         super().__init__()

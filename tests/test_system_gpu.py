@@ -538,11 +538,10 @@ def test_sepconv_trains_from_a_vimeo_directory_through_the_frame_stager(tmp_path
 # ---------------------------------------------------------------------------------------------
 @pytest.fixture
 def lockstep_for(monkeypatch):
-    """Force lockstep on a plugin that opts out (VoxelFlow, where it is speed-neutral) so that its per-task layers exercise
-    the generic fallbacks -- ONE grouped MIOpen convolution on small maps, one plain call per task on large ones.  Its 3x3
-    layers are kept off the savfi Winograd kernel like in the product path: F(2x2,3x3) rounds ~3x coarser than a direct
-    convolution (2e-7 of the output scale), and VoxelFlow's flow-to-pixel map turns that into 1e-3 of a step-0 gradient
-    fingerprint and 1.7e-3 pixel L1 after two steps (against 1.4e-4 / 6.6e-5 through MIOpen; measured, 64x64 fixture)."""
+    """Lockstep switch for the lockstep tests.  Every shipped plugin opts in (VoxelFlow since round 3: its layers run on the
+    direct split-bf16 kernels with per-task filter sets).  For VoxelFlow the Winograd task kernels are additionally fenced off:
+    F(2x2,3x3) rounds ~3x coarser than a direct convolution and its flow-to-pixel map turns that into 1e-3 of a step-0 gradient
+    fingerprint -- the product never sends its layers there (MetaConv2dLayer(direct=True)), the fence keeps it that way here."""
     def apply(system, model):
         system.net.lockstep_tasks = True
         if model == 'voxelflow':
@@ -666,12 +665,10 @@ def test_graphed_lockstep_tasks_match_reference_fixture(name, phase, lockstep_fo
 
 
 def test_default_execution_mode_policy():
-    """config.py defaults (--graph_inner_loop -1, --task_batch 4): a rank with ONE task replays hipGraphs (launch-bound pass), a rank
+    """config.py defaults (--graph_inner_loop -1, --task_batch 8): a rank with ONE task replays hipGraphs (launch-bound pass), a rank
     with several adapts them in lockstep in the eager loop, L2F (not capturable) stays eager -- all with the fixture's numbers."""
-    # VoxelFlow opts out of the lockstep path: its two tasks are replayed from hipGraphs, one graph set per task stream
-    # (--task_streams -1: up to four streams under graphs, one in the eager loops)
     for name, want_graphs, want_lockstep in (('c1_cain_lslr_sgd', 1, 0), ('sepconv_msl_learnable_2step', 0, 1), ('cain_l2f', 0, 0),
-                                             ('voxelflow_lslr_sgd_2step', 2, 0)):
+                                             ('voxelflow_lslr_sgd_2step', 0, 1)):
         g = golden("system_" + name)
         model = str(g['model'])
         system = build_system(model, dict(parse_case_args(g), graph_inner_loop=-1, task_streams=-1))
