@@ -33,6 +33,7 @@
  *                              implicit GEMM on the bf16 matrix cores from error-free 3-way operand splits (fp32-equivalent)
  *                                                                     voxelflow/core/models/voxel_flow.py:357-470 (5x5 layers),
  *                                                                     superslomo/model.py:547-646 (7x7 / 5x5), model_utils.py:308-366
+ *   savfi_ca_pool/mlp_fwd/mlp_bwd/apply_f32   channel attention + residual of CAIN's RCAB   model_utils.py:931-953, :957-990
  *   savfi_frames_u8_to_f32     HWC uint8 frames -> normalised fp32 NCHW  data/vimeo_septuplet.py:68-80, data/video.py:44-51
  *   savfi_*_workspace_floats / savfi_bias_act_scratch_floats: sizes of the caller-owned scratch buffers (return int64_t)
  *
@@ -317,6 +318,25 @@ int savfi_convk_tasks_pre_f32(const float* x, const float* packed, const float* 
 int64_t savfi_convk_wgrad_workspace_floats(int N, int T, int Ci, int Co, int H, int W, int K, int pad);
 int savfi_convk_wgrad_tasks_f32(const float* x, const float* gz, float* gw, float* workspace, int N, int T, int Ci, int Co,
                                 int H, int W, int K, int pad, int precise, void* stream);
+
+/* ----------------------------------------------------------------------------------
+ * Channel attention + residual of CAIN's RCAB (model_utils.py:931-953 MetaCALayer, :957-990 MetaRCAB):
+ *   s = mean_hw(t);  y = sigmoid(W2 relu(W1 s + b1) + b2);  out = t * y + x        t, x, out [N,C,H,W]; T weight sets (n % T)
+ *   savfi_ca_pool_f32       s[plane] = scale * sum_hw a[plane][.] (* b[plane][.] when b != NULL)       planes = N*C
+ *   savfi_ca_mlp_fwd_f32    y [N,C], a1 [N,Cr] (hidden activations, kept for the backward) from s [N,C]; w1 [T,Cr,C], b1 [T,Cr],
+ *                           w2 [T,C,Cr], b2 [T,C]; C <= 1024, Cr <= 64
+ *   savfi_ca_mlp_bwd_f32    r [N,C] = sum_hw g*t  ->  ds [N,C] (gradient w.r.t. s, times inv_hw) and gw1, gb1, gw2, gb2 per task
+ *   savfi_ca_apply_f32      out = a * y[plane] + x          (x != NULL: forward, x = the skip connection)
+ *                           out = a * y[plane] + ds[plane]  (x == NULL: backward, gradient w.r.t. t)
+ * ---------------------------------------------------------------------------------- */
+int savfi_ca_pool_f32(const float* a, const float* b, float* s, int64_t planes, int hw, float scale, void* stream);
+int savfi_ca_mlp_fwd_f32(const float* s, const float* w1, const float* b1, const float* w2, const float* b2, float* y, float* a1,
+                         int N, int T, int C, int Cr, void* stream);
+int savfi_ca_mlp_bwd_f32(const float* r, const float* s, const float* y, const float* a1, const float* w1, const float* w2,
+                         float* ds, float* gw1, float* gb1, float* gw2, float* gb2, int N, int T, int C, int Cr, float inv_hw,
+                         void* stream);
+int savfi_ca_apply_f32(const float* a, const float* y, const float* x, const float* ds, float* out, int64_t planes, int hw,
+                       void* stream);
 
 /* ----------------------------------------------------------------------------------
  * Frame staging (data/vimeo_septuplet.py:68-80, data/video.py:44-51: channel swap, HWC->CHW, .float()/255,

@@ -75,6 +75,10 @@ _PROTOTYPES = {
     "savfi_convk_tasks_pre_f32": [_P, _P, _P, _P] + [c_int] * 9 + [c_float, c_int, _P],
     "savfi_convk_wgrad_workspace_floats": [c_int] * 8,
     "savfi_convk_wgrad_tasks_f32": [_P, _P, _P, _P] + [c_int] * 9 + [_P],
+    "savfi_ca_pool_f32": [_P, _P, _P, c_int64, c_int, c_float, _P],
+    "savfi_ca_mlp_fwd_f32": [_P] * 7 + [c_int] * 4 + [_P],
+    "savfi_ca_mlp_bwd_f32": [_P] * 11 + [c_int] * 4 + [c_float, _P],
+    "savfi_ca_apply_f32": [_P] * 5 + [c_int64, c_int, _P],
     "savfi_frames_u8_to_f32": [_P, _P, c_int64, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float, _P],
     "savfi_upsample2x_window_fwd_f32": [_P, _P] + [c_int] * 12 + [_P],
     "savfi_upsample2x_window_bwd_f32": [_P, _P] + [c_int] * 12 + [_P],

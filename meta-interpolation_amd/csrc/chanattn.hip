@@ -1,0 +1,197 @@
+// Channel attention + residual of CAIN's RCAB (reference model_utils.py:931-953 MetaCALayer, :957-990 MetaRCAB) for gfx950:
+//
+//   s[n][c]  = mean over H x W of t[n][c]                                  (global average pool)
+//   y[n][c]  = sigmoid( W2 . relu( W1 . s[n] + b1 ) + b2 )[c]              (1x1 convs C -> C/r -> C on a 1x1 map)
+//   out      = t * y[n][c] + x                                             (scale, RCAB skip connection)
+//
+// The reference composes this from AdaptiveAvgPool2d, two F.conv2d on [N,C,1,1], ReLU, Sigmoid, a broadcast multiply and an add:
+// 8 launches forward and ~14 backward per block, 60 blocks per pass, each of the two map-sized ones a full HBM round trip of an
+// 11.8 MB map at 720p (config C5), the small ones pure launch latency.  Here: three launches forward (pool, MLP, scale + add) and
+// three backward (dot, MLP backward incl. the parameter gradients, scale backward); every map is read once per launch.
+// Per-task weights (tasks adapted in lockstep): T sets, sample n uses set n % T.  Deterministic (fixed-order reductions).
+#include "common.h"
+
+namespace {
+
+constexpr int CA_T = 256;
+
+// one workgroup per (n, c) plane: s = scale * sum_hw a[.] (* b[.] if b)
+__global__ __launch_bounds__(CA_T) void ca_pool_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ s,
+                                                       int hw, float scale) {
+  __shared__ float red[CA_T / SAVFI_WAVE];
+  const size_t base = (size_t)blockIdx.x * hw;
+  float acc = 0.f;
+  const int hw4 = hw & ~3;
+  if (((base * 4) & 15) == 0) {
+    const float4* a4 = reinterpret_cast<const float4*>(a + base);
+    const float4* b4 = b ? reinterpret_cast<const float4*>(b + base) : nullptr;
+    for (int i = threadIdx.x; i < hw4 / 4; i += CA_T) {
+      const float4 v = a4[i];
+      if (b4) { const float4 u = b4[i]; acc += v.x * u.x + v.y * u.y + v.z * u.z + v.w * u.w; }
+      else acc += (v.x + v.y) + (v.z + v.w);
+    }
+    for (int i = hw4 + threadIdx.x; i < hw; i += CA_T) acc += b ? a[base + i] * b[base + i] : a[base + i];
+  } else {
+    for (int i = threadIdx.x; i < hw; i += CA_T) acc += b ? a[base + i] * b[base + i] : a[base + i];
+  }
+  const float tot = block_sum<CA_T / SAVFI_WAVE>(acc, red);
+  if (threadIdx.x == 0) s[blockIdx.x] = tot * scale;
+}
+
+// one workgroup per sample: y = sigmoid(W2 relu(W1 s + b1) + b2); a1 = relu(...) kept for the backward
+__global__ __launch_bounds__(CA_T) void ca_mlp_fwd_kernel(const float* __restrict__ s, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                          const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ y,
+                                                          float* __restrict__ a1, int T, int C, int Cr) {
+  __shared__ float red[CA_T / SAVFI_WAVE];
+  __shared__ float hid[64];
+  const int n = blockIdx.x, t = n % T;
+  const float* sn = s + (size_t)n * C;
+  const float* W1 = w1 + (size_t)t * Cr * C;
+  const float* W2 = w2 + (size_t)t * C * Cr;
+  for (int j = 0; j < Cr; ++j) {
+    float p = 0.f;
+    for (int c = threadIdx.x; c < C; c += CA_T) p += W1[(size_t)j * C + c] * sn[c];
+    const float z = block_sum<CA_T / SAVFI_WAVE>(p, red);
+    if (threadIdx.x == 0) {
+      const float h = fmaxf(z + b1[t * Cr + j], 0.f);
+      hid[j] = h;
+      a1[(size_t)n * Cr + j] = h;
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += CA_T) {
+    float z = b2[t * C + c];
+    for (int j = 0; j < Cr; ++j) z += W2[(size_t)c * Cr + j] * hid[j];
+    y[(size_t)n * C + c] = 1.f / (1.f + __expf(-z));
+  }
+}
+
+// one workgroup per TASK: loops over its samples n = t, t + T, ...; r[n][c] = sum_hw g * t (from ca_pool_kernel)
+//   dz2 = r y (1 - y); da1 = W2^T dz2; dz1 = da1 [a1 > 0]; ds = W1^T dz1 * inv_hw          -> ds[n][c]
+//   gW2 += dz2 (x) a1, gb2 += dz2, gW1 += dz1 (x) s, gb1 += dz1                             -> per task
+__global__ __launch_bounds__(CA_T) void ca_mlp_bwd_kernel(const float* __restrict__ r, const float* __restrict__ s, const float* __restrict__ y,
+                                                          const float* __restrict__ a1, const float* __restrict__ w1, const float* __restrict__ w2,
+                                                          float* __restrict__ ds, float* __restrict__ gw1, float* __restrict__ gb1,
+                                                          float* __restrict__ gw2, float* __restrict__ gb2, int N, int T, int C, int Cr, float inv_hw) {
+  __shared__ float red[CA_T / SAVFI_WAVE];
+  __shared__ float dz1s[64], a1s[64];
+  const int t = blockIdx.x;
+  const float* W1 = w1 + (size_t)t * Cr * C;
+  const float* W2 = w2 + (size_t)t * C * Cr;
+  float* GW1 = gw1 + (size_t)t * Cr * C;
+  float* GW2 = gw2 + (size_t)t * C * Cr;
+  // thread c owns channels c, c + 256, ... (C <= 1024: up to 4) and their parameter-gradient rows
+  for (int c = threadIdx.x; c < C; c += CA_T) {
+    gb2[t * C + c] = 0.f;
+    for (int j = 0; j < Cr; ++j) { GW2[(size_t)c * Cr + j] = 0.f; GW1[(size_t)j * C + c] = 0.f; }
+  }
+  if (threadIdx.x < Cr) gb1[t * Cr + threadIdx.x] = 0.f;
+  __syncthreads();
+  for (int n = t; n < N; n += T) {
+    const float* rn = r + (size_t)n * C;
+    const float* yn = y + (size_t)n * C;
+    const float* sn = s + (size_t)n * C;
+    if (threadIdx.x < Cr) a1s[threadIdx.x] = a1[(size_t)n * Cr + threadIdx.x];
+    __syncthreads();
+    float dz2[4];
+    int k = 0;
+    for (int c = threadIdx.x; c < C; c += CA_T, ++k) {
+      const float yv = yn[c];
+      dz2[k] = rn[c] * yv * (1.f - yv);
+      gb2[t * C + c] += dz2[k];
+      for (int j = 0; j < Cr; ++j) GW2[(size_t)c * Cr + j] += dz2[k] * a1s[j];
+    }
+    for (int j = 0; j < Cr; ++j) {
+      float p = 0.f;
+      k = 0;
+      for (int c = threadIdx.x; c < C; c += CA_T, ++k) p += W2[(size_t)c * Cr + j] * dz2[k];
+      const float da = block_sum<CA_T / SAVFI_WAVE>(p, red);
+      if (threadIdx.x == 0) {
+        const float d = a1s[j] > 0.f ? da : 0.f;
+        dz1s[j] = d;
+        gb1[t * Cr + j] += d;
+      }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += CA_T) {
+      float v = 0.f;
+      for (int j = 0; j < Cr; ++j) {
+        v += W1[(size_t)j * C + c] * dz1s[j];
+        GW1[(size_t)j * C + c] += dz1s[j] * sn[c];
+      }
+      ds[(size_t)n * C + c] = v * inv_hw;
+    }
+    __syncthreads();
+  }
+}
+
+// out = a * y[plane] + (x ? x : ds[plane])        (forward: x = the skip connection; backward: the pooled-branch gradient)
+__global__ __launch_bounds__(CA_T) void ca_apply_kernel(const float* __restrict__ a, const float* __restrict__ y, const float* __restrict__ x,
+                                                        const float* __restrict__ ds, float* __restrict__ out, int hw, int chunks) {
+  const int plane = blockIdx.x / chunks, chunk = blockIdx.x - plane * chunks;
+  const float yv = y[plane], dv = ds ? ds[plane] : 0.f;
+  const size_t base = (size_t)plane * hw;
+  const int per = (hw + chunks - 1) / chunks;
+  const int lo = chunk * per, hi = min(lo + per, hw);
+  if (((base + lo) & 3) == 0) {
+    const int n4 = (hi - lo) / 4;
+    const float4* a4 = reinterpret_cast<const float4*>(a + base + lo);
+    const float4* x4 = x ? reinterpret_cast<const float4*>(x + base + lo) : nullptr;
+    float4* o4 = reinterpret_cast<float4*>(out + base + lo);
+    for (int i = threadIdx.x; i < n4; i += CA_T) {
+      const float4 v = a4[i];
+      float4 u = x4 ? x4[i] : make_float4(dv, dv, dv, dv);
+      o4[i] = make_float4(v.x * yv + u.x, v.y * yv + u.y, v.z * yv + u.z, v.w * yv + u.w);
+    }
+    for (int i = lo + 4 * n4 + threadIdx.x; i < hi; i += CA_T) out[base + i] = a[base + i] * yv + (x ? x[base + i] : dv);
+  } else {
+    for (int i = lo + threadIdx.x; i < hi; i += CA_T) out[base + i] = a[base + i] * yv + (x ? x[base + i] : dv);
+  }
+}
+
+inline int ca_chunks(int64_t planes, int hw) {
+  // enough workgroups to fill the GPU, at least 4096 elements each
+  int64_t want = (2048 + planes - 1) / planes;
+  int64_t maxc = (hw + 4095) / 4096;
+  int c = (int)(want < maxc ? want : maxc);
+  return c < 1 ? 1 : c;
+}
+
+}  // namespace
+
+extern "C" int savfi_ca_pool_f32(const float* a, const float* b, float* s, int64_t planes, int hw, float scale, void* stream) {
+  if (!a || !s) return SAVFI_E_NULL;
+  if (planes <= 0 || hw <= 0) return SAVFI_E_SHAPE;
+  if (planes >= (1ll << 31)) return SAVFI_E_TOOBIG;
+  hipLaunchKernelGGL(ca_pool_kernel, dim3((unsigned)planes), dim3(CA_T), 0, (hipStream_t)stream, a, b, s, hw, scale);
+  return savfi_launch_status();
+}
+
+extern "C" int savfi_ca_mlp_fwd_f32(const float* s, const float* w1, const float* b1, const float* w2, const float* b2, float* y, float* a1,
+                                    int N, int T, int C, int Cr, void* stream) {
+  if (!s || !w1 || !b1 || !w2 || !b2 || !y || !a1) return SAVFI_E_NULL;
+  if (N <= 0 || T <= 0 || N % T != 0 || C <= 0 || Cr <= 0) return SAVFI_E_SHAPE;
+  if (C > 1024 || Cr > 64) return SAVFI_E_UNSUPPORTED;
+  hipLaunchKernelGGL(ca_mlp_fwd_kernel, dim3(N), dim3(CA_T), 0, (hipStream_t)stream, s, w1, b1, w2, b2, y, a1, T, C, Cr);
+  return savfi_launch_status();
+}
+
+extern "C" int savfi_ca_mlp_bwd_f32(const float* r, const float* s, const float* y, const float* a1, const float* w1, const float* w2,
+                                    float* ds, float* gw1, float* gb1, float* gw2, float* gb2, int N, int T, int C, int Cr, float inv_hw,
+                                    void* stream) {
+  if (!r || !s || !y || !a1 || !w1 || !w2 || !ds || !gw1 || !gb1 || !gw2 || !gb2) return SAVFI_E_NULL;
+  if (N <= 0 || T <= 0 || N % T != 0 || C <= 0 || Cr <= 0) return SAVFI_E_SHAPE;
+  if (C > 1024 || Cr > 64) return SAVFI_E_UNSUPPORTED;
+  hipLaunchKernelGGL(ca_mlp_bwd_kernel, dim3(T), dim3(CA_T), 0, (hipStream_t)stream, r, s, y, a1, w1, w2, ds, gw1, gb1, gw2, gb2, N, T, C, Cr, inv_hw);
+  return savfi_launch_status();
+}
+
+extern "C" int savfi_ca_apply_f32(const float* a, const float* y, const float* x, const float* ds, float* out, int64_t planes, int hw,
+                                  void* stream) {
+  if (!a || !y || !out || (!x && !ds)) return SAVFI_E_NULL;
+  if (planes <= 0 || hw <= 0) return SAVFI_E_SHAPE;
+  const int chunks = ca_chunks(planes, hw);
+  if (planes * chunks >= (1ll << 31)) return SAVFI_E_TOOBIG;
+  hipLaunchKernelGGL(ca_apply_kernel, dim3((unsigned)(planes * chunks)), dim3(CA_T), 0, (hipStream_t)stream, a, y, x, ds, out, hw, chunks);
+  return savfi_launch_status();
+}

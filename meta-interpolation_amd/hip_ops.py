@@ -1136,6 +1136,75 @@ def conv_bias_act(x, weight, bias, stride=1, padding=0, dilation=1, groups=1, sl
 
 
 # --------------------------------------------------------------------------------------------
+# Channel attention + residual of CAIN's RCAB        (reference model_utils.py:931-953, :957-990)
+# --------------------------------------------------------------------------------------------
+class _ChannelAttentionResidual(torch.autograd.Function):
+    """out = t * sigmoid(W2 relu(W1 mean_hw(t) + b1) + b2) + x, also returns the attention y [N,C,1,1] (not differentiable on
+    its own).  w1 [T,Cr,C] / b1 [T,Cr] / w2 [T,C,Cr] / b2 [T,C]: sample n uses set n % T.  First-order only."""
+
+    @staticmethod
+    def forward(ctx, t, x, w1, b1, w2, b2):
+        t, x = t.contiguous(), x.contiguous()
+        w1, b1, w2, b2 = w1.contiguous(), b1.contiguous(), w2.contiguous(), b2.contiguous()
+        _hip.require_cuda(t, x, w1, b1, w2, b2)
+        N, C, H, W = t.shape
+        T, Cr = w1.shape[0], w1.shape[1]
+        assert x.shape == t.shape and N % T == 0 and tuple(w1.shape) == (T, Cr, C) and tuple(w2.shape) == (T, C, Cr), (t.shape, w1.shape, w2.shape)
+        lib = _hip.lib()
+        st = _hip.current_stream()
+        s = torch.empty((N, C), dtype=t.dtype, device=t.device)
+        y = torch.empty((N, C), dtype=t.dtype, device=t.device)
+        a1 = torch.empty((N, Cr), dtype=t.dtype, device=t.device)
+        out = torch.empty_like(t)
+        hw = H * W
+        _hip.launch("ca_pool", lambda: _hip.check(lib.savfi_ca_pool_f32(t.data_ptr(), None, s.data_ptr(), N * C, hw, 1.0 / hw, st),
+                                                  "savfi_ca_pool_f32"), nbytes=4 * t.numel())
+        _hip.launch("ca_mlp", lambda: _hip.check(lib.savfi_ca_mlp_fwd_f32(s.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
+                                                                          y.data_ptr(), a1.data_ptr(), N, T, C, Cr, st), "savfi_ca_mlp_fwd_f32"))
+        _hip.launch("ca_apply", lambda: _hip.check(lib.savfi_ca_apply_f32(t.data_ptr(), y.data_ptr(), x.data_ptr(), None, out.data_ptr(), N * C, hw, st),
+                                                   "savfi_ca_apply_f32"), nbytes=12 * t.numel())
+        ctx.save_for_backward(t, s, y, a1, w1, w2)
+        ctx.mark_non_differentiable(y)
+        return out, y.view(N, C, 1, 1)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g, _gy):
+        t, s, y, a1, w1, w2 = ctx.saved_tensors
+        g = g.contiguous()
+        N, C, H, W = t.shape
+        T, Cr = w1.shape[0], w1.shape[1]
+        hw = H * W
+        lib = _hip.lib()
+        st = _hip.current_stream()
+        r = torch.empty((N, C), dtype=t.dtype, device=t.device)
+        ds = torch.empty((N, C), dtype=t.dtype, device=t.device)
+        gw1, gb1 = torch.empty_like(w1), torch.empty((T, Cr), dtype=t.dtype, device=t.device)
+        gw2, gb2 = torch.empty_like(w2), torch.empty((T, C), dtype=t.dtype, device=t.device)
+        gt = torch.empty_like(t)
+        _hip.launch("ca_pool", lambda: _hip.check(lib.savfi_ca_pool_f32(g.data_ptr(), t.data_ptr(), r.data_ptr(), N * C, hw, 1.0, st),
+                                                  "savfi_ca_pool_f32"), nbytes=8 * t.numel())
+        _hip.launch("ca_mlp_bwd", lambda: _hip.check(lib.savfi_ca_mlp_bwd_f32(
+            r.data_ptr(), s.data_ptr(), y.data_ptr(), a1.data_ptr(), w1.data_ptr(), w2.data_ptr(), ds.data_ptr(), gw1.data_ptr(), gb1.data_ptr(),
+            gw2.data_ptr(), gb2.data_ptr(), N, T, C, Cr, 1.0 / hw, st), "savfi_ca_mlp_bwd_f32"))
+        _hip.launch("ca_apply", lambda: _hip.check(lib.savfi_ca_apply_f32(g.data_ptr(), y.data_ptr(), None, ds.data_ptr(), gt.data_ptr(), N * C, hw, st),
+                                                   "savfi_ca_apply_f32"), nbytes=8 * t.numel())
+        need = ctx.needs_input_grad
+        return (gt if need[0] else None, g if need[1] else None, gw1 if need[2] else None, gb1 if need[3] else None,
+                gw2 if need[4] else None, gb2 if need[5] else None)
+
+
+def channel_attention_residual(t, x, w1, b1, w2, b2):
+    """RCAB tail: (t * CA(t) + x, CA(t)).  Weights of the two 1x1 convolutions as [Cr,C,1,1] / [Cr] / [C,Cr,1,1] / [C], or with a
+    leading task axis T (tasks in lockstep: sample n uses set n % T)."""
+    stacked = w1.dim() == 5
+    T = w1.shape[0] if stacked else 1
+    Cr, C = (w1.shape[1], w1.shape[2]) if stacked else (w1.shape[0], w1.shape[1])
+    out, y = _ChannelAttentionResidual.apply(t, x, w1.reshape(T, Cr, C), b1.reshape(T, Cr), w2.reshape(T, C, Cr), b2.reshape(T, C))
+    return out, y
+
+
+# --------------------------------------------------------------------------------------------
 # Bilinear x2 up-sampling      (sepconv/model.py:191, :213-234; voxel_flow.py:400-414)
 # --------------------------------------------------------------------------------------------
 class _Upsample2x(torch.autograd.Function):

@@ -791,3 +791,34 @@ def test_own_weight_filters_are_cached_per_weight_version():
         w.mul_(2.0)
     y3 = hip_ops.conv_bias_act(x, w, None, 1, 2, 1, 1, 1.0, False, cache)
     assert len(cache) == 2 and _rel(y3.detach(), 2 * y1.detach()) < 1e-6
+
+
+@pytest.mark.parametrize("N,T,C,Cr,H,W", [(2, 1, 192, 12, 16, 16), (4, 2, 192, 12, 12, 20), (1, 1, 64, 4, 33, 47), (3, 3, 16, 2, 5, 7)])
+def test_channel_attention_residual_matches_the_composed_ops(N, T, C, Cr, H, W):
+    """CAIN's RCAB tail (pool -> 1x1 -> ReLU -> 1x1 -> sigmoid -> scale -> + skip) as the fused savfi op against the reference's
+    composition (model_utils.py:931-990) in float64: value, attention, and the gradients of both maps and all four parameters;
+    per-task weight sets (sample n uses set n % T)."""
+    g = torch.Generator().manual_seed(N * 100 + C)
+    t, x = torch.randn(N, C, H, W, generator=g), torch.randn(N, C, H, W, generator=g)
+    w1, b1 = torch.randn(T, Cr, C, 1, 1, generator=g) / math.sqrt(C), torch.randn(T, Cr, generator=g) * 0.1
+    w2, b2 = torch.randn(T, C, Cr, 1, 1, generator=g) / math.sqrt(Cr), torch.randn(T, C, generator=g) * 0.1
+    gout = torch.randn(N, C, H, W, generator=g)
+    leaves = [v.to(DEV).requires_grad_() for v in (t, x, w1, b1, w2, b2)]
+    args = leaves if T > 1 else leaves[:2] + [v[0] for v in leaves[2:]]
+    out, y = hip_ops.channel_attention_residual(*args)
+    grads = torch.autograd.grad(out, leaves, gout.to(DEV))
+    ref = [v.double().requires_grad_() for v in (t, x, w1, b1, w2, b2)]
+    rt, rx, rw1, rb1, rw2, rb2 = ref
+    outs, ys = [], []
+    for n in range(N):
+        k = n % T
+        s = rt[n:n + 1].mean((2, 3), keepdim=True)
+        yy = torch.sigmoid(F.conv2d(F.relu(F.conv2d(s, rw1[k], rb1[k])), rw2[k], rb2[k]))
+        ys.append(yy)
+        outs.append(rt[n:n + 1] * yy + rx[n:n + 1])
+    rout = torch.cat(outs, 0)
+    rgrads = torch.autograd.grad(rout, ref, gout.double())
+    assert _rel(out.detach().cpu().double(), rout.detach()) < 2e-6
+    assert _rel(y.detach().cpu().double(), torch.cat(ys, 0).detach()) < 2e-6
+    for a, r, name in zip(grads, rgrads, ("t", "x", "w1", "b1", "w2", "b2")):
+        assert _rel(a.cpu().double(), r) < 2e-5, name
