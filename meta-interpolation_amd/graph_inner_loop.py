@@ -18,7 +18,12 @@ Tasks in lockstep (``tasks`` = T > 1, --task_batch): the same graphs over T task
 sample-major order, fast weights / moments / gradients stacked [T, *shape], per-sample losses; the identity chain then sums
 the stacked target gradients over the task axis.  T = 1 is the per-task form above, unchanged.
 
-Not captured (the caller falls back to the eager loop): --second_order, --attenuate (L2F), CPU tensors.
+L2F (--attenuate, T = 1, plugins that route every inner-loop tensor): one more graph in front -- the support pass at theta and
+its layer-wise mean gradients (the task embedding) -- then, eagerly, the attenuator MLP (two tiny GEMVs, autograd on) and
+W_0 = gamma * theta; the hand-assembled outer gradient gains d/d theta_k = gamma_k * sum_s w_s G_s,k and d/d gamma_k =
+<sum_s w_s G_s,k, theta_k>, which autograd carries through the attenuator to its parameters and gamma_mult.
+
+Not captured (the caller falls back to the eager loop): --second_order, L2F on a plugin with unrouted tensors or T > 1, CPU tensors.
 """
 import torch
 
@@ -27,8 +32,10 @@ from . import _hip, hip_ops, model_utils, utils
 
 def supported(system, use_second_order):
     a = system.args
+    if a.attenuate and system._routing_known_incomplete():
+        return False
     return (bool(getattr(a, 'graph_inner_loop', 0)) and system.device.type == 'cuda' and not use_second_order
-            and not a.attenuate and hasattr(system.inner_loop_optimizer, 'lr_mode'))
+            and hasattr(system.inner_loop_optimizer, 'lr_mode'))
 
 
 def _frame(out):
@@ -63,6 +70,10 @@ class GraphedInnerLoop:
             (opt, self.rule.keeps_adamax_moment)]
         self.m = [stacked(self.theta[k]) for k in self.routed] if self.rule_id in (1, 2) else None
         self.s = [stacked(self.theta[k]) for k in self.routed] if self.rule_id == 1 else None
+        self.attenuate = bool(getattr(system.args, 'attenuate', False))
+        if self.attenuate:
+            assert T == 1 and not self.unrouted, "graphed L2F: one task per graph set, every inner-loop tensor routed"
+        self.emb_graph, self.emb_out = None, None    # L2F: support pass at theta -> layer-wise mean gradients
         self.step_graphs, self.step_out = [], []     # per step: graph, dict(W_out, g, dir)
         self.target_graphs = {}                      # step index s (params = W_s) -> (graph, outputs)
         self.pool = None
@@ -105,6 +116,18 @@ class GraphedInnerLoop:
         Wn = {k: v.requires_grad_() for k, v in zip(self.routed, new)}
         return dict(W=Wn, g=list(g), dir=(coef if want_coef else list(g)), loss=loss.detach())
 
+    def _embedding(self, W):
+        """L2F task embedding (reference meta_learning_system.py:231-255): support loss at theta, first-order gradients, one
+        fused per-tensor mean."""
+        model_utils.set_own_params_const(True)
+        try:
+            out = _frame(self.net.forward(self.sup[0], self.sup[2], params=W, backup_running_statistics=True, num_step=0))
+        finally:
+            model_utils.set_own_params_const(False)
+        loss = self.crit(out[0:1], self.sup[1][0:1])['total'] + self.crit(out[1:2], self.sup[1][1:2])['total']
+        g = torch.autograd.grad(loss, [W[k] for k in self.routed])
+        return hip_ops.mt_mean(g)
+
     def _target(self, W, s, with_grad):
         crit = self.crit if self.T == 1 else self.crit.per_sample          # T > 1: every loss part is a [T] vector
         if not with_grad:
@@ -127,6 +150,8 @@ class GraphedInnerLoop:
         def run_all():
             W = self.W0
             outs, tg = [], {}
+            if self.attenuate:
+                self._embedding(W)
             for t in range(self.S):
                 o = self._support_step(W, t)
                 outs.append(o)
@@ -148,6 +173,10 @@ class GraphedInnerLoop:
 
         self.pool = torch.cuda.graph_pool_handle()
         W = self.W0
+        if self.attenuate:
+            self.emb_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.emb_graph, pool=self.pool):
+                self.emb_out = self._embedding(W)
         for t in range(self.S):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=self.pool):
@@ -200,6 +229,16 @@ class GraphedInnerLoop:
                 if buf is not None:
                     torch._foreach_zero_(buf)
         logs, task_loss, pred = [], None, None
+        gamma = None
+        if self.attenuate:
+            # L2F: embedding from a replay, gamma eagerly (autograd on: the attenuator's parameters and gamma_mult get their
+            # outer gradient through it), W_0 = gamma * theta into the static buffers
+            self.emb_graph.replay()
+            with torch.enable_grad():
+                gamma = (1 - sysm.gamma_mult * sysm.attenuator(self.emb_out.detach())).clamp(0, 1)
+            with torch.no_grad():
+                scaled = hip_ops.mt_scale(gamma.detach(), [self.theta[k].detach() for k in self.routed])
+                torch._foreach_copy_([self.W0[k] for k in self.routed], scaled)
         # replay: S support steps, target passes where needed
         for t in range(self.S):
             self.step_graphs[t].replay()
@@ -235,7 +274,14 @@ class GraphedInnerLoop:
                         accum.add_params([k for k, _ in own], scaled([g for _, g in own], w))
                 if t > 0 and self.learn_lr and suffix is not None:
                     accum.add_lr_grads(self, t - 1, suffix)
-            if suffix is not None:
+            if suffix is not None and gamma is not None:
+                # identity chain W_S -> ... -> W_0 = gamma * theta
+                g_gamma, g_theta = hip_ops.mt_scale_grads(gamma, [self.theta[k] for k in self.routed], suffix)
+                accum.add_params(self.routed, g_theta)
+                if gamma.requires_grad:
+                    att = [p for p in list(sysm.attenuator.parameters()) + [sysm.gamma_mult] if p.requires_grad]
+                    accum.add_extra(att, torch.autograd.grad(gamma, att, g_gamma, allow_unused=True))
+            elif suffix is not None:
                 # identity chain W_S -> ... -> W_0 = theta broadcast over the tasks: the task axis is summed
                 accum.add_params(self.routed, suffix if T == 1 else [x.sum(0) for x in suffix])
         if T == 1:
@@ -254,6 +300,7 @@ class OuterGradAccumulator:
         self.lr = {}            # lr key -> tensor shaped like the lr parameter (Meta-SGD: element-wise rates)
         self.lr_rows = None     # LSLR: [inner step, routed tensor] scalars
         self.lr_keys = None
+        self.extra = {}         # any other trainable parameter (L2F: attenuator, gamma_mult) -> summed gradient
 
     def add_params(self, keys, grads):
         """param[k] += g  (the first contribution of a key is copied: `grads` may be static graph outputs)."""
@@ -303,8 +350,18 @@ class OuterGradAccumulator:
             if k not in self.lr:
                 self.lr[k] = g.clone()
 
+    def add_extra(self, params, grads):
+        for p, g in zip(params, grads):
+            if g is None:
+                continue
+            if p in self.extra:
+                self.extra[p].add_(g)
+            else:
+                self.extra[p] = g.clone()
+
     def tensors(self):
-        return list(self.param.values()) + list(self.lr.values()) + ([self.lr_rows] if self.lr_rows is not None else [])
+        return (list(self.param.values()) + list(self.lr.values()) + ([self.lr_rows] if self.lr_rows is not None else [])
+                + list(self.extra.values()))
 
     def merge(self, other):
         """Add another accumulator's sums (tasks adapted on another stream; the caller has joined the streams)."""
@@ -317,6 +374,8 @@ class OuterGradAccumulator:
                 self.lr_rows.add_(other.lr_rows)
         if other.lr:
             self.add_lr_tensors(list(other.lr.keys()), list(other.lr.values()))
+        if other.extra:
+            self.add_extra(list(other.extra.keys()), list(other.extra.values()))
 
     def install(self, num_tasks, into=None):
         """Write the accumulated gradients (mean over the GLOBAL meta-batch) into .grad.  `into` = {param: preassigned .grad
@@ -337,6 +396,9 @@ class OuterGradAccumulator:
         if self.lr:
             torch._foreach_mul_(list(self.lr.values()), inv)
         pairs += [(rates[lk], g) for lk, g in self.lr.items()]
+        if self.extra:
+            torch._foreach_mul_(list(self.extra.values()), inv)
+        pairs += list(self.extra.items())
         if into is None:
             for p, g in pairs:
                 p.grad = g

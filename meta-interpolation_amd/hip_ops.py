@@ -386,6 +386,22 @@ class _MtScale(torch.autograd.Function):
         return (g_gamma, *g_ws)
 
 
+def mt_scale_grads(gamma, weights, g_outs):
+    """The backward of mt_scale without autograd (hipGraph loop, where the outer gradient is assembled by hand):
+    returns (g_gamma float32[n] = <g_outs[i], weights[i]>, [gamma[i] * g_outs[i]])."""
+    ws = [w.detach().contiguous() for w in weights]
+    gos = [g.contiguous() for g in g_outs]
+    gamma = gamma.detach().contiguous()
+    _hip.require_cuda(gamma, *ws, *gos)
+    gws = [torch.empty_like(w) for w in ws]
+    gg = torch.zeros_like(gamma)
+    lib = _hip.lib()
+    args = (len(ws), _hip.ptr_array(gos), _hip.ptr_array(ws), gamma.data_ptr(), _hip.ptr_array(gws), gg.data_ptr(),
+            _hip.i64_array([w.numel() for w in ws]), _hip.current_stream())
+    _hip.launch("mt_scale_bwd", lambda: _hip.check(lib.savfi_mt_scale_bwd_f32(*args), "savfi_mt_scale_bwd_f32"))
+    return gg, gws
+
+
 def mt_scale(gamma, weights):
     """gamma float32[n] (device), weights list of n tensors -> [gamma[i] * weights[i]]."""
     ws = [w if w.is_contiguous() else w.contiguous() for w in weights]

@@ -394,6 +394,11 @@ class SceneAdaptiveInterpolation(nn.Module):
             self._routes = ([k for k, gi in zip(fast, g) if gi is not None], [k for k, gi in zip(fast, g) if gi is None])
         return self._routes
 
+    def _routing_known_incomplete(self):
+        """True when the routing probe has run and found inner-loop tensors the plugin never reads from the fast dict (graphed
+        L2F needs every tensor routed); before the probe has run the answer is 'not known to be incomplete'."""
+        return self._routes is not None and bool(self._routes[1])
+
     def _lockstep_width(self, use_second_order, frame_shape):
         """Tasks per lockstep group, or 0 when this pass must take the sequential loop (second order; L2F on a plugin that
         does not route every tensor: its per-task embedding needs per-task gradients of the plugin's own parameters)."""
@@ -554,7 +559,9 @@ class SceneAdaptiveInterpolation(nn.Module):
         frames = data_batch
         num_tasks = len(frames[0])
         self._manual_grads = None
-        if graph_inner_loop.supported(self, use_second_order) and self._wants_graphs(frames, training_phase):
+        if (graph_inner_loop.supported(self, use_second_order)
+                and not (self.args.attenuate and self._routing(frames[0].shape[1:])[1])      # graphed L2F: every tensor routed
+                and self._wants_graphs(frames, training_phase)):
             return self._forward_graphed(frames, epoch, use_multi_step_loss_optimization, num_steps, training_phase,
                                          do_evaluation)
         self._set_pass_flags(use_second_order)
@@ -683,6 +690,9 @@ class SceneAdaptiveInterpolation(nn.Module):
         # --task_batch T: groups of T tasks advance in lockstep through ONE graph set (a shorter last group gets its own);
         # --task_streams N: N graph sets per width (own static buffers and memory pool each), replayed from N threads
         width = max(1, self._lockstep_width(False, frames[0].shape[1:]))
+        if self.args.attenuate:
+            assert not self._routing(frames[0].shape[1:])[1]
+            width = 1          # L2F graph sets hold one task (per-task embedding / gamma between the graphs)
         groups = [local[i:i + width] for i in range(0, len(local), width)]
         n = max(1, min(self._task_streams(graphed=True), len(groups)))
 

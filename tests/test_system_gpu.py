@@ -470,7 +470,8 @@ def test_graph_replays_on_two_task_streams_match_reference_fixture(name):
 # hipGraph-captured inner loop (--graph_inner_loop 1): same results as the eager loop and the fixtures
 # ---------------------------------------------------------------------------------------------
 GRAPH_CASES = ['sepconv_lslr_sgd_2step', 'sepconv_msl_learnable_2step', 'sepconv_metasgd_adamax_2step',
-               'voxelflow_lslr_sgd_2step', 'c1_cain_lslr_sgd', 'cain_lslr_adam_1step', 'rrin_lslr_sgd_2step', 'superslomo_lslr_sgd_2step']
+               'voxelflow_lslr_sgd_2step', 'c1_cain_lslr_sgd', 'cain_lslr_adam_1step', 'rrin_lslr_sgd_2step', 'superslomo_lslr_sgd_2step',
+               'cain_l2f']
 
 
 @pytest.mark.parametrize("name", GRAPH_CASES)
@@ -666,8 +667,8 @@ def test_graphed_lockstep_tasks_match_reference_fixture(name, phase, lockstep_fo
 
 def test_default_execution_mode_policy():
     """config.py defaults (--graph_inner_loop -1, --task_batch 8): a rank with ONE task replays hipGraphs (launch-bound pass), a rank
-    with several adapts them in lockstep in the eager loop, L2F (not capturable) stays eager -- all with the fixture's numbers."""
-    for name, want_graphs, want_lockstep in (('c1_cain_lslr_sgd', 1, 0), ('sepconv_msl_learnable_2step', 0, 1), ('cain_l2f', 0, 0),
+    with several adapts them in lockstep in the eager loop, L2F on a fully routed plugin replays graphs too (the attenuator between them) -- all with the fixture's numbers."""
+    for name, want_graphs, want_lockstep in (('c1_cain_lslr_sgd', 1, 0), ('sepconv_msl_learnable_2step', 0, 1), ('cain_l2f', 1, 0),
                                              ('voxelflow_lslr_sgd_2step', 0, 1)):
         g = golden("system_" + name)
         model = str(g['model'])
