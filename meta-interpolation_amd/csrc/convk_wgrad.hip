@@ -196,39 +196,44 @@ __global__ __launch_bounds__(WG_THREADS, 2) void convk_wgrad_kernel(const WgArgs
     stage_write();
     __syncthreads();
     if (u + 1 < u_end) stage_load(u + 1);
-#pragma unroll
-    for (int r = 0; r < UR; ++r) {
-      bf16x8 aq[MT][3];
+    // software pipeline over the UR x TPW x NT groups of this unit (one group = one tap x one input-channel tile x MT
+    // output-channel tiles = 6 MT MFMAs): the B fragments of the next group are read from LDS while the current group's MFMAs issue
+    constexpr int NG = UR * G::TPW * NT;
+    bf16x8 aq[MT][3], bq[2][3];
+    auto load_a = [&](int r) {
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int p = 0; p < 3; ++p) aq[m][p] = tr_read(p * G::GPLANE + a_addr[m] + r * UW * 16);
+    };
+    auto load_b = [&](int gi) {
+      const int r = gi / (G::TPW * NT), tp = (gi / NT) % G::TPW, nn = gi % NT;
+      int tap = wv + 4 * tp;
+      tap = tap < G::TAPS ? tap : 0;
+      const int ky = tap / KS, kx = tap - ky * KS;
+      const int boff = ((r + ky) * G::XCOLS + kx) * 16;
 #pragma unroll
-      for (int tp = 0; tp < G::TPW; ++tp) {
-        int tap = wv + 4 * tp;
-        const bool live = tap < G::TAPS;        // wave-uniform
-        tap = live ? tap : 0;
-        const int ky = tap / KS, kx = tap - ky * KS;
-        const int boff = ((r + ky) * G::XCOLS + kx) * 16;
-        if (live) {
+      for (int p = 0; p < 3; ++p) bq[gi & 1][p] = tr_read(p * G::XPLANE + b_addr[nn] + boff);
+    };
+    load_b(0);
 #pragma unroll
-          for (int nn = 0; nn < NT; ++nn) {
-            bf16x8 bq[3];
+    for (int gi = 0; gi < NG; ++gi) {
+      const int r = gi / (G::TPW * NT), tp = (gi / NT) % G::TPW, nn = gi % NT;
+      if (gi % (G::TPW * NT) == 0) load_a(r);          // A fragments of a row: once per row (their registers are busy until then)
+      if (gi + 1 < NG) load_b(gi + 1);
+      if (wv + 4 * tp < G::TAPS) {          // wave-uniform: the last tap slot of a wave may be empty
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bq[p] = tr_read(p * G::XPLANE + b_addr[nn] + boff);
+        for (int q = 0; q < 6; ++q)
 #pragma unroll
-            for (int q = 0; q < 6; ++q)
-#pragma unroll
-              for (int m = 0; m < MT; ++m) {
-                if (P2 && q < 5)
-                  lo[P2 ? tp : 0][P2 ? m : 0][P2 ? nn : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                      aq[m][PA[q]], bq[PB[q]], lo[P2 ? tp : 0][P2 ? m : 0][P2 ? nn : 0], 0, 0, 0);
-                else
-                  acc[tp][m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[m][PA[q]], bq[PB[q]], acc[tp][m][nn], 0, 0, 0);
-              }
+          for (int m = 0; m < MT; ++m) {
+            if (P2 && q < 5)
+              lo[P2 ? tp : 0][P2 ? m : 0][P2 ? nn : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                  aq[m][PA[q]], bq[gi & 1][PB[q]], lo[P2 ? tp : 0][P2 ? m : 0][P2 ? nn : 0], 0, 0, 0);
+            else
+              acc[tp][m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[m][PA[q]], bq[gi & 1][PB[q]], acc[tp][m][nn], 0, 0, 0);
           }
-        }
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
   }
