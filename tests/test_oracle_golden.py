@@ -210,3 +210,23 @@ def test_oracle_test_mode_matches_reference(model):
     preds = meta.run_test_iteration(model, base, frames, rule='lslr', optimizer=a['optimizer'], lrs=lrs, num_steps=S,
                                     loss=a['loss'].split('*')[1])
     assert np.abs(torch.stack(preds).numpy() - g[model + '_preds']).mean() < 1e-5
+
+
+@pytest.mark.parametrize("B,C,Ho,Wo,K", [(1, 3, 9, 12, 51), (2, 3, 17, 23, 5), (1, 2, 6, 7, 13)])
+def test_sepconv_c_transcription_agrees_with_the_dain_statement(B, C, Ho, Wo, K):
+    """the op oracle (oracle/sepconv_ref.c, a transcription of sepconv.py:12-29,145-162,172-189) against the
+    reference's second, independently written statement of the same op -- DAIN's SeparableConv CUDA extension
+    (dain/my_package/SeparableConv/separableconv_cuda_kernel.cu:65-77, :113-128), restated in oracle/sepconv_dain.py: forward,
+    both tap gradients, and the input gradient (DAIN's atomics form the exact adjoint; so does the oracle's gI)."""
+    from oracle import sepconv_dain as D
+    g = torch.Generator().manual_seed(B * 100 + K)
+    inp = torch.rand(B, C, Ho + K - 1, Wo + K - 1, generator=g)
+    v = torch.randn(B, K, Ho, Wo, generator=g) / K ** 0.5
+    h = torch.randn(B, K, Ho, Wo, generator=g) / K ** 0.5
+    gO = torch.randn(B, C, Ho, Wo, generator=g)
+    out = O.sepconv_forward_c(inp, v, h).double().numpy()
+    gI, gV, gH = (t.double().numpy() for t in O.sepconv_backward_c(inp, v, h, gO, need_input=True))
+    want = D.forward(inp.numpy(), v.numpy(), h.numpy())
+    w1, w2, w3 = D.backward(inp.numpy(), v.numpy(), h.numpy(), gO.numpy())
+    rel = lambda a, b: np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+    assert rel(out, want) < 2e-6 and rel(gV, w2) < 2e-6 and rel(gH, w3) < 2e-6 and rel(gI, w1) < 2e-6

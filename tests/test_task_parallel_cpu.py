@@ -197,3 +197,79 @@ def test_bench_runs_under_torch_distributed_run_with_two_ranks(task_batch):
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "weak"
     assert line["config"]["global_meta_batch"] == 6 and line["config"]["mode"]["task_batch"] == task_batch
     assert line["value"] > 0 and abs(line["value"] - 6 * 2 * 2 / (line["ms_per_step"] * 2e-3)) < 1e-6 * line["value"]
+
+
+# ---------------------------------------------------------------------------------------------
+# wider worlds (the 8-GPU node of BASELINE configs 4 / 5): 4 and 8 ranks, 5 tasks -> uneven shards, and with 8 ranks three of
+# them adapt NOTHING (they still take part in the all-reduce and must end with the same gradients as everybody else)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("world", [4, 8])
+def test_sharded_outer_gradients_equal_sequential_on_wider_worlds(world):
+    torch.set_num_threads(2)
+    seq = build_toy_system(batch=B, msl=False)
+    want, losses, _ = _grads_after_iteration(seq, synthetic.septuplet_batch(B, H, W), False)
+    with tempfile.TemporaryDirectory() as d:
+        port = 29500 + (os.getpid() % 2000) + 70 + world
+        mp.spawn(_worker, args=(world, port, d, False), nprocs=world, join=True)
+        ranks = [torch.load(os.path.join(d, "rank%d.pt" % r), weights_only=False) for r in range(world)]
+    for r, res in enumerate(ranks):
+        assert set(res['grads']) == set(want), r
+        for k, v in want.items():
+            assert torch.allclose(res['grads'][k], v, rtol=1e-5, atol=1e-7), (r, k)
+            assert torch.equal(res['grads'][k], ranks[0]['grads'][k]), (r, k)       # bit-identical replicas
+        assert abs(res['loss_global'] - losses['loss'].item()) < 1e-6
+        assert res['local_preds'] == list(range(r, B, world))
+
+
+def _bucket_worker(rank, world, port, outdir):
+    """The flat gradient bucket on its own, with the parameter mix of an L2F system: backbone tensors every non-empty rank
+    reaches, 'attenuator' tensors only SOME ranks reach this iteration, and a tensor no rank reaches (must stay None so that
+    the optimizer skips it: no weight decay, no moment update)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tp = TaskParallel()
+        torch.manual_seed(0)
+        params = [torch.nn.Parameter(torch.randn(s)) for s in ((7, 3), (5,), (4, 4), (1,), (6,))]     # backbone x2, attenuator W, gamma_mult, unused
+        out = []
+        for it in range(2):                    # the second iteration reuses the bucket and the cached presence flags
+            views = tp.prepare_gradients(params)
+            assert all(p.grad is views[p] for p in params)
+            g = torch.Generator().manual_seed(100 * it + rank)
+            loss = 0
+            if rank % 2 == 0 or rank == world - 1:                 # "has local tasks"
+                loss = loss + (params[0] * torch.randn(7, 3, generator=g)).sum() + (params[1] * torch.randn(5, generator=g)).sum()
+            if rank == 1 or (it == 1 and rank == 2):               # the L2F tensors: reached by a changing subset of ranks
+                loss = loss + (params[2] * torch.randn(4, 4, generator=g)).sum() + (params[3] * 3.0).sum()
+            if torch.is_tensor(loss):
+                loss.backward()
+            tp.allreduce_gradients(params)
+            out.append([None if p.grad is None else p.grad.detach().clone() for p in params])
+        torch.save(out, os.path.join(outdir, "bucket%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_gradient_bucket_with_partly_reached_parameters(world):
+    with tempfile.TemporaryDirectory() as d:
+        port = 29500 + (os.getpid() % 2000) + 90 + world
+        mp.spawn(_bucket_worker, args=(world, port, d), nprocs=world, join=True)
+        ranks = [torch.load(os.path.join(d, "bucket%d.pt" % r), weights_only=False) for r in range(world)]
+    for it in range(2):
+        want = [torch.zeros(s) for s in ((7, 3), (5,), (4, 4), (1,))]
+        for r in range(world):
+            g = torch.Generator().manual_seed(100 * it + r)
+            if r % 2 == 0 or r == world - 1:
+                want[0] += torch.randn(7, 3, generator=g)
+                want[1] += torch.randn(5, generator=g)
+            if r == 1 or (it == 1 and r == 2):
+                want[2] += torch.randn(4, 4, generator=g)
+                want[3] += 3.0
+        for r in range(world):
+            got = ranks[r][it]
+            assert got[4] is None                                     # reached by nobody: stays None on every rank
+            for a, b in zip(got[:4], want):
+                assert a is not None and torch.allclose(a, b, rtol=1e-6, atol=1e-6)
+            for a, b in zip(got[:4], ranks[0][it][:4]):
+                assert torch.equal(a, b)                              # identical on every rank
