@@ -92,9 +92,16 @@ def cpu_baseline(model, H, W, S, overrides):
     kind = 'metasgd' if overrides.get('metasgd') else 'lslr'
     names_w = {n: base[n] for n in meta.inner_param_names([(n, p) for n, p in base.items() if p.is_floating_point()])}
     lrs = rules.init_lrs(kind, names_w, overrides['inner_lr'], num_steps=S)
+    extra = {}
+    if overrides.get('attenuate'):      # L2F: the same seeded attenuator state the timed system carries
+        L = len(names_w)
+        att = torch.nn.Sequential(torch.nn.Linear(L, L), torch.nn.ReLU(inplace=True), torch.nn.Linear(L, L), torch.nn.Sigmoid())
+        sd, gm = synthetic.seeded_attenuator_state(L)
+        att.load_state_dict(sd)
+        extra = dict(attenuator=att, gamma_mult=gm.clone().requires_grad_())
     t0 = time.perf_counter()
     res = meta.run_iteration(model, base, frames, rule=kind, optimizer=overrides['optimizer'], lrs=lrs,
-                             num_steps=S, loss=overrides['loss'].split('*')[1], training=True)
+                             num_steps=S, loss=overrides['loss'].split('*')[1], training=True, **extra)
     res['loss'].backward()
     dt = time.perf_counter() - t0
     line = {"value": S / dt, "unit": "inner-loop steps/sec", "cores": cores, "os_cpu_count": os.cpu_count(), "cpu_model": _cpu_model(),
@@ -132,11 +139,22 @@ def parity_check(system, theta0, frames, model, H, W, S, oracle_res, dev, mode):
                          _from_unit_range(system, preds[0].squeeze(0).to(dev)), frames[3][0].to(dev)))
     want = float(oracle_res['loss'])
     rel = abs(got - want) / max(abs(want), 1e-30)
+    if os.environ.get("SAVFI_BENCH_DEBUG"):
+        print("[parity] loss got %r want %r | pred mean got %r oracle %r" % (got, want, float(a.mean()), float(b.mean())), file=sys.stderr)
     how = ("lockstep T=%s" % calls) if calls else ("hipGraph replays" if getattr(system, '_graphs', None) else "sequential task loop")
-    return {"loss_rel": rel, "pixel_l1": l1, "dpsnr_db": dpsnr, "ok": bool(rel <= 1e-5 and l1 <= 1e-4 and dpsnr <= 1e-3),
-            "bounds": {"loss_rel": 1e-5, "pixel_l1": 1e-4, "dpsnr_db": 1e-3},
+    out = {"loss_rel": rel, "pixel_l1": l1, "dpsnr_db": dpsnr, "ok": bool(rel <= 1e-5 and l1 <= 1e-4 and dpsnr <= 1e-3),
+           "bounds": {"loss_rel": 1e-5, "pixel_l1": 1e-4, "dpsnr_db": 1e-3}}
+    if model == 'voxelflow' and system.args.optimizer != 'SGD':
+        # C3's rule steps +-lr*c per element whatever |g| and VoxelFlow amplifies rounding ~1000x: after 5 steps at 256x256 the
+        # imported reference differs from ITSELF (another conv summation order / float64) by 1.5e-2 .. 0.13 pixel L1
+        # (tests/golden/full_c3_voxelflow_256x256_s5.npz `spread`).  End-of-iteration numbers cannot meet the contract bounds for
+        # ANY implementation; C3 parity is per step only (tests/test_fullsize_gpu.py::test_full_size_voxelflow_teacher_forced_steps).
+        out["ok"] = None
+        out["note"] = ("chaotic configuration: the reference's own self-deviation here is 1.5e-2..0.13 pixel L1; parity is "
+                       "established per step (teacher-forced steps at the contract bounds), not end to end")
+    return dict(out, **{
             "sample": "the timed system in the timed mode (%s, execution switches %s): one more meta-iteration of %d tasks from the "
-                      "seeded theta, task 0 vs the CPU oracle of cpu_baseline, %d inner steps, %dx%d" % (how, mode, len(frames[0]), S, H, W)}
+                      "seeded theta, task 0 vs the CPU oracle of cpu_baseline, %d inner steps, %dx%d" % (how, mode, len(frames[0]), S, H, W)})
 
 
 def _from_unit_range(system, img01):
@@ -232,11 +250,13 @@ def main():
     for i in range(opt.warmup):
         one_iter(i)
 
-    # HIP events around the HBM-bound custom launches of the workload only (a handful per iteration: the host stays ahead)
-    HBM_KERNELS = {'sepconv': ('sepconv',), 'voxelflow': ('voxelwarp', 'mt_update'), 'cain': ('pixel_', 'mt_update'),
+    # HBM-bound custom launches per plugin.  SepConv's 51-tap op (12 launches per iteration) is timed INSIDE the timed region; the
+    # others (hundreds of small launches for CAIN's channel attention) in the one extra iteration after it, so that their event
+    # records do not sit between the kernels of `value`.
+    HBM_KERNELS = {'sepconv': ('sepconv',), 'voxelflow': ('voxelwarp', 'mt_update'), 'cain': ('pixel_', 'mt_update', 'ca_'),
                    'rrin': ('flowwarp', 'mt_update'), 'superslomo': ('flowwarp', 'mt_update')}
     timer = None
-    if not opt.no_kernel_timer and model in HBM_KERNELS:
+    if not opt.no_kernel_timer and model == 'sepconv':
         timer = _hip.KernelTimer(only=HBM_KERNELS[model])
         _hip.TIMER = timer
     tp.barrier()
@@ -313,17 +333,36 @@ def main():
                         "algorithmic_bytes_per_launch": k["algorithmic_bytes"] / k["launches"],
                         "note": "largest HBM-bound savfi kernel of this workload by time; launches of a few microseconds are "
                                 "latency-bound, not bandwidth-bound (see `kernels` for the others)"}
-        if world == 1 and not toy and dev.type == 'cuda' and not opt.no_kernel_timer and not getattr(system, '_graphs', None):
+        if world == 1 and not toy and dev.type == 'cuda' and not opt.no_kernel_timer:
             # ONE extra meta-iteration of the timed system with HIP events around every convolution launch (outside the timed
-            # region: ~600 event records per iteration would sit between the kernels of `value`)
-            ct = _hip.KernelTimer(only=('conv3x3', 'convk'))
+            # region: ~600 event records per iteration would sit between the kernels of `value`).  Where the timed mode replays
+            # hipGraphs (single-task ranks: C1, C5) a kernel cannot be timed in place: the extra iteration runs the same workload
+            # through the eager loop -- the same kernels on the same shapes -- and also yields the HBM roofline kernel.
+            graphed = bool(getattr(system, '_graphs', None))
+            ct = _hip.KernelTimer(only=('conv3x3', 'convk') + (HBM_KERNELS.get(model, ()) if "roofline" not in line else ()))
+            keep = args.graph_inner_loop
+            if graphed:
+                args.graph_inner_loop = 0
             _hip.TIMER = ct
             try:
                 one_iter(0)
                 sync()
             finally:
                 _hip.TIMER = None
+                args.graph_inner_loop = keep
             cs = ct.summary()
+            if "roofline" not in line:
+                name = max((n for n in cs if cs[n]["algorithmic_bytes"]), key=lambda n: cs[n]["total_ms"], default=None)
+                if name:
+                    k = cs[name]
+                    line["kernels"] = {n: v for n, v in cs.items() if v["algorithmic_bytes"]}
+                    line["roofline"] = {
+                        "bound": "hbm", "kernel": name, "achieved": k["achieved_GBps"], "peak": 8000.0, "unit": "GB/s",
+                        "frac": k["achieved_GBps"] / 8000.0, "traffic": None, "traffic_source": "no PMC measurement for this kernel",
+                        "avg_us_per_launch": k["avg_us"], "launches": k["launches"],
+                        "algorithmic_bytes_per_launch": k["algorithmic_bytes"] / k["launches"],
+                        "note": "largest HBM-bound savfi kernel of this workload by time, timed in ONE extra iteration after the timed "
+                                "region (eager loop; launches of a few microseconds are latency-bound, not bandwidth-bound)"}
             fam = {"winograd_f32_mfma": ("conv3x3_fwd", "conv3x3_bwd_data"), "winograd_wgrad_f32_mfma": ("conv3x3_wgrad",),
                    "direct_bf16x6_mfma": ("convk_fwd", "convk_bwd_data"), "direct_wgrad_bf16x6_mfma": ("convk_wgrad",)}
             # ceilings in direct-equivalent TFLOP/s: fp32 MFMA 157.3 x 2.25 (Winograd F(2x2,3x3) / F(3x3,2x2)); bf16 MFMA 2500 / 6 products

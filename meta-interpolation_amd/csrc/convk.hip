@@ -29,6 +29,8 @@
 //   * Epilogue: bias + (leaky) ReLU, 16-byte stores (4 consecutive pixels per lane).
 // The data gradient is the same kernel on a filter packed flipped / transposed (mode 1) with padding K-1-pad.
 #include "common.h"
+#include <stdio.h>
+#include <stdlib.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
@@ -36,6 +38,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 __device__ float ck_raw_buffer_load_f32(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
+__device__ u32x4 ck_raw_buffer_load_x4(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4i32");
 
 namespace {
 
@@ -123,8 +126,8 @@ struct ConvkArgs {
   const float* bias;   // [T][cout] or null
   float* out;          // [N][cout][Ho][Wo]
   int N, T, cin, cout, H, W, Ho, Wo, pad;
-  int tiles_x, tiles_y, CB, C, co16s;
-  int total, per_xcd, order;
+  int tiles_x, tiles_y, CB, CBnt, C, co16s;     // CB: workgroup-level channel blocks, CBnt: blocks of 16*NT channels
+  int total, per_xcd, order, cg;
   float slope;
 };
 
@@ -138,7 +141,7 @@ struct ConvkGeom {
   static constexpr int TAPS = KS * KS;
   static constexpr int S = (TAPS * QC + 3) / 4;
   static constexpr int ITEMS = POS * QC;                       // (position, octet) items of a chunk
-  static constexpr int IPT = (ITEMS + CK_THREADS - 1) / CK_THREADS;
+  static constexpr int ipt(int threads) { return (ITEMS + threads - 1) / threads; }
   static constexpr int MPR = TW / 16;                          // M-tiles per tile row
 };
 
@@ -147,19 +150,30 @@ struct ConvkGeom {
 // split, the large sum takes one (of exact 16-bit-mantissa products) and the small one rounds 2^-8 lower: 3x closer to
 // float64 (tools/bf16_split_probe.hip "2 accumulators"), better than a blocked fp32 CPU convolution.  For networks that
 // amplify conv rounding (VoxelFlow's flow-to-pixel map: ~1000x into its gradients); costs the registers of half the tile.
-template <int KS, int QC, int NT, int TW, bool P2>
-__global__ __launch_bounds__(CK_THREADS, 2) void convk_kernel(const ConvkArgs a) {
+//
+// CG = 2 ("paired" workgroups, 8 waves): waves 0-3 and 4-7 compute the SAME pixel tile for two neighbouring blocks of 16*NT output
+// channels.  The input tile is staged once for both (the split costs ~0.35 VALU per MFMA at CG = 1 -- and every VALU instruction
+// is paid in matrix-pipe time, PMC: 65 % MFMA + 26 % VALU busy -- half of that at CG = 2), and with one workgroup per CU there is
+// room for TWO input buffers: the next chunk is split and written to the other buffer in the middle of this chunk's MFMAs
+// (one barrier per chunk, no staging bubble).
+template <int KS, int QC, int NT, int TW, bool P2, int CG>
+__global__ __launch_bounds__(CK_THREADS * CG, 2) void convk_kernel(const ConvkArgs a) {
   using G = ConvkGeom<KS, QC, NT, TW>;
+  constexpr int THREADS = CK_THREADS * CG, IPT = G::ipt(THREADS);
+  constexpr bool DB = CG == 2;              // double-buffered input tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, px = lane & 15, g = lane >> 4;
+  const int tid = threadIdx.x, lane = tid & 63, px = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wv = wave & 3, cg = wave >> 2;      // pixel quadrant, channel group
 
   // XCD-contiguous block order: hardware block b runs on XCD b % 8; give each XCD a contiguous range of logical blocks so
   // that the blocks sharing an input tile (or a filter block) meet in ONE L2
   const int logical = (int)(blockIdx.x & 7) * a.per_xcd + (int)(blockIdx.x >> 3);
   if (logical >= a.total) return;
-  int cb, tile;
-  if (a.order == 0) { cb = logical % a.CB; tile = logical / a.CB; }
-  else { const int ntiles = a.total / a.CB; tile = logical % ntiles; cb = logical / ntiles; }
+  int cbw, tile;                             // workgroup-level channel block (CG blocks of 16*NT channels), pixel tile
+  if (a.order == 0) { cbw = logical % a.CB; tile = logical / a.CB; }
+  else { const int ntiles = a.total / a.CB; tile = logical % ntiles; cbw = logical / ntiles; }
+  const int cb = cbw * CG + cg;
+  const bool active = cb < a.CBnt;           // an odd block count leaves the last workgroup's second wave group without work
   const int tx = tile % a.tiles_x;
   const int ty = (tile / a.tiles_x) % a.tiles_y;
   const int n = tile / (a.tiles_x * a.tiles_y);
@@ -173,10 +187,10 @@ __global__ __launch_bounds__(CK_THREADS, 2) void convk_kernel(const ConvkArgs a)
   const int plane_bytes = (int)(plane_in * 4);
 
   // staging geometry of this thread's items (fixed over the chunks): LDS byte offset, buffer offset (octet included)
-  int s_lds[G::IPT], s_voff[G::IPT], s_oct[G::IPT];
+  int s_lds[IPT], s_voff[IPT], s_oct[IPT];
 #pragma unroll
-  for (int k = 0; k < G::IPT; ++k) {
-    const int item = tid + CK_THREADS * k;
+  for (int k = 0; k < IPT; ++k) {
+    const int item = tid + THREADS * k;
     const int o = item / G::POS, pos = item - o * G::POS;
     const int r = pos / G::COLS, c = pos - r * G::COLS;
     const int iy = y0 - a.pad + r, ix = x0 - a.pad + c;
@@ -186,17 +200,17 @@ __global__ __launch_bounds__(CK_THREADS, 2) void convk_kernel(const ConvkArgs a)
     s_lds[k] = item < G::ITEMS ? o * G::OCT + pos * 16 : -1;
   }
 
-  float stage[G::IPT][8];
+  float stage[IPT][8];
   auto stage_load = [&](int chunk) {
     const int soff = chunk * QC * 8 * plane_bytes;
     if ((chunk + 1) * QC * 8 <= a.cin) {       // every channel of the chunk exists (wave-uniform)
 #pragma unroll
-      for (int k = 0; k < G::IPT; ++k)
+      for (int k = 0; k < IPT; ++k)
 #pragma unroll
         for (int e = 0; e < 8; ++e) stage[k][e] = ck_raw_buffer_load_f32(xrs, s_voff[k], soff + e * plane_bytes, 0);
     } else {                                   // the channel tail: the scalar offset is not range checked, test per element
 #pragma unroll
-      for (int k = 0; k < G::IPT; ++k)
+      for (int k = 0; k < IPT; ++k)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const bool have = (chunk * QC + s_oct[k]) * 8 + e < a.cin;
@@ -204,15 +218,16 @@ __global__ __launch_bounds__(CK_THREADS, 2) void convk_kernel(const ConvkArgs a)
         }
     }
   };
-  auto stage_write = [&]() {
+  auto stage_write = [&](int buf) {
+    char* dst = smem + (DB ? buf * G::LDS : 0);
 #pragma unroll
-    for (int k = 0; k < G::IPT; ++k) {
+    for (int k = 0; k < IPT; ++k) {
       if (s_lds[k] < 0) continue;
       u32x4 p1, p2, p3;
       split8(stage[k], p1, p2, p3);
-      *reinterpret_cast<u32x4*>(smem + s_lds[k]) = p1;
-      *reinterpret_cast<u32x4*>(smem + G::PLANE + s_lds[k]) = p2;
-      *reinterpret_cast<u32x4*>(smem + 2 * G::PLANE + s_lds[k]) = p3;
+      *reinterpret_cast<u32x4*>(dst + s_lds[k]) = p1;
+      *reinterpret_cast<u32x4*>(dst + G::PLANE + s_lds[k]) = p2;
+      *reinterpret_cast<u32x4*>(dst + 2 * G::PLANE + s_lds[k]) = p3;
     }
   };
 
@@ -224,8 +239,13 @@ __global__ __launch_bounds__(CK_THREADS, 2) void convk_kernel(const ConvkArgs a)
     abase[i] = (row * G::COLS + col) * 16;
   }
   // B fragments: wp + ((((t co16s + cb NT + nn) C + c) S + s) 3 + plane) 64 + lane
-  const u32x4* __restrict__ wbase = a.wp + ((size_t)((size_t)t * a.co16s + (size_t)cb * NT) * a.C * G::S * 3) * 64 + lane;
-  const size_t wtile = (size_t)a.C * G::S * 3 * 64;            // stride between 16-channel blocks
+  // raw buffer over this task's packed filter: per-lane offset lane * 16 once, everything else in the scalar offset (no
+  // 64-bit address arithmetic in VGPRs between the MFMAs)
+  const size_t wtask = (size_t)a.co16s * a.C * G::S * 3 * 1024;                 // bytes of one task's packed filter (< 2^31, host-checked)
+  const i32x4 wrs = ck_rsrc(reinterpret_cast<const char*>(a.wp) + (size_t)t * wtask, (unsigned)wtask);
+  const int wtile = a.C * G::S * 3 * 1024;                                      // bytes between 16-channel blocks
+  const int wblock = cb * NT * wtile;                                           // this workgroup's first 16-channel block
+  const int wlane = lane * 16;
 
   f32x4 acc[4][NT], lo[P2 ? 4 : 1][P2 ? NT : 1];
 #pragma unroll
@@ -242,12 +262,12 @@ __global__ __launch_bounds__(CK_THREADS, 2) void convk_kernel(const ConvkArgs a)
   constexpr int GT = G::S * NT;
   constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // six products, small terms first
   bf16x8 bq[3][3], aq[4][3];
-  auto load_b = [&](bf16x8 (&dst)[3], const u32x4* __restrict__ wc, int grp) {
+  auto load_b = [&](bf16x8 (&dst)[3], int wc, int grp) {
     const int s = grp / NT, nn = grp % NT;
 #pragma unroll
-    for (int p = 0; p < 3; ++p) dst[p] = __builtin_bit_cast(bf16x8, wc[(size_t)nn * wtile + (s * 3 + p) * 64]);
+    for (int p = 0; p < 3; ++p) dst[p] = __builtin_bit_cast(bf16x8, ck_raw_buffer_load_x4(wrs, wlane, wc + nn * wtile + (s * 3 + p) * 1024, 0));
   };
-  auto load_a = [&](int i, int s) {
+  auto load_a = [&](int i, int s, int buf) {
     const int j = 4 * s + g;
     int tap = j / QC;
     const int o = j % QC;
@@ -255,46 +275,65 @@ __global__ __launch_bounds__(CK_THREADS, 2) void convk_kernel(const ConvkArgs a)
     const int ky = tap / KS, kx = tap - ky * KS;
     const int aoff = o * G::OCT + (ky * G::COLS + kx) * 16;
 #pragma unroll
-    for (int p = 0; p < 3; ++p) aq[i][p] = *reinterpret_cast<const bf16x8*>(smem + p * G::PLANE + abase[i] + aoff);
+    for (int p = 0; p < 3; ++p) aq[i][p] = *reinterpret_cast<const bf16x8*>(smem + (DB ? buf * G::LDS : 0) + p * G::PLANE + abase[i] + aoff);
   };
 
   stage_load(0);
-  for (int c = 0; c < a.C; ++c) {
-    const u32x4* __restrict__ wc = wbase + (size_t)c * G::S * 3 * 64;
-    load_b(bq[0], wc, 0);                       // in flight across the staging bubble
-    if (GT > 1) load_b(bq[1], wc, 1);
-    stage_write();
+  if (DB) {
+    stage_write(0);
     __syncthreads();
+  }
+  for (int c = 0; c < a.C; ++c) {
+    const int wc = wblock + c * (G::S * 3 * 1024);
+    const int buf = c & 1;
+    if (active) {
+      load_b(bq[0], wc, 0);                       // in flight across the staging bubble
+      if (GT > 1) load_b(bq[1], wc, 1);
+    }
+    if (!DB) {
+      stage_write(0);
+      __syncthreads();
+    }
     if (c + 1 < a.C) stage_load(c + 1);          // in flight while this chunk's MFMAs issue
+    if (active) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) load_a(i, 0);
+      for (int i = 0; i < 4; ++i) load_a(i, 0, buf);
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < G::S; ++s) {
 #pragma unroll
       for (int nn = 0; nn < NT; ++nn) {
-        constexpr int dummy = 0; (void)dummy;
         const int grp = s * NT + nn;
-        if (grp + 2 < GT) load_b(bq[(grp + 2) % 3], wc, grp + 2);
-        const bool next_a = nn == NT - 1 && s + 1 < G::S;
+        if (DB && s == G::S / 2 && nn == 0 && c + 1 < a.C) {
+          // paired workgroups: the next chunk goes to the OTHER buffer now (its loads were issued a half chunk ago; every
+          // wave left that buffer at the barrier that ended the previous chunk)
+          stage_write(buf ^ 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (active) {
+          if (grp + 2 < GT) load_b(bq[(grp + 2) % 3], wc, grp + 2);
+          const bool next_a = nn == NT - 1 && s + 1 < G::S;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+          for (int h = 0; h < 2; ++h) {
 #pragma unroll
-          for (int q = 0; q < 6; ++q)
+            for (int q = 0; q < 6; ++q)
 #pragma unroll
-            for (int i = 2 * h; i < 2 * h + 2; ++i) {
-              if (P2 && q < 5)
-                lo[P2 ? i : 0][P2 ? nn : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[i][PA[q]], bq[grp % 3][PB[q]], lo[P2 ? i : 0][P2 ? nn : 0], 0, 0, 0);
-              else
-                acc[i][nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[i][PA[q]], bq[grp % 3][PB[q]], acc[i][nn], 0, 0, 0);
-            }
-          if (next_a) { load_a(2 * h, s + 1); load_a(2 * h + 1, s + 1); }
+              for (int i = 2 * h; i < 2 * h + 2; ++i) {
+                if (P2 && q < 5)
+                  lo[P2 ? i : 0][P2 ? nn : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[i][PA[q]], bq[grp % 3][PB[q]], lo[P2 ? i : 0][P2 ? nn : 0], 0, 0, 0);
+                else
+                  acc[i][nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[i][PA[q]], bq[grp % 3][PB[q]], acc[i][nn], 0, 0, 0);
+              }
+            if (next_a) { load_a(2 * h, s + 1, buf); load_a(2 * h + 1, s + 1, buf); }
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
     __syncthreads();
   }
+  if (!active) return;
 
   // epilogue: lane holds pixels 4 g .. 4 g + 3 of M-tile i (rows of D) for channel 16 nn + px (column of D)
   const size_t plane_out = (size_t)a.Ho * a.Wo;
@@ -329,17 +368,27 @@ __global__ __launch_bounds__(CK_THREADS, 2) void convk_kernel(const ConvkArgs a)
   }
 }
 
-template <int KS, int QC, int NT, int TW, bool P2 = false>
-int launch_convk(const ConvkArgs& a, hipStream_t stream) {
+template <int KS, int QC, int NT, int TW, bool P2, int CG>
+int launch_convk_cg(const ConvkArgs& a, hipStream_t stream) {
   using G = ConvkGeom<KS, QC, NT, TW>;
   static uint32_t configured = 0;
-  auto kern = convk_kernel<KS, QC, NT, TW, P2>;
-  if (G::LDS > 64 * 1024) {
-    const int rc = savfi_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), G::LDS, configured);
+  auto kern = convk_kernel<KS, QC, NT, TW, P2, CG>;
+  constexpr int lds = G::LDS * CG;          // CG = 2: two input buffers
+  static_assert(lds <= 160 * 1024, "input tile buffers exceed the LDS of a CU");
+  if (lds > 64 * 1024) {
+    const int rc = savfi_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds, configured);
     if (rc != SAVFI_OK) return rc;
   }
-  hipLaunchKernelGGL(kern, dim3(a.per_xcd * 8), dim3(CK_THREADS), G::LDS, stream, a);
+  hipLaunchKernelGGL(kern, dim3(a.per_xcd * 8), dim3(CK_THREADS * CG), lds, stream, a);
   return savfi_launch_status();
+}
+
+template <int KS, int QC, int NT, int TW, bool P2 = false>
+int launch_convk(const ConvkArgs& a, hipStream_t stream) {
+  if constexpr (NT >= 2) {
+    if (a.cg == 2) return launch_convk_cg<KS, QC, NT, TW, P2, 2>(a, stream);
+  }
+  return launch_convk_cg<KS, QC, NT, TW, P2, 1>(a, stream);
 }
 
 template <int KS, int QC>
@@ -418,21 +467,37 @@ extern "C" int savfi_convk_tasks_pre_f32(const float* x, const float* packed, co
   a.slope = slope;
   const int qc = ck_qc(a.cin, K);
   a.C = ck_chunks(a.cin, qc);
+  if ((int64_t)ck_round_up((a.cout + 15) / 16, 4) * a.C * ck_steps(K, qc) * 3 * 1024 >= (1ll << 31)) return SAVFI_E_TOOBIG;
   a.co16s = ck_round_up((a.cout + 15) / 16, 4);       // packed filter blocks (zero padded to a multiple of 4)
   // tile shape: the better-filled of 8 x 32 and 16 x 16
   auto fill = [&](int th, int tw) { return (double)a.Ho * a.Wo / ((double)((a.Ho + th - 1) / th * th) * ((a.Wo + tw - 1) / tw * tw)); };
-  const int tw = fill(16, 16) > fill(8, 32) + 1e-9 ? 16 : 32;
+  // 8 x 32 tiles have the smaller halo (340 vs 324 staged cells but 128-byte output rows and half the row count): 16 x 16 only
+  // where it fills clearly better
+  const int tw = fill(16, 16) > 1.08 * fill(8, 32) ? 16 : 32;
   const int th = 256 / tw;
   a.tiles_x = (a.Wo + tw - 1) / tw; a.tiles_y = (a.Ho + th - 1) / th;
   const int64_t tiles = (int64_t)N * a.tiles_x * a.tiles_y;
-  // output channels per workgroup: 64 unless that wastes a half-empty block or leaves the GPU under-filled
-  int nt = 4;
-  const int rem = a.cout % 64;
-  if (a.cout <= 16) nt = 1;
-  else if (a.cout <= 32 || (rem != 0 && rem <= 32 && a.cout < 128)) nt = 2;
-  else if (tiles * ((a.cout + 63) / 64) < 512 && a.cout >= 64) nt = 2;
-  if (precise && nt > 2) nt = 2;
-  a.CB = ((a.cout + 15) / 16 + nt - 1) / nt;
+  // Output channels per wave (16 nt) and wave groups per workgroup (cg), from tools/convk_bench.py sweeps with SAVFI_CONVK_TILE
+  // (profiles/r03_convk_tile_sweep.txt).  W1 = single workgroups of 64 channels (two share a CU), W2 = paired workgroups (8 waves,
+  // one per CU: the input tile is split once for both channel blocks and double buffered).  Pairs of 64-channel blocks win
+  // when they fill the GPU in exactly one round; otherwise single 64-channel workgroups while they oversubscribe the CUs; deep
+  // layers on small maps take pairs of 32-channel blocks (twice the workgroups); the rest single 32-channel workgroups.
+  const int co16 = (a.cout + 15) / 16, co64 = (co16 + 3) / 4, co32 = (co16 + 1) / 2;
+  const int64_t W1 = tiles * co64, W2_4 = tiles * ((co64 + 1) / 2), W2_2 = tiles * ((co32 + 1) / 2);
+  const bool ragged64 = a.cout % 64 != 0 && a.cout % 64 <= 32 && a.cout < 128;      // a half-empty 64-channel block
+  int nt, cg;
+  if (a.cout <= 16) { nt = 1; cg = 1; }
+  else if (!precise && co16 > 2 && co64 >= 2 && W2_4 >= 176 && W2_4 <= 256) { nt = 4; cg = 2; }
+  else if (!precise && co16 > 2 && !ragged64 && W1 >= 448) { nt = 4; cg = 1; }
+  else if (co32 >= 2 && W2_2 >= 160) { nt = 2; cg = 2; }
+  else { nt = 2; cg = 1; }
+  if (const char* e = getenv("SAVFI_CONVK_TILE")) {          // experiment knob: "nt,cg"
+    int en = 0, ec = 0;
+    if (sscanf(e, "%d,%d", &en, &ec) == 2 && (en == 1 || en == 2 || en == 4) && (ec == 1 || ec == 2) && !(precise && en == 4) && !(en == 1 && ec == 2)) { nt = en; cg = ec; }
+  }
+  a.CBnt = (co16 + nt - 1) / nt;
+  a.cg = cg;
+  a.CB = (a.CBnt + cg - 1) / cg;
   if (tiles * a.CB >= (1ll << 30)) return SAVFI_E_TOOBIG;
   a.total = (int)(tiles * a.CB);
   a.per_xcd = (a.total + 7) / 8;

@@ -30,9 +30,17 @@ import torch
 from . import _hip, hip_ops, model_utils, utils
 
 
+# Graphed L2F is OPT-IN (SAVFI_GRAPH_L2F=1): it matches the eager loop and the reference fixtures at 64x64 and 128x192 over
+# several meta-iterations (tests/test_system_gpu.py), but at 1280x720 the THIRD replay of its graph set returns garbage (the
+# parameters entering it are bit-identical to the eager run's; profiles/r03_graphed_l2f_720p.txt) -- unresolved, so config C5 keeps
+# the eager loop, whose numbers are the fixture-checked ones.
+import os as _os
+GRAPH_L2F = bool(_os.environ.get('SAVFI_GRAPH_L2F'))
+
+
 def supported(system, use_second_order):
     a = system.args
-    if a.attenuate and system._routing_known_incomplete():
+    if a.attenuate and (system._routing_known_incomplete() or not GRAPH_L2F):
         return False
     return (bool(getattr(a, 'graph_inner_loop', 0)) and system.device.type == 'cuda' and not use_second_order
             and hasattr(system.inner_loop_optimizer, 'lr_mode'))

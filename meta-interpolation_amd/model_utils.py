@@ -245,6 +245,7 @@ class MetaConvNorm(nn.Module):
 
 
 _META_TYPES = ()
+_NO_CA_FUSED = bool(__import__('os').environ.get('SAVFI_NO_CA_FUSED'))      # experiment knob
 
 
 class MetaSequential(nn.Sequential):
@@ -310,7 +311,7 @@ class MetaRCAB(nn.Module):
 
     def forward(self, x, params=None):
         pv = as_view(params)
-        if x.is_cuda and fuse_conv_act() and _act_slope(self.body[1]) is not None:
+        if x.is_cuda and fuse_conv_act() and _act_slope(self.body[1]) is not None and not _NO_CA_FUSED:
             # first-order pass on the GPU: conv + LeakyReLU, conv, then pool -> MLP -> scale -> skip as the fused savfi op
             # (hip_ops.channel_attention_residual: three launches instead of eight, each map read once per launch)
             sub = (lambda i: None) if pv is None else (lambda i: pv.sub("body").sub(i))
