@@ -280,7 +280,10 @@ def main():
     line = {
         "metric": "inner-loop steps/sec", "value": inner_steps / elapsed, "unit": "inner-loop steps/sec",
         "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": 1e3 * elapsed / opt.steps,
-        "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+        # fp32 arithmetic end to end; the direct convolution kernels evaluate every fp32 product as six bf16 products of exactly
+        # split operands with fp32 accumulation (csrc/convk.hip: as close to float64 as an fp32 fmaf chain)
+        "dtype": "f32 (convolutions on csrc/convk*.hip: bf16x6 split operands, f32 accumulate)", "data": "synthetic",
         "config": {"workload": opt.workload, "plugin": model, "tasks_per_gpu": tasks, "global_meta_batch": tasks * world,
                    "inner_steps": S, "frame": "%dx%dx3" % (H, W),
                    "inner_rule": ("metasgd" if over.get('metasgd') else "lslr") + "+" + over.get('optimizer', 'SGD'),

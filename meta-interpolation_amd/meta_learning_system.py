@@ -696,30 +696,36 @@ class SceneAdaptiveInterpolation(nn.Module):
         groups = [local[i:i + width] for i in range(0, len(local), width)]
         n = max(1, min(self._task_streams(graphed=True), len(groups)))
 
+        owner = {tuple(g): j % n for j, g in enumerate(groups)}
+        needed = {key + (owner[tuple(g)], len(g)) for g in groups}       # graph sets this call replays: never evicted by it
+
         def loop_for(i, T):
             k = key + (i, T)
             if k not in self._graphs:
                 import gc
                 # a graph set pins its static buffers and memory pool: keep the most recently used ones only (evaluation over
-                # clips of many different sizes would otherwise capture, and keep, one set per size)
-                while len(self._graphs) >= self.MAX_GRAPH_SETS:
-                    self._graphs.pop(next(iter(self._graphs)))
+                # clips of many different sizes would otherwise capture, and keep, one set per size) -- but never one this
+                # call still needs (more task streams than MAX_GRAPH_SETS / 2 would otherwise evict their own sets)
+                cap = max(self.MAX_GRAPH_SETS, len(needed))
+                for old in [q for q in self._graphs if q not in needed]:
+                    if len(self._graphs) < cap:
+                        break
+                    self._graphs.pop(old)
                 gc.collect()
                 self._graphs[k] = graph_inner_loop.GraphedInnerLoop(self, frames[0].shape[1:], num_steps,
                                                                     bool(training_phase), msl, tasks=T)
             else:
                 self._graphs[k] = self._graphs.pop(k)          # most recently used last
             return self._graphs[k]
-        owner = {tuple(g): j % n for j, g in enumerate(groups)}
-        for g in groups:                                   # capture on this thread, before any worker starts
-            loop_for(owner[tuple(g)], len(g))
+        # capture / look up on THIS thread, before any worker starts: the workers only read the resolved table
+        loops = {tuple(g): loop_for(owner[tuple(g)], len(g)) for g in groups}
         importance = self.get_per_step_loss_importance_vector()
         accums = [graph_inner_loop.OuterGradAccumulator(self, self.get_inner_loop_parameter_dict(self.net.named_parameters()))
                   if training_phase else None for _ in range(n)]
 
         def body(group):
             i = owner[tuple(group)]
-            task_losses, preds_g, logs_g = loop_for(i, len(group)).run_tasks(frames, list(group), importance, accums[i])
+            task_losses, preds_g, logs_g = loops[tuple(group)].run_tasks(frames, list(group), importance, accums[i])
             out = []
             for t, task_id in enumerate(group):
                 pred = preds_g[t]
