@@ -45,3 +45,8 @@ __device__ __forceinline__ float block_sum(float x, float* lds /* >= NW floats *
   __syncthreads();
   return t;
 }
+
+// csrc/sepconv_x6.hip: gV and gH of the K = 51, C = 3 separable convolution on split-bf16 MFMAs (internal: reached through
+// savfi_sepconv_bwd_f32)
+int savfi_sepconv_bwd_x6_launch(const float* in, const float* v, const float* h, const float* gO, float* gV, float* gH, int B, int Ho,
+                                int Wo, int cus, hipStream_t st);

@@ -107,34 +107,73 @@ __global__ __launch_bounds__(WG_THREADS, 2) void convk_wgrad_kernel(const WgArgs
   const int gplane_b = (int)(gplane * 4), xplane_b = (int)(xplane * 4);
 
   // ---- staging: items = (octet, cell); thread tid takes cotangent items tid + 256 k and input items tid + 256 k ----
+  // An item's offset inside its sample (row dy / column dx of the unit, first channel of its octet) is fixed for the whole
+  // launch: per unit one v_add moves it to the unit's origin, a compare pair masks what hangs over an image edge (the raw
+  // buffer returns 0 beyond num_records), and the channel of each of the 8 loads rides in the scalar offset.  The first
+  // version rebuilt item -> (octet, row, column) -> address with a predicate per element: ~40 VALU per item per unit, as much
+  // as the split itself -- on a datapath the MFMAs share (PMC round 3: 3 VALU per MFMA).
   constexpr int GIPT = (G::GITEMS + WG_THREADS - 1) / WG_THREADS, XIPT = (G::XITEMS + WG_THREADS - 1) / WG_THREADS;
+  constexpr int OOB = 0x7fffffff;
+  int g_rel[GIPT], g_yx[GIPT], x_rel[XIPT], x_yx[XIPT];     // byte offset from the unit origin (OOB: no such item); dy << 16 | dx
+  // octets whose channels all exist take the scalar-offset path; the channel tail of a ragged layer (Co = 3, 51, ...) is masked
+  // per element (wave-uniform choice per launch)
+  const bool g_full = (a.Co & 7) == 0, x_full = (a.Ci & 7) == 0;
+#pragma unroll
+  for (int k = 0; k < GIPT; ++k) {
+    const int item = tid + WG_THREADS * k;
+    const int o = item / G::GCELLS, cell = item - o * G::GCELLS;
+    const int dy = cell / UW, dx = cell - dy * UW;
+    g_yx[k] = dy << 16 | dx;
+    g_rel[k] = (item < G::GITEMS && co0 + 8 * o < a.Co) ? (dy * a.Wo + dx) * 4 + (co0 + 8 * o) * gplane_b : OOB;
+  }
+#pragma unroll
+  for (int k = 0; k < XIPT; ++k) {
+    const int item = tid + WG_THREADS * k;
+    const int o = item / G::XCELLS, cell = item - o * G::XCELLS;
+    const int dy = cell / G::XCOLS, dx = cell - dy * G::XCOLS;
+    x_yx[k] = dy << 16 | dx;
+    x_rel[k] = (item < G::XITEMS && ci0 + 8 * o < a.Ci) ? (dy * a.W + dx) * 4 + (ci0 + 8 * o) * xplane_b : OOB;
+  }
   float stage_g[GIPT][8], stage_x[XIPT][8];
   auto stage_load = [&](int u) {
     const int seg = u % a.ups, rp = (u / a.ups) % a.upr, n = (u / (a.ups * a.upr)) * a.T + t;
     const int y0 = rp * UR, x0 = seg * UW;
     const i32x4 grs = ckw_rsrc(a.gz + (size_t)n * a.Co * gplane, (unsigned)((size_t)a.Co * gplane * 4));
     const i32x4 xrs = ckw_rsrc(a.x + (size_t)n * a.Ci * xplane, (unsigned)((size_t)a.Ci * xplane * 4));
+    const int g_org = (y0 * a.Wo + x0) * 4, x_org = ((y0 - a.pad) * a.W + (x0 - a.pad)) * 4;
+    const bool g_in = y0 + UR <= a.Ho && x0 + UW <= a.Wo;                                   // the unit lies inside the map
+    const bool x_in = y0 >= a.pad && x0 >= a.pad && y0 - a.pad + G::XROWS <= a.H && x0 - a.pad + G::XCOLS <= a.W;
 #pragma unroll
     for (int k = 0; k < GIPT; ++k) {
-      const int item = tid + WG_THREADS * k;
-      const int o = item / G::GCELLS, cell = item - o * G::GCELLS;
-      const int y = y0 + cell / UW, xx = x0 + cell % UW;
-      const bool ok = item < G::GITEMS && y < a.Ho && xx < a.Wo;
-      const int base = (y * a.Wo + xx) * 4, ch0 = co0 + 8 * o;
+      int voff = g_rel[k] == OOB ? OOB : g_rel[k] + g_org;
+      if (!g_in) {
+        const int dy = g_yx[k] >> 16, dx = g_yx[k] & 0xffff;
+        voff = (y0 + dy < a.Ho && x0 + dx < a.Wo) ? voff : OOB;
+      }
+      if (g_full) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e)
-        stage_g[k][e] = ckw_raw_buffer_load_f32(grs, (ok && ch0 + e < a.Co) ? base + (ch0 + e) * gplane_b : 0x7fffffff, 0, 0);
+        for (int e = 0; e < 8; ++e) stage_g[k][e] = ckw_raw_buffer_load_f32(grs, voff, e * gplane_b, 0);
+      } else {
+        const int ch0 = co0 + 8 * ((tid + WG_THREADS * k) / G::GCELLS);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) stage_g[k][e] = ckw_raw_buffer_load_f32(grs, ch0 + e < a.Co ? voff + e * gplane_b : OOB, 0, 0);
+      }
     }
 #pragma unroll
     for (int k = 0; k < XIPT; ++k) {
-      const int item = tid + WG_THREADS * k;
-      const int o = item / G::XCELLS, cell = item - o * G::XCELLS;
-      const int y = y0 - a.pad + cell / G::XCOLS, xx = x0 - a.pad + cell % G::XCOLS;
-      const bool ok = item < G::XITEMS && (unsigned)y < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
-      const int base = (y * a.W + xx) * 4, ch0 = ci0 + 8 * o;
+      int voff = x_rel[k] == OOB ? OOB : x_rel[k] + x_org;
+      if (!x_in) {
+        const int dy = x_yx[k] >> 16, dx = x_yx[k] & 0xffff;
+        voff = ((unsigned)(y0 - a.pad + dy) < (unsigned)a.H && (unsigned)(x0 - a.pad + dx) < (unsigned)a.W) ? voff : OOB;
+      }
+      if (x_full) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e)
-        stage_x[k][e] = ckw_raw_buffer_load_f32(xrs, (ok && ch0 + e < a.Ci) ? base + (ch0 + e) * xplane_b : 0x7fffffff, 0, 0);
+        for (int e = 0; e < 8; ++e) stage_x[k][e] = ckw_raw_buffer_load_f32(xrs, voff, e * xplane_b, 0);
+      } else {
+        const int ch0 = ci0 + 8 * ((tid + WG_THREADS * k) / G::XCELLS);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) stage_x[k][e] = ckw_raw_buffer_load_f32(xrs, ch0 + e < a.Ci ? voff + e * xplane_b : OOB, 0, 0);
+      }
     }
   };
   auto stage_write = [&]() {
@@ -280,14 +319,17 @@ __global__ __launch_bounds__(256) void convk_wgrad_reduce(const float* __restric
 
 struct WgPlan { int mt, nt, cobs, cibs, units, upr, ups, splits, ups_per_split; };
 
-inline int wg_plan(WgPlan& p, int N, int T, int Ci, int Co, int H, int W, int K, int pad) {
+inline int wg_plan(WgPlan& p, int N, int T, int Ci, int Co, int H, int W, int K, int pad, bool precise) {
   if (N <= 0 || T <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0 || N % T != 0 || pad < 0 || pad > K - 1) return SAVFI_E_SHAPE;
   if (K != 3 && K != 5 && K != 7) return SAVFI_E_UNSUPPORTED;
   const int Ho = H + 2 * pad - K + 1, Wo = W + 2 * pad - K + 1;
   if (Ho <= 0 || Wo <= 0) return SAVFI_E_SHAPE;
   if ((int64_t)Ci * H * W >= (1ll << 29) || (int64_t)Co * Ho * Wo >= (1ll << 29)) return SAVFI_E_TOOBIG;
   p.mt = (K == 3 && Co >= 192) ? 4 : 2;     // 5x5 / 7x7: 7 / 13 taps per wave x 4 tiles would not fit the register file
-  p.nt = 1;
+  // two input-channel tiles per workgroup: the cotangent tile is split once for 32 input channels (0.7x the VALU per MFMA);
+  // the second accumulator set of the precise form and the 13 taps per wave of 7x7 leave no registers for it
+  p.nt = (!precise && K != 7 && p.mt == 2 && Ci > 16) ? 2 : 1;
+  if (const char* e = getenv("SAVFI_WGRAD_NT")) { if (atoi(e) == 1) p.nt = 1; }
   p.cobs = (Co + 16 * p.mt - 1) / (16 * p.mt);
   p.cibs = (Ci + 16 * p.nt - 1) / (16 * p.nt);
   p.upr = (Ho + UR - 1) / UR;
@@ -318,17 +360,19 @@ int launch_wgrad(const WgArgs& a, int blocks, hipStream_t stream) {
 }  // namespace
 
 extern "C" int64_t savfi_convk_wgrad_workspace_floats(int N, int T, int Ci, int Co, int H, int W, int K, int pad) {
-  WgPlan p;
-  const int rc = wg_plan(p, N, T, Ci, Co, H, W, K, pad);
+  WgPlan p, q;
+  int rc = wg_plan(p, N, T, Ci, Co, H, W, K, pad, false);
   if (rc != SAVFI_OK) return rc;
-  return (int64_t)p.splits * T * Co * Ci * K * K;
+  rc = wg_plan(q, N, T, Ci, Co, H, W, K, pad, true);
+  if (rc != SAVFI_OK) return rc;
+  return (int64_t)(p.splits > q.splits ? p.splits : q.splits) * T * Co * Ci * K * K;
 }
 
 extern "C" int savfi_convk_wgrad_tasks_f32(const float* x, const float* gz, float* gw, float* workspace, int N, int T, int Ci, int Co,
                                            int H, int W, int K, int pad, int precise, void* stream) {
   if (!x || !gz || !gw || !workspace) return SAVFI_E_NULL;
   WgPlan p;
-  int rc = wg_plan(p, N, T, Ci, Co, H, W, K, pad);
+  int rc = wg_plan(p, N, T, Ci, Co, H, W, K, pad, precise != 0);
   if (rc != SAVFI_OK) return rc;
   WgArgs a;
   a.x = x; a.gz = gz; a.partial = workspace;
@@ -339,8 +383,8 @@ extern "C" int savfi_convk_wgrad_tasks_f32(const float* x, const float* gz, floa
   const int blocks = T * p.cobs * p.cibs * p.splits;
   hipStream_t st = (hipStream_t)stream;
   if (K == 3 && precise) rc = p.mt == 4 ? launch_wgrad<3, 4, 1, true>(a, blocks, st) : launch_wgrad<3, 2, 1, true>(a, blocks, st);
-  else if (K == 3) rc = p.mt == 4 ? launch_wgrad<3, 4, 1>(a, blocks, st) : launch_wgrad<3, 2, 1>(a, blocks, st);
-  else if (K == 5) rc = precise ? launch_wgrad<5, 2, 1, true>(a, blocks, st) : launch_wgrad<5, 2, 1>(a, blocks, st);
+  else if (K == 3) rc = p.mt == 4 ? launch_wgrad<3, 4, 1>(a, blocks, st) : p.nt == 2 ? launch_wgrad<3, 2, 2>(a, blocks, st) : launch_wgrad<3, 2, 1>(a, blocks, st);
+  else if (K == 5) rc = precise ? launch_wgrad<5, 2, 1, true>(a, blocks, st) : p.nt == 2 ? launch_wgrad<5, 2, 2>(a, blocks, st) : launch_wgrad<5, 2, 1>(a, blocks, st);
   else rc = launch_wgrad<7, 2, 1>(a, blocks, st);       // 13 taps per wave: no room for a second accumulator set
   if (rc != SAVFI_OK) return rc;
   const long long n = (long long)T * Co * Ci * K * K;

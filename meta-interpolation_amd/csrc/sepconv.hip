@@ -986,12 +986,14 @@ __global__ void sepconv_bwd_input_direct(const float* __restrict__ v, const floa
   gI[(size_t)bc * Hi * Wi + (size_t)Y * Wi + X] = acc;
 }
 
-// Experiment switches, read ONCE per process (not per launch): SAVFI_SEPCONV_NO_MFMA forces the direct kernels,
+// Experiment switches, read ONCE per process (not per launch): SAVFI_SEPCONV_F32_MFMA keeps the filter gradients on the fp32
+// matrix-core kernel (sepconv_bwd_mfma_p) instead of the split-bf16 one (csrc/sepconv_x6.hip), SAVFI_SEPCONV_NO_MFMA forces the direct kernels,
 // SAVFI_SEPCONV_TILED the tiled (non-persistent) MFMA kernels, SAVFI_SEPCONV_MFMA_ROWS = 8 | 12 | 16 pins their rows per workgroup.
 struct SepconvEnv {
-  bool no_mfma, tiled;
+  bool no_mfma, tiled, f32_mfma;
   int rows;
-  SepconvEnv() : no_mfma(getenv("SAVFI_SEPCONV_NO_MFMA") != nullptr), tiled(getenv("SAVFI_SEPCONV_TILED") != nullptr), rows(0) {
+  SepconvEnv() : no_mfma(getenv("SAVFI_SEPCONV_NO_MFMA") != nullptr), tiled(getenv("SAVFI_SEPCONV_TILED") != nullptr),
+                 f32_mfma(getenv("SAVFI_SEPCONV_F32_MFMA") != nullptr), rows(0) {
     if (const char* e = getenv("SAVFI_SEPCONV_MFMA_ROWS")) {
       const int r = atoi(e);
       if (r == 8 || r == 12 || r == 16) rows = r;
@@ -1140,7 +1142,10 @@ extern "C" int savfi_sepconv_bwd_f32(const float* in, const float* v, const floa
   if (int e = check_dims(B, C, Ho, Wo, K)) return e;
   hipStream_t st = (hipStream_t)stream;
   if (gV || gH) {
-    if (K == KFAST && C == 3 && !sepconv_env().no_mfma && !sepconv_env().tiled && persistent_ok(B, Ho, Wo)) {
+    if (K == KFAST && C == 3 && gV && gH && !sepconv_env().no_mfma && !sepconv_env().tiled && !sepconv_env().f32_mfma &&
+        persistent_ok(B, Ho, Wo)) {
+      if (int e = savfi_sepconv_bwd_x6_launch(in, v, h, gO, gV, gH, B, Ho, Wo, device_cu_count(), st)) return e;
+    } else if (K == KFAST && C == 3 && !sepconv_env().no_mfma && !sepconv_env().tiled && persistent_ok(B, Ho, Wo)) {
       if (int e = launch_bwd_persistent(in, v, h, gO, gV, gH, B, Ho, Wo, st)) return e;
     } else if (K == KFAST && C == 3 && !sepconv_env().no_mfma && mfma_fits(Ho, Wo)) {
       int e;

@@ -1,0 +1,482 @@
+// SepConv filter gradients (gV, gH; K = 51, C = 3) on the bf16 matrix cores with error-free 3-way operand splits
+// ("bf16x6": every fp32 product as six bf16 products of exactly split operands, fp32 accumulate -- the arithmetic of
+// csrc/convk.hip, as close to float64 as an fp32 fmaf chain; tools/bf16_split_probe.hip).
+//
+//   gV[b,fy,y,x] = sum_c gO[b,c,y,x] * sum_fx in[b,c,y+fy,x+fx] * h[b,fx,y,x]
+//   gH[b,fx,y,x] = sum_c gO[b,c,y,x] * sum_fy in[b,c,y+fy,x+fx] * v[b,fy,y,x]
+//
+// Replaces the reference's two cupy/NVRTC filter-gradient kernels (sepconv/sepconv_op/sepconv.py:32-63, :138-190 backward) --
+// same op, same layout -- and supersedes sepconv_bwd_mfma_p (csrc/sepconv.hip) for the shape the model uses.  That kernel
+// runs the two banded GEMMs on v_mfma_f32_16x16x4_f32 and is bound by that pipe (360 MFMAs of 32 cycles per 16 pixels:
+// 88 % busy at 350 us for B = 8, 256 x 448).  v_mfma_f32_16x16x32_bf16 does eight times the k per instruction at half the
+// cycles: six products cost 96 cycles per 16 x 16 x 32 where the fp32 instruction needs 256.
+//
+// Formulation per wave = 16 pixels (y, x0 + 16 wc + j) of one output row, per channel c (own accumulators: gO[c] multiplies the
+// channel's sum afterwards, so the B operands are channel independent):
+//   gV:  D[fy][j] = sum_i In_c[y + fy][16 wc + i] * Hb[i][j],   Hb[i][j] = h[j][i - j] (0 <= i - j < 51): M = fy (4 tiles),
+//        K = i = 64 window columns (2 steps) -- the two columns i = 64, 65 that pixels 14, 15 still reach are a VALU tail;
+//   gH:  D[q][j]  = sum_fy In_c[y + fy][16 wc + q] * v[j][fy],  gH[fx][j] = D[j + fx][j]: M = q (4 tiles + the same two
+//        columns as a tail), K = fy (2 steps, taps 51..63 zero).  Its A operand runs DOWN the window's columns: the gfx950
+//        transpose read ds_read_b64_tr_b16 delivers it from the same row-major window.
+// 288 MFMAs of 16 cycles per 16 pixels (was 360 of 32).
+//
+// LDS (159 KB, one workgroup of 8 waves per CU):
+//   window   three bf16 pieces x 3 channels x 64 circular rows x 80 columns, in blocks of 8 columns:
+//            [piece][c][column / 8][row & 63][8]; a block is 64 x 16 B + 128 B.  gV's 16-byte A fragments (lane = row, 16
+//            consecutive cells = 256 B; the k-groups a hardware lane group mixes sit two blocks = 2304 B apart) and gH's
+//            transpose reads (8 consecutive rows x 4 column quads, the quads of the second block 128 B further) are both
+//            free of bank conflicts;
+//   taps     per wave ONE table [piece][k / 8][j][8] (6 KB) that holds the skewed h band for gV, then v for gH (the B
+//            fragments of a pass live in registers), then the 64 x 16 transpose tile gH leaves through;
+//   side     fp32 copies of window columns 64, 65, 80, 81 (the tails), tail sums of gV.
+// Persistent launch as sepconv_bwd_mfma_p: one workgroup per CU walks an equal share of "phases" (4 output rows of a
+// 32-column strip), the window slides by 8 rows every other phase.
+#include "common.h"
+#include <stdlib.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int XK = 51, XC = 3;
+constexpr int XNT = 512;                         // 8 waves: 4 output rows x 2 groups of 16 pixels
+constexpr int XMC = 32, XPR = 4;                 // strip width, rows per phase
+constexpr int XWIN = 64, XAHEAD = 8;             // circular window rows, rows per slide
+constexpr int XBLK = 64 * 16 + 128, XNBLK = 10;  // bytes per 8-column block, blocks (80 columns)
+constexpr int XPLANE = XNBLK * XBLK, XWINB = 9 * XPLANE;
+constexpr int XTABP = 8 * 256, XTAB = 3 * XTABP; // tap table of a wave: [piece][k / 8][16 j][8]
+constexpr int XSIDE_OFF = XWINB + 8 * XTAB, XSIDE = XC * XWIN * 4 * 4;
+constexpr int XTAIL_OFF = XSIDE_OFF + XSIDE, XTAILB = 416;
+constexpr int XLDS = XTAIL_OFF + 8 * XTAILB;
+static_assert(XLDS <= 160 * 1024, "LDS per CU");
+constexpr int XNREG = (XK + 3) / 4;              // tap registers per lane
+constexpr unsigned X_OOR = 0x80000000u;
+
+__device__ __forceinline__ float x6_bload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void x6_bstore(float val, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), r, (int)voff, (int)soff, 0);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t x6_rsrc(const float* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ unsigned x6_cvt_pk(float lo, float hi) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+// a = a1 + a2 + a3, b = b1 + b2 + b3 exactly (bf16 pieces, round to nearest even); h_p = piece p of a (low half), of b (high half)
+__device__ __forceinline__ void x6_split2(float a, float b, unsigned& h1, unsigned& h2, unsigned& h3) {
+  h1 = x6_cvt_pk(a, b);
+  const float ra = a - __uint_as_float(h1 << 16), rb = b - __uint_as_float(h1 & 0xffff0000u);
+  h2 = x6_cvt_pk(ra, rb);
+  const float qa = ra - __uint_as_float(h2 << 16), qb = rb - __uint_as_float(h2 & 0xffff0000u);
+  h3 = x6_cvt_pk(qa, qb);
+}
+__device__ __forceinline__ void x6_st16(char* p, unsigned v) { *reinterpret_cast<unsigned short*>(p) = (unsigned short)v; }
+// The tap table of a wave changes type as a phase goes on (bf16 pieces -> fp32 transpose tile -> bf16 pieces): LDS operations
+// of one wave execute in program order, this keeps the compiler from reordering them by type-based alias analysis.
+#define X6_ORDER()                      \
+  do {                                  \
+    __builtin_amdgcn_wave_barrier();    \
+    asm volatile("" ::: "memory");      \
+  } while (0)
+
+// rows [r_lo, r_lo + NROWS) of the strip (b, x0): HBM -> registers -> (split) -> their circular slots; thread = (column, row group)
+template <int NROWS>
+struct X6Rows {
+  static constexpr int NIT = NROWS / 4;
+  static_assert(NROWS % 4 == 0 && (XC * NIT) % 2 == 0, "whole row groups, element pairs");
+  float buf[XC][NIT];
+};
+template <int NROWS>
+__device__ __forceinline__ void x6_rows_load(X6Rows<NROWS>& sr, __amdgpu_buffer_rsrc_t in_rs, int b, int x0, int r_lo, int Hi, int Wi, int tid) {
+  const int q = tid & 127, rg = tid >> 7;
+  const int colb = min(x0 + q, Wi - 1) * 4;
+#pragma unroll
+  for (int c = 0; c < XC; ++c)
+#pragma unroll
+    for (int it = 0; it < X6Rows<NROWS>::NIT; ++it) {
+      const int r = min(r_lo + rg + 4 * it, Hi - 1);
+      sr.buf[c][it] = x6_bload(in_rs, (unsigned)(((b * XC + c) * Hi + r) * Wi * 4 + colb), 0u);
+    }
+}
+template <int NROWS>
+__device__ __forceinline__ void x6_rows_write(const X6Rows<NROWS>& sr, char* __restrict__ smem, int r_lo, int tid) {
+  constexpr int NIT = X6Rows<NROWS>::NIT, NE = XC * NIT;
+  const int q = tid & 127, rg = tid >> 7;
+  const int cell = (q >> 3) * XBLK + (q & 7) * 2;
+  const int sidx = q == 64 ? 0 : q == 65 ? 1 : q == 80 ? 2 : q == 81 ? 3 : -1;
+  float* side = reinterpret_cast<float*>(smem + XSIDE_OFF);
+#pragma unroll
+  for (int e = 0; e < NE; e += 2) {
+    const int c0 = e / NIT, i0 = e % NIT, c1 = (e + 1) / NIT, i1 = (e + 1) % NIT;
+    const float a = sr.buf[c0][i0], bb = sr.buf[c1][i1];
+    const int s0 = (r_lo + rg + 4 * i0) & (XWIN - 1), s1 = (r_lo + rg + 4 * i1) & (XWIN - 1);
+    if (q < 8 * XNBLK) {
+      unsigned h1, h2, h3;
+      x6_split2(a, bb, h1, h2, h3);
+      char* d0 = smem + c0 * XPLANE + cell + s0 * 16;
+      char* d1 = smem + c1 * XPLANE + cell + s1 * 16;
+      x6_st16(d0, h1); x6_st16(d0 + 3 * XPLANE, h2); x6_st16(d0 + 6 * XPLANE, h3);
+      x6_st16(d1, h1 >> 16); x6_st16(d1 + 3 * XPLANE, h2 >> 16); x6_st16(d1 + 6 * XPLANE, h3 >> 16);
+    }
+    if (sidx >= 0) {
+      side[(c0 * XWIN + s0) * 4 + sidx] = a;
+      side[(c1 * XWIN + s1) * 4 + sidx] = bb;
+    }
+  }
+}
+
+__global__ __launch_bounds__(XNT) void sepconv_bwd_x6(const float* __restrict__ in, const float* __restrict__ v,
+                                                      const float* __restrict__ h, const float* __restrict__ gO,
+                                                      float* __restrict__ gV, float* __restrict__ gH,
+                                                      int B, int Ho, int Wo, int nph, int ncol, int per_wg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = w & 1, wr = w >> 1;
+  const int j = lane & 15, kg = lane >> 4;
+  char* const tab = smem + XWINB + w * XTAB;
+  float* const side = reinterpret_cast<float*>(smem + XSIDE_OFF);
+  float* const tailb = reinterpret_cast<float*>(smem + XTAIL_OFF + w * XTAILB);
+
+  const int total = B * ncol * nph;
+  const int g0 = blockIdx.x * per_wg, g1 = min(g0 + per_wg, total);
+  if (g0 >= g1) return;
+  const int Hi = Ho + XK - 1, Wi = Wo + XK - 1;
+  const unsigned plane_b = (unsigned)Ho * (unsigned)Wo * 4u;
+  const __amdgpu_buffer_rsrc_t hsrc = x6_rsrc(h, (unsigned)(B * XK) * plane_b);
+  const __amdgpu_buffer_rsrc_t vsrc = x6_rsrc(v, (unsigned)(B * XK) * plane_b);
+  const __amdgpu_buffer_rsrc_t gsrc = x6_rsrc(gO, (unsigned)(B * XC) * plane_b);
+  const __amdgpu_buffer_rsrc_t isrc = x6_rsrc(in, (unsigned)(B * XC) * (unsigned)(Hi * Wi) * 4u);
+  const __amdgpu_buffer_rsrc_t gvdst = x6_rsrc(gV, (unsigned)(B * XK) * plane_b);
+  const __amdgpu_buffer_rsrc_t ghdst = x6_rsrc(gH, (unsigned)(B * XK) * plane_b);
+
+  auto pos_of = [&](int g, int& b, int& x0, int& ph) {
+    const int s = g / nph;
+    ph = g - s * nph;
+    b = s / ncol;
+    x0 = (s - b * ncol) * XMC;
+  };
+  auto pix_off = [&](int b, int x0, int y, int ch) {
+    return (unsigned)b * (unsigned)ch * plane_b + (unsigned)(min(y, Ho - 1) * Wo + min(x0 + 16 * wc + j, Wo - 1)) * 4u;
+  };
+  // lane (j, tg = kg) holds taps 4 it + tg of pixel j; "tap 51" (it = 12, tg = 3) is the next sample's tap 0: the table writers zero it
+  auto load_taps = [&](float (&regs)[XNREG], __amdgpu_buffer_rsrc_t src, int b, int x0, int y) {
+    const unsigned voff = pix_off(b, x0, y, XK) + (unsigned)kg * plane_b;
+#pragma unroll
+    for (int it = 0; it < XNREG; ++it) regs[it] = x6_bload(src, voff, (unsigned)(4 * it) * plane_b);
+  };
+  // h band of the wave's 16 pixels -> table [piece][i / 8][j][i % 8], i = tap + j < 64 (zero elsewhere)
+  auto write_h_table = [&](const float (&regs)[XNREG]) {
+#pragma unroll
+    for (int k = 0; k < XTAB / 1024; ++k) *reinterpret_cast<u32x4*>(tab + (k * 64 + lane) * 16) = (u32x4){0u, 0u, 0u, 0u};
+    const int base_i = kg + j;
+#pragma unroll
+    for (int it = 0; it < XNREG; it += 2) {
+      unsigned h1, h2, h3;
+      x6_split2((it == XNREG - 1 && kg == 3) ? 0.f : regs[it], it + 1 < XNREG ? regs[it + 1] : 0.f, h1, h2, h3);
+      const int i0 = base_i + 4 * it;
+      char* d0 = tab + (i0 >> 3) * 256 + j * 16 + (i0 & 7) * 2;
+      if (it < XNREG - 1 || i0 < 64) { x6_st16(d0, h1); x6_st16(d0 + XTABP, h2); x6_st16(d0 + 2 * XTABP, h3); }
+      if (it + 1 < XNREG) {
+        const int i1 = i0 + 4;
+        char* d1 = tab + (i1 >> 3) * 256 + j * 16 + (i1 & 7) * 2;
+        if (it + 1 < XNREG - 1 || i1 < 64) { x6_st16(d1, h1 >> 16); x6_st16(d1 + XTABP, h2 >> 16); x6_st16(d1 + 2 * XTABP, h3 >> 16); }
+      }
+    }
+  };
+  // v taps -> table position of tap fy = 4 it + tg: k step fy / 32, k group (fy % 16) / 4, element fy % 4 + 4 * ((fy / 16) % 2)
+  // (the order in which gH's two transpose reads deliver the window rows); taps 51..63 are written as zeros
+  auto v_pos = [&](int it) { return (4 * (it >> 3) + (it & 3)) * 256 + 8 * ((it >> 2) & 1); };
+  auto write_v_table = [&](const float (&regs)[XNREG]) {
+    char* const lb = tab + j * 16 + kg * 2;
+#pragma unroll
+    for (int it = 0; it < 16; it += 2) {
+      unsigned h1 = 0u, h2 = 0u, h3 = 0u;
+      if (it < XNREG) x6_split2((it == XNREG - 1 && kg == 3) ? 0.f : regs[it], it + 1 < XNREG ? regs[it + 1] : 0.f, h1, h2, h3);
+      char* d0 = lb + v_pos(it);
+      char* d1 = lb + v_pos(it + 1);
+      x6_st16(d0, h1); x6_st16(d0 + XTABP, h2); x6_st16(d0 + 2 * XTABP, h3);
+      x6_st16(d1, h1 >> 16); x6_st16(d1 + XTABP, h2 >> 16); x6_st16(d1 + 2 * XTABP, h3 >> 16);
+    }
+  };
+  auto tr_read = [&](int addr) -> bf16x4 {
+    typedef __attribute__((address_space(3))) bf16x4 lds_b4;
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(smem + addr));
+  };
+
+  int b, x0, ph;
+  pos_of(g0, b, x0, ph);
+  float hreg[XNREG], vreg[XNREG], gnext[XC];
+  load_taps(hreg, hsrc, b, x0, XPR * ph + wr);
+  load_taps(vreg, vsrc, b, x0, XPR * ph + wr);
+  {
+    const unsigned go = pix_off(b, x0, XPR * ph + wr, XC);
+#pragma unroll
+    for (int c = 0; c < XC; ++c) gnext[c] = x6_bload(gsrc, go, (unsigned)c * plane_b);
+  }
+#pragma unroll 1
+  for (int r = 0; r < XWIN; r += 16) {
+    X6Rows<16> sr;
+    x6_rows_load<16>(sr, isrc, b, x0, XPR * ph + r, Hi, Wi, tid);
+    x6_rows_write<16>(sr, smem, XPR * ph + r, tid);
+  }
+  int loaded_hi = XPR * ph + XWIN;
+  write_h_table(hreg);
+  __syncthreads();
+  if (w >= 4) __builtin_amdgcn_s_sleep(40);       // de-phase the two waves of a SIMD
+
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // six products, small terms first
+  const int permk = ((kg & 1) << 1) | (kg >> 1);      // gV: k group kg <-> columns 8 permk .. (lane-group mates two blocks apart)
+  const int L = lane & 15;
+
+#pragma unroll 1
+  for (int g = g0; g < g1; ++g) {
+    if (g != g0 && ph == 0) {                      // entered the next strip: the whole window is new
+      __syncthreads();
+#pragma unroll 1
+      for (int r = 0; r < XWIN; r += 16) {
+        X6Rows<16> sr;
+        x6_rows_load<16>(sr, isrc, b, x0, r, Hi, Wi, tid);
+        x6_rows_write<16>(sr, smem, r, tid);
+      }
+      loaded_hi = XWIN;
+      __syncthreads();
+    }
+    int nb, nx0, nph_;
+    pos_of(min(g + 1, g1 - 1), nb, nx0, nph_);
+    const bool slide = (g + 1 < g1) && nph_ != 0 && (XPR * nph_ + XPR + XK - 1 > loaded_hi);
+    X6Rows<XAHEAD> slid;
+    if (slide) x6_rows_load<XAHEAD>(slid, isrc, b, x0, loaded_hi, Hi, Wi, tid);
+
+    const int y = XPR * ph + wr;
+    const int x = x0 + 16 * wc + j;
+    const bool pvalid = (x < Wo) && (y < Ho);
+    const unsigned opix_b = (unsigned)b * (unsigned)XK * plane_b + (unsigned)(min(y, Ho - 1) * Wo + min(x, Wo - 1)) * 4u;
+    float g_[XC];
+#pragma unroll
+    for (int c = 0; c < XC; ++c) g_[c] = gnext[c];
+    // what the two tail columns need of this phase's taps and cotangent, before the registers take the next phase's
+    const float h50_14 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hreg[12]), 14 + 32));
+    const float h49_15 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hreg[12]), 15 + 16));
+    const float h50_15 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hreg[12]), 15 + 32));
+    float g14[XC], g15[XC];
+#pragma unroll
+    for (int c = 0; c < XC; ++c) {
+      g14[c] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, g_[c]), 14));
+      g15[c] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, g_[c]), 15));
+    }
+
+    // ---- gV -------------------------------------------------------------------------------------------------------
+    bf16x8 bq[2][3];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bq[s][p] = *reinterpret_cast<const bf16x8*>(tab + p * XTABP + (4 * s + permk) * 256 + j * 16);
+    // next phase's h taps and cotangent: HBM -> registers (the table holds this phase's)
+    load_taps(hreg, hsrc, nb, nx0, XPR * nph_ + wr);
+    {
+      const unsigned go = pix_off(nb, nx0, XPR * nph_ + wr, XC);
+#pragma unroll
+      for (int c = 0; c < XC; ++c) gnext[c] = x6_bload(gsrc, go, (unsigned)c * plane_b);
+    }
+    // the h fragments are in registers: the table takes v now, and the v registers the next phase's taps
+    X6_ORDER();
+    write_v_table(vreg);
+    X6_ORDER();
+    load_taps(vreg, vsrc, nb, nx0, XPR * nph_ + wr);
+
+    const int fyl = min(lane, XK - 1);
+    const int tslot = (y + fyl) & (XWIN - 1);
+    float a64[XC], a65[XC];
+#pragma unroll
+    for (int c = 0; c < XC; ++c) {
+      const f32x2 sv = *reinterpret_cast<const f32x2*>(side + (c * XWIN + tslot) * 4 + 2 * wc);
+      a64[c] = sv.x; a65[c] = sv.y;
+    }
+    {   // columns i = 64 (pixel 14: tap 50; pixel 15: tap 49) and 65 (pixel 15: tap 50): lane = tap row fy
+      float t14 = 0.f, t15 = 0.f;
+#pragma unroll
+      for (int c = 0; c < XC; ++c) {
+        t14 = fmaf(g14[c] * h50_14, a64[c], t14);
+        t15 = fmaf(g15[c] * h49_15, a64[c], t15);
+        t15 = fmaf(g15[c] * h50_15, a65[c], t15);
+      }
+      *reinterpret_cast<f32x2*>(tailb + 2 * fyl) = (f32x2){t14, t15};
+    }
+
+    {
+      f32x4 acc[XC][4];
+#pragma unroll
+      for (int c = 0; c < XC; ++c)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[c][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      int rowoff[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) rowoff[m] = ((y + min(16 * m + j, XK - 1)) & (XWIN - 1)) * 16 + (2 * wc + permk) * XBLK;
+      bf16x8 aq[2][2][3];
+      auto load_a = [&](int slot, int u) {
+        const int c = u >> 2, s = (u >> 1) & 1, mp = u & 1;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int p = 0; p < 3; ++p)
+            aq[slot][t][p] = *reinterpret_cast<const bf16x8*>(smem + (p * 3 + c) * XPLANE + 4 * s * XBLK + rowoff[2 * mp + t]);
+      };
+      __builtin_amdgcn_sched_barrier(0);
+      load_a(0, 0);
+#pragma unroll
+      for (int u = 0; u < 12; ++u) {
+        if (u + 1 < 12) load_a((u + 1) & 1, u + 1);
+        const int c = u >> 2, s = (u >> 1) & 1, mp = u & 1;
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+            acc[c][2 * mp + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[u & 1][t][PA[q]], bq[s][PB[q]], acc[c][2 * mp + t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // D row 4 kg + r of tile m = tap row fy = 16 m + 4 kg + r, column = pixel j; pixels 14, 15 add their tail columns
+      const float tsel = j >= 14 ? 1.f : 0.f;
+      const int tcol = j == 15 ? 1 : 0;
+      const unsigned vo = opix_b + (unsigned)(4 * kg) * plane_b;
+      const unsigned voA = pvalid ? vo : X_OOR, voB = (pvalid && kg == 0) ? vo : X_OOR;
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < (m < 3 ? 4 : 3); ++r) {
+          float val = g_[0] * acc[0][m][r];
+          val = fmaf(g_[1], acc[1][m][r], val);
+          val = fmaf(g_[2], acc[2][m][r], val);
+          val = fmaf(tsel, tailb[2 * min(16 * m + 4 * kg + r, XK - 1) + tcol], val);
+          x6_bstore(val, gvdst, m < 3 ? voA : voB, (unsigned)(16 * m + r) * plane_b);
+        }
+    }
+
+    // ---- gH -------------------------------------------------------------------------------------------------------
+    {
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) bq[s][p] = *reinterpret_cast<const bf16x8*>(tab + p * XTABP + (4 * s + kg) * 256 + j * 16);
+      // tail columns q = 64, 65 (taps 50 / 49, 50 of pixels 14, 15): lane = tap row fy, v from the table's pieces
+      float s6414 = 0.f, s6415 = 0.f, s6515 = 0.f;
+      {
+        const int f5 = fyl & 31;
+        const char* tp = tab + (4 * (fyl >> 5) + ((f5 & 15) >> 2)) * 256 + ((f5 & 3) + 4 * ((f5 >> 4) & 1)) * 2;
+        float v14 = 0.f, v15 = 0.f;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          v14 += __uint_as_float((unsigned)*reinterpret_cast<const unsigned short*>(tp + p * XTABP + 14 * 16) << 16);
+          v15 += __uint_as_float((unsigned)*reinterpret_cast<const unsigned short*>(tp + p * XTABP + 15 * 16) << 16);
+        }
+        const float live = lane < XK ? 1.f : 0.f;
+        v14 *= live; v15 *= live;
+#pragma unroll
+        for (int c = 0; c < XC; ++c) {
+          s6414 = fmaf(g14[c] * v14, a64[c], s6414);
+          s6415 = fmaf(g15[c] * v15, a64[c], s6415);
+          s6515 = fmaf(g15[c] * v15, a65[c], s6515);
+        }
+        s6414 = wave_sum(s6414);
+        s6415 = wave_sum(s6415);
+        s6515 = wave_sum(s6515);
+      }
+      f32x4 acc[XC][4];
+#pragma unroll
+      for (int c = 0; c < XC; ++c)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[c][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      // transpose read: source lane L of group kg points at window row y + 32 s + 16 half + 4 kg + L / 4, column quad L % 4 of the tile
+      int rowh[2][2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+          rowh[s][hf] = ((y + 32 * s + 16 * hf + 4 * kg + (L >> 2)) & (XWIN - 1)) * 16 + (2 * wc + ((L & 3) >> 1)) * XBLK + (L & 1) * 8;
+      bf16x8 aq[2][2][3];
+      auto load_a = [&](int slot, int u) {
+        const int c = u >> 2, s = (u >> 1) & 1, mp = u & 1;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int p = 0; p < 3; ++p) {
+            const int base = (p * 3 + c) * XPLANE + 2 * (2 * mp + t) * XBLK;
+            const bf16x4 lo = tr_read(base + rowh[s][0]), hi = tr_read(base + rowh[s][1]);
+            aq[slot][t][p] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          }
+      };
+      __builtin_amdgcn_sched_barrier(0);
+      load_a(0, 0);
+#pragma unroll
+      for (int u = 0; u < 12; ++u) {
+        if (u + 1 < 12) load_a((u + 1) & 1, u + 1);
+        const int c = u >> 2, s = (u >> 1) & 1, mp = u & 1;
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+            acc[c][2 * mp + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[u & 1][t][PA[q]], bq[s][PB[q]], acc[c][2 * mp + t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // gH[fx][j] = D[j + fx][j]: through a 64 x 16 fp32 tile in the wave's (now dead) tap table, out as 13 x four 64-byte runs
+      {
+        X6_ORDER();
+        float* tile = reinterpret_cast<float*>(tab);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float val = g_[0] * acc[0][m][r];
+            val = fmaf(g_[1], acc[1][m][r], val);
+            val = fmaf(g_[2], acc[2][m][r], val);
+            tile[(16 * m + 4 * kg + r) * 16 + j] = val;
+          }
+        X6_ORDER();
+        const unsigned ho = opix_b + (unsigned)kg * plane_b;
+#pragma unroll
+        for (int t = 0; t < XNREG; ++t) {
+          const int fx = 4 * t + kg;
+          const float val = tile[min(j + fx, 63) * 16 + j];
+          x6_bstore(val, ghdst, (pvalid && fx < XK && j + fx < 64) ? ho : X_OOR, (unsigned)(4 * t) * plane_b);
+        }
+        X6_ORDER();
+      }
+      x6_bstore(s6414, ghdst, (pvalid && lane == 14) ? opix_b : X_OOR, 50u * plane_b);
+      x6_bstore(s6415, ghdst, (pvalid && lane == 15) ? opix_b : X_OOR, 49u * plane_b);
+      x6_bstore(s6515, ghdst, (pvalid && lane == 15) ? opix_b : X_OOR, 50u * plane_b);
+    }
+
+    // the next phase's h band takes the table
+    write_h_table(hreg);
+    X6_ORDER();
+    if (slide) {                                   // the eight oldest rows are behind every wave's next phase
+      __syncthreads();
+      x6_rows_write<XAHEAD>(slid, smem, loaded_hi, tid);
+      loaded_hi += XAHEAD;
+      __syncthreads();
+    }
+    b = nb; x0 = nx0; ph = nph_;
+  }
+}
+
+}  // namespace
+
+// gV and gH of the K = 51, C = 3 op; every tensor below 2^31 bytes (the caller checks).  Declared in csrc/common.h.
+int savfi_sepconv_bwd_x6_launch(const float* in, const float* v, const float* h, const float* gO, float* gV, float* gH, int B, int Ho,
+                                int Wo, int cus, hipStream_t st) {
+  static uint32_t done = 0;
+  if (int e = savfi_ensure_dynamic_lds((const void*)sepconv_bwd_x6, XLDS, done)) return e;
+  const int nph = savfi_cdiv(Ho, XPR), ncol = savfi_cdiv(Wo, XMC);
+  const int64_t total = (int64_t)B * ncol * nph;
+  const int per_wg = savfi_cdiv(total, cus);
+  const int grid = savfi_cdiv(total, per_wg);
+  hipLaunchKernelGGL(sepconv_bwd_x6, dim3(grid), dim3(XNT), XLDS, st, in, v, h, gO, gV, gH, B, Ho, Wo, nph, ncol, per_wg);
+  return savfi_launch_status();
+}
