@@ -315,13 +315,14 @@ def main():
                         break
                 per_call = 4.0 * (3 * (oh + 50) * (ow + 50) + 4 * 51 * oh * ow + 3 * oh * ow)
                 line["roofline"] = {
-                    "bound": "hbm", "kernel": "sepconv_bwd_mfma (gV+gH, K=51)",
+                    "bound": "hbm", "kernel": "sepconv_bwd_x6 (gV+gH, K=51; csrc/sepconv_x6.hip, split-bf16 MFMAs)",
                     "achieved": k["achieved_GBps"], "peak": 8000.0, "unit": "GB/s",
                     "frac": k["achieved_GBps"] / 8000.0, "traffic": traffic, "traffic_source": tnote,
                     "avg_us_per_launch": k["avg_us"], "launches": k["launches"],
                     "algorithmic_bytes_per_launch": k["algorithmic_bytes"] / k["launches"],
                     "note": "algorithmic bytes = %.2f MB per [1,3,%d,%d] sample (x samples per launch: tasks in lockstep x the "
-                            "support pair); fp32 issue ceiling of this op is ~53%% of HBM peak (SURVEY.md 7)"
+                            "support pair); 288 bf16 MFMAs per 16 pixels = 29%% of the launch at full matrix rate, the rest is per-phase tap staging, "
+                            "stores and window barriers with 8 waves per CU (DESIGN.md 4b)"
                             % (per_call / 1e6, oh, ow)}
             elif summ:
                 # workloads without the 51-tap op: the HBM-bound savfi kernel that takes the most time in the timed region

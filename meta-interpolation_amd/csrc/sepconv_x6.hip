@@ -53,7 +53,8 @@ constexpr int XSIDE_OFF = XWINB + 8 * XTAB, XSIDE = XC * XWIN * 4 * 4;
 constexpr int XTAIL_OFF = XSIDE_OFF + XSIDE, XTAILB = 416;
 constexpr int XLDS = XTAIL_OFF + 8 * XTAILB;
 static_assert(XLDS <= 160 * 1024, "LDS per CU");
-constexpr int XNREG = (XK + 3) / 4;              // tap registers per lane
+constexpr int XNREG = (XK + 3) / 4;              // gH leaves in 13 instructions of four taps
+constexpr int XNP = 7;                           // tap pairs per lane
 constexpr unsigned X_OOR = 0x80000000u;
 
 __device__ __forceinline__ float x6_bload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
@@ -166,44 +167,59 @@ __global__ __launch_bounds__(XNT) void sepconv_bwd_x6(const float* __restrict__ 
   auto pix_off = [&](int b, int x0, int y, int ch) {
     return (unsigned)b * (unsigned)ch * plane_b + (unsigned)(min(y, Ho - 1) * Wo + min(x0 + 16 * wc + j, Wo - 1)) * 4u;
   };
-  // lane (j, tg = kg) holds taps 4 it + tg of pixel j; "tap 51" (it = 12, tg = 3) is the next sample's tap 0: the table writers zero it
-  auto load_taps = [&](float (&regs)[XNREG], __amdgpu_buffer_rsrc_t src, int b, int x0, int y) {
-    const unsigned voff = pix_off(b, x0, y, XK) + (unsigned)kg * plane_b;
+  // Tap registers: lane (j, kg) holds 7 PAIRS of neighbouring taps t0 + 8 a + {0, 1}, a = 0..6, so that a split pair
+  // (x6_split2: low half = first tap, high half = second) is exactly the dword a table position takes -- 21 ds_write_b32 per
+  // table where single taps needed 39-48 ds_write_b16 plus shifts and per-tap address arithmetic (PMC: those stores were
+  // half of the kernel's LDS cycles).  v: t0 = 2 kg.  h: t0 = 2 kg - (j & 1): the band position i = tap + j of a pair then
+  // starts even for every pixel.  Taps outside 0..50 are loaded from a clamped plane and zeroed by the table writers.
+  auto load_taps = [&](float (&regs)[XNP][2], __amdgpu_buffer_rsrc_t src, int b, int x0, int y, int t0) {
+    const unsigned pix = pix_off(b, x0, y, XK);
+    const unsigned voff = pix + (unsigned)(t0 + 1) * plane_b;        // plane t0 + 1 >= 0: the range check sees this offset only
+    regs[0][0] = x6_bload(src, pix + (unsigned)max(t0, 0) * plane_b, 0u);
+    regs[0][1] = x6_bload(src, voff, 0u);
 #pragma unroll
-    for (int it = 0; it < XNREG; ++it) regs[it] = x6_bload(src, voff, (unsigned)(4 * it) * plane_b);
+    for (int a = 1; a < XNP - 1; ++a)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) regs[a][e] = x6_bload(src, voff, (unsigned)(8 * a + e - 1) * plane_b);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) regs[XNP - 1][e] = x6_bload(src, pix + (unsigned)min(8 * (XNP - 1) + t0 + e, XK - 1) * plane_b, 0u);
+  };
+  auto tap_or_zero = [&](const float (&regs)[XNP][2], int a, int e, int t0) {
+    if (a == 0 && e == 0) return t0 < 0 ? 0.f : regs[0][0];
+    if (a == XNP - 1) return (8 * (XNP - 1) + t0 + e < XK) ? regs[a][e] : 0.f;
+    return regs[a][e];
   };
   // h band of the wave's 16 pixels -> table [piece][i / 8][j][i % 8], i = tap + j < 64 (zero elsewhere)
-  auto write_h_table = [&](const float (&regs)[XNREG]) {
+  const int h_t0 = 2 * kg - (j & 1), v_t0 = 2 * kg;
+  auto write_h_table = [&](const float (&regs)[XNP][2]) {
 #pragma unroll
     for (int k = 0; k < XTAB / 1024; ++k) *reinterpret_cast<u32x4*>(tab + (k * 64 + lane) * 16) = (u32x4){0u, 0u, 0u, 0u};
-    const int base_i = kg + j;
+    const int base2 = 2 * kg + (j & ~1);                             // position of the lane's first pair: even, <= 20
+    char* const lb = tab + (base2 >> 3) * 256 + j * 16 + (base2 & 7) * 2;
 #pragma unroll
-    for (int it = 0; it < XNREG; it += 2) {
+    for (int a = 0; a < XNP; ++a) {
       unsigned h1, h2, h3;
-      x6_split2((it == XNREG - 1 && kg == 3) ? 0.f : regs[it], it + 1 < XNREG ? regs[it + 1] : 0.f, h1, h2, h3);
-      const int i0 = base_i + 4 * it;
-      char* d0 = tab + (i0 >> 3) * 256 + j * 16 + (i0 & 7) * 2;
-      if (it < XNREG - 1 || i0 < 64) { x6_st16(d0, h1); x6_st16(d0 + XTABP, h2); x6_st16(d0 + 2 * XTABP, h3); }
-      if (it + 1 < XNREG) {
-        const int i1 = i0 + 4;
-        char* d1 = tab + (i1 >> 3) * 256 + j * 16 + (i1 & 7) * 2;
-        if (it + 1 < XNREG - 1 || i1 < 64) { x6_st16(d1, h1 >> 16); x6_st16(d1 + XTABP, h2 >> 16); x6_st16(d1 + 2 * XTABP, h3 >> 16); }
+      x6_split2(tap_or_zero(regs, a, 0, h_t0), tap_or_zero(regs, a, 1, h_t0), h1, h2, h3);
+      char* d = lb + a * 256;
+      if (a < XNP - 1 || base2 < 16) {                               // positions 64, 65 belong to the tail
+        *reinterpret_cast<unsigned*>(d) = h1;
+        *reinterpret_cast<unsigned*>(d + XTABP) = h2;
+        *reinterpret_cast<unsigned*>(d + 2 * XTABP) = h3;
       }
     }
   };
-  // v taps -> table position of tap fy = 4 it + tg: k step fy / 32, k group (fy % 16) / 4, element fy % 4 + 4 * ((fy / 16) % 2)
-  // (the order in which gH's two transpose reads deliver the window rows); taps 51..63 are written as zeros
-  auto v_pos = [&](int it) { return (4 * (it >> 3) + (it & 3)) * 256 + 8 * ((it >> 2) & 1); };
-  auto write_v_table = [&](const float (&regs)[XNREG]) {
-    char* const lb = tab + j * 16 + kg * 2;
+  // v taps -> table position of tap fy: k step fy / 32, k group (fy % 16) / 4, element fy % 4 + 4 * ((fy / 16) % 2) (the
+  // order in which gH's two transpose reads deliver the window rows); taps 51..63 are written as zeros
+  auto write_v_table = [&](const float (&regs)[XNP][2]) {
+    char* const lb = tab + (kg >> 1) * 256 + j * 16 + (kg & 1) * 4;
 #pragma unroll
-    for (int it = 0; it < 16; it += 2) {
+    for (int a = 0; a < 8; ++a) {
       unsigned h1 = 0u, h2 = 0u, h3 = 0u;
-      if (it < XNREG) x6_split2((it == XNREG - 1 && kg == 3) ? 0.f : regs[it], it + 1 < XNREG ? regs[it + 1] : 0.f, h1, h2, h3);
-      char* d0 = lb + v_pos(it);
-      char* d1 = lb + v_pos(it + 1);
-      x6_st16(d0, h1); x6_st16(d0 + XTABP, h2); x6_st16(d0 + 2 * XTABP, h3);
-      x6_st16(d1, h1 >> 16); x6_st16(d1 + XTABP, h2 >> 16); x6_st16(d1 + 2 * XTABP, h3 >> 16);
+      if (a < XNP) x6_split2(tap_or_zero(regs, a, 0, v_t0), tap_or_zero(regs, a, 1, v_t0), h1, h2, h3);
+      char* d = lb + (4 * (a >> 2) + 2 * (a & 1)) * 256 + 8 * ((a >> 1) & 1);
+      *reinterpret_cast<unsigned*>(d) = h1;
+      *reinterpret_cast<unsigned*>(d + XTABP) = h2;
+      *reinterpret_cast<unsigned*>(d + 2 * XTABP) = h3;
     }
   };
   auto tr_read = [&](int addr) -> bf16x4 {
@@ -213,9 +229,9 @@ __global__ __launch_bounds__(XNT) void sepconv_bwd_x6(const float* __restrict__ 
 
   int b, x0, ph;
   pos_of(g0, b, x0, ph);
-  float hreg[XNREG], vreg[XNREG], gnext[XC];
-  load_taps(hreg, hsrc, b, x0, XPR * ph + wr);
-  load_taps(vreg, vsrc, b, x0, XPR * ph + wr);
+  float hreg[XNP][2], vreg[XNP][2], gnext[XC];
+  load_taps(hreg, hsrc, b, x0, XPR * ph + wr, h_t0);
+  load_taps(vreg, vsrc, b, x0, XPR * ph + wr, v_t0);
   {
     const unsigned go = pix_off(b, x0, XPR * ph + wr, XC);
 #pragma unroll
@@ -263,9 +279,10 @@ __global__ __launch_bounds__(XNT) void sepconv_bwd_x6(const float* __restrict__ 
 #pragma unroll
     for (int c = 0; c < XC; ++c) g_[c] = gnext[c];
     // what the two tail columns need of this phase's taps and cotangent, before the registers take the next phase's
-    const float h50_14 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hreg[12]), 14 + 32));
-    const float h49_15 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hreg[12]), 15 + 16));
-    const float h50_15 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hreg[12]), 15 + 32));
+    // pixel 14 (t0 = 2 kg): tap 50 = 48 + 2 -> lane (14, kg = 1), pair 6, first; pixel 15 (t0 = 2 kg - 1): taps 49, 50 = 48 + 1 + {0, 1} -> lane (15, 1)
+    const float h50_14 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hreg[6][0]), 14 + 16));
+    const float h49_15 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hreg[6][0]), 15 + 16));
+    const float h50_15 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hreg[6][1]), 15 + 16));
     float g14[XC], g15[XC];
 #pragma unroll
     for (int c = 0; c < XC; ++c) {
@@ -280,7 +297,7 @@ __global__ __launch_bounds__(XNT) void sepconv_bwd_x6(const float* __restrict__ 
 #pragma unroll
       for (int p = 0; p < 3; ++p) bq[s][p] = *reinterpret_cast<const bf16x8*>(tab + p * XTABP + (4 * s + permk) * 256 + j * 16);
     // next phase's h taps and cotangent: HBM -> registers (the table holds this phase's)
-    load_taps(hreg, hsrc, nb, nx0, XPR * nph_ + wr);
+    load_taps(hreg, hsrc, nb, nx0, XPR * nph_ + wr, h_t0);
     {
       const unsigned go = pix_off(nb, nx0, XPR * nph_ + wr, XC);
 #pragma unroll
@@ -290,7 +307,7 @@ __global__ __launch_bounds__(XNT) void sepconv_bwd_x6(const float* __restrict__ 
     X6_ORDER();
     write_v_table(vreg);
     X6_ORDER();
-    load_taps(vreg, vsrc, nb, nx0, XPR * nph_ + wr);
+    load_taps(vreg, vsrc, nb, nx0, XPR * nph_ + wr, v_t0);
 
     const int fyl = min(lane, XK - 1);
     const int tslot = (y + fyl) & (XWIN - 1);
@@ -334,6 +351,8 @@ __global__ __launch_bounds__(XNT) void sepconv_bwd_x6(const float* __restrict__ 
 #pragma unroll
       for (int u = 0; u < 12; ++u) {
         if (u + 1 < 12) load_a((u + 1) & 1, u + 1);
+        __builtin_amdgcn_sched_barrier(0);          // the next unit's fragments are requested BEFORE this unit's MFMAs issue
+      __builtin_amdgcn_sched_barrier(0);          // the next unit's fragments are requested BEFORE this unit's MFMAs issue
         const int c = u >> 2, s = (u >> 1) & 1, mp = u & 1;
 #pragma unroll
         for (int q = 0; q < 6; ++q)
@@ -417,6 +436,8 @@ __global__ __launch_bounds__(XNT) void sepconv_bwd_x6(const float* __restrict__ 
 #pragma unroll
       for (int u = 0; u < 12; ++u) {
         if (u + 1 < 12) load_a((u + 1) & 1, u + 1);
+        __builtin_amdgcn_sched_barrier(0);          // the next unit's fragments are requested BEFORE this unit's MFMAs issue
+      __builtin_amdgcn_sched_barrier(0);          // the next unit's fragments are requested BEFORE this unit's MFMAs issue
         const int c = u >> 2, s = (u >> 1) & 1, mp = u & 1;
 #pragma unroll
         for (int q = 0; q < 6; ++q)
