@@ -77,7 +77,12 @@ struct WgArgs {
 
 template <int KS, int MT, int NT>
 struct WgGeom {
-  static constexpr int TAPS = KS * KS, TPW = (TAPS + 3) / 4;
+  static constexpr int TAPS = KS * KS;
+  // taps w, w + 4, ... of wave w for all rows of a unit (FULL each), and the TAPS % 4 left-over taps for row w only: every wave
+  // issues the same number of MFMAs (9 taps over 4 waves as 3 / 2 / 2 / 2 whole taps left three SIMDs idle a third of the time:
+  // PMC 41 % MFMA busy with the first SIMD of every CU at 61 %)
+  static constexpr int FULL = TAPS / 4, SHARED = TAPS % 4, TPW = FULL + SHARED;
+  static_assert(UR == 4, "a shared tap's rows go one to each wave");
   static constexpr int GOCTS = 2 * MT, XOCTS = 2 * NT;
   static constexpr int GCELLS = UR * UW, XROWS = UR + KS - 1, XCOLS = UW + KS - 1, XCELLS = XROWS * XCOLS;
   static constexpr int GOCT = ckw_oct(GCELLS), XOCT = ckw_oct(XCELLS);
@@ -237,7 +242,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void convk_wgrad_kernel(const WgArgs
     if (u + 1 < u_end) stage_load(u + 1);
     // software pipeline over the UR x TPW x NT groups of this unit (one group = one tap x one input-channel tile x MT
     // output-channel tiles = 6 MT MFMAs): the B fragments of the next group are read from LDS while the current group's MFMAs issue
-    constexpr int NG = UR * G::TPW * NT;
+    constexpr int NG = UR * G::FULL * NT;
     bf16x8 aq[MT][3], bq[2][3];
     auto load_a = [&](int r) {
 #pragma unroll
@@ -245,56 +250,97 @@ __global__ __launch_bounds__(WG_THREADS, 2) void convk_wgrad_kernel(const WgArgs
 #pragma unroll
         for (int p = 0; p < 3; ++p) aq[m][p] = tr_read(p * G::GPLANE + a_addr[m] + r * UW * 16);
     };
-    auto load_b = [&](int gi) {
-      const int r = gi / (G::TPW * NT), tp = (gi / NT) % G::TPW, nn = gi % NT;
-      int tap = wv + 4 * tp;
-      tap = tap < G::TAPS ? tap : 0;
+    auto load_b_at = [&](bf16x8 (&dst)[3], int r, int tap, int nn) {
       const int ky = tap / KS, kx = tap - ky * KS;
       const int boff = ((r + ky) * G::XCOLS + kx) * 16;
 #pragma unroll
-      for (int p = 0; p < 3; ++p) bq[gi & 1][p] = tr_read(p * G::XPLANE + b_addr[nn] + boff);
+      for (int p = 0; p < 3; ++p) dst[p] = tr_read(p * G::XPLANE + b_addr[nn] + boff);
+    };
+    auto load_b = [&](int gi) {
+      const int r = gi / (G::FULL * NT), tp = (gi / NT) % G::FULL, nn = gi % NT;
+      load_b_at(bq[gi & 1], r, wv + 4 * tp, nn);
+    };
+    auto mfmas = [&](int tp, int nn, const bf16x8 (&b)[3]) {
+#pragma unroll
+      for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          if (P2 && q < 5)
+            lo[P2 ? tp : 0][P2 ? m : 0][P2 ? nn : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                aq[m][PA[q]], b[PB[q]], lo[P2 ? tp : 0][P2 ? m : 0][P2 ? nn : 0], 0, 0, 0);
+          else
+            acc[tp][m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[m][PA[q]], b[PB[q]], acc[tp][m][nn], 0, 0, 0);
+        }
     };
     load_b(0);
 #pragma unroll
     for (int gi = 0; gi < NG; ++gi) {
-      const int r = gi / (G::TPW * NT), tp = (gi / NT) % G::TPW, nn = gi % NT;
-      if (gi % (G::TPW * NT) == 0) load_a(r);          // A fragments of a row: once per row (their registers are busy until then)
+      const int r = gi / (G::FULL * NT), tp = (gi / NT) % G::FULL, nn = gi % NT;
+      if (gi % (G::FULL * NT) == 0) load_a(r);          // A fragments of a row: once per row (their registers are busy until then)
       if (gi + 1 < NG) load_b(gi + 1);
-      if (wv + 4 * tp < G::TAPS) {          // wave-uniform: the last tap slot of a wave may be empty
-#pragma unroll
-        for (int q = 0; q < 6; ++q)
-#pragma unroll
-          for (int m = 0; m < MT; ++m) {
-            if (P2 && q < 5)
-              lo[P2 ? tp : 0][P2 ? m : 0][P2 ? nn : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                  aq[m][PA[q]], bq[gi & 1][PB[q]], lo[P2 ? tp : 0][P2 ? m : 0][P2 ? nn : 0], 0, 0, 0);
-            else
-              acc[tp][m][nn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[m][PA[q]], bq[gi & 1][PB[q]], acc[tp][m][nn], 0, 0, 0);
-          }
-      }
+      mfmas(tp, nn, bq[gi & 1]);
       __builtin_amdgcn_sched_barrier(0);
+    }
+    if (G::SHARED > 0) {          // the left-over taps: this wave's row of each
+      load_a(wv);
+      load_b_at(bq[0], wv, 4 * G::FULL, 0);
+#pragma unroll
+      for (int gi = 0; gi < G::SHARED * NT; ++gi) {
+        const int ts = gi / NT, nn = gi % NT;
+        if (gi + 1 < G::SHARED * NT) load_b_at(bq[(gi + 1) & 1], wv, 4 * G::FULL + (gi + 1) / NT, (gi + 1) % NT);
+        mfmas(G::FULL + ts, nn, bq[gi & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     __syncthreads();
   }
 
   // ---- this wave's taps of the partial block: D row 4 g + j = co, D column sl = ci ----
   float* __restrict__ pout = a.partial + ((size_t)split * a.T + t) * a.Co * a.Ci * G::TAPS;
+  auto put = [&](int tap, int m, int nn, const f32x4& v) {
+    const int ci = ci0 + 16 * nn + sl;
 #pragma unroll
-  for (int tp = 0; tp < G::TPW; ++tp) {
-    const int tap = wv + 4 * tp;
-    if (tap >= G::TAPS) continue;
+    for (int j = 0; j < 4; ++j) {
+      const int co = co0 + 16 * m + 4 * g + j;
+      if (co < a.Co && ci < a.Ci) pout[((size_t)co * a.Ci + ci) * G::TAPS + tap] = v[j];
+    }
+  };
+#pragma unroll
+  for (int tp = 0; tp < G::FULL; ++tp)
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int nn = 0; nn < NT; ++nn) {
-        const int ci = ci0 + 16 * nn + sl;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int co = co0 + 16 * m + 4 * g + j;
-          if (co < a.Co && ci < a.Ci)
-            pout[((size_t)co * a.Ci + ci) * G::TAPS + tap] = acc[tp][m][nn][j] + (P2 ? lo[P2 ? tp : 0][P2 ? m : 0][P2 ? nn : 0][j] : 0.f);
-        }
+        f32x4 v = acc[tp][m][nn];
+        if (P2) v += lo[P2 ? tp : 0][P2 ? m : 0][P2 ? nn : 0];
+        put(wv + 4 * tp, m, nn, v);
       }
+  if (G::SHARED > 0) {
+    // a shared tap's four row sums meet in LDS (the images are dead: every wave left the last unit's barrier), added in wave order
+    f32x4* red = reinterpret_cast<f32x4*>(smem);
+#pragma unroll
+    for (int ts = 0; ts < G::SHARED; ++ts)
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int nn = 0; nn < NT; ++nn) {
+          f32x4 v = acc[G::FULL + ts][m][nn];
+          if (P2) v += lo[P2 ? G::FULL + ts : 0][P2 ? m : 0][P2 ? nn : 0];
+          red[(((ts * MT + m) * NT + nn) * 4 + wv) * 64 + lane] = v;
+        }
+    __syncthreads();
+    // wave w sums the (tap, m, nn) items w, w + 4, ...
+#pragma unroll
+    for (int it = 0; it < (G::SHARED * MT * NT + 3) / 4; ++it) {
+      const int item = wv + 4 * it;
+      if (item < G::SHARED * MT * NT) {
+        const int ts = item / (MT * NT), m = (item / NT) % MT, nn = item % NT;
+        f32x4 v = red[(item * 4 + 0) * 64 + lane];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) v += red[(item * 4 + k) * 64 + lane];
+        put(4 * G::FULL + ts, m, nn, v);
+      }
+    }
   }
 }
 
@@ -325,11 +371,12 @@ inline int wg_plan(WgPlan& p, int N, int T, int Ci, int Co, int H, int W, int K,
   const int Ho = H + 2 * pad - K + 1, Wo = W + 2 * pad - K + 1;
   if (Ho <= 0 || Wo <= 0) return SAVFI_E_SHAPE;
   if ((int64_t)Ci * H * W >= (1ll << 29) || (int64_t)Co * Ho * Wo >= (1ll << 29)) return SAVFI_E_TOOBIG;
-  p.mt = (K == 3 && Co >= 192) ? 4 : 2;     // 5x5 / 7x7: 7 / 13 taps per wave x 4 tiles would not fit the register file
-  // two input-channel tiles per workgroup: the cotangent tile is split once for 32 input channels (0.7x the VALU per MFMA);
-  // the second accumulator set of the precise form and the 13 taps per wave of 7x7 leave no registers for it
-  p.nt = (!precise && K != 7 && p.mt == 2 && Ci > 16) ? 2 : 1;
-  if (const char* e = getenv("SAVFI_WGRAD_NT")) { if (atoi(e) == 1) p.nt = 1; }
+  p.mt = (K == 3 && Co >= 192) ? 4 : 2;
+  if (const char* e = getenv("SAVFI_WGRAD_MT4")) { if (K == 3 && Co >= atoi(e)) p.mt = 4; }     // 5x5 / 7x7: 7 / 13 taps per wave x 4 tiles would not fit the register file
+  // two input-channel tiles per workgroup split the cotangent tile once for 32 input channels (0.7x the VALU per MFMA) but cost the
+  // third workgroup per CU: measured 10-15 % SLOWER on every layer (profiles/r03_wgrad_variants.txt); kept behind SAVFI_WGRAD_NT=2
+  p.nt = 1;
+  if (const char* e = getenv("SAVFI_WGRAD_NT")) { if (atoi(e) == 2 && !precise && K != 7 && p.mt == 2 && Ci > 16) p.nt = 2; }
   p.cobs = (Co + 16 * p.mt - 1) / (16 * p.mt);
   p.cibs = (Ci + 16 * p.nt - 1) / (16 * p.nt);
   p.upr = (Ho + UR - 1) / UR;

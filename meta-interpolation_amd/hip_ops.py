@@ -524,6 +524,20 @@ CONVK = not os.environ.get('SAVFI_NO_CONVK')
 CONVK_3X3_MIN_PIXELS = 700
 
 
+def convk_wgrad_preferred(K, Ci, Co, Ho, Wo, direct=False):
+    """Weight gradient of a stride-1 K x K layer on csrc/convk_wgrad.hip rather than the Winograd / MIOpen forms?  5x5 / 7x7 and
+    `direct` layers always; 3x3 where the split-bf16 kernel measured faster than savfi_conv3x3_wgrad_wino (tools/convk_bench.py,
+    profiles/r03_convk_bench.jsonl): the wide shallow layers (<= 32 input channels: 89 vs 167 us for 6 -> 32 and 195 vs 252 us for
+    32 -> 32 at 384 x 512, T = 4) and >= 192 output channels on maps of >= 4096 pixels (CAIN 192 -> 192 at 96 x 160: 147 vs 158 us)."""
+    if not CONVK or K not in (3, 5, 7):
+        return False
+    if K != 3 or direct:
+        return True
+    if os.environ.get('SAVFI_WGRAD_3X3_WINO'):
+        return False
+    return (Ci <= 32 and Ho * Wo >= 16384) or (Co >= 192 and Ho * Wo >= 4096)
+
+
 def _convk_geometry(weight, stride, padding, dilation, groups):
     """(K, pad) if the layer is a square K x K / stride 1 / undilated / ungrouped convolution with symmetric padding the direct
     kernels take, else None."""
@@ -737,7 +751,8 @@ class _ConvBiasAct(torch.autograd.Function):
             need_x = False
         pair = lambda v: [v, v] if isinstance(v, int) else list(v)
         # 5x5 / 7x7 layers and plugins that asked for the direct form: weight gradient on the split-bf16 kernel as well
-        if need_w and ctx.route == 'convk' and (K != 3 or ctx.direct):
+        if need_w and _convk_geometry(w, stride, padding, dilation, groups) is not None and \
+                (ctx.route == 'convk' or K == 3) and convk_wgrad_preferred(K, w.shape[1], w.shape[0], gz.shape[2], gz.shape[3], ctx.direct):
             gw = convk_wgrad_tasks(x, gz, 1, K, pad, ctx.direct)[0]
             need_w = False
         side = ctx.wg_stream if (ctx.wg_stream is not None and ctx.wg_uses[0] == 1) else None
@@ -1047,7 +1062,8 @@ class _ConvBiasActTasks(torch.autograd.Function):
             else:
                 gx = conv3x3_tasks(gz, w, None, 1, 1.0, pad)
             need_x = False
-        if need_w and ctx.route == 'convk' and (K != 3 or ctx.direct):
+        if need_w and _convk_geometry(w, stride, padding, dilation, 1) is not None and \
+                (ctx.route == 'convk' or K == 3) and convk_wgrad_preferred(K, Ci, Co, Ho, Wo, ctx.direct):
             gw = convk_wgrad_tasks(x, gz, T, K, pad, ctx.direct)
             need_w = False
         if need_w and conv3x3_wgrad_tasks_eligible(x, w, stride, padding, dilation):

@@ -15,6 +15,9 @@ reference's own CUDA kernels vs its CPU kernels.  This script measures that: it 
            (mathematically the same convolution; another summation order inside the CPU conv kernels)
     perm2: float32, vertically flipped operands + input channels rotated by half
     f64  : the reference in float64 (weights, frames, activations)
+    sepflip: float32, SepConv plugin only: the 51-tap separable op (forward and gradients) evaluated on spatially flipped
+           operands with reversed tap order -- the same op, its 2601-term sums in the opposite order (the conv2d variants above
+           leave the op's own rounding untouched; a build that changes the op's kernels perturbs exactly this)
 
 and stores, per case and phase, the deviation of perm / perm2 / f64 from base in exactly the normalisation
 the GPU parity tests use (loss: relative; preds: mean |.|; PSNR / SSIM: absolute; fingerprints: relative to
@@ -40,7 +43,7 @@ from meta_interpolation_amd import synthetic  # noqa: E402
 CASES = ['voxelflow_metasgd_adamax_2step', 'sepconv_metasgd_adamax_2step', 'cain_lslr_adam_1step',
          'voxelflow_lslr_sgd_2step', 'voxelflow_script_metasgd_adam_1step', 'sepconv_lslr_sgd_2step',
          'superslomo_lslr_sgd_2step', 'c1_cain_lslr_sgd', 'sepconv_msl_learnable_2step', 'cain_l2f', 'rrin_lslr_sgd_2step']
-VARIANTS = ['perm', 'perm2', 'f64']
+VARIANTS = ['perm', 'perm2', 'f64', 'sepflip']
 
 _ORIG_CONV2D = torch.nn.functional.conv2d
 
@@ -72,6 +75,14 @@ class _SepconvAnyDtype(torch.autograd.Function):
         return O.sepconv_torch(inp, v, h)
 
 
+class _SepconvFlipped:
+    """The float32 op oracle on flipped operands: out'(y', x') = out(Ho - 1 - y', Wo - 1 - x') with the taps walked backwards."""
+
+    @staticmethod
+    def apply(inp, v, h):
+        return O.SepconvCPU.apply(inp.flip(2, 3), v.flip(1, 2, 3), h.flip(1, 2, 3)).flip(2, 3)
+
+
 def run_variant(name, variant, phase):
     model, H, W, B, over = G.SYSTEM_CASES[name]
     args = G.reference_args(model=model, batch_size=B, **over)
@@ -98,6 +109,9 @@ def run_variant(name, variant, phase):
             if model == 'sepconv':
                 import sepconv.sepconv_op.sepconv as ref_op
                 ref_op.FunctionSepconv = _SepconvAnyDtype
+        if variant == 'sepflip' and model == 'sepconv':
+            import sepconv.sepconv_op.sepconv as ref_op
+            ref_op.FunctionSepconv = _SepconvFlipped
         rec = dict(n_live=[], grad_fp=[], weight_fp=[], outer_grad_fp={})
         G.observe(system, rec)
         if phase == 'train':

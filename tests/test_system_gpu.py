@@ -55,6 +55,13 @@ def tolerances(name, phase='train'):
         table = _SENS[key]                              # [variant, quantity]
         for q in tol:
             tol[q] = max(tol[q], K_SPREAD[q] * float(table[:, _SENS_COL[q]].max()))
+    # Learning-rate gradients of the SepConv plugin on 64 x 64 frames: its Conv4 / Conv5 / Deconv layers have 8 x 8 .. 2 x 2 maps there, one
+    # ReLU unit switching under another summation order moves such a layer's learning-rate gradient by ~1e-3, and the fingerprints take a
+    # few discrete values (1.3e-4 / 7e-4 / 1.2e-3 / 4.1e-3) that the SAME build hits in different processes -- with the round-2 kernels
+    # as with this round's more accurate ones (profiles/r03_lr_gradient_modes_sepconv64.txt).  The 1e-3 gate passed or failed by the
+    # draw; 5e-3 covers the observed modes.  Losses, predictions, weights and per-step gradients keep their gates.
+    if name.startswith('sepconv_') and phase == 'train':
+        tol['outer'] = max(tol['outer'], 5e-3)
     # (rounds 1-2 carried a 1e-2 override on Super SloMo's outer-gradient fingerprints: its 7x7 / 5x5 first stages ran on MIOpen's
     # implicit-GEMM kernels, 3.1e-3 off.  On the direct split-bf16 kernels they measure 6.3e-4 -- inside the common gate.)
     return tol
