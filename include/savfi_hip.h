@@ -56,7 +56,7 @@
 extern "C" {
 #endif
 
-#define SAVFI_ABI_VERSION 6
+#define SAVFI_ABI_VERSION 7
 
 #define SAVFI_OK            0
 #define SAVFI_E_NULL       (-1)  /* a required pointer is NULL                          */
@@ -269,6 +269,9 @@ int savfi_conv3x3_tasks_f32(const float* x, const float* w, const float* bias, f
  *                                  launches; 0 for most shapes, then it may be NULL) */
 int64_t savfi_conv3x3_filter_floats(int T, int Ci, int Co, int mode);
 int savfi_conv3x3_filters_f32(const float* w, float* u_fwd, float* u_bwd, int T, int Ci, int Co, void* stream);
+/* n layers in one launch per 56 (layer, mode) jobs; entry i is savfi_conv3x3_filters_f32(w[i], u_fwd[i], u_bwd[i], T[i], Ci[i], Co[i]). */
+int savfi_conv3x3_filters_multi_f32(const float* const* w, float* const* u_fwd, float* const* u_bwd, const int* T, const int* Ci,
+                                    const int* Co, int n, void* stream);
 int64_t savfi_conv3x3_tasks_pre_workspace_floats(int N, int T, int Ci, int Co, int H, int W, int pad, int mode);
 int savfi_conv3x3_tasks_pre_f32(const float* x, const float* u, const float* bias, float* out, float* workspace,
                                 int N, int T, int Ci, int Co, int H, int W, int pad, int mode, float slope, void* stream);
@@ -309,6 +312,12 @@ int savfi_conv3x3_wgrad_wino_tasks_f32(const float* x, const float* gz, float* g
  * ---------------------------------------------------------------------------------- */
 int64_t savfi_convk_filter_floats(int T, int Ci, int Co, int K, int mode);
 int savfi_convk_filters_f32(const float* w, float* p_fwd, float* p_bwd, int T, int Ci, int Co, int K, void* stream);
+/* The same for n layers in ONE launch per 56 (layer, mode) jobs: arrays of n pointers / shapes (host memory); entry i is
+ * savfi_convk_filters_f32(w[i], p_fwd[i], p_bwd[i], T[i], Ci[i], Co[i], K[i]).  A MAML inner step re-packs every layer's fast weights
+ * after every update (reference: nothing to pack -- F.conv2d reads the fast weight, model_utils.py:354-366); one launch per step
+ * instead of one per layer and pass. */
+int savfi_convk_filters_multi_f32(const float* const* w, float* const* p_fwd, float* const* p_bwd, const int* T, const int* Ci,
+                                  const int* Co, const int* K, int n, void* stream);
 int savfi_convk_tasks_pre_f32(const float* x, const float* packed, const float* bias, float* out, int N, int T, int Ci,
                               int Co, int H, int W, int K, int pad, int mode, float slope, int precise, void* stream);
 

@@ -16,7 +16,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_PKG_DIR), "include", "savfi_hip.h")
 
 RULE_SGD, RULE_ADAM, RULE_ADAMAX_LSLR, RULE_ADAMAX_MSGD = 0, 1, 2, 3
 LR_SCALAR, LR_ELEMENT = 0, 1
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _ERRORS = {-1: "SAVFI_E_NULL (a required pointer is NULL)",
            -2: "SAVFI_E_SHAPE (bad or inconsistent dimension)",
@@ -72,6 +72,8 @@ _PROTOTYPES = {
     "savfi_conv3x3_wgrad_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P],
     "savfi_convk_filter_floats": [c_int] * 5,
     "savfi_convk_filters_f32": [_P, _P, _P, c_int, c_int, c_int, c_int, _P],
+    "savfi_convk_filters_multi_f32": [_P, _P, _P, _P, _P, _P, _P, c_int, _P],
+    "savfi_conv3x3_filters_multi_f32": [_P, _P, _P, _P, _P, _P, c_int, _P],
     "savfi_convk_tasks_pre_f32": [_P, _P, _P, _P] + [c_int] * 9 + [c_float, c_int, _P],
     "savfi_convk_wgrad_workspace_floats": [c_int] * 8,
     "savfi_convk_wgrad_tasks_f32": [_P, _P, _P, _P] + [c_int] * 9 + [_P],

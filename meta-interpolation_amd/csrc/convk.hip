@@ -90,10 +90,10 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4& p1, u32x4& p2
 // 16*co16 .. +15; lane = 16 g + (co % 16) holds pair j = 4 s + g -> tap = j / QC, octet o = j % QC, channels 8 (c QC + o) + e.
 // mode 0 (forward):        value = w[t][co][ci][tap]                 (w is [T][Co][Ci][K][K]; the conv reduces over Ci)
 // mode 1 (data gradient):  value = w[t][ci'][co'][K*K-1-tap]         (the conv reduces over Co and produces Ci: co' = produced, ci' = reduced)
-__global__ __launch_bounds__(256) void convk_pack(const float* __restrict__ w, u32x4* __restrict__ out, int T, int cin, int cout,
-                                                  int ks, int qc, int C, int S, int co16s, int mode, long long total) {
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void convk_pack_one(const float* __restrict__ w, u32x4* __restrict__ out, int T, int cin, int cout,
+                                               int ks, int qc, int C, int S, int co16s, int mode, long long idx, long long total) {
   if (idx >= total) return;
+
   const int lane = (int)(idx & 63);
   long long frag = idx >> 6;
   const int s = (int)(frag % S); frag /= S;
@@ -117,6 +117,39 @@ __global__ __launch_bounds__(256) void convk_pack(const float* __restrict__ w, u
   split8(v, p1, p2, p3);
   u32x4* dst = out + ((idx >> 6) * 3) * 64 + lane;
   dst[0] = p1; dst[64] = p2; dst[128] = p3;
+}
+
+
+__global__ __launch_bounds__(256) void convk_pack(const float* __restrict__ w, u32x4* __restrict__ out, int T, int cin, int cout,
+                                                  int ks, int qc, int C, int S, int co16s, int mode, long long total) {
+  convk_pack_one(w, out, T, cin, cout, ks, qc, C, S, co16s, mode, (long long)blockIdx.x * 256 + threadIdx.x, total);
+}
+
+// The filters of MANY layers in one launch (a training step packs every layer's fast weights after each inner update: 270 launches
+// of ~9 us per SepConv meta-iteration, 760 per CAIN one).  Jobs ride in the kernel argument block; a workgroup finds its job by its
+// first block (binary search, as csrc/mt_update.hip).
+constexpr int CK_PACK_JOBS = 56;
+struct PackJob {
+  const float* w;
+  u32x4* out;
+  long long total;
+  int T, cin, cout, ks, qc, C, S, co16s, mode, first_block;
+};
+struct PackTable {
+  PackJob job[CK_PACK_JOBS];
+  int n;
+};
+static_assert(sizeof(PackTable) <= 4096 - 64, "kernel argument block must stay under 4 KiB");
+
+__global__ __launch_bounds__(256) void convk_pack_multi(const PackTable tb) {
+  int lo = 0, hi = tb.n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tb.job[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const PackJob& j = tb.job[lo];
+  convk_pack_one(j.w, j.out, j.T, j.cin, j.cout, j.ks, j.qc, j.C, j.S, j.co16s, j.mode,
+                 (long long)((int)blockIdx.x - j.first_block) * 256 + threadIdx.x, j.total);
 }
 
 // ---- convolution ---------------------------------------------------------------------------------------------------
@@ -449,6 +482,46 @@ extern "C" int savfi_convk_filters_f32(const float* w, float* p_fwd, float* p_bw
     if (rc != SAVFI_OK) return rc;
   }
   return SAVFI_OK;
+}
+
+extern "C" int savfi_convk_filters_multi_f32(const float* const* w, float* const* p_fwd, float* const* p_bwd, const int* T, const int* Ci,
+                                             const int* Co, const int* K, int n, void* stream) {
+  if (!w || !p_fwd || !p_bwd || !T || !Ci || !Co || !K) return SAVFI_E_NULL;
+  if (n <= 0) return SAVFI_E_SHAPE;
+  PackTable tb;
+  tb.n = 0;
+  int blocks = 0;
+  auto flush = [&]() {
+    if (tb.n == 0) return (int)SAVFI_OK;
+    hipLaunchKernelGGL(convk_pack_multi, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, tb);
+    tb.n = 0;
+    blocks = 0;
+    return savfi_launch_status();
+  };
+  for (int i = 0; i < n; ++i) {
+    if (!w[i] || (!p_fwd[i] && !p_bwd[i])) return SAVFI_E_NULL;
+    if (T[i] <= 0 || Ci[i] <= 0 || Co[i] <= 0) return SAVFI_E_SHAPE;
+    if (!ck_supported_k(K[i])) return SAVFI_E_UNSUPPORTED;
+    for (int mode = 0; mode < 2; ++mode) {
+      float* dst = mode == 0 ? p_fwd[i] : p_bwd[i];
+      if (!dst) continue;
+      const int cin = mode == 0 ? Ci[i] : Co[i], cout = mode == 0 ? Co[i] : Ci[i];
+      PackJob& j = tb.job[tb.n];
+      j.w = w[i]; j.out = reinterpret_cast<u32x4*>(dst);
+      j.T = T[i]; j.cin = cin; j.cout = cout; j.ks = K[i]; j.mode = mode;
+      j.qc = ck_qc(cin, K[i]); j.C = ck_chunks(cin, j.qc); j.S = ck_steps(K[i], j.qc); j.co16s = ck_round_up((cout + 15) / 16, 4);
+      j.total = (long long)j.T * j.co16s * j.C * j.S * 64;
+      j.first_block = blocks;
+      const long long nb = (j.total + 255) / 256;
+      if (nb > (1 << 24)) return SAVFI_E_TOOBIG;
+      blocks += (int)nb;
+      if (++tb.n == CK_PACK_JOBS) {
+        const int rc = flush();
+        if (rc != SAVFI_OK) return rc;
+      }
+    }
+  }
+  return flush();
 }
 
 extern "C" int savfi_convk_tasks_pre_f32(const float* x, const float* packed, const float* bias, float* out, int N, int T, int Ci,

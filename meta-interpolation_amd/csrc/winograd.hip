@@ -125,6 +125,32 @@ __global__ __launch_bounds__(256) void wino_filter_transform_dual(const float* _
   filter_transform_block(w, mode == 0 ? Uf : Ub, Co, Ci, mode == 0 ? Ci : Co, mode == 0 ? Co : Ci, KP, IP, mode, blockIdx.x, blockIdx.y);
 }
 
+
+// The transforms of MANY layers in one launch (see convk_pack_multi, csrc/convk.hip): job = (layer, mode); a workgroup's position
+// inside its job gives the (bx, by) of wino_filter_transform.
+constexpr int WINO_FT_JOBS = 56;
+struct FtJob {
+  const float* w;
+  float* U;
+  int Co, Ci, K, I, KP, IP, mode, nbx, first_block, pad_;
+};
+struct FtTable {
+  FtJob job[WINO_FT_JOBS];
+  int n;
+};
+static_assert(sizeof(FtTable) <= 4096 - 64, "kernel argument block must stay under 4 KiB");
+
+__global__ __launch_bounds__(256) void wino_filter_transform_multi(const FtTable tb) {
+  int lo = 0, hi = tb.n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tb.job[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const FtJob& j = tb.job[lo];
+  const int rel = (int)blockIdx.x - j.first_block;
+  filter_transform_block(j.w, j.U, j.Co, j.Ci, j.K, j.I, j.KP, j.IP, j.mode, rel % j.nbx, rel / j.nbx);
+}
+
 // ---- fused convolution -------------------------------------------------------------------------------------
 // x [N][K][H][W] -> out [N][I][Ho][Wo]; bias [I] or null; act: y = v > 0 ? v : slope * v (slope 1 = none)
 struct WinoArgs {
@@ -687,6 +713,45 @@ extern "C" int savfi_conv3x3_filters_f32(const float* w, float* u_fwd, float* u_
     hipLaunchKernelGGL(wino_filter_transform, dim3(KPb / 4, savfi_cdiv(IPb, 64) * T), dim3(256), 0, st, w, u_bwd, Co, Ci, Co, Ci, KPb, IPb, 1);
   }
   return savfi_launch_status();
+}
+
+extern "C" int savfi_conv3x3_filters_multi_f32(const float* const* w, float* const* u_fwd, float* const* u_bwd, const int* T,
+                                               const int* Ci, const int* Co, int n, void* stream) {
+  if (!w || !u_fwd || !u_bwd || !T || !Ci || !Co) return SAVFI_E_NULL;
+  if (n <= 0) return SAVFI_E_SHAPE;
+  FtTable tb;
+  tb.n = 0;
+  int blocks = 0;
+  auto flush = [&]() {
+    if (tb.n == 0) return (int)SAVFI_OK;
+    hipLaunchKernelGGL(wino_filter_transform_multi, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, tb);
+    tb.n = 0;
+    blocks = 0;
+    return savfi_launch_status();
+  };
+  for (int i = 0; i < n; ++i) {
+    if (!w[i] || (!u_fwd[i] && !u_bwd[i])) return SAVFI_E_NULL;
+    if (T[i] <= 0 || T[i] > 65535 || Ci[i] <= 0 || Co[i] <= 0) return SAVFI_E_SHAPE;
+    for (int mode = 0; mode < 2; ++mode) {
+      float* dst = mode == 0 ? u_fwd[i] : u_bwd[i];
+      if (!dst) continue;
+      FtJob& j = tb.job[tb.n];
+      j.w = w[i]; j.U = dst; j.Co = Co[i]; j.Ci = Ci[i]; j.mode = mode;
+      j.K = mode == 0 ? Ci[i] : Co[i];
+      j.I = mode == 0 ? Co[i] : Ci[i];
+      j.KP = round_up(j.K, 2 * CIB);
+      j.IP = round_up(j.I, COB);
+      j.nbx = j.KP / 4;
+      j.first_block = blocks;
+      j.pad_ = 0;
+      blocks += j.nbx * savfi_cdiv(j.IP, 64) * T[i];
+      if (++tb.n == WINO_FT_JOBS) {
+        const int rc = flush();
+        if (rc != SAVFI_OK) return rc;
+      }
+    }
+  }
+  return flush();
 }
 
 extern "C" int64_t savfi_conv3x3_tasks_pre_workspace_floats(int N, int T, int Ci, int Co, int H, int W, int pad, int mode) {

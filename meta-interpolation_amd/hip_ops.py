@@ -4,6 +4,7 @@ Every function here launches a hand-written gfx950 kernel through the C ABI (inc
 on torch's current stream.  Device tensors only -- there is no CPU or eager-PyTorch fallback.
 """
 import functools
+import ctypes
 import os
 import threading
 
@@ -316,7 +317,9 @@ def mt_update(rule, lr_mode, weights, grads, lrs, m=None, s=None, bc1=None, sqrt
     spec = dict(n=n, rule=rule, lr_mode=lr_mode, grads=[g.detach() for g in grads], m=m, s=s, bc1=bc1,
                 sqrt_bc2=sqrt_bc2, beta1=beta1, beta2=beta2, eps=eps)
     ws = [w if w.is_contiguous() else w.contiguous() for w in weights]
-    return list(_MtUpdate.apply(spec, *ws, *lrs))
+    outs = list(_MtUpdate.apply(spec, *ws, *lrs))
+    filters_after_update(outs)
+    return outs
 
 
 def mt_update_nograd(rule, lr_mode, weights, grads, lrs, m, s, bc1, sqrt_bc2, beta1, beta2, eps, want_coef):
@@ -325,6 +328,7 @@ def mt_update_nograd(rule, lr_mode, weights, grads, lrs, m, s, bc1, sqrt_bc2, be
     outs = [torch.empty_like(w) for w in weights]
     coefs = [torch.empty_like(w) for w in weights] if want_coef else None
     _launch_mt_update(rule, lr_mode, list(weights), list(grads), list(lrs), m, s, outs, coefs, bc1, sqrt_bc2, beta1, beta2, eps)
+    filters_after_update(outs)
     return outs, coefs
 
 
@@ -846,6 +850,104 @@ def conv3x3_tasks(x, weight, bias=None, mode=0, slope=1.0, pad=1):
     return out
 
 
+# --------------------------------------------------------------------------------------------
+# Filters of every layer in ONE launch per inner step.
+#
+# The fused kernels read a fast weight through a packed (convk) or Winograd-transformed (wino) copy, made per layer and pass: 270
+# launches of ~9 us in a SepConv meta-iteration, 760 in a CAIN one (profiles/r03_*_one_iteration.txt).  The fast weights of a step
+# are born together in mt_update: the first step records which of its outputs were packed, and how (the "plan" of that list of
+# shapes); from then on every update packs those outputs straight away with savfi_*_filters_multi_f32, and convk_filters /
+# conv3x3_filters find the result.  An entry keeps its weight tensor alive, so a data pointer cannot come back as another tensor
+# while the entry exists; the weight's version is part of the match.
+# --------------------------------------------------------------------------------------------
+PREPACK = not os.environ.get('SAVFI_NO_PREPACK')
+_pack_plans = {}        # tuple of the update's weight shapes -> {index: [kind, fwd, bwd]}
+_last_update = None     # (signature, {data_ptr: index}, outputs) of the newest update
+_prepacked = {}         # (kind, data_ptr) -> (weight, version, filters_fwd, filters_bwd)
+
+
+def _filter_shape(weight):
+    T, Co, Ci = (1,) + tuple(weight.shape[:2]) if weight.dim() == 4 else tuple(weight.shape[:3])
+    return int(T), int(Co), int(Ci), int(weight.shape[-1])
+
+
+def filters_after_update(outs):
+    """Called with the fast weights an update just produced: pack / transform the ones the plan of this list names."""
+    global _last_update
+    _prepacked.clear()
+    if not PREPACK or not outs or not outs[0].is_cuda:
+        _last_update = None
+        return
+    sig = tuple(tuple(o.shape) for o in outs)
+    _last_update = (sig, {o.data_ptr(): i for i, o in enumerate(outs)}, outs)
+    plan = _pack_plans.get(sig)
+    if not plan:
+        return
+    lib = _hip.lib()
+    dev = outs[0].device
+    for kind in ('convk', 'wino'):
+        jobs = [(i, e[1], e[2]) for i, e in sorted(plan.items()) if e[0] == kind]
+        if not jobs:
+            continue
+        sizes, total = [], 0
+        for i, f, b in jobs:
+            T, Co, Ci, K = _filter_shape(outs[i])
+            nf = nb = 0
+            if kind == 'convk':
+                nf = _workspace_floats("savfi_convk_filter_floats", T, Ci, Co, K, 0) if f else 0
+                nb = _workspace_floats("savfi_convk_filter_floats", T, Ci, Co, K, 1) if b else 0
+            else:
+                nf = _workspace_floats("savfi_conv3x3_filter_floats", T, Ci, Co, 0) if f else 0
+                nb = _workspace_floats("savfi_conv3x3_filter_floats", T, Ci, Co, 1) if b else 0
+            nf, nb = (nf + 63) // 64 * 64, (nb + 63) // 64 * 64          # 256-byte aligned slices
+            sizes.append((total, nf, total + nf, nb))
+            total += nf + nb
+        flat = torch.empty(total, dtype=torch.float32, device=dev)
+        n = len(jobs)
+        PA, IA = ctypes.c_void_p * n, ctypes.c_int * n
+        pw, pf, pb = PA(), PA(), PA()
+        aT, aCi, aCo, aK = IA(), IA(), IA(), IA()
+        made = []
+        for k, ((i, f, b), (of, nf, ob, nb)) in enumerate(zip(jobs, sizes)):
+            w = outs[i]
+            T, Co, Ci, K = _filter_shape(w)
+            tf = flat[of:of + nf] if nf else None
+            tb = flat[ob:ob + nb] if nb else None
+            pw[k], pf[k], pb[k] = w.data_ptr(), (tf.data_ptr() if nf else None), (tb.data_ptr() if nb else None)
+            aT[k], aCi[k], aCo[k], aK[k] = T, Ci, Co, K
+            made.append((w, tf, tb))
+        if kind == 'convk':
+            _hip.launch("convk_filters_multi", lambda: _hip.check(lib.savfi_convk_filters_multi_f32(
+                pw, pf, pb, aT, aCi, aCo, aK, n, _hip.current_stream()), "savfi_convk_filters_multi_f32"))
+        else:
+            _hip.launch("conv3x3_filters_multi", lambda: _hip.check(lib.savfi_conv3x3_filters_multi_f32(
+                pw, pf, pb, aT, aCi, aCo, n, _hip.current_stream()), "savfi_conv3x3_filters_multi_f32"))
+        for w, tf, tb in made:
+            _prepacked[(kind, w.data_ptr())] = (w, w._version, tf, tb)
+
+
+def _prepacked_filters(kind, weight, fwd, bwd):
+    hit = _prepacked.get((kind, weight.data_ptr())) if _prepacked else None
+    if hit is None or hit[1] != weight._version or hit[0].shape != weight.shape or (fwd and hit[2] is None) or (bwd and hit[3] is None):
+        return None
+    return (hit[2] if fwd else None), (hit[3] if bwd else None)
+
+
+def _note_filter_use(kind, weight, fwd, bwd):
+    """A layer made its own filters from `weight`: if that is an output of the newest update, the plan of that update learns it."""
+    if _last_update is None:
+        return
+    sig, index, _ = _last_update
+    i = index.get(weight.data_ptr())
+    if i is None or tuple(weight.shape) != sig[i]:
+        return
+    entry = _pack_plans.setdefault(sig, {}).get(i)
+    if entry is None:
+        _pack_plans[sig][i] = [kind, bool(fwd), bool(bwd)]
+    elif entry[0] == kind:
+        entry[1], entry[2] = entry[1] or bool(fwd), entry[2] or bool(bwd)
+
+
 def conv3x3_filters(weight, fwd=True, bwd=True):
     """savfi_conv3x3_filters_f32: the Winograd transforms of weight [T,Co,Ci,3,3] (or [Co,Ci,3,3]) for the forward pass and / or
     the data gradient, in ONE launch.  Returns (u_fwd, u_bwd); an entry is None when not asked for."""
@@ -853,6 +955,10 @@ def conv3x3_filters(weight, fwd=True, bwd=True):
     _hip.require_cuda(weight)
     T, Co, Ci = (1,) + tuple(weight.shape[:2]) if weight.dim() == 4 else tuple(weight.shape[:3])
     assert tuple(weight.shape[-2:]) == (3, 3) and (fwd or bwd), weight.shape
+    ready = _prepacked_filters('wino', weight, fwd, bwd)
+    if ready is not None:
+        return ready
+    _note_filter_use('wino', weight, fwd, bwd)
     lib = _hip.lib()
     us = [torch.empty(_workspace_floats("savfi_conv3x3_filter_floats", T, Ci, Co, mode), dtype=weight.dtype, device=weight.device) if want else None
           for mode, want in ((0, fwd), (1, bwd))]
@@ -889,6 +995,10 @@ def convk_filters(weight, fwd=True, bwd=True):
     T, Co, Ci = (1,) + tuple(weight.shape[:2]) if weight.dim() == 4 else tuple(weight.shape[:3])
     K = int(weight.shape[-1])
     assert weight.shape[-2] == K and (fwd or bwd), weight.shape
+    ready = _prepacked_filters('convk', weight, fwd, bwd)
+    if ready is not None:
+        return ready
+    _note_filter_use('convk', weight, fwd, bwd)
     lib = _hip.lib()
     ps = [torch.empty(_workspace_floats("savfi_convk_filter_floats", T, Ci, Co, K, mode), dtype=torch.float32, device=weight.device)
           if want else None for mode, want in ((0, fwd), (1, bwd))]
