@@ -38,19 +38,35 @@ __device__ __forceinline__ float scale_of(int in, int out, int align) {
 // sub-networks, whose 51-tap maps are only consumed on the un-padded frame area (sepconv/model.py).
 struct Win { int H, W, sy0, sx0, Hs, Ws, oy0, ox0, Hw, Ww, align; };
 
+// Forward, tiled (round 3): a workgroup owns 8 output rows x 128 output columns.  The <= 6 x 68 source pixels the tile reads are
+// staged in LDS with coalesced loads (2 per thread) and every output takes its four taps from there: the first version issued 16
+// global loads per thread (4 per output; L1 hits, but the address path was the limit: 2.0 TB/s on the 51-channel sub-network maps).
+// Same source indices, weights and order of operations per output: bit-identical results.
+constexpr int UFH = 8, UFW = 128, UFSR = UFH / 2 + 3, UFSC = UFW / 2 + 4;      // tile, staged source rows / columns
 __global__ __launch_bounds__(256) void upsample2x_fwd(const float* __restrict__ in, float* __restrict__ out, Win g) {
+  __shared__ float src[UFSR][UFSC];
   const int Ho = 2 * g.H, Wo = 2 * g.W;
-  // work items of one plane = (row, group of 4 consecutive outputs), numbered row-major: narrow maps (the 64-wide deep
-  // decoder layers) fill their workgroups as well as wide ones
-  const int per_row = (g.Ww + 3) >> 2;
-  const int item = blockIdx.x * 256 + threadIdx.x;
-  if (item >= per_row * g.Hw) return;
-  const int wy = item / per_row, wx = (item - wy * per_row) * 4;
+  const int tiles_x = (g.Ww + UFW - 1) / UFW;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int wy0 = ty * UFH, wx0 = tx * UFW;
+  const float sh = scale_of(g.H, Ho, g.align), sw = scale_of(g.W, Wo, g.align);
   const float* p = in + (size_t)blockIdx.y * g.Hs * g.Ws;
-  const Src sy = source(g.oy0 + wy, g.H, scale_of(g.H, Ho, g.align), g.align);
-  const float sw = scale_of(g.W, Wo, g.align);
-  const float* r0 = p + (size_t)(sy.i0 - g.sy0) * g.Ws - g.sx0;
-  const float* r1 = p + (size_t)(sy.i1 - g.sy0) * g.Ws - g.sx0;
+  // source rows / columns the tile touches (virtual coordinates), from its first and last output
+  const int last_y = min(wy0 + UFH, g.Hw) - 1, last_x = min(wx0 + UFW, g.Ww) - 1;
+  const int ry0 = source(g.oy0 + wy0, g.H, sh, g.align).i0, ry1 = source(g.oy0 + last_y, g.H, sh, g.align).i1;
+  const int rx0 = source(g.ox0 + wx0, g.W, sw, g.align).i0, rx1 = source(g.ox0 + last_x, g.W, sw, g.align).i1;
+  const int nr = ry1 - ry0 + 1, nc = rx1 - rx0 + 1;             // <= UFSR, <= UFSC (scale <= 0.5)
+  for (int i = threadIdx.x; i < nr * nc; i += 256) {
+    const int r = i / nc, c = i - r * nc;
+    src[r][c] = p[(size_t)(ry0 + r - g.sy0) * g.Ws + (rx0 + c - g.sx0)];
+  }
+  __syncthreads();
+  const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;        // 32 groups of 4 outputs per row, 8 rows
+  const int wy = wy0 + ly, wx = wx0 + 4 * lx;
+  if (wy >= g.Hw || wx >= g.Ww) return;
+  const Src sy = source(g.oy0 + wy, g.H, sh, g.align);
+  const float* r0 = &src[sy.i0 - ry0][0] - rx0;
+  const float* r1 = &src[sy.i1 - ry0][0] - rx0;
   float v[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -108,7 +124,12 @@ __global__ __launch_bounds__(256) void upsample2x_bwd(const float* __restrict__ 
 // rows can touch, into LDS; pass 2 folds y from LDS.  Same candidates, same weights, same order of the two nested sums as
 // upsample2x_bwd (bit-identical results), but 15 global loads per source pixel instead of 36 and the x weights once per thread.
 constexpr int UBH = 8, UBW = 64, UBR = 2 * UBH + 4;     // tile rows / cols, output rows a tile can touch
+constexpr int UBC = 2 * UBW + 4;                        // output columns a tile can touch (2 ix - 2 .. 2 ix + 3)
 __global__ __launch_bounds__(256) void upsample2x_bwd_tiled(const float* __restrict__ gout, float* __restrict__ gin, Win g) {
+  // round 3: the output-gradient tile itself is staged first (coalesced, each element once: 10.6 loads per thread where the x
+  // pass read 30 scattered ones per thread from global / L1); both passes then run out of LDS with the same candidates, weights
+  // and order of sums as before (bit-identical).
+  __shared__ float gt[UBR][UBC + 1];
   __shared__ float tmp[UBR][UBW];
   const int Ho = 2 * g.H, Wo = 2 * g.W;
   const int tiles_x = (g.Ws + UBW - 1) / UBW;
@@ -116,9 +137,18 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_tiled(const float* __restr
   const int lx = threadIdx.x & (UBW - 1), rg = threadIdx.x >> 6;          // column in the tile, row group (0..3)
   const int cx = tx * UBW + lx, cy0 = ty * UBH;
   const int ix = g.sx0 + min(cx, g.Ws - 1), iy0 = g.sy0 + cy0;            // virtual source coordinates
+  const int ix_first = g.sx0 + tx * UBW, ix_last = g.sx0 + min(tx * UBW + UBW, g.Ws) - 1;
   const float* gp = gout + (size_t)blockIdx.y * g.Hw * g.Ww;
   const float sh = scale_of(g.H, Ho, g.align), sw = scale_of(g.W, Wo, g.align);
   constexpr int NC = 6;
+  // output rows / columns this tile's source pixels can touch, clipped to the window
+  const int row_lo = max(g.oy0, 2 * iy0 - 2), row_hi = min(g.oy0 + g.Hw - 1, 2 * (iy0 + UBH - 1) + 3);
+  const int col_lo = max(g.ox0, 2 * ix_first - 2), col_hi = min(g.ox0 + g.Ww - 1, 2 * ix_last + 3);
+  const int ncol = col_hi - col_lo + 1, nrow = row_hi - row_lo + 1;
+  for (int i = threadIdx.x; i < nrow * ncol; i += 256) {
+    const int r = i / ncol, c = i - r * ncol;
+    gt[r][c] = gp[(size_t)(row_lo + r - g.oy0) * g.Ww + (col_lo + c - g.ox0)];
+  }
   const int ox_lo = max(g.ox0, 2 * ix - 2), ox_hi = min(g.ox0 + g.Ww - 1, 2 * ix + 3);
   float wxs[NC];
 #pragma unroll
@@ -131,10 +161,9 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_tiled(const float* __restr
     }
     wxs[k] = w;
   }
-  // output rows this tile's source rows can touch: [2 iy0 - 2, 2 (iy0 + UBH - 1) + 3], clipped to the window
-  const int row_lo = max(g.oy0, 2 * iy0 - 2), row_hi = min(g.oy0 + g.Hw - 1, 2 * (iy0 + UBH - 1) + 3);
+  __syncthreads();
   for (int r = row_lo + rg; r <= row_hi; r += 4) {
-    const float* row = gp + (size_t)(r - g.oy0) * g.Ww - g.ox0;
+    const float* row = &gt[r - row_lo][0] - col_lo;
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < NC; ++k)
@@ -192,7 +221,7 @@ extern "C" int savfi_upsample2x_window_fwd_f32(const float* in, float* out, int 
   if (!in || !out) return SAVFI_E_NULL;
   const Win g{H, W, sy0, sx0, Hs, Ws, oy0, ox0, Hw, Ww, align_corners ? 1 : 0};
   if (int rc = check_window(g, planes)) return rc;
-  dim3 grid(savfi_cdiv((int64_t)Hw * savfi_cdiv(Ww, 4), 256), planes, 1);
+  dim3 grid(savfi_cdiv(Hw, UFH) * savfi_cdiv(Ww, UFW), planes, 1);
   hipLaunchKernelGGL(upsample2x_fwd, grid, dim3(256), 0, (hipStream_t)stream, in, out, g);
   return savfi_launch_status();
 }
