@@ -50,3 +50,5 @@ __device__ __forceinline__ float block_sum(float x, float* lds /* >= NW floats *
 // savfi_sepconv_bwd_f32)
 int savfi_sepconv_bwd_x6_launch(const float* in, const float* v, const float* h, const float* gO, float* gV, float* gH, int B, int Ho,
                                 int Wo, int cus, hipStream_t st);
+int savfi_sepconv_fwd_x6_launch(const float* in, const float* v, const float* h, float* out, int B, int Ho, int Wo, int cus,
+                                hipStream_t st);

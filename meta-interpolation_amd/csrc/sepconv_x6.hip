@@ -487,6 +487,227 @@ __global__ __launch_bounds__(XNT) void sepconv_bwd_x6(const float* __restrict__ 
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Forward on the same machinery:  out[b,c,y,x] = sum_fy v[b,fy,y,x] * T_c[fy],   T_c[fy][j] = sum_i In_c[y + fy][16 wc + i] * Hb[i][j]
+// T is the gV product above without the cotangent (144 MFMAs per 16 pixels; the fp32-MFMA forward issues 170 of twice the
+// cycles), its tail columns i = 64, 65 per channel, and the vertical pass runs on the accumulators: lane (j, kg) holds rows
+// fy = 16 m + 4 kg + r of T and loads v for exactly those rows; the four row groups of a pixel meet through two lane exchanges.
+// Replaces the reference's forward kernel (sepconv/sepconv_op/sepconv.py:5-30) -- same op, same layout.
+// ------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(XNT) void sepconv_fwd_x6(const float* __restrict__ in, const float* __restrict__ v,
+                                                      const float* __restrict__ h, float* __restrict__ out,
+                                                      int B, int Ho, int Wo, int nph, int ncol, int per_wg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = w & 1, wr = w >> 1;
+  const int j = lane & 15, kg = lane >> 4;
+  char* const tab = smem + XWINB + w * XTAB;
+  float* const side = reinterpret_cast<float*>(smem + XSIDE_OFF);
+
+  const int total = B * ncol * nph;
+  const int g0 = blockIdx.x * per_wg, g1 = min(g0 + per_wg, total);
+  if (g0 >= g1) return;
+  const int Hi = Ho + XK - 1, Wi = Wo + XK - 1;
+  const unsigned plane_b = (unsigned)Ho * (unsigned)Wo * 4u;
+  const __amdgpu_buffer_rsrc_t hsrc = x6_rsrc(h, (unsigned)(B * XK) * plane_b);
+  const __amdgpu_buffer_rsrc_t vsrc = x6_rsrc(v, (unsigned)(B * XK) * plane_b);
+  const __amdgpu_buffer_rsrc_t isrc = x6_rsrc(in, (unsigned)(B * XC) * (unsigned)(Hi * Wi) * 4u);
+  const __amdgpu_buffer_rsrc_t odst = x6_rsrc(out, (unsigned)(B * XC) * plane_b);
+
+  auto pos_of = [&](int g, int& b, int& x0, int& ph) {
+    const int s = g / nph;
+    ph = g - s * nph;
+    b = s / ncol;
+    x0 = (s - b * ncol) * XMC;
+  };
+  auto pix_off = [&](int b, int x0, int y, int ch) {
+    return (unsigned)b * (unsigned)ch * plane_b + (unsigned)(min(y, Ho - 1) * Wo + min(x0 + 16 * wc + j, Wo - 1)) * 4u;
+  };
+  const int h_t0 = 2 * kg - (j & 1);
+  auto load_h = [&](float (&regs)[XNP][2], int b, int x0, int y) {          // the pair layout of the backward's h taps
+    const unsigned pix = pix_off(b, x0, y, XK);
+    const unsigned voff = pix + (unsigned)(h_t0 + 1) * plane_b;
+    regs[0][0] = x6_bload(hsrc, pix + (unsigned)max(h_t0, 0) * plane_b, 0u);
+    regs[0][1] = x6_bload(hsrc, voff, 0u);
+#pragma unroll
+    for (int a = 1; a < XNP - 1; ++a)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) regs[a][e] = x6_bload(hsrc, voff, (unsigned)(8 * a + e - 1) * plane_b);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) regs[XNP - 1][e] = x6_bload(hsrc, pix + (unsigned)min(8 * (XNP - 1) + h_t0 + e, XK - 1) * plane_b, 0u);
+  };
+  auto h_or_zero = [&](const float (&regs)[XNP][2], int a, int e) {
+    if (a == 0 && e == 0) return h_t0 < 0 ? 0.f : regs[0][0];
+    if (a == XNP - 1) return (8 * (XNP - 1) + h_t0 + e < XK) ? regs[a][e] : 0.f;
+    return regs[a][e];
+  };
+  auto write_h_table = [&](const float (&regs)[XNP][2]) {
+#pragma unroll
+    for (int k = 0; k < XTAB / 1024; ++k) *reinterpret_cast<u32x4*>(tab + (k * 64 + lane) * 16) = (u32x4){0u, 0u, 0u, 0u};
+    const int base2 = 2 * kg + (j & ~1);
+    char* const lb = tab + (base2 >> 3) * 256 + j * 16 + (base2 & 7) * 2;
+#pragma unroll
+    for (int a = 0; a < XNP; ++a) {
+      unsigned h1, h2, h3;
+      x6_split2(h_or_zero(regs, a, 0), h_or_zero(regs, a, 1), h1, h2, h3);
+      char* d = lb + a * 256;
+      if (a < XNP - 1 || base2 < 16) {
+        *reinterpret_cast<unsigned*>(d) = h1;
+        *reinterpret_cast<unsigned*>(d + XTABP) = h2;
+        *reinterpret_cast<unsigned*>(d + 2 * XTABP) = h3;
+      }
+    }
+  };
+  // v in the accumulator layout: vD[m][r] = v[j][16 m + 4 kg + r] (rows >= 51 of the last tile: clamped plane, zeroed at use)
+  auto load_v = [&](float (&regs)[4][4], int b, int x0, int y) {
+    const unsigned pix = pix_off(b, x0, y, XK);
+    const unsigned voff = pix + (unsigned)(4 * kg) * plane_b;
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) regs[m][r] = x6_bload(vsrc, voff, (unsigned)(16 * m + r) * plane_b);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) regs[3][r] = x6_bload(vsrc, pix + (unsigned)min(48 + 4 * kg + r, XK - 1) * plane_b, 0u);
+  };
+
+  int b, x0, ph;
+  pos_of(g0, b, x0, ph);
+  float hreg[XNP][2], vD[4][4];
+  load_h(hreg, b, x0, XPR * ph + wr);
+  load_v(vD, b, x0, XPR * ph + wr);
+#pragma unroll 1
+  for (int r = 0; r < XWIN; r += 16) {
+    X6Rows<16> sr;
+    x6_rows_load<16>(sr, isrc, b, x0, XPR * ph + r, Hi, Wi, tid);
+    x6_rows_write<16>(sr, smem, XPR * ph + r, tid);
+  }
+  int loaded_hi = XPR * ph + XWIN;
+  write_h_table(hreg);
+  __syncthreads();
+  if (w >= 4) __builtin_amdgcn_s_sleep(40);
+
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+  const int permk = ((kg & 1) << 1) | (kg >> 1);
+  float* const tailb = reinterpret_cast<float*>(tab);                  // [c][fy][2] in the wave's table once its fragments are in registers
+
+#pragma unroll 1
+  for (int g = g0; g < g1; ++g) {
+    if (g != g0 && ph == 0) {
+      __syncthreads();
+#pragma unroll 1
+      for (int r = 0; r < XWIN; r += 16) {
+        X6Rows<16> sr;
+        x6_rows_load<16>(sr, isrc, b, x0, r, Hi, Wi, tid);
+        x6_rows_write<16>(sr, smem, r, tid);
+      }
+      loaded_hi = XWIN;
+      __syncthreads();
+    }
+    int nb, nx0, nph_;
+    pos_of(min(g + 1, g1 - 1), nb, nx0, nph_);
+    const bool slide = (g + 1 < g1) && nph_ != 0 && (XPR * nph_ + XPR + XK - 1 > loaded_hi);
+    X6Rows<XAHEAD> slid;
+    if (slide) x6_rows_load<XAHEAD>(slid, isrc, b, x0, loaded_hi, Hi, Wi, tid);
+
+    const int y = XPR * ph + wr;
+    const int x = x0 + 16 * wc + j;
+    const bool pvalid = (x < Wo) && (y < Ho);
+    const float h50_14 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hreg[6][0]), 14 + 16));
+    const float h49_15 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hreg[6][0]), 15 + 16));
+    const float h50_15 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hreg[6][1]), 15 + 16));
+    float vcur[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) vcur[m][r] = (m < 3 || (kg == 0 && r < 3)) ? vD[m][r] : 0.f;
+
+    bf16x8 bq[2][3];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bq[s][p] = *reinterpret_cast<const bf16x8*>(tab + p * XTABP + (4 * s + permk) * 256 + j * 16);
+    load_h(hreg, nb, nx0, XPR * nph_ + wr);
+    load_v(vD, nb, nx0, XPR * nph_ + wr);
+    X6_ORDER();
+    {   // tail columns per channel: lane = tap row fy
+      const int fyl = min(lane, XK - 1);
+      const int tslot = (y + fyl) & (XWIN - 1);
+#pragma unroll
+      for (int c = 0; c < XC; ++c) {
+        const f32x2 sv = *reinterpret_cast<const f32x2*>(side + (c * XWIN + tslot) * 4 + 2 * wc);
+        *reinterpret_cast<f32x2*>(tailb + (c * XK + fyl) * 2) = (f32x2){sv.x * h50_14, fmaf(sv.y, h50_15, sv.x * h49_15)};
+      }
+    }
+    X6_ORDER();
+
+    f32x4 acc[XC][4];
+#pragma unroll
+    for (int c = 0; c < XC; ++c)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) acc[c][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int rowoff[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) rowoff[m] = ((y + min(16 * m + j, XK - 1)) & (XWIN - 1)) * 16 + (2 * wc + permk) * XBLK;
+    bf16x8 aq[2][2][3];
+    auto load_a = [&](int slot, int u) {
+      const int c = u >> 2, s = (u >> 1) & 1, mp = u & 1;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+          aq[slot][t][p] = *reinterpret_cast<const bf16x8*>(smem + (p * 3 + c) * XPLANE + 4 * s * XBLK + rowoff[2 * mp + t]);
+    };
+    __builtin_amdgcn_sched_barrier(0);
+    load_a(0, 0);
+#pragma unroll
+    for (int u = 0; u < 12; ++u) {
+      if (u + 1 < 12) load_a((u + 1) & 1, u + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      const int c = u >> 2, s = (u >> 1) & 1, mp = u & 1;
+#pragma unroll
+      for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          acc[c][2 * mp + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[u & 1][t][PA[q]], bq[s][PB[q]], acc[c][2 * mp + t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // vertical pass: this lane's 16 rows of T (+ the tail columns for pixels 14, 15), then the four row groups of the pixel
+    const float tsel = j >= 14 ? 1.f : 0.f;
+    const int tcol = j == 15 ? 1 : 0;
+    float o[XC];
+#pragma unroll
+    for (int c = 0; c < XC; ++c) {
+      float sum = 0.f;
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float t = fmaf(tsel, tailb[(c * XK + min(16 * m + 4 * kg + r, XK - 1)) * 2 + tcol], acc[c][m][r]);
+          sum = fmaf(vcur[m][r], t, sum);
+        }
+      sum += __shfl_xor(sum, 16, SAVFI_WAVE);
+      sum += __shfl_xor(sum, 32, SAVFI_WAVE);
+      o[c] = sum;
+    }
+    {   // lane group kg stores channel kg
+      const float val = kg == 0 ? o[0] : kg == 1 ? o[1] : o[2];
+      const unsigned oo = (unsigned)b * (unsigned)XC * plane_b + (unsigned)(min(y, Ho - 1) * Wo + min(x, Wo - 1)) * 4u + (unsigned)kg * plane_b;
+      x6_bstore(val, odst, (pvalid && kg < XC) ? oo : X_OOR, 0u);
+    }
+    X6_ORDER();
+    write_h_table(hreg);
+    X6_ORDER();
+    if (slide) {
+      __syncthreads();
+      x6_rows_write<XAHEAD>(slid, smem, loaded_hi, tid);
+      loaded_hi += XAHEAD;
+      __syncthreads();
+    }
+    b = nb; x0 = nx0; ph = nph_;
+  }
+}
+
 }  // namespace
 
 // gV and gH of the K = 51, C = 3 op; every tensor below 2^31 bytes (the caller checks).  Declared in csrc/common.h.
@@ -499,5 +720,18 @@ int savfi_sepconv_bwd_x6_launch(const float* in, const float* v, const float* h,
   const int per_wg = savfi_cdiv(total, cus);
   const int grid = savfi_cdiv(total, per_wg);
   hipLaunchKernelGGL(sepconv_bwd_x6, dim3(grid), dim3(XNT), XLDS, st, in, v, h, gO, gV, gH, B, Ho, Wo, nph, ncol, per_wg);
+  return savfi_launch_status();
+}
+
+// forward of the same op (declared in csrc/common.h)
+int savfi_sepconv_fwd_x6_launch(const float* in, const float* v, const float* h, float* out, int B, int Ho, int Wo, int cus,
+                                hipStream_t st) {
+  static uint32_t done = 0;
+  if (int e = savfi_ensure_dynamic_lds((const void*)sepconv_fwd_x6, XLDS, done)) return e;
+  const int nph = savfi_cdiv(Ho, XPR), ncol = savfi_cdiv(Wo, XMC);
+  const int64_t total = (int64_t)B * ncol * nph;
+  const int per_wg = savfi_cdiv(total, cus);
+  const int grid = savfi_cdiv(total, per_wg);
+  hipLaunchKernelGGL(sepconv_fwd_x6, dim3(grid), dim3(XNT), XLDS, st, in, v, h, out, B, Ho, Wo, nph, ncol, per_wg);
   return savfi_launch_status();
 }
