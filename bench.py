@@ -322,7 +322,7 @@ def main():
                     "algorithmic_bytes_per_launch": k["algorithmic_bytes"] / k["launches"],
                     "note": "algorithmic bytes = %.2f MB per [1,3,%d,%d] sample (x samples per launch: tasks in lockstep x the "
                             "support pair); 288 bf16 MFMAs per 16 pixels = 29%% of the launch at full matrix rate, the rest is per-phase tap staging, "
-                            "stores and window barriers with 8 waves per CU (DESIGN.md 4b)"
+                            "stores and window barriers with 8 waves per CU (DESIGN.md 4e)"
                             % (per_call / 1e6, oh, ow)}
             elif summ:
                 # workloads without the 51-tap op: the HBM-bound savfi kernel that takes the most time in the timed region
