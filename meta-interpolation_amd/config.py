@@ -48,7 +48,7 @@ _FLAGS = {
     ],
     'MI355X': [
         ('fuse_support_pairs', int, 1), ('fuse_conv_act', int, 1), ('graph_inner_loop', int, -1), ('sepconv_window', int, 1),
-        ('task_streams', int, -1), ('wgrad_overlap', int, 0), ('task_batch', int, 8),
+        ('task_streams', int, -1), ('wgrad_overlap', int, 0), ('task_batch', int, 8), ('lazy_logging', int, 1),
         ('synthetic', 'flag', False),
     ],
 }

@@ -104,6 +104,60 @@ class _DeferredMeters:
         return meters
 
 
+class _LazyLog(dict):
+    """The dict run_train_iter returns (`losses`, `metrics`): what needs the device to have finished -- logged losses, PSNR / SSIM
+    meters, the importance vector -- is fetched on the FIRST READ instead of before returning.  A caller that logs every
+    iteration (ExperimentBuilder, the reference's loop) syncs exactly where it did; one that does not read (a timing loop)
+    lets the host run on into the next iteration while the device finishes this one -- the one host sync per iteration was a
+    1-5 ms bubble at every iteration boundary (profiles/r03_*_one_iteration.txt: the largest gap of each trace)."""
+
+    def __init__(self, data, ensure):
+        super().__init__(data)
+        self._data, self._ensure = data, ensure
+
+    def _ready(self):
+        ensure, self._ensure = self._ensure, None
+        if ensure is not None:
+            ensure()
+            dict.update(self, self._data)
+
+    def __getitem__(self, k):
+        self._ready()
+        return dict.__getitem__(self, k)
+
+    def get(self, k, default=None):
+        self._ready()
+        return dict.get(self, k, default)
+
+    def __contains__(self, k):
+        self._ready()
+        return dict.__contains__(self, k)
+
+    def __iter__(self):
+        self._ready()
+        return dict.__iter__(self)
+
+    def __len__(self):
+        self._ready()
+        return dict.__len__(self)
+
+    def keys(self):
+        self._ready()
+        return dict.keys(self)
+
+    def values(self):
+        self._ready()
+        return dict.values(self)
+
+    def items(self):
+        self._ready()
+        return dict.items(self)
+
+    def __repr__(self):
+        self._ready()
+        return dict.__repr__(self)
+
+
 class SceneAdaptiveInterpolation(nn.Module):
     MAX_GRAPH_SETS = 8
 
@@ -652,6 +706,8 @@ class SceneAdaptiveInterpolation(nn.Module):
         """Everything that is logged needs the device to have finished the forward passes.  During training that host sync
         is postponed until the outer backward and the optimizer step are queued (run_train_iter): waiting here would
         drain the queue and the backward would start with the host a whole launch queue behind the GPU."""
+        if self._defer_logging:
+            importance = importance.detach().clone()      # read later: not the live (learnable) vector an outer step may move
         finish = functools.partial(self._finish_logging, losses, metrics, deferred, eval_mse, eval_ssim, importance,
                                    training_phase)
         if self._defer_logging:
@@ -850,7 +906,16 @@ class SceneAdaptiveInterpolation(nn.Module):
             self._defer_logging = False
             finish, self._pending_logging = self._pending_logging, None
         if finish is not None:
-            finish()
+            if self.task_parallel.active or not getattr(self.args, 'lazy_logging', 1) or os.environ.get('SAVFI_EAGER_LOGGING'):
+                finish()          # the logging all-reduce is a collective: every rank issues it here, in program order
+            else:
+                state = {'finish': finish}
+
+                def ensure():
+                    f = state.pop('finish', None)
+                    if f is not None:
+                        f()
+                losses, metrics = _LazyLog(losses, ensure), _LazyLog(metrics, ensure)
         return losses, preds, metrics
 
     def run_validation_iter(self, data_batch):
