@@ -56,7 +56,7 @@
 extern "C" {
 #endif
 
-#define SAVFI_ABI_VERSION 7
+#define SAVFI_ABI_VERSION 8
 
 #define SAVFI_OK            0
 #define SAVFI_E_NULL       (-1)  /* a required pointer is NULL                          */
@@ -320,6 +320,15 @@ int savfi_convk_filters_multi_f32(const float* const* w, float* const* p_fwd, fl
                                   const int* Co, const int* K, int n, void* stream);
 int savfi_convk_tasks_pre_f32(const float* x, const float* packed, const float* bias, float* out, int N, int T, int Ci,
                               int Co, int H, int W, int K, int pad, int mode, float slope, int precise, void* stream);
+/* `reflect` != 0 (mode 0 only, pad < H, W): the border of width `pad` mirrors the image instead of reading zeros, i.e.
+ * conv2d(nn.ReflectionPad2d(pad)(x), w) without the padded copy -- CAIN's MetaConvNorm (reference model_utils.py:821-848).  Its data
+ * gradient is savfi_convk_tasks_pre_f32(mode 1, pad 0) on gy (the gradient of the padded extent) folded by
+ * savfi_reflect_pad_bwd_f32; its weight gradient savfi_convk_wgrad_tasks_reflect_f32. */
+int savfi_convk_tasks_pre_reflect_f32(const float* x, const float* packed, const float* bias, float* out, int N, int T, int Ci,
+                                      int Co, int H, int W, int K, int pad, int mode, float slope, int precise, int reflect,
+                                      void* stream);
+/* gx[planes,H,W] = adjoint of nn.ReflectionPad2d(pad) applied to gp[planes,H+2pad,W+2pad] (gather: deterministic, no zero fill) */
+int savfi_reflect_pad_bwd_f32(const float* gp, float* gx, int planes, int H, int W, int pad, void* stream);
 
 /* Weight gradient of the same convolution (same arithmetic; deterministic: per-workgroup partial blocks added in a fixed order):
  *   gw[T,Co,Ci,K,K], gw[t] = sum over samples n with n % T == t, y, x of gz[n,co,y,x] * x[n,ci,y+ky-pad,x+kx-pad]
@@ -327,6 +336,9 @@ int savfi_convk_tasks_pre_f32(const float* x, const float* packed, const float* 
 int64_t savfi_convk_wgrad_workspace_floats(int N, int T, int Ci, int Co, int H, int W, int K, int pad);
 int savfi_convk_wgrad_tasks_f32(const float* x, const float* gz, float* gw, float* workspace, int N, int T, int Ci, int Co,
                                 int H, int W, int K, int pad, int precise, void* stream);
+/* the same with x's border of width `pad` mirrored (see savfi_convk_tasks_pre_reflect_f32) */
+int savfi_convk_wgrad_tasks_reflect_f32(const float* x, const float* gz, float* gw, float* workspace, int N, int T, int Ci, int Co,
+                                        int H, int W, int K, int pad, int precise, int reflect, void* stream);
 
 /* ----------------------------------------------------------------------------------
  * Channel attention + residual of CAIN's RCAB (model_utils.py:931-953 MetaCALayer, :957-990 MetaRCAB):

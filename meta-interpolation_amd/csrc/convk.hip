@@ -161,6 +161,7 @@ struct ConvkArgs {
   int N, T, cin, cout, H, W, Ho, Wo, pad;
   int tiles_x, tiles_y, CB, CBnt, C, co16s;     // CB: workgroup-level channel blocks, CBnt: blocks of 16*NT channels
   int total, per_xcd, order, cg;
+  int reflect;         // 1: the border of width `pad` mirrors the image (nn.ReflectionPad2d) instead of reading zeros
   float slope;
 };
 
@@ -226,7 +227,11 @@ __global__ __launch_bounds__(CK_THREADS * CG, 2) void convk_kernel(const ConvkAr
     const int item = tid + THREADS * k;
     const int o = item / G::POS, pos = item - o * G::POS;
     const int r = pos / G::COLS, c = pos - r * G::COLS;
-    const int iy = y0 - a.pad + r, ix = x0 - a.pad + c;
+    int iy = y0 - a.pad + r, ix = x0 - a.pad + c;
+    if (a.reflect) {      // mirrored border (pad <= H - 1, W - 1, host-checked); positions past the mirrored band feed no stored output
+      iy = iy < 0 ? -iy : (iy >= a.H ? 2 * a.H - 2 - iy : iy);
+      ix = ix < 0 ? -ix : (ix >= a.W ? 2 * a.W - 2 - ix : ix);
+    }
     const bool ok = item < G::ITEMS && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
     s_voff[k] = ok ? (o * 8 * (int)plane_in + iy * a.W + ix) * 4 : 0x7fffffff;
     s_oct[k] = o;
@@ -526,6 +531,13 @@ extern "C" int savfi_convk_filters_multi_f32(const float* const* w, float* const
 
 extern "C" int savfi_convk_tasks_pre_f32(const float* x, const float* packed, const float* bias, float* out, int N, int T, int Ci,
                                          int Co, int H, int W, int K, int pad, int mode, float slope, int precise, void* stream) {
+  return savfi_convk_tasks_pre_reflect_f32(x, packed, bias, out, N, T, Ci, Co, H, W, K, pad, mode, slope, precise, 0, stream);
+}
+
+extern "C" int savfi_convk_tasks_pre_reflect_f32(const float* x, const float* packed, const float* bias, float* out, int N, int T, int Ci,
+                                                 int Co, int H, int W, int K, int pad, int mode, float slope, int precise, int reflect,
+                                                 void* stream) {
+  if (reflect && (mode != 0 || pad >= H || pad >= W)) return SAVFI_E_UNSUPPORTED;
   if (!x || !packed || !out) return SAVFI_E_NULL;
   if (N <= 0 || T <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0 || N % T != 0 || pad < 0 || pad > K - 1) return SAVFI_E_SHAPE;
   if (!ck_supported_k(K) || (mode != 0 && mode != 1)) return SAVFI_E_UNSUPPORTED;
@@ -538,6 +550,7 @@ extern "C" int savfi_convk_tasks_pre_f32(const float* x, const float* packed, co
   if (a.Ho <= 0 || a.Wo <= 0) return SAVFI_E_SHAPE;
   if ((int64_t)a.cin * H * W >= (1ll << 29) || (int64_t)a.cout * a.Ho * a.Wo >= (1ll << 31)) return SAVFI_E_TOOBIG;   // byte offsets of a sample fit 31 bits
   a.slope = slope;
+  a.reflect = reflect ? 1 : 0;
   const int qc = ck_qc(a.cin, K);
   a.C = ck_chunks(a.cin, qc);
   if ((int64_t)ck_round_up((a.cout + 15) / 16, 4) * a.C * ck_steps(K, qc) * 3 * 1024 >= (1ll << 31)) return SAVFI_E_TOOBIG;
@@ -546,7 +559,8 @@ extern "C" int savfi_convk_tasks_pre_f32(const float* x, const float* packed, co
   auto fill = [&](int th, int tw) { return (double)a.Ho * a.Wo / ((double)((a.Ho + th - 1) / th * th) * ((a.Wo + tw - 1) / tw * tw)); };
   // 8 x 32 tiles have the smaller halo (340 vs 324 staged cells but 128-byte output rows and half the row count): 16 x 16 only
   // where it fills clearly better
-  const int tw = fill(16, 16) > 1.08 * fill(8, 32) ? 16 : 32;
+  int tw = fill(16, 16) > 1.08 * fill(8, 32) ? 16 : 32;
+  if (const char* e = getenv("SAVFI_CONVK_TW")) { const int v = atoi(e); if (v == 16 || v == 32) tw = v; }
   const int th = 256 / tw;
   a.tiles_x = (a.Wo + tw - 1) / tw; a.tiles_y = (a.Ho + th - 1) / th;
   const int64_t tiles = (int64_t)N * a.tiles_x * a.tiles_y;

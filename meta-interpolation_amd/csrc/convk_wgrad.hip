@@ -72,6 +72,7 @@ struct WgArgs {
   const float* gz;      // [N][Co][Ho][Wo]
   float* partial;       // [splits][T][Co][Ci][K*K]
   int N, T, Ci, Co, H, W, Ho, Wo, pad;
+  int reflect;          // 1: x's border of width pad mirrors the image (the forward ran on nn.ReflectionPad2d(x))
   int cobs, cibs, splits, units, units_per_split, upr, ups;   // upr = row pairs per sample, ups = column segments per row
 };
 
@@ -169,7 +170,13 @@ __global__ __launch_bounds__(WG_THREADS, 2) void convk_wgrad_kernel(const WgArgs
       int voff = x_rel[k] == OOB ? OOB : x_rel[k] + x_org;
       if (!x_in) {
         const int dy = x_yx[k] >> 16, dx = x_yx[k] & 0xffff;
-        voff = ((unsigned)(y0 - a.pad + dy) < (unsigned)a.H && (unsigned)(x0 - a.pad + dx) < (unsigned)a.W) ? voff : OOB;
+        int yy = y0 - a.pad + dy, xx2 = x0 - a.pad + dx;
+        if (a.reflect && x_rel[k] != OOB) {      // mirrored border: the item's own channel offset + the mirrored position
+          yy = yy < 0 ? -yy : (yy >= a.H ? 2 * a.H - 2 - yy : yy);
+          xx2 = xx2 < 0 ? -xx2 : (xx2 >= a.W ? 2 * a.W - 2 - xx2 : xx2);
+          voff = x_rel[k] - (dy * a.W + dx) * 4 + (yy * a.W + xx2) * 4;
+        }
+        voff = ((unsigned)yy < (unsigned)a.H && (unsigned)xx2 < (unsigned)a.W) ? voff : OOB;
       }
       if (x_full) {
 #pragma unroll
@@ -417,13 +424,19 @@ extern "C" int64_t savfi_convk_wgrad_workspace_floats(int N, int T, int Ci, int 
 
 extern "C" int savfi_convk_wgrad_tasks_f32(const float* x, const float* gz, float* gw, float* workspace, int N, int T, int Ci, int Co,
                                            int H, int W, int K, int pad, int precise, void* stream) {
+  return savfi_convk_wgrad_tasks_reflect_f32(x, gz, gw, workspace, N, T, Ci, Co, H, W, K, pad, precise, 0, stream);
+}
+
+extern "C" int savfi_convk_wgrad_tasks_reflect_f32(const float* x, const float* gz, float* gw, float* workspace, int N, int T, int Ci,
+                                                   int Co, int H, int W, int K, int pad, int precise, int reflect, void* stream) {
+  if (reflect && (pad >= H || pad >= W)) return SAVFI_E_UNSUPPORTED;
   if (!x || !gz || !gw || !workspace) return SAVFI_E_NULL;
   WgPlan p;
   int rc = wg_plan(p, N, T, Ci, Co, H, W, K, pad, precise != 0);
   if (rc != SAVFI_OK) return rc;
   WgArgs a;
   a.x = x; a.gz = gz; a.partial = workspace;
-  a.N = N; a.T = T; a.Ci = Ci; a.Co = Co; a.H = H; a.W = W; a.pad = pad;
+  a.N = N; a.T = T; a.Ci = Ci; a.Co = Co; a.H = H; a.W = W; a.pad = pad; a.reflect = reflect ? 1 : 0;
   a.Ho = H + 2 * pad - K + 1; a.Wo = W + 2 * pad - K + 1;
   a.cobs = p.cobs; a.cibs = p.cibs; a.splits = p.splits; a.units = p.units; a.units_per_split = p.ups_per_split;
   a.upr = p.upr; a.ups = p.ups;

@@ -687,13 +687,14 @@ class _ConvBiasAct(torch.autograd.Function):
     differentiable): callers use the unfused ops under --second_order."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, padding, dilation, groups, slope, direct=False, cache=None):
+    def forward(ctx, x, w, b, stride, padding, dilation, groups, slope, direct=False, cache=None, reflect=False):
         pad = padding if isinstance(padding, int) else padding[0]
-        ctx.u_bwd, ctx.route = None, None
+        ctx.u_bwd, ctx.route, ctx.reflect = None, None, bool(reflect)
+        assert not reflect or convk_eligible(x, w, stride, padding, dilation, groups, direct), "mirrored borders: direct kernel only"
         if convk_eligible(x, w, stride, padding, dilation, groups, direct):
             K = int(w.shape[-1])
             u_fwd, ctx.u_bwd = _filters('convk', w, True, bool(ctx.needs_input_grad[0]), cache)
-            z = convk_tasks_pre(x, u_fwd, 1, w.shape[1], w.shape[0], K, b, 0, slope, pad, direct)
+            z = convk_tasks_pre(x, u_fwd, 1, w.shape[1], w.shape[0], K, b, 0, slope, pad, direct, reflect)
             ctx.route = 'convk'
         elif conv3x3_eligible(x, w, stride, padding, dilation, groups):
             want_bwd = ctx.needs_input_grad[0] and conv3x3_eligible(x, w, stride, padding, dilation, groups, backward=True)
@@ -745,8 +746,14 @@ class _ConvBiasAct(torch.autograd.Function):
         if need_x and ctx.route == 'convk':
             if u_bwd is None:
                 u_bwd = _filters('convk', w, False, True, ctx.cache)[1]
-            gx = convk_tasks_pre(gz, u_bwd, 1, w.shape[1], w.shape[0], K, None, 1, 1.0, pad, ctx.direct)
+            if ctx.reflect:     # gradient of the mirrored (padded) extent = the full data gradient of the unpadded convolution, folded
+                gx = reflect_pad_bwd(convk_tasks_pre(gz, u_bwd, 1, w.shape[1], w.shape[0], K, None, 1, 1.0, 0, ctx.direct), pad)
+            else:
+                gx = convk_tasks_pre(gz, u_bwd, 1, w.shape[1], w.shape[0], K, None, 1, 1.0, pad, ctx.direct)
             need_x = False
+        if need_w and ctx.reflect:
+            gw = convk_wgrad_tasks(x, gz, 1, K, pad, ctx.direct, True)[0]
+            need_w = False
         elif need_x and conv3x3_eligible(x, w, stride, padding, dilation, groups, backward=True):
             if u_bwd is not None and ctx.route == 'wino':
                 gx = conv3x3_tasks_pre(gz, u_bwd, 1, w.shape[1], w.shape[0], None, 1, 1.0, pad)
@@ -783,7 +790,7 @@ class _ConvBiasAct(torch.autograd.Function):
                                                               False, [0, 0], groups, [need_x, need_w, False])
             gx = gx2 if need_x else gx
             gw = gw2 if need_w else gw
-        return gx, gw, gb, None, None, None, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None, None, None, None
 
 
 # --------------------------------------------------------------------------------------------
@@ -1008,7 +1015,7 @@ def convk_filters(weight, fwd=True, bwd=True):
     return ps[0], ps[1]
 
 
-def convk_tasks_pre(x, packed, T, Ci, Co, K, bias=None, mode=0, slope=1.0, pad=1, precise=False):
+def convk_tasks_pre(x, packed, T, Ci, Co, K, bias=None, mode=0, slope=1.0, pad=1, precise=False, reflect=False):
     """savfi_convk_tasks_pre_f32: direct K x K convolution (mode 0, + bias + activation) or its data gradient (mode 1) on a
     filter packed by convk_filters (same mode); sample n uses filter set n % T."""
     x = x.contiguous()
@@ -1019,14 +1026,14 @@ def convk_tasks_pre(x, packed, T, Ci, Co, K, bias=None, mode=0, slope=1.0, pad=1
     p_eff = pad if mode == 0 else K - 1 - pad
     out = torch.empty((N, I, H + 2 * p_eff - K + 1, W + 2 * p_eff - K + 1), dtype=x.dtype, device=x.device)
     lib = _hip.lib()
-    _hip.launch("convk_fwd" if mode == 0 else "convk_bwd_data", lambda: _hip.check(lib.savfi_convk_tasks_pre_f32(
+    _hip.launch("convk_fwd" if mode == 0 else "convk_bwd_data", lambda: _hip.check(lib.savfi_convk_tasks_pre_reflect_f32(
         x.data_ptr(), packed.data_ptr(), None if bias is None else bias.data_ptr(), out.data_ptr(), N, T, Ci, Co, H, W, K, int(pad),
-        mode, float(slope), int(bool(precise)), _hip.current_stream()), "savfi_convk_tasks_pre_f32"),
+        mode, float(slope), int(bool(precise)), int(bool(reflect)), _hip.current_stream()), "savfi_convk_tasks_pre_reflect_f32"),
         flops=2.0 * K * K * Ci * Co * N * (out.shape[2] * out.shape[3] if mode == 0 else H * W))
     return out
 
 
-def convk_wgrad_tasks(x, gz, T, K, pad, precise=False):
+def convk_wgrad_tasks(x, gz, T, K, pad, precise=False, reflect=False):
     """savfi_convk_wgrad_tasks_f32: gw [T,Co,Ci,K,K], gw[t] over the samples n % T == t (direct K x K form, split-bf16 MFMAs)."""
     x, gz = x.contiguous(), gz.contiguous()
     _hip.require_cuda(x, gz)
@@ -1036,10 +1043,35 @@ def convk_wgrad_tasks(x, gz, T, K, pad, precise=False):
     lib = _hip.lib()
     ws = torch.empty(_workspace_floats("savfi_convk_wgrad_workspace_floats", N, T, Ci, Co, H, W, K, int(pad)), dtype=x.dtype, device=x.device)
     gw = torch.empty((T, Co, Ci, K, K), dtype=x.dtype, device=x.device)
-    _hip.launch("convk_wgrad", lambda: _hip.check(lib.savfi_convk_wgrad_tasks_f32(
+    _hip.launch("convk_wgrad", lambda: _hip.check(lib.savfi_convk_wgrad_tasks_reflect_f32(
         x.data_ptr(), gz.data_ptr(), gw.data_ptr(), ws.data_ptr(), N, T, Ci, Co, H, W, K, int(pad), int(bool(precise)),
-        _hip.current_stream()), "savfi_convk_wgrad_tasks_f32"), flops=2.0 * K * K * Ci * Co * N * gz.shape[2] * gz.shape[3])
+        int(bool(reflect)), _hip.current_stream()), "savfi_convk_wgrad_tasks_reflect_f32"), flops=2.0 * K * K * Ci * Co * N * gz.shape[2] * gz.shape[3])
     return gw
+
+
+def reflect_pad_bwd(gp, pad):
+    """savfi_reflect_pad_bwd_f32: the adjoint of nn.ReflectionPad2d(pad) as a gather; gp [N,C,H+2p,W+2p] -> [N,C,H,W]."""
+    gp = gp.contiguous()
+    _hip.require_cuda(gp)
+    N, C, Hp, Wp = gp.shape
+    H, W = Hp - 2 * pad, Wp - 2 * pad
+    gx = torch.empty((N, C, H, W), dtype=gp.dtype, device=gp.device)
+    lib = _hip.lib()
+    _hip.launch("reflect_pad_bwd", lambda: _hip.check(lib.savfi_reflect_pad_bwd_f32(
+        gp.data_ptr(), gx.data_ptr(), N * C, H, W, int(pad), _hip.current_stream()), "savfi_reflect_pad_bwd_f32"),
+        nbytes=4 * (gp.numel() + gx.numel()))
+    return gx
+
+
+def convk_reflect_eligible(x, weight, pad):
+    """MetaConvNorm (ReflectionPad2d(pad) + K x K convolution, K = 2 pad + 1) as ONE direct convolution that mirrors the border
+    while it stages its tile?  Where the layer would take the direct kernel anyway (forward, data gradient and weight gradient
+    all live in csrc/convk*.hip there) and the fast weight is a plain [Co,Ci,K,K] tensor."""
+    if weight.dim() != 4 or x.dim() != 4 or pad < 1 or int(weight.shape[-1]) != 2 * pad + 1:
+        return False
+    if pad >= x.shape[2] or pad >= x.shape[3]:
+        return False
+    return convk_eligible(x, weight, 1, pad, 1, 1, False)
 
 
 def conv3x3_wgrad_tasks(x, gz, T, pad=1, stream=None, extra_stream=None):
@@ -1270,11 +1302,11 @@ def conv3x3_wgrad(x, gz, pad=1, stream=None, extra_stream=None):
     return gw
 
 
-def conv_bias_act(x, weight, bias, stride=1, padding=0, dilation=1, groups=1, slope=0.0, direct=False, cache=None):
+def conv_bias_act(x, weight, bias, stride=1, padding=0, dilation=1, groups=1, slope=0.0, direct=False, cache=None, reflect=False):
     """act(conv2d(x, weight) + bias) with act = LeakyReLU(slope) (0 -> ReLU, 1 -> identity); bias may be None.  `direct`: a 3x3
     layer wants the direct split-bf16 kernel whatever its size (no Winograd rounding); `cache`: a dict owned by the module whose
     own parameter `weight` is (its packed filters are kept there per weight version), None for fast weights."""
-    return _ConvBiasAct.apply(x, weight, bias, stride, padding, dilation, groups, float(slope), bool(direct), cache)
+    return _ConvBiasAct.apply(x, weight, bias, stride, padding, dilation, groups, float(slope), bool(direct), cache, bool(reflect))
 
 
 # --------------------------------------------------------------------------------------------

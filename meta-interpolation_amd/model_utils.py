@@ -183,9 +183,10 @@ class MetaConv2dLayer(nn.Module):
         nn.init.xavier_uniform_(self.weight)
         self.bias = nn.Parameter(torch.zeros(out_channels)) if use_bias else None
 
-    def forward(self, x, params=None, act_slope=None, padding=None):
+    def forward(self, x, params=None, act_slope=None, padding=None, reflect=False):
         """`act_slope` (set by MetaSequential when an activation follows) applies LeakyReLU(act_slope);
-        `padding` overrides the layer's own zero padding (windowed evaluation, sepconv/model.py)."""
+        `padding` overrides the layer's own zero padding (windowed evaluation, sepconv/model.py); `reflect`: that padding mirrors
+        the image (MetaConvNorm; the caller has checked hip_ops.convk_reflect_eligible)."""
         padding = self.padding if padding is None else padding
         if params is not None:
             pv = as_view(params)
@@ -212,13 +213,15 @@ class MetaConv2dLayer(nn.Module):
             own = self._filters if params is None else None     # own parameter: packed filters cached per weight version, here
             if hip_ops.convk_eligible(x, weight, self.stride, padding, self.dilation_rate, self.groups, direct):
                 return hip_ops.conv_bias_act(x, weight, bias, self.stride, padding, self.dilation_rate, self.groups,
-                                             1.0 if act_slope is None else act_slope, direct, own)
+                                             1.0 if act_slope is None else act_slope, direct, own, reflect)
+            assert not reflect, "mirrored borders are a direct-kernel path (hip_ops.convk_reflect_eligible)"
             if bias is not None and act_slope is not None:
                 return hip_ops.conv_bias_act(x, weight, bias, self.stride, padding, self.dilation_rate, self.groups,
                                              act_slope, direct, own)
             if bias is not None and hip_ops.conv3x3_eligible(x, weight, self.stride, padding, self.dilation_rate, self.groups):
                 # no activation follows: still worth the savfi kernel (bias in its epilogue) for large maps
                 return hip_ops.conv_bias_act(x, weight, bias, self.stride, padding, self.dilation_rate, self.groups, 1.0, direct, own)
+        assert not reflect, "mirrored borders are a direct-kernel path (hip_ops.convk_reflect_eligible)"
         out = F.conv2d(x, weight, bias, self.stride, padding, self.dilation_rate, self.groups)
         if act_slope is not None:
             out = F.relu(out) if act_slope == 0.0 else F.leaky_relu(out, act_slope)
@@ -241,11 +244,19 @@ class MetaConvNorm(nn.Module):
 
     def forward(self, x, params=None, act_slope=None):
         pv = as_view(params)
-        return self.conv(self.reflection_pad(x), params=None if pv is None else pv.sub("conv"), act_slope=act_slope)
+        sub = None if pv is None else pv.sub("conv")
+        if x.is_cuda and fuse_conv_act() and not _NO_REFLECT_FUSED:
+            # the direct kernel mirrors the border while it stages its tile: no padded copy of x, forward or backward
+            weight = self.conv.weight if sub is None else as_view(sub).leaf("weight")
+            pad = self.reflection_pad.padding[0]
+            if hip_ops.convk_reflect_eligible(x, weight, pad):
+                return self.conv(x, params=sub, act_slope=act_slope, padding=pad, reflect=True)
+        return self.conv(self.reflection_pad(x), params=sub, act_slope=act_slope)
 
 
 _META_TYPES = ()
 _NO_CA_FUSED = bool(__import__('os').environ.get('SAVFI_NO_CA_FUSED'))      # experiment knob
+_NO_REFLECT_FUSED = bool(__import__('os').environ.get('SAVFI_NO_REFLECT_FUSED'))
 
 
 class MetaSequential(nn.Sequential):

@@ -822,3 +822,34 @@ def test_channel_attention_residual_matches_the_composed_ops(N, T, C, Cr, H, W):
     assert _rel(y.detach().cpu().double(), torch.cat(ys, 0).detach()) < 2e-6
     for a, r, name in zip(grads, rgrads, ("t", "x", "w1", "b1", "w2", "b2")):
         assert _rel(a.cpu().double(), r) < 2e-5, name
+
+
+@pytest.mark.parametrize("N,Ci,Co,H,W,K", [(2, 64, 64, 40, 56, 3), (1, 192, 192, 33, 47, 3), (2, 8, 64, 30, 41, 5)])
+def test_conv_with_mirrored_border_equals_reflection_pad_plus_conv(N, Ci, Co, H, W, K):
+    """MetaConvNorm fused: conv_bias_act(reflect=True) == conv2d(ReflectionPad2d(K // 2)(x)) + bias + LeakyReLU, forward, data
+    gradient (full data gradient folded by savfi_reflect_pad_bwd_f32) and weight gradient (mirrored staging), against float64."""
+    g = torch.Generator().manual_seed(11 * H + K)
+    p = K // 2
+    x = torch.randn(N, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, K, K, generator=g) / (K * Ci ** 0.5)
+    b = torch.randn(Co, generator=g)
+    gy = torch.randn(N, Co, H, W, generator=g)
+    xr, wr, br = (t.double().requires_grad_() for t in (x, w, b))
+    ref = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(torch.nn.functional.pad(xr, (p,) * 4, mode='reflect'), wr, br), 0.2)
+    ref.backward(gy.double())
+    xd, wd, bd = (t.to(DEV).requires_grad_() for t in (x, w, b))
+    assert hip_ops.convk_reflect_eligible(xd, wd, p)
+    out = hip_ops.conv_bias_act(xd, wd, bd, 1, p, 1, 1, 0.2, False, None, True)
+    out.backward(gy.to(DEV))
+    torch.cuda.synchronize()
+    for got, want in ((out, ref), (xd.grad, xr.grad), (wd.grad, wr.grad), (bd.grad, br.grad)):
+        assert _rel(got.detach().cpu().double(), want.detach()) < 5e-6
+
+
+def test_reflect_pad_backward_is_the_adjoint_for_every_pad():
+    for (H, W, p) in ((9, 13, 1), (7, 6, 3), (4, 5, 2), (2, 3, 1)):
+        gp = torch.randn(3, 2, H + 2 * p, W + 2 * p)
+        x = torch.zeros(3, 2, H, W, dtype=torch.float64, requires_grad=True)
+        torch.nn.functional.pad(x, (p,) * 4, mode='reflect').backward(gp.double())
+        got = hip_ops.reflect_pad_bwd(gp.to(DEV), p)
+        assert _rel(got.cpu().double(), x.grad) < 1e-6

@@ -26,7 +26,7 @@ CHECK = [
 TIME = [
     (3, 32, 32, 384, 512, 4, 8, "sepconv"), (3, 64, 64, 192, 256, 4, 8, "sepconv"), (3, 128, 128, 96, 128, 4, 8, "sepconv"),
     (3, 256, 256, 48, 64, 4, 8, "sepconv"), (3, 512, 512, 24, 32, 4, 8, "sepconv"), (3, 512, 512, 12, 16, 4, 8, "sepconv"),
-    (3, 64, 64, 136, 233, 1, 8, "sepconv subnet"), (3, 51, 51, 258, 450, 1, 8, "sepconv subnet"), (3, 6, 32, 384, 512, 4, 8, "sepconv"),
+    (3, 64, 64, 137, 233, 1, 8, "sepconv subnet"), (3, 51, 51, 258, 450, 1, 8, "sepconv subnet"), (3, 6, 32, 384, 512, 4, 8, "sepconv"),
     (3, 192, 192, 96, 160, 1, 2, "cain 720p"), (3, 192, 192, 96, 160, 1, 1, "cain 720p"), (3, 192, 192, 16, 16, 1, 2, "cain 64x64"),
     (5, 6, 64, 256, 256, 1, 2, "voxelflow"), (5, 64, 128, 128, 128, 1, 2, "voxelflow"), (5, 384, 128, 128, 128, 1, 2, "voxelflow"),
     (5, 192, 64, 256, 256, 1, 2, "voxelflow"), (5, 64, 3, 256, 256, 1, 2, "voxelflow"), (3, 128, 256, 64, 64, 1, 2, "voxelflow"),
