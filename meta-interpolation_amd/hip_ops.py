@@ -890,47 +890,75 @@ def filters_after_update(outs):
     plan = _pack_plans.get(sig)
     if not plan:
         return
-    lib = _hip.lib()
-    dev = outs[0].device
     for kind in ('convk', 'wino'):
-        jobs = [(i, e[1], e[2]) for i, e in sorted(plan.items()) if e[0] == kind]
-        if not jobs:
-            continue
-        sizes, total = [], 0
-        for i, f, b in jobs:
-            T, Co, Ci, K = _filter_shape(outs[i])
-            nf = nb = 0
-            if kind == 'convk':
-                nf = _workspace_floats("savfi_convk_filter_floats", T, Ci, Co, K, 0) if f else 0
-                nb = _workspace_floats("savfi_convk_filter_floats", T, Ci, Co, K, 1) if b else 0
-            else:
-                nf = _workspace_floats("savfi_conv3x3_filter_floats", T, Ci, Co, 0) if f else 0
-                nb = _workspace_floats("savfi_conv3x3_filter_floats", T, Ci, Co, 1) if b else 0
-            nf, nb = (nf + 63) // 64 * 64, (nb + 63) // 64 * 64          # 256-byte aligned slices
-            sizes.append((total, nf, total + nf, nb))
-            total += nf + nb
-        flat = torch.empty(total, dtype=torch.float32, device=dev)
-        n = len(jobs)
-        PA, IA = ctypes.c_void_p * n, ctypes.c_int * n
-        pw, pf, pb = PA(), PA(), PA()
-        aT, aCi, aCo, aK = IA(), IA(), IA(), IA()
-        made = []
-        for k, ((i, f, b), (of, nf, ob, nb)) in enumerate(zip(jobs, sizes)):
-            w = outs[i]
-            T, Co, Ci, K = _filter_shape(w)
-            tf = flat[of:of + nf] if nf else None
-            tb = flat[ob:ob + nb] if nb else None
-            pw[k], pf[k], pb[k] = w.data_ptr(), (tf.data_ptr() if nf else None), (tb.data_ptr() if nb else None)
-            aT[k], aCi[k], aCo[k], aK[k] = T, Ci, Co, K
-            made.append((w, tf, tb))
-        if kind == 'convk':
-            _hip.launch("convk_filters_multi", lambda: _hip.check(lib.savfi_convk_filters_multi_f32(
-                pw, pf, pb, aT, aCi, aCo, aK, n, _hip.current_stream()), "savfi_convk_filters_multi_f32"))
-        else:
-            _hip.launch("conv3x3_filters_multi", lambda: _hip.check(lib.savfi_conv3x3_filters_multi_f32(
-                pw, pf, pb, aT, aCi, aCo, n, _hip.current_stream()), "savfi_conv3x3_filters_multi_f32"))
-        for w, tf, tb in made:
+        jobs = [(outs[i], e[1], e[2]) for i, e in sorted(plan.items()) if e[0] == kind]
+        for (w, _, _), (tf, tb) in zip(jobs, _filters_multi(kind, jobs)):
             _prepacked[(kind, w.data_ptr())] = (w, w._version, tf, tb)
+
+
+def _filters_multi(kind, jobs):
+    """[(weight, want_fwd, want_bwd)] -> [(filters_fwd, filters_bwd)] with ONE launch per 56 (layer, mode) jobs; the results are
+    slices of one buffer."""
+    if not jobs:
+        return []
+    lib = _hip.lib()
+    dev = jobs[0][0].device
+    sizes, total = [], 0
+    for w, f, b in jobs:
+        T, Co, Ci, K = _filter_shape(w)
+        if kind == 'convk':
+            nf = _workspace_floats("savfi_convk_filter_floats", T, Ci, Co, K, 0) if f else 0
+            nb = _workspace_floats("savfi_convk_filter_floats", T, Ci, Co, K, 1) if b else 0
+        else:
+            nf = _workspace_floats("savfi_conv3x3_filter_floats", T, Ci, Co, 0) if f else 0
+            nb = _workspace_floats("savfi_conv3x3_filter_floats", T, Ci, Co, 1) if b else 0
+        nf, nb = (nf + 63) // 64 * 64, (nb + 63) // 64 * 64          # 256-byte aligned slices
+        sizes.append((total, nf, total + nf, nb))
+        total += nf + nb
+    flat = torch.empty(total, dtype=torch.float32, device=dev)
+    n = len(jobs)
+    PA, IA = ctypes.c_void_p * n, ctypes.c_int * n
+    pw, pf, pb = PA(), PA(), PA()
+    aT, aCi, aCo, aK = IA(), IA(), IA(), IA()
+    made = []
+    for k, ((w, f, b), (of, nf, ob, nb)) in enumerate(zip(jobs, sizes)):
+        T, Co, Ci, K = _filter_shape(w)
+        tf = flat[of:of + nf] if nf else None
+        tb = flat[ob:ob + nb] if nb else None
+        pw[k], pf[k], pb[k] = w.data_ptr(), (tf.data_ptr() if nf else None), (tb.data_ptr() if nb else None)
+        aT[k], aCi[k], aCo[k], aK[k] = T, Ci, Co, K
+        made.append((tf, tb))
+    if kind == 'convk':
+        _hip.launch("convk_filters_multi", lambda: _hip.check(lib.savfi_convk_filters_multi_f32(
+            pw, pf, pb, aT, aCi, aCo, aK, n, _hip.current_stream()), "savfi_convk_filters_multi_f32"))
+    else:
+        _hip.launch("conv3x3_filters_multi", lambda: _hip.check(lib.savfi_conv3x3_filters_multi_f32(
+            pw, pf, pb, aT, aCi, aCo, n, _hip.current_stream()), "savfi_conv3x3_filters_multi_f32"))
+    return made
+
+
+def refresh_module_filters(modules):
+    """After an in-place update of the modules' OWN weights (the outer optimizer step): re-make, in one launch per kind, the
+    filters each module's cache holds for the previous version of its weight (CAIN: 500 single-layer packs per meta-iteration)."""
+    if not PREPACK or torch.cuda.is_current_stream_capturing():
+        return
+    st = _hip.current_stream()
+    jobs = {'convk': [], 'wino': []}
+    for m in modules:
+        cache, w = getattr(m, '_filters', None), getattr(m, 'weight', None)
+        if not cache or w is None or not w.is_cuda or not w.is_contiguous():
+            continue
+        for key in reversed(list(cache)):
+            kind, ptr, ver, shape, dev, stream = key
+            if ptr == w.data_ptr() and shape == tuple(w.shape) and stream == st:
+                if ver != w._version:
+                    old = cache[key]
+                    jobs[kind].append((m, key, (w.detach(), old[0] is not None, old[1] is not None)))
+                break
+    for kind, items in jobs.items():
+        for (m, key, (w, _, _)), made in zip(items, _filters_multi(kind, [it[2] for it in items])):
+            m._filters.pop(key, None)
+            m._filters[(kind, w.data_ptr(), w._version, tuple(w.shape), w.device.index, st)] = made
 
 
 def _prepacked_filters(kind, weight, fwd, bwd):

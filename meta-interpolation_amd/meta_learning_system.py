@@ -235,6 +235,7 @@ class SceneAdaptiveInterpolation(nn.Module):
         self._first_order = False
         self._defer_logging = False
         self._pending_logging = None
+        self._filter_modules = None
         self._task_stream_pool = None
         self._routes = None          # (routed, unrouted) inner-loop tensor names, probed once (_routing)
         self._graphs = {}            # (frame shape, steps, training, msl) -> GraphedInnerLoop
@@ -888,6 +889,10 @@ class SceneAdaptiveInterpolation(nn.Module):
             loss.backward()
         self.task_parallel.allreduce_gradients(params)
         self.optimizer.step()
+        if self.device.type == 'cuda':      # the filters every conv layer keeps of its own weight: one launch for all of them
+            if self._filter_modules is None:
+                self._filter_modules = [m for m in self.net.modules() if isinstance(m, model_utils.MetaConv2dLayer)]
+            hip_ops.refresh_module_filters(self._filter_modules)
 
     def run_train_iter(self, data_batch, epoch, do_evaluation=False):
         epoch = int(epoch)
