@@ -125,6 +125,111 @@ __global__ __launch_bounds__(CA_T) void ca_mlp_bwd_kernel(const float* __restric
   }
 }
 
+// ---- hidden width <= 16 (CAIN: C / 16 = 12) and C <= 256: one reduction round instead of one per hidden unit ---------------------
+// The generic kernels above take a block reduction (two barriers) per hidden unit, 12 in a row forward and backward: 13 / 25 us per
+// launch, 360 launches per C5 meta-iteration.  Here a thread carries all CRM partial dot products of its channel, the wave sums are
+// lane exchanges and the four waves meet in LDS once.
+constexpr int CRM = 16;
+
+__device__ __forceinline__ void ca_block_sums(float (&p)[CRM], int Cr, float (*red)[CA_T / SAVFI_WAVE], float* out) {
+  const int lane = threadIdx.x & (SAVFI_WAVE - 1), wid = threadIdx.x / SAVFI_WAVE;
+#pragma unroll
+  for (int j = 0; j < CRM; ++j)
+    if (j < Cr) {
+      const float v = wave_sum(p[j]);
+      if (lane == 0) red[j][wid] = v;
+    }
+  __syncthreads();
+  if ((int)threadIdx.x < Cr) {
+    // the association of block_sum (a butterfly over the four wave totals): bit-identical to the generic kernels
+    static_assert(CA_T / SAVFI_WAVE == 4, "four wave totals");
+    out[threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][2]) + (red[threadIdx.x][1] + red[threadIdx.x][3]);
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(CA_T) void ca_mlp_fwd_small(const float* __restrict__ s, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                         const float* __restrict__ w2, const float* __restrict__ b2, float* __restrict__ y,
+                                                         float* __restrict__ a1, int T, int C, int Cr) {
+  __shared__ float red[CRM][CA_T / SAVFI_WAVE];
+  __shared__ float hid[CRM];
+  const int n = blockIdx.x, t = n % T, c = threadIdx.x;
+  const float* W1 = w1 + (size_t)t * Cr * C;
+  const float* W2 = w2 + (size_t)t * C * Cr;
+  const float sv = c < C ? s[(size_t)n * C + c] : 0.f;
+  float p[CRM];
+#pragma unroll
+  for (int j = 0; j < CRM; ++j) p[j] = (j < Cr && c < C) ? W1[(size_t)j * C + c] * sv : 0.f;
+  ca_block_sums(p, Cr, red, hid);
+  if (c < Cr) {
+    const float h = fmaxf(hid[c] + b1[t * Cr + c], 0.f);
+    a1[(size_t)n * Cr + c] = h;
+    hid[c] = h;
+  }
+  __syncthreads();
+  if (c < C) {
+    float z = b2[t * C + c];
+    for (int j = 0; j < Cr; ++j) z += W2[(size_t)c * Cr + j] * hid[j];
+    y[(size_t)n * C + c] = 1.f / (1.f + __expf(-z));
+  }
+}
+
+__global__ __launch_bounds__(CA_T) void ca_mlp_bwd_small(const float* __restrict__ r, const float* __restrict__ s, const float* __restrict__ y,
+                                                         const float* __restrict__ a1, const float* __restrict__ w1, const float* __restrict__ w2,
+                                                         float* __restrict__ ds, float* __restrict__ gw1, float* __restrict__ gb1,
+                                                         float* __restrict__ gw2, float* __restrict__ gb2, int N, int T, int C, int Cr, float inv_hw) {
+  __shared__ float red[CRM][CA_T / SAVFI_WAVE];
+  __shared__ float da[CRM], a1s[CRM], dz1s[CRM];
+  const int t = blockIdx.x, c = threadIdx.x;
+  const float* W1 = w1 + (size_t)t * Cr * C;
+  const float* W2 = w2 + (size_t)t * C * Cr;
+  // thread c owns channel c: its rows of the parameter gradients live in registers over the task's samples
+  float g_w2[CRM], g_w1[CRM], g_b2 = 0.f, g_b1 = 0.f, w2r[CRM], w1r[CRM];
+#pragma unroll
+  for (int j = 0; j < CRM; ++j) {
+    g_w2[j] = 0.f; g_w1[j] = 0.f;
+    w2r[j] = (j < Cr && c < C) ? W2[(size_t)c * Cr + j] : 0.f;
+    w1r[j] = (j < Cr && c < C) ? W1[(size_t)j * C + c] : 0.f;
+  }
+  for (int n = t; n < N; n += T) {
+    if (c < Cr) a1s[c] = a1[(size_t)n * Cr + c];
+    const float yv = c < C ? y[(size_t)n * C + c] : 0.f;
+    const float dz2 = c < C ? r[(size_t)n * C + c] * yv * (1.f - yv) : 0.f;
+    const float sv = c < C ? s[(size_t)n * C + c] : 0.f;
+    float p[CRM];
+#pragma unroll
+    for (int j = 0; j < CRM; ++j) p[j] = w2r[j] * dz2;
+    ca_block_sums(p, Cr, red, da);            // also publishes a1s (barrier inside)
+    if (c < Cr) {
+      const float d = a1s[c] > 0.f ? da[c] : 0.f;
+      dz1s[c] = d;
+      g_b1 += d;
+    }
+    __syncthreads();
+    g_b2 += dz2;
+    float v = 0.f;
+#pragma unroll
+    for (int j = 0; j < CRM; ++j)
+      if (j < Cr) {
+        g_w2[j] += dz2 * a1s[j];
+        v += w1r[j] * dz1s[j];
+        g_w1[j] += dz1s[j] * sv;
+      }
+    if (c < C) ds[(size_t)n * C + c] = v * inv_hw;
+    __syncthreads();
+  }
+  if (c < C) {
+    gb2[t * C + c] = g_b2;
+#pragma unroll
+    for (int j = 0; j < CRM; ++j)
+      if (j < Cr) {
+        gw2[(size_t)t * C * Cr + (size_t)c * Cr + j] = g_w2[j];
+        gw1[(size_t)t * Cr * C + (size_t)j * C + c] = g_w1[j];
+      }
+  }
+  if (c < Cr) gb1[t * Cr + c] = g_b1;
+}
+
 // out = a * y[plane] + (x ? x : ds[plane])        (forward: x = the skip connection; backward: the pooled-branch gradient)
 __global__ __launch_bounds__(CA_T) void ca_apply_kernel(const float* __restrict__ a, const float* __restrict__ y, const float* __restrict__ x,
                                                         const float* __restrict__ ds, float* __restrict__ out, int hw, int chunks) {
@@ -172,7 +277,8 @@ extern "C" int savfi_ca_mlp_fwd_f32(const float* s, const float* w1, const float
   if (!s || !w1 || !b1 || !w2 || !b2 || !y || !a1) return SAVFI_E_NULL;
   if (N <= 0 || T <= 0 || N % T != 0 || C <= 0 || Cr <= 0) return SAVFI_E_SHAPE;
   if (C > 1024 || Cr > 64) return SAVFI_E_UNSUPPORTED;
-  hipLaunchKernelGGL(ca_mlp_fwd_kernel, dim3(N), dim3(CA_T), 0, (hipStream_t)stream, s, w1, b1, w2, b2, y, a1, T, C, Cr);
+  if (Cr <= CRM && C <= CA_T) hipLaunchKernelGGL(ca_mlp_fwd_small, dim3(N), dim3(CA_T), 0, (hipStream_t)stream, s, w1, b1, w2, b2, y, a1, T, C, Cr);
+  else hipLaunchKernelGGL(ca_mlp_fwd_kernel, dim3(N), dim3(CA_T), 0, (hipStream_t)stream, s, w1, b1, w2, b2, y, a1, T, C, Cr);
   return savfi_launch_status();
 }
 
@@ -182,7 +288,10 @@ extern "C" int savfi_ca_mlp_bwd_f32(const float* r, const float* s, const float*
   if (!r || !s || !y || !a1 || !w1 || !w2 || !ds || !gw1 || !gb1 || !gw2 || !gb2) return SAVFI_E_NULL;
   if (N <= 0 || T <= 0 || N % T != 0 || C <= 0 || Cr <= 0) return SAVFI_E_SHAPE;
   if (C > 1024 || Cr > 64) return SAVFI_E_UNSUPPORTED;
-  hipLaunchKernelGGL(ca_mlp_bwd_kernel, dim3(T), dim3(CA_T), 0, (hipStream_t)stream, r, s, y, a1, w1, w2, ds, gw1, gb1, gw2, gb2, N, T, C, Cr, inv_hw);
+  if (Cr <= CRM && C <= CA_T)
+    hipLaunchKernelGGL(ca_mlp_bwd_small, dim3(T), dim3(CA_T), 0, (hipStream_t)stream, r, s, y, a1, w1, w2, ds, gw1, gb1, gw2, gb2, N, T, C, Cr, inv_hw);
+  else
+    hipLaunchKernelGGL(ca_mlp_bwd_kernel, dim3(T), dim3(CA_T), 0, (hipStream_t)stream, r, s, y, a1, w1, w2, ds, gw1, gb1, gw2, gb2, N, T, C, Cr, inv_hw);
   return savfi_launch_status();
 }
 
