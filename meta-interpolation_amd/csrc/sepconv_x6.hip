@@ -58,9 +58,15 @@ constexpr int XNP = 7;                           // tap pairs per lane
 constexpr unsigned X_OOR = 0x80000000u;
 
 __device__ __forceinline__ float x6_bload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+#ifdef X6_EXP_LOADHIT      // experiment: every load hits the same few cache lines
+  voff &= 0xfffu; soff = 0u;
+#endif
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
 }
 __device__ __forceinline__ void x6_bstore(float val, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+#ifdef X6_EXP_NOSTORE      // experiment: every store is dropped by the range check
+  voff = X_OOR;
+#endif
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), r, (int)voff, (int)soff, 0);
 }
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t x6_rsrc(const float* base, unsigned bytes) {
@@ -87,6 +93,12 @@ __device__ __forceinline__ void x6_st16(char* p, unsigned v) { *reinterpret_cast
     __builtin_amdgcn_wave_barrier();    \
     asm volatile("" ::: "memory");      \
   } while (0)
+
+// experiment switch: wave priority inside the MFMA loops (-DX6_PRIO_LOOP=n)
+#ifndef X6_PRIO_LOOP
+#define X6_PRIO_LOOP 0
+#endif
+#define X6_PRIO(n) do { if (X6_PRIO_LOOP) __builtin_amdgcn_s_setprio(n); } while (0)
 
 // rows [r_lo, r_lo + NROWS) of the strip (b, x0): HBM -> registers -> (split) -> their circular slots; thread = (column, row group)
 template <int NROWS>
@@ -227,9 +239,23 @@ __global__ __launch_bounds__(XNT) void sepconv_bwd_x6(const float* __restrict__ 
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(smem + addr));
   };
 
-  int b, x0, ph;
-  pos_of(g0, b, x0, ph);
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // six products, small terms first
+  const int permk = ((kg & 1) << 1) | (kg >> 1);      // gV: k group kg <-> columns 8 permk .. (lane-group mates two blocks apart)
+  const int L = lane & 15;
+
+  // A workgroup's phases form RUNS inside a strip.  Each run has a prologue (its first taps, the whole window, the first h band) and
+  // a steady loop whose body issues a FIXED number of memory instructions -- the slide's loads included, wanted or not --, so that
+  // the compiler can count vmcnt for the prefetched registers.  With the strip change and the slide loads behind branches inside
+  // the loop it fell back to vmcnt(0) at the top of every phase: a wait for the previous phase's 32 stores to be acknowledged and,
+  // every other phase, for six loads issued a few instructions earlier (experiment: the same kernel with its loads hitting cache
+  // ran 50 us / 16 % faster).
   float hreg[XNP][2], vreg[XNP][2], gnext[XC];
+  int g = g0;
+#pragma unroll 1
+  while (g < g1) {
+  int b, x0, ph;
+  pos_of(g, b, x0, ph);
+  const int run_end = min(g1, g + (nph - ph)), ph_last = ph + (run_end - g) - 1;
   load_taps(hreg, hsrc, b, x0, XPR * ph + wr, h_t0);
   load_taps(vreg, vsrc, b, x0, XPR * ph + wr, v_t0);
   {
@@ -237,6 +263,7 @@ __global__ __launch_bounds__(XNT) void sepconv_bwd_x6(const float* __restrict__ 
 #pragma unroll
     for (int c = 0; c < XC; ++c) gnext[c] = x6_bload(gsrc, go, (unsigned)c * plane_b);
   }
+  __syncthreads();                                  // every wave has left the previous run's window
 #pragma unroll 1
   for (int r = 0; r < XWIN; r += 16) {
     X6Rows<16> sr;
@@ -245,31 +272,16 @@ __global__ __launch_bounds__(XNT) void sepconv_bwd_x6(const float* __restrict__ 
   }
   int loaded_hi = XPR * ph + XWIN;
   write_h_table(hreg);
+  __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
-  if (w >= 4) __builtin_amdgcn_s_sleep(40);       // de-phase the two waves of a SIMD
-
-  constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // six products, small terms first
-  const int permk = ((kg & 1) << 1) | (kg >> 1);      // gV: k group kg <-> columns 8 permk .. (lane-group mates two blocks apart)
-  const int L = lane & 15;
+  if (w >= 4 && g == g0) __builtin_amdgcn_s_sleep(40);       // de-phase the two waves of a SIMD
 
 #pragma unroll 1
-  for (int g = g0; g < g1; ++g) {
-    if (g != g0 && ph == 0) {                      // entered the next strip: the whole window is new
-      __syncthreads();
-#pragma unroll 1
-      for (int r = 0; r < XWIN; r += 16) {
-        X6Rows<16> sr;
-        x6_rows_load<16>(sr, isrc, b, x0, r, Hi, Wi, tid);
-        x6_rows_write<16>(sr, smem, r, tid);
-      }
-      loaded_hi = XWIN;
-      __syncthreads();
-    }
-    int nb, nx0, nph_;
-    pos_of(min(g + 1, g1 - 1), nb, nx0, nph_);
-    const bool slide = (g + 1 < g1) && nph_ != 0 && (XPR * nph_ + XPR + XK - 1 > loaded_hi);
+  for (; g < run_end; ++g) {
+    const int nb = b, nx0 = x0, nph_ = min(ph + 1, ph_last);      // the run's last phase re-reads its own taps
+    const bool slide = (g + 1 < run_end) && (XPR * nph_ + XPR + XK - 1 > loaded_hi);
     X6Rows<XAHEAD> slid;
-    if (slide) x6_rows_load<XAHEAD>(slid, isrc, b, x0, loaded_hi, Hi, Wi, tid);
+    x6_rows_load<XAHEAD>(slid, isrc, b, x0, loaded_hi, Hi, Wi, tid);      // unconditional (rows clamped): a fixed instruction count
 
     const int y = XPR * ph + wr;
     const int x = x0 + 16 * wc + j;
@@ -347,6 +359,7 @@ __global__ __launch_bounds__(XNT) void sepconv_bwd_x6(const float* __restrict__ 
             aq[slot][t][p] = *reinterpret_cast<const bf16x8*>(smem + (p * 3 + c) * XPLANE + 4 * s * XBLK + rowoff[2 * mp + t]);
       };
       __builtin_amdgcn_sched_barrier(0);
+      X6_PRIO(X6_PRIO_LOOP);
       load_a(0, 0);
 #pragma unroll
       for (int u = 0; u < 12; ++u) {
@@ -361,6 +374,7 @@ __global__ __launch_bounds__(XNT) void sepconv_bwd_x6(const float* __restrict__ 
             acc[c][2 * mp + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[u & 1][t][PA[q]], bq[s][PB[q]], acc[c][2 * mp + t], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
+      X6_PRIO(0);
       // D row 4 kg + r of tile m = tap row fy = 16 m + 4 kg + r, column = pixel j; pixels 14, 15 add their tail columns
       const float tsel = j >= 14 ? 1.f : 0.f;
       const int tcol = j == 15 ? 1 : 0;
@@ -432,6 +446,7 @@ __global__ __launch_bounds__(XNT) void sepconv_bwd_x6(const float* __restrict__ 
           }
       };
       __builtin_amdgcn_sched_barrier(0);
+      X6_PRIO(X6_PRIO_LOOP);
       load_a(0, 0);
 #pragma unroll
       for (int u = 0; u < 12; ++u) {
@@ -446,6 +461,7 @@ __global__ __launch_bounds__(XNT) void sepconv_bwd_x6(const float* __restrict__ 
             acc[c][2 * mp + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[u & 1][t][PA[q]], bq[s][PB[q]], acc[c][2 * mp + t], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
+      X6_PRIO(0);
       // gH[fx][j] = D[j + fx][j]: through a 64 x 16 fp32 tile in the wave's (now dead) tap table, out as 13 x four 64-byte runs
       {
         X6_ORDER();
@@ -483,7 +499,8 @@ __global__ __launch_bounds__(XNT) void sepconv_bwd_x6(const float* __restrict__ 
       loaded_hi += XAHEAD;
       __syncthreads();
     }
-    b = nb; x0 = nx0; ph = nph_;
+    ph = nph_;
+  }
   }
 }
 
@@ -571,11 +588,20 @@ __global__ __launch_bounds__(XNT) void sepconv_fwd_x6(const float* __restrict__ 
     for (int r = 0; r < 4; ++r) regs[3][r] = x6_bload(vsrc, pix + (unsigned)min(48 + 4 * kg + r, XK - 1) * plane_b, 0u);
   };
 
-  int b, x0, ph;
-  pos_of(g0, b, x0, ph);
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+  const int permk = ((kg & 1) << 1) | (kg >> 1);
+  float* const tailb = reinterpret_cast<float*>(tab);                  // [c][fy][2] in the wave's table once its fragments are in registers
+
   float hreg[XNP][2], vD[4][4];
+  int g = g0;
+#pragma unroll 1
+  while (g < g1) {          // runs of phases inside a strip: see sepconv_bwd_x6
+  int b, x0, ph;
+  pos_of(g, b, x0, ph);
+  const int run_end = min(g1, g + (nph - ph)), ph_last = ph + (run_end - g) - 1;
   load_h(hreg, b, x0, XPR * ph + wr);
   load_v(vD, b, x0, XPR * ph + wr);
+  __syncthreads();
 #pragma unroll 1
   for (int r = 0; r < XWIN; r += 16) {
     X6Rows<16> sr;
@@ -584,31 +610,16 @@ __global__ __launch_bounds__(XNT) void sepconv_fwd_x6(const float* __restrict__ 
   }
   int loaded_hi = XPR * ph + XWIN;
   write_h_table(hreg);
+  __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
-  if (w >= 4) __builtin_amdgcn_s_sleep(40);
-
-  constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
-  const int permk = ((kg & 1) << 1) | (kg >> 1);
-  float* const tailb = reinterpret_cast<float*>(tab);                  // [c][fy][2] in the wave's table once its fragments are in registers
+  if (w >= 4 && g == g0) __builtin_amdgcn_s_sleep(40);
 
 #pragma unroll 1
-  for (int g = g0; g < g1; ++g) {
-    if (g != g0 && ph == 0) {
-      __syncthreads();
-#pragma unroll 1
-      for (int r = 0; r < XWIN; r += 16) {
-        X6Rows<16> sr;
-        x6_rows_load<16>(sr, isrc, b, x0, r, Hi, Wi, tid);
-        x6_rows_write<16>(sr, smem, r, tid);
-      }
-      loaded_hi = XWIN;
-      __syncthreads();
-    }
-    int nb, nx0, nph_;
-    pos_of(min(g + 1, g1 - 1), nb, nx0, nph_);
-    const bool slide = (g + 1 < g1) && nph_ != 0 && (XPR * nph_ + XPR + XK - 1 > loaded_hi);
+  for (; g < run_end; ++g) {
+    const int nb = b, nx0 = x0, nph_ = min(ph + 1, ph_last);
+    const bool slide = (g + 1 < run_end) && (XPR * nph_ + XPR + XK - 1 > loaded_hi);
     X6Rows<XAHEAD> slid;
-    if (slide) x6_rows_load<XAHEAD>(slid, isrc, b, x0, loaded_hi, Hi, Wi, tid);
+    x6_rows_load<XAHEAD>(slid, isrc, b, x0, loaded_hi, Hi, Wi, tid);
 
     const int y = XPR * ph + wr;
     const int x = x0 + 16 * wc + j;
@@ -659,6 +670,7 @@ __global__ __launch_bounds__(XNT) void sepconv_fwd_x6(const float* __restrict__ 
           aq[slot][t][p] = *reinterpret_cast<const bf16x8*>(smem + (p * 3 + c) * XPLANE + 4 * s * XBLK + rowoff[2 * mp + t]);
     };
     __builtin_amdgcn_sched_barrier(0);
+    X6_PRIO(X6_PRIO_LOOP);
     load_a(0, 0);
 #pragma unroll
     for (int u = 0; u < 12; ++u) {
@@ -672,6 +684,7 @@ __global__ __launch_bounds__(XNT) void sepconv_fwd_x6(const float* __restrict__ 
           acc[c][2 * mp + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[u & 1][t][PA[q]], bq[s][PB[q]], acc[c][2 * mp + t], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
+    X6_PRIO(0);
     // vertical pass: this lane's 16 rows of T (+ the tail columns for pixels 14, 15), then the four row groups of the pixel
     const float tsel = j >= 14 ? 1.f : 0.f;
     const int tcol = j == 15 ? 1 : 0;
@@ -704,7 +717,8 @@ __global__ __launch_bounds__(XNT) void sepconv_fwd_x6(const float* __restrict__ 
       loaded_hi += XAHEAD;
       __syncthreads();
     }
-    b = nb; x0 = nx0; ph = nph_;
+    ph = nph_;
+  }
   }
 }
 
