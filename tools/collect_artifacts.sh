@@ -35,13 +35,13 @@ python bench.py --workload c3_voxelflow_metasgd_256x256_b8_s5 --steps 3 --warmup
 python tools/parity_report.py > $A/r03_parity_report.jsonl 2>/dev/null
 python tools/kernel_bench.py --batches 1,2,4,8 > $A/r03_kernel_bench.jsonl 2>/dev/null
 SAVFI_SEPCONV_F32_MFMA=1 python tools/kernel_bench.py --only sepconv --batches 2,8 --hw 256x448 > $A/r03_kernel_bench_sepconv_f32_mfma.jsonl 2>/dev/null
-python tools/scratch/x6_acc.py > $A/r03_sepconv_x6_accuracy.txt 2>/dev/null
-SAVFI_SEPCONV_F32_MFMA=1 python tools/scratch/x6_acc.py >> $A/r03_sepconv_x6_accuracy.txt 2>/dev/null
+python tools/sepconv_x6_accuracy.py > $A/r03_sepconv_x6_accuracy.txt 2>/dev/null
+SAVFI_SEPCONV_F32_MFMA=1 python tools/sepconv_x6_accuracy.py >> $A/r03_sepconv_x6_accuracy.txt 2>/dev/null
 for w in c2_sepconv_256x448_b4_s5 c3_voxelflow_metasgd_256x256_b8_s5 c5_cain_l2f_720p_b1_s1; do python tools/layer_table.py --workload $w --top 60 >> $A/r03_layer_tables.txt 2>/dev/null; done
 cd /tmp
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/pmcx1 -- python $R/tools/scratch/x6_pmc.py > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/pmcx1 -- python $R/tools/sepconv_x6_pmc.py > /dev/null 2>&1
 python $R/tools/pmc_summary.py /tmp/pmcx1 | head -3 > $A/r03_pmc_sepconv_x6.txt 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU --kernel-trace --output-format csv -d /tmp/pmcx2 -- python $R/tools/scratch/x6_pmc.py > /dev/null 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU --kernel-trace --output-format csv -d /tmp/pmcx2 -- python $R/tools/sepconv_x6_pmc.py > /dev/null 2>&1
 python $R/tools/pmc_summary.py /tmp/pmcx2 | head -3 >> $A/r03_pmc_sepconv_x6.txt 2>&1
 cd $R
 ls -la $A

@@ -1,0 +1,15 @@
+"""PMC driver: the sepconv filter-gradient kernel at B=8 256x448 (the bench shape), a few launches."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from meta_interpolation_amd import _hip
+lib, st = _hip.lib(), _hip.current_stream()
+B, C, Ho, Wo, K = 8, 3, 256, 448, 51
+inp = torch.rand(B, C, Ho + K - 1, Wo + K - 1, device="cuda")
+v = torch.randn(B, K, Ho, Wo, device="cuda") / 7
+h = torch.randn(B, K, Ho, Wo, device="cuda") / 7
+gO = torch.randn(B, C, Ho, Wo, device="cuda")
+gV, gH = torch.empty_like(v), torch.empty_like(h)
+for _ in range(6):
+    _hip.check(lib.savfi_sepconv_bwd_f32(inp.data_ptr(), v.data_ptr(), h.data_ptr(), gO.data_ptr(), None, gV.data_ptr(), gH.data_ptr(), B, C, Ho, Wo, K, st), "bwd")
+torch.cuda.synchronize()
