@@ -1,5 +1,5 @@
 // Section timing of sepconv_bwd_x6 (wave cycles, s_memtime): hipcc --offload-arch=gfx950 -O3 -DX6_TRACE -I include -I meta-interpolation_amd/csrc
-//   -fno-slp-vectorize tools/scratch/x6_trace.hip -o tools/scratch/x6_trace
+//   -fno-slp-vectorize tools/x6_variants/x6_trace.hip -o /tmp/x6_trace   (builds the half-phase-skewed variant next to it, which carries the X6_T probes)
 #include "sepconv_x6_skewed_schedule.hip.txt"
 #include <cstdio>
 #include <vector>
