@@ -69,6 +69,12 @@ __device__ __forceinline__ void x6_bstore(float val, __amdgpu_buffer_rsrc_t r, u
 #endif
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), r, (int)voff, (int)soff, 0);
 }
+__device__ __forceinline__ void x6_bstore4(f32x4 val, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+#ifdef X6_EXP_NOSTORE
+  voff = 0x80000000u;
+#endif
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), r, (int)voff, (int)soff, 0);
+}
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t x6_rsrc(const float* base, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)bytes, 0x00020000);
 }
@@ -94,6 +100,11 @@ __device__ __forceinline__ void x6_st16(char* p, unsigned v) { *reinterpret_cast
     asm volatile("" ::: "memory");      \
   } while (0)
 
+// pitch of the fp32 transpose tile gV leaves through (floats): 4 * 20 = 16 (mod 64) banks between the four row groups of a store
+constexpr int XTP = 20;
+#ifndef X6_SCALAR_STORES
+#define X6_SCALAR_STORES 0
+#endif
 // experiment switch: wave priority inside the MFMA loops (-DX6_PRIO_LOOP=n)
 #ifndef X6_PRIO_LOOP
 #define X6_PRIO_LOOP 0
@@ -146,6 +157,7 @@ __device__ __forceinline__ void x6_rows_write(const X6Rows<NROWS>& sr, char* __r
   }
 }
 
+template <bool VEC>
 __global__ __launch_bounds__(XNT) void sepconv_bwd_x6(const float* __restrict__ in, const float* __restrict__ v,
                                                       const float* __restrict__ h, const float* __restrict__ gO,
                                                       float* __restrict__ gV, float* __restrict__ gH,
@@ -242,6 +254,8 @@ __global__ __launch_bounds__(XNT) void sepconv_bwd_x6(const float* __restrict__ 
   constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // six products, small terms first
   const int permk = ((kg & 1) << 1) | (kg >> 1);      // gV: k group kg <-> columns 8 permk .. (lane-group mates two blocks apart)
   const int L = lane & 15;
+  const int pq = lane & 3, fq = lane >> 2;
+  constexpr bool vec_store = VEC;      // Wo % 4 == 0 (the launcher picks)
 
   // A workgroup's phases form RUNS inside a strip.  Each run has a prologue (its first taps, the whole window, the first h band) and
   // a steady loop whose body issues a FIXED number of memory instructions -- the slide's loads included, wanted or not --, so that
@@ -287,6 +301,9 @@ __global__ __launch_bounds__(XNT) void sepconv_bwd_x6(const float* __restrict__ 
     const int x = x0 + 16 * wc + j;
     const bool pvalid = (x < Wo) && (y < Ho);
     const unsigned opix_b = (unsigned)b * (unsigned)XK * plane_b + (unsigned)(min(y, Ho - 1) * Wo + min(x, Wo - 1)) * 4u;
+    // vector stores (Wo % 4 == 0): lane = (pixel quad pq, tap row fq of a group of 16); a quad is wholly inside the map or outside
+    const int xq = x0 + 16 * wc + 4 * pq;
+    const unsigned qoff = (y < Ho && xq < Wo) ? (unsigned)b * (unsigned)XK * plane_b + (unsigned)(y * Wo + xq) * 4u + (unsigned)fq * plane_b : X_OOR;
     float g_[XC];
 #pragma unroll
     for (int c = 0; c < XC; ++c) g_[c] = gnext[c];
@@ -315,11 +332,6 @@ __global__ __launch_bounds__(XNT) void sepconv_bwd_x6(const float* __restrict__ 
 #pragma unroll
       for (int c = 0; c < XC; ++c) gnext[c] = x6_bload(gsrc, go, (unsigned)c * plane_b);
     }
-    // the h fragments are in registers: the table takes v now, and the v registers the next phase's taps
-    X6_ORDER();
-    write_v_table(vreg);
-    X6_ORDER();
-    load_taps(vreg, vsrc, nb, nx0, XPR * nph_ + wr, v_t0);
 
     const int fyl = min(lane, XK - 1);
     const int tslot = (y + fyl) & (XWIN - 1);
@@ -378,19 +390,46 @@ __global__ __launch_bounds__(XNT) void sepconv_bwd_x6(const float* __restrict__ 
       // D row 4 kg + r of tile m = tap row fy = 16 m + 4 kg + r, column = pixel j; pixels 14, 15 add their tail columns
       const float tsel = j >= 14 ? 1.f : 0.f;
       const int tcol = j == 15 ? 1 : 0;
-      const unsigned vo = opix_b + (unsigned)(4 * kg) * plane_b;
-      const unsigned voA = pvalid ? vo : X_OOR, voB = (pvalid && kg == 0) ? vo : X_OOR;
+      float val[4][4];
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int r = 0; r < (m < 3 ? 4 : 3); ++r) {
-          float val = g_[0] * acc[0][m][r];
-          val = fmaf(g_[1], acc[1][m][r], val);
-          val = fmaf(g_[2], acc[2][m][r], val);
-          val = fmaf(tsel, tailb[2 * min(16 * m + 4 * kg + r, XK - 1) + tcol], val);
-          x6_bstore(val, gvdst, m < 3 ? voA : voB, (unsigned)(16 * m + r) * plane_b);
+        for (int r = 0; r < 4; ++r) {
+          float t = g_[0] * acc[0][m][r];
+          t = fmaf(g_[1], acc[1][m][r], t);
+          t = fmaf(g_[2], acc[2][m][r], t);
+          val[m][r] = fmaf(tsel, tailb[2 * min(16 * m + 4 * kg + r, XK - 1) + tcol], t);
         }
+      if constexpr (vec_store) {
+        // rows of 4 pixels per lane through the wave's table (free: the h fragments are in registers, v is written below): a store
+        // instruction then carries sixteen 64-byte runs as 16-byte pieces instead of four as dwords -- 4 instructions instead of 15
+        X6_ORDER();
+        float* tile = reinterpret_cast<float*>(tab);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) tile[(16 * m + 4 * kg + r) * XTP + j] = val[m][r];
+        X6_ORDER();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v4 = *reinterpret_cast<const f32x4*>(tile + (fq + 16 * q) * XTP + 4 * pq);
+          x6_bstore4(v4, gvdst, (q < 3 || fq < 3) ? qoff : X_OOR, (unsigned)(16 * q) * plane_b);
+        }
+        X6_ORDER();
+      } else {
+        const unsigned vo = opix_b + (unsigned)(4 * kg) * plane_b;
+        const unsigned voA = pvalid ? vo : X_OOR, voB = (pvalid && kg == 0) ? vo : X_OOR;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int r = 0; r < (m < 3 ? 4 : 3); ++r) x6_bstore(val[m][r], gvdst, m < 3 ? voA : voB, (unsigned)(16 * m + r) * plane_b);
+      }
     }
+    // the table takes v now, and the v registers the next phase's taps
+    X6_ORDER();
+    write_v_table(vreg);
+    X6_ORDER();
+    load_taps(vreg, vsrc, nb, nx0, XPR * nph_ + wr, v_t0);
 
     // ---- gH -------------------------------------------------------------------------------------------------------
     {
@@ -476,18 +515,37 @@ __global__ __launch_bounds__(XNT) void sepconv_bwd_x6(const float* __restrict__ 
             tile[(16 * m + 4 * kg + r) * 16 + j] = val;
           }
         X6_ORDER();
-        const unsigned ho = opix_b + (unsigned)kg * plane_b;
+        if constexpr (vec_store) {
+          // lane (pq, fq): pixels 4 pq .. + 3 of tap fx = fq + 16 q; the three tail sums go into their places (pixels 14 / 15, taps 49 / 50)
 #pragma unroll
-        for (int t = 0; t < XNREG; ++t) {
-          const int fx = 4 * t + kg;
-          const float val = tile[min(j + fx, 63) * 16 + j];
-          x6_bstore(val, ghdst, (pvalid && fx < XK && j + fx < 64) ? ho : X_OOR, (unsigned)(4 * t) * plane_b);
+          for (int q = 0; q < 4; ++q) {
+            const int fx = fq + 16 * q;
+            f32x4 v4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int jj = 4 * pq + e;
+              float t = tile[min(jj + fx, 63) * 16 + jj];
+              if (jj + fx >= 64) t = (jj == 14) ? s6414 : (fx == 49 ? s6415 : s6515);
+              v4[e] = t;
+            }
+            x6_bstore4(v4, ghdst, (q < 3 || fq < 3) ? qoff : X_OOR, (unsigned)(16 * q) * plane_b);
+          }
+        } else {
+          const unsigned ho = opix_b + (unsigned)kg * plane_b;
+#pragma unroll
+          for (int t = 0; t < XNREG; ++t) {
+            const int fx = 4 * t + kg;
+            const float val = tile[min(j + fx, 63) * 16 + j];
+            x6_bstore(val, ghdst, (pvalid && fx < XK && j + fx < 64) ? ho : X_OOR, (unsigned)(4 * t) * plane_b);
+          }
         }
         X6_ORDER();
       }
-      x6_bstore(s6414, ghdst, (pvalid && lane == 14) ? opix_b : X_OOR, 50u * plane_b);
-      x6_bstore(s6415, ghdst, (pvalid && lane == 15) ? opix_b : X_OOR, 49u * plane_b);
-      x6_bstore(s6515, ghdst, (pvalid && lane == 15) ? opix_b : X_OOR, 50u * plane_b);
+      if constexpr (!vec_store) {
+        x6_bstore(s6414, ghdst, (pvalid && lane == 14) ? opix_b : X_OOR, 50u * plane_b);
+        x6_bstore(s6415, ghdst, (pvalid && lane == 15) ? opix_b : X_OOR, 49u * plane_b);
+        x6_bstore(s6515, ghdst, (pvalid && lane == 15) ? opix_b : X_OOR, 50u * plane_b);
+      }
     }
 
     // the next phase's h band takes the table
@@ -727,13 +785,19 @@ __global__ __launch_bounds__(XNT) void sepconv_fwd_x6(const float* __restrict__ 
 // gV and gH of the K = 51, C = 3 op; every tensor below 2^31 bytes (the caller checks).  Declared in csrc/common.h.
 int savfi_sepconv_bwd_x6_launch(const float* in, const float* v, const float* h, const float* gO, float* gV, float* gH, int B, int Ho,
                                 int Wo, int cus, hipStream_t st) {
-  static uint32_t done = 0;
-  if (int e = savfi_ensure_dynamic_lds((const void*)sepconv_bwd_x6, XLDS, done)) return e;
   const int nph = savfi_cdiv(Ho, XPR), ncol = savfi_cdiv(Wo, XMC);
   const int64_t total = (int64_t)B * ncol * nph;
   const int per_wg = savfi_cdiv(total, cus);
   const int grid = savfi_cdiv(total, per_wg);
-  hipLaunchKernelGGL(sepconv_bwd_x6, dim3(grid), dim3(XNT), XLDS, st, in, v, h, gO, gV, gH, B, Ho, Wo, nph, ncol, per_wg);
+  if ((Wo & 3) == 0 && !X6_SCALAR_STORES) {
+    static uint32_t done = 0;
+    if (int e = savfi_ensure_dynamic_lds((const void*)sepconv_bwd_x6<true>, XLDS, done)) return e;
+    hipLaunchKernelGGL(sepconv_bwd_x6<true>, dim3(grid), dim3(XNT), XLDS, st, in, v, h, gO, gV, gH, B, Ho, Wo, nph, ncol, per_wg);
+  } else {
+    static uint32_t done = 0;
+    if (int e = savfi_ensure_dynamic_lds((const void*)sepconv_bwd_x6<false>, XLDS, done)) return e;
+    hipLaunchKernelGGL(sepconv_bwd_x6<false>, dim3(grid), dim3(XNT), XLDS, st, in, v, h, gO, gV, gH, B, Ho, Wo, nph, ncol, per_wg);
+  }
   return savfi_launch_status();
 }
 
