@@ -321,7 +321,7 @@ def main():
                     "avg_us_per_launch": k["avg_us"], "launches": k["launches"],
                     "algorithmic_bytes_per_launch": k["algorithmic_bytes"] / k["launches"],
                     "note": "algorithmic bytes = %.2f MB per [1,3,%d,%d] sample (x samples per launch: tasks in lockstep x the "
-                            "support pair); 288 bf16 MFMAs per 16 pixels = 29%% of the launch at full matrix rate, the rest is per-phase tap staging, "
+                            "support pair); 288 bf16 MFMAs per 16 pixels = ~40%% of the launch at full matrix rate (PMC: matrix pipe 39%% busy), the rest is per-phase tap staging, "
                             "stores and window barriers with 8 waves per CU (DESIGN.md 4e)"
                             % (per_call / 1e6, oh, ow)}
             elif summ:

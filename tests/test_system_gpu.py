@@ -62,8 +62,14 @@ def tolerances(name, phase='train'):
     # draw; 5e-3 covers the observed modes.  Losses, predictions, weights and per-step gradients keep their gates.
     if name.startswith('sepconv_') and phase == 'train':
         tol['outer'] = max(tol['outer'], 5e-3)
-    # (rounds 1-2 carried a 1e-2 override on Super SloMo's outer-gradient fingerprints: its 7x7 / 5x5 first stages ran on MIOpen's
-    # implicit-GEMM kernels, 3.1e-3 off.  On the direct split-bf16 kernels they measure 6.3e-4 -- inside the common gate.)
+    # Super SloMo's outer-gradient fingerprints: 6.3e-4 in most processes, 4.9e-3 (net.flowComp.conv2.bias) in about one process
+    # of three -- the same value in all four fixture tests of that process, another process of the same build back at 6.3e-4
+    # (profiles/r03_superslomo_outer_gradient_modes.txt: three full runs of this suite on one box).  The fixture's deep layers
+    # (<= 8 x 8 maps) run on MIOpen, whose find step picks solvers per process; a LeakyReLU unit of such a map switching is ~5e-3 of
+    # that bias's learning-rate gradient: the SepConv case above.  Rounds 1-2 carried 1e-2 here (then for the 7x7 / 5x5 stages on
+    # MIOpen's implicit-GEMM kernels, 3.1e-3 off); the gate removed early this round made the suite fail one run in three.
+    if name.startswith('superslomo_') and phase == 'train':
+        tol['outer'] = max(tol['outer'], 1e-2)
     return tol
 
 
