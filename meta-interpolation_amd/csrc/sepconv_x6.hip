@@ -50,7 +50,7 @@ constexpr int XBLK = 64 * 16 + 128, XNBLK = 10;  // bytes per 8-column block, bl
 constexpr int XPLANE = XNBLK * XBLK, XWINB = 9 * XPLANE;
 constexpr int XTABP = 8 * 256, XTAB = 3 * XTABP; // tap table of a wave: [piece][k / 8][16 j][8]
 constexpr int XSIDE_OFF = XWINB + 8 * XTAB, XSIDE = XC * XWIN * 4 * 4;
-constexpr int XTAIL_OFF = XSIDE_OFF + XSIDE, XTAILB = 416;
+constexpr int XTAIL_OFF = XSIDE_OFF + XSIDE, XTAILB = 512;      // gV tail sums of a wave: [column][64 tap rows] floats
 constexpr int XLDS = XTAIL_OFF + 8 * XTAILB;
 static_assert(XLDS <= 160 * 1024, "LDS per CU");
 constexpr int XNREG = (XK + 3) / 4;              // gH leaves in 13 instructions of four taps
@@ -349,7 +349,8 @@ __global__ __launch_bounds__(XNT) void sepconv_bwd_x6(const float* __restrict__ 
         t15 = fmaf(g15[c] * h49_15, a64[c], t15);
         t15 = fmaf(g15[c] * h50_15, a65[c], t15);
       }
-      *reinterpret_cast<f32x2*>(tailb + 2 * fyl) = (f32x2){t14, t15};
+      tailb[lane] = lane < XK ? t14 : 0.f;          // [column][tap row]: a lane of the epilogue reads its four rows as one 16-byte piece
+      tailb[64 + lane] = lane < XK ? t15 : 0.f;
     }
 
     {
@@ -398,8 +399,14 @@ __global__ __launch_bounds__(XNT) void sepconv_bwd_x6(const float* __restrict__ 
           float t = g_[0] * acc[0][m][r];
           t = fmaf(g_[1], acc[1][m][r], t);
           t = fmaf(g_[2], acc[2][m][r], t);
-          val[m][r] = fmaf(tsel, tailb[2 * min(16 * m + 4 * kg + r, XK - 1) + tcol], t);
+          val[m][r] = t;
         }
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const f32x4 tv = *reinterpret_cast<const f32x4*>(tailb + 64 * tcol + 16 * m + 4 * kg);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) val[m][r] = fmaf(tsel, tv[r], val[m][r]);
+      }
       if constexpr (vec_store) {
         // rows of 4 pixels per lane through the wave's table (free: the h fragments are in registers, v is written below): a store
         // instruction then carries sixteen 64-byte runs as 16-byte pieces instead of four as dwords -- 4 instructions instead of 15
@@ -570,6 +577,7 @@ __global__ __launch_bounds__(XNT) void sepconv_bwd_x6(const float* __restrict__ 
 // fy = 16 m + 4 kg + r of T and loads v for exactly those rows; the four row groups of a pixel meet through two lane exchanges.
 // Replaces the reference's forward kernel (sepconv/sepconv_op/sepconv.py:5-30) -- same op, same layout.
 // ------------------------------------------------------------------------------------------------------------------------
+template <bool VEC>
 __global__ __launch_bounds__(XNT) void sepconv_fwd_x6(const float* __restrict__ in, const float* __restrict__ v,
                                                       const float* __restrict__ h, float* __restrict__ out,
                                                       int B, int Ho, int Wo, int nph, int ncol, int per_wg) {
@@ -634,8 +642,23 @@ __global__ __launch_bounds__(XNT) void sepconv_fwd_x6(const float* __restrict__ 
       }
     }
   };
-  // v in the accumulator layout: vD[m][r] = v[j][16 m + 4 kg + r] (rows >= 51 of the last tile: clamped plane, zeroed at use)
+  // v is wanted in the accumulator layout, vcur[m][r] = v[j][16 m + 4 kg + r].  Widths that are a multiple of 4: lane (pq, fq) loads
+  // pixels 4 pq .. + 3 of tap fq + 16 q as ONE 16-byte piece (4 load instructions of sixteen 64-byte runs instead of 16 of four) and
+  // the layout change goes through a 52 x 16 tile (pitch 20) behind the tail sums in the wave's table; other widths load the
+  // accumulator layout directly.  Rows >= 51: clamped plane, zeroed at use.
+  constexpr bool vec_v = VEC;          // Wo % 4 == 0 (the launcher picks)
+  const int pq = lane & 3, fq = lane >> 2;
   auto load_v = [&](float (&regs)[4][4], int b, int x0, int y) {
+    if constexpr (vec_v) {
+      const unsigned base = (unsigned)b * (unsigned)XK * plane_b + (unsigned)(min(y, Ho - 1) * Wo + min(x0 + 16 * wc + 4 * pq, Wo - 4)) * 4u;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(vsrc, (int)(base + (unsigned)min(fq + 16 * q, XK - 1) * plane_b), 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) regs[q][e] = __uint_as_float(t[e]);
+      }
+      return;
+    }
     const unsigned pix = pix_off(b, x0, y, XK);
     const unsigned voff = pix + (unsigned)(4 * kg) * plane_b;
 #pragma unroll
@@ -648,7 +671,7 @@ __global__ __launch_bounds__(XNT) void sepconv_fwd_x6(const float* __restrict__ 
 
   constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
   const int permk = ((kg & 1) << 1) | (kg >> 1);
-  float* const tailb = reinterpret_cast<float*>(tab);                  // [c][fy][2] in the wave's table once its fragments are in registers
+  float* const tailb = reinterpret_cast<float*>(tab);                  // [c][column][64 tap rows] in the wave's table once its fragments are in registers
 
   float hreg[XNP][2], vD[4][4];
   int g = g0;
@@ -685,17 +708,33 @@ __global__ __launch_bounds__(XNT) void sepconv_fwd_x6(const float* __restrict__ 
     const float h50_14 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hreg[6][0]), 14 + 16));
     const float h49_15 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hreg[6][0]), 15 + 16));
     const float h50_15 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hreg[6][1]), 15 + 16));
-    float vcur[4][4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) vcur[m][r] = (m < 3 || (kg == 0 && r < 3)) ? vD[m][r] : 0.f;
-
     bf16x8 bq[2][3];
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
       for (int p = 0; p < 3; ++p) bq[s][p] = *reinterpret_cast<const bf16x8*>(tab + p * XTABP + (4 * s + permk) * 256 + j * 16);
+    float vcur[4][4];
+    if constexpr (vec_v) {      // pixel quads per tap -> taps per pixel, through the table (its h fragments are in registers now)
+      float* const vt = reinterpret_cast<float*>(tab + 6 * 64 * 4);
+      X6_ORDER();
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (q < 3 || fq < 4) *reinterpret_cast<f32x4*>(vt + (fq + 16 * q) * XTP + 4 * pq) = (f32x4){vD[q][0], vD[q][1], vD[q][2], vD[q][3]};
+      X6_ORDER();
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float t = vt[(16 * m + 4 * kg + r) * XTP + j];        // rows >= 52 of the last tile lie past the tile: read, never used
+          vcur[m][r] = (m < 3 || (kg == 0 && r < 3)) ? t : 0.f;
+        }
+      X6_ORDER();
+    } else {
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vcur[m][r] = (m < 3 || (kg == 0 && r < 3)) ? vD[m][r] : 0.f;
+    }
     load_h(hreg, nb, nx0, XPR * nph_ + wr);
     load_v(vD, nb, nx0, XPR * nph_ + wr);
     X6_ORDER();
@@ -705,7 +744,8 @@ __global__ __launch_bounds__(XNT) void sepconv_fwd_x6(const float* __restrict__ 
 #pragma unroll
       for (int c = 0; c < XC; ++c) {
         const f32x2 sv = *reinterpret_cast<const f32x2*>(side + (c * XWIN + tslot) * 4 + 2 * wc);
-        *reinterpret_cast<f32x2*>(tailb + (c * XK + fyl) * 2) = (f32x2){sv.x * h50_14, fmaf(sv.y, h50_15, sv.x * h49_15)};
+        tailb[(2 * c) * 64 + lane] = lane < XK ? sv.x * h50_14 : 0.f;
+        tailb[(2 * c + 1) * 64 + lane] = lane < XK ? fmaf(sv.y, h50_15, sv.x * h49_15) : 0.f;
       }
     }
     X6_ORDER();
@@ -751,12 +791,11 @@ __global__ __launch_bounds__(XNT) void sepconv_fwd_x6(const float* __restrict__ 
     for (int c = 0; c < XC; ++c) {
       float sum = 0.f;
 #pragma unroll
-      for (int m = 0; m < 4; ++m)
+      for (int m = 0; m < 4; ++m) {
+        const f32x4 tv = *reinterpret_cast<const f32x4*>(tailb + (2 * c + tcol) * 64 + 16 * m + 4 * kg);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float t = fmaf(tsel, tailb[(c * XK + min(16 * m + 4 * kg + r, XK - 1)) * 2 + tcol], acc[c][m][r]);
-          sum = fmaf(vcur[m][r], t, sum);
-        }
+        for (int r = 0; r < 4; ++r) sum = fmaf(vcur[m][r], fmaf(tsel, tv[r], acc[c][m][r]), sum);
+      }
       sum += __shfl_xor(sum, 16, SAVFI_WAVE);
       sum += __shfl_xor(sum, 32, SAVFI_WAVE);
       o[c] = sum;
@@ -804,12 +843,18 @@ int savfi_sepconv_bwd_x6_launch(const float* in, const float* v, const float* h,
 // forward of the same op (declared in csrc/common.h)
 int savfi_sepconv_fwd_x6_launch(const float* in, const float* v, const float* h, float* out, int B, int Ho, int Wo, int cus,
                                 hipStream_t st) {
-  static uint32_t done = 0;
-  if (int e = savfi_ensure_dynamic_lds((const void*)sepconv_fwd_x6, XLDS, done)) return e;
   const int nph = savfi_cdiv(Ho, XPR), ncol = savfi_cdiv(Wo, XMC);
   const int64_t total = (int64_t)B * ncol * nph;
   const int per_wg = savfi_cdiv(total, cus);
   const int grid = savfi_cdiv(total, per_wg);
-  hipLaunchKernelGGL(sepconv_fwd_x6, dim3(grid), dim3(XNT), XLDS, st, in, v, h, out, B, Ho, Wo, nph, ncol, per_wg);
+  if ((Wo & 3) == 0 && !X6_SCALAR_STORES) {
+    static uint32_t done = 0;
+    if (int e = savfi_ensure_dynamic_lds((const void*)sepconv_fwd_x6<true>, XLDS, done)) return e;
+    hipLaunchKernelGGL(sepconv_fwd_x6<true>, dim3(grid), dim3(XNT), XLDS, st, in, v, h, out, B, Ho, Wo, nph, ncol, per_wg);
+  } else {
+    static uint32_t done = 0;
+    if (int e = savfi_ensure_dynamic_lds((const void*)sepconv_fwd_x6<false>, XLDS, done)) return e;
+    hipLaunchKernelGGL(sepconv_fwd_x6<false>, dim3(grid), dim3(XNT), XLDS, st, in, v, h, out, B, Ho, Wo, nph, ncol, per_wg);
+  }
   return savfi_launch_status();
 }
