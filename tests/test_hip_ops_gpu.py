@@ -853,3 +853,54 @@ def test_reflect_pad_backward_is_the_adjoint_for_every_pad():
         torch.nn.functional.pad(x, (p,) * 4, mode='reflect').backward(gp.double())
         got = hip_ops.reflect_pad_bwd(gp.to(DEV), p)
         assert _rel(got.cpu().double(), x.grad) < 1e-6
+
+
+def test_filters_of_many_layers_in_one_launch_equal_the_single_layer_calls():
+    """savfi_convk_filters_multi_f32 / savfi_conv3x3_filters_multi_f32 (hip_ops._filters_multi): bit-identical to one call per layer,
+    for mixed shapes, task counts and forward-only / backward-only jobs."""
+    g = torch.Generator().manual_seed(21)
+    ws = [torch.randn(*shape, generator=g).to(DEV) for shape in
+          ((64, 64, 3, 3), (4, 32, 6, 3, 3), (51, 64, 3, 3), (2, 128, 64, 3, 3), (192, 192, 3, 3))]
+    wants = [(True, True), (True, False), (False, True), (True, True), (True, True)]
+    for kind, single in (('convk', hip_ops.convk_filters), ('wino', hip_ops.conv3x3_filters)):
+        multi = hip_ops._filters_multi(kind, [(w, f, b) for w, (f, b) in zip(ws, wants)])
+        for w, (f, b), (mf, mb) in zip(ws, wants, multi):
+            hip_ops._prepacked.clear()
+            sf, sb = single(w, f, b)
+            for one, many in ((sf, mf), (sb, mb)):
+                assert (one is None) == (many is None)
+                if one is not None:
+                    assert torch.equal(one.view(-1), many.view(-1)[:one.numel()])
+    w5 = torch.randn(64, 6, 5, 5, generator=g).to(DEV)
+    (mf, mb), = hip_ops._filters_multi('convk', [(w5, True, True)])
+    sf, sb = hip_ops.convk_filters(w5, True, True)
+    assert torch.equal(sf.view(-1), mf.view(-1)[:sf.numel()]) and torch.equal(sb.view(-1), mb.view(-1)[:sb.numel()])
+
+
+def test_filters_prepared_after_an_update_are_found_and_follow_the_weight_version():
+    """hip_ops.filters_after_update: the second update of a list of the same shapes packs what the first one's layers used; a hit
+    needs the same tensor AND version (an in-place change of the fast weight invalidates it)."""
+    g = torch.Generator().manual_seed(22)
+    hip_ops._pack_plans.clear()
+    shapes = ((64, 64, 3, 3), (64,), (128, 64, 3, 3))
+    x = torch.randn(2, 64, 40, 48, generator=g).to(DEV)
+
+    def step():
+        outs = [torch.randn(*s, generator=g).to(DEV) for s in shapes]
+        hip_ops.filters_after_update(outs)
+        return outs
+    outs = step()                                   # first update: no plan yet
+    assert not hip_ops._prepacked
+    y1 = hip_ops.conv_bias_act(x, outs[0], outs[1], 1, 1, 1, 1, 0.0)          # learns: index 0 is packed for the direct kernel
+    outs = step()                                   # second update: packed straight away
+    assert ('convk', outs[0].data_ptr()) in hip_ops._prepacked
+    ref = torch.nn.functional.relu(torch.nn.functional.conv2d(x.double().cpu(), outs[0].double().cpu(), outs[1].double().cpu(), padding=1))
+    y2 = hip_ops.conv_bias_act(x, outs[0], outs[1], 1, 1, 1, 1, 0.0)
+    assert _rel(y2.cpu().double(), ref) < 5e-6
+    with torch.no_grad():
+        outs[0].mul_(2.0)                           # version bump: the prepared filters no longer match
+    assert hip_ops._prepacked_filters('convk', outs[0], True, False) is None
+    y3 = hip_ops.conv_bias_act(x, outs[0], outs[1] * 2, 1, 1, 1, 1, 0.0)
+    assert _rel(y3.cpu().double(), 2 * ref) < 5e-6
+    hip_ops._prepacked.clear()
+    del y1
