@@ -56,7 +56,7 @@
 extern "C" {
 #endif
 
-#define SAVFI_ABI_VERSION 8
+#define SAVFI_ABI_VERSION 9
 
 #define SAVFI_OK            0
 #define SAVFI_E_NULL       (-1)  /* a required pointer is NULL                          */
@@ -358,6 +358,15 @@ int savfi_ca_mlp_bwd_f32(const float* r, const float* s, const float* y, const f
                          void* stream);
 int savfi_ca_apply_f32(const float* a, const float* y, const float* x, const float* ds, float* out, int64_t planes, int hw,
                        void* stream);
+
+/* ----------------------------------------------------------------------------------
+ * Per-plane mean removal of CAIN's input frames (model_utils.py:11-15 sub_mean; cain/model.py:70-94):
+ *   mean[p] = sum_i x[p][i] / hw;  out[p][i] = x[p][i] - mean[p]            x, out [planes][hw] (out may alias x), mean [planes]
+ * Two launches, fixed summation order, no cleared memory (safe inside a captured hipGraph, where ATen's multi-workgroup
+ * reduction is not: csrc/submean.hip).  `workspace`: savfi_sub_mean_workspace_floats(planes, hw) floats, caller-owned.
+ * ---------------------------------------------------------------------------------- */
+int64_t savfi_sub_mean_workspace_floats(int64_t planes, int hw);
+int savfi_sub_mean_f32(const float* x, float* out, float* mean, float* workspace, int64_t planes, int hw, void* stream);
 
 /* ----------------------------------------------------------------------------------
  * Frame staging (data/vimeo_septuplet.py:68-80, data/video.py:44-51: channel swap, HWC->CHW, .float()/255,

@@ -16,7 +16,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_PKG_DIR), "include", "savfi_hip.h")
 
 RULE_SGD, RULE_ADAM, RULE_ADAMAX_LSLR, RULE_ADAMAX_MSGD = 0, 1, 2, 3
 LR_SCALAR, LR_ELEMENT = 0, 1
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _ERRORS = {-1: "SAVFI_E_NULL (a required pointer is NULL)",
            -2: "SAVFI_E_SHAPE (bad or inconsistent dimension)",
@@ -84,6 +84,8 @@ _PROTOTYPES = {
     "savfi_ca_mlp_fwd_f32": [_P] * 7 + [c_int] * 4 + [_P],
     "savfi_ca_mlp_bwd_f32": [_P] * 11 + [c_int] * 4 + [c_float, _P],
     "savfi_ca_apply_f32": [_P] * 5 + [c_int64, c_int, _P],
+    "savfi_sub_mean_workspace_floats": [c_int64, c_int],
+    "savfi_sub_mean_f32": [_P, _P, _P, _P, c_int64, c_int, _P],
     "savfi_frames_u8_to_f32": [_P, _P, c_int64, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float, _P],
     "savfi_upsample2x_window_fwd_f32": [_P, _P] + [c_int] * 12 + [_P],
     "savfi_upsample2x_window_bwd_f32": [_P, _P] + [c_int] * 12 + [_P],

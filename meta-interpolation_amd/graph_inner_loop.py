@@ -25,6 +25,8 @@ W_0 = gamma * theta; the hand-assembled outer gradient gains d/d theta_k = gamma
 
 Not captured (the caller falls back to the eager loop): --second_order, L2F on a plugin with unrouted tensors or T > 1, CPU tensors.
 """
+import contextlib
+
 import torch
 
 from . import _hip, hip_ops, model_utils, utils
@@ -182,26 +184,30 @@ class GraphedInnerLoop:
         self.pool = torch.cuda.graph_pool_handle()
         W = self.W0
         if self.attenuate:
-            self.emb_graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.emb_graph, pool=self.pool):
+            with self._captured('embedding') as g:
                 self.emb_out = self._embedding(W)
+            self.emb_graph = g
         for t in range(self.S):
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=self.pool):
+            with self._captured('step%d' % t) as g:
                 o = self._support_step(W, t)
             self.step_graphs.append(g)
             self.step_out.append(o)
             W = o['W']
             if (t + 1) in need_target:
-                tgph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(tgph, pool=self.pool):
+                with self._captured('target%d' % (t + 1)) as tgph:
                     to = self._target(W, t + 1, with_grad)
                 self.target_graphs[t + 1] = (tgph, to)
         if self.S == 0:
-            tgph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(tgph, pool=self.pool):
+            with self._captured('target0') as tgph:
                 to = self._target(W, 0, with_grad)
             self.target_graphs[0] = (tgph, to)
+
+    @contextlib.contextmanager
+    def _captured(self, tag):
+        """One capture into the shared pool."""
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=self.pool):
+            yield g
 
     # ------------------------------------------------------------------------------------------
     def run_task(self, frames, task_id, importance, accum):

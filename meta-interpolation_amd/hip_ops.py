@@ -209,6 +209,48 @@ def pixel_shuffle(input, scale_factor):
 
 
 # --------------------------------------------------------------------------------------------
+# Per-plane mean removal                              (reference: model_utils.py:11-15 sub_mean)
+# --------------------------------------------------------------------------------------------
+class _SubMean(torch.autograd.Function):
+    """x [N,C,H,W] -> (x - mean_hw(x), mean_hw(x) [N,C,1,1]) on savfi_sub_mean_f32: two launches that add in a fixed order and need
+    no cleared memory.  ATen's mean switches to several workgroups per output plus a hipMemsetAsync'ed semaphore array on large
+    frames, and a memset node of a captured hipGraph only clears in the first replay on ROCm 7.2 (csrc/submean.hip)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.set_materialize_grads(False)
+        x = x.contiguous()
+        _hip.require_cuda(x)
+        N, C, H, W = x.shape
+        ctx.hw, ctx.shape = H * W, tuple(x.shape)
+        out = torch.empty_like(x)
+        mean = torch.empty((N, C, 1, 1), dtype=x.dtype, device=x.device)
+        ws = torch.empty(_workspace_floats("savfi_sub_mean_workspace_floats", N * C, H * W), dtype=x.dtype, device=x.device)
+        lib = _hip.lib()
+        _hip.launch("sub_mean", lambda: _hip.check(lib.savfi_sub_mean_f32(
+            x.data_ptr(), out.data_ptr(), mean.data_ptr(), ws.data_ptr(), N * C, H * W, _hip.current_stream()), "savfi_sub_mean_f32"),
+            nbytes=12 * x.numel())
+        return out, mean
+
+    @staticmethod
+    def backward(ctx, g_out, g_mean):
+        # out = x - m(x), mean = m(x), m linear and self-adjoint up to 1/hw: gx = g_out - m(g_out) + g_mean / hw  (differentiable:
+        # the same Function and ATen arithmetic)
+        gx = None
+        if g_out is not None:
+            gx = _SubMean.apply(g_out)[0]
+        if g_mean is not None:
+            share = (g_mean / ctx.hw).expand(ctx.shape)
+            gx = share if gx is None else gx + share
+        return gx
+
+
+def sub_mean(x):
+    """(x - mean, mean): the per-channel spatial mean removed (reference model_utils.py:11-15)."""
+    return _SubMean.apply(x)
+
+
+# --------------------------------------------------------------------------------------------
 # Fused multi-tensor inner-loop update            (reference: inner_loop_optimizers.py)
 # --------------------------------------------------------------------------------------------
 class _MtUpdate(torch.autograd.Function):

@@ -89,9 +89,9 @@ def extract_top_level_dict(current_dict):
 # small tensor helpers
 # --------------------------------------------------------------------------------------------
 def sub_mean(x):
-    """Remove the per-channel spatial mean; returns (x - mean, mean)  (reference :11-15)."""
-    mean = x.mean(2, keepdim=True).mean(3, keepdim=True)
-    return x - mean, mean
+    """Remove the per-channel spatial mean; returns (x - mean, mean)  (reference :11-15).  One savfi op (fixed summation order,
+    safe inside captured hipGraphs -- ATen's large-frame reduction is not: csrc/submean.hip)."""
+    return hip_ops.sub_mean(x)
 
 
 def _pad_to_multiple(size, shift):

@@ -904,3 +904,69 @@ def test_filters_prepared_after_an_update_are_found_and_follow_the_weight_versio
     assert _rel(y3.cpu().double(), 2 * ref) < 5e-6
     hip_ops._prepacked.clear()
     del y1
+
+
+# --------------------------------------------------------------------------------------------
+# sub_mean (reference model_utils.py:11-15): per-plane mean removal
+# --------------------------------------------------------------------------------------------
+SUB_MEAN_SHAPES = [(1, 3, 64, 64), (2, 3, 37, 45), (1, 3, 720, 1280), (3, 2, 1, 5), (1, 1, 129, 127)]
+
+
+@pytest.mark.parametrize("shape", SUB_MEAN_SHAPES)
+def test_sub_mean_matches_the_two_stage_mean(shape):
+    """float64 reference: mean over H, then over W.  Tolerance: 4 ulp of the mean's magnitude on the mean (fp32 sums of <= 1M
+    terms in blocks of 16384) and on the difference."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(*shape, generator=g) + 0.25
+    ref_mean = x.double().mean(2, keepdim=True).mean(3, keepdim=True)
+    out, mean = hip_ops.sub_mean(x.to(DEV))
+    assert tuple(mean.shape) == (shape[0], shape[1], 1, 1)
+    assert (mean.cpu().double() - ref_mean).abs().max().item() < 5e-7
+    assert (out.cpu().double() - (x.double() - ref_mean)).abs().max().item() < 5e-7
+
+
+def test_sub_mean_gradients_and_double_backward():
+    g = torch.Generator().manual_seed(6)
+    x = torch.rand(2, 3, 9, 11, generator=g)
+    wo, wm = torch.randn(2, 3, 9, 11, generator=g), torch.randn(2, 3, 1, 1, generator=g)
+
+    def ref(t):
+        m = t.mean(2, keepdim=True).mean(3, keepdim=True)
+        return t - m, m
+
+    xs = [x.clone().double().requires_grad_(True), x.clone().to(DEV).requires_grad_(True)]
+    grads = []
+    for t, f in zip(xs, (ref, hip_ops.sub_mean)):
+        o, m = f(t)
+        loss = (o * wo.to(t)).sum() + (m * wm.to(t)).sum() + (o * o).sum() * 0.5
+        gx, = torch.autograd.grad(loss, t, create_graph=True)
+        ggx, = torch.autograd.grad((gx * gx).sum(), t)      # through the backward: second-order MAML differentiates it
+        grads.append((gx.detach().cpu().double(), ggx.detach().cpu().double()))
+    assert _rel(grads[1][0], grads[0][0]) < 1e-5
+    assert _rel(grads[1][1], grads[0][1]) < 1e-5
+    # only the mean is used
+    t = x.clone().to(DEV).requires_grad_(True)
+    gx, = torch.autograd.grad((hip_ops.sub_mean(t)[1] * wm.to(DEV)).sum(), t)
+    assert _rel(gx.cpu(), (wm / (9 * 11)).expand(2, 3, 9, 11)) < 1e-6
+
+
+def test_sub_mean_in_a_replayed_graph_follows_its_inputs():
+    """The reason this op exists: at 3 x 720 x 1280 ATen's x.mean(2) runs several workgroups per output behind a hipMemsetAsync'ed
+    semaphore array, and a memset node of a captured hipGraph clears only in the graph's first launch on ROCm 7.2
+    (tools/graph_memset_probe.py) -- from the second replay on the captured mean is stale.  The savfi op is replayed with new frame
+    contents and must match its own eager result bit for bit every time."""
+    x = torch.rand(1, 3, 720, 1280, device=DEV)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        hip_ops.sub_mean(x)
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out, mean = hip_ops.sub_mean(x)
+    for it in range(4):
+        x.uniform_(0.0, 1.0 + it)
+        graph.replay()
+        want_out, want_mean = hip_ops.sub_mean(x)
+        assert torch.equal(mean, want_mean) and torch.equal(out, want_out), it
+        assert abs(mean.mean().item() - (1.0 + it) / 2) < 1e-2

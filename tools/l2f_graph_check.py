@@ -38,6 +38,9 @@ for it in range(3 if 0 in res else 0):
         d = (res[1][it][k] - v).abs().max().item() / max(v.abs().max().item(), 1e-30)
         if d > worst[1]: worst = (k, d)
     print("it", it, "worst outer-grad rel diff graph vs eager:", worst)
+    bad = [(k, (res[1][it][k] - v).abs().max().item() / max(v.abs().max().item(), 1e-30)) for k, v in res[0][it].items() if k in res[1][it]]
+    bad = [(k, d) for k, d in bad if not (d < 1e-3)]
+    print("   tensors off by > 1e-3:", len(bad), "of", len(res[0][it]), [(k[-50:], float('%.3g' % d)) for k, d in bad[:12]])
 
 for it in range(3 if 0 in snaps else 0):
     rows = []
