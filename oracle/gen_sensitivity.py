@@ -18,6 +18,9 @@ reference's own CUDA kernels vs its CPU kernels.  This script measures that: it 
     sepflip: float32, SepConv plugin only: the 51-tap separable op (forward and gradients) evaluated on spatially flipped
            operands with reversed tap order -- the same op, its 2601-term sums in the opposite order (the conv2d variants above
            leave the op's own rounding untouched; a build that changes the op's kernels perturbs exactly this)
+    meanflip: float32, CAIN plugin only: sub_mean's per-channel mean taken over W first, then over H (the reference: H, then W) -- the
+           same mean, rounded differently in its last bit; the frames entering the network move by one ulp (a build that computes
+           the mean with its own kernel, csrc/submean.hip, perturbs exactly this)
 
 and stores, per case and phase, the deviation of perm / perm2 / f64 from base in exactly the normalisation
 the GPU parity tests use (loss: relative; preds: mean |.|; PSNR / SSIM: absolute; fingerprints: relative to
@@ -43,7 +46,7 @@ from meta_interpolation_amd import synthetic  # noqa: E402
 CASES = ['voxelflow_metasgd_adamax_2step', 'sepconv_metasgd_adamax_2step', 'cain_lslr_adam_1step',
          'voxelflow_lslr_sgd_2step', 'voxelflow_script_metasgd_adam_1step', 'sepconv_lslr_sgd_2step',
          'superslomo_lslr_sgd_2step', 'c1_cain_lslr_sgd', 'sepconv_msl_learnable_2step', 'cain_l2f', 'rrin_lslr_sgd_2step']
-VARIANTS = ['perm', 'perm2', 'f64', 'sepflip']
+VARIANTS = ['perm', 'perm2', 'f64', 'sepflip', 'meanflip']
 
 _ORIG_CONV2D = torch.nn.functional.conv2d
 
@@ -83,6 +86,11 @@ class _SepconvFlipped:
         return O.SepconvCPU.apply(inp.flip(2, 3), v.flip(1, 2, 3), h.flip(1, 2, 3)).flip(2, 3)
 
 
+def _sub_mean_flipped(x):
+    mean = x.mean(3, keepdim=True).mean(2, keepdim=True)
+    return x - mean, mean
+
+
 def run_variant(name, variant, phase):
     model, H, W, B, over = G.SYSTEM_CASES[name]
     args = G.reference_args(model=model, batch_size=B, **over)
@@ -112,6 +120,10 @@ def run_variant(name, variant, phase):
         if variant == 'sepflip' and model == 'sepconv':
             import sepconv.sepconv_op.sepconv as ref_op
             ref_op.FunctionSepconv = _SepconvFlipped
+        if variant == 'meanflip' and model == 'cain':
+            import cain.model as ref_cain
+            ref_cain._savfi_orig_sub_mean = ref_cain.sub_mean
+            ref_cain.sub_mean = _sub_mean_flipped
         rec = dict(n_live=[], grad_fp=[], weight_fp=[], outer_grad_fp={})
         G.observe(system, rec)
         if phase == 'train':
@@ -126,6 +138,10 @@ def run_variant(name, variant, phase):
         if model == 'sepconv':
             import sepconv.sepconv_op.sepconv as ref_op
             ref_op.FunctionSepconv = O.SepconvCPU
+        if model == 'cain':
+            import cain.model as ref_cain
+            if hasattr(ref_cain, '_savfi_orig_sub_mean'):
+                ref_cain.sub_mean = ref_cain._savfi_orig_sub_mean
     return dict(loss=float(losses['loss'].item()), preds=torch.stack([p.squeeze(0) for p in preds]).double().numpy(),
                 psnr=float(metrics['psnr'].avg), ssim=float(metrics['ssim'].avg), rec=rec)
 

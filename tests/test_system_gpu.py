@@ -73,6 +73,26 @@ def tolerances(name, phase='train'):
     return tol
 
 
+
+def knee_allowance(g, phase, step, key, tol_g):
+    """Absolute allowance on an updated weight's fingerprint sums under an Adam-type inner rule, derived from the GRADIENT gate.
+    Those rules move an element by lr * g / (|g| + 1e-8) (first step: m-hat = g, sqrt(v-hat) = |g|; Adamax: u = |g|): for |g| >> 1e-8
+    the step is +-lr whatever the rounding of g, but an element whose reference gradient is exactly 0 (a dead ReLU unit) or ~1e-9
+    sits on the knee, where a gradient error d moves the step by lr * d / (d + 1e-8).  The gradient gate admits d = tol_g x (the
+    tensor's gradient abs-sum); concentrated in ONE element that is the allowance returned here (several knee elements would add
+    up to more: not granted).  Seen as 2.1e-6 = 0.02 lr on a 12-element channel-attention bias (abs-sum 0.116, gate 1e-5 relative)
+    of cain_lslr_adam_1step when sub_mean moved to csrc/submean.hip and the frames entering the network moved by one ulp; the
+    fixture shows an exactly-zero element in that tensor's reference gradient.  SGD-type rules are smooth: 0."""
+    args = parse_case_args(g)
+    if args.get('optimizer') not in ('Adam', 'Adamax'):
+        return 0.0
+    keys = list(g['%s_grad_fp_%d_keys' % (phase, step)])
+    if key not in keys:
+        return 0.0
+    d = tol_g * abs(float(g['%s_grad_fp_%d' % (phase, step)][keys.index(key)][1]))
+    return float(args['inner_lr']) * d / (d + 1e-8)
+
+
 TOL = {name: tolerances(name) for name in SYSTEM}
 
 
@@ -113,7 +133,7 @@ def test_iteration_matches_reference_fixture(name, phase):
         keys = list(g['%s_weight_fp_%d_keys' % (phase, i)])
         assert sorted(d) == keys
         for k, row in zip(keys, g['%s_weight_fp_%d' % (phase, i)]):
-            assert_fp_close(d[k], row, tol['w'], (name, 'w', i, k))
+            assert_fp_close(d[k], row, tol['w'], (name, 'w', i, k), extra_abs=knee_allowance(g, phase, i, k, tol['g']))
     for i, d in enumerate(rec['grad_fp']):
         for k, row in zip(list(g['%s_grad_fp_%d_keys' % (phase, i)]), g['%s_grad_fp_%d' % (phase, i)]):
             assert_fp_close(d[k], row, tol['g'], (name, 'g', i, k))
@@ -145,7 +165,7 @@ def test_iteration_matches_reference_fixture_under_default_miopen_solvers(name):
     assert abs(float(metrics['ssim'].avg) - float(g['train_ssim'])) < tol['ssim']
     for i, d in enumerate(rec['weight_fp']):
         for k, row in zip(list(g['train_weight_fp_%d_keys' % i]), g['train_weight_fp_%d' % i]):
-            assert_fp_close(d[k], row, tol['w'], (name, 'w', i, k))
+            assert_fp_close(d[k], row, tol['w'], (name, 'w', i, k), extra_abs=knee_allowance(g, 'train', i, k, tol['g']))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -422,7 +442,7 @@ def test_weight_gradients_on_a_side_stream_match_reference_fixture(name):
             assert_fp_close(d[k], row, tol['g'], (name, 'g', i, k))
     for i, d in enumerate(rec['weight_fp']):
         for k, row in zip(list(g['train_weight_fp_%d_keys' % i]), g['train_weight_fp_%d' % i]):
-            assert_fp_close(d[k], row, tol['w'], (name, 'w', i, k))
+            assert_fp_close(d[k], row, tol['w'], (name, 'w', i, k), extra_abs=knee_allowance(g, 'train', i, k, tol['g']))
 
 
 @pytest.mark.parametrize("optimizer,metasgd", [("Adam", False), ("Adamax", True)])
@@ -640,6 +660,12 @@ def test_lockstep_equals_the_sequential_loop(model, over, lockstep_for):
             continue
         assert k in g1, k
         lim = 5e-2 if (sign_like or model == 'voxelflow') else 2e-3
+        if over.get('attenuate'):
+            # L2F: the attenuation is a function of the embedding pass's gradients, and the reference's own outer gradients move
+            # by 2.65e-3 under another conv summation order on the cain_l2f fixture (tests/golden/sensitivity.npz, `outer`; its 16x16
+            # maps run on MIOpen here, whose solver for a batch of 4 is not the one for a single sample).  Seen: 3.5e-3 on headConv
+            # in one process of five, < 2e-3 in the others; gate at 3 x the reference's self-spread.
+            lim = max(lim, 3 * float(_SENS['cain_l2f/train'][:, _SENS_COL['outer']].max()))
         assert (g1[k] - v).abs().sum().item() <= lim * v.abs().sum().item() + 1e-12, (k, (g1[k] - v).abs().sum().item(), v.abs().sum().item())
 
 

@@ -33,3 +33,25 @@ for nb in (4, 60, 1024, 15360, 1 << 20):
     for lead in (0, 1):
         for trail in (0, 1):
             run(nb, lead, trail)
+
+# ---- the ATen reduction that depends on such a node: x.mean(2) of a 3 x 720 x 1280 frame (several workgroups per output, the
+# last one -- found through the memset semaphores -- writes the result), followed by .mean(3) as in the reference's sub_mean ---------
+x = torch.rand(1, 3, 720, 1280, device='cuda')
+def two_stage():
+    a = x.mean(2, keepdim=True)
+    return [a, a.mean(3, keepdim=True)]
+s = torch.cuda.Stream()
+with torch.cuda.stream(s):
+    for _ in range(2): two_stage()
+torch.cuda.synchronize()
+g = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g):
+    outs = two_stage()
+for it in range(4):
+    if it: x.uniform_(0.0, 1.0 + it)
+    torch.cuda.synchronize()
+    g.replay(); torch.cuda.synchronize()
+    got = [o.clone() for o in outs]
+    want = two_stage(); torch.cuda.synchronize()
+    print("captured x.mean(2).mean(3), replay %d (%s frame): max |graph - eager| = %s" % (
+        it, "new" if it else "captured", ["%.2e" % float((a - b).abs().max()) for a, b in zip(got, want)]), flush=True)
