@@ -32,10 +32,11 @@ import torch
 from . import _hip, hip_ops, model_utils, utils
 
 
-# Graphed L2F is OPT-IN (SAVFI_GRAPH_L2F=1): it matches the eager loop and the reference fixtures at 64x64 and 128x192 over
-# several meta-iterations (tests/test_system_gpu.py), but at 1280x720 the THIRD replay of its graph set returns garbage (the
-# parameters entering it are bit-identical to the eager run's; profiles/r03_graphed_l2f_720p.txt) -- unresolved, so config C5 keeps
-# the eager loop, whose numbers are the fixture-checked ones.
+# Graphed L2F is OPT-IN (SAVFI_GRAPH_L2F=1).  It matches the eager loop and the reference fixtures from 64x64 to 1280x720
+# (tests/test_system_gpu.py, tests/test_fullsize_gpu.py::test_graphed_cain_720p_follows_changing_frames,
+# profiles/r03_graphed_l2f_720p.txt) -- the garbage its third replay returned at 720p earlier this round was a stale captured
+# mean (ATen's x.mean(2) behind a hipGraph memset node, which only clears once on ROCm 7.2: csrc/submean.hip) -- but config C5 is
+# GPU-bound and gains nothing from it (6.93 vs 6.91 steps/s), so the default keeps the eager loop, where kernels can be timed in place.
 import os as _os
 GRAPH_L2F = bool(_os.environ.get('SAVFI_GRAPH_L2F'))
 
