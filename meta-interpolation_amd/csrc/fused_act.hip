@@ -18,20 +18,30 @@ constexpr int NT = 256, CHUNK = 4096;
 
 __device__ __forceinline__ float act(float x, float slope) { return x > 0.f ? x : slope * x; }
 
+// Planes whose size is not a multiple of 4 floats (SepConv's windowed tail: 137 x 233) start at any 4-byte phase: every chunk
+// peels 0-3 leading elements to reach a 16-byte boundary, streams float4s, and finishes with the 0-3 that are left.  `phase_ok`: all
+// operand pointers share their low four address bits (the host checks), so one peel aligns them all; otherwise scalar.
+__device__ __forceinline__ int peel_to_16(const void* p, int count) {
+  const int head = (int)((16u - ((unsigned)(uintptr_t)p & 15u)) & 15u) >> 2;
+  return head < count ? head : count;
+}
+
 __global__ __launch_bounds__(NT) void bias_act_fwd(float* __restrict__ z, const float* __restrict__ bias, int C, int HW,
-                                                   int chunks, float slope, int vec_ok) {
+                                                   int chunks, float slope, int phase_ok) {
   const int plane = blockIdx.x / chunks, ch = blockIdx.x - plane * chunks;
   const float b = bias[plane % C];
   float* p = z + (size_t)plane * HW;
   const int base = ch * CHUNK, end = min(base + CHUNK, HW);
-  if (vec_ok) {
-    const int vend = base + ((end - base) & ~3);
-    for (int e = base + 4 * threadIdx.x; e < vend; e += 4 * NT) {
+  if (phase_ok) {
+    const int vbeg = base + peel_to_16(p + base, end - base);
+    const int vend = vbeg + ((end - vbeg) & ~3);
+    if (base + (int)threadIdx.x < vbeg) p[base + threadIdx.x] = act(p[base + threadIdx.x] + b, slope);
+    for (int e = vbeg + 4 * threadIdx.x; e < vend; e += 4 * NT) {
       float4 v = *reinterpret_cast<float4*>(p + e);
       v.x = act(v.x + b, slope); v.y = act(v.y + b, slope); v.z = act(v.z + b, slope); v.w = act(v.w + b, slope);
       *reinterpret_cast<float4*>(p + e) = v;
     }
-    for (int e = vend + threadIdx.x; e < end; e += NT) p[e] = act(p[e] + b, slope);
+    if (vend + (int)threadIdx.x < end) p[vend + threadIdx.x] = act(p[vend + threadIdx.x] + b, slope);
   } else {
     for (int e = base + threadIdx.x; e < end; e += NT) p[e] = act(p[e] + b, slope);
   }
@@ -39,23 +49,35 @@ __global__ __launch_bounds__(NT) void bias_act_fwd(float* __restrict__ z, const 
 
 __global__ __launch_bounds__(NT) void bias_act_bwd(const float* __restrict__ gy, const float* __restrict__ y,
                                                    float* __restrict__ gz, float* __restrict__ partial, int C, int HW,
-                                                   int chunks, float slope, int vec_ok) {
+                                                   int chunks, float slope, int phase_ok) {
   __shared__ float red[NT / SAVFI_WAVE];
   const int plane = blockIdx.x / chunks, ch = blockIdx.x - plane * chunks;
   const size_t off = (size_t)plane * HW;
   const int base = ch * CHUNK, end = min(base + CHUNK, HW);
   float acc = 0.f;
   auto d = [slope](float g, float out) { return out > 0.f ? g : slope * g; };
-  if (vec_ok) {
-    const int vend = base + ((end - base) & ~3);
-    for (int e = base + 4 * threadIdx.x; e < vend; e += 4 * NT) {
+  if (phase_ok) {
+    const int vbeg = base + peel_to_16(gy + off + base, end - base);
+    const int vend = vbeg + ((end - vbeg) & ~3);
+    if (base + (int)threadIdx.x < vbeg) {
+      const int e = base + threadIdx.x;
+      const float r = d(gy[off + e], y[off + e]);
+      if (gz) gz[off + e] = r;
+      acc += r;
+    }
+    for (int e = vbeg + 4 * threadIdx.x; e < vend; e += 4 * NT) {
       const float4 g = *reinterpret_cast<const float4*>(gy + off + e);
       const float4 o = *reinterpret_cast<const float4*>(y + off + e);
       const float4 r = make_float4(d(g.x, o.x), d(g.y, o.y), d(g.z, o.z), d(g.w, o.w));
       if (gz) *reinterpret_cast<float4*>(gz + off + e) = r;
       acc += (r.x + r.y) + (r.z + r.w);
     }
-    for (int e = vend + threadIdx.x; e < end; e += NT) { const float r = d(gy[off + e], y[off + e]); if (gz) gz[off + e] = r; acc += r; }
+    if (vend + (int)threadIdx.x < end) {
+      const int e = vend + threadIdx.x;
+      const float r = d(gy[off + e], y[off + e]);
+      if (gz) gz[off + e] = r;
+      acc += r;
+    }
   } else {
     for (int e = base + threadIdx.x; e < end; e += NT) { const float r = d(gy[off + e], y[off + e]); if (gz) gz[off + e] = r; acc += r; }
   }
@@ -86,8 +108,8 @@ extern "C" int savfi_bias_act_fwd_f32(float* z, const float* bias, int N, int C,
   const int chunks = savfi_cdiv(HW, CHUNK);
   const int64_t blocks = (int64_t)N * C * chunks;
   if (blocks > 0x7fffffffLL) return SAVFI_E_TOOBIG;
-  const int vec_ok = (((uintptr_t)z & 15u) == 0) && (HW % 4 == 0);
-  hipLaunchKernelGGL(bias_act_fwd, dim3((unsigned)blocks), dim3(NT), 0, (hipStream_t)stream, z, bias, C, HW, chunks, slope, vec_ok);
+  const int phase_ok = 1;      // a single operand: the peel aligns it
+  hipLaunchKernelGGL(bias_act_fwd, dim3((unsigned)blocks), dim3(NT), 0, (hipStream_t)stream, z, bias, C, HW, chunks, slope, phase_ok);
   return savfi_launch_status();
 }
 
@@ -103,9 +125,11 @@ extern "C" int savfi_bias_act_bwd_f32(const float* gy, const float* y, float* gz
   const int chunks = savfi_cdiv(HW, CHUNK);
   const int64_t blocks = (int64_t)N * C * chunks;
   if (blocks > 0x7fffffffLL) return SAVFI_E_TOOBIG;
-  const int vec_ok = ((((uintptr_t)gy | (uintptr_t)y | (uintptr_t)gz) & 15u) == 0) && (HW % 4 == 0);   // NULL gz is "aligned"
+  // one peel aligns all operands when they share their low address bits (a NULL gz takes gy's)
+  const unsigned lo = (unsigned)(uintptr_t)gy & 15u;
+  const int phase_ok = ((unsigned)(uintptr_t)y & 15u) == lo && (!gz || ((unsigned)(uintptr_t)gz & 15u) == lo) && (lo & 3u) == 0;
   hipLaunchKernelGGL(bias_act_bwd, dim3((unsigned)blocks), dim3(NT), 0, (hipStream_t)stream, gy, y, gz, gbias ? scratch : nullptr,
-                     C, HW, chunks, slope, vec_ok);
+                     C, HW, chunks, slope, phase_ok);
   if (int e = savfi_launch_status()) return e;
   if (gbias) {
     hipLaunchKernelGGL(bias_grad_finish, dim3(C), dim3(64), 0, (hipStream_t)stream, scratch, gbias, N, C, chunks);

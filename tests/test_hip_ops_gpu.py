@@ -970,3 +970,49 @@ def test_sub_mean_in_a_replayed_graph_follows_its_inputs():
         want_out, want_mean = hip_ops.sub_mean(x)
         assert torch.equal(mean, want_mean) and torch.equal(out, want_out), it
         assert abs(mean.mean().item() - (1.0 + it) / 2) < 1e-2
+
+
+# --------------------------------------------------------------------------------------------
+# bias + activation epilogue kernels on planes that are not a multiple of 4 floats (SepConv's windowed tail: 137 x 233)
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,C,H,W", [(2, 5, 137, 233), (1, 3, 7, 9), (3, 2, 1, 1), (2, 4, 64, 66), (1, 2, 129, 65)])
+@pytest.mark.parametrize("slope", [0.0, 0.2, 1.0])
+@pytest.mark.parametrize("shift", [0, 1, 3])
+def test_bias_act_kernels_on_odd_planes(N, C, H, W, slope, shift):
+    """savfi_bias_act_fwd_f32 / savfi_bias_act_bwd_f32 straight through the C ABI, operands starting `shift` floats past an
+    aligned address (all three the same shift -> vector body behind a peel; gz shifted differently -> scalar path).  The
+    activation gradient is exact; the bias gradient is a sum of up to 64k terms: 1e-5 of its abs-sum scale."""
+    lib = _hip.lib()
+    g = torch.Generator().manual_seed(9)
+    n = N * C * H * W
+
+    def shifted(t, s):
+        buf = torch.empty(n + 8, device=DEV)
+        view = buf[s:s + n]
+        view.copy_(t.reshape(-1).to(DEV))
+        return buf, view
+
+    z = torch.randn(N, C, H, W, generator=g)
+    b = torch.randn(C, generator=g)
+    want = z + b.view(1, C, 1, 1)
+    want = torch.where(want > 0, want, slope * want)
+    zb, zv = shifted(z, shift)
+    _hip.check(lib.savfi_bias_act_fwd_f32(zv.data_ptr(), b.to(DEV).data_ptr(), N, C, H * W, slope, _hip.current_stream()), "fwd")
+    assert torch.equal(zv.cpu().view(N, C, H, W), want)
+
+    gy = torch.randn(N, C, H, W, generator=g)
+    y = torch.randn(N, C, H, W, generator=g)
+    want_gz = torch.where(y > 0, gy, slope * gy)
+    for gz_shift in (shift, (shift + 1) % 4):
+        _, gyv = shifted(gy, shift)
+        _, yv = shifted(y, shift)
+        gzb = torch.zeros(n + 8, device=DEV)
+        gzv = gzb[gz_shift:gz_shift + n]
+        gb = torch.empty(C, device=DEV)
+        scratch = torch.empty(int(lib.savfi_bias_act_scratch_floats(N, C, H * W)), device=DEV)
+        _hip.check(lib.savfi_bias_act_bwd_f32(gyv.data_ptr(), yv.data_ptr(), gzv.data_ptr(), gb.data_ptr(), scratch.data_ptr(),
+                                              N, C, H * W, slope, _hip.current_stream()), "bwd")
+        assert torch.equal(gzv.cpu().view(N, C, H, W), want_gz)
+        assert float(gzb[:gz_shift].abs().sum()) == 0 and float(gzb[gz_shift + n:].abs().sum()) == 0      # nothing outside
+        ref = want_gz.double().sum((0, 2, 3))
+        assert (gb.cpu().double() - ref).abs().max().item() <= 1e-5 * want_gz.double().abs().sum((0, 2, 3)).max().item() + 1e-6
