@@ -16,7 +16,7 @@ from meta_interpolation_amd.inner_loop_optimizers import LSLRGradientDescentLear
 from meta_interpolation_amd.meta_learning_system import SceneAdaptiveInterpolation
 from oracle import rules as orules
 from tests.helpers import fp as helpers_fp
-from tests.helpers import assert_fp_close, build_plugin, build_system, fp, golden, observe, parse_case_args
+from tests.helpers import FP_ATOL, assert_fp_close, build_plugin, build_system, fp, golden, observe, parse_case_args
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -209,9 +209,15 @@ def test_teacher_forced_steps_meet_the_contract(name):
             loss_g = system._support_loss(frames_gpu, t, Wg, step)
             next_g = system.apply_inner_loop_update(loss_g, Wg, False, step)
             assert set(next_g) <= set(next_o) and len(next_g) > 0
+            grads_o = dict(zip(fast_o.keys(), go))
             for k, v in next_g.items():
                 want = next_o[k].detach()
-                assert_fp_close(fp(v), fp(want), CONTRACT['w'], (name, 'teacher-forced w', t, step, k))
+                knee = 0.0
+                if opt in ('Adam', 'Adamax') and grads_o.get(k) is not None:
+                    # the knee of g / (|g| + 1e-8): see knee_allowance (here from the oracle's own gradient of this step)
+                    d = CONTRACT['g'] * float(grads_o[k].detach().abs().sum())
+                    knee = float(over['inner_lr']) * d / (d + 1e-8)
+                assert_fp_close(fp(v), fp(want), CONTRACT['w'], (name, 'teacher-forced w', t, step, k), extra_abs=knee)
                 # an element that moved the other way: more than half a full step (the largest move in its tensor) from
                 # where the oracle put it.  (Measured against the tensor's step size, not the element's own move: elements with
                 # an exactly-zero oracle gradient -- dead ReLU channels -- do not move at all.)
@@ -666,7 +672,9 @@ def test_lockstep_equals_the_sequential_loop(model, over, lockstep_for):
             # maps run on MIOpen here, whose solver for a batch of 4 is not the one for a single sample).  Seen: 3.5e-3 on headConv
             # in one process of five, < 2e-3 in the others; gate at 3 x the reference's self-spread.
             lim = max(lim, 3 * float(_SENS['cain_l2f/train'][:, _SENS_COL['outer']].max()))
-        assert (g1[k] - v).abs().sum().item() <= lim * v.abs().sum().item() + 1e-12, (k, (g1[k] - v).abs().sum().item(), v.abs().sum().item())
+        # absolute floor = helpers.FP_ATOL: CAIN's channel-attention squeeze layers (conv_du.0: 12 x 192 weights, 12 biases) have gradient
+        # abs-sums of 2e-7 .. 5e-7 where the body convolutions have 1e+1 -- sums of O(1) activations at fp32 leave 1e-9 of noise there
+        assert (g1[k] - v).abs().sum().item() <= lim * v.abs().sum().item() + FP_ATOL, (k, (g1[k] - v).abs().sum().item(), v.abs().sum().item())
 
 
 @pytest.mark.parametrize("name", ['sepconv_msl_learnable_2step', 'voxelflow_lslr_sgd_2step', 'voxelflow_metasgd_adamax_2step',
