@@ -1136,6 +1136,29 @@ def reflect_pad_bwd(gp, pad):
     return gx
 
 
+class _ReflectPad(torch.autograd.Function):
+    """nn.ReflectionPad2d(pad): ATen's forward kernel, the adjoint as ONE gather launch (savfi_reflect_pad_bwd_f32) where ATen's
+    reflection_pad2d_backward zero-fills its result and scatters with atomics (two launches, order-dependent sums) -- the layers
+    whose maps are too small for the mirrored staging of the direct kernels (CAIN at 64x64: 252 pads per meta-iteration)."""
+
+    @staticmethod
+    def forward(ctx, x, pad):
+        ctx.pad = int(pad)
+        return torch.nn.functional.pad(x, (ctx.pad,) * 4, mode='reflect')
+
+    @staticmethod
+    def backward(ctx, g):
+        return reflect_pad_bwd(g, ctx.pad), None
+
+
+def reflect_pad(x, pad):
+    """nn.ReflectionPad2d(pad)(x).  First-order passes on CUDA tensors take the gather adjoint; --second_order (whose backward
+    must itself be differentiable) and CPU tensors stay on ATen."""
+    if double_backward() or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4:
+        return torch.nn.functional.pad(x, (int(pad),) * 4, mode='reflect')
+    return _ReflectPad.apply(x, int(pad))
+
+
 def convk_reflect_eligible(x, weight, pad):
     """MetaConvNorm (ReflectionPad2d(pad) + K x K convolution, K = 2 pad + 1) as ONE direct convolution that mirrors the border
     while it stages its tile?  Where the layer would take the direct kernel anyway (forward, data gradient and weight gradient

@@ -251,7 +251,7 @@ class MetaConvNorm(nn.Module):
             pad = self.reflection_pad.padding[0]
             if hip_ops.convk_reflect_eligible(x, weight, pad):
                 return self.conv(x, params=sub, act_slope=act_slope, padding=pad, reflect=True)
-        return self.conv(self.reflection_pad(x), params=sub, act_slope=act_slope)
+        return self.conv(hip_ops.reflect_pad(x, self.reflection_pad.padding[0]), params=sub, act_slope=act_slope)
 
 
 _META_TYPES = ()

@@ -1016,3 +1016,20 @@ def test_bias_act_kernels_on_odd_planes(N, C, H, W, slope, shift):
         assert float(gzb[:gz_shift].abs().sum()) == 0 and float(gzb[gz_shift + n:].abs().sum()) == 0      # nothing outside
         ref = want_gz.double().sum((0, 2, 3))
         assert (gb.cpu().double() - ref).abs().max().item() <= 1e-5 * want_gz.double().abs().sum((0, 2, 3)).max().item() + 1e-6
+
+
+@pytest.mark.parametrize("shape,pad", [((2, 5, 16, 16), 1), ((1, 3, 7, 9), 2), ((3, 2, 2, 2), 1), ((1, 4, 33, 18), 3)])
+def test_reflect_pad_op_has_atens_values_and_gradient(shape, pad):
+    """hip_ops.reflect_pad = nn.ReflectionPad2d forward (ATen) with the gather adjoint: the gradient of a weighted sum against
+    autograd through F.pad, on maps down to 2 x 2 (every border position folds twice).  Exact up to summation order: 1e-6."""
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(*shape, generator=g).to(DEV)
+    wgt = torch.randn(shape[0], shape[1], shape[2] + 2 * pad, shape[3] + 2 * pad, generator=g).to(DEV)
+    a = x.clone().requires_grad_(True)
+    b = x.clone().requires_grad_(True)
+    ya = hip_ops.reflect_pad(a, pad)
+    yb = F.pad(b, (pad,) * 4, mode='reflect')
+    assert torch.equal(ya, yb)
+    ga, = torch.autograd.grad((ya * wgt).sum(), a)
+    gb, = torch.autograd.grad((yb * wgt).sum(), b)
+    assert _rel(ga, gb) < 1e-6
