@@ -236,7 +236,7 @@ class GraphedInnerLoop:
             dst.copy_(pick(i))
         with torch.no_grad():
             if T == 1:
-                torch._foreach_copy_([self.W0[k] for k in self.routed], [self.theta[k] for k in self.routed])
+                hip_ops.mt_copy([self.W0[k] for k in self.routed], [self.theta[k] for k in self.routed])
             else:
                 for k in self.routed:
                     self.W0[k].copy_(self.theta[k].unsqueeze(0).expand_as(self.W0[k]))
@@ -252,8 +252,7 @@ class GraphedInnerLoop:
             with torch.enable_grad():
                 gamma = (1 - sysm.gamma_mult * sysm.attenuator(self.emb_out.detach())).clamp(0, 1)
             with torch.no_grad():
-                scaled = hip_ops.mt_scale(gamma.detach(), [self.theta[k].detach() for k in self.routed])
-                torch._foreach_copy_([self.W0[k] for k in self.routed], scaled)
+                hip_ops.mt_scale_into(gamma, [self.theta[k] for k in self.routed], [self.W0[k] for k in self.routed])
         # replay: S support steps, target passes where needed
         for t in range(self.S):
             self.step_graphs[t].replay()
@@ -281,7 +280,7 @@ class GraphedInnerLoop:
                     w = weights[t]
                     gs = to['g_routed']
                     if suffix is None:
-                        suffix = scaled(gs, w) if not (isinstance(w, float) and w == 1.0) else [g.clone() for g in gs]
+                        suffix = scaled(gs, w) if not (isinstance(w, float) and w == 1.0) else hip_ops.mt_clone(gs)
                     else:
                         torch._foreach_add_(suffix, scaled(gs, w))
                     own = [(k, g) for k, g in zip(self.unrouted, to['g_own']) if g is not None]
@@ -322,9 +321,10 @@ class OuterGradAccumulator:
         have = [(self.param[k], g) for k, g in zip(keys, grads) if k in self.param]
         if have:
             torch._foreach_add_([a for a, _ in have], [g for _, g in have])
-        for k, g in zip(keys, grads):
-            if k not in self.param:
-                self.param[k] = g.clone()
+        fresh = [(k, g) for k, g in zip(keys, grads) if k not in self.param]
+        if fresh:
+            for (k, _), c in zip(fresh, hip_ops.mt_clone([g for _, g in fresh])):
+                self.param[k] = c
 
     def add_lr_grads(self, gl, t, suffix):
         """dL/d lr_t = <suffix, dir_t> (scalar per tensor for LSLR, element-wise for Meta-SGD)."""
@@ -418,5 +418,5 @@ class OuterGradAccumulator:
             for p, g in pairs:
                 p.grad = g
         elif pairs:
-            torch._foreach_copy_([into[p] for p, _ in pairs], [g.view_as(into[p]) for p, g in pairs])
+            hip_ops.mt_copy([into[p] for p, _ in pairs], [g.view_as(into[p]) for p, g in pairs])
         return [p for p, _ in pairs]

@@ -454,6 +454,54 @@ def mt_scale(gamma, weights):
     return list(_MtScale.apply(gamma.contiguous(), *ws))
 
 
+_ONES = {}
+
+
+def _ones(n, device):
+    t = _ONES.get(device)
+    if t is None or t.numel() < n:
+        t = _ONES[device] = torch.ones(max(int(n), 1024), dtype=torch.float32, device=device)
+    return t
+
+
+def mt_scale_into(gamma, weights, outs):
+    """outs[i] <- gamma[i] * weights[i] without autograd, into tensors the caller owns (the static W_0 buffers of the hipGraph loop)."""
+    ws = [w.detach() if w.is_contiguous() else w.detach().contiguous() for w in weights]
+    outs = [o.detach() for o in outs]
+    gamma = gamma.detach().contiguous()
+    _hip.require_cuda(gamma, *ws, *outs)
+    assert len(ws) == len(outs) and all(o.is_contiguous() and o.numel() == w.numel() and o.dtype == w.dtype for o, w in zip(outs, ws))
+    lib = _hip.lib()
+    args = (len(ws), _hip.ptr_array(ws), gamma.data_ptr(), _hip.ptr_array(outs), _hip.i64_array([w.numel() for w in ws]),
+            _hip.current_stream())
+    _hip.launch("mt_scale", lambda: _hip.check(lib.savfi_mt_scale_f32(*args), "savfi_mt_scale_f32"))
+
+
+def mt_copy(dsts, srcs):
+    """dsts[i] <- srcs[i] for lists of float32 CUDA tensors of equal sizes: ceil(n / 48) launches of the multi-tensor scale kernel
+    with gamma = 1 (x * 1.0f is x, bit for bit) where torch._foreach_copy_ issues one device memcpy per tensor -- 494 of them per
+    task for CAIN, twice per meta-iteration of the hipGraph loop (theta -> W_0, first gradient -> accumulator): ~1000 host-bound
+    launches of a 26 ms iteration at 64 x 64."""
+    dsts, srcs = list(dsts), list(srcs)
+    if not dsts:
+        return
+    plain = all(d.is_cuda and d.dtype == torch.float32 and s.dtype == torch.float32 and s.device == d.device and d.is_contiguous()
+                and d.numel() == s.numel() and d.numel() > 0 for d, s in zip(dsts, srcs))
+    if not plain:
+        with torch.no_grad():
+            torch._foreach_copy_(dsts, [s.view_as(d) if s.shape != d.shape and s.numel() == d.numel() else s for d, s in zip(dsts, srcs)])
+        return
+    mt_scale_into(_ones(len(dsts), dsts[0].device), srcs, dsts)
+
+
+def mt_clone(srcs):
+    """[s.clone() for s in srcs] through mt_copy."""
+    srcs = list(srcs)
+    outs = [torch.empty_like(s, memory_format=torch.contiguous_format) for s in srcs]
+    mt_copy(outs, srcs)
+    return outs
+
+
 # --------------------------------------------------------------------------------------------
 # Fused L1 / MSE                                                     (loss.py:287-290)
 # --------------------------------------------------------------------------------------------

@@ -1033,3 +1033,26 @@ def test_reflect_pad_op_has_atens_values_and_gradient(shape, pad):
     ga, = torch.autograd.grad((ya * wgt).sum(), a)
     gb, = torch.autograd.grad((yb * wgt).sum(), b)
     assert _rel(ga, gb) < 1e-6
+
+
+def test_mt_copy_is_a_bitwise_copy_over_many_tensors():
+    """hip_ops.mt_copy / mt_clone (the multi-tensor scale kernel with gamma = 1): 130 tensors of ragged sizes -- three launch groups --
+    including -0.0, infinities, NaN and denormals, compared as bit patterns; a shape-changing (same numel) destination; and the
+    fallback for non-float32 lists."""
+    g = torch.Generator().manual_seed(3)
+    srcs = [torch.randn(int(n), generator=g) for n in torch.randint(1, 5000, (130,), generator=g)]
+    srcs[0][:6] = torch.tensor([-0.0, float('inf'), float('-inf'), float('nan'), 1e-42, -1e-45])
+    srcs = [s.to(DEV) for s in srcs]
+    srcs[5] = torch.randn(6, 7, generator=g).to(DEV).t()                     # non-contiguous source
+    dsts = [torch.full_like(s, 9.0, memory_format=torch.contiguous_format) for s in srcs]
+    dsts[7] = torch.full((1, srcs[7].numel()), 9.0, device=DEV)               # [1, n] static buffer for an [n] parameter
+    hip_ops.mt_copy(dsts, srcs)
+    for d, s in zip(dsts, srcs):
+        assert torch.equal(d.reshape(-1).view(torch.int32), s.contiguous().reshape(-1).view(torch.int32))
+    for c, s in zip(hip_ops.mt_clone(srcs), srcs):
+        assert c.shape == s.shape and c.data_ptr() != s.data_ptr()
+        assert torch.equal(c.contiguous().view(-1).view(torch.int32), s.contiguous().view(-1).view(torch.int32))
+    ints = [torch.arange(5, device=DEV), torch.arange(3, device=DEV)]
+    outs = [torch.zeros(5, dtype=torch.int64, device=DEV), torch.zeros(3, dtype=torch.int64, device=DEV)]
+    hip_ops.mt_copy(outs, ints)
+    assert all(torch.equal(o, i) for o, i in zip(outs, ints))
