@@ -584,9 +584,10 @@ WINO_MIN_TILES_FWD = 700
 WINO_MIN_TILES_BWD = 700
 WINO_MIN_TILES_FWD_BATCHED = 100      # N >= 2 (support pairs, lockstep batches of shared weights): 16x16 maps and up -- with the filters of all
                                       # layers transformed in one launch per inner step (round 3) the forward is 16.5 vs 31.5 us on CAIN's
-                                      # 192 -> 192 layers at 16x16, N = 2 (profiles/r03_convk_bench.jsonl); config C1 33.7 -> 38.4 steps/s.  The
-                                      # data gradient there (16.1 vs 22.0 us isolated) gave nothing in the loop: its threshold stays
-WINO_MIN_TILES_BWD_BATCHED = 200
+                                      # 192 -> 192 layers at 16x16, N = 2 and the data gradient 16.1 vs 22.0 (profiles/r03_convk_bench.jsonl);
+                                      # config C1: forward 33.7 -> 38.4 steps/s, data gradient another +3 %.  Single samples at that size
+                                      # (64 tiles) measured 1 % slower than MIOpen in the loop: they keep the 700 above
+WINO_MIN_TILES_BWD_BATCHED = 100
 if os.environ.get('SAVFI_WINO_TILES'):      # experiment knob: "fwd,bwd,fwd_batched,bwd_batched"
     WINO_MIN_TILES_FWD, WINO_MIN_TILES_BWD, WINO_MIN_TILES_FWD_BATCHED, WINO_MIN_TILES_BWD_BATCHED = (
         int(t) for t in os.environ['SAVFI_WINO_TILES'].split(','))
