@@ -10,6 +10,8 @@
 //         then a fixed-order sum of the partials (deterministic: no atomics)
 // act(x) = x > 0 ? x : slope * x   (slope 0 = ReLU, 0.2 = CAIN's LeakyReLU, 1 = bias only).
 // Pure HBM streaming: one workgroup per 4096-element chunk of an (n, c) plane, float4 per lane.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -87,6 +89,52 @@ __global__ __launch_bounds__(NT) void bias_act_bwd(const float* __restrict__ gy,
   }
 }
 
+// Small maps (N * HW <= CHUNK, one chunk per plane: CAIN's 16 x 16 maps): ONE launch.  Workgroup c walks the N planes of channel c
+// with the element-to-thread assignment of bias_act_bwd, takes each plane's block sum and adds them in n order in thread 0 --
+// exactly the additions of bias_act_bwd + bias_grad_finish (one partial per plane, summed by lane 0): bit-identical, one launch
+// less per layer (982 of them in 200 ms of config C1).
+__global__ __launch_bounds__(NT) void bias_act_bwd_small(const float* __restrict__ gy, const float* __restrict__ y,
+                                                         float* __restrict__ gz, float* __restrict__ gbias, int N, int C, int HW,
+                                                         float slope, int phase_ok) {
+  __shared__ float red[NT / SAVFI_WAVE];
+  const int c = blockIdx.x;
+  auto d = [slope](float g, float out) { return out > 0.f ? g : slope * g; };
+  float total = 0.f;
+  for (int n = 0; n < N; ++n) {
+    const size_t off = ((size_t)n * C + c) * HW;
+    const int base = 0, end = HW;
+    float acc = 0.f;
+    if (phase_ok) {
+      const int vbeg = base + peel_to_16(gy + off + base, end - base);
+      const int vend = vbeg + ((end - vbeg) & ~3);
+      if (base + (int)threadIdx.x < vbeg) {
+        const int e = base + threadIdx.x;
+        const float r = d(gy[off + e], y[off + e]);
+        if (gz) gz[off + e] = r;
+        acc += r;
+      }
+      for (int e = vbeg + 4 * threadIdx.x; e < vend; e += 4 * NT) {
+        const float4 g = *reinterpret_cast<const float4*>(gy + off + e);
+        const float4 o = *reinterpret_cast<const float4*>(y + off + e);
+        const float4 r = make_float4(d(g.x, o.x), d(g.y, o.y), d(g.z, o.z), d(g.w, o.w));
+        if (gz) *reinterpret_cast<float4*>(gz + off + e) = r;
+        acc += (r.x + r.y) + (r.z + r.w);
+      }
+      if (vend + (int)threadIdx.x < end) {
+        const int e = vend + threadIdx.x;
+        const float r = d(gy[off + e], y[off + e]);
+        if (gz) gz[off + e] = r;
+        acc += r;
+      }
+    } else {
+      for (int e = base + threadIdx.x; e < end; e += NT) { const float r = d(gy[off + e], y[off + e]); if (gz) gz[off + e] = r; acc += r; }
+    }
+    const float tot = block_sum<NT / SAVFI_WAVE>(acc, red);
+    if (threadIdx.x == 0) total += tot;
+  }
+  if (threadIdx.x == 0) gbias[c] = total;
+}
+
 // gbias[c] = sum over n and chunks of partial[(n * C + c) * chunks + ch], always in the same order
 __global__ __launch_bounds__(64) void bias_grad_finish(const float* __restrict__ partial, float* __restrict__ gbias, int N, int C,
                                                        int chunks) {
@@ -128,6 +176,11 @@ extern "C" int savfi_bias_act_bwd_f32(const float* gy, const float* y, float* gz
   // one peel aligns all operands when they share their low address bits (a NULL gz takes gy's)
   const unsigned lo = (unsigned)(uintptr_t)gy & 15u;
   const int phase_ok = ((unsigned)(uintptr_t)y & 15u) == lo && (!gz || ((unsigned)(uintptr_t)gz & 15u) == lo) && (lo & 3u) == 0;
+  static const bool two_stage = getenv("SAVFI_BIAS_ACT_TWO_STAGE") != nullptr;      // experiment knob: the general path on small maps too
+  if (gbias && chunks == 1 && (int64_t)N * HW <= CHUNK && !two_stage) {
+    hipLaunchKernelGGL(bias_act_bwd_small, dim3((unsigned)C), dim3(NT), 0, (hipStream_t)stream, gy, y, gz, gbias, N, C, HW, slope, phase_ok);
+    return savfi_launch_status();
+  }
   hipLaunchKernelGGL(bias_act_bwd, dim3((unsigned)blocks), dim3(NT), 0, (hipStream_t)stream, gy, y, gz, gbias ? scratch : nullptr,
                      C, HW, chunks, slope, phase_ok);
   if (int e = savfi_launch_status()) return e;
