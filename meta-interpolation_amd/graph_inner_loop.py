@@ -86,6 +86,7 @@ class GraphedInnerLoop:
             assert T == 1 and not self.unrouted, "graphed L2F: one task per graph set, every inner-loop tensor routed"
         self.emb_graph, self.emb_out = None, None    # L2F: support pass at theta -> layer-wise mean gradients
         self.step_graphs, self.step_out = [], []     # per step: graph, dict(W_out, g, dir)
+        self._theta_to_w0 = None                     # cached pointer tables of the theta -> W_0 copy (T = 1)
         self.target_graphs = {}                      # step index s (params = W_s) -> (graph, outputs)
         self.pool = None
         self._capture()
@@ -107,6 +108,11 @@ class GraphedInnerLoop:
         return [self.rule._lr(k, t) for k in self.routed]
 
     def _support_step(self, W, t):
+        if t == 0:
+            # W_0 is not the output of an update: give its layers the one-launch-per-kind filter transform the later steps get from
+            # mt_update (the plan is keyed by the list's shapes, which W_0 shares with every W_t); 127 single-layer launches per
+            # replay of CAIN's step graph otherwise
+            hip_ops.filters_after_update([W[k] for k in self.routed])
         model_utils.set_own_params_const(True)      # first-order support pass: non-routed parameters are constants
         try:
             out = _frame(self.net.forward(self.sup[0], self.sup[2], params=W, backup_running_statistics=(t == 0), num_step=t))
@@ -236,7 +242,9 @@ class GraphedInnerLoop:
             dst.copy_(pick(i))
         with torch.no_grad():
             if T == 1:
-                hip_ops.mt_copy([self.W0[k] for k in self.routed], [self.theta[k] for k in self.routed])
+                if self._theta_to_w0 is None:
+                    self._theta_to_w0 = hip_ops.MtCopy([self.W0[k] for k in self.routed], [self.theta[k] for k in self.routed])
+                self._theta_to_w0.run()
             else:
                 for k in self.routed:
                     self.W0[k].copy_(self.theta[k].unsqueeze(0).expand_as(self.W0[k]))
