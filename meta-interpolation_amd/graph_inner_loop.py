@@ -299,13 +299,13 @@ class GraphedInnerLoop:
             if suffix is not None and gamma is not None:
                 # identity chain W_S -> ... -> W_0 = gamma * theta
                 g_gamma, g_theta = hip_ops.mt_scale_grads(gamma, [self.theta[k] for k in self.routed], suffix)
-                accum.add_params(self.routed, g_theta)
+                accum.add_params(self.routed, g_theta, owned=True)
                 if gamma.requires_grad:
                     att = [p for p in list(sysm.attenuator.parameters()) + [sysm.gamma_mult] if p.requires_grad]
                     accum.add_extra(att, torch.autograd.grad(gamma, att, g_gamma, allow_unused=True))
             elif suffix is not None:
                 # identity chain W_S -> ... -> W_0 = theta broadcast over the tasks: the task axis is summed
-                accum.add_params(self.routed, suffix if T == 1 else [x.sum(0) for x in suffix])
+                accum.add_params(self.routed, suffix if T == 1 else [x.sum(0) for x in suffix], owned=True)
         if T == 1:
             return task_loss.reshape(1), pred.clone(), [logs]
         per_task_logs = [[{k: v[t] for k, v in parts.items()} for parts in logs] for t in range(T)]
@@ -324,14 +324,15 @@ class OuterGradAccumulator:
         self.lr_keys = None
         self.extra = {}         # any other trainable parameter (L2F: attenuator, gamma_mult) -> summed gradient
 
-    def add_params(self, keys, grads):
-        """param[k] += g  (the first contribution of a key is copied: `grads` may be static graph outputs)."""
+    def add_params(self, keys, grads, owned=False):
+        """param[k] += g.  The first contribution of a key is copied -- `grads` may be static graph outputs -- unless the caller hands
+        over tensors nobody else holds (`owned`: the suffix sums, which are clones or new sums already)."""
         have = [(self.param[k], g) for k, g in zip(keys, grads) if k in self.param]
         if have:
             torch._foreach_add_([a for a, _ in have], [g for _, g in have])
         fresh = [(k, g) for k, g in zip(keys, grads) if k not in self.param]
         if fresh:
-            for (k, _), c in zip(fresh, hip_ops.mt_clone([g for _, g in fresh])):
+            for (k, g), c in zip(fresh, [g for _, g in fresh] if owned else hip_ops.mt_clone([g for _, g in fresh])):
                 self.param[k] = c
 
     def add_lr_grads(self, gl, t, suffix):
