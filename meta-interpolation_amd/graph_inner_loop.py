@@ -276,7 +276,16 @@ class GraphedInnerLoop:
             w = weights[s]
             term = w * to['parts']['total']
             task_loss = term if task_loss is None else task_loss + term
-            logs.append(to['parts'])
+            # the parts are STATIC output buffers of the captured graph: a later replay of the same graph set (another group of
+            # the same call, the next meta-iteration behind a lazy log) would overwrite what the caller logs -- one stacked
+            # clone per target graph (a handful of scalars)
+            keys = list(to['parts'])
+            vals = [to['parts'][k] for k in keys]
+            if all(v.shape == vals[0].shape and v.dtype == vals[0].dtype for v in vals):
+                stacked = torch.stack(vals)                      # a new tensor: one launch
+                logs.append({k: stacked[i] for i, k in enumerate(keys)})
+            else:
+                logs.append({k: v.clone() for k, v in zip(keys, vals)})
             pred = to['pred']
         if self.training:
             # multi-tensor (foreach) arithmetic throughout: ~100 tensors per list, one or two launches per list

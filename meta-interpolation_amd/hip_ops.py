@@ -499,7 +499,9 @@ class MtCopy:
     the pointer tables are built once -- 2 x 494 ctypes stores per call for CAIN otherwise -- and run() re-checks the addresses."""
 
     def __init__(self, dsts, srcs):
-        self.dsts, self.srcs = [d.detach() for d in dsts], [s.detach() for s in srcs]
+        # the LIVE objects are kept (a `.detach()` alias would keep pointing at the old storage after `p.data = ...` --
+        # module.to() / .float() -- and the address check below could never fail)
+        self.dsts, self.srcs = list(dsts), list(srcs)
         self.plain = bool(self.dsts) and all(
             d.is_cuda and d.dtype == torch.float32 and s.dtype == torch.float32 and s.device == d.device and d.is_contiguous()
             and s.is_contiguous() and d.numel() == s.numel() and d.numel() > 0 for d, s in zip(self.dsts, self.srcs))
@@ -512,7 +514,8 @@ class MtCopy:
         if not self.dsts:
             return
         if not self.plain or any(t.data_ptr() != p for t, p in zip(self.dsts + self.srcs, self.ptrs)):
-            mt_copy(self.dsts, self.srcs)
+            with torch.no_grad():
+                mt_copy([d.detach() for d in self.dsts], [s.detach() for s in self.srcs])
             return
         n, pw, _, po, numel = self.args
         gamma = _ones(n, self.dsts[0].device)

@@ -121,41 +121,28 @@ class _LazyLog(dict):
             ensure()
             dict.update(self, self._data)
 
-    def __getitem__(self, k):
+    def __reduce__(self):            # pickle / torch.save / copy.deepcopy: a plain dict of the finished values
         self._ready()
-        return dict.__getitem__(self, k)
+        return (dict, (dict(self),))
 
-    def get(self, k, default=None):
-        self._ready()
-        return dict.get(self, k, default)
 
-    def __contains__(self, k):
-        self._ready()
-        return dict.__contains__(self, k)
+def _lazy_forward(name):
+    plain = getattr(dict, name)
 
-    def __iter__(self):
+    def method(self, *a, **kw):
         self._ready()
-        return dict.__iter__(self)
+        return plain(self, *a, **kw)
+    method.__name__ = name
+    return method
 
-    def __len__(self):
-        self._ready()
-        return dict.__len__(self)
 
-    def keys(self):
-        self._ready()
-        return dict.keys(self)
-
-    def values(self):
-        self._ready()
-        return dict.values(self)
-
-    def items(self):
-        self._ready()
-        return dict.items(self)
-
-    def __repr__(self):
-        self._ready()
-        return dict.__repr__(self)
+# every accessor and mutator of dict goes through _ready() first: a partly overridden dict subclass would let copy(), pop(),
+# ==, | ... see the dict as it was before the device finished
+for _name in ('__getitem__', '__setitem__', '__delitem__', '__contains__', '__iter__', '__len__', '__repr__', '__eq__', '__ne__',
+              '__or__', '__ror__', '__ior__', '__reversed__', 'get', 'keys', 'values', 'items', 'copy', 'pop', 'popitem',
+              'setdefault', 'update', 'clear'):
+    setattr(_LazyLog, _name, _lazy_forward(_name))
+del _name
 
 
 class SceneAdaptiveInterpolation(nn.Module):

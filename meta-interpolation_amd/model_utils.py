@@ -90,8 +90,12 @@ def extract_top_level_dict(current_dict):
 # --------------------------------------------------------------------------------------------
 def sub_mean(x):
     """Remove the per-channel spatial mean; returns (x - mean, mean)  (reference :11-15).  One savfi op (fixed summation order,
-    safe inside captured hipGraphs -- ATen's large-frame reduction is not: csrc/submean.hip)."""
-    return hip_ops.sub_mean(x)
+    safe inside captured hipGraphs -- ATen's large-frame reduction is not: csrc/submean.hip) for fp32 NCHW tensors on the GPU;
+    anything else (CPU tensors of --cuda False / gloo runs, other dtypes) takes the reference's two ATen means."""
+    if x.is_cuda and x.dtype == torch.float32 and x.dim() == 4:
+        return hip_ops.sub_mean(x)
+    mean = x.mean(2, keepdim=True).mean(3, keepdim=True)
+    return x - mean, mean
 
 
 def _pad_to_multiple(size, shift):

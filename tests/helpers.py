@@ -1,4 +1,5 @@
 """Shared test helpers (CPU side): build oracle inputs from the seeded recipe, read golden fixtures."""
+import ast
 import os
 
 import numpy as np
@@ -37,7 +38,7 @@ def oracle_base(model):
 
 
 def parse_case_args(npz):
-    return dict(eval(str(npz['args'])))
+    return dict(ast.literal_eval(str(npz['args'])))
 
 
 def fp(t):

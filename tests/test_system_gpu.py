@@ -60,7 +60,7 @@ def tolerances(name, phase='train'):
     # few discrete values (1.3e-4 / 7e-4 / 1.2e-3 / 4.1e-3) that the SAME build hits in different processes -- with the round-2 kernels
     # as with this round's more accurate ones (profiles/r03_lr_gradient_modes_sepconv64.txt).  The 1e-3 gate passed or failed by the
     # draw; 5e-3 covers the observed modes.  Losses, predictions, weights and per-step gradients keep their gates.
-    if name.startswith('sepconv_') and phase == 'train':
+    if name.startswith('sepconv_') and phase == 'train' and int(golden('system_' + name)['H']) <= 64:      # the small-map argument only
         tol['outer'] = max(tol['outer'], 5e-3)
     # Super SloMo's outer-gradient fingerprints: 6.3e-4 in most processes, 4.9e-3 (net.flowComp.conv2.bias) in about one process
     # of three -- the same value in all four fixture tests of that process, another process of the same build back at 6.3e-4
