@@ -56,7 +56,7 @@
 extern "C" {
 #endif
 
-#define SAVFI_ABI_VERSION 9
+#define SAVFI_ABI_VERSION 10
 
 #define SAVFI_OK            0
 #define SAVFI_E_NULL       (-1)  /* a required pointer is NULL                          */
@@ -83,6 +83,11 @@ int savfi_sepconv_fwd_f32(const float* in, const float* v, const float* h, float
 int savfi_sepconv_bwd_f32(const float* in, const float* v, const float* h, const float* gO,
                           float* gI, float* gV, float* gH,
                           int B, int C, int Ho, int Wo, int K, void* stream);
+
+/* Diagnostic of the wave-specialised filter-gradient kernel (csrc/sepconv_ws.hip): number of bounded in-kernel waits that
+ * gave up since the library was loaded on the current device.  0 on a healthy build; > 0 means a launch's numbers are wrong
+ * (the kernel never hangs).  Synchronises with the device.  -1: the counter could not be read. */
+int savfi_sepconv_ws_errors(void);
 
 /* ------------------------------------------------------------------------------------
  * VoxelFlow warp + blend (syn_type 'inter').

@@ -988,12 +988,13 @@ __global__ void sepconv_bwd_input_direct(const float* __restrict__ v, const floa
 
 // Experiment switches, read ONCE per process (not per launch): SAVFI_SEPCONV_F32_MFMA keeps the filter gradients on the fp32
 // matrix-core kernel (sepconv_bwd_mfma_p) instead of the split-bf16 one (csrc/sepconv_x6.hip), SAVFI_SEPCONV_NO_MFMA forces the direct kernels,
+// SAVFI_SEPCONV_NO_WS the one-program-per-wave split-bf16 kernel instead of the wave-specialised one (csrc/sepconv_ws.hip),
 // SAVFI_SEPCONV_TILED the tiled (non-persistent) MFMA kernels, SAVFI_SEPCONV_MFMA_ROWS = 8 | 12 | 16 pins their rows per workgroup.
 struct SepconvEnv {
-  bool no_mfma, tiled, f32_mfma;
+  bool no_mfma, tiled, f32_mfma, no_ws;
   int rows;
   SepconvEnv() : no_mfma(getenv("SAVFI_SEPCONV_NO_MFMA") != nullptr), tiled(getenv("SAVFI_SEPCONV_TILED") != nullptr),
-                 f32_mfma(getenv("SAVFI_SEPCONV_F32_MFMA") != nullptr), rows(0) {
+                 f32_mfma(getenv("SAVFI_SEPCONV_F32_MFMA") != nullptr), no_ws(getenv("SAVFI_SEPCONV_NO_WS") != nullptr), rows(0) {
     if (const char* e = getenv("SAVFI_SEPCONV_MFMA_ROWS")) {
       const int r = atoi(e);
       if (r == 8 || r == 12 || r == 16) rows = r;
@@ -1146,7 +1147,10 @@ extern "C" int savfi_sepconv_bwd_f32(const float* in, const float* v, const floa
   if (gV || gH) {
     if (K == KFAST && C == 3 && gV && gH && !sepconv_env().no_mfma && !sepconv_env().tiled && !sepconv_env().f32_mfma &&
         persistent_ok(B, Ho, Wo)) {
-      if (int e = savfi_sepconv_bwd_x6_launch(in, v, h, gO, gV, gH, B, Ho, Wo, device_cu_count(), st)) return e;
+      // widths that are a multiple of 4: the wave-specialised kernel (csrc/sepconv_ws.hip); others: one program per wave (csrc/sepconv_x6.hip)
+      if ((Wo & 3) == 0 && !sepconv_env().no_ws) {
+        if (int e = savfi_sepconv_bwd_ws_launch(in, v, h, gO, gV, gH, B, Ho, Wo, device_cu_count(), st)) return e;
+      } else if (int e = savfi_sepconv_bwd_x6_launch(in, v, h, gO, gV, gH, B, Ho, Wo, device_cu_count(), st)) return e;
     } else if (K == KFAST && C == 3 && !sepconv_env().no_mfma && !sepconv_env().tiled && persistent_ok(B, Ho, Wo)) {
       if (int e = launch_bwd_persistent(in, v, h, gO, gV, gH, B, Ho, Wo, st)) return e;
     } else if (K == KFAST && C == 3 && !sepconv_env().no_mfma && mfma_fits(Ho, Wo)) {

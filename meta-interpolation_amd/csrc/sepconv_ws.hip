@@ -1,0 +1,656 @@
+// SepConv filter gradients (gV, gH; K = 51, C = 3) on split-bf16 MFMAs, WAVE-SPECIALISED: the arithmetic, the LDS window and the
+// table / fragment layouts of csrc/sepconv_x6.hip, but the eight waves of a workgroup no longer run the same program.
+//
+//   gV[b,fy,y,x] = sum_c gO[b,c,y,x] * sum_fx in[b,c,y+fy,x+fx] * h[b,fx,y,x]
+//   gH[b,fx,y,x] = sum_c gO[b,c,y,x] * sum_fy in[b,c,y+fy,x+fx] * v[b,fy,y,x]
+//
+// Replaces the reference's two cupy/NVRTC filter-gradient kernels (sepconv/sepconv_op/sepconv.py:32-63, :138-190 backward).
+//
+// Why.  sepconv_bwd_x6 keeps every wave on one serial program per 16 pixels: taps HBM -> registers -> split -> table -> B fragments
+// -> 144 MFMAs -> scale -> tile -> stores, twice, plus the window slide between two workgroup barriers.  Its section trace
+// (profiles/r03_sepconv_x6_section_trace.txt) shows three quarters of a wave's cycles OUTSIDE the MFMA loops and the matrix pipe 40 %
+// busy: with two waves per SIMD (LDS allows one workgroup per CU) nothing hides a wave's memory latency, table building and
+// barrier skew but the one other wave, which is in the same state half of the time.
+//
+// Here waves w = 0..3 are MFMA waves and waves 4..7 staging waves; pair p = w & 3 (both on one SIMD: a workgroup's waves go to SIMDs
+// cyclically) owns column group p & 1 and output rows (p >> 1) and (p >> 1) + 2 of every phase (4 rows x 32 columns), i.e. two
+// "units" of 16 pixels per phase.  Per unit n of a pair:
+//   staging wave   h taps (prefetched one unit ahead) -> split -> band table -> [flag]; VALU tails of gV; v taps -> split -> table ->
+//                  [flag]; VALU tails of gH; drains the pair's output tile (gV, then gH) into 16-byte stores; loads and splits two new
+//                  window rows per unit (the window slides by 2 rows per unit instead of 8 rows behind two barriers every other phase);
+//   MFMA wave      [flag] 6 B fragments -> 144 MFMAs on the window -> cotangent scaling -> output tile -> [flag], for gV then gH.
+// The only barriers are at the start of a run (a workgroup's stretch of phases inside one 32-column strip: window prologue).  All
+// other ordering is by sequence numbers in LDS: DS operations of a wave execute in program order and the LDS serves them in arrival
+// order, so "data, then flag" by the writer and "flag, then data" by the reader is enough -- no s_waitcnt on VMEM, no barrier.
+//   tab_full / tab_free [pair]    the pair's one tap table (h band of unit n, then v of unit n, then h of unit n + 1 ...): the staging
+//                                 wave refills it as soon as the MFMA wave holds the previous content's fragments in registers
+//   out_full / out_free [pair]    the pair's output tile
+//   prog [wave]                   phases whose window reads the wave has finished;  slide_cnt: window row pairs written (x 4 waves)
+// Every wait is bounded (a wedged protocol ends with wrong numbers and savfi_sepconv_ws_errors() > 0, never with a hung GPU).
+//
+// LDS: window 103 680 B (as sepconv_x6) + 4 x (table 6 144 + output tile 6 400 + tail sums 512) + side columns 3 072 + flags = 159 KB.
+#include "sepconv_x6_shared.h"
+#include <type_traits>
+
+namespace {
+
+constexpr int WNT = 768;                            // 12 waves: per SIMD one MFMA wave and the two staging waves of its pair
+constexpr int WTILEB = 6400;                       // output tile of a pair: gV 64 tap rows x pitch 20 floats; gH 79 rows (fx + 15) x pitch 20
+constexpr int WTAILB = 512;                        // gV tail sums of a pair: [column 14 | 15][64 tap rows] floats
+constexpr int WPAIRB = XTAB + WTILEB + WTAILB;
+constexpr int WPAIR_OFF = XWINB;
+constexpr int WSIDE_OFF = WPAIR_OFF + 4 * WPAIRB;
+constexpr int WSIDEB = XC * XWIN * 4 * 4;
+constexpr int WFLAG_OFF = WSIDE_OFF + WSIDEB;
+constexpr int WLDS = WFLAG_OFF + 128;
+static_assert(WLDS <= 160 * 1024, "LDS per CU");
+constexpr int WPV = 20;                            // tile pitch (floats): rows leave as 16-byte pieces of 4 pixels.  gH: the MFMA wave writes
+                                                   // D[R][j] (R = window column) to row R - j + 15 = fx + 15, i.e. resolves gH[fx][j] = D[j + fx][j]
+                                                   // by its store ADDRESS (conflict free: 16 kg - 19 j mod 32 is a bijection of a half wave)
+enum { F_TAB_FULL = 0, F_TAB_FREE = 4, F_OUT_FULL = 8, F_OUT_FREE = 12, F_PROG = 16, F_SLIDE = 28, F_ERR = 29 };
+constexpr int WSPIN_LIMIT = 1 << 19;
+// experiment switches (timing only, results wrong): -DWS_EXP_NOMFMA the MFMA waves skip both MFMA loops (what the staging waves alone
+// sustain), -DWS_EXP_NOSTAGE the staging waves only run the protocol (what the MFMA waves alone sustain)
+#ifndef WS_EXP_NOMFMA
+#define WS_EXP_NOMFMA 0
+#endif
+#ifndef WS_EXP_NOSTAGE
+#define WS_EXP_NOSTAGE 0
+#endif
+#ifndef WS_PRIO                 // wave priority of the MFMA waves (the staging waves stay at 0)
+#define WS_PRIO 2
+#endif
+#ifndef WS_INTERLEAVE           // 1: the next block's A-fragment reads are spread between this block's MFMAs (one LDS read per matrix-pipe gap)
+#define WS_INTERLEAVE 1
+#endif
+#ifndef WS_EXP_NOAREAD          // the MFMA loops reuse the first unit's A fragments (no LDS reads inside the loops)
+#define WS_EXP_NOAREAD 0
+#endif
+#ifndef WS_EXP_NOMFMAONLY       // the A fragments are read, the MFMAs are not issued
+#define WS_EXP_NOMFMAONLY 0
+#endif
+
+__device__ unsigned ws_error_count = 0;
+// -DWS_TRACE: wave cycles (s_memtime) per section, summed over the units of workgroup 0, in ws_trace[wave][section]
+#ifndef WS_TRACE
+#define WS_TRACE 0
+#endif
+__device__ unsigned long long ws_trace[12][16];
+#define WS_T(k) do { if (WS_TRACE) { const unsigned long long t_ = __builtin_readcyclecounter(); tr_[k] += t_ - tlast_; tlast_ = t_; } } while (0)
+
+typedef __attribute__((address_space(3))) unsigned lds_u32;
+
+__device__ __forceinline__ unsigned ws_peek(const unsigned* f) {
+  const unsigned v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
+// flag >= target (sequence numbers of one run: no wrap)
+__device__ __forceinline__ void ws_wait(unsigned* fl, int idx, int target) {
+  asm volatile("" ::: "memory");
+  if ((int)ws_peek(fl + idx) < target) {
+    int spins = 0;
+    while (true) {
+      __builtin_amdgcn_s_sleep(2);
+      if ((int)ws_peek(fl + idx) >= target) break;
+      if ((++spins & 255) == 0 && (ws_peek(fl + F_ERR) != 0u || spins > WSPIN_LIMIT)) {
+        if ((threadIdx.x & 63) == 0) {
+          __hip_atomic_store(fl + F_ERR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          atomicAdd(&ws_error_count, 1u);
+        }
+        break;
+      }
+    }
+  }
+  asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void ws_set(unsigned* fl, int idx, int value) {
+  asm volatile("" ::: "memory");
+  __hip_atomic_store(fl + idx, (unsigned)value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  asm volatile("" ::: "memory");
+}
+// every wave's prog >= target
+__device__ __forceinline__ void ws_wait_all_prog(unsigned* fl, int target) {
+  asm volatile("" ::: "memory");
+  const int lane7 = min((int)(threadIdx.x & 15), 11);
+  int spins = 0;
+  while (true) {
+    const unsigned v = __hip_atomic_load(fl + F_PROG + lane7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (__builtin_amdgcn_ballot_w64((int)v < target) == 0ull) break;
+    __builtin_amdgcn_s_sleep(2);
+    if ((++spins & 255) == 0 && (ws_peek(fl + F_ERR) != 0u || spins > WSPIN_LIMIT)) {
+      if ((threadIdx.x & 63) == 0) {
+        __hip_atomic_store(fl + F_ERR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        atomicAdd(&ws_error_count, 1u);
+      }
+      break;
+    }
+  }
+  asm volatile("" ::: "memory");
+}
+
+// sum over the 64 lanes, every lane gets the total: four DPP steps inside each row of 16 lanes, then the four row totals by
+// readlane (the ds_bpermute butterfly of __shfl_xor costs an LDS round trip per step: 18 of them per unit were a fifth of a
+// staging wave's cycles)
+__device__ __forceinline__ float ws_wave_sum(float x) {
+  auto dpp = [](float v, auto ctrl) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xf, 0xf, true));
+  };
+  x += dpp(x, std::integral_constant<int, 0xB1>{});      // quad_perm [1,0,3,2]
+  x += dpp(x, std::integral_constant<int, 0x4E>{});      // quad_perm [2,3,0,1]
+  x += dpp(x, std::integral_constant<int, 0x141>{});     // row_half_mirror
+  x += dpp(x, std::integral_constant<int, 0x140>{});     // row_mirror
+  auto rl = [](float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); };
+  return (rl(x, 0) + rl(x, 16)) + (rl(x, 32) + rl(x, 48));
+}
+
+__global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ in, const float* __restrict__ v,
+                                                      const float* __restrict__ h, const float* __restrict__ gO,
+                                                      float* __restrict__ gV, float* __restrict__ gH,
+                                                      int B, int Ho, int Wo, int nph, int ncol, int per_wg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p = w & 3, wc = p & 1, wr0 = p >> 1;
+  const int role = w >> 2;                          // 0: MFMA wave, 1: h-side staging wave, 2: v-side staging wave
+  const bool staging = role != 0;
+  const int j = lane & 15, kg = lane >> 4;
+  char* const tab = smem + WPAIR_OFF + p * WPAIRB;
+  float* const tile = reinterpret_cast<float*>(tab + XTAB);
+  float* const tailb = reinterpret_cast<float*>(tab + XTAB + WTILEB);
+  float* const side = reinterpret_cast<float*>(smem + WSIDE_OFF);
+  unsigned* const fl = reinterpret_cast<unsigned*>(smem + WFLAG_OFF);
+
+  const int total = B * ncol * nph;
+  const int g0 = blockIdx.x * per_wg, g1 = min(g0 + per_wg, total);
+  if (g0 >= g1) return;
+  const int Hi = Ho + XK - 1, Wi = Wo + XK - 1;
+  const unsigned plane_b = (unsigned)Ho * (unsigned)Wo * 4u;
+  const __amdgpu_buffer_rsrc_t hsrc = x6_rsrc(h, (unsigned)(B * XK) * plane_b);
+  const __amdgpu_buffer_rsrc_t vsrc = x6_rsrc(v, (unsigned)(B * XK) * plane_b);
+  const __amdgpu_buffer_rsrc_t gsrc = x6_rsrc(gO, (unsigned)(B * XC) * plane_b);
+  const __amdgpu_buffer_rsrc_t isrc = x6_rsrc(in, (unsigned)(B * XC) * (unsigned)(Hi * Wi) * 4u);
+  const __amdgpu_buffer_rsrc_t gvdst = x6_rsrc(gV, (unsigned)(B * XK) * plane_b);
+  const __amdgpu_buffer_rsrc_t ghdst = x6_rsrc(gH, (unsigned)(B * XK) * plane_b);
+
+  auto pix_off = [&](int b, int x0, int y, int ch) {
+    return (unsigned)b * (unsigned)ch * plane_b + (unsigned)(min(y, Ho - 1) * Wo + min(x0 + 16 * wc + j, Wo - 1)) * 4u;
+  };
+  // Tap registers (as sepconv_bwd_x6): lane (j, kg) holds 7 PAIRS of neighbouring taps t0 + 8 a + {0, 1}: a split pair is exactly the
+  // dword a table position takes.  v: t0 = 2 kg.  h: t0 = 2 kg - (j & 1): the band position i = tap + j of a pair starts even.
+  auto load_taps = [&](float (&regs)[XNP][2], __amdgpu_buffer_rsrc_t src, int b, int x0, int y, int t0) {
+    const unsigned pix = pix_off(b, x0, y, XK);
+    const unsigned voff = pix + (unsigned)(t0 + 1) * plane_b;
+    regs[0][0] = x6_bload(src, pix + (unsigned)max(t0, 0) * plane_b, 0u);
+    regs[0][1] = x6_bload(src, voff, 0u);
+#pragma unroll
+    for (int a = 1; a < XNP - 1; ++a)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) regs[a][e] = x6_bload(src, voff, (unsigned)(8 * a + e - 1) * plane_b);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) regs[XNP - 1][e] = x6_bload(src, pix + (unsigned)min(8 * (XNP - 1) + t0 + e, XK - 1) * plane_b, 0u);
+  };
+  auto tap_or_zero = [&](const float (&regs)[XNP][2], int a, int e, int t0) {
+    if (a == 0 && e == 0) return t0 < 0 ? 0.f : regs[0][0];
+    if (a == XNP - 1) return (8 * (XNP - 1) + t0 + e < XK) ? regs[a][e] : 0.f;
+    return regs[a][e];
+  };
+  const int h_t0 = 2 * kg - (j & 1), v_t0 = 2 * kg;
+  // h band of the unit's 16 pixels -> table [piece][i / 8][j][i % 8], i = tap + j < 64 (zero elsewhere)
+  auto write_h_table = [&](const float (&regs)[XNP][2]) {
+#pragma unroll
+    for (int k = 0; k < XTAB / 1024; ++k) *reinterpret_cast<u32x4*>(tab + (k * 64 + lane) * 16) = (u32x4){0u, 0u, 0u, 0u};
+    const int base2 = 2 * kg + (j & ~1);
+    char* const lb = tab + (base2 >> 3) * 256 + j * 16 + (base2 & 7) * 2;
+#pragma unroll
+    for (int a = 0; a < XNP; ++a) {
+      unsigned h1, h2, h3;
+      x6_split2(tap_or_zero(regs, a, 0, h_t0), tap_or_zero(regs, a, 1, h_t0), h1, h2, h3);
+      char* d = lb + a * 256;
+      if (a < XNP - 1 || base2 < 16) {                               // positions 64, 65 belong to the tail
+        *reinterpret_cast<unsigned*>(d) = h1;
+        *reinterpret_cast<unsigned*>(d + XTABP) = h2;
+        *reinterpret_cast<unsigned*>(d + 2 * XTABP) = h3;
+      }
+    }
+  };
+  // v taps -> table position of tap fy: k step fy / 32, k group (fy % 16) / 4, element fy % 4 + 4 * ((fy / 16) % 2)
+  auto write_v_table = [&](const float (&regs)[XNP][2]) {
+    char* const lb = tab + (kg >> 1) * 256 + j * 16 + (kg & 1) * 4;
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      unsigned h1 = 0u, h2 = 0u, h3 = 0u;
+      if (a < XNP) x6_split2(tap_or_zero(regs, a, 0, v_t0), tap_or_zero(regs, a, 1, v_t0), h1, h2, h3);
+      char* d = lb + (4 * (a >> 2) + 2 * (a & 1)) * 256 + 8 * ((a >> 1) & 1);
+      *reinterpret_cast<unsigned*>(d) = h1;
+      *reinterpret_cast<unsigned*>(d + XTABP) = h2;
+      *reinterpret_cast<unsigned*>(d + 2 * XTABP) = h3;
+    }
+  };
+  auto tr_read = [&](int addr) -> bf16x4 {
+    typedef __attribute__((address_space(3))) bf16x4 lds_b4;
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(smem + addr));
+  };
+  auto rdlane = [&](float x, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l)); };
+
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // six products, small terms first
+  const int permk = ((kg & 1) << 1) | (kg >> 1);
+  const int L = lane & 15;
+  const int pq = lane & 3, fq = lane >> 2;
+
+  int g = g0;
+#pragma unroll 1
+  while (g < g1) {
+    // ---- a run: phases ph0 .. ph0 + nrun - 1 of strip (b, x0) ---------------------------------------------------------------
+    const int s = g / nph, ph0 = g - s * nph, b = s / ncol, x0 = (s - b * ncol) * XMC;
+    const int run_end = min(g1, g + (nph - ph0)), nrun = run_end - g, N = 2 * nrun;
+    const int R0 = XPR * ph0;
+    auto unit_y = [&](int n) { return R0 + XPR * (n >> 1) + wr0 + 2 * (n & 1); };
+
+    float hreg[XNP][2], vreg[XNP][2], gp[XC];       // staging: taps and cotangent of the unit at hand / the next one;  MFMA: gp only
+    __syncthreads();                                // every wave has left the previous run's window, tables and flags
+    if (tid < 32) fl[tid] = 0u;
+    if (role == 1) load_taps(hreg, hsrc, b, x0, unit_y(0), h_t0);
+    if (role == 2) load_taps(vreg, vsrc, b, x0, unit_y(0), v_t0);
+    {
+      const unsigned go = pix_off(b, x0, unit_y(0), XC);
+#pragma unroll
+      for (int c = 0; c < XC; ++c) gp[c] = x6_bload(gsrc, go, (unsigned)c * plane_b);
+    }
+    if (tid < XNT) {                                 // the window prologue keeps sepconv_x6's mapping of 512 threads
+#pragma unroll 1
+      for (int r = 0; r < XWIN; r += 16) {
+        X6Rows<16> sr;
+        x6_rows_load<16>(sr, isrc, b, x0, R0 + r, Hi, Wi, tid);
+        x6_rows_write<16>(sr, smem, R0 + r, tid, WSIDE_OFF);
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+
+    if (!staging) {
+      // =========================================== MFMA wave ===================================================================
+      __builtin_amdgcn_s_setprio(WS_PRIO);
+      unsigned long long tr_[16] = {0}, tlast_ = __builtin_readcyclecounter();
+#pragma unroll 1
+      for (int n = 0; n < N; ++n) {
+        const int q = n >> 1, u = n & 1;
+        const int y = unit_y(n);
+        WS_T(0);
+        float g_[XC];
+#pragma unroll
+        for (int c = 0; c < XC; ++c) g_[c] = gp[c];
+        {
+          const unsigned go = pix_off(b, x0, unit_y(min(n + 1, N - 1)), XC);
+#pragma unroll
+          for (int c = 0; c < XC; ++c) gp[c] = x6_bload(gsrc, go, (unsigned)c * plane_b);
+        }
+        // ---- gV ----
+        bf16x8 bq[2][3];
+        ws_wait(fl, F_TAB_FULL + p, 2 * n + 1);
+        WS_T(1);
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) bq[st][pc] = *reinterpret_cast<const bf16x8*>(tab + pc * XTABP + (4 * st + permk) * 256 + j * 16);
+        ws_set(fl, F_TAB_FREE + p, 2 * n + 1);
+        if (u == 0 && q >= 2) ws_wait(fl, F_SLIDE, 8 * (2 * q - 3));
+        WS_T(2);
+        {
+          f32x4 acc[XC][4];
+#pragma unroll
+          for (int c = 0; c < XC; ++c)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[c][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          int rowoff[4];
+#pragma unroll
+          for (int m = 0; m < 4; ++m) rowoff[m] = ((y + min(16 * m + j, XK - 1)) & (XWIN - 1)) * 16 + (2 * wc + permk) * XBLK;
+          bf16x8 aq[2][2][3];
+          auto load_a = [&](int slot, int uu) {
+            const int c = uu >> 2, st = (uu >> 1) & 1, mp = uu & 1;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+              for (int pc = 0; pc < 3; ++pc)
+                aq[slot][t][pc] = *reinterpret_cast<const bf16x8*>(smem + (pc * 3 + c) * XPLANE + 4 * st * XBLK + rowoff[2 * mp + t]);
+          };
+          __builtin_amdgcn_sched_barrier(0);
+          if (!WS_EXP_NOMFMA) load_a(0, 0);
+#pragma unroll
+          for (int uu = 0; uu < (WS_EXP_NOMFMA ? 0 : 12); ++uu) {
+            if (uu + 1 < 12 && !WS_EXP_NOAREAD) load_a((uu + 1) & 1, uu + 1);
+            if (!WS_INTERLEAVE) __builtin_amdgcn_sched_barrier(0);          // the next block's fragments are requested BEFORE this block's MFMAs issue
+            const int c = uu >> 2, st = (uu >> 1) & 1, mp = uu & 1;
+#pragma unroll
+            for (int qq = 0; qq < 6; ++qq)
+#pragma unroll
+              for (int t = 0; t < 2; ++t) {
+                if (WS_EXP_NOMFMAONLY) { if (qq < 3) acc[c][2 * mp + t][0] += __builtin_bit_cast(float, aq[uu & 1][t][qq][0] + aq[uu & 1][t][qq][7]); continue; }
+                acc[c][2 * mp + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[WS_EXP_NOAREAD ? 0 : (uu & 1)][t][PA[qq]], bq[st][PB[qq]], acc[c][2 * mp + t], 0, 0, 0);
+              }
+            if (WS_INTERLEAVE && uu + 1 < 12) {           // MFMA, DS read, MFMA, DS read ... (6 reads), then the remaining MFMAs
+#pragma unroll
+              for (int i = 0; i < 6; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+              }
+              __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          // D row 4 kg + r of tile m = tap row fy = 16 m + 4 kg + r, column = pixel j
+          WS_T(3);
+          float val[4][4];
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float t = g_[0] * acc[0][m][r];
+              t = fmaf(g_[1], acc[1][m][r], t);
+              t = fmaf(g_[2], acc[2][m][r], t);
+              val[m][r] = t;
+            }
+          WS_T(4);
+          ws_wait(fl, F_OUT_FREE + p, 2 * n);
+          WS_T(5);
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tile[(16 * m + 4 * kg + r) * WPV + j] = val[m][r];
+          ws_set(fl, F_OUT_FULL + p, 2 * n + 1);
+          WS_T(6);
+        }
+        // ---- gH ----
+        ws_wait(fl, F_TAB_FULL + p, 2 * n + 2);
+        WS_T(7);
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) bq[st][pc] = *reinterpret_cast<const bf16x8*>(tab + pc * XTABP + (4 * st + kg) * 256 + j * 16);
+        ws_set(fl, F_TAB_FREE + p, 2 * n + 2);
+        WS_T(8);
+        {
+          f32x4 acc[XC][4];
+#pragma unroll
+          for (int c = 0; c < XC; ++c)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[c][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          // transpose read: source lane L of group kg points at window row y + 32 s + 16 half + 4 kg + L / 4, column quad L % 4 of the tile
+          int rowh[2][2];
+#pragma unroll
+          for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+              rowh[st][hf] = ((y + 32 * st + 16 * hf + 4 * kg + (L >> 2)) & (XWIN - 1)) * 16 + (2 * wc + ((L & 3) >> 1)) * XBLK + (L & 1) * 8;
+          bf16x8 aq[2][2][3];
+          auto load_a = [&](int slot, int uu) {
+            const int c = uu >> 2, st = (uu >> 1) & 1, mp = uu & 1;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+              for (int pc = 0; pc < 3; ++pc) {
+                const int base = (pc * 3 + c) * XPLANE + 2 * (2 * mp + t) * XBLK;
+                const bf16x4 lo = tr_read(base + rowh[st][0]), hi = tr_read(base + rowh[st][1]);
+                aq[slot][t][pc] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+              }
+          };
+          __builtin_amdgcn_sched_barrier(0);
+          if (!WS_EXP_NOMFMA) load_a(0, 0);
+#pragma unroll
+          for (int uu = 0; uu < (WS_EXP_NOMFMA ? 0 : 12); ++uu) {
+            if (uu + 1 < 12 && !WS_EXP_NOAREAD) load_a((uu + 1) & 1, uu + 1);
+            if (!WS_INTERLEAVE) __builtin_amdgcn_sched_barrier(0);          // the next block's fragments are requested BEFORE this block's MFMAs issue
+            const int c = uu >> 2, st = (uu >> 1) & 1, mp = uu & 1;
+#pragma unroll
+            for (int qq = 0; qq < 6; ++qq)
+#pragma unroll
+              for (int t = 0; t < 2; ++t) {
+                if (WS_EXP_NOMFMAONLY) { if (qq < 3) acc[c][2 * mp + t][0] += __builtin_bit_cast(float, aq[uu & 1][t][qq][0] + aq[uu & 1][t][qq][7]); continue; }
+                acc[c][2 * mp + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[WS_EXP_NOAREAD ? 0 : (uu & 1)][t][PA[qq]], bq[st][PB[qq]], acc[c][2 * mp + t], 0, 0, 0);
+              }
+            if (WS_INTERLEAVE && uu + 1 < 12) {           // MFMA, 2 transpose reads, ... (24 reads over the 12 MFMAs)
+#pragma unroll
+              for (int i = 0; i < 12; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          WS_T(9);
+          float val[4][4];
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float t = g_[0] * acc[0][m][r];
+              t = fmaf(g_[1], acc[1][m][r], t);
+              t = fmaf(g_[2], acc[2][m][r], t);
+              val[m][r] = t;
+            }
+          WS_T(10);
+          ws_wait(fl, F_OUT_FREE + p, 2 * n + 1);
+          WS_T(11);
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tile[(16 * m + 4 * kg + r - j + 15) * WPV + j] = val[m][r];
+          ws_set(fl, F_OUT_FULL + p, 2 * n + 2);
+          WS_T(12);
+        }
+        if (u == 1) ws_set(fl, F_PROG + w, q + 1);
+      }
+      __builtin_amdgcn_s_setprio(0);
+      if (WS_TRACE && blockIdx.x == 0 && lane == 0)
+        for (int k = 0; k < 16; ++k) ws_trace[w][k] += tr_[k];
+    } else {
+      // =========================================== staging waves ===============================================================
+      // role 1 (waves 4..7): the h side of the pair's units -- h taps, band table, gV tail columns, gV tile -> HBM, window row 60 + 2 n
+      // role 2 (waves 8..11): the v side -- v taps, table, gH tail columns, gH tile -> HBM, window row 61 + 2 n
+      const bool hside = role == 1;
+      const int ptid = tid - (hside ? 256 : 512);
+      const int gcol = ptid & 127, ggrp = ptid >> 7;        // granule: one window row per role, thread = (column, channels {0, 1} | {2})
+      const int gcell = (gcol >> 3) * XBLK + (gcol & 7) * 2;
+      const int gsidx = gcol == 64 ? 0 : gcol == 65 ? 1 : gcol == 80 ? 2 : gcol == 81 ? 3 : -1;
+      const unsigned gcolb = (unsigned)min(x0 + gcol, Wi - 1) * 4u;
+      const int gc0 = ggrp == 0 ? 0 : 2, gc1 = ggrp == 0 ? 1 : 2;
+      unsigned long long tr_[16] = {0}, tlast_ = __builtin_readcyclecounter();
+#pragma unroll 1
+      for (int n = 0; n < N; ++n) {
+        const int q = n >> 1, u = n & 1;
+        const int y = unit_y(n), y1 = unit_y(min(n + 1, N - 1));
+        const int xq = x0 + 16 * wc + 4 * pq;
+        const unsigned qoff = (y < Ho && xq < Wo) ? (unsigned)b * (unsigned)XK * plane_b + (unsigned)(y * Wo + xq) * 4u + (unsigned)fq * plane_b : X_OOR;
+        // one new window row per role and unit (rows R0 + 60 + 2 n + {0 | 1})
+        float gr0, gr1;
+        const int grow = R0 + 60 + 2 * n + (hside ? 0 : 1);
+        {
+          const int rr = min(grow, Hi - 1);
+          gr0 = WS_EXP_NOSTAGE ? 0.f : x6_bload(isrc, (unsigned)(((b * XC + gc0) * Hi + rr) * Wi) * 4u + gcolb, 0u);
+          gr1 = WS_EXP_NOSTAGE ? 0.f : x6_bload(isrc, (unsigned)(((b * XC + gc1) * Hi + rr) * Wi) * 4u + gcolb, 0u);
+        }
+        float g14[XC], g15[XC];
+#pragma unroll
+        for (int c = 0; c < XC; ++c) { g14[c] = rdlane(gp[c], 14); g15[c] = rdlane(gp[c], 15); }
+        const int fyl = min(lane, XK - 1);
+        const int tslot = (y + fyl) & (XWIN - 1);
+        float s6414 = 0.f, s6415 = 0.f, s6515 = 0.f;
+        WS_T(0);
+        if (hside) {
+          // what the tail columns need of this unit's taps, before the registers take the next unit's
+          const float h50_14 = rdlane(hreg[6][0], 14 + 16), h49_15 = rdlane(hreg[6][0], 15 + 16), h50_15 = rdlane(hreg[6][1], 15 + 16);
+          // the h band of unit n takes the table (the MFMA wave holds v of unit n - 1 in registers)
+          ws_wait(fl, F_TAB_FREE + p, 2 * n);
+          WS_T(1);
+          if (!WS_EXP_NOSTAGE) write_h_table(hreg);
+          ws_set(fl, F_TAB_FULL + p, 2 * n + 1);
+          WS_T(2);
+          // tail columns of gV (i = 64: pixel 14 tap 50, pixel 15 tap 49; i = 65: pixel 15 tap 50): lane = tap row fy
+          if (u == 0 && q >= 2) ws_wait(fl, F_SLIDE, 8 * (2 * q - 3));
+          float a64[XC], a65[XC];
+#pragma unroll
+          for (int c = 0; c < XC; ++c) {
+            const f32x2 sv = *reinterpret_cast<const f32x2*>(side + (c * XWIN + tslot) * 4 + 2 * wc);
+            a64[c] = sv.x; a65[c] = sv.y;
+          }
+          asm volatile("" ::: "memory");
+          if (u == 1) ws_set(fl, F_PROG + w, q + 1);
+          if (!WS_EXP_NOSTAGE) load_taps(hreg, hsrc, b, x0, y1, h_t0);
+          {
+            float t14 = 0.f, t15 = 0.f;
+#pragma unroll
+            for (int c = 0; c < XC; ++c) {
+              t14 = fmaf(g14[c] * h50_14, a64[c], t14);
+              t15 = fmaf(g15[c] * h49_15, a64[c], t15);
+              t15 = fmaf(g15[c] * h50_15, a65[c], t15);
+            }
+            tailb[lane] = lane < XK ? t14 : 0.f;
+            tailb[64 + lane] = lane < XK ? t15 : 0.f;
+          }
+          WS_T(3);
+        } else {
+          // v of unit n takes the table (the MFMA wave holds the h band of unit n in registers)
+          ws_wait(fl, F_TAB_FREE + p, 2 * n + 1);
+          WS_T(1);
+          if (!WS_EXP_NOSTAGE) write_v_table(vreg);
+          // v of pixels 14, 15 by tap row (lane = fy) for the tail columns: read back from the table's pieces BEFORE the table is
+          // published -- once the MFMA wave has taken its fragments the h-side wave refills the table
+          float v14 = 0.f, v15 = 0.f;
+          if (!WS_EXP_NOSTAGE) {
+            const int f5 = fyl & 31;
+            const char* tp = tab + (4 * (fyl >> 5) + ((f5 & 15) >> 2)) * 256 + ((f5 & 3) + 4 * ((f5 >> 4) & 1)) * 2;
+            unsigned short r14[3], r15[3];
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) {
+              r14[pc] = *reinterpret_cast<const unsigned short*>(tp + pc * XTABP + 14 * 16);
+              r15[pc] = *reinterpret_cast<const unsigned short*>(tp + pc * XTABP + 15 * 16);
+            }
+            asm volatile("" ::: "memory");
+            ws_set(fl, F_TAB_FULL + p, 2 * n + 2);
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) {
+              v14 += __uint_as_float((unsigned)r14[pc] << 16);
+              v15 += __uint_as_float((unsigned)r15[pc] << 16);
+            }
+          } else {
+            ws_set(fl, F_TAB_FULL + p, 2 * n + 2);
+          }
+          WS_T(2);
+          // tail columns of gH (q = 64, 65: taps 50 / 49, 50 of pixels 14, 15): lane = tap row fy, v from the table's pieces
+          if (u == 0 && q >= 2) ws_wait(fl, F_SLIDE, 8 * (2 * q - 3));
+          float a64[XC], a65[XC];
+#pragma unroll
+          for (int c = 0; c < XC; ++c) {
+            const f32x2 sv = *reinterpret_cast<const f32x2*>(side + (c * XWIN + tslot) * 4 + 2 * wc);
+            a64[c] = sv.x; a65[c] = sv.y;
+          }
+          asm volatile("" ::: "memory");
+          if (u == 1) ws_set(fl, F_PROG + w, q + 1);
+          if (!WS_EXP_NOSTAGE) {
+            const float lv = lane < XK ? 1.f : 0.f;
+            v14 *= lv; v15 *= lv;
+            float sa = 0.f, sb = 0.f, sc = 0.f;
+#pragma unroll
+            for (int c = 0; c < XC; ++c) {
+              sa = fmaf(g14[c] * v14, a64[c], sa);
+              sb = fmaf(g15[c] * v15, a64[c], sb);
+              sc = fmaf(g15[c] * v15, a65[c], sc);
+            }
+            s6414 = ws_wave_sum(sa);
+            s6415 = ws_wave_sum(sb);
+            s6515 = ws_wave_sum(sc);
+          }
+          asm volatile("" ::: "memory");
+          if (!WS_EXP_NOSTAGE) load_taps(vreg, vsrc, b, x0, y1, v_t0);
+          WS_T(3);
+        }
+        if (!WS_EXP_NOSTAGE) {
+          const unsigned go = pix_off(b, x0, y1, XC);
+#pragma unroll
+          for (int c = 0; c < XC; ++c) gp[c] = x6_bload(gsrc, go, (unsigned)c * plane_b);
+        }
+        // the new window row (slot of row 4 q - 4 + 2 u + {0 | 1}: behind every wave once phase q - 1 is done)
+        {
+          if (q >= 1) ws_wait_all_prog(fl, q);
+          WS_T(4);
+          const int slot = grow & (XWIN - 1);
+          unsigned h1, h2, h3;
+          x6_split2(gr0, gr1, h1, h2, h3);
+          if (gcol < 8 * XNBLK && !WS_EXP_NOSTAGE) {
+            char* d0 = smem + gcell + slot * 16 + gc0 * XPLANE;
+            x6_st16(d0, h1); x6_st16(d0 + 3 * XPLANE, h2); x6_st16(d0 + 6 * XPLANE, h3);
+            if (ggrp == 0) { x6_st16(d0 + XPLANE, h1 >> 16); x6_st16(d0 + 4 * XPLANE, h2 >> 16); x6_st16(d0 + 7 * XPLANE, h3 >> 16); }
+          }
+          if (gsidx >= 0) {
+            side[(gc0 * XWIN + slot) * 4 + gsidx] = gr0;
+            side[(gc1 * XWIN + slot) * 4 + gsidx] = gr1;
+          }
+          asm volatile("" ::: "memory");
+          if (lane == 0) __hip_atomic_fetch_add(fl + F_SLIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          asm volatile("" ::: "memory");
+          WS_T(5);
+        }
+        // the pair's output tile -> HBM
+        if (hside) {
+          ws_wait(fl, F_OUT_FULL + p, 2 * n + 1);
+          WS_T(6);
+#pragma unroll
+          for (int qq = 0; qq < (WS_EXP_NOSTAGE ? 0 : 4); ++qq) {
+            const int row = fq + 16 * qq;
+            f32x4 v4 = *reinterpret_cast<const f32x4*>(tile + row * WPV + 4 * pq);
+            const float t14 = tailb[row], t15 = tailb[64 + row];
+            if (pq == 3) { v4[2] += t14; v4[3] += t15; }
+            x6_bstore4(v4, gvdst, (qq < 3 || fq < 3) ? qoff : X_OOR, (unsigned)(16 * qq) * plane_b);
+          }
+          ws_set(fl, F_OUT_FREE + p, 2 * n + 1);
+          WS_T(7);
+        } else {
+          ws_wait(fl, F_OUT_FULL + p, 2 * n + 2);
+          WS_T(6);
+#pragma unroll
+          for (int qq = 0; qq < (WS_EXP_NOSTAGE ? 0 : 4); ++qq) {
+            const int fx = fq + 16 * qq;
+            f32x4 v4 = *reinterpret_cast<const f32x4*>(tile + (fx + 15) * WPV + 4 * pq);
+            // window columns 64, 65 (pixel 14 tap 50; pixel 15 taps 49, 50) are the VALU tail sums
+            if (pq == 3 && fx == 50) { v4[2] = s6414; v4[3] = s6515; }
+            if (pq == 3 && fx == 49) v4[3] = s6415;
+            x6_bstore4(v4, ghdst, (qq < 3 || fq < 3) ? qoff : X_OOR, (unsigned)(16 * qq) * plane_b);
+          }
+          ws_set(fl, F_OUT_FREE + p, 2 * n + 2);
+          WS_T(7);
+        }
+      }
+      if (WS_TRACE && blockIdx.x == 0 && lane == 0)
+        for (int k = 0; k < 16; ++k) ws_trace[w][k] += tr_[k];
+    }
+    g = run_end;
+  }
+}
+
+}  // namespace
+
+// gV and gH of the K = 51, C = 3 op, widths that are a multiple of 4; every tensor below 2^31 bytes (the caller checks).
+int savfi_sepconv_bwd_ws_launch(const float* in, const float* v, const float* h, const float* gO, float* gV, float* gH, int B, int Ho,
+                                int Wo, int cus, hipStream_t st) {
+  const int nph = savfi_cdiv(Ho, XPR), ncol = savfi_cdiv(Wo, XMC);
+  const int64_t total = (int64_t)B * ncol * nph;
+  const int per_wg = savfi_cdiv(total, cus);
+  const int grid = savfi_cdiv(total, per_wg);
+  static uint32_t done = 0;
+  if (int e = savfi_ensure_dynamic_lds((const void*)sepconv_bwd_ws, WLDS, done)) return e;
+  hipLaunchKernelGGL(sepconv_bwd_ws, dim3(grid), dim3(WNT), WLDS, st, in, v, h, gO, gV, gH, B, Ho, Wo, nph, ncol, per_wg);
+  return savfi_launch_status();
+}
+
+extern "C" int savfi_sepconv_ws_trace(unsigned long long* out /* [12][16] host */, int reset) {
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ws_trace), sizeof(unsigned long long) * 192) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[192] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(ws_trace), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+
+// protocol time-outs since the library was loaded (0 unless a wait of the kernel above gave up: a bug)
+extern "C" int savfi_sepconv_ws_errors(void) {
+  unsigned n = 0;
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(ws_error_count), sizeof(n)) != hipSuccess) return -1;
+  return (int)(n & 0x7fffffffu);
+}

@@ -1,0 +1,29 @@
+"""Section trace of sepconv_bwd_ws (library built with -DWS_TRACE=1, SAVFI_HIP_LIB): wave cycles per section of workgroup 0."""
+import ctypes, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from meta_interpolation_amd import _hip
+B, C, Ho, Wo, K = int(sys.argv[1]) if len(sys.argv) > 1 else 8, 3, 256, 448, 51
+lib, st = _hip.lib(), _hip.current_stream()
+inp = torch.rand(B, C, Ho + K - 1, Wo + K - 1, device="cuda")
+v = torch.randn(B, K, Ho, Wo, device="cuda") / 7
+h = torch.randn(B, K, Ho, Wo, device="cuda") / 7
+gO = torch.randn(B, C, Ho, Wo, device="cuda")
+gV, gH = torch.empty_like(v), torch.empty_like(h)
+f = lambda: _hip.check(lib.savfi_sepconv_bwd_f32(inp.data_ptr(), v.data_ptr(), h.data_ptr(), gO.data_ptr(), None, gV.data_ptr(), gH.data_ptr(), B, C, Ho, Wo, K, st), "bwd")
+buf = (ctypes.c_ulonglong * 192)()
+lib.savfi_sepconv_ws_trace.argtypes = [ctypes.c_void_p, ctypes.c_int]
+for _ in range(3): f()
+lib.savfi_sepconv_ws_trace(buf, 1)
+NL = 5
+for _ in range(NL): f()
+lib.savfi_sepconv_ws_trace(buf, 1)
+units = 2 * ((B * 14 * 64 + 255) // 256)
+print("per unit (2 passes) cycles, workgroup 0, %d units per pair, lib %s" % (units, os.environ.get("SAVFI_HIP_LIB")))
+MF = ["top", "wait tab(h)", "Bfrag h+set+slide wait", "gV MFMA loop", "gV scale", "wait out_free", "tile write+set", "wait tab(v)", "Bfrag v+set", "gH MFMA loop", "gH scale", "wait out_free", "tile write+set"]
+SG_OLD = ["top: granule loads, readlanes", "wait tab_free", "h table write", "B: side, tails-a, h loads", "wait out_full(gH)", "drain gH", "gV tail sums", "wait tab_free", "v table write", "E: gH tails, v loads", "wait out_full(gV)", "drain gV", "wait prog", "granule write"]
+SG = ["top: row load, readlanes", "wait tab_free", "table write+set", "tails (side, sums), tap loads", "wait prog", "window row write", "wait out_full", "drain+stores"]
+for w in range(12):
+    row = [buf[w * 16 + k] / NL / units for k in range(16)]
+    names = MF if w < 4 else SG
+    print("wave %d total %.0f: " % (w, sum(row)) + " | ".join("%s %.0f" % (names[k], row[k]) for k in range(len(names))))
