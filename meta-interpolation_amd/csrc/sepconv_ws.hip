@@ -63,6 +63,9 @@ constexpr int WSPIN_LIMIT = 1 << 19;
 #ifndef WS_INTERLEAVE           // 1: the next block's A-fragment reads are spread between this block's MFMAs (one LDS read per matrix-pipe gap)
 #define WS_INTERLEAVE 1
 #endif
+#ifndef WS_PRIO_TABLE           // wave priority of a staging wave while it builds a table (what the MFMA wave waits for next)
+#define WS_PRIO_TABLE 3
+#endif
 #ifndef WS_EXP_NOAREAD          // the MFMA loops reuse the first unit's A fragments (no LDS reads inside the loops)
 #define WS_EXP_NOAREAD 0
 #endif
@@ -143,6 +146,15 @@ __device__ __forceinline__ float ws_wave_sum(float x) {
   return (rl(x, 0) + rl(x, 16)) + (rl(x, 32) + rl(x, 48));
 }
 
+// the lane id through an opaque copy: values derived from it are temporaries of the place that uses them, not kernel-long live
+// ranges (at the 168-register budget of three waves per SIMD the allocator spills hoisted per-lane constants, and one scratch
+// reload in the MFMA wave's path costs a memory round trip: 1 700 cycles in front of a pass)
+__device__ __forceinline__ int ws_lane() {
+  int t = threadIdx.x;
+  asm volatile("" : "+v"(t));
+  return t & 63;
+}
+
 __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ in, const float* __restrict__ v,
                                                       const float* __restrict__ h, const float* __restrict__ gO,
                                                       float* __restrict__ gV, float* __restrict__ gH,
@@ -159,6 +171,7 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
   float* const side = reinterpret_cast<float*>(smem + WSIDE_OFF);
   unsigned* const fl = reinterpret_cast<unsigned*>(smem + WFLAG_OFF);
 
+  const unsigned long long t_kernel0 = WS_TRACE ? __builtin_readcyclecounter() : 0ull;
   const int total = B * ncol * nph;
   const int g0 = blockIdx.x * per_wg, g1 = min(g0 + per_wg, total);
   if (g0 >= g1) return;
@@ -245,11 +258,9 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
     const int R0 = XPR * ph0;
     auto unit_y = [&](int n) { return R0 + XPR * (n >> 1) + wr0 + 2 * (n & 1); };
 
-    float hreg[XNP][2], vreg[XNP][2], gp[XC];       // staging: taps and cotangent of the unit at hand / the next one;  MFMA: gp only
+    float gp[XC];                                   // cotangent of the unit at hand (staging: of the next one once the tails have theirs)
     __syncthreads();                                // every wave has left the previous run's window, tables and flags
     if (tid < 32) fl[tid] = 0u;
-    if (role == 1) load_taps(hreg, hsrc, b, x0, unit_y(0), h_t0);
-    if (role == 2) load_taps(vreg, vsrc, b, x0, unit_y(0), v_t0);
     {
       const unsigned go = pix_off(b, x0, unit_y(0), XC);
 #pragma unroll
@@ -268,12 +279,90 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
 
     if (!staging) {
       // =========================================== MFMA wave ===================================================================
+      // One stream of passes: gV(0), gH(0), gV(1), ...  Behind the last MFMA block of a pass the NEXT pass's flag checks, B fragments
+      // and first A fragments are issued BEFORE this pass's epilogue (cotangent scaling, tile write), so that their LDS latencies
+      // run under the epilogue's VALU work instead of in front of the next pass's first MFMA.
       __builtin_amdgcn_s_setprio(WS_PRIO);
       unsigned long long tr_[16] = {0}, tlast_ = __builtin_readcyclecounter();
+      bf16x8 bq[2][3], aq[2][2][3];
+      int rowoff[4], rowh[2][2];
+      auto peek_raw = [&](int idx) { return __hip_atomic_load(fl + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+      auto set_rows = [&](int y) {
+        // (recomputed from the lane id each time: hoisted out of the unit loop these per-lane constants are spilled to scratch at the
+        // 168-register budget of three waves per SIMD, and every reload is a memory round trip in front of the next pass)
+        const int lo_ = ws_lane(), jo = lo_ & 15, ko = lo_ >> 4, Lo = jo;
+        const int pk = ((ko & 1) << 1) | (ko >> 1);
+#pragma unroll
+        for (int m = 0; m < 3; ++m) rowoff[m] = ((y + 16 * m + jo) & (XWIN - 1)) * 16 + (2 * wc + pk) * XBLK;
+        // the packed tile: lane row 4 c + r = tap row 48 + r of channel c (r < 3, c < 3; the other four rows are computed and ignored)
+        rowoff[3] = ((y + 48 + min(jo & 3, 2)) & (XWIN - 1)) * 16 + (2 * wc + pk) * XBLK + min(jo >> 2, 2) * XPLANE;
+        // transpose read: source lane L of group kg points at window row y + 32 s + 16 half + 4 kg + L / 4, column quad L % 4 of the tile
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf)
+            rowh[st][hf] = ((y + 32 * st + 16 * hf + 4 * ko + (Lo >> 2)) & (XWIN - 1)) * 16 + (2 * wc + ((Lo & 3) >> 1)) * XBLK + (Lo & 1) * 8;
+      };
+      // gV blocks (12 MFMAs each: two tiles x six products).  Tap rows 0..47 of a channel are three tiles of 16; rows 48..50 of the
+      // THREE channels share one more tile (a lane's A row is any window row of any channel), so 51 rows x 3 channels cost 10 tiles
+      // instead of 12: blocks 0..5 = (channel, k step) x tiles {0, 1}; 6, 7 = k step x {tile 2 of channel 0, of channel 1};
+      // 8, 9 = k step x {tile 2 of channel 2, packed tile}.  Fragment (uu, t) -> accumulator index, plane of the channel, row base.
+      auto gv_acc = [](int uu, int t) { return uu < 6 ? 3 * (uu >> 1) + t : uu < 8 ? 3 * t + 2 : (t == 0 ? 8 : 9); };
+      auto gv_st = [](int uu) { return uu & 1; };
+      auto load_av = [&](int slot, int uu) {           // lane = window row of the tile, 16 B = 8 columns of k group permk
+        const int st = gv_st(uu);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int ai = gv_acc(uu, t), c = ai == 9 ? 0 : ai / 3, m = ai == 9 ? 3 : ai % 3;
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc)
+            aq[slot][t][pc] = *reinterpret_cast<const bf16x8*>(smem + (pc * 3 + c) * XPLANE + 4 * st * XBLK + rowoff[m]);
+        }
+      };
+      auto load_ah = [&](int slot, int uu) {           // gH: two transpose reads per fragment
+        const int c = uu >> 2, st = (uu >> 1) & 1, mp = uu & 1;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) {
+            const int base = (pc * 3 + c) * XPLANE + 2 * (2 * mp + t) * XBLK;
+            const bf16x4 lo = tr_read(base + rowh[st][0]), hi = tr_read(base + rowh[st][1]);
+            aq[slot][t][pc] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          }
+      };
+      auto read_bh = [&]() {
+        const int lo_ = ws_lane(), jo = lo_ & 15, ko = lo_ >> 4, pk = ((ko & 1) << 1) | (ko >> 1);
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) bq[st][pc] = *reinterpret_cast<const bf16x8*>(tab + pc * XTABP + (4 * st + pk) * 256 + jo * 16);
+      };
+      auto read_bv = [&]() {
+        const int lo_ = ws_lane(), jo = lo_ & 15, ko = lo_ >> 4;
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) bq[st][pc] = *reinterpret_cast<const bf16x8*>(tab + pc * XTABP + (4 * st + ko) * 256 + jo * 16);
+      };
+      // the twelve MFMA blocks of a pass (block = channel c, k step st, tile pair mp: 12 MFMAs); the next block's fragments are
+      // requested between this block's MFMAs (one LDS read per matrix-pipe gap).  The caller has issued load_a(0, 0).
+#define WS_MFMA_BLOCK(uu)                                                                                                             \
+      {                                                                                                                               \
+        const int c = (uu) >> 2, st = ((uu) >> 1) & 1, mp = (uu) & 1;                                                                 \
+        _Pragma("unroll") for (int qq = 0; qq < 6; ++qq)                                                                              \
+          _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                                               \
+            acc[c][2 * mp + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[(uu) & 1][t][PA[qq]], bq[st][PB[qq]], acc[c][2 * mp + t], 0, 0, 0); \
+      }
+
+      // before the first pass: h fragments of unit 0, first A fragments
+      set_rows(unit_y(0));
+      ws_wait(fl, F_TAB_FULL + p, 1);
+      read_bh();
+      ws_set(fl, F_TAB_FREE + p, 1);
+      load_av(0, 0);
 #pragma unroll 1
       for (int n = 0; n < N; ++n) {
         const int q = n >> 1, u = n & 1;
-        const int y = unit_y(n);
         WS_T(0);
         float g_[XC];
 #pragma unroll
@@ -283,50 +372,26 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
 #pragma unroll
           for (int c = 0; c < XC; ++c) gp[c] = x6_bload(gsrc, go, (unsigned)c * plane_b);
         }
-        // ---- gV ----
-        bf16x8 bq[2][3];
-        ws_wait(fl, F_TAB_FULL + p, 2 * n + 1);
-        WS_T(1);
-#pragma unroll
-        for (int st = 0; st < 2; ++st)
-#pragma unroll
-          for (int pc = 0; pc < 3; ++pc) bq[st][pc] = *reinterpret_cast<const bf16x8*>(tab + pc * XTABP + (4 * st + permk) * 256 + j * 16);
-        ws_set(fl, F_TAB_FREE + p, 2 * n + 1);
-        if (u == 0 && q >= 2) ws_wait(fl, F_SLIDE, 8 * (2 * q - 3));
-        WS_T(2);
+        // ---- gV: bq = h band, aq[0] = block 0 ----
         {
-          f32x4 acc[XC][4];
+          f32x4 acc[10];                                 // [3 c + m] (m < 3), [9] = packed tile
 #pragma unroll
-          for (int c = 0; c < XC; ++c)
-#pragma unroll
-            for (int m = 0; m < 4; ++m) acc[c][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-          int rowoff[4];
-#pragma unroll
-          for (int m = 0; m < 4; ++m) rowoff[m] = ((y + min(16 * m + j, XK - 1)) & (XWIN - 1)) * 16 + (2 * wc + permk) * XBLK;
-          bf16x8 aq[2][2][3];
-          auto load_a = [&](int slot, int uu) {
-            const int c = uu >> 2, st = (uu >> 1) & 1, mp = uu & 1;
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-              for (int pc = 0; pc < 3; ++pc)
-                aq[slot][t][pc] = *reinterpret_cast<const bf16x8*>(smem + (pc * 3 + c) * XPLANE + 4 * st * XBLK + rowoff[2 * mp + t]);
-          };
+          for (int i = 0; i < 10; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          unsigned pre_tab = 0u, pre_out = 0u;
           __builtin_amdgcn_sched_barrier(0);
-          if (!WS_EXP_NOMFMA) load_a(0, 0);
 #pragma unroll
-          for (int uu = 0; uu < (WS_EXP_NOMFMA ? 0 : 12); ++uu) {
-            if (uu + 1 < 12 && !WS_EXP_NOAREAD) load_a((uu + 1) & 1, uu + 1);
-            if (!WS_INTERLEAVE) __builtin_amdgcn_sched_barrier(0);          // the next block's fragments are requested BEFORE this block's MFMAs issue
-            const int c = uu >> 2, st = (uu >> 1) & 1, mp = uu & 1;
+          for (int uu = 0; uu < 10; ++uu) {
+            if (uu + 1 < 10) load_av((uu + 1) & 1, uu + 1);
+            else { pre_tab = peek_raw(F_TAB_FULL + p); pre_out = peek_raw(F_OUT_FREE + p); }
+            {
+              const int st = gv_st(uu);
 #pragma unroll
-            for (int qq = 0; qq < 6; ++qq)
+              for (int qq = 0; qq < 6; ++qq)
 #pragma unroll
-              for (int t = 0; t < 2; ++t) {
-                if (WS_EXP_NOMFMAONLY) { if (qq < 3) acc[c][2 * mp + t][0] += __builtin_bit_cast(float, aq[uu & 1][t][qq][0] + aq[uu & 1][t][qq][7]); continue; }
-                acc[c][2 * mp + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[WS_EXP_NOAREAD ? 0 : (uu & 1)][t][PA[qq]], bq[st][PB[qq]], acc[c][2 * mp + t], 0, 0, 0);
-              }
-            if (WS_INTERLEAVE && uu + 1 < 12) {           // MFMA, DS read, MFMA, DS read ... (6 reads), then the remaining MFMAs
+                for (int t = 0; t < 2; ++t)
+                  acc[gv_acc(uu, t)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[uu & 1][t][PA[qq]], bq[st][PB[qq]], acc[gv_acc(uu, t)], 0, 0, 0);
+            }
+            if (WS_INTERLEAVE && uu + 1 < 10) {           // MFMA, DS read, MFMA, DS read ... (6 reads), then the remaining MFMAs
 #pragma unroll
               for (int i = 0; i < 6; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -336,76 +401,59 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
             }
             __builtin_amdgcn_sched_barrier(0);
           }
-          // D row 4 kg + r of tile m = tap row fy = 16 m + 4 kg + r, column = pixel j
           WS_T(3);
+          // the next pass (gH of this unit): v fragments, first A fragments -- before this pass's epilogue
+          if ((int)__builtin_amdgcn_readfirstlane((int)pre_tab) < 2 * n + 2) ws_wait(fl, F_TAB_FULL + p, 2 * n + 2);
+          read_bv();
+          ws_set(fl, F_TAB_FREE + p, 2 * n + 2);
+          load_ah(0, 0);
+          WS_T(4);
+          // D row 4 kg + r of tile m = tap row fy = 16 m + 4 kg + r (m < 3), column = pixel j; the packed tile's lane group kg holds
+          // rows 48 + r of channel kg: scaled by that channel's cotangent it goes to tile row 64 + 4 kg + r, the h-side wave adds the
+          // three channels when it drains rows 48..50
           float val[4][4];
 #pragma unroll
-          for (int m = 0; m < 4; ++m)
+          for (int m = 0; m < 3; ++m)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              float t = g_[0] * acc[0][m][r];
-              t = fmaf(g_[1], acc[1][m][r], t);
-              t = fmaf(g_[2], acc[2][m][r], t);
+              float t = g_[0] * acc[m][r];
+              t = fmaf(g_[1], acc[3 + m][r], t);
+              t = fmaf(g_[2], acc[6 + m][r], t);
               val[m][r] = t;
             }
-          WS_T(4);
-          ws_wait(fl, F_OUT_FREE + p, 2 * n);
+          const int lo_ = ws_lane();
+          {
+            const int ko = lo_ >> 4;
+            const float gs = ko == 0 ? g_[0] : ko == 1 ? g_[1] : ko == 2 ? g_[2] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) val[3][r] = gs * acc[9][r];
+          }
+          if ((int)__builtin_amdgcn_readfirstlane((int)pre_out) < 2 * n) ws_wait(fl, F_OUT_FREE + p, 2 * n);
           WS_T(5);
+          {
+            float* const tw = tile + (4 * (lo_ >> 4)) * WPV + (lo_ & 15);
 #pragma unroll
-          for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < 4; ++m)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) tile[(16 * m + 4 * kg + r) * WPV + j] = val[m][r];
+              for (int r = 0; r < 4; ++r) tw[((m < 3 ? 16 * m : 64) + r) * WPV] = val[m][r];
+          }
           ws_set(fl, F_OUT_FULL + p, 2 * n + 1);
           WS_T(6);
         }
-        // ---- gH ----
-        ws_wait(fl, F_TAB_FULL + p, 2 * n + 2);
-        WS_T(7);
-#pragma unroll
-        for (int st = 0; st < 2; ++st)
-#pragma unroll
-          for (int pc = 0; pc < 3; ++pc) bq[st][pc] = *reinterpret_cast<const bf16x8*>(tab + pc * XTABP + (4 * st + kg) * 256 + j * 16);
-        ws_set(fl, F_TAB_FREE + p, 2 * n + 2);
-        WS_T(8);
+        // ---- gH: bq = v, aq[0] = block 0 ----
         {
           f32x4 acc[XC][4];
 #pragma unroll
           for (int c = 0; c < XC; ++c)
 #pragma unroll
             for (int m = 0; m < 4; ++m) acc[c][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
-          // transpose read: source lane L of group kg points at window row y + 32 s + 16 half + 4 kg + L / 4, column quad L % 4 of the tile
-          int rowh[2][2];
-#pragma unroll
-          for (int st = 0; st < 2; ++st)
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf)
-              rowh[st][hf] = ((y + 32 * st + 16 * hf + 4 * kg + (L >> 2)) & (XWIN - 1)) * 16 + (2 * wc + ((L & 3) >> 1)) * XBLK + (L & 1) * 8;
-          bf16x8 aq[2][2][3];
-          auto load_a = [&](int slot, int uu) {
-            const int c = uu >> 2, st = (uu >> 1) & 1, mp = uu & 1;
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-              for (int pc = 0; pc < 3; ++pc) {
-                const int base = (pc * 3 + c) * XPLANE + 2 * (2 * mp + t) * XBLK;
-                const bf16x4 lo = tr_read(base + rowh[st][0]), hi = tr_read(base + rowh[st][1]);
-                aq[slot][t][pc] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-              }
-          };
+          unsigned pre_tab = 0u, pre_out = 0u, pre_slide = 0u;
           __builtin_amdgcn_sched_barrier(0);
-          if (!WS_EXP_NOMFMA) load_a(0, 0);
 #pragma unroll
-          for (int uu = 0; uu < (WS_EXP_NOMFMA ? 0 : 12); ++uu) {
-            if (uu + 1 < 12 && !WS_EXP_NOAREAD) load_a((uu + 1) & 1, uu + 1);
-            if (!WS_INTERLEAVE) __builtin_amdgcn_sched_barrier(0);          // the next block's fragments are requested BEFORE this block's MFMAs issue
-            const int c = uu >> 2, st = (uu >> 1) & 1, mp = uu & 1;
-#pragma unroll
-            for (int qq = 0; qq < 6; ++qq)
-#pragma unroll
-              for (int t = 0; t < 2; ++t) {
-                if (WS_EXP_NOMFMAONLY) { if (qq < 3) acc[c][2 * mp + t][0] += __builtin_bit_cast(float, aq[uu & 1][t][qq][0] + aq[uu & 1][t][qq][7]); continue; }
-                acc[c][2 * mp + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[WS_EXP_NOAREAD ? 0 : (uu & 1)][t][PA[qq]], bq[st][PB[qq]], acc[c][2 * mp + t], 0, 0, 0);
-              }
+          for (int uu = 0; uu < 12; ++uu) {
+            if (uu + 1 < 12) load_ah((uu + 1) & 1, uu + 1);
+            else { pre_tab = peek_raw(F_TAB_FULL + p); pre_out = peek_raw(F_OUT_FREE + p); pre_slide = peek_raw(F_SLIDE); }
+            WS_MFMA_BLOCK(uu)
             if (WS_INTERLEAVE && uu + 1 < 12) {           // MFMA, 2 transpose reads, ... (24 reads over the 12 MFMAs)
 #pragma unroll
               for (int i = 0; i < 12; ++i) {
@@ -416,6 +464,20 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
             __builtin_amdgcn_sched_barrier(0);
           }
           WS_T(9);
+          if (u == 1) ws_set(fl, F_PROG + w, q + 1);           // this phase's window reads are over
+          // the next pass (gV of the next unit): h fragments, first A fragments -- before this pass's epilogue
+          if (n + 1 < N) {
+            const int q1 = (n + 1) >> 1;
+            if ((int)__builtin_amdgcn_readfirstlane((int)pre_tab) < 2 * n + 3) ws_wait(fl, F_TAB_FULL + p, 2 * n + 3);
+            WS_T(13);
+            read_bh();
+            ws_set(fl, F_TAB_FREE + p, 2 * n + 3);
+            if (u == 1 && q1 >= 2 && (int)__builtin_amdgcn_readfirstlane((int)pre_slide) < 8 * (2 * q1 - 3)) ws_wait(fl, F_SLIDE, 8 * (2 * q1 - 3));
+            WS_T(14);
+            set_rows(unit_y(n + 1));
+            load_av(0, 0);
+          }
+          WS_T(10);
           float val[4][4];
 #pragma unroll
           for (int m = 0; m < 4; ++m)
@@ -426,18 +488,21 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
               t = fmaf(g_[2], acc[2][m][r], t);
               val[m][r] = t;
             }
-          WS_T(10);
-          ws_wait(fl, F_OUT_FREE + p, 2 * n + 1);
+          if ((int)__builtin_amdgcn_readfirstlane((int)pre_out) < 2 * n + 1) ws_wait(fl, F_OUT_FREE + p, 2 * n + 1);
           WS_T(11);
+          {
+            const int lo_ = ws_lane();
+            float* const tw = tile + (4 * (lo_ >> 4) - (lo_ & 15) + 15) * WPV + (lo_ & 15);
 #pragma unroll
-          for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < 4; ++m)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) tile[(16 * m + 4 * kg + r - j + 15) * WPV + j] = val[m][r];
+              for (int r = 0; r < 4; ++r) tw[(16 * m + r) * WPV] = val[m][r];
+          }
           ws_set(fl, F_OUT_FULL + p, 2 * n + 2);
           WS_T(12);
         }
-        if (u == 1) ws_set(fl, F_PROG + w, q + 1);
       }
+#undef WS_MFMA_BLOCK
       __builtin_amdgcn_s_setprio(0);
       if (WS_TRACE && blockIdx.x == 0 && lane == 0)
         for (int k = 0; k < 16; ++k) ws_trace[w][k] += tr_[k];
@@ -453,15 +518,24 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
       const unsigned gcolb = (unsigned)min(x0 + gcol, Wi - 1) * 4u;
       const int gc0 = ggrp == 0 ? 0 : 2, gc1 = ggrp == 0 ? 1 : 2;
       unsigned long long tr_[16] = {0}, tlast_ = __builtin_readcyclecounter();
+      float hreg[XNP][2], vreg[XNP][2];               // taps of the unit at hand, then of the next one (one of the two per role)
+      if (hside) load_taps(hreg, hsrc, b, x0, unit_y(0), h_t0);
+      else load_taps(vreg, vsrc, b, x0, unit_y(0), v_t0);
+      float s6414 = 0.f, s6415 = 0.f, s6515 = 0.f;   // v side: gH tail sums of the unit whose tile is drained next
+      unsigned qoff_prev = X_OOR;
+      // Iteration n: (1) the table of unit n -- FIRST: it is what the MFMA wave waits for next --, (2) the tile of unit n - 1 -> HBM,
+      // (3) tail columns of unit n, taps of unit n + 1, (4) one new window row.  Iteration N only drains the last tile.
 #pragma unroll 1
-      for (int n = 0; n < N; ++n) {
-        const int q = n >> 1, u = n & 1;
-        const int y = unit_y(n), y1 = unit_y(min(n + 1, N - 1));
+      for (int n = 0; n <= N; ++n) {
+        const bool live = n < N;
+        const int nn = min(n, N - 1);
+        const int q = nn >> 1, u = nn & 1;
+        const int y = unit_y(nn), y1 = unit_y(min(nn + 1, N - 1));
         const int xq = x0 + 16 * wc + 4 * pq;
-        const unsigned qoff = (y < Ho && xq < Wo) ? (unsigned)b * (unsigned)XK * plane_b + (unsigned)(y * Wo + xq) * 4u + (unsigned)fq * plane_b : X_OOR;
+        const unsigned qoff = (live && y < Ho && xq < Wo) ? (unsigned)b * (unsigned)XK * plane_b + (unsigned)(y * Wo + xq) * 4u + (unsigned)fq * plane_b : X_OOR;
         // one new window row per role and unit (rows R0 + 60 + 2 n + {0 | 1})
         float gr0, gr1;
-        const int grow = R0 + 60 + 2 * n + (hside ? 0 : 1);
+        const int grow = R0 + 60 + 2 * nn + (hside ? 0 : 1);
         {
           const int rr = min(grow, Hi - 1);
           gr0 = WS_EXP_NOSTAGE ? 0.f : x6_bload(isrc, (unsigned)(((b * XC + gc0) * Hi + rr) * Wi) * 4u + gcolb, 0u);
@@ -472,19 +546,41 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
         for (int c = 0; c < XC; ++c) { g14[c] = rdlane(gp[c], 14); g15[c] = rdlane(gp[c], 15); }
         const int fyl = min(lane, XK - 1);
         const int tslot = (y + fyl) & (XWIN - 1);
-        float s6414 = 0.f, s6415 = 0.f, s6515 = 0.f;
         WS_T(0);
         if (hside) {
           // what the tail columns need of this unit's taps, before the registers take the next unit's
           const float h50_14 = rdlane(hreg[6][0], 14 + 16), h49_15 = rdlane(hreg[6][0], 15 + 16), h50_15 = rdlane(hreg[6][1], 15 + 16);
-          // the h band of unit n takes the table (the MFMA wave holds v of unit n - 1 in registers)
-          ws_wait(fl, F_TAB_FREE + p, 2 * n);
-          WS_T(1);
-          if (!WS_EXP_NOSTAGE) write_h_table(hreg);
-          ws_set(fl, F_TAB_FULL + p, 2 * n + 1);
-          WS_T(2);
-          // tail columns of gV (i = 64: pixel 14 tap 50, pixel 15 tap 49; i = 65: pixel 15 tap 50): lane = tap row fy
-          if (u == 0 && q >= 2) ws_wait(fl, F_SLIDE, 8 * (2 * q - 3));
+          // (1) the h band of unit n takes the table (the MFMA wave holds v of unit n - 1 in registers)
+          if (live) {
+            ws_wait(fl, F_TAB_FREE + p, 2 * n);
+            WS_T(1);
+            __builtin_amdgcn_s_setprio(WS_PRIO_TABLE);
+            if (!WS_EXP_NOSTAGE) write_h_table(hreg);
+            ws_set(fl, F_TAB_FULL + p, 2 * n + 1);
+            __builtin_amdgcn_s_setprio(0);
+            WS_T(2);
+          }
+          // (2) the gV tile of unit n - 1 -> HBM (tail sums of that unit still in tailb)
+          if (n > 0) ws_wait(fl, F_OUT_FULL + p, 2 * n - 1);
+          WS_T(6);
+#pragma unroll
+          for (int qq = 0; qq < (WS_EXP_NOSTAGE ? 0 : 4); ++qq) {
+            const int row = fq + 16 * qq;
+            f32x4 v4 = *reinterpret_cast<const f32x4*>(tile + (qq < 3 ? row : 64 + (fq & 3)) * WPV + 4 * pq);
+            if (qq == 3) {      // tap rows 48..50 (fq < 3): the three channels' scaled rows of the packed tile
+              const f32x4 c1 = *reinterpret_cast<const f32x4*>(tile + (68 + (fq & 3)) * WPV + 4 * pq);
+              const f32x4 c2 = *reinterpret_cast<const f32x4*>(tile + (72 + (fq & 3)) * WPV + 4 * pq);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v4[e] = (v4[e] + c1[e]) + c2[e];
+            }
+            const float t14 = tailb[row], t15 = tailb[64 + row];
+            if (pq == 3) { v4[2] += t14; v4[3] += t15; }
+            x6_bstore4(v4, gvdst, (qq < 3 || fq < 3) ? qoff_prev : X_OOR, (unsigned)(16 * qq) * plane_b);
+          }
+          if (n > 0) ws_set(fl, F_OUT_FREE + p, 2 * n - 1);
+          WS_T(7);
+          // (3) tail columns of gV (i = 64: pixel 14 tap 50, pixel 15 tap 49; i = 65: pixel 15 tap 50): lane = tap row fy
+          if (live && u == 0 && q >= 2) ws_wait(fl, F_SLIDE, 8 * (2 * q - 3));
           float a64[XC], a65[XC];
 #pragma unroll
           for (int c = 0; c < XC; ++c) {
@@ -492,7 +588,7 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
             a64[c] = sv.x; a65[c] = sv.y;
           }
           asm volatile("" ::: "memory");
-          if (u == 1) ws_set(fl, F_PROG + w, q + 1);
+          if (live && u == 1) ws_set(fl, F_PROG + w, q + 1);
           if (!WS_EXP_NOSTAGE) load_taps(hreg, hsrc, b, x0, y1, h_t0);
           {
             float t14 = 0.f, t15 = 0.f;
@@ -507,35 +603,53 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
           }
           WS_T(3);
         } else {
-          // v of unit n takes the table (the MFMA wave holds the h band of unit n in registers)
-          ws_wait(fl, F_TAB_FREE + p, 2 * n + 1);
-          WS_T(1);
-          if (!WS_EXP_NOSTAGE) write_v_table(vreg);
-          // v of pixels 14, 15 by tap row (lane = fy) for the tail columns: read back from the table's pieces BEFORE the table is
-          // published -- once the MFMA wave has taken its fragments the h-side wave refills the table
+          // (1) v of unit n takes the table (the MFMA wave holds the h band of unit n in registers)
           float v14 = 0.f, v15 = 0.f;
-          if (!WS_EXP_NOSTAGE) {
-            const int f5 = fyl & 31;
-            const char* tp = tab + (4 * (fyl >> 5) + ((f5 & 15) >> 2)) * 256 + ((f5 & 3) + 4 * ((f5 >> 4) & 1)) * 2;
-            unsigned short r14[3], r15[3];
+          if (live) {
+            ws_wait(fl, F_TAB_FREE + p, 2 * n + 1);
+            WS_T(1);
+            __builtin_amdgcn_s_setprio(WS_PRIO_TABLE);
+            if (!WS_EXP_NOSTAGE) write_v_table(vreg);
+            // v of pixels 14, 15 by tap row (lane = fy) for the tail columns: read back from the table's pieces BEFORE the table is
+            // published -- once the MFMA wave has taken its fragments the h-side wave refills the table
+            if (!WS_EXP_NOSTAGE) {
+              const int f5 = fyl & 31;
+              const char* tp = tab + (4 * (fyl >> 5) + ((f5 & 15) >> 2)) * 256 + ((f5 & 3) + 4 * ((f5 >> 4) & 1)) * 2;
+              unsigned short r14[3], r15[3];
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) {
-              r14[pc] = *reinterpret_cast<const unsigned short*>(tp + pc * XTABP + 14 * 16);
-              r15[pc] = *reinterpret_cast<const unsigned short*>(tp + pc * XTABP + 15 * 16);
-            }
-            asm volatile("" ::: "memory");
-            ws_set(fl, F_TAB_FULL + p, 2 * n + 2);
+              for (int pc = 0; pc < 3; ++pc) {
+                r14[pc] = *reinterpret_cast<const unsigned short*>(tp + pc * XTABP + 14 * 16);
+                r15[pc] = *reinterpret_cast<const unsigned short*>(tp + pc * XTABP + 15 * 16);
+              }
+              asm volatile("" ::: "memory");
+              ws_set(fl, F_TAB_FULL + p, 2 * n + 2);
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) {
-              v14 += __uint_as_float((unsigned)r14[pc] << 16);
-              v15 += __uint_as_float((unsigned)r15[pc] << 16);
+              for (int pc = 0; pc < 3; ++pc) {
+                v14 += __uint_as_float((unsigned)r14[pc] << 16);
+                v15 += __uint_as_float((unsigned)r15[pc] << 16);
+              }
+            } else {
+              ws_set(fl, F_TAB_FULL + p, 2 * n + 2);
             }
-          } else {
-            ws_set(fl, F_TAB_FULL + p, 2 * n + 2);
+            __builtin_amdgcn_s_setprio(0);
+            WS_T(2);
           }
-          WS_T(2);
-          // tail columns of gH (q = 64, 65: taps 50 / 49, 50 of pixels 14, 15): lane = tap row fy, v from the table's pieces
-          if (u == 0 && q >= 2) ws_wait(fl, F_SLIDE, 8 * (2 * q - 3));
+          // (2) the gH tile of unit n - 1 -> HBM
+          if (n > 0) ws_wait(fl, F_OUT_FULL + p, 2 * n);
+          WS_T(6);
+#pragma unroll
+          for (int qq = 0; qq < (WS_EXP_NOSTAGE ? 0 : 4); ++qq) {
+            const int fx = fq + 16 * qq;
+            f32x4 v4 = *reinterpret_cast<const f32x4*>(tile + (fx + 15) * WPV + 4 * pq);
+            // window columns 64, 65 (pixel 14 tap 50; pixel 15 taps 49, 50) are the VALU tail sums
+            if (pq == 3 && fx == 50) { v4[2] = s6414; v4[3] = s6515; }
+            if (pq == 3 && fx == 49) v4[3] = s6415;
+            x6_bstore4(v4, ghdst, (qq < 3 || fq < 3) ? qoff_prev : X_OOR, (unsigned)(16 * qq) * plane_b);
+          }
+          if (n > 0) ws_set(fl, F_OUT_FREE + p, 2 * n);
+          WS_T(7);
+          // (3) tail columns of gH (q = 64, 65: taps 50 / 49, 50 of pixels 14, 15): lane = tap row fy
+          if (live && u == 0 && q >= 2) ws_wait(fl, F_SLIDE, 8 * (2 * q - 3));
           float a64[XC], a65[XC];
 #pragma unroll
           for (int c = 0; c < XC; ++c) {
@@ -543,7 +657,7 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
             a64[c] = sv.x; a65[c] = sv.y;
           }
           asm volatile("" ::: "memory");
-          if (u == 1) ws_set(fl, F_PROG + w, q + 1);
+          if (live && u == 1) ws_set(fl, F_PROG + w, q + 1);
           if (!WS_EXP_NOSTAGE) {
             const float lv = lane < XK ? 1.f : 0.f;
             v14 *= lv; v15 *= lv;
@@ -562,13 +676,14 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
           if (!WS_EXP_NOSTAGE) load_taps(vreg, vsrc, b, x0, y1, v_t0);
           WS_T(3);
         }
+        qoff_prev = qoff;
         if (!WS_EXP_NOSTAGE) {
           const unsigned go = pix_off(b, x0, y1, XC);
 #pragma unroll
           for (int c = 0; c < XC; ++c) gp[c] = x6_bload(gsrc, go, (unsigned)c * plane_b);
         }
-        // the new window row (slot of row 4 q - 4 + 2 u + {0 | 1}: behind every wave once phase q - 1 is done)
-        {
+        // (4) the new window row (slot of row 4 q - 4 + 2 u + {0 | 1}: behind every wave once phase q - 1 is done)
+        if (live) {
           if (q >= 1) ws_wait_all_prog(fl, q);
           WS_T(4);
           const int slot = grow & (XWIN - 1);
@@ -588,41 +703,13 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
           asm volatile("" ::: "memory");
           WS_T(5);
         }
-        // the pair's output tile -> HBM
-        if (hside) {
-          ws_wait(fl, F_OUT_FULL + p, 2 * n + 1);
-          WS_T(6);
-#pragma unroll
-          for (int qq = 0; qq < (WS_EXP_NOSTAGE ? 0 : 4); ++qq) {
-            const int row = fq + 16 * qq;
-            f32x4 v4 = *reinterpret_cast<const f32x4*>(tile + row * WPV + 4 * pq);
-            const float t14 = tailb[row], t15 = tailb[64 + row];
-            if (pq == 3) { v4[2] += t14; v4[3] += t15; }
-            x6_bstore4(v4, gvdst, (qq < 3 || fq < 3) ? qoff : X_OOR, (unsigned)(16 * qq) * plane_b);
-          }
-          ws_set(fl, F_OUT_FREE + p, 2 * n + 1);
-          WS_T(7);
-        } else {
-          ws_wait(fl, F_OUT_FULL + p, 2 * n + 2);
-          WS_T(6);
-#pragma unroll
-          for (int qq = 0; qq < (WS_EXP_NOSTAGE ? 0 : 4); ++qq) {
-            const int fx = fq + 16 * qq;
-            f32x4 v4 = *reinterpret_cast<const f32x4*>(tile + (fx + 15) * WPV + 4 * pq);
-            // window columns 64, 65 (pixel 14 tap 50; pixel 15 taps 49, 50) are the VALU tail sums
-            if (pq == 3 && fx == 50) { v4[2] = s6414; v4[3] = s6515; }
-            if (pq == 3 && fx == 49) v4[3] = s6415;
-            x6_bstore4(v4, ghdst, (qq < 3 || fq < 3) ? qoff : X_OOR, (unsigned)(16 * qq) * plane_b);
-          }
-          ws_set(fl, F_OUT_FREE + p, 2 * n + 2);
-          WS_T(7);
-        }
       }
       if (WS_TRACE && blockIdx.x == 0 && lane == 0)
         for (int k = 0; k < 16; ++k) ws_trace[w][k] += tr_[k];
     }
     g = run_end;
   }
+  if (WS_TRACE && blockIdx.x == 0 && (threadIdx.x & 63) == 0) ws_trace[threadIdx.x >> 6][15] += __builtin_readcyclecounter() - t_kernel0;
 }
 
 }  // namespace

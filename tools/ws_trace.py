@@ -16,14 +16,21 @@ lib.savfi_sepconv_ws_trace.argtypes = [ctypes.c_void_p, ctypes.c_int]
 for _ in range(3): f()
 lib.savfi_sepconv_ws_trace(buf, 1)
 NL = 5
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
 for _ in range(NL): f()
+e1.record(); torch.cuda.synchronize()
+print("traced build: %.1f us per launch" % (1e3 * e0.elapsed_time(e1) / NL))
 lib.savfi_sepconv_ws_trace(buf, 1)
 units = 2 * ((B * 14 * 64 + 255) // 256)
 print("per unit (2 passes) cycles, workgroup 0, %d units per pair, lib %s" % (units, os.environ.get("SAVFI_HIP_LIB")))
-MF = ["top", "wait tab(h)", "Bfrag h+set+slide wait", "gV MFMA loop", "gV scale", "wait out_free", "tile write+set", "wait tab(v)", "Bfrag v+set", "gH MFMA loop", "gH scale", "wait out_free", "tile write+set"]
+MF = ["top", "wait tab(h)", "Bfrag h+set+slide wait", "gV MFMA loop", "gV scale", "wait out_free", "tile write+set", "wait tab(v)", "Bfrag v+set", "gH MFMA loop", "gH scale", "wait out_free", "tile write+set", "T13 wait tab(h next)", "T14 Bfrag+slide wait"]
 SG_OLD = ["top: granule loads, readlanes", "wait tab_free", "h table write", "B: side, tails-a, h loads", "wait out_full(gH)", "drain gH", "gV tail sums", "wait tab_free", "v table write", "E: gH tails, v loads", "wait out_full(gV)", "drain gV", "wait prog", "granule write"]
-SG = ["top: row load, readlanes", "wait tab_free", "table write+set", "tails (side, sums), tap loads", "wait prog", "window row write", "wait out_full", "drain+stores"]
+SG = ["top: row load, readlanes", "wait tab_free", "table write+set", "tails (side, sums), tap loads", "wait prog", "window row write", "wait out_full(prev)", "drain+stores(prev)"]
 for w in range(12):
     row = [buf[w * 16 + k] / NL / units for k in range(16)]
     names = MF if w < 4 else SG
+    print("wave %d kernel cycles per launch %.0f; " % (w, buf[w * 16 + 15] / NL), end="")
+    row[15] = 0
     print("wave %d total %.0f: " % (w, sum(row)) + " | ".join("%s %.0f" % (names[k], row[k]) for k in range(len(names))))
