@@ -48,8 +48,11 @@ import torch  # noqa: E402
 WORKLOADS = {
     # name: (model, H, W, tasks/GPU, inner steps, overrides)
     'c2_sepconv_256x448_b4_s5': ('sepconv', 256, 448, 4, 5, dict(optimizer='SGD', loss='1*L1', inner_lr=1e-5)),
+    # VoxelFlow's seeded weights at the model's own initialisation scale (synthetic.py recipe 'smooth': normal(0, 0.01),
+    # voxel_flow.py:267-274): the configuration the reference reproduces ITSELF on (tests/golden/full_c3s_*.npz, self-spread 3e-7 pixel
+    # L1), so that `parity_check` is a real end-to-end check.  The kernels and their timing do not depend on the weight values.
     'c3_voxelflow_metasgd_256x256_b8_s5': ('voxelflow', 256, 256, 8, 5,
-                                           dict(optimizer='Adamax', metasgd=True, loss='1*MSE', inner_lr=1e-5)),
+                                           dict(optimizer='Adamax', metasgd=True, loss='1*MSE', inner_lr=1e-5, weight_recipe='smooth')),
     'c1_cain_64x64_b1_s1': ('cain', 64, 64, 1, 1, dict(optimizer='SGD', loss='1*L1', inner_lr=1e-5)),
     # one GPU's share of BASELINE config 4 (meta-batch 32 over 8 GPUs): MAML++ multi-step loss = a target pass after every step
     'c4_sepconv_msl_256x448_b4_s5': ('sepconv', 256, 448, 4, 5, dict(optimizer='SGD', loss='1*L1', inner_lr=1e-5,
@@ -87,7 +90,7 @@ def cpu_baseline(model, H, W, S, overrides):
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     os.environ["OMP_NUM_THREADS"] = str(cores)
-    base = oracle_base(model)
+    base = oracle_base(model, recipe=overrides.get('weight_recipe'))
     frames = synthetic.septuplet_batch(1, H, W, model=model)
     kind = 'metasgd' if overrides.get('metasgd') else 'lslr'
     names_w = {n: base[n] for n in meta.inner_param_names([(n, p) for n, p in base.items() if p.is_floating_point()])}
@@ -111,7 +114,7 @@ def cpu_baseline(model, H, W, S, overrides):
     return line, res
 
 
-def parity_check(system, theta0, frames, model, H, W, S, oracle_res, dev, mode):
+def parity_check(system, theta0, frames, model, H, W, S, oracle_res, dev, mode, smooth_weights=False):
     """The TIMED system in the TIMED mode against the oracle's sample: theta back to the seeded weights, outer step disabled,
     one more meta-iteration over the same resident meta-batch; task 0 is the oracle's task."""
     from oracle import meta
@@ -144,7 +147,7 @@ def parity_check(system, theta0, frames, model, H, W, S, oracle_res, dev, mode):
     how = ("lockstep T=%s" % calls) if calls else ("hipGraph replays" if getattr(system, '_graphs', None) else "sequential task loop")
     out = {"loss_rel": rel, "pixel_l1": l1, "dpsnr_db": dpsnr, "ok": bool(rel <= 1e-5 and l1 <= 1e-4 and dpsnr <= 1e-3),
            "bounds": {"loss_rel": 1e-5, "pixel_l1": 1e-4, "dpsnr_db": 1e-3}}
-    if model == 'voxelflow' and system.args.optimizer != 'SGD':
+    if model == 'voxelflow' and system.args.optimizer != 'SGD' and not smooth_weights:
         # C3's rule steps +-lr*c per element whatever |g| and VoxelFlow amplifies rounding ~1000x: after 5 steps at 256x256 the
         # imported reference differs from ITSELF (another conv summation order / float64) by 1.5e-2 .. 0.13 pixel L1
         # (tests/golden/full_c3_voxelflow_256x256_s5.npz `spread`).  End-of-iteration numbers cannot meet the contract bounds for
@@ -184,6 +187,9 @@ def main():
                          '(off by default: the default command runs ONE mode, so that a rocprofv3 trace of it shows the kernels of `value` only)')
     ap.add_argument('--wgrad-overlap', type=int, default=None, help='weight gradients of support passes on a side stream')
     ap.add_argument('--task-batch', type=int, default=None, help='tasks adapted in lockstep (one launch per layer for all of them)')
+    ap.add_argument('--no-strong-c4', action='store_true',
+                    help='skip the second timed region of SepConv runs: BASELINE config 4 (SepConv + MAML++ multi-step loss) at a FIXED '
+                         'global meta-batch of 32 tasks (strong scaling: 32 / gpus tasks per rank), reported as `strong_c4`')
     ap.add_argument('--global-batch', type=int, default=None,
                     help='FIXED global meta-batch (strong scaling: tasks/GPU = global / gpus, e.g. 32 for BASELINE config 4); default: '
                          'the workload\'s tasks per GPU on every rank (weak scaling)')
@@ -208,6 +214,8 @@ def main():
             torch.cuda.synchronize()
 
     model, H, W, tasks, S, over = WORKLOADS[opt.workload]
+    over_all, over = over, {k: v for k, v in over.items() if k != 'weight_recipe'}     # the recipe is not a config.py flag
+    recipe = over_all.get('weight_recipe')
     scaling = "weak"
     if opt.global_batch:
         if opt.global_batch % world:
@@ -228,7 +236,7 @@ def main():
                             number_of_evaluation_steps_per_iter=S, **switches, **over)
         with contextlib.redirect_stdout(sys.stderr):      # the ONE line on stdout is the JSON result
             net = MODEL_REGISTRY[model](args, False)
-        synthetic.load_seeded_weights(net, model)          # identical theta on every rank, no broadcast
+        synthetic.load_seeded_weights(net, model, recipe=recipe)          # identical theta on every rank, no broadcast
         with contextlib.redirect_stdout(sys.stderr):
             system = SceneAdaptiveInterpolation(args, net=net.to(dev))
     if args.attenuate:   # L2F: non-trivial seeded attenuator (gamma_mult = 0 would make it a no-op)
@@ -245,7 +253,10 @@ def main():
     theta0 = {k: v.detach().clone() for k, v in system.state_dict().items()} if (rank == 0 and not toy) else None
 
     def one_iter(it):
-        system.run_train_iter(data_batch=frames, epoch=0, do_evaluation=False)
+        losses, _, _ = system.run_train_iter(data_batch=frames, epoch=0, do_evaluation=False)
+        # the reference's run_train_iter hands back finished numbers and its training loop logs the loss every iteration
+        # (experiment_builder.py:58-74): read it, so that the per-iteration logging sync is inside the timed region
+        float(losses['loss'])
 
     for i in range(opt.warmup):
         one_iter(i)
@@ -259,6 +270,7 @@ def main():
     if not opt.no_kernel_timer and model == 'sepconv':
         timer = _hip.KernelTimer(only=HBM_KERNELS[model])
         _hip.TIMER = timer
+    tp.record_timing = tp.active and dev.type == 'cuda'
     tp.barrier()
     sync()
     t0 = time.perf_counter()
@@ -268,6 +280,10 @@ def main():
     tp.barrier()
     elapsed = time.perf_counter() - t0
     _hip.TIMER = None
+    tp.record_timing = False
+    ar_stats = tp.allreduce_stats()
+    # the replicas took the same optimizer steps from the same theta: bit-identical parameters on every rank (no broadcast anywhere)
+    replicas_ok = tp.replicas_identical([p for p in system.parameters()]) if tp.active else None
     if tp.active:
         import torch.distributed as dist
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -287,9 +303,20 @@ def main():
         "config": {"workload": opt.workload, "plugin": model, "tasks_per_gpu": tasks, "global_meta_batch": tasks * world,
                    "inner_steps": S, "frame": "%dx%dx3" % (H, W),
                    "inner_rule": ("metasgd" if over.get('metasgd') else "lslr") + "+" + over.get('optimizer', 'SGD'),
+                   "seeded_weights": recipe or "default",
                    "parallelism": "task-parallel x%d, 1 all-reduce of outer grads" % world, "mode": mode,
                    "outer_tasks_per_sec": tasks * world * opt.steps / elapsed},
     }
+    if tp.active:
+        import torch.distributed as dist
+        backend = dist.get_backend()
+        line["multi_gpu"] = {
+            "backend": backend + (" (RCCL)" if backend == "nccl" else ""), "rccl_ranks": dist.get_world_size() if backend == "nccl" else 0,
+            "world_size": dist.get_world_size(), "devices_visible_to_rank0": torch.cuda.device_count() if dev.type == 'cuda' else 0,
+            "collectives_per_meta_iteration": 1, "allreduce": ar_stats, "replicas_bit_identical_after_timed_region": replicas_ok,
+            "outer_tasks_per_sec_weak": tasks * world * opt.steps / elapsed if scaling == "weak" else None}
+        if replicas_ok is False:
+            raise SystemExit("replicas diverged: parameters differ between ranks after %d outer steps" % (opt.warmup + opt.steps))
     if rank == 0:
         if timer is not None:
             summ = timer.summary()
@@ -415,11 +442,51 @@ def main():
             except Exception as e:
                 line["fast_path"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
         if world == 1 and not opt.no_cpu_baseline and not toy:
-            line["cpu_baseline"], oracle_res = cpu_baseline(model, H, W, S, over)
+            line["cpu_baseline"], oracle_res = cpu_baseline(model, H, W, S, over_all)
             try:
-                line["parity_check"] = parity_check(system, theta0, frames, model, H, W, S, oracle_res, dev, mode)
+                line["parity_check"] = parity_check(system, theta0, frames, model, H, W, S, oracle_res, dev, mode,
+                                                    smooth_weights=recipe == 'smooth')
             except Exception as e:       # never lose the measurement over the checker
                 line["parity_check"] = {"ok": False, "error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+    tp.barrier()
+    # BASELINE config 4 at its FIXED global meta-batch (32 tasks: strong scaling -- 32 / gpus tasks per rank), every rank count incl. 1,
+    # so that outer-gradient throughput at N GPUs can be set against 1 GPU on the same total work (north star: >= 6x at 8)
+    if model == 'sepconv' and not toy and not opt.no_strong_c4 and not opt.global_batch and 32 % world == 0 and opt.workload.startswith('c2_'):
+        c4_model, c4H, c4W, _, c4S, c4over = WORKLOADS['c4_sepconv_msl_256x448_b4_s5']
+        c4_tasks = 32 // world
+        c4args = default_args(model=c4_model, num_gpu=1, batch_size=32, number_of_training_steps_per_iter=c4S,
+                              number_of_evaluation_steps_per_iter=c4S, **switches, **c4over)
+        with contextlib.redirect_stdout(sys.stderr):
+            c4net = MODEL_REGISTRY[c4_model](c4args, False)
+            synthetic.load_seeded_weights(c4net, c4_model)
+            c4sys = SceneAdaptiveInterpolation(c4args, net=c4net.to(dev))
+        c4frames = [f.to(dev) for f in synthetic.septuplet_batch(32, c4H, c4W, model=c4_model)]
+        c4steps = max(2, min(opt.steps, 3))
+        c4sys.run_train_iter(data_batch=c4frames, epoch=0, do_evaluation=False)          # warm-up (allocator, MIOpen find)
+        c4tp = c4sys.task_parallel
+        c4tp.record_timing = c4tp.active
+        c4tp.barrier()
+        sync()
+        c0 = time.perf_counter()
+        for i in range(c4steps):
+            c4sys.run_train_iter(data_batch=c4frames, epoch=0, do_evaluation=False)
+        sync()
+        c4tp.barrier()
+        c4el = time.perf_counter() - c0
+        c4tp.record_timing = False
+        if c4tp.active:
+            import torch.distributed as dist
+            t = torch.tensor([c4el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            c4el = float(t.item())
+        line["strong_c4"] = {"workload": "SepConv + MAML++ multi-step loss, 256x448, 5 inner steps, global meta-batch 32 (BASELINE config 4)",
+                             "scaling": "strong", "tasks_per_gpu": c4_tasks, "meta_iterations": c4steps,
+                             "ms_per_meta_iteration": 1e3 * c4el / c4steps, "outer_tasks_per_sec": 32 * c4steps / c4el,
+                             "inner_steps_per_sec": 32 * c4S * c4steps / c4el, "allreduce": c4tp.allreduce_stats(),
+                             "replicas_bit_identical": c4tp.replicas_identical([p for p in c4sys.parameters()]) if c4tp.active else None}
+        del c4sys, c4net, c4frames
+        torch.cuda.empty_cache()
+    if rank == 0:
         print(json.dumps(line), flush=True)
     tp.barrier()
 

@@ -991,10 +991,11 @@ __global__ void sepconv_bwd_input_direct(const float* __restrict__ v, const floa
 // SAVFI_SEPCONV_NO_WS the one-program-per-wave split-bf16 kernel instead of the wave-specialised one (csrc/sepconv_ws.hip),
 // SAVFI_SEPCONV_TILED the tiled (non-persistent) MFMA kernels, SAVFI_SEPCONV_MFMA_ROWS = 8 | 12 | 16 pins their rows per workgroup.
 struct SepconvEnv {
-  bool no_mfma, tiled, f32_mfma, no_ws;
+  bool no_mfma, tiled, f32_mfma, no_ws, no_ws_fwd;
   int rows;
   SepconvEnv() : no_mfma(getenv("SAVFI_SEPCONV_NO_MFMA") != nullptr), tiled(getenv("SAVFI_SEPCONV_TILED") != nullptr),
-                 f32_mfma(getenv("SAVFI_SEPCONV_F32_MFMA") != nullptr), no_ws(getenv("SAVFI_SEPCONV_NO_WS") != nullptr), rows(0) {
+                 f32_mfma(getenv("SAVFI_SEPCONV_F32_MFMA") != nullptr), no_ws(getenv("SAVFI_SEPCONV_NO_WS") != nullptr),
+                 no_ws_fwd(getenv("SAVFI_SEPCONV_NO_WS_FWD") != nullptr), rows(0) {
     if (const char* e = getenv("SAVFI_SEPCONV_MFMA_ROWS")) {
       const int r = atoi(e);
       if (r == 8 || r == 12 || r == 16) rows = r;
@@ -1124,6 +1125,7 @@ extern "C" int savfi_sepconv_fwd_f32(const float* in, const float* v, const floa
   if (int e = check_dims(B, C, Ho, Wo, K)) return e;
   hipStream_t st = (hipStream_t)stream;
   if (K == KFAST && C == 3 && !sepconv_env().no_mfma && !sepconv_env().tiled && !sepconv_env().f32_mfma && persistent_ok(B, Ho, Wo))
+    if ((Wo & 3) == 0 && !sepconv_env().no_ws && !sepconv_env().no_ws_fwd) return savfi_sepconv_fwd_ws_launch(in, v, h, out, B, Ho, Wo, device_cu_count(), st);
     return savfi_sepconv_fwd_x6_launch(in, v, h, out, B, Ho, Wo, device_cu_count(), st);
   if (K == KFAST && C == 3 && !sepconv_env().no_mfma && mfma_fits(Ho, Wo)) {
     switch (mfma_rows(B, Ho, Wo)) {

@@ -712,6 +712,339 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
   if (WS_TRACE && blockIdx.x == 0 && (threadIdx.x & 63) == 0) ws_trace[threadIdx.x >> 6][15] += __builtin_readcyclecounter() - t_kernel0;
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Forward on the same machinery:  out[b,c,y,x] = sum_fy v[b,fy,y,x] * T_c[fy],   T_c[fy][j] = sum_i In_c[y + fy][16 wc + i] * Hb[i][j].
+// Replaces the reference's forward kernel (sepconv/sepconv_op/sepconv.py:5-30).
+//   MFMA wave       T on the window with the h band (the gV product without the cotangent: 120 MFMAs per 16 pixels, tap rows 48..50 of the
+//                   three channels packed into one tile), then the vertical pass on its accumulators: lane (j, kg) holds rows 16 m + 4 kg + r
+//                   and takes v for exactly those rows from the pair's v tile (4 x 16 bytes); its three channel sums go to the pair's
+//                   partial-sum tile, one row per lane group kg
+//   h-side wave     h taps -> band table; the tail columns i = 64, 65 as six dot products over the tap rows (lane = tap row: window
+//                   columns 64, 65 from the side copies, v of pixels 14, 15 by one 8-byte load per lane); adds the four lane groups'
+//                   partial sums and the tails and stores the 3 x 16 results; window row 60 + 2 n
+//   v-side wave     v taps (pairs of neighbouring taps per lane) -> v tile [pixel][tap] as 8-byte stores; window row 61 + 2 n
+// LDS: window 103 680 B + 4 x (table 6 144 + v tile 4 608 + partial sums 768) + side columns + flags = 153 KB.
+// ------------------------------------------------------------------------------------------------------------------------------------
+constexpr int FVP = 72;                             // pitch of a v tile row (floats): [pixel j][tap]; 16-byte fragments of the 16 lanes of a
+                                                    // read group fall on 8 j + 4 kg: conflict free
+constexpr int FVTB = 16 * FVP * 4, FOPB = 4 * XC * 16 * 4;
+constexpr int FPAIRB = XTAB + FVTB + FOPB;
+constexpr int FSIDE_OFF = XWINB + 4 * FPAIRB;
+constexpr int FFLAG_OFF = FSIDE_OFF + WSIDEB;
+constexpr int FLDS = FFLAG_OFF + 256;
+static_assert(FLDS <= 160 * 1024, "LDS per CU");
+enum { F_VT_FULL = 8, F_VT_FREE = 12, F_OP_FULL = 32, F_OP_FREE = 36 };     // + F_TAB_*, F_PROG, F_SLIDE, F_ERR as above
+
+__global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ in, const float* __restrict__ v,
+                                                      const float* __restrict__ h, float* __restrict__ out,
+                                                      int B, int Ho, int Wo, int nph, int ncol, int per_wg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p = w & 3, wc = p & 1, wr0 = p >> 1;
+  const int role = w >> 2;                          // 0: MFMA wave, 1: h-side staging wave, 2: v-side staging wave
+  const int j = lane & 15, kg = lane >> 4;
+  char* const tab = smem + XWINB + p * FPAIRB;
+  float* const vt = reinterpret_cast<float*>(tab + XTAB);
+  float* const op = reinterpret_cast<float*>(tab + XTAB + FVTB);
+  float* const side = reinterpret_cast<float*>(smem + FSIDE_OFF);
+  unsigned* const fl = reinterpret_cast<unsigned*>(smem + FFLAG_OFF);
+
+  const int total = B * ncol * nph;
+  const int g0 = blockIdx.x * per_wg, g1 = min(g0 + per_wg, total);
+  if (g0 >= g1) return;
+  const int Hi = Ho + XK - 1, Wi = Wo + XK - 1;
+  const unsigned plane_b = (unsigned)Ho * (unsigned)Wo * 4u;
+  const __amdgpu_buffer_rsrc_t hsrc = x6_rsrc(h, (unsigned)(B * XK) * plane_b);
+  const __amdgpu_buffer_rsrc_t vsrc = x6_rsrc(v, (unsigned)(B * XK) * plane_b);
+  const __amdgpu_buffer_rsrc_t isrc = x6_rsrc(in, (unsigned)(B * XC) * (unsigned)(Hi * Wi) * 4u);
+  const __amdgpu_buffer_rsrc_t odst = x6_rsrc(out, (unsigned)(B * XC) * plane_b);
+
+  auto pix_off = [&](int b, int x0, int y, int ch) {
+    return (unsigned)b * (unsigned)ch * plane_b + (unsigned)(min(y, Ho - 1) * Wo + min(x0 + 16 * wc + j, Wo - 1)) * 4u;
+  };
+  auto load_taps = [&](float (&regs)[XNP][2], __amdgpu_buffer_rsrc_t src, int b, int x0, int y, int t0) {
+    const unsigned pix = pix_off(b, x0, y, XK);
+    const unsigned voff = pix + (unsigned)(t0 + 1) * plane_b;
+    regs[0][0] = x6_bload(src, pix + (unsigned)max(t0, 0) * plane_b, 0u);
+    regs[0][1] = x6_bload(src, voff, 0u);
+#pragma unroll
+    for (int a = 1; a < XNP - 1; ++a)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) regs[a][e] = x6_bload(src, voff, (unsigned)(8 * a + e - 1) * plane_b);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) regs[XNP - 1][e] = x6_bload(src, pix + (unsigned)min(8 * (XNP - 1) + t0 + e, XK - 1) * plane_b, 0u);
+  };
+  auto tap_or_zero = [&](const float (&regs)[XNP][2], int a, int e, int t0) {
+    if (a == 0 && e == 0) return t0 < 0 ? 0.f : regs[0][0];
+    if (a == XNP - 1) return (8 * (XNP - 1) + t0 + e < XK) ? regs[a][e] : 0.f;
+    return regs[a][e];
+  };
+  const int h_t0 = 2 * kg - (j & 1), v_t0 = 2 * kg;
+  auto write_h_table = [&](const float (&regs)[XNP][2]) {
+#pragma unroll
+    for (int k = 0; k < XTAB / 1024; ++k) *reinterpret_cast<u32x4*>(tab + (k * 64 + lane) * 16) = (u32x4){0u, 0u, 0u, 0u};
+    const int base2 = 2 * kg + (j & ~1);
+    char* const lb = tab + (base2 >> 3) * 256 + j * 16 + (base2 & 7) * 2;
+#pragma unroll
+    for (int a = 0; a < XNP; ++a) {
+      unsigned h1, h2, h3;
+      x6_split2(tap_or_zero(regs, a, 0, h_t0), tap_or_zero(regs, a, 1, h_t0), h1, h2, h3);
+      char* d = lb + a * 256;
+      if (a < XNP - 1 || base2 < 16) {
+        *reinterpret_cast<unsigned*>(d) = h1;
+        *reinterpret_cast<unsigned*>(d + XTABP) = h2;
+        *reinterpret_cast<unsigned*>(d + 2 * XTABP) = h3;
+      }
+    }
+  };
+  auto rdlane = [&](float x, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l)); };
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+
+  int g = g0;
+#pragma unroll 1
+  while (g < g1) {
+    const int s = g / nph, ph0 = g - s * nph, b = s / ncol, x0 = (s - b * ncol) * XMC;
+    const int run_end = min(g1, g + (nph - ph0)), nrun = run_end - g, N = 2 * nrun;
+    const int R0 = XPR * ph0;
+    auto unit_y = [&](int n) { return R0 + XPR * (n >> 1) + wr0 + 2 * (n & 1); };
+    __syncthreads();
+    if (tid < 64) fl[tid] = 0u;
+    if (tid < XNT) {
+#pragma unroll 1
+      for (int r = 0; r < XWIN; r += 16) {
+        X6Rows<16> sr;
+        x6_rows_load<16>(sr, isrc, b, x0, R0 + r, Hi, Wi, tid);
+        x6_rows_write<16>(sr, smem, R0 + r, tid, FSIDE_OFF);
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+
+    if (role == 0) {
+      // =========================================== MFMA wave ===================================================================
+      __builtin_amdgcn_s_setprio(WS_PRIO);
+      bf16x8 bq[2][3], aq[2][2][3];
+      int rowoff[4];
+      auto peek_raw = [&](int idx) { return __hip_atomic_load(fl + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+      auto set_rows = [&](int y) {
+        const int lo_ = ws_lane(), jo = lo_ & 15, ko = lo_ >> 4;
+        const int pk = ((ko & 1) << 1) | (ko >> 1);
+#pragma unroll
+        for (int m = 0; m < 3; ++m) rowoff[m] = ((y + 16 * m + jo) & (XWIN - 1)) * 16 + (2 * wc + pk) * XBLK;
+        rowoff[3] = ((y + 48 + min(jo & 3, 2)) & (XWIN - 1)) * 16 + (2 * wc + pk) * XBLK + min(jo >> 2, 2) * XPLANE;
+      };
+      auto gv_acc = [](int uu, int t) { return uu < 6 ? 3 * (uu >> 1) + t : uu < 8 ? 3 * t + 2 : (t == 0 ? 8 : 9); };
+      auto load_av = [&](int slot, int uu) {
+        const int st = uu & 1;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int ai = gv_acc(uu, t), c = ai == 9 ? 0 : ai / 3, m = ai == 9 ? 3 : ai % 3;
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc)
+            aq[slot][t][pc] = *reinterpret_cast<const bf16x8*>(smem + (pc * 3 + c) * XPLANE + 4 * st * XBLK + rowoff[m]);
+        }
+      };
+      auto read_bh = [&]() {
+        const int lo_ = ws_lane(), jo = lo_ & 15, ko = lo_ >> 4, pk = ((ko & 1) << 1) | (ko >> 1);
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) bq[st][pc] = *reinterpret_cast<const bf16x8*>(tab + pc * XTABP + (4 * st + pk) * 256 + jo * 16);
+      };
+      set_rows(unit_y(0));
+      ws_wait(fl, F_TAB_FULL + p, 1);
+      read_bh();
+      ws_set(fl, F_TAB_FREE + p, 1);
+      load_av(0, 0);
+#pragma unroll 1
+      for (int n = 0; n < N; ++n) {
+        const int q = n >> 1, u = n & 1;
+        f32x4 acc[10];                                 // [3 c + m] (m < 3), [9] = packed tile (rows 48 + r of channel kg)
+#pragma unroll
+        for (int i = 0; i < 10; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        unsigned pre_tab = 0u, pre_vt = 0u, pre_op = 0u, pre_slide = 0u;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int uu = 0; uu < 10; ++uu) {
+          if (uu + 1 < 10) load_av((uu + 1) & 1, uu + 1);
+          else { pre_tab = peek_raw(F_TAB_FULL + p); pre_vt = peek_raw(F_VT_FULL + p); pre_op = peek_raw(F_OP_FREE + p); pre_slide = peek_raw(F_SLIDE); }
+          {
+            const int st = uu & 1;
+#pragma unroll
+            for (int qq = 0; qq < 6; ++qq)
+#pragma unroll
+              for (int t = 0; t < 2; ++t)
+                acc[gv_acc(uu, t)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[uu & 1][t][PA[qq]], bq[st][PB[qq]], acc[gv_acc(uu, t)], 0, 0, 0);
+          }
+          if (WS_INTERLEAVE && uu + 1 < 10) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (u == 1) ws_set(fl, F_PROG + w, q + 1);             // this phase's window reads are over
+        // the next unit's h fragments and first A fragments -- before this unit's vertical pass
+        if (n + 1 < N) {
+          const int q1 = (n + 1) >> 1;
+          if ((int)__builtin_amdgcn_readfirstlane((int)pre_tab) < n + 2) ws_wait(fl, F_TAB_FULL + p, n + 2);
+          read_bh();
+          ws_set(fl, F_TAB_FREE + p, n + 2);
+          if (u == 1 && q1 >= 2 && (int)__builtin_amdgcn_readfirstlane((int)pre_slide) < 8 * (2 * q1 - 3)) ws_wait(fl, F_SLIDE, 8 * (2 * q1 - 3));
+          set_rows(unit_y(n + 1));
+          load_av(0, 0);
+        }
+        // vertical pass: v of this lane's rows from the pair's v tile
+        if ((int)__builtin_amdgcn_readfirstlane((int)pre_vt) < n + 1) ws_wait(fl, F_VT_FULL + p, n + 1);
+        const int lo_ = ws_lane(), jo = lo_ & 15, ko = lo_ >> 4;
+        f32x4 vc[4];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) vc[m] = *reinterpret_cast<const f32x4*>(vt + jo * FVP + 16 * m + 4 * ko);
+        vc[3] = *reinterpret_cast<const f32x4*>(vt + jo * FVP + 48);
+        ws_set(fl, F_VT_FREE + p, n + 1);
+        float part[XC];
+#pragma unroll
+        for (int c = 0; c < XC; ++c) {
+          float sum = 0.f;
+#pragma unroll
+          for (int m = 0; m < 3; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sum = fmaf(vc[m][r], acc[3 * c + m][r], sum);
+          part[c] = sum;
+        }
+        {
+          float t = vc[3][0] * acc[9][0];
+          t = fmaf(vc[3][1], acc[9][1], t);
+          t = fmaf(vc[3][2], acc[9][2], t);
+#pragma unroll
+          for (int c = 0; c < XC; ++c) part[c] += (ko == c) ? t : 0.f;
+        }
+        if ((int)__builtin_amdgcn_readfirstlane((int)pre_op) < n) ws_wait(fl, F_OP_FREE + p, n);
+#pragma unroll
+        for (int c = 0; c < XC; ++c) op[(ko * XC + c) * 16 + jo] = part[c];
+        ws_set(fl, F_OP_FULL + p, n + 1);
+      }
+      __builtin_amdgcn_s_setprio(0);
+    } else {
+      // =========================================== staging waves ===============================================================
+      const bool hside = role == 1;
+      const int ptid = tid - (hside ? 256 : 512);
+      const int gcol = ptid & 127, ggrp = ptid >> 7;
+      const int gcell = (gcol >> 3) * XBLK + (gcol & 7) * 2;
+      const int gsidx = gcol == 64 ? 0 : gcol == 65 ? 1 : gcol == 80 ? 2 : gcol == 81 ? 3 : -1;
+      const unsigned gcolb = (unsigned)min(x0 + gcol, Wi - 1) * 4u;
+      const int gc0 = ggrp == 0 ? 0 : 2, gc1 = ggrp == 0 ? 1 : 2;
+      float hreg[XNP][2], vreg[XNP][2];
+      if (hside) load_taps(hreg, hsrc, b, x0, unit_y(0), h_t0);
+      else load_taps(vreg, vsrc, b, x0, unit_y(0), v_t0);
+      float o14[XC] = {0.f, 0.f, 0.f}, o15[XC] = {0.f, 0.f, 0.f};      // h side: tail-column contributions of the unit finalised next
+      unsigned ooff_prev = X_OOR;
+#pragma unroll 1
+      for (int n = 0; n <= N; ++n) {
+        const bool live = n < N;
+        const int nn = min(n, N - 1);
+        const int q = nn >> 1, u = nn & 1;
+        const int y = unit_y(nn), y1 = unit_y(min(nn + 1, N - 1));
+        float gr0, gr1;
+        const int grow = R0 + 60 + 2 * nn + (hside ? 0 : 1);
+        {
+          const int rr = min(grow, Hi - 1);
+          gr0 = x6_bload(isrc, (unsigned)(((b * XC + gc0) * Hi + rr) * Wi) * 4u + gcolb, 0u);
+          gr1 = x6_bload(isrc, (unsigned)(((b * XC + gc1) * Hi + rr) * Wi) * 4u + gcolb, 0u);
+        }
+        const int fyl = min(lane, XK - 1);
+        const int tslot = (y + fyl) & (XWIN - 1);
+        if (hside) {
+          // v of pixels 14, 15 of this unit by tap row (lane = fy): one 8-byte load per lane, in flight under the table build
+          const unsigned v2off = (unsigned)b * (unsigned)XK * plane_b + (unsigned)fyl * plane_b
+                                 + (unsigned)(min(y, Ho - 1) * Wo + min(x0 + 16 * wc + 14, Wo - 2)) * 4u;
+          const unsigned long long v2raw = __builtin_bit_cast(unsigned long long, __builtin_amdgcn_raw_buffer_load_b64(vsrc, (int)v2off, 0, 0));
+          const float h50_14 = rdlane(hreg[6][0], 14 + 16), h49_15 = rdlane(hreg[6][0], 15 + 16), h50_15 = rdlane(hreg[6][1], 15 + 16);
+          // (1) the h band of unit n takes the table
+          if (live) {
+            ws_wait(fl, F_TAB_FREE + p, n);
+            __builtin_amdgcn_s_setprio(WS_PRIO_TABLE);
+            write_h_table(hreg);
+            ws_set(fl, F_TAB_FULL + p, n + 1);
+            __builtin_amdgcn_s_setprio(0);
+          }
+          // (2) unit n - 1: the four lane groups' partial sums + tail columns -> HBM (lane = (channel, pixel))
+          {
+            if (n > 0) ws_wait(fl, F_OP_FULL + p, n);
+            const int c = min(lane >> 4, XC - 1);
+            const float* o = op + c * 16 + j;
+            float val = (o[0] + o[XC * 16]) + (o[2 * XC * 16] + o[3 * XC * 16]);
+            const float t14 = c == 0 ? o14[0] : c == 1 ? o14[1] : o14[2], t15 = c == 0 ? o15[0] : c == 1 ? o15[1] : o15[2];
+            val += j == 14 ? t14 : j == 15 ? t15 : 0.f;
+            x6_bstore(val, odst, lane < 16 * XC ? ooff_prev : X_OOR, 0u);
+            if (n > 0) ws_set(fl, F_OP_FREE + p, n);
+          }
+          // (3) tail columns of unit n: T_c[fy][14] += In_c[y + fy][64] h50_14, T_c[fy][15] += In_c[..][64] h49_15 + In_c[..][65] h50_15,
+          //     times v of the pixel, summed over the tap rows
+          if (live && u == 0 && q >= 2) ws_wait(fl, F_SLIDE, 8 * (2 * q - 3));
+          float a64[XC], a65[XC];
+#pragma unroll
+          for (int c = 0; c < XC; ++c) {
+            const f32x2 sv = *reinterpret_cast<const f32x2*>(side + (c * XWIN + tslot) * 4 + 2 * wc);
+            a64[c] = sv.x; a65[c] = sv.y;
+          }
+          asm volatile("" ::: "memory");
+          if (live && u == 1) ws_set(fl, F_PROG + w, q + 1);
+          load_taps(hreg, hsrc, b, x0, y1, h_t0);
+          {
+            const float lv = lane < XK ? 1.f : 0.f;
+            const float v14 = lv * __uint_as_float((unsigned)v2raw), v15 = lv * __uint_as_float((unsigned)(v2raw >> 32));
+#pragma unroll
+            for (int c = 0; c < XC; ++c) {
+              o14[c] = ws_wave_sum(v14 * (a64[c] * h50_14));
+              o15[c] = ws_wave_sum(v15 * fmaf(a65[c], h50_15, a64[c] * h49_15));
+            }
+          }
+          {
+            const int c = min(lane >> 4, XC - 1), x = x0 + 16 * wc + j;
+            ooff_prev = (live && y < Ho && x < Wo) ? (unsigned)(b * XC + c) * plane_b + (unsigned)(y * Wo + x) * 4u : X_OOR;
+          }
+        } else {
+          // (1) v of unit n -> the pair's v tile [pixel][tap]: the lane's pairs of neighbouring taps as 8-byte stores
+          if (live) {
+            ws_wait(fl, F_VT_FREE + p, n);
+            float* const vw = vt + j * FVP + 2 * kg;
+#pragma unroll
+            for (int a = 0; a < XNP; ++a)
+              *reinterpret_cast<f32x2*>(vw + 8 * a) = (f32x2){tap_or_zero(vreg, a, 0, v_t0), tap_or_zero(vreg, a, 1, v_t0)};
+            ws_set(fl, F_VT_FULL + p, n + 1);
+          }
+          if (live && u == 1) ws_set(fl, F_PROG + w, q + 1);      // this wave reads neither the window nor the side columns
+          load_taps(vreg, vsrc, b, x0, y1, v_t0);
+        }
+        // (4) the new window row
+        if (live) {
+          if (q >= 1) ws_wait_all_prog(fl, q);
+          const int slot = grow & (XWIN - 1);
+          unsigned h1, h2, h3;
+          x6_split2(gr0, gr1, h1, h2, h3);
+          if (gcol < 8 * XNBLK) {
+            char* d0 = smem + gcell + slot * 16 + gc0 * XPLANE;
+            x6_st16(d0, h1); x6_st16(d0 + 3 * XPLANE, h2); x6_st16(d0 + 6 * XPLANE, h3);
+            if (ggrp == 0) { x6_st16(d0 + XPLANE, h1 >> 16); x6_st16(d0 + 4 * XPLANE, h2 >> 16); x6_st16(d0 + 7 * XPLANE, h3 >> 16); }
+          }
+          if (gsidx >= 0) {
+            side[(gc0 * XWIN + slot) * 4 + gsidx] = gr0;
+            side[(gc1 * XWIN + slot) * 4 + gsidx] = gr1;
+          }
+          asm volatile("" ::: "memory");
+          if (lane == 0) __hip_atomic_fetch_add(fl + F_SLIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          asm volatile("" ::: "memory");
+        }
+      }
+    }
+    g = run_end;
+  }
+}
+
 }  // namespace
 
 // gV and gH of the K = 51, C = 3 op, widths that are a multiple of 4; every tensor below 2^31 bytes (the caller checks).
@@ -724,6 +1057,19 @@ int savfi_sepconv_bwd_ws_launch(const float* in, const float* v, const float* h,
   static uint32_t done = 0;
   if (int e = savfi_ensure_dynamic_lds((const void*)sepconv_bwd_ws, WLDS, done)) return e;
   hipLaunchKernelGGL(sepconv_bwd_ws, dim3(grid), dim3(WNT), WLDS, st, in, v, h, gO, gV, gH, B, Ho, Wo, nph, ncol, per_wg);
+  return savfi_launch_status();
+}
+
+// forward of the same op, widths that are a multiple of 4 (declared in csrc/common.h)
+int savfi_sepconv_fwd_ws_launch(const float* in, const float* v, const float* h, float* out, int B, int Ho, int Wo, int cus,
+                                hipStream_t st) {
+  const int nph = savfi_cdiv(Ho, XPR), ncol = savfi_cdiv(Wo, XMC);
+  const int64_t total = (int64_t)B * ncol * nph;
+  const int per_wg = savfi_cdiv(total, cus);
+  const int grid = savfi_cdiv(total, per_wg);
+  static uint32_t done = 0;
+  if (int e = savfi_ensure_dynamic_lds((const void*)sepconv_fwd_ws, FLDS, done)) return e;
+  hipLaunchKernelGGL(sepconv_fwd_ws, dim3(grid), dim3(WNT), FLDS, st, in, v, h, out, B, Ho, Wo, nph, ncol, per_wg);
   return savfi_launch_status();
 }
 

@@ -52,7 +52,10 @@ constexpr int WNT = 256;            // threads
 constexpr int TILES_WG = 64;
 constexpr int COB = 32;             // produced channels per workgroup
 constexpr int CIB = 4;              // reduction channels per chunk (one MFMA k-step), one per wave
-constexpr int VS = 80;              // pitch of a V row [k] in floats: 64 tiles + 16 -> the 4 k-groups hit disjoint banks
+#ifndef WINO_VS
+#define WINO_VS 80
+#endif
+constexpr int VS = WINO_VS;         // pitch of a V row [k] in floats: 64 tiles + 16 -> the 4 k-groups hit disjoint banks
 constexpr int XS = 68;              // pitch of an exchange row [channel] (output stage)
 constexpr int VBUF = 16 * CIB * VS; // floats per V buffer (20 KB)
 constexpr int XBUF = 4 * 2 * 16 * XS;  // exchange: [row xi_r][column c][16 channels][XS]

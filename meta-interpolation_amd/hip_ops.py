@@ -64,8 +64,44 @@ class _VoxelWarp(torch.autograd.Function):
         return g_fr, (g_x3 if need_x else None)
 
 
+def _bilinear_border(img, cx, cy):
+    """F.grid_sample(img, stack(cx, cy), bilinear, padding_mode='border', align_corners=True) written with gathers (ATen
+    GridSampler.h: unnormalise, clip the coordinate, four corners): differentiable in `img`, `cx`, `cy` to any order --
+    ATen's grid_sampler_2d_backward has no derivative, so the fused op and F.grid_sample alike stop at first order."""
+    N, C, H, W = img.shape
+    ix = ((cx + 1.0) * 0.5 * (W - 1)).clamp(0, W - 1)
+    iy = ((cy + 1.0) * 0.5 * (H - 1)).clamp(0, H - 1)
+    x0, y0 = ix.detach().floor(), iy.detach().floor()
+    fx, fy = (ix - x0).unsqueeze(1), (iy - y0).unsqueeze(1)
+    x0i, y0i = x0.long().clamp(0, W - 1), y0.long().clamp(0, H - 1)
+    x1i, y1i = (x0i + 1).clamp(max=W - 1), (y0i + 1).clamp(max=H - 1)
+    flat = img.reshape(N, C, H * W)
+
+    def corner(yi, xi):
+        return flat.gather(2, (yi * W + xi).reshape(N, 1, H * W).expand(N, C, H * W)).reshape(N, C, H, W)
+
+    top = corner(y0i, x0i) * (1 - fx) + corner(y0i, x1i) * fx
+    bot = corner(y1i, x0i) * (1 - fx) + corner(y1i, x1i) * fx
+    return top * (1 - fy) + bot * fy
+
+
+def _voxel_warp_composed(frames, x3):
+    """The VoxelFlow tail (voxelflow/core/models/voxel_flow.py:471-507, syn_type 'inter') from differentiable ATen ops: what
+    --second_order takes (set_double_backward(True)), like pixel shuffle / up-sampling / the losses."""
+    B, _, H, W = frames.shape
+    gx = torch.linspace(-1.0, 1.0, W, device=frames.device, dtype=frames.dtype).view(1, 1, W).expand(B, H, W)
+    gy = torch.linspace(-1.0, 1.0, H, device=frames.device, dtype=frames.dtype).view(1, H, 1).expand(B, H, W)
+    fx, fy = 0.5 * x3[:, 0], 0.5 * x3[:, 1]
+    o1 = _bilinear_border(frames[:, 0:3], gx - fx, gy - fy)
+    o2 = _bilinear_border(frames[:, 3:6], gx + fx, gy + fy)
+    mask = (0.5 * (1.0 + x3[:, 2:3])).expand(B, 3, H, W)
+    return mask * o1 + (1.0 - mask) * o2
+
+
 def voxel_warp_blend(frames, x3):
     """frames [B,6,H,W] (I0|I1), x3 [B,3,H,W] = tanh(conv4) -> interpolated frame [B,3,H,W]."""
+    if double_backward():
+        return _voxel_warp_composed(frames, x3)
     return _VoxelWarp.apply(frames.contiguous(), x3.contiguous())
 
 

@@ -25,7 +25,14 @@ def _stream(seed, name):
     return np.random.RandomState((zlib.crc32(name.encode()) ^ (seed * 2654435761)) & 0x7fffffff)
 
 
-def seeded_state_dict(net, model, seed=12345):
+# VoxelFlow conv weights: normal(0, 0.01) is the model's own initialisation (voxelflow/core/models/voxel_flow.py:267-274).  The default
+# recipe triples it so that a random-weight network produces flows of a sizeable fraction of a pixel (every code path of the warp is
+# exercised) -- which also makes 5 Adamax steps on a noise-like texture chaotic.  Recipe 'smooth' keeps the model's own scale: sub-pixel,
+# smooth flows, an iteration that reproduces itself in the reference (tests/golden/full_c3s_*.npz: the testable C3 contract).
+_VOXELFLOW_STD_MULT = {None: 3.0, 'default': 3.0, 'smooth': 1.0}
+
+
+def seeded_state_dict(net, model, seed=12345, recipe=None):
     """{name: tensor} for every parameter and buffer of `net`, one independent numpy stream per name."""
     out = {}
     for name, ref in net.state_dict().items():
@@ -45,7 +52,7 @@ def seeded_state_dict(net, model, seed=12345):
             fan_in = shape[1] * shape[2] * shape[3]
             fan_out = shape[0] * shape[2] * shape[3]
             if model == 'voxelflow':
-                val = rs.normal(0.0, 0.01, size=shape) * 3.0
+                val = rs.normal(0.0, 0.01, size=shape) * _VOXELFLOW_STD_MULT[recipe]
             else:
                 bound = gain * np.sqrt(6.0 / (fan_in + fan_out))
                 val = rs.uniform(-bound, bound, size=shape)
@@ -57,8 +64,8 @@ def seeded_state_dict(net, model, seed=12345):
     return out
 
 
-def load_seeded_weights(net, model, seed=12345):
-    sd = seeded_state_dict(net, model, seed)
+def load_seeded_weights(net, model, seed=12345, recipe=None):
+    sd = seeded_state_dict(net, model, seed, recipe)
     net.load_state_dict(sd)
     return sd
 

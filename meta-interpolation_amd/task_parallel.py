@@ -61,6 +61,8 @@ class TaskParallel:
         self._flag_cache = {}   # local presence pattern -> device tensor of flags
         self._touched = set()   # id(param) of the parameters the current backward pass reached
         self._hooked = set()
+        self.record_timing = False      # bench.py: HIP events around every gradient all-reduce (the stream the collective is ordered on)
+        self._timing = []               # [(start event, end event, bucket bytes)]
 
     @property
     def active(self):
@@ -134,7 +136,14 @@ class TaskParallel:
         if dev_flags is None:   # one H2D per presence pattern, device-to-device afterwards
             dev_flags = self._flag_cache[key] = torch.tensor([1.0 if h else 0.0 for h in have], dtype=torch.float32).to(bucket.device)
         bucket[total:].copy_(dev_flags, non_blocking=True)
+        timed = self.record_timing and bucket.is_cuda
+        if timed:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
         dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group)
+        if timed:
+            ev1.record()
+            self._timing.append((ev0, ev1, bucket.numel() * bucket.element_size()))
         # A parameter ends with a gradient iff some rank produced one (a None gradient makes the optimizer skip it: no weight
         # decay, no moment update -- zeros would not be the same thing).  When this rank produced every gradient itself the
         # answer is known without looking; otherwise (an empty or partial shard: the rare case) the reduced flags are fetched,
@@ -147,6 +156,38 @@ class TaskParallel:
                 p.grad = v          # the reduced sum, in place in the bucket
             else:
                 p.grad.copy_(v)
+
+    def allreduce_stats(self, reset=True):
+        """HIP-event time of the recorded gradient all-reduces (call after a device synchronize): launches, mean / max ms, bucket
+        bytes, and the bus bandwidth a ring moves for it (2 (G - 1) / G x bytes / time).  None if nothing was recorded."""
+        if not self._timing:
+            return None
+        ms = [a.elapsed_time(b) for a, b, _ in self._timing]
+        nbytes = self._timing[-1][2]
+        if reset:
+            self._timing = []
+        mean = sum(ms) / len(ms)
+        return {"launches": len(ms), "mean_ms": mean, "max_ms": max(ms), "bucket_bytes": nbytes,
+                "algorithm_GBps": nbytes / mean / 1e6 if mean > 0 else None,
+                "bus_GBps": 2.0 * (self.world - 1) / self.world * nbytes / mean / 1e6 if mean > 0 else None}
+
+    def replicas_identical(self, tensors):
+        """True iff every rank holds bit-identical copies of `tensors` (one all-gather of two float64 checksums per rank: sum and
+        sum of squares over everything; identical replicas give identical sums bit for bit)."""
+        if not self.active:
+            return True
+        tensors = [t.detach() for t in tensors]
+        dev = tensors[0].device
+        acc = torch.zeros(2, dtype=torch.float64, device=dev)
+        for t in tensors:
+            d = t.double()
+            acc[0] += d.sum()
+            acc[1] += (d * d).sum()
+        if dist.get_backend(self.group) == "nccl" and not acc.is_cuda:
+            acc = acc.cuda()
+        box = [torch.empty_like(acc) for _ in range(self.world)]
+        dist.all_gather(box, acc, group=self.group)
+        return all(torch.equal(b.cpu(), box[0].cpu()) for b in box)
 
     def allreduce_scalars(self, values):
         """SUM a small list/1-D tensor of logging scalars; returns a tensor on the input's device."""

@@ -91,7 +91,7 @@ def reference_args(**over):
     return args
 
 
-def build_reference_system(args, model, seed=12345):
+def build_reference_system(args, model, seed=12345, recipe=None):
     """Construct the reference SceneAdaptiveInterpolation with seeded weights via the --resume route."""
     import meta_learning_system as ref_mls
     if model == 'sepconv':
@@ -108,7 +108,7 @@ def build_reference_system(args, model, seed=12345):
         for fname in ("checkpoint.pth", "model_best.pth"):      # val/test modes resume from model_best.pth (utils.py:37-40)
             torch.save({'epoch': 0, 'state_dict': {}}, os.path.join("checkpoint", args.exp_name, fname))
         system = ref_mls.SceneAdaptiveInterpolation(args)
-        sd = synthetic.seeded_state_dict(system.net, model, seed)
+        sd = synthetic.seeded_state_dict(system.net, model, seed, recipe)
         system.net.load_state_dict(sd)
     finally:
         os.chdir(cwd)
@@ -178,6 +178,17 @@ SYSTEM_CASES = {
     'superslomo_lslr_sgd_2step': ('superslomo', 64, 64, 2, dict(optimizer='SGD', inner_lr=1e-3, loss='1*L1',
                                                                 number_of_training_steps_per_iter=2,
                                                                 number_of_evaluation_steps_per_iter=2)),
+    # 128 x 128 twins of two 64 x 64 cases: deepest maps 4 x 4 instead of 2 x 2, so that the OUTER-gradient fingerprints are not decided
+    # by one ReLU unit of a 2 x 2 map switching under another summation order (gated at the plain 1e-3)
+    'sepconv_msl_learnable_2step_128': ('sepconv', 128, 128, 2, dict(optimizer='SGD', inner_lr=1e-3, loss='1*L1',
+                                                                   number_of_training_steps_per_iter=2,
+                                                                   number_of_evaluation_steps_per_iter=2,
+                                                                   use_multi_step_loss_optimization=True,
+                                                                   multi_step_loss_num_epochs=10,
+                                                                   learnable_per_layer_per_step_inner_loop_learning_rate=True)),
+    'superslomo_lslr_sgd_2step_128': ('superslomo', 128, 128, 2, dict(optimizer='SGD', inner_lr=1e-3, loss='1*L1',
+                                                                    number_of_training_steps_per_iter=2,
+                                                                    number_of_evaluation_steps_per_iter=2)),
     # the reference's own launch-script settings: run_voxelflow.sh / run_cain.sh (Adam + Meta-SGD, 1 step, lr 1e-5)
     'voxelflow_script_metasgd_adam_1step': ('voxelflow', 64, 64, 1, dict(optimizer='Adam', inner_lr=1e-5, metasgd=True,
                                                                          loss='1*MSE')),

@@ -58,11 +58,17 @@ CASES = {
     'c3sgd_voxelflow_256x256_s5': ('voxelflow', 256, 256, dict(optimizer='SGD', inner_lr=1e-3, loss='1*MSE',
                                                                 number_of_training_steps_per_iter=5,
                                                                 number_of_evaluation_steps_per_iter=5)),
+    # config C3 as benchmarked AND testable: the same rule / sizes / 8-task meta-batch with VoxelFlow's weights at the model's own
+    # initialisation scale (synthetic.py recipe 'smooth': sub-pixel, smooth flows) -- the reference reproduces itself on it
+    'c3s_voxelflow_256x256_b8_s5': ('voxelflow', 256, 256, dict(optimizer='Adamax', inner_lr=1e-5, metasgd=True, loss='1*MSE',
+                                                                 number_of_training_steps_per_iter=5,
+                                                                 number_of_evaluation_steps_per_iter=5)),
     'c5_cain_l2f_720p': ('cain', 720, 1280, dict(optimizer='SGD', inner_lr=1e-3, attenuate=True, loss='1*L1')),
     'c5eval_cain_l2f_720p': ('cain', 720, 1280, dict(optimizer='SGD', inner_lr=1e-3, attenuate=True, loss='1*L1')),
 }
-TASKS = {'c2b4_sepconv_256x448_s5': 4, 'c4_sepconv_msl_256x448_s5': 4}      # meta-batch size (default 1)
-SPREAD_FOR = {'c3_voxelflow_256x256_s5', 'c3sgd_voxelflow_256x256_s5', 'c2_sepconv_256x448_s5'}
+TASKS = {'c2b4_sepconv_256x448_s5': 4, 'c4_sepconv_msl_256x448_s5': 4, 'c3s_voxelflow_256x256_b8_s5': 8}
+RECIPE = {'c3s_voxelflow_256x256_b8_s5': 'smooth'}      # seeded-weights recipe (synthetic.py); stored in the fixture's args as weight_recipe      # meta-batch size (default 1)
+SPREAD_FOR = {'c3_voxelflow_256x256_s5', 'c3sgd_voxelflow_256x256_s5', 'c2_sepconv_256x448_s5', 'c3s_voxelflow_256x256_b8_s5'}
 Q_LO, Q_HI = -0.25, 1.25
 
 
@@ -91,7 +97,7 @@ def run_train(name, variant='base'):
     torch.manual_seed(0)
     torch.nn.functional.conv2d = {'perm': S._conv2d_perm, 'perm2': S._conv2d_perm2}.get(variant, S._ORIG_CONV2D)
     try:
-        system = G.build_reference_system(args, model)
+        system = G.build_reference_system(args, model, recipe=RECIPE.get(name))
         if getattr(args, 'attenuate', False):
             seed_attenuator(system)
         if variant == 'f64':
@@ -128,7 +134,8 @@ def gen_train_case(name):
     model, H, W, over = CASES[name]
     t0 = time.time()
     base = run_train(name)
-    out = {'model': np.array(model), 'H': H, 'W': W, 'B': TASKS.get(name, 1), 'args': np.array(repr(sorted(over.items()))),
+    stored = dict(over, weight_recipe=RECIPE[name]) if name in RECIPE else over
+    out = {'model': np.array(model), 'H': H, 'W': W, 'B': TASKS.get(name, 1), 'args': np.array(repr(sorted(stored.items()))),
            'train_loss': np.float64(base['loss']), 'train_psnr': np.float64(base['psnr']), 'train_ssim': np.float64(base['ssim']),
            'train_n_live': np.array(base['rec']['n_live'])}
     for k, v in base['parts'].items():

@@ -15,18 +15,18 @@ def golden(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
 
 
-def build_plugin(model, device="cpu"):
-    """The product's nn.Module for `model` (constructing it launches no kernel) with seeded weights."""
+def build_plugin(model, device="cpu", recipe=None):
+    """The product's nn.Module for `model` (constructing it launches no kernel) with seeded weights (`recipe`: synthetic.py)."""
     from meta_interpolation_amd.meta_learning_system import MODEL_REGISTRY
     args = default_args(model=model, num_gpu=0)
     net = MODEL_REGISTRY[model](args, False)
-    synthetic.load_seeded_weights(net, model)
+    synthetic.load_seeded_weights(net, model, recipe=recipe)
     return net.to(device)
 
 
-def oracle_base(model):
+def oracle_base(model, recipe=None):
     """{name: tensor} for the oracle: parameters are leaves with requires_grad, buffers are plain."""
-    net = build_plugin(model)
+    net = build_plugin(model, recipe=recipe)
     base = {}
     pnames = {n for n, _ in net.named_parameters()}
     for name, t in net.state_dict().items():
@@ -65,10 +65,11 @@ def build_system(model, overrides, fuse=1, device="cuda"):
     mode (`graph_inner_loop`, `task_batch`, `task_streams` in `overrides`): the fixture tests hook update_params per step."""
     from meta_interpolation_amd.meta_learning_system import SceneAdaptiveInterpolation
     overrides = dict(overrides)
+    recipe = overrides.pop('weight_recipe', None)          # fixture key: which seeded-weights recipe the reference run used
     overrides.setdefault('graph_inner_loop', 0)
     overrides.setdefault('task_streams', 1)
     args = default_args(model=model, num_gpu=1, fuse_support_pairs=fuse, **overrides)
-    net = build_plugin(model, device)
+    net = build_plugin(model, device, recipe=recipe)
     system = SceneAdaptiveInterpolation(args, net=net)
     if args.attenuate:
         sd, gm = synthetic.seeded_attenuator_state(len(system.inner_loop_optimizer.names_learning_rates_dict))

@@ -38,6 +38,32 @@ def test_voxel_warp_matches_reference_model_tail():
     assert np.abs(big.numpy() - g['vf_big_out']).max() < 2e-5   # atanh/tanh round trip in the fixture
 
 
+def test_voxel_warp_written_out_equals_the_grid_sample_statement():
+    """The gather-based statement of the VoxelFlow tail (the one --second_order can differentiate twice) == the F.grid_sample
+    statement pinned above: the reference tail fixture, values and both first-order gradients incl. flows that leave the frame;
+    and it IS twice differentiable (gradgradcheck) where ATen's grid_sampler_2d_backward has no derivative."""
+    g = golden("ops")
+    frames = torch.cat([torch.from_numpy(g['vf_f0']), torch.from_numpy(g['vf_f1'])], 1)
+    ph, pw = 64 - 48, 128 - 80
+    inp = torch.nn.functional.pad(frames, [pw // 2, pw - pw // 2, ph // 2, ph - ph // 2], mode='reflect')
+    for key in ('vf_x3', 'vf_big_x3'):
+        fa, xa = inp.clone().requires_grad_(), torch.from_numpy(g[key]).clone().requires_grad_()
+        fb, xb = inp.clone().requires_grad_(), torch.from_numpy(g[key]).clone().requires_grad_()
+        a, b = O.voxel_warp_blend(fa, xa), O.voxel_warp_blend_written_out(fb, xb)
+        assert (a - b).abs().max().item() < 2e-6
+        w = torch.linspace(0.5, 1.5, a.numel()).reshape(a.shape)
+        ga, gb = torch.autograd.grad((a * w).sum(), [fa, xa]), torch.autograd.grad((b * w).sum(), [fb, xb])
+        for u, v in zip(ga, gb):
+            assert (u - v).abs().max().item() < 1e-5 * max(1.0, u.abs().max().item())
+    gen = torch.Generator().manual_seed(5)
+    f = torch.rand(1, 6, 6, 7, dtype=torch.double, generator=gen).requires_grad_()
+    x = ((torch.rand(1, 3, 6, 7, dtype=torch.double, generator=gen) * 2 - 1) * 0.9).requires_grad_()
+    assert torch.autograd.gradgradcheck(O.voxel_warp_blend_written_out, (f, x), eps=1e-7, atol=1e-5)
+    with pytest.raises(RuntimeError):
+        gx, = torch.autograd.grad(O.voxel_warp_blend(f, x).pow(2).sum(), [x], create_graph=True)
+        torch.autograd.grad(gx.pow(2).sum(), [x])
+
+
 def test_flow_warp_matches_reference_backwarp():
     """The written-out bilinear gather == the reference's backWarp / warp (superslomo/model.py:231-307, rrin/model.py:8-20)
     run here on CPU: values and the flow gradient, with a flow that partly leaves the frame."""

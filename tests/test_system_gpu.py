@@ -392,6 +392,36 @@ def test_second_order_cain_matches_oracle():
     assert checked == 494
 
 
+def test_second_order_voxelflow_matches_oracle():
+    """--second_order through the VoxelFlow tail: set_double_backward(True) swaps the fused warp (first order only, like ATen's
+    grid_sample) for composed device ops; outer gradients must equal the oracle's second-order run through its gather-based
+    statement of the tail (oracle/torch_ops.voxel_warp_blend_written_out).  Seeded weights at the model's own scale ('smooth':
+    sub-pixel flows -- second derivatives of a chaotic flow field are not a test)."""
+    from oracle import meta as ometa, torch_ops as O
+    from tests.helpers import oracle_base
+    over = dict(optimizer='SGD', inner_lr=1e-2, loss='1*MSE', number_of_training_steps_per_iter=2,
+                number_of_evaluation_steps_per_iter=2, second_order=True, first_order_to_second_order_epoch=-1)
+    system = build_system('voxelflow', dict(over, weight_recipe='smooth'))
+    rec = observe(system)
+    frames = synthetic.septuplet_batch(1, 64, 64, model='voxelflow')
+    losses, _, _ = system.run_train_iter(data_batch=frames, epoch=0, do_evaluation=False)
+    base = oracle_base('voxelflow', recipe='smooth')
+    names_w = {n: base[n] for n in ometa.inner_param_names([(n, p) for n, p in base.items() if p.is_floating_point()])}
+    lrs = orules.init_lrs('lslr', names_w, 1e-2, num_steps=2)
+    torch.set_num_threads(16)
+    res = ometa.run_iteration('voxelflow', base, frames, rule='lslr', optimizer='SGD', lrs=lrs, num_steps=2, loss='MSE',
+                              training=True, second_order=True, forward_kwargs=dict(warp=O.voxel_warp_blend_written_out))
+    res['loss'].backward()
+    assert abs(losses['loss'].item() - res['loss'].item()) <= 5e-5 * abs(res['loss'].item())
+    checked = 0
+    for n, p in base.items():
+        key = 'net.' + n
+        if p.requires_grad and p.grad is not None and key in rec['outer_grad_fp']:
+            assert_fp_close(rec['outer_grad_fp'][key], fp(p.grad), 2e-3, ('second-order', n))
+            checked += 1
+    assert checked >= 20
+
+
 # ---------------------------------------------------------------------------------------------
 # concurrent tasks (--task_streams 2): one Python thread + HIP stream per task, same results as the sequential loop
 # ---------------------------------------------------------------------------------------------

@@ -197,6 +197,13 @@ def test_bench_runs_under_torch_distributed_run_with_two_ranks(task_batch):
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "weak"
     assert line["config"]["global_meta_batch"] == 6 and line["config"]["mode"]["task_batch"] == task_batch
     assert line["value"] > 0 and abs(line["value"] - 6 * 2 * 2 / (line["ms_per_step"] * 2e-3)) < 1e-6 * line["value"]
+    # the self-validation block of a multi-rank run: backend, world size, ONE collective per meta-iteration, replicas checked after
+    # the timed region (an 8-GPU line must carry backend "nccl (RCCL)", rccl_ranks 8 and the all-reduce's own HIP-event time)
+    mg = line["multi_gpu"]
+    assert mg["backend"] == "gloo" and mg["rccl_ranks"] == 0 and mg["world_size"] == 2
+    assert mg["collectives_per_meta_iteration"] == 1 and mg["replicas_bit_identical_after_timed_region"] is True
+    assert mg["allreduce"] is None                                   # HIP events exist on the GPU path only
+    assert abs(mg["outer_tasks_per_sec_weak"] - line["config"]["outer_tasks_per_sec"]) < 1e-9
 
 
 # ---------------------------------------------------------------------------------------------
@@ -273,3 +280,51 @@ def test_gradient_bucket_with_partly_reached_parameters(world):
                 assert a is not None and torch.allclose(a, b, rtol=1e-6, atol=1e-6)
             for a, b in zip(got[:4], ranks[0][it][:4]):
                 assert torch.equal(a, b)                              # identical on every rank
+
+
+# ---------------------------------------------------------------------------------------------
+# the REAL SepConv parameter set through the bucket once (world 2, gloo): 21.7 M parameters + learning-rate tables = the 86.7 MB
+# message of BASELINE configs 2 / 4 -- layout, views, presence flags and the replica check at the size the 8-GPU run moves
+# ---------------------------------------------------------------------------------------------
+def _sepconv_bucket_worker(rank, world, port, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(4)
+    try:
+        from meta_interpolation_amd.config import default_args
+        from meta_interpolation_amd.meta_learning_system import MODEL_REGISTRY, SceneAdaptiveInterpolation
+        args = default_args(model='sepconv', num_gpu=0, batch_size=4, number_of_training_steps_per_iter=5,
+                            number_of_evaluation_steps_per_iter=5, optimizer='SGD', loss='1*L1', inner_lr=1e-5)
+        args.cuda = False
+        net = MODEL_REGISTRY['sepconv'](args, False)
+        synthetic.load_seeded_weights(net, 'sepconv')
+        tp = TaskParallel()
+        system = SceneAdaptiveInterpolation(args, net=net, task_parallel=tp)
+        params = [p for p in system.parameters() if p.requires_grad]
+        views = tp.prepare_gradients(params)
+        nbytes = tp._bucket.numel() * 4
+        for i, p in enumerate(params):                 # "the backward pass": gradient of rank r = (r + 1) * (1 + i % 3) everywhere
+            views[p].fill_(float((rank + 1) * (1 + i % 3)))
+        tp.mark_touched(params)
+        tp.allreduce_gradients(params)
+        ok = all(p.grad is views[p] and bool((p.grad == float(3 * (1 + i % 3))).all()) for i, p in enumerate(params))
+        same = tp.replicas_identical([p.grad for p in params])
+        with torch.no_grad():
+            if rank == 1:
+                params[5].view(-1)[0] += 1e-3          # one diverged element on one rank must be caught
+        diverged = tp.replicas_identical(params)
+        torch.save(dict(ok=ok, same=same, diverged_detected=not diverged, nbytes=nbytes, n=len(params),
+                        numel=sum(p.numel() for p in params)), os.path.join(outdir, "sep%d.pt" % rank))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_real_sepconv_parameter_set_through_the_bucket_with_two_ranks():
+    with tempfile.TemporaryDirectory() as d:
+        port = 29500 + (os.getpid() % 2000) + 130
+        mp.spawn(_sepconv_bucket_worker, args=(2, port, d), nprocs=2, join=True)
+        res = [torch.load(os.path.join(d, "sep%d.pt" % r), weights_only=False) for r in range(2)]
+    for r in res:
+        assert r['ok'] and r['same'] and r['diverged_detected']
+        assert r['nbytes'] == 4 * (r['numel'] + r['n'])
+        assert 80e6 < r['nbytes'] < 95e6, r['nbytes']          # the 86.7 MB message of DESIGN.md section 6
