@@ -1124,9 +1124,12 @@ extern "C" int savfi_sepconv_fwd_f32(const float* in, const float* v, const floa
   if (!in || !v || !h || !out) return SAVFI_E_NULL;
   if (int e = check_dims(B, C, Ho, Wo, K)) return e;
   hipStream_t st = (hipStream_t)stream;
-  if (K == KFAST && C == 3 && !sepconv_env().no_mfma && !sepconv_env().tiled && !sepconv_env().f32_mfma && persistent_ok(B, Ho, Wo))
-    if ((Wo & 3) == 0 && !sepconv_env().no_ws && !sepconv_env().no_ws_fwd) return savfi_sepconv_fwd_ws_launch(in, v, h, out, B, Ho, Wo, device_cu_count(), st);
+  if (K == KFAST && C == 3 && !sepconv_env().no_mfma && !sepconv_env().tiled && !sepconv_env().f32_mfma && persistent_ok(B, Ho, Wo)) {
+    // widths that are a multiple of 4: the wave-specialised kernel (csrc/sepconv_ws.hip); others: one program per wave (csrc/sepconv_x6.hip)
+    if ((Wo & 3) == 0 && !sepconv_env().no_ws && !sepconv_env().no_ws_fwd)
+      return savfi_sepconv_fwd_ws_launch(in, v, h, out, B, Ho, Wo, device_cu_count(), st);
     return savfi_sepconv_fwd_x6_launch(in, v, h, out, B, Ho, Wo, device_cu_count(), st);
+  }
   if (K == KFAST && C == 3 && !sepconv_env().no_mfma && mfma_fits(Ho, Wo)) {
     switch (mfma_rows(B, Ho, Wo)) {
       case 8: return launch_fwd_mfma<8>(in, v, h, out, B, Ho, Wo, st);

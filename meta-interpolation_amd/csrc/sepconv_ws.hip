@@ -727,13 +727,13 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
 // ------------------------------------------------------------------------------------------------------------------------------------
 constexpr int FVP = 72;                             // pitch of a v tile row (floats): [pixel j][tap]; 16-byte fragments of the 16 lanes of a
                                                     // read group fall on 8 j + 4 kg: conflict free
-constexpr int FVTB = 16 * FVP * 4, FOPB = 4 * XC * 16 * 4;
+constexpr int FVTB = 16 * FVP * 4, FOPB = 4 * XC * 16 * 4 + 32;   // partial sums [kg][c][16] + the six tail-column sums of the unit
 constexpr int FPAIRB = XTAB + FVTB + FOPB;
 constexpr int FSIDE_OFF = XWINB + 4 * FPAIRB;
 constexpr int FFLAG_OFF = FSIDE_OFF + WSIDEB;
 constexpr int FLDS = FFLAG_OFF + 256;
 static_assert(FLDS <= 160 * 1024, "LDS per CU");
-enum { F_VT_FULL = 8, F_VT_FREE = 12, F_OP_FULL = 32, F_OP_FREE = 36 };     // + F_TAB_*, F_PROG, F_SLIDE, F_ERR as above
+enum { F_VT_FULL = 8, F_VT_FREE = 12, F_OP_FULL = 32, F_OP_FREE = 36, F_TL_FULL = 40, F_TL_FREE = 44 };     // + F_TAB_*, F_PROG, F_SLIDE, F_ERR
 
 __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ in, const float* __restrict__ v,
                                                       const float* __restrict__ h, float* __restrict__ out,
@@ -746,6 +746,7 @@ __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ 
   char* const tab = smem + XWINB + p * FPAIRB;
   float* const vt = reinterpret_cast<float*>(tab + XTAB);
   float* const op = reinterpret_cast<float*>(tab + XTAB + FVTB);
+  float* const tl = op + 4 * XC * 16;              // [pixel 14 | 15][channel]: the unit's tail-column sums
   float* const side = reinterpret_cast<float*>(smem + FSIDE_OFF);
   unsigned* const fl = reinterpret_cast<unsigned*>(smem + FFLAG_OFF);
 
@@ -940,7 +941,6 @@ __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ 
       float hreg[XNP][2], vreg[XNP][2];
       if (hside) load_taps(hreg, hsrc, b, x0, unit_y(0), h_t0);
       else load_taps(vreg, vsrc, b, x0, unit_y(0), v_t0);
-      float o14[XC] = {0.f, 0.f, 0.f}, o15[XC] = {0.f, 0.f, 0.f};      // h side: tail-column contributions of the unit finalised next
       unsigned ooff_prev = X_OOR;
 #pragma unroll 1
       for (int n = 0; n <= N; ++n) {
@@ -958,11 +958,6 @@ __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ 
         const int fyl = min(lane, XK - 1);
         const int tslot = (y + fyl) & (XWIN - 1);
         if (hside) {
-          // v of pixels 14, 15 of this unit by tap row (lane = fy): one 8-byte load per lane, in flight under the table build
-          const unsigned v2off = (unsigned)b * (unsigned)XK * plane_b + (unsigned)fyl * plane_b
-                                 + (unsigned)(min(y, Ho - 1) * Wo + min(x0 + 16 * wc + 14, Wo - 2)) * 4u;
-          const unsigned long long v2raw = __builtin_bit_cast(unsigned long long, __builtin_amdgcn_raw_buffer_load_b64(vsrc, (int)v2off, 0, 0));
-          const float h50_14 = rdlane(hreg[6][0], 14 + 16), h49_15 = rdlane(hreg[6][0], 15 + 16), h50_15 = rdlane(hreg[6][1], 15 + 16);
           // (1) the h band of unit n takes the table
           if (live) {
             ws_wait(fl, F_TAB_FREE + p, n);
@@ -971,19 +966,46 @@ __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ 
             ws_set(fl, F_TAB_FULL + p, n + 1);
             __builtin_amdgcn_s_setprio(0);
           }
-          // (2) unit n - 1: the four lane groups' partial sums + tail columns -> HBM (lane = (channel, pixel))
+          if (live && u == 1) ws_set(fl, F_PROG + w, q + 1);      // this wave reads neither the window nor the side columns
+          load_taps(hreg, hsrc, b, x0, y1, h_t0);
+          // (2) unit n - 1: the four lane groups' partial sums + the tail-column sums of the v-side wave -> HBM (lane = (channel, pixel))
           {
-            if (n > 0) ws_wait(fl, F_OP_FULL + p, n);
+            if (n > 0) { ws_wait(fl, F_OP_FULL + p, n); ws_wait(fl, F_TL_FULL + p, n); }
             const int c = min(lane >> 4, XC - 1);
             const float* o = op + c * 16 + j;
             float val = (o[0] + o[XC * 16]) + (o[2 * XC * 16] + o[3 * XC * 16]);
-            const float t14 = c == 0 ? o14[0] : c == 1 ? o14[1] : o14[2], t15 = c == 0 ? o15[0] : c == 1 ? o15[1] : o15[2];
+            const float t14 = tl[c], t15 = tl[XC + c];
             val += j == 14 ? t14 : j == 15 ? t15 : 0.f;
             x6_bstore(val, odst, lane < 16 * XC ? ooff_prev : X_OOR, 0u);
-            if (n > 0) ws_set(fl, F_OP_FREE + p, n);
+            if (n > 0) { ws_set(fl, F_OP_FREE + p, n); ws_set(fl, F_TL_FREE + p, n); }
           }
+          {
+            const int c = min(lane >> 4, XC - 1), x = x0 + 16 * wc + j;
+            ooff_prev = (live && y < Ho && x < Wo) ? (unsigned)(b * XC + c) * plane_b + (unsigned)(y * Wo + x) * 4u : X_OOR;
+          }
+        } else {
+          // taps 50 of pixel 14 and 49, 50 of pixel 15 of the h band (the tail columns' weights): lanes 0..2, in flight under the tile write
+          const int hl = min(lane, 2);
+          const unsigned hoff = (unsigned)b * (unsigned)XK * plane_b + (unsigned)(hl == 1 ? 49 : 50) * plane_b
+                                + (unsigned)(min(y, Ho - 1) * Wo + min(x0 + 16 * wc + (hl == 0 ? 14 : 15), Wo - 1)) * 4u;
+          const float hraw = x6_bload(hsrc, hoff, 0u);
+          // (1) v of unit n -> the pair's v tile [pixel][tap]: the lane's pairs of neighbouring taps as 8-byte stores
+          float v14 = 0.f, v15 = 0.f;
+          if (live) {
+            ws_wait(fl, F_VT_FREE + p, n);
+            float* const vw = vt + j * FVP + 2 * kg;
+#pragma unroll
+            for (int a = 0; a < XNP; ++a)
+              *reinterpret_cast<f32x2*>(vw + 8 * a) = (f32x2){tap_or_zero(vreg, a, 0, v_t0), tap_or_zero(vreg, a, 1, v_t0)};
+            asm volatile("" ::: "memory");
+            v14 = vt[14 * FVP + fyl];                 // v of pixels 14, 15 by tap row (lane = fy): back from the tile, before it is published
+            v15 = vt[15 * FVP + fyl];
+            asm volatile("" ::: "memory");
+            ws_set(fl, F_VT_FULL + p, n + 1);
+          }
+          load_taps(vreg, vsrc, b, x0, y1, v_t0);
           // (3) tail columns of unit n: T_c[fy][14] += In_c[y + fy][64] h50_14, T_c[fy][15] += In_c[..][64] h49_15 + In_c[..][65] h50_15,
-          //     times v of the pixel, summed over the tap rows
+          //     times v of the pixel, summed over the tap rows -> six sums for the h-side wave's final add
           if (live && u == 0 && q >= 2) ws_wait(fl, F_SLIDE, 8 * (2 * q - 3));
           float a64[XC], a65[XC];
 #pragma unroll
@@ -993,32 +1015,20 @@ __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ 
           }
           asm volatile("" ::: "memory");
           if (live && u == 1) ws_set(fl, F_PROG + w, q + 1);
-          load_taps(hreg, hsrc, b, x0, y1, h_t0);
-          {
+          if (live) {
+            const float h50_14 = rdlane(hraw, 0), h49_15 = rdlane(hraw, 1), h50_15 = rdlane(hraw, 2);
             const float lv = lane < XK ? 1.f : 0.f;
-            const float v14 = lv * __uint_as_float((unsigned)v2raw), v15 = lv * __uint_as_float((unsigned)(v2raw >> 32));
+            v14 *= lv; v15 *= lv;
+            float s14[XC], s15[XC];
 #pragma unroll
             for (int c = 0; c < XC; ++c) {
-              o14[c] = ws_wave_sum(v14 * (a64[c] * h50_14));
-              o15[c] = ws_wave_sum(v15 * fmaf(a65[c], h50_15, a64[c] * h49_15));
+              s14[c] = ws_wave_sum(v14 * (a64[c] * h50_14));
+              s15[c] = ws_wave_sum(v15 * fmaf(a65[c], h50_15, a64[c] * h49_15));
             }
+            ws_wait(fl, F_TL_FREE + p, n);
+            if (lane < 2 * XC) tl[lane] = lane == 0 ? s14[0] : lane == 1 ? s14[1] : lane == 2 ? s14[2] : lane == 3 ? s15[0] : lane == 4 ? s15[1] : s15[2];
+            ws_set(fl, F_TL_FULL + p, n + 1);
           }
-          {
-            const int c = min(lane >> 4, XC - 1), x = x0 + 16 * wc + j;
-            ooff_prev = (live && y < Ho && x < Wo) ? (unsigned)(b * XC + c) * plane_b + (unsigned)(y * Wo + x) * 4u : X_OOR;
-          }
-        } else {
-          // (1) v of unit n -> the pair's v tile [pixel][tap]: the lane's pairs of neighbouring taps as 8-byte stores
-          if (live) {
-            ws_wait(fl, F_VT_FREE + p, n);
-            float* const vw = vt + j * FVP + 2 * kg;
-#pragma unroll
-            for (int a = 0; a < XNP; ++a)
-              *reinterpret_cast<f32x2*>(vw + 8 * a) = (f32x2){tap_or_zero(vreg, a, 0, v_t0), tap_or_zero(vreg, a, 1, v_t0)};
-            ws_set(fl, F_VT_FULL + p, n + 1);
-          }
-          if (live && u == 1) ws_set(fl, F_PROG + w, q + 1);      // this wave reads neither the window nor the side columns
-          load_taps(vreg, vsrc, b, x0, y1, v_t0);
         }
         // (4) the new window row
         if (live) {

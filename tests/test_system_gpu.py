@@ -24,7 +24,9 @@ DEV = "cuda"
 SYSTEM = ['c1_cain_lslr_sgd', 'cain_l2f', 'cain_lslr_adam_1step', 'sepconv_lslr_sgd_2step',
           'sepconv_metasgd_adamax_2step', 'sepconv_msl_learnable_2step', 'voxelflow_metasgd_adamax_2step',
           'voxelflow_lslr_sgd_2step', 'voxelflow_script_metasgd_adam_1step', 'rrin_lslr_sgd_2step',
-          'superslomo_lslr_sgd_2step']
+          'superslomo_lslr_sgd_2step',
+          # 128 x 128 twins (deepest maps 4 x 4): the OUTER-gradient fingerprints at the plain 1e-3 gate
+          'sepconv_msl_learnable_2step_128', 'superslomo_lslr_sgd_2step_128']
 
 # Gates = max(contract bound, K x the REFERENCE's own spread).
 #
@@ -68,7 +70,7 @@ def tolerances(name, phase='train'):
     # (<= 8 x 8 maps) run on MIOpen, whose find step picks solvers per process; a LeakyReLU unit of such a map switching is ~5e-3 of
     # that bias's learning-rate gradient: the SepConv case above.  Rounds 1-2 carried 1e-2 here (then for the 7x7 / 5x5 stages on
     # MIOpen's implicit-GEMM kernels, 3.1e-3 off); the gate removed early this round made the suite fail one run in three.
-    if name.startswith('superslomo_') and phase == 'train':
+    if name.startswith('superslomo_') and phase == 'train' and int(golden('system_' + name)['H']) <= 64:
         tol['outer'] = max(tol['outer'], 1e-2)
     return tol
 
@@ -621,7 +623,9 @@ def lockstep_for(monkeypatch):
 
 
 @pytest.mark.parametrize("name", ['sepconv_msl_learnable_2step', 'voxelflow_lslr_sgd_2step', 'voxelflow_metasgd_adamax_2step',
-                                  'superslomo_lslr_sgd_2step'])          # the 2-task fixtures
+                                  'superslomo_lslr_sgd_2step',
+          # 128 x 128 twins (deepest maps 4 x 4): the OUTER-gradient fingerprints at the plain 1e-3 gate
+          'sepconv_msl_learnable_2step_128', 'superslomo_lslr_sgd_2step_128'])          # the 2-task fixtures
 @pytest.mark.parametrize("phase", ["train", "val"])
 def test_lockstep_tasks_match_reference_fixture(name, phase, lockstep_for):
     g = golden("system_" + name)
@@ -708,7 +712,9 @@ def test_lockstep_equals_the_sequential_loop(model, over, lockstep_for):
 
 
 @pytest.mark.parametrize("name", ['sepconv_msl_learnable_2step', 'voxelflow_lslr_sgd_2step', 'voxelflow_metasgd_adamax_2step',
-                                  'superslomo_lslr_sgd_2step'])
+                                  'superslomo_lslr_sgd_2step',
+          # 128 x 128 twins (deepest maps 4 x 4): the OUTER-gradient fingerprints at the plain 1e-3 gate
+          'sepconv_msl_learnable_2step_128', 'superslomo_lslr_sgd_2step_128'])
 @pytest.mark.parametrize("phase", ["train", "val"])
 def test_graphed_lockstep_tasks_match_reference_fixture(name, phase, lockstep_for):
     """--graph_inner_loop 1 --task_batch 2: the lockstep pass replayed from hipGraphs (stacked static buffers)."""

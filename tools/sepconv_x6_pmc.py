@@ -12,4 +12,7 @@ gO = torch.randn(B, C, Ho, Wo, device="cuda")
 gV, gH = torch.empty_like(v), torch.empty_like(h)
 for _ in range(6):
     _hip.check(lib.savfi_sepconv_bwd_f32(inp.data_ptr(), v.data_ptr(), h.data_ptr(), gO.data_ptr(), None, gV.data_ptr(), gH.data_ptr(), B, C, Ho, Wo, K, st), "bwd")
+out = torch.empty_like(gO)
+for _ in range(6):
+    _hip.check(lib.savfi_sepconv_fwd_f32(inp.data_ptr(), v.data_ptr(), h.data_ptr(), out.data_ptr(), B, C, Ho, Wo, K, st), "fwd")
 torch.cuda.synchronize()
