@@ -56,7 +56,7 @@
 extern "C" {
 #endif
 
-#define SAVFI_ABI_VERSION 10
+#define SAVFI_ABI_VERSION 11
 
 #define SAVFI_OK            0
 #define SAVFI_E_NULL       (-1)  /* a required pointer is NULL                          */
@@ -280,6 +280,12 @@ int savfi_conv3x3_filters_multi_f32(const float* const* w, float* const* u_fwd, 
 int64_t savfi_conv3x3_tasks_pre_workspace_floats(int N, int T, int Ci, int Co, int H, int W, int pad, int mode);
 int savfi_conv3x3_tasks_pre_f32(const float* x, const float* u, const float* bias, float* out, float* workspace,
                                 int N, int T, int Ci, int Co, int H, int W, int pad, int mode, float slope, void* stream);
+/* Data gradient (mode 1) on a transformed filter with the (leaky) ReLU derivative of the layer that PRODUCED this convolution's input
+ * folded into the output stage: gx = dgrad(gy) * (mask > 0 ? 1 : mask_slope); mask [N,Ci,H+2-2pad,W+2-2pad] is the convolution's
+ * forward input (= the producer's activated output).  conv -> ReLU -> conv chains (sepconv/model.py:172-245 Basic / Subnet blocks):
+ * the producer's backward then needs no element-wise pass of its own.  workspace: as savfi_conv3x3_tasks_pre_f32, mode 1. */
+int savfi_conv3x3_dgrad_masked_f32(const float* gy, const float* u, const float* mask, float mask_slope, float* gx,
+                                   float* workspace, int N, int T, int Ci, int Co, int H, int W, int pad, void* stream);
 
 /* Weight gradient of the same convolution (zero padding `pad` in {0,1}), NCHW in and out, deterministic:
  *   gw[Co,Ci,3,3] = sum over n,y,x of gz[n,co,y,x] * x[n,ci,y+a-pad,x+b-pad]      x [N,Ci,H,W], gz [N,Co,H+2pad-2,W+2pad-2]
@@ -325,6 +331,9 @@ int savfi_convk_filters_multi_f32(const float* const* w, float* const* p_fwd, fl
                                   const int* Co, const int* K, int n, void* stream);
 int savfi_convk_tasks_pre_f32(const float* x, const float* packed, const float* bias, float* out, int N, int T, int Ci,
                               int Co, int H, int W, int K, int pad, int mode, float slope, int precise, void* stream);
+/* the same fold for the direct kernels: gx = savfi_convk_tasks_pre_f32(mode 1)(gy) * (mask > 0 ? 1 : mask_slope) */
+int savfi_convk_dgrad_masked_f32(const float* gy, const float* packed, const float* mask, float mask_slope, float* gx, int N, int T,
+                                 int Ci, int Co, int H, int W, int K, int pad, int precise, void* stream);
 /* `reflect` != 0 (mode 0 only, pad < H, W): the border of width `pad` mirrors the image instead of reading zeros, i.e.
  * conv2d(nn.ReflectionPad2d(pad)(x), w) without the padded copy -- CAIN's MetaConvNorm (reference model_utils.py:821-848).  Its data
  * gradient is savfi_convk_tasks_pre_f32(mode 1, pad 0) on gy (the gradient of the padded extent) folded by

@@ -163,6 +163,8 @@ struct ConvkArgs {
   int total, per_xcd, order, cg;
   int reflect;         // 1: the border of width `pad` mirrors the image (nn.ReflectionPad2d) instead of reading zeros
   float slope;
+  const float* mask;   // data gradient only, or null: out *= (mask > 0 ? 1 : mask_slope), mask laid out like out -- the (leaky) ReLU
+  float mask_slope;    // derivative of the layer that PRODUCED this convolution's input, folded into this layer's data gradient
 };
 
 template <int KS, int QC, int NT, int TW>
@@ -394,13 +396,23 @@ __global__ __launch_bounds__(CK_THREADS * CG, 2) void convk_kernel(const ConvkAr
         float u = v[r] + b;
         v[r] = u > 0.f ? u : u * a.slope;
       }
-      float* dst = outn + (size_t)co * plane_out + (size_t)oy * a.Wo + ox;
+      const size_t oidx = (size_t)co * plane_out + (size_t)oy * a.Wo + ox;
+      float* dst = outn + oidx;
       if (vec_ok && ox + 3 < a.Wo) {
+        if (a.mask) {
+          const f32x4 m = *reinterpret_cast<const f32x4*>(a.mask + (size_t)n * a.cout * plane_out + oidx);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = m[r] > 0.f ? v[r] : v[r] * a.mask_slope;
+        }
         *reinterpret_cast<f32x4*>(dst) = v;
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (ox + r < a.Wo) dst[r] = v[r];
+          if (ox + r < a.Wo) {
+            float u = v[r];
+            if (a.mask) u = a.mask[(size_t)n * a.cout * plane_out + oidx + r] > 0.f ? u : u * a.mask_slope;
+            dst[r] = u;
+          }
       }
     }
   }
@@ -534,9 +546,27 @@ extern "C" int savfi_convk_tasks_pre_f32(const float* x, const float* packed, co
   return savfi_convk_tasks_pre_reflect_f32(x, packed, bias, out, N, T, Ci, Co, H, W, K, pad, mode, slope, precise, 0, stream);
 }
 
+static int convk_tasks_pre_impl(const float* x, const float* packed, const float* bias, float* out, int N, int T, int Ci, int Co, int H, int W,
+                                int K, int pad, int mode, float slope, int precise, int reflect, const float* mask, float mask_slope,
+                                void* stream);
+
 extern "C" int savfi_convk_tasks_pre_reflect_f32(const float* x, const float* packed, const float* bias, float* out, int N, int T, int Ci,
                                                  int Co, int H, int W, int K, int pad, int mode, float slope, int precise, int reflect,
                                                  void* stream) {
+  return convk_tasks_pre_impl(x, packed, bias, out, N, T, Ci, Co, H, W, K, pad, mode, slope, precise, reflect, nullptr, 1.f, stream);
+}
+
+// data gradient (mode 1) with the activation derivative of the layer that produced this convolution's input folded into the epilogue:
+// gx = dgrad(gy) * (mask > 0 ? 1 : mask_slope), mask [N,Ci,H+K-1-2p,W+K-1-2p] = this convolution's forward input (include/savfi_hip.h)
+extern "C" int savfi_convk_dgrad_masked_f32(const float* gy, const float* packed, const float* mask, float mask_slope, float* gx, int N, int T,
+                                            int Ci, int Co, int H, int W, int K, int pad, int precise, void* stream) {
+  if (!mask) return SAVFI_E_NULL;
+  return convk_tasks_pre_impl(gy, packed, nullptr, gx, N, T, Ci, Co, H, W, K, pad, 1, 1.f, precise, 0, mask, mask_slope, stream);
+}
+
+static int convk_tasks_pre_impl(const float* x, const float* packed, const float* bias, float* out, int N, int T, int Ci, int Co, int H, int W,
+                                int K, int pad, int mode, float slope, int precise, int reflect, const float* mask, float mask_slope,
+                                void* stream) {
   if (reflect && (mode != 0 || pad >= H || pad >= W)) return SAVFI_E_UNSUPPORTED;
   if (!x || !packed || !out) return SAVFI_E_NULL;
   if (N <= 0 || T <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0 || N % T != 0 || pad < 0 || pad > K - 1) return SAVFI_E_SHAPE;
@@ -550,6 +580,7 @@ extern "C" int savfi_convk_tasks_pre_reflect_f32(const float* x, const float* pa
   if (a.Ho <= 0 || a.Wo <= 0) return SAVFI_E_SHAPE;
   if ((int64_t)a.cin * H * W >= (1ll << 29) || (int64_t)a.cout * a.Ho * a.Wo >= (1ll << 31)) return SAVFI_E_TOOBIG;   // byte offsets of a sample fit 31 bits
   a.slope = slope;
+  a.mask = mask; a.mask_slope = mask_slope;
   a.reflect = reflect ? 1 : 0;
   const int qc = ck_qc(a.cin, K);
   a.C = ck_chunks(a.cin, qc);

@@ -40,6 +40,8 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 __device__ f32x4 savfi_raw_buffer_load_x4(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ void savfi_raw_buffer_store_x2(f32x2 data, i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v2f32");
+__device__ f32x2 savfi_raw_buffer_load_x2(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2f32");
+__device__ float savfi_raw_buffer_load_x1(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
 __device__ void savfi_raw_buffer_store_x1(float data, i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.f32");
 
 namespace {
@@ -168,6 +170,8 @@ struct WinoArgs {
   float* partial;                                          // nsplit > 1: raw partial outputs [split][N][I][Ho][Wo]
   int T;                                                   // filter sets: sample n uses set n % T (U [T][...], bias [T][I])
   int N;                                                   // samples
+  const float* mask;                                       // or null: out *= (mask > 0 ? 1 : mask_slope), mask laid out like out (the
+  float mask_slope;                                        // activation derivative of the layer that produced this data gradient's output)
 #ifdef WINO_TRACE
   unsigned long long* trace;                               // [workgroup][8]: timestamps (100 MHz) + hardware ids
 #endif
@@ -487,6 +491,24 @@ __global__ __launch_bounds__(WNT, 2) void wino_conv3x3(WinoArgs a) {
   float* const obase = a.nsplit == 1 ? a.out : a.partial + (size_t)sp * a.N * a.I * a.Ho * a.Wo;
   const float slope = a.nsplit == 1 ? a.slope : 1.f;       // bias / activation happen in wino_split_reduce
   const unsigned oplane_bytes = (unsigned)(a.Ho * a.Wo) * 4u;
+  // the mask values of this lane's 32 outputs, ALL before the first store (a load issued between stores can only be waited for
+  // together with every older store's write acknowledge: see the bias values above)
+  const bool masked = a.mask != nullptr && a.nsplit == 1;
+  f32x2 mk[2][4][2];
+  if (masked) {
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int rep = 0; rep < 4; ++rep) {
+        const int i = i0 + 16 * cb + w + 4 * rep;
+        const i32x4 mrs = plane_rsrc(a.mask + ((size_t)n * a.I + min(i, a.I - 1)) * a.Ho * a.Wo, i < a.I ? oplane_bytes : 0u);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          if (VEC) mk[cb][rep][r] = savfi_raw_buffer_load_x2(mrs, (int)ooff[r][0], 0, 0);
+          else mk[cb][rep][r] = (f32x2){savfi_raw_buffer_load_x1(mrs, (int)ooff[r][0], 0, 0), savfi_raw_buffer_load_x1(mrs, (int)ooff[r][1], 0, 0)};
+        }
+      }
+  }
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb) {
 #pragma unroll
@@ -521,6 +543,10 @@ __global__ __launch_bounds__(WNT, 2) void wino_conv3x3(WinoArgs a) {
         float v0 = y[r][0] + b, v1 = y[r][1] + b;
         v0 = fmaxf(v0, 0.f) + slope * fminf(v0, 0.f);      // v > 0 ? v : slope * v
         v1 = fmaxf(v1, 0.f) + slope * fminf(v1, 0.f);
+        if (masked) {
+          v0 = mk[cb][rep][r].x > 0.f ? v0 : v0 * a.mask_slope;
+          v1 = mk[cb][rep][r].y > 0.f ? v1 : v1 * a.mask_slope;
+        }
         if (VEC) {
           savfi_raw_buffer_store_x2((f32x2){v0, v1}, ors, (int)ooff[r][0], 0, 0);
         } else {
@@ -548,7 +574,7 @@ __global__ __launch_bounds__(WNT, 2) void wino_conv3x3(WinoArgs a) {
 // out = act(sum over splits of partial (fixed order: deterministic) + bias[c])
 __global__ __launch_bounds__(256) void wino_split_reduce(const float* __restrict__ partial, const float* __restrict__ bias,
                                                          float* __restrict__ out, int nsplit, size_t total, int I, int HW,
-                                                         float slope, int T) {
+                                                         float slope, int T, const float* __restrict__ mask, float mask_slope) {
   const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= total) return;
   float acc = 0.f;
@@ -557,7 +583,9 @@ __global__ __launch_bounds__(256) void wino_split_reduce(const float* __restrict
     const size_t plane = e / HW;                    // n * I + c
     acc += bias[((plane / I) % T) * I + plane % I];
   }
-  out[e] = acc > 0.f ? acc : slope * acc;
+  acc = acc > 0.f ? acc : slope * acc;
+  if (mask) acc = mask[e] > 0.f ? acc : acc * mask_slope;
+  out[e] = acc;
 }
 
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
@@ -642,13 +670,13 @@ namespace {
 
 // launches wino_conv3x3 (+ the split reduction) on an already transformed filter U [T][16 * KP * IP]
 int launch_conv(const WinoPlan& p, const float* x, const float* U, const float* bias, float* out, float* partial, int N, int T,
-                int H, int W, int mode, float slope, hipStream_t st) {
+                int H, int W, int mode, float slope, hipStream_t st, const float* mask = nullptr, float mask_slope = 1.f) {
   const int64_t wgs = (int64_t)p.th * p.tw * (p.IP / COB) * p.nsplit * N;
   if (wgs > 0x7fffffffLL || T > 65535) return SAVFI_E_TOOBIG;
   constexpr size_t lds = (size_t)LDS_FLOATS * sizeof(float);      // 40 KB: two workgroups per CU
   const float* b = mode == 0 ? bias : nullptr;
   WinoArgs a{x, U, b, out, p.K, p.I, p.KP, p.IP, H, W, p.Ho, p.Wo, p.off, p.th, p.tw, slope, p.tile_shift, p.nsplit,
-             p.chunks_per_split, partial, T, N
+             p.chunks_per_split, partial, T, N, mask, mask_slope
 #ifdef WINO_TRACE
              , savfi_wino_trace_buffer((size_t)wgs)
 #endif
@@ -659,7 +687,7 @@ int launch_conv(const WinoPlan& p, const float* x, const float* U, const float* 
   if (p.nsplit > 1) {
     const size_t total = (size_t)N * p.I * p.Ho * p.Wo;
     hipLaunchKernelGGL(wino_split_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, partial, b, out, p.nsplit, total,
-                       p.I, p.Ho * p.Wo, slope, T);
+                       p.I, p.Ho * p.Wo, slope, T, mask, mask_slope);
     return savfi_launch_status();
   }
   return SAVFI_OK;
@@ -770,6 +798,17 @@ extern "C" int savfi_conv3x3_tasks_pre_f32(const float* x, const float* u, const
   if (int e = check_conv_args(p, N, T, Ci, Co, H, W, pad, mode)) return e;
   if (p.partial_floats > 0 && !workspace) return SAVFI_E_NULL;
   return launch_conv(p, x, u, bias, out, workspace, N, T, H, W, mode, slope, (hipStream_t)stream);
+}
+
+// data gradient (mode 1) on a transformed filter with the activation derivative of the layer that produced this convolution's input
+// folded into the output stage: gx = dgrad(gy) * (mask > 0 ? 1 : mask_slope), mask [N,Ci,H+2-2pad,W+2-2pad] = the forward input
+extern "C" int savfi_conv3x3_dgrad_masked_f32(const float* gy, const float* u, const float* mask, float mask_slope, float* gx,
+                                              float* workspace, int N, int T, int Ci, int Co, int H, int W, int pad, void* stream) {
+  if (!gy || !u || !gx || !mask) return SAVFI_E_NULL;
+  WinoPlan p;
+  if (int e = check_conv_args(p, N, T, Ci, Co, H, W, pad, 1)) return e;
+  if (p.partial_floats > 0 && !workspace) return SAVFI_E_NULL;
+  return launch_conv(p, gy, u, nullptr, gx, workspace, N, T, H, W, 1, 1.f, (hipStream_t)stream, mask, mask_slope);
 }
 
 extern "C" int savfi_conv3x3_f32(const float* x, const float* w, const float* bias, float* out, float* workspace,

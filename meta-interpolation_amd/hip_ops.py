@@ -847,8 +847,12 @@ class _ConvBiasAct(torch.autograd.Function):
     differentiable): callers use the unfused ops under --second_order."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, padding, dilation, groups, slope, direct=False, cache=None, reflect=False):
+    def forward(ctx, x, w, b, stride, padding, dilation, groups, slope, direct=False, cache=None, reflect=False, in_slope=None, defer=False):
+        # conv -> ReLU -> conv chains (model_utils.MetaSequential): `defer` -- the consumer of y applies THIS layer's activation
+        # derivative (the gradient arriving here is already d/dz); `in_slope` -- x is the activated output of a layer that deferred
+        # its derivative to this one: it is folded into this layer's data gradient (kernel epilogue where there is one)
         pad = padding if isinstance(padding, int) else padding[0]
+        ctx.in_slope, ctx.defer = in_slope, bool(defer)
         ctx.u_bwd, ctx.route, ctx.reflect = None, None, bool(reflect)
         assert not reflect or convk_eligible(x, w, stride, padding, dilation, groups, direct), "mirrored borders: direct kernel only"
         if convk_eligible(x, w, stride, padding, dilation, groups, direct):
@@ -886,9 +890,10 @@ class _ConvBiasAct(torch.autograd.Function):
         gy = gy.contiguous()
         N, C, H, W = y.shape
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2] and ctx.has_bias
-        identity = slope == 1.0                  # no activation: gz is gy itself, only the bias gradient is computed
-        gz = gy if identity else torch.empty_like(gy)
+        identity = slope == 1.0 or ctx.defer     # no activation, or its derivative already applied by the consumer: gz is gy itself,
+        gz = gy if identity else torch.empty_like(gy)        # only the bias gradient is computed
         gb = torch.empty(C, dtype=gy.dtype, device=gy.device) if need_b else None
+        mask, mslope = (x, ctx.in_slope) if (ctx.in_slope is not None and need_x) else (None, 1.0)
         if need_b or not identity:
             lib = _hip.lib()
             scratch = (torch.empty(_workspace_floats("savfi_bias_act_scratch_floats", N, C, H * W), dtype=gy.dtype, device=gy.device)
@@ -896,7 +901,7 @@ class _ConvBiasAct(torch.autograd.Function):
             _hip.launch("bias_act_bwd", lambda: _hip.check(lib.savfi_bias_act_bwd_f32(
                 gy.data_ptr(), (gy if identity else y).data_ptr(), None if identity else gz.data_ptr(),
                 None if gb is None else gb.data_ptr(), None if scratch is None else scratch.data_ptr(),
-                N, C, H * W, slope, _hip.current_stream()), "savfi_bias_act_bwd_f32"))
+                N, C, H * W, 1.0 if identity else slope, _hip.current_stream()), "savfi_bias_act_bwd_f32"))
         gx = gw = None
         pad = padding if isinstance(padding, int) else padding[0]
         K = int(w.shape[-1])
@@ -909,14 +914,16 @@ class _ConvBiasAct(torch.autograd.Function):
             if ctx.reflect:     # gradient of the mirrored (padded) extent = the full data gradient of the unpadded convolution, folded
                 gx = reflect_pad_bwd(convk_tasks_pre(gz, u_bwd, 1, w.shape[1], w.shape[0], K, None, 1, 1.0, 0, ctx.direct), pad)
             else:
-                gx = convk_tasks_pre(gz, u_bwd, 1, w.shape[1], w.shape[0], K, None, 1, 1.0, pad, ctx.direct)
+                gx = convk_tasks_pre(gz, u_bwd, 1, w.shape[1], w.shape[0], K, None, 1, 1.0, pad, ctx.direct, mask=mask, mask_slope=mslope)
+                mask = None
             need_x = False
         if need_w and ctx.reflect:
             gw = convk_wgrad_tasks(x, gz, 1, K, pad, ctx.direct, True)[0]
             need_w = False
         elif need_x and conv3x3_eligible(x, w, stride, padding, dilation, groups, backward=True):
             if u_bwd is not None and ctx.route == 'wino':
-                gx = conv3x3_tasks_pre(gz, u_bwd, 1, w.shape[1], w.shape[0], None, 1, 1.0, pad)
+                gx = conv3x3_tasks_pre(gz, u_bwd, 1, w.shape[1], w.shape[0], None, 1, 1.0, pad, mask=mask, mask_slope=mslope)
+                mask = None
             else:
                 gx = conv3x3(gz, w, None, 1, 1.0, pad)
             need_x = False
@@ -950,7 +957,9 @@ class _ConvBiasAct(torch.autograd.Function):
                                                               False, [0, 0], groups, [need_x, need_w, False])
             gx = gx2 if need_x else gx
             gw = gw2 if need_w else gw
-        return gx, gw, gb, None, None, None, None, None, None, None, None
+        if mask is not None and gx is not None:      # a route without the fused epilogue: the deferred derivative as its own pass
+            gx = mask_by_activation(gx, mask, mslope)
+        return gx, gw, gb, None, None, None, None, None, None, None, None, None, None
 
 
 # --------------------------------------------------------------------------------------------
@@ -1163,10 +1172,14 @@ def conv3x3_filters(weight, fwd=True, bwd=True):
     return us[0], us[1]
 
 
-def conv3x3_tasks_pre(x, u, T, Ci, Co, bias=None, mode=0, slope=1.0, pad=1):
-    """savfi_conv3x3_tasks_pre_f32: conv3x3_tasks on a filter already transformed by conv3x3_filters (same mode)."""
+def conv3x3_tasks_pre(x, u, T, Ci, Co, bias=None, mode=0, slope=1.0, pad=1, mask=None, mask_slope=1.0):
+    """savfi_conv3x3_tasks_pre_f32: conv3x3_tasks on a filter already transformed by conv3x3_filters (same mode).  `mask` (mode 1):
+    the result is multiplied by (mask > 0 ? 1 : mask_slope) in the kernel's output stage (savfi_conv3x3_dgrad_masked_f32)."""
     x = x.contiguous()
     _hip.require_cuda(x, u)
+    if mask is not None:
+        assert mode == 1 and bias is None and slope == 1.0
+        return _conv3x3_dgrad_masked(x, u, T, Ci, Co, pad, mask.contiguous(), mask_slope)
     N, _, H, W = x.shape
     assert N % T == 0 and x.shape[1] == (Ci if mode == 0 else Co), (x.shape, T, Ci, Co, mode)
     I = Co if mode == 0 else Ci
@@ -1180,6 +1193,55 @@ def conv3x3_tasks_pre(x, u, T, Ci, Co, bias=None, mode=0, slope=1.0, pad=1):
         N, T, Ci, Co, H, W, int(pad), mode, float(slope), _hip.current_stream()), "savfi_conv3x3_tasks_pre_f32"),
         flops=18.0 * Ci * Co * out.shape[2] * out.shape[3] * N if mode == 0 else 18.0 * Ci * Co * H * W * N)
     return out
+
+
+def _conv3x3_dgrad_masked(gy, u, T, Ci, Co, pad, mask, mask_slope):
+    N, _, H, W = gy.shape
+    grow = 2 * (2 - pad) - 2
+    out = torch.empty((N, Ci, H + grow, W + grow), dtype=gy.dtype, device=gy.device)
+    assert mask.shape == out.shape, (mask.shape, out.shape)
+    lib = _hip.lib()
+    nws = _workspace_floats("savfi_conv3x3_tasks_pre_workspace_floats", N, T, Ci, Co, H, W, int(pad), 1)
+    ws = torch.empty(nws, dtype=gy.dtype, device=gy.device) if nws else None
+    _hip.launch("conv3x3_bwd_data", lambda: _hip.check(lib.savfi_conv3x3_dgrad_masked_f32(
+        gy.data_ptr(), u.data_ptr(), mask.data_ptr(), float(mask_slope), out.data_ptr(), None if ws is None else ws.data_ptr(),
+        N, T, Ci, Co, H, W, int(pad), _hip.current_stream()), "savfi_conv3x3_dgrad_masked_f32"), flops=18.0 * Ci * Co * H * W * N)
+    return out
+
+
+def mask_by_activation(g, y, slope):
+    """g * (y > 0 ? 1 : slope): the (leaky) ReLU derivative from the activated output, one element-wise pass (savfi_bias_act_bwd_f32
+    without the bias sums) -- the unfused form of the masked data-gradient epilogues."""
+    g, y = g.contiguous(), y.contiguous()
+    _hip.require_cuda(g, y)
+    out = torch.empty_like(g)
+    N, C = g.shape[:2]
+    hw = g.numel() // (N * C)
+    lib = _hip.lib()
+    _hip.launch("bias_act_bwd", lambda: _hip.check(lib.savfi_bias_act_bwd_f32(
+        g.data_ptr(), y.data_ptr(), out.data_ptr(), None, None, N, C, hw, float(slope), _hip.current_stream()), "savfi_bias_act_bwd_f32"))
+    return out
+
+
+class _MaskGrad(torch.autograd.Function):
+    """identity whose backward multiplies by the activation derivative taken from the (activated) tensor itself: the consumer side of
+    a deferred activation derivative when the consumer is not one of the fused convolutions."""
+
+    @staticmethod
+    def forward(ctx, x, slope):
+        ctx.slope = slope
+        ctx.save_for_backward(x)
+        return x.view_as(x)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        x, = ctx.saved_tensors
+        return mask_by_activation(g, x, ctx.slope), None
+
+
+def mask_grad(x, slope):
+    return _MaskGrad.apply(x, float(slope))
 
 
 def convk_filters(weight, fwd=True, bwd=True):
@@ -1203,9 +1265,10 @@ def convk_filters(weight, fwd=True, bwd=True):
     return ps[0], ps[1]
 
 
-def convk_tasks_pre(x, packed, T, Ci, Co, K, bias=None, mode=0, slope=1.0, pad=1, precise=False, reflect=False):
+def convk_tasks_pre(x, packed, T, Ci, Co, K, bias=None, mode=0, slope=1.0, pad=1, precise=False, reflect=False, mask=None, mask_slope=1.0):
     """savfi_convk_tasks_pre_f32: direct K x K convolution (mode 0, + bias + activation) or its data gradient (mode 1) on a
-    filter packed by convk_filters (same mode); sample n uses filter set n % T."""
+    filter packed by convk_filters (same mode); sample n uses filter set n % T.  `mask` (mode 1): the result is multiplied by
+    (mask > 0 ? 1 : mask_slope) in the kernel's epilogue (savfi_convk_dgrad_masked_f32)."""
     x = x.contiguous()
     _hip.require_cuda(x, packed)
     N, _, H, W = x.shape
@@ -1214,6 +1277,14 @@ def convk_tasks_pre(x, packed, T, Ci, Co, K, bias=None, mode=0, slope=1.0, pad=1
     p_eff = pad if mode == 0 else K - 1 - pad
     out = torch.empty((N, I, H + 2 * p_eff - K + 1, W + 2 * p_eff - K + 1), dtype=x.dtype, device=x.device)
     lib = _hip.lib()
+    if mask is not None:
+        assert mode == 1 and bias is None and slope == 1.0 and not reflect
+        mask = mask.contiguous()
+        assert mask.shape == out.shape, (mask.shape, out.shape)
+        _hip.launch("convk_bwd_data", lambda: _hip.check(lib.savfi_convk_dgrad_masked_f32(
+            x.data_ptr(), packed.data_ptr(), mask.data_ptr(), float(mask_slope), out.data_ptr(), N, T, Ci, Co, H, W, K, int(pad),
+            int(bool(precise)), _hip.current_stream()), "savfi_convk_dgrad_masked_f32"), flops=2.0 * K * K * Ci * Co * N * H * W)
+        return out
     _hip.launch("convk_fwd" if mode == 0 else "convk_bwd_data", lambda: _hip.check(lib.savfi_convk_tasks_pre_reflect_f32(
         x.data_ptr(), packed.data_ptr(), None if bias is None else bias.data_ptr(), out.data_ptr(), N, T, Ci, Co, H, W, K, int(pad),
         mode, float(slope), int(bool(precise)), int(bool(reflect)), _hip.current_stream()), "savfi_convk_tasks_pre_reflect_f32"),
@@ -1336,8 +1407,9 @@ class _ConvBiasActTasks(torch.autograd.Function):
     """y = act(conv2d(x[s], w[s % T]) + b[s % T]) for every sample s.  First-order only (like _ConvBiasAct)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, padding, dilation, slope, direct=False):
+    def forward(ctx, x, w, b, stride, padding, dilation, slope, direct=False, in_slope=None, defer=False):
         x = x.contiguous()
+        ctx.in_slope, ctx.defer = in_slope, bool(defer)          # see _ConvBiasAct.forward
         T, Co, Ci = w.shape[:3]
         N, _, H, W = x.shape
         n = N // T
@@ -1387,9 +1459,10 @@ class _ConvBiasActTasks(torch.autograd.Function):
         N, _, Ho, Wo = y.shape
         n = N // T
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
-        identity = slope == 1.0
+        identity = slope == 1.0 or ctx.defer
         gz = gy if identity else torch.empty_like(gy)
         need_b = need_b and ctx.has_bias
+        mask, mslope = (x, ctx.in_slope) if (ctx.in_slope is not None and need_x) else (None, 1.0)
         gb = torch.empty((T, Co), dtype=gy.dtype, device=gy.device) if need_b else None
         if need_b or not identity:
             lib = _hip.lib()
@@ -1398,7 +1471,7 @@ class _ConvBiasActTasks(torch.autograd.Function):
             _hip.launch("bias_act_bwd", lambda: _hip.check(lib.savfi_bias_act_bwd_f32(
                 gy.data_ptr(), (gy if identity else y).data_ptr(), None if identity else gz.data_ptr(),
                 None if gb is None else gb.data_ptr(), None if scratch is None else scratch.data_ptr(),
-                n, T * Co, Ho * Wo, slope, _hip.current_stream()), "savfi_bias_act_bwd_f32"))
+                n, T * Co, Ho * Wo, 1.0 if identity else slope, _hip.current_stream()), "savfi_bias_act_bwd_f32"))
         gx = gw = None
         pad = padding if isinstance(padding, int) else padding[0]
         K = int(w.shape[-1])
@@ -1407,11 +1480,13 @@ class _ConvBiasActTasks(torch.autograd.Function):
         if need_x and ctx.route == 'convk':
             if u_bwd is None:
                 u_bwd = convk_filters(w, False, True)[1]
-            gx = convk_tasks_pre(gz, u_bwd, T, Ci, Co, K, None, 1, 1.0, pad, ctx.direct)
+            gx = convk_tasks_pre(gz, u_bwd, T, Ci, Co, K, None, 1, 1.0, pad, ctx.direct, mask=mask, mask_slope=mslope)
+            mask = None
             need_x = False
         elif need_x and conv3x3_tasks_eligible(x, w, stride, padding, dilation, backward=True):
             if u_bwd is not None and ctx.route == 'wino':
-                gx = conv3x3_tasks_pre(gz, u_bwd, T, Ci, Co, None, 1, 1.0, pad)
+                gx = conv3x3_tasks_pre(gz, u_bwd, T, Ci, Co, None, 1, 1.0, pad, mask=mask, mask_slope=mslope)
+                mask = None
             else:
                 gx = conv3x3_tasks(gz, w, None, 1, 1.0, pad)
             need_x = False
@@ -1451,12 +1526,15 @@ class _ConvBiasActTasks(torch.autograd.Function):
                     gx = torch.stack([p[0] for p in per], 1).view(N, Ci, H, W)
                 if need_w:
                     gw = torch.stack([p[1] for p in per], 0)
-        return gx, gw, gb, None, None, None, None, None
+        if mask is not None and gx is not None:
+            gx = mask_by_activation(gx, mask, mslope)
+        return gx, gw, gb, None, None, None, None, None, None, None
 
 
-def conv_bias_act_tasks(x, weight, bias, stride=1, padding=0, dilation=1, slope=0.0, direct=False):
-    """act(conv2d(x[s], weight[s % T]) + bias[s % T]): the lockstep form of conv_bias_act."""
-    return _ConvBiasActTasks.apply(x, weight, bias, stride, padding, dilation, float(slope), bool(direct))
+def conv_bias_act_tasks(x, weight, bias, stride=1, padding=0, dilation=1, slope=0.0, direct=False, in_slope=None, defer=False):
+    """act(conv2d(x[s], weight[s % T]) + bias[s % T]): the lockstep form of conv_bias_act (`in_slope`, `defer`: conv_bias_act)."""
+    return _ConvBiasActTasks.apply(x, weight, bias, stride, padding, dilation, float(slope), bool(direct),
+                                   None if in_slope is None else float(in_slope), bool(defer))
 
 
 @functools.lru_cache(maxsize=None)
@@ -1513,11 +1591,16 @@ def conv3x3_wgrad(x, gz, pad=1, stream=None, extra_stream=None):
     return gw
 
 
-def conv_bias_act(x, weight, bias, stride=1, padding=0, dilation=1, groups=1, slope=0.0, direct=False, cache=None, reflect=False):
+def conv_bias_act(x, weight, bias, stride=1, padding=0, dilation=1, groups=1, slope=0.0, direct=False, cache=None, reflect=False,
+                  in_slope=None, defer=False):
     """act(conv2d(x, weight) + bias) with act = LeakyReLU(slope) (0 -> ReLU, 1 -> identity); bias may be None.  `direct`: a 3x3
     layer wants the direct split-bf16 kernel whatever its size (no Winograd rounding); `cache`: a dict owned by the module whose
-    own parameter `weight` is (its packed filters are kept there per weight version), None for fast weights."""
-    return _ConvBiasAct.apply(x, weight, bias, stride, padding, dilation, groups, float(slope), bool(direct), cache, bool(reflect))
+    own parameter `weight` is (its packed filters are kept there per weight version), None for fast weights.
+    conv -> act -> conv chains whose intermediate has ONE consumer (model_utils.MetaSequential): `defer` = that consumer applies this
+    layer's activation derivative, `in_slope` = x is the activated output of a producer that deferred its derivative to this layer
+    (folded into this layer's data gradient: one element-wise pass over the map less per chain link)."""
+    return _ConvBiasAct.apply(x, weight, bias, stride, padding, dilation, groups, float(slope), bool(direct), cache, bool(reflect),
+                              None if in_slope is None else float(in_slope), bool(defer))
 
 
 # --------------------------------------------------------------------------------------------

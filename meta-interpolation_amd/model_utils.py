@@ -12,6 +12,7 @@ loop and layers receive a ``ParamView`` = (flat dict, name prefix); descending a
 concatenation and a leaf lookup is a single dict access.  Plain (possibly nested) dicts are still
 accepted anywhere a ParamView is, so the reference's call pattern ``module(x, params=subdict)`` works.
 """
+import os
 import threading
 
 import torch
@@ -154,6 +155,15 @@ def set_fuse_conv_act(value):
     _TLS.fuse_conv_act = bool(value)
 
 
+_FUSE_CONV_CHAIN = os.environ.get('SAVFI_NO_CONV_CHAIN') is None
+
+
+def fuse_conv_chain():
+    """conv -> act -> conv inside a MetaSequential: the consumer folds the producer's activation derivative into its data gradient
+    (hip_ops.conv_bias_act `defer` / `in_slope`).  SAVFI_NO_CONV_CHAIN=1 keeps every layer's own element-wise pass (A/B runs)."""
+    return _FUSE_CONV_CHAIN
+
+
 def own_params_const():
     return getattr(_TLS, 'own_params_const', False)
 
@@ -187,11 +197,20 @@ class MetaConv2dLayer(nn.Module):
         nn.init.xavier_uniform_(self.weight)
         self.bias = nn.Parameter(torch.zeros(out_channels)) if use_bias else None
 
-    def forward(self, x, params=None, act_slope=None, padding=None, reflect=False):
+    def forward(self, x, params=None, act_slope=None, padding=None, reflect=False, in_slope=None, chain=None):
         """`act_slope` (set by MetaSequential when an activation follows) applies LeakyReLU(act_slope);
         `padding` overrides the layer's own zero padding (windowed evaluation, sepconv/model.py); `reflect`: that padding mirrors
-        the image (MetaConvNorm; the caller has checked hip_ops.convk_reflect_eligible)."""
+        the image (MetaConvNorm; the caller has checked hip_ops.convk_reflect_eligible).
+        conv -> act -> conv chains (MetaSequential): `chain` = {'want_defer': True} asks this layer to leave its activation derivative
+        to its single consumer -- honoured on the fused paths only, which then set chain['deferred'] --; `in_slope` = x is the
+        activated output of a producer that did: its derivative is folded into this layer's data gradient."""
         padding = self.padding if padding is None else padding
+        want_defer = bool(chain and chain.get('want_defer')) and act_slope is not None and not reflect
+
+        def fused(fn, *a):
+            if want_defer:
+                chain['deferred'] = True
+            return fn(*a, in_slope=in_slope, defer=want_defer)
         if params is not None:
             pv = as_view(params)
             weight = pv.leaf("weight")
@@ -206,9 +225,11 @@ class MetaConv2dLayer(nn.Module):
             if x.is_cuda and fuse_conv_act() and self.groups == 1 and (
                     act_slope is not None or bias is None or hip_ops.conv3x3_tasks_eligible(x, weight, self.stride, padding, self.dilation_rate)
                     or hip_ops.convk_eligible(x, weight, self.stride, padding, self.dilation_rate, 1, direct)):
-                return hip_ops.conv_bias_act_tasks(x, weight, bias, self.stride, padding, self.dilation_rate,
-                                                   1.0 if act_slope is None else act_slope, direct)
+                return fused(hip_ops.conv_bias_act_tasks, x, weight, bias, self.stride, padding, self.dilation_rate,
+                             1.0 if act_slope is None else act_slope, direct)
             assert self.groups == 1, "lockstep tasks on a grouped convolution"
+            if in_slope is not None:
+                x = hip_ops.mask_grad(x, in_slope)
             out = hip_ops.conv2d_tasks(x, weight, bias, self.stride, padding, self.dilation_rate)
             if act_slope is not None:
                 out = F.relu(out) if act_slope == 0.0 else F.leaky_relu(out, act_slope)
@@ -216,16 +237,18 @@ class MetaConv2dLayer(nn.Module):
         if x.is_cuda and fuse_conv_act():
             own = self._filters if params is None else None     # own parameter: packed filters cached per weight version, here
             if hip_ops.convk_eligible(x, weight, self.stride, padding, self.dilation_rate, self.groups, direct):
-                return hip_ops.conv_bias_act(x, weight, bias, self.stride, padding, self.dilation_rate, self.groups,
-                                             1.0 if act_slope is None else act_slope, direct, own, reflect)
+                return fused(hip_ops.conv_bias_act, x, weight, bias, self.stride, padding, self.dilation_rate, self.groups,
+                             1.0 if act_slope is None else act_slope, direct, own, reflect)
             assert not reflect, "mirrored borders are a direct-kernel path (hip_ops.convk_reflect_eligible)"
             if bias is not None and act_slope is not None:
-                return hip_ops.conv_bias_act(x, weight, bias, self.stride, padding, self.dilation_rate, self.groups,
-                                             act_slope, direct, own)
+                return fused(hip_ops.conv_bias_act, x, weight, bias, self.stride, padding, self.dilation_rate, self.groups,
+                             act_slope, direct, own)
             if bias is not None and hip_ops.conv3x3_eligible(x, weight, self.stride, padding, self.dilation_rate, self.groups):
                 # no activation follows: still worth the savfi kernel (bias in its epilogue) for large maps
-                return hip_ops.conv_bias_act(x, weight, bias, self.stride, padding, self.dilation_rate, self.groups, 1.0, direct, own)
+                return fused(hip_ops.conv_bias_act, x, weight, bias, self.stride, padding, self.dilation_rate, self.groups, 1.0, direct, own)
         assert not reflect, "mirrored borders are a direct-kernel path (hip_ops.convk_reflect_eligible)"
+        if in_slope is not None:            # not a fused path: the deferred derivative as an identity node on the input
+            x = hip_ops.mask_grad(x, in_slope)
         out = F.conv2d(x, weight, bias, self.stride, padding, self.dilation_rate, self.groups)
         if act_slope is not None:
             out = F.relu(out) if act_slope == 0.0 else F.leaky_relu(out, act_slope)
@@ -273,18 +296,34 @@ class MetaSequential(nn.Sequential):
         pv = as_view(params)
         mods = list(self)
         ind = 0
+        in_slope = None                 # the previous conv left its activation derivative to the next one (see below)
         while ind < len(mods):
             module = mods[ind]
-            kw = {}
+            kw, step = {}, 1
             if isinstance(module, (MetaConv2dLayer, MetaConvNorm)) and ind + 1 < len(mods):
                 slope = _act_slope(mods[ind + 1])
                 if slope is not None:          # conv + activation pair: one fused call, skip the activation module
                     kw["act_slope"] = slope
+                    step = 2
+            chain = None
+            if isinstance(module, MetaConv2dLayer):
+                if in_slope is not None:
+                    kw["in_slope"] = in_slope
+                # conv -> act -> conv: the intermediate map has exactly one consumer (the next conv of this Sequential), which can fold
+                # this layer's activation derivative into its data gradient -- first-order GPU passes only
+                if "act_slope" in kw and ind + 2 < len(mods) and isinstance(mods[ind + 2], MetaConv2dLayer) and input.is_cuda \
+                        and fuse_conv_chain() and fuse_conv_act() and not hip_ops.double_backward() and torch.is_grad_enabled():
+                    chain = {"want_defer": True}
+                    kw["chain"] = chain
+            else:
+                assert in_slope is None
             if pv is not None and isinstance(module, _META_TYPES):
                 input = module(input, params=pv.sub(ind), **kw)
             else:
                 input = module(input, **kw)
-            ind += 2 if kw else 1
+            in_slope = kw["act_slope"] if (chain is not None and chain.get("deferred")) else None
+            ind += step
+        assert in_slope is None
         return input
 
     def restore_backup_stats(self):

@@ -296,6 +296,51 @@ def test_meta_sequential_fuses_conv_relu_pairs_and_matches_reference_modules():
         assert _rel(a, b) < 2e-5
 
 
+@pytest.mark.parametrize("case", ["wino_relu", "convk_relu", "wino_leaky", "tasks_wino", "tasks_convk", "small_maps_miopen"])
+def test_conv_chain_folds_the_activation_derivative_into_the_consumer(case, monkeypatch):
+    """conv -> act -> conv -> act -> conv in a MetaSequential: with the chain fusion the consumer's data-gradient kernel applies the
+    producer's (leaky) ReLU derivative in its epilogue (savfi_conv3x3_dgrad_masked_f32 / savfi_convk_dgrad_masked_f32) and the producer
+    only sums its bias gradient -- the same multiplications, so the gradients of the input and of every weight / bias equal the unchained
+    run (SAVFI_NO_CONV_CHAIN) bit for bit; and an element-wise bias_act_bwd launch disappears per chain link."""
+    from meta_interpolation_amd import model_utils as mu
+    torch.manual_seed(3)
+    C, H, W, T, act = {"wino_relu": (32, 64, 96, 0, torch.nn.ReLU()), "convk_relu": (64, 48, 64, 0, torch.nn.ReLU()),
+                       "wino_leaky": (32, 40, 56, 0, torch.nn.LeakyReLU(0.2)), "tasks_wino": (32, 48, 64, 4, torch.nn.ReLU()),
+                       "tasks_convk": (64, 32, 48, 4, torch.nn.ReLU()), "small_maps_miopen": (16, 3, 5, 0, torch.nn.ReLU())}[case]
+    seq = mu.MetaSequential(mu.MetaConv2dLayer(C, C, 3, 1, 1), act, mu.MetaConv2dLayer(C, C, 3, 1, 1), act,
+                            mu.MetaConv2dLayer(C, C, 3, 1, 1), act).to(DEV)
+    N = 2 * max(T, 1)
+    x0 = torch.randn(N, C, H, W, device=DEV)
+    if T:
+        fast0 = {n: torch.randn((T,) + tuple(p.shape), device=DEV).mul(0.3 / C ** 0.5) for n, p in seq.named_parameters()}
+    else:
+        fast0 = {n: torch.randn_like(p).mul(0.3 / C ** 0.5) for n, p in seq.named_parameters()}
+    results, launches = {}, {}
+    for chained in (True, False):
+        monkeypatch.setattr(mu, '_FUSE_CONV_CHAIN', chained)
+        x = x0.clone().requires_grad_()
+        fast = {n: v.clone().requires_grad_() for n, v in fast0.items()}
+        count = []
+        orig = _hip.launch
+        monkeypatch.setattr(_hip, 'launch', lambda name, fn, **k: (count.append(name), orig(name, fn, **k))[1])
+        mu.set_fuse_conv_act(True)
+        try:
+            y = seq(x, params=fast)
+            grads = torch.autograd.grad(y.square().mean(), [x] + list(fast.values()))
+        finally:
+            mu.set_fuse_conv_act(False)
+            monkeypatch.setattr(_hip, 'launch', orig)
+        results[chained] = [y.detach()] + [g.detach() for g in grads]
+        launches[chained] = count
+    for a, b in zip(results[True], results[False]):
+        assert torch.equal(a, b), (case, (a - b).abs().max().item())
+    # the element-wise derivative pass of the two inner links is gone (the bias-gradient sums stay)
+    n_conv = lambda names: sum(1 for n in names if 'bwd_data' in n)
+    assert n_conv(launches[True]) == n_conv(launches[False])
+    if case != "small_maps_miopen":
+        assert n_conv(launches[True]) == 3
+
+
 @pytest.mark.parametrize("align", [True, False])
 @pytest.mark.parametrize("shape", [(1, 51, 192, 256), (2, 7, 5, 9), (1, 3, 1, 1), (1, 64, 12, 16), (2, 4, 33, 17)])
 def test_upsample2x_matches_aten(align, shape):
