@@ -331,7 +331,9 @@ int savfi_convk_filters_multi_f32(const float* const* w, float* const* p_fwd, fl
                                   const int* Co, const int* K, int n, void* stream);
 int savfi_convk_tasks_pre_f32(const float* x, const float* packed, const float* bias, float* out, int N, int T, int Ci,
                               int Co, int H, int W, int K, int pad, int mode, float slope, int precise, void* stream);
-/* the same fold for the direct kernels: gx = savfi_convk_tasks_pre_f32(mode 1)(gy) * (mask > 0 ? 1 : mask_slope) */
+/* the same fold for the direct kernels: gx = savfi_convk_tasks_pre_f32(mode 1)(gy) * (mask > 0 ? 1 : mask_slope).  K = 3 and
+ * precise = 0 only (the layers of the conv -> act -> conv chains); SAVFI_E_UNSUPPORTED otherwise: the caller masks the plain data
+ * gradient itself (savfi_bias_act_bwd_f32 without bias), as hip_ops.convk_tasks_pre does. */
 int savfi_convk_dgrad_masked_f32(const float* gy, const float* packed, const float* mask, float mask_slope, float* gx, int N, int T,
                                  int Ci, int Co, int H, int W, int K, int pad, int precise, void* stream);
 /* `reflect` != 0 (mode 0 only, pad < H, W): the border of width `pad` mirrors the image instead of reading zeros, i.e.

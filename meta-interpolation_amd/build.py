@@ -55,11 +55,36 @@ def build_library(force=False, verbose=True):
         with open(STAMP) as fh:
             if fh.read().strip() == fp:
                 return LIB_PATH
-    cmd = [find_hipcc()] + HIPCC_FLAGS + ["-I", os.path.join(REPO_DIR, "include"), "-I", CSRC]
-    cmd += _sources() + ["-o", LIB_PATH]
+    # one object per translation unit, compiled in parallel and cached by content (a scratch directory outside the tree: only the linked
+    # library travels with the snapshot), then one link
+    hipcc = find_hipcc()
+    cflags = [f for f in HIPCC_FLAGS if f != "-shared"] + ["-I", os.path.join(REPO_DIR, "include"), "-I", CSRC]
+    cache = os.environ.get("SAVFI_BUILD_CACHE", "/tmp/savfi_build_cache")
+    os.makedirs(cache, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")] + [os.path.join(REPO_DIR, "include", "savfi_hip.h")]
+    hh = hashlib.sha256()
+    for f in headers:
+        with open(f, "rb") as fh:
+            hh.update(fh.read())
+    hh.update(" ".join(cflags).encode())
+
+    def compile_unit(src):
+        h = hh.copy()
+        with open(src, "rb") as fh:
+            h.update(fh.read())
+        obj = os.path.join(cache, os.path.basename(src)[:-4] + "." + h.hexdigest()[:16] + ".o")
+        if not os.path.exists(obj):
+            tmp = obj + ".tmp%d" % os.getpid()
+            subprocess.run([hipcc] + cflags + ["-c", src, "-o", tmp], check=True)
+            os.replace(tmp, obj)
+        return obj
+
     if verbose:
-        print("[savfi build]", " ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True)
+        print("[savfi build]", hipcc, " ".join(cflags), "-c <%d units> (cache %s)" % (len(_sources()), cache), flush=True)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=max(1, min(len(_sources()), (os.cpu_count() or 4)))) as pool:
+        objs = list(pool.map(compile_unit, _sources()))
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc"] + objs + ["-o", LIB_PATH], check=True)
     with open(STAMP, "w") as fh:
         fh.write(fp + "\n")
     return LIB_PATH

@@ -192,7 +192,10 @@ struct ConvkGeom {
 // is paid in matrix-pipe time, PMC: 65 % MFMA + 26 % VALU busy -- half of that at CG = 2), and with one workgroup per CU there is
 // room for TWO input buffers: the next chunk is split and written to the other buffer in the middle of this chunk's MFMAs
 // (one barrier per chunk, no staging bubble).
-template <int KS, int QC, int NT, int TW, bool P2, int CG>
+// MASK: the data gradient's epilogue multiplies by the producer's activation derivative (a.mask).  A template parameter, not a run-time
+// branch: with the mask loads behind `if (a.mask)` between the epilogue's stores every variant of the kernel -- the forward included --
+// lost 6-16 % (64 -> 64 @ 137 x 233: 116 -> 135 us; vmcnt counts loads and stores in one in-order counter, csrc/winograd.hip).
+template <int KS, int QC, int NT, int TW, bool P2, int CG, bool MASK>
 __global__ __launch_bounds__(CK_THREADS * CG, 2) void convk_kernel(const ConvkArgs a) {
   using G = ConvkGeom<KS, QC, NT, TW>;
   constexpr int THREADS = CK_THREADS * CG, IPT = G::ipt(THREADS);
@@ -399,7 +402,7 @@ __global__ __launch_bounds__(CK_THREADS * CG, 2) void convk_kernel(const ConvkAr
       const size_t oidx = (size_t)co * plane_out + (size_t)oy * a.Wo + ox;
       float* dst = outn + oidx;
       if (vec_ok && ox + 3 < a.Wo) {
-        if (a.mask) {
+        if (MASK) {
           const f32x4 m = *reinterpret_cast<const f32x4*>(a.mask + (size_t)n * a.cout * plane_out + oidx);
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = m[r] > 0.f ? v[r] : v[r] * a.mask_slope;
@@ -410,7 +413,7 @@ __global__ __launch_bounds__(CK_THREADS * CG, 2) void convk_kernel(const ConvkAr
         for (int r = 0; r < 4; ++r)
           if (ox + r < a.Wo) {
             float u = v[r];
-            if (a.mask) u = a.mask[(size_t)n * a.cout * plane_out + oidx + r] > 0.f ? u : u * a.mask_slope;
+            if (MASK) u = a.mask[(size_t)n * a.cout * plane_out + oidx + r] > 0.f ? u : u * a.mask_slope;
             dst[r] = u;
           }
       }
@@ -418,11 +421,17 @@ __global__ __launch_bounds__(CK_THREADS * CG, 2) void convk_kernel(const ConvkAr
   }
 }
 
-template <int KS, int QC, int NT, int TW, bool P2, int CG>
+template <int KS, int QC, int NT, int TW, bool P2, int CG, bool MASK = false>
 int launch_convk_cg(const ConvkArgs& a, hipStream_t stream) {
   using G = ConvkGeom<KS, QC, NT, TW>;
+  if constexpr (!MASK) {
+    if (a.mask) {           // masked epilogue: the 3 x 3 kernels of the conv -> act -> conv chains only (hip_ops masks the others itself)
+      if constexpr (KS == 3 && !P2) return launch_convk_cg<KS, QC, NT, TW, P2, CG, true>(a, stream);
+      else return SAVFI_E_UNSUPPORTED;
+    }
+  }
   static uint32_t configured = 0;
-  auto kern = convk_kernel<KS, QC, NT, TW, P2, CG>;
+  auto kern = convk_kernel<KS, QC, NT, TW, P2, CG, MASK>;
   constexpr int lds = G::LDS * CG;          // CG = 2: two input buffers
   static_assert(lds <= 160 * 1024, "input tile buffers exceed the LDS of a CU");
   if (lds > 64 * 1024) {

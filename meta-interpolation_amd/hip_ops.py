@@ -1277,6 +1277,9 @@ def convk_tasks_pre(x, packed, T, Ci, Co, K, bias=None, mode=0, slope=1.0, pad=1
     p_eff = pad if mode == 0 else K - 1 - pad
     out = torch.empty((N, I, H + 2 * p_eff - K + 1, W + 2 * p_eff - K + 1), dtype=x.dtype, device=x.device)
     lib = _hip.lib()
+    if mask is not None and (K != 3 or precise):
+        # the masked epilogue exists for the 3 x 3 kernels of the conv chains; the same multiplication as a separate pass elsewhere
+        return mask_by_activation(convk_tasks_pre(x, packed, T, Ci, Co, K, bias, mode, slope, pad, precise, reflect), mask, mask_slope)
     if mask is not None:
         assert mode == 1 and bias is None and slope == 1.0 and not reflect
         mask = mask.contiguous()
