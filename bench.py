@@ -358,14 +358,14 @@ def main():
                         break
                 per_call = 4.0 * (3 * (oh + 50) * (ow + 50) + 4 * 51 * oh * ow + 3 * oh * ow)
                 line["roofline"] = {
-                    "bound": "hbm", "kernel": "sepconv_bwd_x6 (gV+gH, K=51; csrc/sepconv_x6.hip, split-bf16 MFMAs)",
+                    "bound": "hbm", "kernel": "sepconv_bwd_ws (gV+gH, K=51; csrc/sepconv_ws.hip: split-bf16 MFMAs, MFMA waves + staging waves in pairs)",
                     "achieved": k["achieved_GBps"], "peak": 8000.0, "unit": "GB/s",
                     "frac": k["achieved_GBps"] / 8000.0, "traffic": traffic, "traffic_source": tnote,
                     "avg_us_per_launch": k["avg_us"], "launches": k["launches"],
                     "algorithmic_bytes_per_launch": k["algorithmic_bytes"] / k["launches"],
                     "note": "algorithmic bytes = %.2f MB per [1,3,%d,%d] sample (x samples per launch: tasks in lockstep x the "
-                            "support pair); 288 bf16 MFMAs per 16 pixels = ~40%% of the launch at full matrix rate (PMC: matrix pipe 39%% busy), the rest is per-phase tap staging, "
-                            "stores and window barriers with 8 waves per CU (DESIGN.md 4e)"
+                            "support pair); 264 bf16 MFMAs per 16 pixels = 46%% of the launch at the measured 19 ticks per MFMA; the MFMA wave's cotangent scaling and tile "
+                            "writes (a third of its cycles) and the staging waves' tap splits share the SIMD's VALU port (DESIGN.md 4f, profiles/r04_ws_experiments.txt)"
                             % (per_call / 1e6, oh, ow)}
             elif summ:
                 # workloads without the 51-tap op: the HBM-bound savfi kernel that takes the most time in the timed region
