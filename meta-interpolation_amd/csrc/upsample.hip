@@ -38,11 +38,14 @@ __device__ __forceinline__ float scale_of(int in, int out, int align) {
 // sub-networks, whose 51-tap maps are only consumed on the un-padded frame area (sepconv/model.py).
 struct Win { int H, W, sy0, sx0, Hs, Ws, oy0, ox0, Hw, Ww, align; };
 
-// Forward, tiled (round 3): a workgroup owns 8 output rows x 128 output columns.  The <= 6 x 68 source pixels the tile reads are
-// staged in LDS with coalesced loads (2 per thread) and every output takes its four taps from there: the first version issued 16
-// global loads per thread (4 per output; L1 hits, but the address path was the limit: 2.0 TB/s on the 51-channel sub-network maps).
-// Same source indices, weights and order of operations per output: bit-identical results.
-constexpr int UFH = 8, UFW = 128, UFSR = UFH / 2 + 3, UFSC = UFW / 2 + 4;      // tile, staged source rows / columns
+// Forward, tiled (round 3; re-tiled in round 4): a workgroup owns 32 output rows x 128 output columns, a thread 4 columns of rows
+// ly, ly + 8, ly + 16, ly + 24.  The <= 19 x 68 source pixels the tile reads are staged in LDS with coalesced loads and every output
+// takes its four taps from there (the first version issued 16 global loads per thread; L1 hits, but the address path was the limit).
+// Round 4: the 8-row tiles of round 3 spent most of their instructions on per-thread bookkeeping -- a run-time integer division
+// per staged element, four source() evaluations in x and one in y per FOUR outputs -- at 2.3 TB/s on the 51-channel sub-network maps;
+// here the staging index splits by a constant, the x sources are evaluated once per thread and serve four rows.
+// Same source indices, weights and order of operations per output as every earlier version: bit-identical results.
+constexpr int UFH = 32, UFW = 128, UFSR = UFH / 2 + 3, UFSC = UFW / 2 + 4;      // tile, staged source rows / columns
 __global__ __launch_bounds__(256) void upsample2x_fwd(const float* __restrict__ in, float* __restrict__ out, Win g) {
   __shared__ float src[UFSR][UFSC];
   const int Ho = 2 * g.H, Wo = 2 * g.W;
@@ -56,27 +59,39 @@ __global__ __launch_bounds__(256) void upsample2x_fwd(const float* __restrict__ 
   const int ry0 = source(g.oy0 + wy0, g.H, sh, g.align).i0, ry1 = source(g.oy0 + last_y, g.H, sh, g.align).i1;
   const int rx0 = source(g.ox0 + wx0, g.W, sw, g.align).i0, rx1 = source(g.ox0 + last_x, g.W, sw, g.align).i1;
   const int nr = ry1 - ry0 + 1, nc = rx1 - rx0 + 1;             // <= UFSR, <= UFSC (scale <= 0.5)
-  for (int i = threadIdx.x; i < nr * nc; i += 256) {
-    const int r = i / nc, c = i - r * nc;
-    src[r][c] = p[(size_t)(ry0 + r - g.sy0) * g.Ws + (rx0 + c - g.sx0)];
+  const float* pw = p + (size_t)(ry0 - g.sy0) * g.Ws + (rx0 - g.sx0);
+#pragma unroll
+  for (int k = 0; k < (UFSR * UFSC + 255) / 256; ++k) {
+    const int i = threadIdx.x + 256 * k, r = i / UFSC, c = i - r * UFSC;       // constant divisor
+    if (r < nr && c < nc) src[r][c] = pw[(size_t)r * g.Ws + c];
   }
   __syncthreads();
-  const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;        // 32 groups of 4 outputs per row, 8 rows
-  const int wy = wy0 + ly, wx = wx0 + 4 * lx;
-  if (wy >= g.Hw || wx >= g.Ww) return;
-  const Src sy = source(g.oy0 + wy, g.H, sh, g.align);
-  const float* r0 = &src[sy.i0 - ry0][0] - rx0;
-  const float* r1 = &src[sy.i1 - ry0][0] - rx0;
-  float v[4];
+  const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;        // 32 groups of 4 outputs per row, rows ly + 8 k
+  const int wx = wx0 + 4 * lx;
+  if (wx >= g.Ww) return;
+  int xi0[4], xi1[4];
+  float xl0[4], xl1[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const Src sx = source(min(g.ox0 + wx + k, g.ox0 + g.Ww - 1), g.W, sw, g.align);
-    v[k] = sy.l0 * (sx.l0 * r0[sx.i0] + sx.l1 * r0[sx.i1]) + sy.l1 * (sx.l0 * r1[sx.i0] + sx.l1 * r1[sx.i1]);
+    xi0[k] = sx.i0 - rx0; xi1[k] = sx.i1 - rx0; xl0[k] = sx.l0; xl1[k] = sx.l1;
   }
-  float* o = out + ((size_t)blockIdx.y * g.Hw + wy) * g.Ww + wx;
-  if (wx + 3 < g.Ww && ((((uintptr_t)o) & 15u) == 0)) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-  else
-    for (int k = 0; k < 4 && wx + k < g.Ww; ++k) o[k] = v[k];
+#pragma unroll
+  for (int rr = 0; rr < UFH / 8; ++rr) {
+    const int wy = wy0 + ly + 8 * rr;
+    if (wy >= g.Hw) break;
+    const Src sy = source(g.oy0 + wy, g.H, sh, g.align);
+    const float* r0 = &src[sy.i0 - ry0][0];
+    const float* r1 = &src[sy.i1 - ry0][0];
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      v[k] = sy.l0 * (xl0[k] * r0[xi0[k]] + xl1[k] * r0[xi1[k]]) + sy.l1 * (xl0[k] * r1[xi0[k]] + xl1[k] * r1[xi1[k]]);
+    float* o = out + ((size_t)blockIdx.y * g.Hw + wy) * g.Ww + wx;
+    if (wx + 3 < g.Ww && ((((uintptr_t)o) & 15u) == 0)) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+    else
+      for (int k = 0; k < 4 && wx + k < g.Ww; ++k) o[k] = v[k];
+  }
 }
 
 __global__ __launch_bounds__(256) void upsample2x_bwd(const float* __restrict__ gout, float* __restrict__ gin, Win g) {
@@ -123,7 +138,10 @@ __global__ __launch_bounds__(256) void upsample2x_bwd(const float* __restrict__ 
 // direction -- tmp[oy][ix] = sum over the <= 6 candidate columns of wx * gout[oy][ox] -- for the <= 20 output rows the tile's
 // rows can touch, into LDS; pass 2 folds y from LDS.  Same candidates, same weights, same order of the two nested sums as
 // upsample2x_bwd (bit-identical results), but 15 global loads per source pixel instead of 36 and the x weights once per thread.
-constexpr int UBH = 8, UBW = 64, UBR = 2 * UBH + 4;     // tile rows / cols, output rows a tile can touch
+#ifndef SAVFI_UBH
+#define SAVFI_UBH 8
+#endif
+constexpr int UBH = SAVFI_UBH, UBW = 64, UBR = 2 * UBH + 4;     // tile rows / cols, output rows a tile can touch (16- and 32-row tiles measured slower: LDS per workgroup, profiles/r04_upsample_bench.txt)
 constexpr int UBC = 2 * UBW + 4;                        // output columns a tile can touch (2 ix - 2 .. 2 ix + 3)
 __global__ __launch_bounds__(256) void upsample2x_bwd_tiled(const float* __restrict__ gout, float* __restrict__ gin, Win g) {
   // round 3: the output-gradient tile itself is staged first (coalesced, each element once: 10.6 loads per thread where the x
@@ -145,9 +163,13 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_tiled(const float* __restr
   const int row_lo = max(g.oy0, 2 * iy0 - 2), row_hi = min(g.oy0 + g.Hw - 1, 2 * (iy0 + UBH - 1) + 3);
   const int col_lo = max(g.ox0, 2 * ix_first - 2), col_hi = min(g.ox0 + g.Ww - 1, 2 * ix_last + 3);
   const int ncol = col_hi - col_lo + 1, nrow = row_hi - row_lo + 1;
-  for (int i = threadIdx.x; i < nrow * ncol; i += 256) {
-    const int r = i / ncol, c = i - r * ncol;
-    gt[r][c] = gp[(size_t)(row_lo + r - g.oy0) * g.Ww + (col_lo + c - g.ox0)];
+  {
+    const float* gw = gp + (size_t)(row_lo - g.oy0) * g.Ww + (col_lo - g.ox0);
+#pragma unroll
+    for (int k = 0; k < (UBR * UBC + 255) / 256; ++k) {
+      const int i = threadIdx.x + 256 * k, r = i / UBC, c = i - r * UBC;         // constant divisor (round 4: was a run-time division)
+      if (r < nrow && c < ncol) gt[r][c] = gw[(size_t)r * g.Ww + c];
+    }
   }
   const int ox_lo = max(g.ox0, 2 * ix - 2), ox_hi = min(g.ox0 + g.Ww - 1, 2 * ix + 3);
   float wxs[NC];

@@ -36,7 +36,9 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" is RCCL on ROCm
+            # SAVFI_DIST_BACKEND=gloo: the multi-rank GPU path on a box with fewer GPUs than ranks (ranks share device
+            # local_rank % device_count; RCCL refuses two ranks on one device, gloo stages CUDA tensors through the host)
+            backend = os.environ.get("SAVFI_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")   # "nccl" is RCCL on ROCm
         kwargs = {}
         if backend == "nccl":
             kwargs["device_id"] = torch.device("cuda", torch.cuda.current_device())
