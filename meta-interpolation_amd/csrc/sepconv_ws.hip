@@ -290,6 +290,9 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
       unsigned long long tr_[16] = {0}, tlast_ = __builtin_readcyclecounter();
       bf16x8 bq[2][3], aq[2][2][3];
       int rowoff[4], rowh[2][2];
+      // the same offsets + 6 planes: a DS instruction's immediate offset is 16 bits and the window is 103 KB -- reads of the third bf16 piece
+      // (planes 6..8) through the low bases took a v_add each, inside the MFMA loops (4 per gH block, 2 per gV block)
+      int rowoff_hi[4], rowh_hi[2][2];
       auto peek_raw = [&](int idx) { return __hip_atomic_load(fl + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
       auto set_rows = [&](int y) {
         // (recomputed from the lane id each time: hoisted out of the unit loop these per-lane constants are spilled to scratch at the
@@ -306,6 +309,12 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
 #pragma unroll
           for (int hf = 0; hf < 2; ++hf)
             rowh[st][hf] = ((y + 32 * st + 16 * hf + 4 * ko + (Lo >> 2)) & (XWIN - 1)) * 16 + (2 * wc + ((Lo & 3) >> 1)) * XBLK + (Lo & 1) * 8;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { rowoff_hi[m] = rowoff[m] + 6 * XPLANE; asm volatile("" : "+v"(rowoff_hi[m])); }
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) { rowh_hi[st][hf] = rowh[st][hf] + 6 * XPLANE; asm volatile("" : "+v"(rowh_hi[st][hf])); }
       };
       // gV blocks (12 MFMAs each: two tiles x six products).  Tap rows 0..47 of a channel are three tiles of 16; rows 48..50 of the
       // THREE channels share one more tile (a lane's A row is any window row of any channel), so 51 rows x 3 channels cost 10 tiles
@@ -320,7 +329,10 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
           const int ai = gv_acc(uu, t), c = ai == 9 ? 0 : ai / 3, m = ai == 9 ? 3 : ai % 3;
 #pragma unroll
           for (int pc = 0; pc < 3; ++pc)
-            aq[slot][t][pc] = *reinterpret_cast<const bf16x8*>(smem + (pc * 3 + c) * XPLANE + 4 * st * XBLK + rowoff[m]);
+          {
+            const int plane = pc * 3 + c;
+            aq[slot][t][pc] = *reinterpret_cast<const bf16x8*>(smem + (plane >= 6 ? plane - 6 : plane) * XPLANE + 4 * st * XBLK + (plane >= 6 ? rowoff_hi[m] : rowoff[m]));
+          }
         }
       };
       auto load_ah = [&](int slot, int uu) {           // gH: two transpose reads per fragment
@@ -329,8 +341,9 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
         for (int t = 0; t < 2; ++t)
 #pragma unroll
           for (int pc = 0; pc < 3; ++pc) {
-            const int base = (pc * 3 + c) * XPLANE + 2 * (2 * mp + t) * XBLK;
-            const bf16x4 lo = tr_read(base + rowh[st][0]), hi = tr_read(base + rowh[st][1]);
+            const int plane = pc * 3 + c;
+            const int base = (plane >= 6 ? plane - 6 : plane) * XPLANE + 2 * (2 * mp + t) * XBLK;
+            const bf16x4 lo = tr_read(base + (plane >= 6 ? rowh_hi[st][0] : rowh[st][0])), hi = tr_read(base + (plane >= 6 ? rowh_hi[st][1] : rowh[st][1]));
             aq[slot][t][pc] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
           }
       };
@@ -834,7 +847,7 @@ __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ 
       // =========================================== MFMA wave ===================================================================
       __builtin_amdgcn_s_setprio(WS_PRIO);
       bf16x8 bq[2][3], aq[2][2][3];
-      int rowoff[4];
+      int rowoff[4], rowoff_hi[4];                   // + 6 planes: the third bf16 piece within a DS immediate offset (see sepconv_bwd_ws)
       auto peek_raw = [&](int idx) { return __hip_atomic_load(fl + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
       auto set_rows = [&](int y) {
         const int lo_ = ws_lane(), jo = lo_ & 15, ko = lo_ >> 4;
@@ -842,6 +855,8 @@ __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ 
 #pragma unroll
         for (int m = 0; m < 3; ++m) rowoff[m] = ((y + 16 * m + jo) & (XWIN - 1)) * 16 + (2 * wc + pk) * XBLK;
         rowoff[3] = ((y + 48 + min(jo & 3, 2)) & (XWIN - 1)) * 16 + (2 * wc + pk) * XBLK + min(jo >> 2, 2) * XPLANE;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { rowoff_hi[m] = rowoff[m] + 6 * XPLANE; asm volatile("" : "+v"(rowoff_hi[m])); }
       };
       auto gv_acc = [](int uu, int t) { return uu < 6 ? 3 * (uu >> 1) + t : uu < 8 ? 3 * t + 2 : (t == 0 ? 8 : 9); };
       auto load_av = [&](int slot, int uu) {
@@ -851,7 +866,10 @@ __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ 
           const int ai = gv_acc(uu, t), c = ai == 9 ? 0 : ai / 3, m = ai == 9 ? 3 : ai % 3;
 #pragma unroll
           for (int pc = 0; pc < 3; ++pc)
-            aq[slot][t][pc] = *reinterpret_cast<const bf16x8*>(smem + (pc * 3 + c) * XPLANE + 4 * st * XBLK + rowoff[m]);
+          {
+            const int plane = pc * 3 + c;
+            aq[slot][t][pc] = *reinterpret_cast<const bf16x8*>(smem + (plane >= 6 ? plane - 6 : plane) * XPLANE + 4 * st * XBLK + (plane >= 6 ? rowoff_hi[m] : rowoff[m]));
+          }
         }
       };
       auto read_bh = [&]() {
