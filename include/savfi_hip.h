@@ -56,7 +56,7 @@
 extern "C" {
 #endif
 
-#define SAVFI_ABI_VERSION 11
+#define SAVFI_ABI_VERSION 12
 
 #define SAVFI_OK            0
 #define SAVFI_E_NULL       (-1)  /* a required pointer is NULL                          */
@@ -83,6 +83,17 @@ int savfi_sepconv_fwd_f32(const float* in, const float* v, const float* h, float
 int savfi_sepconv_bwd_f32(const float* in, const float* v, const float* h, const float* gO,
                           float* gI, float* gV, float* gH,
                           int B, int C, int Ho, int Wo, int K, void* stream);
+
+/* The same op on tap tensors that are slices of ONE interleaved buffer: sample b of v / h (and of gV / gH) starts tap_bstride planes of
+ * Ho * Wo floats after sample b - 1 (tap_bstride = K: the contiguous layout of the two entry points above).  The package's SepConv plugin
+ * evaluates the reference's four Subnets (sepconv/model.py:183-194, :239-242, :346-347) as one task-batched launch per layer; their taps are
+ * a [B * 4, K, Ho, Wo] tensor (sample 4 b + s = sub-network s) that the two local convolutions read -- and their filter gradients write --
+ * in place with tap_bstride = 4 * K.  K = 51, C = 3, Wo % 4 == 0, every tensor below 2^31 bytes; SAVFI_E_UNSUPPORTED otherwise (the
+ * caller copies the slices and uses the contiguous entry points).  No gI (frames carry no gradient on this path). */
+int savfi_sepconv_fwd_taps_strided_f32(const float* in, const float* v, const float* h, float* out, int B, int C, int Ho, int Wo, int K,
+                                       int tap_bstride, void* stream);
+int savfi_sepconv_bwd_taps_strided_f32(const float* in, const float* v, const float* h, const float* gO, float* gV, float* gH, int B,
+                                       int C, int Ho, int Wo, int K, int tap_bstride, void* stream);
 
 /* Diagnostic of the wave-specialised filter-gradient kernel (csrc/sepconv_ws.hip): number of bounded in-kernel waits that
  * gave up since the library was loaded on the current device.  0 on a healthy build; > 0 means a launch's numbers are wrong

@@ -1127,7 +1127,7 @@ extern "C" int savfi_sepconv_fwd_f32(const float* in, const float* v, const floa
   if (K == KFAST && C == 3 && !sepconv_env().no_mfma && !sepconv_env().tiled && !sepconv_env().f32_mfma && persistent_ok(B, Ho, Wo)) {
     // widths that are a multiple of 4: the wave-specialised kernel (csrc/sepconv_ws.hip); others: one program per wave (csrc/sepconv_x6.hip)
     if ((Wo & 3) == 0 && !sepconv_env().no_ws && !sepconv_env().no_ws_fwd)
-      return savfi_sepconv_fwd_ws_launch(in, v, h, out, B, Ho, Wo, device_cu_count(), st);
+      return savfi_sepconv_fwd_ws_launch(in, v, h, out, B, Ho, Wo, device_cu_count(), KFAST, st);
     return savfi_sepconv_fwd_x6_launch(in, v, h, out, B, Ho, Wo, device_cu_count(), st);
   }
   if (K == KFAST && C == 3 && !sepconv_env().no_mfma && mfma_fits(Ho, Wo)) {
@@ -1143,6 +1143,35 @@ extern "C" int savfi_sepconv_fwd_f32(const float* in, const float* v, const floa
   return savfi_launch_status();
 }
 
+// The same op on tap tensors that are SLICES of one interleaved buffer: sample b of v / h (gV / gH) starts tap_bstride planes (of Ho * Wo
+// floats) after sample b - 1 (51 = contiguous).  sepconv/model.py runs its four sub-networks as ONE task-batched launch per layer; their
+// outputs form a [B * 4, 51, Ho, Wo] tensor whose sample 4 b + s belongs to sub-network s, and the two local convolutions read (and their
+// gradients write) that buffer in place with tap_bstride = 4 * 51.  K = 51, C = 3, Wo % 4 == 0 (the wave-specialised kernels);
+// anything else: SAVFI_E_UNSUPPORTED (the caller copies the slices and uses the contiguous entry points).
+static int taps_strided_ok(int B, int C, int Ho, int Wo, int K, int tap_bstride) {
+  if (int e = check_dims(B, C, Ho, Wo, K)) return e;
+  if (tap_bstride < K) return SAVFI_E_SHAPE;
+  if (K != KFAST || C != 3 || (Wo & 3) != 0 || sepconv_env().no_mfma || sepconv_env().tiled || sepconv_env().f32_mfma || sepconv_env().no_ws)
+    return SAVFI_E_UNSUPPORTED;
+  const int64_t taps = ((int64_t)(B - 1) * tap_bstride + K) * Ho * Wo * 4;
+  if (taps >= ((int64_t)1 << 31) || !persistent_ok(B, Ho, Wo)) return SAVFI_E_UNSUPPORTED;
+  return SAVFI_OK;
+}
+
+extern "C" int savfi_sepconv_fwd_taps_strided_f32(const float* in, const float* v, const float* h, float* out, int B, int C, int Ho, int Wo,
+                                                  int K, int tap_bstride, void* stream) {
+  if (!in || !v || !h || !out) return SAVFI_E_NULL;
+  if (int e = taps_strided_ok(B, C, Ho, Wo, K, tap_bstride)) return e;
+  return savfi_sepconv_fwd_ws_launch(in, v, h, out, B, Ho, Wo, device_cu_count(), tap_bstride, (hipStream_t)stream);
+}
+
+extern "C" int savfi_sepconv_bwd_taps_strided_f32(const float* in, const float* v, const float* h, const float* gO, float* gV, float* gH,
+                                                  int B, int C, int Ho, int Wo, int K, int tap_bstride, void* stream) {
+  if (!in || !v || !h || !gO || !gV || !gH) return SAVFI_E_NULL;
+  if (int e = taps_strided_ok(B, C, Ho, Wo, K, tap_bstride)) return e;
+  return savfi_sepconv_bwd_ws_launch(in, v, h, gO, gV, gH, B, Ho, Wo, device_cu_count(), tap_bstride, (hipStream_t)stream);
+}
+
 extern "C" int savfi_sepconv_bwd_f32(const float* in, const float* v, const float* h, const float* gO,
                                      float* gI, float* gV, float* gH, int B, int C, int Ho, int Wo, int K,
                                      void* stream) {
@@ -1154,7 +1183,7 @@ extern "C" int savfi_sepconv_bwd_f32(const float* in, const float* v, const floa
         persistent_ok(B, Ho, Wo)) {
       // widths that are a multiple of 4: the wave-specialised kernel (csrc/sepconv_ws.hip); others: one program per wave (csrc/sepconv_x6.hip)
       if ((Wo & 3) == 0 && !sepconv_env().no_ws) {
-        if (int e = savfi_sepconv_bwd_ws_launch(in, v, h, gO, gV, gH, B, Ho, Wo, device_cu_count(), st)) return e;
+        if (int e = savfi_sepconv_bwd_ws_launch(in, v, h, gO, gV, gH, B, Ho, Wo, device_cu_count(), KFAST, st)) return e;
       } else if (int e = savfi_sepconv_bwd_x6_launch(in, v, h, gO, gV, gH, B, Ho, Wo, device_cu_count(), st)) return e;
     } else if (K == KFAST && C == 3 && !sepconv_env().no_mfma && !sepconv_env().tiled && persistent_ok(B, Ho, Wo)) {
       if (int e = launch_bwd_persistent(in, v, h, gO, gV, gH, B, Ho, Wo, st)) return e;

@@ -158,7 +158,7 @@ __device__ __forceinline__ int ws_lane() {
 __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ in, const float* __restrict__ v,
                                                       const float* __restrict__ h, const float* __restrict__ gO,
                                                       float* __restrict__ gV, float* __restrict__ gH,
-                                                      int B, int Ho, int Wo, int nph, int ncol, int per_wg) {
+                                                      int B, int Ho, int Wo, int nph, int ncol, int per_wg, int TB) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int p = w & 3, wc = p & 1, wr0 = p >> 1;
@@ -177,12 +177,12 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
   if (g0 >= g1) return;
   const int Hi = Ho + XK - 1, Wi = Wo + XK - 1;
   const unsigned plane_b = (unsigned)Ho * (unsigned)Wo * 4u;
-  const __amdgpu_buffer_rsrc_t hsrc = x6_rsrc(h, (unsigned)(B * XK) * plane_b);
-  const __amdgpu_buffer_rsrc_t vsrc = x6_rsrc(v, (unsigned)(B * XK) * plane_b);
+  const __amdgpu_buffer_rsrc_t hsrc = x6_rsrc(h, (unsigned)((B - 1) * TB + XK) * plane_b);
+  const __amdgpu_buffer_rsrc_t vsrc = x6_rsrc(v, (unsigned)((B - 1) * TB + XK) * plane_b);
   const __amdgpu_buffer_rsrc_t gsrc = x6_rsrc(gO, (unsigned)(B * XC) * plane_b);
   const __amdgpu_buffer_rsrc_t isrc = x6_rsrc(in, (unsigned)(B * XC) * (unsigned)(Hi * Wi) * 4u);
-  const __amdgpu_buffer_rsrc_t gvdst = x6_rsrc(gV, (unsigned)(B * XK) * plane_b);
-  const __amdgpu_buffer_rsrc_t ghdst = x6_rsrc(gH, (unsigned)(B * XK) * plane_b);
+  const __amdgpu_buffer_rsrc_t gvdst = x6_rsrc(gV, (unsigned)((B - 1) * TB + XK) * plane_b);
+  const __amdgpu_buffer_rsrc_t ghdst = x6_rsrc(gH, (unsigned)((B - 1) * TB + XK) * plane_b);
 
   auto pix_off = [&](int b, int x0, int y, int ch) {
     return (unsigned)b * (unsigned)ch * plane_b + (unsigned)(min(y, Ho - 1) * Wo + min(x0 + 16 * wc + j, Wo - 1)) * 4u;
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
   // Tap registers (as sepconv_bwd_x6): lane (j, kg) holds 7 PAIRS of neighbouring taps t0 + 8 a + {0, 1}: a split pair is exactly the
   // dword a table position takes.  v: t0 = 2 kg.  h: t0 = 2 kg - (j & 1): the band position i = tap + j of a pair starts even.
   auto load_taps = [&](float (&regs)[XNP][2], __amdgpu_buffer_rsrc_t src, int b, int x0, int y, int t0) {
-    const unsigned pix = pix_off(b, x0, y, XK);
+    const unsigned pix = pix_off(b, x0, y, TB);
     const unsigned voff = pix + (unsigned)(t0 + 1) * plane_b;
     regs[0][0] = x6_bload(src, pix + (unsigned)max(t0, 0) * plane_b, 0u);
     regs[0][1] = x6_bload(src, voff, 0u);
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
         const int q = nn >> 1, u = nn & 1;
         const int y = unit_y(nn), y1 = unit_y(min(nn + 1, N - 1));
         const int xq = x0 + 16 * wc + 4 * pq;
-        const unsigned qoff = (live && y < Ho && xq < Wo) ? (unsigned)b * (unsigned)XK * plane_b + (unsigned)(y * Wo + xq) * 4u + (unsigned)fq * plane_b : X_OOR;
+        const unsigned qoff = (live && y < Ho && xq < Wo) ? (unsigned)b * (unsigned)TB * plane_b + (unsigned)(y * Wo + xq) * 4u + (unsigned)fq * plane_b : X_OOR;
         // one new window row per role and unit (rows R0 + 60 + 2 n + {0 | 1})
         float gr0, gr1;
         const int grow = R0 + 60 + 2 * nn + (hside ? 0 : 1);
@@ -757,7 +757,7 @@ enum { F_VT_FULL = 8, F_VT_FREE = 12, F_OP_FULL = 32, F_OP_FREE = 36, F_TL_FULL 
 
 __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ in, const float* __restrict__ v,
                                                       const float* __restrict__ h, float* __restrict__ out,
-                                                      int B, int Ho, int Wo, int nph, int ncol, int per_wg) {
+                                                      int B, int Ho, int Wo, int nph, int ncol, int per_wg, int TB) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int p = w & 3, wc = p & 1, wr0 = p >> 1;
@@ -775,8 +775,8 @@ __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ 
   if (g0 >= g1) return;
   const int Hi = Ho + XK - 1, Wi = Wo + XK - 1;
   const unsigned plane_b = (unsigned)Ho * (unsigned)Wo * 4u;
-  const __amdgpu_buffer_rsrc_t hsrc = x6_rsrc(h, (unsigned)(B * XK) * plane_b);
-  const __amdgpu_buffer_rsrc_t vsrc = x6_rsrc(v, (unsigned)(B * XK) * plane_b);
+  const __amdgpu_buffer_rsrc_t hsrc = x6_rsrc(h, (unsigned)((B - 1) * TB + XK) * plane_b);
+  const __amdgpu_buffer_rsrc_t vsrc = x6_rsrc(v, (unsigned)((B - 1) * TB + XK) * plane_b);
   const __amdgpu_buffer_rsrc_t isrc = x6_rsrc(in, (unsigned)(B * XC) * (unsigned)(Hi * Wi) * 4u);
   const __amdgpu_buffer_rsrc_t odst = x6_rsrc(out, (unsigned)(B * XC) * plane_b);
 
@@ -784,7 +784,7 @@ __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ 
     return (unsigned)b * (unsigned)ch * plane_b + (unsigned)(min(y, Ho - 1) * Wo + min(x0 + 16 * wc + j, Wo - 1)) * 4u;
   };
   auto load_taps = [&](float (&regs)[XNP][2], __amdgpu_buffer_rsrc_t src, int b, int x0, int y, int t0) {
-    const unsigned pix = pix_off(b, x0, y, XK);
+    const unsigned pix = pix_off(b, x0, y, TB);
     const unsigned voff = pix + (unsigned)(t0 + 1) * plane_b;
     regs[0][0] = x6_bload(src, pix + (unsigned)max(t0, 0) * plane_b, 0u);
     regs[0][1] = x6_bload(src, voff, 0u);
@@ -1013,7 +1013,7 @@ __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ 
         } else {
           // taps 50 of pixel 14 and 49, 50 of pixel 15 of the h band (the tail columns' weights): lanes 0..2, in flight under the tile write
           const int hl = min(lane, 2);
-          const unsigned hoff = (unsigned)b * (unsigned)XK * plane_b + (unsigned)(hl == 1 ? 49 : 50) * plane_b
+          const unsigned hoff = (unsigned)b * (unsigned)TB * plane_b + (unsigned)(hl == 1 ? 49 : 50) * plane_b
                                 + (unsigned)(min(y, Ho - 1) * Wo + min(x0 + 16 * wc + (hl == 0 ? 14 : 15), Wo - 1)) * 4u;
           const float hraw = x6_bload(hsrc, hoff, 0u);
           // (1) v of unit n -> the pair's v tile [pixel][tap]: the lane's pairs of neighbouring taps as 8-byte stores
@@ -1088,20 +1088,22 @@ __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ 
 }  // namespace
 
 // gV and gH of the K = 51, C = 3 op, widths that are a multiple of 4; every tensor below 2^31 bytes (the caller checks).
+// TB: tap planes between two samples of v / h / gV / gH (51 for contiguous [B,51,Ho,Wo] tensors; larger when the tensors are slices of one
+// interleaved [B * S, 51, Ho, Wo] buffer: sepconv/model.py runs its four sub-networks as one task-batched launch per layer)
 int savfi_sepconv_bwd_ws_launch(const float* in, const float* v, const float* h, const float* gO, float* gV, float* gH, int B, int Ho,
-                                int Wo, int cus, hipStream_t st) {
+                                int Wo, int cus, int TB, hipStream_t st) {
   const int nph = savfi_cdiv(Ho, XPR), ncol = savfi_cdiv(Wo, XMC);
   const int64_t total = (int64_t)B * ncol * nph;
   const int per_wg = savfi_cdiv(total, cus);
   const int grid = savfi_cdiv(total, per_wg);
   static uint32_t done = 0;
   if (int e = savfi_ensure_dynamic_lds((const void*)sepconv_bwd_ws, WLDS, done)) return e;
-  hipLaunchKernelGGL(sepconv_bwd_ws, dim3(grid), dim3(WNT), WLDS, st, in, v, h, gO, gV, gH, B, Ho, Wo, nph, ncol, per_wg);
+  hipLaunchKernelGGL(sepconv_bwd_ws, dim3(grid), dim3(WNT), WLDS, st, in, v, h, gO, gV, gH, B, Ho, Wo, nph, ncol, per_wg, TB);
   return savfi_launch_status();
 }
 
 // forward of the same op, widths that are a multiple of 4 (declared in csrc/common.h)
-int savfi_sepconv_fwd_ws_launch(const float* in, const float* v, const float* h, float* out, int B, int Ho, int Wo, int cus,
+int savfi_sepconv_fwd_ws_launch(const float* in, const float* v, const float* h, float* out, int B, int Ho, int Wo, int cus, int TB,
                                 hipStream_t st) {
   const int nph = savfi_cdiv(Ho, XPR), ncol = savfi_cdiv(Wo, XMC);
   const int64_t total = (int64_t)B * ncol * nph;
@@ -1109,7 +1111,7 @@ int savfi_sepconv_fwd_ws_launch(const float* in, const float* v, const float* h,
   const int grid = savfi_cdiv(total, per_wg);
   static uint32_t done = 0;
   if (int e = savfi_ensure_dynamic_lds((const void*)sepconv_fwd_ws, FLDS, done)) return e;
-  hipLaunchKernelGGL(sepconv_fwd_ws, dim3(grid), dim3(WNT), FLDS, st, in, v, h, out, B, Ho, Wo, nph, ncol, per_wg);
+  hipLaunchKernelGGL(sepconv_fwd_ws, dim3(grid), dim3(WNT), FLDS, st, in, v, h, out, B, Ho, Wo, nph, ncol, per_wg, TB);
   return savfi_launch_status();
 }
 

@@ -1130,6 +1130,37 @@ def refresh_module_filters(modules):
             m._filters[(kind, w.data_ptr(), w._version, tuple(w.shape), w.device.index, st)] = made
 
 
+# Long-lived constant weights (sepconv/model.py: the four sub-networks' own parameters stacked into one task-batched layer; rebuilt when a
+# parameter changes): their packed / transformed filters are made once per tensor, whichever function asks.  Keyed on the data pointer of a
+# tensor the registry keeps alive, so the pointer cannot be recycled while the entry exists.
+_const_weights = {}
+
+
+def register_const_weight(w):
+    _const_weights[w.data_ptr()] = [w, w._version, {}]
+    return w
+
+
+def unregister_const_weight(w):
+    _const_weights.pop(w.data_ptr(), None)
+
+
+def _const_filters(kind, weight, fwd, bwd, make):
+    """(filters_fwd, filters_bwd) of a registered constant weight (made on first use by `make(fwd, bwd)`), or None."""
+    e = _const_weights.get(weight.data_ptr()) if _const_weights else None
+    if e is None or e[1] != weight._version or e[0].shape != weight.shape or torch.cuda.is_current_stream_capturing():
+        return None
+    have = e[2].setdefault((kind, _hip.current_stream()), [None, None])
+    need_f, need_b = fwd and have[0] is None, bwd and have[1] is None
+    if need_f or need_b:
+        pf, pb = make(need_f, need_b)
+        if need_f:
+            have[0] = pf
+        if need_b:
+            have[1] = pb
+    return (have[0] if fwd else None), (have[1] if bwd else None)
+
+
 def _prepacked_filters(kind, weight, fwd, bwd):
     hit = _prepacked.get((kind, weight.data_ptr())) if _prepacked else None
     if hit is None or hit[1] != weight._version or hit[0].shape != weight.shape or (fwd and hit[2] is None) or (bwd and hit[3] is None):
@@ -1162,14 +1193,20 @@ def conv3x3_filters(weight, fwd=True, bwd=True):
     ready = _prepacked_filters('wino', weight, fwd, bwd)
     if ready is not None:
         return ready
+
+    def make(fwd, bwd):
+        lib = _hip.lib()
+        us = [torch.empty(_workspace_floats("savfi_conv3x3_filter_floats", T, Ci, Co, mode), dtype=weight.dtype, device=weight.device) if want else None
+              for mode, want in ((0, fwd), (1, bwd))]
+        _hip.launch("conv3x3_filters", lambda: _hip.check(lib.savfi_conv3x3_filters_f32(
+            weight.data_ptr(), None if us[0] is None else us[0].data_ptr(), None if us[1] is None else us[1].data_ptr(), T, Ci, Co,
+            _hip.current_stream()), "savfi_conv3x3_filters_f32"))
+        return us[0], us[1]
+    ready = _const_filters('wino', weight, fwd, bwd, make)
+    if ready is not None:
+        return ready
     _note_filter_use('wino', weight, fwd, bwd)
-    lib = _hip.lib()
-    us = [torch.empty(_workspace_floats("savfi_conv3x3_filter_floats", T, Ci, Co, mode), dtype=weight.dtype, device=weight.device) if want else None
-          for mode, want in ((0, fwd), (1, bwd))]
-    _hip.launch("conv3x3_filters", lambda: _hip.check(lib.savfi_conv3x3_filters_f32(
-        weight.data_ptr(), None if us[0] is None else us[0].data_ptr(), None if us[1] is None else us[1].data_ptr(), T, Ci, Co,
-        _hip.current_stream()), "savfi_conv3x3_filters_f32"))
-    return us[0], us[1]
+    return make(fwd, bwd)
 
 
 def conv3x3_tasks_pre(x, u, T, Ci, Co, bias=None, mode=0, slope=1.0, pad=1, mask=None, mask_slope=1.0):
@@ -1255,14 +1292,20 @@ def convk_filters(weight, fwd=True, bwd=True):
     ready = _prepacked_filters('convk', weight, fwd, bwd)
     if ready is not None:
         return ready
+
+    def make(fwd, bwd):
+        lib = _hip.lib()
+        ps = [torch.empty(_workspace_floats("savfi_convk_filter_floats", T, Ci, Co, K, mode), dtype=torch.float32, device=weight.device)
+              if want else None for mode, want in ((0, fwd), (1, bwd))]
+        _hip.launch("convk_filters", lambda: _hip.check(lib.savfi_convk_filters_f32(
+            weight.data_ptr(), None if ps[0] is None else ps[0].data_ptr(), None if ps[1] is None else ps[1].data_ptr(), T, Ci, Co, K,
+            _hip.current_stream()), "savfi_convk_filters_f32"))
+        return ps[0], ps[1]
+    ready = _const_filters('convk', weight, fwd, bwd, make)
+    if ready is not None:
+        return ready
     _note_filter_use('convk', weight, fwd, bwd)
-    lib = _hip.lib()
-    ps = [torch.empty(_workspace_floats("savfi_convk_filter_floats", T, Ci, Co, K, mode), dtype=torch.float32, device=weight.device)
-          if want else None for mode, want in ((0, fwd), (1, bwd))]
-    _hip.launch("convk_filters", lambda: _hip.check(lib.savfi_convk_filters_f32(
-        weight.data_ptr(), None if ps[0] is None else ps[0].data_ptr(), None if ps[1] is None else ps[1].data_ptr(), T, Ci, Co, K,
-        _hip.current_stream()), "savfi_convk_filters_f32"))
-    return ps[0], ps[1]
+    return make(fwd, bwd)
 
 
 def convk_tasks_pre(x, packed, T, Ci, Co, K, bias=None, mode=0, slope=1.0, pad=1, precise=False, reflect=False, mask=None, mask_slope=1.0):

@@ -20,14 +20,16 @@ just the window it feeds (savfi_upsample2x_window_*), and FunctionSepconv produc
 directly from the frame padded by 25 px.  Same values as the full-canvas evaluation (which stays available:
 ``windowed=False`` / ``--sepconv_window 0``; tests compare the two), forward and backward.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import hip_ops
 from ..hip_ops import Upsample2x, upsample_bilinear2x_window, upsample_window_sources
-from ..model_utils import MetaConv2dLayer, MetaSequential, as_view, zero_grad_params
-from .sepconv_op.sepconv import FunctionSepconv
+from ..model_utils import MetaConv2dLayer, MetaSequential, as_view, own_params_const, zero_grad_params
+from .sepconv_op.sepconv import FunctionSepconv, FunctionSepconvPair
 
 FILTER_TAPS = 51
 HALF = FILTER_TAPS // 2  # 25
@@ -66,6 +68,7 @@ class MetaNetwork(nn.Module):
     def __init__(self, resume=False, strModel='lf', windowed=True):
         super().__init__()
         self.windowed = bool(windowed)
+        self.batch_subnets = os.environ.get('SAVFI_SEPCONV_SUBNETS_ONE_BY_ONE') is None     # windowed tail: the four Subnets as one launch per layer
         self._windows = {}
         for i, (name, cin, cout) in enumerate(_ENCODER, start=1):
             setattr(self, name, _basic(cin, cout))
@@ -145,10 +148,68 @@ class MetaNetwork(nn.Module):
         x = upsample_bilinear2x_window(x, win['half'], (win['crop'][0], win['crop'][2]), win['up'], True)
         return seq[7](x, padding=0)       # [N,51,height,width]: exactly the frame area
 
+    # ---- the four Subnets as ONE task-batched launch per layer (round 4) -------------------------------
+    # The Subnets share their input and their layer shapes.  Layer 1 of all four is one 64 -> 256 convolution; its output
+    # [N, 4 * 64, h, w] IS [4 N, 64, h, w] with sample 4 n + s belonging to Subnet s, the layout of the lockstep machinery (sample i uses
+    # filter set i % T, hip_ops.conv_bias_act_tasks), so layers 2..4 run with T = 4 filter sets on it; the taps stay in that interleaved
+    # buffer and FunctionSepconvPair reads them (and writes their gradients) in place.  5 convolution launches per pass instead of 16, whole
+    # rounds of the chip on the 137 x 233 maps (4 608 workgroups = 9.0 rounds where one Subnet's 1 152 were 2.25), the data gradient of
+    # layer 1 sums over the Subnets inside the convolution (no accumulation passes over `combine`'s gradient).  Same arithmetic per output
+    # as the Subnet-by-Subnet evaluation (`batch_subnets=False`, SAVFI_SEPCONV_SUBNETS_ONE_BY_ONE=1: tests compare the two).
+    _SUBNETS = ("moduleVertical1", "moduleHorizontal1", "moduleVertical2", "moduleHorizontal2")
+
+    def _stacked_subnet_params(self):
+        subs = [getattr(self, n) for n in self._SUBNETS]
+        const = own_params_const()
+        if const and torch.cuda.is_current_stream_capturing():
+            # inside a hipGraph capture the stacking kernels belong to the graph (replayed on the live parameters); a cached tensor made
+            # outside would be baked in by address and go stale with the next outer step
+            with torch.no_grad():
+                cat = lambda i, a: torch.cat([getattr(s[i], a).detach() for s in subs], 0)
+                stack = lambda i, a: torch.stack([getattr(s[i], a).detach() for s in subs], 0)
+                return dict(w0=cat(0, 'weight'), b0=cat(0, 'bias'), **{k + str(i): stack(i, a) for i in (2, 4, 7) for k, a in (('w', 'weight'), ('b', 'bias'))})
+        if not const:                                  # the outer pass differentiates them: built inside the graph, every time
+            cat = lambda i, a: torch.cat([getattr(s[i], a) for s in subs], 0)
+            stack = lambda i, a: torch.stack([getattr(s[i], a) for s in subs], 0)
+            return dict(w0=cat(0, 'weight'), b0=cat(0, 'bias'), **{k + str(i): stack(i, a) for i in (2, 4, 7) for k, a in (('w', 'weight'), ('b', 'bias'))})
+        ps = [p for s in subs for i in (0, 2, 4, 7) for p in (s[i].weight, s[i].bias)]
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        hit = self.__dict__.get('_subnet_stack')
+        if hit is None or hit[0] != key:
+            if hit is not None:
+                for t in hit[1].values():
+                    hip_ops.unregister_const_weight(t)
+            with torch.no_grad():
+                cat = lambda i, a: torch.cat([getattr(s[i], a).detach() for s in subs], 0)
+                stack = lambda i, a: torch.stack([getattr(s[i], a).detach() for s in subs], 0)
+                made = dict(w0=cat(0, 'weight'), b0=cat(0, 'bias'), **{k + str(i): stack(i, a) for i in (2, 4, 7) for k, a in (('w', 'weight'), ('b', 'bias'))})
+            for k, t in made.items():
+                if k[0] == 'w':
+                    hip_ops.register_const_weight(t)   # their packed / transformed filters are made once, not per pass
+            hit = (key, made)
+            self.__dict__['_subnet_stack'] = hit
+        return hit[1]
+
+    def _windowed_tail_batched(self, frame0, frame1, crop, win):
+        ref = getattr(self, self._SUBNETS[0])
+        sp = self._stacked_subnet_params()
+        N = crop.size(0)
+        x = ref[0](crop, params={'weight': sp['w0'], 'bias': sp['b0']}, act_slope=0.0)          # [N, 256, h, w]
+        x = x.view(4 * N, 64, x.size(2), x.size(3))                                            # sample 4 n + s: Subnet s
+        x = ref[2](x, params={'weight': sp['w2'], 'bias': sp['b2']}, act_slope=0.0)
+        x = ref[4](x, params={'weight': sp['w4'], 'bias': sp['b4']}, act_slope=0.0)
+        x = upsample_bilinear2x_window(x, win['half'], (win['crop'][0], win['crop'][2]), win['up'], True)
+        taps = ref[7](x, params={'weight': sp['w7'], 'bias': sp['b7']}, padding=0)               # [4 N, 51, height, width]
+        rim = (HALF,) * 4
+        return FunctionSepconvPair.apply(F.pad(frame0, rim, mode='replicate'), F.pad(frame1, rim, mode='replicate'), taps)
+
     def _windowed_tail(self, frame0, frame1, combine, height, width, ph, pw):
         win = self._window(height, width, ph, pw)
         cy0, cy1, cx0, cx1 = win['crop']
         crop = combine[:, :, cy0:cy1, cx0:cx1].contiguous()
+        if (self.batch_subnets and width % 4 == 0 and not frame0.requires_grad and not frame1.requires_grad
+                and 4 * crop.size(0) * FILTER_TAPS * height * width * 4 < 2 ** 31):
+            return self._windowed_tail_batched(frame0, frame1, crop, win)
         rim = (HALF,) * 4
         dot1 = FunctionSepconv.apply(F.pad(frame0, rim, mode='replicate'),
                                      self._subnet_window(self.moduleVertical1, crop, win),

@@ -73,6 +73,62 @@ class FunctionSepconv(torch.autograd.Function):
         return gI, gV, gH
 
 
+class FunctionSepconvPair(torch.autograd.Function):
+    """sepconv(input0, taps[0::4], taps[1::4]) + sepconv(input1, taps[2::4], taps[3::4]) on an INTERLEAVED tap tensor.
+
+        FunctionSepconvPair.apply(input0[B,C,Ho+K-1,Wo+K-1], input1[...], taps[4*B,K,Ho,Wo]) -> output[B,C,Ho,Wo]
+
+    taps[4 b + s] are the K tap planes of sample b from sub-network s (0: vertical1, 1: horizontal1, 2: vertical2, 3: horizontal2) --
+    the layout the plugin's four Subnets leave when they run as ONE task-batched launch per layer (sepconv/model.py).  The two local
+    convolutions of the reference (sepconv/model.py:346-347 -> sepconv_op/sepconv.py:247-380) read that buffer in place and their filter
+    gradients are written into one buffer of the same layout (savfi_sepconv_*_taps_strided_f32, tap_bstride = 4 K): no slices are
+    copied out, no gradients are concatenated.  The frames carry no gradient on this path (needs_input_grad is asserted)."""
+
+    @staticmethod
+    def supported(input0, taps):
+        K, Wo = taps.size(1), taps.size(3)
+        return (input0.is_cuda and taps.is_cuda and input0.dtype == torch.float32 and K == 51 and input0.size(1) == 3 and Wo % 4 == 0
+                and taps.size(0) % 4 == 0 and taps.numel() * 4 < 2 ** 31)
+
+    @staticmethod
+    def forward(ctx, input0, input1, taps):
+        B, C, Hi, Wi = input0.shape
+        K, Ho, Wo = taps.shape[1:]
+        assert input1.shape == input0.shape and taps.size(0) == 4 * B and Hi - K == Ho - 1 and Wi - K == Wo - 1, (input0.shape, taps.shape)
+        assert input0.is_contiguous() and input1.is_contiguous() and taps.is_contiguous()
+        _hip.require_cuda(input0, input1, taps)
+        ctx.save_for_backward(input0, input1, taps)
+        out0 = torch.empty((B, C, Ho, Wo), dtype=input0.dtype, device=input0.device)
+        out1 = torch.empty_like(out0)
+        lib, st = _hip.lib(), _hip.current_stream()
+        plane = K * Ho * Wo * 4
+        for inp, out, s in ((input0, out0, 0), (input1, out1, 2)):
+            _hip.launch("sepconv_fwd", lambda inp=inp, out=out, s=s: _hip.check(lib.savfi_sepconv_fwd_taps_strided_f32(
+                inp.data_ptr(), taps.data_ptr() + s * plane, taps.data_ptr() + (s + 1) * plane, out.data_ptr(),
+                B, C, Ho, Wo, K, 4 * K, st), "savfi_sepconv_fwd_taps_strided_f32"), nbytes=algorithmic_bytes(B, C, Ho, Wo, K))
+        return out0.add_(out1)
+
+    @staticmethod
+    def backward(ctx, gradOutput):
+        input0, input1, taps = ctx.saved_tensors
+        assert not ctx.needs_input_grad[0] and not ctx.needs_input_grad[1], "FunctionSepconvPair: frames carry no gradient on this path"
+        if not ctx.needs_input_grad[2]:
+            return None, None, None
+        B, C = input0.shape[:2]
+        K, Ho, Wo = taps.shape[1:]
+        gradOutput = gradOutput.contiguous()
+        _hip.require_cuda(gradOutput)
+        gT = torch.empty_like(taps)
+        lib, st = _hip.lib(), _hip.current_stream()
+        plane = K * Ho * Wo * 4
+        for inp, s in ((input0, 0), (input1, 2)):
+            _hip.launch("sepconv_bwd", lambda inp=inp, s=s: _hip.check(lib.savfi_sepconv_bwd_taps_strided_f32(
+                inp.data_ptr(), taps.data_ptr() + s * plane, taps.data_ptr() + (s + 1) * plane, gradOutput.data_ptr(),
+                gT.data_ptr() + s * plane, gT.data_ptr() + (s + 1) * plane, B, C, Ho, Wo, K, 4 * K, st),
+                "savfi_sepconv_bwd_taps_strided_f32"), nbytes=algorithmic_bytes(B, C, Ho, Wo, K, grads=2))
+        return None, None, gT
+
+
 class ModuleSepconv(torch.nn.Module):
     """Module form kept for surface parity (reference :382-389); takes the three op inputs."""
 

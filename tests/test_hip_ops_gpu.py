@@ -429,6 +429,53 @@ def test_sepconv_windowed_tail_equals_full_canvas(hw):
         assert (g_win[n] - ref).abs().max() <= 2e-5 * ref.abs().max() + 1e-9, n
 
 
+@pytest.mark.parametrize("const", [False, True])
+@pytest.mark.parametrize("hw", [(64, 96), (72, 60), (256, 448)])
+def test_sepconv_subnets_as_one_batched_launch_equal_one_by_one(hw, const):
+    """sepconv/model.py: the four Subnets as ONE task-batched launch per layer (layer 1 a 64 -> 256 convolution, layers 2..4 with four
+    filter sets on the interleaved [4 N, C, h, w] maps, the taps read in place by FunctionSepconvPair / savfi_sepconv_*_taps_strided_f32)
+    against the Subnet-by-Subnet evaluation (reference sepconv/model.py:346-347): predictions, fast-weight gradients and -- when the
+    plugin's own parameters are differentiated (`const` False: the outer pass) -- the Subnets' own gradients.  `const`: the support
+    passes' mode (own parameters are constants; the stacked weights and their packed filters are cached across passes)."""
+    from meta_interpolation_amd import model_utils as mu, synthetic
+    from meta_interpolation_amd.sepconv.model import MetaNetwork
+    H, W = hw
+    net = MetaNetwork(windowed=True)
+    synthetic.load_seeded_weights(net, 'sepconv')
+    net = net.cuda()
+    frames = synthetic.septuplet_batch(2, H, W, model='sepconv')
+    f0, f1, tgt = frames[2].cuda(), frames[4].cuda(), frames[3].cuda()
+    routed = {n: p for n, p in net.named_parameters() if n.startswith(('moduleConv', 'moduleDeconv'))}
+    res = {}
+    mu.set_fuse_conv_act(True)
+    mu.set_own_params_const(const)
+    try:
+        for batched in (True, False, True):          # the second batched run hits the stacked-weight / filter cache
+            net.batch_subnets = batched
+            fast = {n: p.detach().clone().requires_grad_() for n, p in routed.items()}
+            out = net(f0, f1, params=fast)
+            loss = (out - tgt).abs().mean()
+            wrt = list(fast.values()) + ([] if const else [p for n, p in net.named_parameters() if n not in routed])
+            names = list(fast) + ([] if const else [n for n, _ in net.named_parameters() if n not in routed])
+            grads = torch.autograd.grad(loss, wrt, allow_unused=True)
+            cur = (out.detach(), dict(zip(names, grads)))
+            if batched and True in res:
+                assert torch.equal(cur[0], res[True][0])         # deterministic, cache or no cache
+            res[batched] = cur
+    finally:
+        mu.set_fuse_conv_act(False)
+        mu.set_own_params_const(False)
+    from meta_interpolation_amd import _hip
+    assert _hip.lib().savfi_sepconv_ws_errors() == 0
+    (o_b, g_b), (o_s, g_s) = res[True], res[False]
+    assert (o_b - o_s).abs().max() < 2e-6
+    for n, ref in g_s.items():
+        if ref is None:
+            assert g_b[n] is None, n
+            continue
+        assert (g_b[n] - ref).abs().max() <= 2e-5 * ref.abs().max() + 1e-9, (n, (g_b[n] - ref).abs().max().item(), ref.abs().max().item())
+
+
 # ---------------------------------------------------------------------------------------------
 # Winograd F(2x2,3x3) convolution on the fp32 matrix cores
 # ---------------------------------------------------------------------------------------------
