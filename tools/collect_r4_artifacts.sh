@@ -4,7 +4,7 @@ set -x
 R=$GRAFT_REPO_ROOT
 A=$R/gpurun_out/art4; mkdir -p $A
 cd $R
-python bench.py --steps 5 --warmup 2 > $A/r04_bench_line.json 2> $A/r04_bench_line.err
+T0=$(date +%s); python bench.py > $A/r04_bench_line.json 2> $A/r04_bench_line.err; T1=$(date +%s); echo "python bench.py (default flags): wall $((T1 - T0)) s" > $A/r04_bench_default_run_time.txt
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_c2 -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-strong-c4 > $A/r04_bench_line_profiled.json 2>/dev/null
 python $R/tools/gap_report.py /tmp/prof_c2 0 > $A/r04_bench_c2_one_iteration.txt 2>&1
@@ -21,4 +21,6 @@ python tools/layer_table.py --workload c2_sepconv_256x448_b4_s5 --top 60 > $A/r0
 python tools/kernel_bench.py --batches 1,2,4,8 > $A/r04_kernel_bench.jsonl 2>/dev/null
 python tools/parity_report.py > $A/r04_parity_report.jsonl 2>/dev/null
 python -m pytest tests -m gpu -q 2>&1 | tail -9 > $A/r04_pytest_gpu_tail.txt
-ls -la $A
+
+SAVFI_SEPCONV_SUBNETS_ONE_BY_ONE=1 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-strong-c4 --no-kernel-timer 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); d['config']['mode']['subnets']='one by one (SAVFI_SEPCONV_SUBNETS_ONE_BY_ONE=1)'; print(json.dumps(d))" >> $A/r04_modes.jsonl
+python -c "import __graft_entry__ as g; g.smoke()" > $A/r04_smoke.txt 2>&1; tail -3 $A/r04_smoke.txt
