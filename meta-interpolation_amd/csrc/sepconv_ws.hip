@@ -66,6 +66,9 @@ constexpr int WSPIN_LIMIT = 1 << 19;
 #ifndef WS_PRIO_TABLE           // wave priority of a staging wave while it builds a table (what the MFMA wave waits for next)
 #define WS_PRIO_TABLE 3
 #endif
+#ifndef WS_GH_READS_PER_GAP       // gH: transpose reads of the next block per MFMA gap (12 per block: 2 = in the first six gaps, 1 = one per gap)
+#define WS_GH_READS_PER_GAP 2
+#endif
 #ifndef WS_EXP_NOAREAD          // the MFMA loops reuse the first unit's A fragments (no LDS reads inside the loops)
 #define WS_EXP_NOAREAD 0
 #endif
@@ -475,7 +478,7 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
 #pragma unroll
               for (int i = 0; i < 12; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, WS_GH_READS_PER_GAP, 0);
               }
             }
             __builtin_amdgcn_sched_barrier(0);

@@ -199,6 +199,80 @@ class HD(object):
         return self.data_length[self.current_set_name]
 
 
+def _to_float_chw_totensor(u8_hwc, model):
+    """The tensor pipeline of the two evaluation-only readers below: transforms.ToTensor() (uint8 / 255) FIRST, then the plugin's
+    normalisation on it -- VoxelFlow: Normalize(127.5, 127.5)(t * 255), which is not bit-identical to normalising the uint8 values
+    directly (data/middlebury.py:88-93, data/snufilm.py:53-56 vs data/vimeo_septuplet.py:74-80)."""
+    t = torch.from_numpy(np.ascontiguousarray(np.transpose(u8_hwc, (2, 0, 1)))).float().div(255)
+    if model == 'voxelflow':
+        t = (t * 255.0 - torch.full((3, 1, 1), 0.5 * 255)) / torch.full((3, 1, 1), 0.5 * 255)
+    elif model == 'superslomo':
+        t = (t - torch.tensor((0.429, 0.431, 0.397)).view(3, 1, 1)) / torch.ones(3, 1, 1)
+    return t
+
+
+class Middlebury(object):
+    """data/middlebury.py:12-105 (`--dataset middlebury`): the 'other' scenes with eight input frames; frames 09, 10, 11, 12 are the
+    inputs, `other-gt-interp/<scene>/frame10i11.png` the target, returned as a septuplet-shaped list [f0, 0, f1, gt, f2, 0, f3]
+    (zeros where Vimeo has frames this set does not).  Validation split only."""
+
+    def __init__(self, args):
+        self.args = args
+        self.data_root = args.data_root
+        self.image_root = os.path.join(self.data_root, 'other-data-all')
+        self.gt_root = os.path.join(self.data_root, 'other-gt-interp')
+        self.imglist, self.gt_list = [], []
+        for d in sorted(glob.glob(self.image_root + '/*')):
+            frames = sorted(glob.glob(d + '/*.png'))
+            if len(frames) == 8:                       # scenes with two frames only are skipped, other counts are ignored (:37-42)
+                self.imglist.append(frames[2:6])
+                self.gt_list.append(os.path.join(self.gt_root, d.split('/')[-1], 'frame10i11.png'))
+        self.batch_size = {'train': 1, 'val': 1, 'test': 1}
+        self.current_set_name = 'val'
+        self.data_length = {'train': 0, 'val': len(self.imglist), 'test': 0}
+
+    def __getitem__(self, index):
+        paths, gt_path = self.imglist[index], self.gt_list[index]
+        imgs = [_to_float_chw_totensor(_read_rgb(p), self.args.model) for p in paths]
+        gt = _to_float_chw_totensor(_read_rgb(gt_path), self.args.model)
+        dummy = torch.zeros_like(gt)
+        return ([imgs[0], dummy, imgs[1], gt, imgs[2], dummy, imgs[3]],
+                {'imgpaths': [paths[0], "", paths[1], gt_path, paths[2], "", paths[3]]})
+
+    def switch_set(self, set_name, current_iter=None):
+        self.current_set_name = set_name
+
+    def __len__(self):
+        return self.data_length[self.current_set_name]
+
+
+class SNUFILM(object):
+    """data/snufilm.py:8-69 (`--dataset snufilm`): `data_root/test-hard-meta.txt`, one quintuplet of image paths per line, returned
+    as [f0, 0, f1, f2, f3, 0, f4].  Validation split only."""
+
+    def __init__(self, args):
+        self.args = args
+        with open(os.path.join(args.data_root, 'test-hard-meta.txt'), 'r') as f:
+            self.frame_list = [v.split(' ') for v in f.read().splitlines()]
+        self.batch_size = {'train': 1, 'val': 1, 'test': 1}
+        self.current_set_name = 'val'
+        self.data_length = {'train': 0, 'val': len(self.frame_list), 'test': 0}
+        print("Test dataset has %d quintuplets" % len(self.frame_list))
+
+    def __getitem__(self, index):
+        paths = self.frame_list[index]
+        imgs = [_to_float_chw_totensor(_read_rgb(p), self.args.model) for p in paths]
+        dummy = torch.zeros_like(imgs[0])
+        return (imgs[:1] + [dummy] + imgs[1:4] + [dummy] + imgs[-1:],
+                {'imgpaths': paths[:1] + [''] + paths[1:4] + [''] + paths[-1:]})
+
+    def switch_set(self, set_name, current_iter=None):
+        self.current_set_name = set_name
+
+    def __len__(self):
+        return self.data_length[self.current_set_name]
+
+
 class FrameStager(object):
     """Decoded uint8 frames -> fp32 [B,3,H,W] tensors on the GPU (see the module docstring).
 
@@ -381,4 +455,9 @@ def MetaLearningSystemDataLoader(args, current_iter=0):
         return DatasetProvider(args, HD(args), current_iter)
     if args.dataset == 'test':
         return DatasetProvider(args, Video(args), current_iter)
-    raise NotImplementedError("dataset %r is outside this build's scope (vimeo90k, hd, test, or --synthetic)" % args.dataset)
+    if args.dataset == 'middlebury':
+        return DatasetProvider(args, Middlebury(args), current_iter)
+    if args.dataset == 'snufilm':
+        return DatasetProvider(args, SNUFILM(args), current_iter)
+    # 'davis': the reference's dispatch names data/davis.py, which is not in its repository (data/__init__.py:546-548)
+    raise NotImplementedError("dataset %r: the reference ships no reader for it (vimeo90k, hd, middlebury, snufilm, test, or --synthetic)" % args.dataset)

@@ -163,3 +163,40 @@ def write_fake_hd(root, lengths=(9, 7, 4), height=48, width=64, seed=21):
         for k in range(n):
             Image.fromarray(_fake_frame(rng, height, width, k)).save(os.path.join(root, 'video%02d' % v, '%04d.png' % k))
     return root
+
+
+def write_fake_middlebury(root, height=48, width=64, seed=33):
+    """`root/other-data-all/<scene>/frame07..14.png` (8 frames; one scene with only two is skipped by the reader) and
+    `root/other-gt-interp/<scene>/frame10i11.png` for data/middlebury.py:26-44."""
+    import os
+    from PIL import Image
+    rng = np.random.RandomState(seed)
+    for scene, n in (('Beanbags', 8), ('Dimetrodon', 2), ('Walking', 8)):
+        os.makedirs(os.path.join(root, 'other-data-all', scene), exist_ok=True)
+        os.makedirs(os.path.join(root, 'other-gt-interp', scene), exist_ok=True)
+        first = 7 if n == 8 else 10
+        for k in range(n):
+            Image.fromarray(_fake_frame(rng, height, width, k)).save(os.path.join(root, 'other-data-all', scene, 'frame%02d.png' % (first + k)))
+        Image.fromarray(_fake_frame(rng, height, width, 99)).save(os.path.join(root, 'other-gt-interp', scene, 'frame10i11.png'))
+    return root
+
+
+def write_fake_snufilm(root, clips=3, height=48, width=64, seed=44):
+    """`root/test-hard-meta.txt`: one line of five space-separated image paths per sample (data/snufilm.py:15-19), frames under root/test/."""
+    import os
+    from PIL import Image
+    rng = np.random.RandomState(seed)
+    lines = []
+    for c in range(clips):
+        d = os.path.join(root, 'test', 'clip%02d' % c)
+        os.makedirs(d, exist_ok=True)
+        paths = []
+        for k in range(5):
+            path = os.path.join(d, '%05d.png' % (4 * k))
+            Image.fromarray(_fake_frame(rng, height, width, k)).save(path)
+            paths.append(path)
+        lines.append(' '.join(paths))
+    with open(os.path.join(root, 'test-hard-meta.txt'), 'w') as f:
+        f.write('\n'.join(lines) + '\n')
+    return root
+

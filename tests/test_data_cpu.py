@@ -76,6 +76,39 @@ def test_hd_reader_matches_the_reference_class(tmp_path, model):
             assert np.allclose(fp, g['hd_%s_%d_fp%d' % (model, idx, f)], rtol=1e-12)
 
 
+@pytest.mark.parametrize("model", ["sepconv", "voxelflow", "superslomo"])
+@pytest.mark.parametrize("tag", ["middlebury", "snufilm"])
+def test_evaluation_set_readers_match_the_reference_classes(tmp_path, tag, model):
+    """data/middlebury.py / data/snufilm.py (`--dataset middlebury | snufilm`): septuplet-shaped samples with zero frames where the set
+    has none, ToTensor-then-normalise arithmetic, bit-exact against the reference classes' own outputs on the same PNGs."""
+    g = golden("data_readers")
+    if tag == 'middlebury':
+        root = synthetic.write_fake_middlebury(str(tmp_path / "mb"))
+        ds = data.Middlebury(types.SimpleNamespace(data_root=root, model=model))
+    else:
+        root = synthetic.write_fake_snufilm(str(tmp_path / "snu"))
+        ds = data.SNUFILM(types.SimpleNamespace(data_root=root, model=model))
+    assert len(ds) == int(g['%s_%s_len' % (tag, model)][0]) and ds.data_length['train'] == 0
+    for idx in range(len(ds)):
+        images, meta = ds[idx]
+        assert len(images) == 7
+        assert [os.path.relpath(p, root) if p else '' for p in meta['imgpaths']] == list(g['%s_%s_%d_paths' % (tag, model, idx)])
+        for f, im in enumerate(images):
+            fp, sample = summary(im)
+            assert np.array_equal(sample, g['%s_%s_%d_s%d' % (tag, model, idx, f)])            # bit-exact
+            assert np.allclose(fp, g['%s_%s_%d_fp%d' % (tag, model, idx, f)], rtol=1e-12)
+
+
+def test_dataset_dispatch_covers_the_reference_names(tmp_path):
+    root = synthetic.write_fake_snufilm(str(tmp_path / "snu"))
+    args = types.SimpleNamespace(data_root=root, batch_size=1, val_batch_size=1, test_batch_size=1, mode='val', model='sepconv', num_gpu=0,
+                                 num_workers=0, random_seed=5, dataset='snufilm', synthetic=False)
+    prov = data.MetaLearningSystemDataLoader(args)
+    assert prov.dataset.data_length['val'] == 3
+    with pytest.raises(NotImplementedError):
+        data.MetaLearningSystemDataLoader(types.SimpleNamespace(**dict(vars(args), dataset='davis')))
+
+
 def test_video_reader_renames_and_pads_short_clips(tmp_path):
     from PIL import Image
     root = tmp_path / "short"
@@ -103,7 +136,7 @@ def test_provider_surface_and_batch_layout(vimeo_root):
     assert len(val) == 1 and val[0][0][0].shape == (1, 3, 260, 272)         # validation frames are not cropped
     assert prov.dataset.current_set_name == 'val'
     with pytest.raises(NotImplementedError):
-        data.MetaLearningSystemDataLoader(vimeo_args(vimeo_root, 'sepconv', 'train', dataset='middlebury'))
+        data.MetaLearningSystemDataLoader(vimeo_args(vimeo_root, 'sepconv', 'train', dataset='davis'))      # named by the reference's dispatch, but data/davis.py is not in its repository
 
 
 def test_training_batches_are_reproducible_with_parallel_decode(vimeo_root):
