@@ -174,7 +174,9 @@ class MetaNetwork(nn.Module):
             return dict(w0=cat(0, 'weight'), b0=cat(0, 'bias'), **{k + str(i): stack(i, a) for i in (2, 4, 7) for k, a in (('w', 'weight'), ('b', 'bias'))})
         ps = [p for s in subs for i in (0, 2, 4, 7) for p in (s[i].weight, s[i].bias)]
         key = tuple((p.data_ptr(), p._version) for p in ps)
-        hit = self.__dict__.get('_subnet_stack')
+        stream = torch.cuda.current_stream().cuda_stream            # one copy per stream: task streams never share a tensor made on another
+        cache = self.__dict__.setdefault('_subnet_stacks', {})
+        hit = cache.get(stream)
         if hit is None or hit[0] != key:
             if hit is not None:
                 for t in hit[1].values():
@@ -187,7 +189,7 @@ class MetaNetwork(nn.Module):
                 if k[0] == 'w':
                     hip_ops.register_const_weight(t)   # their packed / transformed filters are made once, not per pass
             hit = (key, made)
-            self.__dict__['_subnet_stack'] = hit
+            cache[stream] = hit
         return hit[1]
 
     def _windowed_tail_batched(self, frame0, frame1, crop, win):
