@@ -1136,7 +1136,12 @@ def refresh_module_filters(modules):
 _const_weights = {}
 
 
+_CONST_WEIGHTS_MAX = 64         # a model that goes away without unregistering leaves its entries behind: oldest out (16 per SepConv net and stream)
+
+
 def register_const_weight(w):
+    while len(_const_weights) >= _CONST_WEIGHTS_MAX:
+        _const_weights.pop(next(iter(_const_weights)))
     _const_weights[w.data_ptr()] = [w, w._version, {}]
     return w
 
