@@ -171,19 +171,38 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_tiled(const float* __restr
       if (r < nrow && c < ncol) gt[r][c] = gw[(size_t)r * g.Ww + c];
     }
   }
+  // round 4: the weights of the tile's 64 columns and 8 rows are evaluated ONCE per workgroup into LDS (6 candidates each: 384 + 48
+  // source() evaluations spread over the 256 threads) -- every thread used to evaluate its column's six x weights (four threads per
+  // column) and six y weights per output (64 threads per row): ~300 of its ~500 instructions.  Same candidates, same source()
+  // arithmetic, same order of the sums: bit-identical.
+  __shared__ float wxl[UBW][NC], wyl[UBH][NC];
+  for (int i = threadIdx.x; i < UBW * NC; i += 256) {
+    const int c = i / NC, k = i - c * NC;
+    const int ixc = g.sx0 + min(tx * UBW + c, g.Ws - 1);
+    const int ox = max(g.ox0, 2 * ixc - 2) + k;
+    float w = 0.f;
+    if (ox <= min(g.ox0 + g.Ww - 1, 2 * ixc + 3)) {
+      const Src s = source(ox, g.W, sw, g.align);
+      w = (s.i0 == ixc ? s.l0 : 0.f) + (s.i1 == ixc ? s.l1 : 0.f);
+    }
+    wxl[c][k] = w;
+  }
+  if (threadIdx.x < UBH * NC) {
+    const int r = threadIdx.x / NC, k = threadIdx.x - r * NC;
+    const int iy = iy0 + r;
+    const int oy = max(g.oy0, 2 * iy - 2) + k;
+    float w = 0.f;
+    if (oy <= min(g.oy0 + g.Hw - 1, 2 * iy + 3)) {
+      const Src s = source(oy, g.H, sh, g.align);
+      w = (s.i0 == iy ? s.l0 : 0.f) + (s.i1 == iy ? s.l1 : 0.f);
+    }
+    wyl[r][k] = w;
+  }
   const int ox_lo = max(g.ox0, 2 * ix - 2), ox_hi = min(g.ox0 + g.Ww - 1, 2 * ix + 3);
+  __syncthreads();
   float wxs[NC];
 #pragma unroll
-  for (int k = 0; k < NC; ++k) {
-    const int ox = ox_lo + k;
-    float w = 0.f;
-    if (ox <= ox_hi) {
-      const Src s = source(ox, g.W, sw, g.align);
-      w = (s.i0 == ix ? s.l0 : 0.f) + (s.i1 == ix ? s.l1 : 0.f);
-    }
-    wxs[k] = w;
-  }
-  __syncthreads();
+  for (int k = 0; k < NC; ++k) wxs[k] = wxl[lx][k];
   for (int r = row_lo + rg; r <= row_hi; r += 4) {
     const float* row = &gt[r - row_lo][0] - col_lo;
     float t = 0.f;
@@ -199,11 +218,11 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_tiled(const float* __restr
     if (cy >= g.Hs || cx >= g.Ws) continue;
     const int oy_lo = max(g.oy0, 2 * iy - 2), oy_hi = min(g.oy0 + g.Hw - 1, 2 * iy + 3);
     float acc = 0.f;
-    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
-      const Src s = source(oy, g.H, sh, g.align);
-      const float wy = (s.i0 == iy ? s.l0 : 0.f) + (s.i1 == iy ? s.l1 : 0.f);
-      if (wy == 0.f) continue;
-      acc = fmaf(wy, tmp[oy - row_lo][lx], acc);
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      const float wy = wyl[rg + 4 * rr][k];
+      if (oy_lo + k > oy_hi || wy == 0.f) continue;
+      acc = fmaf(wy, tmp[oy_lo + k - row_lo][lx], acc);
     }
     gin[((size_t)blockIdx.y * g.Hs + cy) * g.Ws + cx] = acc;
   }
