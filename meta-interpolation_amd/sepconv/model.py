@@ -209,8 +209,8 @@ class MetaNetwork(nn.Module):
         win = self._window(height, width, ph, pw)
         cy0, cy1, cx0, cx1 = win['crop']
         crop = combine[:, :, cy0:cy1, cx0:cx1].contiguous()
-        if (self.batch_subnets and width % 4 == 0 and not frame0.requires_grad and not frame1.requires_grad
-                and 4 * crop.size(0) * FILTER_TAPS * height * width * 4 < 2 ** 31):
+        if (self.batch_subnets and not frame0.requires_grad and not frame1.requires_grad
+                and FunctionSepconvPair.supported(frame0, crop.size(0), height, width, FILTER_TAPS)):
             return self._windowed_tail_batched(frame0, frame1, crop, win)
         rim = (HALF,) * 4
         dot1 = FunctionSepconv.apply(F.pad(frame0, rim, mode='replicate'),

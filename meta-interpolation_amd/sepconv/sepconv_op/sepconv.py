@@ -85,10 +85,11 @@ class FunctionSepconvPair(torch.autograd.Function):
     copied out, no gradients are concatenated.  The frames carry no gradient on this path (needs_input_grad is asserted)."""
 
     @staticmethod
-    def supported(input0, taps):
-        K, Wo = taps.size(1), taps.size(3)
-        return (input0.is_cuda and taps.is_cuda and input0.dtype == torch.float32 and K == 51 and input0.size(1) == 3 and Wo % 4 == 0
-                and taps.size(0) % 4 == 0 and taps.numel() * 4 < 2 ** 31)
+    def supported(frame, batch, height, width, taps=51):
+        """Can the strided entry points take `batch` samples of a [*, 3, height, width] frame (savfi_sepconv_*_taps_strided_f32: the
+        wave-specialised kernels -- K = 51, C = 3, width % 4 == 0, the interleaved tap tensor below 2^31 bytes)?"""
+        return (frame.is_cuda and frame.dtype == torch.float32 and frame.size(1) == 3 and taps == 51 and width % 4 == 0
+                and 4 * batch * taps * height * width * 4 < 2 ** 31)
 
     @staticmethod
     def forward(ctx, input0, input1, taps):
