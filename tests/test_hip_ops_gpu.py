@@ -119,6 +119,46 @@ def test_sepconv_does_not_write_out_of_bounds():
     assert _rel(bufs["out"][pad:pad + n_out].cpu().view(B, C, Ho, Wo), O.sepconv_forward_c(inp, v, h)) < 1e-5
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 96), (1, 256, 448), (3, 37, 52)])
+def test_sepconv_taps_strided_entry_points_equal_the_contiguous_ones(shape):
+    """savfi_sepconv_{fwd,bwd}_taps_strided_f32 through the C ABI: v / h (and gV / gH) as slices of one interleaved [B * 4, 51, Ho, Wo]
+    buffer (tap_bstride = 4 * 51, the layout sepconv/model.py's batched Subnets leave) give bit for bit what the contiguous entry
+    points give on copies of the slices, the planes of the buffer the call does not own stay untouched, and the protocol counter stays
+    at zero; shapes the wave-specialised kernels do not take are refused, not mis-computed."""
+    B, Ho, Wo = shape
+    K, C = 51, 3
+    lib, st = _hip.lib(), _hip.current_stream()
+    g = torch.Generator().manual_seed(11)
+    inp = torch.rand(B, C, Ho + K - 1, Wo + K - 1, generator=g).to(DEV)
+    taps = (torch.randn(4 * B, K, Ho, Wo, generator=g) / 7).to(DEV)
+    gO = torch.randn(B, C, Ho, Wo, generator=g).to(DEV)
+    plane = K * Ho * Wo * 4
+    for s in (0, 2):                                  # (v, h) = sub-networks (s, s + 1)
+        v, h = taps.view(B, 4, K, Ho, Wo)[:, s].contiguous(), taps.view(B, 4, K, Ho, Wo)[:, s + 1].contiguous()
+        out_c, out_s = torch.empty(B, C, Ho, Wo, device=DEV), torch.empty(B, C, Ho, Wo, device=DEV)
+        _hip.check(lib.savfi_sepconv_fwd_f32(inp.data_ptr(), v.data_ptr(), h.data_ptr(), out_c.data_ptr(), B, C, Ho, Wo, K, st), "fwd")
+        _hip.check(lib.savfi_sepconv_fwd_taps_strided_f32(inp.data_ptr(), taps.data_ptr() + s * plane, taps.data_ptr() + (s + 1) * plane,
+                                                          out_s.data_ptr(), B, C, Ho, Wo, K, 4 * K, st), "fwd strided")
+        assert torch.equal(out_s, out_c)
+        gV, gH = torch.empty_like(v), torch.empty_like(h)
+        _hip.check(lib.savfi_sepconv_bwd_f32(inp.data_ptr(), v.data_ptr(), h.data_ptr(), gO.data_ptr(), None, gV.data_ptr(), gH.data_ptr(),
+                                             B, C, Ho, Wo, K, st), "bwd")
+        gT = torch.full_like(taps, float('nan'))
+        _hip.check(lib.savfi_sepconv_bwd_taps_strided_f32(inp.data_ptr(), taps.data_ptr() + s * plane, taps.data_ptr() + (s + 1) * plane,
+                                                          gO.data_ptr(), gT.data_ptr() + s * plane, gT.data_ptr() + (s + 1) * plane,
+                                                          B, C, Ho, Wo, K, 4 * K, st), "bwd strided")
+        gT5 = gT.view(B, 4, K, Ho, Wo)
+        assert torch.equal(gT5[:, s], gV) and torch.equal(gT5[:, s + 1], gH)
+        other = [k for k in range(4) if k not in (s, s + 1)]
+        assert torch.isnan(gT5[:, other]).all()       # the other sub-networks' planes were not written
+    assert lib.savfi_sepconv_ws_errors() == 0
+    # refused: a width the ws kernels do not take, a stride below K, other K
+    args = lambda Wo_, K_, stride: (inp.data_ptr(), taps.data_ptr(), taps.data_ptr(), gO.data_ptr(), B, C, Ho, Wo_, K_, stride, st)
+    assert lib.savfi_sepconv_fwd_taps_strided_f32(*args(Wo - 1, K, 4 * K)) == -3
+    assert lib.savfi_sepconv_fwd_taps_strided_f32(*args(Wo, K, K - 1)) == -2
+    assert lib.savfi_sepconv_fwd_taps_strided_f32(*args(Wo, 25, 100)) == -3
+
+
 def test_sepconv_argument_errors():
     lib = _hip.lib()
     x = torch.zeros(16, device=DEV)
