@@ -72,7 +72,7 @@ def test_train_loop_runs_from_a_vimeo_directory_with_the_toy_plugin(tmp_path, mo
 def test_unsupported_datasets_fail_loudly():
     import pytest
     system = build_toy_system(batch=1, steps=1)
-    system.args.synthetic, system.args.dataset = False, 'middlebury'
+    system.args.synthetic, system.args.dataset = False, 'davis'          # the one name of the reference's dispatch without a reader in its repository
     with pytest.raises(NotImplementedError):
         MetaLearningSystemDataLoader(system.args)
 
