@@ -32,6 +32,10 @@
 #include "sepconv_x6_shared.h"
 #include <type_traits>
 
+typedef int ws_i32x4 __attribute__((ext_vector_type(4)));
+// 16-byte raw buffer load (the clang builtin of this release narrows the b128 form to one dword: csrc/winograd.hip)
+__device__ f32x4 ws_raw_load_x4(ws_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+
 namespace {
 
 constexpr int WNT = 768;                            // 12 waves: per SIMD one MFMA wave and the two staging waves of its pair
@@ -81,11 +85,15 @@ __device__ unsigned ws_error_count = 0;
 #ifndef WS_TRACE
 #define WS_TRACE 0
 #endif
-__device__ unsigned long long ws_trace[12][16];
+__device__ unsigned long long ws_trace[16][16];
 #define WS_T(k) do { if (WS_TRACE) { const unsigned long long t_ = __builtin_readcyclecounter(); tr_[k] += t_ - tlast_; tlast_ = t_; } } while (0)
 
 typedef __attribute__((address_space(3))) unsigned lds_u32;
 
+__device__ __forceinline__ ws_i32x4 ws_rsrc4(const float* base, unsigned bytes) {
+  const unsigned long long q = reinterpret_cast<unsigned long long>(base);
+  return (ws_i32x4){(int)(unsigned)q, (int)(unsigned)(q >> 32), (int)bytes, 0x00020000};
+}
 __device__ __forceinline__ unsigned ws_peek(const unsigned* f) {
   const unsigned v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
@@ -736,6 +744,664 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------
+// The same filter gradients with TWO MFMA waves per SIMD (16 waves, 128 registers each): see the MFMA-wave comment inside.
+// LDS: window 103 680 B + 4 x (table 6 144 + gH tile 6 400 + tails 2 x 512) + side columns + flags = 157.5 KB.
+// ------------------------------------------------------------------------------------------------------------------------------------
+#ifndef WS2_DRAIN_LATE
+#define WS2_DRAIN_LATE 1
+#endif
+#ifndef WS2_ROWS_H
+#define WS2_ROWS_H 1
+#endif
+#ifndef WS2_ROW_LAG
+#define WS2_ROW_LAG 2
+#endif
+constexpr int W2NT = 1024;
+constexpr int W2PAIRB = XTAB + WTILEB + 1024;
+constexpr int W2SIDE_OFF = WPAIR_OFF + 4 * W2PAIRB;
+constexpr int W2FLAG_OFF = W2SIDE_OFF + WSIDEB;
+constexpr int W2LDS = W2FLAG_OFF + 256;
+static_assert(W2LDS <= 160 * 1024, "LDS per CU");
+enum { F2_PROG = 32, F2_TAIL_FULL = 48, F2_TAIL_FREE = 52 };       // + F_TAB_*, F_OUT_*, F_SLIDE, F_ERR of sepconv_bwd_ws; 16 progress slots
+__device__ __forceinline__ void ws2_wait_all_prog(unsigned* fl, int target) {
+  asm volatile("" ::: "memory");
+  const int l15 = (int)(threadIdx.x & 15);
+  int spins = 0;
+  while (true) {
+    const unsigned v = __hip_atomic_load(fl + F2_PROG + l15, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (__builtin_amdgcn_ballot_w64((int)v < target) == 0ull) break;
+    __builtin_amdgcn_s_sleep(2);
+    if ((++spins & 255) == 0 && (ws_peek(fl + F_ERR) != 0u || spins > WSPIN_LIMIT)) {
+      if ((threadIdx.x & 63) == 0) {
+        __hip_atomic_store(fl + F_ERR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        atomicAdd(&ws_error_count, 1u);
+      }
+      break;
+    }
+  }
+  asm volatile("" ::: "memory");
+}
+
+__global__ __launch_bounds__(W2NT) void sepconv_bwd_ws2(const float* __restrict__ in, const float* __restrict__ v,
+                                                      const float* __restrict__ h, const float* __restrict__ gO,
+                                                      float* __restrict__ gV, float* __restrict__ gH,
+                                                      int B, int Ho, int Wo, int nph, int ncol, int per_wg, int TB) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p = w & 3, wc = p & 1, wr0 = p >> 1;
+  const int role = w >> 2;                          // 0, 1: MFMA waves A, B (even / odd units), 2: h-side staging wave, 3: v-side staging wave
+  const bool staging = role >= 2;
+  const int j = lane & 15, kg = lane >> 4;
+  char* const tab = smem + WPAIR_OFF + p * W2PAIRB;
+  float* const tile = reinterpret_cast<float*>(tab + XTAB);
+  float* const tailb = reinterpret_cast<float*>(tab + XTAB + WTILEB);      // [unit parity][column 14 | 15][64 tap rows]
+  float* const side = reinterpret_cast<float*>(smem + W2SIDE_OFF);
+  unsigned* const fl = reinterpret_cast<unsigned*>(smem + W2FLAG_OFF);
+
+  const unsigned long long t_kernel0 = WS_TRACE ? __builtin_readcyclecounter() : 0ull;
+  const int total = B * ncol * nph;
+  const int g0 = blockIdx.x * per_wg, g1 = min(g0 + per_wg, total);
+  if (g0 >= g1) return;
+  const int Hi = Ho + XK - 1, Wi = Wo + XK - 1;
+  const unsigned plane_b = (unsigned)Ho * (unsigned)Wo * 4u;
+  const __amdgpu_buffer_rsrc_t hsrc = x6_rsrc(h, (unsigned)((B - 1) * TB + XK) * plane_b);
+  const __amdgpu_buffer_rsrc_t vsrc = x6_rsrc(v, (unsigned)((B - 1) * TB + XK) * plane_b);
+  const __amdgpu_buffer_rsrc_t gsrc = x6_rsrc(gO, (unsigned)(B * XC) * plane_b);
+  const __amdgpu_buffer_rsrc_t isrc = x6_rsrc(in, (unsigned)(B * XC) * (unsigned)(Hi * Wi) * 4u);
+  const __amdgpu_buffer_rsrc_t gvdst = x6_rsrc(gV, (unsigned)((B - 1) * TB + XK) * plane_b);
+  const __amdgpu_buffer_rsrc_t ghdst = x6_rsrc(gH, (unsigned)((B - 1) * TB + XK) * plane_b);
+
+  auto pix_off = [&](int b, int x0, int y, int ch) {
+    return (unsigned)b * (unsigned)ch * plane_b + (unsigned)(min(y, Ho - 1) * Wo + min(x0 + 16 * wc + j, Wo - 1)) * 4u;
+  };
+  // Tap registers (as sepconv_bwd_x6): lane (j, kg) holds 7 PAIRS of neighbouring taps t0 + 8 a + {0, 1}: a split pair is exactly the
+  // dword a table position takes.  v: t0 = 2 kg.  h: t0 = 2 kg - (j & 1): the band position i = tap + j of a pair starts even.
+  auto load_taps = [&](float (&regs)[XNP][2], __amdgpu_buffer_rsrc_t src, int b, int x0, int y, int t0) {
+    const unsigned pix = pix_off(b, x0, y, TB);
+    const unsigned voff = pix + (unsigned)(t0 + 1) * plane_b;
+    regs[0][0] = x6_bload(src, pix + (unsigned)max(t0, 0) * plane_b, 0u);
+    regs[0][1] = x6_bload(src, voff, 0u);
+#pragma unroll
+    for (int a = 1; a < XNP - 1; ++a)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) regs[a][e] = x6_bload(src, voff, (unsigned)(8 * a + e - 1) * plane_b);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) regs[XNP - 1][e] = x6_bload(src, pix + (unsigned)min(8 * (XNP - 1) + t0 + e, XK - 1) * plane_b, 0u);
+  };
+  auto tap_or_zero = [&](const float (&regs)[XNP][2], int a, int e, int t0) {
+    if (a == 0 && e == 0) return t0 < 0 ? 0.f : regs[0][0];
+    if (a == XNP - 1) return (8 * (XNP - 1) + t0 + e < XK) ? regs[a][e] : 0.f;
+    return regs[a][e];
+  };
+  const int h_t0 = 2 * kg - (j & 1), v_t0 = 2 * kg;
+  // h band of the unit's 16 pixels -> table [piece][i / 8][j][i % 8], i = tap + j < 64 (zero elsewhere)
+  auto write_h_table = [&](const float (&regs)[XNP][2]) {
+#pragma unroll
+    for (int k = 0; k < XTAB / 1024; ++k) *reinterpret_cast<u32x4*>(tab + (k * 64 + lane) * 16) = (u32x4){0u, 0u, 0u, 0u};
+    const int base2 = 2 * kg + (j & ~1);
+    char* const lb = tab + (base2 >> 3) * 256 + j * 16 + (base2 & 7) * 2;
+#pragma unroll
+    for (int a = 0; a < XNP; ++a) {
+      unsigned h1, h2, h3;
+      x6_split2(tap_or_zero(regs, a, 0, h_t0), tap_or_zero(regs, a, 1, h_t0), h1, h2, h3);
+      char* d = lb + a * 256;
+      if (a < XNP - 1 || base2 < 16) {                               // positions 64, 65 belong to the tail
+        *reinterpret_cast<unsigned*>(d) = h1;
+        *reinterpret_cast<unsigned*>(d + XTABP) = h2;
+        *reinterpret_cast<unsigned*>(d + 2 * XTABP) = h3;
+      }
+    }
+  };
+  // v taps -> table position of tap fy: k step fy / 32, k group (fy % 16) / 4, element fy % 4 + 4 * ((fy / 16) % 2)
+  auto write_v_table = [&](const float (&regs)[XNP][2]) {
+    char* const lb = tab + (kg >> 1) * 256 + j * 16 + (kg & 1) * 4;
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+      unsigned h1 = 0u, h2 = 0u, h3 = 0u;
+      if (a < XNP) x6_split2(tap_or_zero(regs, a, 0, v_t0), tap_or_zero(regs, a, 1, v_t0), h1, h2, h3);
+      char* d = lb + (4 * (a >> 2) + 2 * (a & 1)) * 256 + 8 * ((a >> 1) & 1);
+      *reinterpret_cast<unsigned*>(d) = h1;
+      *reinterpret_cast<unsigned*>(d + XTABP) = h2;
+      *reinterpret_cast<unsigned*>(d + 2 * XTABP) = h3;
+    }
+  };
+  auto tr_read = [&](int addr) -> bf16x4 {
+    typedef __attribute__((address_space(3))) bf16x4 lds_b4;
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(smem + addr));
+  };
+  auto rdlane = [&](float x, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l)); };
+
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // six products, small terms first
+  const int permk = ((kg & 1) << 1) | (kg >> 1);
+  const int L = lane & 15;
+  const int pq = lane & 3, fq = lane >> 2;
+  // Order of the pair's ONE tap table: h(2 q), h(2 q + 1), v(2 q), v(2 q + 1), h(2 q + 2) ...  With the single-MFMA-wave order (h(n), v(n),
+  // h(n + 1) ...) wave B's band could only be built after wave A had taken v(n) at the END of its gV pass: the two waves' gV passes
+  // and both table builds formed one serial chain (measured: each MFMA wave idled ~4 000 ticks per unit for its next band).  In this
+  // order B's band follows A's at once, the two waves run ~one table build apart, and every build overlaps MFMA loops.
+  auto seq_h = [](int n) { return 4 * (n >> 1) + 1 + (n & 1); };
+  auto seq_v = [](int n) { return 4 * (n >> 1) + 3 + (n & 1); };
+
+  // The run loop exists twice, once per role (a wave never changes role): in one loop with a run-time branch every per-lane constant
+  // of the staging program stays live through the MFMA program and vice versa (168 registers: 44 spilled, 180 bytes of scratch per lane).
+  auto run_all = [&](auto stg_) __attribute__((always_inline)) {
+  constexpr bool STG = decltype(stg_)::value;
+  int g = g0;
+#pragma unroll 1
+  while (g < g1) {
+    // ---- a run: phases ph0 .. ph0 + nrun - 1 of strip (b, x0) ---------------------------------------------------------------
+    const int s = g / nph, ph0 = g - s * nph, b = s / ncol, x0 = (s - b * ncol) * XMC;
+    const int run_end = min(g1, g + (nph - ph0)), nrun = run_end - g, N = 2 * nrun;
+    const int R0 = XPR * ph0;
+    auto unit_y = [&](int n) { return R0 + XPR * (n >> 1) + wr0 + 2 * (n & 1); };
+
+    float gp[XC];                                   // cotangent of the unit at hand (staging: of the next one once the tails have theirs)
+    __syncthreads();                                // every wave has left the previous run's window, tables and flags
+    if (tid < 64) fl[tid] = 0u;
+    {
+      const unsigned go = pix_off(b, x0, unit_y(0), XC);
+#pragma unroll
+      for (int c = 0; c < XC; ++c) gp[c] = x6_bload(gsrc, go, (unsigned)c * plane_b);
+    }
+    if (tid < XNT) {                                 // the window prologue keeps sepconv_x6's mapping of 512 threads
+#pragma unroll 1
+      for (int r = 0; r < XWIN; r += 16) {
+        X6Rows<16> sr;
+        x6_rows_load<16>(sr, isrc, b, x0, R0 + r, Hi, Wi, tid);
+        x6_rows_write<16>(sr, smem, R0 + r, tid, W2SIDE_OFF);
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+
+    if constexpr (!STG) {
+      // =========================================== MFMA waves A / B ===========================================================
+      // TWO MFMA waves per SIMD: wave A (role 0) runs the even units of the pair, wave B (role 1) the odd ones, both passes each.  They
+      // take the pair's one tap table in turn (h(0) A, v(0) A, h(1) B, v(1) B, ... : the sequence numbers already serialise it), so B
+      // runs half a unit behind A and one wave's epilogues -- cotangent scaling, tails, stores, tile writes -- and the latency of its
+      // fragment reads fall under the OTHER wave's MFMAs (tools/mfma_chain_probe: two waves per SIMD whose fragment reads are fully
+      // exposed still keep the matrix pipe at one MFMA per 19 ticks; the same work inside ONE wave's MFMA stream cost 20 ticks per
+      // instruction, profiles/r04_ws_experiments.txt).  128 registers per wave (16 waves): ONE set of A fragments, a pass in two
+      // halves of 6 accumulator tiles.  gV with swapped operands leaves from the registers (no tile, no drain by the h-side wave).
+      __builtin_amdgcn_s_setprio(WS_PRIO);
+      unsigned long long tr_[16] = {0}, tlast_ = __builtin_readcyclecounter();
+      const int par = role;                            // 0: even units, 1: odd units
+      bf16x8 bq[2][3], aq[2][3];
+      int rowoff[4], rowh[2][2];
+      const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+      auto peek_raw = [&](int idx) { return __hip_atomic_load(fl + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+      auto behind = [&](unsigned peeked, int target) { return (int)__builtin_amdgcn_readfirstlane((int)peeked) < target; };
+      auto set_rows = [&](int y) {
+        const int lo_ = ws_lane(), jo = lo_ & 15, ko = lo_ >> 4, Lo = jo;
+        const int pk = ((ko & 1) << 1) | (ko >> 1);
+#pragma unroll
+        for (int m = 0; m < 3; ++m) rowoff[m] = ((y + 16 * m + jo) & (XWIN - 1)) * 16 + (2 * wc + pk) * XBLK;
+        rowoff[3] = ((y + 48 + min(jo & 3, 2)) & (XWIN - 1)) * 16 + (2 * wc + pk) * XBLK + min(jo >> 2, 2) * XPLANE;
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf)
+            rowh[st][hf] = ((y + 32 * st + 16 * hf + 4 * ko + (Lo >> 2)) & (XWIN - 1)) * 16 + (2 * wc + ((Lo & 3) >> 1)) * XBLK + (Lo & 1) * 8;
+      };
+      // gV blocks uu = 0..9 as in sepconv_bwd_ws: 0..5 = (channel uu / 2, k step uu % 2) x tiles {0, 1}; 6, 7 = k step x {tile 2 of channel 0, of
+      // channel 1}; 8, 9 = k step x {tile 2 of channel 2, packed tile (tap rows 48..50 of the three channels)}
+      auto gv_tile = [](int uu, int t) { return uu < 6 ? 3 * (uu >> 1) + t : uu < 8 ? 3 * t + 2 : (t == 0 ? 8 : 9); };
+      auto load_av = [&](int uu) {
+        const int st = uu & 1;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const int ai = gv_tile(uu, t), c = ai == 9 ? 0 : ai / 3, m = ai == 9 ? 3 : ai % 3;
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc)
+            aq[t][pc] = *reinterpret_cast<const bf16x8*>(smem + (pc * 3 + c) * XPLANE + 4 * st * XBLK + rowoff[m]);
+        }
+      };
+      auto load_ah = [&](int c, int st, int mp) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) {
+            const int base = (pc * 3 + c) * XPLANE + 2 * (2 * mp + t) * XBLK;
+            const bf16x4 lo = tr_read(base + rowh[st][0]), hi = tr_read(base + rowh[st][1]);
+            aq[t][pc] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+          }
+      };
+      auto read_bh = [&]() {
+        const int lo_ = ws_lane(), jo = lo_ & 15, ko = lo_ >> 4, pk = ((ko & 1) << 1) | (ko >> 1);
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) bq[st][pc] = *reinterpret_cast<const bf16x8*>(tab + pc * XTABP + (4 * st + pk) * 256 + jo * 16);
+      };
+      auto read_bv = [&]() {
+        const int lo_ = ws_lane(), jo = lo_ & 15, ko = lo_ >> 4;
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) bq[st][pc] = *reinterpret_cast<const bf16x8*>(tab + pc * XTABP + (4 * st + ko) * 256 + jo * 16);
+      };
+      const ws_i32x4 g4rs = ws_rsrc4(gO, (unsigned)(B * XC) * plane_b);
+      f32x4 G[XC];                                     // gV's cotangent: four pixels of a tap row per lane
+      float gj[XC];                                    // gH's: pixel j
+      auto load_G = [&](int y) {
+        const int ko = ws_lane() >> 4;
+        const unsigned off = (unsigned)b * (unsigned)XC * plane_b + (unsigned)(min(y, Ho - 1) * Wo + min(x0 + 16 * wc + 4 * ko, Wo - 4)) * 4u;
+#pragma unroll
+        for (int c = 0; c < XC; ++c) G[c] = ws_raw_load_x4(g4rs, (int)off, (int)((unsigned)c * plane_b), 0);
+      };
+      auto load_gj = [&](int y) {
+        const unsigned go = pix_off(b, x0, y, XC);
+#pragma unroll
+        for (int c = 0; c < XC; ++c) gj[c] = x6_bload(gsrc, go, (unsigned)c * plane_b);
+      };
+      auto dpp1 = [](float x, auto ctrl) {              // lane L takes lane L + n of its row of 16 (zero beyond the row)
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true));
+      };
+      if (par < N) {
+        set_rows(unit_y(par));
+        load_G(unit_y(par));
+        load_gj(unit_y(par));
+        ws_wait(fl, F_TAB_FULL + p, seq_h(par));
+        read_bh();
+        ws_set(fl, F_TAB_FREE + p, seq_h(par));
+      }
+#pragma unroll 1
+      for (int n = par; n < N; n += 2) {
+        const int q = n >> 1;
+        const int y = unit_y(n), n2 = n + 2;
+        WS_T(0);
+        const float* const tb = tailb + (n & 1) * 128;
+        unsigned qoff;                                  // this lane's gV piece: tap row L, pixels 4 kg .. 4 kg + 3 of output row y
+        bool last;
+        int Lo;
+        {
+          const int lo_ = ws_lane(), xq = x0 + 16 * wc + 4 * (lo_ >> 4);
+          Lo = lo_ & 15; last = (lo_ >> 4) == 3;
+          qoff = (y < Ho && xq < Wo) ? (unsigned)b * (unsigned)TB * plane_b + (unsigned)(y * Wo + xq) * 4u + (unsigned)Lo * plane_b : X_OOR;
+        }
+        // ---------------- gV, first half: tap rows 0..31 (tiles 0, 1 of the three channels) ----------------
+        {
+          f32x4 acc[6];
+#pragma unroll
+          for (int i = 0; i < 6; ++i) acc[i] = zero4;
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int uu = 0; uu < 6; ++uu) {
+            load_av(uu);
+            if (!WS_EXP_NOMFMA) {
+#pragma unroll
+              for (int qq = 0; qq < 6; ++qq)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                  acc[2 * (uu >> 1) + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[uu & 1][PB[qq]], aq[t][PA[qq]], acc[2 * (uu >> 1) + t], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          WS_T(3);
+          ws_wait(fl, F2_TAIL_FULL + p, n + 1);
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const float t14 = tb[16 * t + Lo], t15 = tb[64 + 16 * t + Lo];
+            f32x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float s = G[0][r] * acc[t][r];
+              s = fmaf(G[1][r], acc[2 + t][r], s);
+              s = fmaf(G[2][r], acc[4 + t][r], s);
+              o[r] = s;
+            }
+            o[2] += last ? t14 : 0.f;
+            o[3] += last ? t15 : 0.f;
+            x6_bstore4(o, gvdst, qoff, (unsigned)(16 * t) * plane_b);
+          }
+          WS_T(4);
+        }
+        // ---------------- gV, second half: tap rows 32..47 of the three channels and the packed tile (rows 48..50) ----------------
+        {
+          f32x4 acc[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[i] = zero4;
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int uu = 6; uu < 10; ++uu) {
+            load_av(uu);
+            if (!WS_EXP_NOMFMA) {
+#pragma unroll
+              for (int qq = 0; qq < 6; ++qq)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                  acc[2 * ((uu - 6) >> 1) + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[uu & 1][PB[qq]], aq[t][PA[qq]], acc[2 * ((uu - 6) >> 1) + t], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          WS_T(5);
+          // the band's fragments are consumed: v of this unit (the table goes back to the staging waves before the epilogue)
+          ws_wait(fl, F_TAB_FULL + p, seq_v(n));
+          read_bv();
+          ws_set(fl, F_TAB_FREE + p, seq_v(n));
+          {
+            const float t14 = tb[32 + Lo], t15 = tb[64 + 32 + Lo], p14 = tb[48 + Lo], p15 = tb[64 + 48 + Lo];
+            asm volatile("" ::: "memory");
+            ws_set(fl, F2_TAIL_FREE + p, n + 1);
+            const int cs = Lo >> 2;                     // packed tile: column L = 4 c + r' is tap row 48 + r' of channel c
+            f32x4 o, xp;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float s = G[0][r] * acc[0][r];
+              s = fmaf(G[1][r], acc[1][r], s);
+              s = fmaf(G[2][r], acc[2][r], s);
+              o[r] = s;
+              const float gs = cs == 0 ? G[0][r] : cs == 1 ? G[1][r] : cs == 2 ? G[2][r] : 0.f;
+              const float xv = gs * acc[3][r];
+              const float x1 = dpp1(xv, std::integral_constant<int, 0x104>{}), x2 = dpp1(xv, std::integral_constant<int, 0x108>{});
+              xp[r] = (xv + x1) + x2;
+            }
+            o[2] += last ? t14 : 0.f;
+            o[3] += last ? t15 : 0.f;
+            xp[2] += last ? p14 : 0.f;
+            xp[3] += last ? p15 : 0.f;
+            x6_bstore4(o, gvdst, qoff, 32u * plane_b);
+            x6_bstore4(xp, gvdst, Lo < 3 ? qoff : X_OOR, 48u * plane_b);
+          }
+          load_G(unit_y(min(n2, N - 1)));
+          WS_T(6);
+        }
+        // ---------------- gH: tiles {0, 1} then {2, 3} of the three channels ----------------
+#pragma unroll
+        for (int mp = 0; mp < 2; ++mp) {
+          f32x4 acc[6];
+#pragma unroll
+          for (int i = 0; i < 6; ++i) acc[i] = zero4;
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int cb = 0; cb < 6; ++cb) {
+            const int c = cb >> 1, st = cb & 1;
+            load_ah(c, st, mp);
+            if (!WS_EXP_NOMFMA) {
+#pragma unroll
+              for (int qq = 0; qq < 6; ++qq)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                  acc[2 * c + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[t][PA[qq]], bq[st][PB[qq]], acc[2 * c + t], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          WS_T(mp == 0 ? 9 : 10);
+          if (mp == 1) {
+            ws_set(fl, F2_PROG + w, q + 1);                            // this wave's window reads of phase q are over (one unit per phase and wave)
+            // the next unit of this wave: its h band, rows -- before this pass's last epilogue
+            if (n2 < N) {
+              ws_wait(fl, F_TAB_FULL + p, seq_h(n2));
+              read_bh();
+              ws_set(fl, F_TAB_FREE + p, seq_h(n2));
+              const int q2 = n2 >> 1;
+              if (q2 >= 2) ws_wait(fl, F_SLIDE, 8 * (2 * q2 - 3));
+              set_rows(unit_y(n2));
+            }
+          }
+          if (mp == 0) ws_wait(fl, F_OUT_FREE + p, n);        // the previous unit's tile is drained
+          {
+            const int lo_ = ws_lane();
+            float* const tw = tile + (4 * (lo_ >> 4) - (lo_ & 15) + 15) * WPV + (lo_ & 15);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                float s = gj[0] * acc[t][r];
+                s = fmaf(gj[1], acc[2 + t][r], s);
+                s = fmaf(gj[2], acc[4 + t][r], s);
+                tw[(16 * (2 * mp + t) + r) * WPV] = s;
+              }
+          }
+          if (mp == 1) {
+            ws_set(fl, F_OUT_FULL + p, n + 1);
+            load_gj(unit_y(min(n2, N - 1)));
+          }
+          WS_T(mp == 0 ? 11 : 12);
+        }
+      }
+      __builtin_amdgcn_s_setprio(0);
+      if (WS_TRACE && blockIdx.x == 0 && lane == 0)
+        for (int k = 0; k < 16; ++k) ws_trace[w][k] += tr_[k];
+    } else {
+      // =========================================== staging waves ===============================================================
+      // role 1 (waves 4..7): the h side of the pair's units -- h taps, band table, gV tail columns, gV tile -> HBM, window row 60 + 2 n
+      // role 2 (waves 8..11): the v side -- v taps, table, gH tail columns, gH tile -> HBM, window row 61 + 2 n
+      const bool hside = role == 2;
+      const int ptid = tid - (hside ? 512 : 768);
+      const int gcol = ptid & 127, ggrp = ptid >> 7;        // granule: one window row per role, thread = (column, channels {0, 1} | {2})
+      const int gcell = (gcol >> 3) * XBLK + (gcol & 7) * 2;
+      const int gsidx = gcol == 64 ? 0 : gcol == 65 ? 1 : gcol == 80 ? 2 : gcol == 81 ? 3 : -1;
+      const unsigned gcolb = (unsigned)min(x0 + gcol, Wi - 1) * 4u;
+      const int gc0 = ggrp == 0 ? 0 : 2, gc1 = ggrp == 0 ? 1 : 2;
+      unsigned long long tr_[16] = {0}, tlast_ = __builtin_readcyclecounter();
+      float hreg[XNP][2], vreg[XNP][2];               // taps of the unit at hand, then of the next one (one of the two per role)
+      if (hside) load_taps(hreg, hsrc, b, x0, unit_y(0), h_t0);
+      else load_taps(vreg, vsrc, b, x0, unit_y(0), v_t0);
+      float s6414 = 0.f, s6415 = 0.f, s6515 = 0.f;   // v side: gH tail sums of the unit whose tile is drained next
+      float n6414 = 0.f, n6415 = 0.f, n6515 = 0.f;   // ... of the unit at hand
+      unsigned qoff_prev = X_OOR;
+      // Iteration n: (1) the table of unit n -- FIRST: it is what the MFMA wave waits for next --, (2) the tile of unit n - 1 -> HBM,
+      // (3) tail columns of unit n, taps of unit n + 1, (4) one new window row.  Iteration N only drains the last tile.
+#pragma unroll 1
+      for (int n = 0; n <= N; ++n) {
+        const bool live = n < N;
+        const int nn = min(n, N - 1);
+        const int q = nn >> 1, u = nn & 1;
+        const int y = unit_y(nn), y1 = unit_y(min(nn + 1, N - 1));
+        const int xq = x0 + 16 * wc + 4 * pq;
+        const unsigned qoff = (live && y < Ho && xq < Wo) ? (unsigned)b * (unsigned)TB * plane_b + (unsigned)(y * Wo + xq) * 4u + (unsigned)fq * plane_b : X_OOR;
+        // one new window row per role and unit (rows R0 + 60 + 2 n + {0 | 1})
+        float gr0, gr1;
+        // The window rows trail the tables by WS2_ROW_LAG units: row pair m is loaded and written in iteration m + LAG.  Its write has to wait
+        // until every wave is past phase m / 2 -- with two MFMA waves per SIMD wave B runs half a unit behind A, and a staging wave that
+        // sits in that wait cannot build the next table (measured: the MFMA waves idled ~4 000 ticks per unit for tables); two units later
+        // the condition holds when the wave gets there, and the consumers only need row pair m from phase m / 2 + 2 on.
+        const int rn = nn - WS2_ROW_LAG;
+        // BOTH rows of the pair are the h-side wave's (WS2_ROWS_H): the v-side wave is the busiest of the four (tap loads behind its tail
+        // sums, the gH drain), the h-side wave lost its drain when gV began to leave from the MFMA waves' registers
+        const int grow = R0 + 60 + 2 * max(rn, 0) + ((hside || WS2_ROWS_H) ? 0 : 1);
+        float gr2 = 0.f, gr3 = 0.f;
+        if (hside || !WS2_ROWS_H) {
+          const int rr = min(grow, Hi - 1);
+          gr0 = WS_EXP_NOSTAGE ? 0.f : x6_bload(isrc, (unsigned)(((b * XC + gc0) * Hi + rr) * Wi) * 4u + gcolb, 0u);
+          gr1 = WS_EXP_NOSTAGE ? 0.f : x6_bload(isrc, (unsigned)(((b * XC + gc1) * Hi + rr) * Wi) * 4u + gcolb, 0u);
+          if (WS2_ROWS_H) {
+            const int r2 = min(grow + 1, Hi - 1);
+            gr2 = WS_EXP_NOSTAGE ? 0.f : x6_bload(isrc, (unsigned)(((b * XC + gc0) * Hi + r2) * Wi) * 4u + gcolb, 0u);
+            gr3 = WS_EXP_NOSTAGE ? 0.f : x6_bload(isrc, (unsigned)(((b * XC + gc1) * Hi + r2) * Wi) * 4u + gcolb, 0u);
+          }
+        } else { gr0 = 0.f; gr1 = 0.f; }
+        float g14[XC], g15[XC];
+#pragma unroll
+        for (int c = 0; c < XC; ++c) { g14[c] = rdlane(gp[c], 14); g15[c] = rdlane(gp[c], 15); }
+        const int fyl = min(lane, XK - 1);
+        const int tslot = (y + fyl) & (XWIN - 1);
+        WS_T(0);
+        if (hside) {
+          // what the tail columns need of this unit's taps, before the registers take the next unit's
+          const float h50_14 = rdlane(hreg[6][0], 14 + 16), h49_15 = rdlane(hreg[6][0], 15 + 16), h50_15 = rdlane(hreg[6][1], 15 + 16);
+          // (1) the h band of unit n takes the table (the MFMA wave holds v of unit n - 1 in registers)
+          if (live) {
+            ws_wait(fl, F_TAB_FREE + p, seq_h(n) - 1);
+            WS_T(1);
+            __builtin_amdgcn_s_setprio(WS_PRIO_TABLE);
+            if (!WS_EXP_NOSTAGE) write_h_table(hreg);
+            ws_set(fl, F_TAB_FULL + p, seq_h(n));
+            __builtin_amdgcn_s_setprio(0);
+            WS_T(2);
+          }
+          // (2) (gV leaves from the MFMA waves' registers: nothing to drain on this side)
+          // (3) tail columns of gV (i = 64: pixel 14 tap 50, pixel 15 tap 49; i = 65: pixel 15 tap 50): lane = tap row fy
+          if (live && u == 0 && q >= 2) ws_wait(fl, F_SLIDE, 8 * (2 * q - 3));
+          float a64[XC], a65[XC];
+#pragma unroll
+          for (int c = 0; c < XC; ++c) {
+            const f32x2 sv = *reinterpret_cast<const f32x2*>(side + (c * XWIN + tslot) * 4 + 2 * wc);
+            a64[c] = sv.x; a65[c] = sv.y;
+          }
+          asm volatile("" ::: "memory");
+          if (live && u == 1) ws_set(fl, F2_PROG + w, q + 1);
+          if (!WS_EXP_NOSTAGE) load_taps(hreg, hsrc, b, x0, y1, h_t0);
+          {
+            float t14 = 0.f, t15 = 0.f;
+#pragma unroll
+            for (int c = 0; c < XC; ++c) {
+              t14 = fmaf(g14[c] * h50_14, a64[c], t14);
+              t15 = fmaf(g15[c] * h49_15, a64[c], t15);
+              t15 = fmaf(g15[c] * h50_15, a65[c], t15);
+            }
+            // the MFMA wave of unit n adds them to pixels 14, 15 when it stores the unit's gV rows (two buffers by unit parity)
+            if (live) {
+              ws_wait(fl, F2_TAIL_FREE + p, n - 1);
+              float* const tbw = tailb + (n & 1) * 128;
+              tbw[lane] = lane < XK ? t14 : 0.f;
+              tbw[64 + lane] = lane < XK ? t15 : 0.f;
+              ws_set(fl, F2_TAIL_FULL + p, n + 1);
+            }
+          }
+          WS_T(3);
+        } else {
+          // (1) v of unit n takes the table (the MFMA wave holds the h band of unit n in registers)
+          float v14 = 0.f, v15 = 0.f;
+          if (live) {
+            ws_wait(fl, F_TAB_FREE + p, seq_v(n) - 1);
+            WS_T(1);
+            __builtin_amdgcn_s_setprio(WS_PRIO_TABLE);
+            if (!WS_EXP_NOSTAGE) write_v_table(vreg);
+            // v of pixels 14, 15 by tap row (lane = fy) for the tail columns: read back from the table's pieces BEFORE the table is
+            // published -- once the MFMA wave has taken its fragments the h-side wave refills the table
+            if (!WS_EXP_NOSTAGE) {
+              const int f5 = fyl & 31;
+              const char* tp = tab + (4 * (fyl >> 5) + ((f5 & 15) >> 2)) * 256 + ((f5 & 3) + 4 * ((f5 >> 4) & 1)) * 2;
+              unsigned short r14[3], r15[3];
+#pragma unroll
+              for (int pc = 0; pc < 3; ++pc) {
+                r14[pc] = *reinterpret_cast<const unsigned short*>(tp + pc * XTABP + 14 * 16);
+                r15[pc] = *reinterpret_cast<const unsigned short*>(tp + pc * XTABP + 15 * 16);
+              }
+              asm volatile("" ::: "memory");
+              ws_set(fl, F_TAB_FULL + p, seq_v(n));
+#pragma unroll
+              for (int pc = 0; pc < 3; ++pc) {
+                v14 += __uint_as_float((unsigned)r14[pc] << 16);
+                v15 += __uint_as_float((unsigned)r15[pc] << 16);
+              }
+            } else {
+              ws_set(fl, F_TAB_FULL + p, seq_v(n));
+            }
+            __builtin_amdgcn_s_setprio(0);
+            WS_T(2);
+          }
+          // (2) the gH tile of unit n - 1 is drained at the END of this iteration (WS2_DRAIN_LATE): with two MFMA waves per SIMD gH(n - 1) is
+          // still being computed when this iteration starts, and a wave parked here builds no table and issues no tap load
+          if (!WS2_DRAIN_LATE) {
+          // (2) the gH tile of unit n - 1 -> HBM
+            if (n > 0) ws_wait(fl, F_OUT_FULL + p, n);
+            WS_T(6);
+#pragma unroll
+            for (int qq = 0; qq < (WS_EXP_NOSTAGE ? 0 : 4); ++qq) {
+              const int fx = fq + 16 * qq;
+              f32x4 v4 = *reinterpret_cast<const f32x4*>(tile + (fx + 15) * WPV + 4 * pq);
+              // window columns 64, 65 (pixel 14 tap 50; pixel 15 taps 49, 50) are the VALU tail sums
+              if (pq == 3 && fx == 50) { v4[2] = s6414; v4[3] = s6515; }
+              if (pq == 3 && fx == 49) v4[3] = s6415;
+              x6_bstore4(v4, ghdst, (qq < 3 || fq < 3) ? qoff_prev : X_OOR, (unsigned)(16 * qq) * plane_b);
+            }
+            if (n > 0) ws_set(fl, F_OUT_FREE + p, n);
+            WS_T(7);
+          }
+          // (3) tail columns of gH (q = 64, 65: taps 50 / 49, 50 of pixels 14, 15): lane = tap row fy
+          if (live && u == 0 && q >= 2) ws_wait(fl, F_SLIDE, 8 * (2 * q - 3));
+          float a64[XC], a65[XC];
+#pragma unroll
+          for (int c = 0; c < XC; ++c) {
+            const f32x2 sv = *reinterpret_cast<const f32x2*>(side + (c * XWIN + tslot) * 4 + 2 * wc);
+            a64[c] = sv.x; a65[c] = sv.y;
+          }
+          asm volatile("" ::: "memory");
+          if (live && u == 1) ws_set(fl, F2_PROG + w, q + 1);
+          if (!WS_EXP_NOSTAGE) {
+            const float lv = lane < XK ? 1.f : 0.f;
+            v14 *= lv; v15 *= lv;
+            float sa = 0.f, sb = 0.f, sc = 0.f;
+#pragma unroll
+            for (int c = 0; c < XC; ++c) {
+              sa = fmaf(g14[c] * v14, a64[c], sa);
+              sb = fmaf(g15[c] * v15, a64[c], sb);
+              sc = fmaf(g15[c] * v15, a65[c], sc);
+            }
+            n6414 = ws_wave_sum(sa);
+            n6415 = ws_wave_sum(sb);
+            n6515 = ws_wave_sum(sc);
+          }
+          if (!WS2_DRAIN_LATE) { s6414 = n6414; s6415 = n6415; s6515 = n6515; }
+          asm volatile("" ::: "memory");
+          if (!WS_EXP_NOSTAGE) load_taps(vreg, vsrc, b, x0, y1, v_t0);
+          WS_T(3);
+        }
+        if (!WS_EXP_NOSTAGE) {
+          const unsigned go = pix_off(b, x0, y1, XC);
+#pragma unroll
+          for (int c = 0; c < XC; ++c) gp[c] = x6_bload(gsrc, go, (unsigned)c * plane_b);
+        }
+        // (4) the new window row (slot of row 4 q - 4 + 2 u + {0 | 1}: behind every wave once phase q - 1 is done)
+        if (live && rn >= 0 && (hside || !WS2_ROWS_H)) {
+          if ((rn >> 1) >= 1) ws2_wait_all_prog(fl, rn >> 1);
+          WS_T(4);
+#pragma unroll
+          for (int rw = 0; rw < (WS2_ROWS_H ? 2 : 1); ++rw) {
+            const int slot = (grow + rw) & (XWIN - 1);
+            const float ga = rw == 0 ? gr0 : gr2, gb = rw == 0 ? gr1 : gr3;
+            unsigned h1, h2, h3;
+            x6_split2(ga, gb, h1, h2, h3);
+            if (gcol < 8 * XNBLK && !WS_EXP_NOSTAGE) {
+              char* d0 = smem + gcell + slot * 16 + gc0 * XPLANE;
+              x6_st16(d0, h1); x6_st16(d0 + 3 * XPLANE, h2); x6_st16(d0 + 6 * XPLANE, h3);
+              if (ggrp == 0) { x6_st16(d0 + XPLANE, h1 >> 16); x6_st16(d0 + 4 * XPLANE, h2 >> 16); x6_st16(d0 + 7 * XPLANE, h3 >> 16); }
+            }
+            if (gsidx >= 0) {
+              side[(gc0 * XWIN + slot) * 4 + gsidx] = ga;
+              side[(gc1 * XWIN + slot) * 4 + gsidx] = gb;
+            }
+            asm volatile("" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add(fl + F_SLIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            asm volatile("" ::: "memory");
+          }
+          WS_T(5);
+        }
+        if (!hside && WS2_DRAIN_LATE) {
+          // (2) the gH tile of unit n - 1 -> HBM
+          if (n > 0) ws_wait(fl, F_OUT_FULL + p, n);
+          WS_T(6);
+#pragma unroll
+          for (int qq = 0; qq < (WS_EXP_NOSTAGE ? 0 : 4); ++qq) {
+            const int fx = fq + 16 * qq;
+            f32x4 v4 = *reinterpret_cast<const f32x4*>(tile + (fx + 15) * WPV + 4 * pq);
+            // window columns 64, 65 (pixel 14 tap 50; pixel 15 taps 49, 50) are the VALU tail sums
+            if (pq == 3 && fx == 50) { v4[2] = s6414; v4[3] = s6515; }
+            if (pq == 3 && fx == 49) v4[3] = s6415;
+            x6_bstore4(v4, ghdst, (qq < 3 || fq < 3) ? qoff_prev : X_OOR, (unsigned)(16 * qq) * plane_b);
+          }
+          if (n > 0) ws_set(fl, F_OUT_FREE + p, n);
+          WS_T(7);
+          s6414 = n6414; s6415 = n6415; s6515 = n6515;
+        }
+        qoff_prev = qoff;
+      }
+      if (WS_TRACE && blockIdx.x == 0 && lane == 0)
+        for (int k = 0; k < 16; ++k) ws_trace[w][k] += tr_[k];
+    }
+    g = run_end;
+  }
+  };
+  if (!staging) run_all(std::false_type{});
+  else run_all(std::true_type{});
+  if (WS_TRACE && blockIdx.x == 0 && (threadIdx.x & 63) == 0) ws_trace[threadIdx.x >> 6][15] += __builtin_readcyclecounter() - t_kernel0;
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------------------
 // Forward on the same machinery:  out[b,c,y,x] = sum_fy v[b,fy,y,x] * T_c[fy],   T_c[fy][j] = sum_i In_c[y + fy][16 wc + i] * Hb[i][j].
 // Replaces the reference's forward kernel (sepconv/sepconv_op/sepconv.py:5-30).
 //   MFMA wave       T on the window with the h band (the gV product without the cotangent: 120 MFMAs per 16 pixels, tap rows 48..50 of the
@@ -1099,6 +1765,13 @@ int savfi_sepconv_bwd_ws_launch(const float* in, const float* v, const float* h,
   const int64_t total = (int64_t)B * ncol * nph;
   const int per_wg = savfi_cdiv(total, cus);
   const int grid = savfi_cdiv(total, per_wg);
+  static const bool two = getenv("SAVFI_SEPCONV_WS2") != nullptr;
+  if (two) {
+    static uint32_t done2 = 0;
+    if (int e = savfi_ensure_dynamic_lds((const void*)sepconv_bwd_ws2, W2LDS, done2)) return e;
+    hipLaunchKernelGGL(sepconv_bwd_ws2, dim3(grid), dim3(W2NT), W2LDS, st, in, v, h, gO, gV, gH, B, Ho, Wo, nph, ncol, per_wg, TB);
+    return savfi_launch_status();
+  }
   static uint32_t done = 0;
   if (int e = savfi_ensure_dynamic_lds((const void*)sepconv_bwd_ws, WLDS, done)) return e;
   hipLaunchKernelGGL(sepconv_bwd_ws, dim3(grid), dim3(WNT), WLDS, st, in, v, h, gO, gV, gH, B, Ho, Wo, nph, ncol, per_wg, TB);
@@ -1118,10 +1791,10 @@ int savfi_sepconv_fwd_ws_launch(const float* in, const float* v, const float* h,
   return savfi_launch_status();
 }
 
-extern "C" int savfi_sepconv_ws_trace(unsigned long long* out /* [12][16] host */, int reset) {
+extern "C" int savfi_sepconv_ws_trace(unsigned long long* out /* [16][16] host */, int reset) {
   if (hipDeviceSynchronize() != hipSuccess) return -1;
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ws_trace), sizeof(unsigned long long) * 192) != hipSuccess) return -1;
-  if (reset) { unsigned long long z[192] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(ws_trace), z, sizeof(z)) != hipSuccess) return -1; }
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ws_trace), sizeof(unsigned long long) * 256) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[256] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(ws_trace), z, sizeof(z)) != hipSuccess) return -1; }
   return 0;
 }
 

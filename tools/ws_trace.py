@@ -11,7 +11,7 @@ h = torch.randn(B, K, Ho, Wo, device="cuda") / 7
 gO = torch.randn(B, C, Ho, Wo, device="cuda")
 gV, gH = torch.empty_like(v), torch.empty_like(h)
 f = lambda: _hip.check(lib.savfi_sepconv_bwd_f32(inp.data_ptr(), v.data_ptr(), h.data_ptr(), gO.data_ptr(), None, gV.data_ptr(), gH.data_ptr(), B, C, Ho, Wo, K, st), "bwd")
-buf = (ctypes.c_ulonglong * 192)()
+buf = (ctypes.c_ulonglong * 256)()
 lib.savfi_sepconv_ws_trace.argtypes = [ctypes.c_void_p, ctypes.c_int]
 for _ in range(3): f()
 lib.savfi_sepconv_ws_trace(buf, 1)
@@ -28,9 +28,11 @@ print("per unit (2 passes) cycles, workgroup 0, %d units per pair, lib %s" % (un
 MF = ["top", "wait tab(h)", "Bfrag h+set+slide wait", "gV MFMA loop", "gV scale", "wait out_free", "tile write+set", "wait tab(v)", "Bfrag v+set", "gH MFMA loop", "gH scale", "wait out_free", "tile write+set", "T13 wait tab(h next)", "T14 Bfrag+slide wait"]
 SG_OLD = ["top: granule loads, readlanes", "wait tab_free", "h table write", "B: side, tails-a, h loads", "wait out_full(gH)", "drain gH", "gV tail sums", "wait tab_free", "v table write", "E: gH tails, v loads", "wait out_full(gV)", "drain gV", "wait prog", "granule write"]
 SG = ["top: row load, readlanes", "wait tab_free", "table write+set", "tails (side, sums), tap loads", "wait prog", "window row write", "wait out_full(prev)", "drain+stores(prev)"]
-for w in range(12):
+two = os.environ.get('SAVFI_SEPCONV_WS2') is not None
+MF2 = ['top', '-', '-', 'gV half 1 loop (72 MFMAs)', 'tail wait + epilogue 1 (2 stores)', 'gV half 2 loop (48)', 'v frags + epilogue 2 (2 stores)', '-', '-', 'gH half 1 loop (72)', 'gH half 2 loop (72)', 'epilogue h1 (wait out_free, 8 writes)', 'next h frags, rows, epilogue h2, set', '-', '-']
+for w in range(16 if two else 12):
     row = [buf[w * 16 + k] / NL / units for k in range(16)]
-    names = MF if w < 4 else SG
+    names = (MF2 if w < 8 else SG) if two else (MF if w < 4 else SG)
     print("wave %d kernel cycles per launch %.0f; " % (w, buf[w * 16 + 15] / NL), end="")
     row[15] = 0
     print("wave %d total %.0f: " % (w, sum(row)) + " | ".join("%s %.0f" % (names[k], row[k]) for k in range(len(names))))
