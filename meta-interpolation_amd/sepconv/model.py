@@ -138,6 +138,13 @@ class MetaNetwork(nn.Module):
             # convs' own zero padding is the true one, elsewhere the (wrong) outer rings are never read
             cy0, cy1 = max(0, sy[0] - 3), min(hh, sy[1] + 1 + 3)
             cx0, cx1 = max(0, sx[0] - 3), min(hw, sx[1] + 1 + 3)
+            # a width that is a multiple of 4 where the canvas allows (233 -> 236 at 256 x 448): the convolution epilogues and the
+            # element-wise kernels store 16 bytes per lane instead of four dwords; the extra columns lie beyond the halo and are never read
+            if os.environ.get('SAVFI_SEPCONV_CROP_EXACT') is None:
+                extra = (-(cx1 - cx0)) % 4
+                grow_r = min(extra, hw - cx1)
+                cx1 += grow_r
+                cx0 -= min(extra - grow_r, cx0)
             self._windows[key] = dict(half=(hh, hw), crop=(cy0, cy1, cx0, cx1), up=up)
         return self._windows[key]
 
