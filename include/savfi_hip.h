@@ -56,7 +56,7 @@
 extern "C" {
 #endif
 
-#define SAVFI_ABI_VERSION 12
+#define SAVFI_ABI_VERSION 13
 
 #define SAVFI_OK            0
 #define SAVFI_E_NULL       (-1)  /* a required pointer is NULL                          */
@@ -94,6 +94,23 @@ int savfi_sepconv_fwd_taps_strided_f32(const float* in, const float* v, const fl
                                        int tap_bstride, void* stream);
 int savfi_sepconv_bwd_taps_strided_f32(const float* in, const float* v, const float* h, const float* gO, float* gV, float* gH, int B,
                                        int C, int Ho, int Wo, int K, int tap_bstride, void* stream);
+
+/* Frames of 8-bit images.  The reference hands the op decoded PNG frames: ToTensor's k / 255 with k = 0..255 (data/vimeo_septuplet.py:24-36;
+ * sepconv/model.py:346-347 only replication-pads them).  255 * in is then an integer that one bf16 holds exactly, and an fp32 product
+ * in * tap costs three exact bf16 products (k times the tap's three bf16 pieces) instead of six; the sum is scaled by 1/255 once.
+ *   savfi_frames8_classify_f32   x [n] floats -> cls [SAVFI_FRAMES8_WORDS] words (device, 16-byte aligned, need not be initialised):
+ *                                word i != 0 = classifier workgroup i met an element that is not fl32(k / 255) to within 2 ulp
+ *   savfi_sepconv_{fwd,bwd}_frames8_f32   the two strided entry points above with the words of `in` as an extra argument.  BOTH kernel
+ *                                variants are launched and the words select one ON THE DEVICE (no host round trip, graph-capture safe):
+ *                                all words zero -> the three-product kernel, otherwise the six-product kernel of the entry points above.
+ *                                Same results to fp32 rounding for frames that qualify, identical results for frames that do not.
+ * tap_bstride = K for contiguous tap tensors.  K = 51, C = 3, Wo % 4 == 0; SAVFI_E_UNSUPPORTED otherwise (use the entry points above). */
+#define SAVFI_FRAMES8_WORDS 256
+int savfi_frames8_classify_f32(const float* x, int64_t n, unsigned* cls, void* stream);
+int savfi_sepconv_fwd_frames8_f32(const float* in, const float* v, const float* h, float* out, const unsigned* cls, int B, int C, int Ho,
+                                  int Wo, int K, int tap_bstride, void* stream);
+int savfi_sepconv_bwd_frames8_f32(const float* in, const float* v, const float* h, const float* gO, float* gV, float* gH,
+                                  const unsigned* cls, int B, int C, int Ho, int Wo, int K, int tap_bstride, void* stream);
 
 /* Diagnostic of the wave-specialised filter-gradient kernel (csrc/sepconv_ws.hip): number of bounded in-kernel waits that
  * gave up since the library was loaded on the current device.  0 on a healthy build; > 0 means a launch's numbers are wrong

@@ -76,6 +76,9 @@ constexpr int WSPIN_LIMIT = 1 << 19;
 #ifndef WS_EXP_NOAREAD          // the MFMA loops reuse the first unit's A fragments (no LDS reads inside the loops)
 #define WS_EXP_NOAREAD 0
 #endif
+#ifndef WS_EXP_UNITMAJOR        // see load_taps of sepconv_bwd_ws
+#define WS_EXP_UNITMAJOR 0
+#endif
 #ifndef WS_EXP_NOMFMAONLY       // the A fragments are read, the MFMAs are not issued
 #define WS_EXP_NOMFMAONLY 0
 #endif
@@ -166,10 +169,48 @@ __device__ __forceinline__ int ws_lane() {
   return t & 63;
 }
 
+// Frames of 8-bit images.  The reference feeds the op decoded PNG frames (data/vimeo_septuplet.py: ToTensor = k / 255, k = 0..255;
+// sepconv/model.py:346-347 passes them through a replication pad).  255 w = k is then an integer that ONE bf16 holds exactly: the window needs
+// one piece instead of three, an fp32 product three bf16 products (k x the taps' three pieces, each exact) instead of six, and the result is
+// scaled by 1 / 255 once (the cotangent in the filter gradients, the channel sums in the forward).  Whether a frame tensor has the property is
+// decided ON THE DEVICE, per call: savfi_frames8_classify_f32 leaves one word per classifier workgroup (non-zero = it met an element that is
+// not the fp32 quotient k / 255 to within 2 ulp), the <U8 = true> and <U8 = false> instances of a kernel are both launched and the one the
+// words do not select returns at once -- no host round trip (graph-capture safe), any other input takes the six-product path unchanged.
+constexpr int CLS_WG = 256, CLS_NT = 1024;         // classifier grid: one 16-byte load of the words per lane of the consumer
+template <bool U8>
+__device__ __forceinline__ bool ws_frames8_mine(const unsigned* __restrict__ cls) {
+  if (cls == nullptr) return !U8;
+  const u32x4 pv = reinterpret_cast<const u32x4*>(cls)[threadIdx.x & 63];
+  const bool bad = __builtin_amdgcn_ballot_w64((pv.x | pv.y | pv.z | pv.w) != 0u) != 0ull;
+  return bad != U8;
+}
+__device__ __forceinline__ bool ws_not_frames8(float w) {
+  const float k = rintf(w * 255.f);
+  const float d = fmaf(w, 255.f, -k);              // 255 w - k, rounded once: k delta for w = (k / 255)(1 + delta)
+  return !(k >= 0.f && k <= 255.f && fabsf(d) <= k * 2.4e-7f);   // NaN, negative zero's k = -0 passes (w = -0 is k = 0)
+}
+__global__ __launch_bounds__(CLS_NT) void frames8_classify(const float* __restrict__ x, long long n, unsigned* __restrict__ cls) {
+  const long long n4 = (reinterpret_cast<unsigned long long>(x) & 15ull) == 0ull ? n / 4 : 0;
+  const long long t = (long long)blockIdx.x * CLS_NT + threadIdx.x, stride = (long long)CLS_WG * CLS_NT;
+  bool bad = false;
+  for (long long i = t; i < n4; i += 4 * stride) {
+    f32x4 q[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) q[u] = reinterpret_cast<const f32x4*>(x)[min(i + u * stride, n4 - 1)];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) bad |= ws_not_frames8(q[u].x) | ws_not_frames8(q[u].y) | ws_not_frames8(q[u].z) | ws_not_frames8(q[u].w);
+  }
+  for (long long i = 4 * n4 + t; i < n; i += stride) bad |= ws_not_frames8(x[i]);
+  const int any = __syncthreads_or(bad ? 1 : 0);
+  if (threadIdx.x == 0) cls[blockIdx.x] = any ? 1u : 0u;
+}
+
+template <bool U8>
 __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ in, const float* __restrict__ v,
                                                       const float* __restrict__ h, const float* __restrict__ gO,
                                                       float* __restrict__ gV, float* __restrict__ gH,
-                                                      int B, int Ho, int Wo, int nph, int ncol, int per_wg, int TB) {
+                                                      int B, int Ho, int Wo, int nph, int ncol, int per_wg, int TB,
+                                                      const unsigned* __restrict__ cls) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int p = w & 3, wc = p & 1, wr0 = p >> 1;
@@ -186,6 +227,7 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
   const int total = B * ncol * nph;
   const int g0 = blockIdx.x * per_wg, g1 = min(g0 + per_wg, total);
   if (g0 >= g1) return;
+  if (!ws_frames8_mine<U8>(cls)) return;
   const int Hi = Ho + XK - 1, Wi = Wo + XK - 1;
   const unsigned plane_b = (unsigned)Ho * (unsigned)Wo * 4u;
   const __amdgpu_buffer_rsrc_t hsrc = x6_rsrc(h, (unsigned)((B - 1) * TB + XK) * plane_b);
@@ -200,17 +242,23 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
   };
   // Tap registers (as sepconv_bwd_x6): lane (j, kg) holds 7 PAIRS of neighbouring taps t0 + 8 a + {0, 1}: a split pair is exactly the
   // dword a table position takes.  v: t0 = 2 kg.  h: t0 = 2 kg - (j & 1): the band position i = tap + j of a pair starts even.
+  // -DWS_EXP_UNITMAJOR (timing only, results wrong): the tap tensors addressed as if they were laid out [y][x / 16][tap][16] per sample --
+  // a unit's 51 x 64 bytes contiguous -- instead of [tap][y][x]: what the op would cost on taps produced in that layout
+  const unsigned tap_stride = WS_EXP_UNITMAJOR ? 64u : plane_b;
+  auto unit_off = [&](int b, int x0, int y) {
+    return (unsigned)b * (unsigned)TB * plane_b + (unsigned)((min(y, Ho - 1) * (Wo >> 4) + min((x0 >> 4) + wc, (Wo >> 4) - 1)) * XK) * 64u;
+  };
   auto load_taps = [&](float (&regs)[XNP][2], __amdgpu_buffer_rsrc_t src, int b, int x0, int y, int t0) {
-    const unsigned pix = pix_off(b, x0, y, TB);
-    const unsigned voff = pix + (unsigned)(t0 + 1) * plane_b;
-    regs[0][0] = x6_bload(src, pix + (unsigned)max(t0, 0) * plane_b, 0u);
+    const unsigned pix = WS_EXP_UNITMAJOR ? unit_off(b, x0, y) + (unsigned)j * 4u : pix_off(b, x0, y, TB);
+    const unsigned voff = pix + (unsigned)(t0 + 1) * tap_stride;
+    regs[0][0] = x6_bload(src, pix + (unsigned)max(t0, 0) * tap_stride, 0u);
     regs[0][1] = x6_bload(src, voff, 0u);
 #pragma unroll
     for (int a = 1; a < XNP - 1; ++a)
 #pragma unroll
-      for (int e = 0; e < 2; ++e) regs[a][e] = x6_bload(src, voff, (unsigned)(8 * a + e - 1) * plane_b);
+      for (int e = 0; e < 2; ++e) regs[a][e] = x6_bload(src, voff, (unsigned)(8 * a + e - 1) * tap_stride);
 #pragma unroll
-    for (int e = 0; e < 2; ++e) regs[XNP - 1][e] = x6_bload(src, pix + (unsigned)min(8 * (XNP - 1) + t0 + e, XK - 1) * plane_b, 0u);
+    for (int e = 0; e < 2; ++e) regs[XNP - 1][e] = x6_bload(src, pix + (unsigned)min(8 * (XNP - 1) + t0 + e, XK - 1) * tap_stride, 0u);
   };
   auto tap_or_zero = [&](const float (&regs)[XNP][2], int a, int e, int t0) {
     if (a == 0 && e == 0) return t0 < 0 ? 0.f : regs[0][0];
@@ -256,6 +304,9 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
   auto rdlane = [&](float x, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l)); };
 
   constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // six products, small terms first
+  constexpr int PB8[3] = {2, 1, 0};                  // U8: the window is one piece (PA = 0)
+  constexpr int NPC = U8 ? 1 : 3, NQ = U8 ? 3 : 6;   // window pieces, products per fp32 product
+  constexpr int DEPTH = U8 ? 2 : 1, NSL = DEPTH + 1; // A fragments are requested DEPTH blocks ahead (a U8 block is 6 MFMAs: half the cover)
   const int permk = ((kg & 1) << 1) | (kg >> 1);
   const int L = lane & 15;
   const int pq = lane & 3, fq = lane >> 2;
@@ -286,7 +337,7 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
       for (int r = 0; r < XWIN; r += 16) {
         X6Rows<16> sr;
         x6_rows_load<16>(sr, isrc, b, x0, R0 + r, Hi, Wi, tid);
-        x6_rows_write<16>(sr, smem, R0 + r, tid, WSIDE_OFF);
+        x6_rows_write<16, U8>(sr, smem, R0 + r, tid, WSIDE_OFF);
       }
     }
     __builtin_amdgcn_s_waitcnt(0);
@@ -299,7 +350,7 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
       // run under the epilogue's VALU work instead of in front of the next pass's first MFMA.
       __builtin_amdgcn_s_setprio(WS_PRIO);
       unsigned long long tr_[16] = {0}, tlast_ = __builtin_readcyclecounter();
-      bf16x8 bq[2][3], aq[2][2][3];
+      bf16x8 bq[2][3], aq[NSL][2][NPC];
       int rowoff[4], rowh[2][2];
       // the same offsets + 6 planes: a DS instruction's immediate offset is 16 bits and the window is 103 KB -- reads of the third bf16 piece
       // (planes 6..8) through the low bases took a v_add each, inside the MFMA loops (4 per gH block, 2 per gV block)
@@ -320,12 +371,14 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
 #pragma unroll
           for (int hf = 0; hf < 2; ++hf)
             rowh[st][hf] = ((y + 32 * st + 16 * hf + 4 * ko + (Lo >> 2)) & (XWIN - 1)) * 16 + (2 * wc + ((Lo & 3) >> 1)) * XBLK + (Lo & 1) * 8;
+        if constexpr (!U8) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) { rowoff_hi[m] = rowoff[m] + 6 * XPLANE; asm volatile("" : "+v"(rowoff_hi[m])); }
+          for (int m = 0; m < 4; ++m) { rowoff_hi[m] = rowoff[m] + 6 * XPLANE; asm volatile("" : "+v"(rowoff_hi[m])); }
 #pragma unroll
-        for (int st = 0; st < 2; ++st)
+          for (int st = 0; st < 2; ++st)
 #pragma unroll
-          for (int hf = 0; hf < 2; ++hf) { rowh_hi[st][hf] = rowh[st][hf] + 6 * XPLANE; asm volatile("" : "+v"(rowh_hi[st][hf])); }
+            for (int hf = 0; hf < 2; ++hf) { rowh_hi[st][hf] = rowh[st][hf] + 6 * XPLANE; asm volatile("" : "+v"(rowh_hi[st][hf])); }
+        }
       };
       // gV blocks (12 MFMAs each: two tiles x six products).  Tap rows 0..47 of a channel are three tiles of 16; rows 48..50 of the
       // THREE channels share one more tile (a lane's A row is any window row of any channel), so 51 rows x 3 channels cost 10 tiles
@@ -339,7 +392,7 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
         for (int t = 0; t < 2; ++t) {
           const int ai = gv_acc(uu, t), c = ai == 9 ? 0 : ai / 3, m = ai == 9 ? 3 : ai % 3;
 #pragma unroll
-          for (int pc = 0; pc < 3; ++pc)
+          for (int pc = 0; pc < NPC; ++pc)
           {
             const int plane = pc * 3 + c;
             aq[slot][t][pc] = *reinterpret_cast<const bf16x8*>(smem + (plane >= 6 ? plane - 6 : plane) * XPLANE + 4 * st * XBLK + (plane >= 6 ? rowoff_hi[m] : rowoff[m]));
@@ -351,7 +404,7 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-          for (int pc = 0; pc < 3; ++pc) {
+          for (int pc = 0; pc < NPC; ++pc) {
             const int plane = pc * 3 + c;
             const int base = (plane >= 6 ? plane - 6 : plane) * XPLANE + 2 * (2 * mp + t) * XBLK;
             const bf16x4 lo = tr_read(base + (plane >= 6 ? rowh_hi[st][0] : rowh[st][0])), hi = tr_read(base + (plane >= 6 ? rowh_hi[st][1] : rowh[st][1]));
@@ -377,9 +430,9 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
 #define WS_MFMA_BLOCK(uu)                                                                                                             \
       {                                                                                                                               \
         const int c = (uu) >> 2, st = ((uu) >> 1) & 1, mp = (uu) & 1;                                                                 \
-        _Pragma("unroll") for (int qq = 0; qq < 6; ++qq)                                                                              \
+        _Pragma("unroll") for (int qq = 0; qq < NQ; ++qq)                                                                             \
           _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                                               \
-            acc[c][2 * mp + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[(uu) & 1][t][PA[qq]], bq[st][PB[qq]], acc[c][2 * mp + t], 0, 0, 0); \
+            acc[c][2 * mp + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[(uu) % NSL][t][U8 ? 0 : PA[qq]], bq[st][U8 ? PB8[qq] : PB[qq]], acc[c][2 * mp + t], 0, 0, 0); \
       }
 
       // before the first pass: h fragments of unit 0, first A fragments
@@ -387,14 +440,15 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
       ws_wait(fl, F_TAB_FULL + p, 1);
       read_bh();
       ws_set(fl, F_TAB_FREE + p, 1);
-      load_av(0, 0);
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) load_av(d, d);
 #pragma unroll 1
       for (int n = 0; n < N; ++n) {
         const int q = n >> 1, u = n & 1;
         WS_T(0);
-        float g_[XC];
+        float g_[XC];                                  // U8: the window holds 255 w -- the cotangent carries the 1 / 255
 #pragma unroll
-        for (int c = 0; c < XC; ++c) g_[c] = gp[c];
+        for (int c = 0; c < XC; ++c) g_[c] = U8 ? gp[c] * (1.0f / 255.0f) : gp[c];
         {
           const unsigned go = pix_off(b, x0, unit_y(min(n + 1, N - 1)), XC);
 #pragma unroll
@@ -409,23 +463,23 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int uu = 0; uu < 10; ++uu) {
-            if (uu + 1 < 10) load_av((uu + 1) & 1, uu + 1);
-            else { pre_tab = peek_raw(F_TAB_FULL + p); pre_out = peek_raw(F_OUT_FREE + p); }
+            if (uu + DEPTH < 10) load_av((uu + DEPTH) % NSL, uu + DEPTH);
+            if (uu == 9) { pre_tab = peek_raw(F_TAB_FULL + p); pre_out = peek_raw(F_OUT_FREE + p); }
             {
               const int st = gv_st(uu);
 #pragma unroll
-              for (int qq = 0; qq < 6; ++qq)
+              for (int qq = 0; qq < NQ; ++qq)
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
-                  acc[gv_acc(uu, t)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[uu & 1][t][PA[qq]], bq[st][PB[qq]], acc[gv_acc(uu, t)], 0, 0, 0);
+                  acc[gv_acc(uu, t)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[uu % NSL][t][U8 ? 0 : PA[qq]], bq[st][U8 ? PB8[qq] : PB[qq]], acc[gv_acc(uu, t)], 0, 0, 0);
             }
-            if (WS_INTERLEAVE && uu + 1 < 10) {           // MFMA, DS read, MFMA, DS read ... (6 reads), then the remaining MFMAs
+            if (WS_INTERLEAVE && uu + DEPTH < 10) {       // MFMA, DS read, MFMA, DS read ... (2 NPC reads), then the remaining MFMAs
 #pragma unroll
-              for (int i = 0; i < 6; ++i) {
+              for (int i = 0; i < 2 * NPC; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
               }
-              __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+              __builtin_amdgcn_sched_group_barrier(0x008, 2 * NQ - 2 * NPC, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
           }
@@ -434,7 +488,8 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
           if ((int)__builtin_amdgcn_readfirstlane((int)pre_tab) < 2 * n + 2) ws_wait(fl, F_TAB_FULL + p, 2 * n + 2);
           read_bv();
           ws_set(fl, F_TAB_FREE + p, 2 * n + 2);
-          load_ah(0, 0);
+#pragma unroll
+          for (int d = 0; d < DEPTH; ++d) load_ah(d, d);
           WS_T(4);
           // D row 4 kg + r of tile m = tap row fy = 16 m + 4 kg + r (m < 3), column = pixel j; the packed tile's lane group kg holds
           // rows 48 + r of channel kg: scaled by that channel's cotangent it goes to tile row 64 + 4 kg + r, the h-side wave adds the
@@ -479,14 +534,23 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int uu = 0; uu < 12; ++uu) {
-            if (uu + 1 < 12) load_ah((uu + 1) & 1, uu + 1);
-            else { pre_tab = peek_raw(F_TAB_FULL + p); pre_out = peek_raw(F_OUT_FREE + p); pre_slide = peek_raw(F_SLIDE); }
+            if (uu + DEPTH < 12) load_ah((uu + DEPTH) % NSL, uu + DEPTH);
+            if (uu == 11) { pre_tab = peek_raw(F_TAB_FULL + p); pre_out = peek_raw(F_OUT_FREE + p); pre_slide = peek_raw(F_SLIDE); }
             WS_MFMA_BLOCK(uu)
-            if (WS_INTERLEAVE && uu + 1 < 12) {           // MFMA, 2 transpose reads, ... (24 reads over the 12 MFMAs)
+            if (WS_INTERLEAVE && uu + DEPTH < 12) {
+              if constexpr (U8) {                          // MFMA, transpose read, ... (4 reads over the first 4 of 6 MFMAs)
 #pragma unroll
-              for (int i = 0; i < 12; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, WS_GH_READS_PER_GAP, 0);
+                for (int i = 0; i < 4; ++i) {
+                  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                  __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+              } else {                                     // MFMA, 2 transpose reads, ... (24 reads over the 12 MFMAs)
+#pragma unroll
+                for (int i = 0; i < 12; ++i) {
+                  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                  __builtin_amdgcn_sched_group_barrier(0x100, WS_GH_READS_PER_GAP, 0);
+                }
               }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -503,7 +567,8 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
             if (u == 1 && q1 >= 2 && (int)__builtin_amdgcn_readfirstlane((int)pre_slide) < 8 * (2 * q1 - 3)) ws_wait(fl, F_SLIDE, 8 * (2 * q1 - 3));
             WS_T(14);
             set_rows(unit_y(n + 1));
-            load_av(0, 0);
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) load_av(d, d);
           }
           WS_T(10);
           float val[4][4];
@@ -560,7 +625,9 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
         const int q = nn >> 1, u = nn & 1;
         const int y = unit_y(nn), y1 = unit_y(min(nn + 1, N - 1));
         const int xq = x0 + 16 * wc + 4 * pq;
-        const unsigned qoff = (live && y < Ho && xq < Wo) ? (unsigned)b * (unsigned)TB * plane_b + (unsigned)(y * Wo + xq) * 4u + (unsigned)fq * plane_b : X_OOR;
+        const unsigned qoff = !(live && y < Ho && xq < Wo) ? X_OOR
+                              : WS_EXP_UNITMAJOR ? unit_off(b, x0, y) + (unsigned)pq * 16u + (unsigned)fq * 64u
+                                                 : (unsigned)b * (unsigned)TB * plane_b + (unsigned)(y * Wo + xq) * 4u + (unsigned)fq * plane_b;
         // one new window row per role and unit (rows R0 + 60 + 2 n + {0 | 1})
         float gr0, gr1;
         const int grow = R0 + 60 + 2 * nn + (hside ? 0 : 1);
@@ -603,7 +670,7 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
             }
             const float t14 = tailb[row], t15 = tailb[64 + row];
             if (pq == 3) { v4[2] += t14; v4[3] += t15; }
-            x6_bstore4(v4, gvdst, (qq < 3 || fq < 3) ? qoff_prev : X_OOR, (unsigned)(16 * qq) * plane_b);
+            x6_bstore4(v4, gvdst, (qq < 3 || fq < 3) ? qoff_prev : X_OOR, (unsigned)(16 * qq) * tap_stride);
           }
           if (n > 0) ws_set(fl, F_OUT_FREE + p, 2 * n - 1);
           WS_T(7);
@@ -672,7 +739,7 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
             // window columns 64, 65 (pixel 14 tap 50; pixel 15 taps 49, 50) are the VALU tail sums
             if (pq == 3 && fx == 50) { v4[2] = s6414; v4[3] = s6515; }
             if (pq == 3 && fx == 49) v4[3] = s6415;
-            x6_bstore4(v4, ghdst, (qq < 3 || fq < 3) ? qoff_prev : X_OOR, (unsigned)(16 * qq) * plane_b);
+            x6_bstore4(v4, ghdst, (qq < 3 || fq < 3) ? qoff_prev : X_OOR, (unsigned)(16 * qq) * tap_stride);
           }
           if (n > 0) ws_set(fl, F_OUT_FREE + p, 2 * n);
           WS_T(7);
@@ -686,6 +753,7 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
           }
           asm volatile("" ::: "memory");
           if (live && u == 1) ws_set(fl, F_PROG + w, q + 1);
+          WS_T(8);
           if (!WS_EXP_NOSTAGE) {
             const float lv = lane < XK ? 1.f : 0.f;
             v14 *= lv; v15 *= lv;
@@ -701,6 +769,7 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
             s6515 = ws_wave_sum(sc);
           }
           asm volatile("" ::: "memory");
+          WS_T(9);
           if (!WS_EXP_NOSTAGE) load_taps(vreg, vsrc, b, x0, y1, v_t0);
           WS_T(3);
         }
@@ -715,12 +784,21 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
           if (q >= 1) ws_wait_all_prog(fl, q);
           WS_T(4);
           const int slot = grow & (XWIN - 1);
-          unsigned h1, h2, h3;
-          x6_split2(gr0, gr1, h1, h2, h3);
-          if (gcol < 8 * XNBLK && !WS_EXP_NOSTAGE) {
-            char* d0 = smem + gcell + slot * 16 + gc0 * XPLANE;
-            x6_st16(d0, h1); x6_st16(d0 + 3 * XPLANE, h2); x6_st16(d0 + 6 * XPLANE, h3);
-            if (ggrp == 0) { x6_st16(d0 + XPLANE, h1 >> 16); x6_st16(d0 + 4 * XPLANE, h2 >> 16); x6_st16(d0 + 7 * XPLANE, h3 >> 16); }
+          if constexpr (U8) {
+            const unsigned k1 = x6_cvt_pk(rintf(gr0 * 255.f), rintf(gr1 * 255.f));
+            if (gcol < 8 * XNBLK && !WS_EXP_NOSTAGE) {
+              char* d0 = smem + gcell + slot * 16 + gc0 * XPLANE;
+              x6_st16(d0, k1);
+              if (ggrp == 0) x6_st16(d0 + XPLANE, k1 >> 16);
+            }
+          } else {
+            unsigned h1, h2, h3;
+            x6_split2(gr0, gr1, h1, h2, h3);
+            if (gcol < 8 * XNBLK && !WS_EXP_NOSTAGE) {
+              char* d0 = smem + gcell + slot * 16 + gc0 * XPLANE;
+              x6_st16(d0, h1); x6_st16(d0 + 3 * XPLANE, h2); x6_st16(d0 + 6 * XPLANE, h3);
+              if (ggrp == 0) { x6_st16(d0 + XPLANE, h1 >> 16); x6_st16(d0 + 4 * XPLANE, h2 >> 16); x6_st16(d0 + 7 * XPLANE, h3 >> 16); }
+            }
           }
           if (gsidx >= 0) {
             side[(gc0 * XWIN + slot) * 4 + gsidx] = gr0;
@@ -1424,9 +1502,11 @@ constexpr int FLDS = FFLAG_OFF + 256;
 static_assert(FLDS <= 160 * 1024, "LDS per CU");
 enum { F_VT_FULL = 8, F_VT_FREE = 12, F_OP_FULL = 32, F_OP_FREE = 36, F_TL_FULL = 40, F_TL_FREE = 44 };     // + F_TAB_*, F_PROG, F_SLIDE, F_ERR
 
+template <bool U8>
 __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ in, const float* __restrict__ v,
                                                       const float* __restrict__ h, float* __restrict__ out,
-                                                      int B, int Ho, int Wo, int nph, int ncol, int per_wg, int TB) {
+                                                      int B, int Ho, int Wo, int nph, int ncol, int per_wg, int TB,
+                                                      const unsigned* __restrict__ cls) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int p = w & 3, wc = p & 1, wr0 = p >> 1;
@@ -1442,6 +1522,7 @@ __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ 
   const int total = B * ncol * nph;
   const int g0 = blockIdx.x * per_wg, g1 = min(g0 + per_wg, total);
   if (g0 >= g1) return;
+  if (!ws_frames8_mine<U8>(cls)) return;
   const int Hi = Ho + XK - 1, Wi = Wo + XK - 1;
   const unsigned plane_b = (unsigned)Ho * (unsigned)Wo * 4u;
   const __amdgpu_buffer_rsrc_t hsrc = x6_rsrc(h, (unsigned)((B - 1) * TB + XK) * plane_b);
@@ -1489,6 +1570,9 @@ __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ 
   };
   auto rdlane = [&](float x, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l)); };
   constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+  constexpr int PB8[3] = {2, 1, 0};                  // U8: see sepconv_bwd_ws
+  constexpr int NPC = U8 ? 1 : 3, NQ = U8 ? 3 : 6;
+  constexpr int DEPTH = U8 ? 2 : 1, NSL = DEPTH + 1;
 
   auto run_all = [&](auto stg_) __attribute__((always_inline)) {       // one run loop per role (see sepconv_bwd_ws)
   constexpr bool STG = decltype(stg_)::value;
@@ -1506,7 +1590,7 @@ __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ 
       for (int r = 0; r < XWIN; r += 16) {
         X6Rows<16> sr;
         x6_rows_load<16>(sr, isrc, b, x0, R0 + r, Hi, Wi, tid);
-        x6_rows_write<16>(sr, smem, R0 + r, tid, FSIDE_OFF);
+        x6_rows_write<16, U8>(sr, smem, R0 + r, tid, FSIDE_OFF);
       }
     }
     __builtin_amdgcn_s_waitcnt(0);
@@ -1515,7 +1599,7 @@ __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ 
     if constexpr (!STG) {
       // =========================================== MFMA wave ===================================================================
       __builtin_amdgcn_s_setprio(WS_PRIO);
-      bf16x8 bq[2][3], aq[2][2][3];
+      bf16x8 bq[2][3], aq[NSL][2][NPC];
       int rowoff[4], rowoff_hi[4];                   // + 6 planes: the third bf16 piece within a DS immediate offset (see sepconv_bwd_ws)
       auto peek_raw = [&](int idx) { return __hip_atomic_load(fl + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
       auto set_rows = [&](int y) {
@@ -1524,8 +1608,10 @@ __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ 
 #pragma unroll
         for (int m = 0; m < 3; ++m) rowoff[m] = ((y + 16 * m + jo) & (XWIN - 1)) * 16 + (2 * wc + pk) * XBLK;
         rowoff[3] = ((y + 48 + min(jo & 3, 2)) & (XWIN - 1)) * 16 + (2 * wc + pk) * XBLK + min(jo >> 2, 2) * XPLANE;
+        if constexpr (!U8) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) { rowoff_hi[m] = rowoff[m] + 6 * XPLANE; asm volatile("" : "+v"(rowoff_hi[m])); }
+          for (int m = 0; m < 4; ++m) { rowoff_hi[m] = rowoff[m] + 6 * XPLANE; asm volatile("" : "+v"(rowoff_hi[m])); }
+        }
       };
       auto gv_acc = [](int uu, int t) { return uu < 6 ? 3 * (uu >> 1) + t : uu < 8 ? 3 * t + 2 : (t == 0 ? 8 : 9); };
       auto load_av = [&](int slot, int uu) {
@@ -1534,7 +1620,7 @@ __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ 
         for (int t = 0; t < 2; ++t) {
           const int ai = gv_acc(uu, t), c = ai == 9 ? 0 : ai / 3, m = ai == 9 ? 3 : ai % 3;
 #pragma unroll
-          for (int pc = 0; pc < 3; ++pc)
+          for (int pc = 0; pc < NPC; ++pc)
           {
             const int plane = pc * 3 + c;
             aq[slot][t][pc] = *reinterpret_cast<const bf16x8*>(smem + (plane >= 6 ? plane - 6 : plane) * XPLANE + 4 * st * XBLK + (plane >= 6 ? rowoff_hi[m] : rowoff[m]));
@@ -1552,7 +1638,8 @@ __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ 
       ws_wait(fl, F_TAB_FULL + p, 1);
       read_bh();
       ws_set(fl, F_TAB_FREE + p, 1);
-      load_av(0, 0);
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) load_av(d, d);
 #pragma unroll 1
       for (int n = 0; n < N; ++n) {
         const int q = n >> 1, u = n & 1;
@@ -1563,23 +1650,23 @@ __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ 
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int uu = 0; uu < 10; ++uu) {
-          if (uu + 1 < 10) load_av((uu + 1) & 1, uu + 1);
-          else { pre_tab = peek_raw(F_TAB_FULL + p); pre_vt = peek_raw(F_VT_FULL + p); pre_op = peek_raw(F_OP_FREE + p); pre_slide = peek_raw(F_SLIDE); }
+          if (uu + DEPTH < 10) load_av((uu + DEPTH) % NSL, uu + DEPTH);
+          if (uu == 9) { pre_tab = peek_raw(F_TAB_FULL + p); pre_vt = peek_raw(F_VT_FULL + p); pre_op = peek_raw(F_OP_FREE + p); pre_slide = peek_raw(F_SLIDE); }
           {
             const int st = uu & 1;
 #pragma unroll
-            for (int qq = 0; qq < 6; ++qq)
+            for (int qq = 0; qq < NQ; ++qq)
 #pragma unroll
               for (int t = 0; t < 2; ++t)
-                acc[gv_acc(uu, t)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[uu & 1][t][PA[qq]], bq[st][PB[qq]], acc[gv_acc(uu, t)], 0, 0, 0);
+                acc[gv_acc(uu, t)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[uu % NSL][t][U8 ? 0 : PA[qq]], bq[st][U8 ? PB8[qq] : PB[qq]], acc[gv_acc(uu, t)], 0, 0, 0);
           }
-          if (WS_INTERLEAVE && uu + 1 < 10) {
+          if (WS_INTERLEAVE && uu + DEPTH < 10) {
 #pragma unroll
-            for (int i = 0; i < 6; ++i) {
+            for (int i = 0; i < 2 * NPC; ++i) {
               __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
               __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * NQ - 2 * NPC, 0);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -1592,7 +1679,8 @@ __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ 
           ws_set(fl, F_TAB_FREE + p, n + 2);
           if (u == 1 && q1 >= 2 && (int)__builtin_amdgcn_readfirstlane((int)pre_slide) < 8 * (2 * q1 - 3)) ws_wait(fl, F_SLIDE, 8 * (2 * q1 - 3));
           set_rows(unit_y(n + 1));
-          load_av(0, 0);
+#pragma unroll
+          for (int d = 0; d < DEPTH; ++d) load_av(d, d);
         }
         // vertical pass: v of this lane's rows from the pair's v tile
         if ((int)__builtin_amdgcn_readfirstlane((int)pre_vt) < n + 1) ws_wait(fl, F_VT_FULL + p, n + 1);
@@ -1618,6 +1706,10 @@ __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ 
           t = fmaf(vc[3][2], acc[9][2], t);
 #pragma unroll
           for (int c = 0; c < XC; ++c) part[c] += (ko == c) ? t : 0.f;
+        }
+        if constexpr (U8) {                            // the window holds 255 w
+#pragma unroll
+          for (int c = 0; c < XC; ++c) part[c] *= 1.0f / 255.0f;
         }
         if ((int)__builtin_amdgcn_readfirstlane((int)pre_op) < n) ws_wait(fl, F_OP_FREE + p, n);
 #pragma unroll
@@ -1730,12 +1822,21 @@ __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ 
         if (live) {
           if (q >= 1) ws_wait_all_prog(fl, q);
           const int slot = grow & (XWIN - 1);
-          unsigned h1, h2, h3;
-          x6_split2(gr0, gr1, h1, h2, h3);
-          if (gcol < 8 * XNBLK) {
-            char* d0 = smem + gcell + slot * 16 + gc0 * XPLANE;
-            x6_st16(d0, h1); x6_st16(d0 + 3 * XPLANE, h2); x6_st16(d0 + 6 * XPLANE, h3);
-            if (ggrp == 0) { x6_st16(d0 + XPLANE, h1 >> 16); x6_st16(d0 + 4 * XPLANE, h2 >> 16); x6_st16(d0 + 7 * XPLANE, h3 >> 16); }
+          if constexpr (U8) {
+            const unsigned k1 = x6_cvt_pk(rintf(gr0 * 255.f), rintf(gr1 * 255.f));
+            if (gcol < 8 * XNBLK) {
+              char* d0 = smem + gcell + slot * 16 + gc0 * XPLANE;
+              x6_st16(d0, k1);
+              if (ggrp == 0) x6_st16(d0 + XPLANE, k1 >> 16);
+            }
+          } else {
+            unsigned h1, h2, h3;
+            x6_split2(gr0, gr1, h1, h2, h3);
+            if (gcol < 8 * XNBLK) {
+              char* d0 = smem + gcell + slot * 16 + gc0 * XPLANE;
+              x6_st16(d0, h1); x6_st16(d0 + 3 * XPLANE, h2); x6_st16(d0 + 6 * XPLANE, h3);
+              if (ggrp == 0) { x6_st16(d0 + XPLANE, h1 >> 16); x6_st16(d0 + 4 * XPLANE, h2 >> 16); x6_st16(d0 + 7 * XPLANE, h3 >> 16); }
+            }
           }
           if (gsidx >= 0) {
             side[(gc0 * XWIN + slot) * 4 + gsidx] = gr0;
@@ -1759,35 +1860,54 @@ __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ 
 // gV and gH of the K = 51, C = 3 op, widths that are a multiple of 4; every tensor below 2^31 bytes (the caller checks).
 // TB: tap planes between two samples of v / h / gV / gH (51 for contiguous [B,51,Ho,Wo] tensors; larger when the tensors are slices of one
 // interleaved [B * S, 51, Ho, Wo] buffer: sepconv/model.py runs its four sub-networks as one task-batched launch per layer)
+// cls: the words of savfi_frames8_classify_f32 on `in` (device memory; both instances of the kernel are launched and the device picks one),
+// or nullptr (the six-product kernel only)
 int savfi_sepconv_bwd_ws_launch(const float* in, const float* v, const float* h, const float* gO, float* gV, float* gH, int B, int Ho,
-                                int Wo, int cus, int TB, hipStream_t st) {
+                                int Wo, int cus, int TB, const unsigned* cls, hipStream_t st) {
   const int nph = savfi_cdiv(Ho, XPR), ncol = savfi_cdiv(Wo, XMC);
   const int64_t total = (int64_t)B * ncol * nph;
   const int per_wg = savfi_cdiv(total, cus);
   const int grid = savfi_cdiv(total, per_wg);
   static const bool two = getenv("SAVFI_SEPCONV_WS2") != nullptr;
-  if (two) {
+  if (two && !cls) {
     static uint32_t done2 = 0;
     if (int e = savfi_ensure_dynamic_lds((const void*)sepconv_bwd_ws2, W2LDS, done2)) return e;
     hipLaunchKernelGGL(sepconv_bwd_ws2, dim3(grid), dim3(W2NT), W2LDS, st, in, v, h, gO, gV, gH, B, Ho, Wo, nph, ncol, per_wg, TB);
     return savfi_launch_status();
   }
-  static uint32_t done = 0;
-  if (int e = savfi_ensure_dynamic_lds((const void*)sepconv_bwd_ws, WLDS, done)) return e;
-  hipLaunchKernelGGL(sepconv_bwd_ws, dim3(grid), dim3(WNT), WLDS, st, in, v, h, gO, gV, gH, B, Ho, Wo, nph, ncol, per_wg, TB);
+  static uint32_t done = 0, done8 = 0;
+  if (cls) {
+    if (int e = savfi_ensure_dynamic_lds((const void*)sepconv_bwd_ws<true>, WLDS, done8)) return e;
+    hipLaunchKernelGGL(sepconv_bwd_ws<true>, dim3(grid), dim3(WNT), WLDS, st, in, v, h, gO, gV, gH, B, Ho, Wo, nph, ncol, per_wg, TB, cls);
+  }
+  if (int e = savfi_ensure_dynamic_lds((const void*)sepconv_bwd_ws<false>, WLDS, done)) return e;
+  hipLaunchKernelGGL(sepconv_bwd_ws<false>, dim3(grid), dim3(WNT), WLDS, st, in, v, h, gO, gV, gH, B, Ho, Wo, nph, ncol, per_wg, TB, cls);
   return savfi_launch_status();
 }
 
 // forward of the same op, widths that are a multiple of 4 (declared in csrc/common.h)
 int savfi_sepconv_fwd_ws_launch(const float* in, const float* v, const float* h, float* out, int B, int Ho, int Wo, int cus, int TB,
-                                hipStream_t st) {
+                                const unsigned* cls, hipStream_t st) {
   const int nph = savfi_cdiv(Ho, XPR), ncol = savfi_cdiv(Wo, XMC);
   const int64_t total = (int64_t)B * ncol * nph;
   const int per_wg = savfi_cdiv(total, cus);
   const int grid = savfi_cdiv(total, per_wg);
-  static uint32_t done = 0;
-  if (int e = savfi_ensure_dynamic_lds((const void*)sepconv_fwd_ws, FLDS, done)) return e;
-  hipLaunchKernelGGL(sepconv_fwd_ws, dim3(grid), dim3(WNT), FLDS, st, in, v, h, out, B, Ho, Wo, nph, ncol, per_wg, TB);
+  static uint32_t done = 0, done8 = 0;
+  if (cls) {
+    if (int e = savfi_ensure_dynamic_lds((const void*)sepconv_fwd_ws<true>, FLDS, done8)) return e;
+    hipLaunchKernelGGL(sepconv_fwd_ws<true>, dim3(grid), dim3(WNT), FLDS, st, in, v, h, out, B, Ho, Wo, nph, ncol, per_wg, TB, cls);
+  }
+  if (int e = savfi_ensure_dynamic_lds((const void*)sepconv_fwd_ws<false>, FLDS, done)) return e;
+  hipLaunchKernelGGL(sepconv_fwd_ws<false>, dim3(grid), dim3(WNT), FLDS, st, in, v, h, out, B, Ho, Wo, nph, ncol, per_wg, TB, cls);
+  return savfi_launch_status();
+}
+
+// one word per classifier workgroup into cls[0 .. SAVFI_FRAMES8_WORDS): non-zero = an element of x[0 .. n) is not k / 255 (see ws_frames8_mine)
+extern "C" int savfi_frames8_classify_f32(const float* x, int64_t n, unsigned* cls, void* stream) {
+  if (!x || !cls) return SAVFI_E_NULL;
+  if (n <= 0) return SAVFI_E_SHAPE;
+  static_assert(CLS_WG == SAVFI_FRAMES8_WORDS, "include/savfi_hip.h");
+  hipLaunchKernelGGL(frames8_classify, dim3(CLS_WG), dim3(CLS_NT), 0, (hipStream_t)stream, x, (long long)n, cls);
   return savfi_launch_status();
 }
 

@@ -100,7 +100,9 @@ __device__ __forceinline__ void x6_rows_load(X6Rows<NROWS>& sr, __amdgpu_buffer_
       sr.buf[c][it] = x6_bload(in_rs, (unsigned)(((b * XC + c) * Hi + r) * Wi * 4 + colb), 0u);
     }
 }
-template <int NROWS>
+// U8 (csrc/sepconv_ws.hip, frames of 8-bit images): the window holds k = 255 w, an integer 0..255 and so ONE exact bf16 piece (plane c);
+// the side columns keep the fp32 values.
+template <int NROWS, bool U8 = false>
 __device__ __forceinline__ void x6_rows_write(const X6Rows<NROWS>& sr, char* __restrict__ smem, int r_lo, int tid, int side_off = XSIDE_OFF) {
   constexpr int NIT = X6Rows<NROWS>::NIT, NE = XC * NIT;
   const int q = tid & 127, rg = tid >> 7;
@@ -113,12 +115,17 @@ __device__ __forceinline__ void x6_rows_write(const X6Rows<NROWS>& sr, char* __r
     const float a = sr.buf[c0][i0], bb = sr.buf[c1][i1];
     const int s0 = (r_lo + rg + 4 * i0) & (XWIN - 1), s1 = (r_lo + rg + 4 * i1) & (XWIN - 1);
     if (q < 8 * XNBLK) {
-      unsigned h1, h2, h3;
-      x6_split2(a, bb, h1, h2, h3);
       char* d0 = smem + c0 * XPLANE + cell + s0 * 16;
       char* d1 = smem + c1 * XPLANE + cell + s1 * 16;
-      x6_st16(d0, h1); x6_st16(d0 + 3 * XPLANE, h2); x6_st16(d0 + 6 * XPLANE, h3);
-      x6_st16(d1, h1 >> 16); x6_st16(d1 + 3 * XPLANE, h2 >> 16); x6_st16(d1 + 6 * XPLANE, h3 >> 16);
+      if constexpr (U8) {
+        const unsigned k1 = x6_cvt_pk(rintf(a * 255.f), rintf(bb * 255.f));
+        x6_st16(d0, k1); x6_st16(d1, k1 >> 16);
+      } else {
+        unsigned h1, h2, h3;
+        x6_split2(a, bb, h1, h2, h3);
+        x6_st16(d0, h1); x6_st16(d0 + 3 * XPLANE, h2); x6_st16(d0 + 6 * XPLANE, h3);
+        x6_st16(d1, h1 >> 16); x6_st16(d1 + 3 * XPLANE, h2 >> 16); x6_st16(d1 + 6 * XPLANE, h3 >> 16);
+      }
     }
     if (sidx >= 0) {
       side[(c0 * XWIN + s0) * 4 + sidx] = a;

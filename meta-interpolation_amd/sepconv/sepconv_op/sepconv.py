@@ -9,9 +9,34 @@ NotImplementedError for CPU tensors (:293-294, :373-374).  The work is done by
 savfi_sepconv_fwd_f32 / savfi_sepconv_bwd_f32 (include/savfi_hip.h) on torch's current stream;
 there is no string templating, no JIT, no per-shape compile, and the outputs need no pre-zeroing.
 """
+import os
+
 import torch
 
 from ... import _hip
+
+# Frames of 8-bit images (include/savfi_hip.h, csrc/sepconv_ws.hip): the op classifies its frame tensor on the device at every forward
+# call and hands the words to savfi_sepconv_{fwd,bwd}_frames8_f32, which run the three-product kernels on frames that are k / 255 and the
+# six-product kernels on anything else.  SAVFI_SEPCONV_NO_FRAMES8=1: always the six-product kernels (A/B runs).
+FRAMES8 = os.environ.get('SAVFI_SEPCONV_NO_FRAMES8') is None
+FRAMES8_WORDS = 256
+_E_UNSUPPORTED = -3
+
+
+def frames8_supported(frame, B, C, Ho, Wo, K, tap_bstride=None):
+    """shapes savfi_sepconv_*_frames8_f32 take (the wave-specialised kernels: K = 51, C = 3, Wo % 4 == 0, taps below 2^31 bytes)"""
+    tb = K if tap_bstride is None else tap_bstride
+    return (FRAMES8 and frame.is_cuda and frame.dtype == torch.float32 and K == 51 and C == 3 and Wo % 4 == 0
+            and ((B - 1) * tb + K) * Ho * Wo * 4 < 2 ** 31)
+
+
+def frames8_classify(frame):
+    """int32[FRAMES8_WORDS] on the frame's device: all zero = every element of `frame` is the fp32 quotient k / 255, k = 0..255"""
+    cls = torch.empty(FRAMES8_WORDS, dtype=torch.int32, device=frame.device)
+    lib = _hip.lib()
+    _hip.launch("frames8_classify", lambda: _hip.check(lib.savfi_frames8_classify_f32(
+        frame.data_ptr(), frame.numel(), cls.data_ptr(), _hip.current_stream()), "savfi_frames8_classify_f32"), nbytes=4 * frame.numel())
+    return cls
 
 
 def algorithmic_bytes(B, C, Ho, Wo, K, grads=0):
@@ -40,18 +65,35 @@ class FunctionSepconv(torch.autograd.Function):
         if not input.is_cuda:
             raise NotImplementedError("FunctionSepconv has no CPU path (neither does the reference)")
         _hip.require_cuda(input, vertical, horizontal)
-        ctx.save_for_backward(input, vertical, horizontal)
         output = torch.empty((B, C, Ho, Wo), dtype=input.dtype, device=input.device)
         lib = _hip.lib()
-        _hip.launch("sepconv_fwd", lambda: _hip.check(lib.savfi_sepconv_fwd_f32(
-            input.data_ptr(), vertical.data_ptr(), horizontal.data_ptr(), output.data_ptr(),
-            B, C, Ho, Wo, K, _hip.current_stream()), "savfi_sepconv_fwd_f32"),
-            nbytes=algorithmic_bytes(B, C, Ho, Wo, K))
+        cls = None
+        if not ctx.needs_input_grad[0] and frames8_supported(input, B, C, Ho, Wo, K):
+            cls = frames8_classify(input)
+            rc = [0]
+
+            def run8():
+                rc[0] = lib.savfi_sepconv_fwd_frames8_f32(input.data_ptr(), vertical.data_ptr(), horizontal.data_ptr(), output.data_ptr(),
+                                                          cls.data_ptr(), B, C, Ho, Wo, K, K, _hip.current_stream())
+                if rc[0] != _E_UNSUPPORTED:
+                    _hip.check(rc[0], "savfi_sepconv_fwd_frames8_f32")
+            _hip.launch("sepconv_fwd", run8, nbytes=algorithmic_bytes(B, C, Ho, Wo, K))
+            if rc[0] == _E_UNSUPPORTED:
+                cls = None
+        if cls is None:
+            _hip.launch("sepconv_fwd", lambda: _hip.check(lib.savfi_sepconv_fwd_f32(
+                input.data_ptr(), vertical.data_ptr(), horizontal.data_ptr(), output.data_ptr(),
+                B, C, Ho, Wo, K, _hip.current_stream()), "savfi_sepconv_fwd_f32"),
+                nbytes=algorithmic_bytes(B, C, Ho, Wo, K))
+            ctx.save_for_backward(input, vertical, horizontal)
+        else:
+            ctx.save_for_backward(input, vertical, horizontal, cls)
         return output
 
     @staticmethod
     def backward(ctx, gradOutput):
-        input, vertical, horizontal = ctx.saved_tensors
+        input, vertical, horizontal = ctx.saved_tensors[:3]
+        cls = ctx.saved_tensors[3] if len(ctx.saved_tensors) > 3 else None
         B, C, Ho, Wo, K = _dims(input, vertical, horizontal)
         if not gradOutput.is_contiguous():
             gradOutput = gradOutput.contiguous()
@@ -62,7 +104,13 @@ class FunctionSepconv(torch.autograd.Function):
         gI = torch.empty_like(input) if need_i else None
         gV = torch.empty_like(vertical) if need_v else None
         gH = torch.empty_like(horizontal) if need_h else None
-        if need_i or need_v or need_h:
+        if cls is not None and need_v and need_h and not need_i:
+            lib = _hip.lib()
+            _hip.launch("sepconv_bwd", lambda: _hip.check(lib.savfi_sepconv_bwd_frames8_f32(
+                input.data_ptr(), vertical.data_ptr(), horizontal.data_ptr(), gradOutput.data_ptr(), gV.data_ptr(), gH.data_ptr(),
+                cls.data_ptr(), B, C, Ho, Wo, K, K, _hip.current_stream()), "savfi_sepconv_bwd_frames8_f32"),
+                nbytes=algorithmic_bytes(B, C, Ho, Wo, K, grads=2))
+        elif need_i or need_v or need_h:
             lib = _hip.lib()
             p = lambda t: None if t is None else t.data_ptr()
             name = "sepconv_bwd" if not need_i else "sepconv_bwd+gI"
@@ -98,20 +146,27 @@ class FunctionSepconvPair(torch.autograd.Function):
         assert input1.shape == input0.shape and taps.size(0) == 4 * B and Hi - K == Ho - 1 and Wi - K == Wo - 1, (input0.shape, taps.shape)
         assert input0.is_contiguous() and input1.is_contiguous() and taps.is_contiguous()
         _hip.require_cuda(input0, input1, taps)
-        ctx.save_for_backward(input0, input1, taps)
         out0 = torch.empty((B, C, Ho, Wo), dtype=input0.dtype, device=input0.device)
         out1 = torch.empty_like(out0)
         lib, st = _hip.lib(), _hip.current_stream()
         plane = K * Ho * Wo * 4
-        for inp, out, s in ((input0, out0, 0), (input1, out1, 2)):
-            _hip.launch("sepconv_fwd", lambda inp=inp, out=out, s=s: _hip.check(lib.savfi_sepconv_fwd_taps_strided_f32(
-                inp.data_ptr(), taps.data_ptr() + s * plane, taps.data_ptr() + (s + 1) * plane, out.data_ptr(),
-                B, C, Ho, Wo, K, 4 * K, st), "savfi_sepconv_fwd_taps_strided_f32"), nbytes=algorithmic_bytes(B, C, Ho, Wo, K))
+        words = [frames8_classify(inp) for inp in (input0, input1)] if frames8_supported(input0, B, C, Ho, Wo, K, 4 * K) else None
+        for i, (inp, out, s) in enumerate(((input0, out0, 0), (input1, out1, 2))):
+            if words is not None:
+                _hip.launch("sepconv_fwd", lambda inp=inp, out=out, s=s, i=i: _hip.check(lib.savfi_sepconv_fwd_frames8_f32(
+                    inp.data_ptr(), taps.data_ptr() + s * plane, taps.data_ptr() + (s + 1) * plane, out.data_ptr(), words[i].data_ptr(),
+                    B, C, Ho, Wo, K, 4 * K, st), "savfi_sepconv_fwd_frames8_f32"), nbytes=algorithmic_bytes(B, C, Ho, Wo, K))
+            else:
+                _hip.launch("sepconv_fwd", lambda inp=inp, out=out, s=s: _hip.check(lib.savfi_sepconv_fwd_taps_strided_f32(
+                    inp.data_ptr(), taps.data_ptr() + s * plane, taps.data_ptr() + (s + 1) * plane, out.data_ptr(),
+                    B, C, Ho, Wo, K, 4 * K, st), "savfi_sepconv_fwd_taps_strided_f32"), nbytes=algorithmic_bytes(B, C, Ho, Wo, K))
+        ctx.save_for_backward(input0, input1, taps, *(words or ()))
         return out0.add_(out1)
 
     @staticmethod
     def backward(ctx, gradOutput):
-        input0, input1, taps = ctx.saved_tensors
+        input0, input1, taps = ctx.saved_tensors[:3]
+        words = ctx.saved_tensors[3:] or None
         assert not ctx.needs_input_grad[0] and not ctx.needs_input_grad[1], "FunctionSepconvPair: frames carry no gradient on this path"
         if not ctx.needs_input_grad[2]:
             return None, None, None
@@ -122,11 +177,17 @@ class FunctionSepconvPair(torch.autograd.Function):
         gT = torch.empty_like(taps)
         lib, st = _hip.lib(), _hip.current_stream()
         plane = K * Ho * Wo * 4
-        for inp, s in ((input0, 0), (input1, 2)):
-            _hip.launch("sepconv_bwd", lambda inp=inp, s=s: _hip.check(lib.savfi_sepconv_bwd_taps_strided_f32(
-                inp.data_ptr(), taps.data_ptr() + s * plane, taps.data_ptr() + (s + 1) * plane, gradOutput.data_ptr(),
-                gT.data_ptr() + s * plane, gT.data_ptr() + (s + 1) * plane, B, C, Ho, Wo, K, 4 * K, st),
-                "savfi_sepconv_bwd_taps_strided_f32"), nbytes=algorithmic_bytes(B, C, Ho, Wo, K, grads=2))
+        for i, (inp, s) in enumerate(((input0, 0), (input1, 2))):
+            if words is not None:
+                _hip.launch("sepconv_bwd", lambda inp=inp, s=s, i=i: _hip.check(lib.savfi_sepconv_bwd_frames8_f32(
+                    inp.data_ptr(), taps.data_ptr() + s * plane, taps.data_ptr() + (s + 1) * plane, gradOutput.data_ptr(),
+                    gT.data_ptr() + s * plane, gT.data_ptr() + (s + 1) * plane, words[i].data_ptr(), B, C, Ho, Wo, K, 4 * K, st),
+                    "savfi_sepconv_bwd_frames8_f32"), nbytes=algorithmic_bytes(B, C, Ho, Wo, K, grads=2))
+            else:
+                _hip.launch("sepconv_bwd", lambda inp=inp, s=s: _hip.check(lib.savfi_sepconv_bwd_taps_strided_f32(
+                    inp.data_ptr(), taps.data_ptr() + s * plane, taps.data_ptr() + (s + 1) * plane, gradOutput.data_ptr(),
+                    gT.data_ptr() + s * plane, gT.data_ptr() + (s + 1) * plane, B, C, Ho, Wo, K, 4 * K, st),
+                    "savfi_sepconv_bwd_taps_strided_f32"), nbytes=algorithmic_bytes(B, C, Ho, Wo, K, grads=2))
         return None, None, gT
 
 

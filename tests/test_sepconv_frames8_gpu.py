@@ -1,0 +1,217 @@
+"""-m gpu: the SepConv op on frames of 8-bit images (savfi_frames8_classify_f32, savfi_sepconv_{fwd,bwd}_frames8_f32; csrc/sepconv_ws.hip).
+
+The reference feeds the op decoded PNG frames, k / 255 (data/vimeo_septuplet.py:24-36, sepconv/model.py:346-347).  For such a frame tensor the
+device selects kernels that hold the window as the integers k (one exact bf16 piece) and spend three bf16 products per fp32 product; for any
+other tensor it selects the six-product kernels.  Checked here: the classifier, both selections through the C ABI against the CPU oracle at
+the tolerance of tests/test_hip_ops_gpu.py (1e-5 of max|ref|: fp32 sums of 2601 products in another association), that the selection is
+what the words say, and that tensors which do not qualify get bit-identical results to the entry points without the words."""
+import math
+
+import pytest
+import torch
+
+from meta_interpolation_amd import _hip
+from meta_interpolation_amd.sepconv.sepconv_op import sepconv as S
+from oracle import torch_ops as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+K = 51
+
+
+def _rel(a, b):
+    return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-12)
+
+
+def _inputs(B, Ho, Wo, seed, frames8=True):
+    g = torch.Generator().manual_seed(seed)
+    if frames8:
+        inp = torch.randint(0, 256, (B, 3, Ho + K - 1, Wo + K - 1), generator=g).float().div(255)      # ToTensor's arithmetic
+    else:
+        inp = torch.rand(B, 3, Ho + K - 1, Wo + K - 1, generator=g)
+    v = torch.randn(B, K, Ho, Wo, generator=g) / math.sqrt(K)
+    h = torch.randn(B, K, Ho, Wo, generator=g) / math.sqrt(K)
+    gO = torch.randn(B, 3, Ho, Wo, generator=g)
+    return inp, v, h, gO
+
+
+def _words(x):
+    w = S.frames8_classify(x)
+    torch.cuda.synchronize()
+    return w
+
+
+def test_classifier_accepts_k_over_255_and_nothing_else():
+    g = torch.Generator().manual_seed(3)
+    x = torch.randint(0, 256, (2, 3, 77, 131), generator=g).float().div(255).to(DEV)
+    assert int(_words(x).abs().sum()) == 0
+    # float64 quotient rounded to fp32 (numpy's route in synthetic.py) is the same number or its neighbour: accepted
+    x64 = (torch.randint(0, 256, (5, 3, 33, 47), generator=g).double() / 255.0).float().to(DEV)
+    assert int(_words(x64).abs().sum()) == 0
+    for bad in (0.5, 1.0 + 1e-6, -1.0 / 255, 3e-5, float("nan"), float("inf"), 100.0 / 255 * (1 + 1e-6)):
+        y = x.clone()
+        y.view(-1)[12345] = bad
+        assert int(_words(y).abs().sum()) > 0, bad
+    # one odd element at either end of a tensor whose length is no multiple of 4, and a misaligned base pointer
+    z = torch.randint(0, 256, (4099,), generator=g).float().div(255).to(DEV)
+    assert int(_words(z).abs().sum()) == 0
+    assert int(_words(z[1:]).abs().sum()) == 0
+    for pos in (0, 4098):
+        y = z.clone()
+        y[pos] = 0.3
+        assert int(_words(y).abs().sum()) > 0
+    assert int(_words(torch.rand(1, 3, 64, 64, device=DEV)).abs().sum()) > 0
+
+
+@pytest.mark.parametrize("B,Ho,Wo", [(1, 16, 32), (2, 37, 36), (1, 128, 128), (2, 64, 96), (1, 9, 68), (3, 5, 4)])
+def test_frames8_kernels_vs_oracle(B, Ho, Wo):
+    inp, v, h, gO = _inputs(B, Ho, Wo, seed=100 * B + Ho)
+    ref = O.sepconv_forward_c(inp, v, h)
+    _, rV, rH = O.sepconv_backward_c(inp, v, h, gO)
+    di = inp.to(DEV)
+    dv, dh = (t.to(DEV).requires_grad_() for t in (v, h))
+    assert S.frames8_supported(di, B, 3, Ho, Wo, K)
+    out = S.FunctionSepconv.apply(di, dv, dh)
+    out.backward(gO.to(DEV))
+    torch.cuda.synchronize()
+    assert _rel(out.detach().cpu(), ref) < 1e-5
+    assert _rel(dv.grad.cpu(), rV) < 1e-5
+    assert _rel(dh.grad.cpu(), rH) < 1e-5
+    assert _hip.lib().savfi_sepconv_ws_errors() == 0
+
+
+def _abi_fwd(inp, v, h, words, tb=K):
+    B, _, Ho, Wo = v.shape[0], None, v.shape[2], v.shape[3]
+    out = torch.empty(B, 3, Ho, Wo, device=DEV)
+    lib = _hip.lib()
+    if words is None:
+        _hip.check(lib.savfi_sepconv_fwd_taps_strided_f32(inp.data_ptr(), v.data_ptr(), h.data_ptr(), out.data_ptr(), B, 3, Ho, Wo, K, tb,
+                                                          _hip.current_stream()), "fwd")
+    else:
+        _hip.check(lib.savfi_sepconv_fwd_frames8_f32(inp.data_ptr(), v.data_ptr(), h.data_ptr(), out.data_ptr(), words.data_ptr(), B, 3, Ho, Wo,
+                                                     K, tb, _hip.current_stream()), "fwd8")
+    return out
+
+
+def _abi_bwd(inp, v, h, gO, words, tb=K):
+    B, Ho, Wo = v.shape[0], v.shape[2], v.shape[3]
+    gV, gH = torch.empty_like(v), torch.empty_like(h)
+    lib = _hip.lib()
+    if words is None:
+        _hip.check(lib.savfi_sepconv_bwd_taps_strided_f32(inp.data_ptr(), v.data_ptr(), h.data_ptr(), gO.data_ptr(), gV.data_ptr(), gH.data_ptr(),
+                                                          B, 3, Ho, Wo, K, tb, _hip.current_stream()), "bwd")
+    else:
+        _hip.check(lib.savfi_sepconv_bwd_frames8_f32(inp.data_ptr(), v.data_ptr(), h.data_ptr(), gO.data_ptr(), gV.data_ptr(), gH.data_ptr(),
+                                                     words.data_ptr(), B, 3, Ho, Wo, K, tb, _hip.current_stream()), "bwd8")
+    return gV, gH
+
+
+def test_the_words_select_the_kernel_on_the_device():
+    B, Ho, Wo = 2, 40, 64
+    zero = torch.zeros(S.FRAMES8_WORDS, dtype=torch.int32, device=DEV)
+    one = torch.zeros(S.FRAMES8_WORDS, dtype=torch.int32, device=DEV)
+    one[S.FRAMES8_WORDS - 1] = 1
+    # (a) frames that do not qualify + words that say so: bit-identical to the entry points without the words
+    inp, v, h, gO = (t.to(DEV) for t in _inputs(B, Ho, Wo, seed=5, frames8=False))
+    words = _words(inp)
+    assert int(words.abs().sum()) > 0
+    assert torch.equal(_abi_fwd(inp, v, h, words), _abi_fwd(inp, v, h, None))
+    for a, b in zip(_abi_bwd(inp, v, h, gO, words), _abi_bwd(inp, v, h, gO, None)):
+        assert torch.equal(a, b)
+    # (b) the same frames with forged all-zero words: the three-product kernels run (they round 255 w to an integer: visibly wrong here)
+    assert _rel(_abi_fwd(inp, v, h, zero), _abi_fwd(inp, v, h, None)) > 1e-4
+    assert _rel(_abi_bwd(inp, v, h, gO, zero)[0], _abi_bwd(inp, v, h, gO, None)[0]) > 1e-4
+    # (c) frames that qualify with forged non-zero words: the six-product kernels, bit for bit; with their own words: the same to fp32 rounding
+    inp8 = _inputs(B, Ho, Wo, seed=6)[0].to(DEV)
+    assert torch.equal(_abi_fwd(inp8, v, h, one), _abi_fwd(inp8, v, h, None))
+    w8 = _words(inp8)
+    assert int(w8.abs().sum()) == 0
+    assert _rel(_abi_fwd(inp8, v, h, w8), _abi_fwd(inp8, v, h, None)) < 2e-6
+    for a, b in zip(_abi_bwd(inp8, v, h, gO, w8), _abi_bwd(inp8, v, h, gO, None)):
+        assert _rel(a, b) < 2e-6
+    assert _hip.lib().savfi_sepconv_ws_errors() == 0
+
+
+def test_frames8_is_as_close_to_float64_as_the_six_product_kernels():
+    """against a float64 evaluation of the op and its autograd on the fp32 inputs (oracle/torch_ops.sepconv_torch in double)"""
+    B, Ho, Wo = 1, 32, 64
+    inp, v, h, gO = _inputs(B, Ho, Wo, seed=11)
+    v64, h64 = v.double().requires_grad_(), h.double().requires_grad_()
+    ref = O.sepconv_torch(inp.double(), v64, h64)
+    ref.backward(gO.double())
+    d = [t.to(DEV) for t in (inp, v, h)]
+    w8 = _words(d[0])
+    err = lambda x, r: (x.cpu().double() - r).abs().max().item() / r.abs().max().item()
+    e8, e6 = err(_abi_fwd(*d, w8), ref.detach()), err(_abi_fwd(*d, None), ref.detach())
+    g8, g6 = _abi_bwd(*d, gO.to(DEV), w8), _abi_bwd(*d, gO.to(DEV), None)
+    print("max error / max|ref| against float64: forward %.3g (three products) %.3g (six); gV %.3g %.3g; gH %.3g %.3g"
+          % (e8, e6, err(g8[0], v64.grad), err(g6[0], v64.grad), err(g8[1], h64.grad), err(g6[1], h64.grad)))
+    assert e8 < max(2 * e6, 5e-7)
+    assert err(g8[0], v64.grad) < max(2 * err(g6[0], v64.grad), 5e-7)
+    assert err(g8[1], h64.grad) < max(2 * err(g6[1], h64.grad), 5e-7)
+
+
+def test_full_size_frames8_against_the_six_product_kernels_and_refusals():
+    B, Ho, Wo = 4, 256, 448
+    inp, v, h, gO = (t.to(DEV) for t in _inputs(B, Ho, Wo, seed=21))
+    w8 = _words(inp)
+    assert int(w8.abs().sum()) == 0
+    assert _rel(_abi_fwd(inp, v, h, w8), _abi_fwd(inp, v, h, None)) < 2e-6
+    for a, b in zip(_abi_bwd(inp, v, h, gO, w8), _abi_bwd(inp, v, h, gO, None)):
+        assert _rel(a, b) < 2e-6
+    assert _hip.lib().savfi_sepconv_ws_errors() == 0
+    lib = _hip.lib()
+    out = torch.empty(B, 3, Ho, Wo, device=DEV)
+    args = (inp.data_ptr(), v.data_ptr(), h.data_ptr(), out.data_ptr())
+    assert lib.savfi_sepconv_fwd_frames8_f32(*args, None, B, 3, Ho, Wo, K, K, _hip.current_stream()) == -1          # NULL words
+    assert lib.savfi_sepconv_fwd_frames8_f32(*args, w8.data_ptr(), B, 3, Ho, Wo - 2, K, K, _hip.current_stream()) == -3   # width % 4
+    assert lib.savfi_sepconv_fwd_frames8_f32(*args, w8.data_ptr(), B, 3, Ho, Wo, 13, 13, _hip.current_stream()) == -3     # K != 51
+    assert lib.savfi_frames8_classify_f32(None, 5, w8.data_ptr(), _hip.current_stream()) == -1
+    assert lib.savfi_frames8_classify_f32(inp.data_ptr(), 0, w8.data_ptr(), _hip.current_stream()) == -2
+
+
+def test_op_falls_back_for_shapes_and_tensors_outside_the_fast_path(monkeypatch):
+    # width % 4 != 0, a frame that carries a gradient, the switch: all through the entry points without the words, same numbers as before
+    inp, v, h, gO = _inputs(1, 20, 30, seed=8)
+    di, dv, dh = inp.to(DEV), v.to(DEV).requires_grad_(), h.to(DEV).requires_grad_()
+    assert not S.frames8_supported(di, 1, 3, 20, 30, K)
+    out = S.FunctionSepconv.apply(di, dv, dh)
+    out.backward(gO.to(DEV))
+    assert _rel(out.detach().cpu(), O.sepconv_forward_c(inp, v, h)) < 1e-5
+    inp, v, h, gO = _inputs(1, 24, 40, seed=9)
+    di, dv, dh = (t.to(DEV).requires_grad_() for t in (inp, v, h))
+    out = S.FunctionSepconv.apply(di, dv, dh)
+    out.backward(gO.to(DEV))
+    rI, rV, rH = O.sepconv_backward_c(inp, v, h, gO, need_input=True)
+    assert _rel(di.grad.cpu(), rI) < 1e-5 and _rel(dv.grad.cpu(), rV) < 1e-5 and _rel(dh.grad.cpu(), rH) < 1e-5
+    monkeypatch.setattr(S, "FRAMES8", False)
+    d2 = inp.to(DEV)
+    dv2, dh2 = v.to(DEV).requires_grad_(), h.to(DEV).requires_grad_()
+    out2 = S.FunctionSepconv.apply(d2, dv2, dh2)
+    out2.backward(gO.to(DEV))
+    monkeypatch.setattr(S, "FRAMES8", True)
+    dv3, dh3 = v.to(DEV).requires_grad_(), h.to(DEV).requires_grad_()
+    out3 = S.FunctionSepconv.apply(d2, dv3, dh3)
+    out3.backward(gO.to(DEV))
+    assert _rel(out3.detach(), out2.detach()) < 2e-6 and _rel(dv3.grad, dv2.grad) < 2e-6 and _rel(dh3.grad, dh2.grad) < 2e-6
+
+
+def test_pair_op_on_interleaved_taps_with_frames8(monkeypatch):
+    B, Ho, Wo = 2, 36, 64
+    g = torch.Generator().manual_seed(31)
+    f0 = torch.randint(0, 256, (B, 3, Ho + K - 1, Wo + K - 1), generator=g).float().div(255).to(DEV)
+    f1 = torch.randint(0, 256, (B, 3, Ho + K - 1, Wo + K - 1), generator=g).float().div(255).to(DEV)
+    taps = (torch.randn(4 * B, K, Ho, Wo, generator=g) / math.sqrt(K)).to(DEV)
+    gO = torch.randn(B, 3, Ho, Wo, generator=g).to(DEV)
+    res = []
+    for on in (True, False):
+        monkeypatch.setattr(S, "FRAMES8", on)
+        t = taps.clone().requires_grad_()
+        out = S.FunctionSepconvPair.apply(f0, f1, t)
+        out.backward(gO)
+        res.append((out.detach(), t.grad))
+    assert _rel(res[0][0], res[1][0]) < 2e-6 and _rel(res[0][1], res[1][1]) < 2e-6
+    ref = O.sepconv_forward_c(f0.cpu(), taps[0::4].cpu().contiguous(), taps[1::4].cpu().contiguous()) + \
+        O.sepconv_forward_c(f1.cpu(), taps[2::4].cpu().contiguous(), taps[3::4].cpu().contiguous())
+    assert _rel(res[0][0].cpu(), ref) < 1e-5
+    assert _hip.lib().savfi_sepconv_ws_errors() == 0

@@ -5,12 +5,18 @@ import torch
 from meta_interpolation_amd import _hip
 B, C, Ho, Wo, K = int(sys.argv[1]) if len(sys.argv) > 1 else 8, 3, 256, 448, 51
 lib, st = _hip.lib(), _hip.current_stream()
-inp = torch.rand(B, C, Ho + K - 1, Wo + K - 1, device="cuda")
+F8 = len(sys.argv) > 2 and sys.argv[2] == "f8"       # frames of 8-bit images through savfi_sepconv_bwd_frames8_f32 (the three-product kernel)
+inp = torch.randint(0, 256, (B, C, Ho + K - 1, Wo + K - 1), device="cuda").float().div(255) if F8 else torch.rand(B, C, Ho + K - 1, Wo + K - 1, device="cuda")
 v = torch.randn(B, K, Ho, Wo, device="cuda") / 7
 h = torch.randn(B, K, Ho, Wo, device="cuda") / 7
 gO = torch.randn(B, C, Ho, Wo, device="cuda")
 gV, gH = torch.empty_like(v), torch.empty_like(h)
-f = lambda: _hip.check(lib.savfi_sepconv_bwd_f32(inp.data_ptr(), v.data_ptr(), h.data_ptr(), gO.data_ptr(), None, gV.data_ptr(), gH.data_ptr(), B, C, Ho, Wo, K, st), "bwd")
+if F8:
+    from meta_interpolation_amd.sepconv.sepconv_op import sepconv as S
+    words = S.frames8_classify(inp)
+    f = lambda: _hip.check(lib.savfi_sepconv_bwd_frames8_f32(inp.data_ptr(), v.data_ptr(), h.data_ptr(), gO.data_ptr(), gV.data_ptr(), gH.data_ptr(), words.data_ptr(), B, C, Ho, Wo, K, K, st), "bwd8")
+else:
+    f = lambda: _hip.check(lib.savfi_sepconv_bwd_f32(inp.data_ptr(), v.data_ptr(), h.data_ptr(), gO.data_ptr(), None, gV.data_ptr(), gH.data_ptr(), B, C, Ho, Wo, K, st), "bwd")
 buf = (ctypes.c_ulonglong * 256)()
 lib.savfi_sepconv_ws_trace.argtypes = [ctypes.c_void_p, ctypes.c_int]
 for _ in range(3): f()
@@ -27,7 +33,7 @@ units = 2 * ((B * 14 * 64 + 255) // 256)
 print("per unit (2 passes) cycles, workgroup 0, %d units per pair, lib %s" % (units, os.environ.get("SAVFI_HIP_LIB")))
 MF = ["top", "wait tab(h)", "Bfrag h+set+slide wait", "gV MFMA loop", "gV scale", "wait out_free", "tile write+set", "wait tab(v)", "Bfrag v+set", "gH MFMA loop", "gH scale", "wait out_free", "tile write+set", "T13 wait tab(h next)", "T14 Bfrag+slide wait"]
 SG_OLD = ["top: granule loads, readlanes", "wait tab_free", "h table write", "B: side, tails-a, h loads", "wait out_full(gH)", "drain gH", "gV tail sums", "wait tab_free", "v table write", "E: gH tails, v loads", "wait out_full(gV)", "drain gV", "wait prog", "granule write"]
-SG = ["top: row load, readlanes", "wait tab_free", "table write+set", "tails (side, sums), tap loads", "wait prog", "window row write", "wait out_full(prev)", "drain+stores(prev)"]
+SG = ["top: row load, readlanes", "wait tab_free", "table write+set", "tails (side, sums), tap loads", "wait prog", "window row write", "wait out_full(prev)", "drain+stores(prev)", "v: slide wait + side reads", "v: tail sums"]
 two = os.environ.get('SAVFI_SEPCONV_WS2') is not None
 MF2 = ['top', '-', '-', 'gV half 1 loop (72 MFMAs)', 'tail wait + epilogue 1 (2 stores)', 'gV half 2 loop (48)', 'v frags + epilogue 2 (2 stores)', '-', '-', 'gH half 1 loop (72)', 'gH half 2 loop (72)', 'epilogue h1 (wait out_free, 8 writes)', 'next h frags, rows, epilogue h2, set', '-', '-']
 for w in range(16 if two else 12):
