@@ -315,7 +315,10 @@ def main():
         "value_reading_the_loss_every_iteration": tasks * world * S * opt.steps / elapsed_logged,
         # fp32 arithmetic end to end; the direct convolution kernels evaluate every fp32 product as six bf16 products of exactly
         # split operands with fp32 accumulation (csrc/convk.hip: as close to float64 as an fp32 fmaf chain)
-        "dtype": "f32 (convolutions on csrc/convk*.hip: bf16x6 split operands, f32 accumulate)", "data": "synthetic",
+        # the 51-tap op on frames of 8-bit images (k / 255, classified on the device at every call): the frame operand is the exact integer k
+        # in ONE bf16 piece, so three exact bf16 products per fp32 product (csrc/sepconv_ws.hip)
+        "dtype": "f32 (convolutions on csrc/convk*.hip: bf16x6 split operands, f32 accumulate; 51-tap op on 8-bit frames: exact "
+                 "integer frames x bf16x3 split taps, f32 accumulate)", "data": "synthetic",
         "config": {"workload": opt.workload, "plugin": model, "tasks_per_gpu": tasks, "global_meta_batch": tasks * world,
                    "inner_steps": S, "frame": "%dx%dx3" % (H, W),
                    "inner_rule": ("metasgd" if over.get('metasgd') else "lslr") + "+" + over.get('optimizer', 'SGD'),
@@ -342,7 +345,7 @@ def main():
                 # the op runs on the frame window (H x W) or, with --sepconv-window 0, on the reference's padded canvas
                 oh, ow = (H, W) if args.sepconv_window else net.padded_size(H, W)
                 traffic, tnote = None, "no committed PMC measurement found"
-                for tname in ("r04_hbm_traffic_sepconv.json", "r03_hbm_traffic_sepconv.json", "r02_hbm_traffic_sepconv.json", "r01_hbm_traffic_sepconv.json"):
+                for tname in ("r04_hbm_traffic_sepconv_frames8.json", "r04_hbm_traffic_sepconv.json", "r03_hbm_traffic_sepconv.json", "r02_hbm_traffic_sepconv.json", "r01_hbm_traffic_sepconv.json"):
                     tpath = os.path.join(REPO, "profiles", tname)
                     if not os.path.exists(tpath):
                         continue
@@ -358,14 +361,18 @@ def main():
                         break
                 per_call = 4.0 * (3 * (oh + 50) * (ow + 50) + 4 * 51 * oh * ow + 3 * oh * ow)
                 line["roofline"] = {
-                    "bound": "hbm", "kernel": "sepconv_bwd_ws (gV+gH, K=51; csrc/sepconv_ws.hip: split-bf16 MFMAs, MFMA waves + staging waves in pairs)",
+                    "bound": "hbm", "kernel": "sepconv_bwd_ws<U8> (gV+gH, K=51; csrc/sepconv_ws.hip: frames of 8-bit images as exact integers x split-bf16 taps "
+                                              "on MFMAs, MFMA waves + staging waves in pairs; the timed interval also holds the six-product instance's "
+                                              "early exit: both are launched, the device picks)",
                     "achieved": k["achieved_GBps"], "peak": 8000.0, "unit": "GB/s",
                     "frac": k["achieved_GBps"] / 8000.0, "traffic": traffic, "traffic_source": tnote,
                     "avg_us_per_launch": k["avg_us"], "launches": k["launches"],
                     "algorithmic_bytes_per_launch": k["algorithmic_bytes"] / k["launches"],
                     "note": "algorithmic bytes = %.2f MB per [1,3,%d,%d] sample (x samples per launch: tasks in lockstep x the "
-                            "support pair); 264 bf16 MFMAs per 16 pixels = 46%% of the launch at the measured 19 ticks per MFMA; the MFMA wave's cotangent scaling and tile "
-                            "writes (a third of its cycles) and the staging waves' tap splits share the SIMD's VALU port (DESIGN.md 4f, profiles/r04_ws_experiments.txt)"
+                            "support pair); 132 bf16 MFMAs per 16 pixels (the MFMA waves alone sustain 124 us per B = 8 launch); the launch is bound by the "
+                            "staging waves' tap loads and gradient stores backing up in the memory pipeline -- 64-byte pieces of 204 planes a multiple of "
+                            "64 KB apart (with every load hitting the cache: 161 us; with the taps addressed unit-major: 189 against 222 us isolated; "
+                            "DESIGN.md 4g, profiles/r04_frames8_experiments.txt)"
                             % (per_call / 1e6, oh, ow)}
             elif summ:
                 # workloads without the 51-tap op: the HBM-bound savfi kernel that takes the most time in the timed region

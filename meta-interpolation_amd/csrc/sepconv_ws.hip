@@ -176,6 +176,19 @@ __device__ __forceinline__ int ws_lane() {
 // decided ON THE DEVICE, per call: savfi_frames8_classify_f32 leaves one word per classifier workgroup (non-zero = it met an element that is
 // not the fp32 quotient k / 255 to within 2 ulp), the <U8 = true> and <U8 = false> instances of a kernel are both launched and the one the
 // words do not select returns at once -- no host round trip (graph-capture safe), any other input takes the six-product path unchanged.
+// which phases a workgroup takes (see the kernels)
+__device__ __forceinline__ void ws_work_range(int aligned, int S, int nph, int per_wg, int& g0, int& g1, int& span, int& base) {
+  const int nfull = aligned ? nph / per_wg : 0, nA = S * nfull, bx = (int)blockIdx.x;
+  if (bx < nA) {
+    const int c = bx / S, st = bx - c * S;
+    span = nph; base = 0; g0 = st * nph + c * per_wg; g1 = g0 + per_wg;
+  } else if (aligned) {
+    span = max(nph - nfull * per_wg, 1); base = nfull * per_wg;
+    g0 = (bx - nA) * per_wg; g1 = min(g0 + per_wg, S * (nph - nfull * per_wg));
+  } else {
+    span = nph; base = 0; g0 = bx * per_wg; g1 = min(g0 + per_wg, S * nph);
+  }
+}
 constexpr int CLS_WG = 256, CLS_NT = 1024;         // classifier grid: one 16-byte load of the words per lane of the consumer
 template <bool U8>
 __device__ __forceinline__ bool ws_frames8_mine(const unsigned* __restrict__ cls) {
@@ -210,7 +223,7 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
                                                       const float* __restrict__ h, const float* __restrict__ gO,
                                                       float* __restrict__ gV, float* __restrict__ gH,
                                                       int B, int Ho, int Wo, int nph, int ncol, int per_wg, int TB,
-                                                      const unsigned* __restrict__ cls) {
+                                                      const unsigned* __restrict__ cls, int aligned) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int p = w & 3, wc = p & 1, wr0 = p >> 1;
@@ -224,8 +237,14 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
   unsigned* const fl = reinterpret_cast<unsigned*>(smem + WFLAG_OFF);
 
   const unsigned long long t_kernel0 = WS_TRACE ? __builtin_readcyclecounter() : 0ull;
-  const int total = B * ncol * nph;
-  const int g0 = blockIdx.x * per_wg, g1 = min(g0 + per_wg, total);
+  // A workgroup's phases: position g of a linear order in which strip = g / span and phase = base + g % span.
+  //   aligned == 0 (default): strip-major order of all phases cut into pieces of per_wg (span = nph): workgroups that run side by side
+  //                 work on unrelated rows.
+  //   aligned != 0 (experiment, slower: see ws_aligned_env): every strip's phases [c per_wg, (c + 1) per_wg) go to workgroup c S + strip
+  //                 (S strips), the workgroups of one chunk walk down the same rows of neighbouring strips at the same time; what is left of
+  //                 each strip (nph % per_wg phases) is cut in the old way.
+  int g0, g1, span, base;
+  ws_work_range(aligned, B * ncol, nph, per_wg, g0, g1, span, base);
   if (g0 >= g1) return;
   if (!ws_frames8_mine<U8>(cls)) return;
   const int Hi = Ho + XK - 1, Wi = Wo + XK - 1;
@@ -319,8 +338,8 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
 #pragma unroll 1
   while (g < g1) {
     // ---- a run: phases ph0 .. ph0 + nrun - 1 of strip (b, x0) ---------------------------------------------------------------
-    const int s = g / nph, ph0 = g - s * nph, b = s / ncol, x0 = (s - b * ncol) * XMC;
-    const int run_end = min(g1, g + (nph - ph0)), nrun = run_end - g, N = 2 * nrun;
+    const int s = g / span, gin = g - s * span, ph0 = base + gin, b = s / ncol, x0 = (s - b * ncol) * XMC;
+    const int run_end = min(g1, g + (span - gin)), nrun = run_end - g, N = 2 * nrun;
     const int R0 = XPR * ph0;
     auto unit_y = [&](int n) { return R0 + XPR * (n >> 1) + wr0 + 2 * (n & 1); };
 
@@ -1506,7 +1525,7 @@ template <bool U8>
 __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ in, const float* __restrict__ v,
                                                       const float* __restrict__ h, float* __restrict__ out,
                                                       int B, int Ho, int Wo, int nph, int ncol, int per_wg, int TB,
-                                                      const unsigned* __restrict__ cls) {
+                                                      const unsigned* __restrict__ cls, int aligned) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int p = w & 3, wc = p & 1, wr0 = p >> 1;
@@ -1519,8 +1538,14 @@ __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ 
   float* const side = reinterpret_cast<float*>(smem + FSIDE_OFF);
   unsigned* const fl = reinterpret_cast<unsigned*>(smem + FFLAG_OFF);
 
-  const int total = B * ncol * nph;
-  const int g0 = blockIdx.x * per_wg, g1 = min(g0 + per_wg, total);
+  // A workgroup's phases: position g of a linear order in which strip = g / span and phase = base + g % span.
+  //   aligned == 0 (default): strip-major order of all phases cut into pieces of per_wg (span = nph): workgroups that run side by side
+  //                 work on unrelated rows.
+  //   aligned != 0 (experiment, slower: see ws_aligned_env): every strip's phases [c per_wg, (c + 1) per_wg) go to workgroup c S + strip
+  //                 (S strips), the workgroups of one chunk walk down the same rows of neighbouring strips at the same time; what is left of
+  //                 each strip (nph % per_wg phases) is cut in the old way.
+  int g0, g1, span, base;
+  ws_work_range(aligned, B * ncol, nph, per_wg, g0, g1, span, base);
   if (g0 >= g1) return;
   if (!ws_frames8_mine<U8>(cls)) return;
   const int Hi = Ho + XK - 1, Wi = Wo + XK - 1;
@@ -1579,8 +1604,8 @@ __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ 
   int g = g0;
 #pragma unroll 1
   while (g < g1) {
-    const int s = g / nph, ph0 = g - s * nph, b = s / ncol, x0 = (s - b * ncol) * XMC;
-    const int run_end = min(g1, g + (nph - ph0)), nrun = run_end - g, N = 2 * nrun;
+    const int s = g / span, gin = g - s * span, ph0 = base + gin, b = s / ncol, x0 = (s - b * ncol) * XMC;
+    const int run_end = min(g1, g + (span - gin)), nrun = run_end - g, N = 2 * nrun;
     const int R0 = XPR * ph0;
     auto unit_y = [&](int n) { return R0 + XPR * (n >> 1) + wr0 + 2 * (n & 1); };
     __syncthreads();
@@ -1860,6 +1885,20 @@ __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ 
 // gV and gH of the K = 51, C = 3 op, widths that are a multiple of 4; every tensor below 2^31 bytes (the caller checks).
 // TB: tap planes between two samples of v / h / gV / gH (51 for contiguous [B,51,Ho,Wo] tensors; larger when the tensors are slices of one
 // interleaved [B * S, 51, Ho, Wo] buffer: sepconv/model.py runs its four sub-networks as one task-batched launch per layer)
+// SAVFI_SEPCONV_WS_ALIGNED=1 (experiment): chunks of phases aligned across strips (ws_work_range) instead of the strip-major cut.
+// Measured SLOWER (B = 8, 256 x 448, one box: backward 233 -> 245 us, forward 133 -> 148 us isolated; 197 -> 207 / 126 -> 137 in the bench loop):
+// workgroups that walk the same rows together concentrate the chip's requests on few DRAM channels -- the planes of a 256 x 448 tap tensor
+// are a multiple of 64 KB apart -- and spread over the channels is worth more here than open-page hits.
+static int ws_aligned_env() {
+  const char* e = getenv("SAVFI_SEPCONV_WS_ALIGNED");
+  return e ? atoi(e) : 0;
+}
+static int ws_grid(int aligned, int S, int nph, int per_wg) {
+  if (!aligned) return savfi_cdiv((int64_t)S * nph, per_wg);
+  const int nfull = nph / per_wg;
+  return S * nfull + savfi_cdiv((int64_t)S * (nph - nfull * per_wg), per_wg);
+}
+
 // cls: the words of savfi_frames8_classify_f32 on `in` (device memory; both instances of the kernel are launched and the device picks one),
 // or nullptr (the six-product kernel only)
 int savfi_sepconv_bwd_ws_launch(const float* in, const float* v, const float* h, const float* gO, float* gV, float* gH, int B, int Ho,
@@ -1867,21 +1906,22 @@ int savfi_sepconv_bwd_ws_launch(const float* in, const float* v, const float* h,
   const int nph = savfi_cdiv(Ho, XPR), ncol = savfi_cdiv(Wo, XMC);
   const int64_t total = (int64_t)B * ncol * nph;
   const int per_wg = savfi_cdiv(total, cus);
-  const int grid = savfi_cdiv(total, per_wg);
+  static const int aligned = ws_aligned_env();
+  const int grid = ws_grid(aligned, B * ncol, nph, per_wg);
   static const bool two = getenv("SAVFI_SEPCONV_WS2") != nullptr;
   if (two && !cls) {
     static uint32_t done2 = 0;
     if (int e = savfi_ensure_dynamic_lds((const void*)sepconv_bwd_ws2, W2LDS, done2)) return e;
-    hipLaunchKernelGGL(sepconv_bwd_ws2, dim3(grid), dim3(W2NT), W2LDS, st, in, v, h, gO, gV, gH, B, Ho, Wo, nph, ncol, per_wg, TB);
+    hipLaunchKernelGGL(sepconv_bwd_ws2, dim3((unsigned)savfi_cdiv(total, per_wg)), dim3(W2NT), W2LDS, st, in, v, h, gO, gV, gH, B, Ho, Wo, nph, ncol, per_wg, TB);
     return savfi_launch_status();
   }
   static uint32_t done = 0, done8 = 0;
   if (cls) {
     if (int e = savfi_ensure_dynamic_lds((const void*)sepconv_bwd_ws<true>, WLDS, done8)) return e;
-    hipLaunchKernelGGL(sepconv_bwd_ws<true>, dim3(grid), dim3(WNT), WLDS, st, in, v, h, gO, gV, gH, B, Ho, Wo, nph, ncol, per_wg, TB, cls);
+    hipLaunchKernelGGL(sepconv_bwd_ws<true>, dim3(grid), dim3(WNT), WLDS, st, in, v, h, gO, gV, gH, B, Ho, Wo, nph, ncol, per_wg, TB, cls, aligned);
   }
   if (int e = savfi_ensure_dynamic_lds((const void*)sepconv_bwd_ws<false>, WLDS, done)) return e;
-  hipLaunchKernelGGL(sepconv_bwd_ws<false>, dim3(grid), dim3(WNT), WLDS, st, in, v, h, gO, gV, gH, B, Ho, Wo, nph, ncol, per_wg, TB, cls);
+  hipLaunchKernelGGL(sepconv_bwd_ws<false>, dim3(grid), dim3(WNT), WLDS, st, in, v, h, gO, gV, gH, B, Ho, Wo, nph, ncol, per_wg, TB, cls, aligned);
   return savfi_launch_status();
 }
 
@@ -1891,14 +1931,15 @@ int savfi_sepconv_fwd_ws_launch(const float* in, const float* v, const float* h,
   const int nph = savfi_cdiv(Ho, XPR), ncol = savfi_cdiv(Wo, XMC);
   const int64_t total = (int64_t)B * ncol * nph;
   const int per_wg = savfi_cdiv(total, cus);
-  const int grid = savfi_cdiv(total, per_wg);
+  static const int aligned = ws_aligned_env();
+  const int grid = ws_grid(aligned, B * ncol, nph, per_wg);
   static uint32_t done = 0, done8 = 0;
   if (cls) {
     if (int e = savfi_ensure_dynamic_lds((const void*)sepconv_fwd_ws<true>, FLDS, done8)) return e;
-    hipLaunchKernelGGL(sepconv_fwd_ws<true>, dim3(grid), dim3(WNT), FLDS, st, in, v, h, out, B, Ho, Wo, nph, ncol, per_wg, TB, cls);
+    hipLaunchKernelGGL(sepconv_fwd_ws<true>, dim3(grid), dim3(WNT), FLDS, st, in, v, h, out, B, Ho, Wo, nph, ncol, per_wg, TB, cls, aligned);
   }
   if (int e = savfi_ensure_dynamic_lds((const void*)sepconv_fwd_ws<false>, FLDS, done)) return e;
-  hipLaunchKernelGGL(sepconv_fwd_ws<false>, dim3(grid), dim3(WNT), FLDS, st, in, v, h, out, B, Ho, Wo, nph, ncol, per_wg, TB, cls);
+  hipLaunchKernelGGL(sepconv_fwd_ws<false>, dim3(grid), dim3(WNT), FLDS, st, in, v, h, out, B, Ho, Wo, nph, ncol, per_wg, TB, cls, aligned);
   return savfi_launch_status();
 }
 

@@ -40,15 +40,19 @@ def run():
         bb.copy_(a)
     for (B, Ho, Wo) in CASES:
         C, K = 3, 51
-        inp = torch.rand(B, C, Ho + K - 1, Wo + K - 1, device='cuda')
+        # frames of 8-bit images (k / 255), through the entry points the plugin uses: per call the three-product kernel and the
+        # six-product instance's early exit (both launched, the device picks: csrc/sepconv_ws.hip)
+        inp = torch.randint(0, 256, (B, C, Ho + K - 1, Wo + K - 1), device='cuda').float().div(255)
+        words = torch.empty(256, dtype=torch.int32, device='cuda')
+        lib.savfi_frames8_classify_f32(inp.data_ptr(), inp.numel(), words.data_ptr(), st)
         v = torch.randn(B, K, Ho, Wo, device='cuda') / 7
         h = torch.randn(B, K, Ho, Wo, device='cuda') / 7
         gO = torch.randn(B, C, Ho, Wo, device='cuda')
         out, gV, gH = torch.empty_like(gO), torch.empty_like(v), torch.empty_like(h)
         for _ in range(3):
-            lib.savfi_sepconv_fwd_f32(inp.data_ptr(), v.data_ptr(), h.data_ptr(), out.data_ptr(), B, C, Ho, Wo, K, st)
-            lib.savfi_sepconv_bwd_f32(inp.data_ptr(), v.data_ptr(), h.data_ptr(), gO.data_ptr(), None, gV.data_ptr(),
-                                      gH.data_ptr(), B, C, Ho, Wo, K, st)
+            assert lib.savfi_sepconv_fwd_frames8_f32(inp.data_ptr(), v.data_ptr(), h.data_ptr(), out.data_ptr(), words.data_ptr(), B, C, Ho, Wo, K, K, st) == 0
+            assert lib.savfi_sepconv_bwd_frames8_f32(inp.data_ptr(), v.data_ptr(), h.data_ptr(), gO.data_ptr(), gV.data_ptr(), gH.data_ptr(),
+                                                     words.data_ptr(), B, C, Ho, Wo, K, K, st) == 0
         torch.cuda.synchronize()
 
 
@@ -68,10 +72,10 @@ def _collect(d, counter):
         kind = 'sepconv_fwd' if 'sepconv_fwd' in name else 'sepconv_bwd' if 'sepconv_bwd' in name else None
         if kind is None:
             continue
-        out.setdefault((kind, seen[kind] // 3), []).append(float(row['Counter_Value']))
+        out.setdefault((kind, seen[kind] // 6), []).append(float(row['Counter_Value']))       # two dispatches per call: see run()
         seen[kind] += 1
     # the calibration copy is the largest of the elementwise / copy kernels (tensor initialisation launches some small ones)
-    return {k: (max(v) if k[0] == 'copy' else sum(v) / len(v)) for k, v in out.items()}
+    return {k: (max(v) if k[0] == 'copy' else sum(v) / 3.0) for k, v in out.items()}
 
 
 def parse(dfetch, dwrite):
