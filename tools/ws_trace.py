@@ -31,7 +31,7 @@ print("traced build: %.1f us per launch" % (1e3 * e0.elapsed_time(e1) / NL))
 lib.savfi_sepconv_ws_trace(buf, 1)
 units = 2 * ((B * 14 * 64 + 255) // 256)
 print("per unit (2 passes) cycles, workgroup 0, %d units per pair, lib %s" % (units, os.environ.get("SAVFI_HIP_LIB")))
-MF = ["top", "wait tab(h)", "Bfrag h+set+slide wait", "gV MFMA loop", "gV scale", "wait out_free", "tile write+set", "wait tab(v)", "Bfrag v+set", "gH MFMA loop", "gH scale", "wait out_free", "tile write+set", "T13 wait tab(h next)", "T14 Bfrag+slide wait"]
+MF = ["top", "-", "-", "gV MFMA loop", "wait tab(v) + v fragments + first gH A fragments", "gV scale + wait out_free", "tile write+set", "-", "-", "gH MFMA loop", "next rows + first gV A fragments", "gH scale + wait out_free", "tile write+set", "wait tab(h next)", "h fragments + slide wait"]
 SG_OLD = ["top: granule loads, readlanes", "wait tab_free", "h table write", "B: side, tails-a, h loads", "wait out_full(gH)", "drain gH", "gV tail sums", "wait tab_free", "v table write", "E: gH tails, v loads", "wait out_full(gV)", "drain gV", "wait prog", "granule write"]
 SG = ["top: row load, readlanes", "wait tab_free", "table write+set", "tails (side, sums), tap loads", "wait prog", "window row write", "wait out_full(prev)", "drain+stores(prev)", "v: slide wait + side reads", "v: tail sums"]
 two = os.environ.get('SAVFI_SEPCONV_WS2') is not None
