@@ -10,6 +10,14 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef short bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
+// cache-policy bits of the kernels' buffer loads / 16-byte stores (aux operand: 1 = sc0, 2 = nt, 16 = sc1); experiment switches
+#ifndef X6_LOAD_AUX
+#define X6_LOAD_AUX 0
+#endif
+#ifndef X6_STORE_AUX
+#define X6_STORE_AUX 0
+#endif
+
 namespace {
 
 constexpr int XK = 51, XC = 3;
@@ -31,7 +39,7 @@ __device__ __forceinline__ float x6_bload(__amdgpu_buffer_rsrc_t r, unsigned vof
 #ifdef X6_EXP_LOADHIT      // experiment: every load hits the same few cache lines
   voff &= 0xfffu; soff = 0u;
 #endif
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, X6_LOAD_AUX));
 }
 __device__ __forceinline__ void x6_bstore(float val, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
 #ifdef X6_EXP_NOSTORE      // experiment: every store is dropped by the range check
@@ -43,7 +51,7 @@ __device__ __forceinline__ void x6_bstore4(f32x4 val, __amdgpu_buffer_rsrc_t r, 
 #ifdef X6_EXP_NOSTORE
   voff = 0x80000000u;
 #endif
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), r, (int)voff, (int)soff, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), r, (int)voff, (int)soff, X6_STORE_AUX);
 }
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t x6_rsrc(const float* base, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)bytes, 0x00020000);
