@@ -22,6 +22,7 @@
 // writes ONE partial block; convk_wgrad_reduce adds the partial blocks in a fixed order (no atomics).
 #include "common.h"
 #include <stdlib.h>
+#include <algorithm>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
@@ -372,6 +373,18 @@ __global__ __launch_bounds__(256) void convk_wgrad_reduce(const float* __restric
 
 struct WgPlan { int mt, nt, cobs, cibs, units, upr, ups, splits, ups_per_split; };
 
+inline int savfi_cu_count() {
+  static int cus[32] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  int& n = cus[dev & 31];
+  if (n == 0) {
+    int v = 0;
+    n = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+  }
+  return n;
+}
+
 inline int wg_plan(WgPlan& p, int N, int T, int Ci, int Co, int H, int W, int K, int pad, bool precise) {
   if (N <= 0 || T <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0 || N % T != 0 || pad < 0 || pad > K - 1) return SAVFI_E_SHAPE;
   if (K != 3 && K != 5 && K != 7) return SAVFI_E_UNSUPPORTED;
@@ -390,7 +403,29 @@ inline int wg_plan(WgPlan& p, int N, int T, int Ci, int Co, int H, int W, int K,
   p.ups = (Wo + UW - 1) / UW;
   p.units = (N / T) * p.upr * p.ups;
   const int blocks = T * p.cobs * p.cibs;
-  int splits = (768 + blocks - 1) / blocks;            // ~3 workgroups per CU over the launch
+  // How many pieces the pixel range is cut into.  A launch runs in ROUNDS of `slots` resident workgroups (2 per CU for the 4-tile and the
+  // 5x5 / 7x7 / two-accumulator variants: 176-256 registers; 3 for <3,2,1>: 126 registers, 46 KB of LDS), and a round lasts as long as a
+  // workgroup's units: time ~ rounds x (units per split + 1) + a little per split for the partial blocks and their reduction.  The old rule
+  // (~768 workgroups per launch) left CAIN's 192 -> 192 @96x160 layer with 792 workgroups for 512 slots: a second round 55 % full, 167 us;
+  // 504 workgroups of 18 units instead of 792 of 11: 145 us (SAVFI_WGRAD_TARGET=n restores the old rule with n workgroups).
+  int splits;
+  static const int target = getenv("SAVFI_WGRAD_TARGET") ? atoi(getenv("SAVFI_WGRAD_TARGET")) : 0;
+  if (target > 0) {
+    splits = (target + blocks - 1) / blocks;
+  } else {
+    const int per_cu = (K == 3 && p.mt == 2 && p.nt == 1 && !precise) ? 3 : 2;
+    const int64_t slots = (int64_t)per_cu * savfi_cu_count();
+    double best_cost = 0.0;
+    splits = 1;
+    const int smax = (int)std::min<int64_t>(p.units, 4 * slots / blocks + 1);
+    for (int sp = 1; sp <= smax; ++sp) {
+      const int ups = (p.units + sp - 1) / sp;
+      if ((p.units + ups - 1) / ups != sp) continue;                   // not a distinct cut
+      const int64_t rounds = ((int64_t)blocks * sp + slots - 1) / slots;
+      const double cost = (double)rounds * (ups + 1.0) + 0.06 * sp;
+      if (sp == 1 || cost < best_cost) { best_cost = cost; splits = sp; }
+    }
+  }
   if (splits > p.units) splits = p.units;
   if (splits < 1) splits = 1;
   p.ups_per_split = (p.units + splits - 1) / splits;

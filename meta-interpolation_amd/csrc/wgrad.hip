@@ -622,10 +622,13 @@ bool ww_plan(WWPlan& p, int N, int T, int Ci, int Co, int H, int W, int pad) {
   const int64_t chunks = (int64_t)(N / T) * p.ty_cnt * p.cpr;
   if (chunks > 0x7fffffffLL) return false;
   p.chunks_total = (int)chunks;
-  // splits: enough workgroups for a few rounds of the 512 slots, at least 32 chunks each (output stage + 36 KB partial block)
+  // splits: enough workgroups for a few rounds of the 512 slots, at least 16 chunks each (output stage + 36 KB partial block; 32 left the
+  // small task-batched maps -- 256 -> 256 @24x32, 64 -> 64 @96x128, 128 -> 128 @48x64 at T = 4 -- with a quarter to a third of the slots:
+  // 90 / 77 / 76 us -> 74 / 70 / 68 with 16, no further gain below; tools/wino_wgrad_time.py)
   const int64_t blocks = (int64_t)T * p.cobs * p.cibs;
   int64_t want = (512 * 2 + blocks - 1) / blocks;
-  const int64_t most = chunks / 32 > 0 ? chunks / 32 : 1;
+  static const int min_chunks = getenv("SAVFI_WWGRAD_MIN_CHUNKS") ? atoi(getenv("SAVFI_WWGRAD_MIN_CHUNKS")) : 16;
+  const int64_t most = chunks / min_chunks > 0 ? chunks / min_chunks : 1;
   if (want > most) want = most;
   if (want < 1) want = 1;
   p.chunks_per_split = savfi_cdiv(chunks, want);
