@@ -95,11 +95,17 @@ struct WgGeom {
 };
 
 // P2: the cross terms of the six-product sum in their own accumulators (see csrc/convk.hip)
-template <int KS, int MT, int NT, bool P2>
-__global__ __launch_bounds__(WG_THREADS, 2) void convk_wgrad_kernel(const WgArgs a) {
-  using G = WgGeom<KS, MT, NT>;
+// NG: groups of four waves per workgroup.  Group ng works on input-channel tiles ng NT .. ng NT + NT - 1 of the workgroup's 16 NT NG input
+// channels exactly as the four waves of an NG = 1 workgroup work on theirs (taps w & 3, w & 3 + 4, ...), against ONE staged cotangent tile:
+// the cotangent (16 MT output channels x 128 pixels: most of a unit's bytes and of its split arithmetic) is loaded and split once for twice
+// the MFMAs, and a CU holds one 8-wave workgroup instead of two 4-wave ones (the same two waves per SIMD).
+template <int KS, int MT, int NT, bool P2, int NG = 1>
+__global__ __launch_bounds__(WG_THREADS * NG, NG == 1 ? 2 : 1) void convk_wgrad_kernel(const WgArgs a) {
+  using G = WgGeom<KS, MT, NT * NG>;
+  constexpr int NTHR = WG_THREADS * NG;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wq = wv & 3, ng = wv >> 2;              // tap owner inside the group; group
   const int g = lane >> 4, sl = lane & 15, kq = sl >> 2, c4 = sl & 3;     // transpose-read source lane: pixel kq, channel quad c4
 
   int b = blockIdx.x;
@@ -107,7 +113,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void convk_wgrad_kernel(const WgArgs
   const int cib = b % a.cibs; b /= a.cibs;
   const int cob = b % a.cobs;
   const int t = b / a.cobs;
-  const int co0 = cob * 16 * MT, ci0 = cib * 16 * NT;
+  const int co0 = cob * 16 * MT, ci0 = cib * 16 * NT * NG;
   const int u_begin = split * a.units_per_split, u_end = min(u_begin + a.units_per_split, a.units);
 
   const size_t gplane = (size_t)a.Ho * a.Wo, xplane = (size_t)a.H * a.W;
@@ -119,7 +125,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void convk_wgrad_kernel(const WgArgs
   // buffer returns 0 beyond num_records), and the channel of each of the 8 loads rides in the scalar offset.  The first
   // version rebuilt item -> (octet, row, column) -> address with a predicate per element: ~40 VALU per item per unit, as much
   // as the split itself -- on a datapath the MFMAs share (PMC round 3: 3 VALU per MFMA).
-  constexpr int GIPT = (G::GITEMS + WG_THREADS - 1) / WG_THREADS, XIPT = (G::XITEMS + WG_THREADS - 1) / WG_THREADS;
+  constexpr int GIPT = (G::GITEMS + NTHR - 1) / NTHR, XIPT = (G::XITEMS + NTHR - 1) / NTHR;
   constexpr int OOB = 0x7fffffff;
   int g_rel[GIPT], g_yx[GIPT], x_rel[XIPT], x_yx[XIPT];     // byte offset from the unit origin (OOB: no such item); dy << 16 | dx
   // octets whose channels all exist take the scalar-offset path; the channel tail of a ragged layer (Co = 3, 51, ...) is masked
@@ -127,7 +133,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void convk_wgrad_kernel(const WgArgs
   const bool g_full = (a.Co & 7) == 0, x_full = (a.Ci & 7) == 0;
 #pragma unroll
   for (int k = 0; k < GIPT; ++k) {
-    const int item = tid + WG_THREADS * k;
+    const int item = tid + NTHR * k;
     const int o = item / G::GCELLS, cell = item - o * G::GCELLS;
     const int dy = cell / UW, dx = cell - dy * UW;
     g_yx[k] = dy << 16 | dx;
@@ -135,7 +141,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void convk_wgrad_kernel(const WgArgs
   }
 #pragma unroll
   for (int k = 0; k < XIPT; ++k) {
-    const int item = tid + WG_THREADS * k;
+    const int item = tid + NTHR * k;
     const int o = item / G::XCELLS, cell = item - o * G::XCELLS;
     const int dy = cell / G::XCOLS, dx = cell - dy * G::XCOLS;
     x_yx[k] = dy << 16 | dx;
@@ -161,7 +167,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void convk_wgrad_kernel(const WgArgs
 #pragma unroll
         for (int e = 0; e < 8; ++e) stage_g[k][e] = ckw_raw_buffer_load_f32(grs, voff, e * gplane_b, 0);
       } else {
-        const int ch0 = co0 + 8 * ((tid + WG_THREADS * k) / G::GCELLS);
+        const int ch0 = co0 + 8 * ((tid + NTHR * k) / G::GCELLS);
 #pragma unroll
         for (int e = 0; e < 8; ++e) stage_g[k][e] = ckw_raw_buffer_load_f32(grs, ch0 + e < a.Co ? voff + e * gplane_b : OOB, 0, 0);
       }
@@ -183,7 +189,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void convk_wgrad_kernel(const WgArgs
 #pragma unroll
         for (int e = 0; e < 8; ++e) stage_x[k][e] = ckw_raw_buffer_load_f32(xrs, voff, e * xplane_b, 0);
       } else {
-        const int ch0 = ci0 + 8 * ((tid + WG_THREADS * k) / G::XCELLS);
+        const int ch0 = ci0 + 8 * ((tid + NTHR * k) / G::XCELLS);
 #pragma unroll
         for (int e = 0; e < 8; ++e) stage_x[k][e] = ckw_raw_buffer_load_f32(xrs, ch0 + e < a.Ci ? voff + e * xplane_b : OOB, 0, 0);
       }
@@ -192,7 +198,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void convk_wgrad_kernel(const WgArgs
   auto stage_write = [&]() {
 #pragma unroll
     for (int k = 0; k < GIPT; ++k) {
-      const int item = tid + WG_THREADS * k;
+      const int item = tid + NTHR * k;
       if (item >= G::GITEMS) continue;
       const int o = item / G::GCELLS, cell = item - o * G::GCELLS;
       char* dst = smem + o * G::GOCT + cell * 16;
@@ -204,7 +210,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void convk_wgrad_kernel(const WgArgs
     }
 #pragma unroll
     for (int k = 0; k < XIPT; ++k) {
-      const int item = tid + WG_THREADS * k;
+      const int item = tid + NTHR * k;
       if (item >= G::XITEMS) continue;
       const int o = item / G::XCELLS, cell = item - o * G::XCELLS;
       char* dst = smem + G::XBASE + o * G::XOCT + cell * 16;
@@ -222,7 +228,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void convk_wgrad_kernel(const WgArgs
 #pragma unroll
   for (int m = 0; m < MT; ++m) a_addr[m] = (2 * m + (c4 >> 1)) * G::GOCT + (8 * g + kq) * 16 + frag_lane;
 #pragma unroll
-  for (int nn = 0; nn < NT; ++nn) b_addr[nn] = G::XBASE + (2 * nn + (c4 >> 1)) * G::XOCT + (8 * g + kq) * 16 + frag_lane;
+  for (int nn = 0; nn < NT; ++nn) b_addr[nn] = G::XBASE + (2 * (ng * NT + nn) + (c4 >> 1)) * G::XOCT + (8 * g + kq) * 16 + frag_lane;
 
   f32x4 acc[G::TPW][MT][NT], lo[P2 ? G::TPW : 1][P2 ? MT : 1][P2 ? NT : 1];
 #pragma unroll
@@ -250,7 +256,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void convk_wgrad_kernel(const WgArgs
     if (u + 1 < u_end) stage_load(u + 1);
     // software pipeline over the UR x TPW x NT groups of this unit (one group = one tap x one input-channel tile x MT
     // output-channel tiles = 6 MT MFMAs): the B fragments of the next group are read from LDS while the current group's MFMAs issue
-    constexpr int NG = UR * G::FULL * NT;
+    constexpr int NGRP = UR * G::FULL * NT;
     bf16x8 aq[MT][3], bq[2][3];
     auto load_a = [&](int r) {
 #pragma unroll
@@ -266,7 +272,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void convk_wgrad_kernel(const WgArgs
     };
     auto load_b = [&](int gi) {
       const int r = gi / (G::FULL * NT), tp = (gi / NT) % G::FULL, nn = gi % NT;
-      load_b_at(bq[gi & 1], r, wv + 4 * tp, nn);
+      load_b_at(bq[gi & 1], r, wq + 4 * tp, nn);
     };
     auto mfmas = [&](int tp, int nn, const bf16x8 (&b)[3]) {
 #pragma unroll
@@ -282,20 +288,20 @@ __global__ __launch_bounds__(WG_THREADS, 2) void convk_wgrad_kernel(const WgArgs
     };
     load_b(0);
 #pragma unroll
-    for (int gi = 0; gi < NG; ++gi) {
+    for (int gi = 0; gi < NGRP; ++gi) {
       const int r = gi / (G::FULL * NT), tp = (gi / NT) % G::FULL, nn = gi % NT;
       if (gi % (G::FULL * NT) == 0) load_a(r);          // A fragments of a row: once per row (their registers are busy until then)
-      if (gi + 1 < NG) load_b(gi + 1);
+      if (gi + 1 < NGRP) load_b(gi + 1);
       mfmas(tp, nn, bq[gi & 1]);
       __builtin_amdgcn_sched_barrier(0);
     }
     if (G::SHARED > 0) {          // the left-over taps: this wave's row of each
-      load_a(wv);
-      load_b_at(bq[0], wv, 4 * G::FULL, 0);
+      load_a(wq);
+      load_b_at(bq[0], wq, 4 * G::FULL, 0);
 #pragma unroll
       for (int gi = 0; gi < G::SHARED * NT; ++gi) {
         const int ts = gi / NT, nn = gi % NT;
-        if (gi + 1 < G::SHARED * NT) load_b_at(bq[(gi + 1) & 1], wv, 4 * G::FULL + (gi + 1) / NT, (gi + 1) % NT);
+        if (gi + 1 < G::SHARED * NT) load_b_at(bq[(gi + 1) & 1], wq, 4 * G::FULL + (gi + 1) / NT, (gi + 1) % NT);
         mfmas(G::FULL + ts, nn, bq[gi & 1]);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -305,8 +311,8 @@ __global__ __launch_bounds__(WG_THREADS, 2) void convk_wgrad_kernel(const WgArgs
 
   // ---- this wave's taps of the partial block: D row 4 g + j = co, D column sl = ci ----
   float* __restrict__ pout = a.partial + ((size_t)split * a.T + t) * a.Co * a.Ci * G::TAPS;
-  auto put = [&](int tap, int m, int nn, const f32x4& v) {
-    const int ci = ci0 + 16 * nn + sl;
+  auto put = [&](int tap, int m, int nng, const f32x4& v) {      // nng: input-channel tile of the workgroup (group * NT + tile)
+    const int ci = ci0 + 16 * nng + sl;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int co = co0 + 16 * m + 4 * g + j;
@@ -321,7 +327,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void convk_wgrad_kernel(const WgArgs
       for (int nn = 0; nn < NT; ++nn) {
         f32x4 v = acc[tp][m][nn];
         if (P2) v += lo[P2 ? tp : 0][P2 ? m : 0][P2 ? nn : 0];
-        put(wv + 4 * tp, m, nn, v);
+        put(wq + 4 * tp, m, ng * NT + nn, v);
       }
   if (G::SHARED > 0) {
     // a shared tap's four row sums meet in LDS (the images are dead: every wave left the last unit's barrier), added in wave order
@@ -334,19 +340,22 @@ __global__ __launch_bounds__(WG_THREADS, 2) void convk_wgrad_kernel(const WgArgs
         for (int nn = 0; nn < NT; ++nn) {
           f32x4 v = acc[G::FULL + ts][m][nn];
           if (P2) v += lo[P2 ? G::FULL + ts : 0][P2 ? m : 0][P2 ? nn : 0];
-          red[(((ts * MT + m) * NT + nn) * 4 + wv) * 64 + lane] = v;
+          red[(((((ng * G::SHARED + ts) * MT + m) * NT + nn)) * 4 + wq) * 64 + lane] = v;
         }
     __syncthreads();
-    // wave w sums the (tap, m, nn) items w, w + 4, ...
+    // wave w sums the (group, tap, m, nn) items w, w + 4 NG, ...
+    constexpr int RITEMS = G::SHARED * MT * NT;        // per group
+    static_assert((size_t)NG * RITEMS * 4 * 64 * sizeof(f32x4) <= (size_t)G::LDS, "the shared taps' row sums fit the dead images");
 #pragma unroll
-    for (int it = 0; it < (G::SHARED * MT * NT + 3) / 4; ++it) {
-      const int item = wv + 4 * it;
-      if (item < G::SHARED * MT * NT) {
-        const int ts = item / (MT * NT), m = (item / NT) % MT, nn = item % NT;
+    for (int it = 0; it < (NG * RITEMS + 4 * NG - 1) / (4 * NG); ++it) {
+      const int item = wv + 4 * NG * it;
+      if (item < NG * RITEMS) {
+        const int ngi = item / RITEMS, rr = item - ngi * RITEMS;
+        const int ts = rr / (MT * NT), m = (rr / NT) % MT, nn = rr % NT;
         f32x4 v = red[(item * 4 + 0) * 64 + lane];
 #pragma unroll
         for (int k = 1; k < 4; ++k) v += red[(item * 4 + k) * 64 + lane];
-        put(4 * G::FULL + ts, m, nn, v);
+        put(4 * G::FULL + ts, m, ngi * NT + nn, v);
       }
     }
   }
@@ -371,7 +380,7 @@ __global__ __launch_bounds__(256) void convk_wgrad_reduce(const float* __restric
   }
 }
 
-struct WgPlan { int mt, nt, cobs, cibs, units, upr, ups, splits, ups_per_split; };
+struct WgPlan { int mt, nt, ng, cobs, cibs, units, upr, ups, splits, ups_per_split; };
 
 inline int savfi_cu_count() {
   static int cus[32] = {0};
@@ -397,8 +406,16 @@ inline int wg_plan(WgPlan& p, int N, int T, int Ci, int Co, int H, int W, int K,
   // third workgroup per CU: measured 10-15 % SLOWER on every layer (profiles/r03_wgrad_variants.txt); kept behind SAVFI_WGRAD_NT=2
   p.nt = 1;
   if (const char* e = getenv("SAVFI_WGRAD_NT")) { if (atoi(e) == 2 && !precise && K != 7 && p.mt == 2 && Ci > 16) p.nt = 2; }
+  // 8-wave workgroups on 64 x 32 channels (NG = 2, see the kernel) for the 4-tile variant, opt-in (SAVFI_WGRAD_NG=2): measured equal to
+  // the 4-wave form (CAIN 192 -> 192 @96x160 N = 2: 149 vs 153 us per call; C5 slice 7.23 vs 7.34 steps/s) -- splitting the cotangent tile
+  // once for twice the MFMAs buys nothing, the kernel is not bound by its VALU work
+  p.ng = 1;
+  {
+    static const int ng_env = getenv("SAVFI_WGRAD_NG") ? atoi(getenv("SAVFI_WGRAD_NG")) : 1;
+    if (ng_env == 2 && K == 3 && p.mt == 4 && !precise && Ci >= 32) p.ng = 2;
+  }
   p.cobs = (Co + 16 * p.mt - 1) / (16 * p.mt);
-  p.cibs = (Ci + 16 * p.nt - 1) / (16 * p.nt);
+  p.cibs = (Ci + 16 * p.nt * p.ng - 1) / (16 * p.nt * p.ng);
   p.upr = (Ho + UR - 1) / UR;
   p.ups = (Wo + UW - 1) / UW;
   p.units = (N / T) * p.upr * p.ups;
@@ -413,7 +430,7 @@ inline int wg_plan(WgPlan& p, int N, int T, int Ci, int Co, int H, int W, int K,
   if (target > 0) {
     splits = (target + blocks - 1) / blocks;
   } else {
-    const int per_cu = (K == 3 && p.mt == 2 && p.nt == 1 && !precise) ? 3 : 2;
+    const int per_cu = p.ng == 2 ? 1 : (K == 3 && p.mt == 2 && p.nt == 1 && !precise) ? 3 : 2;
     const int64_t slots = (int64_t)per_cu * savfi_cu_count();
     double best_cost = 0.0;
     splits = 1;
@@ -433,16 +450,16 @@ inline int wg_plan(WgPlan& p, int N, int T, int Ci, int Co, int H, int W, int K,
   return SAVFI_OK;
 }
 
-template <int KS, int MT, int NT, bool P2 = false>
+template <int KS, int MT, int NT, bool P2 = false, int NG = 1>
 int launch_wgrad(const WgArgs& a, int blocks, hipStream_t stream) {
-  using G = WgGeom<KS, MT, NT>;
+  using G = WgGeom<KS, MT, NT * NG>;
   static uint32_t configured = 0;
-  auto kern = convk_wgrad_kernel<KS, MT, NT, P2>;
+  auto kern = convk_wgrad_kernel<KS, MT, NT, P2, NG>;
   if (G::LDS > 64 * 1024) {
     const int rc = savfi_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), G::LDS, configured);
     if (rc != SAVFI_OK) return rc;
   }
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(WG_THREADS), G::LDS, stream, a);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(WG_THREADS * NG), G::LDS, stream, a);
   return savfi_launch_status();
 }
 
@@ -478,6 +495,7 @@ extern "C" int savfi_convk_wgrad_tasks_reflect_f32(const float* x, const float* 
   const int blocks = T * p.cobs * p.cibs * p.splits;
   hipStream_t st = (hipStream_t)stream;
   if (K == 3 && precise) rc = p.mt == 4 ? launch_wgrad<3, 4, 1, true>(a, blocks, st) : launch_wgrad<3, 2, 1, true>(a, blocks, st);
+  else if (K == 3 && p.ng == 2) rc = launch_wgrad<3, 4, 1, false, 2>(a, blocks, st);
   else if (K == 3) rc = p.mt == 4 ? launch_wgrad<3, 4, 1>(a, blocks, st) : p.nt == 2 ? launch_wgrad<3, 2, 2>(a, blocks, st) : launch_wgrad<3, 2, 1>(a, blocks, st);
   else if (K == 5) rc = precise ? launch_wgrad<5, 2, 1, true>(a, blocks, st) : p.nt == 2 ? launch_wgrad<5, 2, 2>(a, blocks, st) : launch_wgrad<5, 2, 1>(a, blocks, st);
   else rc = launch_wgrad<7, 2, 1>(a, blocks, st);       // 13 taps per wave: no room for a second accumulator set

@@ -825,6 +825,9 @@ CONVK_CASES = [  # K, Ci, Co, H, W, pad, T, N
     (3, 24, 40, 9, 70, 2, 1, 1), (5, 6, 64, 32, 32, 2, 1, 2), (5, 64, 128, 16, 48, 2, 2, 2), (5, 64, 3, 24, 40, 2, 1, 2),
     (5, 20, 24, 11, 13, 0, 1, 1), (7, 6, 32, 24, 40, 3, 1, 1), (7, 32, 32, 16, 36, 3, 2, 2), (7, 20, 2, 10, 12, 6, 1, 1),
     (3, 1, 1, 1, 1, 1, 1, 1), (5, 3, 17, 33, 65, 4, 1, 1),
+    # >= 192 output channels: the weight gradient's 4-tile variant (with SAVFI_WGRAD_NG=2: 8-wave workgroups on 64 x 32 channels where
+    # Ci >= 32); ragged channel blocks, T > 1, a map smaller than a unit
+    (3, 192, 192, 33, 47, 1, 1, 1), (3, 200, 208, 20, 40, 1, 2, 4), (3, 64, 256, 12, 16, 0, 1, 2), (3, 40, 192, 3, 5, 1, 1, 1), (3, 24, 192, 9, 33, 1, 1, 1),
 ]
 
 
