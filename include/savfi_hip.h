@@ -56,7 +56,7 @@
 extern "C" {
 #endif
 
-#define SAVFI_ABI_VERSION 13
+#define SAVFI_ABI_VERSION 14
 
 #define SAVFI_OK            0
 #define SAVFI_E_NULL       (-1)  /* a required pointer is NULL                          */
@@ -104,13 +104,17 @@ int savfi_sepconv_bwd_taps_strided_f32(const float* in, const float* v, const fl
  *                                variants are launched and the words select one ON THE DEVICE (no host round trip, graph-capture safe):
  *                                all words zero -> the three-product kernel, otherwise the six-product kernel of the entry points above.
  *                                Same results to fp32 rounding for frames that qualify, identical results for frames that do not.
- * tap_bstride = K for contiguous tap tensors.  K = 51, C = 3, Wo % 4 == 0; SAVFI_E_UNSUPPORTED otherwise (use the entry points above). */
+ * tap_bstride = K for contiguous tap tensors.  K = 51, C = 3, Wo % 4 == 0; SAVFI_E_UNSUPPORTED otherwise (use the entry points above).
+ * taps_unit16 != 0: v and h are UNIT-MAJOR -- a sample is [Ho][Wo / 16][K][16] instead of [K][Ho][Wo], the layout
+ *   savfi_conv3x3_tasks_pre_unit16_f32 writes (Wo % 16 == 0): the 51 taps of 16 neighbouring pixels are one contiguous run of
+ *   51 x 64 bytes instead of 64-byte pieces of 51 planes.  The sample stride (tap_bstride planes of Ho * Wo floats) is unchanged, and
+ *   gV / gH are written [K][Ho][Wo] as always (the producing convolution's gradient kernels read that). */
 #define SAVFI_FRAMES8_WORDS 256
 int savfi_frames8_classify_f32(const float* x, int64_t n, unsigned* cls, void* stream);
 int savfi_sepconv_fwd_frames8_f32(const float* in, const float* v, const float* h, float* out, const unsigned* cls, int B, int C, int Ho,
-                                  int Wo, int K, int tap_bstride, void* stream);
+                                  int Wo, int K, int tap_bstride, int taps_unit16, void* stream);
 int savfi_sepconv_bwd_frames8_f32(const float* in, const float* v, const float* h, const float* gO, float* gV, float* gH,
-                                  const unsigned* cls, int B, int C, int Ho, int Wo, int K, int tap_bstride, void* stream);
+                                  const unsigned* cls, int B, int C, int Ho, int Wo, int K, int tap_bstride, int taps_unit16, void* stream);
 
 /* Diagnostic of the wave-specialised filter-gradient kernel (csrc/sepconv_ws.hip): number of bounded in-kernel waits that
  * gave up since the library was loaded on the current device.  0 on a healthy build; > 0 means a launch's numbers are wrong
@@ -314,6 +318,15 @@ int savfi_conv3x3_tasks_pre_f32(const float* x, const float* u, const float* bia
  * the producer's backward then needs no element-wise pass of its own.  workspace: as savfi_conv3x3_tasks_pre_f32, mode 1. */
 int savfi_conv3x3_dgrad_masked_f32(const float* gy, const float* u, const float* mask, float mask_slope, float* gx,
                                    float* workspace, int N, int T, int Ci, int Co, int H, int W, int pad, void* stream);
+
+/* savfi_conv3x3_tasks_pre_f32, forward (mode 0) only, with the result written UNIT-MAJOR: out[n] is [Ho][Wo / 16][Co][16] instead of
+ * [Co][Ho][Wo] -- the 16-pixel units of the SepConv kernels with a unit's Co x 64 bytes contiguous (the layout `taps_unit16` of
+ * savfi_sepconv_{fwd,bwd}_frames8_f32 reads).  The SepConv plugin's last Subnet convolution (reference sepconv/model.py:183-194: the
+ * 51 -> 51 layer behind the bilinear x2) writes its taps this way.  Needs Wo % 16 == 0, a sample below 2^31 bytes and a launch without
+ * a reduction split (savfi_conv3x3_unit16_supported says so: 1 / 0); SAVFI_E_UNSUPPORTED otherwise.  No workspace. */
+int savfi_conv3x3_unit16_supported(int N, int T, int Ci, int Co, int H, int W, int pad);
+int savfi_conv3x3_tasks_pre_unit16_f32(const float* x, const float* u, const float* bias, float* out, int N, int T, int Ci, int Co,
+                                       int H, int W, int pad, float slope, void* stream);
 
 /* Weight gradient of the same convolution (zero padding `pad` in {0,1}), NCHW in and out, deterministic:
  *   gw[Co,Ci,3,3] = sum over n,y,x of gz[n,co,y,x] * x[n,ci,y+a-pad,x+b-pad]      x [N,Ci,H,W], gz [N,Co,H+2pad-2,W+2pad-2]

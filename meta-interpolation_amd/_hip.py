@@ -16,7 +16,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_PKG_DIR), "include", "savfi_hip.h")
 
 RULE_SGD, RULE_ADAM, RULE_ADAMAX_LSLR, RULE_ADAMAX_MSGD = 0, 1, 2, 3
 LR_SCALAR, LR_ELEMENT = 0, 1
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 _ERRORS = {-1: "SAVFI_E_NULL (a required pointer is NULL)",
            -2: "SAVFI_E_SHAPE (bad or inconsistent dimension)",
@@ -40,8 +40,8 @@ _PROTOTYPES = {
     "savfi_sepconv_fwd_taps_strided_f32": [_P, _P, _P, _P] + [c_int] * 6 + [_P],
     "savfi_sepconv_bwd_taps_strided_f32": [_P, _P, _P, _P, _P, _P] + [c_int] * 6 + [_P],
     "savfi_frames8_classify_f32": [_P, c_int64, _P, _P],
-    "savfi_sepconv_fwd_frames8_f32": [_P, _P, _P, _P, _P] + [c_int] * 6 + [_P],
-    "savfi_sepconv_bwd_frames8_f32": [_P, _P, _P, _P, _P, _P, _P] + [c_int] * 6 + [_P],
+    "savfi_sepconv_fwd_frames8_f32": [_P, _P, _P, _P, _P] + [c_int] * 7 + [_P],
+    "savfi_sepconv_bwd_frames8_f32": [_P, _P, _P, _P, _P, _P, _P] + [c_int] * 7 + [_P],
     "savfi_sepconv_ws_errors": [],
     "savfi_conv3x3_dgrad_masked_f32": [_P, _P, _P, c_float, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P],
     "savfi_convk_dgrad_masked_f32": [_P, _P, _P, c_float, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P],
@@ -72,6 +72,8 @@ _PROTOTYPES = {
     "savfi_conv3x3_filters_f32": [_P, _P, _P, c_int, c_int, c_int, _P],
     "savfi_conv3x3_tasks_pre_workspace_floats": [c_int] * 8,
     "savfi_conv3x3_tasks_pre_f32": [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P],
+    "savfi_conv3x3_unit16_supported": [c_int] * 7,
+    "savfi_conv3x3_tasks_pre_unit16_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P],
     "savfi_conv3x3_wgrad_tasks_workspace_floats": [c_int] * 7,
     "savfi_conv3x3_wgrad_tasks_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P],
     "savfi_conv3x3_wgrad_wino_tasks_workspace_floats": [c_int] * 7,

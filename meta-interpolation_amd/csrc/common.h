@@ -55,6 +55,6 @@ int savfi_sepconv_fwd_x6_launch(const float* in, const float* v, const float* h,
 // csrc/sepconv_ws.hip: the same gradients with MFMA waves and staging waves in pairs (widths that are a multiple of 4)
 // TB = tap planes between two samples of v / h / gV / gH (51: contiguous tensors)
 int savfi_sepconv_bwd_ws_launch(const float* in, const float* v, const float* h, const float* gO, float* gV, float* gH, int B, int Ho,
-                                int Wo, int cus, int TB, const unsigned* cls, hipStream_t st);
+                                int Wo, int cus, int TB, const unsigned* cls, int taps_unit16, hipStream_t st);
 int savfi_sepconv_fwd_ws_launch(const float* in, const float* v, const float* h, float* out, int B, int Ho, int Wo, int cus, int TB,
-                                const unsigned* cls, hipStream_t st);
+                                const unsigned* cls, int taps_unit16, hipStream_t st);

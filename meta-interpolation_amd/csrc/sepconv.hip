@@ -1127,7 +1127,7 @@ extern "C" int savfi_sepconv_fwd_f32(const float* in, const float* v, const floa
   if (K == KFAST && C == 3 && !sepconv_env().no_mfma && !sepconv_env().tiled && !sepconv_env().f32_mfma && persistent_ok(B, Ho, Wo)) {
     // widths that are a multiple of 4: the wave-specialised kernel (csrc/sepconv_ws.hip); others: one program per wave (csrc/sepconv_x6.hip)
     if ((Wo & 3) == 0 && !sepconv_env().no_ws && !sepconv_env().no_ws_fwd)
-      return savfi_sepconv_fwd_ws_launch(in, v, h, out, B, Ho, Wo, device_cu_count(), KFAST, nullptr, st);
+      return savfi_sepconv_fwd_ws_launch(in, v, h, out, B, Ho, Wo, device_cu_count(), KFAST, nullptr, 0, st);
     return savfi_sepconv_fwd_x6_launch(in, v, h, out, B, Ho, Wo, device_cu_count(), st);
   }
   if (K == KFAST && C == 3 && !sepconv_env().no_mfma && mfma_fits(Ho, Wo)) {
@@ -1162,31 +1162,33 @@ extern "C" int savfi_sepconv_fwd_taps_strided_f32(const float* in, const float* 
                                                   int K, int tap_bstride, void* stream) {
   if (!in || !v || !h || !out) return SAVFI_E_NULL;
   if (int e = taps_strided_ok(B, C, Ho, Wo, K, tap_bstride)) return e;
-  return savfi_sepconv_fwd_ws_launch(in, v, h, out, B, Ho, Wo, device_cu_count(), tap_bstride, nullptr, (hipStream_t)stream);
+  return savfi_sepconv_fwd_ws_launch(in, v, h, out, B, Ho, Wo, device_cu_count(), tap_bstride, nullptr, 0, (hipStream_t)stream);
 }
 
 extern "C" int savfi_sepconv_bwd_taps_strided_f32(const float* in, const float* v, const float* h, const float* gO, float* gV, float* gH,
                                                   int B, int C, int Ho, int Wo, int K, int tap_bstride, void* stream) {
   if (!in || !v || !h || !gO || !gV || !gH) return SAVFI_E_NULL;
   if (int e = taps_strided_ok(B, C, Ho, Wo, K, tap_bstride)) return e;
-  return savfi_sepconv_bwd_ws_launch(in, v, h, gO, gV, gH, B, Ho, Wo, device_cu_count(), tap_bstride, nullptr, (hipStream_t)stream);
+  return savfi_sepconv_bwd_ws_launch(in, v, h, gO, gV, gH, B, Ho, Wo, device_cu_count(), tap_bstride, nullptr, 0, (hipStream_t)stream);
 }
 
 // the strided entry points with the words of savfi_frames8_classify_f32(in) (csrc/sepconv_ws.hip): the device picks the three-product
 // kernel for frames of 8-bit images and the six-product kernel for anything else
 extern "C" int savfi_sepconv_fwd_frames8_f32(const float* in, const float* v, const float* h, float* out, const unsigned* cls, int B, int C,
-                                             int Ho, int Wo, int K, int tap_bstride, void* stream) {
+                                             int Ho, int Wo, int K, int tap_bstride, int taps_unit16, void* stream) {
   if (!in || !v || !h || !out || !cls) return SAVFI_E_NULL;
   if (int e = taps_strided_ok(B, C, Ho, Wo, K, tap_bstride)) return e;
   if (sepconv_env().no_ws_fwd) return SAVFI_E_UNSUPPORTED;
-  return savfi_sepconv_fwd_ws_launch(in, v, h, out, B, Ho, Wo, device_cu_count(), tap_bstride, cls, (hipStream_t)stream);
+  return savfi_sepconv_fwd_ws_launch(in, v, h, out, B, Ho, Wo, device_cu_count(), tap_bstride, cls, taps_unit16 ? 1 : 0, (hipStream_t)stream);
 }
 
 extern "C" int savfi_sepconv_bwd_frames8_f32(const float* in, const float* v, const float* h, const float* gO, float* gV, float* gH,
-                                             const unsigned* cls, int B, int C, int Ho, int Wo, int K, int tap_bstride, void* stream) {
+                                             const unsigned* cls, int B, int C, int Ho, int Wo, int K, int tap_bstride, int taps_unit16,
+                                             void* stream) {
   if (!in || !v || !h || !gO || !gV || !gH || !cls) return SAVFI_E_NULL;
   if (int e = taps_strided_ok(B, C, Ho, Wo, K, tap_bstride)) return e;
-  return savfi_sepconv_bwd_ws_launch(in, v, h, gO, gV, gH, B, Ho, Wo, device_cu_count(), tap_bstride, cls, (hipStream_t)stream);
+  return savfi_sepconv_bwd_ws_launch(in, v, h, gO, gV, gH, B, Ho, Wo, device_cu_count(), tap_bstride, cls, taps_unit16 ? 1 : 0,
+                                     (hipStream_t)stream);
 }
 
 extern "C" int savfi_sepconv_bwd_f32(const float* in, const float* v, const float* h, const float* gO,
@@ -1200,7 +1202,7 @@ extern "C" int savfi_sepconv_bwd_f32(const float* in, const float* v, const floa
         persistent_ok(B, Ho, Wo)) {
       // widths that are a multiple of 4: the wave-specialised kernel (csrc/sepconv_ws.hip); others: one program per wave (csrc/sepconv_x6.hip)
       if ((Wo & 3) == 0 && !sepconv_env().no_ws) {
-        if (int e = savfi_sepconv_bwd_ws_launch(in, v, h, gO, gV, gH, B, Ho, Wo, device_cu_count(), KFAST, nullptr, st)) return e;
+        if (int e = savfi_sepconv_bwd_ws_launch(in, v, h, gO, gV, gH, B, Ho, Wo, device_cu_count(), KFAST, nullptr, 0, st)) return e;
       } else if (int e = savfi_sepconv_bwd_x6_launch(in, v, h, gO, gV, gH, B, Ho, Wo, device_cu_count(), st)) return e;
     } else if (K == KFAST && C == 3 && !sepconv_env().no_mfma && !sepconv_env().tiled && persistent_ok(B, Ho, Wo)) {
       if (int e = launch_bwd_persistent(in, v, h, gO, gV, gH, B, Ho, Wo, st)) return e;

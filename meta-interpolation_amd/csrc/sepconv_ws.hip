@@ -223,7 +223,7 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
                                                       const float* __restrict__ h, const float* __restrict__ gO,
                                                       float* __restrict__ gV, float* __restrict__ gH,
                                                       int B, int Ho, int Wo, int nph, int ncol, int per_wg, int TB,
-                                                      const unsigned* __restrict__ cls, int aligned) {
+                                                      const unsigned* __restrict__ cls, int aligned, int unit16) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int p = w & 3, wc = p & 1, wr0 = p >> 1;
@@ -261,14 +261,16 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
   };
   // Tap registers (as sepconv_bwd_x6): lane (j, kg) holds 7 PAIRS of neighbouring taps t0 + 8 a + {0, 1}: a split pair is exactly the
   // dword a table position takes.  v: t0 = 2 kg.  h: t0 = 2 kg - (j & 1): the band position i = tap + j of a pair starts even.
-  // -DWS_EXP_UNITMAJOR (timing only, results wrong): the tap tensors addressed as if they were laid out [y][x / 16][tap][16] per sample --
-  // a unit's 51 x 64 bytes contiguous -- instead of [tap][y][x]: what the op would cost on taps produced in that layout
-  const unsigned tap_stride = WS_EXP_UNITMAJOR ? 64u : plane_b;
+  // unit16: v and h are laid out [y][x / 16][tap][16] per sample (savfi_conv3x3_tasks_pre_unit16_f32) -- a unit's 51 x 64 bytes are
+  // contiguous -- instead of [tap][y][x]; gV / gH stay [tap][y][x].  -DWS_EXP_UNITMAJOR=1 (timing only, results wrong): loads AND stores
+  // addressed that way: what the op would cost with its gradients in that layout too
+  const bool umaj = WS_EXP_UNITMAJOR || unit16;
+  const unsigned tap_stride = umaj ? 64u : plane_b;
   auto unit_off = [&](int b, int x0, int y) {
     return (unsigned)b * (unsigned)TB * plane_b + (unsigned)((min(y, Ho - 1) * (Wo >> 4) + min((x0 >> 4) + wc, (Wo >> 4) - 1)) * XK) * 64u;
   };
   auto load_taps = [&](float (&regs)[XNP][2], __amdgpu_buffer_rsrc_t src, int b, int x0, int y, int t0) {
-    const unsigned pix = WS_EXP_UNITMAJOR ? unit_off(b, x0, y) + (unsigned)j * 4u : pix_off(b, x0, y, TB);
+    const unsigned pix = umaj ? unit_off(b, x0, y) + (unsigned)j * 4u : pix_off(b, x0, y, TB);
     const unsigned voff = pix + (unsigned)(t0 + 1) * tap_stride;
     regs[0][0] = x6_bload(src, pix + (unsigned)max(t0, 0) * tap_stride, 0u);
     regs[0][1] = x6_bload(src, voff, 0u);
@@ -645,7 +647,7 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
         const int y = unit_y(nn), y1 = unit_y(min(nn + 1, N - 1));
         const int xq = x0 + 16 * wc + 4 * pq;
         const unsigned qoff = !(live && y < Ho && xq < Wo) ? X_OOR
-                              : WS_EXP_UNITMAJOR ? unit_off(b, x0, y) + (unsigned)pq * 16u + (unsigned)fq * 64u
+                              : WS_EXP_UNITMAJOR == 1 ? unit_off(b, x0, y) + (unsigned)pq * 16u + (unsigned)fq * 64u
                                                  : (unsigned)b * (unsigned)TB * plane_b + (unsigned)(y * Wo + xq) * 4u + (unsigned)fq * plane_b;
         // one new window row per role and unit (rows R0 + 60 + 2 n + {0 | 1})
         float gr0, gr1;
@@ -689,7 +691,7 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
             }
             const float t14 = tailb[row], t15 = tailb[64 + row];
             if (pq == 3) { v4[2] += t14; v4[3] += t15; }
-            x6_bstore4(v4, gvdst, (qq < 3 || fq < 3) ? qoff_prev : X_OOR, (unsigned)(16 * qq) * tap_stride);
+            x6_bstore4(v4, gvdst, (qq < 3 || fq < 3) ? qoff_prev : X_OOR, (unsigned)(16 * qq) * (WS_EXP_UNITMAJOR == 1 ? 64u : plane_b));
           }
           if (n > 0) ws_set(fl, F_OUT_FREE + p, 2 * n - 1);
           WS_T(7);
@@ -758,7 +760,7 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
             // window columns 64, 65 (pixel 14 tap 50; pixel 15 taps 49, 50) are the VALU tail sums
             if (pq == 3 && fx == 50) { v4[2] = s6414; v4[3] = s6515; }
             if (pq == 3 && fx == 49) v4[3] = s6415;
-            x6_bstore4(v4, ghdst, (qq < 3 || fq < 3) ? qoff_prev : X_OOR, (unsigned)(16 * qq) * tap_stride);
+            x6_bstore4(v4, ghdst, (qq < 3 || fq < 3) ? qoff_prev : X_OOR, (unsigned)(16 * qq) * (WS_EXP_UNITMAJOR == 1 ? 64u : plane_b));
           }
           if (n > 0) ws_set(fl, F_OUT_FREE + p, 2 * n);
           WS_T(7);
@@ -1525,7 +1527,7 @@ template <bool U8>
 __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ in, const float* __restrict__ v,
                                                       const float* __restrict__ h, float* __restrict__ out,
                                                       int B, int Ho, int Wo, int nph, int ncol, int per_wg, int TB,
-                                                      const unsigned* __restrict__ cls, int aligned) {
+                                                      const unsigned* __restrict__ cls, int aligned, int unit16) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int p = w & 3, wc = p & 1, wr0 = p >> 1;
@@ -1558,17 +1560,22 @@ __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ 
   auto pix_off = [&](int b, int x0, int y, int ch) {
     return (unsigned)b * (unsigned)ch * plane_b + (unsigned)(min(y, Ho - 1) * Wo + min(x0 + 16 * wc + j, Wo - 1)) * 4u;
   };
+  // unit16: v and h are laid out [y][x / 16][tap][16] per sample (see sepconv_bwd_ws)
+  const unsigned tap_stride = unit16 ? 64u : plane_b;
+  auto unit_off = [&](int b, int x0, int y) {
+    return (unsigned)b * (unsigned)TB * plane_b + (unsigned)((min(y, Ho - 1) * (Wo >> 4) + min((x0 >> 4) + wc, (Wo >> 4) - 1)) * XK) * 64u;
+  };
   auto load_taps = [&](float (&regs)[XNP][2], __amdgpu_buffer_rsrc_t src, int b, int x0, int y, int t0) {
-    const unsigned pix = pix_off(b, x0, y, TB);
-    const unsigned voff = pix + (unsigned)(t0 + 1) * plane_b;
-    regs[0][0] = x6_bload(src, pix + (unsigned)max(t0, 0) * plane_b, 0u);
+    const unsigned pix = unit16 ? unit_off(b, x0, y) + (unsigned)j * 4u : pix_off(b, x0, y, TB);
+    const unsigned voff = pix + (unsigned)(t0 + 1) * tap_stride;
+    regs[0][0] = x6_bload(src, pix + (unsigned)max(t0, 0) * tap_stride, 0u);
     regs[0][1] = x6_bload(src, voff, 0u);
 #pragma unroll
     for (int a = 1; a < XNP - 1; ++a)
 #pragma unroll
-      for (int e = 0; e < 2; ++e) regs[a][e] = x6_bload(src, voff, (unsigned)(8 * a + e - 1) * plane_b);
+      for (int e = 0; e < 2; ++e) regs[a][e] = x6_bload(src, voff, (unsigned)(8 * a + e - 1) * tap_stride);
 #pragma unroll
-    for (int e = 0; e < 2; ++e) regs[XNP - 1][e] = x6_bload(src, pix + (unsigned)min(8 * (XNP - 1) + t0 + e, XK - 1) * plane_b, 0u);
+    for (int e = 0; e < 2; ++e) regs[XNP - 1][e] = x6_bload(src, pix + (unsigned)min(8 * (XNP - 1) + t0 + e, XK - 1) * tap_stride, 0u);
   };
   auto tap_or_zero = [&](const float (&regs)[XNP][2], int a, int e, int t0) {
     if (a == 0 && e == 0) return t0 < 0 ? 0.f : regs[0][0];
@@ -1799,8 +1806,9 @@ __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ 
         } else {
           // taps 50 of pixel 14 and 49, 50 of pixel 15 of the h band (the tail columns' weights): lanes 0..2, in flight under the tile write
           const int hl = min(lane, 2);
-          const unsigned hoff = (unsigned)b * (unsigned)TB * plane_b + (unsigned)(hl == 1 ? 49 : 50) * plane_b
-                                + (unsigned)(min(y, Ho - 1) * Wo + min(x0 + 16 * wc + (hl == 0 ? 14 : 15), Wo - 1)) * 4u;
+          const unsigned hoff = unit16 ? unit_off(b, x0, y) + (unsigned)(hl == 1 ? 49 : 50) * 64u + (unsigned)(hl == 0 ? 14 : 15) * 4u
+                                       : (unsigned)b * (unsigned)TB * plane_b + (unsigned)(hl == 1 ? 49 : 50) * plane_b
+                                             + (unsigned)(min(y, Ho - 1) * Wo + min(x0 + 16 * wc + (hl == 0 ? 14 : 15), Wo - 1)) * 4u;
           const float hraw = x6_bload(hsrc, hoff, 0u);
           // (1) v of unit n -> the pair's v tile [pixel][tap]: the lane's pairs of neighbouring taps as 8-byte stores
           float v14 = 0.f, v15 = 0.f;
@@ -1902,14 +1910,15 @@ static int ws_grid(int aligned, int S, int nph, int per_wg) {
 // cls: the words of savfi_frames8_classify_f32 on `in` (device memory; both instances of the kernel are launched and the device picks one),
 // or nullptr (the six-product kernel only)
 int savfi_sepconv_bwd_ws_launch(const float* in, const float* v, const float* h, const float* gO, float* gV, float* gH, int B, int Ho,
-                                int Wo, int cus, int TB, const unsigned* cls, hipStream_t st) {
+                                int Wo, int cus, int TB, const unsigned* cls, int taps_unit16, hipStream_t st) {
   const int nph = savfi_cdiv(Ho, XPR), ncol = savfi_cdiv(Wo, XMC);
   const int64_t total = (int64_t)B * ncol * nph;
   const int per_wg = savfi_cdiv(total, cus);
   static const int aligned = ws_aligned_env();
   const int grid = ws_grid(aligned, B * ncol, nph, per_wg);
+  if (taps_unit16 && (Wo & 15) != 0) return SAVFI_E_UNSUPPORTED;
   static const bool two = getenv("SAVFI_SEPCONV_WS2") != nullptr;
-  if (two && !cls) {
+  if (two && !cls && !taps_unit16) {
     static uint32_t done2 = 0;
     if (int e = savfi_ensure_dynamic_lds((const void*)sepconv_bwd_ws2, W2LDS, done2)) return e;
     hipLaunchKernelGGL(sepconv_bwd_ws2, dim3((unsigned)savfi_cdiv(total, per_wg)), dim3(W2NT), W2LDS, st, in, v, h, gO, gV, gH, B, Ho, Wo, nph, ncol, per_wg, TB);
@@ -1918,28 +1927,29 @@ int savfi_sepconv_bwd_ws_launch(const float* in, const float* v, const float* h,
   static uint32_t done = 0, done8 = 0;
   if (cls) {
     if (int e = savfi_ensure_dynamic_lds((const void*)sepconv_bwd_ws<true>, WLDS, done8)) return e;
-    hipLaunchKernelGGL(sepconv_bwd_ws<true>, dim3(grid), dim3(WNT), WLDS, st, in, v, h, gO, gV, gH, B, Ho, Wo, nph, ncol, per_wg, TB, cls, aligned);
+    hipLaunchKernelGGL(sepconv_bwd_ws<true>, dim3(grid), dim3(WNT), WLDS, st, in, v, h, gO, gV, gH, B, Ho, Wo, nph, ncol, per_wg, TB, cls, aligned, taps_unit16);
   }
   if (int e = savfi_ensure_dynamic_lds((const void*)sepconv_bwd_ws<false>, WLDS, done)) return e;
-  hipLaunchKernelGGL(sepconv_bwd_ws<false>, dim3(grid), dim3(WNT), WLDS, st, in, v, h, gO, gV, gH, B, Ho, Wo, nph, ncol, per_wg, TB, cls, aligned);
+  hipLaunchKernelGGL(sepconv_bwd_ws<false>, dim3(grid), dim3(WNT), WLDS, st, in, v, h, gO, gV, gH, B, Ho, Wo, nph, ncol, per_wg, TB, cls, aligned, taps_unit16);
   return savfi_launch_status();
 }
 
 // forward of the same op, widths that are a multiple of 4 (declared in csrc/common.h)
 int savfi_sepconv_fwd_ws_launch(const float* in, const float* v, const float* h, float* out, int B, int Ho, int Wo, int cus, int TB,
-                                const unsigned* cls, hipStream_t st) {
+                                const unsigned* cls, int taps_unit16, hipStream_t st) {
   const int nph = savfi_cdiv(Ho, XPR), ncol = savfi_cdiv(Wo, XMC);
   const int64_t total = (int64_t)B * ncol * nph;
   const int per_wg = savfi_cdiv(total, cus);
   static const int aligned = ws_aligned_env();
   const int grid = ws_grid(aligned, B * ncol, nph, per_wg);
+  if (taps_unit16 && (Wo & 15) != 0) return SAVFI_E_UNSUPPORTED;
   static uint32_t done = 0, done8 = 0;
   if (cls) {
     if (int e = savfi_ensure_dynamic_lds((const void*)sepconv_fwd_ws<true>, FLDS, done8)) return e;
-    hipLaunchKernelGGL(sepconv_fwd_ws<true>, dim3(grid), dim3(WNT), FLDS, st, in, v, h, out, B, Ho, Wo, nph, ncol, per_wg, TB, cls, aligned);
+    hipLaunchKernelGGL(sepconv_fwd_ws<true>, dim3(grid), dim3(WNT), FLDS, st, in, v, h, out, B, Ho, Wo, nph, ncol, per_wg, TB, cls, aligned, taps_unit16);
   }
   if (int e = savfi_ensure_dynamic_lds((const void*)sepconv_fwd_ws<false>, FLDS, done)) return e;
-  hipLaunchKernelGGL(sepconv_fwd_ws<false>, dim3(grid), dim3(WNT), FLDS, st, in, v, h, out, B, Ho, Wo, nph, ncol, per_wg, TB, cls, aligned);
+  hipLaunchKernelGGL(sepconv_fwd_ws<false>, dim3(grid), dim3(WNT), FLDS, st, in, v, h, out, B, Ho, Wo, nph, ncol, per_wg, TB, cls, aligned, taps_unit16);
   return savfi_launch_status();
 }
 

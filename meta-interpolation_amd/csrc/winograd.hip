@@ -172,6 +172,7 @@ struct WinoArgs {
   int N;                                                   // samples
   const float* mask;                                       // or null: out *= (mask > 0 ? 1 : mask_slope), mask laid out like out (the
   float mask_slope;                                        // activation derivative of the layer that produced this data gradient's output)
+  int out_unit16;                                          // 1: out is written [n][y][x / 16][channel][16] (see savfi_conv3x3_tasks_pre_unit16_f32)
 #ifdef WINO_TRACE
   unsigned long long* trace;                               // [workgroup][8]: timestamps (100 MHz) + hardware ids
 #endif
@@ -487,6 +488,11 @@ __global__ __launch_bounds__(WNT, 2) void wino_conv3x3(WinoArgs a) {
 #pragma unroll
       for (int c = 0; c < 2; ++c)
         ooff[r][c] = (oy + r < a.Ho && ox + c < a.Wo) ? (unsigned)((oy + r) * a.Wo + ox + c) * 4u : 0x80000000u;
+    if (a.out_unit16) {      // unit-major: a sample is [y][x / 16][channel][16]; ox is even, so the pair of a row store stays inside its unit
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+        ooff[r][0] = (oy + r < a.Ho && ox < a.Wo) ? (unsigned)(((oy + r) * (a.Wo >> 4) + (ox >> 4)) * a.I) * 64u + (unsigned)(ox & 15) * 4u : 0x80000000u;
+    }
   }
   float* const obase = a.nsplit == 1 ? a.out : a.partial + (size_t)sp * a.N * a.I * a.Ho * a.Wo;
   const float slope = a.nsplit == 1 ? a.slope : 1.f;       // bias / activation happen in wino_split_reduce
@@ -537,7 +543,9 @@ __global__ __launch_bounds__(WNT, 2) void wino_conv3x3(WinoArgs a) {
         y[1][c] = s[1][c] - s[2][c] - s[3][c];
       }
       const float b = bvals[cb][rep];
-      const i32x4 ors = plane_rsrc(obase + ((size_t)n * a.I + min(i, a.I - 1)) * a.Ho * a.Wo, i < a.I ? oplane_bytes : 0u);
+      const i32x4 ors = a.out_unit16 ? plane_rsrc(obase + (size_t)n * a.I * a.Ho * a.Wo, i < a.I ? (unsigned)a.I * oplane_bytes : 0u)
+                                     : plane_rsrc(obase + ((size_t)n * a.I + min(i, a.I - 1)) * a.Ho * a.Wo, i < a.I ? oplane_bytes : 0u);
+      const unsigned ch_off = a.out_unit16 ? (unsigned)min(i, a.I - 1) * 64u : 0u;
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         float v0 = y[r][0] + b, v1 = y[r][1] + b;
@@ -548,7 +556,7 @@ __global__ __launch_bounds__(WNT, 2) void wino_conv3x3(WinoArgs a) {
           v1 = mk[cb][rep][r].y > 0.f ? v1 : v1 * a.mask_slope;
         }
         if (VEC) {
-          savfi_raw_buffer_store_x2((f32x2){v0, v1}, ors, (int)ooff[r][0], 0, 0);
+          savfi_raw_buffer_store_x2((f32x2){v0, v1}, ors, (int)(ooff[r][0] + ch_off), 0, 0);
         } else {
           savfi_raw_buffer_store_x1(v0, ors, (int)ooff[r][0], 0, 0);
           savfi_raw_buffer_store_x1(v1, ors, (int)ooff[r][1], 0, 0);
@@ -670,13 +678,14 @@ namespace {
 
 // launches wino_conv3x3 (+ the split reduction) on an already transformed filter U [T][16 * KP * IP]
 int launch_conv(const WinoPlan& p, const float* x, const float* U, const float* bias, float* out, float* partial, int N, int T,
-                int H, int W, int mode, float slope, hipStream_t st, const float* mask = nullptr, float mask_slope = 1.f) {
+                int H, int W, int mode, float slope, hipStream_t st, const float* mask = nullptr, float mask_slope = 1.f,
+                int out_unit16 = 0) {
   const int64_t wgs = (int64_t)p.th * p.tw * (p.IP / COB) * p.nsplit * N;
   if (wgs > 0x7fffffffLL || T > 65535) return SAVFI_E_TOOBIG;
   constexpr size_t lds = (size_t)LDS_FLOATS * sizeof(float);      // 40 KB: two workgroups per CU
   const float* b = mode == 0 ? bias : nullptr;
   WinoArgs a{x, U, b, out, p.K, p.I, p.KP, p.IP, H, W, p.Ho, p.Wo, p.off, p.th, p.tw, slope, p.tile_shift, p.nsplit,
-             p.chunks_per_split, partial, T, N, mask, mask_slope
+             p.chunks_per_split, partial, T, N, mask, mask_slope, out_unit16
 #ifdef WINO_TRACE
              , savfi_wino_trace_buffer((size_t)wgs)
 #endif
@@ -798,6 +807,27 @@ extern "C" int savfi_conv3x3_tasks_pre_f32(const float* x, const float* u, const
   if (int e = check_conv_args(p, N, T, Ci, Co, H, W, pad, mode)) return e;
   if (p.partial_floats > 0 && !workspace) return SAVFI_E_NULL;
   return launch_conv(p, x, u, bias, out, workspace, N, T, H, W, mode, slope, (hipStream_t)stream);
+}
+
+// savfi_conv3x3_tasks_pre_f32, forward only, with the result written UNIT-MAJOR: out[n] is [Ho][Wo / 16][Co][16] instead of [Co][Ho][Wo] --
+// the 16-pixel units of csrc/sepconv_ws.hip with a unit's Co x 64 bytes contiguous.  The SepConv plugin's last Subnet convolution writes
+// its 51 taps per pixel in this layout and the 51-tap op reads them as contiguous runs instead of 64-byte pieces of 51 planes a multiple
+// of 64 KB apart.  Wo % 16 == 0, a sample below 2^31 bytes, no reduction split; SAVFI_E_UNSUPPORTED otherwise.
+static int unit16_ok(const WinoPlan& p) {
+  return p.nsplit == 1 && p.Wo % 16 == 0 && (int64_t)p.I * p.Ho * p.Wo * 4 < ((int64_t)1 << 31);
+}
+extern "C" int savfi_conv3x3_unit16_supported(int N, int T, int Ci, int Co, int H, int W, int pad) {
+  WinoPlan p;
+  if (check_conv_args(p, N, T, Ci, Co, H, W, pad, 0)) return 0;
+  return unit16_ok(p) ? 1 : 0;
+}
+extern "C" int savfi_conv3x3_tasks_pre_unit16_f32(const float* x, const float* u, const float* bias, float* out, int N, int T, int Ci, int Co,
+                                                  int H, int W, int pad, float slope, void* stream) {
+  if (!x || !u || !out) return SAVFI_E_NULL;
+  WinoPlan p;
+  if (int e = check_conv_args(p, N, T, Ci, Co, H, W, pad, 0)) return e;
+  if (!unit16_ok(p)) return SAVFI_E_UNSUPPORTED;
+  return launch_conv(p, x, u, bias, out, nullptr, N, T, H, W, 0, slope, (hipStream_t)stream, nullptr, 1.f, 1);
 }
 
 // data gradient (mode 1) on a transformed filter with the activation derivative of the layer that produced this convolution's input

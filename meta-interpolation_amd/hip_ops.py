@@ -1214,9 +1214,20 @@ def conv3x3_filters(weight, fwd=True, bwd=True):
     return make(fwd, bwd)
 
 
-def conv3x3_tasks_pre(x, u, T, Ci, Co, bias=None, mode=0, slope=1.0, pad=1, mask=None, mask_slope=1.0):
+def conv3x3_unit16_supported(x, w, pad):
+    """Can the 3x3 layer (x [N,Ci,H,W], task weights w [T,Co,Ci,3,3], zero padding `pad`) write its result unit-major
+    (savfi_conv3x3_tasks_pre_unit16_f32)?  It runs on the Winograd kernel, its width is a multiple of 16, no reduction split."""
+    if not (x.is_cuda and w.dim() == 5 and conv3x3_tasks_eligible(x, w, 1, pad, 1) and not convk_eligible(x, w, 1, pad, 1, 1, False)):
+        return False
+    N, Ci, H, W = x.shape
+    return int(_hip.lib().savfi_conv3x3_unit16_supported(N, w.shape[0], Ci, w.shape[1], H, W, int(pad))) == 1
+
+
+def conv3x3_tasks_pre(x, u, T, Ci, Co, bias=None, mode=0, slope=1.0, pad=1, mask=None, mask_slope=1.0, out_unit16=False):
     """savfi_conv3x3_tasks_pre_f32: conv3x3_tasks on a filter already transformed by conv3x3_filters (same mode).  `mask` (mode 1):
-    the result is multiplied by (mask > 0 ? 1 : mask_slope) in the kernel's output stage (savfi_conv3x3_dgrad_masked_f32)."""
+    the result is multiplied by (mask > 0 ? 1 : mask_slope) in the kernel's output stage (savfi_conv3x3_dgrad_masked_f32).
+    `out_unit16` (mode 0): the result tensor has the usual shape [N,Co,Ho,Wo] but its MEMORY is unit-major, [N][Ho][Wo/16][Co][16]
+    (savfi_conv3x3_tasks_pre_unit16_f32) -- for FunctionSepconvPair(..., taps_unit16=True) only."""
     x = x.contiguous()
     _hip.require_cuda(x, u)
     if mask is not None:
@@ -1227,6 +1238,13 @@ def conv3x3_tasks_pre(x, u, T, Ci, Co, bias=None, mode=0, slope=1.0, pad=1, mask
     I = Co if mode == 0 else Ci
     grow = 2 * (pad if mode == 0 else 2 - pad) - 2
     lib = _hip.lib()
+    if out_unit16:
+        assert mode == 0
+        out = torch.empty((N, I, H + grow, W + grow), dtype=x.dtype, device=x.device)
+        _hip.launch("conv3x3_fwd", lambda: _hip.check(lib.savfi_conv3x3_tasks_pre_unit16_f32(
+            x.data_ptr(), u.data_ptr(), None if bias is None else bias.data_ptr(), out.data_ptr(), N, T, Ci, Co, H, W, int(pad), float(slope),
+            _hip.current_stream()), "savfi_conv3x3_tasks_pre_unit16_f32"), flops=18.0 * Ci * Co * out.shape[2] * out.shape[3] * N)
+        return out
     nws = _workspace_floats("savfi_conv3x3_tasks_pre_workspace_floats", N, T, Ci, Co, H, W, int(pad), mode)
     ws = torch.empty(nws, dtype=x.dtype, device=x.device) if nws else None
     out = torch.empty((N, I, H + grow, W + grow), dtype=x.dtype, device=x.device)
@@ -1458,7 +1476,7 @@ class _ConvBiasActTasks(torch.autograd.Function):
     """y = act(conv2d(x[s], w[s % T]) + b[s % T]) for every sample s.  First-order only (like _ConvBiasAct)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, padding, dilation, slope, direct=False, in_slope=None, defer=False):
+    def forward(ctx, x, w, b, stride, padding, dilation, slope, direct=False, in_slope=None, defer=False, out_unit16=False):
         x = x.contiguous()
         ctx.in_slope, ctx.defer = in_slope, bool(defer)          # see _ConvBiasAct.forward
         T, Co, Ci = w.shape[:3]
@@ -1466,6 +1484,10 @@ class _ConvBiasActTasks(torch.autograd.Function):
         n = N // T
         pad = padding if isinstance(padding, int) else padding[0]
         ctx.u_bwd, ctx.route = None, None
+        if out_unit16:
+            # the result's MEMORY is unit-major (its only consumer is FunctionSepconvPair(taps_unit16=True)); the cotangent that comes back
+            # is laid out like the shape says, so nothing changes in backward.  The caller has asked conv3x3_unit16_supported.
+            assert slope == 1.0 and not defer and conv3x3_unit16_supported(x, w, pad), "unit-major output: Winograd route, no activation"
         if convk_eligible(x, w, stride, padding, dilation, 1, direct):
             u_fwd, ctx.u_bwd = convk_filters(w, True, bool(ctx.needs_input_grad[0]))
             z = convk_tasks_pre(x, u_fwd, T, Ci, Co, int(w.shape[-1]), b, 0, slope, pad, direct)
@@ -1474,7 +1496,7 @@ class _ConvBiasActTasks(torch.autograd.Function):
             # both filter transforms of this layer in one launch: the data gradient of the same step will want the other one
             want_bwd = ctx.needs_input_grad[0] and conv3x3_tasks_eligible(x, w, stride, padding, dilation, backward=True)
             u_fwd, ctx.u_bwd = conv3x3_filters(w, True, want_bwd)
-            z = conv3x3_tasks_pre(x, u_fwd, T, Ci, Co, b, 0, slope, pad)
+            z = conv3x3_tasks_pre(x, u_fwd, T, Ci, Co, b, 0, slope, pad, out_unit16=out_unit16)
             ctx.route = 'wino'
         else:
             if _grouped_ok(x):
@@ -1579,13 +1601,15 @@ class _ConvBiasActTasks(torch.autograd.Function):
                     gw = torch.stack([p[1] for p in per], 0)
         if mask is not None and gx is not None:
             gx = mask_by_activation(gx, mask, mslope)
-        return gx, gw, gb, None, None, None, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None, None, None, None
 
 
-def conv_bias_act_tasks(x, weight, bias, stride=1, padding=0, dilation=1, slope=0.0, direct=False, in_slope=None, defer=False):
-    """act(conv2d(x[s], weight[s % T]) + bias[s % T]): the lockstep form of conv_bias_act (`in_slope`, `defer`: conv_bias_act)."""
+def conv_bias_act_tasks(x, weight, bias, stride=1, padding=0, dilation=1, slope=0.0, direct=False, in_slope=None, defer=False,
+                        out_unit16=False):
+    """act(conv2d(x[s], weight[s % T]) + bias[s % T]): the lockstep form of conv_bias_act (`in_slope`, `defer`: conv_bias_act).
+    `out_unit16`: the result's memory is unit-major (conv3x3_tasks_pre; only after conv3x3_unit16_supported said yes, slope 1)."""
     return _ConvBiasActTasks.apply(x, weight, bias, stride, padding, dilation, float(slope), bool(direct),
-                                   None if in_slope is None else float(in_slope), bool(defer))
+                                   None if in_slope is None else float(in_slope), bool(defer), bool(out_unit16))
 
 
 @functools.lru_cache(maxsize=None)

@@ -28,8 +28,10 @@ import torch.nn.functional as F
 
 from .. import hip_ops
 from ..hip_ops import Upsample2x, upsample_bilinear2x_window, upsample_window_sources
-from ..model_utils import MetaConv2dLayer, MetaSequential, as_view, own_params_const, zero_grad_params
-from .sepconv_op.sepconv import FunctionSepconv, FunctionSepconvPair
+from ..model_utils import MetaConv2dLayer, MetaSequential, as_view, fuse_conv_act, own_params_const, zero_grad_params
+from .sepconv_op.sepconv import FunctionSepconv, FunctionSepconvPair, frames8_supported
+
+TAPS_UNIT16 = os.environ.get('SAVFI_SEPCONV_TAPS_PLANAR') is None
 
 FILTER_TAPS = 51
 HALF = FILTER_TAPS // 2  # 25
@@ -208,9 +210,19 @@ class MetaNetwork(nn.Module):
         x = ref[2](x, params={'weight': sp['w2'], 'bias': sp['b2']}, act_slope=0.0)
         x = ref[4](x, params={'weight': sp['w4'], 'bias': sp['b4']}, act_slope=0.0)
         x = upsample_bilinear2x_window(x, win['half'], (win['crop'][0], win['crop'][2]), win['up'], True)
-        taps = ref[7](x, params={'weight': sp['w7'], 'bias': sp['b7']}, padding=0)               # [4 N, 51, height, width]
+        # The taps leave the last convolution UNIT-MAJOR where the shapes allow (a sample [H][W / 16][51][16] instead of [51][H][W]): the
+        # 51-tap op then reads a unit's taps as one contiguous run instead of 64-byte pieces of 51 planes.  The tensor keeps
+        # its shape; only FunctionSepconvPair reads it.  SAVFI_SEPCONV_TAPS_PLANAR=1: the plain layout (A/B runs).
+        height, width = win['up'][2] - 2, win['up'][3] - 2
+        unit16 = (TAPS_UNIT16 and fuse_conv_act() and width % 16 == 0 and frames8_supported(frame0, N, 3, height, width, FILTER_TAPS, 4 * FILTER_TAPS)
+                  and hip_ops.conv3x3_unit16_supported(x, sp['w7'], 0))
+        if unit16:
+            taps = hip_ops.conv_bias_act_tasks(x, sp['w7'], sp['b7'], ref[7].stride, 0, ref[7].dilation_rate, 1.0,
+                                               getattr(ref[7], 'direct', False), None, False, True)
+        else:
+            taps = ref[7](x, params={'weight': sp['w7'], 'bias': sp['b7']}, padding=0)           # [4 N, 51, height, width]
         rim = (HALF,) * 4
-        return FunctionSepconvPair.apply(F.pad(frame0, rim, mode='replicate'), F.pad(frame1, rim, mode='replicate'), taps)
+        return FunctionSepconvPair.apply(F.pad(frame0, rim, mode='replicate'), F.pad(frame1, rim, mode='replicate'), taps, unit16)
 
     def _windowed_tail(self, frame0, frame1, combine, height, width, ph, pw):
         win = self._window(height, width, ph, pw)

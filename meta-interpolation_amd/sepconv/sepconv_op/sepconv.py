@@ -74,7 +74,7 @@ class FunctionSepconv(torch.autograd.Function):
 
             def run8():
                 rc[0] = lib.savfi_sepconv_fwd_frames8_f32(input.data_ptr(), vertical.data_ptr(), horizontal.data_ptr(), output.data_ptr(),
-                                                          cls.data_ptr(), B, C, Ho, Wo, K, K, _hip.current_stream())
+                                                          cls.data_ptr(), B, C, Ho, Wo, K, K, 0, _hip.current_stream())
                 if rc[0] != _E_UNSUPPORTED:
                     _hip.check(rc[0], "savfi_sepconv_fwd_frames8_f32")
             _hip.launch("sepconv_fwd", run8, nbytes=algorithmic_bytes(B, C, Ho, Wo, K))
@@ -108,7 +108,7 @@ class FunctionSepconv(torch.autograd.Function):
             lib = _hip.lib()
             _hip.launch("sepconv_bwd", lambda: _hip.check(lib.savfi_sepconv_bwd_frames8_f32(
                 input.data_ptr(), vertical.data_ptr(), horizontal.data_ptr(), gradOutput.data_ptr(), gV.data_ptr(), gH.data_ptr(),
-                cls.data_ptr(), B, C, Ho, Wo, K, K, _hip.current_stream()), "savfi_sepconv_bwd_frames8_f32"),
+                cls.data_ptr(), B, C, Ho, Wo, K, K, 0, _hip.current_stream()), "savfi_sepconv_bwd_frames8_f32"),
                 nbytes=algorithmic_bytes(B, C, Ho, Wo, K, grads=2))
         elif need_i or need_v or need_h:
             lib = _hip.lib()
@@ -130,7 +130,12 @@ class FunctionSepconvPair(torch.autograd.Function):
     the layout the plugin's four Subnets leave when they run as ONE task-batched launch per layer (sepconv/model.py).  The two local
     convolutions of the reference (sepconv/model.py:346-347 -> sepconv_op/sepconv.py:247-380) read that buffer in place and their filter
     gradients are written into one buffer of the same layout (savfi_sepconv_*_taps_strided_f32, tap_bstride = 4 K): no slices are
-    copied out, no gradients are concatenated.  The frames carry no gradient on this path (needs_input_grad is asserted)."""
+    copied out, no gradients are concatenated.  The frames carry no gradient on this path (needs_input_grad is asserted).
+
+    taps_unit16=True: the MEMORY of `taps` is unit-major -- sample [Ho][Wo / 16][K][16] instead of [K][Ho][Wo], what the plugin's last Subnet
+    convolution writes through hip_ops.conv_bias_act_tasks(..., out_unit16=True) -- and the kernels read a unit's 51 taps x 16 pixels as one
+    contiguous run (include/savfi_hip.h `taps_unit16`; frames8 entry points only: check frames8_supported and Wo % 16 == 0 first).  The
+    returned tap gradient is laid out as its shape says."""
 
     @staticmethod
     def supported(frame, batch, height, width, taps=51):
@@ -140,7 +145,7 @@ class FunctionSepconvPair(torch.autograd.Function):
                 and 4 * batch * taps * height * width * 4 < 2 ** 31)
 
     @staticmethod
-    def forward(ctx, input0, input1, taps):
+    def forward(ctx, input0, input1, taps, taps_unit16=False):
         B, C, Hi, Wi = input0.shape
         K, Ho, Wo = taps.shape[1:]
         assert input1.shape == input0.shape and taps.size(0) == 4 * B and Hi - K == Ho - 1 and Wi - K == Wo - 1, (input0.shape, taps.shape)
@@ -151,11 +156,14 @@ class FunctionSepconvPair(torch.autograd.Function):
         lib, st = _hip.lib(), _hip.current_stream()
         plane = K * Ho * Wo * 4
         words = [frames8_classify(inp) for inp in (input0, input1)] if frames8_supported(input0, B, C, Ho, Wo, K, 4 * K) else None
+        u16 = 1 if taps_unit16 else 0
+        assert not u16 or (words is not None and Wo % 16 == 0), "unit-major taps: the frames8 entry points, widths that are a multiple of 16"
+        ctx.taps_unit16 = u16
         for i, (inp, out, s) in enumerate(((input0, out0, 0), (input1, out1, 2))):
             if words is not None:
                 _hip.launch("sepconv_fwd", lambda inp=inp, out=out, s=s, i=i: _hip.check(lib.savfi_sepconv_fwd_frames8_f32(
                     inp.data_ptr(), taps.data_ptr() + s * plane, taps.data_ptr() + (s + 1) * plane, out.data_ptr(), words[i].data_ptr(),
-                    B, C, Ho, Wo, K, 4 * K, st), "savfi_sepconv_fwd_frames8_f32"), nbytes=algorithmic_bytes(B, C, Ho, Wo, K))
+                    B, C, Ho, Wo, K, 4 * K, u16, st), "savfi_sepconv_fwd_frames8_f32"), nbytes=algorithmic_bytes(B, C, Ho, Wo, K))
             else:
                 _hip.launch("sepconv_fwd", lambda inp=inp, out=out, s=s: _hip.check(lib.savfi_sepconv_fwd_taps_strided_f32(
                     inp.data_ptr(), taps.data_ptr() + s * plane, taps.data_ptr() + (s + 1) * plane, out.data_ptr(),
@@ -169,7 +177,7 @@ class FunctionSepconvPair(torch.autograd.Function):
         words = ctx.saved_tensors[3:] or None
         assert not ctx.needs_input_grad[0] and not ctx.needs_input_grad[1], "FunctionSepconvPair: frames carry no gradient on this path"
         if not ctx.needs_input_grad[2]:
-            return None, None, None
+            return None, None, None, None
         B, C = input0.shape[:2]
         K, Ho, Wo = taps.shape[1:]
         gradOutput = gradOutput.contiguous()
@@ -181,14 +189,14 @@ class FunctionSepconvPair(torch.autograd.Function):
             if words is not None:
                 _hip.launch("sepconv_bwd", lambda inp=inp, s=s, i=i: _hip.check(lib.savfi_sepconv_bwd_frames8_f32(
                     inp.data_ptr(), taps.data_ptr() + s * plane, taps.data_ptr() + (s + 1) * plane, gradOutput.data_ptr(),
-                    gT.data_ptr() + s * plane, gT.data_ptr() + (s + 1) * plane, words[i].data_ptr(), B, C, Ho, Wo, K, 4 * K, st),
+                    gT.data_ptr() + s * plane, gT.data_ptr() + (s + 1) * plane, words[i].data_ptr(), B, C, Ho, Wo, K, 4 * K, ctx.taps_unit16, st),
                     "savfi_sepconv_bwd_frames8_f32"), nbytes=algorithmic_bytes(B, C, Ho, Wo, K, grads=2))
             else:
                 _hip.launch("sepconv_bwd", lambda inp=inp, s=s: _hip.check(lib.savfi_sepconv_bwd_taps_strided_f32(
                     inp.data_ptr(), taps.data_ptr() + s * plane, taps.data_ptr() + (s + 1) * plane, gradOutput.data_ptr(),
                     gT.data_ptr() + s * plane, gT.data_ptr() + (s + 1) * plane, B, C, Ho, Wo, K, 4 * K, st),
                     "savfi_sepconv_bwd_taps_strided_f32"), nbytes=algorithmic_bytes(B, C, Ho, Wo, K, grads=2))
-        return None, None, gT
+        return None, None, gT, None
 
 
 class ModuleSepconv(torch.nn.Module):

@@ -80,7 +80,7 @@ def test_frames8_kernels_vs_oracle(B, Ho, Wo):
     assert _hip.lib().savfi_sepconv_ws_errors() == 0
 
 
-def _abi_fwd(inp, v, h, words, tb=K):
+def _abi_fwd(inp, v, h, words, tb=K, u16=0):
     B, _, Ho, Wo = v.shape[0], None, v.shape[2], v.shape[3]
     out = torch.empty(B, 3, Ho, Wo, device=DEV)
     lib = _hip.lib()
@@ -89,11 +89,11 @@ def _abi_fwd(inp, v, h, words, tb=K):
                                                           _hip.current_stream()), "fwd")
     else:
         _hip.check(lib.savfi_sepconv_fwd_frames8_f32(inp.data_ptr(), v.data_ptr(), h.data_ptr(), out.data_ptr(), words.data_ptr(), B, 3, Ho, Wo,
-                                                     K, tb, _hip.current_stream()), "fwd8")
+                                                     K, tb, u16, _hip.current_stream()), "fwd8")
     return out
 
 
-def _abi_bwd(inp, v, h, gO, words, tb=K):
+def _abi_bwd(inp, v, h, gO, words, tb=K, u16=0):
     B, Ho, Wo = v.shape[0], v.shape[2], v.shape[3]
     gV, gH = torch.empty_like(v), torch.empty_like(h)
     lib = _hip.lib()
@@ -102,7 +102,7 @@ def _abi_bwd(inp, v, h, gO, words, tb=K):
                                                           B, 3, Ho, Wo, K, tb, _hip.current_stream()), "bwd")
     else:
         _hip.check(lib.savfi_sepconv_bwd_frames8_f32(inp.data_ptr(), v.data_ptr(), h.data_ptr(), gO.data_ptr(), gV.data_ptr(), gH.data_ptr(),
-                                                     words.data_ptr(), B, 3, Ho, Wo, K, tb, _hip.current_stream()), "bwd8")
+                                                     words.data_ptr(), B, 3, Ho, Wo, K, tb, u16, _hip.current_stream()), "bwd8")
     return gV, gH
 
 
@@ -163,9 +163,10 @@ def test_full_size_frames8_against_the_six_product_kernels_and_refusals():
     lib = _hip.lib()
     out = torch.empty(B, 3, Ho, Wo, device=DEV)
     args = (inp.data_ptr(), v.data_ptr(), h.data_ptr(), out.data_ptr())
-    assert lib.savfi_sepconv_fwd_frames8_f32(*args, None, B, 3, Ho, Wo, K, K, _hip.current_stream()) == -1          # NULL words
-    assert lib.savfi_sepconv_fwd_frames8_f32(*args, w8.data_ptr(), B, 3, Ho, Wo - 2, K, K, _hip.current_stream()) == -3   # width % 4
-    assert lib.savfi_sepconv_fwd_frames8_f32(*args, w8.data_ptr(), B, 3, Ho, Wo, 13, 13, _hip.current_stream()) == -3     # K != 51
+    assert lib.savfi_sepconv_fwd_frames8_f32(*args, None, B, 3, Ho, Wo, K, K, 0, _hip.current_stream()) == -1          # NULL words
+    assert lib.savfi_sepconv_fwd_frames8_f32(*args, w8.data_ptr(), B, 3, Ho, Wo - 2, K, K, 0, _hip.current_stream()) == -3   # width % 4
+    assert lib.savfi_sepconv_fwd_frames8_f32(*args, w8.data_ptr(), B, 3, Ho, Wo, 13, 13, 0, _hip.current_stream()) == -3     # K != 51
+    assert lib.savfi_sepconv_fwd_frames8_f32(*args, w8.data_ptr(), B, 3, Ho, Wo - 4, K, K, 1, _hip.current_stream()) == -3   # unit-major taps: width % 16
     assert lib.savfi_frames8_classify_f32(None, 5, w8.data_ptr(), _hip.current_stream()) == -1
     assert lib.savfi_frames8_classify_f32(inp.data_ptr(), 0, w8.data_ptr(), _hip.current_stream()) == -2
 
@@ -214,4 +215,51 @@ def test_pair_op_on_interleaved_taps_with_frames8(monkeypatch):
     ref = O.sepconv_forward_c(f0.cpu(), taps[0::4].cpu().contiguous(), taps[1::4].cpu().contiguous()) + \
         O.sepconv_forward_c(f1.cpu(), taps[2::4].cpu().contiguous(), taps[3::4].cpu().contiguous())
     assert _rel(res[0][0].cpu(), ref) < 1e-5
+    assert _hip.lib().savfi_sepconv_ws_errors() == 0
+
+
+def _to_unit16(t):
+    """[B,K,H,W] values -> a tensor of the same shape whose MEMORY is [B][H][W/16][K][16] (what savfi_conv3x3_tasks_pre_unit16_f32 writes)"""
+    B, Kk, H, W = t.shape
+    return t.view(B, Kk, H, W // 16, 16).permute(0, 2, 3, 1, 4).contiguous().view(B, Kk, H, W)
+
+
+@pytest.mark.parametrize("B,Ho,Wo,f8", [(2, 37, 48, True), (1, 64, 96, True), (3, 5, 16, True), (2, 40, 64, False)])
+def test_unit_major_taps_give_the_same_bits(B, Ho, Wo, f8):
+    """taps_unit16: the same values read from the unit-major layout -- identical results, forward and both filter gradients, on the
+    three-product kernels and (frames that do not qualify) on the six-product ones; the gradients come back [K][Ho][Wo]"""
+    inp, v, h, gO = (t.to(DEV) for t in _inputs(B, Ho, Wo, seed=77 + Ho, frames8=f8))
+    words = _words(inp)
+    assert (int(words.abs().sum()) == 0) == f8
+    vu, hu = _to_unit16(v), _to_unit16(h)
+    assert torch.equal(_abi_fwd(inp, vu, hu, words, u16=1), _abi_fwd(inp, v, h, words))
+    for a, b in zip(_abi_bwd(inp, vu, hu, gO, words, u16=1), _abi_bwd(inp, v, h, gO, words)):
+        assert torch.equal(a, b)
+    assert _hip.lib().savfi_sepconv_ws_errors() == 0
+
+
+def test_winograd_convolution_writes_unit_major_and_the_pair_op_reads_it():
+    """hip_ops.conv_bias_act_tasks(out_unit16=True) -> FunctionSepconvPair(taps_unit16=True) against the plain layout: the convolution's
+    result rearranged is bit-identical, the op's output and every gradient (taps -> convolution input, weights, bias) are bit-identical"""
+    from meta_interpolation_amd import hip_ops
+    B, T, C, Ho, Wo = 2, 4, K, 96, 128          # large enough for a launch without a reduction split (smaller ones are refused)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B * T, C, Ho + 2, Wo + 2, generator=g).to(DEV)
+    w = (torch.randn(T, K, C, 3, 3, generator=g) / (3 * math.sqrt(C))).to(DEV)
+    b = (torch.randn(T, K, generator=g) * 0.1).to(DEV)
+    f0 = torch.randint(0, 256, (B, 3, Ho + K - 1, Wo + K - 1), generator=g).float().div(255).to(DEV)
+    f1 = torch.randint(0, 256, (B, 3, Ho + K - 1, Wo + K - 1), generator=g).float().div(255).to(DEV)
+    gO = torch.randn(B, 3, Ho, Wo, generator=g).to(DEV)
+    assert hip_ops.conv3x3_unit16_supported(x, w, 0)
+    assert not hip_ops.conv3x3_unit16_supported(x[:, :, :38, :66].contiguous(), w, 0)       # 80 workgroups: the reduction is split
+    res = []
+    for u16 in (False, True):
+        xs, ws, bs = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+        taps = hip_ops.conv_bias_act_tasks(xs, ws, bs, 1, 0, 1, 1.0, False, None, False, u16)
+        out = S.FunctionSepconvPair.apply(f0, f1, taps, u16)
+        out.backward(gO)
+        res.append((taps.detach(), out.detach(), xs.grad, ws.grad, bs.grad))
+    assert torch.equal(res[1][0], _to_unit16(res[0][0]))
+    for a, bb in zip(res[0][1:], res[1][1:]):
+        assert torch.equal(a, bb)
     assert _hip.lib().savfi_sepconv_ws_errors() == 0

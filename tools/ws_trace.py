@@ -14,7 +14,7 @@ gV, gH = torch.empty_like(v), torch.empty_like(h)
 if F8:
     from meta_interpolation_amd.sepconv.sepconv_op import sepconv as S
     words = S.frames8_classify(inp)
-    f = lambda: _hip.check(lib.savfi_sepconv_bwd_frames8_f32(inp.data_ptr(), v.data_ptr(), h.data_ptr(), gO.data_ptr(), gV.data_ptr(), gH.data_ptr(), words.data_ptr(), B, C, Ho, Wo, K, K, st), "bwd8")
+    f = lambda: _hip.check(lib.savfi_sepconv_bwd_frames8_f32(inp.data_ptr(), v.data_ptr(), h.data_ptr(), gO.data_ptr(), gV.data_ptr(), gH.data_ptr(), words.data_ptr(), B, C, Ho, Wo, K, K, 0, st), "bwd8")
 else:
     f = lambda: _hip.check(lib.savfi_sepconv_bwd_f32(inp.data_ptr(), v.data_ptr(), h.data_ptr(), gO.data_ptr(), None, gV.data_ptr(), gH.data_ptr(), B, C, Ho, Wo, K, st), "bwd")
 buf = (ctypes.c_ulonglong * 256)()
