@@ -362,17 +362,17 @@ def main():
                 per_call = 4.0 * (3 * (oh + 50) * (ow + 50) + 4 * 51 * oh * ow + 3 * oh * ow)
                 line["roofline"] = {
                     "bound": "hbm", "kernel": "sepconv_bwd_ws<U8> (gV+gH, K=51; csrc/sepconv_ws.hip: frames of 8-bit images as exact integers x split-bf16 taps "
-                                              "on MFMAs, MFMA waves + staging waves in pairs; the timed interval also holds the six-product instance's "
-                                              "early exit: both are launched, the device picks)",
+                                              "on MFMAs, MFMA waves + staging waves in pairs, taps unit-major from the producing convolution; the timed interval "
+                                              "also holds the six-product instance's early exit: both are launched, the device picks)",
                     "achieved": k["achieved_GBps"], "peak": 8000.0, "unit": "GB/s",
                     "frac": k["achieved_GBps"] / 8000.0, "traffic": traffic, "traffic_source": tnote,
                     "avg_us_per_launch": k["avg_us"], "launches": k["launches"],
                     "algorithmic_bytes_per_launch": k["algorithmic_bytes"] / k["launches"],
                     "note": "algorithmic bytes = %.2f MB per [1,3,%d,%d] sample (x samples per launch: tasks in lockstep x the "
                             "support pair); 132 bf16 MFMAs per 16 pixels (the MFMA waves alone sustain 124 us per B = 8 launch); the launch is bound by the "
-                            "staging waves' tap loads and gradient stores backing up in the memory pipeline -- 64-byte pieces of 204 planes a multiple of "
-                            "64 KB apart (with every load hitting the cache: 161 us; with the taps addressed unit-major: 189 against 222 us isolated; "
-                            "DESIGN.md 4g, profiles/r04_frames8_experiments.txt)"
+                            "staging waves' tap loads and gradient stores backing up in the memory pipeline (with every load hitting the cache: 137 us in "
+                            "this loop); the taps are read unit-major (contiguous runs), the gradients are still written as 64-byte pieces of 102 planes a "
+                            "multiple of 64 KB apart -- with those unit-major too: 0.54 on the slowest box (DESIGN.md 4g, 9; profiles/r04_frames8_experiments.txt)"
                             % (per_call / 1e6, oh, ow)}
             elif summ:
                 # workloads without the 51-tap op: the HBM-bound savfi kernel that takes the most time in the timed region
