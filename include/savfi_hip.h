@@ -108,7 +108,9 @@ int savfi_sepconv_bwd_taps_strided_f32(const float* in, const float* v, const fl
  * taps_unit16 != 0: v and h are UNIT-MAJOR -- a sample is [Ho][Wo / 16][K][16] instead of [K][Ho][Wo], the layout
  *   savfi_conv3x3_tasks_pre_unit16_f32 writes (Wo % 16 == 0): the 51 taps of 16 neighbouring pixels are one contiguous run of
  *   51 x 64 bytes instead of 64-byte pieces of 51 planes.  The sample stride (tap_bstride planes of Ho * Wo floats) is unchanged, and
- *   gV / gH are written [K][Ho][Wo] as always (the producing convolution's gradient kernels read that). */
+ *   gV / gH are written [K][Ho][Wo] (what the producing convolution's gradient kernels read) unless bit 1 is set as well (taps_unit16 = 3,
+ *   backward only): then gV / gH are unit-major too -- for a producer whose data gradient reads that layout (savfi_conv3x3_dgrad_in_unit16_f32)
+ *   and whose weights need no gradient in this pass. */
 #define SAVFI_FRAMES8_WORDS 256
 int savfi_frames8_classify_f32(const float* x, int64_t n, unsigned* cls, void* stream);
 int savfi_sepconv_fwd_frames8_f32(const float* in, const float* v, const float* h, float* out, const unsigned* cls, int B, int C, int Ho,
@@ -327,6 +329,12 @@ int savfi_conv3x3_dgrad_masked_f32(const float* gy, const float* u, const float*
 int savfi_conv3x3_unit16_supported(int N, int T, int Ci, int Co, int H, int W, int pad);
 int savfi_conv3x3_tasks_pre_unit16_f32(const float* x, const float* u, const float* bias, float* out, int N, int T, int Ci, int Co,
                                        int H, int W, int pad, float slope, void* stream);
+/* The data gradient of that layer on a cotangent that is unit-major as well: gy[n] is [H][W / 16][Co][16] (savfi_sepconv_bwd_frames8_f32 with
+ * taps_unit16 = 3), gx [N][Ci][H+2-2pad][W+2-2pad] as always; u = the layer's data-gradient filter transform (savfi_conv3x3_filters_f32).
+ * W % 16 == 0, no reduction split (savfi_conv3x3_in_unit16_supported: 1 / 0); SAVFI_E_UNSUPPORTED otherwise. */
+int savfi_conv3x3_in_unit16_supported(int N, int T, int Ci, int Co, int H, int W, int pad);
+int savfi_conv3x3_dgrad_in_unit16_f32(const float* gy, const float* u, float* gx, int N, int T, int Ci, int Co, int H, int W, int pad,
+                                      void* stream);
 
 /* Weight gradient of the same convolution (zero padding `pad` in {0,1}), NCHW in and out, deterministic:
  *   gw[Co,Ci,3,3] = sum over n,y,x of gz[n,co,y,x] * x[n,ci,y+a-pad,x+b-pad]      x [N,Ci,H,W], gz [N,Co,H+2pad-2,W+2pad-2]

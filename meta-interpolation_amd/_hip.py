@@ -73,6 +73,8 @@ _PROTOTYPES = {
     "savfi_conv3x3_tasks_pre_workspace_floats": [c_int] * 8,
     "savfi_conv3x3_tasks_pre_f32": [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P],
     "savfi_conv3x3_unit16_supported": [c_int] * 7,
+    "savfi_conv3x3_in_unit16_supported": [c_int] * 7,
+    "savfi_conv3x3_dgrad_in_unit16_f32": [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P],
     "savfi_conv3x3_tasks_pre_unit16_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P],
     "savfi_conv3x3_wgrad_tasks_workspace_floats": [c_int] * 7,
     "savfi_conv3x3_wgrad_tasks_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P],

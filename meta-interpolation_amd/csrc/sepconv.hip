@@ -1179,7 +1179,7 @@ extern "C" int savfi_sepconv_fwd_frames8_f32(const float* in, const float* v, co
   if (!in || !v || !h || !out || !cls) return SAVFI_E_NULL;
   if (int e = taps_strided_ok(B, C, Ho, Wo, K, tap_bstride)) return e;
   if (sepconv_env().no_ws_fwd) return SAVFI_E_UNSUPPORTED;
-  return savfi_sepconv_fwd_ws_launch(in, v, h, out, B, Ho, Wo, device_cu_count(), tap_bstride, cls, taps_unit16 ? 1 : 0, (hipStream_t)stream);
+  return savfi_sepconv_fwd_ws_launch(in, v, h, out, B, Ho, Wo, device_cu_count(), tap_bstride, cls, taps_unit16 & 1, (hipStream_t)stream);
 }
 
 extern "C" int savfi_sepconv_bwd_frames8_f32(const float* in, const float* v, const float* h, const float* gO, float* gV, float* gH,
@@ -1187,7 +1187,7 @@ extern "C" int savfi_sepconv_bwd_frames8_f32(const float* in, const float* v, co
                                              void* stream) {
   if (!in || !v || !h || !gO || !gV || !gH || !cls) return SAVFI_E_NULL;
   if (int e = taps_strided_ok(B, C, Ho, Wo, K, tap_bstride)) return e;
-  return savfi_sepconv_bwd_ws_launch(in, v, h, gO, gV, gH, B, Ho, Wo, device_cu_count(), tap_bstride, cls, taps_unit16 ? 1 : 0,
+  return savfi_sepconv_bwd_ws_launch(in, v, h, gO, gV, gH, B, Ho, Wo, device_cu_count(), tap_bstride, cls, taps_unit16 & 3,
                                      (hipStream_t)stream);
 }
 

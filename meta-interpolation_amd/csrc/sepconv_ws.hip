@@ -264,7 +264,8 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
   // unit16: v and h are laid out [y][x / 16][tap][16] per sample (savfi_conv3x3_tasks_pre_unit16_f32) -- a unit's 51 x 64 bytes are
   // contiguous -- instead of [tap][y][x]; gV / gH stay [tap][y][x].  -DWS_EXP_UNITMAJOR=1 (timing only, results wrong): loads AND stores
   // addressed that way: what the op would cost with its gradients in that layout too
-  const bool umaj = WS_EXP_UNITMAJOR || unit16;
+  const bool umaj = WS_EXP_UNITMAJOR || (unit16 & 1);
+  const bool umaj_st = WS_EXP_UNITMAJOR == 1 || (unit16 & 2);        // gV / gH unit-major as well (bit 1 of taps_unit16)
   const unsigned tap_stride = umaj ? 64u : plane_b;
   auto unit_off = [&](int b, int x0, int y) {
     return (unsigned)b * (unsigned)TB * plane_b + (unsigned)((min(y, Ho - 1) * (Wo >> 4) + min((x0 >> 4) + wc, (Wo >> 4) - 1)) * XK) * 64u;
@@ -647,7 +648,7 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
         const int y = unit_y(nn), y1 = unit_y(min(nn + 1, N - 1));
         const int xq = x0 + 16 * wc + 4 * pq;
         const unsigned qoff = !(live && y < Ho && xq < Wo) ? X_OOR
-                              : WS_EXP_UNITMAJOR == 1 ? unit_off(b, x0, y) + (unsigned)pq * 16u + (unsigned)fq * 64u
+                              : umaj_st ? unit_off(b, x0, y) + (unsigned)pq * 16u + (unsigned)fq * 64u
                                                  : (unsigned)b * (unsigned)TB * plane_b + (unsigned)(y * Wo + xq) * 4u + (unsigned)fq * plane_b;
         // one new window row per role and unit (rows R0 + 60 + 2 n + {0 | 1})
         float gr0, gr1;
@@ -691,7 +692,7 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
             }
             const float t14 = tailb[row], t15 = tailb[64 + row];
             if (pq == 3) { v4[2] += t14; v4[3] += t15; }
-            x6_bstore4(v4, gvdst, (qq < 3 || fq < 3) ? qoff_prev : X_OOR, (unsigned)(16 * qq) * (WS_EXP_UNITMAJOR == 1 ? 64u : plane_b));
+            x6_bstore4(v4, gvdst, (qq < 3 || fq < 3) ? qoff_prev : X_OOR, (unsigned)(16 * qq) * (umaj_st ? 64u : plane_b));
           }
           if (n > 0) ws_set(fl, F_OUT_FREE + p, 2 * n - 1);
           WS_T(7);
@@ -760,7 +761,7 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
             // window columns 64, 65 (pixel 14 tap 50; pixel 15 taps 49, 50) are the VALU tail sums
             if (pq == 3 && fx == 50) { v4[2] = s6414; v4[3] = s6515; }
             if (pq == 3 && fx == 49) v4[3] = s6415;
-            x6_bstore4(v4, ghdst, (qq < 3 || fq < 3) ? qoff_prev : X_OOR, (unsigned)(16 * qq) * (WS_EXP_UNITMAJOR == 1 ? 64u : plane_b));
+            x6_bstore4(v4, ghdst, (qq < 3 || fq < 3) ? qoff_prev : X_OOR, (unsigned)(16 * qq) * (umaj_st ? 64u : plane_b));
           }
           if (n > 0) ws_set(fl, F_OUT_FREE + p, 2 * n);
           WS_T(7);
@@ -1561,12 +1562,13 @@ __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ 
     return (unsigned)b * (unsigned)ch * plane_b + (unsigned)(min(y, Ho - 1) * Wo + min(x0 + 16 * wc + j, Wo - 1)) * 4u;
   };
   // unit16: v and h are laid out [y][x / 16][tap][16] per sample (see sepconv_bwd_ws)
-  const unsigned tap_stride = unit16 ? 64u : plane_b;
+  const bool umaj = (unit16 & 1) != 0;
+  const unsigned tap_stride = umaj ? 64u : plane_b;
   auto unit_off = [&](int b, int x0, int y) {
     return (unsigned)b * (unsigned)TB * plane_b + (unsigned)((min(y, Ho - 1) * (Wo >> 4) + min((x0 >> 4) + wc, (Wo >> 4) - 1)) * XK) * 64u;
   };
   auto load_taps = [&](float (&regs)[XNP][2], __amdgpu_buffer_rsrc_t src, int b, int x0, int y, int t0) {
-    const unsigned pix = unit16 ? unit_off(b, x0, y) + (unsigned)j * 4u : pix_off(b, x0, y, TB);
+    const unsigned pix = umaj ? unit_off(b, x0, y) + (unsigned)j * 4u : pix_off(b, x0, y, TB);
     const unsigned voff = pix + (unsigned)(t0 + 1) * tap_stride;
     regs[0][0] = x6_bload(src, pix + (unsigned)max(t0, 0) * tap_stride, 0u);
     regs[0][1] = x6_bload(src, voff, 0u);
@@ -1806,7 +1808,7 @@ __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ 
         } else {
           // taps 50 of pixel 14 and 49, 50 of pixel 15 of the h band (the tail columns' weights): lanes 0..2, in flight under the tile write
           const int hl = min(lane, 2);
-          const unsigned hoff = unit16 ? unit_off(b, x0, y) + (unsigned)(hl == 1 ? 49 : 50) * 64u + (unsigned)(hl == 0 ? 14 : 15) * 4u
+          const unsigned hoff = umaj ? unit_off(b, x0, y) + (unsigned)(hl == 1 ? 49 : 50) * 64u + (unsigned)(hl == 0 ? 14 : 15) * 4u
                                        : (unsigned)b * (unsigned)TB * plane_b + (unsigned)(hl == 1 ? 49 : 50) * plane_b
                                              + (unsigned)(min(y, Ho - 1) * Wo + min(x0 + 16 * wc + (hl == 0 ? 14 : 15), Wo - 1)) * 4u;
           const float hraw = x6_bload(hsrc, hoff, 0u);

@@ -33,6 +33,7 @@
 //
 // The data gradient is the same kernel on the flipped / transposed filter (wino_filter_transform mode 1).
 #include "common.h"
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -218,6 +219,26 @@ __device__ __forceinline__ Patch make_patch(int y0, int x0, int H, int W) {
   return p;
 }
 
+// Unit-major INPUT (savfi_conv3x3_tasks_pre_in_unit16_f32: a sample is [y][x / 16][channel][16]).  A 4-pixel patch row may straddle two
+// units, so a row is TWO 8-byte loads (x0 is even and W a multiple of 16: a pair is whole inside one unit and whole inside or outside the
+// image); rows and pairs outside the image get an offset beyond the buffer (zeros): no column masks, no corner fix-up.  The offsets are
+// those of channel 0; a channel is 64 bytes further (it rides in the descriptor's base).
+struct Patch16 {
+  unsigned va[4], vb[4];
+};
+__device__ __forceinline__ Patch16 make_patch16(int y0, int x0, int H, int W, int K) {
+  Patch16 p;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int y = y0 + r;
+    const bool row = y >= 0 && y < H;
+    const int xa = x0, xb = x0 + 2;
+    p.va[r] = (row && xa >= 0 && xa < W) ? (unsigned)((y * (W >> 4) + (xa >> 4)) * K) * 64u + (unsigned)(xa & 15) * 4u : 0x80000000u;
+    p.vb[r] = (row && xb >= 0 && xb < W) ? (unsigned)((y * (W >> 4) + (xb >> 4)) * K) * 64u + (unsigned)(xb & 15) * 4u : 0x80000000u;
+  }
+  return p;
+}
+
 __device__ __forceinline__ LaneMasks make_lane_masks(int x0, int W) {
   LaneMasks lm;
   lm.partial_cols = 0;
@@ -246,6 +267,15 @@ __device__ __forceinline__ void load_patch(float (&d)[16], const float* __restri
   for (int r = 0; r < 4; ++r) {
     const f32x4 v = savfi_raw_buffer_load_x4(rs, (int)p.voff[r], 0, 0);
     d[4 * r + 0] = v.x; d[4 * r + 1] = v.y; d[4 * r + 2] = v.z; d[4 * r + 3] = v.w;
+  }
+}
+
+__device__ __forceinline__ void load_patch(float (&d)[16], const float* __restrict__ chan, unsigned bytes, const Patch16& p) {
+  const i32x4 rs = plane_rsrc(chan, bytes);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const f32x2 a = savfi_raw_buffer_load_x2(rs, (int)p.va[r], 0, 0), b = savfi_raw_buffer_load_x2(rs, (int)p.vb[r], 0, 0);
+    d[4 * r + 0] = a.x; d[4 * r + 1] = a.y; d[4 * r + 2] = b.x; d[4 * r + 3] = b.y;
   }
 }
 
@@ -302,8 +332,9 @@ __device__ __forceinline__ void input_transform(float (&v)[16], const float (&d)
 //   group  3     those patch registers are dead: the 4 row loads of chunk c+3 are issued into them
 //   groups 4-7   (B^T d) B, one row each, written straight into the other V buffer
 //   group  7     last use of this chunk's A fragments: those of chunk c+2 are loaded in place
+template <typename PatchT>
 __device__ __forceinline__ void chunk_body(f32x4 (&acc)[4][2][4], f32x4 (&afr)[2], const float* __restrict__ vcur,
-                                           float (&d)[16], const Patch& patch, int fixup, int tbw, const LaneMasks& lm,
+                                           float (&d)[16], const PatchT& patch, int fixup, int tbw, const LaneMasks& lm,
                                            float* __restrict__ vnext,
                                            const float* __restrict__ plane3, unsigned plane_bytes, i32x4 urs, unsigned unext, unsigned ulane) {
   f32x4 bfr[2];
@@ -343,7 +374,8 @@ __device__ __forceinline__ void chunk_body(f32x4 (&acc)[4][2][4], f32x4 (&afr)[2
 }
 
 // VEC: the output width is even (pairs never straddle a row end and are 8-byte aligned)
-template <bool VEC>
+// IN16: the input is unit-major (Patch16)
+template <bool VEC, bool IN16 = false>
 __global__ __launch_bounds__(WNT, 2) void wino_conv3x3(WinoArgs a) {
 #ifdef WINO_TRACE
   const unsigned long long tr0 = __builtin_amdgcn_s_memrealtime();
@@ -383,8 +415,13 @@ __global__ __launch_bounds__(WNT, 2) void wino_conv3x3(WinoArgs a) {
   // this thread's tile for the input transform: lane -> tile (4 x 16), wave -> channel within the chunk
   const int tsh = a.tile_shift, tbw = 1 << tsh, tbh = TILES_WG >> tsh;
   const int px0 = 2 * (tbx * tbw + (lane & (tbw - 1))) - a.off;
-  const Patch patch = make_patch(2 * (tby * tbh + (lane >> tsh)) - a.off, px0, a.H, a.W);
-  const unsigned plane_bytes = (unsigned)cplane * 4u;
+  using PatchT = typename std::conditional<IN16, Patch16, Patch>::type;
+  PatchT patch;
+  if constexpr (IN16) patch = make_patch16(2 * (tby * tbh + (lane >> tsh)) - a.off, px0, a.H, a.W, a.K);
+  else patch = make_patch(2 * (tby * tbh + (lane >> tsh)) - a.off, px0, a.H, a.W);
+  // IN16: the descriptor starts at the channel's first 64 bytes inside the sample and ends where the LAST channel's would: every real
+  // access lies inside, 0x80000000 outside
+  const unsigned plane_bytes = IN16 ? (unsigned)a.K * (unsigned)cplane * 4u - (unsigned)(a.K - 1) * 64u : (unsigned)cplane * 4u;
 
   f32x4 acc[4][2][4];
 #pragma unroll
@@ -404,13 +441,13 @@ __global__ __launch_bounds__(WNT, 2) void wino_conv3x3(WinoArgs a) {
   const i32x4 urs = plane_rsrc(a.U + (size_t)task * 16 * a.KP * a.IP, ubytes);
   const unsigned ubase = ((unsigned)cob * 4u + (unsigned)w) * 64u * 32u;
   const unsigned ulane = (unsigned)lane * 32u;
-  auto plane_of = [&](int chunk) { return xp + (size_t)min(min(chunk, nchunk - 1) * CIB + w, a.K - 1) * cplane; };
+  auto plane_of = [&](int chunk) { return xp + (size_t)min(min(chunk, nchunk - 1) * CIB + w, a.K - 1) * (IN16 ? (size_t)16 : cplane); };
   auto u_of = [&](int chunk) { return ubase + (unsigned)min(chunk, nchunk - 1) * (unsigned)ustride; };
 
   // fix-ups (wave-uniform): bit 0 = some column of some lane is outside the image; bits 1-2 = `off` in the workgroup that
   // owns tile (0, 0) of a padded map (its lane 0 holds the row that would start before the plane)
   const LaneMasks lm = make_lane_masks(px0, a.W);
-  const int fixup = (lm.partial_cols != 0 ? 1 : 0) | ((tb == 0 && a.off > 0) ? 2 * a.off : 0);
+  const int fixup = IN16 ? 0 : (lm.partial_cols != 0 ? 1 : 0) | ((tb == 0 && a.off > 0) ? 2 * a.off : 0);
 
   // The 8 bias values of this wave are fetched HERE, with the first patches: vmcnt counts loads and stores in one in-order
   // counter, so a bias load issued between the output stage's stores (as the first version did, once per channel) can only be
@@ -679,7 +716,7 @@ namespace {
 // launches wino_conv3x3 (+ the split reduction) on an already transformed filter U [T][16 * KP * IP]
 int launch_conv(const WinoPlan& p, const float* x, const float* U, const float* bias, float* out, float* partial, int N, int T,
                 int H, int W, int mode, float slope, hipStream_t st, const float* mask = nullptr, float mask_slope = 1.f,
-                int out_unit16 = 0) {
+                int out_unit16 = 0, int in_unit16 = 0) {
   const int64_t wgs = (int64_t)p.th * p.tw * (p.IP / COB) * p.nsplit * N;
   if (wgs > 0x7fffffffLL || T > 65535) return SAVFI_E_TOOBIG;
   constexpr size_t lds = (size_t)LDS_FLOATS * sizeof(float);      // 40 KB: two workgroups per CU
@@ -690,7 +727,8 @@ int launch_conv(const WinoPlan& p, const float* x, const float* U, const float* 
              , savfi_wino_trace_buffer((size_t)wgs)
 #endif
   };
-  if (p.Wo % 2 == 0) hipLaunchKernelGGL(wino_conv3x3<true>, dim3((unsigned)wgs), dim3(WNT), lds, st, a);
+  if (in_unit16) hipLaunchKernelGGL((wino_conv3x3<true, true>), dim3((unsigned)wgs), dim3(WNT), lds, st, a);
+  else if (p.Wo % 2 == 0) hipLaunchKernelGGL(wino_conv3x3<true>, dim3((unsigned)wgs), dim3(WNT), lds, st, a);
   else hipLaunchKernelGGL(wino_conv3x3<false>, dim3((unsigned)wgs), dim3(WNT), lds, st, a);
   if (int e = savfi_launch_status()) return e;
   if (p.nsplit > 1) {
@@ -828,6 +866,26 @@ extern "C" int savfi_conv3x3_tasks_pre_unit16_f32(const float* x, const float* u
   if (int e = check_conv_args(p, N, T, Ci, Co, H, W, pad, 0)) return e;
   if (!unit16_ok(p)) return SAVFI_E_UNSUPPORTED;
   return launch_conv(p, x, u, bias, out, nullptr, N, T, H, W, 0, slope, (hipStream_t)stream, nullptr, 1.f, 1);
+}
+
+// The data gradient (mode 1) of savfi_conv3x3_tasks_pre_unit16_f32's layer on a cotangent that is UNIT-MAJOR too: gy[n] is
+// [H][W / 16][Co][16] (what savfi_sepconv_bwd_frames8_f32 writes with bit 1 of taps_unit16), gx is [Ci][H+2-2pad][W+2-2pad] as always.
+// W % 16 == 0, an even output width, a sample of gy below 2^31 bytes, no reduction split; SAVFI_E_UNSUPPORTED otherwise.
+static int in_unit16_ok(const WinoPlan& p, int H, int W) {
+  return p.nsplit == 1 && W % 16 == 0 && p.Wo % 2 == 0 && (int64_t)p.K * H * W * 4 < ((int64_t)1 << 31);
+}
+extern "C" int savfi_conv3x3_in_unit16_supported(int N, int T, int Ci, int Co, int H, int W, int pad) {
+  WinoPlan p;
+  if (check_conv_args(p, N, T, Ci, Co, H, W, pad, 1)) return 0;
+  return in_unit16_ok(p, H, W) ? 1 : 0;
+}
+extern "C" int savfi_conv3x3_dgrad_in_unit16_f32(const float* gy, const float* u, float* gx, int N, int T, int Ci, int Co, int H, int W,
+                                                 int pad, void* stream) {
+  if (!gy || !u || !gx) return SAVFI_E_NULL;
+  WinoPlan p;
+  if (int e = check_conv_args(p, N, T, Ci, Co, H, W, pad, 1)) return e;
+  if (!in_unit16_ok(p, H, W)) return SAVFI_E_UNSUPPORTED;
+  return launch_conv(p, gy, u, nullptr, gx, nullptr, N, T, H, W, 1, 1.f, (hipStream_t)stream, nullptr, 1.f, 0, 1);
 }
 
 // data gradient (mode 1) on a transformed filter with the activation derivative of the layer that produced this convolution's input

@@ -1223,6 +1223,27 @@ def conv3x3_unit16_supported(x, w, pad):
     return int(_hip.lib().savfi_conv3x3_unit16_supported(N, w.shape[0], Ci, w.shape[1], H, W, int(pad))) == 1
 
 
+def conv3x3_in_unit16_supported(gy_shape, w, pad):
+    """Can the data gradient of the 3x3 layer (cotangent of shape gy_shape, task weights w [T,Co,Ci,3,3]) read a unit-major cotangent
+    (savfi_conv3x3_dgrad_in_unit16_f32)?"""
+    N, Co, H, W = gy_shape
+    return int(_hip.lib().savfi_conv3x3_in_unit16_supported(N, w.shape[0], w.shape[2], Co, H, W, int(pad))) == 1
+
+
+def conv3x3_dgrad_in_unit16(gy, u, T, Ci, Co, pad):
+    """savfi_conv3x3_dgrad_in_unit16_f32: the data gradient on a cotangent whose MEMORY is unit-major ([N][H][W/16][Co][16])."""
+    gy = gy.contiguous()
+    _hip.require_cuda(gy, u)
+    N, _, H, W = gy.shape
+    grow = 2 * (2 - pad) - 2
+    out = torch.empty((N, Ci, H + grow, W + grow), dtype=gy.dtype, device=gy.device)
+    lib = _hip.lib()
+    _hip.launch("conv3x3_bwd_data", lambda: _hip.check(lib.savfi_conv3x3_dgrad_in_unit16_f32(
+        gy.data_ptr(), u.data_ptr(), out.data_ptr(), N, T, Ci, Co, H, W, int(pad), _hip.current_stream()),
+        "savfi_conv3x3_dgrad_in_unit16_f32"), flops=18.0 * Ci * Co * H * W * N)
+    return out
+
+
 def conv3x3_tasks_pre(x, u, T, Ci, Co, bias=None, mode=0, slope=1.0, pad=1, mask=None, mask_slope=1.0, out_unit16=False):
     """savfi_conv3x3_tasks_pre_f32: conv3x3_tasks on a filter already transformed by conv3x3_filters (same mode).  `mask` (mode 1):
     the result is multiplied by (mask > 0 ? 1 : mask_slope) in the kernel's output stage (savfi_conv3x3_dgrad_masked_f32).
@@ -1479,6 +1500,10 @@ class _ConvBiasActTasks(torch.autograd.Function):
     def forward(ctx, x, w, b, stride, padding, dilation, slope, direct=False, in_slope=None, defer=False, out_unit16=False):
         x = x.contiguous()
         ctx.in_slope, ctx.defer = in_slope, bool(defer)          # see _ConvBiasAct.forward
+        # out_unit16 == 2: the cotangent that comes back is unit-major as well (FunctionSepconvPair(..., grads_unit16=True)): only the
+        # data gradient may be asked for (the caller has checked conv3x3_in_unit16_supported and that w, b carry no gradient)
+        ctx.gy_unit16 = int(out_unit16) == 2
+        out_unit16 = bool(out_unit16)
         T, Co, Ci = w.shape[:3]
         N, _, H, W = x.shape
         n = N // T
@@ -1532,6 +1557,17 @@ class _ConvBiasActTasks(torch.autograd.Function):
         N, _, Ho, Wo = y.shape
         n = N // T
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        if ctx.gy_unit16:
+            assert not need_w and not (need_b and ctx.has_bias) and slope == 1.0 and ctx.in_slope is None and ctx.route == 'wino', \
+                "a unit-major cotangent: data gradient of the Winograd route only"
+            if not need_x:
+                return (None,) * 11
+            pad = padding if isinstance(padding, int) else padding[0]
+            u_bwd = ctx.u_bwd if w._version == ctx.w_version else None
+            ctx.u_bwd = None
+            if u_bwd is None:
+                u_bwd = conv3x3_filters(w, False, True)[1]
+            return (conv3x3_dgrad_in_unit16(gy, u_bwd, T, Ci, Co, pad),) + (None,) * 10
         identity = slope == 1.0 or ctx.defer
         gz = gy if identity else torch.empty_like(gy)
         need_b = need_b and ctx.has_bias
@@ -1609,7 +1645,7 @@ def conv_bias_act_tasks(x, weight, bias, stride=1, padding=0, dilation=1, slope=
     """act(conv2d(x[s], weight[s % T]) + bias[s % T]): the lockstep form of conv_bias_act (`in_slope`, `defer`: conv_bias_act).
     `out_unit16`: the result's memory is unit-major (conv3x3_tasks_pre; only after conv3x3_unit16_supported said yes, slope 1)."""
     return _ConvBiasActTasks.apply(x, weight, bias, stride, padding, dilation, float(slope), bool(direct),
-                                   None if in_slope is None else float(in_slope), bool(defer), bool(out_unit16))
+                                   None if in_slope is None else float(in_slope), bool(defer), int(out_unit16))
 
 
 @functools.lru_cache(maxsize=None)

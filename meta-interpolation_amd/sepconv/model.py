@@ -32,6 +32,7 @@ from ..model_utils import MetaConv2dLayer, MetaSequential, as_view, fuse_conv_ac
 from .sepconv_op.sepconv import FunctionSepconv, FunctionSepconvPair, frames8_supported
 
 TAPS_UNIT16 = os.environ.get('SAVFI_SEPCONV_TAPS_PLANAR') is None
+GRADS_UNIT16 = os.environ.get('SAVFI_SEPCONV_GRADS_PLANAR') is None
 
 FILTER_TAPS = 51
 HALF = FILTER_TAPS // 2  # 25
@@ -216,13 +217,18 @@ class MetaNetwork(nn.Module):
         height, width = win['up'][2] - 2, win['up'][3] - 2
         unit16 = (TAPS_UNIT16 and fuse_conv_act() and width % 16 == 0 and frames8_supported(frame0, N, 3, height, width, FILTER_TAPS, 4 * FILTER_TAPS)
                   and hip_ops.conv3x3_unit16_supported(x, sp['w7'], 0))
+        # The tap GRADIENTS come back unit-major as well where only the convolution's data gradient will read them: the Subnets' own
+        # weights carry no gradient in the inner loop (constant, detached); in the outer pass they do, and the weight-gradient and bias
+        # kernels read the plain layout.  SAVFI_SEPCONV_GRADS_PLANAR=1: always the plain layout.
+        grads16 = (unit16 and GRADS_UNIT16 and not sp['w7'].requires_grad and not sp['b7'].requires_grad
+                   and hip_ops.conv3x3_in_unit16_supported((4 * N, FILTER_TAPS, height, width), sp['w7'], 0))
         if unit16:
             taps = hip_ops.conv_bias_act_tasks(x, sp['w7'], sp['b7'], ref[7].stride, 0, ref[7].dilation_rate, 1.0,
-                                               getattr(ref[7], 'direct', False), None, False, True)
+                                               getattr(ref[7], 'direct', False), None, False, 2 if grads16 else 1)
         else:
             taps = ref[7](x, params={'weight': sp['w7'], 'bias': sp['b7']}, padding=0)           # [4 N, 51, height, width]
         rim = (HALF,) * 4
-        return FunctionSepconvPair.apply(F.pad(frame0, rim, mode='replicate'), F.pad(frame1, rim, mode='replicate'), taps, unit16)
+        return FunctionSepconvPair.apply(F.pad(frame0, rim, mode='replicate'), F.pad(frame1, rim, mode='replicate'), taps, unit16, grads16)
 
     def _windowed_tail(self, frame0, frame1, combine, height, width, ph, pw):
         win = self._window(height, width, ph, pw)

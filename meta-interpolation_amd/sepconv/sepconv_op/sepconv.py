@@ -135,7 +135,8 @@ class FunctionSepconvPair(torch.autograd.Function):
     taps_unit16=True: the MEMORY of `taps` is unit-major -- sample [Ho][Wo / 16][K][16] instead of [K][Ho][Wo], what the plugin's last Subnet
     convolution writes through hip_ops.conv_bias_act_tasks(..., out_unit16=True) -- and the kernels read a unit's 51 taps x 16 pixels as one
     contiguous run (include/savfi_hip.h `taps_unit16`; frames8 entry points only: check frames8_supported and Wo % 16 == 0 first).  The
-    returned tap gradient is laid out as its shape says."""
+    returned tap gradient is laid out as its shape says -- unless grads_unit16=True: then its memory is unit-major too, for a producer
+    whose backward reads that (hip_ops.conv_bias_act_tasks(..., out_unit16=2): data gradient only)."""
 
     @staticmethod
     def supported(frame, batch, height, width, taps=51):
@@ -145,7 +146,7 @@ class FunctionSepconvPair(torch.autograd.Function):
                 and 4 * batch * taps * height * width * 4 < 2 ** 31)
 
     @staticmethod
-    def forward(ctx, input0, input1, taps, taps_unit16=False):
+    def forward(ctx, input0, input1, taps, taps_unit16=False, grads_unit16=False):
         B, C, Hi, Wi = input0.shape
         K, Ho, Wo = taps.shape[1:]
         assert input1.shape == input0.shape and taps.size(0) == 4 * B and Hi - K == Ho - 1 and Wi - K == Wo - 1, (input0.shape, taps.shape)
@@ -158,7 +159,8 @@ class FunctionSepconvPair(torch.autograd.Function):
         words = [frames8_classify(inp) for inp in (input0, input1)] if frames8_supported(input0, B, C, Ho, Wo, K, 4 * K) else None
         u16 = 1 if taps_unit16 else 0
         assert not u16 or (words is not None and Wo % 16 == 0), "unit-major taps: the frames8 entry points, widths that are a multiple of 16"
-        ctx.taps_unit16 = u16
+        assert not grads_unit16 or u16, "unit-major gradients go with unit-major taps"
+        ctx.taps_unit16 = u16 | (2 if grads_unit16 else 0)
         for i, (inp, out, s) in enumerate(((input0, out0, 0), (input1, out1, 2))):
             if words is not None:
                 _hip.launch("sepconv_fwd", lambda inp=inp, out=out, s=s, i=i: _hip.check(lib.savfi_sepconv_fwd_frames8_f32(
@@ -177,7 +179,7 @@ class FunctionSepconvPair(torch.autograd.Function):
         words = ctx.saved_tensors[3:] or None
         assert not ctx.needs_input_grad[0] and not ctx.needs_input_grad[1], "FunctionSepconvPair: frames carry no gradient on this path"
         if not ctx.needs_input_grad[2]:
-            return None, None, None, None
+            return None, None, None, None, None
         B, C = input0.shape[:2]
         K, Ho, Wo = taps.shape[1:]
         gradOutput = gradOutput.contiguous()
@@ -196,7 +198,7 @@ class FunctionSepconvPair(torch.autograd.Function):
                     inp.data_ptr(), taps.data_ptr() + s * plane, taps.data_ptr() + (s + 1) * plane, gradOutput.data_ptr(),
                     gT.data_ptr() + s * plane, gT.data_ptr() + (s + 1) * plane, B, C, Ho, Wo, K, 4 * K, st),
                     "savfi_sepconv_bwd_taps_strided_f32"), nbytes=algorithmic_bytes(B, C, Ho, Wo, K, grads=2))
-        return None, None, gT, None
+        return None, None, gT, None, None
 
 
 class ModuleSepconv(torch.nn.Module):

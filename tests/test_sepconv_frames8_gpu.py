@@ -262,4 +262,16 @@ def test_winograd_convolution_writes_unit_major_and_the_pair_op_reads_it():
     assert torch.equal(res[1][0], _to_unit16(res[0][0]))
     for a, bb in zip(res[0][1:], res[1][1:]):
         assert torch.equal(a, bb)
+    # the tap gradients unit-major as well (constant weights: the convolution's backward is its data gradient only, which reads them so)
+    assert hip_ops.conv3x3_in_unit16_supported((B * T, K, Ho, Wo), w, 0)
+    xs = x.clone().requires_grad_()
+    taps = hip_ops.conv_bias_act_tasks(xs, w, b, 1, 0, 1, 1.0, False, None, False, 2)
+    out = S.FunctionSepconvPair.apply(f0, f1, taps, True, True)
+    out.backward(gO)
+    assert torch.equal(out.detach(), res[0][1]) and torch.equal(xs.grad, res[0][2])
+    # ... and the op alone: gV / gH unit-major are the planar ones rearranged
+    inp, v, h, g2 = (t.to(DEV) for t in _inputs(2, 40, 64, seed=3))
+    w8 = _words(inp)
+    for a, bb in zip(_abi_bwd(inp, _to_unit16(v), _to_unit16(h), g2, w8, u16=3), _abi_bwd(inp, v, h, g2, w8)):
+        assert torch.equal(a, _to_unit16(bb))
     assert _hip.lib().savfi_sepconv_ws_errors() == 0
