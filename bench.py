@@ -362,7 +362,7 @@ def main():
                 per_call = 4.0 * (3 * (oh + 50) * (ow + 50) + 4 * 51 * oh * ow + 3 * oh * ow)
                 line["roofline"] = {
                     "bound": "hbm", "kernel": "sepconv_bwd_ws<U8> (gV+gH, K=51; csrc/sepconv_ws.hip: frames of 8-bit images as exact integers x split-bf16 taps "
-                                              "on MFMAs, MFMA waves + staging waves in pairs, taps unit-major from the producing convolution; the timed interval "
+                                              "on MFMAs, MFMA waves + staging waves in pairs, taps and inner-loop tap gradients unit-major; the timed interval "
                                               "also holds the six-product instance's early exit: both are launched, the device picks)",
                     "achieved": k["achieved_GBps"], "peak": 8000.0, "unit": "GB/s",
                     "frac": k["achieved_GBps"] / 8000.0, "traffic": traffic, "traffic_source": tnote,
@@ -371,8 +371,8 @@ def main():
                     "note": "algorithmic bytes = %.2f MB per [1,3,%d,%d] sample (x samples per launch: tasks in lockstep x the "
                             "support pair); 132 bf16 MFMAs per 16 pixels (the MFMA waves alone sustain 124 us per B = 8 launch); the launch is bound by the "
                             "staging waves' tap loads and gradient stores backing up in the memory pipeline (with every load hitting the cache: 137 us in "
-                            "this loop); the taps are read unit-major (contiguous runs), the gradients are still written as 64-byte pieces of 102 planes a "
-                            "multiple of 64 KB apart -- with those unit-major too: 0.54 on the slowest box (DESIGN.md 4g, 9; profiles/r04_frames8_experiments.txt)"
+                            "this loop on planar taps); taps and, in the inner loop (10 of 12 launches), their gradients are unit-major -- contiguous runs "
+                            "instead of 64-byte pieces of planes a multiple of 64 KB apart (DESIGN.md 4g, 9; profiles/r04_frames8_experiments.txt)"
                             % (per_call / 1e6, oh, ow)}
             elif summ:
                 # workloads without the 51-tap op: the HBM-bound savfi kernel that takes the most time in the timed region

@@ -7,7 +7,9 @@ cd $R
 T0=$(date +%s); python bench.py > $A/r04_bench_line.json 2> $A/r04_bench_line.err; T1=$(date +%s); echo "python bench.py (default flags): wall $((T1 - T0)) s" > $A/r04_bench_default_run_time.txt
 # A/B on this box: the six-product kernels for every frame tensor
 SAVFI_SEPCONV_NO_FRAMES8=1 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-strong-c4 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); d['config']['mode']['sepconv']='six-product kernels (SAVFI_SEPCONV_NO_FRAMES8=1)'; print(json.dumps(d))" > $A/r04_frames8_ab.jsonl
-python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-strong-c4 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); d['config']['mode']['sepconv']='frames8 (default)'; print(json.dumps(d))" >> $A/r04_frames8_ab.jsonl
+SAVFI_SEPCONV_TAPS_PLANAR=1 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-strong-c4 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); d['config']['mode']['sepconv']='frames8, taps and gradients planar (SAVFI_SEPCONV_TAPS_PLANAR=1)'; print(json.dumps(d))" >> $A/r04_frames8_ab.jsonl
+SAVFI_SEPCONV_GRADS_PLANAR=1 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-strong-c4 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); d['config']['mode']['sepconv']='frames8, taps unit-major, gradients planar (SAVFI_SEPCONV_GRADS_PLANAR=1)'; print(json.dumps(d))" >> $A/r04_frames8_ab.jsonl
+python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-strong-c4 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); d['config']['mode']['sepconv']='frames8, taps and inner-loop gradients unit-major (default)'; print(json.dumps(d))" >> $A/r04_frames8_ab.jsonl
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_c2 -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-strong-c4 > $A/r04_bench_line_profiled.json 2>/dev/null
 python $R/tools/gap_report.py /tmp/prof_c2 0 > $A/r04_bench_c2_one_iteration.txt 2>&1
@@ -23,8 +25,8 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ
 python $R/tools/pmc_summary.py /tmp/pmc2 sepconv >> $A/r04_pmc_sepconv_ws_frames8.txt 2>&1
 cd $R
 python tools/frames8_time.py 8 > $A/r04_frames8_time.txt 2>&1
-SAVFI_HIP_LIB=tools/scratch/variants/libsavfi_trace.so python tools/ws_trace.py 8 f8 > $A/r04_ws_section_trace_frames8.txt 2>&1
-for w in c4_sepconv_msl_256x448_b4_s5; do python bench.py --workload $w --steps 3 --warmup 2 2>/dev/null >> $A/r04_other_configs_frames8.jsonl; done
+python tools/layer_table.py --workload c2_sepconv_256x448_b4_s5 --top 60 > $A/r04_layer_table_c2_final.txt 2>/dev/null
+for w in c4_sepconv_msl_256x448_b4_s5 c3_voxelflow_metasgd_256x256_b8_s5 c5_cain_l2f_720p_b1_s1 rrin_256x448_b4_s5 superslomo_256x448_b4_s5 c1_cain_64x64_b1_s1; do python bench.py --workload $w --steps 3 --warmup 2 2>/dev/null >> $A/r04_other_configs_frames8.jsonl; done
 python -m pytest tests -m gpu -q 2>&1 | tail -9 > $A/r04_pytest_gpu_tail.txt
 python -c "import __graft_entry__ as g; g.smoke()" > $A/r04_smoke.txt 2>&1; tail -3 $A/r04_smoke.txt
 cat $A/r04_bench_line.json | cut -c1-1500; cat $A/r04_bench_default_run_time.txt; tail -3 $A/r04_pytest_gpu_tail.txt

@@ -23,6 +23,8 @@ runs = {
     "bwd_frames8": lambda: lib.savfi_sepconv_bwd_frames8_f32(P(inp), P(v), P(h), P(gO), P(gV), P(gH), P(words), B, C, Ho, Wo, K, K, 0, st),
     "fwd_six": lambda: lib.savfi_sepconv_fwd_taps_strided_f32(P(inp), P(v), P(h), P(out), B, C, Ho, Wo, K, K, st),
     "fwd_frames8": lambda: lib.savfi_sepconv_fwd_frames8_f32(P(inp), P(v), P(h), P(out), P(words), B, C, Ho, Wo, K, K, 0, st),
+    "bwd_frames8_unit16": lambda: lib.savfi_sepconv_bwd_frames8_f32(P(inp), P(v), P(h), P(gO), P(gV), P(gH), P(words), B, C, Ho, Wo, K, K, 3, st),
+    "fwd_frames8_unit16": lambda: lib.savfi_sepconv_fwd_frames8_f32(P(inp), P(v), P(h), P(out), P(words), B, C, Ho, Wo, K, K, 1, st),
     "classify": lambda: lib.savfi_frames8_classify_f32(P(inp), inp.numel(), P(words), st),
 }
 for name, f in runs.items():

@@ -50,9 +50,9 @@ def run():
         gO = torch.randn(B, C, Ho, Wo, device='cuda')
         out, gV, gH = torch.empty_like(gO), torch.empty_like(v), torch.empty_like(h)
         for _ in range(3):
-            assert lib.savfi_sepconv_fwd_frames8_f32(inp.data_ptr(), v.data_ptr(), h.data_ptr(), out.data_ptr(), words.data_ptr(), B, C, Ho, Wo, K, K, 0, st) == 0
+            assert lib.savfi_sepconv_fwd_frames8_f32(inp.data_ptr(), v.data_ptr(), h.data_ptr(), out.data_ptr(), words.data_ptr(), B, C, Ho, Wo, K, K, 1, st) == 0      # taps unit-major, as the plugin calls it
             assert lib.savfi_sepconv_bwd_frames8_f32(inp.data_ptr(), v.data_ptr(), h.data_ptr(), gO.data_ptr(), gV.data_ptr(), gH.data_ptr(),
-                                                     words.data_ptr(), B, C, Ho, Wo, K, K, 0, st) == 0
+                                                     words.data_ptr(), B, C, Ho, Wo, K, K, 3, st) == 0   # taps and gradients unit-major (inner loop)
         torch.cuda.synchronize()
 
 
