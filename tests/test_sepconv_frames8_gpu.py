@@ -275,3 +275,26 @@ def test_winograd_convolution_writes_unit_major_and_the_pair_op_reads_it():
     for a, bb in zip(_abi_bwd(inp, _to_unit16(v), _to_unit16(h), g2, w8, u16=3), _abi_bwd(inp, v, h, g2, w8)):
         assert torch.equal(a, _to_unit16(bb))
     assert _hip.lib().savfi_sepconv_ws_errors() == 0
+
+
+def test_unit_major_convolution_entry_points_refuse_what_they_cannot_do():
+    from meta_interpolation_amd import hip_ops
+    lib, st = _hip.lib(), _hip.current_stream()
+    N, T, C, H, W = 8, 4, K, 98, 130
+    x = torch.randn(N, C, H, W, device=DEV)
+    u = hip_ops.conv3x3_filters(torch.randn(T, C, C, 3, 3, device=DEV), True, True)
+    out = torch.empty(N, C, H - 2, W - 2, device=DEV)
+    P = lambda t: t.data_ptr()
+    assert lib.savfi_conv3x3_unit16_supported(N, T, C, C, H, W, 0) == 1
+    assert lib.savfi_conv3x3_tasks_pre_unit16_f32(None, P(u[0]), None, P(out), N, T, C, C, H, W, 0, 1.0, st) == -1
+    assert lib.savfi_conv3x3_tasks_pre_unit16_f32(P(x), P(u[0]), None, P(out), N, T, C, C, H, W - 2, 0, 1.0, st) == -3      # width 126: not % 16
+    assert lib.savfi_conv3x3_tasks_pre_unit16_f32(P(x), P(u[0]), None, P(out), 4, T, C, C, 38, 66, 0, 1.0, st) == -3        # split reduction
+    assert lib.savfi_conv3x3_unit16_supported(N, T, C, C, H, W - 2, 0) == 0 and lib.savfi_conv3x3_unit16_supported(N, 3, C, C, H, W, 0) == 0
+    gy = torch.randn(N, C, H - 2, W - 2, device=DEV)
+    assert lib.savfi_conv3x3_in_unit16_supported(N, T, C, C, H - 2, W - 2, 0) == 1
+    assert lib.savfi_conv3x3_dgrad_in_unit16_f32(P(gy), None, P(x), N, T, C, C, H - 2, W - 2, 0, st) == -1
+    assert lib.savfi_conv3x3_dgrad_in_unit16_f32(P(gy), P(u[1]), P(x), N, T, C, C, H - 2, W - 4, 0, st) == -3              # width 126
+    assert lib.savfi_conv3x3_in_unit16_supported(N, T, C, C, H - 2, W - 4, 0) == 0
+    # the Python gate of the plugin says no where the direct split-bf16 kernel would run the layer (64 -> 64 channels)
+    assert not hip_ops.conv3x3_unit16_supported(torch.randn(8, 64, 98, 130, device=DEV), torch.randn(4, 64, 64, 3, 3, device=DEV), 0)
+    torch.cuda.synchronize()
