@@ -46,12 +46,14 @@ constexpr int WPAIR_OFF = XWINB;
 constexpr int WSIDE_OFF = WPAIR_OFF + 4 * WPAIRB;
 constexpr int WSIDEB = XC * XWIN * 4 * 4;
 constexpr int WFLAG_OFF = WSIDE_OFF + WSIDEB;
-constexpr int WLDS = WFLAG_OFF + 128;
+constexpr int WLDS = WFLAG_OFF + 256;
+static_assert(3 * XPLANE + 4 * (XTAB + WTILEB) <= XWINB, "U8: the pairs' second tables and tiles fit the six unused window planes");
 static_assert(WLDS <= 160 * 1024, "LDS per CU");
 constexpr int WPV = 20;                            // tile pitch (floats): rows leave as 16-byte pieces of 4 pixels.  gH: the MFMA wave writes
                                                    // D[R][j] (R = window column) to row R - j + 15 = fx + 15, i.e. resolves gH[fx][j] = D[j + fx][j]
                                                    // by its store ADDRESS (conflict free: 16 kg - 19 j mod 32 is a bijection of a half wave)
-enum { F_TAB_FULL = 0, F_TAB_FREE = 4, F_OUT_FULL = 8, F_OUT_FREE = 12, F_PROG = 16, F_SLIDE = 28, F_ERR = 29 };
+enum { F_TAB_FULL = 0, F_TAB_FREE = 4, F_OUT_FULL = 8, F_OUT_FREE = 12, F_PROG = 16, F_SLIDE = 28, F_ERR = 29,
+       F_TABV_FULL = 32, F_TABV_FREE = 36, F_OUTH_FULL = 40, F_OUTH_FREE = 44 };     // U8 (WS_U8_DECOUPLE): the v table / the gH tile of a pair
 constexpr int WSPIN_LIMIT = 1 << 19;
 // experiment switches (timing only, results wrong): -DWS_EXP_NOMFMA the MFMA waves skip both MFMA loops (what the staging waves alone
 // sustain), -DWS_EXP_NOSTAGE the staging waves only run the protocol (what the MFMA waves alone sustain)
@@ -76,6 +78,9 @@ constexpr int WSPIN_LIMIT = 1 << 19;
 #ifndef WS_EXP_NOAREAD          // the MFMA loops reuse the first unit's A fragments (no LDS reads inside the loops)
 #define WS_EXP_NOAREAD 0
 #endif
+#ifndef WS_U8_DECOUPLE          // U8 backward: separate h / v tables and gV / gH tiles per pair (see the kernel).  Experiment, off: correct
+#define WS_U8_DECOUPLE 0        // (the op's tests pass) and SLOWER, 178 -> 190 us per launch in the bench loop -- the staging waves run further
+#endif                          // ahead and put more requests into a memory pipeline that is already full; the one-table protocol is its flow control
 #ifndef WS_EXP_UNITMAJOR        // see load_taps of sepconv_bwd_ws
 #define WS_EXP_UNITMAJOR 0
 #endif
@@ -232,6 +237,12 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
   const int j = lane & 15, kg = lane >> 4;
   char* const tab = smem + WPAIR_OFF + p * WPAIRB;
   float* const tile = reinterpret_cast<float*>(tab + XTAB);
+  // -DWS_U8_DECOUPLE=1 (experiment, measured slower: see the switch): the U8 window needs 3 of its 9 planes, and the pair gets a SECOND table
+  // and a SECOND tile in the freed space -- the h band and v in their own tables, gV and gH through their own tiles, each with its own
+  // sequence numbers: a staging wave may build the next table while the MFMA wave still computes on the other one
+  constexpr bool DEC = U8 && WS_U8_DECOUPLE;
+  char* const tabv = DEC ? smem + 3 * XPLANE + p * (XTAB + WTILEB) : tab;
+  float* const tileh = DEC ? reinterpret_cast<float*>(tabv + XTAB) : tile;
   float* const tailb = reinterpret_cast<float*>(tab + XTAB + WTILEB);
   float* const side = reinterpret_cast<float*>(smem + WSIDE_OFF);
   unsigned* const fl = reinterpret_cast<unsigned*>(smem + WFLAG_OFF);
@@ -308,7 +319,7 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
   };
   // v taps -> table position of tap fy: k step fy / 32, k group (fy % 16) / 4, element fy % 4 + 4 * ((fy / 16) % 2)
   auto write_v_table = [&](const float (&regs)[XNP][2]) {
-    char* const lb = tab + (kg >> 1) * 256 + j * 16 + (kg & 1) * 4;
+    char* const lb = tabv + (kg >> 1) * 256 + j * 16 + (kg & 1) * 4;
 #pragma unroll
     for (int a = 0; a < 8; ++a) {
       unsigned h1 = 0u, h2 = 0u, h3 = 0u;
@@ -348,7 +359,7 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
 
     float gp[XC];                                   // cotangent of the unit at hand (staging: of the next one once the tails have theirs)
     __syncthreads();                                // every wave has left the previous run's window, tables and flags
-    if (tid < 32) fl[tid] = 0u;
+    if (tid < 64) fl[tid] = 0u;
     {
       const unsigned go = pix_off(b, x0, unit_y(0), XC);
 #pragma unroll
@@ -445,7 +456,7 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
 #pragma unroll
         for (int st = 0; st < 2; ++st)
 #pragma unroll
-          for (int pc = 0; pc < 3; ++pc) bq[st][pc] = *reinterpret_cast<const bf16x8*>(tab + pc * XTABP + (4 * st + ko) * 256 + jo * 16);
+          for (int pc = 0; pc < 3; ++pc) bq[st][pc] = *reinterpret_cast<const bf16x8*>(tabv + pc * XTABP + (4 * st + ko) * 256 + jo * 16);
       };
       // the twelve MFMA blocks of a pass (block = channel c, k step st, tile pair mp: 12 MFMAs); the next block's fragments are
       // requested between this block's MFMAs (one LDS read per matrix-pipe gap).  The caller has issued load_a(0, 0).
@@ -486,7 +497,7 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
 #pragma unroll
           for (int uu = 0; uu < 10; ++uu) {
             if (uu + DEPTH < 10) load_av((uu + DEPTH) % NSL, uu + DEPTH);
-            if (uu == 9) { pre_tab = peek_raw(F_TAB_FULL + p); pre_out = peek_raw(F_OUT_FREE + p); }
+            if (uu == 9) { pre_tab = peek_raw((DEC ? F_TABV_FULL : F_TAB_FULL) + p); pre_out = peek_raw(F_OUT_FREE + p); }
             {
               const int st = gv_st(uu);
 #pragma unroll
@@ -507,9 +518,9 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
           }
           WS_T(3);
           // the next pass (gH of this unit): v fragments, first A fragments -- before this pass's epilogue
-          if ((int)__builtin_amdgcn_readfirstlane((int)pre_tab) < 2 * n + 2) ws_wait(fl, F_TAB_FULL + p, 2 * n + 2);
+          if ((int)__builtin_amdgcn_readfirstlane((int)pre_tab) < (DEC ? n + 1 : 2 * n + 2)) ws_wait(fl, (DEC ? F_TABV_FULL : F_TAB_FULL) + p, DEC ? n + 1 : 2 * n + 2);
           read_bv();
-          ws_set(fl, F_TAB_FREE + p, 2 * n + 2);
+          ws_set(fl, (DEC ? F_TABV_FREE : F_TAB_FREE) + p, DEC ? n + 1 : 2 * n + 2);
 #pragma unroll
           for (int d = 0; d < DEPTH; ++d) load_ah(d, d);
           WS_T(4);
@@ -533,7 +544,7 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
 #pragma unroll
             for (int r = 0; r < 4; ++r) val[3][r] = gs * acc[9][r];
           }
-          if ((int)__builtin_amdgcn_readfirstlane((int)pre_out) < 2 * n) ws_wait(fl, F_OUT_FREE + p, 2 * n);
+          if ((int)__builtin_amdgcn_readfirstlane((int)pre_out) < (DEC ? n : 2 * n)) ws_wait(fl, F_OUT_FREE + p, DEC ? n : 2 * n);
           WS_T(5);
           {
             float* const tw = tile + (4 * (lo_ >> 4)) * WPV + (lo_ & 15);
@@ -542,7 +553,7 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
 #pragma unroll
               for (int r = 0; r < 4; ++r) tw[((m < 3 ? 16 * m : 64) + r) * WPV] = val[m][r];
           }
-          ws_set(fl, F_OUT_FULL + p, 2 * n + 1);
+          ws_set(fl, F_OUT_FULL + p, DEC ? n + 1 : 2 * n + 1);
           WS_T(6);
         }
         // ---- gH: bq = v, aq[0] = block 0 ----
@@ -557,7 +568,7 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
 #pragma unroll
           for (int uu = 0; uu < 12; ++uu) {
             if (uu + DEPTH < 12) load_ah((uu + DEPTH) % NSL, uu + DEPTH);
-            if (uu == 11) { pre_tab = peek_raw(F_TAB_FULL + p); pre_out = peek_raw(F_OUT_FREE + p); pre_slide = peek_raw(F_SLIDE); }
+            if (uu == 11) { pre_tab = peek_raw(F_TAB_FULL + p); pre_out = peek_raw((DEC ? F_OUTH_FREE : F_OUT_FREE) + p); pre_slide = peek_raw(F_SLIDE); }
             WS_MFMA_BLOCK(uu)
             if (WS_INTERLEAVE && uu + DEPTH < 12) {
               if constexpr (U8) {                          // MFMA, transpose read, ... (4 reads over the first 4 of 6 MFMAs)
@@ -582,10 +593,10 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
           // the next pass (gV of the next unit): h fragments, first A fragments -- before this pass's epilogue
           if (n + 1 < N) {
             const int q1 = (n + 1) >> 1;
-            if ((int)__builtin_amdgcn_readfirstlane((int)pre_tab) < 2 * n + 3) ws_wait(fl, F_TAB_FULL + p, 2 * n + 3);
+            if ((int)__builtin_amdgcn_readfirstlane((int)pre_tab) < (DEC ? n + 2 : 2 * n + 3)) ws_wait(fl, F_TAB_FULL + p, DEC ? n + 2 : 2 * n + 3);
             WS_T(13);
             read_bh();
-            ws_set(fl, F_TAB_FREE + p, 2 * n + 3);
+            ws_set(fl, F_TAB_FREE + p, DEC ? n + 2 : 2 * n + 3);
             if (u == 1 && q1 >= 2 && (int)__builtin_amdgcn_readfirstlane((int)pre_slide) < 8 * (2 * q1 - 3)) ws_wait(fl, F_SLIDE, 8 * (2 * q1 - 3));
             WS_T(14);
             set_rows(unit_y(n + 1));
@@ -603,17 +614,17 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
               t = fmaf(g_[2], acc[2][m][r], t);
               val[m][r] = t;
             }
-          if ((int)__builtin_amdgcn_readfirstlane((int)pre_out) < 2 * n + 1) ws_wait(fl, F_OUT_FREE + p, 2 * n + 1);
+          if ((int)__builtin_amdgcn_readfirstlane((int)pre_out) < (DEC ? n : 2 * n + 1)) ws_wait(fl, (DEC ? F_OUTH_FREE : F_OUT_FREE) + p, DEC ? n : 2 * n + 1);
           WS_T(11);
           {
             const int lo_ = ws_lane();
-            float* const tw = tile + (4 * (lo_ >> 4) - (lo_ & 15) + 15) * WPV + (lo_ & 15);
+            float* const tw = tileh + (4 * (lo_ >> 4) - (lo_ & 15) + 15) * WPV + (lo_ & 15);
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
               for (int r = 0; r < 4; ++r) tw[(16 * m + r) * WPV] = val[m][r];
           }
-          ws_set(fl, F_OUT_FULL + p, 2 * n + 2);
+          ws_set(fl, (DEC ? F_OUTH_FULL : F_OUT_FULL) + p, DEC ? n + 1 : 2 * n + 2);
           WS_T(12);
         }
       }
@@ -669,16 +680,16 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
           const float h50_14 = rdlane(hreg[6][0], 14 + 16), h49_15 = rdlane(hreg[6][0], 15 + 16), h50_15 = rdlane(hreg[6][1], 15 + 16);
           // (1) the h band of unit n takes the table (the MFMA wave holds v of unit n - 1 in registers)
           if (live) {
-            ws_wait(fl, F_TAB_FREE + p, 2 * n);
+            ws_wait(fl, F_TAB_FREE + p, DEC ? n : 2 * n);
             WS_T(1);
             __builtin_amdgcn_s_setprio(WS_PRIO_TABLE);
             if (!WS_EXP_NOSTAGE) write_h_table(hreg);
-            ws_set(fl, F_TAB_FULL + p, 2 * n + 1);
+            ws_set(fl, F_TAB_FULL + p, DEC ? n + 1 : 2 * n + 1);
             __builtin_amdgcn_s_setprio(0);
             WS_T(2);
           }
           // (2) the gV tile of unit n - 1 -> HBM (tail sums of that unit still in tailb)
-          if (n > 0) ws_wait(fl, F_OUT_FULL + p, 2 * n - 1);
+          if (n > 0) ws_wait(fl, F_OUT_FULL + p, DEC ? n : 2 * n - 1);
           WS_T(6);
 #pragma unroll
           for (int qq = 0; qq < (WS_EXP_NOSTAGE ? 0 : 4); ++qq) {
@@ -694,7 +705,7 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
             if (pq == 3) { v4[2] += t14; v4[3] += t15; }
             x6_bstore4(v4, gvdst, (qq < 3 || fq < 3) ? qoff_prev : X_OOR, (unsigned)(16 * qq) * (umaj_st ? 64u : plane_b));
           }
-          if (n > 0) ws_set(fl, F_OUT_FREE + p, 2 * n - 1);
+          if (n > 0) ws_set(fl, F_OUT_FREE + p, DEC ? n : 2 * n - 1);
           WS_T(7);
           // (3) tail columns of gV (i = 64: pixel 14 tap 50, pixel 15 tap 49; i = 65: pixel 15 tap 50): lane = tap row fy
           if (live && u == 0 && q >= 2) ws_wait(fl, F_SLIDE, 8 * (2 * q - 3));
@@ -723,7 +734,7 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
           // (1) v of unit n takes the table (the MFMA wave holds the h band of unit n in registers)
           float v14 = 0.f, v15 = 0.f;
           if (live) {
-            ws_wait(fl, F_TAB_FREE + p, 2 * n + 1);
+            ws_wait(fl, (DEC ? F_TABV_FREE : F_TAB_FREE) + p, DEC ? n : 2 * n + 1);
             WS_T(1);
             __builtin_amdgcn_s_setprio(WS_PRIO_TABLE);
             if (!WS_EXP_NOSTAGE) write_v_table(vreg);
@@ -731,7 +742,7 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
             // published -- once the MFMA wave has taken its fragments the h-side wave refills the table
             if (!WS_EXP_NOSTAGE) {
               const int f5 = fyl & 31;
-              const char* tp = tab + (4 * (fyl >> 5) + ((f5 & 15) >> 2)) * 256 + ((f5 & 3) + 4 * ((f5 >> 4) & 1)) * 2;
+              const char* tp = tabv + (4 * (fyl >> 5) + ((f5 & 15) >> 2)) * 256 + ((f5 & 3) + 4 * ((f5 >> 4) & 1)) * 2;
               unsigned short r14[3], r15[3];
 #pragma unroll
               for (int pc = 0; pc < 3; ++pc) {
@@ -739,31 +750,31 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
                 r15[pc] = *reinterpret_cast<const unsigned short*>(tp + pc * XTABP + 15 * 16);
               }
               asm volatile("" ::: "memory");
-              ws_set(fl, F_TAB_FULL + p, 2 * n + 2);
+              ws_set(fl, (DEC ? F_TABV_FULL : F_TAB_FULL) + p, DEC ? n + 1 : 2 * n + 2);
 #pragma unroll
               for (int pc = 0; pc < 3; ++pc) {
                 v14 += __uint_as_float((unsigned)r14[pc] << 16);
                 v15 += __uint_as_float((unsigned)r15[pc] << 16);
               }
             } else {
-              ws_set(fl, F_TAB_FULL + p, 2 * n + 2);
+              ws_set(fl, (DEC ? F_TABV_FULL : F_TAB_FULL) + p, DEC ? n + 1 : 2 * n + 2);
             }
             __builtin_amdgcn_s_setprio(0);
             WS_T(2);
           }
           // (2) the gH tile of unit n - 1 -> HBM
-          if (n > 0) ws_wait(fl, F_OUT_FULL + p, 2 * n);
+          if (n > 0) ws_wait(fl, (DEC ? F_OUTH_FULL : F_OUT_FULL) + p, DEC ? n : 2 * n);
           WS_T(6);
 #pragma unroll
           for (int qq = 0; qq < (WS_EXP_NOSTAGE ? 0 : 4); ++qq) {
             const int fx = fq + 16 * qq;
-            f32x4 v4 = *reinterpret_cast<const f32x4*>(tile + (fx + 15) * WPV + 4 * pq);
+            f32x4 v4 = *reinterpret_cast<const f32x4*>(tileh + (fx + 15) * WPV + 4 * pq);
             // window columns 64, 65 (pixel 14 tap 50; pixel 15 taps 49, 50) are the VALU tail sums
             if (pq == 3 && fx == 50) { v4[2] = s6414; v4[3] = s6515; }
             if (pq == 3 && fx == 49) v4[3] = s6415;
             x6_bstore4(v4, ghdst, (qq < 3 || fq < 3) ? qoff_prev : X_OOR, (unsigned)(16 * qq) * (umaj_st ? 64u : plane_b));
           }
-          if (n > 0) ws_set(fl, F_OUT_FREE + p, 2 * n);
+          if (n > 0) ws_set(fl, (DEC ? F_OUTH_FREE : F_OUT_FREE) + p, DEC ? n : 2 * n);
           WS_T(7);
           // (3) tail columns of gH (q = 64, 65: taps 50 / 49, 50 of pixels 14, 15): lane = tap row fy
           if (live && u == 0 && q >= 2) ws_wait(fl, F_SLIDE, 8 * (2 * q - 3));
