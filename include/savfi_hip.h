@@ -56,7 +56,7 @@
 extern "C" {
 #endif
 
-#define SAVFI_ABI_VERSION 14
+#define SAVFI_ABI_VERSION 15
 
 #define SAVFI_OK            0
 #define SAVFI_E_NULL       (-1)  /* a required pointer is NULL                          */
@@ -122,6 +122,16 @@ int savfi_sepconv_bwd_frames8_f32(const float* in, const float* v, const float* 
  * gave up since the library was loaded on the current device.  0 on a healthy build; > 0 means a launch's numbers are wrong
  * (the kernel never hangs).  Synchronises with the device.  -1: the counter could not be read. */
 int savfi_sepconv_ws_errors(void);
+/* The same count WITHOUT a device synchronisation.  savfi_sepconv_ws_watch() -- once per device, outside a stream capture -- maps one host
+ * word into the device; a wait that gives up also adds to that word (system-scope atomic), which the host sees at the latest when the
+ * launch has completed.  savfi_sepconv_ws_errors_peek() reads the word: the caller checks it wherever it has synchronised anyway (the
+ * package: after reading an iteration's loss, meta_learning_system.py) and refuses the iteration's numbers when it is non-zero.
+ * -1: not armed on this device. */
+int savfi_sepconv_ws_watch(void);
+int savfi_sepconv_ws_errors_peek(void);
+/* Test hook: the spin limit of the kernels' bounded waits (default 1 << 19 spins of s_sleep 2).  A NEGATIVE limit makes every wait that does
+ * not find its flag at once give up -- tests/ provoke the error path with it.  *previous (may be NULL) receives the old limit; launches issued afterwards use the new one. */
+int savfi_sepconv_ws_debug_spin_limit(int limit, int* previous);
 
 /* ------------------------------------------------------------------------------------
  * VoxelFlow warp + blend (syn_type 'inter').

@@ -16,7 +16,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_PKG_DIR), "include", "savfi_hip.h")
 
 RULE_SGD, RULE_ADAM, RULE_ADAMAX_LSLR, RULE_ADAMAX_MSGD = 0, 1, 2, 3
 LR_SCALAR, LR_ELEMENT = 0, 1
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 _ERRORS = {-1: "SAVFI_E_NULL (a required pointer is NULL)",
            -2: "SAVFI_E_SHAPE (bad or inconsistent dimension)",
@@ -43,6 +43,9 @@ _PROTOTYPES = {
     "savfi_sepconv_fwd_frames8_f32": [_P, _P, _P, _P, _P] + [c_int] * 7 + [_P],
     "savfi_sepconv_bwd_frames8_f32": [_P, _P, _P, _P, _P, _P, _P] + [c_int] * 7 + [_P],
     "savfi_sepconv_ws_errors": [],
+    "savfi_sepconv_ws_watch": [],
+    "savfi_sepconv_ws_errors_peek": [],
+    "savfi_sepconv_ws_debug_spin_limit": [c_int, POINTER(c_int)],
     "savfi_conv3x3_dgrad_masked_f32": [_P, _P, _P, c_float, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P],
     "savfi_convk_dgrad_masked_f32": [_P, _P, _P, c_float, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P],
     "savfi_voxelwarp_fwd_f32": [_P, _P, _P, c_int, c_int, c_int, _P],
@@ -149,6 +152,31 @@ def check(code, what):
     if code < 0:
         raise SavfiHipError("%s: %s" % (what, _ERRORS.get(code, "error %d" % code)))
     raise SavfiHipError("%s: HIP launch failed with hipError_t %d" % (what, code))
+
+
+_ws_watched = set()
+
+
+def ws_watch():
+    """Arm the no-sync error word of the wave-specialised SepConv kernels on the current device (once; not inside a stream capture)."""
+    import torch
+    dev = torch.cuda.current_device()
+    if dev not in _ws_watched:
+        check(lib().savfi_sepconv_ws_watch(), "savfi_sepconv_ws_watch")
+        _ws_watched.add(dev)
+
+
+def ws_check(where=""):
+    """Raise when a bounded in-kernel wait of csrc/sepconv_ws.hip has given up since the library was loaded: the launch it happened in
+    returned wrong numbers (the kernels never hang).  Reads one mapped host word -- no HIP call, no synchronisation: call it where the
+    device has been synchronised anyway.  A no-op until ws_watch() armed the word on this device."""
+    if _lib is None or not _ws_watched:
+        return
+    n = _lib.savfi_sepconv_ws_errors_peek()
+    if n > 0:
+        raise SavfiHipError("%d bounded wait(s) of the wave-specialised SepConv kernels gave up (csrc/sepconv_ws.hip)%s: the results of "
+                            "the launches since the last check are wrong.  A kernel bug, or the GPU was shared with another process for "
+                            "longer than the spin limit." % (n, (" -- " + where) if where else ""))
 
 
 def ptr_array(tensors):

@@ -47,14 +47,20 @@ constexpr int WSIDE_OFF = WPAIR_OFF + 4 * WPAIRB;
 constexpr int WSIDEB = XC * XWIN * 4 * 4;
 constexpr int WFLAG_OFF = WSIDE_OFF + WSIDEB;
 constexpr int WLDS = WFLAG_OFF + 256;
-static_assert(3 * XPLANE + 4 * (XTAB + WTILEB) <= XWINB, "U8: the pairs' second tables and tiles fit the six unused window planes");
 static_assert(WLDS <= 160 * 1024, "LDS per CU");
+constexpr int WRINGB = 4096;                       // DMA: a staging wave's slot for the raw taps of one unit (51 x 64 bytes, four 1 KB pieces)
+constexpr int WRING_GP = 3328;                     // the unit's cotangent [channel][16 pixels] behind the taps
+constexpr int WS_LGKMCNT0 = 0xC07F;                // s_waitcnt lgkmcnt(0), the other counters unconstrained
+constexpr int WRING_ROW = 3584;                    // the wave's 64 columns x two channels of the window row of the unit's iteration
+constexpr int WS_DMA_UNIT = 7;                     // LDS-DMA instructions per unit: four pieces of the taps, the cotangent, two of the window row
+constexpr int WS_DMA_ITER = 4 + WS_DMA_UNIT;       // vector memory operations of a staging wave's iteration: four drain stores, one unit's fetch
+typedef __attribute__((address_space(3))) void ws_lds_void;
 constexpr int WPV = 20;                            // tile pitch (floats): rows leave as 16-byte pieces of 4 pixels.  gH: the MFMA wave writes
                                                    // D[R][j] (R = window column) to row R - j + 15 = fx + 15, i.e. resolves gH[fx][j] = D[j + fx][j]
                                                    // by its store ADDRESS (conflict free: 16 kg - 19 j mod 32 is a bijection of a half wave)
 enum { F_TAB_FULL = 0, F_TAB_FREE = 4, F_OUT_FULL = 8, F_OUT_FREE = 12, F_PROG = 16, F_SLIDE = 28, F_ERR = 29,
-       F_TABV_FULL = 32, F_TABV_FREE = 36, F_OUTH_FULL = 40, F_OUTH_FREE = 44 };     // U8 (WS_U8_DECOUPLE): the v table / the gH tile of a pair
-constexpr int WSPIN_LIMIT = 1 << 19;
+       F_LIMIT = 30,
+       F_ERRW = 62 };                              // two words: the address of the mapped host word (savfi_sepconv_ws_watch) or 0                             // spins of a bounded wait (x s_sleep 2) before it gives up: a kernel argument, kept in LDS
 // experiment switches (timing only, results wrong): -DWS_EXP_NOMFMA the MFMA waves skip both MFMA loops (what the staging waves alone
 // sustain), -DWS_EXP_NOSTAGE the staging waves only run the protocol (what the MFMA waves alone sustain)
 #ifndef WS_EXP_NOMFMA
@@ -78,9 +84,6 @@ constexpr int WSPIN_LIMIT = 1 << 19;
 #ifndef WS_EXP_NOAREAD          // the MFMA loops reuse the first unit's A fragments (no LDS reads inside the loops)
 #define WS_EXP_NOAREAD 0
 #endif
-#ifndef WS_U8_DECOUPLE          // U8 backward: separate h / v tables and gV / gH tiles per pair (see the kernel).  Experiment, off: correct
-#define WS_U8_DECOUPLE 0        // (the op's tests pass) and SLOWER, 178 -> 190 us per launch in the bench loop -- the staging waves run further
-#endif                          // ahead and put more requests into a memory pipeline that is already full; the one-table protocol is its flow control
 #ifndef WS_EXP_UNITMAJOR        // see load_taps of sepconv_bwd_ws
 #define WS_EXP_UNITMAJOR 0
 #endif
@@ -89,11 +92,17 @@ constexpr int WSPIN_LIMIT = 1 << 19;
 #endif
 
 __device__ unsigned ws_error_count = 0;
+typedef __attribute__((address_space(1))) unsigned ws_global_u32;
 // -DWS_TRACE: wave cycles (s_memtime) per section, summed over the units of workgroup 0, in ws_trace[wave][section]
 #ifndef WS_TRACE
 #define WS_TRACE 0
 #endif
+#if WS_TRACE
 __device__ unsigned long long ws_trace[16][16];
+#define WS_TRACE_ADD(wave, k, x) (ws_trace[wave][k] += (x))
+#else
+#define WS_TRACE_ADD(wave, k, x) ((void)0)
+#endif
 #define WS_T(k) do { if (WS_TRACE) { const unsigned long long t_ = __builtin_readcyclecounter(); tr_[k] += t_ - tlast_; tlast_ = t_; } } while (0)
 
 typedef __attribute__((address_space(3))) unsigned lds_u32;
@@ -106,21 +115,32 @@ __device__ __forceinline__ unsigned ws_peek(const unsigned* f) {
   const unsigned v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
 }
+// a bounded wait gave up: the workgroup's error flag (every later wait of the workgroup leaves at its next check), the device counter
+// and -- when savfi_sepconv_ws_watch() armed it -- the mapped host word the product reads without a device synchronisation
+__device__ __forceinline__ void ws_give_up(unsigned* fl) {
+  if ((threadIdx.x & 63) == 0) {
+    __hip_atomic_store(fl + F_ERR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    atomicAdd(&ws_error_count, 1u);
+    // the mapped host word: its address is a kernel argument kept in LDS (a load from a device symbol here, or a flat atomic, makes
+    // hipcc's vmcnt bookkeeping pessimistic for every wait the staging loop has: its row loads then waited for all drain stores)
+    const unsigned long long q = (unsigned long long)fl[F_ERRW] | ((unsigned long long)fl[F_ERRW + 1] << 32);
+    if (q) __hip_atomic_fetch_add(reinterpret_cast<ws_global_u32*>(q), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+// one step of a spin loop; true = give up (limit < 0: at once -- the test hook savfi_sepconv_ws_debug_spin_limit)
+__device__ __forceinline__ bool ws_spin_over(unsigned* fl, int& spins, int limit) {
+  return ((++spins & 255) == 0 || limit < 0) && (ws_peek(fl + F_ERR) != 0u || spins > limit);
+}
 // flag >= target (sequence numbers of one run: no wrap)
 __device__ __forceinline__ void ws_wait(unsigned* fl, int idx, int target) {
   asm volatile("" ::: "memory");
   if ((int)ws_peek(fl + idx) < target) {
     int spins = 0;
+    const int limit = (int)ws_peek(fl + F_LIMIT);
     while (true) {
       __builtin_amdgcn_s_sleep(2);
       if ((int)ws_peek(fl + idx) >= target) break;
-      if ((++spins & 255) == 0 && (ws_peek(fl + F_ERR) != 0u || spins > WSPIN_LIMIT)) {
-        if ((threadIdx.x & 63) == 0) {
-          __hip_atomic_store(fl + F_ERR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          atomicAdd(&ws_error_count, 1u);
-        }
-        break;
-      }
+      if (ws_spin_over(fl, spins, limit)) { ws_give_up(fl); break; }
     }
   }
   asm volatile("" ::: "memory");
@@ -130,22 +150,18 @@ __device__ __forceinline__ void ws_set(unsigned* fl, int idx, int value) {
   __hip_atomic_store(fl + idx, (unsigned)value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   asm volatile("" ::: "memory");
 }
-// every wave's prog >= target
+// every wave's prog >= target (nw progress slots from fl[first])
+template <int FIRST = F_PROG, int NW = 12>
 __device__ __forceinline__ void ws_wait_all_prog(unsigned* fl, int target) {
   asm volatile("" ::: "memory");
-  const int lane7 = min((int)(threadIdx.x & 15), 11);
+  const int slot = min((int)(threadIdx.x & 15), NW - 1);
   int spins = 0;
+  const int limit = (int)ws_peek(fl + F_LIMIT);
   while (true) {
-    const unsigned v = __hip_atomic_load(fl + F_PROG + lane7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const unsigned v = __hip_atomic_load(fl + FIRST + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (__builtin_amdgcn_ballot_w64((int)v < target) == 0ull) break;
     __builtin_amdgcn_s_sleep(2);
-    if ((++spins & 255) == 0 && (ws_peek(fl + F_ERR) != 0u || spins > WSPIN_LIMIT)) {
-      if ((threadIdx.x & 63) == 0) {
-        __hip_atomic_store(fl + F_ERR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        atomicAdd(&ws_error_count, 1u);
-      }
-      break;
-    }
+    if (ws_spin_over(fl, spins, limit)) { ws_give_up(fl); break; }
   }
   asm volatile("" ::: "memory");
 }
@@ -216,19 +232,19 @@ __global__ __launch_bounds__(CLS_NT) void frames8_classify(const float* __restri
 #pragma unroll
     for (int u = 0; u < 4; ++u) q[u] = reinterpret_cast<const f32x4*>(x)[min(i + u * stride, n4 - 1)];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) bad |= ws_not_frames8(q[u].x) | ws_not_frames8(q[u].y) | ws_not_frames8(q[u].z) | ws_not_frames8(q[u].w);
+    for (int u = 0; u < 4; ++u) bad |= (int)ws_not_frames8(q[u].x) | (int)ws_not_frames8(q[u].y) | (int)ws_not_frames8(q[u].z) | (int)ws_not_frames8(q[u].w);
   }
   for (long long i = 4 * n4 + t; i < n; i += stride) bad |= ws_not_frames8(x[i]);
   const int any = __syncthreads_or(bad ? 1 : 0);
   if (threadIdx.x == 0) cls[blockIdx.x] = any ? 1u : 0u;
 }
 
-template <bool U8>
+template <bool U8, bool DMA = false>
 __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ in, const float* __restrict__ v,
                                                       const float* __restrict__ h, const float* __restrict__ gO,
                                                       float* __restrict__ gV, float* __restrict__ gH,
                                                       int B, int Ho, int Wo, int nph, int ncol, int per_wg, int TB,
-                                                      const unsigned* __restrict__ cls, int aligned, int unit16) {
+                                                      const unsigned* __restrict__ cls, int aligned, int unit16, int spin_limit, unsigned* errw) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int p = w & 3, wc = p & 1, wr0 = p >> 1;
@@ -237,21 +253,17 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
   const int j = lane & 15, kg = lane >> 4;
   char* const tab = smem + WPAIR_OFF + p * WPAIRB;
   float* const tile = reinterpret_cast<float*>(tab + XTAB);
-  // -DWS_U8_DECOUPLE=1 (experiment, measured slower: see the switch): the U8 window needs 3 of its 9 planes, and the pair gets a SECOND table
-  // and a SECOND tile in the freed space -- the h band and v in their own tables, gV and gH through their own tiles, each with its own
-  // sequence numbers: a staging wave may build the next table while the MFMA wave still computes on the other one
-  constexpr bool DEC = U8 && WS_U8_DECOUPLE;
-  char* const tabv = DEC ? smem + 3 * XPLANE + p * (XTAB + WTILEB) : tab;
-  float* const tileh = DEC ? reinterpret_cast<float*>(tabv + XTAB) : tile;
+  char* const tabv = tab;                          // one table per pair: the h band of unit n, then v of unit n, then h of unit n + 1 ...
+  float* const tileh = tile;                       // one output tile per pair: gV, then gH
   float* const tailb = reinterpret_cast<float*>(tab + XTAB + WTILEB);
   float* const side = reinterpret_cast<float*>(smem + WSIDE_OFF);
   unsigned* const fl = reinterpret_cast<unsigned*>(smem + WFLAG_OFF);
 
-  const unsigned long long t_kernel0 = WS_TRACE ? __builtin_readcyclecounter() : 0ull;
+  [[maybe_unused]] const unsigned long long t_kernel0 = WS_TRACE ? __builtin_readcyclecounter() : 0ull;
   // A workgroup's phases: position g of a linear order in which strip = g / span and phase = base + g % span.
   //   aligned == 0 (default): strip-major order of all phases cut into pieces of per_wg (span = nph): workgroups that run side by side
   //                 work on unrelated rows.
-  //   aligned != 0 (experiment, slower: see ws_aligned_env): every strip's phases [c per_wg, (c + 1) per_wg) go to workgroup c S + strip
+  //   aligned != 0 (experiment, slower: -DWS_ALIGNED=1): every strip's phases [c per_wg, (c + 1) per_wg) go to workgroup c S + strip
   //                 (S strips), the workgroups of one chunk walk down the same rows of neighbouring strips at the same time; what is left of
   //                 each strip (nph % per_wg phases) is cut in the old way.
   int g0, g1, span, base;
@@ -260,8 +272,9 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
   if (!ws_frames8_mine<U8>(cls)) return;
   const int Hi = Ho + XK - 1, Wi = Wo + XK - 1;
   const unsigned plane_b = (unsigned)Ho * (unsigned)Wo * 4u;
-  const __amdgpu_buffer_rsrc_t hsrc = x6_rsrc(h, (unsigned)((B - 1) * TB + XK) * plane_b);
-  const __amdgpu_buffer_rsrc_t vsrc = x6_rsrc(v, (unsigned)((B - 1) * TB + XK) * plane_b);
+  const unsigned tap_bytes = (unsigned)((B - 1) * TB + XK) * plane_b;
+  const __amdgpu_buffer_rsrc_t hsrc = x6_rsrc(h, tap_bytes);
+  const __amdgpu_buffer_rsrc_t vsrc = x6_rsrc(v, tap_bytes);
   const __amdgpu_buffer_rsrc_t gsrc = x6_rsrc(gO, (unsigned)(B * XC) * plane_b);
   const __amdgpu_buffer_rsrc_t isrc = x6_rsrc(in, (unsigned)(B * XC) * (unsigned)(Hi * Wi) * 4u);
   const __amdgpu_buffer_rsrc_t gvdst = x6_rsrc(gV, (unsigned)((B - 1) * TB + XK) * plane_b);
@@ -299,6 +312,69 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
     return regs[a][e];
   };
   const int h_t0 = 2 * kg - (j & 1), v_t0 = 2 * kg;
+  // DMA (U8, unit-major taps): a unit's 51 x 64 bytes are ONE contiguous run, and the U8 window leaves planes 3..8 of the window area
+  // unused.  Every staging wave owns two slots there and fetches a unit's bytes TWO units ahead with LDS-DMA loads (buffer_load ... lds:
+  // no destination registers, so depth costs nothing): four 16-byte-per-lane pieces of the run (1 KB per instruction; lanes past byte 3264
+  // switched off by the range check) and one dword piece with the unit's cotangent [channel][16 pixels] behind them.  It picks its seven
+  // tap pairs out of the slot with ds_read_b32.  The slot's bytes are ordered for the wave's own reads by a COUNTED s_waitcnt: every
+  // iteration issues exactly WS_DMA_ITER vector memory operations after the fetch of the unit that the next iteration reads.
+  static_assert(!DMA || U8, "the ring lives in the window planes only the U8 window leaves free");
+  static_assert(3 * XPLANE + 8 * 2 * WRINGB <= XWINB, "eight waves x two slots in planes 3..8");
+  char* const ring = smem + 3 * XPLANE + (staging ? w - 4 : 0) * 2 * WRINGB;
+  // (inline assembly, not the raw_ptr_buffer_load_lds builtin: hipcc orders every later LDS read that may alias behind a fetch it knows
+  // of -- the next flag read would wait for the unit just requested.  M0 carries the slot's LDS address and is restored; the instruction
+  // offset moves the memory and the LDS address alike.)
+  // n: the unit's number in the run; the wave's share (64 columns x two channels) of the window row that iteration n writes rides along
+  auto dma_unit = [&](const float* src, unsigned src_bytes, int b, int x0, int R0, int wr0_, int n, int slot) {
+    const int y = R0 + XPR * (n >> 1) + wr0_ + 2 * (n & 1);
+    const unsigned dst = (unsigned)(unsigned long long)(ws_lds_void*)(ring + slot * WRINGB);
+    const unsigned run = unit_off(b, x0, y) + (unsigned)lane * 16u;
+    static_assert((XK * 64 - 3072) / 16 == 12, "lanes of the fourth piece");
+    const unsigned go = lane < 16 * XC ? pix_off(b, x0, y, XC) + (unsigned)kg * plane_b : X_OOR;
+    const int ws_ = w - 4, gcol_ = (ws_ & 1) * 64 + lane, gc0_ = (ws_ & 2) ? 2 : 0, gc1_ = (ws_ & 2) ? 2 : 1;
+    const int rr = min(R0 + 60 + 2 * n + (ws_ >> 2), Hi - 1);
+    const unsigned colb = (unsigned)min(x0 + gcol_, Wi - 1) * 4u;
+    const unsigned r0 = (unsigned)(((b * XC + gc0_) * Hi + rr) * Wi) * 4u + colb, r1 = (unsigned)(((b * XC + gc1_) * Hi + rr) * Wi) * 4u + colb;
+    const ws_i32x4 rs = ws_rsrc4(src, src_bytes), rg = ws_rsrc4(gO, (unsigned)(B * XC) * plane_b);
+    const ws_i32x4 ri = ws_rsrc4(in, (unsigned)(B * XC) * (unsigned)(Hi * Wi) * 4u);
+    unsigned keep;
+    unsigned long long keepx;
+    // the fourth piece under an EXEC of twelve lanes: a lane switched off by the range check would still write zeros over the slot's tail
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %2\n\t"
+                 "s_mov_b64 %1, exec\n\t"
+                 "buffer_load_dwordx4 %6, %10, 0 offen lds\n\t"
+                 "buffer_load_dwordx4 %6, %10, 0 offen offset:1024 lds\n\t"
+                 "buffer_load_dwordx4 %6, %10, 0 offen offset:2048 lds\n\t"
+                 "s_mov_b64 exec, 0xfff\n\t"
+                 "buffer_load_dwordx4 %6, %10, 0 offen offset:3072 lds\n\t"
+                 "s_mov_b64 exec, %1\n\t"
+                 "s_mov_b32 m0, %3\n\t"
+                 "s_nop 0\n\t"
+                 "buffer_load_dword %7, %11, 0 offen lds\n\t"
+                 "s_mov_b32 m0, %4\n\t"
+                 "s_nop 0\n\t"
+                 "buffer_load_dword %8, %12, 0 offen lds\n\t"
+                 "s_mov_b32 m0, %5\n\t"
+                 "s_nop 0\n\t"
+                 "buffer_load_dword %9, %12, 0 offen lds\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep), "=&s"(keepx)
+                 : "s"(dst), "s"(dst + WRING_GP), "s"(dst + WRING_ROW), "s"(dst + WRING_ROW + 256), "v"(run), "v"(go), "v"(r0), "v"(r1),
+                   "s"(rs), "s"(rg), "s"(ri)
+                 : "memory");
+  };
+  auto slot_taps = [&](float (&regs)[XNP][2], int t0, int slot) {   // the registers load_taps fills, out of the slot [tap][16 pixels]
+    const float* const sl = reinterpret_cast<const float*>(ring + slot * WRINGB) + j;
+    regs[0][0] = sl[max(t0, 0) * 16];
+    regs[0][1] = sl[(t0 + 1) * 16];
+#pragma unroll
+    for (int a = 1; a < XNP - 1; ++a)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) regs[a][e] = sl[(t0 + 8 * a + e) * 16];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) regs[XNP - 1][e] = sl[min(8 * (XNP - 1) + t0 + e, XK - 1) * 16];
+  };
   // h band of the unit's 16 pixels -> table [piece][i / 8][j][i % 8], i = tap + j < 64 (zero elsewhere)
   auto write_h_table = [&](const float (&regs)[XNP][2]) {
 #pragma unroll
@@ -340,8 +416,6 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
   constexpr int PB8[3] = {2, 1, 0};                  // U8: the window is one piece (PA = 0)
   constexpr int NPC = U8 ? 1 : 3, NQ = U8 ? 3 : 6;   // window pieces, products per fp32 product
   constexpr int DEPTH = U8 ? 2 : 1, NSL = DEPTH + 1; // A fragments are requested DEPTH blocks ahead (a U8 block is 6 MFMAs: half the cover)
-  const int permk = ((kg & 1) << 1) | (kg >> 1);
-  const int L = lane & 15;
   const int pq = lane & 3, fq = lane >> 2;
 
   // The run loop exists twice, once per role (a wave never changes role): in one loop with a run-time branch every per-lane constant
@@ -359,18 +433,26 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
 
     float gp[XC];                                   // cotangent of the unit at hand (staging: of the next one once the tails have theirs)
     __syncthreads();                                // every wave has left the previous run's window, tables and flags
-    if (tid < 64) fl[tid] = 0u;
+    if (tid < 64) {
+      const unsigned long long q = reinterpret_cast<unsigned long long>(errw);
+      fl[tid] = tid == F_LIMIT ? (unsigned)spin_limit : tid == F_ERRW ? (unsigned)q : tid == F_ERRW + 1 ? (unsigned)(q >> 32) : 0u;
+    }
     {
       const unsigned go = pix_off(b, x0, unit_y(0), XC);
 #pragma unroll
       for (int c = 0; c < XC; ++c) gp[c] = x6_bload(gsrc, go, (unsigned)c * plane_b);
     }
+    if constexpr (DMA && STG) {                      // the first two units' fetches: their latency runs under the window prologue
+      dma_unit(role == 1 ? h : v, tap_bytes, b, x0, R0, wr0, 0, 0);
+      dma_unit(role == 1 ? h : v, tap_bytes, b, x0, R0, wr0, min(1, N - 1), 1);
+    }
     if (tid < XNT) {                                 // the window prologue keeps sepconv_x6's mapping of 512 threads
+      constexpr int PR = U8 ? 32 : 16;               // rows per round trip (the U8 kernel has the registers for two rounds instead of four)
 #pragma unroll 1
-      for (int r = 0; r < XWIN; r += 16) {
-        X6Rows<16> sr;
-        x6_rows_load<16>(sr, isrc, b, x0, R0 + r, Hi, Wi, tid);
-        x6_rows_write<16, U8>(sr, smem, R0 + r, tid, WSIDE_OFF);
+      for (int r = 0; r < XWIN; r += PR) {
+        X6Rows<PR> sr;
+        x6_rows_load<PR>(sr, isrc, b, x0, R0 + r, Hi, Wi, tid);
+        x6_rows_write<PR, U8>(sr, smem, R0 + r, tid, WSIDE_OFF);
       }
     }
     __builtin_amdgcn_s_waitcnt(0);
@@ -497,7 +579,7 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
 #pragma unroll
           for (int uu = 0; uu < 10; ++uu) {
             if (uu + DEPTH < 10) load_av((uu + DEPTH) % NSL, uu + DEPTH);
-            if (uu == 9) { pre_tab = peek_raw((DEC ? F_TABV_FULL : F_TAB_FULL) + p); pre_out = peek_raw(F_OUT_FREE + p); }
+            if (uu == 9) { pre_tab = peek_raw(F_TAB_FULL + p); pre_out = peek_raw(F_OUT_FREE + p); }
             {
               const int st = gv_st(uu);
 #pragma unroll
@@ -518,9 +600,9 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
           }
           WS_T(3);
           // the next pass (gH of this unit): v fragments, first A fragments -- before this pass's epilogue
-          if ((int)__builtin_amdgcn_readfirstlane((int)pre_tab) < (DEC ? n + 1 : 2 * n + 2)) ws_wait(fl, (DEC ? F_TABV_FULL : F_TAB_FULL) + p, DEC ? n + 1 : 2 * n + 2);
+          if ((int)__builtin_amdgcn_readfirstlane((int)pre_tab) < (2 * n + 2)) ws_wait(fl, F_TAB_FULL + p, 2 * n + 2);
           read_bv();
-          ws_set(fl, (DEC ? F_TABV_FREE : F_TAB_FREE) + p, DEC ? n + 1 : 2 * n + 2);
+          ws_set(fl, F_TAB_FREE + p, 2 * n + 2);
 #pragma unroll
           for (int d = 0; d < DEPTH; ++d) load_ah(d, d);
           WS_T(4);
@@ -544,7 +626,7 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
 #pragma unroll
             for (int r = 0; r < 4; ++r) val[3][r] = gs * acc[9][r];
           }
-          if ((int)__builtin_amdgcn_readfirstlane((int)pre_out) < (DEC ? n : 2 * n)) ws_wait(fl, F_OUT_FREE + p, DEC ? n : 2 * n);
+          if ((int)__builtin_amdgcn_readfirstlane((int)pre_out) < (2 * n)) ws_wait(fl, F_OUT_FREE + p, 2 * n);
           WS_T(5);
           {
             float* const tw = tile + (4 * (lo_ >> 4)) * WPV + (lo_ & 15);
@@ -553,7 +635,7 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
 #pragma unroll
               for (int r = 0; r < 4; ++r) tw[((m < 3 ? 16 * m : 64) + r) * WPV] = val[m][r];
           }
-          ws_set(fl, F_OUT_FULL + p, DEC ? n + 1 : 2 * n + 1);
+          ws_set(fl, F_OUT_FULL + p, 2 * n + 1);
           WS_T(6);
         }
         // ---- gH: bq = v, aq[0] = block 0 ----
@@ -568,7 +650,7 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
 #pragma unroll
           for (int uu = 0; uu < 12; ++uu) {
             if (uu + DEPTH < 12) load_ah((uu + DEPTH) % NSL, uu + DEPTH);
-            if (uu == 11) { pre_tab = peek_raw(F_TAB_FULL + p); pre_out = peek_raw((DEC ? F_OUTH_FREE : F_OUT_FREE) + p); pre_slide = peek_raw(F_SLIDE); }
+            if (uu == 11) { pre_tab = peek_raw(F_TAB_FULL + p); pre_out = peek_raw(F_OUT_FREE + p); pre_slide = peek_raw(F_SLIDE); }
             WS_MFMA_BLOCK(uu)
             if (WS_INTERLEAVE && uu + DEPTH < 12) {
               if constexpr (U8) {                          // MFMA, transpose read, ... (4 reads over the first 4 of 6 MFMAs)
@@ -593,10 +675,10 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
           // the next pass (gV of the next unit): h fragments, first A fragments -- before this pass's epilogue
           if (n + 1 < N) {
             const int q1 = (n + 1) >> 1;
-            if ((int)__builtin_amdgcn_readfirstlane((int)pre_tab) < (DEC ? n + 2 : 2 * n + 3)) ws_wait(fl, F_TAB_FULL + p, DEC ? n + 2 : 2 * n + 3);
+            if ((int)__builtin_amdgcn_readfirstlane((int)pre_tab) < (2 * n + 3)) ws_wait(fl, F_TAB_FULL + p, 2 * n + 3);
             WS_T(13);
             read_bh();
-            ws_set(fl, F_TAB_FREE + p, DEC ? n + 2 : 2 * n + 3);
+            ws_set(fl, F_TAB_FREE + p, 2 * n + 3);
             if (u == 1 && q1 >= 2 && (int)__builtin_amdgcn_readfirstlane((int)pre_slide) < 8 * (2 * q1 - 3)) ws_wait(fl, F_SLIDE, 8 * (2 * q1 - 3));
             WS_T(14);
             set_rows(unit_y(n + 1));
@@ -614,7 +696,7 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
               t = fmaf(g_[2], acc[2][m][r], t);
               val[m][r] = t;
             }
-          if ((int)__builtin_amdgcn_readfirstlane((int)pre_out) < (DEC ? n : 2 * n + 1)) ws_wait(fl, (DEC ? F_OUTH_FREE : F_OUT_FREE) + p, DEC ? n : 2 * n + 1);
+          if ((int)__builtin_amdgcn_readfirstlane((int)pre_out) < (2 * n + 1)) ws_wait(fl, F_OUT_FREE + p, 2 * n + 1);
           WS_T(11);
           {
             const int lo_ = ws_lane();
@@ -624,14 +706,14 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
 #pragma unroll
               for (int r = 0; r < 4; ++r) tw[(16 * m + r) * WPV] = val[m][r];
           }
-          ws_set(fl, (DEC ? F_OUTH_FULL : F_OUT_FULL) + p, DEC ? n + 1 : 2 * n + 2);
+          ws_set(fl, F_OUT_FULL + p, 2 * n + 2);
           WS_T(12);
         }
       }
 #undef WS_MFMA_BLOCK
       __builtin_amdgcn_s_setprio(0);
       if (WS_TRACE && blockIdx.x == 0 && lane == 0)
-        for (int k = 0; k < 16; ++k) ws_trace[w][k] += tr_[k];
+        for (int k = 0; k < 16; ++k) WS_TRACE_ADD(w, k, tr_[k]);
     } else {
       // =========================================== staging waves ===============================================================
       // role 1 (waves 4..7): the h side of the pair's units -- h taps, band table, gV tail columns, gV tile -> HBM, window row 60 + 2 n
@@ -644,8 +726,14 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
       const unsigned gcolb = (unsigned)min(x0 + gcol, Wi - 1) * 4u;
       const int gc0 = ggrp == 0 ? 0 : 2, gc1 = ggrp == 0 ? 1 : 2;
       unsigned long long tr_[16] = {0}, tlast_ = __builtin_readcyclecounter();
-      float hreg[XNP][2], vreg[XNP][2];               // taps of the unit at hand, then of the next one (one of the two per role)
-      if (hside) load_taps(hreg, hsrc, b, x0, unit_y(0), h_t0);
+      // taps of the unit at hand, then of the next one (one of the two per role; DMA: ONE array -- the slot reads assign it at the top of
+      // every iteration, and a second, never assigned array would be carried around the loop as sixteen register copies)
+      float treg_a[XNP][2], treg_b[XNP][2];
+      float (&hreg)[XNP][2] = treg_a;
+      float (&vreg)[XNP][2] = DMA ? treg_a : treg_b;
+      if constexpr (DMA) {
+        // (units 0 and 1 were requested before the window prologue)
+      } else if (hside) load_taps(hreg, hsrc, b, x0, unit_y(0), h_t0);
       else load_taps(vreg, vsrc, b, x0, unit_y(0), v_t0);
       float s6414 = 0.f, s6415 = 0.f, s6515 = 0.f;   // v side: gH tail sums of the unit whose tile is drained next
       unsigned qoff_prev = X_OOR;
@@ -661,13 +749,33 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
         const unsigned qoff = !(live && y < Ho && xq < Wo) ? X_OOR
                               : umaj_st ? unit_off(b, x0, y) + (unsigned)pq * 16u + (unsigned)fq * 64u
                                                  : (unsigned)b * (unsigned)TB * plane_b + (unsigned)(y * Wo + xq) * 4u + (unsigned)fq * plane_b;
+        if constexpr (DMA) {
+          // unit n's bytes have landed in slot n & 1: everything but the last iteration's WS_DMA_ITER operations (before the first
+          // iteration: but the second unit's fetch) has completed
+          asm volatile("" ::: "memory");
+          // (assembly: with the builtin hipcc's own bookkeeping of THIS loop turned pessimistic -- its wait for the row loads became vmcnt(1))
+          static_assert(WS_DMA_UNIT == 7 && WS_DMA_ITER == 11, "the immediates below");
+          if (n == 0) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+          WS_T(11);
+          asm volatile("" ::: "memory");
+          slot_taps(treg_a, hside ? h_t0 : v_t0, n & 1);
+          const float* const gs = reinterpret_cast<const float*>(ring + (n & 1) * WRINGB + WRING_GP) + j;
+#pragma unroll
+          for (int c = 0; c < XC; ++c) gp[c] = gs[16 * c];
+          asm volatile("" ::: "memory");
+        }
         // one new window row per role and unit (rows R0 + 60 + 2 n + {0 | 1})
         float gr0, gr1;
         const int grow = R0 + 60 + 2 * nn + (hside ? 0 : 1);
         {
           const int rr = min(grow, Hi - 1);
-          gr0 = WS_EXP_NOSTAGE ? 0.f : x6_bload(isrc, (unsigned)(((b * XC + gc0) * Hi + rr) * Wi) * 4u + gcolb, 0u);
-          gr1 = WS_EXP_NOSTAGE ? 0.f : x6_bload(isrc, (unsigned)(((b * XC + gc1) * Hi + rr) * Wi) * 4u + gcolb, 0u);
+          if constexpr (DMA) {                       // fetched with the unit: read back where the row is written
+            gr0 = gr1 = 0.f;
+          } else {
+            gr0 = WS_EXP_NOSTAGE ? 0.f : x6_bload(isrc, (unsigned)(((b * XC + gc0) * Hi + rr) * Wi) * 4u + gcolb, 0u);
+            gr1 = WS_EXP_NOSTAGE ? 0.f : x6_bload(isrc, (unsigned)(((b * XC + gc1) * Hi + rr) * Wi) * 4u + gcolb, 0u);
+          }
         }
         float g14[XC], g15[XC];
 #pragma unroll
@@ -680,16 +788,16 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
           const float h50_14 = rdlane(hreg[6][0], 14 + 16), h49_15 = rdlane(hreg[6][0], 15 + 16), h50_15 = rdlane(hreg[6][1], 15 + 16);
           // (1) the h band of unit n takes the table (the MFMA wave holds v of unit n - 1 in registers)
           if (live) {
-            ws_wait(fl, F_TAB_FREE + p, DEC ? n : 2 * n);
+            ws_wait(fl, F_TAB_FREE + p, 2 * n);
             WS_T(1);
             __builtin_amdgcn_s_setprio(WS_PRIO_TABLE);
             if (!WS_EXP_NOSTAGE) write_h_table(hreg);
-            ws_set(fl, F_TAB_FULL + p, DEC ? n + 1 : 2 * n + 1);
+            ws_set(fl, F_TAB_FULL + p, 2 * n + 1);
             __builtin_amdgcn_s_setprio(0);
             WS_T(2);
           }
           // (2) the gV tile of unit n - 1 -> HBM (tail sums of that unit still in tailb)
-          if (n > 0) ws_wait(fl, F_OUT_FULL + p, DEC ? n : 2 * n - 1);
+          if (n > 0) ws_wait(fl, F_OUT_FULL + p, 2 * n - 1);
           WS_T(6);
 #pragma unroll
           for (int qq = 0; qq < (WS_EXP_NOSTAGE ? 0 : 4); ++qq) {
@@ -705,7 +813,7 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
             if (pq == 3) { v4[2] += t14; v4[3] += t15; }
             x6_bstore4(v4, gvdst, (qq < 3 || fq < 3) ? qoff_prev : X_OOR, (unsigned)(16 * qq) * (umaj_st ? 64u : plane_b));
           }
-          if (n > 0) ws_set(fl, F_OUT_FREE + p, DEC ? n : 2 * n - 1);
+          if (n > 0) ws_set(fl, F_OUT_FREE + p, 2 * n - 1);
           WS_T(7);
           // (3) tail columns of gV (i = 64: pixel 14 tap 50, pixel 15 tap 49; i = 65: pixel 15 tap 50): lane = tap row fy
           if (live && u == 0 && q >= 2) ws_wait(fl, F_SLIDE, 8 * (2 * q - 3));
@@ -717,7 +825,7 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
           }
           asm volatile("" ::: "memory");
           if (live && u == 1) ws_set(fl, F_PROG + w, q + 1);
-          if (!WS_EXP_NOSTAGE) load_taps(hreg, hsrc, b, x0, y1, h_t0);
+          if constexpr (!DMA) if (!WS_EXP_NOSTAGE) load_taps(hreg, hsrc, b, x0, y1, h_t0);
           {
             float t14 = 0.f, t15 = 0.f;
 #pragma unroll
@@ -734,7 +842,7 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
           // (1) v of unit n takes the table (the MFMA wave holds the h band of unit n in registers)
           float v14 = 0.f, v15 = 0.f;
           if (live) {
-            ws_wait(fl, (DEC ? F_TABV_FREE : F_TAB_FREE) + p, DEC ? n : 2 * n + 1);
+            ws_wait(fl, F_TAB_FREE + p, 2 * n + 1);
             WS_T(1);
             __builtin_amdgcn_s_setprio(WS_PRIO_TABLE);
             if (!WS_EXP_NOSTAGE) write_v_table(vreg);
@@ -750,20 +858,20 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
                 r15[pc] = *reinterpret_cast<const unsigned short*>(tp + pc * XTABP + 15 * 16);
               }
               asm volatile("" ::: "memory");
-              ws_set(fl, (DEC ? F_TABV_FULL : F_TAB_FULL) + p, DEC ? n + 1 : 2 * n + 2);
+              ws_set(fl, F_TAB_FULL + p, 2 * n + 2);
 #pragma unroll
               for (int pc = 0; pc < 3; ++pc) {
                 v14 += __uint_as_float((unsigned)r14[pc] << 16);
                 v15 += __uint_as_float((unsigned)r15[pc] << 16);
               }
             } else {
-              ws_set(fl, (DEC ? F_TABV_FULL : F_TAB_FULL) + p, DEC ? n + 1 : 2 * n + 2);
+              ws_set(fl, F_TAB_FULL + p, 2 * n + 2);
             }
             __builtin_amdgcn_s_setprio(0);
             WS_T(2);
           }
           // (2) the gH tile of unit n - 1 -> HBM
-          if (n > 0) ws_wait(fl, (DEC ? F_OUTH_FULL : F_OUT_FULL) + p, DEC ? n : 2 * n);
+          if (n > 0) ws_wait(fl, F_OUT_FULL + p, 2 * n);
           WS_T(6);
 #pragma unroll
           for (int qq = 0; qq < (WS_EXP_NOSTAGE ? 0 : 4); ++qq) {
@@ -774,7 +882,7 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
             if (pq == 3 && fx == 49) v4[3] = s6415;
             x6_bstore4(v4, ghdst, (qq < 3 || fq < 3) ? qoff_prev : X_OOR, (unsigned)(16 * qq) * (umaj_st ? 64u : plane_b));
           }
-          if (n > 0) ws_set(fl, (DEC ? F_OUTH_FREE : F_OUT_FREE) + p, DEC ? n : 2 * n);
+          if (n > 0) ws_set(fl, F_OUT_FREE + p, 2 * n);
           WS_T(7);
           // (3) tail columns of gH (q = 64, 65: taps 50 / 49, 50 of pixels 14, 15): lane = tap row fy
           if (live && u == 0 && q >= 2) ws_wait(fl, F_SLIDE, 8 * (2 * q - 3));
@@ -803,11 +911,11 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
           }
           asm volatile("" ::: "memory");
           WS_T(9);
-          if (!WS_EXP_NOSTAGE) load_taps(vreg, vsrc, b, x0, y1, v_t0);
+          if constexpr (!DMA) if (!WS_EXP_NOSTAGE) load_taps(vreg, vsrc, b, x0, y1, v_t0);
           WS_T(3);
         }
         qoff_prev = qoff;
-        if (!WS_EXP_NOSTAGE) {
+        if constexpr (!DMA) if (!WS_EXP_NOSTAGE) {
           const unsigned go = pix_off(b, x0, y1, XC);
 #pragma unroll
           for (int c = 0; c < XC; ++c) gp[c] = x6_bload(gsrc, go, (unsigned)c * plane_b);
@@ -817,6 +925,10 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
           if (q >= 1) ws_wait_all_prog(fl, q);
           WS_T(4);
           const int slot = grow & (XWIN - 1);
+          if constexpr (DMA) {
+            const float* const rs_ = reinterpret_cast<const float*>(ring + (n & 1) * WRINGB + WRING_ROW) + lane;
+            gr0 = rs_[0]; gr1 = rs_[64];
+          }
           if constexpr (U8) {
             const unsigned k1 = x6_cvt_pk(rintf(gr0 * 255.f), rintf(gr1 * 255.f));
             if (gcol < 8 * XNBLK && !WS_EXP_NOSTAGE) {
@@ -842,675 +954,25 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
           asm volatile("" ::: "memory");
           WS_T(5);
         }
+        if constexpr (DMA) {
+          // LAST in the iteration (the count of the wait above): slot n & 1 -- its reads returned long ago -- takes unit n + 2
+          asm volatile("" ::: "memory");
+          __builtin_amdgcn_s_waitcnt(WS_LGKMCNT0);
+          dma_unit(hside ? h : v, tap_bytes, b, x0, R0, wr0, min(n + 2, N - 1), n & 1);
+          asm volatile("" ::: "memory");
+          WS_T(10);
+        }
       }
       if (WS_TRACE && blockIdx.x == 0 && lane == 0)
-        for (int k = 0; k < 16; ++k) ws_trace[w][k] += tr_[k];
+        for (int k = 0; k < 16; ++k) WS_TRACE_ADD(w, k, tr_[k]);
     }
     g = run_end;
   }
   };
   if (!staging) run_all(std::false_type{});
   else run_all(std::true_type{});
-  if (WS_TRACE && blockIdx.x == 0 && (threadIdx.x & 63) == 0) ws_trace[threadIdx.x >> 6][15] += __builtin_readcyclecounter() - t_kernel0;
+  if (WS_TRACE && blockIdx.x == 0 && (threadIdx.x & 63) == 0) WS_TRACE_ADD(threadIdx.x >> 6, 15, __builtin_readcyclecounter() - t_kernel0);
 }
-
-// ------------------------------------------------------------------------------------------------------------------------------------
-// The same filter gradients with TWO MFMA waves per SIMD (16 waves, 128 registers each): see the MFMA-wave comment inside.
-// LDS: window 103 680 B + 4 x (table 6 144 + gH tile 6 400 + tails 2 x 512) + side columns + flags = 157.5 KB.
-// ------------------------------------------------------------------------------------------------------------------------------------
-#ifndef WS2_DRAIN_LATE
-#define WS2_DRAIN_LATE 1
-#endif
-#ifndef WS2_ROWS_H
-#define WS2_ROWS_H 1
-#endif
-#ifndef WS2_ROW_LAG
-#define WS2_ROW_LAG 2
-#endif
-constexpr int W2NT = 1024;
-constexpr int W2PAIRB = XTAB + WTILEB + 1024;
-constexpr int W2SIDE_OFF = WPAIR_OFF + 4 * W2PAIRB;
-constexpr int W2FLAG_OFF = W2SIDE_OFF + WSIDEB;
-constexpr int W2LDS = W2FLAG_OFF + 256;
-static_assert(W2LDS <= 160 * 1024, "LDS per CU");
-enum { F2_PROG = 32, F2_TAIL_FULL = 48, F2_TAIL_FREE = 52 };       // + F_TAB_*, F_OUT_*, F_SLIDE, F_ERR of sepconv_bwd_ws; 16 progress slots
-__device__ __forceinline__ void ws2_wait_all_prog(unsigned* fl, int target) {
-  asm volatile("" ::: "memory");
-  const int l15 = (int)(threadIdx.x & 15);
-  int spins = 0;
-  while (true) {
-    const unsigned v = __hip_atomic_load(fl + F2_PROG + l15, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (__builtin_amdgcn_ballot_w64((int)v < target) == 0ull) break;
-    __builtin_amdgcn_s_sleep(2);
-    if ((++spins & 255) == 0 && (ws_peek(fl + F_ERR) != 0u || spins > WSPIN_LIMIT)) {
-      if ((threadIdx.x & 63) == 0) {
-        __hip_atomic_store(fl + F_ERR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        atomicAdd(&ws_error_count, 1u);
-      }
-      break;
-    }
-  }
-  asm volatile("" ::: "memory");
-}
-
-__global__ __launch_bounds__(W2NT) void sepconv_bwd_ws2(const float* __restrict__ in, const float* __restrict__ v,
-                                                      const float* __restrict__ h, const float* __restrict__ gO,
-                                                      float* __restrict__ gV, float* __restrict__ gH,
-                                                      int B, int Ho, int Wo, int nph, int ncol, int per_wg, int TB) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int p = w & 3, wc = p & 1, wr0 = p >> 1;
-  const int role = w >> 2;                          // 0, 1: MFMA waves A, B (even / odd units), 2: h-side staging wave, 3: v-side staging wave
-  const bool staging = role >= 2;
-  const int j = lane & 15, kg = lane >> 4;
-  char* const tab = smem + WPAIR_OFF + p * W2PAIRB;
-  float* const tile = reinterpret_cast<float*>(tab + XTAB);
-  float* const tailb = reinterpret_cast<float*>(tab + XTAB + WTILEB);      // [unit parity][column 14 | 15][64 tap rows]
-  float* const side = reinterpret_cast<float*>(smem + W2SIDE_OFF);
-  unsigned* const fl = reinterpret_cast<unsigned*>(smem + W2FLAG_OFF);
-
-  const unsigned long long t_kernel0 = WS_TRACE ? __builtin_readcyclecounter() : 0ull;
-  const int total = B * ncol * nph;
-  const int g0 = blockIdx.x * per_wg, g1 = min(g0 + per_wg, total);
-  if (g0 >= g1) return;
-  const int Hi = Ho + XK - 1, Wi = Wo + XK - 1;
-  const unsigned plane_b = (unsigned)Ho * (unsigned)Wo * 4u;
-  const __amdgpu_buffer_rsrc_t hsrc = x6_rsrc(h, (unsigned)((B - 1) * TB + XK) * plane_b);
-  const __amdgpu_buffer_rsrc_t vsrc = x6_rsrc(v, (unsigned)((B - 1) * TB + XK) * plane_b);
-  const __amdgpu_buffer_rsrc_t gsrc = x6_rsrc(gO, (unsigned)(B * XC) * plane_b);
-  const __amdgpu_buffer_rsrc_t isrc = x6_rsrc(in, (unsigned)(B * XC) * (unsigned)(Hi * Wi) * 4u);
-  const __amdgpu_buffer_rsrc_t gvdst = x6_rsrc(gV, (unsigned)((B - 1) * TB + XK) * plane_b);
-  const __amdgpu_buffer_rsrc_t ghdst = x6_rsrc(gH, (unsigned)((B - 1) * TB + XK) * plane_b);
-
-  auto pix_off = [&](int b, int x0, int y, int ch) {
-    return (unsigned)b * (unsigned)ch * plane_b + (unsigned)(min(y, Ho - 1) * Wo + min(x0 + 16 * wc + j, Wo - 1)) * 4u;
-  };
-  // Tap registers (as sepconv_bwd_x6): lane (j, kg) holds 7 PAIRS of neighbouring taps t0 + 8 a + {0, 1}: a split pair is exactly the
-  // dword a table position takes.  v: t0 = 2 kg.  h: t0 = 2 kg - (j & 1): the band position i = tap + j of a pair starts even.
-  auto load_taps = [&](float (&regs)[XNP][2], __amdgpu_buffer_rsrc_t src, int b, int x0, int y, int t0) {
-    const unsigned pix = pix_off(b, x0, y, TB);
-    const unsigned voff = pix + (unsigned)(t0 + 1) * plane_b;
-    regs[0][0] = x6_bload(src, pix + (unsigned)max(t0, 0) * plane_b, 0u);
-    regs[0][1] = x6_bload(src, voff, 0u);
-#pragma unroll
-    for (int a = 1; a < XNP - 1; ++a)
-#pragma unroll
-      for (int e = 0; e < 2; ++e) regs[a][e] = x6_bload(src, voff, (unsigned)(8 * a + e - 1) * plane_b);
-#pragma unroll
-    for (int e = 0; e < 2; ++e) regs[XNP - 1][e] = x6_bload(src, pix + (unsigned)min(8 * (XNP - 1) + t0 + e, XK - 1) * plane_b, 0u);
-  };
-  auto tap_or_zero = [&](const float (&regs)[XNP][2], int a, int e, int t0) {
-    if (a == 0 && e == 0) return t0 < 0 ? 0.f : regs[0][0];
-    if (a == XNP - 1) return (8 * (XNP - 1) + t0 + e < XK) ? regs[a][e] : 0.f;
-    return regs[a][e];
-  };
-  const int h_t0 = 2 * kg - (j & 1), v_t0 = 2 * kg;
-  // h band of the unit's 16 pixels -> table [piece][i / 8][j][i % 8], i = tap + j < 64 (zero elsewhere)
-  auto write_h_table = [&](const float (&regs)[XNP][2]) {
-#pragma unroll
-    for (int k = 0; k < XTAB / 1024; ++k) *reinterpret_cast<u32x4*>(tab + (k * 64 + lane) * 16) = (u32x4){0u, 0u, 0u, 0u};
-    const int base2 = 2 * kg + (j & ~1);
-    char* const lb = tab + (base2 >> 3) * 256 + j * 16 + (base2 & 7) * 2;
-#pragma unroll
-    for (int a = 0; a < XNP; ++a) {
-      unsigned h1, h2, h3;
-      x6_split2(tap_or_zero(regs, a, 0, h_t0), tap_or_zero(regs, a, 1, h_t0), h1, h2, h3);
-      char* d = lb + a * 256;
-      if (a < XNP - 1 || base2 < 16) {                               // positions 64, 65 belong to the tail
-        *reinterpret_cast<unsigned*>(d) = h1;
-        *reinterpret_cast<unsigned*>(d + XTABP) = h2;
-        *reinterpret_cast<unsigned*>(d + 2 * XTABP) = h3;
-      }
-    }
-  };
-  // v taps -> table position of tap fy: k step fy / 32, k group (fy % 16) / 4, element fy % 4 + 4 * ((fy / 16) % 2)
-  auto write_v_table = [&](const float (&regs)[XNP][2]) {
-    char* const lb = tab + (kg >> 1) * 256 + j * 16 + (kg & 1) * 4;
-#pragma unroll
-    for (int a = 0; a < 8; ++a) {
-      unsigned h1 = 0u, h2 = 0u, h3 = 0u;
-      if (a < XNP) x6_split2(tap_or_zero(regs, a, 0, v_t0), tap_or_zero(regs, a, 1, v_t0), h1, h2, h3);
-      char* d = lb + (4 * (a >> 2) + 2 * (a & 1)) * 256 + 8 * ((a >> 1) & 1);
-      *reinterpret_cast<unsigned*>(d) = h1;
-      *reinterpret_cast<unsigned*>(d + XTABP) = h2;
-      *reinterpret_cast<unsigned*>(d + 2 * XTABP) = h3;
-    }
-  };
-  auto tr_read = [&](int addr) -> bf16x4 {
-    typedef __attribute__((address_space(3))) bf16x4 lds_b4;
-    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(smem + addr));
-  };
-  auto rdlane = [&](float x, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l)); };
-
-  constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // six products, small terms first
-  const int permk = ((kg & 1) << 1) | (kg >> 1);
-  const int L = lane & 15;
-  const int pq = lane & 3, fq = lane >> 2;
-  // Order of the pair's ONE tap table: h(2 q), h(2 q + 1), v(2 q), v(2 q + 1), h(2 q + 2) ...  With the single-MFMA-wave order (h(n), v(n),
-  // h(n + 1) ...) wave B's band could only be built after wave A had taken v(n) at the END of its gV pass: the two waves' gV passes
-  // and both table builds formed one serial chain (measured: each MFMA wave idled ~4 000 ticks per unit for its next band).  In this
-  // order B's band follows A's at once, the two waves run ~one table build apart, and every build overlaps MFMA loops.
-  auto seq_h = [](int n) { return 4 * (n >> 1) + 1 + (n & 1); };
-  auto seq_v = [](int n) { return 4 * (n >> 1) + 3 + (n & 1); };
-
-  // The run loop exists twice, once per role (a wave never changes role): in one loop with a run-time branch every per-lane constant
-  // of the staging program stays live through the MFMA program and vice versa (168 registers: 44 spilled, 180 bytes of scratch per lane).
-  auto run_all = [&](auto stg_) __attribute__((always_inline)) {
-  constexpr bool STG = decltype(stg_)::value;
-  int g = g0;
-#pragma unroll 1
-  while (g < g1) {
-    // ---- a run: phases ph0 .. ph0 + nrun - 1 of strip (b, x0) ---------------------------------------------------------------
-    const int s = g / nph, ph0 = g - s * nph, b = s / ncol, x0 = (s - b * ncol) * XMC;
-    const int run_end = min(g1, g + (nph - ph0)), nrun = run_end - g, N = 2 * nrun;
-    const int R0 = XPR * ph0;
-    auto unit_y = [&](int n) { return R0 + XPR * (n >> 1) + wr0 + 2 * (n & 1); };
-
-    float gp[XC];                                   // cotangent of the unit at hand (staging: of the next one once the tails have theirs)
-    __syncthreads();                                // every wave has left the previous run's window, tables and flags
-    if (tid < 64) fl[tid] = 0u;
-    {
-      const unsigned go = pix_off(b, x0, unit_y(0), XC);
-#pragma unroll
-      for (int c = 0; c < XC; ++c) gp[c] = x6_bload(gsrc, go, (unsigned)c * plane_b);
-    }
-    if (tid < XNT) {                                 // the window prologue keeps sepconv_x6's mapping of 512 threads
-#pragma unroll 1
-      for (int r = 0; r < XWIN; r += 16) {
-        X6Rows<16> sr;
-        x6_rows_load<16>(sr, isrc, b, x0, R0 + r, Hi, Wi, tid);
-        x6_rows_write<16>(sr, smem, R0 + r, tid, W2SIDE_OFF);
-      }
-    }
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
-
-    if constexpr (!STG) {
-      // =========================================== MFMA waves A / B ===========================================================
-      // TWO MFMA waves per SIMD: wave A (role 0) runs the even units of the pair, wave B (role 1) the odd ones, both passes each.  They
-      // take the pair's one tap table in turn (h(0) A, v(0) A, h(1) B, v(1) B, ... : the sequence numbers already serialise it), so B
-      // runs half a unit behind A and one wave's epilogues -- cotangent scaling, tails, stores, tile writes -- and the latency of its
-      // fragment reads fall under the OTHER wave's MFMAs (tools/mfma_chain_probe: two waves per SIMD whose fragment reads are fully
-      // exposed still keep the matrix pipe at one MFMA per 19 ticks; the same work inside ONE wave's MFMA stream cost 20 ticks per
-      // instruction, profiles/r04_ws_experiments.txt).  128 registers per wave (16 waves): ONE set of A fragments, a pass in two
-      // halves of 6 accumulator tiles.  gV with swapped operands leaves from the registers (no tile, no drain by the h-side wave).
-      __builtin_amdgcn_s_setprio(WS_PRIO);
-      unsigned long long tr_[16] = {0}, tlast_ = __builtin_readcyclecounter();
-      const int par = role;                            // 0: even units, 1: odd units
-      bf16x8 bq[2][3], aq[2][3];
-      int rowoff[4], rowh[2][2];
-      const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
-      auto peek_raw = [&](int idx) { return __hip_atomic_load(fl + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
-      auto behind = [&](unsigned peeked, int target) { return (int)__builtin_amdgcn_readfirstlane((int)peeked) < target; };
-      auto set_rows = [&](int y) {
-        const int lo_ = ws_lane(), jo = lo_ & 15, ko = lo_ >> 4, Lo = jo;
-        const int pk = ((ko & 1) << 1) | (ko >> 1);
-#pragma unroll
-        for (int m = 0; m < 3; ++m) rowoff[m] = ((y + 16 * m + jo) & (XWIN - 1)) * 16 + (2 * wc + pk) * XBLK;
-        rowoff[3] = ((y + 48 + min(jo & 3, 2)) & (XWIN - 1)) * 16 + (2 * wc + pk) * XBLK + min(jo >> 2, 2) * XPLANE;
-#pragma unroll
-        for (int st = 0; st < 2; ++st)
-#pragma unroll
-          for (int hf = 0; hf < 2; ++hf)
-            rowh[st][hf] = ((y + 32 * st + 16 * hf + 4 * ko + (Lo >> 2)) & (XWIN - 1)) * 16 + (2 * wc + ((Lo & 3) >> 1)) * XBLK + (Lo & 1) * 8;
-      };
-      // gV blocks uu = 0..9 as in sepconv_bwd_ws: 0..5 = (channel uu / 2, k step uu % 2) x tiles {0, 1}; 6, 7 = k step x {tile 2 of channel 0, of
-      // channel 1}; 8, 9 = k step x {tile 2 of channel 2, packed tile (tap rows 48..50 of the three channels)}
-      auto gv_tile = [](int uu, int t) { return uu < 6 ? 3 * (uu >> 1) + t : uu < 8 ? 3 * t + 2 : (t == 0 ? 8 : 9); };
-      auto load_av = [&](int uu) {
-        const int st = uu & 1;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const int ai = gv_tile(uu, t), c = ai == 9 ? 0 : ai / 3, m = ai == 9 ? 3 : ai % 3;
-#pragma unroll
-          for (int pc = 0; pc < 3; ++pc)
-            aq[t][pc] = *reinterpret_cast<const bf16x8*>(smem + (pc * 3 + c) * XPLANE + 4 * st * XBLK + rowoff[m]);
-        }
-      };
-      auto load_ah = [&](int c, int st, int mp) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int pc = 0; pc < 3; ++pc) {
-            const int base = (pc * 3 + c) * XPLANE + 2 * (2 * mp + t) * XBLK;
-            const bf16x4 lo = tr_read(base + rowh[st][0]), hi = tr_read(base + rowh[st][1]);
-            aq[t][pc] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-          }
-      };
-      auto read_bh = [&]() {
-        const int lo_ = ws_lane(), jo = lo_ & 15, ko = lo_ >> 4, pk = ((ko & 1) << 1) | (ko >> 1);
-#pragma unroll
-        for (int st = 0; st < 2; ++st)
-#pragma unroll
-          for (int pc = 0; pc < 3; ++pc) bq[st][pc] = *reinterpret_cast<const bf16x8*>(tab + pc * XTABP + (4 * st + pk) * 256 + jo * 16);
-      };
-      auto read_bv = [&]() {
-        const int lo_ = ws_lane(), jo = lo_ & 15, ko = lo_ >> 4;
-#pragma unroll
-        for (int st = 0; st < 2; ++st)
-#pragma unroll
-          for (int pc = 0; pc < 3; ++pc) bq[st][pc] = *reinterpret_cast<const bf16x8*>(tab + pc * XTABP + (4 * st + ko) * 256 + jo * 16);
-      };
-      const ws_i32x4 g4rs = ws_rsrc4(gO, (unsigned)(B * XC) * plane_b);
-      f32x4 G[XC];                                     // gV's cotangent: four pixels of a tap row per lane
-      float gj[XC];                                    // gH's: pixel j
-      auto load_G = [&](int y) {
-        const int ko = ws_lane() >> 4;
-        const unsigned off = (unsigned)b * (unsigned)XC * plane_b + (unsigned)(min(y, Ho - 1) * Wo + min(x0 + 16 * wc + 4 * ko, Wo - 4)) * 4u;
-#pragma unroll
-        for (int c = 0; c < XC; ++c) G[c] = ws_raw_load_x4(g4rs, (int)off, (int)((unsigned)c * plane_b), 0);
-      };
-      auto load_gj = [&](int y) {
-        const unsigned go = pix_off(b, x0, y, XC);
-#pragma unroll
-        for (int c = 0; c < XC; ++c) gj[c] = x6_bload(gsrc, go, (unsigned)c * plane_b);
-      };
-      auto dpp1 = [](float x, auto ctrl) {              // lane L takes lane L + n of its row of 16 (zero beyond the row)
-        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true));
-      };
-      if (par < N) {
-        set_rows(unit_y(par));
-        load_G(unit_y(par));
-        load_gj(unit_y(par));
-        ws_wait(fl, F_TAB_FULL + p, seq_h(par));
-        read_bh();
-        ws_set(fl, F_TAB_FREE + p, seq_h(par));
-      }
-#pragma unroll 1
-      for (int n = par; n < N; n += 2) {
-        const int q = n >> 1;
-        const int y = unit_y(n), n2 = n + 2;
-        WS_T(0);
-        const float* const tb = tailb + (n & 1) * 128;
-        unsigned qoff;                                  // this lane's gV piece: tap row L, pixels 4 kg .. 4 kg + 3 of output row y
-        bool last;
-        int Lo;
-        {
-          const int lo_ = ws_lane(), xq = x0 + 16 * wc + 4 * (lo_ >> 4);
-          Lo = lo_ & 15; last = (lo_ >> 4) == 3;
-          qoff = (y < Ho && xq < Wo) ? (unsigned)b * (unsigned)TB * plane_b + (unsigned)(y * Wo + xq) * 4u + (unsigned)Lo * plane_b : X_OOR;
-        }
-        // ---------------- gV, first half: tap rows 0..31 (tiles 0, 1 of the three channels) ----------------
-        {
-          f32x4 acc[6];
-#pragma unroll
-          for (int i = 0; i < 6; ++i) acc[i] = zero4;
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int uu = 0; uu < 6; ++uu) {
-            load_av(uu);
-            if (!WS_EXP_NOMFMA) {
-#pragma unroll
-              for (int qq = 0; qq < 6; ++qq)
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-                  acc[2 * (uu >> 1) + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[uu & 1][PB[qq]], aq[t][PA[qq]], acc[2 * (uu >> 1) + t], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-          }
-          WS_T(3);
-          ws_wait(fl, F2_TAIL_FULL + p, n + 1);
-#pragma unroll
-          for (int t = 0; t < 2; ++t) {
-            const float t14 = tb[16 * t + Lo], t15 = tb[64 + 16 * t + Lo];
-            f32x4 o;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              float s = G[0][r] * acc[t][r];
-              s = fmaf(G[1][r], acc[2 + t][r], s);
-              s = fmaf(G[2][r], acc[4 + t][r], s);
-              o[r] = s;
-            }
-            o[2] += last ? t14 : 0.f;
-            o[3] += last ? t15 : 0.f;
-            x6_bstore4(o, gvdst, qoff, (unsigned)(16 * t) * plane_b);
-          }
-          WS_T(4);
-        }
-        // ---------------- gV, second half: tap rows 32..47 of the three channels and the packed tile (rows 48..50) ----------------
-        {
-          f32x4 acc[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) acc[i] = zero4;
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int uu = 6; uu < 10; ++uu) {
-            load_av(uu);
-            if (!WS_EXP_NOMFMA) {
-#pragma unroll
-              for (int qq = 0; qq < 6; ++qq)
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-                  acc[2 * ((uu - 6) >> 1) + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[uu & 1][PB[qq]], aq[t][PA[qq]], acc[2 * ((uu - 6) >> 1) + t], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-          }
-          WS_T(5);
-          // the band's fragments are consumed: v of this unit (the table goes back to the staging waves before the epilogue)
-          ws_wait(fl, F_TAB_FULL + p, seq_v(n));
-          read_bv();
-          ws_set(fl, F_TAB_FREE + p, seq_v(n));
-          {
-            const float t14 = tb[32 + Lo], t15 = tb[64 + 32 + Lo], p14 = tb[48 + Lo], p15 = tb[64 + 48 + Lo];
-            asm volatile("" ::: "memory");
-            ws_set(fl, F2_TAIL_FREE + p, n + 1);
-            const int cs = Lo >> 2;                     // packed tile: column L = 4 c + r' is tap row 48 + r' of channel c
-            f32x4 o, xp;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              float s = G[0][r] * acc[0][r];
-              s = fmaf(G[1][r], acc[1][r], s);
-              s = fmaf(G[2][r], acc[2][r], s);
-              o[r] = s;
-              const float gs = cs == 0 ? G[0][r] : cs == 1 ? G[1][r] : cs == 2 ? G[2][r] : 0.f;
-              const float xv = gs * acc[3][r];
-              const float x1 = dpp1(xv, std::integral_constant<int, 0x104>{}), x2 = dpp1(xv, std::integral_constant<int, 0x108>{});
-              xp[r] = (xv + x1) + x2;
-            }
-            o[2] += last ? t14 : 0.f;
-            o[3] += last ? t15 : 0.f;
-            xp[2] += last ? p14 : 0.f;
-            xp[3] += last ? p15 : 0.f;
-            x6_bstore4(o, gvdst, qoff, 32u * plane_b);
-            x6_bstore4(xp, gvdst, Lo < 3 ? qoff : X_OOR, 48u * plane_b);
-          }
-          load_G(unit_y(min(n2, N - 1)));
-          WS_T(6);
-        }
-        // ---------------- gH: tiles {0, 1} then {2, 3} of the three channels ----------------
-#pragma unroll
-        for (int mp = 0; mp < 2; ++mp) {
-          f32x4 acc[6];
-#pragma unroll
-          for (int i = 0; i < 6; ++i) acc[i] = zero4;
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int cb = 0; cb < 6; ++cb) {
-            const int c = cb >> 1, st = cb & 1;
-            load_ah(c, st, mp);
-            if (!WS_EXP_NOMFMA) {
-#pragma unroll
-              for (int qq = 0; qq < 6; ++qq)
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-                  acc[2 * c + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[t][PA[qq]], bq[st][PB[qq]], acc[2 * c + t], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-          }
-          WS_T(mp == 0 ? 9 : 10);
-          if (mp == 1) {
-            ws_set(fl, F2_PROG + w, q + 1);                            // this wave's window reads of phase q are over (one unit per phase and wave)
-            // the next unit of this wave: its h band, rows -- before this pass's last epilogue
-            if (n2 < N) {
-              ws_wait(fl, F_TAB_FULL + p, seq_h(n2));
-              read_bh();
-              ws_set(fl, F_TAB_FREE + p, seq_h(n2));
-              const int q2 = n2 >> 1;
-              if (q2 >= 2) ws_wait(fl, F_SLIDE, 8 * (2 * q2 - 3));
-              set_rows(unit_y(n2));
-            }
-          }
-          if (mp == 0) ws_wait(fl, F_OUT_FREE + p, n);        // the previous unit's tile is drained
-          {
-            const int lo_ = ws_lane();
-            float* const tw = tile + (4 * (lo_ >> 4) - (lo_ & 15) + 15) * WPV + (lo_ & 15);
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                float s = gj[0] * acc[t][r];
-                s = fmaf(gj[1], acc[2 + t][r], s);
-                s = fmaf(gj[2], acc[4 + t][r], s);
-                tw[(16 * (2 * mp + t) + r) * WPV] = s;
-              }
-          }
-          if (mp == 1) {
-            ws_set(fl, F_OUT_FULL + p, n + 1);
-            load_gj(unit_y(min(n2, N - 1)));
-          }
-          WS_T(mp == 0 ? 11 : 12);
-        }
-      }
-      __builtin_amdgcn_s_setprio(0);
-      if (WS_TRACE && blockIdx.x == 0 && lane == 0)
-        for (int k = 0; k < 16; ++k) ws_trace[w][k] += tr_[k];
-    } else {
-      // =========================================== staging waves ===============================================================
-      // role 1 (waves 4..7): the h side of the pair's units -- h taps, band table, gV tail columns, gV tile -> HBM, window row 60 + 2 n
-      // role 2 (waves 8..11): the v side -- v taps, table, gH tail columns, gH tile -> HBM, window row 61 + 2 n
-      const bool hside = role == 2;
-      const int ptid = tid - (hside ? 512 : 768);
-      const int gcol = ptid & 127, ggrp = ptid >> 7;        // granule: one window row per role, thread = (column, channels {0, 1} | {2})
-      const int gcell = (gcol >> 3) * XBLK + (gcol & 7) * 2;
-      const int gsidx = gcol == 64 ? 0 : gcol == 65 ? 1 : gcol == 80 ? 2 : gcol == 81 ? 3 : -1;
-      const unsigned gcolb = (unsigned)min(x0 + gcol, Wi - 1) * 4u;
-      const int gc0 = ggrp == 0 ? 0 : 2, gc1 = ggrp == 0 ? 1 : 2;
-      unsigned long long tr_[16] = {0}, tlast_ = __builtin_readcyclecounter();
-      float hreg[XNP][2], vreg[XNP][2];               // taps of the unit at hand, then of the next one (one of the two per role)
-      if (hside) load_taps(hreg, hsrc, b, x0, unit_y(0), h_t0);
-      else load_taps(vreg, vsrc, b, x0, unit_y(0), v_t0);
-      float s6414 = 0.f, s6415 = 0.f, s6515 = 0.f;   // v side: gH tail sums of the unit whose tile is drained next
-      float n6414 = 0.f, n6415 = 0.f, n6515 = 0.f;   // ... of the unit at hand
-      unsigned qoff_prev = X_OOR;
-      // Iteration n: (1) the table of unit n -- FIRST: it is what the MFMA wave waits for next --, (2) the tile of unit n - 1 -> HBM,
-      // (3) tail columns of unit n, taps of unit n + 1, (4) one new window row.  Iteration N only drains the last tile.
-#pragma unroll 1
-      for (int n = 0; n <= N; ++n) {
-        const bool live = n < N;
-        const int nn = min(n, N - 1);
-        const int q = nn >> 1, u = nn & 1;
-        const int y = unit_y(nn), y1 = unit_y(min(nn + 1, N - 1));
-        const int xq = x0 + 16 * wc + 4 * pq;
-        const unsigned qoff = (live && y < Ho && xq < Wo) ? (unsigned)b * (unsigned)TB * plane_b + (unsigned)(y * Wo + xq) * 4u + (unsigned)fq * plane_b : X_OOR;
-        // one new window row per role and unit (rows R0 + 60 + 2 n + {0 | 1})
-        float gr0, gr1;
-        // The window rows trail the tables by WS2_ROW_LAG units: row pair m is loaded and written in iteration m + LAG.  Its write has to wait
-        // until every wave is past phase m / 2 -- with two MFMA waves per SIMD wave B runs half a unit behind A, and a staging wave that
-        // sits in that wait cannot build the next table (measured: the MFMA waves idled ~4 000 ticks per unit for tables); two units later
-        // the condition holds when the wave gets there, and the consumers only need row pair m from phase m / 2 + 2 on.
-        const int rn = nn - WS2_ROW_LAG;
-        // BOTH rows of the pair are the h-side wave's (WS2_ROWS_H): the v-side wave is the busiest of the four (tap loads behind its tail
-        // sums, the gH drain), the h-side wave lost its drain when gV began to leave from the MFMA waves' registers
-        const int grow = R0 + 60 + 2 * max(rn, 0) + ((hside || WS2_ROWS_H) ? 0 : 1);
-        float gr2 = 0.f, gr3 = 0.f;
-        if (hside || !WS2_ROWS_H) {
-          const int rr = min(grow, Hi - 1);
-          gr0 = WS_EXP_NOSTAGE ? 0.f : x6_bload(isrc, (unsigned)(((b * XC + gc0) * Hi + rr) * Wi) * 4u + gcolb, 0u);
-          gr1 = WS_EXP_NOSTAGE ? 0.f : x6_bload(isrc, (unsigned)(((b * XC + gc1) * Hi + rr) * Wi) * 4u + gcolb, 0u);
-          if (WS2_ROWS_H) {
-            const int r2 = min(grow + 1, Hi - 1);
-            gr2 = WS_EXP_NOSTAGE ? 0.f : x6_bload(isrc, (unsigned)(((b * XC + gc0) * Hi + r2) * Wi) * 4u + gcolb, 0u);
-            gr3 = WS_EXP_NOSTAGE ? 0.f : x6_bload(isrc, (unsigned)(((b * XC + gc1) * Hi + r2) * Wi) * 4u + gcolb, 0u);
-          }
-        } else { gr0 = 0.f; gr1 = 0.f; }
-        float g14[XC], g15[XC];
-#pragma unroll
-        for (int c = 0; c < XC; ++c) { g14[c] = rdlane(gp[c], 14); g15[c] = rdlane(gp[c], 15); }
-        const int fyl = min(lane, XK - 1);
-        const int tslot = (y + fyl) & (XWIN - 1);
-        WS_T(0);
-        if (hside) {
-          // what the tail columns need of this unit's taps, before the registers take the next unit's
-          const float h50_14 = rdlane(hreg[6][0], 14 + 16), h49_15 = rdlane(hreg[6][0], 15 + 16), h50_15 = rdlane(hreg[6][1], 15 + 16);
-          // (1) the h band of unit n takes the table (the MFMA wave holds v of unit n - 1 in registers)
-          if (live) {
-            ws_wait(fl, F_TAB_FREE + p, seq_h(n) - 1);
-            WS_T(1);
-            __builtin_amdgcn_s_setprio(WS_PRIO_TABLE);
-            if (!WS_EXP_NOSTAGE) write_h_table(hreg);
-            ws_set(fl, F_TAB_FULL + p, seq_h(n));
-            __builtin_amdgcn_s_setprio(0);
-            WS_T(2);
-          }
-          // (2) (gV leaves from the MFMA waves' registers: nothing to drain on this side)
-          // (3) tail columns of gV (i = 64: pixel 14 tap 50, pixel 15 tap 49; i = 65: pixel 15 tap 50): lane = tap row fy
-          if (live && u == 0 && q >= 2) ws_wait(fl, F_SLIDE, 8 * (2 * q - 3));
-          float a64[XC], a65[XC];
-#pragma unroll
-          for (int c = 0; c < XC; ++c) {
-            const f32x2 sv = *reinterpret_cast<const f32x2*>(side + (c * XWIN + tslot) * 4 + 2 * wc);
-            a64[c] = sv.x; a65[c] = sv.y;
-          }
-          asm volatile("" ::: "memory");
-          if (live && u == 1) ws_set(fl, F2_PROG + w, q + 1);
-          if (!WS_EXP_NOSTAGE) load_taps(hreg, hsrc, b, x0, y1, h_t0);
-          {
-            float t14 = 0.f, t15 = 0.f;
-#pragma unroll
-            for (int c = 0; c < XC; ++c) {
-              t14 = fmaf(g14[c] * h50_14, a64[c], t14);
-              t15 = fmaf(g15[c] * h49_15, a64[c], t15);
-              t15 = fmaf(g15[c] * h50_15, a65[c], t15);
-            }
-            // the MFMA wave of unit n adds them to pixels 14, 15 when it stores the unit's gV rows (two buffers by unit parity)
-            if (live) {
-              ws_wait(fl, F2_TAIL_FREE + p, n - 1);
-              float* const tbw = tailb + (n & 1) * 128;
-              tbw[lane] = lane < XK ? t14 : 0.f;
-              tbw[64 + lane] = lane < XK ? t15 : 0.f;
-              ws_set(fl, F2_TAIL_FULL + p, n + 1);
-            }
-          }
-          WS_T(3);
-        } else {
-          // (1) v of unit n takes the table (the MFMA wave holds the h band of unit n in registers)
-          float v14 = 0.f, v15 = 0.f;
-          if (live) {
-            ws_wait(fl, F_TAB_FREE + p, seq_v(n) - 1);
-            WS_T(1);
-            __builtin_amdgcn_s_setprio(WS_PRIO_TABLE);
-            if (!WS_EXP_NOSTAGE) write_v_table(vreg);
-            // v of pixels 14, 15 by tap row (lane = fy) for the tail columns: read back from the table's pieces BEFORE the table is
-            // published -- once the MFMA wave has taken its fragments the h-side wave refills the table
-            if (!WS_EXP_NOSTAGE) {
-              const int f5 = fyl & 31;
-              const char* tp = tab + (4 * (fyl >> 5) + ((f5 & 15) >> 2)) * 256 + ((f5 & 3) + 4 * ((f5 >> 4) & 1)) * 2;
-              unsigned short r14[3], r15[3];
-#pragma unroll
-              for (int pc = 0; pc < 3; ++pc) {
-                r14[pc] = *reinterpret_cast<const unsigned short*>(tp + pc * XTABP + 14 * 16);
-                r15[pc] = *reinterpret_cast<const unsigned short*>(tp + pc * XTABP + 15 * 16);
-              }
-              asm volatile("" ::: "memory");
-              ws_set(fl, F_TAB_FULL + p, seq_v(n));
-#pragma unroll
-              for (int pc = 0; pc < 3; ++pc) {
-                v14 += __uint_as_float((unsigned)r14[pc] << 16);
-                v15 += __uint_as_float((unsigned)r15[pc] << 16);
-              }
-            } else {
-              ws_set(fl, F_TAB_FULL + p, seq_v(n));
-            }
-            __builtin_amdgcn_s_setprio(0);
-            WS_T(2);
-          }
-          // (2) the gH tile of unit n - 1 is drained at the END of this iteration (WS2_DRAIN_LATE): with two MFMA waves per SIMD gH(n - 1) is
-          // still being computed when this iteration starts, and a wave parked here builds no table and issues no tap load
-          if (!WS2_DRAIN_LATE) {
-          // (2) the gH tile of unit n - 1 -> HBM
-            if (n > 0) ws_wait(fl, F_OUT_FULL + p, n);
-            WS_T(6);
-#pragma unroll
-            for (int qq = 0; qq < (WS_EXP_NOSTAGE ? 0 : 4); ++qq) {
-              const int fx = fq + 16 * qq;
-              f32x4 v4 = *reinterpret_cast<const f32x4*>(tile + (fx + 15) * WPV + 4 * pq);
-              // window columns 64, 65 (pixel 14 tap 50; pixel 15 taps 49, 50) are the VALU tail sums
-              if (pq == 3 && fx == 50) { v4[2] = s6414; v4[3] = s6515; }
-              if (pq == 3 && fx == 49) v4[3] = s6415;
-              x6_bstore4(v4, ghdst, (qq < 3 || fq < 3) ? qoff_prev : X_OOR, (unsigned)(16 * qq) * plane_b);
-            }
-            if (n > 0) ws_set(fl, F_OUT_FREE + p, n);
-            WS_T(7);
-          }
-          // (3) tail columns of gH (q = 64, 65: taps 50 / 49, 50 of pixels 14, 15): lane = tap row fy
-          if (live && u == 0 && q >= 2) ws_wait(fl, F_SLIDE, 8 * (2 * q - 3));
-          float a64[XC], a65[XC];
-#pragma unroll
-          for (int c = 0; c < XC; ++c) {
-            const f32x2 sv = *reinterpret_cast<const f32x2*>(side + (c * XWIN + tslot) * 4 + 2 * wc);
-            a64[c] = sv.x; a65[c] = sv.y;
-          }
-          asm volatile("" ::: "memory");
-          if (live && u == 1) ws_set(fl, F2_PROG + w, q + 1);
-          if (!WS_EXP_NOSTAGE) {
-            const float lv = lane < XK ? 1.f : 0.f;
-            v14 *= lv; v15 *= lv;
-            float sa = 0.f, sb = 0.f, sc = 0.f;
-#pragma unroll
-            for (int c = 0; c < XC; ++c) {
-              sa = fmaf(g14[c] * v14, a64[c], sa);
-              sb = fmaf(g15[c] * v15, a64[c], sb);
-              sc = fmaf(g15[c] * v15, a65[c], sc);
-            }
-            n6414 = ws_wave_sum(sa);
-            n6415 = ws_wave_sum(sb);
-            n6515 = ws_wave_sum(sc);
-          }
-          if (!WS2_DRAIN_LATE) { s6414 = n6414; s6415 = n6415; s6515 = n6515; }
-          asm volatile("" ::: "memory");
-          if (!WS_EXP_NOSTAGE) load_taps(vreg, vsrc, b, x0, y1, v_t0);
-          WS_T(3);
-        }
-        if (!WS_EXP_NOSTAGE) {
-          const unsigned go = pix_off(b, x0, y1, XC);
-#pragma unroll
-          for (int c = 0; c < XC; ++c) gp[c] = x6_bload(gsrc, go, (unsigned)c * plane_b);
-        }
-        // (4) the new window row (slot of row 4 q - 4 + 2 u + {0 | 1}: behind every wave once phase q - 1 is done)
-        if (live && rn >= 0 && (hside || !WS2_ROWS_H)) {
-          if ((rn >> 1) >= 1) ws2_wait_all_prog(fl, rn >> 1);
-          WS_T(4);
-#pragma unroll
-          for (int rw = 0; rw < (WS2_ROWS_H ? 2 : 1); ++rw) {
-            const int slot = (grow + rw) & (XWIN - 1);
-            const float ga = rw == 0 ? gr0 : gr2, gb = rw == 0 ? gr1 : gr3;
-            unsigned h1, h2, h3;
-            x6_split2(ga, gb, h1, h2, h3);
-            if (gcol < 8 * XNBLK && !WS_EXP_NOSTAGE) {
-              char* d0 = smem + gcell + slot * 16 + gc0 * XPLANE;
-              x6_st16(d0, h1); x6_st16(d0 + 3 * XPLANE, h2); x6_st16(d0 + 6 * XPLANE, h3);
-              if (ggrp == 0) { x6_st16(d0 + XPLANE, h1 >> 16); x6_st16(d0 + 4 * XPLANE, h2 >> 16); x6_st16(d0 + 7 * XPLANE, h3 >> 16); }
-            }
-            if (gsidx >= 0) {
-              side[(gc0 * XWIN + slot) * 4 + gsidx] = ga;
-              side[(gc1 * XWIN + slot) * 4 + gsidx] = gb;
-            }
-            asm volatile("" ::: "memory");
-            if (lane == 0) __hip_atomic_fetch_add(fl + F_SLIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            asm volatile("" ::: "memory");
-          }
-          WS_T(5);
-        }
-        if (!hside && WS2_DRAIN_LATE) {
-          // (2) the gH tile of unit n - 1 -> HBM
-          if (n > 0) ws_wait(fl, F_OUT_FULL + p, n);
-          WS_T(6);
-#pragma unroll
-          for (int qq = 0; qq < (WS_EXP_NOSTAGE ? 0 : 4); ++qq) {
-            const int fx = fq + 16 * qq;
-            f32x4 v4 = *reinterpret_cast<const f32x4*>(tile + (fx + 15) * WPV + 4 * pq);
-            // window columns 64, 65 (pixel 14 tap 50; pixel 15 taps 49, 50) are the VALU tail sums
-            if (pq == 3 && fx == 50) { v4[2] = s6414; v4[3] = s6515; }
-            if (pq == 3 && fx == 49) v4[3] = s6415;
-            x6_bstore4(v4, ghdst, (qq < 3 || fq < 3) ? qoff_prev : X_OOR, (unsigned)(16 * qq) * plane_b);
-          }
-          if (n > 0) ws_set(fl, F_OUT_FREE + p, n);
-          WS_T(7);
-          s6414 = n6414; s6415 = n6415; s6515 = n6515;
-        }
-        qoff_prev = qoff;
-      }
-      if (WS_TRACE && blockIdx.x == 0 && lane == 0)
-        for (int k = 0; k < 16; ++k) ws_trace[w][k] += tr_[k];
-    }
-    g = run_end;
-  }
-  };
-  if (!staging) run_all(std::false_type{});
-  else run_all(std::true_type{});
-  if (WS_TRACE && blockIdx.x == 0 && (threadIdx.x & 63) == 0) ws_trace[threadIdx.x >> 6][15] += __builtin_readcyclecounter() - t_kernel0;
-}
-
 
 // ------------------------------------------------------------------------------------------------------------------------------------
 // Forward on the same machinery:  out[b,c,y,x] = sum_fy v[b,fy,y,x] * T_c[fy],   T_c[fy][j] = sum_i In_c[y + fy][16 wc + i] * Hb[i][j].
@@ -1539,7 +1001,7 @@ template <bool U8>
 __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ in, const float* __restrict__ v,
                                                       const float* __restrict__ h, float* __restrict__ out,
                                                       int B, int Ho, int Wo, int nph, int ncol, int per_wg, int TB,
-                                                      const unsigned* __restrict__ cls, int aligned, int unit16) {
+                                                      const unsigned* __restrict__ cls, int aligned, int unit16, int spin_limit, unsigned* errw) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int p = w & 3, wc = p & 1, wr0 = p >> 1;
@@ -1555,7 +1017,7 @@ __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ 
   // A workgroup's phases: position g of a linear order in which strip = g / span and phase = base + g % span.
   //   aligned == 0 (default): strip-major order of all phases cut into pieces of per_wg (span = nph): workgroups that run side by side
   //                 work on unrelated rows.
-  //   aligned != 0 (experiment, slower: see ws_aligned_env): every strip's phases [c per_wg, (c + 1) per_wg) go to workgroup c S + strip
+  //   aligned != 0 (experiment, slower: -DWS_ALIGNED=1): every strip's phases [c per_wg, (c + 1) per_wg) go to workgroup c S + strip
   //                 (S strips), the workgroups of one chunk walk down the same rows of neighbouring strips at the same time; what is left of
   //                 each strip (nph % per_wg phases) is cut in the old way.
   int g0, g1, span, base;
@@ -1629,7 +1091,10 @@ __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ 
     const int R0 = XPR * ph0;
     auto unit_y = [&](int n) { return R0 + XPR * (n >> 1) + wr0 + 2 * (n & 1); };
     __syncthreads();
-    if (tid < 64) fl[tid] = 0u;
+    if (tid < 64) {
+      const unsigned long long q = reinterpret_cast<unsigned long long>(errw);
+      fl[tid] = tid == F_LIMIT ? (unsigned)spin_limit : tid == F_ERRW ? (unsigned)q : tid == F_ERRW + 1 ? (unsigned)(q >> 32) : 0u;
+    }
     if (tid < XNT) {
 #pragma unroll 1
       for (int r = 0; r < XWIN; r += 16) {
@@ -1906,13 +1371,20 @@ __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ 
 // gV and gH of the K = 51, C = 3 op, widths that are a multiple of 4; every tensor below 2^31 bytes (the caller checks).
 // TB: tap planes between two samples of v / h / gV / gH (51 for contiguous [B,51,Ho,Wo] tensors; larger when the tensors are slices of one
 // interleaved [B * S, 51, Ho, Wo] buffer: sepconv/model.py runs its four sub-networks as one task-batched launch per layer)
-// SAVFI_SEPCONV_WS_ALIGNED=1 (experiment): chunks of phases aligned across strips (ws_work_range) instead of the strip-major cut.
+// -DWS_ALIGNED=1 (experiment build): chunks of phases aligned across strips (ws_work_range) instead of the strip-major cut.
 // Measured SLOWER (B = 8, 256 x 448, one box: backward 233 -> 245 us, forward 133 -> 148 us isolated; 197 -> 207 / 126 -> 137 in the bench loop):
 // workgroups that walk the same rows together concentrate the chip's requests on few DRAM channels -- the planes of a 256 x 448 tap tensor
 // are a multiple of 64 KB apart -- and spread over the channels is worth more here than open-page hits.
-static int ws_aligned_env() {
-  const char* e = getenv("SAVFI_SEPCONV_WS_ALIGNED");
-  return e ? atoi(e) : 0;
+#ifndef WS_ALIGNED
+#define WS_ALIGNED 0
+#endif
+static int ws_spin_limit_host = 1 << 19;      // savfi_sepconv_ws_debug_spin_limit; handed to every launch
+namespace {
+constexpr int WS_MAX_DEV = 64;
+unsigned* ws_watch_word[WS_MAX_DEV] = {nullptr};     // host addresses of the mapped words (savfi_sepconv_ws_watch), per device
+unsigned* ws_watch_dev[WS_MAX_DEV] = {nullptr};      // their device addresses
+int ws_watch_last_dev = -1;                          // (one process drives one GPU: the device of the last savfi_sepconv_ws_watch call)
+unsigned* ws_watch_device_word() { return ws_watch_last_dev >= 0 ? ws_watch_dev[ws_watch_last_dev] : nullptr; }
 }
 static int ws_grid(int aligned, int S, int nph, int per_wg) {
   if (!aligned) return savfi_cdiv((int64_t)S * nph, per_wg);
@@ -1927,23 +1399,22 @@ int savfi_sepconv_bwd_ws_launch(const float* in, const float* v, const float* h,
   const int nph = savfi_cdiv(Ho, XPR), ncol = savfi_cdiv(Wo, XMC);
   const int64_t total = (int64_t)B * ncol * nph;
   const int per_wg = savfi_cdiv(total, cus);
-  static const int aligned = ws_aligned_env();
+  constexpr int aligned = WS_ALIGNED;
   const int grid = ws_grid(aligned, B * ncol, nph, per_wg);
   if (taps_unit16 && (Wo & 15) != 0) return SAVFI_E_UNSUPPORTED;
-  static const bool two = getenv("SAVFI_SEPCONV_WS2") != nullptr;
-  if (two && !cls && !taps_unit16) {
-    static uint32_t done2 = 0;
-    if (int e = savfi_ensure_dynamic_lds((const void*)sepconv_bwd_ws2, W2LDS, done2)) return e;
-    hipLaunchKernelGGL(sepconv_bwd_ws2, dim3((unsigned)savfi_cdiv(total, per_wg)), dim3(W2NT), W2LDS, st, in, v, h, gO, gV, gH, B, Ho, Wo, nph, ncol, per_wg, TB);
-    return savfi_launch_status();
-  }
   static uint32_t done = 0, done8 = 0;
   if (cls) {
-    if (int e = savfi_ensure_dynamic_lds((const void*)sepconv_bwd_ws<true>, WLDS, done8)) return e;
-    hipLaunchKernelGGL(sepconv_bwd_ws<true>, dim3(grid), dim3(WNT), WLDS, st, in, v, h, gO, gV, gH, B, Ho, Wo, nph, ncol, per_wg, TB, cls, aligned, taps_unit16);
+    if (taps_unit16 & 1) {
+      static uint32_t done8d = 0;
+      if (int e = savfi_ensure_dynamic_lds((const void*)sepconv_bwd_ws<true, true>, WLDS, done8d)) return e;
+      hipLaunchKernelGGL((sepconv_bwd_ws<true, true>), dim3(grid), dim3(WNT), WLDS, st, in, v, h, gO, gV, gH, B, Ho, Wo, nph, ncol, per_wg, TB, cls, aligned, taps_unit16, ws_spin_limit_host, ws_watch_device_word());
+    } else {
+      if (int e = savfi_ensure_dynamic_lds((const void*)sepconv_bwd_ws<true, false>, WLDS, done8)) return e;
+      hipLaunchKernelGGL((sepconv_bwd_ws<true, false>), dim3(grid), dim3(WNT), WLDS, st, in, v, h, gO, gV, gH, B, Ho, Wo, nph, ncol, per_wg, TB, cls, aligned, taps_unit16, ws_spin_limit_host, ws_watch_device_word());
+    }
   }
-  if (int e = savfi_ensure_dynamic_lds((const void*)sepconv_bwd_ws<false>, WLDS, done)) return e;
-  hipLaunchKernelGGL(sepconv_bwd_ws<false>, dim3(grid), dim3(WNT), WLDS, st, in, v, h, gO, gV, gH, B, Ho, Wo, nph, ncol, per_wg, TB, cls, aligned, taps_unit16);
+  if (int e = savfi_ensure_dynamic_lds((const void*)sepconv_bwd_ws<false, false>, WLDS, done)) return e;
+  hipLaunchKernelGGL((sepconv_bwd_ws<false, false>), dim3(grid), dim3(WNT), WLDS, st, in, v, h, gO, gV, gH, B, Ho, Wo, nph, ncol, per_wg, TB, cls, aligned, taps_unit16, ws_spin_limit_host, ws_watch_device_word());
   return savfi_launch_status();
 }
 
@@ -1953,16 +1424,16 @@ int savfi_sepconv_fwd_ws_launch(const float* in, const float* v, const float* h,
   const int nph = savfi_cdiv(Ho, XPR), ncol = savfi_cdiv(Wo, XMC);
   const int64_t total = (int64_t)B * ncol * nph;
   const int per_wg = savfi_cdiv(total, cus);
-  static const int aligned = ws_aligned_env();
+  constexpr int aligned = WS_ALIGNED;
   const int grid = ws_grid(aligned, B * ncol, nph, per_wg);
   if (taps_unit16 && (Wo & 15) != 0) return SAVFI_E_UNSUPPORTED;
   static uint32_t done = 0, done8 = 0;
   if (cls) {
     if (int e = savfi_ensure_dynamic_lds((const void*)sepconv_fwd_ws<true>, FLDS, done8)) return e;
-    hipLaunchKernelGGL(sepconv_fwd_ws<true>, dim3(grid), dim3(WNT), FLDS, st, in, v, h, out, B, Ho, Wo, nph, ncol, per_wg, TB, cls, aligned, taps_unit16);
+    hipLaunchKernelGGL(sepconv_fwd_ws<true>, dim3(grid), dim3(WNT), FLDS, st, in, v, h, out, B, Ho, Wo, nph, ncol, per_wg, TB, cls, aligned, taps_unit16, ws_spin_limit_host, ws_watch_device_word());
   }
   if (int e = savfi_ensure_dynamic_lds((const void*)sepconv_fwd_ws<false>, FLDS, done)) return e;
-  hipLaunchKernelGGL(sepconv_fwd_ws<false>, dim3(grid), dim3(WNT), FLDS, st, in, v, h, out, B, Ho, Wo, nph, ncol, per_wg, TB, cls, aligned, taps_unit16);
+  hipLaunchKernelGGL(sepconv_fwd_ws<false>, dim3(grid), dim3(WNT), FLDS, st, in, v, h, out, B, Ho, Wo, nph, ncol, per_wg, TB, cls, aligned, taps_unit16, ws_spin_limit_host, ws_watch_device_word());
   return savfi_launch_status();
 }
 
@@ -1975,17 +1446,51 @@ extern "C" int savfi_frames8_classify_f32(const float* x, int64_t n, unsigned* c
   return savfi_launch_status();
 }
 
+#if WS_TRACE
 extern "C" int savfi_sepconv_ws_trace(unsigned long long* out /* [16][16] host */, int reset) {
   if (hipDeviceSynchronize() != hipSuccess) return -1;
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ws_trace), sizeof(unsigned long long) * 256) != hipSuccess) return -1;
   if (reset) { unsigned long long z[256] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(ws_trace), z, sizeof(z)) != hipSuccess) return -1; }
   return 0;
 }
+#endif
 
-// protocol time-outs since the library was loaded (0 unless a wait of the kernel above gave up: a bug)
+// protocol time-outs since the library was loaded (0 unless a wait of the kernels above gave up: a bug, or a GPU shared with another
+// process for longer than the spin limit)
 extern "C" int savfi_sepconv_ws_errors(void) {
   unsigned n = 0;
   if (hipDeviceSynchronize() != hipSuccess) return -1;
   if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(ws_error_count), sizeof(n)) != hipSuccess) return -1;
   return (int)(n & 0x7fffffffu);
+}
+
+// The same count without a device synchronisation: savfi_sepconv_ws_watch() (once per device, outside a stream capture) maps one host
+// word into the device; a wait that gives up adds to it with a system-scope atomic, which the host sees at the latest when the launch
+// has completed.  savfi_sepconv_ws_errors_peek() only reads that word: the product calls it wherever it has synchronised anyway (after
+// reading the loss) and raises.
+extern "C" int savfi_sepconv_ws_watch(void) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= WS_MAX_DEV) return -1;
+  ws_watch_last_dev = dev;
+  if (ws_watch_word[dev]) return SAVFI_OK;
+  unsigned* hp = nullptr;
+  if (hipHostMalloc((void**)&hp, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return -1;
+  *hp = 0u;
+  unsigned* dp = nullptr;
+  if (hipHostGetDevicePointer((void**)&dp, hp, 0) != hipSuccess) return -1;
+  ws_watch_word[dev] = hp;
+  ws_watch_dev[dev] = dp;
+  return SAVFI_OK;
+}
+extern "C" int savfi_sepconv_ws_errors_peek(void) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= WS_MAX_DEV || !ws_watch_word[dev]) return -1;
+  return (int)(__atomic_load_n(ws_watch_word[dev], __ATOMIC_ACQUIRE) & 0x7fffffffu);
+}
+// Test hook: the spin limit of the kernels' bounded waits (default 1 << 19 spins of s_sleep 2; a NEGATIVE limit makes every wait that does
+// not find its flag at once give up -- how tests/ provoke the error path).  The previous limit goes to *previous (may be NULL).
+extern "C" int savfi_sepconv_ws_debug_spin_limit(int limit, int* previous) {
+  if (previous) *previous = ws_spin_limit_host;
+  ws_spin_limit_host = limit;
+  return SAVFI_OK;
 }

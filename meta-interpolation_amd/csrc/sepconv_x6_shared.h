@@ -52,6 +52,12 @@ __device__ __forceinline__ void x6_bstore4(f32x4 val, __amdgpu_buffer_rsrc_t r, 
   voff = 0x80000000u;
 #endif
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), r, (int)voff, (int)soff, X6_STORE_AUX);
+  // A 128-bit buffer store reads its data registers over several cycles; a VALU write of one of them in the very next issue slot
+  // reaches the register first (gfx950, measured: element 0 of the rows 32 + fq of gV wrong in the last lanes of every 16, run-to-run
+  // different -- the store was followed at once by the v_add that reuses its first data register).  hipcc (ROCm 7.2) inserts the wait
+  // state only for the form WITHOUT an SGPR soffset (GCNHazardRecognizer: "the hazard only exists if soffset is not a register"); ours
+  // carries one.  The data stays live through two wait states after the store.
+  asm volatile("s_nop 1" ::"v"(val));
 }
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t x6_rsrc(const float* base, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)bytes, 0x00020000);

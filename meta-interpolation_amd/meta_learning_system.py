@@ -28,7 +28,7 @@ import torch
 import torch.nn as nn
 import torch.optim as optim
 
-from . import graph_inner_loop, hip_ops, model_utils, utils
+from . import _hip, graph_inner_loop, hip_ops, model_utils, utils
 from .inner_loop_optimizers import LSLRGradientDescentLearningRule, MetaSGDLearningRule
 from .loss import Loss
 from .task_parallel import TaskParallel
@@ -219,6 +219,9 @@ class SceneAdaptiveInterpolation(nn.Module):
 
         self.criterion = criterion if criterion is not None else Loss(args)
         self.task_parallel = task_parallel if task_parallel is not None else TaskParallel()
+        if self.device.type == 'cuda':
+            with torch.cuda.device(self.device):
+                _hip.ws_watch()
         self._first_order = False
         self._defer_logging = False
         self._pending_logging = None
@@ -730,6 +733,9 @@ class SceneAdaptiveInterpolation(nn.Module):
         weights = importance.detach().cpu().numpy()
         for idx in range(len(weights)):
             losses['loss_importance_vector_{}'.format(idx)] = np.asarray(weights[idx])
+        # the device has finished everything these numbers depend on: a bounded wait of the wave-specialised SepConv kernels that
+        # gave up (csrc/sepconv_ws.hip) left its count in a mapped host word -- wrong numbers must not be logged as a loss
+        _hip.ws_check("meta-iteration at epoch %d" % self.current_epoch)
 
     def _forward_graphed(self, frames, epoch, use_multi_step_loss_optimization, num_steps, training_phase,
                          do_evaluation):
@@ -893,6 +899,7 @@ class SceneAdaptiveInterpolation(nn.Module):
             hip_ops.refresh_module_filters(self._filter_modules)
 
     def run_train_iter(self, data_batch, epoch, do_evaluation=False):
+        _hip.ws_check("an earlier iteration")       # one host word: what a caller that never reads its losses would otherwise miss
         epoch = int(epoch)
         self.current_epoch = epoch
         if not self.training:
@@ -922,12 +929,14 @@ class SceneAdaptiveInterpolation(nn.Module):
         return losses, preds, metrics
 
     def run_validation_iter(self, data_batch):
+        _hip.ws_check("an earlier iteration")
         data_batch = [frame.to(device=self.device, non_blocking=True) for frame in data_batch]
         return self.evaluation_forward_prop(data_batch=data_batch, epoch=self.current_epoch)
 
     def run_test_iter(self, data_batch):
         """Adapt on a 4-frame clip ((0,2)->1, (1,3)->2), then interpolate between frames 1 and 2
         (reference :630-697).  Returns a list of [3,H,W] predictions."""
+        _hip.ws_check("an earlier iteration")
         if self.training:
             self.eval()
         frames = [frame.to(device=self.device, non_blocking=True) for frame in data_batch]

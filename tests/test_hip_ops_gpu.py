@@ -159,19 +159,6 @@ def test_sepconv_taps_strided_entry_points_equal_the_contiguous_ones(shape):
     assert lib.savfi_sepconv_fwd_taps_strided_f32(*args(Wo, 25, 100)) == -3
 
 
-def test_sepconv_two_mfma_waves_per_simd_variant_matches():
-    """SAVFI_SEPCONV_WS2=1 (csrc/sepconv_ws.hip sepconv_bwd_ws2: two MFMA waves per SIMD, an opt-in experiment) gives the shipped kernel's
-    filter gradients -- tools/ws_check.py in a child process (the switch is read once per process), against the one-program-per-wave kernels."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, SAVFI_SEPCONV_WS2='1')
-    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'ws_check.py'), '--shapes', '1x64x96,2x100x128,1x8x32', '--time-batch', '0'],
-                         env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0 and out.stdout.strip().splitlines()[-1] == 'OK', out.stdout[-2000:] + out.stderr[-2000:]
-
-
 def test_sepconv_argument_errors():
     lib = _hip.lib()
     x = torch.zeros(16, device=DEV)

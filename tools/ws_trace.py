@@ -5,6 +5,7 @@ import torch
 from meta_interpolation_amd import _hip
 B, C, Ho, Wo, K = int(sys.argv[1]) if len(sys.argv) > 1 else 8, 3, 256, 448, 51
 lib, st = _hip.lib(), _hip.current_stream()
+U16 = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 F8 = len(sys.argv) > 2 and sys.argv[2] == "f8"       # frames of 8-bit images through savfi_sepconv_bwd_frames8_f32 (the three-product kernel)
 inp = torch.randint(0, 256, (B, C, Ho + K - 1, Wo + K - 1), device="cuda").float().div(255) if F8 else torch.rand(B, C, Ho + K - 1, Wo + K - 1, device="cuda")
 v = torch.randn(B, K, Ho, Wo, device="cuda") / 7
@@ -14,7 +15,7 @@ gV, gH = torch.empty_like(v), torch.empty_like(h)
 if F8:
     from meta_interpolation_amd.sepconv.sepconv_op import sepconv as S
     words = S.frames8_classify(inp)
-    f = lambda: _hip.check(lib.savfi_sepconv_bwd_frames8_f32(inp.data_ptr(), v.data_ptr(), h.data_ptr(), gO.data_ptr(), gV.data_ptr(), gH.data_ptr(), words.data_ptr(), B, C, Ho, Wo, K, K, 0, st), "bwd8")
+    f = lambda: _hip.check(lib.savfi_sepconv_bwd_frames8_f32(inp.data_ptr(), v.data_ptr(), h.data_ptr(), gO.data_ptr(), gV.data_ptr(), gH.data_ptr(), words.data_ptr(), B, C, Ho, Wo, K, K, U16, st), "bwd8")
 else:
     f = lambda: _hip.check(lib.savfi_sepconv_bwd_f32(inp.data_ptr(), v.data_ptr(), h.data_ptr(), gO.data_ptr(), None, gV.data_ptr(), gH.data_ptr(), B, C, Ho, Wo, K, st), "bwd")
 buf = (ctypes.c_ulonglong * 256)()
@@ -33,7 +34,7 @@ units = 2 * ((B * 14 * 64 + 255) // 256)
 print("per unit (2 passes) cycles, workgroup 0, %d units per pair, lib %s" % (units, os.environ.get("SAVFI_HIP_LIB")))
 MF = ["top", "-", "-", "gV MFMA loop", "wait tab(v) + v fragments + first gH A fragments", "gV scale + wait out_free", "tile write+set", "-", "-", "gH MFMA loop", "next rows + first gV A fragments", "gH scale + wait out_free", "tile write+set", "wait tab(h next)", "h fragments + slide wait"]
 SG_OLD = ["top: granule loads, readlanes", "wait tab_free", "h table write", "B: side, tails-a, h loads", "wait out_full(gH)", "drain gH", "gV tail sums", "wait tab_free", "v table write", "E: gH tails, v loads", "wait out_full(gV)", "drain gV", "wait prog", "granule write"]
-SG = ["top: row load, readlanes", "wait tab_free", "table write+set", "tails (side, sums), tap loads", "wait prog", "window row write", "wait out_full(prev)", "drain+stores(prev)", "v: slide wait + side reads", "v: tail sums"]
+SG = ["top: (slot reads), row load, readlanes", "wait tab_free", "table write+set", "tails (side, sums), tap loads", "wait prog", "window row write", "wait out_full(prev)", "drain+stores(prev)", "v: slide wait + side reads", "v: tail sums", "DMA: fetch issue (7 instr)", "DMA: vmcnt wait"]
 two = os.environ.get('SAVFI_SEPCONV_WS2') is not None
 MF2 = ['top', '-', '-', 'gV half 1 loop (72 MFMAs)', 'tail wait + epilogue 1 (2 stores)', 'gV half 2 loop (48)', 'v frags + epilogue 2 (2 stores)', '-', '-', 'gH half 1 loop (72)', 'gH half 2 loop (72)', 'epilogue h1 (wait out_free, 8 writes)', 'next h frags, rows, epilogue h2, set', '-', '-']
 for w in range(16 if two else 12):
