@@ -84,6 +84,20 @@ enum { F_TAB_FULL = 0, F_TAB_FREE = 4, F_OUT_FULL = 8, F_OUT_FREE = 12, F_PROG =
 #ifndef WS_EXP_NOAREAD          // the MFMA loops reuse the first unit's A fragments (no LDS reads inside the loops)
 #define WS_EXP_NOAREAD 0
 #endif
+#ifndef WS_DMA_TAP_POLICY_ID    // cache policy of the tap fetches (DMA kernels): 0 default, 1 nt (non-temporal), 2 sc1, 3 sc1 nt, 4 sc0 sc1
+#define WS_DMA_TAP_POLICY_ID 0
+#endif
+#if WS_DMA_TAP_POLICY_ID == 1
+#define WS_DMA_TAP_POLICY " nt"
+#elif WS_DMA_TAP_POLICY_ID == 2
+#define WS_DMA_TAP_POLICY " sc1"
+#elif WS_DMA_TAP_POLICY_ID == 3
+#define WS_DMA_TAP_POLICY " sc1 nt"
+#elif WS_DMA_TAP_POLICY_ID == 4
+#define WS_DMA_TAP_POLICY " sc0 sc1"
+#else
+#define WS_DMA_TAP_POLICY ""
+#endif
 #ifndef WS_EXP_UNITMAJOR        // see load_taps of sepconv_bwd_ws
 #define WS_EXP_UNITMAJOR 0
 #endif
@@ -99,9 +113,12 @@ typedef __attribute__((address_space(1))) unsigned ws_global_u32;
 #endif
 #if WS_TRACE
 __device__ unsigned long long ws_trace[16][16];
-#define WS_TRACE_ADD(wave, k, x) (ws_trace[wave][k] += (x))
+__device__ unsigned long long ws_trace_wg[1024][2];           // per workgroup: cycles of wave 0 from entry to exit, runs
+#define WS_TRACE_ADD(wave_, slot_, val_) (ws_trace[wave_][slot_] += (val_))
+#define WS_TRACE_WG(slot_, val_) do { if (blockIdx.x < 1024 && threadIdx.x == 0) ws_trace_wg[blockIdx.x][slot_] += (val_); } while (0)
 #else
-#define WS_TRACE_ADD(wave, k, x) ((void)0)
+#define WS_TRACE_ADD(wave_, slot_, val_) ((void)0)
+#define WS_TRACE_WG(slot_, val_) ((void)0)
 #endif
 #define WS_T(k) do { if (WS_TRACE) { const unsigned long long t_ = __builtin_readcyclecounter(); tr_[k] += t_ - tlast_; tlast_ = t_; } } while (0)
 
@@ -197,18 +214,25 @@ __device__ __forceinline__ int ws_lane() {
 // decided ON THE DEVICE, per call: savfi_frames8_classify_f32 leaves one word per classifier workgroup (non-zero = it met an element that is
 // not the fp32 quotient k / 255 to within 2 ulp), the <U8 = true> and <U8 = false> instances of a kernel are both launched and the one the
 // words do not select returns at once -- no host round trip (graph-capture safe), any other input takes the six-product path unchanged.
-// which phases a workgroup takes (see the kernels)
-__device__ __forceinline__ void ws_work_range(int aligned, int S, int nph, int per_wg, int& g0, int& g1, int& span, int& base) {
-  const int nfull = aligned ? nph / per_wg : 0, nA = S * nfull, bx = (int)blockIdx.x;
-  if (bx < nA) {
-    const int c = bx / S, st = bx - c * S;
-    span = nph; base = 0; g0 = st * nph + c * per_wg; g1 = g0 + per_wg;
-  } else if (aligned) {
-    span = max(nph - nfull * per_wg, 1); base = nfull * per_wg;
-    g0 = (bx - nA) * per_wg; g1 = min(g0 + per_wg, S * (nph - nfull * per_wg));
-  } else {
-    span = nph; base = 0; g0 = bx * per_wg; g1 = min(g0 + per_wg, S * nph);
-  }
+// Which phases a workgroup takes.  The phases of all strips in strip-major order (position g: strip g / nph, phase g % nph) are cut into
+// gridDim.x consecutive pieces; a piece that crosses into the next strip starts a second RUN there (a new window: 64 rows through two
+// round trips, the first units' fetches, the pipeline's ramp -- 20 000 cycles = 1.5 phases measured, profiles/r05_ws_workgroup_times.txt:
+// workgroups with two runs 422 000 cycles, with one 402 000, and the launch waits for the slowest).  So the cut is made on a COST axis of
+// half phases on which every strip is WS_RUN_COST slots longer than its phases: a piece with a strip start inside gets that many half
+// phases fewer.  (An "aligned" order -- the workgroups of a chunk walking the same rows of neighbouring strips together -- was measured
+// slower three times, planar and unit-major taps alike: spread over the DRAM channels beats locality here; tools/r5/membench.hip.)
+#ifndef WS_RUN_COST
+#define WS_RUN_COST 3
+#endif
+__device__ __forceinline__ int ws_cost_to_phase(long long t, int nph) {
+  const int C = 2 * nph + WS_RUN_COST;
+  const int strip = (int)(t / C), r = (int)(t - (long long)strip * C);
+  return strip * nph + min(max((r - WS_RUN_COST + 1) >> 1, 0), nph);
+}
+__device__ __forceinline__ void ws_work_range(int S, int nph, int& g0, int& g1) {
+  const long long T = (long long)S * (2 * nph + WS_RUN_COST), G = gridDim.x, bx = blockIdx.x;
+  g0 = ws_cost_to_phase(bx * T / G, nph);
+  g1 = ws_cost_to_phase((bx + 1) * T / G, nph);
 }
 constexpr int CLS_WG = 256, CLS_NT = 1024;         // classifier grid: one 16-byte load of the words per lane of the consumer
 template <bool U8>
@@ -243,8 +267,8 @@ template <bool U8, bool DMA = false>
 __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ in, const float* __restrict__ v,
                                                       const float* __restrict__ h, const float* __restrict__ gO,
                                                       float* __restrict__ gV, float* __restrict__ gH,
-                                                      int B, int Ho, int Wo, int nph, int ncol, int per_wg, int TB,
-                                                      const unsigned* __restrict__ cls, int aligned, int unit16, int spin_limit, unsigned* errw) {
+                                                      int B, int Ho, int Wo, int nph, int ncol, int TB,
+                                                      const unsigned* __restrict__ cls, int unit16, int spin_limit, unsigned* errw) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int p = w & 3, wc = p & 1, wr0 = p >> 1;
@@ -260,14 +284,11 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
   unsigned* const fl = reinterpret_cast<unsigned*>(smem + WFLAG_OFF);
 
   [[maybe_unused]] const unsigned long long t_kernel0 = WS_TRACE ? __builtin_readcyclecounter() : 0ull;
-  // A workgroup's phases: position g of a linear order in which strip = g / span and phase = base + g % span.
-  //   aligned == 0 (default): strip-major order of all phases cut into pieces of per_wg (span = nph): workgroups that run side by side
-  //                 work on unrelated rows.
-  //   aligned != 0 (experiment, slower: -DWS_ALIGNED=1): every strip's phases [c per_wg, (c + 1) per_wg) go to workgroup c S + strip
-  //                 (S strips), the workgroups of one chunk walk down the same rows of neighbouring strips at the same time; what is left of
-  //                 each strip (nph % per_wg phases) is cut in the old way.
-  int g0, g1, span, base;
-  ws_work_range(aligned, B * ncol, nph, per_wg, g0, g1, span, base);
+  // a workgroup's phases: positions [g0, g1) of the strip-major order (ws_work_range)
+  int g0, g1;
+  constexpr int base = 0;
+  const int span = nph;
+  ws_work_range(B * ncol, nph, g0, g1);
   if (g0 >= g1) return;
   if (!ws_frames8_mine<U8>(cls)) return;
   const int Hi = Ho + XK - 1, Wi = Wo + XK - 1;
@@ -343,11 +364,11 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
     asm volatile("s_mov_b32 %0, m0\n\t"
                  "s_mov_b32 m0, %2\n\t"
                  "s_mov_b64 %1, exec\n\t"
-                 "buffer_load_dwordx4 %6, %10, 0 offen lds\n\t"
-                 "buffer_load_dwordx4 %6, %10, 0 offen offset:1024 lds\n\t"
-                 "buffer_load_dwordx4 %6, %10, 0 offen offset:2048 lds\n\t"
+                 "buffer_load_dwordx4 %6, %10, 0 offen" WS_DMA_TAP_POLICY " lds\n\t"
+                 "buffer_load_dwordx4 %6, %10, 0 offen offset:1024" WS_DMA_TAP_POLICY " lds\n\t"
+                 "buffer_load_dwordx4 %6, %10, 0 offen offset:2048" WS_DMA_TAP_POLICY " lds\n\t"
                  "s_mov_b64 exec, 0xfff\n\t"
-                 "buffer_load_dwordx4 %6, %10, 0 offen offset:3072 lds\n\t"
+                 "buffer_load_dwordx4 %6, %10, 0 offen offset:3072" WS_DMA_TAP_POLICY " lds\n\t"
                  "s_mov_b64 exec, %1\n\t"
                  "s_mov_b32 m0, %3\n\t"
                  "s_nop 0\n\t"
@@ -967,11 +988,13 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
         for (int k = 0; k < 16; ++k) WS_TRACE_ADD(w, k, tr_[k]);
     }
     g = run_end;
+    if (WS_TRACE) WS_TRACE_WG(1, 1);
   }
   };
   if (!staging) run_all(std::false_type{});
   else run_all(std::true_type{});
   if (WS_TRACE && blockIdx.x == 0 && (threadIdx.x & 63) == 0) WS_TRACE_ADD(threadIdx.x >> 6, 15, __builtin_readcyclecounter() - t_kernel0);
+  if (WS_TRACE) WS_TRACE_WG(0, __builtin_readcyclecounter() - t_kernel0);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------
@@ -1000,8 +1023,8 @@ enum { F_VT_FULL = 8, F_VT_FREE = 12, F_OP_FULL = 32, F_OP_FREE = 36, F_TL_FULL 
 template <bool U8>
 __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ in, const float* __restrict__ v,
                                                       const float* __restrict__ h, float* __restrict__ out,
-                                                      int B, int Ho, int Wo, int nph, int ncol, int per_wg, int TB,
-                                                      const unsigned* __restrict__ cls, int aligned, int unit16, int spin_limit, unsigned* errw) {
+                                                      int B, int Ho, int Wo, int nph, int ncol, int TB,
+                                                      const unsigned* __restrict__ cls, int unit16, int spin_limit, unsigned* errw) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int p = w & 3, wc = p & 1, wr0 = p >> 1;
@@ -1014,14 +1037,11 @@ __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ 
   float* const side = reinterpret_cast<float*>(smem + FSIDE_OFF);
   unsigned* const fl = reinterpret_cast<unsigned*>(smem + FFLAG_OFF);
 
-  // A workgroup's phases: position g of a linear order in which strip = g / span and phase = base + g % span.
-  //   aligned == 0 (default): strip-major order of all phases cut into pieces of per_wg (span = nph): workgroups that run side by side
-  //                 work on unrelated rows.
-  //   aligned != 0 (experiment, slower: -DWS_ALIGNED=1): every strip's phases [c per_wg, (c + 1) per_wg) go to workgroup c S + strip
-  //                 (S strips), the workgroups of one chunk walk down the same rows of neighbouring strips at the same time; what is left of
-  //                 each strip (nph % per_wg phases) is cut in the old way.
-  int g0, g1, span, base;
-  ws_work_range(aligned, B * ncol, nph, per_wg, g0, g1, span, base);
+  // a workgroup's phases: positions [g0, g1) of the strip-major order (ws_work_range)
+  int g0, g1;
+  constexpr int base = 0;
+  const int span = nph;
+  ws_work_range(B * ncol, nph, g0, g1);
   if (g0 >= g1) return;
   if (!ws_frames8_mine<U8>(cls)) return;
   const int Hi = Ho + XK - 1, Wi = Wo + XK - 1;
@@ -1371,13 +1391,6 @@ __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ 
 // gV and gH of the K = 51, C = 3 op, widths that are a multiple of 4; every tensor below 2^31 bytes (the caller checks).
 // TB: tap planes between two samples of v / h / gV / gH (51 for contiguous [B,51,Ho,Wo] tensors; larger when the tensors are slices of one
 // interleaved [B * S, 51, Ho, Wo] buffer: sepconv/model.py runs its four sub-networks as one task-batched launch per layer)
-// -DWS_ALIGNED=1 (experiment build): chunks of phases aligned across strips (ws_work_range) instead of the strip-major cut.
-// Measured SLOWER (B = 8, 256 x 448, one box: backward 233 -> 245 us, forward 133 -> 148 us isolated; 197 -> 207 / 126 -> 137 in the bench loop):
-// workgroups that walk the same rows together concentrate the chip's requests on few DRAM channels -- the planes of a 256 x 448 tap tensor
-// are a multiple of 64 KB apart -- and spread over the channels is worth more here than open-page hits.
-#ifndef WS_ALIGNED
-#define WS_ALIGNED 0
-#endif
 static int ws_spin_limit_host = 1 << 19;      // savfi_sepconv_ws_debug_spin_limit; handed to every launch
 namespace {
 constexpr int WS_MAX_DEV = 64;
@@ -1386,11 +1399,8 @@ unsigned* ws_watch_dev[WS_MAX_DEV] = {nullptr};      // their device addresses
 int ws_watch_last_dev = -1;                          // (one process drives one GPU: the device of the last savfi_sepconv_ws_watch call)
 unsigned* ws_watch_device_word() { return ws_watch_last_dev >= 0 ? ws_watch_dev[ws_watch_last_dev] : nullptr; }
 }
-static int ws_grid(int aligned, int S, int nph, int per_wg) {
-  if (!aligned) return savfi_cdiv((int64_t)S * nph, per_wg);
-  const int nfull = nph / per_wg;
-  return S * nfull + savfi_cdiv((int64_t)S * (nph - nfull * per_wg), per_wg);
-}
+// one workgroup per CU (LDS), fewer when there are fewer phases than CUs
+static int ws_grid(int64_t total, int cus) { return (int)savfi_cdiv(total, savfi_cdiv(total, cus)); }
 
 // cls: the words of savfi_frames8_classify_f32 on `in` (device memory; both instances of the kernel are launched and the device picks one),
 // or nullptr (the six-product kernel only)
@@ -1398,23 +1408,21 @@ int savfi_sepconv_bwd_ws_launch(const float* in, const float* v, const float* h,
                                 int Wo, int cus, int TB, const unsigned* cls, int taps_unit16, hipStream_t st) {
   const int nph = savfi_cdiv(Ho, XPR), ncol = savfi_cdiv(Wo, XMC);
   const int64_t total = (int64_t)B * ncol * nph;
-  const int per_wg = savfi_cdiv(total, cus);
-  constexpr int aligned = WS_ALIGNED;
-  const int grid = ws_grid(aligned, B * ncol, nph, per_wg);
+  const int grid = ws_grid(total, cus);
   if (taps_unit16 && (Wo & 15) != 0) return SAVFI_E_UNSUPPORTED;
   static uint32_t done = 0, done8 = 0;
   if (cls) {
     if (taps_unit16 & 1) {
       static uint32_t done8d = 0;
       if (int e = savfi_ensure_dynamic_lds((const void*)sepconv_bwd_ws<true, true>, WLDS, done8d)) return e;
-      hipLaunchKernelGGL((sepconv_bwd_ws<true, true>), dim3(grid), dim3(WNT), WLDS, st, in, v, h, gO, gV, gH, B, Ho, Wo, nph, ncol, per_wg, TB, cls, aligned, taps_unit16, ws_spin_limit_host, ws_watch_device_word());
+      hipLaunchKernelGGL((sepconv_bwd_ws<true, true>), dim3(grid), dim3(WNT), WLDS, st, in, v, h, gO, gV, gH, B, Ho, Wo, nph, ncol, TB, cls, taps_unit16, ws_spin_limit_host, ws_watch_device_word());
     } else {
       if (int e = savfi_ensure_dynamic_lds((const void*)sepconv_bwd_ws<true, false>, WLDS, done8)) return e;
-      hipLaunchKernelGGL((sepconv_bwd_ws<true, false>), dim3(grid), dim3(WNT), WLDS, st, in, v, h, gO, gV, gH, B, Ho, Wo, nph, ncol, per_wg, TB, cls, aligned, taps_unit16, ws_spin_limit_host, ws_watch_device_word());
+      hipLaunchKernelGGL((sepconv_bwd_ws<true, false>), dim3(grid), dim3(WNT), WLDS, st, in, v, h, gO, gV, gH, B, Ho, Wo, nph, ncol, TB, cls, taps_unit16, ws_spin_limit_host, ws_watch_device_word());
     }
   }
   if (int e = savfi_ensure_dynamic_lds((const void*)sepconv_bwd_ws<false, false>, WLDS, done)) return e;
-  hipLaunchKernelGGL((sepconv_bwd_ws<false, false>), dim3(grid), dim3(WNT), WLDS, st, in, v, h, gO, gV, gH, B, Ho, Wo, nph, ncol, per_wg, TB, cls, aligned, taps_unit16, ws_spin_limit_host, ws_watch_device_word());
+  hipLaunchKernelGGL((sepconv_bwd_ws<false, false>), dim3(grid), dim3(WNT), WLDS, st, in, v, h, gO, gV, gH, B, Ho, Wo, nph, ncol, TB, cls, taps_unit16, ws_spin_limit_host, ws_watch_device_word());
   return savfi_launch_status();
 }
 
@@ -1423,17 +1431,15 @@ int savfi_sepconv_fwd_ws_launch(const float* in, const float* v, const float* h,
                                 const unsigned* cls, int taps_unit16, hipStream_t st) {
   const int nph = savfi_cdiv(Ho, XPR), ncol = savfi_cdiv(Wo, XMC);
   const int64_t total = (int64_t)B * ncol * nph;
-  const int per_wg = savfi_cdiv(total, cus);
-  constexpr int aligned = WS_ALIGNED;
-  const int grid = ws_grid(aligned, B * ncol, nph, per_wg);
+  const int grid = ws_grid(total, cus);
   if (taps_unit16 && (Wo & 15) != 0) return SAVFI_E_UNSUPPORTED;
   static uint32_t done = 0, done8 = 0;
   if (cls) {
     if (int e = savfi_ensure_dynamic_lds((const void*)sepconv_fwd_ws<true>, FLDS, done8)) return e;
-    hipLaunchKernelGGL(sepconv_fwd_ws<true>, dim3(grid), dim3(WNT), FLDS, st, in, v, h, out, B, Ho, Wo, nph, ncol, per_wg, TB, cls, aligned, taps_unit16, ws_spin_limit_host, ws_watch_device_word());
+    hipLaunchKernelGGL(sepconv_fwd_ws<true>, dim3(grid), dim3(WNT), FLDS, st, in, v, h, out, B, Ho, Wo, nph, ncol, TB, cls, taps_unit16, ws_spin_limit_host, ws_watch_device_word());
   }
   if (int e = savfi_ensure_dynamic_lds((const void*)sepconv_fwd_ws<false>, FLDS, done)) return e;
-  hipLaunchKernelGGL(sepconv_fwd_ws<false>, dim3(grid), dim3(WNT), FLDS, st, in, v, h, out, B, Ho, Wo, nph, ncol, per_wg, TB, cls, aligned, taps_unit16, ws_spin_limit_host, ws_watch_device_word());
+  hipLaunchKernelGGL(sepconv_fwd_ws<false>, dim3(grid), dim3(WNT), FLDS, st, in, v, h, out, B, Ho, Wo, nph, ncol, TB, cls, taps_unit16, ws_spin_limit_host, ws_watch_device_word());
   return savfi_launch_status();
 }
 
@@ -1447,6 +1453,12 @@ extern "C" int savfi_frames8_classify_f32(const float* x, int64_t n, unsigned* c
 }
 
 #if WS_TRACE
+extern "C" int savfi_sepconv_ws_trace_wg(unsigned long long* out /* [1024][2] host */, int reset) {
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ws_trace_wg), sizeof(unsigned long long) * 2048) != hipSuccess) return -1;
+  if (reset) { static unsigned long long z[2048] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(ws_trace_wg), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
 extern "C" int savfi_sepconv_ws_trace(unsigned long long* out /* [16][16] host */, int reset) {
   if (hipDeviceSynchronize() != hipSuccess) return -1;
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ws_trace), sizeof(unsigned long long) * 256) != hipSuccess) return -1;

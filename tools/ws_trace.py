@@ -22,6 +22,9 @@ buf = (ctypes.c_ulonglong * 256)()
 lib.savfi_sepconv_ws_trace.argtypes = [ctypes.c_void_p, ctypes.c_int]
 for _ in range(3): f()
 lib.savfi_sepconv_ws_trace(buf, 1)
+wgbuf = (ctypes.c_ulonglong * 2048)()
+lib.savfi_sepconv_ws_trace_wg.argtypes = [ctypes.c_void_p, ctypes.c_int]
+lib.savfi_sepconv_ws_trace_wg(wgbuf, 1)
 NL = 5
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -43,3 +46,13 @@ for w in range(16 if two else 12):
     print("wave %d kernel cycles per launch %.0f; " % (w, buf[w * 16 + 15] / NL), end="")
     row[15] = 0
     print("wave %d total %.0f: " % (w, sum(row)) + " | ".join("%s %.0f" % (names[k], row[k]) for k in range(len(names))))
+
+# per workgroup: cycles from entry to exit (wave 0), by number of runs
+lib.savfi_sepconv_ws_trace_wg(wgbuf, 1)
+rows = [(wgbuf[2 * i] / NL, wgbuf[2 * i + 1] / NL) for i in range(1024) if wgbuf[2 * i]]
+if rows:
+    for nr in sorted(set(round(r[1]) for r in rows)):
+        c = sorted(r[0] for r in rows if round(r[1]) == nr)
+        print("workgroups with %d run(s): %d, cycles min %.0f median %.0f max %.0f" % (nr, len(c), c[0], c[len(c) // 2], c[-1]))
+    c = sorted(r[0] for r in rows)
+    print("all %d workgroups: min %.0f mean %.0f max %.0f (max / mean %.3f)" % (len(c), c[0], sum(c) / len(c), c[-1], c[-1] / (sum(c) / len(c))))
