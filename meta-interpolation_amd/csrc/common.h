@@ -54,7 +54,9 @@ int savfi_sepconv_fwd_x6_launch(const float* in, const float* v, const float* h,
                                 hipStream_t st);
 // csrc/sepconv_ws.hip: the same gradients with MFMA waves and staging waves in pairs (widths that are a multiple of 4)
 // TB = tap planes between two samples of v / h / gV / gH (51: contiguous tensors)
+// in2 / cls2 != nullptr: the pair launch -- B virtual samples 2 b + f, frame f of sample b (`in` / `in2`), see the kernel
 int savfi_sepconv_bwd_ws_launch(const float* in, const float* v, const float* h, const float* gO, float* gV, float* gH, int B, int Ho,
-                                int Wo, int cus, int TB, const unsigned* cls, int taps_unit16, hipStream_t st);
+                                int Wo, int cus, int TB, const unsigned* cls, int taps_unit16, hipStream_t st, const float* in2 = nullptr,
+                                const unsigned* cls2 = nullptr);
 int savfi_sepconv_fwd_ws_launch(const float* in, const float* v, const float* h, float* out, int B, int Ho, int Wo, int cus, int TB,
                                 const unsigned* cls, int taps_unit16, hipStream_t st);

@@ -1191,6 +1191,21 @@ extern "C" int savfi_sepconv_bwd_frames8_f32(const float* in, const float* v, co
                                      (hipStream_t)stream);
 }
 
+// Both local convolutions of an interleaved tap tensor in ONE launch: taps / gtaps [4 B][K][Ho][Wo] with sample 4 b + s = sub-network s
+// (0: v of frame 0, 1: h of frame 0, 2: v of frame 1, 3: h of frame 1), in0 / in1 the two frames, gO the cotangent of their sum.  The kernel
+// sees 2 B virtual samples at a tap stride of 2 K planes (csrc/sepconv_ws.hip `pair`).  Same results, bit for bit, as the two calls of
+// savfi_sepconv_bwd_frames8_f32 it replaces.
+extern "C" int savfi_sepconv_bwd_pair_frames8_f32(const float* in0, const float* in1, const float* taps, const float* gO, float* gtaps,
+                                                  const unsigned* cls0, const unsigned* cls1, int B, int C, int Ho, int Wo, int K,
+                                                  int taps_unit16, void* stream) {
+  if (!in0 || !in1 || !taps || !gO || !gtaps || !cls0 || !cls1) return SAVFI_E_NULL;
+  if (int e = taps_strided_ok(B, C, Ho, Wo, K, 4 * K)) return e;
+  if (B > 0x3fffffff / 2 || !persistent_ok(2 * B, Ho, Wo)) return SAVFI_E_UNSUPPORTED;
+  const size_t plane = (size_t)K * Ho * Wo;
+  return savfi_sepconv_bwd_ws_launch(in0, taps, taps + plane, gO, gtaps, gtaps + plane, 2 * B, Ho, Wo, device_cu_count(), 2 * K, cls0,
+                                     taps_unit16 & 3, (hipStream_t)stream, in1, cls1);
+}
+
 extern "C" int savfi_sepconv_bwd_f32(const float* in, const float* v, const float* h, const float* gO,
                                      float* gI, float* gV, float* gH, int B, int C, int Ho, int Wo, int K,
                                      void* stream) {

@@ -236,9 +236,13 @@ __device__ __forceinline__ void ws_work_range(int S, int nph, int& g0, int& g1) 
 }
 constexpr int CLS_WG = 256, CLS_NT = 1024;         // classifier grid: one 16-byte load of the words per lane of the consumer
 template <bool U8>
-__device__ __forceinline__ bool ws_frames8_mine(const unsigned* __restrict__ cls) {
+__device__ __forceinline__ bool ws_frames8_mine(const unsigned* __restrict__ cls, const unsigned* __restrict__ cls2 = nullptr) {
   if (cls == nullptr) return !U8;
-  const u32x4 pv = reinterpret_cast<const u32x4*>(cls)[threadIdx.x & 63];
+  u32x4 pv = reinterpret_cast<const u32x4*>(cls)[threadIdx.x & 63];
+  if (cls2 != nullptr) {                             // two frame tensors (the pair launch): both have to qualify
+    const u32x4 qv = reinterpret_cast<const u32x4*>(cls2)[threadIdx.x & 63];
+    pv.x |= qv.x; pv.y |= qv.y; pv.z |= qv.z; pv.w |= qv.w;
+  }
   const bool bad = __builtin_amdgcn_ballot_w64((pv.x | pv.y | pv.z | pv.w) != 0u) != 0ull;
   return bad != U8;
 }
@@ -268,7 +272,14 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
                                                       const float* __restrict__ h, const float* __restrict__ gO,
                                                       float* __restrict__ gV, float* __restrict__ gH,
                                                       int B, int Ho, int Wo, int nph, int ncol, int TB,
-                                                      const unsigned* __restrict__ cls, int unit16, int spin_limit, unsigned* errw) {
+                                                      const unsigned* __restrict__ cls, int unit16, int spin_limit, unsigned* errw,
+                                                      const float* __restrict__ in2, const unsigned* __restrict__ cls2, int pair) {
+  // pair != 0 (savfi_sepconv_bwd_pair_frames8_f32): the TWO local convolutions of the plugin's tail in one launch.  B counts virtual samples
+  // b' = 2 b + f: frame f of sample b -- `in` for f = 0, `in2` for f = 1 --, the cotangent of sample b, and the taps of sub-networks 2 f
+  // (v) and 2 f + 1 (h) of the interleaved tensor, which are simply virtual sample b' at a stride of TB = 2 K planes.  Nothing else
+  // changes: a launch has a fixed cost of about 24 us (the window prologue and the pipeline's ramp of every workgroup, the last
+  // workgroup's tail, the other instance's early exit; B = 4: 97 us, B = 8: 170 us in the bench loop), so one launch of 2 B samples is
+  // faster than two of B.
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int p = w & 3, wc = p & 1, wr0 = p >> 1;
@@ -290,14 +301,15 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
   const int span = nph;
   ws_work_range(B * ncol, nph, g0, g1);
   if (g0 >= g1) return;
-  if (!ws_frames8_mine<U8>(cls)) return;
+  if (!ws_frames8_mine<U8>(cls, pair ? cls2 : nullptr)) return;
   const int Hi = Ho + XK - 1, Wi = Wo + XK - 1;
   const unsigned plane_b = (unsigned)Ho * (unsigned)Wo * 4u;
   const unsigned tap_bytes = (unsigned)((B - 1) * TB + XK) * plane_b;
   const __amdgpu_buffer_rsrc_t hsrc = x6_rsrc(h, tap_bytes);
   const __amdgpu_buffer_rsrc_t vsrc = x6_rsrc(v, tap_bytes);
-  const __amdgpu_buffer_rsrc_t gsrc = x6_rsrc(gO, (unsigned)(B * XC) * plane_b);
-  const __amdgpu_buffer_rsrc_t isrc = x6_rsrc(in, (unsigned)(B * XC) * (unsigned)(Hi * Wi) * 4u);
+  const int Bimg = pair ? B >> 1 : B;               // samples of the frames and of the cotangent
+  const __amdgpu_buffer_rsrc_t gsrc = x6_rsrc(gO, (unsigned)(Bimg * XC) * plane_b);
+  const unsigned in_bytes = (unsigned)(Bimg * XC) * (unsigned)(Hi * Wi) * 4u;
   const __amdgpu_buffer_rsrc_t gvdst = x6_rsrc(gV, (unsigned)((B - 1) * TB + XK) * plane_b);
   const __amdgpu_buffer_rsrc_t ghdst = x6_rsrc(gH, (unsigned)((B - 1) * TB + XK) * plane_b);
 
@@ -346,18 +358,18 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
   // of -- the next flag read would wait for the unit just requested.  M0 carries the slot's LDS address and is restored; the instruction
   // offset moves the memory and the LDS address alike.)
   // n: the unit's number in the run; the wave's share (64 columns x two channels) of the window row that iteration n writes rides along
-  auto dma_unit = [&](const float* src, unsigned src_bytes, int b, int x0, int R0, int wr0_, int n, int slot) {
+  auto dma_unit = [&](const float* src, unsigned src_bytes, const float* frame, int b, int bi, int x0, int R0, int wr0_, int n, int slot) {
     const int y = R0 + XPR * (n >> 1) + wr0_ + 2 * (n & 1);
     const unsigned dst = (unsigned)(unsigned long long)(ws_lds_void*)(ring + slot * WRINGB);
     const unsigned run = unit_off(b, x0, y) + (unsigned)lane * 16u;
     static_assert((XK * 64 - 3072) / 16 == 12, "lanes of the fourth piece");
-    const unsigned go = lane < 16 * XC ? pix_off(b, x0, y, XC) + (unsigned)kg * plane_b : X_OOR;
+    const unsigned go = lane < 16 * XC ? pix_off(bi, x0, y, XC) + (unsigned)kg * plane_b : X_OOR;
     const int ws_ = w - 4, gcol_ = (ws_ & 1) * 64 + lane, gc0_ = (ws_ & 2) ? 2 : 0, gc1_ = (ws_ & 2) ? 2 : 1;
     const int rr = min(R0 + 60 + 2 * n + (ws_ >> 2), Hi - 1);
     const unsigned colb = (unsigned)min(x0 + gcol_, Wi - 1) * 4u;
-    const unsigned r0 = (unsigned)(((b * XC + gc0_) * Hi + rr) * Wi) * 4u + colb, r1 = (unsigned)(((b * XC + gc1_) * Hi + rr) * Wi) * 4u + colb;
-    const ws_i32x4 rs = ws_rsrc4(src, src_bytes), rg = ws_rsrc4(gO, (unsigned)(B * XC) * plane_b);
-    const ws_i32x4 ri = ws_rsrc4(in, (unsigned)(B * XC) * (unsigned)(Hi * Wi) * 4u);
+    const unsigned r0 = (unsigned)(((bi * XC + gc0_) * Hi + rr) * Wi) * 4u + colb, r1 = (unsigned)(((bi * XC + gc1_) * Hi + rr) * Wi) * 4u + colb;
+    const ws_i32x4 rs = ws_rsrc4(src, src_bytes), rg = ws_rsrc4(gO, (unsigned)(Bimg * XC) * plane_b);
+    const ws_i32x4 ri = ws_rsrc4(frame, in_bytes);
     unsigned keep;
     unsigned long long keepx;
     // the fourth piece under an EXEC of twelve lanes: a lane switched off by the range check would still write zeros over the slot's tail
@@ -448,6 +460,9 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
   while (g < g1) {
     // ---- a run: phases ph0 .. ph0 + nrun - 1 of strip (b, x0) ---------------------------------------------------------------
     const int s = g / span, gin = g - s * span, ph0 = base + gin, b = s / ncol, x0 = (s - b * ncol) * XMC;
+    const int bi = pair ? b >> 1 : b;
+    const float* const frame = (pair && (b & 1)) ? in2 : in;
+    const __amdgpu_buffer_rsrc_t isrc = x6_rsrc(frame, in_bytes);
     const int run_end = min(g1, g + (span - gin)), nrun = run_end - g, N = 2 * nrun;
     const int R0 = XPR * ph0;
     auto unit_y = [&](int n) { return R0 + XPR * (n >> 1) + wr0 + 2 * (n & 1); };
@@ -459,20 +474,20 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
       fl[tid] = tid == F_LIMIT ? (unsigned)spin_limit : tid == F_ERRW ? (unsigned)q : tid == F_ERRW + 1 ? (unsigned)(q >> 32) : 0u;
     }
     {
-      const unsigned go = pix_off(b, x0, unit_y(0), XC);
+      const unsigned go = pix_off(bi, x0, unit_y(0), XC);
 #pragma unroll
       for (int c = 0; c < XC; ++c) gp[c] = x6_bload(gsrc, go, (unsigned)c * plane_b);
     }
     if constexpr (DMA && STG) {                      // the first two units' fetches: their latency runs under the window prologue
-      dma_unit(role == 1 ? h : v, tap_bytes, b, x0, R0, wr0, 0, 0);
-      dma_unit(role == 1 ? h : v, tap_bytes, b, x0, R0, wr0, min(1, N - 1), 1);
+      dma_unit(role == 1 ? h : v, tap_bytes, frame, b, bi, x0, R0, wr0, 0, 0);
+      dma_unit(role == 1 ? h : v, tap_bytes, frame, b, bi, x0, R0, wr0, min(1, N - 1), 1);
     }
     if (tid < XNT) {                                 // the window prologue keeps sepconv_x6's mapping of 512 threads
       constexpr int PR = U8 ? 32 : 16;               // rows per round trip (the U8 kernel has the registers for two rounds instead of four)
 #pragma unroll 1
       for (int r = 0; r < XWIN; r += PR) {
         X6Rows<PR> sr;
-        x6_rows_load<PR>(sr, isrc, b, x0, R0 + r, Hi, Wi, tid);
+        x6_rows_load<PR>(sr, isrc, bi, x0, R0 + r, Hi, Wi, tid);
         x6_rows_write<PR, U8>(sr, smem, R0 + r, tid, WSIDE_OFF);
       }
     }
@@ -586,7 +601,7 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
 #pragma unroll
         for (int c = 0; c < XC; ++c) g_[c] = U8 ? gp[c] * (1.0f / 255.0f) : gp[c];
         {
-          const unsigned go = pix_off(b, x0, unit_y(min(n + 1, N - 1)), XC);
+          const unsigned go = pix_off(bi, x0, unit_y(min(n + 1, N - 1)), XC);
 #pragma unroll
           for (int c = 0; c < XC; ++c) gp[c] = x6_bload(gsrc, go, (unsigned)c * plane_b);
         }
@@ -794,8 +809,8 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
           if constexpr (DMA) {                       // fetched with the unit: read back where the row is written
             gr0 = gr1 = 0.f;
           } else {
-            gr0 = WS_EXP_NOSTAGE ? 0.f : x6_bload(isrc, (unsigned)(((b * XC + gc0) * Hi + rr) * Wi) * 4u + gcolb, 0u);
-            gr1 = WS_EXP_NOSTAGE ? 0.f : x6_bload(isrc, (unsigned)(((b * XC + gc1) * Hi + rr) * Wi) * 4u + gcolb, 0u);
+            gr0 = WS_EXP_NOSTAGE ? 0.f : x6_bload(isrc, (unsigned)(((bi * XC + gc0) * Hi + rr) * Wi) * 4u + gcolb, 0u);
+            gr1 = WS_EXP_NOSTAGE ? 0.f : x6_bload(isrc, (unsigned)(((bi * XC + gc1) * Hi + rr) * Wi) * 4u + gcolb, 0u);
           }
         }
         float g14[XC], g15[XC];
@@ -937,7 +952,7 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
         }
         qoff_prev = qoff;
         if constexpr (!DMA) if (!WS_EXP_NOSTAGE) {
-          const unsigned go = pix_off(b, x0, y1, XC);
+          const unsigned go = pix_off(bi, x0, y1, XC);
 #pragma unroll
           for (int c = 0; c < XC; ++c) gp[c] = x6_bload(gsrc, go, (unsigned)c * plane_b);
         }
@@ -979,7 +994,7 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
           // LAST in the iteration (the count of the wait above): slot n & 1 -- its reads returned long ago -- takes unit n + 2
           asm volatile("" ::: "memory");
           __builtin_amdgcn_s_waitcnt(WS_LGKMCNT0);
-          dma_unit(hside ? h : v, tap_bytes, b, x0, R0, wr0, min(n + 2, N - 1), n & 1);
+          dma_unit(hside ? h : v, tap_bytes, frame, b, bi, x0, R0, wr0, min(n + 2, N - 1), n & 1);
           asm volatile("" ::: "memory");
           WS_T(10);
         }
@@ -1405,7 +1420,9 @@ static int ws_grid(int64_t total, int cus) { return (int)savfi_cdiv(total, savfi
 // cls: the words of savfi_frames8_classify_f32 on `in` (device memory; both instances of the kernel are launched and the device picks one),
 // or nullptr (the six-product kernel only)
 int savfi_sepconv_bwd_ws_launch(const float* in, const float* v, const float* h, const float* gO, float* gV, float* gH, int B, int Ho,
-                                int Wo, int cus, int TB, const unsigned* cls, int taps_unit16, hipStream_t st) {
+                                int Wo, int cus, int TB, const unsigned* cls, int taps_unit16, hipStream_t st, const float* in2,
+                                const unsigned* cls2) {
+  const int pair = in2 != nullptr ? 1 : 0;          // B virtual samples = two frames per sample (see the kernel)
   const int nph = savfi_cdiv(Ho, XPR), ncol = savfi_cdiv(Wo, XMC);
   const int64_t total = (int64_t)B * ncol * nph;
   const int grid = ws_grid(total, cus);
@@ -1415,14 +1432,14 @@ int savfi_sepconv_bwd_ws_launch(const float* in, const float* v, const float* h,
     if (taps_unit16 & 1) {
       static uint32_t done8d = 0;
       if (int e = savfi_ensure_dynamic_lds((const void*)sepconv_bwd_ws<true, true>, WLDS, done8d)) return e;
-      hipLaunchKernelGGL((sepconv_bwd_ws<true, true>), dim3(grid), dim3(WNT), WLDS, st, in, v, h, gO, gV, gH, B, Ho, Wo, nph, ncol, TB, cls, taps_unit16, ws_spin_limit_host, ws_watch_device_word());
+      hipLaunchKernelGGL((sepconv_bwd_ws<true, true>), dim3(grid), dim3(WNT), WLDS, st, in, v, h, gO, gV, gH, B, Ho, Wo, nph, ncol, TB, cls, taps_unit16, ws_spin_limit_host, ws_watch_device_word(), in2, cls2, pair);
     } else {
       if (int e = savfi_ensure_dynamic_lds((const void*)sepconv_bwd_ws<true, false>, WLDS, done8)) return e;
-      hipLaunchKernelGGL((sepconv_bwd_ws<true, false>), dim3(grid), dim3(WNT), WLDS, st, in, v, h, gO, gV, gH, B, Ho, Wo, nph, ncol, TB, cls, taps_unit16, ws_spin_limit_host, ws_watch_device_word());
+      hipLaunchKernelGGL((sepconv_bwd_ws<true, false>), dim3(grid), dim3(WNT), WLDS, st, in, v, h, gO, gV, gH, B, Ho, Wo, nph, ncol, TB, cls, taps_unit16, ws_spin_limit_host, ws_watch_device_word(), in2, cls2, pair);
     }
   }
   if (int e = savfi_ensure_dynamic_lds((const void*)sepconv_bwd_ws<false, false>, WLDS, done)) return e;
-  hipLaunchKernelGGL((sepconv_bwd_ws<false, false>), dim3(grid), dim3(WNT), WLDS, st, in, v, h, gO, gV, gH, B, Ho, Wo, nph, ncol, TB, cls, taps_unit16, ws_spin_limit_host, ws_watch_device_word());
+  hipLaunchKernelGGL((sepconv_bwd_ws<false, false>), dim3(grid), dim3(WNT), WLDS, st, in, v, h, gO, gV, gH, B, Ho, Wo, nph, ncol, TB, cls, taps_unit16, ws_spin_limit_host, ws_watch_device_word(), in2, cls2, pair);
   return savfi_launch_status();
 }
 

@@ -187,6 +187,13 @@ class FunctionSepconvPair(torch.autograd.Function):
         gT = torch.empty_like(taps)
         lib, st = _hip.lib(), _hip.current_stream()
         plane = K * Ho * Wo * 4
+        if words is not None and not os.environ.get('SAVFI_SEPCONV_PAIR_TWO_LAUNCHES'):
+            # ONE launch for both local convolutions (2 B virtual samples): a launch of these kernels has a fixed cost of ~24 us
+            _hip.launch("sepconv_bwd", lambda: _hip.check(lib.savfi_sepconv_bwd_pair_frames8_f32(
+                input0.data_ptr(), input1.data_ptr(), taps.data_ptr(), gradOutput.data_ptr(), gT.data_ptr(), words[0].data_ptr(),
+                words[1].data_ptr(), B, C, Ho, Wo, K, ctx.taps_unit16, st), "savfi_sepconv_bwd_pair_frames8_f32"),
+                nbytes=2 * algorithmic_bytes(B, C, Ho, Wo, K, grads=2))
+            return None, None, gT, None, None
         for i, (inp, s) in enumerate(((input0, 0), (input1, 2))):
             if words is not None:
                 _hip.launch("sepconv_bwd", lambda inp=inp, s=s, i=i: _hip.check(lib.savfi_sepconv_bwd_frames8_f32(

@@ -298,3 +298,48 @@ def test_unit_major_convolution_entry_points_refuse_what_they_cannot_do():
     # the Python gate of the plugin says no where the direct split-bf16 kernel would run the layer (64 -> 64 channels)
     assert not hip_ops.conv3x3_unit16_supported(torch.randn(8, 64, 98, 130, device=DEV), torch.randn(4, 64, 64, 3, 3, device=DEV), 0)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("B,Ho,Wo,f8,u16", [(2, 37, 36, True, 0), (3, 40, 64, True, 1), (2, 64, 96, True, 3), (1, 24, 48, False, 0), (2, 33, 32, "one", 1)])
+def test_pair_launch_gives_the_bits_of_the_two_launches(B, Ho, Wo, f8, u16):
+    """savfi_sepconv_bwd_pair_frames8_f32: both local convolutions of an interleaved tap tensor [4 B][K][Ho][Wo] in ONE launch (2 B virtual
+    samples) against the two calls of savfi_sepconv_bwd_frames8_f32 it replaces -- planar and unit-major taps / gradients, frames of 8-bit
+    images, float frames, and a pair of which only ONE frame qualifies (the device then takes the six-product kernel for both)"""
+    lib, st = _hip.lib(), _hip.current_stream()
+    g = torch.Generator().manual_seed(1000 + Ho)
+    frames = []
+    for i in range(2):
+        if f8 is True or (f8 == "one" and i == 0):
+            frames.append(torch.randint(0, 256, (B, 3, Ho + K - 1, Wo + K - 1), generator=g).float().div(255).to(DEV))
+        else:
+            frames.append(torch.rand(B, 3, Ho + K - 1, Wo + K - 1, generator=g).to(DEV))
+    taps = (torch.randn(4 * B, K, Ho, Wo, generator=g) / math.sqrt(K)).to(DEV)
+    if u16 & 1:
+        taps = _to_unit16(taps)
+    gO = torch.randn(B, 3, Ho, Wo, generator=g).to(DEV)
+    words = [_words(f) for f in frames]
+    plane = K * Ho * Wo * 4
+    two = torch.full_like(taps, float('nan'))
+    for i, s in ((0, 0), (1, 2)):
+        _hip.check(lib.savfi_sepconv_bwd_frames8_f32(frames[i].data_ptr(), taps.data_ptr() + s * plane, taps.data_ptr() + (s + 1) * plane,
+                                                     gO.data_ptr(), two.data_ptr() + s * plane, two.data_ptr() + (s + 1) * plane,
+                                                     words[i].data_ptr(), B, 3, Ho, Wo, K, 4 * K, u16, st), "two launches")
+    one = torch.full_like(taps, float('nan'))
+    _hip.check(lib.savfi_sepconv_bwd_pair_frames8_f32(frames[0].data_ptr(), frames[1].data_ptr(), taps.data_ptr(), gO.data_ptr(), one.data_ptr(),
+                                                      words[0].data_ptr(), words[1].data_ptr(), B, 3, Ho, Wo, K, u16, st), "pair launch")
+    torch.cuda.synchronize()
+    assert not torch.isnan(two).any()
+    if f8 == "one":
+        # frame 0 alone takes the three-product kernel, in the pair both take the six-product kernel: sub-networks 2, 3 are bit-identical,
+        # sub-networks 0, 1 agree to fp32 rounding
+        t5, o5 = two.view(B, 4, K, Ho, Wo), one.view(B, 4, K, Ho, Wo)
+        assert torch.equal(t5[:, 2:], o5[:, 2:])
+        assert _rel(o5[:, :2], t5[:, :2]) < 1e-5
+    else:
+        assert torch.equal(one, two)
+    # refusals: a missing pointer, a width that is no multiple of 4
+    assert lib.savfi_sepconv_bwd_pair_frames8_f32(frames[0].data_ptr(), None, taps.data_ptr(), gO.data_ptr(), one.data_ptr(),
+                                                  words[0].data_ptr(), words[1].data_ptr(), B, 3, Ho, Wo, K, u16, st) == -1
+    assert lib.savfi_sepconv_bwd_pair_frames8_f32(frames[0].data_ptr(), frames[1].data_ptr(), taps.data_ptr(), gO.data_ptr(), one.data_ptr(),
+                                                  words[0].data_ptr(), words[1].data_ptr(), B, 3, Ho, Wo - 1, K, 0, st) == -3
+    assert lib.savfi_sepconv_ws_errors() == 0
