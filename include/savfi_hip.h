@@ -122,7 +122,11 @@ int savfi_sepconv_bwd_frames8_f32(const float* in, const float* v, const float* 
  * FunctionSepconv twice, on frame 0 with sub-networks 0 / 1 and on frame 1 with sub-networks 2 / 3, and adds the results -- their backward
  * passes share the cotangent gO).  taps, gtaps [4 B][K][Ho][Wo] (sample 4 b + s = sub-network s: v0, h0, v1, h1); in0, in1 the frames with
  * their own classifier words.  The three-product kernel runs when BOTH frames qualify.  A launch of these kernels has a fixed cost of about
- * 24 us at 256 x 448, so one launch over 2 B samples is faster than two over B; the results are the same bit for bit.  taps_unit16 as above. */
+ * 24 us at 256 x 448, so one launch over 2 B samples is faster than two over B; the results are the same bit for bit.  taps_unit16 as above.
+ * The forward of the pair the same way: out [B][2][C][Ho][Wo] holds the two local convolutions of every sample, the caller adds them. */
+int savfi_sepconv_fwd_pair_frames8_f32(const float* in0, const float* in1, const float* taps, float* out /* [B][2][C][Ho][Wo] */,
+                                       const unsigned* cls0, const unsigned* cls1, int B, int C, int Ho, int Wo, int K, int taps_unit16,
+                                       void* stream);
 int savfi_sepconv_bwd_pair_frames8_f32(const float* in0, const float* in1, const float* taps, const float* gO, float* gtaps,
                                        const unsigned* cls0, const unsigned* cls1, int B, int C, int Ho, int Wo, int K, int taps_unit16,
                                        void* stream);

@@ -43,6 +43,7 @@ _PROTOTYPES = {
     "savfi_sepconv_fwd_frames8_f32": [_P, _P, _P, _P, _P] + [c_int] * 7 + [_P],
     "savfi_sepconv_bwd_frames8_f32": [_P, _P, _P, _P, _P, _P, _P] + [c_int] * 7 + [_P],
     "savfi_sepconv_bwd_pair_frames8_f32": [_P] * 7 + [c_int] * 6 + [_P],
+    "savfi_sepconv_fwd_pair_frames8_f32": [_P] * 6 + [c_int] * 6 + [_P],
     "savfi_sepconv_ws_errors": [],
     "savfi_sepconv_ws_watch": [],
     "savfi_sepconv_ws_errors_peek": [],

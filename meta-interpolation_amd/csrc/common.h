@@ -59,4 +59,5 @@ int savfi_sepconv_bwd_ws_launch(const float* in, const float* v, const float* h,
                                 int Wo, int cus, int TB, const unsigned* cls, int taps_unit16, hipStream_t st, const float* in2 = nullptr,
                                 const unsigned* cls2 = nullptr);
 int savfi_sepconv_fwd_ws_launch(const float* in, const float* v, const float* h, float* out, int B, int Ho, int Wo, int cus, int TB,
-                                const unsigned* cls, int taps_unit16, hipStream_t st);
+                                const unsigned* cls, int taps_unit16, hipStream_t st, const float* in2 = nullptr,
+                                const unsigned* cls2 = nullptr);

@@ -1191,6 +1191,19 @@ extern "C" int savfi_sepconv_bwd_frames8_f32(const float* in, const float* v, co
                                      (hipStream_t)stream);
 }
 
+// The forward of both local convolutions in ONE launch: out [B][2][C][Ho][Wo], out[b][f] = the local convolution of frame f of sample b with
+// sub-networks 2 f / 2 f + 1 of taps [4 B][K][Ho][Wo]; the caller adds out[:, 0] and out[:, 1] (sepconv/model.py:346-347).  Bit for bit the
+// results of the two calls of savfi_sepconv_fwd_frames8_f32 it replaces.
+extern "C" int savfi_sepconv_fwd_pair_frames8_f32(const float* in0, const float* in1, const float* taps, float* out, const unsigned* cls0,
+                                                  const unsigned* cls1, int B, int C, int Ho, int Wo, int K, int taps_unit16, void* stream) {
+  if (!in0 || !in1 || !taps || !out || !cls0 || !cls1) return SAVFI_E_NULL;
+  if (int e = taps_strided_ok(B, C, Ho, Wo, K, 4 * K)) return e;
+  if (sepconv_env().no_ws_fwd || B > 0x3fffffff / 2 || !persistent_ok(2 * B, Ho, Wo)) return SAVFI_E_UNSUPPORTED;
+  const size_t plane = (size_t)K * Ho * Wo;
+  return savfi_sepconv_fwd_ws_launch(in0, taps, taps + plane, out, 2 * B, Ho, Wo, device_cu_count(), 2 * K, cls0, taps_unit16 & 1,
+                                     (hipStream_t)stream, in1, cls1);
+}
+
 // Both local convolutions of an interleaved tap tensor in ONE launch: taps / gtaps [4 B][K][Ho][Wo] with sample 4 b + s = sub-network s
 // (0: v of frame 0, 1: h of frame 0, 2: v of frame 1, 3: h of frame 1), in0 / in1 the two frames, gO the cotangent of their sum.  The kernel
 // sees 2 B virtual samples at a tap stride of 2 K planes (csrc/sepconv_ws.hip `pair`).  Same results, bit for bit, as the two calls of

@@ -222,7 +222,7 @@ __device__ __forceinline__ int ws_lane() {
 // phases fewer.  (An "aligned" order -- the workgroups of a chunk walking the same rows of neighbouring strips together -- was measured
 // slower three times, planar and unit-major taps alike: spread over the DRAM channels beats locality here; tools/r5/membench.hip.)
 #ifndef WS_RUN_COST
-#define WS_RUN_COST 3
+#define WS_RUN_COST 2
 #endif
 __device__ __forceinline__ int ws_cost_to_phase(long long t, int nph) {
   const int C = 2 * nph + WS_RUN_COST;
@@ -1039,7 +1039,10 @@ template <bool U8>
 __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ in, const float* __restrict__ v,
                                                       const float* __restrict__ h, float* __restrict__ out,
                                                       int B, int Ho, int Wo, int nph, int ncol, int TB,
-                                                      const unsigned* __restrict__ cls, int unit16, int spin_limit, unsigned* errw) {
+                                                      const unsigned* __restrict__ cls, int unit16, int spin_limit, unsigned* errw,
+                                                      const float* __restrict__ in2, const unsigned* __restrict__ cls2, int pair) {
+  // pair != 0 (savfi_sepconv_fwd_pair_frames8_f32; see sepconv_bwd_ws): B virtual samples b' = 2 b + f -- frame f of sample b from `in`
+  // (f = 0) or `in2` (f = 1), taps at a stride of TB = 2 K planes, result b' of `out` ([B / 2][2][C][Ho][Wo]: the caller adds the two)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int p = w & 3, wc = p & 1, wr0 = p >> 1;
@@ -1058,12 +1061,12 @@ __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ 
   const int span = nph;
   ws_work_range(B * ncol, nph, g0, g1);
   if (g0 >= g1) return;
-  if (!ws_frames8_mine<U8>(cls)) return;
+  if (!ws_frames8_mine<U8>(cls, pair ? cls2 : nullptr)) return;
   const int Hi = Ho + XK - 1, Wi = Wo + XK - 1;
   const unsigned plane_b = (unsigned)Ho * (unsigned)Wo * 4u;
   const __amdgpu_buffer_rsrc_t hsrc = x6_rsrc(h, (unsigned)((B - 1) * TB + XK) * plane_b);
   const __amdgpu_buffer_rsrc_t vsrc = x6_rsrc(v, (unsigned)((B - 1) * TB + XK) * plane_b);
-  const __amdgpu_buffer_rsrc_t isrc = x6_rsrc(in, (unsigned)(B * XC) * (unsigned)(Hi * Wi) * 4u);
+  const unsigned in_bytes = (unsigned)((pair ? B >> 1 : B) * XC) * (unsigned)(Hi * Wi) * 4u;
   const __amdgpu_buffer_rsrc_t odst = x6_rsrc(out, (unsigned)(B * XC) * plane_b);
 
   auto pix_off = [&](int b, int x0, int y, int ch) {
@@ -1122,6 +1125,8 @@ __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ 
 #pragma unroll 1
   while (g < g1) {
     const int s = g / span, gin = g - s * span, ph0 = base + gin, b = s / ncol, x0 = (s - b * ncol) * XMC;
+    const int bi = pair ? b >> 1 : b;
+    const __amdgpu_buffer_rsrc_t isrc = x6_rsrc((pair && (b & 1)) ? in2 : in, in_bytes);
     const int run_end = min(g1, g + (span - gin)), nrun = run_end - g, N = 2 * nrun;
     const int R0 = XPR * ph0;
     auto unit_y = [&](int n) { return R0 + XPR * (n >> 1) + wr0 + 2 * (n & 1); };
@@ -1134,7 +1139,7 @@ __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ 
 #pragma unroll 1
       for (int r = 0; r < XWIN; r += 16) {
         X6Rows<16> sr;
-        x6_rows_load<16>(sr, isrc, b, x0, R0 + r, Hi, Wi, tid);
+        x6_rows_load<16>(sr, isrc, bi, x0, R0 + r, Hi, Wi, tid);
         x6_rows_write<16, U8>(sr, smem, R0 + r, tid, FSIDE_OFF);
       }
     }
@@ -1285,8 +1290,8 @@ __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ 
         const int grow = R0 + 60 + 2 * nn + (hside ? 0 : 1);
         {
           const int rr = min(grow, Hi - 1);
-          gr0 = x6_bload(isrc, (unsigned)(((b * XC + gc0) * Hi + rr) * Wi) * 4u + gcolb, 0u);
-          gr1 = x6_bload(isrc, (unsigned)(((b * XC + gc1) * Hi + rr) * Wi) * 4u + gcolb, 0u);
+          gr0 = x6_bload(isrc, (unsigned)(((bi * XC + gc0) * Hi + rr) * Wi) * 4u + gcolb, 0u);
+          gr1 = x6_bload(isrc, (unsigned)(((bi * XC + gc1) * Hi + rr) * Wi) * 4u + gcolb, 0u);
         }
         const int fyl = min(lane, XK - 1);
         const int tslot = (y + fyl) & (XWIN - 1);
@@ -1445,7 +1450,8 @@ int savfi_sepconv_bwd_ws_launch(const float* in, const float* v, const float* h,
 
 // forward of the same op, widths that are a multiple of 4 (declared in csrc/common.h)
 int savfi_sepconv_fwd_ws_launch(const float* in, const float* v, const float* h, float* out, int B, int Ho, int Wo, int cus, int TB,
-                                const unsigned* cls, int taps_unit16, hipStream_t st) {
+                                const unsigned* cls, int taps_unit16, hipStream_t st, const float* in2, const unsigned* cls2) {
+  const int pair = in2 != nullptr ? 1 : 0;
   const int nph = savfi_cdiv(Ho, XPR), ncol = savfi_cdiv(Wo, XMC);
   const int64_t total = (int64_t)B * ncol * nph;
   const int grid = ws_grid(total, cus);
@@ -1453,10 +1459,10 @@ int savfi_sepconv_fwd_ws_launch(const float* in, const float* v, const float* h,
   static uint32_t done = 0, done8 = 0;
   if (cls) {
     if (int e = savfi_ensure_dynamic_lds((const void*)sepconv_fwd_ws<true>, FLDS, done8)) return e;
-    hipLaunchKernelGGL(sepconv_fwd_ws<true>, dim3(grid), dim3(WNT), FLDS, st, in, v, h, out, B, Ho, Wo, nph, ncol, TB, cls, taps_unit16, ws_spin_limit_host, ws_watch_device_word());
+    hipLaunchKernelGGL(sepconv_fwd_ws<true>, dim3(grid), dim3(WNT), FLDS, st, in, v, h, out, B, Ho, Wo, nph, ncol, TB, cls, taps_unit16, ws_spin_limit_host, ws_watch_device_word(), in2, cls2, pair);
   }
   if (int e = savfi_ensure_dynamic_lds((const void*)sepconv_fwd_ws<false>, FLDS, done)) return e;
-  hipLaunchKernelGGL(sepconv_fwd_ws<false>, dim3(grid), dim3(WNT), FLDS, st, in, v, h, out, B, Ho, Wo, nph, ncol, TB, cls, taps_unit16, ws_spin_limit_host, ws_watch_device_word());
+  hipLaunchKernelGGL(sepconv_fwd_ws<false>, dim3(grid), dim3(WNT), FLDS, st, in, v, h, out, B, Ho, Wo, nph, ncol, TB, cls, taps_unit16, ws_spin_limit_host, ws_watch_device_word(), in2, cls2, pair);
   return savfi_launch_status();
 }
 

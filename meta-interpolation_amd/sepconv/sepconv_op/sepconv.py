@@ -161,6 +161,14 @@ class FunctionSepconvPair(torch.autograd.Function):
         assert not u16 or (words is not None and Wo % 16 == 0), "unit-major taps: the frames8 entry points, widths that are a multiple of 16"
         assert not grads_unit16 or u16, "unit-major gradients go with unit-major taps"
         ctx.taps_unit16 = u16 | (2 if grads_unit16 else 0)
+        if words is not None and not os.environ.get('SAVFI_SEPCONV_PAIR_TWO_LAUNCHES'):
+            # ONE launch for both local convolutions (2 B virtual samples; see backward): out2[b, f] = the convolution of frame f
+            out2 = torch.empty((B, 2, C, Ho, Wo), dtype=input0.dtype, device=input0.device)
+            _hip.launch("sepconv_fwd", lambda: _hip.check(lib.savfi_sepconv_fwd_pair_frames8_f32(
+                input0.data_ptr(), input1.data_ptr(), taps.data_ptr(), out2.data_ptr(), words[0].data_ptr(), words[1].data_ptr(),
+                B, C, Ho, Wo, K, u16, st), "savfi_sepconv_fwd_pair_frames8_f32"), nbytes=2 * algorithmic_bytes(B, C, Ho, Wo, K))
+            ctx.save_for_backward(input0, input1, taps, *words)
+            return out2[:, 0].add(out2[:, 1])
         for i, (inp, out, s) in enumerate(((input0, out0, 0), (input1, out1, 2))):
             if words is not None:
                 _hip.launch("sepconv_fwd", lambda inp=inp, out=out, s=s, i=i: _hip.check(lib.savfi_sepconv_fwd_frames8_f32(

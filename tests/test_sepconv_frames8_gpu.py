@@ -337,7 +337,23 @@ def test_pair_launch_gives_the_bits_of_the_two_launches(B, Ho, Wo, f8, u16):
         assert _rel(o5[:, :2], t5[:, :2]) < 1e-5
     else:
         assert torch.equal(one, two)
+    # the forward of the pair: out[b, f] = the local convolution of frame f, bit for bit the two launches'
+    out_two = torch.full((2, B, 3, Ho, Wo), float('nan'), device=DEV)
+    for i, s in ((0, 0), (1, 2)):
+        _hip.check(lib.savfi_sepconv_fwd_frames8_f32(frames[i].data_ptr(), taps.data_ptr() + s * plane, taps.data_ptr() + (s + 1) * plane,
+                                                     out_two[i].data_ptr(), words[i].data_ptr(), B, 3, Ho, Wo, K, 4 * K, u16 & 1, st), "two launches")
+    out_one = torch.full((B, 2, 3, Ho, Wo), float('nan'), device=DEV)
+    _hip.check(lib.savfi_sepconv_fwd_pair_frames8_f32(frames[0].data_ptr(), frames[1].data_ptr(), taps.data_ptr(), out_one.data_ptr(),
+                                                      words[0].data_ptr(), words[1].data_ptr(), B, 3, Ho, Wo, K, u16 & 1, st), "pair launch")
+    torch.cuda.synchronize()
+    assert not torch.isnan(out_two).any()
+    if f8 == "one":
+        assert torch.equal(out_one[:, 1], out_two[1]) and _rel(out_one[:, 0], out_two[0]) < 1e-5
+    else:
+        assert torch.equal(out_one.transpose(0, 1), out_two)
     # refusals: a missing pointer, a width that is no multiple of 4
+    assert lib.savfi_sepconv_fwd_pair_frames8_f32(frames[0].data_ptr(), frames[1].data_ptr(), None, out_one.data_ptr(),
+                                                  words[0].data_ptr(), words[1].data_ptr(), B, 3, Ho, Wo, K, 0, st) == -1
     assert lib.savfi_sepconv_bwd_pair_frames8_f32(frames[0].data_ptr(), None, taps.data_ptr(), gO.data_ptr(), one.data_ptr(),
                                                   words[0].data_ptr(), words[1].data_ptr(), B, 3, Ho, Wo, K, u16, st) == -1
     assert lib.savfi_sepconv_bwd_pair_frames8_f32(frames[0].data_ptr(), frames[1].data_ptr(), taps.data_ptr(), gO.data_ptr(), one.data_ptr(),

@@ -56,3 +56,6 @@ if rows:
         print("workgroups with %d run(s): %d, cycles min %.0f median %.0f max %.0f" % (nr, len(c), c[0], c[len(c) // 2], c[-1]))
     c = sorted(r[0] for r in rows)
     print("all %d workgroups: min %.0f mean %.0f max %.0f (max / mean %.3f)" % (len(c), c[0], sum(c) / len(c), c[-1], c[-1] / (sum(c) / len(c))))
+    for x in range(8):
+        c = [r[0] for i, r in enumerate(rows) if i % 8 == x]
+        print("XCD %d (blockIdx %% 8): %d workgroups, mean %.0f min %.0f max %.0f" % (x, len(c), sum(c) / len(c), min(c), max(c)))
