@@ -68,6 +68,9 @@ WORKLOADS = {
 }
 
 
+CPU_BASELINE_THREADS = 16
+
+
 def _cpu_model():
     try:
         with open('/proc/cpuinfo') as fh:
@@ -86,8 +89,10 @@ def cpu_baseline(model, H, W, S, overrides):
     from meta_interpolation_amd import synthetic
     from oracle import meta, rules
     from tests.helpers import oracle_base
-    # N=1 convolutions do not scale past a few dozen threads (256 threads: 10x slower than 32)
-    cores = min(os.cpu_count() or 1, 32)
+    # The thread count is the best of a recorded sweep on the GPU box's host (2 x EPYC 9575F, 256 logical CPUs:
+    # profiles/r05_cpu_baseline_threads.txt, tools/cpu_baseline_threads.py): one task's N = 1 convolutions stop scaling at a few dozen
+    # threads and lose beyond.  SAVFI_CPU_BASELINE_THREADS overrides (the sweep's knob).
+    cores = int(os.environ.get('SAVFI_CPU_BASELINE_THREADS') or min(os.cpu_count() or 1, CPU_BASELINE_THREADS))
     torch.set_num_threads(cores)
     os.environ["OMP_NUM_THREADS"] = str(cores)
     base = oracle_base(model, recipe=overrides.get('weight_recipe'))
@@ -332,6 +337,7 @@ def main():
         line["multi_gpu"] = {
             "backend": backend + (" (RCCL)" if backend == "nccl" else ""), "rccl_ranks": dist.get_world_size() if backend == "nccl" else 0,
             "world_size": dist.get_world_size(), "devices_visible_to_rank0": torch.cuda.device_count() if dev.type == 'cuda' else 0,
+            "rccl_version": ".".join(str(x) for x in torch.cuda.nccl.version()) if backend == "nccl" else None,
             "collectives_per_meta_iteration": 1, "allreduce": ar_stats, "replicas_bit_identical_after_timed_region": replicas_ok,
             "outer_tasks_per_sec_weak": tasks * world * opt.steps / elapsed if scaling == "weak" else None}
         if replicas_ok is False:
@@ -345,7 +351,7 @@ def main():
                 # the op runs on the frame window (H x W) or, with --sepconv-window 0, on the reference's padded canvas
                 oh, ow = (H, W) if args.sepconv_window else net.padded_size(H, W)
                 traffic, tnote = None, "no committed PMC measurement found"
-                for tname in ("r04_hbm_traffic_sepconv_frames8.json", "r04_hbm_traffic_sepconv.json", "r03_hbm_traffic_sepconv.json", "r02_hbm_traffic_sepconv.json", "r01_hbm_traffic_sepconv.json"):
+                for tname in ("r05_hbm_traffic_sepconv.json", "r04_hbm_traffic_sepconv_frames8.json", "r04_hbm_traffic_sepconv.json", "r03_hbm_traffic_sepconv.json", "r02_hbm_traffic_sepconv.json", "r01_hbm_traffic_sepconv.json"):
                     tpath = os.path.join(REPO, "profiles", tname)
                     if not os.path.exists(tpath):
                         continue
@@ -353,7 +359,8 @@ def main():
                     # FETCH_SIZE x2 per the gfx950 calibration), scaled to this run's launch mix through the measured
                     # traffic / algorithmic ratio of the shape
                     tk = json.load(open(tpath))["kernels"]
-                    keys = [kk for kk in tk if kk.startswith("sepconv_bwd_B") and kk.endswith("_%dx%d" % (oh, ow))]
+                    keys = ([kk for kk in tk if kk.startswith("sepconv_bwd_pairB") and kk.endswith("_%dx%d" % (oh, ow))]
+                            or [kk for kk in tk if kk.startswith("sepconv_bwd_B") and kk.endswith("_%dx%d" % (oh, ow))])
                     if keys:
                         ratio = sum(tk[kk]["traffic_over_algorithmic"] for kk in keys) / len(keys)
                         traffic = ratio * k["algorithmic_bytes"] / k["launches"]
@@ -361,18 +368,19 @@ def main():
                         break
                 per_call = 4.0 * (3 * (oh + 50) * (ow + 50) + 4 * 51 * oh * ow + 3 * oh * ow)
                 line["roofline"] = {
-                    "bound": "hbm", "kernel": "sepconv_bwd_ws<U8> (gV+gH, K=51; csrc/sepconv_ws.hip: frames of 8-bit images as exact integers x split-bf16 taps "
-                                              "on MFMAs, MFMA waves + staging waves in pairs, taps and inner-loop tap gradients unit-major; the timed interval "
-                                              "also holds the six-product instance's early exit: both are launched, the device picks)",
+                    "bound": "hbm", "kernel": "sepconv_bwd_ws<U8, DMA> (gV+gH, K=51; csrc/sepconv_ws.hip: frames of 8-bit images as exact integers x split-bf16 "
+                                              "taps on MFMAs, MFMA waves + staging waves in pairs, taps / cotangent / window rows fetched by LDS-DMA two units "
+                                              "ahead, taps and inner-loop tap gradients unit-major, both local convolutions of the tail in one launch; the "
+                                              "timed interval also holds the six-product instance's early exit: both are launched, the device picks)",
                     "achieved": k["achieved_GBps"], "peak": 8000.0, "unit": "GB/s",
                     "frac": k["achieved_GBps"] / 8000.0, "traffic": traffic, "traffic_source": tnote,
                     "avg_us_per_launch": k["avg_us"], "launches": k["launches"],
                     "algorithmic_bytes_per_launch": k["algorithmic_bytes"] / k["launches"],
-                    "note": "algorithmic bytes = %.2f MB per [1,3,%d,%d] sample (x samples per launch: tasks in lockstep x the "
-                            "support pair); 132 bf16 MFMAs per 16 pixels (the MFMA waves alone sustain 124 us per B = 8 launch); the launch is bound by the "
-                            "staging waves' tap loads and gradient stores backing up in the memory pipeline (with every load hitting the cache: 137 us in "
-                            "this loop on planar taps); taps and, in the inner loop (10 of 12 launches), their gradients are unit-major -- contiguous runs "
-                            "instead of 64-byte pieces of planes a multiple of 64 KB apart (DESIGN.md 4g, 9; profiles/r04_frames8_experiments.txt)"
+                    "note": "algorithmic bytes = %.2f MB per local convolution of one [1,3,%d,%d] sample (x tasks in lockstep x the support "
+                            "pair x the two local convolutions of the tail per launch: 5 inner-loop launches of 16 and 1 outer-pass launch of 8 "
+                            "per meta-iteration); 132 bf16 MFMAs per 16 pixels.  A copy kernel of the same chunked footprint reaches 5.2 TB/s = "
+                            "0.65 of the 8 TB/s this fraction is taken against on these boxes (torch's device copy: 5.3; tools/r5/membench.hip), "
+                            "the kernel's HBM traffic is 1.1 x its algorithmic bytes (DESIGN.md 4h; profiles/r05_*)"
                             % (per_call / 1e6, oh, ow)}
             elif summ:
                 # workloads without the 51-tap op: the HBM-bound savfi kernel that takes the most time in the timed region

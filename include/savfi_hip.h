@@ -90,6 +90,9 @@ int savfi_sepconv_bwd_f32(const float* in, const float* v, const float* h, const
  * a [B * 4, K, Ho, Wo] tensor (sample 4 b + s = sub-network s) that the two local convolutions read -- and their filter gradients write --
  * in place with tap_bstride = 4 * K.  K = 51, C = 3, Wo % 4 == 0, every tensor below 2^31 bytes; SAVFI_E_UNSUPPORTED otherwise (the
  * caller copies the slices and uses the contiguous entry points).  No gI (frames carry no gradient on this path). */
+/* 1 when the strided / frames8 / pair entry points take the problem in this process (shapes, sizes AND the A/B environment switches that
+ * make them return SAVFI_E_UNSUPPORTED), 0 otherwise: what a caller asks before it chooses the interleaved tap tensor. */
+int savfi_sepconv_taps_strided_supported(int B, int C, int Ho, int Wo, int K, int tap_bstride);
 int savfi_sepconv_fwd_taps_strided_f32(const float* in, const float* v, const float* h, float* out, int B, int C, int Ho, int Wo, int K,
                                        int tap_bstride, void* stream);
 int savfi_sepconv_bwd_taps_strided_f32(const float* in, const float* v, const float* h, const float* gO, float* gV, float* gH, int B,

@@ -37,6 +37,7 @@ _PROTOTYPES = {
     "savfi_version": [],
     "savfi_sepconv_fwd_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P],
     "savfi_sepconv_bwd_f32": [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P],
+    "savfi_sepconv_taps_strided_supported": [c_int] * 6,
     "savfi_sepconv_fwd_taps_strided_f32": [_P, _P, _P, _P] + [c_int] * 6 + [_P],
     "savfi_sepconv_bwd_taps_strided_f32": [_P, _P, _P, _P, _P, _P] + [c_int] * 6 + [_P],
     "savfi_frames8_classify_f32": [_P, c_int64, _P, _P],

@@ -1158,6 +1158,12 @@ static int taps_strided_ok(int B, int C, int Ho, int Wo, int K, int tap_bstride)
   return SAVFI_OK;
 }
 
+// 1: the strided / frames8 / pair entry points take this problem NOW (shapes, sizes and the A/B switches of this process:
+// SAVFI_SEPCONV_NO_WS, _NO_WS_FWD, _NO_MFMA, _TILED, _F32_MFMA make them refuse), 0: the caller uses the contiguous entry points
+extern "C" int savfi_sepconv_taps_strided_supported(int B, int C, int Ho, int Wo, int K, int tap_bstride) {
+  return taps_strided_ok(B, C, Ho, Wo, K, tap_bstride) == SAVFI_OK && !sepconv_env().no_ws_fwd ? 1 : 0;
+}
+
 extern "C" int savfi_sepconv_fwd_taps_strided_f32(const float* in, const float* v, const float* h, float* out, int B, int C, int Ho, int Wo,
                                                   int K, int tap_bstride, void* stream) {
   if (!in || !v || !h || !out) return SAVFI_E_NULL;

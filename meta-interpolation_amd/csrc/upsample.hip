@@ -11,6 +11,8 @@
 //   i0 = (int)src, i1 = i0 + (i0 < in-1), l1 = src - i0, l0 = 1 - l1
 // Backward is a gather (no atomics, deterministic): every input pixel visits the <= 6 output rows/columns
 // whose i0 / i1 can equal it and re-evaluates the forward's weights.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -228,6 +230,105 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_tiled(const float* __restr
   }
 }
 
+// The same adjoint as a stream (round 5): a WAVE owns a strip of 64 source columns x USR source rows and walks down the <= 2 USR + 5 output
+// rows it can touch, four at a time: the rows' <= 132 columns come in as three coalesced dword loads per lane, pass through a wave-private
+// LDS row (no workgroup barrier: a wave's DS operations execute in order), every lane folds its six x candidates, and the row's sum goes
+// to the one or two source rows it belongs to (src(oy)'s i0 / i1: exactly the candidates of the tiled form that weigh non-zero) -- three
+// rolling accumulators, a finished source row leaves as one coalesced 256-byte store.  Same candidates, weights and order of the sums as
+// upsample2x_bwd / _tiled (bit-identical); the tiled form moved 10.5 KB in and 2 KB out per workgroup behind two barriers and reached
+// 2.1 - 2.4 TB/s on the large maps (profiles/r05_upsample_bench.txt).
+#ifndef SAVFI_USR
+#define SAVFI_USR 32
+#endif
+constexpr int USR = SAVFI_USR, USW = 64, USB = 4, USP = 2 * USW + 8;        // strip rows / columns, output rows per batch, LDS row pitch (floats)
+__global__ __launch_bounds__(256) void upsample2x_bwd_strip(const float* __restrict__ gout, float* __restrict__ gin, Win g) {
+  __shared__ float rows[4][USB][USP];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int Ho = 2 * g.H, Wo = 2 * g.W;
+  const int strips_x = (g.Ws + USW - 1) / USW, strips_y = (g.Hs + USR - 1) / USR;
+  const int strip = blockIdx.x * 4 + w;
+  if (strip >= strips_x * strips_y) return;                 // (whole waves leave: no barrier below)
+  const int sy = strip / strips_x, sx = strip - sy * strips_x;
+  const int cx = sx * USW + lane, cy_a = sy * USR, cy_b = min(cy_a + USR, g.Hs);
+  const bool col_ok = cx < g.Ws;
+  const int ix = g.sx0 + min(cx, g.Ws - 1);
+  const int ix_first = g.sx0 + sx * USW, ix_last = g.sx0 + min(sx * USW + USW, g.Ws) - 1;
+  const int iy_a = g.sy0 + cy_a, iy_b = g.sy0 + cy_b;       // virtual source rows [iy_a, iy_b)
+  const float* gp = gout + (size_t)blockIdx.y * g.Hw * g.Ww;
+  float* gq = gin + (size_t)blockIdx.y * g.Hs * g.Ws;
+  const float sh = scale_of(g.H, Ho, g.align), sw = scale_of(g.W, Wo, g.align);
+  constexpr int NC = 6;
+  const int oy_end = g.oy0 + g.Hw - 1, ox_end = g.ox0 + g.Ww - 1;
+  const int row_lo = max(g.oy0, 2 * iy_a - 2), row_hi = min(oy_end, 2 * (iy_b - 1) + 3);
+  const int col_lo = max(g.ox0, 2 * ix_first - 2), col_hi = min(ox_end, 2 * ix_last + 3);
+  const int ox_lo = max(g.ox0, 2 * ix - 2), ox_hi = min(ox_end, 2 * ix + 3);
+  float wxs[NC];
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    const int ox = ox_lo + k;
+    float wgt = 0.f;
+    if (ox <= ox_hi) {
+      const Src s = source(ox, g.W, sw, g.align);
+      wgt = (s.i0 == ix ? s.l0 : 0.f) + (s.i1 == ix ? s.l1 : 0.f);
+    }
+    wxs[k] = wgt;
+  }
+  const int rel = ox_lo - col_lo;                           // the lane's first candidate inside the staged row
+  const int ncol = col_hi - col_lo + 1;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f;                       // source rows cur, cur + 1, cur + 2
+  int cur = iy_a;
+  auto emit = [&]() {                                        // source row `cur` is complete
+    if (col_ok) gq[(size_t)(cur - g.sy0) * g.Ws + cx] = a0;
+    a0 = a1; a1 = a2; a2 = 0.f; ++cur;
+  };
+  for (int r0 = row_lo; r0 <= row_hi; r0 += USB) {
+    float gl[USB][3];
+#pragma unroll
+    for (int b = 0; b < USB; ++b) {
+      const int oy = min(r0 + b, row_hi);
+      const float* src = gp + (size_t)(oy - g.oy0) * g.Ww + (col_lo - g.ox0);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int col = lane + 64 * c;
+        gl[b][c] = col < ncol ? src[col] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < USB; ++b) {
+      rows[w][b][lane] = gl[b][0];
+      rows[w][b][lane + 64] = gl[b][1];
+      if (lane < USP - 128) rows[w][b][lane + 128] = gl[b][2];
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int b = 0; b < USB; ++b) {
+      const int oy = r0 + b;
+      if (oy > row_hi) break;
+      while (cur < iy_b && oy > min(oy_end, 2 * cur + 3)) emit();
+      const float* row = &rows[w][b][rel];
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < NC; ++k)
+        if (ox_lo + k <= ox_hi) t = fmaf(wxs[k], row[k], t);
+      const Src s = source(oy, g.H, sh, g.align);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int iy = e == 0 ? s.i0 : s.i1;
+        if (e == 1 && s.i1 == s.i0) break;
+        const float wy = (s.i0 == iy ? s.l0 : 0.f) + (s.i1 == iy ? s.l1 : 0.f);
+        // a candidate of source row iy in the tiled form: oy inside [2 iy - 2, 2 iy + 3] (it always is, by construction of that window)
+        if (wy == 0.f || iy < cur || iy >= iy_b || oy < 2 * iy - 2 || oy > 2 * iy + 3) continue;
+        const int d = iy - cur;
+        if (d == 0) a0 = fmaf(wy, t, a0);
+        else if (d == 1) a1 = fmaf(wy, t, a1);
+        else a2 = fmaf(wy, t, a2);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  while (cur < iy_b) emit();
+}
+
 // host mirror of source(): first / last source index an output range touches
 void touched(int o_first, int o_last, int in, int out, int align, int* lo, int* hi) {
   const float scale = align ? (out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f) : 0.5f;
@@ -273,7 +374,11 @@ extern "C" int savfi_upsample2x_window_bwd_f32(const float* gout, float* gin, in
   if (!gout || !gin) return SAVFI_E_NULL;
   const Win g{H, W, sy0, sx0, Hs, Ws, oy0, ox0, Hw, Ww, align_corners ? 1 : 0};
   if (int rc = check_window(g, planes)) return rc;
-  if (Ws >= 32) {      // wide enough to fill 64-column tiles reasonably: the separable, LDS-tiled form
+  static const int form = getenv("SAVFI_UPSAMPLE_BWD_FORM") ? atoi(getenv("SAVFI_UPSAMPLE_BWD_FORM")) : 0;      // A/B: 1 = the tiled form of rounds 2-4
+  if (Ws >= 32 && form != 1) {      // the streaming form: a wave per strip of 64 columns
+    dim3 grid(savfi_cdiv(savfi_cdiv(Ws, USW) * savfi_cdiv(Hs, USR), 4), planes, 1);
+    hipLaunchKernelGGL(upsample2x_bwd_strip, grid, dim3(256), 0, (hipStream_t)stream, gout, gin, g);
+  } else if (Ws >= 32) {      // the separable, LDS-tiled form
     dim3 grid(savfi_cdiv(Hs, UBH) * savfi_cdiv(Ws, UBW), planes, 1);
     hipLaunchKernelGGL(upsample2x_bwd_tiled, grid, dim3(256), 0, (hipStream_t)stream, gout, gin, g);
   } else {

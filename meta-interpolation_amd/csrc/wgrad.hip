@@ -316,6 +316,13 @@ extern "C" int savfi_conv3x3_wgrad_tasks_f32(const float* x, const float* gz, fl
   const int ntiles = p.cobs * p.cibs;
   const size_t block_floats = (size_t)ntiles * TILE_FLOATS;
   float* stage2 = workspace + p.partial_floats;
+  if (p.ngroups == 1) {
+    // at most RG splits: the blocks of the splits are laid out like the blocks of the groups, and level 2 adds them in the order level 1
+    // would have (0 + p0 + p1 ...): one launch instead of two, the same bits (round 5: 276 reduction launches per C2 iteration)
+    hipLaunchKernelGGL(wgrad_reduce2, dim3(savfi_cdiv(Co * Ci * 9, 256), T), dim3(256), 0, st, workspace, gw, Co, Ci, p.cibs, ntiles,
+                       (int)p.splits);
+    return savfi_launch_status();
+  }
   hipLaunchKernelGGL(wgrad_reduce1, dim3((unsigned)((block_floats / 4 + 255) / 256), p.ngroups, T), dim3(256), 0, st, workspace,
                      stage2, block_floats, (int)p.splits);
   if (int e = savfi_launch_status()) return e;
@@ -670,6 +677,11 @@ extern "C" int savfi_conv3x3_wgrad_wino_tasks_f32(const float* x, const float* g
   const int ntiles = p.cobs * p.cibs;
   const size_t block_floats = (size_t)ntiles * WW_BLOCK_FLOATS;
   float* stage2 = workspace + p.partial_floats;
+  if (p.ngroups == 1) {      // at most RG splits: level 2 alone, on the splits' blocks (see savfi_conv3x3_wgrad_tasks_f32)
+    hipLaunchKernelGGL(wino_wgrad_reduce2, dim3(savfi_cdiv(Co * Ci * 9, 256), T), dim3(256), 0, st, workspace, gw, Co, Ci, p.cibs, ntiles,
+                       p.nsplit);
+    return savfi_launch_status();
+  }
   hipLaunchKernelGGL(wgrad_reduce1, dim3((unsigned)((block_floats / 4 + 255) / 256), p.ngroups, T), dim3(256), 0, st, workspace,
                      stage2, block_floats, p.nsplit);
   if (int e = savfi_launch_status()) return e;

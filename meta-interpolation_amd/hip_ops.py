@@ -1130,24 +1130,55 @@ def refresh_module_filters(modules):
             m._filters[(kind, w.data_ptr(), w._version, tuple(w.shape), w.device.index, st)] = made
 
 
+# Memory-layout tags.  Two tensors of the SepConv tail keep the shape [4N, 51, H, W] while their MEMORY is unit-major, [H][W / 16][51][16]
+# per sample: the taps between the last Subnet convolution and FunctionSepconvPair, and their cotangent on the way back.
+# The layout travels as an attribute of the tensor object; producer and consumer name what they write / expect, and a tensor that reaches
+# a consumer with another tag -- or a unit-major one that reaches a consumer which knows nothing of tags after a hook, a clone or a sum
+# replaced the object -- fails here instead of being read as scrambled numbers.
+UNIT16 = "unit16"
+
+
+def tag_layout(t, layout):
+    t._savfi_layout = layout
+    return t
+
+
+def layout_of(t):
+    return getattr(t, "_savfi_layout", None)
+
+
+def require_layout(t, layout, what):
+    got = layout_of(t)
+    if got != layout:
+        raise SavfiLayoutError("%s: memory layout %r expected, the tensor is tagged %r (a unit-major tensor keeps the shape [N,51,H,W] "
+                               "while its memory is [N][H][W/16][51][16]; only its producer's partner may read it)" % (what, layout, got))
+
+
+class SavfiLayoutError(RuntimeError):
+    pass
+
+
 # Long-lived constant weights (sepconv/model.py: the four sub-networks' own parameters stacked into one task-batched layer; rebuilt when a
 # parameter changes): their packed / transformed filters are made once per tensor, whichever function asks.  Keyed on the data pointer of a
 # tensor the registry keeps alive, so the pointer cannot be recycled while the entry exists.
 _const_weights = {}
+_const_weights_lock = threading.Lock()      # --task_streams: the per-task Python threads register / evict concurrently
 
 
 _CONST_WEIGHTS_MAX = 64         # a model that goes away without unregistering leaves its entries behind: oldest out (16 per SepConv net and stream)
 
 
 def register_const_weight(w):
-    while len(_const_weights) >= _CONST_WEIGHTS_MAX:
-        _const_weights.pop(next(iter(_const_weights)))
-    _const_weights[w.data_ptr()] = [w, w._version, {}]
+    with _const_weights_lock:
+        while len(_const_weights) >= _CONST_WEIGHTS_MAX:
+            _const_weights.pop(next(iter(_const_weights)), None)
+        _const_weights[w.data_ptr()] = [w, w._version, {}]
     return w
 
 
 def unregister_const_weight(w):
-    _const_weights.pop(w.data_ptr(), None)
+    with _const_weights_lock:
+        _const_weights.pop(w.data_ptr(), None)
 
 
 def _const_filters(kind, weight, fwd, bwd, make):
@@ -1546,12 +1577,17 @@ class _ConvBiasActTasks(torch.autograd.Function):
         ctx.wg_stream = weight_gradient_stream() if x.is_cuda else None
         ctx.wg_uses = _weight_use_counter(w) if ctx.wg_stream is not None else None
         ctx.save_for_backward(x, w, z)
+        if out_unit16:
+            tag_layout(z, UNIT16)           # the tensor's shape does not say how its memory is laid out: its consumer checks the tag
         return z
 
     @staticmethod
     def backward(ctx, gy):
         x, w, y = ctx.saved_tensors
         stride, padding, dilation, slope = ctx.conf
+        # the cotangent's memory layout is a contract between two autograd functions that its shape cannot carry: the producer tags the
+        # tensor, and anything in between (a hook, an accumulation of two consumers' gradients, a clone) loses or contradicts the tag
+        require_layout(gy, UNIT16 if ctx.gy_unit16 else None, "the cotangent of conv_bias_act_tasks(out_unit16=%d)" % (2 if ctx.gy_unit16 else 1))
         gy = gy.contiguous()
         T, Co, Ci = w.shape[:3]
         N, _, Ho, Wo = y.shape
@@ -1644,8 +1680,9 @@ def conv_bias_act_tasks(x, weight, bias, stride=1, padding=0, dilation=1, slope=
                         out_unit16=False):
     """act(conv2d(x[s], weight[s % T]) + bias[s % T]): the lockstep form of conv_bias_act (`in_slope`, `defer`: conv_bias_act).
     `out_unit16`: the result's memory is unit-major (conv3x3_tasks_pre; only after conv3x3_unit16_supported said yes, slope 1)."""
-    return _ConvBiasActTasks.apply(x, weight, bias, stride, padding, dilation, float(slope), bool(direct),
-                                   None if in_slope is None else float(in_slope), bool(defer), int(out_unit16))
+    z = _ConvBiasActTasks.apply(x, weight, bias, stride, padding, dilation, float(slope), bool(direct),
+                                None if in_slope is None else float(in_slope), bool(defer), int(out_unit16))
+    return tag_layout(z, UNIT16) if out_unit16 else z
 
 
 @functools.lru_cache(maxsize=None)

@@ -27,7 +27,8 @@ def frames8_supported(frame, B, C, Ho, Wo, K, tap_bstride=None):
     """shapes savfi_sepconv_*_frames8_f32 take (the wave-specialised kernels: K = 51, C = 3, Wo % 4 == 0, taps below 2^31 bytes)"""
     tb = K if tap_bstride is None else tap_bstride
     return (FRAMES8 and frame.is_cuda and frame.dtype == torch.float32 and K == 51 and C == 3 and Wo % 4 == 0
-            and ((B - 1) * tb + K) * Ho * Wo * 4 < 2 ** 31)
+            and ((B - 1) * tb + K) * Ho * Wo * 4 < 2 ** 31
+            and _hip.lib().savfi_sepconv_taps_strided_supported(B, C, Ho, Wo, K, tb) == 1)     # (the process's A/B switches included)
 
 
 def frames8_classify(frame):
@@ -143,7 +144,10 @@ class FunctionSepconvPair(torch.autograd.Function):
         """Can the strided entry points take `batch` samples of a [*, 3, height, width] frame (savfi_sepconv_*_taps_strided_f32: the
         wave-specialised kernels -- K = 51, C = 3, width % 4 == 0, the interleaved tap tensor below 2^31 bytes)?"""
         return (frame.is_cuda and frame.dtype == torch.float32 and frame.size(1) == 3 and taps == 51 and width % 4 == 0
-                and 4 * batch * taps * height * width * 4 < 2 ** 31)
+                and 4 * batch * taps * height * width * 4 < 2 ** 31
+                # ... and the library takes it in this process: the A/B switches (SAVFI_SEPCONV_NO_WS, _NO_MFMA, ...) make the strided
+                # entry points refuse, and this op has no other path -- the caller then runs the Subnets one by one
+                and _hip.lib().savfi_sepconv_taps_strided_supported(batch, 3, height, width, taps, 4 * taps) == 1)
 
     @staticmethod
     def forward(ctx, input0, input1, taps, taps_unit16=False, grads_unit16=False):
@@ -151,6 +155,8 @@ class FunctionSepconvPair(torch.autograd.Function):
         K, Ho, Wo = taps.shape[1:]
         assert input1.shape == input0.shape and taps.size(0) == 4 * B and Hi - K == Ho - 1 and Wi - K == Wo - 1, (input0.shape, taps.shape)
         assert input0.is_contiguous() and input1.is_contiguous() and taps.is_contiguous()
+        from ... import hip_ops
+        hip_ops.require_layout(taps, hip_ops.UNIT16 if taps_unit16 else None, "FunctionSepconvPair(taps_unit16=%s): taps" % bool(taps_unit16))
         _hip.require_cuda(input0, input1, taps)
         out0 = torch.empty((B, C, Ho, Wo), dtype=input0.dtype, device=input0.device)
         out1 = torch.empty_like(out0)
@@ -192,6 +198,7 @@ class FunctionSepconvPair(torch.autograd.Function):
         K, Ho, Wo = taps.shape[1:]
         gradOutput = gradOutput.contiguous()
         _hip.require_cuda(gradOutput)
+        from ... import hip_ops
         gT = torch.empty_like(taps)
         lib, st = _hip.lib(), _hip.current_stream()
         plane = K * Ho * Wo * 4
@@ -201,6 +208,8 @@ class FunctionSepconvPair(torch.autograd.Function):
                 input0.data_ptr(), input1.data_ptr(), taps.data_ptr(), gradOutput.data_ptr(), gT.data_ptr(), words[0].data_ptr(),
                 words[1].data_ptr(), B, C, Ho, Wo, K, ctx.taps_unit16, st), "savfi_sepconv_bwd_pair_frames8_f32"),
                 nbytes=2 * algorithmic_bytes(B, C, Ho, Wo, K, grads=2))
+            if ctx.taps_unit16 & 2:
+                hip_ops.tag_layout(gT, hip_ops.UNIT16)
             return None, None, gT, None, None
         for i, (inp, s) in enumerate(((input0, 0), (input1, 2))):
             if words is not None:
@@ -213,6 +222,8 @@ class FunctionSepconvPair(torch.autograd.Function):
                     inp.data_ptr(), taps.data_ptr() + s * plane, taps.data_ptr() + (s + 1) * plane, gradOutput.data_ptr(),
                     gT.data_ptr() + s * plane, gT.data_ptr() + (s + 1) * plane, B, C, Ho, Wo, K, 4 * K, st),
                     "savfi_sepconv_bwd_taps_strided_f32"), nbytes=algorithmic_bytes(B, C, Ho, Wo, K, grads=2))
+        if ctx.taps_unit16 & 2:
+            hip_ops.tag_layout(gT, hip_ops.UNIT16)
         return None, None, gT, None, None
 
 

@@ -359,3 +359,38 @@ def test_pair_launch_gives_the_bits_of_the_two_launches(B, Ho, Wo, f8, u16):
     assert lib.savfi_sepconv_bwd_pair_frames8_f32(frames[0].data_ptr(), frames[1].data_ptr(), taps.data_ptr(), gO.data_ptr(), one.data_ptr(),
                                                   words[0].data_ptr(), words[1].data_ptr(), B, 3, Ho, Wo - 1, K, 0, st) == -3
     assert lib.savfi_sepconv_ws_errors() == 0
+
+
+def test_a_unit_major_tensor_that_loses_its_tag_is_refused():
+    """The taps and their cotangent keep the shape [4N,51,H,W] while their memory is unit-major; producer and consumer agree through a
+    tag on the tensor object (hip_ops.tag_layout / require_layout).  A clone, a hook's replacement or a sum of two consumers' gradients
+    carries no tag -- or a planar consumer meets a tagged tensor -- and the consumer raises instead of reading scrambled numbers."""
+    from meta_interpolation_amd import hip_ops
+    B, T, C, Ho, Wo = 1, 4, K, 96, 128
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(B * T, C, Ho + 2, Wo + 2, generator=g).to(DEV)
+    w = (torch.randn(T, K, C, 3, 3, generator=g) / (3 * math.sqrt(C))).to(DEV)
+    b = (torch.randn(T, K, generator=g) * 0.1).to(DEV)
+    f0 = torch.randint(0, 256, (B, 3, Ho + K - 1, Wo + K - 1), generator=g).float().div(255).to(DEV)
+    gO = torch.randn(B, 3, Ho, Wo, generator=g).to(DEV)
+    taps = hip_ops.conv_bias_act_tasks(x, w, b, 1, 0, 1, 1.0, False, None, False, 1)
+    assert hip_ops.layout_of(taps) == hip_ops.UNIT16
+    with pytest.raises(hip_ops.SavfiLayoutError):
+        S.FunctionSepconvPair.apply(f0, f0, taps.clone(), True)            # the clone has the bytes but not the tag
+    with pytest.raises(hip_ops.SavfiLayoutError):
+        S.FunctionSepconvPair.apply(f0, f0, taps, False)                   # a planar reader of a unit-major tensor
+    planar = hip_ops.conv_bias_act_tasks(x, w, b, 1, 0, 1, 1.0, False, None, False, 0)
+    with pytest.raises(hip_ops.SavfiLayoutError):
+        S.FunctionSepconvPair.apply(f0, f0, planar, True)                  # a unit-major reader of a planar tensor
+    # the cotangent: a hook that replaces it (here: by an equal copy) breaks the contract of out_unit16 = 2, and the backward says so
+    xs = x.clone().requires_grad_()
+    taps = hip_ops.conv_bias_act_tasks(xs, w, b, 1, 0, 1, 1.0, False, None, False, 2)
+    taps.register_hook(lambda gr: gr.clone())
+    out = S.FunctionSepconvPair.apply(f0, f0, taps, True, True)
+    with pytest.raises(hip_ops.SavfiLayoutError):
+        out.backward(gO)
+    # ... and untouched it goes through
+    xs = x.clone().requires_grad_()
+    taps = hip_ops.conv_bias_act_tasks(xs, w, b, 1, 0, 1, 1.0, False, None, False, 2)
+    S.FunctionSepconvPair.apply(f0, f0, taps, True, True).backward(gO)
+    assert xs.grad is not None and torch.isfinite(xs.grad).all()

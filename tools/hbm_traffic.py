@@ -16,6 +16,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CAL_BYTES = 512 * 1024 * 1024
 # (B, Ho, Wo): the full padded canvas of the reference and the frame window this build evaluates (sepconv/model.py)
 CASES = [(1, 384, 512), (1, 256, 448), (2, 256, 448), (4, 256, 448), (8, 256, 448)]     # B = 8 / 4: lockstep support / target pass
+# (B, Ho, Wo, pair): the pair launches of the plugin's tail (savfi_sepconv_{fwd,bwd}_pair_frames8_f32: both local convolutions of B samples)
+PAIR_CASES = [(4, 256, 448), (8, 256, 448)]
 
 
 def mfma_rows(B, Ho, Wo):
@@ -54,6 +56,21 @@ def run():
             assert lib.savfi_sepconv_bwd_frames8_f32(inp.data_ptr(), v.data_ptr(), h.data_ptr(), gO.data_ptr(), gV.data_ptr(), gH.data_ptr(),
                                                      words.data_ptr(), B, C, Ho, Wo, K, K, 3, st) == 0   # taps and gradients unit-major (inner loop)
         torch.cuda.synchronize()
+    for (B, Ho, Wo) in PAIR_CASES:
+        C, K = 3, 51
+        fr = [torch.randint(0, 256, (B, C, Ho + K - 1, Wo + K - 1), device='cuda').float().div(255) for _ in range(2)]
+        words = [torch.empty(256, dtype=torch.int32, device='cuda') for _ in range(2)]
+        for f, wd in zip(fr, words):
+            lib.savfi_frames8_classify_f32(f.data_ptr(), f.numel(), wd.data_ptr(), st)
+        taps = torch.randn(4 * B, K, Ho, Wo, device='cuda') / 7
+        gO = torch.randn(B, C, Ho, Wo, device='cuda')
+        out2, gT = torch.empty(B, 2, C, Ho, Wo, device='cuda'), torch.empty_like(taps)
+        for _ in range(3):
+            assert lib.savfi_sepconv_fwd_pair_frames8_f32(fr[0].data_ptr(), fr[1].data_ptr(), taps.data_ptr(), out2.data_ptr(), words[0].data_ptr(),
+                                                          words[1].data_ptr(), B, C, Ho, Wo, K, 1, st) == 0
+            assert lib.savfi_sepconv_bwd_pair_frames8_f32(fr[0].data_ptr(), fr[1].data_ptr(), taps.data_ptr(), gO.data_ptr(), gT.data_ptr(),
+                                                          words[0].data_ptr(), words[1].data_ptr(), B, C, Ho, Wo, K, 3, st) == 0
+        torch.cuda.synchronize()
 
 
 def _collect(d, counter):
@@ -89,13 +106,14 @@ def parse(dfetch, dwrite):
                                                        "WRITE_SIZE_KiB": cal_w, "fetch_correction": corr_f,
                                                        "write_correction": corr_w}, "kernels": {}}
     for (kind, ci), val in sorted(f.items()):
-        if kind == 'copy' or ci >= len(CASES):
+        if kind == 'copy' or ci >= len(CASES) + len(PAIR_CASES):
             continue
         wv = w.get((kind, ci), 0.0)
-        B, Ho, Wo = CASES[ci]
-        alg = algorithmic_bytes(B, 3, Ho, Wo, 51, grads=2 if kind == 'sepconv_bwd' else 0)
+        pair = ci >= len(CASES)
+        B, Ho, Wo = PAIR_CASES[ci - len(CASES)] if pair else CASES[ci]
+        alg = (2 if pair else 1) * algorithmic_bytes(B, 3, Ho, Wo, 51, grads=2 if kind == 'sepconv_bwd' else 0)
         rd, wr = val * 1024 * corr_f, wv * 1024 * corr_w
-        res["kernels"]["%s_B%d_%dx%d" % (kind, B, Ho, Wo)] = {
+        res["kernels"]["%s_%sB%d_%dx%d" % (kind, "pair" if pair else "", B, Ho, Wo)] = {
             "FETCH_SIZE_KiB": val, "WRITE_SIZE_KiB": wv, "hbm_read_bytes": rd, "hbm_write_bytes": wr, "traffic": rd + wr,
             "algorithmic_bytes": alg, "traffic_over_algorithmic": (rd + wr) / alg}
     print(json.dumps(res, indent=1))
