@@ -237,11 +237,9 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_tiled(const float* __restr
 // rolling accumulators, a finished source row leaves as one coalesced 256-byte store.  Same candidates, weights and order of the sums as
 // upsample2x_bwd / _tiled (bit-identical); the tiled form moved 10.5 KB in and 2 KB out per workgroup behind two barriers and reached
 // 2.1 - 2.4 TB/s on the large maps (profiles/r05_upsample_bench.txt).
-#ifndef SAVFI_USR
-#define SAVFI_USR 32
-#endif
-constexpr int USR = SAVFI_USR, USW = 64, USB = 4, USP = 2 * USW + 8;        // strip rows / columns, output rows per batch, LDS row pitch (floats)
-__global__ __launch_bounds__(256) void upsample2x_bwd_strip(const float* __restrict__ gout, float* __restrict__ gin, Win g) {
+constexpr int USW = 64, USB = 4, USP = 2 * USW + 8;        // strip columns, output rows per batch, LDS row pitch (floats)
+// USR: source rows per strip (the host picks 32, 16 or 8: enough waves to hide the walk's latency -- a wave's batches are serial)
+__global__ __launch_bounds__(256) void upsample2x_bwd_strip(const float* __restrict__ gout, float* __restrict__ gin, Win g, int USR) {
   __shared__ float rows[4][USB][USP];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int Ho = 2 * g.H, Wo = 2 * g.W;
@@ -281,8 +279,8 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_strip(const float* __restr
     if (col_ok) gq[(size_t)(cur - g.sy0) * g.Ws + cx] = a0;
     a0 = a1; a1 = a2; a2 = 0.f; ++cur;
   };
-  for (int r0 = row_lo; r0 <= row_hi; r0 += USB) {
-    float gl[USB][3];
+  float gnext[USB][3];
+  auto load_batch = [&](int r0) {
 #pragma unroll
     for (int b = 0; b < USB; ++b) {
       const int oy = min(r0 + b, row_hi);
@@ -290,9 +288,18 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_strip(const float* __restr
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         const int col = lane + 64 * c;
-        gl[b][c] = col < ncol ? src[col] : 0.f;
+        gnext[b][c] = col < ncol ? src[col] : 0.f;
       }
     }
+  };
+  if (row_lo <= row_hi) load_batch(row_lo);
+  for (int r0 = row_lo; r0 <= row_hi; r0 += USB) {
+    float gl[USB][3];
+#pragma unroll
+    for (int b = 0; b < USB; ++b)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) gl[b][c] = gnext[b][c];
+    if (r0 + USB <= row_hi) load_batch(r0 + USB);           // the next batch's rows are in flight under this batch's folds
 #pragma unroll
     for (int b = 0; b < USB; ++b) {
       rows[w][b][lane] = gl[b][0];
@@ -375,9 +382,14 @@ extern "C" int savfi_upsample2x_window_bwd_f32(const float* gout, float* gin, in
   const Win g{H, W, sy0, sx0, Hs, Ws, oy0, ox0, Hw, Ww, align_corners ? 1 : 0};
   if (int rc = check_window(g, planes)) return rc;
   static const int form = getenv("SAVFI_UPSAMPLE_BWD_FORM") ? atoi(getenv("SAVFI_UPSAMPLE_BWD_FORM")) : 0;      // A/B: 1 = the tiled form of rounds 2-4
-  if (Ws >= 32 && form != 1) {      // the streaming form: a wave per strip of 64 columns
-    dim3 grid(savfi_cdiv(savfi_cdiv(Ws, USW) * savfi_cdiv(Hs, USR), 4), planes, 1);
-    hipLaunchKernelGGL(upsample2x_bwd_strip, grid, dim3(256), 0, (hipStream_t)stream, gout, gin, g);
+  // the streaming form where it has the waves to hide its serial walk (>= 8 per SIMD at some strip height), else the tiled form
+  int usr = 0;
+  for (int cand = 32; cand >= 8 && !usr; cand >>= 1)
+    if ((int64_t)savfi_cdiv(Ws, USW) * savfi_cdiv(Hs, cand) * planes >= 8192) usr = cand;
+  if (form == 2) usr = 32;
+  if (Ws >= 32 && form != 1 && usr) {
+    dim3 grid(savfi_cdiv(savfi_cdiv(Ws, USW) * savfi_cdiv(Hs, usr), 4), planes, 1);
+    hipLaunchKernelGGL(upsample2x_bwd_strip, grid, dim3(256), 0, (hipStream_t)stream, gout, gin, g, usr);
   } else if (Ws >= 32) {      // the separable, LDS-tiled form
     dim3 grid(savfi_cdiv(Hs, UBH) * savfi_cdiv(Ws, UBW), planes, 1);
     hipLaunchKernelGGL(upsample2x_bwd_tiled, grid, dim3(256), 0, (hipStream_t)stream, gout, gin, g);
