@@ -84,8 +84,10 @@ enum { F_TAB_FULL = 0, F_TAB_FREE = 4, F_OUT_FULL = 8, F_OUT_FREE = 12, F_PROG =
 #ifndef WS_EXP_NOAREAD          // the MFMA loops reuse the first unit's A fragments (no LDS reads inside the loops)
 #define WS_EXP_NOAREAD 0
 #endif
+// (nt: the taps are read once.  With both local convolutions in one launch -- 1.5 GB per launch -- the non-temporal fetch is worth 4 %:
+// 306 -> 294.5 us in the bench loop, twice on one box, profiles/r05_dma_policy_ab.txt; on the half-sized launches it was 1 %)
 #ifndef WS_DMA_TAP_POLICY_ID    // cache policy of the tap fetches (DMA kernels): 0 default, 1 nt (non-temporal), 2 sc1, 3 sc1 nt, 4 sc0 sc1
-#define WS_DMA_TAP_POLICY_ID 0
+#define WS_DMA_TAP_POLICY_ID 1
 #endif
 #if WS_DMA_TAP_POLICY_ID == 1
 #define WS_DMA_TAP_POLICY " nt"

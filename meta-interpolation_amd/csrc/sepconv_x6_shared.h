@@ -14,8 +14,10 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #ifndef X6_LOAD_AUX
 #define X6_LOAD_AUX 0
 #endif
+// stores: sc1 (16).  Round 5, pair launches in the bench loop, two repeats on one box (profiles/r05_dma_policy_ab_box2.txt): default 291.9 /
+// 293.7 us, sc1 289.0 / 288.0, nt 292.0 / 294.7 with the half-sized launch 168 -> 191.  (Round 4 on the dword-load kernels: all neutral.)
 #ifndef X6_STORE_AUX
-#define X6_STORE_AUX 0
+#define X6_STORE_AUX 16
 #endif
 
 namespace {
