@@ -200,6 +200,37 @@ __device__ __forceinline__ float ws_wave_sum(float x) {
   return (rl(x, 0) + rl(x, 16)) + (rl(x, 32) + rl(x, 48));
 }
 
+// Six sums over the 64 lanes at once (round 5).  gfx950's v_permlane32_swap / v_permlane16_swap exchange halves / odd and even rows
+// of 16 lanes between two registers: swap + add folds TWO values' halves (rows) and packs the partial sums into one register, so six
+// values need 5 swaps + 5 adds and then ONE row reduction (4 DPP steps) on each of two registers -- 18 instructions where six
+// ws_wave_sum take ~90 (24 of them v_readlane) and 2 300 of the forward's 5 100 cycles per unit on its v-side wave.
+//   q : every lane of row 0 / 1 / 2 / 3 holds the total of x[0] / x[2] / x[1] / x[3];   q2: rows 0 / 2 hold the totals of x[4] / x[5]
+__device__ __forceinline__ void ws_wave_sum6(const float (&x)[6], float& q, float& q2) {
+  auto fold32 = [](float a, float b) {               // lanes 0..31: a[l] + a[l + 32], lanes 32..63: b[l - 32] + b[l]
+    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+    const unsigned r0 = r[0], r1 = r[1];             // (a bit_cast of a vector ELEMENT reads element 0 whatever the index: DESIGN.md 4f)
+    return __builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1);
+  };
+  auto fold16 = [](float a, float b) {               // rows: a.r0 + a.r1, b.r0 + b.r1, a.r2 + a.r3, b.r2 + b.r3
+    const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+    const unsigned r0 = r[0], r1 = r[1];
+    return __builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1);
+  };
+  auto dpp = [](float v, auto ctrl) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xf, 0xf, true));
+  };
+  auto row_sum = [&](float v) {
+    v += dpp(v, std::integral_constant<int, 0xB1>{});      // quad_perm [1,0,3,2]
+    v += dpp(v, std::integral_constant<int, 0x4E>{});      // quad_perm [2,3,0,1]
+    v += dpp(v, std::integral_constant<int, 0x141>{});     // row_half_mirror
+    v += dpp(v, std::integral_constant<int, 0x140>{});     // row_mirror
+    return v;
+  };
+  const float p01 = fold32(x[0], x[1]), p23 = fold32(x[2], x[3]), p45 = fold32(x[4], x[5]);
+  q = row_sum(fold16(p01, p23));
+  q2 = row_sum(fold16(p45, 0.f));
+}
+
 // the lane id through an opaque copy: values derived from it are temporaries of the place that uses them, not kernel-long live
 // ranges (at the 168-register budget of three waves per SIMD the allocator spills hoisted per-lane constants, and one scratch
 // reload in the MFMA wave's path costs a memory round trip: 1 700 cycles in front of a pass)
@@ -504,6 +535,14 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
       __builtin_amdgcn_s_setprio(WS_PRIO);
       unsigned long long tr_[16] = {0}, tlast_ = __builtin_readcyclecounter();
       bf16x8 bq[2][3], aq[NSL][2][NPC];
+      if (WS_EXP_NOAREAD) {                          // (timing / counter experiment: the A fragments are never read)
+#pragma unroll
+        for (int a = 0; a < NSL; ++a)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int pc = 0; pc < NPC; ++pc) aq[a][t][pc] = (bf16x8){1, 2, 3, 4, 5, 6, 7, 8};
+      }
       int rowoff[4], rowh[2][2];
       // the same offsets + 6 planes: a DS instruction's immediate offset is 16 bits and the window is 103 KB -- reads of the third bf16 piece
       // (planes 6..8) through the low bases took a v_add each, inside the MFMA loops (4 per gH block, 2 per gV block)
@@ -540,6 +579,7 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
       auto gv_acc = [](int uu, int t) { return uu < 6 ? 3 * (uu >> 1) + t : uu < 8 ? 3 * t + 2 : (t == 0 ? 8 : 9); };
       auto gv_st = [](int uu) { return uu & 1; };
       auto load_av = [&](int slot, int uu) {           // lane = window row of the tile, 16 B = 8 columns of k group permk
+        if (WS_EXP_NOAREAD) return;
         const int st = gv_st(uu);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -553,6 +593,7 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
         }
       };
       auto load_ah = [&](int slot, int uu) {           // gH: two transpose reads per fragment
+        if (WS_EXP_NOAREAD) return;
         const int c = uu >> 2, st = (uu >> 1) & 1, mp = uu & 1;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -1057,6 +1098,7 @@ __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ 
   float* const side = reinterpret_cast<float*>(smem + FSIDE_OFF);
   unsigned* const fl = reinterpret_cast<unsigned*>(smem + FFLAG_OFF);
 
+  [[maybe_unused]] const unsigned long long t_kernel0 = WS_TRACE ? __builtin_readcyclecounter() : 0ull;
   // a workgroup's phases: positions [g0, g1) of the strip-major order (ws_work_range)
   int g0, g1;
   constexpr int base = 0;
@@ -1151,6 +1193,7 @@ __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ 
     if constexpr (!STG) {
       // =========================================== MFMA wave ===================================================================
       __builtin_amdgcn_s_setprio(WS_PRIO);
+      unsigned long long tr_[16] = {0}, tlast_ = __builtin_readcyclecounter();
       bf16x8 bq[2][3], aq[NSL][2][NPC];
       int rowoff[4], rowoff_hi[4];                   // + 6 planes: the third bf16 piece within a DS immediate offset (see sepconv_bwd_ws)
       auto peek_raw = [&](int idx) { return __hip_atomic_load(fl + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
@@ -1195,6 +1238,7 @@ __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ 
 #pragma unroll 1
       for (int n = 0; n < N; ++n) {
         const int q = n >> 1, u = n & 1;
+        WS_T(0);
         f32x4 acc[10];                                 // [3 c + m] (m < 3), [9] = packed tile (rows 48 + r of channel kg)
 #pragma unroll
         for (int i = 0; i < 10; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1222,6 +1266,7 @@ __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ 
           }
           __builtin_amdgcn_sched_barrier(0);
         }
+        WS_T(1);
         if (u == 1) ws_set(fl, F_PROG + w, q + 1);             // this phase's window reads are over
         // the next unit's h fragments and first A fragments -- before this unit's vertical pass
         if (n + 1 < N) {
@@ -1234,8 +1279,10 @@ __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ 
 #pragma unroll
           for (int d = 0; d < DEPTH; ++d) load_av(d, d);
         }
+        WS_T(2);
         // vertical pass: v of this lane's rows from the pair's v tile
         if ((int)__builtin_amdgcn_readfirstlane((int)pre_vt) < n + 1) ws_wait(fl, F_VT_FULL + p, n + 1);
+        WS_T(3);
         const int lo_ = ws_lane(), jo = lo_ & 15, ko = lo_ >> 4;
         f32x4 vc[4];
 #pragma unroll
@@ -1263,12 +1310,17 @@ __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ 
 #pragma unroll
           for (int c = 0; c < XC; ++c) part[c] *= 1.0f / 255.0f;
         }
+        WS_T(4);
         if ((int)__builtin_amdgcn_readfirstlane((int)pre_op) < n) ws_wait(fl, F_OP_FREE + p, n);
+        WS_T(5);
 #pragma unroll
         for (int c = 0; c < XC; ++c) op[(ko * XC + c) * 16 + jo] = part[c];
         ws_set(fl, F_OP_FULL + p, n + 1);
+        WS_T(6);
       }
       __builtin_amdgcn_s_setprio(0);
+      if (WS_TRACE && blockIdx.x == 0 && lane == 0)
+        for (int k = 0; k < 16; ++k) WS_TRACE_ADD(w, k, tr_[k]);
     } else {
       // =========================================== staging waves ===============================================================
       const bool hside = role == 1;
@@ -1278,12 +1330,19 @@ __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ 
       const int gsidx = gcol == 64 ? 0 : gcol == 65 ? 1 : gcol == 80 ? 2 : gcol == 81 ? 3 : -1;
       const unsigned gcolb = (unsigned)min(x0 + gcol, Wi - 1) * 4u;
       const int gc0 = ggrp == 0 ? 0 : 2, gc1 = ggrp == 0 ? 1 : 2;
+      unsigned long long tr_[16] = {0}, tlast_ = __builtin_readcyclecounter();
       float hreg[XNP][2], vreg[XNP][2];
       if (hside) load_taps(hreg, hsrc, b, x0, unit_y(0), h_t0);
       else load_taps(vreg, vsrc, b, x0, unit_y(0), v_t0);
-      unsigned ooff_prev = X_OOR;
+      unsigned ooff_prev = X_OOR, ooff_prev2 = X_OOR;
+      // The h side hands out the result of unit n - 2 in iteration n, AFTER it has written the table of unit n (round 5).  One unit
+      // behind, its iteration n waited for the MFMA wave's vertical pass of unit n - 1 -- which that wave starts only once it holds the
+      // table of unit n -- and wrote the table of unit n + 1 after that wait, the output, the window row: the MFMA wave then waited
+      // 2 900 of its 4 900 cycles per unit for the next table (profiles/r05_ws_trace_fwd_before.txt).  Two units behind nothing in the
+      // h side's loop waits for the unit the MFMA wave is working on.
+      const int NIT = N + (hside ? 1 : 0);
 #pragma unroll 1
-      for (int n = 0; n <= N; ++n) {
+      for (int n = 0; n <= NIT; ++n) {
         const bool live = n < N;
         const int nn = min(n, N - 1);
         const int q = nn >> 1, u = nn & 1;
@@ -1297,30 +1356,37 @@ __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ 
         }
         const int fyl = min(lane, XK - 1);
         const int tslot = (y + fyl) & (XWIN - 1);
+        WS_T(0);
         if (hside) {
           // (1) the h band of unit n takes the table
           if (live) {
             ws_wait(fl, F_TAB_FREE + p, n);
+            WS_T(1);
             __builtin_amdgcn_s_setprio(WS_PRIO_TABLE);
             write_h_table(hreg);
             ws_set(fl, F_TAB_FULL + p, n + 1);
             __builtin_amdgcn_s_setprio(0);
+            WS_T(2);
           }
           if (live && u == 1) ws_set(fl, F_PROG + w, q + 1);      // this wave reads neither the window nor the side columns
           load_taps(hreg, hsrc, b, x0, y1, h_t0);
-          // (2) unit n - 1: the four lane groups' partial sums + the tail-column sums of the v-side wave -> HBM (lane = (channel, pixel))
+          WS_T(3);
+          // (2) unit n - 2: the four lane groups' partial sums + the tail-column sums of the v-side wave -> HBM (lane = (channel, pixel))
           {
-            if (n > 0) { ws_wait(fl, F_OP_FULL + p, n); ws_wait(fl, F_TL_FULL + p, n); }
+            if (n > 1) { ws_wait(fl, F_OP_FULL + p, n - 1); ws_wait(fl, F_TL_FULL + p, n - 1); }
+            WS_T(6);
             const int c = min(lane >> 4, XC - 1);
             const float* o = op + c * 16 + j;
             float val = (o[0] + o[XC * 16]) + (o[2 * XC * 16] + o[3 * XC * 16]);
             const float t14 = tl[c], t15 = tl[XC + c];
             val += j == 14 ? t14 : j == 15 ? t15 : 0.f;
-            x6_bstore(val, odst, lane < 16 * XC ? ooff_prev : X_OOR, 0u);
-            if (n > 0) { ws_set(fl, F_OP_FREE + p, n); ws_set(fl, F_TL_FREE + p, n); }
+            x6_bstore(val, odst, lane < 16 * XC ? ooff_prev2 : X_OOR, 0u);
+            if (n > 1) { ws_set(fl, F_OP_FREE + p, n - 1); ws_set(fl, F_TL_FREE + p, n - 1); }
+            WS_T(7);
           }
           {
             const int c = min(lane >> 4, XC - 1), x = x0 + 16 * wc + j;
+            ooff_prev2 = ooff_prev;
             ooff_prev = (live && y < Ho && x < Wo) ? (unsigned)(b * XC + c) * plane_b + (unsigned)(y * Wo + x) * 4u : X_OOR;
           }
         } else {
@@ -1334,6 +1400,7 @@ __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ 
           float v14 = 0.f, v15 = 0.f;
           if (live) {
             ws_wait(fl, F_VT_FREE + p, n);
+            WS_T(1);
             float* const vw = vt + j * FVP + 2 * kg;
 #pragma unroll
             for (int a = 0; a < XNP; ++a)
@@ -1343,8 +1410,10 @@ __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ 
             v15 = vt[15 * FVP + fyl];
             asm volatile("" ::: "memory");
             ws_set(fl, F_VT_FULL + p, n + 1);
+            WS_T(2);
           }
           load_taps(vreg, vsrc, b, x0, y1, v_t0);
+          WS_T(3);
           // (3) tail columns of unit n: T_c[fy][14] += In_c[y + fy][64] h50_14, T_c[fy][15] += In_c[..][64] h49_15 + In_c[..][65] h50_15,
           //     times v of the pixel, summed over the tap rows -> six sums for the h-side wave's final add
           if (live && u == 0 && q >= 2) ws_wait(fl, F_SLIDE, 8 * (2 * q - 3));
@@ -1356,24 +1425,35 @@ __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ 
           }
           asm volatile("" ::: "memory");
           if (live && u == 1) ws_set(fl, F_PROG + w, q + 1);
+          WS_T(8);
           if (live) {
             const float h50_14 = rdlane(hraw, 0), h49_15 = rdlane(hraw, 1), h50_15 = rdlane(hraw, 2);
             const float lv = lane < XK ? 1.f : 0.f;
             v14 *= lv; v15 *= lv;
-            float s14[XC], s15[XC];
+            float xs[6];                                   // tl[c] = sum over the tap rows of xs[c] (pixel 14), tl[3 + c] = of xs[3 + c] (pixel 15)
 #pragma unroll
             for (int c = 0; c < XC; ++c) {
-              s14[c] = ws_wave_sum(v14 * (a64[c] * h50_14));
-              s15[c] = ws_wave_sum(v15 * fmaf(a65[c], h50_15, a64[c] * h49_15));
+              xs[c] = v14 * (a64[c] * h50_14);
+              xs[3 + c] = v15 * fmaf(a65[c], h50_15, a64[c] * h49_15);
             }
+            float qa, qb;
+            ws_wave_sum6(xs, qa, qb);                      // rows of qa: xs[0], xs[2], xs[1], xs[3]; rows 0 / 2 of qb: xs[4], xs[5]
+            WS_T(9);
             ws_wait(fl, F_TL_FREE + p, n);
-            if (lane < 2 * XC) tl[lane] = lane == 0 ? s14[0] : lane == 1 ? s14[1] : lane == 2 ? s14[2] : lane == 3 ? s15[0] : lane == 4 ? s15[1] : s15[2];
+            WS_T(10);
+            {
+              const int row = lane >> 4;
+              if ((lane & 15) == 0) tl[row == 0 ? 0 : row == 1 ? 2 : row == 2 ? 1 : 3] = qa;
+              if (lane == 0 || lane == 32) tl[4 + (lane >> 5)] = qb;
+            }
             ws_set(fl, F_TL_FULL + p, n + 1);
           }
         }
         // (4) the new window row
+        WS_T(11);
         if (live) {
           if (q >= 1) ws_wait_all_prog(fl, q);
+          WS_T(4);
           const int slot = grow & (XWIN - 1);
           if constexpr (U8) {
             const unsigned k1 = x6_cvt_pk(rintf(gr0 * 255.f), rintf(gr1 * 255.f));
@@ -1398,14 +1478,20 @@ __global__ __launch_bounds__(WNT) void sepconv_fwd_ws(const float* __restrict__ 
           asm volatile("" ::: "memory");
           if (lane == 0) __hip_atomic_fetch_add(fl + F_SLIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           asm volatile("" ::: "memory");
+          WS_T(5);
         }
       }
+      if (WS_TRACE && blockIdx.x == 0 && lane == 0)
+        for (int k = 0; k < 16; ++k) WS_TRACE_ADD(w, k, tr_[k]);
     }
     g = run_end;
+    if (WS_TRACE) WS_TRACE_WG(1, 1);
   }
   };
   if (role == 0) run_all(std::false_type{});
   else run_all(std::true_type{});
+  if (WS_TRACE && blockIdx.x == 0 && (threadIdx.x & 63) == 0) WS_TRACE_ADD(threadIdx.x >> 6, 15, __builtin_readcyclecounter() - t_kernel0);
+  if (WS_TRACE) WS_TRACE_WG(0, __builtin_readcyclecounter() - t_kernel0);
 }
 
 }  // namespace

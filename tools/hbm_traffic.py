@@ -81,10 +81,13 @@ def _collect(d, counter):
     rows = [r for r in csv.DictReader(open(path)) if r['Counter_Name'] == counter]
     rows.sort(key=lambda r: int(r['Dispatch_Id']))
     out, seen = {}, {'sepconv_fwd': 0, 'sepconv_bwd': 0}
+    first_sepconv = min((int(r['Dispatch_Id']) for r in rows if 'sepconv' in r['Kernel_Name']), default=1 << 62)
     for row in rows:
         name = row['Kernel_Name']
         if 'elementwise' in name or 'copy' in name.lower():
-            out.setdefault(('copy', -1), []).append(float(row['Counter_Value']))
+            # the calibration copies run before the first sepconv launch; later cases allocate tensors larger than the calibration buffer
+            if int(row['Dispatch_Id']) < first_sepconv:
+                out.setdefault(('copy', -1), []).append(float(row['Counter_Value']))
             continue
         kind = 'sepconv_fwd' if 'sepconv_fwd' in name else 'sepconv_bwd' if 'sepconv_bwd' in name else None
         if kind is None:
