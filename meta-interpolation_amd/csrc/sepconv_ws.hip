@@ -984,9 +984,12 @@ __global__ __launch_bounds__(WNT) void sepconv_bwd_ws(const float* __restrict__ 
               sb = fmaf(g15[c] * v15, a64[c], sb);
               sc = fmaf(g15[c] * v15, a65[c], sc);
             }
-            s6414 = ws_wave_sum(sa);
-            s6415 = ws_wave_sum(sb);
-            s6515 = ws_wave_sum(sc);
+            {                                              // three sums as one packed reduction (ws_wave_sum6): rows sa, sc, sb, 0
+              const float xs[6] = {sa, sb, sc, 0.f, 0.f, 0.f};
+              float qa, qb;
+              ws_wave_sum6(xs, qa, qb);
+              s6414 = rdlane(qa, 0); s6415 = rdlane(qa, 32); s6515 = rdlane(qa, 16);
+            }
           }
           asm volatile("" ::: "memory");
           WS_T(9);
