@@ -380,6 +380,13 @@ int savfi_conv3x3_wgrad_tasks_f32(const float* x, const float* gz, float* gw, fl
 int64_t savfi_conv3x3_wgrad_wino_tasks_workspace_floats(int N, int T, int Ci, int Co, int H, int W, int pad);
 int savfi_conv3x3_wgrad_wino_tasks_f32(const float* x, const float* gz, float* gw, float* workspace, int N, int T, int Ci,
                                        int Co, int H, int W, int pad, void* stream);
+/* ... and the bias gradient with it (round 5): gb [T][Co], gb[t][co] = sum of gz over the samples n % T == t and the map -- the gradient of
+ * a bias added to this convolution's output (model_utils.py:308-366 MetaConv2dLayer: F.conv2d(..., bias)).  The weight gradient reads gz
+ * anyway; the separate pass (savfi_bias_act_bwd_f32 with gz = NULL) read the whole map once more.  Sums in a fixed order (deterministic).
+ * workspace: savfi_conv3x3_wgrad_wino_tasks_bias_workspace_floats(...) floats. */
+int64_t savfi_conv3x3_wgrad_wino_tasks_bias_workspace_floats(int N, int T, int Ci, int Co, int H, int W, int pad);
+int savfi_conv3x3_wgrad_wino_tasks_bias_f32(const float* x, const float* gz, float* gw, float* gb, float* workspace, int N, int T, int Ci,
+                                            int Co, int H, int W, int pad, void* stream);
 
 /* ----------------------------------------------------------------------------------
  * Direct K x K convolution, K in {3, 5, 7}, stride 1, zero padding `pad` (0 .. K-1), T filter sets (sample n uses set n % T):

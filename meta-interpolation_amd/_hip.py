@@ -86,6 +86,8 @@ _PROTOTYPES = {
     "savfi_conv3x3_wgrad_tasks_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P],
     "savfi_conv3x3_wgrad_wino_tasks_workspace_floats": [c_int] * 7,
     "savfi_conv3x3_wgrad_wino_tasks_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P],
+    "savfi_conv3x3_wgrad_wino_tasks_bias_workspace_floats": [c_int] * 7,
+    "savfi_conv3x3_wgrad_wino_tasks_bias_f32": [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P],
     "savfi_conv3x3_wgrad_workspace_floats": [c_int] * 6,
     "savfi_conv3x3_wgrad_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P],
     "savfi_convk_filter_floats": [c_int] * 5,

@@ -55,7 +55,10 @@ constexpr int WRING_ROW = 3584;                    // the wave's 64 columns x tw
 constexpr int WS_DMA_UNIT = 7;                     // LDS-DMA instructions per unit: four pieces of the taps, the cotangent, two of the window row
 constexpr int WS_DMA_ITER = 4 + WS_DMA_UNIT;       // vector memory operations of a staging wave's iteration: four drain stores, one unit's fetch
 typedef __attribute__((address_space(3))) void ws_lds_void;
-constexpr int WPV = 20;                            // tile pitch (floats): rows leave as 16-byte pieces of 4 pixels.  gH: the MFMA wave writes
+#ifndef WS_TILE_PITCH
+#define WS_TILE_PITCH 20
+#endif
+constexpr int WPV = WS_TILE_PITCH;                            // tile pitch (floats): rows leave as 16-byte pieces of 4 pixels.  gH: the MFMA wave writes
                                                    // D[R][j] (R = window column) to row R - j + 15 = fx + 15, i.e. resolves gH[fx][j] = D[j + fx][j]
                                                    // by its store ADDRESS (conflict free: 16 kg - 19 j mod 32 is a bijection of a half wave)
 enum { F_TAB_FULL = 0, F_TAB_FREE = 4, F_OUT_FULL = 8, F_OUT_FREE = 12, F_PROG = 16, F_SLIDE = 28, F_ERR = 29,

@@ -376,6 +376,8 @@ struct WWArgs {
   int ty_cnt, tx_cnt, cpr;        // tile rows, tile columns, chunks per tile row
   int chunks_total;               // per task: (N / T) * ty_cnt * cpr
   int chunks_per_split;
+  float* bias_partial;            // or null: [T][nsplit][cobs * 32] sums of the cotangent per produced channel (round 5: the bias gradient
+                                  // rides on the weight gradient's read of gz instead of a pass of its own over the map)
 };
 
 }  // namespace
@@ -447,7 +449,10 @@ __device__ __forceinline__ void ww_load(WWChunk& c, const WWArgs& a, const WWPos
 }
 
 // registers -> transforms -> this thread's rows of the V and Y buffers
-__device__ __forceinline__ void ww_transform_store(WWChunk& c, const WWArgs& a, float* __restrict__ ybuf, float* __restrict__ vbuf, int ch, int tl) {
+// bias_acc: or null -- this thread's slot of the workgroup's channel sums in LDS (the 128-register budget of four workgroups per CU has no
+// room for one more live value across the MFMA loop: a register accumulator spilled an accumulator tile to scratch inside the loop)
+__device__ __forceinline__ void ww_transform_store(WWChunk& c, const WWArgs& a, float* __restrict__ ybuf, float* __restrict__ vbuf, int ch, int tl,
+                                                   float* __restrict__ bias_acc) {
   float (&d)[16] = c.d;
   if (c.cx == 0 && a.pad > 0) {     // wave-uniform: only the first chunk of a tile row
     if (tl == 0) {
@@ -483,6 +488,7 @@ __device__ __forceinline__ void ww_transform_store(WWChunk& c, const WWArgs& a, 
         (f32x4){t[4 * r] - t[4 * r + 2], t[4 * r + 1] + t[4 * r + 2], t[4 * r + 2] - t[4 * r + 1], t[4 * r + 1] - t[4 * r + 3]};
   // Y' = G'' g G''^T with G'' = [1 0; 1 1; 1 -1; 0 1] (the factors .5 of rows / columns 1, 2 are applied in the output stage)
   const float g00 = c.g[0], g01 = c.g[1], g10 = c.g[2], g11 = c.g[3];
+  if (bias_acc) *bias_acc += (g00 + g01) + (g10 + g11);       // (cotangent outside the map / beyond Co is zero here)
   const float s0[2] = {g00, g01}, s1[2] = {g00 + g10, g01 + g11}, s2[2] = {g00 - g10, g01 - g11}, s3[2] = {g10, g11};
   *reinterpret_cast<f32x4*>(ybuf + (0 * WW_CB + ch) * WW_PY + 4 * tl) = (f32x4){s0[0], s0[0] + s0[1], s0[0] - s0[1], s0[1]};
   *reinterpret_cast<f32x4*>(ybuf + (1 * WW_CB + ch) * WW_PY + 4 * tl) = (f32x4){s1[0], s1[0] + s1[1], s1[0] - s1[1], s1[1]};
@@ -490,6 +496,7 @@ __device__ __forceinline__ void ww_transform_store(WWChunk& c, const WWArgs& a, 
   *reinterpret_cast<f32x4*>(ybuf + (3 * WW_CB + ch) * WW_PY + 4 * tl) = (f32x4){s3[0], s3[0] + s3[1], s3[0] - s3[1], s3[1]};
 }
 
+template <bool BIAS>
 __global__ __launch_bounds__(256, WW_DOUBLE ? 2 : 4) void wino_wgrad3x3(WWArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -523,10 +530,15 @@ __global__ __launch_bounds__(256, WW_DOUBLE ? 2 : 4) void wino_wgrad3x3(WWArgs a
   const unsigned gplane = co < a.Co ? (unsigned)(co * a.Ho * a.Wo) * 4u : WW_OOR;
   ww_set_row(pos, a);
   if (q0 < q1) ww_load(cur, a, pos, task, tl, xplane, gplane);
+  // BIAS: this thread's tiles of produced channel co, summed in LDS behind the chunk buffers (first ci block of every co block only)
+  // (the slot's address is recomputed from the thread index where it is used: a pointer kept across the loop was spilled)
+  const bool do_bias = BIAS && cib == 0;
+  auto bias_slot = [&]() { return lds + WW_LDS_FLOATS + threadIdx.x; };
+  if (do_bias) *bias_slot() = 0.f;
   for (int q = q0; q < q1; ++q) {
     float* buf = lds + (WW_DOUBLE ? ((q - q0) & 1) * WW_BUF : 0);
     if (!WW_DOUBLE && q != q0) __syncthreads();          // every wave is done with the previous chunk's fragments
-    ww_transform_store(cur, a, buf, buf + WW_HALF, ch, tl);
+    ww_transform_store(cur, a, buf, buf + WW_HALF, ch, tl, do_bias ? bias_slot() : nullptr);
     if (q + 1 < q1) {                                  // next chunk: in flight during this chunk's MFMAs
       if (++pos.cx == a.cpr) {                         // wave-uniform
         pos.cx = 0;
@@ -557,6 +569,16 @@ __global__ __launch_bounds__(256, WW_DOUBLE ? 2 : 4) void wino_wgrad3x3(WWArgs a
     }
   }
   __syncthreads();
+  if (do_bias) {                                       // workgroup-uniform: the first ci block of every co block hands out the channel sums
+    auto dpp = [](float v, auto ctrl) {
+      return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xf, 0xf, true));
+    };
+    float bsum = *bias_slot();                          // the eight tile lanes of a channel: lanes 8 ch' .. 8 ch' + 7
+    bsum += dpp(bsum, std::integral_constant<int, 0xB1>{});      // quad_perm [1,0,3,2]
+    bsum += dpp(bsum, std::integral_constant<int, 0x4E>{});      // quad_perm [2,3,0,1]
+    bsum += dpp(bsum, std::integral_constant<int, 0x141>{});     // row_half_mirror
+    if (tl == 0) a.bias_partial[(((size_t)task * gridDim.x + blockIdx.x) * (gridDim.y / a.cibs) + cob) * WW_CB + ch] = bsum;
+  }
 
   // output stage.  Column pass in registers (this wave holds row r = w, scale s_r s_c with s = 1, .5, .5, 1):
   //   u[b] = sum_c A'^T[b][c] s_c M[r][c]:  u0 = m0 + (m1 + m2)/2,  u1 = (m1 - m2)/2,  u2 = (m1 + m2)/2 - m3;   times s_r
@@ -612,6 +634,17 @@ __global__ __launch_bounds__(256) void wino_wgrad_reduce2(const float* __restric
   gw[e] = s;
 }
 
+// gb[t][co] = sum over the splits (fixed order) of bias_partial[t][split][co]
+__global__ __launch_bounds__(64) void wino_wgrad_bias_reduce(const float* __restrict__ bias_partial, float* __restrict__ gb, int Co, int cobs,
+                                                             int nsplit) {
+  const int co = blockIdx.x * 64 + threadIdx.x, task = blockIdx.y;
+  if (co >= Co) return;
+  const float* p = bias_partial + (size_t)task * nsplit * cobs * WW_CB + co;
+  float s = 0.f;
+  for (int sp = 0; sp < nsplit; ++sp) s += p[(size_t)sp * cobs * WW_CB];
+  gb[(size_t)task * Co + co] = s;
+}
+
 struct WWPlan {
   int Ho, Wo, cobs, cibs, ty_cnt, tx_cnt, cpr, chunks_total, chunks_per_split, nsplit, ngroups;
   int64_t partial_floats, stage2_floats;
@@ -656,9 +689,35 @@ extern "C" int64_t savfi_conv3x3_wgrad_wino_tasks_workspace_floats(int N, int T,
   return p.partial_floats + p.stage2_floats;
 }
 
+extern "C" int64_t savfi_conv3x3_wgrad_wino_tasks_bias_workspace_floats(int N, int T, int Ci, int Co, int H, int W, int pad) {
+  const int64_t base = savfi_conv3x3_wgrad_wino_tasks_workspace_floats(N, T, Ci, Co, H, W, pad);
+  if (base < 0) return base;
+  WWPlan p;
+  ww_plan(p, N, T, Ci, Co, H, W, pad);
+  return base + (int64_t)T * p.nsplit * p.cobs * WW_CB;
+}
+
+static int wino_wgrad_tasks(const float* x, const float* gz, float* gw, float* gb, float* workspace, int N, int T, int Ci, int Co, int H,
+                            int W, int pad, void* stream);
+
 // Same contract as savfi_conv3x3_wgrad_tasks_f32 (gw [T][Co][Ci][3][3], gw[t] over the samples n % T == t), Winograd form.
 extern "C" int savfi_conv3x3_wgrad_wino_tasks_f32(const float* x, const float* gz, float* gw, float* workspace, int N, int T,
                                                   int Ci, int Co, int H, int W, int pad, void* stream) {
+  return wino_wgrad_tasks(x, gz, gw, nullptr, workspace, N, T, Ci, Co, H, W, pad, stream);
+}
+
+// ... and the bias gradient with it: gb [T][Co], gb[t][co] = the sum of gz over the samples n % T == t and the map -- what a bias added to
+// the convolution's output gets.  The weight gradient reads gz anyway; its first ci block of every co block sums what it reads (the
+// separate pass, savfi_bias_act_bwd_f32 in its sums-only use, read the whole map once more: 34 us for a [8,32,384,512] map).
+// workspace: savfi_conv3x3_wgrad_wino_tasks_bias_workspace_floats.
+extern "C" int savfi_conv3x3_wgrad_wino_tasks_bias_f32(const float* x, const float* gz, float* gw, float* gb, float* workspace, int N, int T,
+                                                       int Ci, int Co, int H, int W, int pad, void* stream) {
+  if (!gb) return SAVFI_E_NULL;
+  return wino_wgrad_tasks(x, gz, gw, gb, workspace, N, T, Ci, Co, H, W, pad, stream);
+}
+
+static int wino_wgrad_tasks(const float* x, const float* gz, float* gw, float* gb, float* workspace, int N, int T, int Ci, int Co, int H,
+                            int W, int pad, void* stream) {
   if (!x || !gz || !gw || !workspace) return SAVFI_E_NULL;
   if (N <= 0 || T <= 0 || N % T != 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return SAVFI_E_SHAPE;
   if (pad != 0 && pad != 1) return SAVFI_E_UNSUPPORTED;
@@ -668,12 +727,20 @@ extern "C" int savfi_conv3x3_wgrad_wino_tasks_f32(const float* x, const float* g
   if ((int64_t)Ci * H * W >= ((int64_t)1 << 28) || (int64_t)Co * p.Ho * p.Wo >= ((int64_t)1 << 28)) return SAVFI_E_TOOBIG;
   if (p.ngroups > 65535 || (int64_t)p.cobs * p.cibs > 65535 || (int64_t)Co * Ci * 9 > 0x7fffffffLL || T > 65535) return SAVFI_E_TOOBIG;
   hipStream_t st = (hipStream_t)stream;
-  constexpr size_t lds = (size_t)WW_LDS_FLOATS * sizeof(float);
-  static uint32_t attr_done = 0;
-  if (int e = savfi_ensure_dynamic_lds((const void*)wino_wgrad3x3, lds, attr_done)) return e;
-  WWArgs a{x, gz, workspace, Ci, Co, H, W, p.Ho, p.Wo, pad, T, p.cibs, p.ty_cnt, p.tx_cnt, p.cpr, p.chunks_total, p.chunks_per_split};
-  hipLaunchKernelGGL(wino_wgrad3x3, dim3(p.nsplit, p.cobs * p.cibs, T), dim3(256), lds, st, a);
+  constexpr size_t lds = (size_t)WW_LDS_FLOATS * sizeof(float), lds_bias = lds + 256 * sizeof(float);
+  static uint32_t attr_done = 0, attr_done_b = 0;
+  if (int e = gb ? savfi_ensure_dynamic_lds((const void*)wino_wgrad3x3<true>, lds_bias, attr_done_b)
+                 : savfi_ensure_dynamic_lds((const void*)wino_wgrad3x3<false>, lds, attr_done)) return e;
+  float* bias_partial = gb ? workspace + p.partial_floats + p.stage2_floats : nullptr;
+  WWArgs a{x, gz, workspace, Ci, Co, H, W, p.Ho, p.Wo, pad, T, p.cibs, p.ty_cnt, p.tx_cnt, p.cpr, p.chunks_total, p.chunks_per_split,
+           bias_partial};
+  if (gb) hipLaunchKernelGGL(wino_wgrad3x3<true>, dim3(p.nsplit, p.cobs * p.cibs, T), dim3(256), lds_bias, st, a);
+  else hipLaunchKernelGGL(wino_wgrad3x3<false>, dim3(p.nsplit, p.cobs * p.cibs, T), dim3(256), lds, st, a);
   if (int e = savfi_launch_status()) return e;
+  if (gb) {
+    hipLaunchKernelGGL(wino_wgrad_bias_reduce, dim3(savfi_cdiv(Co, 64), T), dim3(64), 0, st, bias_partial, gb, Co, p.cobs, p.nsplit);
+    if (int e = savfi_launch_status()) return e;
+  }
   const int ntiles = p.cobs * p.cibs;
   const size_t block_floats = (size_t)ntiles * WW_BLOCK_FLOATS;
   float* stage2 = workspace + p.partial_floats;

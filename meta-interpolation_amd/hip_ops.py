@@ -1477,9 +1477,19 @@ def convk_reflect_eligible(x, weight, pad):
     return convk_eligible(x, weight, 1, pad, 1, 1, False)
 
 
-def conv3x3_wgrad_tasks(x, gz, T, pad=1, stream=None, extra_stream=None):
+WGRAD_FUSE_BIAS = not os.environ.get('SAVFI_WGRAD_NO_BIAS')     # A/B: the bias sums as a pass of their own (rounds 2-4)
+
+
+def conv3x3_wgrad_tasks_sums_bias(x_shape, co, T, pad):
+    """Will conv3x3_wgrad_tasks(..., want_bias=True) hand out the bias gradient with the weight gradient (the Winograd form does)?"""
+    N, Ci, H, W = x_shape
+    return WGRAD_FUSE_BIAS and _wgrad_wino(N, Ci, co, H + 2 * pad - 2, W + 2 * pad - 2)
+
+
+def conv3x3_wgrad_tasks(x, gz, T, pad=1, stream=None, extra_stream=None, want_bias=False):
     """savfi_conv3x3_wgrad_tasks_f32: gw [T,Co,Ci,3,3], gw[t] over the samples n % T == t.  `stream` / `extra_stream`: as in
-    conv3x3_wgrad (launch on a side stream, buffers from the current stream's pool)."""
+    conv3x3_wgrad (launch on a side stream, buffers from the current stream's pool).  want_bias (only where
+    conv3x3_wgrad_tasks_sums_bias says yes): returns (gw, gb [T,Co]) -- the sums of gz ride on the weight gradient's read of it."""
     x, gz = x.contiguous(), gz.contiguous()
     _hip.require_cuda(x, gz)
     N, Ci, H, W = x.shape
@@ -1487,8 +1497,20 @@ def conv3x3_wgrad_tasks(x, gz, T, pad=1, stream=None, extra_stream=None):
     assert N % T == 0 and tuple(gz.shape) == (N, Co, H + 2 * pad - 2, W + 2 * pad - 2), (x.shape, gz.shape, pad, T)
     lib = _hip.lib()
     form = "wino_" if _wgrad_wino(N, Ci, Co, H + 2 * pad - 2, W + 2 * pad - 2) else ""
-    ws = torch.empty(_workspace_floats("savfi_conv3x3_wgrad_%stasks_workspace_floats" % form, N, T, Ci, Co, H, W, int(pad)), dtype=x.dtype, device=x.device)
     gw = torch.empty((T, Co, Ci, 3, 3), dtype=x.dtype, device=x.device)
+    if want_bias:
+        assert form == "wino_" and WGRAD_FUSE_BIAS, "ask conv3x3_wgrad_tasks_sums_bias first"
+        ws = torch.empty(_workspace_floats("savfi_conv3x3_wgrad_wino_tasks_bias_workspace_floats", N, T, Ci, Co, H, W, int(pad)), dtype=x.dtype, device=x.device)
+        gb = torch.empty((T, Co), dtype=x.dtype, device=x.device)
+        if extra_stream is not None:
+            for t in (ws, gw, gb):
+                t.record_stream(extra_stream)
+        _hip.launch("conv3x3_wgrad", lambda: _hip.check(lib.savfi_conv3x3_wgrad_wino_tasks_bias_f32(
+            x.data_ptr(), gz.data_ptr(), gw.data_ptr(), gb.data_ptr(), ws.data_ptr(), N, T, Ci, Co, H, W, int(pad),
+            _hip.current_stream() if stream is None else stream), "savfi_conv3x3_wgrad_wino_tasks_bias_f32"),
+            flops=18.0 * Ci * Co * gz.shape[2] * gz.shape[3] * N)
+        return gw, gb
+    ws = torch.empty(_workspace_floats("savfi_conv3x3_wgrad_%stasks_workspace_floats" % form, N, T, Ci, Co, H, W, int(pad)), dtype=x.dtype, device=x.device)
     if extra_stream is not None:
         ws.record_stream(extra_stream)
         gw.record_stream(extra_stream)
@@ -1608,11 +1630,19 @@ class _ConvBiasActTasks(torch.autograd.Function):
         gz = gy if identity else torch.empty_like(gy)
         need_b = need_b and ctx.has_bias
         mask, mslope = (x, ctx.in_slope) if (ctx.in_slope is not None and need_x) else (None, 1.0)
-        gb = torch.empty((T, Co), dtype=gy.dtype, device=gy.device) if need_b else None
-        if need_b or not identity:
+        # the bias gradient rides on the weight gradient's read of gz where that is the Winograd form and this function has nothing else to
+        # do with the cotangent (no activation derivative to apply here): one pass over the map less
+        pad_ = padding if isinstance(padding, int) else padding[0]
+        K_ = int(w.shape[-1])
+        wgrad_is_wino3 = (need_w and not (_convk_geometry(w, stride, padding, dilation, 1) is not None and (ctx.route == 'convk' or K_ == 3)
+                                          and convk_wgrad_preferred(K_, Ci, Co, Ho, Wo, ctx.direct))
+                          and conv3x3_wgrad_tasks_eligible(x, w, stride, padding, dilation))
+        fuse_b = bool(need_b and identity and wgrad_is_wino3 and conv3x3_wgrad_tasks_sums_bias(x.shape, Co, T, pad_))
+        gb = torch.empty((T, Co), dtype=gy.dtype, device=gy.device) if (need_b and not fuse_b) else None
+        if (need_b and not fuse_b) or not identity:
             lib = _hip.lib()
             scratch = (torch.empty(_workspace_floats("savfi_bias_act_scratch_floats", n, T * Co, Ho * Wo), dtype=gy.dtype, device=gy.device)
-                       if need_b else None)
+                       if gb is not None else None)
             _hip.launch("bias_act_bwd", lambda: _hip.check(lib.savfi_bias_act_bwd_f32(
                 gy.data_ptr(), (gy if identity else y).data_ptr(), None if identity else gz.data_ptr(),
                 None if gb is None else gb.data_ptr(), None if scratch is None else scratch.data_ptr(),
@@ -1645,11 +1675,13 @@ class _ConvBiasActTasks(torch.autograd.Function):
                 ready = torch.cuda.Event()
                 ready.record()
                 side.wait_event(ready)
-                gw = conv3x3_wgrad_tasks(x, gz, T, pad, stream=side.cuda_stream, extra_stream=side)
+                gw = conv3x3_wgrad_tasks(x, gz, T, pad, stream=side.cuda_stream, extra_stream=side, want_bias=fuse_b)
                 x.record_stream(side)
                 gz.record_stream(side)
             else:
-                gw = conv3x3_wgrad_tasks(x, gz, T, pad)
+                gw = conv3x3_wgrad_tasks(x, gz, T, pad, want_bias=fuse_b)
+            if fuse_b:
+                gw, gb = gw
             need_w = False
         if need_x or need_w:
             pair = lambda v: [v, v] if isinstance(v, int) else list(v)

@@ -1191,3 +1191,26 @@ def test_mt_copy_is_a_bitwise_copy_over_many_tensors():
     outs = [torch.zeros(5, dtype=torch.int64, device=DEV), torch.zeros(3, dtype=torch.int64, device=DEV)]
     hip_ops.mt_copy(outs, ints)
     assert all(torch.equal(o, i) for o, i in zip(outs, ints))
+
+
+@pytest.mark.parametrize("N,T,Ci,Co,H,W,pad", [(8, 4, 32, 32, 96, 128, 1), (4, 1, 51, 51, 66, 130, 0), (8, 4, 64, 40, 48, 64, 1), (2, 2, 20, 70, 37, 53, 1)])
+def test_winograd_weight_gradient_hands_out_the_bias_gradient(N, T, Ci, Co, H, W, pad):
+    """savfi_conv3x3_wgrad_wino_tasks_bias_f32: the weight gradient is bit for bit the one of savfi_conv3x3_wgrad_wino_tasks_f32, and
+    gb[t][co] is the sum of the cotangent over the samples n % T == t and the map (float64 reference, fp32 rounding of ~1e5 terms)"""
+    lib, st = _hip.lib(), _hip.current_stream()
+    g = torch.Generator().manual_seed(N * 1000 + Co)
+    Ho, Wo = H + 2 * pad - 2, W + 2 * pad - 2
+    x = torch.randn(N, Ci, H, W, generator=g).to(DEV)
+    gz = torch.randn(N, Co, Ho, Wo, generator=g).to(DEV)
+    ws0 = torch.empty(int(lib.savfi_conv3x3_wgrad_wino_tasks_workspace_floats(N, T, Ci, Co, H, W, pad)), device=DEV)
+    ws1 = torch.empty(int(lib.savfi_conv3x3_wgrad_wino_tasks_bias_workspace_floats(N, T, Ci, Co, H, W, pad)), device=DEV)
+    assert ws1.numel() > ws0.numel()
+    gw0 = torch.full((T, Co, Ci, 3, 3), float('nan'), device=DEV)
+    gw1, gb = torch.full_like(gw0, float('nan')), torch.full((T, Co), float('nan'), device=DEV)
+    _hip.check(lib.savfi_conv3x3_wgrad_wino_tasks_f32(x.data_ptr(), gz.data_ptr(), gw0.data_ptr(), ws0.data_ptr(), N, T, Ci, Co, H, W, pad, st), "plain")
+    _hip.check(lib.savfi_conv3x3_wgrad_wino_tasks_bias_f32(x.data_ptr(), gz.data_ptr(), gw1.data_ptr(), gb.data_ptr(), ws1.data_ptr(), N, T, Ci, Co, H, W, pad, st), "with bias")
+    torch.cuda.synchronize()
+    assert torch.equal(gw0, gw1)
+    ref = gz.double().view(N // T, T, Co, -1).sum((0, 3))
+    assert (gb.double() - ref).abs().max().item() <= 1e-5 * gz.double().abs().view(N // T, T, Co, -1).sum((0, 3)).max().item()
+    assert lib.savfi_conv3x3_wgrad_wino_tasks_bias_f32(x.data_ptr(), gz.data_ptr(), gw1.data_ptr(), None, ws1.data_ptr(), N, T, Ci, Co, H, W, pad, st) == -1
