@@ -11,6 +11,8 @@ tag() { python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitl
 SAVFI_SEPCONV_PAIR_TWO_LAUNCHES=1 $B 2>/dev/null | tag "two launches per pass (SAVFI_SEPCONV_PAIR_TWO_LAUNCHES=1)" > $A/r05_pair_ab.jsonl
 $B 2>/dev/null | tag "one launch per pass (default)" >> $A/r05_pair_ab.jsonl
 SAVFI_UPSAMPLE_BWD_FORM=1 $B 2>/dev/null | tag "default, bilinear x2 backward tiled (SAVFI_UPSAMPLE_BWD_FORM=1)" >> $A/r05_pair_ab.jsonl
+SAVFI_WGRAD_NO_BIAS=1 $B 2>/dev/null | tag "default, bias sums as their own pass (SAVFI_WGRAD_NO_BIAS=1)" >> $A/r05_pair_ab.jsonl
+$B 2>/dev/null | tag "one launch per pass (default), again" >> $A/r05_pair_ab.jsonl
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_c2 -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-strong-c4 > $A/r05_bench_line_profiled.json 2>/dev/null
 python $R/tools/gap_report.py /tmp/prof_c2 0 > $A/r05_bench_c2_one_iteration.txt 2>&1
@@ -29,6 +31,7 @@ python $R/tools/pmc_summary.py /tmp/pmc3 sepconv >> $A/r05_pmc_sepconv_ws_final.
 cd $R
 SAVFI_HIP_LIB=$V/libsavfi_trace.so python tools/ws_trace.py 8 f8 3 > $A/r05_ws_trace_dma.txt 2>&1
 SAVFI_HIP_LIB=$V/libsavfi_trace.so python tools/ws_trace.py 4 f8 3 > $A/r05_ws_trace_dma_b4.txt 2>&1
+SAVFI_HIP_LIB=$V/libsavfi_trace.so python tools/ws_trace_fwd.py 8 1 > $A/r05_ws_trace_fwd.txt 2>&1
 python tools/frames8_time.py 8 > $A/r05_frames8_time.txt 2>&1
 python tools/frames8_time.py 4 256 448 bwd_frames8_unit16,fwd_frames8_unit16 >> $A/r05_frames8_time.txt 2>&1
 tools/scratch/membench > $A/r05_membench.txt 2>&1
