@@ -56,7 +56,7 @@
 extern "C" {
 #endif
 
-#define SAVFI_ABI_VERSION 15
+#define SAVFI_ABI_VERSION 16
 
 #define SAVFI_OK            0
 #define SAVFI_E_NULL       (-1)  /* a required pointer is NULL                          */
@@ -437,6 +437,14 @@ int savfi_convk_wgrad_tasks_f32(const float* x, const float* gz, float* gw, floa
 /* the same with x's border of width `pad` mirrored (see savfi_convk_tasks_pre_reflect_f32) */
 int savfi_convk_wgrad_tasks_reflect_f32(const float* x, const float* gz, float* gw, float* workspace, int N, int T, int Ci, int Co,
                                         int H, int W, int K, int pad, int precise, int reflect, void* stream);
+/* the same (precise = 0) that also hands out the bias gradient gb [T,Co] = sums of gz over the samples n % T == t and the map: the sums ride
+ * on the kernel's staging of gz (fixed order, bit-reproducible; gw is bit-identical to the call above), which saves the bias pass over
+ * the map (reference: the bias gradient autograd returns for MetaConv2dLayer's F.conv2d, model_utils.py:308-366).  Only for the shapes
+ * savfi_convk_wgrad_sums_bias() answers 1 for (3 x 3 layers of >= 48 -> 48 channels: the all-taps kernel, csrc/convk_wgrad.hip);
+ * SAVFI_E_UNSUPPORTED otherwise.  Same workspace as above. */
+int savfi_convk_wgrad_sums_bias(int N, int T, int Ci, int Co, int H, int W, int K, int pad);
+int savfi_convk_wgrad_tasks_bias_f32(const float* x, const float* gz, float* gw, float* gb, float* workspace, int N, int T, int Ci, int Co,
+                                     int H, int W, int K, int pad, int reflect, void* stream);
 
 /* ----------------------------------------------------------------------------------
  * Channel attention + residual of CAIN's RCAB (model_utils.py:931-953 MetaCALayer, :957-990 MetaRCAB):

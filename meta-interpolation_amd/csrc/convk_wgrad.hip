@@ -52,15 +52,17 @@ __device__ __forceinline__ unsigned ckw_cvt_pk_bf16(float lo, float hi) {
   return r;
 }
 
+typedef float f32x2k __attribute__((ext_vector_type(2)));
+// (the two subtractions of a pair as packed fp32 operations: v_pk_add_f32, 9 VALU per pair of elements instead of 11)
 __device__ __forceinline__ void ckw_split8(const float (&v)[8], u32x4& p1, u32x4& p2, u32x4& p3) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const float a = v[2 * i], b = v[2 * i + 1];
-    const unsigned h1 = ckw_cvt_pk_bf16(a, b);
-    const float ra = a - __uint_as_float(h1 << 16), rb = b - __uint_as_float(h1 & 0xffff0000u);
-    const unsigned h2 = ckw_cvt_pk_bf16(ra, rb);
-    const float qa = ra - __uint_as_float(h2 << 16), qb = rb - __uint_as_float(h2 & 0xffff0000u);
-    p1[i] = h1; p2[i] = h2; p3[i] = ckw_cvt_pk_bf16(qa, qb);
+    const f32x2k ab = {v[2 * i], v[2 * i + 1]};
+    const unsigned h1 = ckw_cvt_pk_bf16(ab.x, ab.y);
+    const f32x2k r = ab - (f32x2k){__uint_as_float(h1 << 16), __uint_as_float(h1 & 0xffff0000u)};
+    const unsigned h2 = ckw_cvt_pk_bf16(r.x, r.y);
+    const f32x2k q = r - (f32x2k){__uint_as_float(h2 << 16), __uint_as_float(h2 & 0xffff0000u)};
+    p1[i] = h1; p2[i] = h2; p3[i] = ckw_cvt_pk_bf16(q.x, q.y);
   }
 }
 
@@ -361,6 +363,267 @@ __global__ __launch_bounds__(WG_THREADS * NG, NG == 1 ? 2 : 1) void convk_wgrad_
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// 3 x 3, ALL NINE TAPS PER WAVE on a RING of input rows (round 5).  The kernel above is bound by its LDS reads and its staging, not by the
+// matrix pipe: with the taps dealt out to the waves every wave re-reads the whole cotangent tile (0.5 KB of fragments per MFMA -- what the
+// LDS delivers per SIMD in the 16 cycles of an MFMA), a unit of 4 x 32 pixels needs a 6 x 34 input tile (1.6 x the split work) behind two
+// workgroup barriers, and LDS has no room for a second buffer.
+// Here a wave owns a 32 x 16 block of (output, input) channels with all nine taps in its own accumulators (9 x 2 tiles = 72 registers): the
+// cotangent fragments of a 32-pixel row (6 transpose reads) are read ONCE for nine taps, an input fragment (3 reads) feeds 12 MFMAs -- 0.31 KB
+// per MFMA.  Workgroup = 8 waves on 64 x 64 channels and the same pixels.  A unit is TWO rows x 32 pixels and a workgroup walks DOWN the rows
+// of a 32-column segment: the input rows live in a ring of three row pairs (a unit reads two pairs, the third is being written), the
+// cotangent tile is double buffered, so every input element is split ONCE (34 / 32 of the pixels), the staging of the next unit sits
+// between the two rows of MFMAs of this one, and a step has ONE barrier.  An "item" of the pipeline = one input row pair (+ the cotangent
+// rows of the unit it completes); the first item of a run of units in a segment brings only the pair above them.  512 threads: one
+// cotangent cell x 8 channels and one input cell x 8 channels each (the 32 cells of the two halo columns go to the first half wave).  A
+// lane ends up with the nine taps of four (co, ci) pairs: 36 contiguous bytes each.  BIAS: the channel sums of the cotangent (the bias
+// gradient) ride on the staging registers -- wave o stages octet o of the 64 output channels.
+// Measured (profiles/r05_wgrad3_forms.txt): 128 -> 128 @96x128, T = 4 x 2 samples: 161 us against 200 (tap-split kernel) and 183 (Winograd
+// F(3x3, 2x2) on the fp32 matrix cores); timing-only ablations: no staging 123, MFMAs + fragment reads + epilogue alone 110 (86 = the MFMAs).
+// ------------------------------------------------------------------------------------------------------------------
+namespace ring {
+constexpr int NTHR = 512, MT = 2, UR2 = 2;
+constexpr int GCELLS = UR2 * UW;                       // 64 cells per cotangent buffer
+constexpr int XCOLS = UW + 2, XPAIR = UR2 * XCOLS;     // 34 columns; 68 cells per row pair
+constexpr int GOCT = ckw_oct(2 * GCELLS), XOCT = ckw_oct(3 * XPAIR);
+constexpr int GPLANE = 8 * GOCT, XPLANE = 8 * XOCT, XBASE = 3 * GPLANE, LDS = 3 * GPLANE + 3 * XPLANE;
+static_assert(8 * XPAIR == NTHR + 32, "one input cell per thread + 32 for the first half wave");
+struct Item {            // wave-uniform
+  int n, seg, xpair;     // sample, column segment, input row pair (rows 2 xpair - pad, + 1)
+  int has_g;             // this item also brings the cotangent rows 2 (xpair - 1), + 1 and completes that unit
+  int xslot, gbuf;       // ring slot of the pair (0..2), cotangent buffer (0 / 1)
+  int valid;
+};
+}  // namespace ring
+
+template <bool BIAS>
+__global__ __launch_bounds__(ring::NTHR, 1) void convk_wgrad3_ring(const WgArgs a, float* __restrict__ bias_partial) {
+  using namespace ring;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wv & 1, wn = wv >> 1;
+  const int g = lane >> 4, sl = lane & 15, kq = sl >> 2, c4 = sl & 3;     // transpose-read source lane: pixel kq, channel quad c4
+
+  int b = blockIdx.x;
+  const int split = b % a.splits; b /= a.splits;
+  const int cib = b % a.cibs; b /= a.cibs;
+  const int cob = b % a.cobs;
+  const int t = b / a.cobs;
+  const int co0 = cob * 64, ci0 = cib * 64;
+  const int u_begin = split * a.units_per_split, u_end = min(u_begin + a.units_per_split, a.units);
+  const size_t gplane = (size_t)a.Ho * a.Wo, xplane = (size_t)a.H * a.W;
+  const int gplane_b_ = (int)(gplane * 4), xplane_b_ = (int)(xplane * 4);
+  constexpr int OOB = 0x7fffffff;
+
+  // ---- this thread's staging cells (fixed for the launch) ----
+  const int go = tid >> 6, gcell = tid & 63, gdy = gcell >> 5, gdx = gcell & 31;
+  const int g_rel = co0 + 8 * go < a.Co ? (gdy * a.Wo + gdx) * 4 + (co0 + 8 * go) * gplane_b_ : OOB;
+  const int g_dst = go * GOCT + gcell * 16;
+  int xo[2], xdy[2], xdx[2], x_rel[2], x_dst[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int item = k == 0 ? tid : NTHR + (tid & 31);
+    xo[k] = item / XPAIR;
+    const int cell = item - xo[k] * XPAIR;
+    xdy[k] = cell / XCOLS; xdx[k] = cell - xdy[k] * XCOLS;
+    x_rel[k] = ci0 + 8 * xo[k] < a.Ci ? (xdy[k] * a.W + xdx[k]) * 4 + (ci0 + 8 * xo[k]) * xplane_b_ : OOB;
+    x_dst[k] = XBASE + xo[k] * XOCT + cell * 16;
+  }
+  const bool extra = tid < 32;                               // wave 0, first half: the 32 cells beyond 512
+  const bool g_full = (a.Co & 7) == 0, x_full = (a.Ci & 7) == 0;
+
+  float sg[8], sx[2][8];
+  auto stage_load = [&](const Item& it) {
+    // the channel strides enter the loads' scalar offsets as e * stride; kept opaque here so that the fourteen products are recomputed
+    // (SALU) per item instead of living in SGPRs across the MFMA rows (they were spilled to VGPR lanes: 49 v_readlane + hazard nops per step)
+    int gplane_b = gplane_b_, xplane_b = xplane_b_;
+    asm volatile("" : "+s"(gplane_b), "+s"(xplane_b));
+    const int x0 = it.seg * UW;
+    if (it.has_g) {
+      const int y0 = (it.xpair - 1) * UR2;
+      const i32x4 grs = ckw_rsrc(a.gz + (size_t)it.n * a.Co * gplane, (unsigned)((size_t)a.Co * gplane * 4));
+      int voff = g_rel == OOB ? OOB : g_rel + (y0 * a.Wo + x0) * 4;
+      if (!(y0 + UR2 <= a.Ho && x0 + UW <= a.Wo)) voff = (y0 + gdy < a.Ho && x0 + gdx < a.Wo) ? voff : OOB;
+      if (g_full) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sg[e] = ckw_raw_buffer_load_f32(grs, voff, e * gplane_b, 0);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sg[e] = ckw_raw_buffer_load_f32(grs, co0 + 8 * go + e < a.Co ? voff + e * gplane_b : OOB, 0, 0);
+      }
+    }
+    const int yx = it.xpair * UR2 - a.pad, xx = x0 - a.pad;
+    const i32x4 xrs = ckw_rsrc(a.x + (size_t)it.n * a.Ci * xplane, (unsigned)((size_t)a.Ci * xplane * 4));
+    const bool x_in = yx >= 0 && xx >= 0 && yx + UR2 <= a.H && xx + XCOLS <= a.W;
+    const int x_org = (yx * a.W + xx) * 4;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (k == 1 && !extra) continue;
+      int voff = x_rel[k] == OOB ? OOB : x_rel[k] + x_org;
+      if (!x_in) {
+        int yy = yx + xdy[k], xx2 = xx + xdx[k];
+        if (a.reflect && x_rel[k] != OOB) {
+          yy = yy < 0 ? -yy : (yy >= a.H ? 2 * a.H - 2 - yy : yy);
+          xx2 = xx2 < 0 ? -xx2 : (xx2 >= a.W ? 2 * a.W - 2 - xx2 : xx2);
+          voff = x_rel[k] - (xdy[k] * a.W + xdx[k]) * 4 + (yy * a.W + xx2) * 4;
+        }
+        voff = ((unsigned)yy < (unsigned)a.H && (unsigned)xx2 < (unsigned)a.W) ? voff : OOB;
+      }
+      if (x_full) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sx[k][e] = ckw_raw_buffer_load_f32(xrs, voff, e * xplane_b, 0);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sx[k][e] = ckw_raw_buffer_load_f32(xrs, ci0 + 8 * xo[k] + e < a.Ci ? voff + e * xplane_b : OOB, 0, 0);
+      }
+    }
+  };
+  float bsum[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
+  const bool do_bias = BIAS && cib == 0;
+  auto stage_write = [&](const Item& it) {
+    u32x4 p1, p2, p3;
+    if (it.has_g) {
+      if (do_bias) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bsum[e] += sg[e];
+      }
+      char* dst = smem + g_dst + it.gbuf * (GCELLS * 16);
+      ckw_split8(sg, p1, p2, p3);
+      *reinterpret_cast<u32x4*>(dst) = p1;
+      *reinterpret_cast<u32x4*>(dst + GPLANE) = p2;
+      *reinterpret_cast<u32x4*>(dst + 2 * GPLANE) = p3;
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (k == 1 && !extra) continue;
+      char* dst = smem + x_dst[k] + it.xslot * (XPAIR * 16);
+      ckw_split8(sx[k], p1, p2, p3);
+      *reinterpret_cast<u32x4*>(dst) = p1;
+      *reinterpret_cast<u32x4*>(dst + XPLANE) = p2;
+      *reinterpret_cast<u32x4*>(dst + 2 * XPLANE) = p3;
+    }
+  };
+
+  // ---- the item sequence of this workgroup: units u_begin .. u_end - 1, row pair fastest inside (sample, segment) ----
+  int u = u_begin, xcount = 0, gcount = 0;
+  bool fresh = true;
+  auto next_item = [&]() -> Item {
+    Item it;
+    it.valid = u < u_end;
+    if (!it.valid) { it.has_g = 0; it.n = it.seg = it.xpair = it.xslot = it.gbuf = 0; return it; }
+    const int rp = u % a.upr, rest = u / a.upr;
+    it.seg = rest % a.ups;
+    it.n = (rest / a.ups) * a.T + t;
+    it.xslot = xcount % 3; ++xcount;
+    if (fresh) {
+      it.xpair = rp; it.has_g = 0; it.gbuf = 0; fresh = false;
+    } else {
+      it.xpair = rp + 1; it.has_g = 1; it.gbuf = gcount & 1; ++gcount;
+      ++u;
+      fresh = (u % a.upr) == 0;            // the next unit starts a new segment (or sample)
+    }
+    return it;
+  };
+
+  // ---- fragment addresses (transpose reads) ----
+  const int frag_lane = (c4 & 1) * 8;
+  int a_addr[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) a_addr[m] = (2 * (MT * wm + m) + (c4 >> 1)) * GOCT + (8 * g + kq) * 16 + frag_lane;
+  const int b_addr = XBASE + (2 * wn + (c4 >> 1)) * XOCT + (8 * g + kq) * 16 + frag_lane;
+
+  f32x4 acc[9][MT];
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[tp][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  auto tr_read = [&](int addr, int imm) -> bf16x8 {
+    typedef __attribute__((address_space(3))) bf16x4 lds_b4;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(smem + addr + imm));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_b4*)(smem + addr + imm + 4 * 16));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+  constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+
+  Item cur = next_item(), prev;
+  prev.valid = 0; prev.has_g = 0; prev.xslot = 0; prev.gbuf = 0;
+  if (cur.valid) stage_load(cur);
+  while (cur.valid || prev.has_g) {
+    const Item nxt = next_item();
+    // the unit completed by `prev`: cotangent buffer prev.gbuf, input rows 0, 1 in the slot before prev.xslot, rows 2, 3 in prev.xslot
+    bf16x8 aq[2][MT][3], bq[2][3];
+    int brow[4];
+    {
+      const int s1 = prev.xslot, s0 = s1 == 0 ? 2 : s1 - 1;
+      brow[0] = b_addr + (s0 * UR2) * XCOLS * 16; brow[1] = brow[0] + XCOLS * 16;
+      brow[2] = b_addr + (s1 * UR2) * XCOLS * 16; brow[3] = brow[2] + XCOLS * 16;
+    }
+    const int abase = prev.gbuf * (GCELLS * 16);
+    auto load_a = [&](int r) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) aq[r][m][p] = tr_read(a_addr[m] + abase, p * GPLANE + r * UW * 16);
+    };
+    auto load_b = [&](int gi) {
+      const int r = gi / 9, tap = gi % 9, ky = tap / 3, kx = tap % 3;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bq[gi & 1][p] = tr_read(brow[r + ky], p * XPLANE + kx * 16);
+    };
+    // row 0 reads its own fragments first (the one exposed LDS latency of a step); row 1's cotangent fragments and first input fragment are
+    // requested inside row 0, so that the staging between the rows does not sit in front of a wait
+    auto row_of_mfmas = [&](int r) {
+      if (r == 0) { load_a(0); load_b(0); }
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int gi = 9 * r + tap;
+        if (gi + 1 < 18) load_b(gi + 1);
+        if (r == 0 && tap == 4) load_a(1);
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+            acc[tap][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[r][m][PA[q]], bq[gi & 1][PB[q]], acc[tap][m], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    if (prev.has_g) row_of_mfmas(0);
+    if (cur.valid) stage_write(cur);                 // (waits for its loads: issued a step ago)
+    if (nxt.valid) stage_load(nxt);
+    __builtin_amdgcn_sched_barrier(0);
+    if (prev.has_g) row_of_mfmas(1);
+    __syncthreads();
+    prev = cur; cur = nxt;
+  }
+
+  if (do_bias) {          // wave `go` holds the sums of its octet's eight channels over this workgroup's units: lanes meet, lane 0 stores
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float s = wave_sum(bsum[e]);
+      const int co = co0 + 8 * go + e;
+      if (lane == 0 && co < a.Co) bias_partial[((size_t)split * a.T + t) * a.Co + co] = s;
+    }
+  }
+
+  // ---- D row 4 g + j = co, D column sl = ci; this lane's nine taps of a (co, ci) pair are contiguous in the partial block ----
+  float* __restrict__ pout = a.partial + ((size_t)split * a.T + t) * a.Co * a.Ci * 9;
+  const int ci = ci0 + 16 * wn + sl;
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int co = co0 + 16 * (MT * wm + m) + 4 * g + j;
+      if (co < a.Co && ci < a.Ci) {
+        float* o = pout + ((size_t)co * a.Ci + ci) * 9;
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) o[tp] = acc[tp][m][j];
+      }
+    }
+}
+
 // Sum of the partial blocks in a FIXED order (deterministic): a workgroup = 32 outputs x 8 split groups; thread (output, group)
 // adds the splits k = group (mod 8) in increasing order, the eight group sums meet in LDS and are added in group order.
 __global__ __launch_bounds__(256) void convk_wgrad_reduce(const float* __restrict__ partial, float* __restrict__ gw, long long n, int splits) {
@@ -380,7 +643,7 @@ __global__ __launch_bounds__(256) void convk_wgrad_reduce(const float* __restric
   }
 }
 
-struct WgPlan { int mt, nt, ng, cobs, cibs, units, upr, ups, splits, ups_per_split; };
+struct WgPlan { int mt, nt, ng, cobs, cibs, units, upr, ups, splits, ups_per_split, form; };   // form (3 x 3): 0 taps dealt out to the waves, 2 all taps per wave on a ring of input rows
 
 inline int savfi_cu_count() {
   static int cus[32] = {0};
@@ -414,9 +677,15 @@ inline int wg_plan(WgPlan& p, int N, int T, int Ci, int Co, int H, int W, int K,
     static const int ng_env = getenv("SAVFI_WGRAD_NG") ? atoi(getenv("SAVFI_WGRAD_NG")) : 1;
     if (ng_env == 2 && K == 3 && p.mt == 4 && !precise && Ci >= 32) p.ng = 2;
   }
+  // 3 x 3 with at least 48 channels on both sides: all nine taps per wave on 64 x 64 channel blocks, one 8-wave workgroup per CU
+  // (SAVFI_WGRAD3_FORM=0: the tap-split kernel, for A/Bs)
+  static const int form_env = getenv("SAVFI_WGRAD3_FORM") ? atoi(getenv("SAVFI_WGRAD3_FORM")) : 2;
+  p.form = (K == 3 && !precise && Co >= 48 && Ci >= 48 && form_env == 2) ? 2 : 0;
+  if (p.form) { p.mt = 4; p.nt = 4; p.ng = 1; }
   p.cobs = (Co + 16 * p.mt - 1) / (16 * p.mt);
   p.cibs = (Ci + 16 * p.nt * p.ng - 1) / (16 * p.nt * p.ng);
-  p.upr = (Ho + UR - 1) / UR;
+  const int ur = p.form == 2 ? ring::UR2 : UR;
+  p.upr = (Ho + ur - 1) / ur;
   p.ups = (Wo + UW - 1) / UW;
   p.units = (N / T) * p.upr * p.ups;
   const int blocks = T * p.cobs * p.cibs;
@@ -430,7 +699,7 @@ inline int wg_plan(WgPlan& p, int N, int T, int Ci, int Co, int H, int W, int K,
   if (target > 0) {
     splits = (target + blocks - 1) / blocks;
   } else {
-    const int per_cu = p.ng == 2 ? 1 : (K == 3 && p.mt == 2 && p.nt == 1 && !precise) ? 3 : 2;
+    const int per_cu = (p.ng == 2 || p.form) ? 1 : (K == 3 && p.mt == 2 && p.nt == 1 && !precise) ? 3 : 2;
     const int64_t slots = (int64_t)per_cu * savfi_cu_count();
     double best_cost = 0.0;
     splits = 1;
@@ -439,7 +708,7 @@ inline int wg_plan(WgPlan& p, int N, int T, int Ci, int Co, int H, int W, int K,
       const int ups = (p.units + sp - 1) / sp;
       if ((p.units + ups - 1) / ups != sp) continue;                   // not a distinct cut
       const int64_t rounds = ((int64_t)blocks * sp + slots - 1) / slots;
-      const double cost = (double)rounds * (ups + 1.0) + 0.06 * sp;
+      const double cost = p.form == 2 ? (double)rounds * (ups + 3.0) + 0.12 * sp : (double)rounds * (ups + 1.0) + 0.06 * sp;
       if (sp == 1 || cost < best_cost) { best_cost = cost; splits = sp; }
     }
   }
@@ -448,6 +717,16 @@ inline int wg_plan(WgPlan& p, int N, int T, int Ci, int Co, int H, int W, int K,
   p.ups_per_split = (p.units + splits - 1) / splits;
   p.splits = (p.units + p.ups_per_split - 1) / p.ups_per_split;
   return SAVFI_OK;
+}
+
+int launch_wgrad3_ring(const WgArgs& a, int blocks, float* bias_partial, hipStream_t stream) {
+  static uint32_t configured = 0, configured_b = 0;
+  const int rc = bias_partial ? savfi_ensure_dynamic_lds(reinterpret_cast<const void*>(convk_wgrad3_ring<true>), ring::LDS, configured_b)
+                              : savfi_ensure_dynamic_lds(reinterpret_cast<const void*>(convk_wgrad3_ring<false>), ring::LDS, configured);
+  if (rc != SAVFI_OK) return rc;
+  if (bias_partial) hipLaunchKernelGGL(convk_wgrad3_ring<true>, dim3(blocks), dim3(ring::NTHR), ring::LDS, stream, a, bias_partial);
+  else hipLaunchKernelGGL(convk_wgrad3_ring<false>, dim3(blocks), dim3(ring::NTHR), ring::LDS, stream, a, bias_partial);
+  return savfi_launch_status();
 }
 
 template <int KS, int MT, int NT, bool P2 = false, int NG = 1>
@@ -471,7 +750,12 @@ extern "C" int64_t savfi_convk_wgrad_workspace_floats(int N, int T, int Ci, int 
   if (rc != SAVFI_OK) return rc;
   rc = wg_plan(q, N, T, Ci, Co, H, W, K, pad, true);
   if (rc != SAVFI_OK) return rc;
-  return (int64_t)(p.splits > q.splits ? p.splits : q.splits) * T * Co * Ci * K * K;
+  return (int64_t)(p.splits > q.splits ? p.splits : q.splits) * T * Co * (Ci * K * K + 1);     // (+ 1: the bias sums' partial blocks)
+}
+
+extern "C" int savfi_convk_wgrad_sums_bias(int N, int T, int Ci, int Co, int H, int W, int K, int pad) {
+  WgPlan p;
+  return wg_plan(p, N, T, Ci, Co, H, W, K, pad, false) == SAVFI_OK && p.form == 2 ? 1 : 0;
 }
 
 extern "C" int savfi_convk_wgrad_tasks_f32(const float* x, const float* gz, float* gw, float* workspace, int N, int T, int Ci, int Co,
@@ -479,8 +763,26 @@ extern "C" int savfi_convk_wgrad_tasks_f32(const float* x, const float* gz, floa
   return savfi_convk_wgrad_tasks_reflect_f32(x, gz, gw, workspace, N, T, Ci, Co, H, W, K, pad, precise, 0, stream);
 }
 
+namespace {
+int convk_wgrad_run(const float* x, const float* gz, float* gw, float* gb, float* workspace, int N, int T, int Ci, int Co, int H, int W, int K,
+                    int pad, int precise, int reflect, void* stream);
+}
+
 extern "C" int savfi_convk_wgrad_tasks_reflect_f32(const float* x, const float* gz, float* gw, float* workspace, int N, int T, int Ci,
                                                    int Co, int H, int W, int K, int pad, int precise, int reflect, void* stream) {
+  return convk_wgrad_run(x, gz, gw, nullptr, workspace, N, T, Ci, Co, H, W, K, pad, precise, reflect, stream);
+}
+
+extern "C" int savfi_convk_wgrad_tasks_bias_f32(const float* x, const float* gz, float* gw, float* gb, float* workspace, int N, int T, int Ci,
+                                                int Co, int H, int W, int K, int pad, int reflect, void* stream) {
+  if (!gb) return SAVFI_E_NULL;
+  if (!savfi_convk_wgrad_sums_bias(N, T, Ci, Co, H, W, K, pad)) return SAVFI_E_UNSUPPORTED;
+  return convk_wgrad_run(x, gz, gw, gb, workspace, N, T, Ci, Co, H, W, K, pad, 0, reflect, stream);
+}
+
+namespace {
+int convk_wgrad_run(const float* x, const float* gz, float* gw, float* gb, float* workspace, int N, int T, int Ci, int Co, int H, int W, int K,
+                    int pad, int precise, int reflect, void* stream) {
   if (reflect && (pad >= H || pad >= W)) return SAVFI_E_UNSUPPORTED;
   if (!x || !gz || !gw || !workspace) return SAVFI_E_NULL;
   WgPlan p;
@@ -494,7 +796,9 @@ extern "C" int savfi_convk_wgrad_tasks_reflect_f32(const float* x, const float* 
   a.upr = p.upr; a.ups = p.ups;
   const int blocks = T * p.cobs * p.cibs * p.splits;
   hipStream_t st = (hipStream_t)stream;
-  if (K == 3 && precise) rc = p.mt == 4 ? launch_wgrad<3, 4, 1, true>(a, blocks, st) : launch_wgrad<3, 2, 1, true>(a, blocks, st);
+  float* bias_partial = gb ? workspace + (size_t)p.splits * T * Co * Ci * K * K : nullptr;
+  if (p.form == 2) rc = launch_wgrad3_ring(a, blocks, bias_partial, st);
+  else if (K == 3 && precise) rc = p.mt == 4 ? launch_wgrad<3, 4, 1, true>(a, blocks, st) : launch_wgrad<3, 2, 1, true>(a, blocks, st);
   else if (K == 3 && p.ng == 2) rc = launch_wgrad<3, 4, 1, false, 2>(a, blocks, st);
   else if (K == 3) rc = p.mt == 4 ? launch_wgrad<3, 4, 1>(a, blocks, st) : p.nt == 2 ? launch_wgrad<3, 2, 2>(a, blocks, st) : launch_wgrad<3, 2, 1>(a, blocks, st);
   else if (K == 5) rc = precise ? launch_wgrad<5, 2, 1, true>(a, blocks, st) : p.nt == 2 ? launch_wgrad<5, 2, 2>(a, blocks, st) : launch_wgrad<5, 2, 1>(a, blocks, st);
@@ -502,5 +806,7 @@ extern "C" int savfi_convk_wgrad_tasks_reflect_f32(const float* x, const float* 
   if (rc != SAVFI_OK) return rc;
   const long long n = (long long)T * Co * Ci * K * K;
   hipLaunchKernelGGL(convk_wgrad_reduce, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, st, workspace, gw, n, p.splits);
+  if (gb) hipLaunchKernelGGL(convk_wgrad_reduce, dim3((unsigned)((T * Co + 31) / 32)), dim3(256), 0, st, bias_partial, gb, (long long)T * Co, p.splits);
   return savfi_launch_status();
 }
+}  // namespace

@@ -688,17 +688,25 @@ CONVK = not os.environ.get('SAVFI_NO_CONVK')
 CONVK_3X3_MIN_PIXELS = 700
 
 
+CONVK_WGRAD3_RING_MIN_PIXELS = 3000
+
+
 def convk_wgrad_preferred(K, Ci, Co, Ho, Wo, direct=False):
     """Weight gradient of a stride-1 K x K layer on csrc/convk_wgrad.hip rather than the Winograd / MIOpen forms?  5x5 / 7x7 and
-    `direct` layers always; 3x3 where the split-bf16 kernel measured faster than savfi_conv3x3_wgrad_wino (tools/convk_bench.py,
-    profiles/r03_convk_bench.jsonl): the wide shallow layers (<= 32 input channels: 89 vs 167 us for 6 -> 32 and 195 vs 252 us for
-    32 -> 32 at 384 x 512, T = 4) and >= 192 output channels on maps of >= 4096 pixels (CAIN 192 -> 192 at 96 x 160: 147 vs 158 us)."""
+    `direct` layers always; 3x3 where the split-bf16 kernels measured faster than savfi_conv3x3_wgrad_wino:
+    * >= 48 -> 48 channels on maps of >= 3000 pixels -- the all-taps kernel on the row ring (round 5; tools/wgrad3_forms_time.py,
+      profiles/r05_wgrad3_forms.txt: 160-167 vs 181-184 us on 64 -> 64 @192x256 / 128 -> 128 @96x128, 82 vs 99 on 128 -> 64 @96x128, 57 vs 69 on
+      64 -> 64 @96x128 at T = 4 x 2 samples; CAIN 192 -> 192 @96x160: 127 vs 164; the deep 24x32 / 12x16 layers stay on Winograd: 215 vs 180);
+    * the wide shallow layers (<= 32 input channels: 89 vs 167 us for 6 -> 32 and 195 vs 252 us for 32 -> 32 at 384 x 512, T = 4)
+      and >= 192 output channels on maps of >= 4096 pixels on the tap-split kernel (profiles/r03_convk_bench.jsonl)."""
     if not CONVK or K not in (3, 5, 7):
         return False
     if K != 3 or direct:
         return True
     if os.environ.get('SAVFI_WGRAD_3X3_WINO'):
         return False
+    if Ci >= 48 and Co >= 48 and Ho * Wo >= CONVK_WGRAD3_RING_MIN_PIXELS:
+        return True
     return (Ci <= 32 and Ho * Wo >= 16384) or (Co >= 192 and Ho * Wo >= 4096)
 
 
@@ -1413,8 +1421,15 @@ def convk_tasks_pre(x, packed, T, Ci, Co, K, bias=None, mode=0, slope=1.0, pad=1
     return out
 
 
-def convk_wgrad_tasks(x, gz, T, K, pad, precise=False, reflect=False):
-    """savfi_convk_wgrad_tasks_f32: gw [T,Co,Ci,K,K], gw[t] over the samples n % T == t (direct K x K form, split-bf16 MFMAs)."""
+def convk_wgrad_tasks_sums_bias(x_shape, co, T, K, pad, precise=False):
+    """Will convk_wgrad_tasks(..., want_bias=True) hand out the bias gradient with the weight gradient (the all-taps 3 x 3 kernel does)?"""
+    N, Ci, H, W = x_shape
+    return bool(WGRAD_FUSE_BIAS and not precise and _hip.lib().savfi_convk_wgrad_sums_bias(N, T, Ci, co, H, W, K, int(pad)))
+
+
+def convk_wgrad_tasks(x, gz, T, K, pad, precise=False, reflect=False, want_bias=False):
+    """savfi_convk_wgrad_tasks_f32: gw [T,Co,Ci,K,K], gw[t] over the samples n % T == t (direct K x K form, split-bf16 MFMAs).
+    want_bias (only where convk_wgrad_tasks_sums_bias says yes): returns (gw, gb [T,Co]) -- the sums of gz ride on the kernel's staging of it."""
     x, gz = x.contiguous(), gz.contiguous()
     _hip.require_cuda(x, gz)
     N, Ci, H, W = x.shape
@@ -1423,9 +1438,17 @@ def convk_wgrad_tasks(x, gz, T, K, pad, precise=False, reflect=False):
     lib = _hip.lib()
     ws = torch.empty(_workspace_floats("savfi_convk_wgrad_workspace_floats", N, T, Ci, Co, H, W, K, int(pad)), dtype=x.dtype, device=x.device)
     gw = torch.empty((T, Co, Ci, K, K), dtype=x.dtype, device=x.device)
+    flops = 2.0 * K * K * Ci * Co * N * gz.shape[2] * gz.shape[3]
+    if want_bias:
+        assert not precise and convk_wgrad_tasks_sums_bias(x.shape, Co, T, K, pad), "ask convk_wgrad_tasks_sums_bias first"
+        gb = torch.empty((T, Co), dtype=x.dtype, device=x.device)
+        _hip.launch("convk_wgrad", lambda: _hip.check(lib.savfi_convk_wgrad_tasks_bias_f32(
+            x.data_ptr(), gz.data_ptr(), gw.data_ptr(), gb.data_ptr(), ws.data_ptr(), N, T, Ci, Co, H, W, K, int(pad),
+            int(bool(reflect)), _hip.current_stream()), "savfi_convk_wgrad_tasks_bias_f32"), flops=flops)
+        return gw, gb
     _hip.launch("convk_wgrad", lambda: _hip.check(lib.savfi_convk_wgrad_tasks_reflect_f32(
         x.data_ptr(), gz.data_ptr(), gw.data_ptr(), ws.data_ptr(), N, T, Ci, Co, H, W, K, int(pad), int(bool(precise)),
-        int(bool(reflect)), _hip.current_stream()), "savfi_convk_wgrad_tasks_reflect_f32"), flops=2.0 * K * K * Ci * Co * N * gz.shape[2] * gz.shape[3])
+        int(bool(reflect)), _hip.current_stream()), "savfi_convk_wgrad_tasks_reflect_f32"), flops=flops)
     return gw
 
 
@@ -1630,14 +1653,15 @@ class _ConvBiasActTasks(torch.autograd.Function):
         gz = gy if identity else torch.empty_like(gy)
         need_b = need_b and ctx.has_bias
         mask, mslope = (x, ctx.in_slope) if (ctx.in_slope is not None and need_x) else (None, 1.0)
-        # the bias gradient rides on the weight gradient's read of gz where that is the Winograd form and this function has nothing else to
-        # do with the cotangent (no activation derivative to apply here): one pass over the map less
+        # the bias gradient rides on the weight gradient's read of gz where that is the Winograd form or the all-taps direct kernel and this
+        # function has nothing else to do with the cotangent (no activation derivative to apply here): one pass over the map less
         pad_ = padding if isinstance(padding, int) else padding[0]
         K_ = int(w.shape[-1])
-        wgrad_is_wino3 = (need_w and not (_convk_geometry(w, stride, padding, dilation, 1) is not None and (ctx.route == 'convk' or K_ == 3)
-                                          and convk_wgrad_preferred(K_, Ci, Co, Ho, Wo, ctx.direct))
-                          and conv3x3_wgrad_tasks_eligible(x, w, stride, padding, dilation))
-        fuse_b = bool(need_b and identity and wgrad_is_wino3 and conv3x3_wgrad_tasks_sums_bias(x.shape, Co, T, pad_))
+        wgrad_is_convk = bool(need_w and _convk_geometry(w, stride, padding, dilation, 1) is not None and (ctx.route == 'convk' or K_ == 3)
+                              and convk_wgrad_preferred(K_, Ci, Co, Ho, Wo, ctx.direct))
+        wgrad_is_wino3 = need_w and not wgrad_is_convk and conv3x3_wgrad_tasks_eligible(x, w, stride, padding, dilation)
+        fuse_b = bool(need_b and identity and ((wgrad_is_wino3 and conv3x3_wgrad_tasks_sums_bias(x.shape, Co, T, pad_))
+                                               or (wgrad_is_convk and convk_wgrad_tasks_sums_bias(x.shape, Co, T, K_, pad_, ctx.direct))))
         gb = torch.empty((T, Co), dtype=gy.dtype, device=gy.device) if (need_b and not fuse_b) else None
         if (need_b and not fuse_b) or not identity:
             lib = _hip.lib()
@@ -1665,9 +1689,10 @@ class _ConvBiasActTasks(torch.autograd.Function):
             else:
                 gx = conv3x3_tasks(gz, w, None, 1, 1.0, pad)
             need_x = False
-        if need_w and _convk_geometry(w, stride, padding, dilation, 1) is not None and \
-                (ctx.route == 'convk' or K == 3) and convk_wgrad_preferred(K, Ci, Co, Ho, Wo, ctx.direct):
-            gw = convk_wgrad_tasks(x, gz, T, K, pad, ctx.direct)
+        if wgrad_is_convk:
+            gw = convk_wgrad_tasks(x, gz, T, K, pad, ctx.direct, want_bias=fuse_b)
+            if fuse_b:
+                gw, gb = gw
             need_w = False
         if need_w and conv3x3_wgrad_tasks_eligible(x, w, stride, padding, dilation):
             side = ctx.wg_stream if (ctx.wg_stream is not None and ctx.wg_uses[0] == 1) else None

@@ -1214,3 +1214,30 @@ def test_winograd_weight_gradient_hands_out_the_bias_gradient(N, T, Ci, Co, H, W
     ref = gz.double().view(N // T, T, Co, -1).sum((0, 3))
     assert (gb.double() - ref).abs().max().item() <= 1e-5 * gz.double().abs().view(N // T, T, Co, -1).sum((0, 3)).max().item()
     assert lib.savfi_conv3x3_wgrad_wino_tasks_bias_f32(x.data_ptr(), gz.data_ptr(), gw1.data_ptr(), None, ws1.data_ptr(), N, T, Ci, Co, H, W, pad, st) == -1
+
+
+@pytest.mark.parametrize("N,T,Ci,Co,H,W,pad,reflect", [
+    (8, 4, 64, 64, 48, 64, 1, 0), (4, 1, 51, 51, 66, 130, 0, 0), (2, 2, 70, 100, 37, 53, 1, 0), (2, 1, 192, 192, 33, 47, 1, 1),
+    (3, 3, 64, 128, 5, 200, 2, 0), (1, 1, 48, 48, 1, 1, 1, 0), (6, 2, 128, 64, 31, 33, 1, 0)])
+def test_all_taps_weight_gradient_matches_float64_and_hands_out_the_bias_gradient(N, T, Ci, Co, H, W, pad, reflect):
+    """convk_wgrad3_ring (3 x 3 layers of >= 48 -> 48 channels: all nine taps per wave, input rows on a ring): against a float64 weight gradient
+    on maps with odd row counts, ragged channel blocks, several column segments, every padding, a mirrored border and T > 1; with the bias
+    sums on (savfi_convk_wgrad_tasks_bias_f32) the weight gradient is bit for bit the same and gb[t][co] is the sum of the cotangent."""
+    lib, st = _hip.lib(), _hip.current_stream()
+    assert lib.savfi_convk_wgrad_sums_bias(N, T, Ci, Co, H, W, 3, pad) == 1 and lib.savfi_convk_wgrad_sums_bias(N, T, 32, Co, H, W, 3, pad) == 0
+    g = torch.Generator().manual_seed(N * 1000 + Co + H)
+    Ho, Wo = H + 2 * pad - 2, W + 2 * pad - 2
+    x = torch.randn(N, Ci, H, W, generator=g)
+    gz = torch.randn(N, Co, Ho, Wo, generator=g)
+    xd, gd = x.to(DEV), gz.to(DEV)
+    gw0 = hip_ops.convk_wgrad_tasks(xd, gd, T, 3, pad, False, bool(reflect))
+    gw1, gb = hip_ops.convk_wgrad_tasks(xd, gd, T, 3, pad, False, bool(reflect), want_bias=True)
+    assert torch.equal(gw0, gw1)
+    xs = F.pad(x.double(), (pad,) * 4, mode='reflect') if reflect else x.double()
+    wref = torch.stack([torch.nn.grad.conv2d_weight(xs[t::T], (Co, Ci, 3, 3), gz.double()[t::T], padding=0 if reflect else pad) for t in range(T)], 0)
+    assert _rel(gw0.cpu().double(), wref) < 3e-6
+    ref = gz.double().view(N // T, T, Co, -1).sum((0, 3))
+    assert (gb.cpu().double() - ref).abs().max().item() <= 1e-5 * max(1.0, gz.double().abs().view(N // T, T, Co, -1).sum((0, 3)).max().item())
+    ws = torch.empty(int(lib.savfi_convk_wgrad_workspace_floats(N, T, 32, Co, H, W, 3, pad)), device=DEV)
+    x32 = torch.zeros(N, 32, H, W, device=DEV)
+    assert lib.savfi_convk_wgrad_tasks_bias_f32(x32.data_ptr(), gd.data_ptr(), gw1.data_ptr(), gb.data_ptr(), ws.data_ptr(), N, T, 32, Co, H, W, 3, pad, 0, st) != 0

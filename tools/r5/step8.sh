@@ -1,10 +1,9 @@
-R=$GRAFT_REPO_ROOT; A=$R/gpurun_out/r5s8; mkdir -p $A; cd $R
-V=$R/tools/scratch/variants
-python -m pytest tests/test_sepconv_frames8_gpu.py tests/test_hip_ops_gpu.py tests/test_ws_timeout_gpu.py -x -q -k "sepconv or frames8 or pair or wait" 2>&1 | tail -3
-python tools/frames8_time.py 8 256 448 fwd_six,fwd_frames8,fwd_frames8_unit16 2>&1 | grep op | cut -c1-220
-SAVFI_HIP_LIB=$V/libsavfi_trace.so python tools/ws_trace_fwd.py 8 1 > $A/fwd_trace.txt 2>&1
-tail -14 $A/fwd_trace.txt | cut -c1-400
-B="python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-strong-c4"
-P='import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(sys.argv[1], round(d["value"],1), {k:(round(v["avg_us"],1), round(v["min_us"],1)) for k,v in d["kernels"].items()}, round(d["roofline"]["frac"],4))'
-$B 2>/dev/null | python -c "$P" default
-$B 2>/dev/null | python -c "$P" default
+#!/bin/bash
+# PMC of the all-taps weight gradient
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/w3; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/pmc1 -- python $R/tools/wgrad3_pmc.py > /dev/null 2>&1
+python $R/tools/pmc_summary.py /tmp/pmc1 wgrad > $O/pmc.txt 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU --kernel-trace --output-format csv -d /tmp/pmc2 -- python $R/tools/wgrad3_pmc.py > /dev/null 2>&1
+python $R/tools/pmc_summary.py /tmp/pmc2 wgrad >> $O/pmc.txt 2>&1
+rocprofv3 --pmc SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_LDS_MEM_VIOLATIONS SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU_MFMA_MOPS_BF16 --kernel-trace --output-format csv -d /tmp/pmc3 -- python $R/tools/wgrad3_pmc.py > /dev/null 2>&1
+python $R/tools/pmc_summary.py /tmp/pmc3 wgrad >> $O/pmc.txt 2>&1
