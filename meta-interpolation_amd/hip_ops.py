@@ -705,7 +705,7 @@ def convk_wgrad_preferred(K, Ci, Co, Ho, Wo, direct=False):
         return True
     if os.environ.get('SAVFI_WGRAD_3X3_WINO'):
         return False
-    if Ci >= 48 and Co >= 48 and Ho * Wo >= CONVK_WGRAD3_RING_MIN_PIXELS:
+    if Ci >= 48 and Co >= 48 and Ho * Wo >= CONVK_WGRAD3_RING_MIN_PIXELS and not os.environ.get('SAVFI_WGRAD3_NO_RING'):      # (the switch: A/Bs)
         return True
     return (Ci <= 32 and Ho * Wo >= 16384) or (Co >= 192 and Ho * Wo >= 4096)
 

@@ -12,6 +12,7 @@ SAVFI_SEPCONV_PAIR_TWO_LAUNCHES=1 $B 2>/dev/null | tag "two launches per pass (S
 $B 2>/dev/null | tag "one launch per pass (default)" >> $A/r05_pair_ab.jsonl
 SAVFI_UPSAMPLE_BWD_FORM=1 $B 2>/dev/null | tag "default, bilinear x2 backward tiled (SAVFI_UPSAMPLE_BWD_FORM=1)" >> $A/r05_pair_ab.jsonl
 SAVFI_WGRAD_NO_BIAS=1 $B 2>/dev/null | tag "default, bias sums as their own pass (SAVFI_WGRAD_NO_BIAS=1)" >> $A/r05_pair_ab.jsonl
+SAVFI_WGRAD3_NO_RING=1 $B 2>/dev/null | tag "default, 3x3 weight gradients routed as before the all-taps kernel (SAVFI_WGRAD3_NO_RING=1)" >> $A/r05_pair_ab.jsonl
 $B 2>/dev/null | tag "one launch per pass (default), again" >> $A/r05_pair_ab.jsonl
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_c2 -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-strong-c4 > $A/r05_bench_line_profiled.json 2>/dev/null
@@ -38,7 +39,16 @@ tools/scratch/membench > $A/r05_membench.txt 2>&1
 python tools/glue_bench.py 2>&1 | grep map > $A/r05_glue_bench.txt
 python tools/upsample_bench.py 2>&1 | grep lib > $A/r05_upsample_bench.txt
 SAVFI_UPSAMPLE_BWD_FORM=1 python tools/upsample_bench.py 2>&1 | grep lib | sed 's/"lib": "default"/"lib": "tiled form (SAVFI_UPSAMPLE_BWD_FORM=1)"/' >> $A/r05_upsample_bench.txt
+(python tools/wgrad3_forms_time.py c2; python tools/wgrad3_forms_time.py c5) 2>&1 | grep "^{" > $A/r05_wgrad3_forms.txt
+(SAVFI_WGRAD3_FORM=0 python tools/wgrad3_forms_time.py c2; SAVFI_WGRAD3_FORM=0 python tools/wgrad3_forms_time.py c5) 2>&1 | grep "^{" | sed 's/^{/{"form": "tap-split kernel (SAVFI_WGRAD3_FORM=0)", /' >> $A/r05_wgrad3_forms.txt
+cd /tmp
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d /tmp/pmcw1 -- python $R/tools/wgrad3_pmc.py > /dev/null 2>&1
+python $R/tools/pmc_summary.py /tmp/pmcw1 wgrad > $A/r05_pmc_wgrad3.txt 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU --kernel-trace --output-format csv -d /tmp/pmcw2 -- python $R/tools/wgrad3_pmc.py > /dev/null 2>&1
+python $R/tools/pmc_summary.py /tmp/pmcw2 wgrad >> $A/r05_pmc_wgrad3.txt 2>&1
+cd $R
 python tools/layer_table.py --workload c2_sepconv_256x448_b4_s5 --top 60 > $A/r05_layer_table_c2.txt 2>/dev/null
+SAVFI_WGRAD3_FORM=0 python bench.py --workload c5_cain_l2f_720p_b1_s1 --steps 3 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); d['config']['note']='3x3 weight gradients on the tap-split kernel (SAVFI_WGRAD3_FORM=0)'; print(json.dumps(d))" > $A/r05_c5_wgrad_ab.jsonl
 for w in c4_sepconv_msl_256x448_b4_s5 c3_voxelflow_metasgd_256x256_b8_s5 c5_cain_l2f_720p_b1_s1 rrin_256x448_b4_s5 superslomo_256x448_b4_s5 c1_cain_64x64_b1_s1; do python bench.py --workload $w --steps 3 --warmup 2 2>/dev/null >> $A/r05_other_configs.jsonl; done
 python -m pytest tests -m gpu -q 2>&1 | tail -9 > $A/r05_pytest_gpu_tail.txt
 python -c "import __graft_entry__ as g; g.smoke()" > $A/r05_smoke.txt 2>&1; tail -3 $A/r05_smoke.txt
