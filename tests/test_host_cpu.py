@@ -313,3 +313,22 @@ def test_composed_voxel_warp_for_second_order_matches_the_oracle_and_differentia
     f = torch.rand(1, 6, 5, 6, dtype=torch.double, generator=gen).requires_grad_()
     x = ((torch.rand(1, 3, 5, 6, dtype=torch.double, generator=gen) * 2 - 1) * 0.9).requires_grad_()
     assert torch.autograd.gradgradcheck(hip_ops._voxel_warp_composed, (f, x), eps=1e-7, atol=1e-5)
+
+
+def test_3x3_weight_gradient_routing_rules(monkeypatch):
+    """hip_ops.convk_wgrad_preferred: which weight gradients go to the split-bf16 kernels (pure host logic; the measured table behind the
+    rules: profiles/r05_wgrad3_forms.txt) -- and the library agrees on which of them hand out the bias sums."""
+    from meta_interpolation_amd import hip_ops, _hip
+    pref = hip_ops.convk_wgrad_preferred
+    assert pref(5, 6, 64, 256, 256) and pref(7, 32, 32, 256, 448)                       # 5x5 / 7x7: always
+    assert pref(3, 128, 128, 96, 128) and pref(3, 64, 51, 137, 236) and pref(3, 51, 51, 256, 448)     # all-taps kernel: >= 48 -> 48, >= 3000 px
+    assert not pref(3, 512, 512, 24, 32) and not pref(3, 512, 512, 12, 16)              # deep small maps: Winograd form
+    assert pref(3, 32, 32, 384, 512) and not pref(3, 32, 32, 96, 128)                   # wide shallow layers on the tap-split kernel
+    assert pref(3, 512, 512, 12, 16, direct=True)                                       # a plugin that asks for the direct form gets it
+    monkeypatch.setenv('SAVFI_WGRAD3_NO_RING', '1')
+    assert not pref(3, 128, 128, 96, 128) and pref(3, 192, 192, 96, 160)
+    monkeypatch.delenv('SAVFI_WGRAD3_NO_RING')
+    lib = _hip.lib()
+    assert lib.savfi_convk_wgrad_sums_bias(8, 4, 128, 128, 96, 128, 3, 1) == 1
+    assert lib.savfi_convk_wgrad_sums_bias(8, 4, 32, 32, 384, 512, 3, 1) == 0 and lib.savfi_convk_wgrad_sums_bias(2, 1, 64, 128, 128, 128, 5, 2) == 0
+    assert lib.savfi_convk_wgrad_workspace_floats(8, 4, 128, 128, 96, 128, 3, 1) >= 4 * 128 * (128 * 9 + 1)
