@@ -28,7 +28,7 @@ import torch.nn.functional as F
 
 from .. import hip_ops
 from ..hip_ops import Upsample2x, upsample_bilinear2x_window, upsample_window_sources
-from ..model_utils import MetaConv2dLayer, MetaSequential, as_view, fuse_conv_act, own_params_const, zero_grad_params
+from ..model_utils import MetaConv2dLayer, MetaSequential, as_view, fuse_conv_act, fuse_conv_chain, own_params_const, zero_grad_params
 from .sepconv_op.sepconv import FunctionSepconv, FunctionSepconvPair, frames8_supported
 
 TAPS_UNIT16 = os.environ.get('SAVFI_SEPCONV_TAPS_PLANAR') is None
@@ -151,10 +151,19 @@ class MetaNetwork(nn.Module):
             self._windows[key] = dict(half=(hh, hw), crop=(cy0, cy1, cx0, cx1), up=up)
         return self._windows[key]
 
+    @staticmethod
+    def _chain(x):
+        """conv -> ReLU -> conv outside a MetaSequential (the windowed Subnets call their layers one by one): may the producer leave its
+        activation derivative to its single consumer?  The rule of MetaSequential.forward (model_utils.py)."""
+        return bool(x.is_cuda and fuse_conv_chain() and fuse_conv_act() and not hip_ops.double_backward() and torch.is_grad_enabled())
+
     def _subnet_window(self, seq, crop, win):
-        x = seq[0](crop, act_slope=0.0)
-        x = seq[2](x, act_slope=0.0)
-        x = seq[4](x, act_slope=0.0)
+        ch = self._chain(crop)
+        c0, c2 = ({'want_defer': True} if ch else None), ({'want_defer': True} if ch else None)
+        slope = lambda c: 0.0 if (c is not None and c.get('deferred')) else None
+        x = seq[0](crop, act_slope=0.0, chain=c0)
+        x = seq[2](x, act_slope=0.0, in_slope=slope(c0), chain=c2)
+        x = seq[4](x, act_slope=0.0, in_slope=slope(c2))
         x = upsample_bilinear2x_window(x, win['half'], (win['crop'][0], win['crop'][2]), win['up'], True)
         return seq[7](x, padding=0)       # [N,51,height,width]: exactly the frame area
 
@@ -206,10 +215,15 @@ class MetaNetwork(nn.Module):
         ref = getattr(self, self._SUBNETS[0])
         sp = self._stacked_subnet_params()
         N = crop.size(0)
-        x = ref[0](crop, params={'weight': sp['w0'], 'bias': sp['b0']}, act_slope=0.0)          # [N, 256, h, w]
+        # conv -> ReLU -> conv: the intermediate maps have one consumer each, which folds the producer's ReLU derivative into its data
+        # gradient (the three element-wise passes over [4 N, 64, h, w] that the layers called one by one used to run: 2.5 ms of a C2 iteration)
+        ch = self._chain(crop)
+        c0, c2 = ({'want_defer': True} if ch else None), ({'want_defer': True} if ch else None)
+        slope = lambda c: 0.0 if (c is not None and c.get('deferred')) else None
+        x = ref[0](crop, params={'weight': sp['w0'], 'bias': sp['b0']}, act_slope=0.0, chain=c0)          # [N, 256, h, w]
         x = x.view(4 * N, 64, x.size(2), x.size(3))                                            # sample 4 n + s: Subnet s
-        x = ref[2](x, params={'weight': sp['w2'], 'bias': sp['b2']}, act_slope=0.0)
-        x = ref[4](x, params={'weight': sp['w4'], 'bias': sp['b4']}, act_slope=0.0)
+        x = ref[2](x, params={'weight': sp['w2'], 'bias': sp['b2']}, act_slope=0.0, in_slope=slope(c0), chain=c2)
+        x = ref[4](x, params={'weight': sp['w4'], 'bias': sp['b4']}, act_slope=0.0, in_slope=slope(c2))
         x = upsample_bilinear2x_window(x, win['half'], (win['crop'][0], win['crop'][2]), win['up'], True)
         # The taps leave the last convolution UNIT-MAJOR where the shapes allow (a sample [H][W / 16][51][16] instead of [51][H][W]): the
         # 51-tap op then reads a unit's taps as one contiguous run instead of 64-byte pieces of 51 planes.  The tensor keeps
