@@ -299,6 +299,13 @@ int savfi_upsample2x_window_fwd_f32(const float* in, float* out, int planes, int
                                     int Hs, int Ws, int oy0, int ox0, int Hw, int Ww, int align_corners, void* stream);
 int savfi_upsample2x_window_bwd_f32(const float* gout, float* gin, int planes, int H, int W, int sy0, int sx0,
                                     int Hs, int Ws, int oy0, int ox0, int Hw, int Ww, int align_corners, void* stream);
+/* the same adjoint with the (leaky) ReLU derivative of the up-sampled map's PRODUCER folded into its store:
+ *   gin[i] *= (y[i] > 0 ? 1 : slope),   y [planes,Hs,Ws] = that producer's activated output = the op's forward input (y == NULL: plain)
+ * -- what autograd runs as ReLU's backward between the two (reference: nn.ReLU after the Subnets' third convolution and after every
+ * Basic block in front of an Upsample, sepconv/model.py:172-245); here one element-wise pass over the map less. */
+int savfi_upsample2x_window_bwd_masked_f32(const float* gout, const float* y, float slope, float* gin, int planes, int H, int W,
+                                           int sy0, int sx0, int Hs, int Ws, int oy0, int ox0, int Hw, int Ww, int align_corners,
+                                           void* stream);
 
 /* ----------------------------------------------------------------------------------
  * 3x3 / stride 1 / zero-pad 1 convolution of the backbones (sepconv/model.py:172-245 Basic / Subnet /

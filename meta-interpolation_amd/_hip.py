@@ -111,6 +111,7 @@ _PROTOTYPES = {
     "savfi_frames_u8_to_f32": [_P, _P, c_int64, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float, _P],
     "savfi_upsample2x_window_fwd_f32": [_P, _P] + [c_int] * 12 + [_P],
     "savfi_upsample2x_window_bwd_f32": [_P, _P] + [c_int] * 12 + [_P],
+    "savfi_upsample2x_window_bwd_masked_f32": [_P, _P, c_float, _P] + [c_int] * 12 + [_P],
     "savfi_bias_act_fwd_f32": [_P, _P, c_int, c_int, c_int, c_float, _P],
     "savfi_bias_act_scratch_floats": [c_int, c_int, c_int],
     "savfi_bias_act_bwd_f32": [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P],

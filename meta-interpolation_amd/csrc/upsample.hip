@@ -96,7 +96,13 @@ __global__ __launch_bounds__(256) void upsample2x_fwd(const float* __restrict__ 
   }
 }
 
-__global__ __launch_bounds__(256) void upsample2x_bwd(const float* __restrict__ gout, float* __restrict__ gin, Win g) {
+// (leaky) ReLU derivative of the producer of the up-sampled map, folded into the adjoint's store: gin *= (y > 0 ? 1 : slope), y = that
+// producer's activated output = this op's input (same shape as gin); y == nullptr: the plain adjoint.  (round 5: the element-wise pass
+// savfi_bias_act_bwd_f32 that the producing convolution ran over its cotangent, reference: ReLU's backward under autograd)
+struct UpMask { const float* y; float slope; };
+__device__ __forceinline__ float up_masked(float v, const UpMask& m, size_t idx) { return m.y ? (m.y[idx] > 0.f ? v : m.slope * v) : v; }
+
+__global__ __launch_bounds__(256) void upsample2x_bwd(const float* __restrict__ gout, float* __restrict__ gin, Win g, UpMask um) {
   const int Ho = 2 * g.H, Wo = 2 * g.W;
   const int item = blockIdx.x * 256 + threadIdx.x;           // pixels of one source plane, row-major
   if (item >= g.Hs * g.Ws) return;
@@ -133,7 +139,8 @@ __global__ __launch_bounds__(256) void upsample2x_bwd(const float* __restrict__ 
       if (ox_lo + k <= ox_hi) t = fmaf(wxs[k], row[ox_lo + k], t);
     acc = fmaf(wy, t, acc);
   }
-  gin[((size_t)blockIdx.y * g.Hs + cy) * g.Ws + cx] = acc;
+  const size_t oi = ((size_t)blockIdx.y * g.Hs + cy) * g.Ws + cx;
+  gin[oi] = up_masked(acc, um, oi);
 }
 
 // The same adjoint, separable and tiled (round 2): a workgroup owns 8 source rows x 64 source columns.  Pass 1 folds the x
@@ -145,7 +152,7 @@ __global__ __launch_bounds__(256) void upsample2x_bwd(const float* __restrict__ 
 #endif
 constexpr int UBH = SAVFI_UBH, UBW = 64, UBR = 2 * UBH + 4;     // tile rows / cols, output rows a tile can touch (16- and 32-row tiles measured slower: LDS per workgroup, profiles/r04_upsample_bench.txt)
 constexpr int UBC = 2 * UBW + 4;                        // output columns a tile can touch (2 ix - 2 .. 2 ix + 3)
-__global__ __launch_bounds__(256) void upsample2x_bwd_tiled(const float* __restrict__ gout, float* __restrict__ gin, Win g) {
+__global__ __launch_bounds__(256) void upsample2x_bwd_tiled(const float* __restrict__ gout, float* __restrict__ gin, Win g, UpMask um) {
   // round 3: the output-gradient tile itself is staged first (coalesced, each element once: 10.6 loads per thread where the x
   // pass read 30 scattered ones per thread from global / L1); both passes then run out of LDS with the same candidates, weights
   // and order of sums as before (bit-identical).
@@ -226,7 +233,8 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_tiled(const float* __restr
       if (oy_lo + k > oy_hi || wy == 0.f) continue;
       acc = fmaf(wy, tmp[oy_lo + k - row_lo][lx], acc);
     }
-    gin[((size_t)blockIdx.y * g.Hs + cy) * g.Ws + cx] = acc;
+    const size_t oi = ((size_t)blockIdx.y * g.Hs + cy) * g.Ws + cx;
+    gin[oi] = up_masked(acc, um, oi);
   }
 }
 
@@ -239,7 +247,7 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_tiled(const float* __restr
 // 2.1 - 2.4 TB/s on the large maps (profiles/r05_upsample_bench.txt).
 constexpr int USW = 64, USB = 4, USP = 2 * USW + 8;        // strip columns, output rows per batch, LDS row pitch (floats)
 // USR: source rows per strip (the host picks 32, 16 or 8: enough waves to hide the walk's latency -- a wave's batches are serial)
-__global__ __launch_bounds__(256) void upsample2x_bwd_strip(const float* __restrict__ gout, float* __restrict__ gin, Win g, int USR) {
+__global__ __launch_bounds__(256) void upsample2x_bwd_strip(const float* __restrict__ gout, float* __restrict__ gin, Win g, int USR, UpMask um) {
   __shared__ float rows[4][USB][USP];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int Ho = 2 * g.H, Wo = 2 * g.W;
@@ -276,7 +284,10 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_strip(const float* __restr
   float a0 = 0.f, a1 = 0.f, a2 = 0.f;                       // source rows cur, cur + 1, cur + 2
   int cur = iy_a;
   auto emit = [&]() {                                        // source row `cur` is complete
-    if (col_ok) gq[(size_t)(cur - g.sy0) * g.Ws + cx] = a0;
+    if (col_ok) {
+      const size_t oi = (size_t)(cur - g.sy0) * g.Ws + cx;
+      gq[oi] = up_masked(a0, um, (size_t)blockIdx.y * g.Hs * g.Ws + oi);
+    }
     a0 = a1; a1 = a2; a2 = 0.f; ++cur;
   };
   float gnext[USB][3];
@@ -378,7 +389,14 @@ extern "C" int savfi_upsample2x_window_fwd_f32(const float* in, float* out, int 
 extern "C" int savfi_upsample2x_window_bwd_f32(const float* gout, float* gin, int planes, int H, int W, int sy0, int sx0,
                                                int Hs, int Ws, int oy0, int ox0, int Hw, int Ww, int align_corners,
                                                void* stream) {
+  return savfi_upsample2x_window_bwd_masked_f32(gout, nullptr, 1.f, gin, planes, H, W, sy0, sx0, Hs, Ws, oy0, ox0, Hw, Ww, align_corners, stream);
+}
+
+extern "C" int savfi_upsample2x_window_bwd_masked_f32(const float* gout, const float* y, float slope, float* gin, int planes, int H, int W,
+                                                      int sy0, int sx0, int Hs, int Ws, int oy0, int ox0, int Hw, int Ww,
+                                                      int align_corners, void* stream) {
   if (!gout || !gin) return SAVFI_E_NULL;
+  const UpMask um{y, slope};
   const Win g{H, W, sy0, sx0, Hs, Ws, oy0, ox0, Hw, Ww, align_corners ? 1 : 0};
   if (int rc = check_window(g, planes)) return rc;
   static const int form = getenv("SAVFI_UPSAMPLE_BWD_FORM") ? atoi(getenv("SAVFI_UPSAMPLE_BWD_FORM")) : 0;      // A/B: 1 = the tiled form of rounds 2-4
@@ -389,13 +407,13 @@ extern "C" int savfi_upsample2x_window_bwd_f32(const float* gout, float* gin, in
   if (form == 2) usr = 32;
   if (Ws >= 32 && form != 1 && usr) {
     dim3 grid(savfi_cdiv(savfi_cdiv(Ws, USW) * savfi_cdiv(Hs, usr), 4), planes, 1);
-    hipLaunchKernelGGL(upsample2x_bwd_strip, grid, dim3(256), 0, (hipStream_t)stream, gout, gin, g, usr);
+    hipLaunchKernelGGL(upsample2x_bwd_strip, grid, dim3(256), 0, (hipStream_t)stream, gout, gin, g, usr, um);
   } else if (Ws >= 32) {      // the separable, LDS-tiled form
     dim3 grid(savfi_cdiv(Hs, UBH) * savfi_cdiv(Ws, UBW), planes, 1);
-    hipLaunchKernelGGL(upsample2x_bwd_tiled, grid, dim3(256), 0, (hipStream_t)stream, gout, gin, g);
+    hipLaunchKernelGGL(upsample2x_bwd_tiled, grid, dim3(256), 0, (hipStream_t)stream, gout, gin, g, um);
   } else {
     dim3 grid(savfi_cdiv((int64_t)Hs * Ws, 256), planes, 1);
-    hipLaunchKernelGGL(upsample2x_bwd, grid, dim3(256), 0, (hipStream_t)stream, gout, gin, g);
+    hipLaunchKernelGGL(upsample2x_bwd, grid, dim3(256), 0, (hipStream_t)stream, gout, gin, g, um);
   }
   return savfi_launch_status();
 }

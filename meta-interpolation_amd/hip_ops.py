@@ -1885,7 +1885,9 @@ class _Upsample2x(torch.autograd.Function):
     [H, W] map, the result the window [oy0:oy0+Hw, ox0:ox0+Ww] of its x2 up-sampling (full op: crop = window = all)."""
 
     @staticmethod
-    def forward(ctx, x, align_corners, geom):
+    def forward(ctx, x, align_corners, geom, in_slope=None):
+        """in_slope: x is the activated output of a fused convolution that left its (leaky) ReLU derivative to this op (its single
+        consumer; conv_bias_act `defer`): the adjoint multiplies by it in its store (first-order passes only)."""
         _hip.require_cuda(x)
         N, C = x.shape[:2]
         H, W, sy0, sx0, Hs, Ws, oy0, ox0, Hw, Ww = geom
@@ -1895,13 +1897,26 @@ class _Upsample2x(torch.autograd.Function):
         _hip.launch("upsample2x_fwd", lambda: _hip.check(lib.savfi_upsample2x_window_fwd_f32(
             x.data_ptr(), out.data_ptr(), N * C, *geom, int(align_corners), _hip.current_stream()),
             "savfi_upsample2x_window_fwd_f32"), nbytes=4 * N * C * (Hs * Ws + Hw * Ww))
-        ctx.align, ctx.geom = bool(align_corners), geom
+        ctx.align, ctx.geom, ctx.in_slope = bool(align_corners), geom, in_slope
+        if in_slope is not None:
+            ctx.save_for_backward(x)
         return out
 
     @staticmethod
     def backward(ctx, g):
+        if ctx.in_slope is not None:
+            x, = ctx.saved_tensors
+            g = g.contiguous()
+            N, C = g.shape[:2]
+            H, W, sy0, sx0, Hs, Ws, oy0, ox0, Hw, Ww = ctx.geom
+            gin = torch.empty((N, C, Hs, Ws), dtype=g.dtype, device=g.device)
+            lib = _hip.lib()
+            _hip.launch("upsample2x_bwd", lambda: _hip.check(lib.savfi_upsample2x_window_bwd_masked_f32(
+                g.data_ptr(), x.data_ptr(), float(ctx.in_slope), gin.data_ptr(), N * C, *ctx.geom, int(ctx.align), _hip.current_stream()),
+                "savfi_upsample2x_window_bwd_masked_f32"), nbytes=4 * N * C * (2 * Hs * Ws + Hw * Ww))
+            return gin, None, None, None
         # linear op: its adjoint goes through the Function too, so double-backward keeps working
-        return _Upsample2xAdjoint.apply(g, ctx.align, ctx.geom), None, None
+        return _Upsample2xAdjoint.apply(g, ctx.align, ctx.geom), None, None, None
 
 
 class _Upsample2xAdjoint(torch.autograd.Function):
@@ -1922,7 +1937,7 @@ class _Upsample2xAdjoint(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gg):
-        return _Upsample2x.apply(gg.contiguous(), ctx.align, ctx.geom), None, None
+        return _Upsample2x.apply(gg.contiguous(), ctx.align, ctx.geom, None), None, None
 
 
 def upsample_window_sources(o0, o1, size_in, align_corners):
@@ -1940,19 +1955,20 @@ def upsample_window_sources(o0, o1, size_in, align_corners):
     return lo, min(hi + 1, size_in - 1)
 
 
-def upsample_bilinear2x_window(x, full_hw, crop_origin, out_window, align_corners):
+def upsample_bilinear2x_window(x, full_hw, crop_origin, out_window, align_corners, in_slope=None):
     """x = crop of a virtual [N,C,*full_hw] map starting at crop_origin (y, x); returns rows/cols
-    out_window = (oy0, ox0, Hw, Ww) of its bilinear x2 up-sampling."""
+    out_window = (oy0, ox0, Hw, Ww) of its bilinear x2 up-sampling.  in_slope: see _Upsample2x.forward."""
     H, W = full_hw
     geom = (int(H), int(W), int(crop_origin[0]), int(crop_origin[1]), int(x.shape[2]), int(x.shape[3]),
             int(out_window[0]), int(out_window[1]), int(out_window[2]), int(out_window[3]))
-    return _Upsample2x.apply(x.contiguous(), bool(align_corners), geom)
+    return _Upsample2x.apply(x.contiguous(), bool(align_corners), geom, None if in_slope is None else float(in_slope))
 
 
-def upsample_bilinear2x(x, align_corners):
-    """[N,C,H,W] -> [N,C,2H,2W], bilinear, ATen-identical source indices."""
+def upsample_bilinear2x(x, align_corners, in_slope=None):
+    """[N,C,H,W] -> [N,C,2H,2W], bilinear, ATen-identical source indices.  in_slope: see _Upsample2x.forward."""
     H, W = int(x.shape[2]), int(x.shape[3])
-    return _Upsample2x.apply(x.contiguous(), bool(align_corners), (H, W, 0, 0, H, W, 0, 0, 2 * H, 2 * W))
+    return _Upsample2x.apply(x.contiguous(), bool(align_corners), (H, W, 0, 0, H, W, 0, 0, 2 * H, 2 * W),
+                             None if in_slope is None else float(in_slope))
 
 
 class Upsample2x(torch.nn.Module):
@@ -1962,10 +1978,11 @@ class Upsample2x(torch.nn.Module):
         super().__init__()
         self.align_corners = align_corners
 
-    def forward(self, x):
+    def forward(self, x, in_slope=None):
         if not x.is_cuda:    # CPU tensors (host-logic tests): the plain ATen op
+            assert in_slope is None, "a deferred activation derivative is a GPU path"
             return torch.nn.functional.interpolate(x, scale_factor=2, mode='bilinear', align_corners=self.align_corners)
-        return upsample_bilinear2x(x, self.align_corners)
+        return upsample_bilinear2x(x, self.align_corners, in_slope)
 
     def extra_repr(self):
         return 'scale_factor=2, mode=bilinear, align_corners=%s' % self.align_corners

@@ -292,11 +292,14 @@ class MetaSequential(nn.Sequential):
     def is_meta_layer(self, module):
         return isinstance(module, _META_TYPES)
 
-    def forward(self, input, params=None):
+    def forward(self, input, params=None, in_slope=None, defer_last=False):
+        """in_slope: `input` is the activated output of a convolution that left its activation derivative to this Sequential's first
+        module (a MetaConv2dLayer or an Upsample2x).  defer_last: the caller promises that the result has exactly one consumer that can
+        take over the LAST conv + activation pair's derivative (an Upsample2x; a Sequential called with in_slope): returns (result,
+        slope or None) instead of the result."""
         pv = as_view(params)
         mods = list(self)
-        ind = 0
-        in_slope = None                 # the previous conv left its activation derivative to the next one (see below)
+        ind = 0                         # in_slope: the previous conv left its activation derivative to the next module (see below)
         while ind < len(mods):
             module = mods[ind]
             kw, step = {}, 1
@@ -311,18 +314,25 @@ class MetaSequential(nn.Sequential):
                     kw["in_slope"] = in_slope
                 # conv -> act -> conv: the intermediate map has exactly one consumer (the next conv of this Sequential), which can fold
                 # this layer's activation derivative into its data gradient -- first-order GPU passes only
-                if "act_slope" in kw and ind + 2 < len(mods) and isinstance(mods[ind + 2], MetaConv2dLayer) and input.is_cuda \
+                # (round 5: ... or an Upsample2x, whose adjoint multiplies by it in its store; or, with defer_last, the caller's consumer)
+                takes_over = (isinstance(mods[ind + 2], (MetaConv2dLayer, hip_ops.Upsample2x)) if ind + 2 < len(mods) else bool(defer_last))
+                if "act_slope" in kw and takes_over and input.is_cuda \
                         and fuse_conv_chain() and fuse_conv_act() and not hip_ops.double_backward() and torch.is_grad_enabled():
                     chain = {"want_defer": True}
                     kw["chain"] = chain
-            else:
-                assert in_slope is None
+            elif isinstance(module, hip_ops.Upsample2x):
+                if in_slope is not None:
+                    kw["in_slope"] = in_slope
+            elif in_slope is not None:       # (a first module that cannot take it over: the derivative as an identity node on the input)
+                input = hip_ops.mask_grad(input, in_slope)
             if pv is not None and isinstance(module, _META_TYPES):
                 input = module(input, params=pv.sub(ind), **kw)
             else:
                 input = module(input, **kw)
             in_slope = kw["act_slope"] if (chain is not None and chain.get("deferred")) else None
             ind += step
+        if defer_last:
+            return input, in_slope
         assert in_slope is None
         return input
 

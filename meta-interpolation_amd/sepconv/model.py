@@ -113,8 +113,9 @@ class MetaNetwork(nn.Module):
             skips.append(x)
             x = getattr(self, "modulePool%d" % i)(x)
         for name, _, _ in _DECODER:
-            x = getattr(self, name)(x, fast(name))
-            x = getattr(self, name.replace("Deconv", "Upsample"))(x)   # own parameters, as the reference
+            # (the block's last ReLU has one consumer, the bilinear x2 of its Upsample: its derivative is left to that op's adjoint)
+            x, slope = getattr(self, name)(x, fast(name), defer_last=True)
+            x = getattr(self, name.replace("Deconv", "Upsample"))(x, in_slope=slope)   # own parameters, as the reference
             x = x + skips.pop()
         combine = x  # [N,64,ph/2,pw/2]
 
@@ -163,8 +164,9 @@ class MetaNetwork(nn.Module):
         slope = lambda c: 0.0 if (c is not None and c.get('deferred')) else None
         x = seq[0](crop, act_slope=0.0, chain=c0)
         x = seq[2](x, act_slope=0.0, in_slope=slope(c0), chain=c2)
-        x = seq[4](x, act_slope=0.0, in_slope=slope(c2))
-        x = upsample_bilinear2x_window(x, win['half'], (win['crop'][0], win['crop'][2]), win['up'], True)
+        c4 = {'want_defer': True} if ch else None
+        x = seq[4](x, act_slope=0.0, in_slope=slope(c2), chain=c4)
+        x = upsample_bilinear2x_window(x, win['half'], (win['crop'][0], win['crop'][2]), win['up'], True, slope(c4))
         return seq[7](x, padding=0)       # [N,51,height,width]: exactly the frame area
 
     # ---- the four Subnets as ONE task-batched launch per layer (round 4) -------------------------------
@@ -223,8 +225,9 @@ class MetaNetwork(nn.Module):
         x = ref[0](crop, params={'weight': sp['w0'], 'bias': sp['b0']}, act_slope=0.0, chain=c0)          # [N, 256, h, w]
         x = x.view(4 * N, 64, x.size(2), x.size(3))                                            # sample 4 n + s: Subnet s
         x = ref[2](x, params={'weight': sp['w2'], 'bias': sp['b2']}, act_slope=0.0, in_slope=slope(c0), chain=c2)
-        x = ref[4](x, params={'weight': sp['w4'], 'bias': sp['b4']}, act_slope=0.0, in_slope=slope(c2))
-        x = upsample_bilinear2x_window(x, win['half'], (win['crop'][0], win['crop'][2]), win['up'], True)
+        c4 = {'want_defer': True} if ch else None
+        x = ref[4](x, params={'weight': sp['w4'], 'bias': sp['b4']}, act_slope=0.0, in_slope=slope(c2), chain=c4)
+        x = upsample_bilinear2x_window(x, win['half'], (win['crop'][0], win['crop'][2]), win['up'], True, slope(c4))
         # The taps leave the last convolution UNIT-MAJOR where the shapes allow (a sample [H][W / 16][51][16] instead of [51][H][W]): the
         # 51-tap op then reads a unit's taps as one contiguous run instead of 64-byte pieces of 51 planes.  The tensor keeps
         # its shape; only FunctionSepconvPair reads it.  SAVFI_SEPCONV_TAPS_PLANAR=1: the plain layout (A/B runs).

@@ -1241,3 +1241,27 @@ def test_all_taps_weight_gradient_matches_float64_and_hands_out_the_bias_gradien
     ws = torch.empty(int(lib.savfi_convk_wgrad_workspace_floats(N, T, 32, Co, H, W, 3, pad)), device=DEV)
     x32 = torch.zeros(N, 32, H, W, device=DEV)
     assert lib.savfi_convk_wgrad_tasks_bias_f32(x32.data_ptr(), gd.data_ptr(), gw1.data_ptr(), gb.data_ptr(), ws.data_ptr(), N, T, 32, Co, H, W, 3, pad, 0, st) != 0
+
+
+@pytest.mark.parametrize("shape,geom_kind,slope", [((3, 5, 12, 16), "full", 0.0), ((2, 64, 40, 70), "full", 0.2), ((2, 7, 31, 45), "window", 0.0),
+                                                   ((1, 3, 100, 130), "window", 0.0), ((4, 33, 9, 8), "full", 0.0)])
+def test_upsample_adjoint_folds_the_producers_relu_derivative(shape, geom_kind, slope):
+    """savfi_upsample2x_window_bwd_masked_f32 (all three kernel forms: small maps, the tiled and the streaming one): the adjoint of the
+    bilinear x2 times (y > 0 ? 1 : slope) of its own input == the plain adjoint followed by savfi_bias_act_bwd_f32's derivative, bit for bit."""
+    g = torch.Generator().manual_seed(shape[2] * 7 + shape[3])
+    x = torch.randn(*shape, generator=g).to(DEV)
+    if geom_kind == "full":
+        up = lambda t, sl: hip_ops.upsample_bilinear2x(t, True, sl)
+    else:
+        N, C, H, W = shape
+        full, origin = (H + 9, W + 6), (4, 3)
+        oy0, ox0 = 2 * origin[0] + 6, 2 * origin[1] + 6
+        win = (oy0, ox0, 2 * H - 14, 2 * W - 14)
+        up = lambda t, sl: hip_ops.upsample_bilinear2x_window(t, full, origin, win, True, sl)
+    xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+    ya, yb = up(xa, None), up(xb, slope)
+    assert torch.equal(ya, yb)
+    gy = torch.randn(ya.shape, generator=g).to(DEV)
+    ga, = torch.autograd.grad(ya, xa, gy)
+    gb, = torch.autograd.grad(yb, xb, gy)
+    assert torch.equal(gb, hip_ops.mask_by_activation(ga, x, slope))
