@@ -172,6 +172,13 @@ int savfi_voxelwarp_bwd_f32(const float* frames, const float* x3, const float* g
  * ---------------------------------------------------------------------------------- */
 int savfi_avgpool2x2_fwd_f32(const float* in, float* out, int64_t planes, int H, int W, void* stream);
 int savfi_avgpool2x2_bwd_f32(const float* gout, float* gin, int64_t planes, int H, int W, void* stream);
+/* the adjoint of "pool AND keep": an activated map y [planes,H,W] feeds the pooling and, unchanged, a skip connection (an encoder block
+ * of sepconv/model.py:176-187 + the decoder's `tensorUpsample + tensorConv`); gout [planes,H/2,W/2] and gskip [planes,H,W] are the two
+ * consumers' cotangents (either may be NULL), and the (leaky) ReLU derivative of y's producer is applied in the same pass (y NULL: none):
+ *   gin = (gout[y/2][x/2] / 4 + gskip) * (y > 0 ? 1 : slope)
+ * -- what autograd runs as the pooling's adjoint, an accumulation and ReLU's backward: three element-wise passes. */
+int savfi_avgpool2x2_bwd_fused_f32(const float* gout, const float* gskip, const float* y, float slope, float* gin, int64_t planes, int H, int W,
+                                   void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Backward warping by a pixel-unit flow (SuperSloMo backWarp superslomo/model.py:231-307, RRIN warp

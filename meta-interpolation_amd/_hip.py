@@ -55,6 +55,7 @@ _PROTOTYPES = {
     "savfi_voxelwarp_bwd_f32": [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P],
     "savfi_avgpool2x2_fwd_f32": [_P, _P, c_int64, c_int, c_int, _P],
     "savfi_avgpool2x2_bwd_f32": [_P, _P, c_int64, c_int, c_int, _P],
+    "savfi_avgpool2x2_bwd_fused_f32": [_P, _P, _P, c_float, _P, c_int64, c_int, c_int, _P],
     "savfi_flowwarp_fwd_f32": [_P, _P, _P, c_int, c_int, c_int, c_int, _P],
     "savfi_flowwarp_bwd_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P],
     "savfi_pixel_unshuffle_f32": [_P, _P, c_int, c_int, c_int, c_int, c_int, _P],

@@ -146,6 +146,56 @@ class _AvgPool2x2Adjoint(torch.autograd.Function):
         return _AvgPool2x2.apply(gg.contiguous()), None
 
 
+class _AvgPool2x2AndSkip(torch.autograd.Function):
+    """(pool(x), x): an encoder block's activated output feeds the pooling and a skip connection.  backward: ONE pass
+    gin = (pool^T(g_pool) + g_skip) * (x > 0 ? 1 : in_slope) -- the pooling's adjoint, autograd's accumulation of the two consumers'
+    cotangents and the producer's deferred activation derivative (conv_bias_act `defer`).  First-order passes only."""
+
+    @staticmethod
+    def forward(ctx, x, in_slope):
+        _hip.require_cuda(x)
+        N, C, H, W = x.shape
+        out = torch.empty((N, C, H // 2, W // 2), dtype=x.dtype, device=x.device)
+        lib = _hip.lib()
+        _hip.launch("avgpool2x2_fwd", lambda: _hip.check(lib.savfi_avgpool2x2_fwd_f32(
+            x.data_ptr(), out.data_ptr(), N * C, H, W, _hip.current_stream()), "savfi_avgpool2x2_fwd_f32"),
+            nbytes=4 * N * C * (H * W + (H // 2) * (W // 2)))
+        ctx.in_slope = in_slope
+        ctx.save_for_backward(x)
+        ctx.set_materialize_grads(False)
+        return out, x.view_as(x)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_pool, g_skip):
+        if g_pool is None and g_skip is None:
+            return None, None
+        x, = ctx.saved_tensors
+        N, C, H, W = x.shape
+        g_pool = None if g_pool is None else g_pool.contiguous()
+        g_skip = None if g_skip is None else g_skip.contiguous()
+        gin = torch.empty_like(x)
+        lib = _hip.lib()
+        _hip.launch("avgpool2x2_bwd", lambda: _hip.check(lib.savfi_avgpool2x2_bwd_fused_f32(
+            None if g_pool is None else g_pool.data_ptr(), None if g_skip is None else g_skip.data_ptr(),
+            None if ctx.in_slope is None else x.data_ptr(), 1.0 if ctx.in_slope is None else float(ctx.in_slope), gin.data_ptr(),
+            N * C, H, W, _hip.current_stream()), "savfi_avgpool2x2_bwd_fused_f32"),
+            nbytes=4 * N * C * (H * W * (2 + (g_skip is not None)) + (H // 2) * (W // 2)))
+        return gin, None
+
+
+def avg_pool2x2_and_skip(x, in_slope=None):
+    """(avg_pool2x2(x), x) with ONE element-wise pass in backward (see _AvgPool2x2AndSkip); in_slope: x is the activated output of a
+    fused convolution that left its activation derivative to this op.  GPU float32 [N,C,H>=2,W>=2] tensors in first-order passes; anything
+    else takes the plain ops (with the derivative as an identity node)."""
+    if (x.is_cuda and x.dim() == 4 and x.shape[2] >= 2 and x.shape[3] >= 2 and x.dtype == torch.float32 and not double_backward()
+            and torch.is_grad_enabled()):
+        return _AvgPool2x2AndSkip.apply(x.contiguous(), None if in_slope is None else float(in_slope))
+    if in_slope is not None:
+        x = mask_grad(x, in_slope)
+    return avg_pool2x2(x), x
+
+
 def avg_pool2x2(x):
     """F.avg_pool2d(x, 2) == nn.AvgPool2d(2, 2): [N,C,H,W] -> [N,C,H//2,W//2]; plain ATen on CPU tensors (host-logic tests)."""
     if not x.is_cuda or x.dim() != 4 or x.shape[2] < 2 or x.shape[3] < 2 or x.dtype != torch.float32:

@@ -109,9 +109,15 @@ class MetaNetwork(nn.Module):
         x = torch.cat([first, second], 1)
         skips = []
         for i, (name, _, _) in enumerate(_ENCODER, start=1):
-            x = getattr(self, name)(x, fast(name))
-            skips.append(x)
-            x = getattr(self, "modulePool%d" % i)(x)
+            # the block's activated output feeds the pooling and a skip connection: one op with one element-wise pass in backward (the
+            # pooling's adjoint + the sum of the two cotangents + the block's last ReLU derivative, which the block leaves to it)
+            x, slope = getattr(self, name)(x, fast(name), defer_last=True)
+            if x.is_cuda:
+                x, skip = hip_ops.avg_pool2x2_and_skip(x, slope)
+            else:
+                assert slope is None
+                x, skip = getattr(self, "modulePool%d" % i)(x), x
+            skips.append(skip)
         for name, _, _ in _DECODER:
             # (the block's last ReLU has one consumer, the bilinear x2 of its Upsample: its derivative is left to that op's adjoint)
             x, slope = getattr(self, name)(x, fast(name), defer_last=True)

@@ -1265,3 +1265,25 @@ def test_upsample_adjoint_folds_the_producers_relu_derivative(shape, geom_kind, 
     ga, = torch.autograd.grad(ya, xa, gy)
     gb, = torch.autograd.grad(yb, xb, gy)
     assert torch.equal(gb, hip_ops.mask_by_activation(ga, x, slope))
+
+
+@pytest.mark.parametrize("shape,slope,use", [((2, 5, 12, 16), 0.0, "both"), ((3, 7, 13, 17), 0.2, "both"), ((2, 32, 64, 96), 0.0, "pool"),
+                                             ((1, 3, 9, 8), None, "both"), ((2, 4, 10, 11), 0.0, "skip")])
+def test_pool_and_skip_adjoint_is_one_pass_with_the_same_values(shape, slope, use):
+    """hip_ops.avg_pool2x2_and_skip: (pool(x), x); its backward = (pool^T(g_pool) + g_skip) * (x > 0 ? 1 : slope) in one kernel
+    (savfi_avgpool2x2_bwd_fused_f32) == the three passes it replaces, bit for bit (odd rows / columns, a consumer without gradient)."""
+    g = torch.Generator().manual_seed(shape[2] * 31 + shape[3])
+    x = torch.randn(*shape, generator=g).to(DEV)
+    a = torch.randn(shape[0], shape[1], shape[2] // 2, shape[3] // 2, generator=g).to(DEV)
+    b = torch.randn(*shape, generator=g).to(DEV)
+    xa = x.clone().requires_grad_()
+    pooled, skip = hip_ops.avg_pool2x2_and_skip(xa, slope)
+    assert torch.equal(pooled, hip_ops.avg_pool2x2(x)) and torch.equal(skip, x)
+    loss = (pooled * a).sum() * (use != "skip") + (skip * b).sum() * (use != "pool")
+    got, = torch.autograd.grad(loss, xa)
+    xb = x.clone().requires_grad_()
+    gp, = torch.autograd.grad((hip_ops.avg_pool2x2(xb) * a).sum(), xb)
+    want = gp * (use != "skip") + b * (use != "pool")
+    if slope is not None:
+        want = hip_ops.mask_by_activation(want, x, slope)
+    assert torch.equal(got, want)
