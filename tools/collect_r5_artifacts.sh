@@ -12,6 +12,7 @@ SAVFI_SEPCONV_PAIR_TWO_LAUNCHES=1 $B 2>/dev/null | tag "two launches per pass (S
 $B 2>/dev/null | tag "one launch per pass (default)" >> $A/r05_pair_ab.jsonl
 SAVFI_UPSAMPLE_BWD_FORM=1 $B 2>/dev/null | tag "default, bilinear x2 backward tiled (SAVFI_UPSAMPLE_BWD_FORM=1)" >> $A/r05_pair_ab.jsonl
 SAVFI_WGRAD_NO_BIAS=1 $B 2>/dev/null | tag "default, bias sums as their own pass (SAVFI_WGRAD_NO_BIAS=1)" >> $A/r05_pair_ab.jsonl
+SAVFI_NO_CONV_CHAIN=1 $B 2>/dev/null | tag "default, every conv + ReLU with its own derivative pass (SAVFI_NO_CONV_CHAIN=1: no deferral to the next convolution / bilinear x2 / pool-and-skip adjoint)" >> $A/r05_pair_ab.jsonl
 SAVFI_WGRAD3_NO_RING=1 $B 2>/dev/null | tag "default, 3x3 weight gradients routed as before the all-taps kernel (SAVFI_WGRAD3_NO_RING=1)" >> $A/r05_pair_ab.jsonl
 $B 2>/dev/null | tag "one launch per pass (default), again" >> $A/r05_pair_ab.jsonl
 cd /tmp && export TMPDIR=/tmp
