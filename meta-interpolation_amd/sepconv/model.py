@@ -21,6 +21,7 @@ directly from the frame padded by 25 px.  Same values as the full-canvas evaluat
 ``windowed=False`` / ``--sepconv_window 0``; tests compare the two), forward and backward.
 """
 import os
+import threading
 
 import torch
 import torch.nn as nn
@@ -59,6 +60,8 @@ def _subnet():
                           Upsample2x(align_corners=True),
                           _conv(FILTER_TAPS, FILTER_TAPS))
 
+
+_FRAME_TLS = threading.local()       # MetaNetwork._prepared_frames: per thread, per network
 
 _ENCODER = [("moduleConv1", 6, 32), ("moduleConv2", 32, 64), ("moduleConv3", 64, 128),
             ("moduleConv4", 128, 256), ("moduleConv5", 256, 512)]
@@ -99,14 +102,13 @@ class MetaNetwork(nn.Module):
     def forward(self, tensorFirst, tensorSecond, params=None, **kwargs):
         height, width = tensorFirst.size(2), tensorFirst.size(3)
         ph, pw = self.padded_size(height, width)
-        pad_in = (HALF, pw - HALF - width, HALF, ph - HALF - height)
-        first = F.pad(tensorFirst, pad_in, mode='replicate')
-        second = F.pad(tensorSecond, pad_in, mode='replicate')
+        prep = self._prepared_frames(tensorFirst, tensorSecond, ph, pw)
+        first, second = prep['first'], prep['second']
 
         pv = as_view(params)
         fast = (lambda n: None) if pv is None else pv.sub
 
-        x = torch.cat([first, second], 1)
+        x = prep['x']
         skips = []
         for i, (name, _, _) in enumerate(_ENCODER, start=1):
             # the block's activated output feeds the pooling and a skip connection: one op with one element-wise pass in backward (the
@@ -126,13 +128,43 @@ class MetaNetwork(nn.Module):
         combine = x  # [N,64,ph/2,pw/2]
 
         if self.windowed and combine.is_cuda:
-            return self._windowed_tail(tensorFirst, tensorSecond, combine, height, width, ph, pw)
+            return self._windowed_tail(tensorFirst, tensorSecond, combine, height, width, ph, pw, prep)
         dot1 = FunctionSepconv.apply(self.modulePad(first).contiguous(),
                                      self.moduleVertical1(combine), self.moduleHorizontal1(combine))
         dot2 = FunctionSepconv.apply(self.modulePad(second).contiguous(),
                                      self.moduleVertical2(combine), self.moduleHorizontal2(combine))
         out = dot1 + dot2
         return out[:, :, HALF:HALF + height, HALF:HALF + width]
+
+    # ---- what a forward makes of the two frames alone: the network's input canvas and the frames with the 51-tap op's rim ----
+    # The inner loop runs every step on the SAME support frames (reference meta_learning_system.py:387-396: the task's support triplets),
+    # so the four replication pads and the concatenation of a pass are made once per frame pair, not once per step: the last pair(s) are
+    # kept per thread, keyed by the tensors' identity and version (the cache holds the tensors, so an address cannot come back as another
+    # tensor).  Frames that carry gradients, CPU tensors and passes inside a hipGraph capture take the plain ops.
+    def _prepared_frames(self, f0, f1, ph, pw):
+        height, width = f0.size(2), f0.size(3)
+        pad_in = (HALF, pw - HALF - width, HALF, ph - HALF - height)
+
+        def make():
+            first = F.pad(f0, pad_in, mode='replicate')
+            second = F.pad(f1, pad_in, mode='replicate')
+            out = dict(first=first, second=second, x=torch.cat([first, second], 1))
+            if self.windowed and f0.is_cuda:
+                rim = (HALF,) * 4
+                out['rim0'], out['rim1'] = F.pad(f0, rim, mode='replicate'), F.pad(f1, rim, mode='replicate')
+            return out
+        if (not f0.is_cuda or f0.requires_grad or f1.requires_grad or torch.cuda.is_current_stream_capturing()
+                or os.environ.get('SAVFI_SEPCONV_NO_FRAME_CACHE')):
+            return make()
+        cache = _FRAME_TLS.__dict__.setdefault('entries', {}).setdefault(id(self), [])
+        for e in cache:
+            if e[0] is f0 and e[1] is f1 and e[2] == (f0._version, f1._version, ph, pw, torch.cuda.current_stream().cuda_stream):
+                return e[3]
+        with torch.no_grad():
+            made = make()
+        cache.append((f0, f1, (f0._version, f1._version, ph, pw, torch.cuda.current_stream().cuda_stream), made))
+        del cache[:-2]                       # support frames + target frames of the current task group
+        return made
 
     # ---- windowed evaluation of everything after tensorCombine (see the module docstring) -------------
     def _window(self, height, width, ph, pw):
@@ -219,7 +251,7 @@ class MetaNetwork(nn.Module):
             cache[stream] = hit
         return hit[1]
 
-    def _windowed_tail_batched(self, frame0, frame1, crop, win):
+    def _windowed_tail_batched(self, frame0, frame1, crop, win, prep=None):
         ref = getattr(self, self._SUBNETS[0])
         sp = self._stacked_subnet_params()
         N = crop.size(0)
@@ -251,15 +283,17 @@ class MetaNetwork(nn.Module):
         else:
             taps = ref[7](x, params={'weight': sp['w7'], 'bias': sp['b7']}, padding=0)           # [4 N, 51, height, width]
         rim = (HALF,) * 4
-        return FunctionSepconvPair.apply(F.pad(frame0, rim, mode='replicate'), F.pad(frame1, rim, mode='replicate'), taps, unit16, grads16)
+        r0 = prep['rim0'] if prep is not None and 'rim0' in prep else F.pad(frame0, rim, mode='replicate')
+        r1 = prep['rim1'] if prep is not None and 'rim1' in prep else F.pad(frame1, rim, mode='replicate')
+        return FunctionSepconvPair.apply(r0, r1, taps, unit16, grads16)
 
-    def _windowed_tail(self, frame0, frame1, combine, height, width, ph, pw):
+    def _windowed_tail(self, frame0, frame1, combine, height, width, ph, pw, prep=None):
         win = self._window(height, width, ph, pw)
         cy0, cy1, cx0, cx1 = win['crop']
         crop = combine[:, :, cy0:cy1, cx0:cx1].contiguous()
         if (self.batch_subnets and not frame0.requires_grad and not frame1.requires_grad
                 and FunctionSepconvPair.supported(frame0, crop.size(0), height, width, FILTER_TAPS)):
-            return self._windowed_tail_batched(frame0, frame1, crop, win)
+            return self._windowed_tail_batched(frame0, frame1, crop, win, prep)
         rim = (HALF,) * 4
         dot1 = FunctionSepconv.apply(F.pad(frame0, rim, mode='replicate'),
                                      self._subnet_window(self.moduleVertical1, crop, win),
