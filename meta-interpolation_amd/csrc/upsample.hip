@@ -91,7 +91,10 @@ __global__ __launch_bounds__(256) void upsample2x_fwd(const float* __restrict__ 
       v[k] = sy.l0 * (xl0[k] * r0[xi0[k]] + xl1[k] * r0[xi1[k]]) + sy.l1 * (xl0[k] * r1[xi0[k]] + xl1[k] * r1[xi1[k]]);
     float* o = out + ((size_t)blockIdx.y * g.Hw + wy) * g.Ww + wx;
     if (wx + 3 < g.Ww && ((((uintptr_t)o) & 15u) == 0)) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-    else
+    else if (wx + 3 < g.Ww && ((((uintptr_t)o) & 7u) == 0)) {      // (a window row of 450 floats: every other row is only 8-byte aligned)
+      *reinterpret_cast<float2*>(o) = make_float2(v[0], v[1]);
+      *reinterpret_cast<float2*>(o + 2) = make_float2(v[2], v[3]);
+    } else
       for (int k = 0; k < 4 && wx + k < g.Ww; ++k) o[k] = v[k];
   }
 }

@@ -1,4 +1,4 @@
-R=$GRAFT_REPO_ROOT; cd $R
-V=$R/tools/scratch/variants
-for n in wpv16 wpv24; do SAVFI_HIP_LIB=$V/libsavfi_$n.so python tools/r5/dbg2.py $V/libsavfi_$n.so 2>&1 | tail -3; done
-VARIANTS="wpv16 wpv24" bash tools/r5/step4.sh
+#!/bin/bash
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/w3; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_c2 -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-strong-c4 > /dev/null 2>&1
+python $R/tools/gap_report.py /tmp/prof_c2 0 > $O/one_iter.txt 2>&1
