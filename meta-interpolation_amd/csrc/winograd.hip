@@ -44,9 +44,11 @@ __device__ void savfi_raw_buffer_store_x2(f32x2 data, i32x4 rsrc, int voffset, i
 __device__ f32x2 savfi_raw_buffer_load_x2(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2f32");
 __device__ float savfi_raw_buffer_load_x1(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
 __device__ void savfi_raw_buffer_store_x1(float data, i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.f32");
+__device__ void savfi_raw_buffer_store_x4(f32x4 data, i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v4f32");
 
 namespace {
 
+#include "winograd4.h"      // Winograd F(4x4, 3x3) for the layers of at most 64 -> 64 channels (namespace w4)
 
 constexpr int WNT = 256;            // threads
 // 64 tiles per workgroup, one per lane, as a 2^(6-s) x 2^s block of tiles (s = WinoArgs::tile_shift, picked per launch):
@@ -116,7 +118,8 @@ __device__ __forceinline__ void filter_transform_block(const float* __restrict__
 
 __global__ __launch_bounds__(256) void wino_filter_transform(const float* __restrict__ w, float* __restrict__ U,
                                                              int Co, int Ci, int K, int I, int KP, int IP, int mode) {
-  filter_transform_block(w, U, Co, Ci, K, I, KP, IP, mode, blockIdx.x, blockIdx.y);
+  if (w4::use_f4(K, I)) w4::filter_transform_block4(w, U, Co, Ci, K, I, KP, IP, mode, blockIdx.x, blockIdx.y);
+  else filter_transform_block(w, U, Co, Ci, K, I, KP, IP, mode, blockIdx.x, blockIdx.y);
 }
 
 // Both transforms of a layer in ONE launch (blockIdx.z = mode): the forward pass of a training step knows that the data
@@ -128,7 +131,8 @@ __global__ __launch_bounds__(256) void wino_filter_transform_dual(const float* _
   const int mode = blockIdx.z;
   const int KP = mode == 0 ? KPf : KPb, IP = mode == 0 ? IPf : IPb;
   if ((int)blockIdx.x >= KP / 4 || (int)blockIdx.y >= ((IP + 63) / 64) * T) return;
-  filter_transform_block(w, mode == 0 ? Uf : Ub, Co, Ci, mode == 0 ? Ci : Co, mode == 0 ? Co : Ci, KP, IP, mode, blockIdx.x, blockIdx.y);
+  if (w4::use_f4(Ci, Co)) w4::filter_transform_block4(w, mode == 0 ? Uf : Ub, Co, Ci, mode == 0 ? Ci : Co, mode == 0 ? Co : Ci, KP, IP, mode, blockIdx.x, blockIdx.y);
+  else filter_transform_block(w, mode == 0 ? Uf : Ub, Co, Ci, mode == 0 ? Ci : Co, mode == 0 ? Co : Ci, KP, IP, mode, blockIdx.x, blockIdx.y);
 }
 
 
@@ -154,7 +158,8 @@ __global__ __launch_bounds__(256) void wino_filter_transform_multi(const FtTable
   }
   const FtJob& j = tb.job[lo];
   const int rel = (int)blockIdx.x - j.first_block;
-  filter_transform_block(j.w, j.U, j.Co, j.Ci, j.K, j.I, j.KP, j.IP, j.mode, rel % j.nbx, rel / j.nbx);
+  if (w4::use_f4(j.K, j.I)) w4::filter_transform_block4(j.w, j.U, j.Co, j.Ci, j.K, j.I, j.KP, j.IP, j.mode, rel % j.nbx, rel / j.nbx);
+  else filter_transform_block(j.w, j.U, j.Co, j.Ci, j.K, j.I, j.KP, j.IP, j.mode, rel % j.nbx, rel / j.nbx);
 }
 
 // ---- fused convolution -------------------------------------------------------------------------------------
@@ -641,18 +646,41 @@ int round_up(int v, int m) { return (v + m - 1) / m * m; }
 struct WinoPlan {
   int K, I, KP, IP, off, Ho, Wo, th, tw, tile_shift, nsplit, chunks_per_split;
   int64_t u_floats, partial_floats;
+  bool f4;            // Winograd F(4x4, 3x3) (winograd4.h): 4x4-pixel tiles, 32 per workgroup, no reduction split
 };
+
+// padded reduction / produced channel counts of a layer's transformed filter (both forms)
+inline int kp_for(int K, int I) { return w4::use_f4(K, I) ? w4::kp_of(K) : (K + 2 * CIB - 1) / (2 * CIB) * (2 * CIB); }
+inline int ip_for(int K, int I) { return w4::use_f4(K, I) ? w4::ip_of(I) : (I + COB - 1) / COB * COB; }
+inline int64_t u_floats_for(int K, int I) { return (int64_t)(w4::use_f4(K, I) ? w4::PTS : 16) * kp_for(K, I) * ip_for(K, I); }
 
 bool make_plan(WinoPlan& p, int N, int Ci, int Co, int H, int W, int pad, int mode) {
   p.K = mode == 0 ? Ci : Co;
   p.I = mode == 0 ? Co : Ci;       // reduction / produced channels
-  p.KP = round_up(p.K, 2 * CIB);   // an even number of chunks (see the channel loop)
-  p.IP = round_up(p.I, COB);
+  p.f4 = w4::use_f4(p.K, p.I);
+  p.KP = kp_for(p.K, p.I);         // F(2x2): an even number of chunks (see the channel loop)
+  p.IP = ip_for(p.K, p.I);
   // forward: patch origin 2t - pad; gradient of a pad-p convolution = pad-(2-p) correlation with the flipped filter
   p.off = mode == 0 ? pad : 2 - pad;
   p.Ho = H + 2 * p.off - 2;
   p.Wo = W + 2 * p.off - 2;
   if (p.Ho <= 0 || p.Wo <= 0) return false;
+  if (p.f4) {
+    // 32 tiles of 4 x 4 pixels as a 2^(5-s) x 2^s block: fewest blocks, ties to 4 x 8 (16 x 32 pixels)
+    const int ty4 = savfi_cdiv(p.Ho, 4), tx4 = savfi_cdiv(p.Wo, 4);
+    int64_t best4 = -1;
+    for (int s : {3, 4, 2, 5, 1, 0}) {
+      const int64_t blocks = (int64_t)savfi_cdiv(ty4, w4::TT >> s) * savfi_cdiv(tx4, 1 << s);
+      if (best4 < 0 || blocks < best4) { best4 = blocks; p.tile_shift = s; }
+    }
+    p.th = savfi_cdiv(ty4, w4::TT >> p.tile_shift);
+    p.tw = savfi_cdiv(tx4, 1 << p.tile_shift);
+    p.nsplit = 1;
+    p.chunks_per_split = p.KP / w4::KC;
+    p.u_floats = u_floats_for(p.K, p.I);
+    p.partial_floats = 0;
+    return true;
+  }
   // tile block shape: the one that covers the tile map with the fewest blocks (ties: the widest rows, 4 x 16 first)
   const int ty = savfi_cdiv(p.Ho, 2), tx = savfi_cdiv(p.Wo, 2);
   int64_t best = -1;
@@ -717,6 +745,26 @@ namespace {
 int launch_conv(const WinoPlan& p, const float* x, const float* U, const float* bias, float* out, float* partial, int N, int T,
                 int H, int W, int mode, float slope, hipStream_t st, const float* mask = nullptr, float mask_slope = 1.f,
                 int out_unit16 = 0, int in_unit16 = 0) {
+  if (p.f4) {
+    const int64_t wgs4 = (int64_t)p.th * p.tw * (p.IP / w4::COB) * N;
+    if (wgs4 > 0x7fffffffLL || T > 65535) return SAVFI_E_TOOBIG;
+    if (mask && (out_unit16 || in_unit16)) return SAVFI_E_UNSUPPORTED;
+    if (in_unit16 && ((p.off != 1 && p.off != 2) || p.Wo % 2 != 0)) return SAVFI_E_UNSUPPORTED;
+    constexpr size_t lds4 = (size_t)w4::LDS_FLOATS * sizeof(float);      // 72 KB: two workgroups per CU
+    w4::W4Args a4{x, U, mode == 0 ? bias : nullptr, out, p.K, p.I, p.KP, p.IP, H, W, p.Ho, p.Wo, p.off, p.th, p.tw, slope,
+                  p.tile_shift, T, N, mask, mask_slope, out_unit16};
+    const int vecw = p.Wo % 4 == 0 ? 4 : (p.Wo % 2 == 0 ? 2 : 1);
+    auto go = [&](auto kern) -> int {
+      static uint32_t configured = 0;
+      if (int rc = savfi_ensure_dynamic_lds(reinterpret_cast<const void*>(kern), lds4, configured)) return rc;
+      hipLaunchKernelGGL(kern, dim3((unsigned)wgs4), dim3(256), lds4, st, a4);
+      return savfi_launch_status();
+    };
+    if (in_unit16 && p.off == 1) return vecw == 4 ? go(w4::wino4_conv3x3<4, 2, false>) : go(w4::wino4_conv3x3<2, 2, false>);
+    if (in_unit16) return vecw == 4 ? go(w4::wino4_conv3x3<4, 3, false>) : go(w4::wino4_conv3x3<2, 3, false>);
+    if (mask) return vecw == 4 ? go(w4::wino4_conv3x3<4, 0, true>) : vecw == 2 ? go(w4::wino4_conv3x3<2, 0, true>) : go(w4::wino4_conv3x3<1, 0, true>);
+    return vecw == 4 ? go(w4::wino4_conv3x3<4, 0, false>) : vecw == 2 ? go(w4::wino4_conv3x3<2, 0, false>) : go(w4::wino4_conv3x3<1, 0, false>);
+  }
   const int64_t wgs = (int64_t)p.th * p.tw * (p.IP / COB) * p.nsplit * N;
   if (wgs > 0x7fffffffLL || T > 65535) return SAVFI_E_TOOBIG;
   constexpr size_t lds = (size_t)LDS_FLOATS * sizeof(float);      // 40 KB: two workgroups per CU
@@ -747,6 +795,8 @@ int check_conv_args(WinoPlan& p, int N, int T, int Ci, int Co, int H, int W, int
   // 32-bit byte offsets inside a channel plane, and 0x80000000 must lie beyond the input and the output plane
   if ((int64_t)H * W >= ((int64_t)1 << 29) || (int64_t)p.Ho * p.Wo >= ((int64_t)1 << 29)) return SAVFI_E_TOOBIG;
   if (p.u_floats >= ((int64_t)1 << 29)) return SAVFI_E_TOOBIG;           // one task's transformed filter: 32-bit byte offsets
+  // F(4x4): a sample's channels ride in ONE descriptor (two channels per wave); the output's too
+  if (p.f4 && ((int64_t)p.K * H * W >= ((int64_t)1 << 29) || (int64_t)p.I * p.Ho * p.Wo >= ((int64_t)1 << 29))) return SAVFI_E_TOOBIG;
   return SAVFI_OK;
 }
 
@@ -774,13 +824,13 @@ extern "C" int savfi_conv3x3_tasks_f32(const float* x, const float* w, const flo
 extern "C" int64_t savfi_conv3x3_filter_floats(int T, int Ci, int Co, int mode) {
   if (T <= 0 || Ci <= 0 || Co <= 0 || (mode != 0 && mode != 1)) return SAVFI_E_SHAPE;
   const int K = mode == 0 ? Ci : Co, I = mode == 0 ? Co : Ci;
-  return (int64_t)T * 16 * round_up(K, 2 * CIB) * round_up(I, COB);
+  return (int64_t)T * u_floats_for(K, I);
 }
 
 extern "C" int savfi_conv3x3_filters_f32(const float* w, float* u_fwd, float* u_bwd, int T, int Ci, int Co, void* stream) {
   if (!w || (!u_fwd && !u_bwd)) return SAVFI_E_NULL;
   if (T <= 0 || T > 65535 || Ci <= 0 || Co <= 0) return SAVFI_E_SHAPE;
-  const int KPf = round_up(Ci, 2 * CIB), IPf = round_up(Co, COB), KPb = round_up(Co, 2 * CIB), IPb = round_up(Ci, COB);
+  const int KPf = kp_for(Ci, Co), IPf = ip_for(Ci, Co), KPb = kp_for(Co, Ci), IPb = ip_for(Co, Ci);
   hipStream_t st = (hipStream_t)stream;
   if (u_fwd && u_bwd) {
     const int gx = (KPf > KPb ? KPf : KPb) / 4, gy = savfi_cdiv(IPf > IPb ? IPf : IPb, 64) * T;
@@ -817,8 +867,8 @@ extern "C" int savfi_conv3x3_filters_multi_f32(const float* const* w, float* con
       j.w = w[i]; j.U = dst; j.Co = Co[i]; j.Ci = Ci[i]; j.mode = mode;
       j.K = mode == 0 ? Ci[i] : Co[i];
       j.I = mode == 0 ? Co[i] : Ci[i];
-      j.KP = round_up(j.K, 2 * CIB);
-      j.IP = round_up(j.I, COB);
+      j.KP = kp_for(j.K, j.I);
+      j.IP = ip_for(j.K, j.I);
       j.nbx = j.KP / 4;
       j.first_block = blocks;
       j.pad_ = 0;
@@ -852,7 +902,8 @@ extern "C" int savfi_conv3x3_tasks_pre_f32(const float* x, const float* u, const
 // its 51 taps per pixel in this layout and the 51-tap op reads them as contiguous runs instead of 64-byte pieces of 51 planes a multiple
 // of 64 KB apart.  Wo % 16 == 0, a sample below 2^31 bytes, no reduction split; SAVFI_E_UNSUPPORTED otherwise.
 static int unit16_ok(const WinoPlan& p) {
-  return p.nsplit == 1 && p.Wo % 16 == 0 && (int64_t)p.I * p.Ho * p.Wo * 4 < ((int64_t)1 << 31);
+  // (F(4x4) marks a dropped channel with bit 30 of the offset: a sample below 2^30 bytes)
+  return p.nsplit == 1 && p.Wo % 16 == 0 && (int64_t)p.I * p.Ho * p.Wo * 4 < ((int64_t)1 << (p.f4 ? 30 : 31));
 }
 extern "C" int savfi_conv3x3_unit16_supported(int N, int T, int Ci, int Co, int H, int W, int pad) {
   WinoPlan p;
