@@ -425,10 +425,13 @@ def main():
                         "algorithmic_bytes_per_launch": k["algorithmic_bytes"] / k["launches"],
                         "note": "largest HBM-bound savfi kernel of this workload by time, timed in ONE extra iteration after the timed "
                                 "region (eager loop; launches of a few microseconds are latency-bound, not bandwidth-bound)"}
-            fam = {"winograd_f32_mfma": ("conv3x3_fwd", "conv3x3_bwd_data"), "winograd_wgrad_f32_mfma": ("conv3x3_wgrad",),
+            fam = {"winograd4_f32_mfma": ("conv3x3f4_fwd", "conv3x3f4_bwd_data"), "winograd_f32_mfma": ("conv3x3_fwd", "conv3x3_bwd_data"),
+                   "winograd_wgrad_f32_mfma": ("conv3x3_wgrad",),
                    "direct_bf16x6_mfma": ("convk_fwd", "convk_bwd_data"), "direct_wgrad_bf16x6_mfma": ("convk_wgrad",)}
-            # ceilings in direct-equivalent TFLOP/s: fp32 MFMA 157.3 x 2.25 (Winograd F(2x2,3x3) / F(3x3,2x2)); bf16 MFMA 2500 / 6 products
-            peak = {"winograd_f32_mfma": 353.9, "winograd_wgrad_f32_mfma": 353.9, "direct_bf16x6_mfma": 416.7, "direct_wgrad_bf16x6_mfma": 416.7}
+            # ceilings in direct-equivalent TFLOP/s: fp32 MFMA 157.3 x 4 (Winograd F(4x4,3x3): 36 multiplies per 16 outputs x 9 taps) / x 2.25
+            # (F(2x2,3x3) / F(3x3,2x2)); bf16 MFMA 2500 / 6 products
+            peak = {"winograd4_f32_mfma": 629.2, "winograd_f32_mfma": 353.9, "winograd_wgrad_f32_mfma": 353.9, "direct_bf16x6_mfma": 416.7,
+                    "direct_wgrad_bf16x6_mfma": 416.7}
             rows, tot_ms, tot_fl = {}, 0.0, 0.0
             for f, names in fam.items():
                 ms = sum(cs[n]["total_ms"] for n in names if n in cs)
@@ -442,7 +445,7 @@ def main():
                 line["roofline_mfma"] = {"bound": "mfma", "unit": "direct-equivalent TFLOP/s", "families": rows,
                                          "all_conv_kernels": {"ms_per_iteration": tot_ms, "achieved": tot_fl / tot_ms / 1e9},
                                          "note": "HIP events around every savfi convolution launch in one extra iteration of the timed "
-                                                 "system (same mode); Winograd ceilings = fp32 MFMA peak x 2.25, direct = bf16 MFMA peak / 6"}
+                                                 "system (same mode); Winograd ceilings = fp32 MFMA peak x 4 (F(4x4)) / x 2.25 (F(2x2)), direct = bf16 MFMA peak / 6"}
         if world == 1 and not toy and opt.fast_path and not switches and not getattr(system, '_graphs', None):
             # The default mode adapted the tasks in lockstep in the eager loop (where the roofline kernel can be timed in place).
             # The same workload and step count again from hipGraph replays of single tasks on four task streams -- the fastest

@@ -16,7 +16,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_PKG_DIR), "include", "savfi_hip.h")
 
 RULE_SGD, RULE_ADAM, RULE_ADAMAX_LSLR, RULE_ADAMAX_MSGD = 0, 1, 2, 3
 LR_SCALAR, LR_ELEMENT = 0, 1
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 _ERRORS = {-1: "SAVFI_E_NULL (a required pointer is NULL)",
            -2: "SAVFI_E_SHAPE (bad or inconsistent dimension)",
@@ -76,6 +76,7 @@ _PROTOTYPES = {
     "savfi_conv3x3_tasks_workspace_floats": [c_int] * 8,
     "savfi_conv3x3_tasks_f32": [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P],
     "savfi_conv3x3_filter_floats": [c_int] * 4,
+    "savfi_conv3x3_f4_workgroups": [c_int] * 7,
     "savfi_conv3x3_filters_f32": [_P, _P, _P, c_int, c_int, c_int, _P],
     "savfi_conv3x3_tasks_pre_workspace_floats": [c_int] * 8,
     "savfi_conv3x3_tasks_pre_f32": [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P],
@@ -147,7 +148,7 @@ def lib():
         except AttributeError:
             raise SavfiHipError("%s does not export %s" % (LIB_PATH, name))
         fn.argtypes = argtypes
-        fn.restype = c_int64 if name.endswith('_floats') else c_int
+        fn.restype = c_int64 if name.endswith(('_floats', '_workgroups')) else c_int
     got = handle.savfi_version()
     if got != ABI_VERSION:
         raise SavfiHipError("libsavfi_hip ABI %d != expected %d; rebuild" % (got, ABI_VERSION))

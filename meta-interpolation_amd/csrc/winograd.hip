@@ -735,6 +735,16 @@ extern "C" int64_t savfi_conv3x3_tasks_workspace_floats(int N, int T, int Ci, in
   return (int64_t)T * p.u_floats + p.partial_floats;
 }
 
+// Workgroups the F(4x4, 3x3) kernel (winograd4.h) launches for this call -- 0 when the layer's channel counts keep it on F(2x2).  The
+// host routes by it: F(4x4) has no reduction split, so a launch that cannot fill the chip's 512 workgroup slots belongs elsewhere.
+extern "C" int64_t savfi_conv3x3_f4_workgroups(int N, int Ci, int Co, int H, int W, int pad, int mode) {
+  if (N <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return SAVFI_E_SHAPE;
+  if ((mode != 0 && mode != 1) || (pad != 0 && pad != 1)) return SAVFI_E_UNSUPPORTED;
+  WinoPlan p;
+  if (!make_plan(p, N, Ci, Co, H, W, pad, mode)) return SAVFI_E_SHAPE;
+  return p.f4 ? (int64_t)p.th * p.tw * (p.IP / w4::COB) * N : 0;
+}
+
 extern "C" int64_t savfi_conv3x3_workspace_floats(int N, int Ci, int Co, int H, int W, int pad, int mode) {
   return savfi_conv3x3_tasks_workspace_floats(N, 1, Ci, Co, H, W, pad, mode);
 }
@@ -923,6 +933,8 @@ extern "C" int savfi_conv3x3_tasks_pre_unit16_f32(const float* x, const float* u
 // [H][W / 16][Co][16] (what savfi_sepconv_bwd_frames8_f32 writes with bit 1 of taps_unit16), gx is [Ci][H+2-2pad][W+2-2pad] as always.
 // W % 16 == 0, an even output width, a sample of gy below 2^31 bytes, no reduction split; SAVFI_E_UNSUPPORTED otherwise.
 static int in_unit16_ok(const WinoPlan& p, int H, int W) {
+  // (F(2x2): a patch row is two 8-byte pairs of an EVEN first column -- pad 0 only; found by tools/r6/wino4_check.py, the plugin's tail is pad 0)
+  if (!p.f4 && p.off % 2 != 0) return 0;
   return p.nsplit == 1 && W % 16 == 0 && p.Wo % 2 == 0 && (int64_t)p.K * H * W * 4 < ((int64_t)1 << 31);
 }
 extern "C" int savfi_conv3x3_in_unit16_supported(int N, int T, int Ci, int Co, int H, int W, int pad) {

@@ -1,4 +1,4 @@
-// Winograd F(4x4, 3x3) for the 3x3 / stride 1 layers of at most 64 -> 64 channels (included by winograd.hip only: the
+// Winograd F(4x4, 3x3) for the 3x3 / stride 1 layers of at most 256 -> 256 channels (included by winograd.hip only: the
 // multi-layer filter transform launches both forms from one kernel).
 //
 // Why.  The F(2x2, 3x3) kernel above multiplies 16 Winograd points per 4 outputs (2.25x fewer multiplies than the direct sum);
@@ -37,7 +37,7 @@ constexpr int LDS_FLOATS = XBUF > 2 * VBUF ? XBUF : 2 * VBUF;
 #define W4_ABL 0          // timing-only ablations (tools/build_variant.sh ... -DW4_ABL=n): wrong results
 #endif
 #ifndef SAVFI_W4_MAXC
-#define SAVFI_W4_MAXC 64
+#define SAVFI_W4_MAXC 256
 #endif
 
 // which layers run on this form: by channel counts only (the filter transform does not know the map size)
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void wino4_conv3x3(W4Args a) {
   const int y0 = 4 * (tby * tbh + (tl >> tsh)) - a.off, x0 = 4 * (tbx * tbw + (tl & (tbw - 1))) - a.off;
   constexpr int WC = IN16 ? IN16 - 1 : 0;       // first column of a row's 16-byte load
   unsigned pv[6], pn[IN16 ? 6 : 1], pn2[IN16 == 2 ? 6 : 1];
-  unsigned long long shl = 0, colm[6];
+  unsigned long long shl = 0, colm[6] = {~0ull, ~0ull, ~0ull, ~0ull, ~0ull, ~0ull};
   int partial = 0;
   unsigned chunk_bytes;              // channel step of the descriptor per chunk
   unsigned plane_b;                  // bytes between two channels as this thread addresses them
@@ -262,27 +262,28 @@ __global__ __launch_bounds__(256, 2) void wino4_conv3x3(W4Args a) {
       }
     }
   };
-  // left-edge tiles were loaded from column 0: move the row right by `off`; then clear the columns outside the image
-  auto fix_row = [&](int r) {
-    if constexpr (!IN16) {
-      if (shl != 0) {
-        if (a.off == 1) {
+  // Waves with a tile on the left / right image border (wave-uniform `edge`: ONE branch per chunk -- per-row and per-column branches
+  // were 48 per chunk, in every wave): left-edge tiles were loaded from column 0 -- move the rows right by `off` --, then clear the
+  // columns outside the image.  Unconditional selects on lane masks (a mask of all ones changes nothing).
+  const bool edge = !IN16 && (shl != 0 || partial != 0);
+  auto fix_patch = [&]() {
+    if (a.off == 1) {
 #pragma unroll
-          for (int c = 5; c >= 1; --c) asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(d[r][c]) : "v"(d[r][c - 1]), "s"(shl));
-        } else {
+      for (int r = 0; r < 6; ++r)
 #pragma unroll
-          for (int c = 5; c >= 2; --c) asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(d[r][c]) : "v"(d[r][c - 2]), "s"(shl));
-        }
-      }
-      if (partial) {
+        for (int c = 5; c >= 1; --c) asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(d[r][c]) : "v"(d[r][c - 1]), "s"(shl));
+    } else if (a.off == 2) {
 #pragma unroll
-        for (int c = 0; c < 6; ++c)
-          if (partial & (1 << c)) asm volatile("v_cndmask_b32 %0, 0, %0, %1" : "+v"(d[r][c]) : "s"(colm[c]));
-      }
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = 5; c >= 2; --c) asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(d[r][c]) : "v"(d[r][c - 2]), "s"(shl));
     }
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int c = 0; c < 6; ++c) asm volatile("v_cndmask_b32 %0, 0, %0, %1" : "+v"(d[r][c]) : "s"(colm[c]));
   };
   auto row_pass = [&](int r) {
-    fix_row(r);
     float o[6];
     bt6(d[r][0], d[r][1], d[r][2], d[r][3], d[r][4], d[r][5], o);
 #pragma unroll
@@ -320,16 +321,6 @@ __global__ __launch_bounds__(256, 2) void wino4_conv3x3(W4Args a) {
   auto load_a2 = [&](unsigned uo) { a2 = savfi_raw_buffer_load_x2(urs, (int)ulane2, (int)uo, 0); };
   const int vr = (9 * w * 8 + kg) * 32 + 2 * j;        // + (q * 2 + s) * 128 floats
 
-  // bias of this thread's output channels: round cb, pair qq -> channel i0 + 16 cb + (tid >> 5) + 8 qq
-  float bvals[2][2];
-#pragma unroll
-  for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-    for (int qq = 0; qq < 2; ++qq) {
-      const int i = i0 + 16 * cb + (tid >> 5) + 8 * qq;
-      bvals[cb][qq] = (a.bias && i < a.I) ? a.bias[task * a.I + i] : 0.f;
-    }
-
   // ---- prologue: P(0) -> V(0); P(1) and A(0, half 0) in flight ----
   {
     const i32x4 rs = xrs(0);
@@ -337,6 +328,7 @@ __global__ __launch_bounds__(256, 2) void wino4_conv3x3(W4Args a) {
     load_narrow(rs);
   }
   load_a4(0, u_of(0, 0)); load_a4(1, u_of(0, 0)); load_a4(2, u_of(0, 0)); load_a4(3, u_of(0, 0)); load_a2(u_of(0, 0));
+  if (edge) fix_patch();
 #pragma unroll
   for (int r = 0; r < 6; ++r) row_pass(r);
 #pragma unroll
@@ -351,7 +343,8 @@ __global__ __launch_bounds__(256, 2) void wino4_conv3x3(W4Args a) {
 
   // One chunk: 18 steps of 4 MFMAs (half s = step / 9, point q = step % 9).  Steps 9-11: row pass of the next chunk's patch; steps
   // 12-17: its column pass into the other V buffer; the patch after that is requested behind the 4th / 6th column.
-  auto chunk = [&](int ch, const float* vcur, float* vnext, bool last) {
+  auto chunk = [&](int ch, const float* vcur, float* vnext, auto last_tag) {
+    constexpr bool last = decltype(last_tag)::value;
     f32x2 bq[3];
     bq[0] = *reinterpret_cast<const f32x2*>(vcur + vr);
     bq[1] = *reinterpret_cast<const f32x2*>(vcur + vr + 256);
@@ -381,6 +374,7 @@ __global__ __launch_bounds__(256, 2) void wino4_conv3x3(W4Args a) {
       }
       if (!last) {
         if (W4_ABL != 2) {
+          if (g == 9 && edge) fix_patch();
           if (g >= 9 && g < 12) { row_pass(2 * (g - 9)); row_pass(2 * (g - 9) + 1); }
           if (g >= 12) col_pass(CORD[g - 12], vnext);
         }
@@ -394,10 +388,10 @@ __global__ __launch_bounds__(256, 2) void wino4_conv3x3(W4Args a) {
   };
   for (int ch = 0; ch < nch - 1; ++ch) {
     const int cur = ch & 1;
-    chunk(ch, lds + cur * VBUF, lds + (cur ^ 1) * VBUF, false);
+    chunk(ch, lds + cur * VBUF, lds + (cur ^ 1) * VBUF, std::false_type{});
     __syncthreads();
   }
-  chunk(nch - 1, lds + ((nch - 1) & 1) * VBUF, lds, true);
+  chunk(nch - 1, lds + ((nch - 1) & 1) * VBUF, lds, std::true_type{});
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
 
@@ -413,6 +407,17 @@ __global__ __launch_bounds__(256, 2) void wino4_conv3x3(W4Args a) {
     return;
   }
   // ---- output stage ------------------------------------------------------------------------------------------------
+  // bias of this thread's output channels: round cb, pair qq -> channel i0 + 16 cb + (tid >> 5) + 8 qq (fetched here, behind the channel
+  // loop, where no store is outstanding yet: a load issued between stores waits for every older store's acknowledge)
+  float bvals[2][2];
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+    for (int qq = 0; qq < 2; ++qq) {
+      const int i = i0 + 16 * cb + (tid >> 5) + 8 * qq;
+      bvals[cb][qq] = (a.bias && i < a.I) ? a.bias[task * a.I + i] : 0.f;
+    }
+
   // this thread finishes pairs p = tid + 256 qq of a round: tile p % 32 (= tid % 32), channel p / 32 of the round's 16
   const int otl = tid & 31, och = tid >> 5;
   const int oy = 4 * (tby * tbh + (otl >> tsh)), ox = 4 * (tbx * tbw + (otl & (tbw - 1)));

@@ -773,6 +773,27 @@ def _convk_geometry(weight, stride, padding, dilation, groups):
     return K, int(pad)
 
 
+# Winograd F(4x4, 3x3) (csrc/winograd4.h; round 6): the 3x3 layers of at most 256 -> 256 channels, wherever its launch fills the chip --
+# measured against the direct split-bf16 kernel on one box (tools/r6/wino4_time.py deep convk, profiles/r06_wino4_vs_convk.txt):
+# 64 -> 64 @192x256 121 / 131 vs 142 / 147 us (forward / data gradient, T = 4 x 2 samples), 128 -> 128 @96x128 115 / 111 vs 128 / 128,
+# 256 -> 256 @48x64 118 / 115 vs 133 / 132, 64 -> 64 @137x236 N = 32 324 / 320 vs 385 / 393; 128 -> 128 @48x64 (192 workgroups) 46 vs 42:
+# below ~300 workgroups (2 per CU x 256 CUs = 512 slots) the direct kernel keeps the layer.
+WINO4_MIN_WORKGROUPS = 300
+
+
+@functools.lru_cache(maxsize=None)
+def _conv3x3_name(Ci, Co, what):
+    """Timer name of a savfi_conv3x3_* launch: 'conv3x3f4_*' for the layers the library runs on its F(4x4) kernel (by channel counts)."""
+    f4 = int(_hip.lib().savfi_conv3x3_f4_workgroups(1, int(Ci), int(Co), 8, 8, 1, 0)) > 0
+    return ("conv3x3f4_" if f4 else "conv3x3_") + what
+
+
+def wino4_workgroups(N, Ci, Co, H, W, pad, mode=0):
+    """Workgroups savfi_conv3x3_* would launch on its F(4x4) kernel for this call; 0: the layer's channel counts keep it on F(2x2)."""
+    n = int(_hip.lib().savfi_conv3x3_f4_workgroups(int(N), int(Ci), int(Co), int(H), int(W), int(pad), int(mode)))
+    return max(n, 0)
+
+
 def convk_eligible(x, weight, stride, padding, dilation, groups=1, direct=False):
     """Does this convolution (and its data gradient) run on the direct split-bf16 kernel?  weight [Co,Ci,K,K] or [T,Co,Ci,K,K]."""
     if not (CONVK and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
@@ -788,7 +809,10 @@ def convk_eligible(x, weight, stride, padding, dilation, groups=1, direct=False)
         return False
     if K != 3 or direct:
         return True
-    return Ho * Wo >= CONVK_3X3_MIN_PIXELS and (Ci <= 8 or (Ci >= 64 and Co >= 64 and Co % 64 == 0))
+    if not (Ho * Wo >= CONVK_3X3_MIN_PIXELS and (Ci <= 8 or (Ci >= 64 and Co >= 64 and Co % 64 == 0))):
+        return False
+    # (the <= 8-channel input layers stay here: an F(4x4) chunk is 8 reduction channels, half of them padding for 6 -> 32)
+    return Ci <= 8 or pad > 1 or not WINOGRAD_CONV or wino4_workgroups(x.shape[0], Ci, Co, H, W, pad) < WINO4_MIN_WORKGROUPS
 
 
 # Packed / transformed filters of a module's OWN parameters are cached per weight version: a first-order meta-iteration
@@ -1077,7 +1101,7 @@ def conv3x3_tasks(x, weight, bias=None, mode=0, slope=1.0, pad=1):
     lib = _hip.lib()
     ws = torch.empty(_workspace_floats("savfi_conv3x3_tasks_workspace_floats", N, T, Ci, Co, H, W, int(pad), mode), dtype=x.dtype, device=x.device)
     out = torch.empty((N, I, H + grow, W + grow), dtype=x.dtype, device=x.device)
-    _hip.launch("conv3x3_fwd" if mode == 0 else "conv3x3_bwd_data", lambda: _hip.check(lib.savfi_conv3x3_tasks_f32(
+    _hip.launch(_conv3x3_name(Ci, Co, "fwd" if mode == 0 else "bwd_data"), lambda: _hip.check(lib.savfi_conv3x3_tasks_f32(
         x.data_ptr(), weight.data_ptr(), None if bias is None else bias.data_ptr(), out.data_ptr(), ws.data_ptr(),
         N, T, Ci, Co, H, W, int(pad), mode, float(slope), _hip.current_stream()), "savfi_conv3x3_tasks_f32"),
         flops=18.0 * Ci * Co * out.shape[2] * out.shape[3] * N if mode == 0 else 18.0 * Ci * Co * H * W * N)
@@ -1327,7 +1351,7 @@ def conv3x3_dgrad_in_unit16(gy, u, T, Ci, Co, pad):
     grow = 2 * (2 - pad) - 2
     out = torch.empty((N, Ci, H + grow, W + grow), dtype=gy.dtype, device=gy.device)
     lib = _hip.lib()
-    _hip.launch("conv3x3_bwd_data", lambda: _hip.check(lib.savfi_conv3x3_dgrad_in_unit16_f32(
+    _hip.launch(_conv3x3_name(Ci, Co, "bwd_data"), lambda: _hip.check(lib.savfi_conv3x3_dgrad_in_unit16_f32(
         gy.data_ptr(), u.data_ptr(), out.data_ptr(), N, T, Ci, Co, H, W, int(pad), _hip.current_stream()),
         "savfi_conv3x3_dgrad_in_unit16_f32"), flops=18.0 * Ci * Co * H * W * N)
     return out
@@ -1351,14 +1375,14 @@ def conv3x3_tasks_pre(x, u, T, Ci, Co, bias=None, mode=0, slope=1.0, pad=1, mask
     if out_unit16:
         assert mode == 0
         out = torch.empty((N, I, H + grow, W + grow), dtype=x.dtype, device=x.device)
-        _hip.launch("conv3x3_fwd", lambda: _hip.check(lib.savfi_conv3x3_tasks_pre_unit16_f32(
+        _hip.launch(_conv3x3_name(Ci, Co, "fwd"), lambda: _hip.check(lib.savfi_conv3x3_tasks_pre_unit16_f32(
             x.data_ptr(), u.data_ptr(), None if bias is None else bias.data_ptr(), out.data_ptr(), N, T, Ci, Co, H, W, int(pad), float(slope),
             _hip.current_stream()), "savfi_conv3x3_tasks_pre_unit16_f32"), flops=18.0 * Ci * Co * out.shape[2] * out.shape[3] * N)
         return out
     nws = _workspace_floats("savfi_conv3x3_tasks_pre_workspace_floats", N, T, Ci, Co, H, W, int(pad), mode)
     ws = torch.empty(nws, dtype=x.dtype, device=x.device) if nws else None
     out = torch.empty((N, I, H + grow, W + grow), dtype=x.dtype, device=x.device)
-    _hip.launch("conv3x3_fwd" if mode == 0 else "conv3x3_bwd_data", lambda: _hip.check(lib.savfi_conv3x3_tasks_pre_f32(
+    _hip.launch(_conv3x3_name(Ci, Co, "fwd" if mode == 0 else "bwd_data"), lambda: _hip.check(lib.savfi_conv3x3_tasks_pre_f32(
         x.data_ptr(), u.data_ptr(), None if bias is None else bias.data_ptr(), out.data_ptr(), None if ws is None else ws.data_ptr(),
         N, T, Ci, Co, H, W, int(pad), mode, float(slope), _hip.current_stream()), "savfi_conv3x3_tasks_pre_f32"),
         flops=18.0 * Ci * Co * out.shape[2] * out.shape[3] * N if mode == 0 else 18.0 * Ci * Co * H * W * N)
@@ -1373,7 +1397,7 @@ def _conv3x3_dgrad_masked(gy, u, T, Ci, Co, pad, mask, mask_slope):
     lib = _hip.lib()
     nws = _workspace_floats("savfi_conv3x3_tasks_pre_workspace_floats", N, T, Ci, Co, H, W, int(pad), 1)
     ws = torch.empty(nws, dtype=gy.dtype, device=gy.device) if nws else None
-    _hip.launch("conv3x3_bwd_data", lambda: _hip.check(lib.savfi_conv3x3_dgrad_masked_f32(
+    _hip.launch(_conv3x3_name(Ci, Co, "bwd_data"), lambda: _hip.check(lib.savfi_conv3x3_dgrad_masked_f32(
         gy.data_ptr(), u.data_ptr(), mask.data_ptr(), float(mask_slope), out.data_ptr(), None if ws is None else ws.data_ptr(),
         N, T, Ci, Co, H, W, int(pad), _hip.current_stream()), "savfi_conv3x3_dgrad_masked_f32"), flops=18.0 * Ci * Co * H * W * N)
     return out
@@ -1815,7 +1839,7 @@ def conv3x3(x, weight, bias=None, mode=0, slope=1.0, pad=1):
     lib = _hip.lib()
     ws = torch.empty(_workspace_floats("savfi_conv3x3_workspace_floats", N, Ci, Co, H, W, int(pad), mode), dtype=x.dtype, device=x.device)
     out = torch.empty((N, I, H + grow, W + grow), dtype=x.dtype, device=x.device)
-    _hip.launch("conv3x3_fwd" if mode == 0 else "conv3x3_bwd_data", lambda: _hip.check(lib.savfi_conv3x3_f32(
+    _hip.launch(_conv3x3_name(Ci, Co, "fwd" if mode == 0 else "bwd_data"), lambda: _hip.check(lib.savfi_conv3x3_f32(
         x.data_ptr(), weight.data_ptr(), None if bias is None else bias.data_ptr(), out.data_ptr(), ws.data_ptr(),
         N, Ci, Co, H, W, int(pad), mode, float(slope), _hip.current_stream()), "savfi_conv3x3_f32"),
         flops=18.0 * Ci * Co * out.shape[2] * out.shape[3] * N if mode == 0 else 18.0 * Ci * Co * H * W * N)

@@ -517,8 +517,21 @@ def test_sepconv_subnets_as_one_batched_launch_equal_one_by_one(hw, const):
 
 
 # ---------------------------------------------------------------------------------------------
-# Winograd F(2x2,3x3) convolution on the fp32 matrix cores
+# Winograd convolution on the fp32 matrix cores: F(4x4,3x3) up to 256 -> 256 channels (csrc/winograd4.h), F(2x2,3x3) beyond
 # ---------------------------------------------------------------------------------------------
+def conv3x3_close(got, want, Ci, Co):
+    """Rounding bound of the form the layer runs on, against float64.  F(2x2): 2e-6 of the result's scale (measured 2-4e-7).  F(4x4)
+    (interpolation points 0, +-1, +-2, inf): its transforms multiply by up to 8 before they cancel -- measured 1.5-4e-7 rms, 3e-6..1e-5 max
+    over tools/r6/wino4_check.py's shapes (a numpy transcription of the same arithmetic: 3.6e-7 / 4.6e-6; the direct fp32 sum 7e-8 / 6e-7).
+    Gates: 2e-5 max AND 1e-6 rms of the scale -- the system-level contract (pixel L1 1e-4, loss 1e-5) is held by the fixture tests."""
+    scale = want.abs().max()
+    d = (got - want)
+    if max(Ci, Co) <= 256:
+        return bool(d.abs().max() <= 2e-5 * scale) and bool(d.pow(2).mean().sqrt() <= 1e-6 * scale)
+    return bool(d.abs().max() <= 2e-6 * scale)
+
+
+
 CONV_SHAPES = [
     # N, Ci, Co, H, W
     (1, 8, 64, 16, 64),       # exactly one tile block
@@ -527,6 +540,8 @@ CONV_SHAPES = [
     (2, 51, 51, 18, 30),
     (1, 128, 128, 48, 64),
     (1, 3, 5, 5, 7),
+    (2, 256, 256, 13, 21),    # the deepest F(4x4) layer
+    (1, 320, 288, 12, 20),    # beyond 256 channels: the F(2x2) kernel
 ]
 
 
@@ -540,13 +555,12 @@ def test_conv3x3_forward_matches_conv2d(shape, pad):
     b = torch.randn(Co, generator=g)
     want = F.conv2d(x.double(), w.double(), b.double(), padding=pad)
     got = hip_ops.conv3x3(x.cuda(), w.cuda(), b.cuda(), mode=0, slope=1.0, pad=pad).cpu().double()
-    scale = want.abs().max()
     assert got.shape == want.shape
-    assert (got - want).abs().max() <= 2e-6 * scale
+    assert conv3x3_close(got, want, Ci, Co)
     got = hip_ops.conv3x3(x.cuda(), w.cuda(), b.cuda(), mode=0, slope=0.0, pad=pad).cpu().double()
-    assert (got - F.relu(want)).abs().max() <= 2e-6 * scale
+    assert conv3x3_close(got, F.relu(want), Ci, Co)
     got = hip_ops.conv3x3(x.cuda(), w.cuda(), None, mode=0, slope=0.2, pad=pad).cpu().double()
-    assert (got - F.leaky_relu(F.conv2d(x.double(), w.double(), None, padding=pad), 0.2)).abs().max() <= 2e-6 * scale
+    assert conv3x3_close(got, F.leaky_relu(F.conv2d(x.double(), w.double(), None, padding=pad), 0.2), Ci, Co)
 
 
 @pytest.mark.parametrize("pad", [1, 0])
@@ -561,10 +575,11 @@ def test_conv3x3_data_gradient_matches_autograd(shape, pad):
     (want,) = torch.autograd.grad(y, x, gy.double())
     got = hip_ops.conv3x3(gy.cuda(), w.cuda(), None, mode=1, slope=1.0, pad=pad).cpu().double()
     assert got.shape == want.shape
-    assert (got - want).abs().max() <= 2e-6 * want.abs().max()
+    assert conv3x3_close(got, want, Ci, Co)
 
 
-@pytest.mark.parametrize("T,N,Ci,Co,H,W,pad", [(1, 2, 6, 32, 24, 40, 1), (4, 8, 51, 51, 18, 30, 1), (2, 4, 64, 32, 16, 64, 0), (4, 8, 256, 256, 12, 16, 1)])
+@pytest.mark.parametrize("T,N,Ci,Co,H,W,pad", [(1, 2, 6, 32, 24, 40, 1), (4, 8, 51, 51, 18, 30, 1), (2, 4, 64, 32, 16, 64, 0), (4, 8, 256, 256, 12, 16, 1),
+                                               (4, 8, 320, 320, 12, 16, 1)])
 def test_conv3x3_split_entry_points_equal_the_fused_one(T, N, Ci, Co, H, W, pad):
     """savfi_conv3x3_filters_f32 (both transforms in one launch) + savfi_conv3x3_tasks_pre_f32 == savfi_conv3x3_tasks_f32,
     bit for bit, forward and data gradient (the last shape splits its reduction channels: partial-output workspace)."""

@@ -242,7 +242,7 @@ def test_winograd_convolution_writes_unit_major_and_the_pair_op_reads_it():
     """hip_ops.conv_bias_act_tasks(out_unit16=True) -> FunctionSepconvPair(taps_unit16=True) against the plain layout: the convolution's
     result rearranged is bit-identical, the op's output and every gradient (taps -> convolution input, weights, bias) are bit-identical"""
     from meta_interpolation_amd import hip_ops
-    B, T, C, Ho, Wo = 2, 4, K, 96, 128          # large enough for a launch without a reduction split (smaller ones are refused)
+    B, T, C, Ho, Wo = 2, 4, K, 96, 128
     g = torch.Generator().manual_seed(5)
     x = torch.randn(B * T, C, Ho + 2, Wo + 2, generator=g).to(DEV)
     w = (torch.randn(T, K, C, 3, 3, generator=g) / (3 * math.sqrt(C))).to(DEV)
@@ -251,7 +251,9 @@ def test_winograd_convolution_writes_unit_major_and_the_pair_op_reads_it():
     f1 = torch.randint(0, 256, (B, 3, Ho + K - 1, Wo + K - 1), generator=g).float().div(255).to(DEV)
     gO = torch.randn(B, 3, Ho, Wo, generator=g).to(DEV)
     assert hip_ops.conv3x3_unit16_supported(x, w, 0)
-    assert not hip_ops.conv3x3_unit16_supported(x[:, :, :38, :66].contiguous(), w, 0)       # 80 workgroups: the reduction is split
+    # (51 -> 51 runs on the F(4x4) kernel, which never splits its reduction: small launches qualify too; the F(2x2) kernel's split
+    # launches of deeper layers are refused -- test_unit_major_convolution_entry_points_refuse_what_they_cannot_do)
+    assert hip_ops.conv3x3_unit16_supported(x[:, :, :38, :66].contiguous(), w, 0)
     res = []
     for u16 in (False, True):
         xs, ws, bs = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
@@ -288,15 +290,24 @@ def test_unit_major_convolution_entry_points_refuse_what_they_cannot_do():
     assert lib.savfi_conv3x3_unit16_supported(N, T, C, C, H, W, 0) == 1
     assert lib.savfi_conv3x3_tasks_pre_unit16_f32(None, P(u[0]), None, P(out), N, T, C, C, H, W, 0, 1.0, st) == -1
     assert lib.savfi_conv3x3_tasks_pre_unit16_f32(P(x), P(u[0]), None, P(out), N, T, C, C, H, W - 2, 0, 1.0, st) == -3      # width 126: not % 16
-    assert lib.savfi_conv3x3_tasks_pre_unit16_f32(P(x), P(u[0]), None, P(out), 4, T, C, C, 38, 66, 0, 1.0, st) == -3        # split reduction
+    # a layer beyond the F(4x4) kernel's 256 channels on a small map: the F(2x2) kernel splits its reduction over workgroups -> refused
+    C2 = 320
+    u2 = hip_ops.conv3x3_filters(torch.randn(T, C2, C2, 3, 3, device=DEV), True, True)
+    x2, out2 = torch.randn(4, C2, 38, 66, device=DEV), torch.empty(4, C2, 36, 64, device=DEV)
+    assert lib.savfi_conv3x3_f4_workgroups(4, C2, C2, 38, 66, 0, 0) == 0 and lib.savfi_conv3x3_f4_workgroups(4, C, C, 38, 66, 0, 0) == 4 * 5 * 2
+    assert lib.savfi_conv3x3_unit16_supported(4, T, C2, C2, 38, 66, 0) == 0
+    assert lib.savfi_conv3x3_tasks_pre_unit16_f32(P(x2), P(u2[0]), None, P(out2), 4, T, C2, C2, 38, 66, 0, 1.0, st) == -3
+    assert lib.savfi_conv3x3_tasks_pre_unit16_f32(P(x), P(u[0]), None, P(out), 4, T, C, C, 38, 66, 0, 1.0, st) == 0         # F(4x4): no split
     assert lib.savfi_conv3x3_unit16_supported(N, T, C, C, H, W - 2, 0) == 0 and lib.savfi_conv3x3_unit16_supported(N, 3, C, C, H, W, 0) == 0
     gy = torch.randn(N, C, H - 2, W - 2, device=DEV)
     assert lib.savfi_conv3x3_in_unit16_supported(N, T, C, C, H - 2, W - 2, 0) == 1
     assert lib.savfi_conv3x3_dgrad_in_unit16_f32(P(gy), None, P(x), N, T, C, C, H - 2, W - 2, 0, st) == -1
     assert lib.savfi_conv3x3_dgrad_in_unit16_f32(P(gy), P(u[1]), P(x), N, T, C, C, H - 2, W - 4, 0, st) == -3              # width 126
     assert lib.savfi_conv3x3_in_unit16_supported(N, T, C, C, H - 2, W - 4, 0) == 0
-    # the Python gate of the plugin says no where the direct split-bf16 kernel would run the layer (64 -> 64 channels)
-    assert not hip_ops.conv3x3_unit16_supported(torch.randn(8, 64, 98, 130, device=DEV), torch.randn(4, 64, 64, 3, 3, device=DEV), 0)
+    # the Python gate of the plugin says no where the direct split-bf16 kernel would run the layer (64 -> 64 channels on a launch too small
+    # to fill the chip with F(4x4) workgroups)
+    assert not hip_ops.conv3x3_unit16_supported(torch.randn(4, 64, 38, 66, device=DEV), torch.randn(4, 64, 64, 3, 3, device=DEV), 0)
+    assert hip_ops.conv3x3_unit16_supported(torch.randn(8, 64, 98, 130, device=DEV), torch.randn(4, 64, 64, 3, 3, device=DEV), 0)
     torch.cuda.synchronize()
 
 

@@ -36,5 +36,11 @@ for T, N, Ci, Co, H, W, pad in SHAPES:
     tf = timeit(lambda: hip_ops.conv3x3_tasks_pre(x, u_f, T, Ci, Co, b, 0, 0.2, pad))
     tb = timeit(lambda: hip_ops.conv3x3_tasks_pre(gy, u_b, T, Ci, Co, None, 1, 1.0, pad))
     fl = 18.0 * Ci * Co * Ho * Wo * N
-    out.append('%d->%d@%dx%d N%d: %.0f / %.0f us (%.0f / %.0f TF)' % (Ci, Co, H, W, N, tf, tb, fl / tf / 1e6, fl / tb / 1e6))
+    line = '%d->%d@%dx%d N%d: %.0f / %.0f us (%.0f / %.0f TF)' % (Ci, Co, H, W, N, tf, tb, fl / tf / 1e6, fl / tb / 1e6)
+    if 'convk' in sys.argv:          # the direct split-bf16 kernel on the same box
+        p_f, p_b = hip_ops.convk_filters(w, True, True)
+        kf = timeit(lambda: hip_ops.convk_tasks_pre(x, p_f, T, Ci, Co, 3, b, 0, 0.2, pad))
+        kb = timeit(lambda: hip_ops.convk_tasks_pre(gy, p_b, T, Ci, Co, 3, None, 1, 1.0, pad))
+        line += ' [convk %.0f / %.0f us]' % (kf, kb)
+    out.append(line)
 print(os.environ.get('SAVFI_HIP_LIB', 'default'), ' | '.join(out), flush=True)
