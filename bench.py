@@ -57,6 +57,10 @@ WORKLOADS = {
     # one GPU's share of BASELINE config 4 (meta-batch 32 over 8 GPUs): MAML++ multi-step loss = a target pass after every step
     'c4_sepconv_msl_256x448_b4_s5': ('sepconv', 256, 448, 4, 5, dict(optimizer='SGD', loss='1*L1', inner_lr=1e-5,
                                                                        use_multi_step_loss_optimization=True)),
+    # the configuration the reference's own scripts/run_sepconv.sh:6-17 trains: Adamax + Meta-SGD (element-wise learnable learning rates),
+    # 3 inner steps, meta-batch 3 (pinned at size by tests/golden/full_c2script_sepconv_256x448_b3_s3.npz)
+    'c2script_sepconv_metasgd_adamax_256x448_b3_s3': ('sepconv', 256, 448, 3, 3, dict(optimizer='Adamax', metasgd=True, loss='1*L1',
+                                                                                      inner_lr=1e-5)),
     # same launch sequence as C2 on tiny frames: wall time ~= the host-side floor of one C2 meta-iteration
     'c2_host_floor_64x64_b4_s5': ('sepconv', 64, 64, 4, 5, dict(optimizer='SGD', loss='1*L1', inner_lr=1e-5)),
     # SURVEY 8(f) rank 4 plugins (no BASELINE.json config names them: extra lines, same metric)

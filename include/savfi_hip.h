@@ -56,7 +56,7 @@
 extern "C" {
 #endif
 
-#define SAVFI_ABI_VERSION 17
+#define SAVFI_ABI_VERSION 18
 
 #define SAVFI_OK            0
 #define SAVFI_E_NULL       (-1)  /* a required pointer is NULL                          */
@@ -145,6 +145,9 @@ int savfi_sepconv_ws_errors(void);
  * -1: not armed on this device. */
 int savfi_sepconv_ws_watch(void);
 int savfi_sepconv_ws_errors_peek(void);
+/* Clears the current device's mapped word and returns the count it held (-1: not armed): for a caller that has handled the reported
+ * time-out (the product drops the meta-iteration BEFORE its outer optimizer step and raises) and goes on. */
+int savfi_sepconv_ws_errors_reset(void);
 /* Test hook: the spin limit of the kernels' bounded waits (default 1 << 19 spins of s_sleep 2).  A NEGATIVE limit makes every wait that does
  * not find its flag at once give up -- tests/ provoke the error path with it.  *previous (may be NULL) receives the old limit; launches issued afterwards use the new one. */
 int savfi_sepconv_ws_debug_spin_limit(int limit, int* previous);

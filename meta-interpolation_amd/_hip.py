@@ -16,7 +16,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_PKG_DIR), "include", "savfi_hip.h")
 
 RULE_SGD, RULE_ADAM, RULE_ADAMAX_LSLR, RULE_ADAMAX_MSGD = 0, 1, 2, 3
 LR_SCALAR, LR_ELEMENT = 0, 1
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 _ERRORS = {-1: "SAVFI_E_NULL (a required pointer is NULL)",
            -2: "SAVFI_E_SHAPE (bad or inconsistent dimension)",
@@ -48,6 +48,7 @@ _PROTOTYPES = {
     "savfi_sepconv_ws_errors": [],
     "savfi_sepconv_ws_watch": [],
     "savfi_sepconv_ws_errors_peek": [],
+    "savfi_sepconv_ws_errors_reset": [],
     "savfi_sepconv_ws_debug_spin_limit": [c_int, POINTER(c_int)],
     "savfi_conv3x3_dgrad_masked_f32": [_P, _P, _P, c_float, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P],
     "savfi_convk_dgrad_masked_f32": [_P, _P, _P, c_float, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P],
@@ -184,9 +185,15 @@ def ws_check(where=""):
         return
     n = _lib.savfi_sepconv_ws_errors_peek()
     if n > 0:
+        _lib.savfi_sepconv_ws_errors_reset()      # reported once: a caller that handles the exception continues from a clean word
         raise SavfiHipError("%d bounded wait(s) of the wave-specialised SepConv kernels gave up (csrc/sepconv_ws.hip)%s: the results of "
                             "the launches since the last check are wrong.  A kernel bug, or the GPU was shared with another process for "
                             "longer than the spin limit." % (n, (" -- " + where) if where else ""))
+
+
+def ws_armed():
+    """Has ws_watch() armed the error word on some device of this process (i.e. can ws_check() see anything)?"""
+    return bool(_ws_watched)
 
 
 def ptr_array(tensors):

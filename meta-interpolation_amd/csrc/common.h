@@ -6,6 +6,9 @@
 
 #define SAVFI_WAVE 64
 
+// A/B knobs of the kernels are COMPILE-TIME macros (tools/build_variant.sh NAME unit.hip -DSAVFI_...=v builds a variant library for
+// SAVFI_HIP_LIB): the shipped library reads no environment variable (tests/test_host_cpu.py greps for strays).
+
 static inline int savfi_launch_status() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? SAVFI_OK : (int)e;

@@ -600,7 +600,9 @@ static int convk_tasks_pre_impl(const float* x, const float* packed, const float
   // 8 x 32 tiles have the smaller halo (340 vs 324 staged cells but 128-byte output rows and half the row count): 16 x 16 only
   // where it fills clearly better
   int tw = fill(16, 16) > 1.08 * fill(8, 32) ? 16 : 32;
-  if (const char* e = getenv("SAVFI_CONVK_TW")) { const int v = atoi(e); if (v == 16 || v == 32) tw = v; }
+#ifdef SAVFI_CONVK_TW          // variant builds: 16 or 32
+  tw = SAVFI_CONVK_TW;
+#endif
   const int th = 256 / tw;
   a.tiles_x = (a.Wo + tw - 1) / tw; a.tiles_y = (a.Ho + th - 1) / th;
   const int64_t tiles = (int64_t)N * a.tiles_x * a.tiles_y;
@@ -618,10 +620,9 @@ static int convk_tasks_pre_impl(const float* x, const float* packed, const float
   else if (!precise && co16 > 2 && !ragged64 && W1 >= 448) { nt = 4; cg = 1; }
   else if (co32 >= 2 && W2_2 >= 160) { nt = 2; cg = 2; }
   else { nt = 2; cg = 1; }
-  if (const char* e = getenv("SAVFI_CONVK_TILE")) {          // experiment knob: "nt,cg"
-    int en = 0, ec = 0;
-    if (sscanf(e, "%d,%d", &en, &ec) == 2 && (en == 1 || en == 2 || en == 4) && (ec == 1 || ec == 2) && !(precise && en == 4) && !(en == 1 && ec == 2)) { nt = en; cg = ec; }
-  }
+#if defined(SAVFI_CONVK_TILE_NT) && defined(SAVFI_CONVK_TILE_CG)      // variant builds (tools/convk_tile_sweep.py): nt in {1, 2, 4}, cg in {1, 2}
+  if (!(precise && SAVFI_CONVK_TILE_NT == 4) && !(SAVFI_CONVK_TILE_NT == 1 && SAVFI_CONVK_TILE_CG == 2)) { nt = SAVFI_CONVK_TILE_NT; cg = SAVFI_CONVK_TILE_CG; }
+#endif
   a.CBnt = (co16 + nt - 1) / nt;
   a.cg = cg;
   a.CB = (a.CBnt + cg - 1) / cg;

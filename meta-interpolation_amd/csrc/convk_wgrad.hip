@@ -664,23 +664,28 @@ inline int wg_plan(WgPlan& p, int N, int T, int Ci, int Co, int H, int W, int K,
   if (Ho <= 0 || Wo <= 0) return SAVFI_E_SHAPE;
   if ((int64_t)Ci * H * W >= (1ll << 29) || (int64_t)Co * Ho * Wo >= (1ll << 29)) return SAVFI_E_TOOBIG;
   p.mt = (K == 3 && Co >= 192) ? 4 : 2;
-  if (const char* e = getenv("SAVFI_WGRAD_MT4")) { if (K == 3 && Co >= atoi(e)) p.mt = 4; }     // 5x5 / 7x7: 7 / 13 taps per wave x 4 tiles would not fit the register file
+#ifdef SAVFI_WGRAD_MT4          // variant builds: the 4-tile form from this many output channels (5x5 / 7x7: 7 / 13 taps per wave x 4 tiles would not fit)
+  if (K == 3 && Co >= SAVFI_WGRAD_MT4) p.mt = 4;
+#endif
   // two input-channel tiles per workgroup split the cotangent tile once for 32 input channels (0.7x the VALU per MFMA) but cost the
   // third workgroup per CU: measured 10-15 % SLOWER on every layer (profiles/r03_wgrad_variants.txt); kept behind SAVFI_WGRAD_NT=2
   p.nt = 1;
-  if (const char* e = getenv("SAVFI_WGRAD_NT")) { if (atoi(e) == 2 && !precise && K != 7 && p.mt == 2 && Ci > 16) p.nt = 2; }
+#if defined(SAVFI_WGRAD_NT) && SAVFI_WGRAD_NT == 2
+  if (!precise && K != 7 && p.mt == 2 && Ci > 16) p.nt = 2;
+#endif
   // 8-wave workgroups on 64 x 32 channels (NG = 2, see the kernel) for the 4-tile variant, opt-in (SAVFI_WGRAD_NG=2): measured equal to
   // the 4-wave form (CAIN 192 -> 192 @96x160 N = 2: 149 vs 153 us per call; C5 slice 7.23 vs 7.34 steps/s) -- splitting the cotangent tile
   // once for twice the MFMAs buys nothing, the kernel is not bound by its VALU work
   p.ng = 1;
-  {
-    static const int ng_env = getenv("SAVFI_WGRAD_NG") ? atoi(getenv("SAVFI_WGRAD_NG")) : 1;
-    if (ng_env == 2 && K == 3 && p.mt == 4 && !precise && Ci >= 32) p.ng = 2;
-  }
+#if defined(SAVFI_WGRAD_NG) && SAVFI_WGRAD_NG == 2
+  if (K == 3 && p.mt == 4 && !precise && Ci >= 32) p.ng = 2;
+#endif
   // 3 x 3 with at least 48 channels on both sides: all nine taps per wave on 64 x 64 channel blocks, one 8-wave workgroup per CU
   // (SAVFI_WGRAD3_FORM=0: the tap-split kernel, for A/Bs)
-  static const int form_env = getenv("SAVFI_WGRAD3_FORM") ? atoi(getenv("SAVFI_WGRAD3_FORM")) : 2;
-  p.form = (K == 3 && !precise && Co >= 48 && Ci >= 48 && form_env == 2) ? 2 : 0;
+#ifndef SAVFI_WGRAD3_FORM
+#define SAVFI_WGRAD3_FORM 2
+#endif
+  p.form = (K == 3 && !precise && Co >= 48 && Ci >= 48 && SAVFI_WGRAD3_FORM == 2) ? 2 : 0;
   if (p.form) { p.mt = 4; p.nt = 4; p.ng = 1; }
   p.cobs = (Co + 16 * p.mt - 1) / (16 * p.mt);
   p.cibs = (Ci + 16 * p.nt * p.ng - 1) / (16 * p.nt * p.ng);
@@ -695,7 +700,10 @@ inline int wg_plan(WgPlan& p, int N, int T, int Ci, int Co, int H, int W, int K,
   // (~768 workgroups per launch) left CAIN's 192 -> 192 @96x160 layer with 792 workgroups for 512 slots: a second round 55 % full, 167 us;
   // 504 workgroups of 18 units instead of 792 of 11: 145 us (SAVFI_WGRAD_TARGET=n restores the old rule with n workgroups).
   int splits;
-  static const int target = getenv("SAVFI_WGRAD_TARGET") ? atoi(getenv("SAVFI_WGRAD_TARGET")) : 0;
+#ifndef SAVFI_WGRAD_TARGET
+#define SAVFI_WGRAD_TARGET 0
+#endif
+  constexpr int target = SAVFI_WGRAD_TARGET;
   if (target > 0) {
     splits = (target + blocks - 1) / blocks;
   } else {

@@ -176,7 +176,11 @@ extern "C" int savfi_bias_act_bwd_f32(const float* gy, const float* y, float* gz
   // one peel aligns all operands when they share their low address bits (a NULL gz takes gy's)
   const unsigned lo = (unsigned)(uintptr_t)gy & 15u;
   const int phase_ok = ((unsigned)(uintptr_t)y & 15u) == lo && (!gz || ((unsigned)(uintptr_t)gz & 15u) == lo) && (lo & 3u) == 0;
-  static const bool two_stage = getenv("SAVFI_BIAS_ACT_TWO_STAGE") != nullptr;      // experiment knob: the general path on small maps too
+#ifdef SAVFI_BIAS_ACT_TWO_STAGE      // variant builds: the general path on small maps too
+  constexpr bool two_stage = true;
+#else
+  constexpr bool two_stage = false;
+#endif
   if (gbias && chunks == 1 && (int64_t)N * HW <= CHUNK && !two_stage) {
     hipLaunchKernelGGL(bias_act_bwd_small, dim3((unsigned)C), dim3(NT), 0, (hipStream_t)stream, gy, y, gz, gbias, N, C, HW, slope, phase_ok);
     return savfi_launch_status();

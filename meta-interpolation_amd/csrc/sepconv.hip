@@ -986,24 +986,45 @@ __global__ void sepconv_bwd_input_direct(const float* __restrict__ v, const floa
   gI[(size_t)bc * Hi * Wi + (size_t)Y * Wi + X] = acc;
 }
 
-// Experiment switches, read ONCE per process (not per launch): SAVFI_SEPCONV_F32_MFMA keeps the filter gradients on the fp32
-// matrix-core kernel (sepconv_bwd_mfma_p) instead of the split-bf16 one (csrc/sepconv_x6.hip), SAVFI_SEPCONV_NO_MFMA forces the direct kernels,
-// SAVFI_SEPCONV_NO_WS the one-program-per-wave split-bf16 kernel instead of the wave-specialised one (csrc/sepconv_ws.hip),
-// SAVFI_SEPCONV_TILED the tiled (non-persistent) MFMA kernels, SAVFI_SEPCONV_MFMA_ROWS = 8 | 12 | 16 pins their rows per workgroup.
+// Kernel-generation switches of VARIANT BUILDS (compile-time: tools/build_variant.sh NAME sepconv.hip -DSAVFI_SEPCONV_...; the shipped
+// library has none set): SAVFI_SEPCONV_F32_MFMA keeps the filter gradients on the fp32 matrix-core kernel (sepconv_bwd_mfma_p) instead of the
+// split-bf16 one (csrc/sepconv_x6.hip), SAVFI_SEPCONV_NO_MFMA forces the direct kernels, SAVFI_SEPCONV_NO_WS the one-program-per-wave
+// split-bf16 kernel instead of the wave-specialised one (csrc/sepconv_ws.hip; _NO_WS_FWD: forward only), SAVFI_SEPCONV_TILED the tiled
+// (non-persistent) MFMA kernels, SAVFI_SEPCONV_MFMA_ROWS = 8 | 12 | 16 pins their rows per workgroup.
 struct SepconvEnv {
   bool no_mfma, tiled, f32_mfma, no_ws, no_ws_fwd;
   int rows;
-  SepconvEnv() : no_mfma(getenv("SAVFI_SEPCONV_NO_MFMA") != nullptr), tiled(getenv("SAVFI_SEPCONV_TILED") != nullptr),
-                 f32_mfma(getenv("SAVFI_SEPCONV_F32_MFMA") != nullptr), no_ws(getenv("SAVFI_SEPCONV_NO_WS") != nullptr),
-                 no_ws_fwd(getenv("SAVFI_SEPCONV_NO_WS_FWD") != nullptr), rows(0) {
-    if (const char* e = getenv("SAVFI_SEPCONV_MFMA_ROWS")) {
-      const int r = atoi(e);
-      if (r == 8 || r == 12 || r == 16) rows = r;
-    }
-  }
 };
+#ifdef SAVFI_SEPCONV_NO_MFMA
+#define SV_NO_MFMA true
+#else
+#define SV_NO_MFMA false
+#endif
+#ifdef SAVFI_SEPCONV_TILED
+#define SV_TILED true
+#else
+#define SV_TILED false
+#endif
+#ifdef SAVFI_SEPCONV_F32_MFMA
+#define SV_F32_MFMA true
+#else
+#define SV_F32_MFMA false
+#endif
+#ifdef SAVFI_SEPCONV_NO_WS
+#define SV_NO_WS true
+#else
+#define SV_NO_WS false
+#endif
+#ifdef SAVFI_SEPCONV_NO_WS_FWD
+#define SV_NO_WS_FWD true
+#else
+#define SV_NO_WS_FWD false
+#endif
+#ifndef SAVFI_SEPCONV_MFMA_ROWS
+#define SAVFI_SEPCONV_MFMA_ROWS 0
+#endif
 const SepconvEnv& sepconv_env() {
-  static const SepconvEnv env;
+  static const SepconvEnv env{SV_NO_MFMA, SV_TILED, SV_F32_MFMA, SV_NO_WS, SV_NO_WS_FWD, SAVFI_SEPCONV_MFMA_ROWS};
   return env;
 }
 

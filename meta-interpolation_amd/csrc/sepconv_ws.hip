@@ -1510,8 +1510,12 @@ namespace {
 constexpr int WS_MAX_DEV = 64;
 unsigned* ws_watch_word[WS_MAX_DEV] = {nullptr};     // host addresses of the mapped words (savfi_sepconv_ws_watch), per device
 unsigned* ws_watch_dev[WS_MAX_DEV] = {nullptr};      // their device addresses
-int ws_watch_last_dev = -1;                          // (one process drives one GPU: the device of the last savfi_sepconv_ws_watch call)
-unsigned* ws_watch_device_word() { return ws_watch_last_dev >= 0 ? ws_watch_dev[ws_watch_last_dev] : nullptr; }
+// the word of the device this launch goes to (a process may drive several GPUs: a per-launch hipGetDevice, ~50 ns, not a global)
+unsigned* ws_watch_device_word() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= WS_MAX_DEV) return nullptr;
+  return ws_watch_dev[dev];
+}
 }
 // one workgroup per CU (LDS), fewer when there are fewer phases than CUs
 static int ws_grid(int64_t total, int cus) { return (int)savfi_cdiv(total, savfi_cdiv(total, cus)); }
@@ -1600,7 +1604,6 @@ extern "C" int savfi_sepconv_ws_errors(void) {
 extern "C" int savfi_sepconv_ws_watch(void) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= WS_MAX_DEV) return -1;
-  ws_watch_last_dev = dev;
   if (ws_watch_word[dev]) return SAVFI_OK;
   unsigned* hp = nullptr;
   if (hipHostMalloc((void**)&hp, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return -1;
@@ -1615,6 +1618,14 @@ extern "C" int savfi_sepconv_ws_errors_peek(void) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= WS_MAX_DEV || !ws_watch_word[dev]) return -1;
   return (int)(__atomic_load_n(ws_watch_word[dev], __ATOMIC_ACQUIRE) & 0x7fffffffu);
+}
+// Clears the current device's mapped word and returns the count it held (or -1: not armed).  A caller that has HANDLED a reported time-out
+// (dropped the iteration, restored its state) continues from zero; without it every later check of the process would raise again.  The
+// synchronising counter of savfi_sepconv_ws_errors() keeps counting (it is the process's total).
+extern "C" int savfi_sepconv_ws_errors_reset(void) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= WS_MAX_DEV || !ws_watch_word[dev]) return -1;
+  return (int)(__atomic_exchange_n(ws_watch_word[dev], 0u, __ATOMIC_ACQ_REL) & 0x7fffffffu);
 }
 // Test hook: the spin limit of the kernels' bounded waits (default 1 << 19 spins of s_sleep 2; a NEGATIVE limit makes every wait that does
 // not find its flag at once give up -- how tests/ provoke the error path).  The previous limit goes to *previous (may be NULL).

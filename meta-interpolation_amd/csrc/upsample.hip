@@ -402,7 +402,10 @@ extern "C" int savfi_upsample2x_window_bwd_masked_f32(const float* gout, const f
   const UpMask um{y, slope};
   const Win g{H, W, sy0, sx0, Hs, Ws, oy0, ox0, Hw, Ww, align_corners ? 1 : 0};
   if (int rc = check_window(g, planes)) return rc;
-  static const int form = getenv("SAVFI_UPSAMPLE_BWD_FORM") ? atoi(getenv("SAVFI_UPSAMPLE_BWD_FORM")) : 0;      // A/B: 1 = the tiled form of rounds 2-4
+#ifndef SAVFI_UPSAMPLE_BWD_FORM
+#define SAVFI_UPSAMPLE_BWD_FORM 0      // variant builds: 1 = the tiled form of rounds 2-4
+#endif
+  constexpr int form = SAVFI_UPSAMPLE_BWD_FORM;
   // the streaming form where it has the waves to hide its serial walk (>= 8 per SIMD at some strip height), else the tiled form
   int usr = 0;
   for (int cand = 32; cand >= 8 && !usr; cand >>= 1)

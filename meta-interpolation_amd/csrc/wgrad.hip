@@ -667,7 +667,10 @@ bool ww_plan(WWPlan& p, int N, int T, int Ci, int Co, int H, int W, int pad) {
   // 90 / 77 / 76 us -> 74 / 70 / 68 with 16, no further gain below; tools/wino_wgrad_time.py)
   const int64_t blocks = (int64_t)T * p.cobs * p.cibs;
   int64_t want = (512 * 2 + blocks - 1) / blocks;
-  static const int min_chunks = getenv("SAVFI_WWGRAD_MIN_CHUNKS") ? atoi(getenv("SAVFI_WWGRAD_MIN_CHUNKS")) : 16;
+#ifndef SAVFI_WWGRAD_MIN_CHUNKS
+#define SAVFI_WWGRAD_MIN_CHUNKS 16
+#endif
+  constexpr int min_chunks = SAVFI_WWGRAD_MIN_CHUNKS;
   const int64_t most = chunks / min_chunks > 0 ? chunks / min_chunks : 1;
   if (want > most) want = most;
   if (want < 1) want = 1;

@@ -694,14 +694,17 @@ bool make_plan(WinoPlan& p, int N, int Ci, int Co, int H, int W, int pad, int mo
   const int64_t wgs = (int64_t)p.th * p.tw * (p.IP / COB) * N;
   // split only launches that would leave workgroup slots empty (2 per CU x 256 CUs): the partial outputs cost an
   // extra pass, which loses on launches that already fill the chip (64->64 at 192x256: 64 -> 87 us when split)
-  static const int slots = getenv("SAVFI_WINO_SPLIT_SLOTS") ? atoi(getenv("SAVFI_WINO_SPLIT_SLOTS")) : 512;
+#ifndef SAVFI_WINO_SPLIT_SLOTS
+#define SAVFI_WINO_SPLIT_SLOTS 512      // variant builds: 0 = never split
+#endif
+  constexpr int slots = SAVFI_WINO_SPLIT_SLOTS;
   int want = (int)(slots / wgs);
   want = want < 1 ? 1 : (want > 8 ? 8 : want);
   int cps = round_up(savfi_cdiv(nchunk, want), 2);
   if (cps < 8) cps = nchunk < 8 ? nchunk : 8;          // at least 8 chunks per workgroup (prologue / output stage cost)
   p.chunks_per_split = cps;
   p.nsplit = savfi_cdiv(nchunk, cps);
-  if (const char* e = getenv("SAVFI_WINO_NO_SPLIT")) { (void)e; p.nsplit = 1; p.chunks_per_split = nchunk; }
+  if (SAVFI_WINO_SPLIT_SLOTS == 0) { p.nsplit = 1; p.chunks_per_split = nchunk; }
   p.u_floats = (int64_t)16 * p.KP * p.IP;
   p.partial_floats = p.nsplit > 1 ? (int64_t)p.nsplit * N * p.I * p.Ho * p.Wo : 0;
   return true;

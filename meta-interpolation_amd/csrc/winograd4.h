@@ -439,7 +439,6 @@ __global__ __launch_bounds__(256, 2) void wino4_conv3x3(W4Args a) {
     const int have = a.I - ie < 0 ? 0 : (a.I - ie > 2 ? 2 : a.I - ie);
     return w4_rsrc(base + ((size_t)n * a.I + (ie < a.I ? ie : 0)) * a.Ho * a.Wo, (unsigned)have * oplane);
   };
-  constexpr bool masked = MASK;
   float mk[MASK ? 2 : 1][MASK ? 2 : 1][4][4];
   if constexpr (MASK) {          // every mask value before the first store (one in-order counter for loads and stores)
 #pragma unroll

@@ -38,7 +38,7 @@ from . import _hip, hip_ops, model_utils, utils
 # mean (ATen's x.mean(2) behind a hipGraph memset node, which only clears once on ROCm 7.2: csrc/submean.hip) -- but config C5 is
 # GPU-bound and gains nothing from it (6.93 vs 6.91 steps/s), so the default keeps the eager loop, where kernels can be timed in place.
 import os as _os
-GRAPH_L2F = bool(_os.environ.get('SAVFI_GRAPH_L2F'))
+GRAPH_L2F = False      # tools/graph_vs_eager.py, tools/memset_capture_audit.py set it: L2F from graph replays (DESIGN: the ROCm 7.2 memset-node finding)
 
 
 def supported(system, use_second_order):

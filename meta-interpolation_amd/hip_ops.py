@@ -695,7 +695,7 @@ def mse_loss_per_sample(a, b):
 # 1.1-1.9x for the data gradient on every layer shape of the four plugins down to 24x32 maps (12x16 / 16x16 stay on MIOpen:
 # forward 1.27x, data gradient 0.87x, on ~40 us kernels); at N = 1 it wins from 48x64 maps up (1.05-1.9x) and loses on 24x32 (0.86-1.04x).  (Round 1 needed 6000-
 # 20000 tiles: the corner-tile tail and the output stage's store stalls, DESIGN.md 4b, weighed most on small maps.)
-WINOGRAD_CONV = not os.environ.get('SAVFI_NO_WINOGRAD')
+WINOGRAD_CONV = True            # (routing knobs are module attributes: tools and tests set them, no environment variable is read)
 WINO_MIN_TILES_FWD = 700
 WINO_MIN_TILES_BWD = 700
 WINO_MIN_TILES_FWD_BATCHED = 100      # N >= 2 (support pairs, lockstep batches of shared weights): 16x16 maps and up -- with the filters of all
@@ -704,9 +704,6 @@ WINO_MIN_TILES_FWD_BATCHED = 100      # N >= 2 (support pairs, lockstep batches 
                                       # config C1: forward 33.7 -> 38.4 steps/s, data gradient another +3 %.  Single samples at that size
                                       # (64 tiles) measured 1 % slower than MIOpen in the loop: they keep the 700 above
 WINO_MIN_TILES_BWD_BATCHED = 100
-if os.environ.get('SAVFI_WINO_TILES'):      # experiment knob: "fwd,bwd,fwd_batched,bwd_batched"
-    WINO_MIN_TILES_FWD, WINO_MIN_TILES_BWD, WINO_MIN_TILES_FWD_BATCHED, WINO_MIN_TILES_BWD_BATCHED = (
-        int(t) for t in os.environ['SAVFI_WINO_TILES'].split(','))
 # The weight gradient of the same layers runs on savfi_conv3x3_wgrad_f32 (NCHW-native MFMA kernel, deterministic) when a
 # map has >= 3000 output pixels and >= 16 input channels: 1.2-1.8x faster than MIOpen's igemm kernel + its two layout
 # transposes there (tools/wgrad_bench.py, profiles/r01_wgrad_bench.jsonl); the deep 24x32 / 12x16 layers stay on MIOpen.
@@ -715,7 +712,7 @@ WGRAD_MIN_CI = 16
 # Winograd form of the weight gradient (savfi_conv3x3_wgrad_wino_tasks_f32, F(3x3, 2x2)): 1.4-1.6x faster than the direct kernel
 # on the large layers and 1.2-1.5x faster than MIOpen (grouped or not) on the deep 24x32 / 12x16 ones once a call carries enough
 # work; below ~5 GFLOP the three launches (kernel + two reduction levels) are the cost and the old routing stays.
-WGRAD_WINO = not os.environ.get('SAVFI_NO_WINO_WGRAD')
+WGRAD_WINO = True
 WGRAD_WINO_MIN_GFLOP = 5.0
 WGRAD_WINO_MIN_PIXELS = 192
 
@@ -734,11 +731,13 @@ def _wgrad_wino(N, Ci, Co, Ho, Wo):
 #   3x3: where it beats the Winograd kernel -- layers of >= 64 -> 64 channels in whole 64-channel blocks on maps of >= 700 pixels
 #        (220-240 vs 200-208 direct-equivalent TFLOP/s) and the <= 8-channel input layers -- or where a plugin asks for the
 #        direct form because it amplifies Winograd rounding (VoxelFlow: `direct=True`).
-CONVK = not os.environ.get('SAVFI_NO_CONVK')
+CONVK = True
 CONVK_3X3_MIN_PIXELS = 700
 
 
 CONVK_WGRAD3_RING_MIN_PIXELS = 3000
+CONVK_WGRAD3 = True             # A/B: False = every 3 x 3 weight gradient on the Winograd form
+CONVK_WGRAD3_RING = True        # A/B: False = no all-taps kernel (the tap-split kernel's rules alone)
 
 
 def convk_wgrad_preferred(K, Ci, Co, Ho, Wo, direct=False):
@@ -753,9 +752,9 @@ def convk_wgrad_preferred(K, Ci, Co, Ho, Wo, direct=False):
         return False
     if K != 3 or direct:
         return True
-    if os.environ.get('SAVFI_WGRAD_3X3_WINO'):
+    if not CONVK_WGRAD3:
         return False
-    if Ci >= 48 and Co >= 48 and Ho * Wo >= CONVK_WGRAD3_RING_MIN_PIXELS and not os.environ.get('SAVFI_WGRAD3_NO_RING'):      # (the switch: A/Bs)
+    if Ci >= 48 and Co >= 48 and Ho * Wo >= CONVK_WGRAD3_RING_MIN_PIXELS and CONVK_WGRAD3_RING:
         return True
     return (Ci <= 32 and Ho * Wo >= 16384) or (Co >= 192 and Ho * Wo >= 4096)
 
@@ -1059,8 +1058,6 @@ class _ConvBiasAct(torch.autograd.Function):
 TASKS_MIN_TILES_FWD = 1          # N * ceil(Ho/2) * ceil(Wo/2) tiles over all tasks
 TASKS_MIN_TILES_BWD = 1
 TASKS_WGRAD_MIN_PIXELS = 3000
-if os.environ.get('SAVFI_TASKS_TILES'):      # experiment knob: "fwd,bwd,wgrad_pixels"
-    TASKS_MIN_TILES_FWD, TASKS_MIN_TILES_BWD, TASKS_WGRAD_MIN_PIXELS = (int(t) for t in os.environ['SAVFI_TASKS_TILES'].split(','))
 
 
 def _is3x3s1(weight, stride, padding, dilation):
@@ -1118,7 +1115,7 @@ def conv3x3_tasks(x, weight, bias=None, mode=0, slope=1.0, pad=1):
 # conv3x3_filters find the result.  An entry keeps its weight tensor alive, so a data pointer cannot come back as another tensor
 # while the entry exists; the weight's version is part of the match.
 # --------------------------------------------------------------------------------------------
-PREPACK = not os.environ.get('SAVFI_NO_PREPACK')
+PREPACK = True
 _pack_plans = {}        # tuple of the update's weight shapes -> {index: [kind, fwd, bwd]}
 _last_update = None     # (signature, {data_ptr: index}, outputs) of the newest update
 _prepacked = {}         # (kind, data_ptr) -> (weight, version, filters_fwd, filters_bwd)
@@ -1574,7 +1571,7 @@ def convk_reflect_eligible(x, weight, pad):
     return convk_eligible(x, weight, 1, pad, 1, 1, False)
 
 
-WGRAD_FUSE_BIAS = not os.environ.get('SAVFI_WGRAD_NO_BIAS')     # A/B: the bias sums as a pass of their own (rounds 2-4)
+WGRAD_FUSE_BIAS = True     # A/B: False = the bias sums as a pass of their own (rounds 2-4)
 
 
 def conv3x3_wgrad_tasks_sums_bias(x_shape, co, T, pad):
@@ -1734,7 +1731,10 @@ class _ConvBiasActTasks(torch.autograd.Function):
         wgrad_is_convk = bool(need_w and _convk_geometry(w, stride, padding, dilation, 1) is not None and (ctx.route == 'convk' or K_ == 3)
                               and convk_wgrad_preferred(K_, Ci, Co, Ho, Wo, ctx.direct))
         wgrad_is_wino3 = need_w and not wgrad_is_convk and conv3x3_wgrad_tasks_eligible(x, w, stride, padding, dilation)
-        fuse_b = bool(need_b and identity and ((wgrad_is_wino3 and conv3x3_wgrad_tasks_sums_bias(x.shape, Co, T, pad_))
+        # (not beside the Winograd weight gradient on the SIDE stream: a bias gradient autograd consumes on the compute stream -- stacked
+        # biases, a bias shared between ops -- must be produced there; the side-stream guard counts uses of the WEIGHT only)
+        wino3_on_side = wgrad_is_wino3 and ctx.wg_stream is not None and ctx.wg_uses[0] == 1
+        fuse_b = bool(need_b and identity and ((wgrad_is_wino3 and not wino3_on_side and conv3x3_wgrad_tasks_sums_bias(x.shape, Co, T, pad_))
                                                or (wgrad_is_convk and convk_wgrad_tasks_sums_bias(x.shape, Co, T, K_, pad_, ctx.direct))))
         gb = torch.empty((T, Co), dtype=gy.dtype, device=gy.device) if (need_b and not fuse_b) else None
         if (need_b and not fuse_b) or not identity:
@@ -1979,6 +1979,10 @@ class _Upsample2x(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         if ctx.in_slope is not None:
+            # a raw kernel without a graph: under create_graph=True it would hand out zero second-order terms silently -- refuse instead
+            # (the callers pass in_slope in first-order passes only: hip_ops.double_backward() is checked at forward time)
+            if torch.is_grad_enabled() and g.requires_grad:
+                raise RuntimeError("upsample2x with a deferred activation derivative (in_slope) is first-order only")
             x, = ctx.saved_tensors
             g = g.contiguous()
             N, C = g.shape[:2]

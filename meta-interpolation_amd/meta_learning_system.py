@@ -461,7 +461,7 @@ class SceneAdaptiveInterpolation(nn.Module):
         width = int(getattr(self.args, 'task_batch', 0) or 0)
         if width <= 1 or use_second_order:
             return 0
-        if not getattr(self.net, 'lockstep_tasks', False) and not os.environ.get('SAVFI_LOCKSTEP_ALL'):
+        if not getattr(self.net, 'lockstep_tasks', False):
             # lockstep is OPT-IN per plugin (class attribute `lockstep_tasks = True`): the pass stacks the tasks' samples into
             # one [n*T, ...] batch and hands 5-D stacked weights to MetaConv2dLayer, which is only right for a plugin whose
             # samples never interact (no train-mode BatchNorm) and that reads fast weights through the meta layers only
@@ -878,6 +878,10 @@ class SceneAdaptiveInterpolation(nn.Module):
                             num_steps=self.args.number_of_evaluation_steps_per_iter, training_phase=False,
                             do_evaluation=True)
 
+    def _ws_kernels_in_use(self):
+        """Does this system's network run the wave-specialised SepConv kernels (the only kernels with bounded in-kernel waits)?"""
+        return self.args.model == 'sepconv'
+
     def meta_update(self, loss):
         """zero_grad -> backward -> (all-reduce of outer grads) -> optimizer step  (reference :551-574)."""
         self.optimizer.zero_grad()
@@ -892,6 +896,12 @@ class SceneAdaptiveInterpolation(nn.Module):
         elif loss.requires_grad:
             loss.backward()
         self.task_parallel.allreduce_gradients(params)
+        if self.device.type == 'cuda' and self._ws_kernels_in_use() and _hip.ws_armed():
+            # Fail closed: a bounded wait of the wave-specialised SepConv kernels that gave up (csrc/sepconv_ws.hip) has produced wrong
+            # gradients.  The stream is drained HERE, before theta moves -- one host wait per meta-iteration, ~0.3 % of a C2 iteration
+            # (profiles/r06_ws_check_cost.txt) -- and the exception leaves theta, the optimizer state and the scheduler untouched.
+            torch.cuda.current_stream(self.device).synchronize()
+            _hip.ws_check("this meta-iteration at epoch %d: its outer step was NOT applied" % self.current_epoch)
         self.optimizer.step()
         if self.device.type == 'cuda':      # the filters every conv layer keeps of its own weight: one launch for all of them
             if self._filter_modules is None:
@@ -916,7 +926,7 @@ class SceneAdaptiveInterpolation(nn.Module):
             self._defer_logging = False
             finish, self._pending_logging = self._pending_logging, None
         if finish is not None:
-            if self.task_parallel.active or not getattr(self.args, 'lazy_logging', 1) or os.environ.get('SAVFI_EAGER_LOGGING'):
+            if self.task_parallel.active or not getattr(self.args, 'lazy_logging', 1):
                 finish()          # the logging all-reduce is a collective: every rank issues it here, in program order
             else:
                 state = {'finish': finish}

@@ -155,7 +155,7 @@ def set_fuse_conv_act(value):
     _TLS.fuse_conv_act = bool(value)
 
 
-_FUSE_CONV_CHAIN = os.environ.get('SAVFI_NO_CONV_CHAIN') is None
+_FUSE_CONV_CHAIN = True      # A/B and tests: model_utils._FUSE_CONV_CHAIN = False switches every deferral off
 
 
 def fuse_conv_chain():
@@ -282,8 +282,8 @@ class MetaConvNorm(nn.Module):
 
 
 _META_TYPES = ()
-_NO_CA_FUSED = bool(__import__('os').environ.get('SAVFI_NO_CA_FUSED'))      # experiment knob
-_NO_REFLECT_FUSED = bool(__import__('os').environ.get('SAVFI_NO_REFLECT_FUSED'))
+_NO_CA_FUSED = False           # A/B (module attributes): True = CAIN's channel attention / mirrored borders from their unfused ops
+_NO_REFLECT_FUSED = False
 
 
 class MetaSequential(nn.Sequential):

@@ -32,8 +32,10 @@ from ..hip_ops import Upsample2x, upsample_bilinear2x_window, upsample_window_so
 from ..model_utils import MetaConv2dLayer, MetaSequential, as_view, fuse_conv_act, fuse_conv_chain, own_params_const, zero_grad_params
 from .sepconv_op.sepconv import FunctionSepconv, FunctionSepconvPair, frames8_supported
 
-TAPS_UNIT16 = os.environ.get('SAVFI_SEPCONV_TAPS_PLANAR') is None
-GRADS_UNIT16 = os.environ.get('SAVFI_SEPCONV_GRADS_PLANAR') is None
+TAPS_UNIT16 = True        # A/B (module attributes, no environment variable): False = planar taps / tap gradients
+GRADS_UNIT16 = True
+FRAME_CACHE = True        # False: pads / concatenation of the frame pair once per forward
+CROP_EXACT = False        # True: the Subnets' window without the alignment slack
 
 FILTER_TAPS = 51
 HALF = FILTER_TAPS // 2  # 25
@@ -74,7 +76,7 @@ class MetaNetwork(nn.Module):
     def __init__(self, resume=False, strModel='lf', windowed=True):
         super().__init__()
         self.windowed = bool(windowed)
-        self.batch_subnets = os.environ.get('SAVFI_SEPCONV_SUBNETS_ONE_BY_ONE') is None     # windowed tail: the four Subnets as one launch per layer
+        self.batch_subnets = True     # windowed tail: the four Subnets as one launch per layer (A/B: set False on the instance)
         self._windows = {}
         for i, (name, cin, cout) in enumerate(_ENCODER, start=1):
             setattr(self, name, _basic(cin, cout))
@@ -154,7 +156,7 @@ class MetaNetwork(nn.Module):
                 out['rim0'], out['rim1'] = F.pad(f0, rim, mode='replicate'), F.pad(f1, rim, mode='replicate')
             return out
         if (not f0.is_cuda or f0.requires_grad or f1.requires_grad or torch.cuda.is_current_stream_capturing()
-                or os.environ.get('SAVFI_SEPCONV_NO_FRAME_CACHE')):
+                or not FRAME_CACHE):
             return make()
         cache = _FRAME_TLS.__dict__.setdefault('entries', {}).setdefault(id(self), [])
         for e in cache:
@@ -182,7 +184,7 @@ class MetaNetwork(nn.Module):
             cx0, cx1 = max(0, sx[0] - 3), min(hw, sx[1] + 1 + 3)
             # a width that is a multiple of 4 where the canvas allows (233 -> 236 at 256 x 448): the convolution epilogues and the
             # element-wise kernels store 16 bytes per lane instead of four dwords; the extra columns lie beyond the halo and are never read
-            if os.environ.get('SAVFI_SEPCONV_CROP_EXACT') is None:
+            if not CROP_EXACT:
                 extra = (-(cx1 - cx0)) % 4
                 grow_r = min(extra, hw - cx1)
                 cx1 += grow_r

@@ -18,7 +18,8 @@ from ... import _hip
 # Frames of 8-bit images (include/savfi_hip.h, csrc/sepconv_ws.hip): the op classifies its frame tensor on the device at every forward
 # call and hands the words to savfi_sepconv_{fwd,bwd}_frames8_f32, which run the three-product kernels on frames that are k / 255 and the
 # six-product kernels on anything else.  SAVFI_SEPCONV_NO_FRAMES8=1: always the six-product kernels (A/B runs).
-FRAMES8 = os.environ.get('SAVFI_SEPCONV_NO_FRAMES8') is None
+FRAMES8 = True            # A/B (module attributes): False = never the 8-bit-frame kernels
+PAIR_ONE_LAUNCH = True    # False: the two local convolutions of the tail as two launches
 FRAMES8_WORDS = 256
 _E_UNSUPPORTED = -3
 
@@ -158,8 +159,6 @@ class FunctionSepconvPair(torch.autograd.Function):
         from ... import hip_ops
         hip_ops.require_layout(taps, hip_ops.UNIT16 if taps_unit16 else None, "FunctionSepconvPair(taps_unit16=%s): taps" % bool(taps_unit16))
         _hip.require_cuda(input0, input1, taps)
-        out0 = torch.empty((B, C, Ho, Wo), dtype=input0.dtype, device=input0.device)
-        out1 = torch.empty_like(out0)
         lib, st = _hip.lib(), _hip.current_stream()
         plane = K * Ho * Wo * 4
         words = [frames8_classify(inp) for inp in (input0, input1)] if frames8_supported(input0, B, C, Ho, Wo, K, 4 * K) else None
@@ -167,7 +166,9 @@ class FunctionSepconvPair(torch.autograd.Function):
         assert not u16 or (words is not None and Wo % 16 == 0), "unit-major taps: the frames8 entry points, widths that are a multiple of 16"
         assert not grads_unit16 or u16, "unit-major gradients go with unit-major taps"
         ctx.taps_unit16 = u16 | (2 if grads_unit16 else 0)
-        if words is not None and not os.environ.get('SAVFI_SEPCONV_PAIR_TWO_LAUNCHES'):
+        # the pair launch holds 2 B virtual samples: its own limit (a very large B on tiny frames falls back to two launches)
+        ctx.pair = bool(words is not None and PAIR_ONE_LAUNCH and frames8_supported(input0, 2 * B, C, Ho, Wo, K, 2 * K))      # (virtual sample 2 b + f: taps 2 K planes apart)
+        if ctx.pair:
             # ONE launch for both local convolutions (2 B virtual samples; see backward): out2[b, f] = the convolution of frame f
             out2 = torch.empty((B, 2, C, Ho, Wo), dtype=input0.dtype, device=input0.device)
             _hip.launch("sepconv_fwd", lambda: _hip.check(lib.savfi_sepconv_fwd_pair_frames8_f32(
@@ -175,6 +176,8 @@ class FunctionSepconvPair(torch.autograd.Function):
                 B, C, Ho, Wo, K, u16, st), "savfi_sepconv_fwd_pair_frames8_f32"), nbytes=2 * algorithmic_bytes(B, C, Ho, Wo, K))
             ctx.save_for_backward(input0, input1, taps, *words)
             return out2[:, 0].add(out2[:, 1])
+        out0 = torch.empty((B, C, Ho, Wo), dtype=input0.dtype, device=input0.device)
+        out1 = torch.empty_like(out0)
         for i, (inp, out, s) in enumerate(((input0, out0, 0), (input1, out1, 2))):
             if words is not None:
                 _hip.launch("sepconv_fwd", lambda inp=inp, out=out, s=s, i=i: _hip.check(lib.savfi_sepconv_fwd_frames8_f32(
@@ -202,7 +205,7 @@ class FunctionSepconvPair(torch.autograd.Function):
         gT = torch.empty_like(taps)
         lib, st = _hip.lib(), _hip.current_stream()
         plane = K * Ho * Wo * 4
-        if words is not None and not os.environ.get('SAVFI_SEPCONV_PAIR_TWO_LAUNCHES'):
+        if ctx.pair:
             # ONE launch for both local convolutions (2 B virtual samples): a launch of these kernels has a fixed cost of ~24 us
             _hip.launch("sepconv_bwd", lambda: _hip.check(lib.savfi_sepconv_bwd_pair_frames8_f32(
                 input0.data_ptr(), input1.data_ptr(), taps.data_ptr(), gradOutput.data_ptr(), gT.data_ptr(), words[0].data_ptr(),

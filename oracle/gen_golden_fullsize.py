@@ -14,6 +14,10 @@ shims as gen_golden.py, no reference file modified -- at the sizes BASELINE.json
                                  1234+t) -- what the product adapts in lockstep (T=4) / from graphs on task streams
     c4_sepconv_msl_256x448_s5    one GPU's share of config C4: 4 tasks, MAML++ multi-step loss (a weighted target pass after
                                  every inner step) + learnable per-layer per-step learning rates
+    c2script_sepconv_256x448_b3_s3   the configuration the reference's own scripts/run_sepconv.sh:6-17 trains: Adamax + Meta-SGD (element-wise
+                                 learnable learning rates, inner_loop_optimizers.py:385-425), 3 inner steps, meta-batch 3, inner_lr 1e-5
+    c4b32_sepconv_msl_256x448_s5 config C4 at its stated meta-batch: run_train_iter over 32 tasks (meta_learning_system.py:338,366); stored:
+                                 the 32-task mean loss / PSNR / SSIM, the frames of tasks 0 and 31, outer-gradient fingerprints
     c5_cain_l2f_720p             CAIN + L2F attenuation, 1 inner step, 1280x720, run_train_iter   (config C5)
     c5eval_cain_l2f_720p         the reference's ExperimentBuilder.evaluation_iteration (experiment_builder.py:93-148) on the
                                  same clip: 720x1280 > 5e5 pixels, so two 720x640 halves are adapted separately and stitched
@@ -52,6 +56,15 @@ CASES = {
                                                              use_multi_step_loss_optimization=True,
                                                              multi_step_loss_num_epochs=10,
                                                              learnable_per_layer_per_step_inner_loop_learning_rate=True)),
+    'c2script_sepconv_256x448_b3_s3': ('sepconv', 256, 448, dict(optimizer='Adamax', inner_lr=1e-5, metasgd=True, loss='1*L1',
+                                                                 number_of_training_steps_per_iter=3,
+                                                                 number_of_evaluation_steps_per_iter=3)),
+    'c4b32_sepconv_msl_256x448_s5': ('sepconv', 256, 448, dict(optimizer='SGD', inner_lr=1e-3, loss='1*L1',
+                                                                number_of_training_steps_per_iter=5,
+                                                                number_of_evaluation_steps_per_iter=5,
+                                                                use_multi_step_loss_optimization=True,
+                                                                multi_step_loss_num_epochs=10,
+                                                                learnable_per_layer_per_step_inner_loop_learning_rate=True)),
     'c3_voxelflow_256x256_s5': ('voxelflow', 256, 256, dict(optimizer='Adamax', inner_lr=1e-5, metasgd=True, loss='1*MSE',
                                                              number_of_training_steps_per_iter=5,
                                                              number_of_evaluation_steps_per_iter=5)),
@@ -66,9 +79,12 @@ CASES = {
     'c5_cain_l2f_720p': ('cain', 720, 1280, dict(optimizer='SGD', inner_lr=1e-3, attenuate=True, loss='1*L1')),
     'c5eval_cain_l2f_720p': ('cain', 720, 1280, dict(optimizer='SGD', inner_lr=1e-3, attenuate=True, loss='1*L1')),
 }
-TASKS = {'c2b4_sepconv_256x448_s5': 4, 'c4_sepconv_msl_256x448_s5': 4, 'c3s_voxelflow_256x256_b8_s5': 8}
+TASKS = {'c2b4_sepconv_256x448_s5': 4, 'c4_sepconv_msl_256x448_s5': 4, 'c3s_voxelflow_256x256_b8_s5': 8, 'c2script_sepconv_256x448_b3_s3': 3,
+         'c4b32_sepconv_msl_256x448_s5': 32}
+KEEP_TASKS = {'c4b32_sepconv_msl_256x448_s5': (0, 31)}     # which tasks' predicted frames a fixture stores (default: all)
 RECIPE = {'c3s_voxelflow_256x256_b8_s5': 'smooth'}      # seeded-weights recipe (synthetic.py); stored in the fixture's args as weight_recipe      # meta-batch size (default 1)
-SPREAD_FOR = {'c3_voxelflow_256x256_s5', 'c3sgd_voxelflow_256x256_s5', 'c2_sepconv_256x448_s5', 'c3s_voxelflow_256x256_b8_s5'}
+SPREAD_FOR = {'c3_voxelflow_256x256_s5', 'c3sgd_voxelflow_256x256_s5', 'c2_sepconv_256x448_s5', 'c3s_voxelflow_256x256_b8_s5',
+              'c2script_sepconv_256x448_b3_s3'}
 Q_LO, Q_HI = -0.25, 1.25
 
 
@@ -77,8 +93,11 @@ def pack_pred(pred, compact=False):
     p = pred.detach().float()
     if p.shape[-2] * p.shape[-1] <= 256 * 448 and not compact:
         return {'pred': p.numpy()}
-    q = ((p[:, ::2, ::2].clamp(Q_LO, Q_HI) - Q_LO) / (Q_HI - Q_LO) * 65535.0).round().numpy().astype(np.uint16)
-    return {'pred_u16_stride2': q, 'pred_q_range': np.array([Q_LO, Q_HI])}
+    # (seeded weights: a frame may leave [-0.25, 1.25] -- the range widens to hold it, the resolution (range / 65535) with it; the
+    # tests add half a step to their gate)
+    lo, hi = min(Q_LO, float(p.min())), max(Q_HI, float(p.max()))
+    q = ((p[:, ::2, ::2] - lo) / (hi - lo) * 65535.0).round().numpy().astype(np.uint16)
+    return {'pred_u16_stride2': q, 'pred_q_range': np.array([lo, hi])}
 
 
 def seed_attenuator(system):
@@ -142,6 +161,8 @@ def gen_train_case(name):
         out['train_part_' + k] = np.float64(v)
     out.update({'train_' + k: v for k, v in pack_pred(torch.from_numpy(base['preds'][0])).items()})
     for t in range(1, TASKS.get(name, 1)):       # further tasks of the meta-batch: the compact form (keeps the fixture small)
+        if name in KEEP_TASKS and t not in KEEP_TASKS[name]:
+            continue
         out.update({'train_task%d_%s' % (t, k): v for k, v in pack_pred(torch.from_numpy(base['preds'][t]), compact=True).items()})
     G.pack_fp('train_grad_fp', base['rec']['grad_fp'], out)
     G.pack_fp('train_weight_fp', base['rec']['weight_fp'], out)
@@ -194,7 +215,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--only', nargs='*', default=None)
     opts = ap.parse_args()
-    torch.set_num_threads(8)
+    torch.set_num_threads(int(os.environ.get('ORACLE_THREADS', 8)))
     G.install_shims()
     for name in (opts.only or list(CASES)):
         print('[golden full-size]', name, flush=True)

@@ -325,10 +325,35 @@ def test_3x3_weight_gradient_routing_rules(monkeypatch):
     assert not pref(3, 512, 512, 24, 32) and not pref(3, 512, 512, 12, 16)              # deep small maps: Winograd form
     assert pref(3, 32, 32, 384, 512) and not pref(3, 32, 32, 96, 128)                   # wide shallow layers on the tap-split kernel
     assert pref(3, 512, 512, 12, 16, direct=True)                                       # a plugin that asks for the direct form gets it
-    monkeypatch.setenv('SAVFI_WGRAD3_NO_RING', '1')
+    monkeypatch.setattr(hip_ops, 'CONVK_WGRAD3_RING', False)      # the A/B switch is a module attribute (no environment variable is read)
     assert not pref(3, 128, 128, 96, 128) and pref(3, 192, 192, 96, 160)
-    monkeypatch.delenv('SAVFI_WGRAD3_NO_RING')
+    monkeypatch.setattr(hip_ops, 'CONVK_WGRAD3_RING', True)
     lib = _hip.lib()
     assert lib.savfi_convk_wgrad_sums_bias(8, 4, 128, 128, 96, 128, 3, 1) == 1
     assert lib.savfi_convk_wgrad_sums_bias(8, 4, 32, 32, 384, 512, 3, 1) == 0 and lib.savfi_convk_wgrad_sums_bias(2, 1, 64, 128, 128, 128, 5, 2) == 0
     assert lib.savfi_convk_wgrad_workspace_floats(8, 4, 128, 128, 96, 128, 3, 1) >= 4 * 128 * (128 * 9 + 1)
+
+
+def test_the_shipped_product_reads_no_experiment_switches():
+    """A/B switches are variant builds (tools/build_variant.sh: compile-time macros) or module attributes a tool sets -- not environment
+    variables of the shipped product: no getenv in csrc/, and the package reads only these documented SAVFI_* variables."""
+    import re
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "meta-interpolation_amd")
+    allowed = {"SAVFI_HIP_LIB", "SAVFI_DIST_BACKEND", "SAVFI_PIN_DEVICE", "SAVFI_BUILD_CACHE"}
+    strays = []
+    for dirpath, _, files in os.walk(pkg):
+        if '__pycache__' in dirpath or os.path.basename(dirpath) == 'lib':
+            continue
+        for f in files:
+            path = os.path.join(dirpath, f)
+            if f.endswith(('.hip', '.h')):
+                for i, line in enumerate(open(path), 1):
+                    if 'getenv' in line and not line.lstrip().startswith('//'):
+                        strays.append('%s:%d getenv' % (path, i))
+            elif f.endswith('.py'):
+                for i, line in enumerate(open(path), 1):
+                    if 'environ' in line:
+                        for name in re.findall(r"SAVFI_[A-Z0-9_]+", line):
+                            if name not in allowed:
+                                strays.append('%s:%d %s' % (path, i, name))
+    assert not strays, strays

@@ -293,10 +293,11 @@ def test_unit_major_convolution_entry_points_refuse_what_they_cannot_do():
     # a layer beyond the F(4x4) kernel's 256 channels on a small map: the F(2x2) kernel splits its reduction over workgroups -> refused
     C2 = 320
     u2 = hip_ops.conv3x3_filters(torch.randn(T, C2, C2, 3, 3, device=DEV), True, True)
-    x2, out2 = torch.randn(4, C2, 38, 66, device=DEV), torch.empty(4, C2, 36, 64, device=DEV)
-    assert lib.savfi_conv3x3_f4_workgroups(4, C2, C2, 38, 66, 0, 0) == 0 and lib.savfi_conv3x3_f4_workgroups(4, C, C, 38, 66, 0, 0) == 4 * 5 * 2
-    assert lib.savfi_conv3x3_unit16_supported(4, T, C2, C2, 38, 66, 0) == 0
-    assert lib.savfi_conv3x3_tasks_pre_unit16_f32(P(x2), P(u2[0]), None, P(out2), 4, T, C2, C2, 38, 66, 0, 1.0, st) == -3
+    x2, out2 = torch.randn(4, C2, 14, 18, device=DEV), torch.empty(4, C2, 12, 16, device=DEV)       # 40 workgroups: split
+    assert lib.savfi_conv3x3_f4_workgroups(4, C2, C2, 14, 18, 0, 0) == 0 and lib.savfi_conv3x3_f4_workgroups(4, C, C, 38, 66, 0, 0) == 4 * 5 * 2
+    assert lib.savfi_conv3x3_tasks_pre_workspace_floats(4, T, C2, C2, 14, 18, 0, 0) > 0
+    assert lib.savfi_conv3x3_unit16_supported(4, T, C2, C2, 14, 18, 0) == 0
+    assert lib.savfi_conv3x3_tasks_pre_unit16_f32(P(x2), P(u2[0]), None, P(out2), 4, T, C2, C2, 14, 18, 0, 1.0, st) == -3
     assert lib.savfi_conv3x3_tasks_pre_unit16_f32(P(x), P(u[0]), None, P(out), 4, T, C, C, 38, 66, 0, 1.0, st) == 0         # F(4x4): no split
     assert lib.savfi_conv3x3_unit16_supported(N, T, C, C, H, W - 2, 0) == 0 and lib.savfi_conv3x3_unit16_supported(N, 3, C, C, H, W, 0) == 0
     gy = torch.randn(N, C, H - 2, W - 2, device=DEV)

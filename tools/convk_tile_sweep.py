@@ -29,7 +29,7 @@ def child():
         fl = 2.0 * 9 * ci * co * H * W * N
         tf = timeit(lambda: hip_ops.convk_tasks_pre(x, pf, T, ci, co, 3, None, 0, 0.0, 1))
         tb = timeit(lambda: hip_ops.convk_tasks_pre(gy, pb, T, ci, co, 3, None, 1, 1.0, 1))
-        print(json.dumps({"tile": os.environ.get("SAVFI_CONVK_TILE", "heuristic"), "layer": "%d->%d @%dx%d T=%d N=%d" % (ci, co, H, W, T, N),
+        print(json.dumps({"tile": os.path.basename(os.environ.get("SAVFI_HIP_LIB", "heuristic")), "layer": "%d->%d @%dx%d T=%d N=%d" % (ci, co, H, W, T, N),
                           "fwd_us": round(tf, 1), "fwd_TF": round(fl / tf / 1e6), "dgrad_us": round(tb, 1), "dgrad_TF": round(fl / tb / 1e6)}), flush=True)
 
 
@@ -40,6 +40,7 @@ if __name__ == "__main__":
         for tile in (None, "4,1", "4,2", "2,1", "2,2"):
             env = dict(os.environ)
             if tile:
-                env["SAVFI_CONVK_TILE"] = tile
+                # a variant per tile: tools/build_variant.sh tile_N_C convk.hip -DSAVFI_CONVK_TILE_NT=N -DSAVFI_CONVK_TILE_CG=C
+                env["SAVFI_HIP_LIB"] = os.path.join(os.path.dirname(os.path.abspath(__file__)), "variants", "libsavfi_tile_%s.so" % tile.replace(",", "_"))
             out = subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=env, capture_output=True, text=True).stdout
             print("".join(l + "\n" for l in out.splitlines() if l.startswith("{")), end="", flush=True)

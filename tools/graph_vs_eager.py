@@ -18,10 +18,11 @@ ap.add_argument('--no-step', action='store_true', help='skip the outer optimizer
 ap.add_argument('--perturb', type=float, default=0.0, help='relative perturbation of the SECOND run\'s frames (sensitivity control)')
 ap.add_argument('--modes', default='0,1', help="graph_inner_loop of the two runs compared ('0,0': the eager loop against itself)")
 opt = ap.parse_args()
-if opt.l2f:
-    os.environ['SAVFI_GRAPH_L2F'] = '1'
 import torch
 from meta_interpolation_amd import synthetic
+if opt.l2f:
+    from meta_interpolation_amd import graph_inner_loop
+    graph_inner_loop.GRAPH_L2F = True
 from meta_interpolation_amd.config import default_args
 from meta_interpolation_amd.meta_learning_system import MODEL_REGISTRY, SceneAdaptiveInterpolation
 runs = {}

@@ -15,10 +15,11 @@ ap.add_argument('--steps', type=int, default=2)
 ap.add_argument('--batch', type=int, default=1)
 ap.add_argument('--msl', type=int, default=1)
 opt = ap.parse_args()
-if opt.l2f:
-    os.environ['SAVFI_GRAPH_L2F'] = '1'
 import torch
 from meta_interpolation_amd import synthetic
+if opt.l2f:
+    from meta_interpolation_amd import graph_inner_loop
+    graph_inner_loop.GRAPH_L2F = True
 from meta_interpolation_amd.config import default_args
 from meta_interpolation_amd.meta_learning_system import MODEL_REGISTRY, SceneAdaptiveInterpolation
 H, W = (int(v) for v in opt.size.split('x'))

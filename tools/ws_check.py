@@ -1,5 +1,5 @@
 """The wave-specialised SepConv filter-gradient kernel (csrc/sepconv_ws.hip) against the one-program-per-wave kernel
-(csrc/sepconv_x6.hip: SAVFI_SEPCONV_NO_WS=1, a second process) on the same seeded inputs, its protocol time-out counter, and
+(csrc/sepconv_x6.hip: a variant library built with tools/build_variant.sh nows sepconv.hip -DSAVFI_SEPCONV_NO_WS, a second process) on the same seeded inputs, its protocol time-out counter, and
 HIP-event timings of both at the bench shape.
 
     python tools/ws_check.py [--shapes 2x256x448,1x64x96,3x100x128] [--time-batch 8]
@@ -96,7 +96,7 @@ def main():
             print(json.dumps(dict(kernel='x6 fwd', B=o.time_batch, us=run_fwd(o.time_batch, 256, 448, iters=o.iters)[1])), flush=True)
         return
     tmp = tempfile.mkdtemp(prefix='ws_check_')
-    env = dict(os.environ, SAVFI_SEPCONV_NO_WS='1')
+    env = dict(os.environ, SAVFI_HIP_LIB=os.path.join(os.path.dirname(os.path.abspath(__file__)), 'variants', 'libsavfi_nows.so'))
     child = subprocess.run([sys.executable, os.path.abspath(__file__), '--shapes', o.shapes, '--dump', tmp,
                             '--time-batch', str(o.time_batch), '--iters', str(o.iters)], env=env, capture_output=True, text=True)
     print(child.stdout.strip(), flush=True)

@@ -21,5 +21,5 @@ for _ in range(40):
 torch.cuda.synchronize()
 t = sorted(1e3 * a.elapsed_time(b) for a, b in evs)
 nbytes = 4 * B * (3 * 306 * 498 + 4 * 51 * 256 * 448 + 3 * 256 * 448)
-print(json.dumps(dict(lib=os.path.basename(os.environ.get("SAVFI_HIP_LIB", "default")), no_ws=os.environ.get("SAVFI_SEPCONV_NO_WS"), B=B, mean_us=round(sum(t) / len(t), 1), min_us=round(t[0], 1), median_us=round(t[len(t) // 2], 1),
+print(json.dumps(dict(lib=os.path.basename(os.environ.get("SAVFI_HIP_LIB", "default")), B=B, mean_us=round(sum(t) / len(t), 1), min_us=round(t[0], 1), median_us=round(t[len(t) // 2], 1),
                       hbm_frac_median=round(nbytes / t[len(t) // 2] / 1e6 / 8.0, 4), errors=lib.savfi_sepconv_ws_errors())), flush=True)
