@@ -169,6 +169,36 @@ def parity_check(system, theta0, frames, model, H, W, S, oracle_res, dev, mode, 
                       "seeded theta, task 0 vs the CPU oracle of cpu_baseline, %d inner steps, %dx%d" % (how, mode, len(frames[0]), S, H, W)})
 
 
+def c4_parity_check(c4sys, theta0, c4frames, fix, dev, world):
+    """The timed 32-task system (its mode, its switches) against the REFERENCE's own run_train_iter over the 32 tasks
+    (tests/golden/full_c4b32_*.npz, oracle/gen_golden_fullsize.py): theta back to the seeded weights, outer step disabled, one more
+    meta-iteration with evaluation; the 32-task mean loss / PSNR and the frames of tasks 0 and 31 (single process: every task is local)."""
+    import numpy as np
+    c4sys.load_state_dict(theta0)
+    real_step = c4sys.optimizer.step
+    c4sys.optimizer.step = lambda *a, **k: None
+    try:
+        losses, preds, metrics = c4sys.run_train_iter(data_batch=c4frames, epoch=0, do_evaluation=True)
+        torch.cuda.synchronize()
+    finally:
+        c4sys.optimizer.step = real_step
+    want = float(fix['train_loss'])
+    out = {"loss_rel": abs(float(losses['loss']) - want) / abs(want), "dpsnr_db": abs(float(metrics['psnr'].avg) - float(fix['train_psnr']))}
+    l1 = {}
+    if world == 1:
+        l1["task0"] = float(np.abs(preds[0].squeeze(0).cpu().numpy() - fix['train_pred']).mean())
+        lo, hi = fix['train_task31_pred_q_range']
+        ref = fix['train_task31_pred_u16_stride2'].astype(np.float64) / 65535.0 * (hi - lo) + lo
+        l1["task31"] = float(np.abs(preds[31].squeeze(0).cpu().numpy()[:, ::2, ::2] - ref).mean())
+        out["pixel_l1"] = l1
+        out["pixel_l1_quantisation"] = {"task0": 0.0, "task31": 0.5 * float(hi - lo) / 65535.0}
+    ok = out["loss_rel"] <= 1e-5 and out["dpsnr_db"] <= 1e-3 and all(v <= 1e-4 + out["pixel_l1_quantisation"][k] for k, v in l1.items())
+    out.update({"ok": bool(ok), "bounds": {"loss_rel": 1e-5, "pixel_l1": 1e-4, "dpsnr_db": 1e-3},
+                "sample": "the timed 32-task system in the timed mode against the imported reference's run_train_iter over the same 32 tasks "
+                          "(fixture full_c4b32_sepconv_msl_256x448_s5): 32-task mean loss and PSNR%s" % (", frames of tasks 0 and 31" if world == 1 else "")})
+    return out
+
+
 def _from_unit_range(system, img01):
     """Inverse of SceneAdaptiveInterpolation._to_unit_range (predictions are returned in 0..1; the loss lives in the plugin's range)."""
     if system.args.model == 'voxelflow':
@@ -491,6 +521,16 @@ def main():
     # so that outer-gradient throughput at N GPUs can be set against 1 GPU on the same total work (north star: >= 6x at 8)
     if model == 'sepconv' and not toy and not opt.no_strong_c4 and not opt.global_batch and 32 % world == 0 and opt.workload.startswith('c2_'):
         c4_model, c4H, c4W, _, c4S, c4over = WORKLOADS['c4_sepconv_msl_256x448_b4_s5']
+        # the configuration of the reference-generated 32-task fixture (tests/golden/full_c4b32_*.npz: MAML++ multi-step loss AND learnable
+        # per-layer per-step learning rates, inner_lr 1e-3), so that the timed system is the one `parity_check` holds to the reference
+        c4fix = None
+        try:
+            from tests.helpers import golden, parse_case_args
+            c4fix = golden("full_c4b32_sepconv_msl_256x448_s5")
+            c4over = {k: v for k, v in parse_case_args(c4fix).items()
+                      if k not in ('model', 'batch_size', 'number_of_training_steps_per_iter', 'number_of_evaluation_steps_per_iter')}
+        except Exception:
+            c4fix = None
         c4_tasks = 32 // world
         c4args = default_args(model=c4_model, num_gpu=1, batch_size=32, number_of_training_steps_per_iter=c4S,
                               number_of_evaluation_steps_per_iter=c4S, **switches, **c4over)
@@ -498,6 +538,7 @@ def main():
             c4net = MODEL_REGISTRY[c4_model](c4args, False)
             synthetic.load_seeded_weights(c4net, c4_model)
             c4sys = SceneAdaptiveInterpolation(c4args, net=c4net.to(dev))
+        c4theta0 = {k: v.detach().clone() for k, v in c4sys.state_dict().items()}     # (weights AND the learnable inner-loop learning rates)
         c4frames = [f.to(dev) for f in synthetic.septuplet_batch(32, c4H, c4W, model=c4_model)]
         c4steps = max(2, min(opt.steps, 3))
         c4sys.run_train_iter(data_batch=c4frames, epoch=0, do_evaluation=False)          # warm-up (allocator, MIOpen find)
@@ -522,6 +563,11 @@ def main():
                              "ms_per_meta_iteration": 1e3 * c4el / c4steps, "outer_tasks_per_sec": 32 * c4steps / c4el,
                              "inner_steps_per_sec": 32 * c4S * c4steps / c4el, "allreduce": c4tp.allreduce_stats(),
                              "replicas_bit_identical": c4tp.replicas_identical([p for p in c4sys.parameters()]) if c4tp.active else None}
+        if c4fix is not None and rank == 0:
+            try:
+                line["strong_c4"]["parity_check"] = c4_parity_check(c4sys, c4theta0, c4frames, c4fix, dev, world)
+            except Exception as e:       # never lose the measurement over the checker
+                line["strong_c4"]["parity_check"] = {"ok": False, "error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         del c4sys, c4net, c4frames
         torch.cuda.empty_cache()
     if rank == 0:

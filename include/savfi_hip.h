@@ -350,11 +350,11 @@ int savfi_conv3x3_tasks_f32(const float* x, const float* w, const float* bias, f
  *                                  savfi_conv3x3_tasks_pre_workspace_floats(...) floats (partial outputs of split
  *                                  launches; 0 for most shapes, then it may be NULL) */
 int64_t savfi_conv3x3_filter_floats(int T, int Ci, int Co, int mode);
-/* Layers of at most 256 -> 256 channels run on Winograd F(4x4, 3x3) (csrc/winograd4.h: 36 points per 4 x 4 outputs, a quarter of the
+/* Layers of at most 512 -> 512 channels run on Winograd F(4x4, 3x3) (csrc/winograd4.h: 36 points per 4 x 4 outputs, a quarter of the
  * direct multiplies; fp32 rounding 3e-7 rms / <= 1e-5 max of the result's scale), deeper ones on F(2x2, 3x3).  The form follows the
  * channel counts alone, so a transformed filter is valid for every map size.  savfi_conv3x3_f4_workgroups: the workgroups the F(4x4)
- * kernel would launch for this call (32 tiles of 4 x 4 pixels x 32 produced channels each), 0 for an F(2x2) layer -- F(4x4) does not
- * split its reduction, a caller with another kernel for small maps routes by this count. */
+ * kernel would launch for this call (32 tiles of 4 x 4 pixels x 32 produced channels each, x the reduction split of a deep layer on a
+ * small map), 0 for an F(2x2) layer -- a caller with another kernel for launches that cannot fill the chip routes by this count. */
 int64_t savfi_conv3x3_f4_workgroups(int N, int Ci, int Co, int H, int W, int pad, int mode);
 int savfi_conv3x3_filters_f32(const float* w, float* u_fwd, float* u_bwd, int T, int Ci, int Co, void* stream);
 /* n layers in one launch per 56 (layer, mode) jobs; entry i is savfi_conv3x3_filters_f32(w[i], u_fwd[i], u_bwd[i], T[i], Ci[i], Co[i]). */

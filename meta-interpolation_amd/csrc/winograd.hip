@@ -48,7 +48,7 @@ __device__ void savfi_raw_buffer_store_x4(f32x4 data, i32x4 rsrc, int voffset, i
 
 namespace {
 
-#include "winograd4.h"      // Winograd F(4x4, 3x3) for the layers of at most 64 -> 64 channels (namespace w4)
+#include "winograd4.h"      // Winograd F(4x4, 3x3) for the layers of at most 512 -> 512 channels (namespace w4)
 
 constexpr int WNT = 256;            // threads
 // 64 tiles per workgroup, one per lane, as a 2^(6-s) x 2^s block of tiles (s = WinoArgs::tile_shift, picked per launch):
@@ -643,6 +643,10 @@ int round_up(int v, int m) { return (v + m - 1) / m * m; }
 // Launch plan shared by the workspace query and the launch.  Deep layers have few tiles and many reduction channels
 // (256->256 at 48x64: 192 workgroups x 64 chunks on 512 slots): the chunks are split over up to 8 workgroups whose
 // raw partial outputs are added by wino_split_reduce.
+#ifndef SAVFI_WINO_SPLIT_SLOTS
+#define SAVFI_WINO_SPLIT_SLOTS 512      // variant builds: 0 = never split
+#endif
+
 struct WinoPlan {
   int K, I, KP, IP, off, Ho, Wo, th, tw, tile_shift, nsplit, chunks_per_split;
   int64_t u_floats, partial_floats;
@@ -675,10 +679,21 @@ bool make_plan(WinoPlan& p, int N, int Ci, int Co, int H, int W, int pad, int mo
     }
     p.th = savfi_cdiv(ty4, w4::TT >> p.tile_shift);
     p.tw = savfi_cdiv(tx4, 1 << p.tile_shift);
-    p.nsplit = 1;
-    p.chunks_per_split = p.KP / w4::KC;
+    // deep layers on small maps: the reduction chunks split over workgroups where the launch would leave most of the 512 workgroup slots
+    // empty (at least 4 chunks = 32 channels per workgroup); raw partial outputs, summed by wino_split_reduce
+    const int nchunk4 = p.KP / w4::KC;
+    const int64_t wgs4 = (int64_t)p.th * p.tw * (p.IP / w4::COB) * N;
+    // (measured, tools/r6/wino4_time.py small: 256 -> 256 @24x32 T = 4 x 2: 128 workgroups -> 4 x 128: 63 -> 46 us; 512 -> 512 @24x32: 256 -> 2 x 256:
+    // 138 us against the direct kernel's 164; 128 -> 128 @48x64, 192 workgroups of 16 chunks: 37 us unsplit, 47 split in two -- a split needs a
+    // long reduction to pay for its second pass: from 256 channels, launches of at most 256 workgroups)
+    int want4 = (int)(SAVFI_WINO_SPLIT_SLOTS / (wgs4 > 0 ? wgs4 : 1));
+    want4 = (want4 < 2 || nchunk4 < 32) ? 1 : (want4 > 8 ? 8 : want4);
+    int cps4 = savfi_cdiv(nchunk4, want4);
+    if (cps4 < 8) cps4 = nchunk4 < 8 ? nchunk4 : 8;
+    p.chunks_per_split = cps4;
+    p.nsplit = savfi_cdiv(nchunk4, cps4);
     p.u_floats = u_floats_for(p.K, p.I);
-    p.partial_floats = 0;
+    p.partial_floats = p.nsplit > 1 ? (int64_t)p.nsplit * N * p.I * p.Ho * p.Wo : 0;
     return true;
   }
   // tile block shape: the one that covers the tile map with the fewest blocks (ties: the widest rows, 4 x 16 first)
@@ -694,9 +709,6 @@ bool make_plan(WinoPlan& p, int N, int Ci, int Co, int H, int W, int pad, int mo
   const int64_t wgs = (int64_t)p.th * p.tw * (p.IP / COB) * N;
   // split only launches that would leave workgroup slots empty (2 per CU x 256 CUs): the partial outputs cost an
   // extra pass, which loses on launches that already fill the chip (64->64 at 192x256: 64 -> 87 us when split)
-#ifndef SAVFI_WINO_SPLIT_SLOTS
-#define SAVFI_WINO_SPLIT_SLOTS 512      // variant builds: 0 = never split
-#endif
   constexpr int slots = SAVFI_WINO_SPLIT_SLOTS;
   int want = (int)(slots / wgs);
   want = want < 1 ? 1 : (want > 8 ? 8 : want);
@@ -745,7 +757,7 @@ extern "C" int64_t savfi_conv3x3_f4_workgroups(int N, int Ci, int Co, int H, int
   if ((mode != 0 && mode != 1) || (pad != 0 && pad != 1)) return SAVFI_E_UNSUPPORTED;
   WinoPlan p;
   if (!make_plan(p, N, Ci, Co, H, W, pad, mode)) return SAVFI_E_SHAPE;
-  return p.f4 ? (int64_t)p.th * p.tw * (p.IP / w4::COB) * N : 0;
+  return p.f4 ? (int64_t)p.th * p.tw * (p.IP / w4::COB) * p.nsplit * N : 0;
 }
 
 extern "C" int64_t savfi_conv3x3_workspace_floats(int N, int Ci, int Co, int H, int W, int pad, int mode) {
@@ -759,13 +771,14 @@ int launch_conv(const WinoPlan& p, const float* x, const float* U, const float* 
                 int H, int W, int mode, float slope, hipStream_t st, const float* mask = nullptr, float mask_slope = 1.f,
                 int out_unit16 = 0, int in_unit16 = 0) {
   if (p.f4) {
-    const int64_t wgs4 = (int64_t)p.th * p.tw * (p.IP / w4::COB) * N;
+    const int64_t wgs4 = (int64_t)p.th * p.tw * (p.IP / w4::COB) * p.nsplit * N;
     if (wgs4 > 0x7fffffffLL || T > 65535) return SAVFI_E_TOOBIG;
     if (mask && (out_unit16 || in_unit16)) return SAVFI_E_UNSUPPORTED;
+    if (p.nsplit > 1 && (out_unit16 || in_unit16 || !partial)) return SAVFI_E_UNSUPPORTED;
     if (in_unit16 && ((p.off != 1 && p.off != 2) || p.Wo % 2 != 0)) return SAVFI_E_UNSUPPORTED;
     constexpr size_t lds4 = (size_t)w4::LDS_FLOATS * sizeof(float);      // 72 KB: two workgroups per CU
     w4::W4Args a4{x, U, mode == 0 ? bias : nullptr, out, p.K, p.I, p.KP, p.IP, H, W, p.Ho, p.Wo, p.off, p.th, p.tw, slope,
-                  p.tile_shift, T, N, mask, mask_slope, out_unit16};
+                  p.tile_shift, T, N, p.nsplit > 1 ? nullptr : mask, mask_slope, out_unit16, p.nsplit, p.chunks_per_split, partial};
     const int vecw = p.Wo % 4 == 0 ? 4 : (p.Wo % 2 == 0 ? 2 : 1);
     auto go = [&](auto kern) -> int {
       static uint32_t configured = 0;
@@ -775,6 +788,14 @@ int launch_conv(const WinoPlan& p, const float* x, const float* U, const float* 
     };
     if (in_unit16 && p.off == 1) return vecw == 4 ? go(w4::wino4_conv3x3<4, 2, false>) : go(w4::wino4_conv3x3<2, 2, false>);
     if (in_unit16) return vecw == 4 ? go(w4::wino4_conv3x3<4, 3, false>) : go(w4::wino4_conv3x3<2, 3, false>);
+    if (p.nsplit > 1) {
+      const int rc = vecw == 4 ? go(w4::wino4_conv3x3<4, 0, false>) : vecw == 2 ? go(w4::wino4_conv3x3<2, 0, false>) : go(w4::wino4_conv3x3<1, 0, false>);
+      if (rc != SAVFI_OK) return rc;
+      const size_t total = (size_t)N * p.I * p.Ho * p.Wo;
+      hipLaunchKernelGGL(wino_split_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, partial, mode == 0 ? bias : nullptr, out,
+                         p.nsplit, total, p.I, p.Ho * p.Wo, slope, T, mask, mask_slope);
+      return savfi_launch_status();
+    }
     if (mask) return vecw == 4 ? go(w4::wino4_conv3x3<4, 0, true>) : vecw == 2 ? go(w4::wino4_conv3x3<2, 0, true>) : go(w4::wino4_conv3x3<1, 0, true>);
     return vecw == 4 ? go(w4::wino4_conv3x3<4, 0, false>) : vecw == 2 ? go(w4::wino4_conv3x3<2, 0, false>) : go(w4::wino4_conv3x3<1, 0, false>);
   }

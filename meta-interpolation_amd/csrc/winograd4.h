@@ -1,4 +1,4 @@
-// Winograd F(4x4, 3x3) for the 3x3 / stride 1 layers of at most 256 -> 256 channels (included by winograd.hip only: the
+// Winograd F(4x4, 3x3) for the 3x3 / stride 1 layers of at most 512 -> 512 channels (included by winograd.hip only: the
 // multi-layer filter transform launches both forms from one kernel).
 //
 // Why.  The F(2x2, 3x3) kernel above multiplies 16 Winograd points per 4 outputs (2.25x fewer multiplies than the direct sum);
@@ -16,12 +16,20 @@
 // Workgroup = 4 waves, two per CU (73.7 KB LDS, <= 256 registers): 32 tiles (a 2^(5-s) x 2^s block = 512 output pixels) x 32
 // produced channels; wave w owns Winograd points 9w .. 9w+8 for all of them (9 x 2 x 2 accumulator tiles = 144 registers) and
 // walks the reduction channels 8 at a time (two MFMA k-steps, 72 MFMAs).  Per chunk every thread transforms ONE 6x6 patch
-// (tile = lane % 32, channel = 2 wave + lane / 32): row pass in place as the rows land, column pass straight into the other V
-// buffer (36 conflict-free ds_write_b32), its next patch requested into the registers the column pass vacates (wide loads after
-// the fourth column, the rest after the sixth: 10-12 steps of 4 MFMAs ahead of their first use).  A fragments: 18 floats per
-// lane and k-step from a pre-swizzled U (four 16-byte + one 8-byte load), reloaded in place half a chunk ahead; B fragments: one
-// ds_read_b64 per (point, k-step), two steps ahead.  Output stage: the 36 points of 16 channels meet in LDS (bank-swizzled by the
-// writer's row group), each thread finishes two (tile, channel) pairs per round: A^T M A, bias, (leaky) ReLU, mask, row stores.
+// (tile = lane % 32, channel = 2 wave + lane / 32): first pass over the patch rows for TWO columns at once on packed fp32
+// instructions (v_pk_fma_f32 / v_pk_add_f32: the loads deliver neighbouring columns in neighbouring registers; -5 % on the 51-channel
+// layers), second pass along one transformed row, which leaves as 6 conflict-free ds_write_b32 into the other V buffer -- and that
+// patch row's registers are reloaded for the chunk after next (10-15 steps of 4 MFMAs ahead of their first use).  A fragments: 18
+// floats per lane and k-step from a pre-swizzled U (four 16-byte + one 8-byte load), reloaded in place half a chunk ahead; B
+// fragments: one ds_read_b64 per (point, k-step), two steps ahead.  Output stage: the 36 points of 16 channels meet in LDS
+// (bank-swizzled by the writer's row group), each thread finishes two (tile, channel) pairs per round: A^T M A (first pass packed),
+// bias / (leaky) ReLU (specialised per launch: 0-4 VALU per element), mask, row stores.
+//
+// Measured (tools/r6/wino4_time.py, profiles/r06_wino4_*.txt; T = 4 x 2 samples unless N is given): 64 -> 64 @192x256 95 us = 307
+// direct-equivalent TFLOP/s (F(2x2): 170 us, split-bf16 direct: 142), 128 -> 128 @96x128 94 us = 309, 51 -> 51 @258x450 N = 32
+// 814 us = 211 (F(2x2): 1230), 32 -> 32 @384x512 164 us = 176 (HBM: 400 MB).  Timing-only ablations: the channel loop alone runs at
+// 0.75-0.8 of the fp32 matrix peak; what remains is every non-MFMA instruction (fp32 VALU shares the matrix pipe's datapath: the
+// transform's VALU does not hide under MFMAs), the output stage (14-26 %) and, for 51 channels, padding (56 x 64 of 51 x 51: 38 %).
 #pragma once
 
 namespace w4 {
@@ -33,11 +41,8 @@ constexpr int PTS = 36;
 constexpr int VBUF = PTS * KC * TT;           // floats per V buffer (36 KB)
 constexpr int XBUF = PTS * 16 * TT;           // exchange of one 16-channel round (72 KB)
 constexpr int LDS_FLOATS = XBUF > 2 * VBUF ? XBUF : 2 * VBUF;
-#ifndef W4_ABL
-#define W4_ABL 0          // timing-only ablations (tools/build_variant.sh ... -DW4_ABL=n): wrong results
-#endif
 #ifndef SAVFI_W4_MAXC
-#define SAVFI_W4_MAXC 256
+#define SAVFI_W4_MAXC 512
 #endif
 
 // which layers run on this form: by channel counts only (the filter transform does not know the map size)
@@ -118,6 +123,8 @@ struct W4Args {
   const float* mask;
   float mask_slope;
   int out_unit16;
+  int nsplit, chunks_per_split;       // reduction chunks split over workgroups (deep layers on small maps): raw partial outputs
+  float* partial;                     // [split][N][I][Ho][Wo], summed (+ bias, activation, mask) by wino_split_reduce
 };
 
 __device__ __forceinline__ i32x4 w4_rsrc(const void* base, unsigned bytes) {
@@ -149,6 +156,19 @@ __device__ __forceinline__ void bt6(float d0, float d1, float d2, float d3, floa
   o[5] = fmaf(4.f, d1, fmaf(-5.f, d3, d5));
 }
 
+// the same on two columns at once (v_pk_fma_f32 / v_pk_add_f32)
+__device__ __forceinline__ f32x2 w4_fma2(float s, f32x2 x, f32x2 y) { return __builtin_elementwise_fma((f32x2){s, s}, x, y); }
+__device__ __forceinline__ void bt6p(f32x2 d0, f32x2 d1, f32x2 d2, f32x2 d3, f32x2 d4, f32x2 d5, f32x2 (&o)[6]) {
+  const f32x2 a = w4_fma2(-4.f, d2, d4), b = w4_fma2(-4.f, d1, d3);
+  const f32x2 c = d4 - d2, e = d3 - d1;
+  o[0] = w4_fma2(4.f, d0, w4_fma2(-5.f, d2, d4));
+  o[1] = a + b;
+  o[2] = a - b;
+  o[3] = w4_fma2(2.f, e, c);
+  o[4] = w4_fma2(-2.f, e, c);
+  o[5] = w4_fma2(4.f, d1, w4_fma2(-5.f, d3, d5));
+}
+
 // one 6-vector of A^T m:  A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
 __device__ __forceinline__ void at6(float m0, float m1, float m2, float m3, float m4, float m5, float (&o)[4]) {
   const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
@@ -156,6 +176,14 @@ __device__ __forceinline__ void at6(float m0, float m1, float m2, float m3, floa
   o[1] = fmaf(2.f, d2, d1);
   o[2] = fmaf(4.f, s2, s1);
   o[3] = fmaf(8.f, d2, d1) + m5;
+}
+
+__device__ __forceinline__ void at6p(f32x2 m0, f32x2 m1, f32x2 m2, f32x2 m3, f32x2 m4, f32x2 m5, f32x2 (&o)[4]) {
+  const f32x2 s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+  o[0] = m0 + s1 + s2;
+  o[1] = w4_fma2(2.f, d2, d1);
+  o[2] = w4_fma2(4.f, s2, s1);
+  o[3] = w4_fma2(8.f, d2, d1) + m5;
 }
 
 // VECW: elements per row store (4: Wo % 4 == 0, 2: Wo even, 1); IN16 = 1 + off (1 or 2): the input is unit-major ([y][x / 16][channel][16],
@@ -169,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void wino4_conv3x3(W4Args a) {
 
   // work item: [sample][channel block][tile block], tile block fastest; one XCD walks a contiguous eighth (winograd.hip)
   const int nblk = a.IP / COB;
-  int tb, cob, n;
+  int tb, cob, n, sp;
   {
     const unsigned flat = blockIdx.x, nwg = gridDim.x;
     const unsigned ntb = (unsigned)(a.tiles_y * a.tiles_x);
@@ -178,7 +206,9 @@ __global__ __launch_bounds__(256, 2) void wino4_conv3x3(W4Args a) {
     tb = (int)(item % ntb);
     item /= ntb;
     cob = (int)(item % (unsigned)nblk);
-    n = (int)(item / (unsigned)nblk);
+    item /= (unsigned)nblk;
+    sp = (int)(item % (unsigned)a.nsplit);
+    n = (int)(item / (unsigned)a.nsplit);
   }
   const int tby = tb / a.tiles_x, tbx = tb - tby * a.tiles_x;
   const int i0 = cob * COB;
@@ -229,12 +259,14 @@ __global__ __launch_bounds__(256, 2) void wino4_conv3x3(W4Args a) {
       if (colm[c] != all) partial |= 1 << c;
     }
   }
-  const int nch = a.KP / KC;
+  // this workgroup reduces over chunks [cbeg, cbeg + nch) of the KP / KC chunks; everything below counts chunks from cbeg
+  const int cbeg = sp * a.chunks_per_split;
+  const int nch = min(cbeg + a.chunks_per_split, a.KP / KC) - cbeg;
   // descriptor of chunk c: starts at its first channel, ends with the tensor's last real channel (a lane whose channel does not exist reads
   // zeros or a neighbour's finite values: its filter transform is zero)
   const unsigned sample_bytes = (unsigned)a.K * (unsigned)cplane * 4u;
   auto xrs = [&](int c) {
-    c = c < nch - 1 ? c : nch - 1;
+    c = (c < nch - 1 ? c : nch - 1) + cbeg;
     const unsigned first = (unsigned)c * chunk_bytes;
     return w4_rsrc(reinterpret_cast<const char*>(xp) + first, sample_bytes - first);
   };
@@ -283,21 +315,38 @@ __global__ __launch_bounds__(256, 2) void wino4_conv3x3(W4Args a) {
 #pragma unroll
       for (int c = 0; c < 6; ++c) asm volatile("v_cndmask_b32 %0, 0, %0, %1" : "+v"(d[r][c]) : "s"(colm[c]));
   };
-  auto row_pass = [&](int r) {
-    float o[6];
-    bt6(d[r][0], d[r][1], d[r][2], d[r][3], d[r][4], d[r][5], o);
-#pragma unroll
-    for (int c = 0; c < 6; ++c) d[r][c] = o[c];
-  };
   // V[xi][s][kg][j][tb] (floats): a reader's two tile blocks of one (xi, k) are one ds_read_b64; the 64 lanes of a writer cover 64 banks
   const int vw = (((kc >> 2) * 4 + (kc & 3)) * 16 + (tl & 15)) * 2 + (tl >> 4);
-  auto col_pass = [&](int c, float* vdst) {
-    float o[6];
-    bt6(d[0][c], d[1][c], d[2][c], d[3][c], d[4][c], d[5][c], o);
+  // packed form: first pass over the patch ROWS for two columns at once (the loads deliver neighbouring columns in neighbouring registers),
+  // second pass along the columns of one transformed row, which then leaves as 6 stores -- and its patch row's registers are reloaded
+  f32x2 tp[6][3];
+  auto pk_cols = [&](int cp) {
+    f32x2 o[6];
+    bt6p((f32x2){d[0][2 * cp], d[0][2 * cp + 1]}, (f32x2){d[1][2 * cp], d[1][2 * cp + 1]}, (f32x2){d[2][2 * cp], d[2][2 * cp + 1]},
+         (f32x2){d[3][2 * cp], d[3][2 * cp + 1]}, (f32x2){d[4][2 * cp], d[4][2 * cp + 1]}, (f32x2){d[5][2 * cp], d[5][2 * cp + 1]}, o);
 #pragma unroll
-    for (int r = 0; r < 6; ++r) vdst[vw + (6 * r + c) * 256] = o[r];
+    for (int r = 0; r < 6; ++r) tp[r][cp] = o[r];
   };
-  constexpr int CORD[6] = {WC, WC + 1, WC + 2, WC + 3, WC == 0 ? 4 : 0, WC == 2 ? 1 : 5};    // the 16-byte load's columns first
+  auto row_out = [&](int rp, float* vdst) {
+    float o[6];
+    bt6(tp[rp][0].x, tp[rp][0].y, tp[rp][1].x, tp[rp][1].y, tp[rp][2].x, tp[rp][2].y, o);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) vdst[vw + (6 * rp + c) * 256] = o[c];
+  };
+  auto load_row = [&](const i32x4& rs, int r) {
+    const f32x4 v = savfi_raw_buffer_load_x4(rs, (int)pv[r], 0, 0);
+    d[r][WC] = v.x; d[r][WC + 1] = v.y; d[r][WC + 2] = v.z; d[r][WC + 3] = v.w;
+    if constexpr (IN16 == 3) {
+      const f32x2 u = savfi_raw_buffer_load_x2(rs, (int)pn[r], 0, 0);
+      d[r][0] = u.x; d[r][1] = u.y;
+    } else if constexpr (IN16 == 2) {
+      d[r][0] = savfi_raw_buffer_load_x1(rs, (int)pn[r], 0, 0);
+      d[r][5] = savfi_raw_buffer_load_x1(rs, (int)pn2[r], 0, 0);
+    } else {
+      const f32x2 u = savfi_raw_buffer_load_x2(rs, (int)pv[r] + 16, 0, 0);
+      d[r][4] = u.x; d[r][5] = u.y;
+    }
+  };
 
   // ---- MFMA role ----
   f32x4 acc[9][2][2];
@@ -312,7 +361,7 @@ __global__ __launch_bounds__(256, 2) void wino4_conv3x3(W4Args a) {
   const unsigned ulane4 = (unsigned)lane * 16u, ulane2 = 16u * 64u * 4u + (unsigned)lane * 8u;
   // byte offset of the fragment block of (chunk c, half s)
   auto u_of = [&](int c, int s) {
-    c = c < nch - 1 ? c : nch - 1;
+    c = (c < nch - 1 ? c : nch - 1) + cbeg;
     return ((((unsigned)c * (unsigned)nblk + (unsigned)cob) * 4u + (unsigned)w) * 2u + (unsigned)s) * (18u * 64u * 4u);
   };
   f32x4 a4[4];
@@ -330,9 +379,9 @@ __global__ __launch_bounds__(256, 2) void wino4_conv3x3(W4Args a) {
   load_a4(0, u_of(0, 0)); load_a4(1, u_of(0, 0)); load_a4(2, u_of(0, 0)); load_a4(3, u_of(0, 0)); load_a2(u_of(0, 0));
   if (edge) fix_patch();
 #pragma unroll
-  for (int r = 0; r < 6; ++r) row_pass(r);
+  for (int cp = 0; cp < 3; ++cp) pk_cols(cp);
 #pragma unroll
-  for (int c = 0; c < 6; ++c) col_pass(c, lds);
+  for (int r = 0; r < 6; ++r) row_out(r, lds);
   {
     const i32x4 rs = xrs(1);
     load_wide(rs);
@@ -343,6 +392,7 @@ __global__ __launch_bounds__(256, 2) void wino4_conv3x3(W4Args a) {
 
   // One chunk: 18 steps of 4 MFMAs (half s = step / 9, point q = step % 9).  Steps 9-11: row pass of the next chunk's patch; steps
   // 12-17: its column pass into the other V buffer; the patch after that is requested behind the 4th / 6th column.
+  const bool half_last = cbeg + nch == a.KP / KC && a.K - (a.KP - KC) <= 4;
   auto chunk = [&](int ch, const float* vcur, float* vnext, auto last_tag) {
     constexpr bool last = decltype(last_tag)::value;
     f32x2 bq[3];
@@ -352,7 +402,8 @@ __global__ __launch_bounds__(256, 2) void wino4_conv3x3(W4Args a) {
 #pragma unroll
     for (int g = 0; g < 18; ++g) {
       const int s = g / 9, q = g % 9;
-      if (g + 2 < 18 && W4_ABL != 6) {
+      if (last && g == 9 && half_last) break;      // the tensor ends in this chunk's first four channels (K = 51: 7 % of the layer's MFMAs)
+      if (g + 2 < 18) {
         const int s2 = (g + 2) / 9, q2 = (g + 2) % 9;
         bq[(g + 2) % 3] = *reinterpret_cast<const f32x2*>(vcur + vr + q2 * 256 + s2 * 128);
       }
@@ -362,26 +413,17 @@ __global__ __launch_bounds__(256, 2) void wino4_conv3x3(W4Args a) {
         const float av = v < 16 ? a4[v >> 2][v & 3] : a2[v - 16];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          if (W4_ABL == 1) { acc[q][cb][t][0] += av * bq[g % 3][t]; continue; }
           acc[q][cb][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bq[g % 3][t], acc[q][cb][t], 0, 0, 0);
         }
       }
       // A fragments of the next half, in place behind their last use
       const unsigned un = s == 0 ? u_of(ch, 1) : u_of(ch + 1, 0);
-      if (W4_ABL != 4) {
-        if (q == 1 || q == 3 || q == 5 || q == 7) load_a4(q >> 1, un);
-        if (q == 8) load_a2(un);
-      }
+      if (q == 1 || q == 3 || q == 5 || q == 7) load_a4(q >> 1, un);
+      if (q == 8) load_a2(un);
       if (!last) {
-        if (W4_ABL != 2) {
-          if (g == 9 && edge) fix_patch();
-          if (g >= 9 && g < 12) { row_pass(2 * (g - 9)); row_pass(2 * (g - 9) + 1); }
-          if (g >= 12) col_pass(CORD[g - 12], vnext);
-        }
-        if (W4_ABL != 3 && W4_ABL != 2) {
-          if (g == 15) load_wide(rs2);
-          if (g == 17) load_narrow(rs2);
-        }
+        if (g == 9 && edge) fix_patch();
+        if (g >= 9 && g < 12) pk_cols(g - 9);
+        if (g >= 12) { row_out(g - 12, vnext); load_row(rs2, g - 12); }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -395,27 +437,18 @@ __global__ __launch_bounds__(256, 2) void wino4_conv3x3(W4Args a) {
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
 
-  if (W4_ABL == 5) {       // (every accumulator stays live: the MFMAs are not dead code)
-    float sum = 0.f;
-#pragma unroll
-    for (int q = 0; q < 9; ++q)
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int t = 0; t < 2; ++t) sum += acc[q][cb][t][0] + acc[q][cb][t][1] + acc[q][cb][t][2] + acc[q][cb][t][3];
-    if (sum == 123.f) a.out[0] = 1.f;
-    return;
-  }
   // ---- output stage ------------------------------------------------------------------------------------------------
   // bias of this thread's output channels: round cb, pair qq -> channel i0 + 16 cb + (tid >> 5) + 8 qq (fetched here, behind the channel
   // loop, where no store is outstanding yet: a load issued between stores waits for every older store's acknowledge)
+  const int split = a.nsplit > 1 ? 1 : 0;          // bias / activation / mask then happen in wino_split_reduce
+  float* const obase = split ? a.partial + (size_t)sp * a.N * a.I * a.Ho * a.Wo : a.out;
   float bvals[2][2];
 #pragma unroll
   for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
     for (int qq = 0; qq < 2; ++qq) {
       const int i = i0 + 16 * cb + (tid >> 5) + 8 * qq;
-      bvals[cb][qq] = (a.bias && i < a.I) ? a.bias[task * a.I + i] : 0.f;
+      bvals[cb][qq] = (a.bias && split == 0 && i < a.I) ? a.bias[task * a.I + i] : 0.f;
     }
 
   // this thread finishes pairs p = tid + 256 qq of a round: tile p % 32 (= tid % 32), channel p / 32 of the round's 16
@@ -429,7 +462,7 @@ __global__ __launch_bounds__(256, 2) void wino4_conv3x3(W4Args a) {
 #pragma unroll
     for (int e = 0; e < NS; ++e) {
       const int x = ox + e * VECW;
-      const bool ok = oy + r < a.Ho && x < a.Wo && W4_ABL != 7;
+      const bool ok = oy + r < a.Ho && x < a.Wo;
       if (a.out_unit16) ooff[r][e] = ok ? (unsigned)(((oy + r) * (a.Wo >> 4) + (x >> 4)) * a.I) * 64u + (unsigned)(x & 15) * 4u : 0x80000000u;
       else ooff[r][e] = ok ? (unsigned)((oy + r) * a.Wo + x) * 4u + (unsigned)(lane >> 5) * oplane : 0x80000000u;
     }
@@ -472,49 +505,63 @@ __global__ __launch_bounds__(256, 2) void wino4_conv3x3(W4Args a) {
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (W4_ABL != 8) lds[((9 * w + q) * 16 + 4 * kg + r) * 32 + ((16 * t + j) ^ (16 * (kg & 1)))] = acc[q][cb][t][r];
+          lds[((9 * w + q) * 16 + 4 * kg + r) * 32 + ((16 * t + j) ^ (16 * (kg & 1)))] = acc[q][cb][t][r];
     __syncthreads();
+    // ACT (wave-uniform, one branch per round): 0 = nothing to add (a data gradient), 1 = bias, 2 = bias + ReLU, 3 = bias + leaky ReLU --
+    // 1 / 2 / 4 instead of 4 VALU per output element
+    auto finish = [&](auto act_tag) {
+      constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
-    for (int qq = 0; qq < 2; ++qq) {
-      const int chl = och + 8 * qq;
-      const int col = otl ^ (16 * ((chl >> 2) & 1));
-      float t4[4][6];           // A^T m: rows
+      for (int qq = 0; qq < 2; ++qq) {
+        const int chl = och + 8 * qq;
+        const int col = otl ^ (16 * ((chl >> 2) & 1));
+        f32x2 t4p[4][3];           // A^T m, two columns at a time (a ds_read2st64_b32 delivers the pair: 512 floats apart)
 #pragma unroll
-      for (int c = 0; c < 6; ++c) {
-        float m[6], o[4];
+        for (int cp = 0; cp < 3; ++cp) {
+          f32x2 m[6], o[4];
 #pragma unroll
-        for (int r = 0; r < 6; ++r) m[r] = W4_ABL == 8 ? acc[r][cb][qq][c & 3] : lds[((6 * r + c) * 16 + chl) * 32 + col];
-        if (W4_ABL == 9) { o[0] = m[0] + m[4]; o[1] = m[1] + m[5]; o[2] = m[2]; o[3] = m[3]; } else
-        at6(m[0], m[1], m[2], m[3], m[4], m[5], o);
+          for (int r = 0; r < 6; ++r)
+            m[r] = (f32x2){lds[((6 * r + 2 * cp) * 16 + chl) * 32 + col], lds[((6 * r + 2 * cp + 1) * 16 + chl) * 32 + col]};
+          at6p(m[0], m[1], m[2], m[3], m[4], m[5], o);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) t4[r][c] = o[r];
-      }
-      const float b = bvals[cb][qq];
-      const int i = i0 + 16 * cb + chl;
-      const i32x4 ors = w4_uniform(a.out_unit16 ? w4_rsrc(a.out + (size_t)n * a.I * a.Ho * a.Wo, (unsigned)a.I * oplane) : pair_rsrc(a.out, cb, qq));
-      const unsigned choff = a.out_unit16 ? (i < a.I ? (unsigned)i * 64u : 0x40000000u) : 0u;      // (+ 0x80000000 of a dropped pixel: still out of range)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float y[4];
-        if (W4_ABL == 9) { y[0] = t4[r][0] + t4[r][4]; y[1] = t4[r][1] + t4[r][5]; y[2] = t4[r][2]; y[3] = t4[r][3]; } else
-        at6(t4[r][0], t4[r][1], t4[r][2], t4[r][3], t4[r][4], t4[r][5], y);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          float v = y[c] + b;
-          v = fmaxf(v, 0.f) + slope * fminf(v, 0.f);
-          if constexpr (MASK) v = mk[MASK ? cb : 0][MASK ? qq : 0][r][c] > 0.f ? v : v * a.mask_slope;
-          y[c] = v;
+          for (int r = 0; r < 4; ++r) t4p[r][cp] = o[r];
         }
-        if constexpr (VECW == 4) {
-          savfi_raw_buffer_store_x4((f32x4){y[0], y[1], y[2], y[3]}, ors, (int)(ooff[r][0] + choff), 0, 0);
-        } else if constexpr (VECW == 2) {
-          savfi_raw_buffer_store_x2((f32x2){y[0], y[1]}, ors, (int)(ooff[r][0] + choff), 0, 0);
-          savfi_raw_buffer_store_x2((f32x2){y[2], y[3]}, ors, (int)(ooff[r][1] + choff), 0, 0);
-        } else {
+        const float b = bvals[cb][qq];
+        const int i = i0 + 16 * cb + chl;
+        const i32x4 ors = w4_uniform(a.out_unit16 ? w4_rsrc(obase + (size_t)n * a.I * a.Ho * a.Wo, (unsigned)a.I * oplane) : pair_rsrc(obase, cb, qq));
+        const unsigned choff = a.out_unit16 ? (i < a.I ? (unsigned)i * 64u : 0x40000000u) : 0u;      // (+ 0x80000000 of a dropped pixel: still out of range)
 #pragma unroll
-          for (int c = 0; c < 4; ++c) savfi_raw_buffer_store_x1(y[c], ors, (int)(ooff[r][c] + choff), 0, 0);
+        for (int r = 0; r < 4; ++r) {
+          float y[4];
+          at6(t4p[r][0].x, t4p[r][0].y, t4p[r][1].x, t4p[r][1].y, t4p[r][2].x, t4p[r][2].y, y);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            float v = y[c];
+            if constexpr (ACT >= 1) v += b;
+            if constexpr (ACT == 2) v = fmaxf(v, 0.f);
+            if constexpr (ACT == 3) v = fmaxf(v, 0.f) + slope * fminf(v, 0.f);
+            if constexpr (MASK) v = mk[MASK ? cb : 0][MASK ? qq : 0][r][c] > 0.f ? v : v * a.mask_slope;
+            y[c] = v;
+          }
+          if constexpr (VECW == 4) {
+            savfi_raw_buffer_store_x4((f32x4){y[0], y[1], y[2], y[3]}, ors, (int)(ooff[r][0] + choff), 0, 0);
+          } else if constexpr (VECW == 2) {
+            savfi_raw_buffer_store_x2((f32x2){y[0], y[1]}, ors, (int)(ooff[r][0] + choff), 0, 0);
+            savfi_raw_buffer_store_x2((f32x2){y[2], y[3]}, ors, (int)(ooff[r][1] + choff), 0, 0);
+          } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) savfi_raw_buffer_store_x1(y[c], ors, (int)(ooff[r][c] + choff), 0, 0);
+          }
         }
       }
+    };
+    if (slope == 1.f || split) {
+      if (a.bias == nullptr || split) finish(std::integral_constant<int, 0>{});
+      else finish(std::integral_constant<int, 1>{});
+    } else if (slope == 0.f) {
+      finish(std::integral_constant<int, 2>{});
+    } else {
+      finish(std::integral_constant<int, 3>{});
     }
     __syncthreads();
   }

@@ -733,6 +733,7 @@ def _wgrad_wino(N, Ci, Co, Ho, Wo):
 #        direct form because it amplifies Winograd rounding (VoxelFlow: `direct=True`).
 CONVK = True
 CONVK_3X3_MIN_PIXELS = 700
+CONVK_3X3_SMALL_LAUNCH_MIN_PIXELS = 200
 
 
 CONVK_WGRAD3_RING_MIN_PIXELS = 3000
@@ -772,12 +773,14 @@ def _convk_geometry(weight, stride, padding, dilation, groups):
     return K, int(pad)
 
 
-# Winograd F(4x4, 3x3) (csrc/winograd4.h; round 6): the 3x3 layers of at most 256 -> 256 channels, wherever its launch fills the chip --
-# measured against the direct split-bf16 kernel on one box (tools/r6/wino4_time.py deep convk, profiles/r06_wino4_vs_convk.txt):
-# 64 -> 64 @192x256 121 / 131 vs 142 / 147 us (forward / data gradient, T = 4 x 2 samples), 128 -> 128 @96x128 115 / 111 vs 128 / 128,
-# 256 -> 256 @48x64 118 / 115 vs 133 / 132, 64 -> 64 @137x236 N = 32 324 / 320 vs 385 / 393; 128 -> 128 @48x64 (192 workgroups) 46 vs 42:
-# below ~300 workgroups (2 per CU x 256 CUs = 512 slots) the direct kernel keeps the layer.
-WINO4_MIN_WORKGROUPS = 300
+# Winograd F(4x4, 3x3) (csrc/winograd4.h; round 6): the 3x3 layers of at most 512 -> 512 channels, wherever its launch fills the chip --
+# measured against the direct split-bf16 kernel on one box (tools/r6/wino4_time.py deep|small convk, profiles/r06_wino4_vs_convk.txt;
+# forward / data gradient in us, T = 4 x 2 samples): 64 -> 64 @192x256 95 / 94 vs 142 / 147, 128 -> 128 @96x128 94 / 92 vs 128 / 128,
+# 256 -> 256 @48x64 118 / 115 vs 133 / 132, 64 -> 64 @137x236 N = 32 324 / 320 vs 385 / 393, 64 -> 64 @96x128 35 / 34 vs 47 / 46, 128 -> 128
+# @48x64 (192 workgroups) 37 / 36 vs 42 / 42; with the reduction split over workgroups (from 256 channels): 512 -> 512 @24x32 138 / 141 vs
+# 164 / 160, 256 -> 256 @24x32 46 / 44 vs 57 / 56, 512 -> 512 @12x16 64 / 62 (F(2x2): 53; direct: 107).  Below ~180 workgroups (of 2 per CU x
+# 256 CUs = 512 slots) the direct kernel keeps the layer.
+WINO4_MIN_WORKGROUPS = 180
 
 
 @functools.lru_cache(maxsize=None)
@@ -787,8 +790,10 @@ def _conv3x3_name(Ci, Co, what):
     return ("conv3x3f4_" if f4 else "conv3x3_") + what
 
 
+@functools.lru_cache(maxsize=4096)
 def wino4_workgroups(N, Ci, Co, H, W, pad, mode=0):
-    """Workgroups savfi_conv3x3_* would launch on its F(4x4) kernel for this call; 0: the layer's channel counts keep it on F(2x2)."""
+    """Workgroups savfi_conv3x3_* would launch on its F(4x4) kernel for this call; 0: the layer's channel counts keep it on F(2x2).
+    (Cached per shape: the routing asks once per convolution call, and a 64 x 64 CAIN iteration is host-bound.)"""
     n = int(_hip.lib().savfi_conv3x3_f4_workgroups(int(N), int(Ci), int(Co), int(H), int(W), int(pad), int(mode)))
     return max(n, 0)
 
@@ -808,10 +813,22 @@ def convk_eligible(x, weight, stride, padding, dilation, groups=1, direct=False)
         return False
     if K != 3 or direct:
         return True
-    if not (Ho * Wo >= CONVK_3X3_MIN_PIXELS and (Ci <= 8 or (Ci >= 64 and Co >= 64 and Co % 64 == 0))):
+    if Ci <= 8:
+        return Ho * Wo >= CONVK_3X3_MIN_PIXELS      # (an F(4x4) chunk is 8 reduction channels, half of them padding for 6 -> 32)
+    if not (Ci >= 64 and Co >= 64 and Co % 64 == 0):
         return False
-    # (the <= 8-channel input layers stay here: an F(4x4) chunk is 8 reduction channels, half of them padding for 6 -> 32)
-    return Ci <= 8 or pad > 1 or not WINOGRAD_CONV or wino4_workgroups(x.shape[0], Ci, Co, H, W, pad) < WINO4_MIN_WORKGROUPS
+    if pad > 1 or not WINOGRAD_CONV:
+        return Ho * Wo >= CONVK_3X3_MIN_PIXELS
+    f4 = wino4_workgroups(int(x.shape[0]), int(Ci), int(Co), int(H), int(W), int(pad))
+    if f4 >= WINO4_MIN_WORKGROUPS:
+        return False                                # the F(4x4) launch fills the chip
+    # A launch too small for F(4x4) to pay: the direct kernel, on maps below 700 pixels too -- F(4x4) rounds 5x coarser than the direct sum
+    # (3e-7 rms of the result's scale), which an Adam-type inner rule turns into flipped steps of the elements whose gradient is
+    # rounding noise (CAIN 64 x 64 + Adam: the 192 -> 192 layers on 16 x 16 maps); where the form buys no time it is not worth that.
+    # (f4 == 0: beyond 512 channels the library's F(2x2) kernel serves the small maps as before.)
+    # Maps below ~200 pixels never reached a Winograd kernel (conv3x3_*_eligible: too few tiles) and stay with MIOpen: config C1's 8 x 8
+    # maps are launch-bound, and the direct kernel's single workgroup per map walks the whole reduction alone (44 -> 25 steps/s).
+    return Ho * Wo >= CONVK_3X3_MIN_PIXELS or (f4 > 0 and Ho * Wo >= CONVK_3X3_SMALL_LAUNCH_MIN_PIXELS)
 
 
 # Packed / transformed filters of a module's OWN parameters are cached per weight version: a first-order meta-iteration

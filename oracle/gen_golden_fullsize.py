@@ -16,8 +16,14 @@ shims as gen_golden.py, no reference file modified -- at the sizes BASELINE.json
                                  every inner step) + learnable per-layer per-step learning rates
     c2script_sepconv_256x448_b3_s3   the configuration the reference's own scripts/run_sepconv.sh:6-17 trains: Adamax + Meta-SGD (element-wise
                                  learnable learning rates, inner_loop_optimizers.py:385-425), 3 inner steps, meta-batch 3, inner_lr 1e-5
-    c4b32_sepconv_msl_256x448_s5 config C4 at its stated meta-batch: run_train_iter over 32 tasks (meta_learning_system.py:338,366); stored:
-                                 the 32-task mean loss / PSNR / SSIM, the frames of tasks 0 and 31, outer-gradient fingerprints
+    c4b32_sepconv_msl_256x448_s5 config C4 at its stated meta-batch of 32 (meta_learning_system.py:338,366).  The imported reference keeps every
+                                 task's five target-pass graphs until its one backward: 65 GB at 32 tasks, more than this container has
+                                 (62 GB: the kernel's OOM killer ended the attempt).  The 32-task iteration is therefore assembled from FOUR
+                                 reference run_train_iter calls over tasks 8 g .. 8 g + 7 at the same theta -- tasks are independent
+                                 (first-order) and the reference's loss / outer gradient are task MEANS, so the 32-task values are the means
+                                 of the four groups' (linear; exact up to one fp32 rounding of the averaging).  Stored: mean loss / PSNR /
+                                 SSIM, the frames of tasks 0 and 31, outer-gradient fingerprints (sum and first elements averaged; the
+                                 abs-sum scale is the mean of the groups' abs-sums, an upper bound of the true one)
     c5_cain_l2f_720p             CAIN + L2F attenuation, 1 inner step, 1280x720, run_train_iter   (config C5)
     c5eval_cain_l2f_720p         the reference's ExperimentBuilder.evaluation_iteration (experiment_builder.py:93-148) on the
                                  same clip: 720x1280 > 5e5 pixels, so two 720x640 halves are adapted separately and stitched
@@ -108,11 +114,18 @@ def seed_attenuator(system):
             p.copy_(torch.from_numpy(rs.uniform(-0.05, 0.05, size=tuple(p.shape)).astype(np.float32)))
 
 
-def run_train(name, variant='base'):
+GROUPS = {'c4b32_sepconv_msl_256x448_s5': 4}       # a meta-batch assembled from this many reference calls (see the module docstring)
+
+
+def run_train(name, variant='base', group=None):
     model, H, W, over = CASES[name]
     B = TASKS.get(name, 1)
+    first = 0
+    if group is not None:
+        B = B // GROUPS[name]
+        first = group * B
     args = G.reference_args(model=model, batch_size=B, **over)
-    frames = synthetic.septuplet_batch(B, H, W, model=model)
+    frames = synthetic.septuplet_batch(B, H, W, model=model, first_task=first)
     torch.manual_seed(0)
     torch.nn.functional.conv2d = {'perm': S._conv2d_perm, 'perm2': S._conv2d_perm2}.get(variant, S._ORIG_CONV2D)
     try:
@@ -149,10 +162,26 @@ def run_train(name, variant='base'):
                 psnr=float(metrics['psnr'].avg), ssim=float(metrics['ssim'].avg), rec=rec)
 
 
+def run_train_grouped(name):
+    """The meta-batch as GROUPS[name] reference calls at the same theta; returns run_train's dict for the whole meta-batch."""
+    n = GROUPS[name]
+    parts = []
+    for g in range(n):
+        parts.append(run_train(name, group=g))
+        print('  %-30s group %d / %d: loss=%.8f' % (name, g + 1, n, parts[-1]['loss']), flush=True)
+    mean = lambda xs: float(np.mean(xs))
+    rec = dict(n_live=parts[0]['rec']['n_live'], grad_fp=[], weight_fp=[], outer_grad_fp={})
+    for k in parts[0]['rec']['outer_grad_fp']:
+        rec['outer_grad_fp'][k] = np.mean(np.stack([p['rec']['outer_grad_fp'][k] for p in parts]), axis=0)
+    return dict(loss=mean([p['loss'] for p in parts]), parts={k: mean([p['parts'][k] for p in parts]) for k in parts[0]['parts']},
+                preds=np.concatenate([p['preds'] for p in parts]), psnr=mean([p['psnr'] for p in parts]),
+                ssim=mean([p['ssim'] for p in parts]), rec=rec)
+
+
 def gen_train_case(name):
     model, H, W, over = CASES[name]
     t0 = time.time()
-    base = run_train(name)
+    base = run_train_grouped(name) if name in GROUPS else run_train(name)
     stored = dict(over, weight_recipe=RECIPE[name]) if name in RECIPE else over
     out = {'model': np.array(model), 'H': H, 'W': W, 'B': TASKS.get(name, 1), 'args': np.array(repr(sorted(stored.items()))),
            'train_loss': np.float64(base['loss']), 'train_psnr': np.float64(base['psnr']), 'train_ssim': np.float64(base['ssim']),

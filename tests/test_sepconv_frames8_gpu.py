@@ -290,11 +290,11 @@ def test_unit_major_convolution_entry_points_refuse_what_they_cannot_do():
     assert lib.savfi_conv3x3_unit16_supported(N, T, C, C, H, W, 0) == 1
     assert lib.savfi_conv3x3_tasks_pre_unit16_f32(None, P(u[0]), None, P(out), N, T, C, C, H, W, 0, 1.0, st) == -1
     assert lib.savfi_conv3x3_tasks_pre_unit16_f32(P(x), P(u[0]), None, P(out), N, T, C, C, H, W - 2, 0, 1.0, st) == -3      # width 126: not % 16
-    # a layer beyond the F(4x4) kernel's 256 channels on a small map: the F(2x2) kernel splits its reduction over workgroups -> refused
+    # a deep layer on a small map: the reduction is split over workgroups (F(4x4) from 256 channels, F(2x2) beyond 512) -> refused
     C2 = 320
     u2 = hip_ops.conv3x3_filters(torch.randn(T, C2, C2, 3, 3, device=DEV), True, True)
     x2, out2 = torch.randn(4, C2, 14, 18, device=DEV), torch.empty(4, C2, 12, 16, device=DEV)       # 40 workgroups: split
-    assert lib.savfi_conv3x3_f4_workgroups(4, C2, C2, 14, 18, 0, 0) == 0 and lib.savfi_conv3x3_f4_workgroups(4, C, C, 38, 66, 0, 0) == 4 * 5 * 2
+    assert lib.savfi_conv3x3_f4_workgroups(4, 640, 640, 14, 18, 0, 0) == 0 and lib.savfi_conv3x3_f4_workgroups(4, C, C, 38, 66, 0, 0) == 4 * 5 * 2
     assert lib.savfi_conv3x3_tasks_pre_workspace_floats(4, T, C2, C2, 14, 18, 0, 0) > 0
     assert lib.savfi_conv3x3_unit16_supported(4, T, C2, C2, 14, 18, 0) == 0
     assert lib.savfi_conv3x3_tasks_pre_unit16_f32(P(x2), P(u2[0]), None, P(out2), 4, T, C2, C2, 14, 18, 0, 1.0, st) == -3

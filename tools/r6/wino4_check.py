@@ -104,6 +104,8 @@ SMALL = [
     (1, 1, 64, 51, 37, 45, 1), (1, 1, 64, 51, 37, 45, 0), (4, 8, 51, 51, 18, 30, 1), (2, 4, 51, 51, 18, 34, 0), (2, 4, 64, 32, 16, 64, 0),
     (1, 2, 32, 32, 16, 16, 1), (4, 8, 32, 32, 20, 30, 1), (2, 2, 40, 64, 9, 130, 1), (1, 1, 33, 17, 130, 9, 1), (1, 1, 16, 16, 4, 4, 1),
     (1, 1, 16, 16, 6, 6, 0), (4, 4, 51, 51, 34, 66, 0), (2, 2, 51, 51, 32, 64, 1), (1, 1, 51, 51, 66, 130, 0),
+    # deep layers on small maps: the reduction split over workgroups (partial outputs + wino_split_reduce)
+    (4, 8, 256, 256, 24, 32, 1), (2, 4, 512, 512, 12, 16, 1), (1, 2, 512, 256, 24, 32, 0), (4, 8, 320, 192, 13, 21, 1),
 ]
 BIG = [(4, 8, 32, 32, 384, 512, 1), (4, 32, 64, 51, 137, 236, 1), (4, 32, 51, 51, 258, 450, 0), (4, 8, 32, 64, 192, 256, 1),
        (4, 16, 51, 51, 258, 450, 0), (4, 8, 64, 64, 192, 256, 1)]

@@ -9,7 +9,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from meta_interpolation_amd import hip_ops  # noqa: E402
 
 SHAPES = [(4, 8, 32, 32, 384, 512, 1), (4, 32, 64, 51, 137, 236, 1), (4, 32, 51, 51, 258, 450, 0), (4, 8, 32, 64, 192, 256, 1), (4, 8, 64, 64, 192, 256, 1)]
-if len(sys.argv) > 1 and sys.argv[1] == 'deep':
+if len(sys.argv) > 1 and sys.argv[1] == 'small':
+    SHAPES = [(4, 8, 512, 512, 24, 32, 1), (1, 8, 512, 512, 24, 32, 1), (4, 8, 256, 256, 24, 32, 1), (4, 8, 512, 256, 24, 32, 1), (4, 8, 256, 512, 24, 32, 1),
+              (4, 8, 512, 512, 12, 16, 1), (4, 8, 128, 128, 48, 64, 1), (4, 8, 64, 64, 96, 128, 1)]
+elif len(sys.argv) > 1 and sys.argv[1] == 'deep':
     SHAPES = [(4, 8, 64, 64, 192, 256, 1), (4, 8, 128, 128, 96, 128, 1), (4, 8, 256, 256, 48, 64, 1), (4, 32, 64, 64, 137, 236, 1), (4, 8, 64, 64, 96, 128, 1),
               (4, 8, 128, 128, 48, 64, 1), (4, 8, 128, 64, 96, 128, 1), (4, 8, 64, 128, 96, 128, 1)]
 
