@@ -56,7 +56,7 @@
 extern "C" {
 #endif
 
-#define SAVFI_ABI_VERSION 18
+#define SAVFI_ABI_VERSION 19
 
 #define SAVFI_OK            0
 #define SAVFI_E_NULL       (-1)  /* a required pointer is NULL                          */
@@ -356,6 +356,15 @@ int64_t savfi_conv3x3_filter_floats(int T, int Ci, int Co, int mode);
  * kernel would launch for this call (32 tiles of 4 x 4 pixels x 32 produced channels each, x the reduction split of a deep layer on a
  * small map), 0 for an F(2x2) layer -- a caller with another kernel for launches that cannot fill the chip routes by this count. */
 int64_t savfi_conv3x3_f4_workgroups(int N, int Ci, int Co, int H, int W, int pad, int mode);
+/* The caller's choice of the form per layer AND map: bit 1 of every `mode` argument of the savfi_conv3x3_* functions (mode | 2) and `form`
+ * = 2 below select the F(2x2) kernel whatever the channel counts -- for launches too small for F(4x4) to pay (it rounds 5x coarser; an
+ * Adam-type inner rule turns that into flipped steps of elements whose gradient is rounding noise).  form = 0 / bit clear: by the channel
+ * counts.  A transformed filter is valid for the form it was made for only.  The plain entry points are form 0. */
+int savfi_conv3x3_filters_form_f32(const float* w, float* u_fwd, float* u_bwd, int T, int Ci, int Co, int form, void* stream);
+int savfi_conv3x3_filters_multi_form_f32(const float* const* w, float* const* u_fwd, float* const* u_bwd, const int* T, const int* Ci,
+                                         const int* Co, const int* form, int n, void* stream);
+int savfi_conv3x3_dgrad_masked_form_f32(const float* gy, const float* u, const float* mask, float mask_slope, float* gx, float* workspace,
+                                        int N, int T, int Ci, int Co, int H, int W, int pad, int form, void* stream);
 int savfi_conv3x3_filters_f32(const float* w, float* u_fwd, float* u_bwd, int T, int Ci, int Co, void* stream);
 /* n layers in one launch per 56 (layer, mode) jobs; entry i is savfi_conv3x3_filters_f32(w[i], u_fwd[i], u_bwd[i], T[i], Ci[i], Co[i]). */
 int savfi_conv3x3_filters_multi_f32(const float* const* w, float* const* u_fwd, float* const* u_bwd, const int* T, const int* Ci,

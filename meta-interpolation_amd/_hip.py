@@ -16,7 +16,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_PKG_DIR), "include", "savfi_hip.h")
 
 RULE_SGD, RULE_ADAM, RULE_ADAMAX_LSLR, RULE_ADAMAX_MSGD = 0, 1, 2, 3
 LR_SCALAR, LR_ELEMENT = 0, 1
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 _ERRORS = {-1: "SAVFI_E_NULL (a required pointer is NULL)",
            -2: "SAVFI_E_SHAPE (bad or inconsistent dimension)",
@@ -78,6 +78,9 @@ _PROTOTYPES = {
     "savfi_conv3x3_tasks_f32": [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P],
     "savfi_conv3x3_filter_floats": [c_int] * 4,
     "savfi_conv3x3_f4_workgroups": [c_int] * 7,
+    "savfi_conv3x3_filters_form_f32": [_P, _P, _P, c_int, c_int, c_int, c_int, _P],
+    "savfi_conv3x3_filters_multi_form_f32": [_P, _P, _P, _P, _P, _P, _P, c_int, _P],
+    "savfi_conv3x3_dgrad_masked_form_f32": [_P, _P, _P, c_float, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P],
     "savfi_conv3x3_filters_f32": [_P, _P, _P, c_int, c_int, c_int, _P],
     "savfi_conv3x3_tasks_pre_workspace_floats": [c_int] * 8,
     "savfi_conv3x3_tasks_pre_f32": [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P],

@@ -117,8 +117,8 @@ __device__ __forceinline__ void filter_transform_block(const float* __restrict__
 }
 
 __global__ __launch_bounds__(256) void wino_filter_transform(const float* __restrict__ w, float* __restrict__ U,
-                                                             int Co, int Ci, int K, int I, int KP, int IP, int mode) {
-  if (w4::use_f4(K, I)) w4::filter_transform_block4(w, U, Co, Ci, K, I, KP, IP, mode, blockIdx.x, blockIdx.y);
+                                                             int Co, int Ci, int K, int I, int KP, int IP, int mode, int f4) {
+  if (f4) w4::filter_transform_block4(w, U, Co, Ci, K, I, KP, IP, mode, blockIdx.x, blockIdx.y);
   else filter_transform_block(w, U, Co, Ci, K, I, KP, IP, mode, blockIdx.x, blockIdx.y);
 }
 
@@ -127,11 +127,11 @@ __global__ __launch_bounds__(256) void wino_filter_transform(const float* __rest
 // 5 % of a SepConv meta-iteration).  The grid covers the larger of the two block ranges; surplus blocks leave at once.
 __global__ __launch_bounds__(256) void wino_filter_transform_dual(const float* __restrict__ w, float* __restrict__ Uf,
                                                                   float* __restrict__ Ub, int Co, int Ci, int KPf, int IPf,
-                                                                  int KPb, int IPb, int T) {
+                                                                  int KPb, int IPb, int T, int f4) {
   const int mode = blockIdx.z;
   const int KP = mode == 0 ? KPf : KPb, IP = mode == 0 ? IPf : IPb;
   if ((int)blockIdx.x >= KP / 4 || (int)blockIdx.y >= ((IP + 63) / 64) * T) return;
-  if (w4::use_f4(Ci, Co)) w4::filter_transform_block4(w, mode == 0 ? Uf : Ub, Co, Ci, mode == 0 ? Ci : Co, mode == 0 ? Co : Ci, KP, IP, mode, blockIdx.x, blockIdx.y);
+  if (f4) w4::filter_transform_block4(w, mode == 0 ? Uf : Ub, Co, Ci, mode == 0 ? Ci : Co, mode == 0 ? Co : Ci, KP, IP, mode, blockIdx.x, blockIdx.y);
   else filter_transform_block(w, mode == 0 ? Uf : Ub, Co, Ci, mode == 0 ? Ci : Co, mode == 0 ? Co : Ci, KP, IP, mode, blockIdx.x, blockIdx.y);
 }
 
@@ -142,7 +142,7 @@ constexpr int WINO_FT_JOBS = 56;
 struct FtJob {
   const float* w;
   float* U;
-  int Co, Ci, K, I, KP, IP, mode, nbx, first_block, pad_;
+  int Co, Ci, K, I, KP, IP, mode, nbx, first_block, f4;
 };
 struct FtTable {
   FtJob job[WINO_FT_JOBS];
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void wino_filter_transform_multi(const FtTable
   }
   const FtJob& j = tb.job[lo];
   const int rel = (int)blockIdx.x - j.first_block;
-  if (w4::use_f4(j.K, j.I)) w4::filter_transform_block4(j.w, j.U, j.Co, j.Ci, j.K, j.I, j.KP, j.IP, j.mode, rel % j.nbx, rel / j.nbx);
+  if (j.f4) w4::filter_transform_block4(j.w, j.U, j.Co, j.Ci, j.K, j.I, j.KP, j.IP, j.mode, rel % j.nbx, rel / j.nbx);
   else filter_transform_block(j.w, j.U, j.Co, j.Ci, j.K, j.I, j.KP, j.IP, j.mode, rel % j.nbx, rel / j.nbx);
 }
 
@@ -654,16 +654,21 @@ struct WinoPlan {
 };
 
 // padded reduction / produced channel counts of a layer's transformed filter (both forms)
-inline int kp_for(int K, int I) { return w4::use_f4(K, I) ? w4::kp_of(K) : (K + 2 * CIB - 1) / (2 * CIB) * (2 * CIB); }
-inline int ip_for(int K, int I) { return w4::use_f4(K, I) ? w4::ip_of(I) : (I + COB - 1) / COB * COB; }
-inline int64_t u_floats_for(int K, int I) { return (int64_t)(w4::use_f4(K, I) ? w4::PTS : 16) * kp_for(K, I) * ip_for(K, I); }
+// `form` 2: the F(2x2) kernel whatever the channel counts (a caller's choice per layer AND map: savfi_conv3x3_*_form_f32 / bit 1 of `mode`);
+// 0: by the channel counts (F(4x4) up to 512 -> 512)
+inline bool f4_for(int K, int I, int form) { return form != 2 && w4::use_f4(K, I); }
+inline int kp_for(int K, int I, int form) { return f4_for(K, I, form) ? w4::kp_of(K) : (K + 2 * CIB - 1) / (2 * CIB) * (2 * CIB); }
+inline int ip_for(int K, int I, int form) { return f4_for(K, I, form) ? w4::ip_of(I) : (I + COB - 1) / COB * COB; }
+inline int64_t u_floats_for(int K, int I, int form) { return (int64_t)(f4_for(K, I, form) ? w4::PTS : 16) * kp_for(K, I, form) * ip_for(K, I, form); }
 
 bool make_plan(WinoPlan& p, int N, int Ci, int Co, int H, int W, int pad, int mode) {
+  const int form = (mode & 2) ? 2 : 0;       // bit 1 of `mode`: the F(2x2) form
+  mode &= 1;
   p.K = mode == 0 ? Ci : Co;
   p.I = mode == 0 ? Co : Ci;       // reduction / produced channels
-  p.f4 = w4::use_f4(p.K, p.I);
-  p.KP = kp_for(p.K, p.I);         // F(2x2): an even number of chunks (see the channel loop)
-  p.IP = ip_for(p.K, p.I);
+  p.f4 = f4_for(p.K, p.I, form);
+  p.KP = kp_for(p.K, p.I, form);   // F(2x2): an even number of chunks (see the channel loop)
+  p.IP = ip_for(p.K, p.I, form);
   // forward: patch origin 2t - pad; gradient of a pad-p convolution = pad-(2-p) correlation with the flipped filter
   p.off = mode == 0 ? pad : 2 - pad;
   p.Ho = H + 2 * p.off - 2;
@@ -692,7 +697,7 @@ bool make_plan(WinoPlan& p, int N, int Ci, int Co, int H, int W, int pad, int mo
     if (cps4 < 8) cps4 = nchunk4 < 8 ? nchunk4 : 8;
     p.chunks_per_split = cps4;
     p.nsplit = savfi_cdiv(nchunk4, cps4);
-    p.u_floats = u_floats_for(p.K, p.I);
+    p.u_floats = u_floats_for(p.K, p.I, form);
     p.partial_floats = p.nsplit > 1 ? (int64_t)p.nsplit * N * p.I * p.Ho * p.Wo : 0;
     return true;
   }
@@ -744,7 +749,7 @@ extern "C" int savfi_debug_wino_trace(unsigned long long* host, long long cap) {
 
 extern "C" int64_t savfi_conv3x3_tasks_workspace_floats(int N, int T, int Ci, int Co, int H, int W, int pad, int mode) {
   if (N <= 0 || T <= 0 || N % T != 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return SAVFI_E_SHAPE;
-  if ((mode != 0 && mode != 1) || (pad != 0 && pad != 1)) return SAVFI_E_UNSUPPORTED;
+  if ((mode & ~3) || (pad != 0 && pad != 1)) return SAVFI_E_UNSUPPORTED;
   WinoPlan p;
   if (!make_plan(p, N, Ci, Co, H, W, pad, mode)) return SAVFI_E_SHAPE;
   return (int64_t)T * p.u_floats + p.partial_floats;
@@ -754,7 +759,7 @@ extern "C" int64_t savfi_conv3x3_tasks_workspace_floats(int N, int T, int Ci, in
 // host routes by it: F(4x4) has no reduction split, so a launch that cannot fill the chip's 512 workgroup slots belongs elsewhere.
 extern "C" int64_t savfi_conv3x3_f4_workgroups(int N, int Ci, int Co, int H, int W, int pad, int mode) {
   if (N <= 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return SAVFI_E_SHAPE;
-  if ((mode != 0 && mode != 1) || (pad != 0 && pad != 1)) return SAVFI_E_UNSUPPORTED;
+  if ((mode & ~3) || (pad != 0 && pad != 1)) return SAVFI_E_UNSUPPORTED;
   WinoPlan p;
   if (!make_plan(p, N, Ci, Co, H, W, pad, mode)) return SAVFI_E_SHAPE;
   return p.f4 ? (int64_t)p.th * p.tw * (p.IP / w4::COB) * p.nsplit * N : 0;
@@ -777,7 +782,7 @@ int launch_conv(const WinoPlan& p, const float* x, const float* U, const float* 
     if (p.nsplit > 1 && (out_unit16 || in_unit16 || !partial)) return SAVFI_E_UNSUPPORTED;
     if (in_unit16 && ((p.off != 1 && p.off != 2) || p.Wo % 2 != 0)) return SAVFI_E_UNSUPPORTED;
     constexpr size_t lds4 = (size_t)w4::LDS_FLOATS * sizeof(float);      // 72 KB: two workgroups per CU
-    w4::W4Args a4{x, U, mode == 0 ? bias : nullptr, out, p.K, p.I, p.KP, p.IP, H, W, p.Ho, p.Wo, p.off, p.th, p.tw, slope,
+    w4::W4Args a4{x, U, (mode & 1) == 0 ? bias : nullptr, out, p.K, p.I, p.KP, p.IP, H, W, p.Ho, p.Wo, p.off, p.th, p.tw, slope,
                   p.tile_shift, T, N, p.nsplit > 1 ? nullptr : mask, mask_slope, out_unit16, p.nsplit, p.chunks_per_split, partial};
     const int vecw = p.Wo % 4 == 0 ? 4 : (p.Wo % 2 == 0 ? 2 : 1);
     auto go = [&](auto kern) -> int {
@@ -792,7 +797,7 @@ int launch_conv(const WinoPlan& p, const float* x, const float* U, const float* 
       const int rc = vecw == 4 ? go(w4::wino4_conv3x3<4, 0, false>) : vecw == 2 ? go(w4::wino4_conv3x3<2, 0, false>) : go(w4::wino4_conv3x3<1, 0, false>);
       if (rc != SAVFI_OK) return rc;
       const size_t total = (size_t)N * p.I * p.Ho * p.Wo;
-      hipLaunchKernelGGL(wino_split_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, partial, mode == 0 ? bias : nullptr, out,
+      hipLaunchKernelGGL(wino_split_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, partial, (mode & 1) == 0 ? bias : nullptr, out,
                          p.nsplit, total, p.I, p.Ho * p.Wo, slope, T, mask, mask_slope);
       return savfi_launch_status();
     }
@@ -802,7 +807,7 @@ int launch_conv(const WinoPlan& p, const float* x, const float* U, const float* 
   const int64_t wgs = (int64_t)p.th * p.tw * (p.IP / COB) * p.nsplit * N;
   if (wgs > 0x7fffffffLL || T > 65535) return SAVFI_E_TOOBIG;
   constexpr size_t lds = (size_t)LDS_FLOATS * sizeof(float);      // 40 KB: two workgroups per CU
-  const float* b = mode == 0 ? bias : nullptr;
+  const float* b = (mode & 1) == 0 ? bias : nullptr;
   WinoArgs a{x, U, b, out, p.K, p.I, p.KP, p.IP, H, W, p.Ho, p.Wo, p.off, p.th, p.tw, slope, p.tile_shift, p.nsplit,
              p.chunks_per_split, partial, T, N, mask, mask_slope, out_unit16
 #ifdef WINO_TRACE
@@ -824,7 +829,7 @@ int launch_conv(const WinoPlan& p, const float* x, const float* U, const float* 
 
 int check_conv_args(WinoPlan& p, int N, int T, int Ci, int Co, int H, int W, int pad, int mode) {
   if (N <= 0 || T <= 0 || N % T != 0 || Ci <= 0 || Co <= 0 || H <= 0 || W <= 0) return SAVFI_E_SHAPE;
-  if ((mode != 0 && mode != 1) || (pad != 0 && pad != 1) || (int64_t)H * W < 4) return SAVFI_E_UNSUPPORTED;   // rows are 16-byte loads
+  if ((mode & ~3) || (pad != 0 && pad != 1) || (int64_t)H * W < 4) return SAVFI_E_UNSUPPORTED;   // rows are 16-byte loads
   if (!make_plan(p, N, Ci, Co, H, W, pad, mode)) return SAVFI_E_SHAPE;
   // 32-bit byte offsets inside a channel plane, and 0x80000000 must lie beyond the input and the output plane
   if ((int64_t)H * W >= ((int64_t)1 << 29) || (int64_t)p.Ho * p.Wo >= ((int64_t)1 << 29)) return SAVFI_E_TOOBIG;
@@ -845,7 +850,7 @@ extern "C" int savfi_conv3x3_tasks_f32(const float* x, const float* w, const flo
   if (int e = check_conv_args(p, N, T, Ci, Co, H, W, pad, mode)) return e;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(wino_filter_transform, dim3(p.KP / 4, savfi_cdiv(p.IP, 64) * T), dim3(256), 0, st, w, workspace, Co, Ci, p.K,
-                     p.I, p.KP, p.IP, mode);
+                     p.I, p.KP, p.IP, mode & 1, p.f4 ? 1 : 0);
   if (int e = savfi_launch_status()) return e;
   return launch_conv(p, x, workspace, bias, out, workspace + (int64_t)T * p.u_floats, N, T, H, W, mode, slope, st);
 }
@@ -856,29 +861,36 @@ extern "C" int savfi_conv3x3_tasks_f32(const float* x, const float* w, const flo
 // with an already transformed filter (workspace: savfi_conv3x3_tasks_workspace_floats minus the filter, i.e.
 // savfi_conv3x3_tasks_pre_workspace_floats, possibly 0 -> may be NULL).
 extern "C" int64_t savfi_conv3x3_filter_floats(int T, int Ci, int Co, int mode) {
-  if (T <= 0 || Ci <= 0 || Co <= 0 || (mode != 0 && mode != 1)) return SAVFI_E_SHAPE;
-  const int K = mode == 0 ? Ci : Co, I = mode == 0 ? Co : Ci;
-  return (int64_t)T * u_floats_for(K, I);
+  if (T <= 0 || Ci <= 0 || Co <= 0 || (mode & ~3)) return SAVFI_E_SHAPE;
+  const int K = (mode & 1) == 0 ? Ci : Co, I = (mode & 1) == 0 ? Co : Ci;
+  return (int64_t)T * u_floats_for(K, I, (mode & 2) ? 2 : 0);
 }
 
-extern "C" int savfi_conv3x3_filters_f32(const float* w, float* u_fwd, float* u_bwd, int T, int Ci, int Co, void* stream) {
+// `form` 0: the kernel form follows the channel counts; 2: the F(2x2) form (for a layer the caller will run with bit 1 of `mode` set)
+extern "C" int savfi_conv3x3_filters_form_f32(const float* w, float* u_fwd, float* u_bwd, int T, int Ci, int Co, int form, void* stream) {
   if (!w || (!u_fwd && !u_bwd)) return SAVFI_E_NULL;
   if (T <= 0 || T > 65535 || Ci <= 0 || Co <= 0) return SAVFI_E_SHAPE;
-  const int KPf = kp_for(Ci, Co), IPf = ip_for(Ci, Co), KPb = kp_for(Co, Ci), IPb = ip_for(Co, Ci);
+  if (form != 0 && form != 2) return SAVFI_E_UNSUPPORTED;
+  const int KPf = kp_for(Ci, Co, form), IPf = ip_for(Ci, Co, form), KPb = kp_for(Co, Ci, form), IPb = ip_for(Co, Ci, form);
+  const int f4 = f4_for(Ci, Co, form) ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
   if (u_fwd && u_bwd) {
     const int gx = (KPf > KPb ? KPf : KPb) / 4, gy = savfi_cdiv(IPf > IPb ? IPf : IPb, 64) * T;
-    hipLaunchKernelGGL(wino_filter_transform_dual, dim3(gx, gy, 2), dim3(256), 0, st, w, u_fwd, u_bwd, Co, Ci, KPf, IPf, KPb, IPb, T);
+    hipLaunchKernelGGL(wino_filter_transform_dual, dim3(gx, gy, 2), dim3(256), 0, st, w, u_fwd, u_bwd, Co, Ci, KPf, IPf, KPb, IPb, T, f4);
   } else if (u_fwd) {
-    hipLaunchKernelGGL(wino_filter_transform, dim3(KPf / 4, savfi_cdiv(IPf, 64) * T), dim3(256), 0, st, w, u_fwd, Co, Ci, Ci, Co, KPf, IPf, 0);
+    hipLaunchKernelGGL(wino_filter_transform, dim3(KPf / 4, savfi_cdiv(IPf, 64) * T), dim3(256), 0, st, w, u_fwd, Co, Ci, Ci, Co, KPf, IPf, 0, f4);
   } else {
-    hipLaunchKernelGGL(wino_filter_transform, dim3(KPb / 4, savfi_cdiv(IPb, 64) * T), dim3(256), 0, st, w, u_bwd, Co, Ci, Co, Ci, KPb, IPb, 1);
+    hipLaunchKernelGGL(wino_filter_transform, dim3(KPb / 4, savfi_cdiv(IPb, 64) * T), dim3(256), 0, st, w, u_bwd, Co, Ci, Co, Ci, KPb, IPb, 1, f4);
   }
   return savfi_launch_status();
 }
+extern "C" int savfi_conv3x3_filters_f32(const float* w, float* u_fwd, float* u_bwd, int T, int Ci, int Co, void* stream) {
+  return savfi_conv3x3_filters_form_f32(w, u_fwd, u_bwd, T, Ci, Co, 0, stream);
+}
 
-extern "C" int savfi_conv3x3_filters_multi_f32(const float* const* w, float* const* u_fwd, float* const* u_bwd, const int* T,
-                                               const int* Ci, const int* Co, int n, void* stream) {
+// form: per layer, as savfi_conv3x3_filters_form_f32 (NULL: 0 for every layer)
+extern "C" int savfi_conv3x3_filters_multi_form_f32(const float* const* w, float* const* u_fwd, float* const* u_bwd, const int* T,
+                                                    const int* Ci, const int* Co, const int* form, int n, void* stream) {
   if (!w || !u_fwd || !u_bwd || !T || !Ci || !Co) return SAVFI_E_NULL;
   if (n <= 0) return SAVFI_E_SHAPE;
   FtTable tb;
@@ -894,6 +906,8 @@ extern "C" int savfi_conv3x3_filters_multi_f32(const float* const* w, float* con
   for (int i = 0; i < n; ++i) {
     if (!w[i] || (!u_fwd[i] && !u_bwd[i])) return SAVFI_E_NULL;
     if (T[i] <= 0 || T[i] > 65535 || Ci[i] <= 0 || Co[i] <= 0) return SAVFI_E_SHAPE;
+    const int fm = form ? form[i] : 0;
+    if (fm != 0 && fm != 2) return SAVFI_E_UNSUPPORTED;
     for (int mode = 0; mode < 2; ++mode) {
       float* dst = mode == 0 ? u_fwd[i] : u_bwd[i];
       if (!dst) continue;
@@ -901,11 +915,11 @@ extern "C" int savfi_conv3x3_filters_multi_f32(const float* const* w, float* con
       j.w = w[i]; j.U = dst; j.Co = Co[i]; j.Ci = Ci[i]; j.mode = mode;
       j.K = mode == 0 ? Ci[i] : Co[i];
       j.I = mode == 0 ? Co[i] : Ci[i];
-      j.KP = kp_for(j.K, j.I);
-      j.IP = ip_for(j.K, j.I);
+      j.KP = kp_for(j.K, j.I, fm);
+      j.IP = ip_for(j.K, j.I, fm);
       j.nbx = j.KP / 4;
       j.first_block = blocks;
-      j.pad_ = 0;
+      j.f4 = f4_for(j.K, j.I, fm) ? 1 : 0;
       blocks += j.nbx * savfi_cdiv(j.IP, 64) * T[i];
       if (++tb.n == WINO_FT_JOBS) {
         const int rc = flush();
@@ -914,6 +928,10 @@ extern "C" int savfi_conv3x3_filters_multi_f32(const float* const* w, float* con
     }
   }
   return flush();
+}
+extern "C" int savfi_conv3x3_filters_multi_f32(const float* const* w, float* const* u_fwd, float* const* u_bwd, const int* T,
+                                               const int* Ci, const int* Co, int n, void* stream) {
+  return savfi_conv3x3_filters_multi_form_f32(w, u_fwd, u_bwd, T, Ci, Co, nullptr, n, stream);
 }
 
 extern "C" int64_t savfi_conv3x3_tasks_pre_workspace_floats(int N, int T, int Ci, int Co, int H, int W, int pad, int mode) {
@@ -977,13 +995,19 @@ extern "C" int savfi_conv3x3_dgrad_in_unit16_f32(const float* gy, const float* u
 
 // data gradient (mode 1) on a transformed filter with the activation derivative of the layer that produced this convolution's input
 // folded into the output stage: gx = dgrad(gy) * (mask > 0 ? 1 : mask_slope), mask [N,Ci,H+2-2pad,W+2-2pad] = the forward input
-extern "C" int savfi_conv3x3_dgrad_masked_f32(const float* gy, const float* u, const float* mask, float mask_slope, float* gx,
-                                              float* workspace, int N, int T, int Ci, int Co, int H, int W, int pad, void* stream) {
+extern "C" int savfi_conv3x3_dgrad_masked_form_f32(const float* gy, const float* u, const float* mask, float mask_slope, float* gx,
+                                                   float* workspace, int N, int T, int Ci, int Co, int H, int W, int pad, int form,
+                                                   void* stream) {
   if (!gy || !u || !gx || !mask) return SAVFI_E_NULL;
+  if (form != 0 && form != 2) return SAVFI_E_UNSUPPORTED;
   WinoPlan p;
-  if (int e = check_conv_args(p, N, T, Ci, Co, H, W, pad, 1)) return e;
+  if (int e = check_conv_args(p, N, T, Ci, Co, H, W, pad, 1 | form)) return e;
   if (p.partial_floats > 0 && !workspace) return SAVFI_E_NULL;
   return launch_conv(p, gy, u, nullptr, gx, workspace, N, T, H, W, 1, 1.f, (hipStream_t)stream, mask, mask_slope);
+}
+extern "C" int savfi_conv3x3_dgrad_masked_f32(const float* gy, const float* u, const float* mask, float mask_slope, float* gx,
+                                              float* workspace, int N, int T, int Ci, int Co, int H, int W, int pad, void* stream) {
+  return savfi_conv3x3_dgrad_masked_form_f32(gy, u, mask, mask_slope, gx, workspace, N, T, Ci, Co, H, W, pad, 0, stream);
 }
 
 extern "C" int savfi_conv3x3_f32(const float* x, const float* w, const float* bias, float* out, float* workspace,

@@ -733,7 +733,6 @@ def _wgrad_wino(N, Ci, Co, Ho, Wo):
 #        direct form because it amplifies Winograd rounding (VoxelFlow: `direct=True`).
 CONVK = True
 CONVK_3X3_MIN_PIXELS = 700
-CONVK_3X3_SMALL_LAUNCH_MIN_PIXELS = 200
 
 
 CONVK_WGRAD3_RING_MIN_PIXELS = 3000
@@ -813,22 +812,20 @@ def convk_eligible(x, weight, stride, padding, dilation, groups=1, direct=False)
         return False
     if K != 3 or direct:
         return True
-    if Ci <= 8:
-        return Ho * Wo >= CONVK_3X3_MIN_PIXELS      # (an F(4x4) chunk is 8 reduction channels, half of them padding for 6 -> 32)
-    if not (Ci >= 64 and Co >= 64 and Co % 64 == 0):
+    if not (Ho * Wo >= CONVK_3X3_MIN_PIXELS and (Ci <= 8 or (Ci >= 64 and Co >= 64 and Co % 64 == 0))):
         return False
-    if pad > 1 or not WINOGRAD_CONV:
-        return Ho * Wo >= CONVK_3X3_MIN_PIXELS
-    f4 = wino4_workgroups(int(x.shape[0]), int(Ci), int(Co), int(H), int(W), int(pad))
-    if f4 >= WINO4_MIN_WORKGROUPS:
-        return False                                # the F(4x4) launch fills the chip
-    # A launch too small for F(4x4) to pay: the direct kernel, on maps below 700 pixels too -- F(4x4) rounds 5x coarser than the direct sum
-    # (3e-7 rms of the result's scale), which an Adam-type inner rule turns into flipped steps of the elements whose gradient is
-    # rounding noise (CAIN 64 x 64 + Adam: the 192 -> 192 layers on 16 x 16 maps); where the form buys no time it is not worth that.
-    # (f4 == 0: beyond 512 channels the library's F(2x2) kernel serves the small maps as before.)
-    # Maps below ~200 pixels never reached a Winograd kernel (conv3x3_*_eligible: too few tiles) and stay with MIOpen: config C1's 8 x 8
-    # maps are launch-bound, and the direct kernel's single workgroup per map walks the whole reduction alone (44 -> 25 steps/s).
-    return Ho * Wo >= CONVK_3X3_MIN_PIXELS or (f4 > 0 and Ho * Wo >= CONVK_3X3_SMALL_LAUNCH_MIN_PIXELS)
+    # (the <= 8-channel input layers stay here: an F(4x4) chunk is 8 reduction channels, half of them padding for 6 -> 32)
+    return Ci <= 8 or pad > 1 or not WINOGRAD_CONV or wino4_workgroups(int(x.shape[0]), int(Ci), int(Co), int(H), int(W), int(pad)) < WINO4_MIN_WORKGROUPS
+
+
+def wino_form2(x, weight, pad):
+    """Does a layer on the Winograd route run the F(2x2) kernel although its channel counts would put it on F(4x4)?  Yes where the F(4x4)
+    launch would not fill the chip (small maps: the 64 x 64 fixtures, config C1): F(2x2) splits its reduction from 128 workgroups down and
+    rounds 5x finer (an Adam-type inner rule turns F(4x4)'s rounding into flipped steps of the elements whose gradient is rounding
+    noise: CAIN 64 x 64 + Adam).  The filters of such a layer are kind 'wino2' (savfi_conv3x3_*_form_f32 / bit 1 of `mode`)."""
+    Co, Ci = weight.shape[-4], weight.shape[-3]
+    n = wino4_workgroups(int(x.shape[0]), int(Ci), int(Co), int(x.shape[2]), int(x.shape[3]), int(pad))
+    return 0 < n < WINO4_MIN_WORKGROUPS
 
 
 # Packed / transformed filters of a module's OWN parameters are cached per weight version: a first-order meta-iteration
@@ -841,7 +838,7 @@ _FILTER_CACHE_PER_MODULE = 6
 
 
 def _filters(kind, weight, fwd, bwd, cache):
-    make = convk_filters if kind == 'convk' else conv3x3_filters
+    make = convk_filters if kind == 'convk' else (conv3x3_filters if kind == 'wino' else (lambda w_, f_, b_: conv3x3_filters(w_, f_, b_, f2=True)))
     if cache is None or torch.cuda.is_current_stream_capturing():
         return make(weight, fwd, bwd)
     key = (kind, weight.data_ptr(), weight._version, tuple(weight.shape), weight.device.index, _hip.current_stream())
@@ -960,9 +957,9 @@ class _ConvBiasAct(torch.autograd.Function):
             ctx.route = 'convk'
         elif conv3x3_eligible(x, w, stride, padding, dilation, groups):
             want_bwd = ctx.needs_input_grad[0] and conv3x3_eligible(x, w, stride, padding, dilation, groups, backward=True)
-            u_fwd, ctx.u_bwd = _filters('wino', w, True, want_bwd, cache)
-            z = conv3x3_tasks_pre(x, u_fwd, 1, w.shape[1], w.shape[0], b, 0, slope, pad)
-            ctx.route = 'wino'
+            ctx.route = 'wino2' if wino_form2(x, w, pad) else 'wino'
+            u_fwd, ctx.u_bwd = _filters(ctx.route, w, True, want_bwd, cache)
+            z = conv3x3_tasks_pre(x, u_fwd, 1, w.shape[1], w.shape[0], b, 0, slope, pad, f2=ctx.route == 'wino2')
         else:
             z = torch.nn.functional.conv2d(x, w, None, stride, padding, dilation, groups)
             if not z.is_contiguous():
@@ -1019,8 +1016,9 @@ class _ConvBiasAct(torch.autograd.Function):
             gw = convk_wgrad_tasks(x, gz, 1, K, pad, ctx.direct, True)[0]
             need_w = False
         elif need_x and conv3x3_eligible(x, w, stride, padding, dilation, groups, backward=True):
-            if u_bwd is not None and ctx.route == 'wino':
-                gx = conv3x3_tasks_pre(gz, u_bwd, 1, w.shape[1], w.shape[0], None, 1, 1.0, pad, mask=mask, mask_slope=mslope)
+            if u_bwd is not None and ctx.route in ('wino', 'wino2'):
+                gx = conv3x3_tasks_pre(gz, u_bwd, 1, w.shape[1], w.shape[0], None, 1, 1.0, pad, mask=mask, mask_slope=mslope,
+                                       f2=ctx.route == 'wino2')
                 mask = None
             else:
                 gx = conv3x3(gz, w, None, 1, 1.0, pad)
@@ -1103,8 +1101,9 @@ def conv3x3_wgrad_tasks_eligible(x, weight, stride, padding, dilation):
     return Ho * Wo >= TASKS_WGRAD_MIN_PIXELS or (Ho > 0 and Wo > 0 and _wgrad_wino(N, Ci, weight.shape[1], Ho, Wo))
 
 
-def conv3x3_tasks(x, weight, bias=None, mode=0, slope=1.0, pad=1):
-    """savfi_conv3x3_tasks_f32 without autograd: weight [T,Co,Ci,3,3], bias [T,Co] or None; sample n uses task n % T."""
+def conv3x3_tasks(x, weight, bias=None, mode=0, slope=1.0, pad=1, f2=False):
+    """savfi_conv3x3_tasks_f32 without autograd: weight [T,Co,Ci,3,3], bias [T,Co] or None; sample n uses task n % T.  f2: the F(2x2) form."""
+    fbit = 2 if f2 else 0
     x, weight = x.contiguous(), weight.contiguous()
     _hip.require_cuda(x, weight)
     N, _, H, W = x.shape
@@ -1113,11 +1112,11 @@ def conv3x3_tasks(x, weight, bias=None, mode=0, slope=1.0, pad=1):
     I = Co if mode == 0 else Ci
     grow = 2 * (pad if mode == 0 else 2 - pad) - 2
     lib = _hip.lib()
-    ws = torch.empty(_workspace_floats("savfi_conv3x3_tasks_workspace_floats", N, T, Ci, Co, H, W, int(pad), mode), dtype=x.dtype, device=x.device)
+    ws = torch.empty(_workspace_floats("savfi_conv3x3_tasks_workspace_floats", N, T, Ci, Co, H, W, int(pad), mode | fbit), dtype=x.dtype, device=x.device)
     out = torch.empty((N, I, H + grow, W + grow), dtype=x.dtype, device=x.device)
     _hip.launch(_conv3x3_name(Ci, Co, "fwd" if mode == 0 else "bwd_data"), lambda: _hip.check(lib.savfi_conv3x3_tasks_f32(
         x.data_ptr(), weight.data_ptr(), None if bias is None else bias.data_ptr(), out.data_ptr(), ws.data_ptr(),
-        N, T, Ci, Co, H, W, int(pad), mode, float(slope), _hip.current_stream()), "savfi_conv3x3_tasks_f32"),
+        N, T, Ci, Co, H, W, int(pad), mode | fbit, float(slope), _hip.current_stream()), "savfi_conv3x3_tasks_f32"),
         flops=18.0 * Ci * Co * out.shape[2] * out.shape[3] * N if mode == 0 else 18.0 * Ci * Co * H * W * N)
     return out
 
@@ -1155,7 +1154,7 @@ def filters_after_update(outs):
     plan = _pack_plans.get(sig)
     if not plan:
         return
-    for kind in ('convk', 'wino'):
+    for kind in ('convk', 'wino', 'wino2'):
         jobs = [(outs[i], e[1], e[2]) for i, e in sorted(plan.items()) if e[0] == kind]
         for (w, _, _), (tf, tb) in zip(jobs, _filters_multi(kind, jobs)):
             _prepacked[(kind, w.data_ptr())] = (w, w._version, tf, tb)
@@ -1175,8 +1174,9 @@ def _filters_multi(kind, jobs):
             nf = _workspace_floats("savfi_convk_filter_floats", T, Ci, Co, K, 0) if f else 0
             nb = _workspace_floats("savfi_convk_filter_floats", T, Ci, Co, K, 1) if b else 0
         else:
-            nf = _workspace_floats("savfi_conv3x3_filter_floats", T, Ci, Co, 0) if f else 0
-            nb = _workspace_floats("savfi_conv3x3_filter_floats", T, Ci, Co, 1) if b else 0
+            fbit = 2 if kind == 'wino2' else 0
+            nf = _workspace_floats("savfi_conv3x3_filter_floats", T, Ci, Co, 0 | fbit) if f else 0
+            nb = _workspace_floats("savfi_conv3x3_filter_floats", T, Ci, Co, 1 | fbit) if b else 0
         nf, nb = (nf + 63) // 64 * 64, (nb + 63) // 64 * 64          # 256-byte aligned slices
         sizes.append((total, nf, total + nf, nb))
         total += nf + nb
@@ -1197,8 +1197,9 @@ def _filters_multi(kind, jobs):
         _hip.launch("convk_filters_multi", lambda: _hip.check(lib.savfi_convk_filters_multi_f32(
             pw, pf, pb, aT, aCi, aCo, aK, n, _hip.current_stream()), "savfi_convk_filters_multi_f32"))
     else:
-        _hip.launch("conv3x3_filters_multi", lambda: _hip.check(lib.savfi_conv3x3_filters_multi_f32(
-            pw, pf, pb, aT, aCi, aCo, n, _hip.current_stream()), "savfi_conv3x3_filters_multi_f32"))
+        aF = IA(*([2 if kind == 'wino2' else 0] * n))
+        _hip.launch("conv3x3_filters_multi", lambda: _hip.check(lib.savfi_conv3x3_filters_multi_form_f32(
+            pw, pf, pb, aT, aCi, aCo, aF, n, _hip.current_stream()), "savfi_conv3x3_filters_multi_form_f32"))
     return made
 
 
@@ -1208,7 +1209,7 @@ def refresh_module_filters(modules):
     if not PREPACK or torch.cuda.is_current_stream_capturing():
         return
     st = _hip.current_stream()
-    jobs = {'convk': [], 'wino': []}
+    jobs = {'convk': [], 'wino': [], 'wino2': []}
     for m in modules:
         cache, w = getattr(m, '_filters', None), getattr(m, 'weight', None)
         if not cache or w is None or not w.is_cuda or not w.is_contiguous():
@@ -1315,29 +1316,31 @@ def _note_filter_use(kind, weight, fwd, bwd):
         entry[1], entry[2] = entry[1] or bool(fwd), entry[2] or bool(bwd)
 
 
-def conv3x3_filters(weight, fwd=True, bwd=True):
-    """savfi_conv3x3_filters_f32: the Winograd transforms of weight [T,Co,Ci,3,3] (or [Co,Ci,3,3]) for the forward pass and / or
-    the data gradient, in ONE launch.  Returns (u_fwd, u_bwd); an entry is None when not asked for."""
+def conv3x3_filters(weight, fwd=True, bwd=True, f2=False):
+    """savfi_conv3x3_filters_form_f32: the Winograd transforms of weight [T,Co,Ci,3,3] (or [Co,Ci,3,3]) for the forward pass and / or
+    the data gradient, in ONE launch.  Returns (u_fwd, u_bwd); an entry is None when not asked for.  f2: the F(2x2) form whatever the
+    channel counts (kind 'wino2': wino_form2) -- such filters go with conv3x3_tasks_pre(..., f2=True) only."""
+    kind, fbit = ('wino2', 2) if f2 else ('wino', 0)
     weight = weight.contiguous()
     _hip.require_cuda(weight)
     T, Co, Ci = (1,) + tuple(weight.shape[:2]) if weight.dim() == 4 else tuple(weight.shape[:3])
     assert tuple(weight.shape[-2:]) == (3, 3) and (fwd or bwd), weight.shape
-    ready = _prepacked_filters('wino', weight, fwd, bwd)
+    ready = _prepacked_filters(kind, weight, fwd, bwd)
     if ready is not None:
         return ready
 
     def make(fwd, bwd):
         lib = _hip.lib()
-        us = [torch.empty(_workspace_floats("savfi_conv3x3_filter_floats", T, Ci, Co, mode), dtype=weight.dtype, device=weight.device) if want else None
+        us = [torch.empty(_workspace_floats("savfi_conv3x3_filter_floats", T, Ci, Co, mode | fbit), dtype=weight.dtype, device=weight.device) if want else None
               for mode, want in ((0, fwd), (1, bwd))]
-        _hip.launch("conv3x3_filters", lambda: _hip.check(lib.savfi_conv3x3_filters_f32(
-            weight.data_ptr(), None if us[0] is None else us[0].data_ptr(), None if us[1] is None else us[1].data_ptr(), T, Ci, Co,
-            _hip.current_stream()), "savfi_conv3x3_filters_f32"))
+        _hip.launch("conv3x3_filters", lambda: _hip.check(lib.savfi_conv3x3_filters_form_f32(
+            weight.data_ptr(), None if us[0] is None else us[0].data_ptr(), None if us[1] is None else us[1].data_ptr(), T, Ci, Co, fbit,
+            _hip.current_stream()), "savfi_conv3x3_filters_form_f32"))
         return us[0], us[1]
-    ready = _const_filters('wino', weight, fwd, bwd, make)
+    ready = _const_filters(kind, weight, fwd, bwd, make)
     if ready is not None:
         return ready
-    _note_filter_use('wino', weight, fwd, bwd)
+    _note_filter_use(kind, weight, fwd, bwd)
     return make(fwd, bwd)
 
 
@@ -1345,6 +1348,8 @@ def conv3x3_unit16_supported(x, w, pad):
     """Can the 3x3 layer (x [N,Ci,H,W], task weights w [T,Co,Ci,3,3], zero padding `pad`) write its result unit-major
     (savfi_conv3x3_tasks_pre_unit16_f32)?  It runs on the Winograd kernel, its width is a multiple of 16, no reduction split."""
     if not (x.is_cuda and w.dim() == 5 and conv3x3_tasks_eligible(x, w, 1, pad, 1) and not convk_eligible(x, w, 1, pad, 1, 1, False)):
+        return False
+    if wino_form2(x, w, pad):          # a small launch runs the F(2x2) form (kind 'wino2'), whose unit-major entry points are the form-0 ones
         return False
     N, Ci, H, W = x.shape
     return int(_hip.lib().savfi_conv3x3_unit16_supported(N, w.shape[0], Ci, w.shape[1], H, W, int(pad))) == 1
@@ -1371,49 +1376,52 @@ def conv3x3_dgrad_in_unit16(gy, u, T, Ci, Co, pad):
     return out
 
 
-def conv3x3_tasks_pre(x, u, T, Ci, Co, bias=None, mode=0, slope=1.0, pad=1, mask=None, mask_slope=1.0, out_unit16=False):
+def conv3x3_tasks_pre(x, u, T, Ci, Co, bias=None, mode=0, slope=1.0, pad=1, mask=None, mask_slope=1.0, out_unit16=False, f2=False):
     """savfi_conv3x3_tasks_pre_f32: conv3x3_tasks on a filter already transformed by conv3x3_filters (same mode).  `mask` (mode 1):
     the result is multiplied by (mask > 0 ? 1 : mask_slope) in the kernel's output stage (savfi_conv3x3_dgrad_masked_f32).
     `out_unit16` (mode 0): the result tensor has the usual shape [N,Co,Ho,Wo] but its MEMORY is unit-major, [N][Ho][Wo/16][Co][16]
-    (savfi_conv3x3_tasks_pre_unit16_f32) -- for FunctionSepconvPair(..., taps_unit16=True) only."""
+    (savfi_conv3x3_tasks_pre_unit16_f32) -- for FunctionSepconvPair(..., taps_unit16=True) only.  `f2`: `u` is a kind-'wino2' filter
+    (conv3x3_filters(..., f2=True)): the F(2x2) kernel (bit 1 of the C ABI's `mode`)."""
     x = x.contiguous()
     _hip.require_cuda(x, u)
+    fbit = 2 if f2 else 0
     if mask is not None:
         assert mode == 1 and bias is None and slope == 1.0
-        return _conv3x3_dgrad_masked(x, u, T, Ci, Co, pad, mask.contiguous(), mask_slope)
+        return _conv3x3_dgrad_masked(x, u, T, Ci, Co, pad, mask.contiguous(), mask_slope, fbit)
     N, _, H, W = x.shape
     assert N % T == 0 and x.shape[1] == (Ci if mode == 0 else Co), (x.shape, T, Ci, Co, mode)
     I = Co if mode == 0 else Ci
     grow = 2 * (pad if mode == 0 else 2 - pad) - 2
     lib = _hip.lib()
     if out_unit16:
-        assert mode == 0
+        assert mode == 0 and not f2
         out = torch.empty((N, I, H + grow, W + grow), dtype=x.dtype, device=x.device)
         _hip.launch(_conv3x3_name(Ci, Co, "fwd"), lambda: _hip.check(lib.savfi_conv3x3_tasks_pre_unit16_f32(
             x.data_ptr(), u.data_ptr(), None if bias is None else bias.data_ptr(), out.data_ptr(), N, T, Ci, Co, H, W, int(pad), float(slope),
             _hip.current_stream()), "savfi_conv3x3_tasks_pre_unit16_f32"), flops=18.0 * Ci * Co * out.shape[2] * out.shape[3] * N)
         return out
-    nws = _workspace_floats("savfi_conv3x3_tasks_pre_workspace_floats", N, T, Ci, Co, H, W, int(pad), mode)
+    nws = _workspace_floats("savfi_conv3x3_tasks_pre_workspace_floats", N, T, Ci, Co, H, W, int(pad), mode | fbit)
     ws = torch.empty(nws, dtype=x.dtype, device=x.device) if nws else None
     out = torch.empty((N, I, H + grow, W + grow), dtype=x.dtype, device=x.device)
-    _hip.launch(_conv3x3_name(Ci, Co, "fwd" if mode == 0 else "bwd_data"), lambda: _hip.check(lib.savfi_conv3x3_tasks_pre_f32(
+    name = ("conv3x3_" + ("fwd" if mode == 0 else "bwd_data")) if f2 else _conv3x3_name(Ci, Co, "fwd" if mode == 0 else "bwd_data")
+    _hip.launch(name, lambda: _hip.check(lib.savfi_conv3x3_tasks_pre_f32(
         x.data_ptr(), u.data_ptr(), None if bias is None else bias.data_ptr(), out.data_ptr(), None if ws is None else ws.data_ptr(),
-        N, T, Ci, Co, H, W, int(pad), mode, float(slope), _hip.current_stream()), "savfi_conv3x3_tasks_pre_f32"),
+        N, T, Ci, Co, H, W, int(pad), mode | fbit, float(slope), _hip.current_stream()), "savfi_conv3x3_tasks_pre_f32"),
         flops=18.0 * Ci * Co * out.shape[2] * out.shape[3] * N if mode == 0 else 18.0 * Ci * Co * H * W * N)
     return out
 
 
-def _conv3x3_dgrad_masked(gy, u, T, Ci, Co, pad, mask, mask_slope):
+def _conv3x3_dgrad_masked(gy, u, T, Ci, Co, pad, mask, mask_slope, fbit=0):
     N, _, H, W = gy.shape
     grow = 2 * (2 - pad) - 2
     out = torch.empty((N, Ci, H + grow, W + grow), dtype=gy.dtype, device=gy.device)
     assert mask.shape == out.shape, (mask.shape, out.shape)
     lib = _hip.lib()
-    nws = _workspace_floats("savfi_conv3x3_tasks_pre_workspace_floats", N, T, Ci, Co, H, W, int(pad), 1)
+    nws = _workspace_floats("savfi_conv3x3_tasks_pre_workspace_floats", N, T, Ci, Co, H, W, int(pad), 1 | fbit)
     ws = torch.empty(nws, dtype=gy.dtype, device=gy.device) if nws else None
-    _hip.launch(_conv3x3_name(Ci, Co, "bwd_data"), lambda: _hip.check(lib.savfi_conv3x3_dgrad_masked_f32(
+    _hip.launch("conv3x3_bwd_data" if fbit else _conv3x3_name(Ci, Co, "bwd_data"), lambda: _hip.check(lib.savfi_conv3x3_dgrad_masked_form_f32(
         gy.data_ptr(), u.data_ptr(), mask.data_ptr(), float(mask_slope), out.data_ptr(), None if ws is None else ws.data_ptr(),
-        N, T, Ci, Co, H, W, int(pad), _hip.current_stream()), "savfi_conv3x3_dgrad_masked_f32"), flops=18.0 * Ci * Co * H * W * N)
+        N, T, Ci, Co, H, W, int(pad), fbit, _hip.current_stream()), "savfi_conv3x3_dgrad_masked_form_f32"), flops=18.0 * Ci * Co * H * W * N)
     return out
 
 
@@ -1684,9 +1692,11 @@ class _ConvBiasActTasks(torch.autograd.Function):
         elif conv3x3_tasks_eligible(x, w, stride, padding, dilation):
             # both filter transforms of this layer in one launch: the data gradient of the same step will want the other one
             want_bwd = ctx.needs_input_grad[0] and conv3x3_tasks_eligible(x, w, stride, padding, dilation, backward=True)
-            u_fwd, ctx.u_bwd = conv3x3_filters(w, True, want_bwd)
-            z = conv3x3_tasks_pre(x, u_fwd, T, Ci, Co, b, 0, slope, pad, out_unit16=out_unit16)
-            ctx.route = 'wino'
+            f2 = wino_form2(x, w, pad)
+            assert not (f2 and out_unit16), "unit-major output: not on the F(2x2) form of a small launch (conv3x3_unit16_supported says so)"
+            u_fwd, ctx.u_bwd = conv3x3_filters(w, True, want_bwd, f2=f2)
+            z = conv3x3_tasks_pre(x, u_fwd, T, Ci, Co, b, 0, slope, pad, out_unit16=out_unit16, f2=f2)
+            ctx.route = 'wino2' if f2 else 'wino'
         else:
             if _grouped_ok(x):
                 z = torch.nn.functional.conv2d(x.view(n, T * Ci, H, W), w.reshape(T * Co, Ci, *w.shape[3:]), None, stride, padding,
@@ -1774,11 +1784,11 @@ class _ConvBiasActTasks(torch.autograd.Function):
             mask = None
             need_x = False
         elif need_x and conv3x3_tasks_eligible(x, w, stride, padding, dilation, backward=True):
-            if u_bwd is not None and ctx.route == 'wino':
-                gx = conv3x3_tasks_pre(gz, u_bwd, T, Ci, Co, None, 1, 1.0, pad, mask=mask, mask_slope=mslope)
+            if u_bwd is not None and ctx.route in ('wino', 'wino2'):
+                gx = conv3x3_tasks_pre(gz, u_bwd, T, Ci, Co, None, 1, 1.0, pad, mask=mask, mask_slope=mslope, f2=ctx.route == 'wino2')
                 mask = None
             else:
-                gx = conv3x3_tasks(gz, w, None, 1, 1.0, pad)
+                gx = conv3x3_tasks(gz, w, None, 1, 1.0, pad, f2=ctx.route == 'wino2')
             need_x = False
         if wgrad_is_convk:
             gw = convk_wgrad_tasks(x, gz, T, K, pad, ctx.direct, want_bias=fuse_b)

@@ -600,6 +600,35 @@ def test_conv3x3_split_entry_points_equal_the_fused_one(T, N, Ci, Co, H, W, pad)
             assert torch.equal(hip_ops.conv3x3_tasks_pre(gy, u_b, T, Ci, Co, None, 1, 1.0, pad), want_gx)
 
 
+@pytest.mark.parametrize("T,N,Ci,Co,H,W,pad", [(1, 2, 51, 51, 18, 30, 1), (4, 8, 192, 192, 16, 16, 1), (2, 4, 64, 32, 16, 64, 0)])
+def test_conv3x3_form2_keeps_small_launches_on_the_f2x2_kernel(T, N, Ci, Co, H, W, pad):
+    """A launch too small for F(4x4) to pay runs the F(2x2) kernel although its channel counts would select F(4x4) (hip_ops.wino_form2 ->
+    filters of kind 'wino2', bit 1 of the C ABI's `mode`): F(2x2)'s rounding bound (2e-6 of the scale) against float64, forward, data
+    gradient and masked data gradient; and the form-0 call of the same layer is the F(4x4) kernel (different bits)."""
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(N, Ci, H, W, generator=g)
+    w = torch.randn(T, Co, Ci, 3, 3, generator=g) / (3 * Ci ** 0.5)
+    b = torch.randn(T, Co, generator=g)
+    xc, wc, bc = x.to(DEV), w.to(DEV), b.to(DEV)
+    assert hip_ops.wino_form2(xc, wc, pad)
+    want = torch.cat([F.leaky_relu(F.conv2d(x[n:n + 1].double(), w[n % T].double(), b[n % T].double(), padding=pad), 0.2) for n in range(N)])
+    u_f, u_b = hip_ops.conv3x3_filters(wc, True, True, f2=True)
+    got = hip_ops.conv3x3_tasks_pre(xc, u_f, T, Ci, Co, bc, 0, 0.2, pad, f2=True)
+    assert (got.cpu().double() - want).abs().max() <= 2e-6 * want.abs().max()
+    assert torch.equal(got, hip_ops.conv3x3_tasks(xc, wc, bc, 0, 0.2, pad, f2=True))
+    assert not torch.equal(got, hip_ops.conv3x3_tasks(xc, wc, bc, 0, 0.2, pad))          # form 0: the F(4x4) kernel
+    gy = torch.randn(want.shape, generator=g)
+    wantg = torch.cat([F.conv_transpose2d(gy[n:n + 1].double(), w[n % T].double(), padding=pad) for n in range(N)])
+    gotg = hip_ops.conv3x3_tasks_pre(gy.to(DEV), u_b, T, Ci, Co, None, 1, 1.0, pad, f2=True)
+    assert (gotg.cpu().double() - wantg).abs().max() <= 2e-6 * wantg.abs().max()
+    mask = torch.randn(wantg.shape, generator=g).to(DEV)
+    gotm = hip_ops.conv3x3_tasks_pre(gy.to(DEV), u_b, T, Ci, Co, None, 1, 1.0, pad, mask=mask, mask_slope=0.1, f2=True)
+    assert torch.equal(gotm, gotg * torch.where(mask > 0, 1.0, 0.1))
+    # the layer's module-level route: conv_bias_act_tasks picks the form by the launch
+    y = hip_ops.conv_bias_act_tasks(xc, wc, bc, 1, pad, 1, 0.2)
+    assert torch.equal(y, got)
+
+
 @pytest.mark.parametrize("T,N,Ci,Co,H,W,pad", [(1, 1, 3, 5, 6, 8, 1), (1, 2, 32, 32, 16, 16, 1), (2, 4, 6, 32, 24, 40, 1), (1, 1, 64, 51, 37, 45, 1),
                                                (1, 2, 51, 51, 18, 30, 0), (4, 8, 32, 32, 20, 30, 1), (1, 1, 8, 8, 5, 7, 0), (2, 2, 40, 70, 9, 130, 1)])
 def test_conv3x3_wgrad_winograd_form_matches_autograd(T, N, Ci, Co, H, W, pad):

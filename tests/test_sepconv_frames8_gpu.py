@@ -251,9 +251,10 @@ def test_winograd_convolution_writes_unit_major_and_the_pair_op_reads_it():
     f1 = torch.randint(0, 256, (B, 3, Ho + K - 1, Wo + K - 1), generator=g).float().div(255).to(DEV)
     gO = torch.randn(B, 3, Ho, Wo, generator=g).to(DEV)
     assert hip_ops.conv3x3_unit16_supported(x, w, 0)
-    # (51 -> 51 runs on the F(4x4) kernel, which never splits its reduction: small launches qualify too; the F(2x2) kernel's split
-    # launches of deeper layers are refused -- test_unit_major_convolution_entry_points_refuse_what_they_cannot_do)
-    assert hip_ops.conv3x3_unit16_supported(x[:, :, :38, :66].contiguous(), w, 0)
+    # (a launch too small for the F(4x4) kernel to pay -- 40 workgroups -- runs the F(2x2) form, kind 'wino2', whose reduction is split: the
+    # plugin's gate says no; the library's form-0 entry point itself would take it:
+    # test_unit_major_convolution_entry_points_refuse_what_they_cannot_do)
+    assert not hip_ops.conv3x3_unit16_supported(x[:, :, :38, :66].contiguous(), w, 0)
     res = []
     for u16 in (False, True):
         xs, ws, bs = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
