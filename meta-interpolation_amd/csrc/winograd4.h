@@ -66,13 +66,17 @@ __device__ __forceinline__ void g_rows(const float (&g)[3], float (&t)[6]) {
   t[5] = g[2];
 }
 
+// One workgroup = 4 reduction channels (one k-step: chunk and s fixed) x 64 produced channels = the eight whole [18 x 64] fragment blocks
+// (2 channel blocks x 4 waves, 36 KB) of that k-step.  A thread's 36 values belong to 36 different 4-byte slots of those blocks: they meet
+// in LDS and leave as 16-byte stores of whole blocks (round 6: the scattered dword stores ran at 3.3 TB/s, and with 36 points per weight
+// the transforms of the fast weights are 2.3 GB per inner step of config C2 -- 4 ms per meta-iteration).
 __device__ __forceinline__ void filter_transform_block4(const float* __restrict__ w, float* __restrict__ U, int Co, int Ci, int K, int I,
                                                         int KP, int IP, int mode, int bx, int by) {
+  __shared__ __attribute__((aligned(16))) float stage[8 * 18 * 64];
   const int kk = threadIdx.x & 3, ii = threadIdx.x >> 2;
   const int nI = (IP + 63) / 64;
   const int k = 4 * bx + kk, i = 64 * (by % nI) + ii;
   const int task = by / nI;
-  if (i >= IP || k >= KP) return;
   w += (size_t)task * Co * Ci * 9;
   U += (size_t)task * PTS * KP * IP;
   float g[3][3];
@@ -94,8 +98,8 @@ __device__ __forceinline__ void filter_transform_block4(const float* __restrict_
 #pragma unroll
     for (int r = 0; r < 6; ++r) t[r][b] = o[r];
   }
-  const int chunk = k >> 3, s = (k >> 2) & 1, kg = k & 3, cob = i >> 5, cb = (i >> 4) & 1, il = i & 15, ncob = IP / COB;
-  const int lane = kg * 16 + il;
+  const int cbl = ii >> 5, cb = (ii >> 4) & 1, il = ii & 15;      // channel block of the pair, 16-channel half, lane column
+  const int lane = kk * 16 + il;
 #pragma unroll
   for (int r = 0; r < 6; ++r) {
     float o[6];
@@ -103,10 +107,23 @@ __device__ __forceinline__ void filter_transform_block4(const float* __restrict_
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
       const int xi = 6 * r + c, wave = xi / 9, v = 2 * (xi % 9) + cb;
-      float* blk = U + ((((size_t)chunk * ncob + cob) * 4 + wave) * 2 + s) * (18 * 64);
+      float* blk = stage + (cbl * 4 + wave) * (18 * 64);
       if (v < 16) blk[((v >> 2) * 64 + lane) * 4 + (v & 3)] = o[c];
       else blk[16 * 64 + lane * 2 + (v - 16)] = o[c];
     }
+  }
+  __syncthreads();
+  // block (cbl, wave) of this k-step -> U block (((chunk ncob + cob) 4 + wave) 2 + s)
+  const int chunk = bx >> 1, s2 = bx & 1, ncob = IP / COB, cob0 = 2 * (by % nI);
+  if (4 * bx >= KP) return;
+#pragma unroll
+  for (int it = 0; it < 8 * 18 * 64 / 4 / 256; ++it) {           // 9 float4 per thread
+    const int e = (it * 256 + threadIdx.x) * 4;                  // float index inside the 8 staged blocks
+    const int blkid = e / (18 * 64), off = e - blkid * (18 * 64);
+    const int cobq = cob0 + (blkid >> 2), wv = blkid & 3;
+    if (cobq >= ncob) continue;
+    float* dst = U + ((((size_t)chunk * ncob + cobq) * 4 + wv) * 2 + s2) * (18 * 64) + off;
+    *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(stage + e);
   }
 }
 

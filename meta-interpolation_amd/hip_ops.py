@@ -780,6 +780,7 @@ def _convk_geometry(weight, stride, padding, dilation, groups):
 # 164 / 160, 256 -> 256 @24x32 46 / 44 vs 57 / 56, 512 -> 512 @12x16 64 / 62 (F(2x2): 53; direct: 107).  Below ~180 workgroups (of 2 per CU x
 # 256 CUs = 512 slots) the direct kernel keeps the layer.
 WINO4_MIN_WORKGROUPS = 180
+WINO4_MIN_PIXELS = 400
 
 
 @functools.lru_cache(maxsize=None)
@@ -824,8 +825,14 @@ def wino_form2(x, weight, pad):
     rounds 5x finer (an Adam-type inner rule turns F(4x4)'s rounding into flipped steps of the elements whose gradient is rounding
     noise: CAIN 64 x 64 + Adam).  The filters of such a layer are kind 'wino2' (savfi_conv3x3_*_form_f32 / bit 1 of `mode`)."""
     Co, Ci = weight.shape[-4], weight.shape[-3]
-    n = wino4_workgroups(int(x.shape[0]), int(Ci), int(Co), int(x.shape[2]), int(x.shape[3]), int(pad))
-    return 0 < n < WINO4_MIN_WORKGROUPS
+    H, W = int(x.shape[2]), int(x.shape[3])
+    n = wino4_workgroups(int(x.shape[0]), int(Ci), int(Co), H, W, int(pad))
+    if n <= 0:
+        return False
+    # ... and on maps below ~400 pixels: a 12 x 16 map is 12 of a workgroup's 32 tiles, and the 36-point filter transform of a deep layer
+    # (2.25x F(2x2)'s: 151 MB per 512 -> 512 layer, direction and inner step at T = 4) costs more than the kernel saves there:
+    # 512 -> 512 @12x16, T = 4 x 2: 67 + 67 us + 92 us of transforms on F(4x4) against 53 + 52 + 41 on F(2x2)
+    return n < WINO4_MIN_WORKGROUPS or (H + 2 * pad - 2) * (W + 2 * pad - 2) < WINO4_MIN_PIXELS
 
 
 # Packed / transformed filters of a module's OWN parameters are cached per weight version: a first-order meta-iteration
