@@ -356,7 +356,8 @@ def main():
         # split operands with fp32 accumulation (csrc/convk.hip: as close to float64 as an fp32 fmaf chain)
         # the 51-tap op on frames of 8-bit images (k / 255, classified on the device at every call): the frame operand is the exact integer k
         # in ONE bf16 piece, so three exact bf16 products per fp32 product (csrc/sepconv_ws.hip)
-        "dtype": "f32 (convolutions on csrc/convk*.hip: bf16x6 split operands, f32 accumulate; 51-tap op on 8-bit frames: exact "
+        "dtype": "f32 (3x3 convolutions: Winograd F(4x4) / F(2x2) on exact-f32 MFMAs, csrc/winograd4.h + winograd.hip; weight gradients and "
+                 "5x5 / 7x7 / direct layers on csrc/convk*.hip: bf16x6 split operands, f32 accumulate; 51-tap op on 8-bit frames: exact "
                  "integer frames x bf16x3 split taps, f32 accumulate)", "data": "synthetic",
         "config": {"workload": opt.workload, "plugin": model, "tasks_per_gpu": tasks, "global_meta_batch": tasks * world,
                    "inner_steps": S, "frame": "%dx%dx3" % (H, W),
