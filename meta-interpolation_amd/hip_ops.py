@@ -537,7 +537,11 @@ def mt_scale_grads(gamma, weights, g_outs):
 def mt_scale(gamma, weights):
     """gamma float32[n] (device), weights list of n tensors -> [gamma[i] * weights[i]]."""
     ws = [w if w.is_contiguous() else w.contiguous() for w in weights]
-    return list(_MtScale.apply(gamma.contiguous(), *ws))
+    outs = list(_MtScale.apply(gamma.contiguous(), *ws))
+    # L2F's attenuated weights are born together like an update's fast weights: their filters in one launch per kind (config C5: 254
+    # single-layer transforms of ~9 us per meta-iteration otherwise); defined further down, with the plan it keeps per list of shapes
+    filters_after_update([o.detach() for o in outs])
+    return outs
 
 
 _ONES = {}
