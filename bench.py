@@ -386,7 +386,7 @@ def main():
                 # the op runs on the frame window (H x W) or, with --sepconv-window 0, on the reference's padded canvas
                 oh, ow = (H, W) if args.sepconv_window else net.padded_size(H, W)
                 traffic, tnote = None, "no committed PMC measurement found"
-                for tname in ("r05_hbm_traffic_sepconv.json", "r04_hbm_traffic_sepconv_frames8.json", "r04_hbm_traffic_sepconv.json", "r03_hbm_traffic_sepconv.json", "r02_hbm_traffic_sepconv.json", "r01_hbm_traffic_sepconv.json"):
+                for tname in ("r06_hbm_traffic_sepconv.json", "r05_hbm_traffic_sepconv.json", "r04_hbm_traffic_sepconv_frames8.json", "r04_hbm_traffic_sepconv.json", "r03_hbm_traffic_sepconv.json", "r02_hbm_traffic_sepconv.json", "r01_hbm_traffic_sepconv.json"):
                     tpath = os.path.join(REPO, "profiles", tname)
                     if not os.path.exists(tpath):
                         continue
