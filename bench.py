@@ -169,11 +169,9 @@ def parity_check(system, theta0, frames, model, H, W, S, oracle_res, dev, mode, 
                       "seeded theta, task 0 vs the CPU oracle of cpu_baseline, %d inner steps, %dx%d" % (how, mode, len(frames[0]), S, H, W)})
 
 
-def c4_parity_check(c4sys, theta0, c4frames, fix, dev, world):
-    """The timed 32-task system (its mode, its switches) against the REFERENCE's own run_train_iter over the 32 tasks
-    (tests/golden/full_c4b32_*.npz, oracle/gen_golden_fullsize.py): theta back to the seeded weights, outer step disabled, one more
-    meta-iteration with evaluation; the 32-task mean loss / PSNR and the frames of tasks 0 and 31 (single process: every task is local)."""
-    import numpy as np
+def c4_parity_run(c4sys, theta0, c4frames):
+    """One more meta-iteration of the timed 32-task system from the seeded state, outer step disabled, with evaluation.  Collective: every
+    rank calls it."""
     c4sys.load_state_dict(theta0)
     real_step = c4sys.optimizer.step
     c4sys.optimizer.step = lambda *a, **k: None
@@ -182,20 +180,34 @@ def c4_parity_check(c4sys, theta0, c4frames, fix, dev, world):
         torch.cuda.synchronize()
     finally:
         c4sys.optimizer.step = real_step
+    # (preds is indexed by the global task; a task another rank adapted is an empty entry here)
+    frame = lambda p: p.squeeze(0).detach().cpu().numpy() if torch.is_tensor(p) else None
+    # (task-parallel runs keep the LOCAL share in losses['loss'] -- it is what their backward starts from -- and the ranks' sum in 'loss_global')
+    return float(losses.get('loss_global', losses['loss'])), float(metrics['psnr'].avg), [frame(preds[0]), frame(preds[-1])]
+
+
+def c4_parity_eval(res, fix, world):
+    """The timed 32-task system (its mode, its switches) against the REFERENCE's run_train_iter over the 32 tasks
+    (tests/golden/full_c4b32_*.npz, oracle/gen_golden_fullsize.py): the 32-task mean loss / PSNR (after the ranks' logging reduce) and the
+    frame of task 0 (rank 0's first task at any world size); in a single process also task 31."""
+    import numpy as np
+    loss, psnr, (first, last) = res
     want = float(fix['train_loss'])
-    out = {"loss_rel": abs(float(losses['loss']) - want) / abs(want), "dpsnr_db": abs(float(metrics['psnr'].avg) - float(fix['train_psnr']))}
-    l1 = {}
-    if world == 1:
-        l1["task0"] = float(np.abs(preds[0].squeeze(0).cpu().numpy() - fix['train_pred']).mean())
+    out = {"loss_rel": abs(loss - want) / abs(want), "dpsnr_db": abs(psnr - float(fix['train_psnr']))}
+    l1, quant = {}, {}
+    if first is not None:
+        l1["task0"], quant["task0"] = float(np.abs(first - fix['train_pred']).mean()), 0.0
+    if world == 1 and last is not None:
         lo, hi = fix['train_task31_pred_q_range']
         ref = fix['train_task31_pred_u16_stride2'].astype(np.float64) / 65535.0 * (hi - lo) + lo
-        l1["task31"] = float(np.abs(preds[31].squeeze(0).cpu().numpy()[:, ::2, ::2] - ref).mean())
-        out["pixel_l1"] = l1
-        out["pixel_l1_quantisation"] = {"task0": 0.0, "task31": 0.5 * float(hi - lo) / 65535.0}
-    ok = out["loss_rel"] <= 1e-5 and out["dpsnr_db"] <= 1e-3 and all(v <= 1e-4 + out["pixel_l1_quantisation"][k] for k, v in l1.items())
+        l1["task31"] = float(np.abs(last[:, ::2, ::2] - ref).mean())
+        quant["task31"] = 0.5 * float(hi - lo) / 65535.0
+    out["pixel_l1"], out["pixel_l1_quantisation"] = l1, quant
+    ok = out["loss_rel"] <= 1e-5 and out["dpsnr_db"] <= 1e-3 and all(v <= 1e-4 + quant[k] for k, v in l1.items())
     out.update({"ok": bool(ok), "bounds": {"loss_rel": 1e-5, "pixel_l1": 1e-4, "dpsnr_db": 1e-3},
-                "sample": "the timed 32-task system in the timed mode against the imported reference's run_train_iter over the same 32 tasks "
-                          "(fixture full_c4b32_sepconv_msl_256x448_s5): 32-task mean loss and PSNR%s" % (", frames of tasks 0 and 31" if world == 1 else "")})
+                "sample": "the timed 32-task system in the timed mode (world size %d) against the imported reference's run_train_iter over the "
+                          "same 32 tasks (fixture full_c4b32_sepconv_msl_256x448_s5): 32-task mean loss and PSNR, frame of task 0%s"
+                          % (world, " and of task 31" if world == 1 else "")})
     return out
 
 
@@ -564,11 +576,15 @@ def main():
                              "ms_per_meta_iteration": 1e3 * c4el / c4steps, "outer_tasks_per_sec": 32 * c4steps / c4el,
                              "inner_steps_per_sec": 32 * c4S * c4steps / c4el, "allreduce": c4tp.allreduce_stats(),
                              "replicas_bit_identical": c4tp.replicas_identical([p for p in c4sys.parameters()]) if c4tp.active else None}
-        if c4fix is not None and rank == 0:
-            try:
-                line["strong_c4"]["parity_check"] = c4_parity_check(c4sys, c4theta0, c4frames, c4fix, dev, world)
-            except Exception as e:       # never lose the measurement over the checker
-                line["strong_c4"]["parity_check"] = {"ok": False, "error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        if c4fix is not None:
+            # EVERY rank runs the checked iteration (it holds the same collectives as a timed one: the all-reduce of the outer gradients,
+            # the logging reduce); rank 0 compares -- at N > 1 that is the RCCL path itself against the reference
+            c4res = c4_parity_run(c4sys, c4theta0, c4frames)
+            if rank == 0:
+                try:
+                    line["strong_c4"]["parity_check"] = c4_parity_eval(c4res, c4fix, world)
+                except Exception as e:       # never lose the measurement over the checker
+                    line["strong_c4"]["parity_check"] = {"ok": False, "error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         del c4sys, c4net, c4frames
         torch.cuda.empty_cache()
     if rank == 0:
