@@ -7,7 +7,7 @@
 // the SepConv tail (51 -> 51 @258x450, 64 -> 51, 32 -> 32 @384x512: 22 ms of a C2 meta-iteration at F(2x2)) the multiplies are
 // the cost.  Rounding: interpolation points 0, +-1, +-2, inf (Lavin & Gray); against float64 the fp32 result is 3.6e-7 rms /
 // 4.6e-6 max of the output's scale (direct fp32 sum: 7e-8 / 6e-7, F(2x2): 6e-8 / 4e-7; numpy transcription of the same
-// arithmetic, tools/wino4_rounding.py) -- two orders below north_star's 1e-4 pixel L1.  Deeper layers keep F(2x2) / the split-bf16
+// arithmetic, tools/r6/wino4_rounding.py) -- two orders below north_star's 1e-4 pixel L1.  Deeper layers keep F(2x2) / the split-bf16
 // direct kernel: their reduction splits, and the error of F(4x4) grows with the reduction length.
 //
 //   Y = A^T [ (G g G^T) (.) (B^T d B) ] A        per 4x4 output tile, d = its 6x6 input patch
