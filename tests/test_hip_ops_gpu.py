@@ -629,6 +629,48 @@ def test_conv3x3_form2_keeps_small_launches_on_the_f2x2_kernel(T, N, Ci, Co, H, 
     assert torch.equal(y, got)
 
 
+@pytest.mark.parametrize("T,N,Ci,Co,H,W,pad", [(4, 32, 51, 51, 258, 450, 0), (4, 8, 64, 64, 192, 256, 1), (4, 8, 512, 512, 24, 32, 1), (4, 8, 32, 32, 384, 512, 1)])
+def test_conv3x3_full_size_properties(T, N, Ci, Co, H, W, pad):
+    """The benchmark's layer shapes, where float64 references take minutes: size-independent properties of the F(4x4) kernel instead.
+    Adjointness -- <conv(x), y> == <x, dgrad(y)> (forward and data gradient are two launches on two filter transforms; unit-major in /
+    out where the layer has them); linearity in the input; a one-hot centre-tap filter routes channel ci to channel co and reproduces it
+    within the form's rounding."""
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(N, Ci, H, W, generator=g).to(DEV)
+    w = (torch.randn(T, Co, Ci, 3, 3, generator=g) / (3 * Ci ** 0.5)).to(DEV)
+    assert hip_ops.wino4_workgroups(N, Ci, Co, H, W, pad) >= hip_ops.WINO4_MIN_WORKGROUPS and not hip_ops.wino_form2(x, w, pad)
+    u_f, u_b = hip_ops.conv3x3_filters(w, True, True)
+    y = hip_ops.conv3x3_tasks_pre(x, u_f, T, Ci, Co, None, 0, 1.0, pad)
+    gy = torch.randn(y.shape, generator=g).to(DEV)
+    gx = hip_ops.conv3x3_tasks_pre(gy, u_b, T, Ci, Co, None, 1, 1.0, pad)
+    assert gx.shape == x.shape
+    lhs, rhs = (y.double() * gy.double()).sum().item(), (x.double() * gx.double()).sum().item()
+    scale = (y.double().abs() * gy.double().abs()).sum().item()
+    assert abs(lhs - rhs) <= 2e-6 * scale, (lhs, rhs, scale)
+    x2 = torch.randn(x.shape, generator=g).to(DEV)
+    y2 = hip_ops.conv3x3_tasks_pre(x2, u_f, T, Ci, Co, None, 0, 1.0, pad)
+    y12 = hip_ops.conv3x3_tasks_pre(x + 0.5 * x2, u_f, T, Ci, Co, None, 0, 1.0, pad)
+    assert (y12 - (y + 0.5 * y2)).abs().max().item() <= 2e-5 * y12.abs().max().item()
+    if y.shape[3] % 16 == 0 and hip_ops.conv3x3_unit16_supported(x, w, pad):          # the unit-major twins move the same bits
+        yu = hip_ops.conv3x3_tasks_pre(x, u_f, T, Ci, Co, None, 0, 1.0, pad, out_unit16=True)
+        B, K, Ho, Wo = y.shape
+        assert torch.equal(yu.reshape(B, Ho, Wo // 16, K, 16).permute(0, 3, 1, 2, 4).reshape(B, K, Ho, Wo), y)
+        if hip_ops.conv3x3_in_unit16_supported(tuple(gy.shape), w, pad):
+            gyu = gy.reshape(B, K, Ho, Wo // 16, 16).permute(0, 2, 3, 1, 4).contiguous().reshape(B, K, Ho, Wo)
+            assert torch.equal(hip_ops.conv3x3_dgrad_in_unit16(gyu, u_b, T, Ci, Co, pad), gx)
+    onehot = torch.zeros_like(w)
+    for t in range(T):
+        for co in range(Co):
+            onehot[t, co, (co * 7 + t) % Ci, 1, 1] = 1.0
+    u1, _ = hip_ops.conv3x3_filters(onehot, True, False)
+    z = hip_ops.conv3x3_tasks_pre(x, u1, T, Ci, Co, None, 0, 1.0, pad)
+    crop = slice(1 - pad, H - (1 - pad)), slice(1 - pad, W - (1 - pad))
+    for n in (0, N - 1):
+        t = n % T
+        src = torch.stack([x[n, (co * 7 + t) % Ci][crop] for co in range(Co)])
+        assert (z[n] - src).abs().max().item() <= 2e-5 * x.abs().max().item()
+
+
 @pytest.mark.parametrize("T,N,Ci,Co,H,W,pad", [(1, 1, 3, 5, 6, 8, 1), (1, 2, 32, 32, 16, 16, 1), (2, 4, 6, 32, 24, 40, 1), (1, 1, 64, 51, 37, 45, 1),
                                                (1, 2, 51, 51, 18, 30, 0), (4, 8, 32, 32, 20, 30, 1), (1, 1, 8, 8, 5, 7, 0), (2, 2, 40, 70, 9, 130, 1)])
 def test_conv3x3_wgrad_winograd_form_matches_autograd(T, N, Ci, Co, H, W, pad):
