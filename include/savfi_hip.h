@@ -56,7 +56,7 @@
 extern "C" {
 #endif
 
-#define SAVFI_ABI_VERSION 19
+#define SAVFI_ABI_VERSION 20
 
 #define SAVFI_OK            0
 #define SAVFI_E_NULL       (-1)  /* a required pointer is NULL                          */
@@ -459,6 +459,13 @@ int savfi_convk_tasks_pre_reflect_f32(const float* x, const float* packed, const
                                       void* stream);
 /* gx[planes,H,W] = adjoint of nn.ReflectionPad2d(pad) applied to gp[planes,H+2pad,W+2pad] (gather: deterministic, no zero fill) */
 int savfi_reflect_pad_bwd_f32(const float* gp, float* gx, int planes, int H, int W, int pad, void* stream);
+/* the same fold plus a second cotangent of the unpadded map: gx = fold(gp) + add (add[planes,H,W]; NULL = savfi_reflect_pad_bwd_f32).
+ * CAIN's RCAB (reference model_utils.py:957-990) pads x for its first convolution and adds x to its result: both gradients of x in
+ * one pass (ABI 20) */
+int savfi_reflect_pad_bwd_add_f32(const float* gp, const float* add, float* gx, int planes, int H, int W, int pad, void* stream);
+/* xp[planes,H+2pad,W+2pad] = nn.ReflectionPad2d(pad)(x[planes,H,W]) (reference model_utils.py:829, :838), pad < H, W: the padded copy
+ * the Winograd kernels read (ABI 20) */
+int savfi_reflect_pad_fwd_f32(const float* x, float* xp, int planes, int H, int W, int pad, void* stream);
 
 /* Weight gradient of the same convolution (same arithmetic; deterministic: per-workgroup partial blocks added in a fixed order):
  *   gw[T,Co,Ci,K,K], gw[t] = sum over samples n with n % T == t, y, x of gz[n,co,y,x] * x[n,ci,y+ky-pad,x+kx-pad]

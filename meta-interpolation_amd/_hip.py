@@ -16,7 +16,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_PKG_DIR), "include", "savfi_hip.h")
 
 RULE_SGD, RULE_ADAM, RULE_ADAMAX_LSLR, RULE_ADAMAX_MSGD = 0, 1, 2, 3
 LR_SCALAR, LR_ELEMENT = 0, 1
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 _ERRORS = {-1: "SAVFI_E_NULL (a required pointer is NULL)",
            -2: "SAVFI_E_SHAPE (bad or inconsistent dimension)",
@@ -104,6 +104,8 @@ _PROTOTYPES = {
     "savfi_convk_tasks_pre_reflect_f32": [_P, _P, _P, _P] + [c_int] * 9 + [c_float, c_int, c_int, _P],
     "savfi_convk_wgrad_tasks_reflect_f32": [_P, _P, _P, _P] + [c_int] * 10 + [_P],
     "savfi_reflect_pad_bwd_f32": [_P, _P, c_int, c_int, c_int, c_int, _P],
+    "savfi_reflect_pad_fwd_f32": [_P, _P, c_int, c_int, c_int, c_int, _P],
+    "savfi_reflect_pad_bwd_add_f32": [_P, _P, _P, c_int, c_int, c_int, c_int, _P],
     "savfi_convk_wgrad_workspace_floats": [c_int] * 8,
     "savfi_convk_wgrad_sums_bias": [c_int] * 8,
     "savfi_convk_wgrad_tasks_bias_f32": [_P, _P, _P, _P, _P] + [c_int] * 9 + [_P],

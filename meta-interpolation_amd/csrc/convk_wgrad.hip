@@ -626,10 +626,10 @@ __global__ __launch_bounds__(ring::NTHR, 1) void convk_wgrad3_ring(const WgArgs 
 
 // Sum of the partial blocks in a FIXED order (deterministic): a workgroup = 32 outputs x 8 split groups; thread (output, group)
 // adds the splits k = group (mod 8) in increasing order, the eight group sums meet in LDS and are added in group order.
-__global__ __launch_bounds__(256) void convk_wgrad_reduce(const float* __restrict__ partial, float* __restrict__ gw, long long n, int splits) {
+__device__ __forceinline__ void wgrad_reduce_block(const float* __restrict__ partial, float* __restrict__ out, long long n, int splits, unsigned block) {
   __shared__ float part[8][32];
   const int o = threadIdx.x & 31, grp = threadIdx.x >> 5;
-  const long long i = (long long)blockIdx.x * 32 + o;
+  const long long i = (long long)block * 32 + o;
   float s = 0.f;
   if (i < n)
     for (int k = grp; k < splits; k += 8) s += partial[(size_t)k * n + i];
@@ -639,8 +639,41 @@ __global__ __launch_bounds__(256) void convk_wgrad_reduce(const float* __restric
     float tot = part[0][o];
 #pragma unroll
     for (int q = 1; q < 8; ++q) tot += part[q][o];
-    gw[i] = tot;
+    out[i] = tot;
   }
+}
+
+// The same sums in the same order, four neighbouring outputs per thread as one 16-byte load per split (n a multiple of 4: every
+// partial block starts 16-byte aligned): a quarter of the workgroups, 512-byte runs per half wave instead of 128.
+__device__ __forceinline__ void wgrad_reduce_block4(const float* __restrict__ partial, float* __restrict__ out, long long n, int splits, unsigned block) {
+  __shared__ float4 part[8][32];
+  const int o = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const long long i = ((long long)block * 32 + o) * 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n)
+    for (int k = grp; k < splits; k += 8) {
+      const float4 v = *reinterpret_cast<const float4*>(partial + (size_t)k * n + i);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  part[grp][o] = s;
+  __syncthreads();
+  if (grp == 0 && i < n) {
+    float4 tot = part[0][o];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) { tot.x += part[q][o].x; tot.y += part[q][o].y; tot.z += part[q][o].z; tot.w += part[q][o].w; }
+    *reinterpret_cast<float4*>(out + i) = tot;
+  }
+}
+
+// ONE launch for the weight gradient and, behind its workgroups, the bias sums (a launch of their own was 4 us, 381 times in a CAIN
+// meta-iteration at 720p)
+template <bool V4>
+__global__ __launch_bounds__(256) void convk_wgrad_reduce(const float* __restrict__ partial, float* __restrict__ gw, long long n, int splits,
+                                                          unsigned main_blocks, const float* __restrict__ bias_partial, float* __restrict__ gb,
+                                                          long long nb) {
+  if (blockIdx.x >= main_blocks) { wgrad_reduce_block(bias_partial, gb, nb, splits, blockIdx.x - main_blocks); return; }
+  if (V4) wgrad_reduce_block4(partial, gw, n, splits, blockIdx.x);
+  else wgrad_reduce_block(partial, gw, n, splits, blockIdx.x);
 }
 
 struct WgPlan { int mt, nt, ng, cobs, cibs, units, upr, ups, splits, ups_per_split, form; };   // form (3 x 3): 0 taps dealt out to the waves, 2 all taps per wave on a ring of input rows
@@ -813,8 +846,11 @@ int convk_wgrad_run(const float* x, const float* gz, float* gw, float* gb, float
   else rc = launch_wgrad<7, 2, 1>(a, blocks, st);       // 13 taps per wave: no room for a second accumulator set
   if (rc != SAVFI_OK) return rc;
   const long long n = (long long)T * Co * Ci * K * K;
-  hipLaunchKernelGGL(convk_wgrad_reduce, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, st, workspace, gw, n, p.splits);
-  if (gb) hipLaunchKernelGGL(convk_wgrad_reduce, dim3((unsigned)((T * Co + 31) / 32)), dim3(256), 0, st, bias_partial, gb, (long long)T * Co, p.splits);
+  const bool v4 = n % 4 == 0 && (((uintptr_t)workspace | (uintptr_t)gw) & 15u) == 0;
+  const long long nb = gb ? (long long)T * Co : 0;
+  const unsigned main_blocks = (unsigned)(v4 ? (n / 4 + 31) / 32 : (n + 31) / 32), bias_blocks = (unsigned)((nb + 31) / 32);
+  if (v4) hipLaunchKernelGGL(convk_wgrad_reduce<true>, dim3(main_blocks + bias_blocks), dim3(256), 0, st, workspace, gw, n, p.splits, main_blocks, bias_partial, gb, nb);
+  else hipLaunchKernelGGL(convk_wgrad_reduce<false>, dim3(main_blocks + bias_blocks), dim3(256), 0, st, workspace, gw, n, p.splits, main_blocks, bias_partial, gb, nb);
   return savfi_launch_status();
 }
 }  // namespace

@@ -382,8 +382,8 @@ class _MtUpdate(torch.autograd.Function):
                 gos = [g_outs[i].contiguous() for i in idx]
                 dirs = [ctx.dirs[i] for i in idx]
                 dev = gos[0].device
-                if ctx.lr_mode == _hip.LR_SCALAR:
-                    dst = [torch.zeros((), dtype=torch.float32, device=dev) for _ in idx]
+                if ctx.lr_mode == _hip.LR_SCALAR:      # (one zero fill for all of them: 0-dim views of one buffer)
+                    dst = list(torch.zeros(len(idx), dtype=torch.float32, device=dev).unbind(0))
                 else:
                     dst = [torch.empty_like(go) for go in gos]
                 lib = _hip.lib()
@@ -1000,17 +1000,25 @@ class _ConvBiasAct(torch.autograd.Function):
         gz = gy if identity else torch.empty_like(gy)        # only the bias gradient is computed
         gb = torch.empty(C, dtype=gy.dtype, device=gy.device) if need_b else None
         mask, mslope = (x, ctx.in_slope) if (ctx.in_slope is not None and need_x) else (None, 1.0)
-        if need_b or not identity:
+        pad = padding if isinstance(padding, int) else padding[0]
+        K = int(w.shape[-1])
+        # the bias gradient rides on the all-taps weight-gradient kernel's staging of the cotangent where this function has nothing else
+        # to do with it (no activation, or its derivative left to the consumer): one pass over the map and two launches less per layer
+        wgrad_is_convk = bool(need_w and (ctx.reflect or (_convk_geometry(w, stride, padding, dilation, groups) is not None
+                                                          and (ctx.route == 'convk' or K == 3)
+                                                          and convk_wgrad_preferred(K, w.shape[1], w.shape[0], H, W, ctx.direct))))
+        fuse_b = bool(need_b and identity and wgrad_is_convk and convk_wgrad_tasks_sums_bias(x.shape, C, 1, K, pad, ctx.direct))
+        if fuse_b:
+            gb = None
+        if (need_b and not fuse_b) or not identity:
             lib = _hip.lib()
             scratch = (torch.empty(_workspace_floats("savfi_bias_act_scratch_floats", N, C, H * W), dtype=gy.dtype, device=gy.device)
-                       if need_b else None)
+                       if gb is not None else None)
             _hip.launch("bias_act_bwd", lambda: _hip.check(lib.savfi_bias_act_bwd_f32(
                 gy.data_ptr(), (gy if identity else y).data_ptr(), None if identity else gz.data_ptr(),
                 None if gb is None else gb.data_ptr(), None if scratch is None else scratch.data_ptr(),
                 N, C, H * W, 1.0 if identity else slope, _hip.current_stream()), "savfi_bias_act_bwd_f32"))
         gx = gw = None
-        pad = padding if isinstance(padding, int) else padding[0]
-        K = int(w.shape[-1])
         # the filter packed / transformed at forward time is only valid for the weight version the forward saw
         u_bwd = ctx.u_bwd if w._version == ctx.w_version else None
         ctx.u_bwd = None
@@ -1024,7 +1032,8 @@ class _ConvBiasAct(torch.autograd.Function):
                 mask = None
             need_x = False
         if need_w and ctx.reflect:
-            gw = convk_wgrad_tasks(x, gz, 1, K, pad, ctx.direct, True)[0]
+            res = convk_wgrad_tasks(x, gz, 1, K, pad, ctx.direct, True, want_bias=fuse_b)
+            gw, gb = (res[0][0], res[1][0]) if fuse_b else (res[0], gb)
             need_w = False
         elif need_x and conv3x3_eligible(x, w, stride, padding, dilation, groups, backward=True):
             if u_bwd is not None and ctx.route in ('wino', 'wino2'):
@@ -1038,7 +1047,8 @@ class _ConvBiasAct(torch.autograd.Function):
         # 5x5 / 7x7 layers and plugins that asked for the direct form: weight gradient on the split-bf16 kernel as well
         if need_w and _convk_geometry(w, stride, padding, dilation, groups) is not None and \
                 (ctx.route == 'convk' or K == 3) and convk_wgrad_preferred(K, w.shape[1], w.shape[0], gz.shape[2], gz.shape[3], ctx.direct):
-            gw = convk_wgrad_tasks(x, gz, 1, K, pad, ctx.direct)[0]
+            res = convk_wgrad_tasks(x, gz, 1, K, pad, ctx.direct, want_bias=fuse_b)
+            gw, gb = (res[0][0], res[1][0]) if fuse_b else (res[0], gb)
             need_w = False
         side = ctx.wg_stream if (ctx.wg_stream is not None and ctx.wg_uses[0] == 1) else None
         if need_w and side is not None:
@@ -1559,14 +1569,23 @@ def convk_wgrad_tasks(x, gz, T, K, pad, precise=False, reflect=False, want_bias=
     return gw
 
 
-def reflect_pad_bwd(gp, pad):
-    """savfi_reflect_pad_bwd_f32: the adjoint of nn.ReflectionPad2d(pad) as a gather; gp [N,C,H+2p,W+2p] -> [N,C,H,W]."""
+def reflect_pad_bwd(gp, pad, add=None):
+    """savfi_reflect_pad_bwd_f32: the adjoint of nn.ReflectionPad2d(pad) as a gather; gp [N,C,H+2p,W+2p] -> [N,C,H,W].
+    add [N,C,H,W]: a second cotangent of the unpadded map, added in the same pass (savfi_reflect_pad_bwd_add_f32)."""
     gp = gp.contiguous()
     _hip.require_cuda(gp)
     N, C, Hp, Wp = gp.shape
     H, W = Hp - 2 * pad, Wp - 2 * pad
     gx = torch.empty((N, C, H, W), dtype=gp.dtype, device=gp.device)
     lib = _hip.lib()
+    if add is not None:
+        add = add.contiguous()
+        _hip.require_cuda(add)
+        assert tuple(add.shape) == (N, C, H, W) and add.dtype == gp.dtype, (add.shape, gp.shape, pad)
+        _hip.launch("reflect_pad_bwd", lambda: _hip.check(lib.savfi_reflect_pad_bwd_add_f32(
+            gp.data_ptr(), add.data_ptr(), gx.data_ptr(), N * C, H, W, int(pad), _hip.current_stream()), "savfi_reflect_pad_bwd_add_f32"),
+            nbytes=4 * (gp.numel() + 2 * gx.numel()))
+        return gx
     _hip.launch("reflect_pad_bwd", lambda: _hip.check(lib.savfi_reflect_pad_bwd_f32(
         gp.data_ptr(), gx.data_ptr(), N * C, H, W, int(pad), _hip.current_stream()), "savfi_reflect_pad_bwd_f32"),
         nbytes=4 * (gp.numel() + gx.numel()))
@@ -1574,18 +1593,59 @@ def reflect_pad_bwd(gp, pad):
 
 
 class _ReflectPad(torch.autograd.Function):
-    """nn.ReflectionPad2d(pad): ATen's forward kernel, the adjoint as ONE gather launch (savfi_reflect_pad_bwd_f32) where ATen's
+    """nn.ReflectionPad2d(pad): savfi_reflect_pad_fwd_f32, the adjoint as ONE gather launch (savfi_reflect_pad_bwd_f32) where ATen's
     reflection_pad2d_backward zero-fills its result and scatters with atomics (two launches, order-dependent sums) -- the layers
     whose maps are too small for the mirrored staging of the direct kernels (CAIN at 64x64: 252 pads per meta-iteration)."""
 
     @staticmethod
     def forward(ctx, x, pad):
         ctx.pad = int(pad)
-        return torch.nn.functional.pad(x, (ctx.pad,) * 4, mode='reflect')
+        return _reflect_pad_fwd(x, ctx.pad)
 
     @staticmethod
     def backward(ctx, g):
         return reflect_pad_bwd(g, ctx.pad), None
+
+
+def _reflect_pad_fwd(x, p):
+    x = x.contiguous()
+    _hip.require_cuda(x)
+    N, C, H, W = x.shape
+    assert 0 <= p < H and p < W, (x.shape, p)
+    if N * C > 65535:          # beyond the launch grid's plane axis: ATen's kernel
+        return torch.nn.functional.pad(x, (p,) * 4, mode='reflect')
+    xp = torch.empty((N, C, H + 2 * p, W + 2 * p), dtype=x.dtype, device=x.device)
+    lib = _hip.lib()
+    _hip.launch("reflect_pad", lambda: _hip.check(lib.savfi_reflect_pad_fwd_f32(
+        x.data_ptr(), xp.data_ptr(), N * C, H, W, p, _hip.current_stream()), "savfi_reflect_pad_fwd_f32"),
+        nbytes=4 * (x.numel() + xp.numel()))
+    return xp
+
+
+class _ReflectPadSkip(torch.autograd.Function):
+    """(nn.ReflectionPad2d(pad)(x), x): the padded map for a convolution and the map itself for a connection round it (CAIN's RCAB,
+    reference model_utils.py:957-990).  The two cotangents of x arrive in ONE backward call and leave as one pass, fold(g_pad) + g_skip
+    (savfi_reflect_pad_bwd_add_f32), where autograd would add the fold's result and the skip gradient in an element-wise kernel of its own."""
+
+    @staticmethod
+    def forward(ctx, x, pad):
+        ctx.pad = int(pad)
+        ctx.set_materialize_grads(False)
+        return _reflect_pad_fwd(x, ctx.pad), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g_pad, g_skip):
+        if g_pad is None:
+            return g_skip, None
+        return reflect_pad_bwd(g_pad, ctx.pad, add=g_skip), None
+
+
+def reflect_pad_with_skip(x, pad):
+    """(nn.ReflectionPad2d(pad)(x), x) with the two gradients of x added inside the fold (_ReflectPadSkip); passes that need a
+    differentiable backward, CPU tensors and other dtypes: ATen's pad and x itself."""
+    if double_backward() or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 4:
+        return torch.nn.functional.pad(x, (int(pad),) * 4, mode='reflect'), x
+    return _ReflectPadSkip.apply(x, int(pad))
 
 
 def reflect_pad(x, pad):

@@ -269,16 +269,23 @@ class MetaConvNorm(nn.Module):
                                     use_bias=True)
         self.norm = norm
 
-    def forward(self, x, params=None, act_slope=None):
+    def forward(self, x, params=None, act_slope=None, in_slope=None, chain=None, want_skip=False):
+        """`chain` / `in_slope`: MetaConv2dLayer's conv -> act -> conv protocol, through the mirrored border: a padded map's ReLU mask is
+        the mirrored mask, so the consumer's data gradient masked by its PADDED input and then folded is d/dz of the producer.
+        `want_skip`: returns (result, x') with x' = x for a connection round this layer (an RCAB's skip): where a padded copy is made,
+        the cotangent that comes back along x' is added inside the pad's adjoint (hip_ops.reflect_pad_with_skip)."""
         pv = as_view(params)
         sub = None if pv is None else pv.sub("conv")
+        pad = self.reflection_pad.padding[0]
         if x.is_cuda and fuse_conv_act() and not _NO_REFLECT_FUSED:
             # the direct kernel mirrors the border while it stages its tile: no padded copy of x, forward or backward
             weight = self.conv.weight if sub is None else as_view(sub).leaf("weight")
-            pad = self.reflection_pad.padding[0]
             if hip_ops.convk_reflect_eligible(x, weight, pad):
-                return self.conv(x, params=sub, act_slope=act_slope, padding=pad, reflect=True)
-        return self.conv(hip_ops.reflect_pad(x, self.reflection_pad.padding[0]), params=sub, act_slope=act_slope)
+                out = self.conv(x, params=sub, act_slope=act_slope, padding=pad, reflect=True, in_slope=in_slope)
+                return (out, x) if want_skip else out
+        xp, xs = hip_ops.reflect_pad_with_skip(x, pad) if want_skip else (hip_ops.reflect_pad(x, pad), x)
+        out = self.conv(xp, params=sub, act_slope=act_slope, in_slope=in_slope, chain=chain)
+        return (out, xs) if want_skip else out
 
 
 _META_TYPES = ()
@@ -379,8 +386,17 @@ class MetaRCAB(nn.Module):
             # first-order pass on the GPU: conv + LeakyReLU, conv, then pool -> MLP -> scale -> skip as the fused savfi op
             # (hip_ops.channel_attention_residual: three launches instead of eight, each map read once per launch)
             sub = (lambda i: None) if pv is None else (lambda i: pv.sub("body").sub(i))
-            t = self.body[0](x, params=sub(0), act_slope=_act_slope(self.body[1]))
-            t = self.body[2](t, params=sub(2))
+            # conv -> ReLU -> (mirror) -> conv: the ReLU's derivative goes into the second convolution's data gradient (its masked
+            # epilogue), the first convolution's bias gradient then rides on its weight-gradient kernel: no pass over the cotangent
+            slope = _act_slope(self.body[1])
+            chain = ({"want_defer": True} if (fuse_conv_chain() and not hip_ops.double_backward() and torch.is_grad_enabled()
+                                              and isinstance(self.body[0], MetaConvNorm) and isinstance(self.body[2], MetaConvNorm))
+                     else None)
+            if isinstance(self.body[0], MetaConvNorm):      # (x's two cotangents -- this convolution's and the skip's -- meet in the pad's adjoint)
+                t, x = self.body[0](x, params=sub(0), act_slope=slope, want_skip=True, **({} if chain is None else {"chain": chain}))
+            else:
+                t = self.body[0](x, params=sub(0), act_slope=slope)
+            t = self.body[2](t, params=sub(2), **({"in_slope": slope} if (chain is not None and chain.get("deferred")) else {}))
             du = self.body[3].conv_du
             if pv is not None:
                 leaf = pv.sub("body").sub(3).sub("conv_du")

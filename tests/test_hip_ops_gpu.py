@@ -340,8 +340,8 @@ def test_meta_sequential_fuses_conv_relu_pairs_and_matches_reference_modules():
 def test_conv_chain_folds_the_activation_derivative_into_the_consumer(case, monkeypatch):
     """conv -> act -> conv -> act -> conv in a MetaSequential: with the chain fusion the consumer's data-gradient kernel applies the
     producer's (leaky) ReLU derivative in its epilogue (savfi_conv3x3_dgrad_masked_f32 / savfi_convk_dgrad_masked_f32) and the producer
-    only sums its bias gradient -- the same multiplications, so the gradients of the input and of every weight / bias equal the unchained
-    run (SAVFI_NO_CONV_CHAIN) bit for bit; and an element-wise bias_act_bwd launch disappears per chain link."""
+    only sums its bias gradient -- the same multiplications, so the gradients of the input and of every weight equal the unchained
+    run (model_utils._FUSE_CONV_CHAIN = False) bit for bit, the bias gradients to summation order; and an element-wise bias_act_bwd launch disappears per chain link."""
     from meta_interpolation_amd import model_utils as mu
     torch.manual_seed(3)
     C, H, W, T, act = {"wino_relu": (32, 64, 96, 0, torch.nn.ReLU()), "convk_relu": (64, 48, 64, 0, torch.nn.ReLU()),
@@ -372,13 +372,75 @@ def test_conv_chain_folds_the_activation_derivative_into_the_consumer(case, monk
             monkeypatch.setattr(_hip, 'launch', orig)
         results[chained] = [y.detach()] + [g.detach() for g in grads]
         launches[chained] = count
-    for a, b in zip(results[True], results[False]):
-        assert torch.equal(a, b), (case, (a - b).abs().max().item())
-    # the element-wise derivative pass of the two inner links is gone (the bias-gradient sums stay)
+    for name, a, b in zip(["y", "x"] + list(fast0), results[True], results[False]):
+        if name.endswith("bias"):       # a link that defers has nothing to do with its cotangent: where its weight gradient runs on the
+            assert _rel(a, b) < 2e-6, (case, name, _rel(a, b))      # all-taps kernel the bias sums ride on it (another summation order)
+        else:
+            assert torch.equal(a, b), (case, name, (a - b).abs().max().item())
+    # the element-wise derivative pass of the two inner links is gone (the bias-gradient sums stay, or ride on the weight gradient)
     n_conv = lambda names: sum(1 for n in names if 'bwd_data' in n)
     assert n_conv(launches[True]) == n_conv(launches[False])
     if case != "small_maps_miopen":
         assert n_conv(launches[True]) == 3
+
+
+@pytest.mark.parametrize("case", ["c5_shape", "small_f2", "tasks"])
+def test_rcab_folds_the_relu_derivative_through_the_mirrored_border(case, monkeypatch):
+    """CAIN's RCAB (reference model_utils.py:957-990): mirror -> conv -> ReLU -> mirror -> conv -> channel attention + skip.  The ReLU's
+    derivative goes into the SECOND convolution's data gradient, masked by its padded input (a padded map's mask is the mirrored mask,
+    so masking before the fold equals masking after it, bit for bit with slope 0), and both bias gradients ride on the all-taps
+    weight-gradient kernel where that runs: no element-wise pass over a cotangent is left.  Against the run without the chain: output,
+    input gradient and weight gradients bit-equal, bias gradients to summation order; and against the module in float64 on the CPU."""
+    import copy
+    from meta_interpolation_amd import model_utils as mu
+    torch.manual_seed(5)
+    C, N, H, W, T = {"c5_shape": (192, 1, 96, 160, 0), "small_f2": (64, 2, 20, 24, 0), "tasks": (64, 8, 16, 16, 4)}[case]
+    rcab = mu.MetaRCAB(C, C, 3, 16).to(DEV)
+    x0 = torch.randn(N, C, H, W, device=DEV)
+    if T:
+        fast0 = {n: torch.randn((T,) + tuple(p.shape), device=DEV).mul(0.5 / (p[0].numel() ** 0.5 if p.dim() > 1 else 4.0))
+                 for n, p in rcab.named_parameters()}
+    else:
+        fast0 = {n: (torch.randn_like(p).mul(0.5 / p[0].numel() ** 0.5) if p.dim() > 1 else torch.randn_like(p).mul(0.1))
+                 for n, p in rcab.named_parameters()}
+    names = list(fast0)
+    results, launches = {}, {}
+    for chained in (True, False):
+        monkeypatch.setattr(mu, '_FUSE_CONV_CHAIN', chained)
+        x = x0.clone().requires_grad_()
+        fast = {n: v.clone().requires_grad_() for n, v in fast0.items()}
+        count = []
+        orig = _hip.launch
+        monkeypatch.setattr(_hip, 'launch', lambda name, fn, **k: (count.append(name), orig(name, fn, **k))[1])
+        mu.set_fuse_conv_act(True)
+        try:
+            y = rcab(x, params=fast)
+            grads = torch.autograd.grad(y.square().mean(), [x] + list(fast.values()))
+        finally:
+            mu.set_fuse_conv_act(False)
+            monkeypatch.setattr(_hip, 'launch', orig)
+        results[chained] = [y.detach()] + [g.detach() for g in grads]
+        launches[chained] = count
+    for name, a, b in zip(["out", "x"] + names, results[True], results[False]):
+        if name.endswith("conv.bias"):
+            assert _rel(a, b) < 2e-6, (case, name, _rel(a, b))
+        else:
+            assert torch.equal(a, b), (case, name, (a - b).abs().max().item())
+    if case == "c5_shape":          # F(4x4) data gradients, all-taps weight gradients: nothing element-wise between the kernels
+        assert sum(1 for n in launches[True] if 'bwd_data' in n) == 2
+        assert 'bias_act_bwd' not in launches[True] and launches[False].count('bias_act_bwd') == 1
+    if not T:
+        ref = copy.deepcopy(rcab).cpu().double()
+        xr = x0.cpu().double().requires_grad_()
+        fr = {n: v.cpu().double().requires_grad_() for n, v in fast0.items()}
+        yr = ref(xr, params=fr)
+        gr = torch.autograd.grad(yr.square().mean(), [xr] + list(fr.values()))
+        # (gradients in the 2-norm with room for a few flipped masks: a pre-activation within rounding of zero -- a handful of the
+        # block's 3 million -- takes the other side of the ReLU in float32 and moves whole terms; a missing or misplaced mask is an
+        # error of order one)
+        for name, a, b in zip(["out", "x"] + names, results[True], [yr.detach()] + list(gr)):
+            err = ((a.cpu().double() - b).norm() / b.norm()).item()
+            assert err < (2e-5 if name == "out" else 1e-3), (case, name, err)
 
 
 @pytest.mark.parametrize("align", [True, False])
@@ -1240,9 +1302,11 @@ def test_bias_act_kernels_on_odd_planes(N, C, H, W, slope, shift):
         assert (gb.cpu().double() - ref).abs().max().item() <= 1e-5 * want_gz.double().abs().sum((0, 2, 3)).max().item() + 1e-6
 
 
-@pytest.mark.parametrize("shape,pad", [((2, 5, 16, 16), 1), ((1, 3, 7, 9), 2), ((3, 2, 2, 2), 1), ((1, 4, 33, 18), 3)])
+@pytest.mark.parametrize("shape,pad", [((2, 5, 16, 16), 1), ((1, 3, 7, 9), 2), ((3, 2, 2, 2), 1), ((1, 4, 33, 18), 3), ((2, 24, 96, 160), 1),
+                                       ((1, 2, 31, 45), 1), ((1, 1, 5, 4), 3)])
 def test_reflect_pad_op_has_atens_values_and_gradient(shape, pad):
-    """hip_ops.reflect_pad = nn.ReflectionPad2d forward (ATen) with the gather adjoint: the gradient of a weighted sum against
+    """hip_ops.reflect_pad = nn.ReflectionPad2d (savfi_reflect_pad_fwd_f32: the same values as ATen's kernel, bit for bit, on aligned,
+    8-byte and odd row phases) with the gather adjoint: the gradient of a weighted sum against
     autograd through F.pad, on maps down to 2 x 2 (every border position folds twice).  Exact up to summation order: 1e-6."""
     g = torch.Generator().manual_seed(11)
     x = torch.randn(*shape, generator=g).to(DEV)
@@ -1255,6 +1319,16 @@ def test_reflect_pad_op_has_atens_values_and_gradient(shape, pad):
     ga, = torch.autograd.grad((ya * wgt).sum(), a)
     gb, = torch.autograd.grad((yb * wgt).sum(), b)
     assert _rel(ga, gb) < 1e-6
+    # the padded map and the map itself for a connection round the layer: both cotangents in the fold's pass, the same additions as
+    # autograd's own (fold, then + skip): bit-equal; and each output alone
+    w2 = torch.randn(*shape, generator=g).to(DEV)
+    c = x.clone().requires_grad_(True)
+    yc, xs = hip_ops.reflect_pad_with_skip(c, pad)
+    assert torch.equal(yc, yb) and torch.equal(xs, x)
+    gc, = torch.autograd.grad((yc * wgt).sum() + (xs * w2).sum(), c, retain_graph=True)
+    assert torch.equal(gc, ga + w2)
+    assert torch.equal(torch.autograd.grad((yc * wgt).sum(), c, retain_graph=True)[0], ga)
+    assert torch.equal(torch.autograd.grad((xs * w2).sum(), c)[0], w2)
 
 
 def test_mt_copy_is_a_bitwise_copy_over_many_tensors():
