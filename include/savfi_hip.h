@@ -503,6 +503,11 @@ int savfi_ca_mlp_bwd_f32(const float* r, const float* s, const float* y, const f
                          void* stream);
 int savfi_ca_apply_f32(const float* a, const float* y, const float* x, const float* ds, float* out, int64_t planes, int hw,
                        void* stream);
+/* forward of the same block with the MLP inside the apply launch (Cr <= 16, C <= 256; SAVFI_E_UNSUPPORTED otherwise: the two calls
+ * above): out = a * y + x with y = sigmoid(W2 relu(W1 s + b1) + b2) of the sample, s [N,C] from savfi_ca_pool_f32; y [N,C] and
+ * a1 [N,Cr] are written for the backward, bit-identical to savfi_ca_mlp_fwd_f32's (ABI 20) */
+int savfi_ca_apply_mlp_f32(const float* a, const float* s, const float* w1, const float* b1, const float* w2, const float* b2,
+                           const float* x, float* out, float* y, float* a1, int N, int T, int C, int Cr, int hw, void* stream);
 
 /* ----------------------------------------------------------------------------------
  * Per-plane mean removal of CAIN's input frames (model_utils.py:11-15 sub_mean; cain/model.py:70-94):

@@ -275,6 +275,59 @@ __global__ __launch_bounds__(CA_T) void ca_apply_kernel(const float* __restrict_
   }
 }
 
+// Forward, hidden width <= 16 and C <= 256: the attention MLP inside the apply launch.  Every workgroup repeats ca_mlp_fwd_small's
+// arithmetic for its sample (the same code on the same 256 threads: the same y bit for bit in every workgroup, 2 300 multiply-adds and
+// 18 KB of weights from L2) and then scales its chunk of its plane; the workgroups of channel 0 keep a1, chunk 0 of every plane keeps y
+// for the backward.  The MLP launch of its own was 10 us of latency between the pool and the apply, 180 times per C5 meta-iteration.
+__global__ __launch_bounds__(CA_T) void ca_apply_mlp_kernel(const float* __restrict__ a, const float* __restrict__ s, const float* __restrict__ w1,
+                                                            const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
+                                                            const float* __restrict__ x, float* __restrict__ out, float* __restrict__ y,
+                                                            float* __restrict__ a1, int hw, int chunks, int T, int C, int Cr) {
+  __shared__ float red[CRM][CA_T / SAVFI_WAVE];
+  __shared__ float hid[CRM];
+  __shared__ float ysh;
+  const int plane = blockIdx.x / chunks, chunk = blockIdx.x - plane * chunks;
+  const int n = plane / C, cch = plane - n * C, t = n % T, c = threadIdx.x;
+  const float* W1 = w1 + (size_t)t * Cr * C;
+  const float* W2 = w2 + (size_t)t * C * Cr;
+  const float sv = c < C ? s[(size_t)n * C + c] : 0.f;
+  float p[CRM];
+#pragma unroll
+  for (int j = 0; j < CRM; ++j) p[j] = (j < Cr && c < C) ? W1[(size_t)j * C + c] * sv : 0.f;
+  ca_block_sums(p, Cr, red, hid);
+  if (c < Cr) {
+    const float h = fmaxf(hid[c] + b1[t * Cr + c], 0.f);
+    if (cch == 0 && chunk == 0) a1[(size_t)n * Cr + c] = h;
+    hid[c] = h;
+  }
+  __syncthreads();
+  if (c == cch) {
+    float z = b2[t * C + c];
+    for (int j = 0; j < Cr; ++j) z += W2[(size_t)c * Cr + j] * hid[j];
+    const float yv = 1.f / (1.f + __expf(-z));
+    if (chunk == 0) y[plane] = yv;
+    ysh = yv;
+  }
+  __syncthreads();
+  const float yv = ysh;
+  const size_t base = (size_t)plane * hw;
+  const int per = (hw + chunks - 1) / chunks;
+  const int lo = chunk * per, hi = min(lo + per, hw);
+  if (((base + lo) & 3) == 0) {
+    const int n4 = (hi - lo) / 4;
+    const float4* a4 = reinterpret_cast<const float4*>(a + base + lo);
+    const float4* x4 = reinterpret_cast<const float4*>(x + base + lo);
+    float4* o4 = reinterpret_cast<float4*>(out + base + lo);
+    for (int i = threadIdx.x; i < n4; i += CA_T) {
+      const float4 v = a4[i], u = x4[i];
+      o4[i] = make_float4(v.x * yv + u.x, v.y * yv + u.y, v.z * yv + u.z, v.w * yv + u.w);
+    }
+    for (int i = lo + 4 * n4 + threadIdx.x; i < hi; i += CA_T) out[base + i] = a[base + i] * yv + x[base + i];
+  } else {
+    for (int i = lo + threadIdx.x; i < hi; i += CA_T) out[base + i] = a[base + i] * yv + x[base + i];
+  }
+}
+
 inline int ca_chunks(int64_t planes, int hw) {
   // enough workgroups to fill the GPU, at least 4096 elements each
   int64_t want = (2048 + planes - 1) / planes;
@@ -314,6 +367,19 @@ extern "C" int savfi_ca_mlp_bwd_f32(const float* r, const float* s, const float*
     hipLaunchKernelGGL(ca_mlp_bwd_small, dim3(T), dim3(CA_T), 0, (hipStream_t)stream, r, s, y, a1, w1, w2, ds, gw1, gb1, gw2, gb2, N, T, C, Cr, inv_hw);
   else
     hipLaunchKernelGGL(ca_mlp_bwd_kernel, dim3(T), dim3(CA_T), 0, (hipStream_t)stream, r, s, y, a1, w1, w2, ds, gw1, gb1, gw2, gb2, N, T, C, Cr, inv_hw);
+  return savfi_launch_status();
+}
+
+extern "C" int savfi_ca_apply_mlp_f32(const float* a, const float* s, const float* w1, const float* b1, const float* w2, const float* b2,
+                                      const float* x, float* out, float* y, float* a1, int N, int T, int C, int Cr, int hw, void* stream) {
+  if (!a || !s || !w1 || !b1 || !w2 || !b2 || !x || !out || !y || !a1) return SAVFI_E_NULL;
+  if (N <= 0 || T <= 0 || N % T != 0 || C <= 0 || Cr <= 0 || hw <= 0) return SAVFI_E_SHAPE;
+  if (Cr > CRM || C > CA_T) return SAVFI_E_UNSUPPORTED;       // the separate launches (savfi_ca_mlp_fwd_f32 + savfi_ca_apply_f32)
+  const int64_t planes = (int64_t)N * C;
+  const int chunks = ca_chunks(planes, hw);
+  if (planes * chunks >= (1ll << 31)) return SAVFI_E_TOOBIG;
+  hipLaunchKernelGGL(ca_apply_mlp_kernel, dim3((unsigned)(planes * chunks)), dim3(CA_T), 0, (hipStream_t)stream, a, s, w1, b1, w2, b2, x, out, y, a1,
+                     hw, chunks, T, C, Cr);
   return savfi_launch_status();
 }
 

@@ -2004,10 +2004,15 @@ class _ChannelAttentionResidual(torch.autograd.Function):
         hw = H * W
         _hip.launch("ca_pool", lambda: _hip.check(lib.savfi_ca_pool_f32(t.data_ptr(), None, s.data_ptr(), N * C, hw, 1.0 / hw, st),
                                                   "savfi_ca_pool_f32"), nbytes=4 * t.numel())
-        _hip.launch("ca_mlp", lambda: _hip.check(lib.savfi_ca_mlp_fwd_f32(s.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
-                                                                          y.data_ptr(), a1.data_ptr(), N, T, C, Cr, st), "savfi_ca_mlp_fwd_f32"))
-        _hip.launch("ca_apply", lambda: _hip.check(lib.savfi_ca_apply_f32(t.data_ptr(), y.data_ptr(), x.data_ptr(), None, out.data_ptr(), N * C, hw, st),
-                                                   "savfi_ca_apply_f32"), nbytes=12 * t.numel())
+        if Cr <= 16 and C <= 256:       # the MLP inside the apply launch (every workgroup repeats it for its sample: the same y, bit for bit)
+            _hip.launch("ca_apply", lambda: _hip.check(lib.savfi_ca_apply_mlp_f32(
+                t.data_ptr(), s.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), x.data_ptr(), out.data_ptr(),
+                y.data_ptr(), a1.data_ptr(), N, T, C, Cr, hw, st), "savfi_ca_apply_mlp_f32"), nbytes=12 * t.numel())
+        else:
+            _hip.launch("ca_mlp", lambda: _hip.check(lib.savfi_ca_mlp_fwd_f32(s.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
+                                                                              y.data_ptr(), a1.data_ptr(), N, T, C, Cr, st), "savfi_ca_mlp_fwd_f32"))
+            _hip.launch("ca_apply", lambda: _hip.check(lib.savfi_ca_apply_f32(t.data_ptr(), y.data_ptr(), x.data_ptr(), None, out.data_ptr(), N * C, hw, st),
+                                                       "savfi_ca_apply_f32"), nbytes=12 * t.numel())
         ctx.save_for_backward(t, s, y, a1, w1, w2)
         ctx.mark_non_differentiable(y)
         return out, y.view(N, C, 1, 1)

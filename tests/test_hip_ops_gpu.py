@@ -1077,7 +1077,8 @@ def test_own_weight_filters_are_cached_per_weight_version():
     assert len(cache) == 2 and _rel(y3.detach(), 2 * y1.detach()) < 1e-6
 
 
-@pytest.mark.parametrize("N,T,C,Cr,H,W", [(2, 1, 192, 12, 16, 16), (4, 2, 192, 12, 12, 20), (1, 1, 64, 4, 33, 47), (3, 3, 16, 2, 5, 7), (2, 1, 320, 20, 8, 8)])
+@pytest.mark.parametrize("N,T,C,Cr,H,W", [(2, 1, 192, 12, 16, 16), (4, 2, 192, 12, 12, 20), (1, 1, 64, 4, 33, 47), (3, 3, 16, 2, 5, 7), (2, 1, 320, 20, 8, 8),
+                                          (2, 1, 192, 12, 96, 160), (1, 1, 192, 12, 90, 161)])
 def test_channel_attention_residual_matches_the_composed_ops(N, T, C, Cr, H, W):
     """CAIN's RCAB tail (pool -> 1x1 -> ReLU -> 1x1 -> sigmoid -> scale -> + skip) as the fused savfi op against the reference's
     composition (model_utils.py:931-990) in float64: value, attention, and the gradients of both maps and all four parameters;
