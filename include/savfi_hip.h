@@ -508,6 +508,12 @@ int savfi_ca_apply_f32(const float* a, const float* y, const float* x, const flo
  * a1 [N,Cr] are written for the backward, bit-identical to savfi_ca_mlp_fwd_f32's (ABI 20) */
 int savfi_ca_apply_mlp_f32(const float* a, const float* s, const float* w1, const float* b1, const float* w2, const float* b2,
                            const float* x, float* out, float* y, float* a1, int N, int T, int C, int Cr, int hw, void* stream);
+/* backward of the same with the MLP's backward inside the apply launch (same limits): gt = g * y + ds, ds recomputed per workgroup,
+ * r [N,C] = sum_hw g * t from savfi_ca_pool_f32; gw1 [T,Cr,C], gb1 [T,Cr], gw2 [T,C,Cr], gb2 [T,C] from T workgroups at the front of
+ * the grid; every result bit-identical to savfi_ca_mlp_bwd_f32 + savfi_ca_apply_f32 (ABI 20) */
+int savfi_ca_apply_bwd_mlp_f32(const float* g, const float* r, const float* s, const float* y, const float* a1, const float* w1,
+                               const float* w2, float* gt, float* gw1, float* gb1, float* gw2, float* gb2, int N, int T, int C, int Cr,
+                               int hw, void* stream);
 
 /* ----------------------------------------------------------------------------------
  * Per-plane mean removal of CAIN's input frames (model_utils.py:11-15 sub_mean; cain/model.py:70-94):

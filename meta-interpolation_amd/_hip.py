@@ -115,6 +115,7 @@ _PROTOTYPES = {
     "savfi_ca_mlp_bwd_f32": [_P] * 11 + [c_int] * 4 + [c_float, _P],
     "savfi_ca_apply_f32": [_P] * 5 + [c_int64, c_int, _P],
     "savfi_ca_apply_mlp_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P],
+    "savfi_ca_apply_bwd_mlp_f32": [_P] * 12 + [c_int, c_int, c_int, c_int, c_int, _P],
     "savfi_sub_mean_workspace_floats": [c_int64, c_int],
     "savfi_sub_mean_f32": [_P, _P, _P, _P, c_int64, c_int, _P],
     "savfi_frames_u8_to_f32": [_P, _P, c_int64, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_float, _P],

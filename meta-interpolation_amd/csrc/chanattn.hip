@@ -328,6 +328,99 @@ __global__ __launch_bounds__(CA_T) void ca_apply_mlp_kernel(const float* __restr
   }
 }
 
+// Backward of the same: gt = g * y + ds with ds recomputed per workgroup (ca_mlp_bwd_small's arithmetic for the workgroup's sample: the same
+// ds bit for bit), and the four parameter gradients from T workgroups of their own AT THE FRONT of the grid (task t: the whole body of
+// ca_mlp_bwd_small), which run beside the streaming workgroups instead of in a 10 us launch between the pool and the apply.
+__global__ __launch_bounds__(CA_T) void ca_apply_bwd_mlp_kernel(const float* __restrict__ g, const float* __restrict__ r, const float* __restrict__ s,
+                                                                const float* __restrict__ y, const float* __restrict__ a1, const float* __restrict__ w1,
+                                                                const float* __restrict__ w2, float* __restrict__ gt, float* __restrict__ gw1,
+                                                                float* __restrict__ gb1, float* __restrict__ gw2, float* __restrict__ gb2, int hw,
+                                                                int chunks, int N, int T, int C, int Cr, float inv_hw) {
+  __shared__ float red[CRM][CA_T / SAVFI_WAVE];
+  __shared__ float da[CRM], a1s[CRM], dz1s[CRM];
+  __shared__ float dsh;
+  const int c = threadIdx.x;
+  if ((int)blockIdx.x < T) {          // parameter gradients of task t (ca_mlp_bwd_small without the ds store)
+    const int t = blockIdx.x;
+    const float* W2 = w2 + (size_t)t * C * Cr;
+    float g_w2[CRM], g_w1[CRM], g_b2 = 0.f, g_b1 = 0.f, w2r[CRM];
+#pragma unroll
+    for (int j = 0; j < CRM; ++j) {
+      g_w2[j] = 0.f; g_w1[j] = 0.f;
+      w2r[j] = (j < Cr && c < C) ? W2[(size_t)c * Cr + j] : 0.f;
+    }
+    for (int n = t; n < N; n += T) {
+      if (c < Cr) a1s[c] = a1[(size_t)n * Cr + c];
+      const float yv = c < C ? y[(size_t)n * C + c] : 0.f;
+      const float dz2 = c < C ? r[(size_t)n * C + c] * yv * (1.f - yv) : 0.f;
+      const float sv = c < C ? s[(size_t)n * C + c] : 0.f;
+      float p[CRM];
+#pragma unroll
+      for (int j = 0; j < CRM; ++j) p[j] = w2r[j] * dz2;
+      ca_block_sums(p, Cr, red, da);
+      if (c < Cr) {
+        const float d = a1s[c] > 0.f ? da[c] : 0.f;
+        dz1s[c] = d;
+        g_b1 += d;
+      }
+      __syncthreads();
+      g_b2 += dz2;
+#pragma unroll
+      for (int j = 0; j < CRM; ++j)
+        if (j < Cr) {
+          g_w2[j] += dz2 * a1s[j];
+          g_w1[j] += dz1s[j] * sv;
+        }
+      __syncthreads();
+    }
+    if (c < C) {
+      gb2[t * C + c] = g_b2;
+#pragma unroll
+      for (int j = 0; j < CRM; ++j)
+        if (j < Cr) {
+          gw2[(size_t)t * C * Cr + (size_t)c * Cr + j] = g_w2[j];
+          gw1[(size_t)t * Cr * C + (size_t)j * C + c] = g_w1[j];
+        }
+    }
+    if (c < Cr) gb1[t * Cr + c] = g_b1;
+    return;
+  }
+  const int blk = blockIdx.x - T;
+  const int plane = blk / chunks, chunk = blk - plane * chunks;
+  const int n = plane / C, cch = plane - n * C, t = n % T;
+  const float* W1 = w1 + (size_t)t * Cr * C;
+  const float* W2 = w2 + (size_t)t * C * Cr;
+  if (c < Cr) a1s[c] = a1[(size_t)n * Cr + c];
+  const float yc = c < C ? y[(size_t)n * C + c] : 0.f;
+  const float dz2 = c < C ? r[(size_t)n * C + c] * yc * (1.f - yc) : 0.f;
+  float p[CRM];
+#pragma unroll
+  for (int j = 0; j < CRM; ++j) p[j] = (j < Cr && c < C) ? W2[(size_t)c * Cr + j] * dz2 : 0.f;
+  ca_block_sums(p, Cr, red, da);            // also publishes a1s (barrier inside)
+  if (c == cch) {
+    float v = 0.f;
+    for (int j = 0; j < Cr; ++j) v += W1[(size_t)j * C + c] * (a1s[j] > 0.f ? da[j] : 0.f);
+    dsh = v * inv_hw;
+  }
+  __syncthreads();
+  const float yv = y[plane], dv = dsh;
+  const size_t base = (size_t)plane * hw;
+  const int per = (hw + chunks - 1) / chunks;
+  const int lo = chunk * per, hi = min(lo + per, hw);
+  if (((base + lo) & 3) == 0) {
+    const int n4 = (hi - lo) / 4;
+    const float4* a4 = reinterpret_cast<const float4*>(g + base + lo);
+    float4* o4 = reinterpret_cast<float4*>(gt + base + lo);
+    for (int i = threadIdx.x; i < n4; i += CA_T) {
+      const float4 v = a4[i];
+      o4[i] = make_float4(v.x * yv + dv, v.y * yv + dv, v.z * yv + dv, v.w * yv + dv);
+    }
+    for (int i = lo + 4 * n4 + threadIdx.x; i < hi; i += CA_T) gt[base + i] = g[base + i] * yv + dv;
+  } else {
+    for (int i = lo + threadIdx.x; i < hi; i += CA_T) gt[base + i] = g[base + i] * yv + dv;
+  }
+}
+
 inline int ca_chunks(int64_t planes, int hw) {
   // enough workgroups to fill the GPU, at least 4096 elements each
   int64_t want = (2048 + planes - 1) / planes;
@@ -380,6 +473,20 @@ extern "C" int savfi_ca_apply_mlp_f32(const float* a, const float* s, const floa
   if (planes * chunks >= (1ll << 31)) return SAVFI_E_TOOBIG;
   hipLaunchKernelGGL(ca_apply_mlp_kernel, dim3((unsigned)(planes * chunks)), dim3(CA_T), 0, (hipStream_t)stream, a, s, w1, b1, w2, b2, x, out, y, a1,
                      hw, chunks, T, C, Cr);
+  return savfi_launch_status();
+}
+
+extern "C" int savfi_ca_apply_bwd_mlp_f32(const float* g, const float* r, const float* s, const float* y, const float* a1, const float* w1,
+                                          const float* w2, float* gt, float* gw1, float* gb1, float* gw2, float* gb2, int N, int T, int C, int Cr,
+                                          int hw, void* stream) {
+  if (!g || !r || !s || !y || !a1 || !w1 || !w2 || !gt || !gw1 || !gb1 || !gw2 || !gb2) return SAVFI_E_NULL;
+  if (N <= 0 || T <= 0 || N % T != 0 || C <= 0 || Cr <= 0 || hw <= 0) return SAVFI_E_SHAPE;
+  if (Cr > CRM || C > CA_T) return SAVFI_E_UNSUPPORTED;       // the separate launches (savfi_ca_mlp_bwd_f32 + savfi_ca_apply_f32)
+  const int64_t planes = (int64_t)N * C;
+  const int chunks = ca_chunks(planes, hw);
+  if (planes * chunks + T >= (1ll << 31)) return SAVFI_E_TOOBIG;
+  hipLaunchKernelGGL(ca_apply_bwd_mlp_kernel, dim3((unsigned)(planes * chunks + T)), dim3(CA_T), 0, (hipStream_t)stream, g, r, s, y, a1, w1, w2, gt,
+                     gw1, gb1, gw2, gb2, hw, chunks, N, T, C, Cr, 1.f / (float)hw);
   return savfi_launch_status();
 }
 

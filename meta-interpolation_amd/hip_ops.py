@@ -1983,6 +1983,9 @@ def conv_bias_act(x, weight, bias, stride=1, padding=0, dilation=1, groups=1, sl
 # --------------------------------------------------------------------------------------------
 # Channel attention + residual of CAIN's RCAB        (reference model_utils.py:931-953, :957-990)
 # --------------------------------------------------------------------------------------------
+CA_FUSE_MLP = True       # A/B and tests: False = pool, MLP and apply as three launches per direction
+
+
 class _ChannelAttentionResidual(torch.autograd.Function):
     """out = t * sigmoid(W2 relu(W1 mean_hw(t) + b1) + b2) + x, also returns the attention y [N,C,1,1] (not differentiable on
     its own).  w1 [T,Cr,C] / b1 [T,Cr] / w2 [T,C,Cr] / b2 [T,C]: sample n uses set n % T.  First-order only."""
@@ -2004,7 +2007,7 @@ class _ChannelAttentionResidual(torch.autograd.Function):
         hw = H * W
         _hip.launch("ca_pool", lambda: _hip.check(lib.savfi_ca_pool_f32(t.data_ptr(), None, s.data_ptr(), N * C, hw, 1.0 / hw, st),
                                                   "savfi_ca_pool_f32"), nbytes=4 * t.numel())
-        if Cr <= 16 and C <= 256:       # the MLP inside the apply launch (every workgroup repeats it for its sample: the same y, bit for bit)
+        if CA_FUSE_MLP and Cr <= 16 and C <= 256:       # the MLP inside the apply launch (every workgroup repeats it for its sample: the same y, bit for bit)
             _hip.launch("ca_apply", lambda: _hip.check(lib.savfi_ca_apply_mlp_f32(
                 t.data_ptr(), s.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), x.data_ptr(), out.data_ptr(),
                 y.data_ptr(), a1.data_ptr(), N, T, C, Cr, hw, st), "savfi_ca_apply_mlp_f32"), nbytes=12 * t.numel())
@@ -2034,11 +2037,16 @@ class _ChannelAttentionResidual(torch.autograd.Function):
         gt = torch.empty_like(t)
         _hip.launch("ca_pool", lambda: _hip.check(lib.savfi_ca_pool_f32(g.data_ptr(), t.data_ptr(), r.data_ptr(), N * C, hw, 1.0, st),
                                                   "savfi_ca_pool_f32"), nbytes=8 * t.numel())
-        _hip.launch("ca_mlp_bwd", lambda: _hip.check(lib.savfi_ca_mlp_bwd_f32(
-            r.data_ptr(), s.data_ptr(), y.data_ptr(), a1.data_ptr(), w1.data_ptr(), w2.data_ptr(), ds.data_ptr(), gw1.data_ptr(), gb1.data_ptr(),
-            gw2.data_ptr(), gb2.data_ptr(), N, T, C, Cr, 1.0 / hw, st), "savfi_ca_mlp_bwd_f32"))
-        _hip.launch("ca_apply", lambda: _hip.check(lib.savfi_ca_apply_f32(g.data_ptr(), y.data_ptr(), None, ds.data_ptr(), gt.data_ptr(), N * C, hw, st),
-                                                   "savfi_ca_apply_f32"), nbytes=8 * t.numel())
+        if CA_FUSE_MLP and Cr <= 16 and C <= 256:       # the MLP's backward inside the apply launch: ds per workgroup, the parameter gradients from T workgroups
+            _hip.launch("ca_apply", lambda: _hip.check(lib.savfi_ca_apply_bwd_mlp_f32(             # at the front of its grid
+                g.data_ptr(), r.data_ptr(), s.data_ptr(), y.data_ptr(), a1.data_ptr(), w1.data_ptr(), w2.data_ptr(), gt.data_ptr(), gw1.data_ptr(),
+                gb1.data_ptr(), gw2.data_ptr(), gb2.data_ptr(), N, T, C, Cr, hw, st), "savfi_ca_apply_bwd_mlp_f32"), nbytes=8 * t.numel())
+        else:
+            _hip.launch("ca_mlp_bwd", lambda: _hip.check(lib.savfi_ca_mlp_bwd_f32(
+                r.data_ptr(), s.data_ptr(), y.data_ptr(), a1.data_ptr(), w1.data_ptr(), w2.data_ptr(), ds.data_ptr(), gw1.data_ptr(), gb1.data_ptr(),
+                gw2.data_ptr(), gb2.data_ptr(), N, T, C, Cr, 1.0 / hw, st), "savfi_ca_mlp_bwd_f32"))
+            _hip.launch("ca_apply", lambda: _hip.check(lib.savfi_ca_apply_f32(g.data_ptr(), y.data_ptr(), None, ds.data_ptr(), gt.data_ptr(), N * C, hw, st),
+                                                       "savfi_ca_apply_f32"), nbytes=8 * t.numel())
         need = ctx.needs_input_grad
         return (gt if need[0] else None, g if need[1] else None, gw1 if need[2] else None, gb1 if need[3] else None,
                 gw2 if need[4] else None, gb2 if need[5] else None)
