@@ -740,11 +740,12 @@ CONVK_3X3_MIN_PIXELS = 700
 
 
 CONVK_WGRAD3_RING_MIN_PIXELS = 3000
+CONVK_WGRAD3_RING_SMALL_MIN_PIXELS = 64
 CONVK_WGRAD3 = True             # A/B: False = every 3 x 3 weight gradient on the Winograd form
 CONVK_WGRAD3_RING = True        # A/B: False = no all-taps kernel (the tap-split kernel's rules alone)
 
 
-def convk_wgrad_preferred(K, Ci, Co, Ho, Wo, direct=False):
+def convk_wgrad_preferred(K, Ci, Co, Ho, Wo, direct=False, N=None):
     """Weight gradient of a stride-1 K x K layer on csrc/convk_wgrad.hip rather than the Winograd / MIOpen forms?  5x5 / 7x7 and
     `direct` layers always; 3x3 where the split-bf16 kernels measured faster than savfi_conv3x3_wgrad_wino:
     * >= 48 -> 48 channels on maps of >= 3000 pixels -- the all-taps kernel on the row ring (round 5; tools/wgrad3_forms_time.py,
@@ -759,6 +760,11 @@ def convk_wgrad_preferred(K, Ci, Co, Ho, Wo, direct=False):
     if not CONVK_WGRAD3:
         return False
     if Ci >= 48 and Co >= 48 and Ho * Wo >= CONVK_WGRAD3_RING_MIN_PIXELS and CONVK_WGRAD3_RING:
+        return True
+    # ... and the small maps the Winograd form does not take either (N samples; CAIN at 64x64: 192 -> 192 @16x16, where MIOpen's
+    # weight gradient is im2col + two GEMMs + col2im, 33 us in four launches against 12 + 5: config C1 45.5 -> 47.1 steps/s)
+    if N is not None and Ci >= 48 and Co >= 48 and Ho * Wo >= CONVK_WGRAD3_RING_SMALL_MIN_PIXELS and CONVK_WGRAD3_RING \
+            and not _wgrad_wino(N, Ci, Co, Ho, Wo):
         return True
     return (Ci <= 32 and Ho * Wo >= 16384) or (Co >= 192 and Ho * Wo >= 4096)
 
@@ -1006,7 +1012,7 @@ class _ConvBiasAct(torch.autograd.Function):
         # to do with it (no activation, or its derivative left to the consumer): one pass over the map and two launches less per layer
         wgrad_is_convk = bool(need_w and (ctx.reflect or (_convk_geometry(w, stride, padding, dilation, groups) is not None
                                                           and (ctx.route == 'convk' or K == 3)
-                                                          and convk_wgrad_preferred(K, w.shape[1], w.shape[0], H, W, ctx.direct))))
+                                                          and convk_wgrad_preferred(K, w.shape[1], w.shape[0], H, W, ctx.direct, N))))
         fuse_b = bool(need_b and identity and wgrad_is_convk and convk_wgrad_tasks_sums_bias(x.shape, C, 1, K, pad, ctx.direct))
         if fuse_b:
             gb = None
@@ -1046,7 +1052,7 @@ class _ConvBiasAct(torch.autograd.Function):
         pair = lambda v: [v, v] if isinstance(v, int) else list(v)
         # 5x5 / 7x7 layers and plugins that asked for the direct form: weight gradient on the split-bf16 kernel as well
         if need_w and _convk_geometry(w, stride, padding, dilation, groups) is not None and \
-                (ctx.route == 'convk' or K == 3) and convk_wgrad_preferred(K, w.shape[1], w.shape[0], gz.shape[2], gz.shape[3], ctx.direct):
+                (ctx.route == 'convk' or K == 3) and convk_wgrad_preferred(K, w.shape[1], w.shape[0], gz.shape[2], gz.shape[3], ctx.direct, gz.shape[0]):
             res = convk_wgrad_tasks(x, gz, 1, K, pad, ctx.direct, want_bias=fuse_b)
             gw, gb = (res[0][0], res[1][0]) if fuse_b else (res[0], gb)
             need_w = False
@@ -1827,7 +1833,7 @@ class _ConvBiasActTasks(torch.autograd.Function):
         pad_ = padding if isinstance(padding, int) else padding[0]
         K_ = int(w.shape[-1])
         wgrad_is_convk = bool(need_w and _convk_geometry(w, stride, padding, dilation, 1) is not None and (ctx.route == 'convk' or K_ == 3)
-                              and convk_wgrad_preferred(K_, Ci, Co, Ho, Wo, ctx.direct))
+                              and convk_wgrad_preferred(K_, Ci, Co, Ho, Wo, ctx.direct, x.shape[0]))
         wgrad_is_wino3 = need_w and not wgrad_is_convk and conv3x3_wgrad_tasks_eligible(x, w, stride, padding, dilation)
         # (not beside the Winograd weight gradient on the SIDE stream: a bias gradient autograd consumes on the compute stream -- stacked
         # biases, a bias shared between ops -- must be produced there; the side-stream guard counts uses of the WEIGHT only)

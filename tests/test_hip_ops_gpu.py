@@ -1380,7 +1380,8 @@ def test_winograd_weight_gradient_hands_out_the_bias_gradient(N, T, Ci, Co, H, W
 
 @pytest.mark.parametrize("N,T,Ci,Co,H,W,pad,reflect", [
     (8, 4, 64, 64, 48, 64, 1, 0), (4, 1, 51, 51, 66, 130, 0, 0), (2, 2, 70, 100, 37, 53, 1, 0), (2, 1, 192, 192, 33, 47, 1, 1),
-    (3, 3, 64, 128, 5, 200, 2, 0), (1, 1, 48, 48, 1, 1, 1, 0), (6, 2, 128, 64, 31, 33, 1, 0)])
+    (3, 3, 64, 128, 5, 200, 2, 0), (1, 1, 48, 48, 1, 1, 1, 0), (6, 2, 128, 64, 31, 33, 1, 0),
+    (2, 1, 192, 192, 18, 18, 0, 0), (1, 1, 64, 64, 8, 14, 1, 0), (4, 2, 192, 192, 16, 16, 1, 1)])      # the small maps of CAIN at 64 x 64
 def test_all_taps_weight_gradient_matches_float64_and_hands_out_the_bias_gradient(N, T, Ci, Co, H, W, pad, reflect):
     """convk_wgrad3_ring (3 x 3 layers of >= 48 -> 48 channels: all nine taps per wave, input rows on a ring): against a float64 weight gradient
     on maps with odd row counts, ragged channel blocks, several column segments, every padding, a mirrored border and T > 1; with the bias
