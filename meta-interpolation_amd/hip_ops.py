@@ -2024,11 +2024,14 @@ class _ChannelAttentionResidual(torch.autograd.Function):
                                                        "savfi_ca_apply_f32"), nbytes=12 * t.numel())
         ctx.save_for_backward(t, s, y, a1, w1, w2)
         ctx.mark_non_differentiable(y)
+        ctx.set_materialize_grads(False)        # (else autograd fills a zero tensor for the attention's cotangent on every backward call)
         return out, y.view(N, C, 1, 1)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g, _gy):
+        if g is None:
+            return (None,) * 6
         t, s, y, a1, w1, w2 = ctx.saved_tensors
         g = g.contiguous()
         N, C, H, W = t.shape
