@@ -258,6 +258,20 @@ class MetaConv2dLayer(nn.Module):
         pass
 
 
+def conv_pair(conv_a, conv_b, x, params_a, params_b, slope_a, slope_b=None):
+    """conv_a -> (Leaky)ReLU(slope_a) -> conv_b [-> (Leaky)ReLU(slope_b)] for two MetaConv2dLayers where conv_a's activated output has
+    conv_b as its ONLY consumer (the blocks of the RRIN / Super SloMo UNets, written out by hand there): MetaSequential's conv -> act ->
+    conv protocol -- conv_b's data gradient applies conv_a's activation derivative in its epilogue, conv_a's bias gradient rides on its
+    weight gradient: no element-wise pass over conv_a's cotangent."""
+    chain = ({"want_defer": True} if (x.is_cuda and fuse_conv_chain() and fuse_conv_act() and not hip_ops.double_backward()
+                                      and torch.is_grad_enabled()) else None)
+    y = conv_a(x, params=params_a, act_slope=slope_a, **({} if chain is None else {"chain": chain}))
+    kw = {"in_slope": slope_a} if (chain is not None and chain.get("deferred")) else {}
+    if slope_b is not None:
+        kw["act_slope"] = slope_b
+    return conv_b(y, params=params_b, **kw)
+
+
 class MetaConvNorm(nn.Module):
     """reflection pad + conv (norm is never enabled by the three plugins; reference :821-848)."""
 

@@ -14,7 +14,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import hip_ops
-from ..model_utils import InOutPaddings, MetaConv2dLayer, as_view, zero_grad_params
+from ..model_utils import InOutPaddings, MetaConv2dLayer, as_view, conv_pair, zero_grad_params
 
 SLOPE = 0.1
 
@@ -33,8 +33,7 @@ class MetaUNetConvBlock(nn.Module):
 
     def forward(self, x, params=None):
         pv = _sub(as_view(params), "block")
-        x = self.block['0'](x, params=_sub(pv, "0"), act_slope=SLOPE)
-        return self.block['2'](x, params=_sub(pv, "2"), act_slope=SLOPE)
+        return conv_pair(self.block['0'], self.block['2'], x, _sub(pv, "0"), _sub(pv, "2"), SLOPE, SLOPE)
 
 
 class MetaUNetUpBlock(nn.Module):

@@ -14,7 +14,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import hip_ops
-from ..model_utils import MetaConv2dLayer, _pad_to_multiple, as_view, zero_grad_params
+from ..model_utils import MetaConv2dLayer, _pad_to_multiple, as_view, conv_pair, zero_grad_params
 from ..rrin.model import warp
 
 SLOPE = 0.1
@@ -40,8 +40,7 @@ class down(nn.Module):
 
     def forward(self, x, params=None):
         pv = as_view(params)
-        x = self.conv1(hip_ops.avg_pool2x2(x), params=_sub(pv, "conv1"), act_slope=SLOPE)
-        return self.conv2(x, params=_sub(pv, "conv2"), act_slope=SLOPE)
+        return conv_pair(self.conv1, self.conv2, hip_ops.avg_pool2x2(x), _sub(pv, "conv1"), _sub(pv, "conv2"), SLOPE, SLOPE)
 
 
 class up(nn.Module):
@@ -78,8 +77,7 @@ class MetaUNet(nn.Module):
 
     def forward(self, x, params=None):
         pv = as_view(params)
-        x = self.conv1(x, params=_sub(pv, "conv1"), act_slope=SLOPE)
-        skips = [self.conv2(x, params=_sub(pv, "conv2"), act_slope=SLOPE)]
+        skips = [conv_pair(self.conv1, self.conv2, x, _sub(pv, "conv1"), _sub(pv, "conv2"), SLOPE, SLOPE)]
         for name in ("down1", "down2", "down3", "down4"):
             skips.append(getattr(self, name)(skips[-1], params=_sub(pv, name)))
         x = self.down5(skips[-1], params=_sub(pv, "down5"))
