@@ -39,12 +39,14 @@ def main():
     ap.add_argument('--top', type=int, default=40)
     o = ap.parse_args()
     model, H, W, tasks, S, over = bench.WORKLOADS[o.workload]
+    recipe = over.get('weight_recipe')
+    over = {k: v for k, v in over.items() if k != 'weight_recipe'}        # the recipe is not a config.py flag (bench.py does the same)
     dev = torch.device('cuda')
     args = default_args(model=model, num_gpu=1, batch_size=tasks, number_of_training_steps_per_iter=S,
                         number_of_evaluation_steps_per_iter=S, **over)
     with contextlib.redirect_stdout(sys.stderr):
         net = MODEL_REGISTRY[model](args, False)
-        synthetic.load_seeded_weights(net, model)
+        synthetic.load_seeded_weights(net, model, recipe=recipe)
         system = SceneAdaptiveInterpolation(args, net=net.to(dev))
     frames = [f.to(dev) for f in synthetic.septuplet_batch(tasks, H, W, model=model)]
     sh = lambda x: "x".join(str(int(v)) for v in x.shape)
