@@ -675,10 +675,21 @@ bool make_plan(WinoPlan& p, int N, int Ci, int Co, int H, int W, int pad, int mo
   p.Wo = W + 2 * p.off - 2;
   if (p.Ho <= 0 || p.Wo <= 0) return false;
   if (p.f4) {
-    // 32 tiles of 4 x 4 pixels as a 2^(5-s) x 2^s block: fewest blocks, ties to 4 x 8 (16 x 32 pixels)
+    // 32 tiles of 4 x 4 pixels as a 2^(5-s) x 2^s block: fewest blocks, ties to the WIDEST block (1 x 32 tiles = 4 x 128 pixels: 512-byte
+    // row segments in and out).  Measured against the 4 x 8 preference of the first version, tools/r6/wino4_time.py: 32 -> 32 @384x512
+    // 161 -> 152 us, 51 -> 51 @258x450 813 -> 760, 64 -> 64 @192x256 113 -> 110, the others within +-1 % (SAVFI_W4_TS_ORDER=0: the old order)
     const int ty4 = savfi_cdiv(p.Ho, 4), tx4 = savfi_cdiv(p.Wo, 4);
     int64_t best4 = -1;
+#ifndef SAVFI_W4_TS_ORDER
+#define SAVFI_W4_TS_ORDER 2
+#endif
+#if SAVFI_W4_TS_ORDER == 0
     for (int s : {3, 4, 2, 5, 1, 0}) {
+#elif SAVFI_W4_TS_ORDER == 1
+    for (int s : {4, 3, 5, 2, 1, 0}) {
+#else
+    for (int s : {5, 4, 3, 2, 1, 0}) {
+#endif
       const int64_t blocks = (int64_t)savfi_cdiv(ty4, w4::TT >> s) * savfi_cdiv(tx4, 1 << s);
       if (best4 < 0 || blocks < best4) { best4 = blocks; p.tile_shift = s; }
     }
