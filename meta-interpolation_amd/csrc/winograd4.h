@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void wino4_conv3x3(W4Args a) {
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
       colm[c] = __builtin_amdgcn_ballot_w64(x0 + c >= 0 && x0 + c < a.W);
-      if (colm[c] != all) partial |= 1 << c;
+      if (colm[c] != all) partial |= 1 << c;      // (bit c: some lane of this wave must clear column c)
     }
   }
   // this workgroup reduces over chunks [cbeg, cbeg + nch) of the KP / KC chunks; everything below counts chunks from cbeg
@@ -313,24 +313,30 @@ __global__ __launch_bounds__(256, 2) void wino4_conv3x3(W4Args a) {
   };
   // Waves with a tile on the left / right image border (wave-uniform `edge`: ONE branch per chunk -- per-row and per-column branches
   // were 48 per chunk, in every wave): left-edge tiles were loaded from column 0 -- move the rows right by `off` --, then clear the
-  // columns outside the image.  Unconditional selects on lane masks (a mask of all ones changes nothing).
+  // columns outside the image.  Selects on lane masks behind wave-uniform tests: only what the wave needs (with tile blocks 32 tiles wide
+  // every workgroup of a map up to 256 pixels wide is a border workgroup: a right-edge wave clears one column, 6 selects, where the
+  // unconditional form spent 30 + 36 on masks that change nothing).
   const bool edge = !IN16 && (shl != 0 || partial != 0);
   auto fix_patch = [&]() {
-    if (a.off == 1) {
+    if (shl != 0) {
+      if (a.off == 1) {
 #pragma unroll
-      for (int r = 0; r < 6; ++r)
+        for (int r = 0; r < 6; ++r)
 #pragma unroll
-        for (int c = 5; c >= 1; --c) asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(d[r][c]) : "v"(d[r][c - 1]), "s"(shl));
-    } else if (a.off == 2) {
+          for (int c = 5; c >= 1; --c) asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(d[r][c]) : "v"(d[r][c - 1]), "s"(shl));
+      } else if (a.off == 2) {
 #pragma unroll
-      for (int r = 0; r < 6; ++r)
+        for (int r = 0; r < 6; ++r)
 #pragma unroll
-        for (int c = 5; c >= 2; --c) asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(d[r][c]) : "v"(d[r][c - 2]), "s"(shl));
+          for (int c = 5; c >= 2; --c) asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(d[r][c]) : "v"(d[r][c - 2]), "s"(shl));
+      }
     }
 #pragma unroll
-    for (int r = 0; r < 6; ++r)
+    for (int c = 0; c < 6; ++c)
+      if (partial & (1 << c)) {
 #pragma unroll
-      for (int c = 0; c < 6; ++c) asm volatile("v_cndmask_b32 %0, 0, %0, %1" : "+v"(d[r][c]) : "s"(colm[c]));
+        for (int r = 0; r < 6; ++r) asm volatile("v_cndmask_b32 %0, 0, %0, %1" : "+v"(d[r][c]) : "s"(colm[c]));
+      }
   };
   // V[xi][s][kg][j][tb] (floats): a reader's two tile blocks of one (xi, k) are one ds_read_b64; the 64 lanes of a writer cover 64 banks
   const int vw = (((kc >> 2) * 4 + (kc & 3)) * 16 + (tl & 15)) * 2 + (tl >> 4);
